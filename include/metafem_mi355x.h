@@ -1,0 +1,234 @@
+/*
+ * metafem_mi355x.h -- C ABI of libmetafem_mi355x.so, the MI355X (gfx950) assembly-and-solve
+ * backend for MetaFEM.jl's hot path.
+ *
+ * Every entry point replaces one seam of the reference (jxx2/MetaFEM.jl v0.1.4; citations are
+ * file:line under the reference's src/).  The reference has no FFI: its seams are Julia
+ * Function-typed fields and fixed-name callees of generated code, so the ABI
+ * below is what a `ccall` shim binds -- see INTEGRATION.md for the Julia side.
+ *
+ * Conventions
+ *   - all array arguments are DEVICE pointers owned by the caller unless marked [host];
+ *   - Float = double (FEM_Float, misc/02_Global_Macros.jl:124); column indices are int32
+ *     (FEM_Int, :123); row pointers are int32 or int64 (512^3 hex-8 has nnz > 2^31, F8);
+ *   - `index_base` is 1 for arrays coming straight from Julia (CUSPARSE 'O' convention,
+ *     misc/04_GPU_Utils.jl:131) and 0 otherwise;
+ *   - every function returns 0 on success, a negative mfem_status otherwise and never
+ *     throws/aborts across the boundary; mfem_last_error() gives the message (thread local);
+ *   - work is enqueued on the context's stream; functions that return a scalar to the host
+ *     synchronise that stream, nothing else does;
+ *   - a context is bound to one device and used by one host thread at a time.
+ */
+#ifndef METAFEM_MI355X_H
+#define METAFEM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFEM_ABI_VERSION 1
+
+typedef enum {
+  MFEM_OK = 0,
+  MFEM_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unknown enum) */
+  MFEM_ERR_HIP = -2,       /* a HIP runtime call failed */
+  MFEM_ERR_UNSUPPORTED = -3,
+  MFEM_ERR_NOT_CONVERGED = -4, /* never returned by mfem_solve (reference semantics: it reports, not fails) */
+  MFEM_ERR_COMM = -5
+} mfem_status;
+
+typedef struct mfem_context_s* mfem_context;
+typedef struct mfem_csr_s* mfem_csr;       /* CSR pattern + SpMV plan (no values) */
+typedef struct mfem_brick_s* mfem_brick;   /* structured hex mesh (make_Brick ordering) */
+typedef struct mfem_mesh_s* mfem_mesh;     /* general (unstructured) mesh: coords + controlpoint_IDs */
+typedef struct mfem_comm_s* mfem_comm;     /* RCCL communicator + slab neighbours */
+
+/* ---- context -------------------------------------------------------------------------- */
+int mfem_abi_version(void);
+const char* mfem_last_error(void);
+/* device: HIP ordinal.  stream: hipStream_t to enqueue on (NULL = the null stream). */
+int mfem_context_create(int device, void* stream, mfem_context* out);
+int mfem_context_set_stream(mfem_context ctx, void* stream);
+int mfem_context_destroy(mfem_context ctx);
+int mfem_context_sync(mfem_context ctx);
+
+/* ---- S1 primitives: the CUSPARSE/CUBLAS call sites of the Krylov loop -------------------- */
+/* CSR pattern (replaces FEM_SpMat_CSR(K_J_ptr, K_J, ...), misc/04_GPU_Utils.jl:120).  The
+ * arrays are borrowed, not copied: they must outlive the handle.  rowptr_bits = 32 | 64. */
+int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
+                    const int32_t* colidx, int index_base, mfem_csr* out);
+int mfem_csr_destroy(mfem_csr A);
+/* y = alpha*A*x + beta*y : mul!(b, A, x, alpha, beta), misc/04_GPU_Utils.jl:131 (CUSPARSE mv! 'N'). */
+int mfem_spmv_csr(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y,
+                  double alpha, double beta);
+/* y = a*x + b*y  (the broadcast axpy family of every solver body, e.g. 03_BiCGstabl.jl:50,57). */
+int mfem_axpby(mfem_context ctx, int64_t n, double a, const double* x, double b, double* y);
+/* *out [host] = sum x_i*y_i  (LinearAlgebra.dot on CuArray -> CUBLAS dot; 03_BiCGstabl.jl:45). */
+int mfem_dot(mfem_context ctx, int64_t n, const double* x, const double* y, double* out);
+/* *out [host] = ||x||_2      (norm -> CUBLAS nrm2; solver/04_Time_Domain.jl:51). */
+int mfem_nrm2(mfem_context ctx, int64_t n, const double* x, double* out);
+/* x_i = U[0,1) from the counter-based generator (seed, stream_id); replaces FEM_rand ->
+ * CUDA.Random.rand! (misc/04_GPU_Utils.jl:22), which is unseeded in the reference (F9). */
+int mfem_rand(mfem_context ctx, int64_t n, uint64_t seed, uint32_t stream_id, double* x);
+
+/* Jacobi kernels of Pr_Jacobi!/Pl_Jacobi (linear_solver/02_Preconditioner.jl). */
+int mfem_jacobi_by_diagonal(mfem_context ctx, mfem_csr A, const double* vals, double* d);   /* :122-130, d preset to 1 */
+int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double* vals, double* d);    /* :132-139 (+ sqrt :112) */
+int mfem_jacobi_by_row(mfem_context ctx, mfem_csr A, const double* vals, double* d);        /* :170-177 */
+int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double* d);       /* :141-148, in place */
+
+/* ---- S1: the linear solver seam  fem_domain.linear_solver(globalfield) -------------------- */
+typedef enum {
+  MFEM_SOLVER_CG = 0,          /* added (not in the reference, F5); symmetric definite K only */
+  MFEM_SOLVER_BICGSTABL_GS = 1,/* bicgstabl_GS!  linear_solver/03_BiCGstabl.jl:18-96 */
+  MFEM_SOLVER_IDRS = 2,        /* idrs!          linear_solver/04_IDRs.jl:26-95 */
+  MFEM_SOLVER_CGS2 = 3         /* cgs2!          linear_solver/07_CGS.jl:54-105 */
+} mfem_solver_kind;
+
+typedef enum {
+  MFEM_PRECOND_NONE = 0,            /* Identity, 02_Preconditioner.jl:78-86 */
+  MFEM_PRECOND_JACOBI_RIGHT_DIAG = 1,   /* Pr_Jacobi!(normalized_by_column=false), :103-120 */
+  MFEM_PRECOND_JACOBI_RIGHT_COLNORM = 2 /* Pr_Jacobi!(normalized_by_column=true) */
+} mfem_precond_kind;
+
+typedef struct {
+  int32_t method;        /* mfem_solver_kind */
+  int32_t precond;       /* mfem_precond_kind.  For CG, JACOBI_* means M = |diag K| (standard PCG). */
+  int32_t l_or_s;        /* `s` kwarg: BiCGStab l (default 2) / IDR s (default 4) */
+  int32_t maxiter;       /* per pass */
+  int32_t max_pass;      /* restart passes, iterative_Solve! default 4 */
+  int32_t check_every;   /* host polls the device convergence flag every this many iterations (>=1) */
+  double converge_tol;   /* ABSOLUTE on ||r||_2/sqrt(n): globalfield.converge_tol (F10) */
+  uint64_t seed;         /* shadow-vector seed (reference is unseeded, F9) */
+  int32_t fixed_iterations; /* !=0: ignore converge_tol, run exactly maxiter iterations in ONE pass (benchmark mode) */
+  int32_t scale_in_place;   /* !=0: Pr_Jacobi! semantics -- `vals` is overwritten by the column-scaled matrix
+                               (the reference scales its private gather K_total[K_val_ids], :35,118).
+                               ==0: the library scales a private copy (nnz*8 B of workspace). */
+} mfem_solve_options;
+
+typedef struct {
+  int32_t passes;
+  int32_t iterations;      /* sum over passes of the solver's returned iteration count */
+  double final_res;        /* true residual ||b - A x||/sqrt(n) of the last pass */
+  double initial_res;
+  double solve_ms;         /* device time, hip events on the context stream */
+  int32_t converged;
+  int32_t spmv_count;
+} mfem_solve_stats;
+
+/* delta_x = iterative_Solve!(globalfield; Sv_func!, Pr_func!, max_pass, maxiter, s)
+ * (linear_solver/02_Preconditioner.jl:32-76).  b = residue, x_out = the returned vector
+ * (caller-allocated, length n; x0 = 0 as in :45).  K_val_ids is the identity in this backend. */
+int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
+               const mfem_solve_options* opts, mfem_solve_stats* stats);
+/* Optional: caller-supplied shadow vectors for the next mfem_solve on this context
+ * (count = 1 for BiCGStab/CGS2, s for IDR; each length n, contiguous).  NULL restores the RNG. */
+int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int32_t count);
+
+/* ---- structured brick mesh: make_Brick + mesh_Classical(Lagrange) + update_Mesh -------- */
+/* Lattice of (p*nx+1)(p*ny+1)(p*nz+1) control points, id = (i*(p*ny+1) + j)*(p*nz+1) + k
+ * (make_Brick vertex order, mesh/ref_geometry/201_Helper_TM.jl:36-41, applied to the order-p
+ * lattice); elements i-outer/k-inner (:43-51).  Coordinates are generated on device and may be
+ * overwritten through mfem_brick_coords (isoparametric geometry is evaluated on the fly from
+ * them -- nothing of update_BasicElements_3D's per-element tables is stored, F7). */
+int mfem_brick_create(mfem_context ctx, int32_t nx, int32_t ny, int32_t nz, double lx, double ly, double lz,
+                      int32_t itp_order, int32_t itg_order, mfem_brick* out);
+int mfem_brick_destroy(mfem_brick m);
+int64_t mfem_brick_num_controlpoints(mfem_brick m);
+int64_t mfem_brick_num_elements(mfem_brick m);
+/* SoA device coords x1|x2|x3, each ncp doubles (controlpoints.x1/x2/x3). */
+double* mfem_brick_coords(mfem_brick m, int32_t dim_id);
+/* Slab restriction for domain decomposition along i: this handle then owns node
+ * planes [i_lo, i_hi) of the global lattice and assembles only those rows; columns refer to the
+ * LOCAL numbering [ghost_lo | owned | ghost_hi].  Default = whole mesh. */
+int mfem_brick_set_slab(mfem_brick m, int32_t plane_lo, int32_t plane_hi);
+
+/* assemble_SparseID! + sort + generate_J_ptr (solver/03_GlobalAssembly.jl:77-140;
+ * misc/04_GPU_Utils.jl:87-118) for n_fields field-major blocks (all (dual,base) pairs present):
+ * analytic row-sorted CSR, no hash table, no COO sort.  Outputs are library-owned device arrays
+ * valid until mfem_csr_destroy: rowptr is int64, 0-based. */
+int mfem_brick_pattern(mfem_context ctx, mfem_brick m, int32_t n_fields, mfem_csr* out);
+const int64_t* mfem_csr_rowptr64(mfem_csr A);
+const int32_t* mfem_csr_colidx(mfem_csr A);
+int64_t mfem_csr_nnz(mfem_csr A);
+int64_t mfem_csr_n(mfem_csr A);
+
+/* ---- S2 fused assembly closures (constant-coefficient fast paths) ------------------------ */
+/* Faces of the brick in the reference's local face numbering (ref_geometry/002_Initialization.jl:8;
+ * spatial_discretization/103_Integrations.jl:24-30): bit f-1 set <=> face f,
+ * 1: z=0, 2: y=0, 3: x=L, 4: y=L, 5: x=0, 6: z=L. */
+typedef struct {
+  double k;            /* -k*Bilinear(T{;i},T{;i})                   thermal_conduction/3D_Script.jl:30 */
+  double h;            /* h*Bilinear(T, Tenv - T) on robin_faces     :31 */
+  double Tenv;
+  uint32_t robin_faces;
+} mfem_thermal_params;
+
+/* K_linear_func for the thermal weak form: vals (CSR order of mfem_brick_pattern(.., 1, ..)) =
+ *   sum_el sum_q w (-k) dN_a.dN_b + sum_facets sum_q w^s (-h) N_a N_b.   Overwrites vals. */
+int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
+                                double* vals);
+/* K_nonlinear_func (residual part) for the same form, evaluated matrix-free at x_star:
+ *   residue[a] = sum_q w(-k dN_a.dT + N_a s) + sum_q w^s N_a h (Tenv - T).   s = nodal source
+ * (CONTROLPOINT_VAR `s`, may be NULL = 0).  Overwrites residue. */
+int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const mfem_thermal_params* p,
+                                const double* x_star, const double* s, double* residue);
+
+typedef struct {
+  double lambda, mu;       /* sigma = lambda*delta*eps_mm + 2 mu eps   cantilever/3D_Script.jl:53-57 */
+  double tau;              /* tau*Bilinear(d{i}, dw{i} - d{i}) on penalty_faces, dw = 0   :60 */
+  uint32_t penalty_faces;
+  uint32_t traction_faces; /* Bilinear(d{i}, sig{i,j} n{j}) with constant sig   :61 */
+  double sig[6];           /* symmetric tensor 11,22,33,23,13,12 */
+} mfem_elasticity_params;
+int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_elasticity_params* p,
+                                   double* vals);
+int mfem_brick_residual_elasticity(mfem_context ctx, mfem_brick m, const mfem_elasticity_params* p,
+                                   const double* x_star, double* residue);
+
+/* ---- S3 generic element operators (reference signatures, accumulate semantics) ----------- */
+/* itp_vals is integral_vals[itg, itp, n_sd, n_host] column-major with the derivative hyper-cube
+ * flattened to n_sd slots; *_sd are flat 0-based slot offsets (the reference's sd_IDs tuple).
+ * ids are 0- or 1-based per index_base.  n_threads = length of elIDs (one work item each).
+ * colour_offsets (n_colours+1, [host]) partitions the work items into race-free batches; pass
+ * n_colours = 0 to use FP64 atomics instead (the reference's behaviour, 06_FEM_Kernel.jl:10,42,77). */
+typedef struct {
+  int32_t itg, itp, n_sd;
+  int64_t n_host;          /* last dim of itp_vals */
+  int32_t index_base;
+  int32_t n_colours;
+  const int64_t* colour_offsets; /* [host] */
+} mfem_op_layout;
+/* _Var_Basic  solver/06_FEM_Kernel.jl:1-13 : target[q,t] += sum_a N[q,a,sd,host_t] x[cp[a,el_t]+shift] */
+int mfem_op_var(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t sd, int64_t cpID_shift,
+                const int32_t* el_g_cpIDs, const double* x, double* target, const int32_t* itg_hostIDs,
+                const int32_t* elIDs, int64_t n_threads);
+/* _Kval_Basic :28-45 : K[slot[a,b,el_t]+shift] += sum_q N[q,a,dsd] N[q,b,bsd] vals[q,t] */
+int mfem_op_kval(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t dual_sd, int32_t base_sd,
+                 const double* vals, const int32_t* sparse_IDs_by_el, int64_t sparse_ID_shift, double* K_val,
+                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads);
+/* _Res_Basic :65-79 : residue[cp[a,el_t]+shift] += sum_q N[q,a,dsd] vals[q,t] */
+int mfem_op_res(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t dual_sd, const double* vals,
+                int64_t cpID_shift, const int32_t* el_g_cpIDs, double* residue, const int32_t* itg_hostIDs,
+                const int32_t* elIDs, int64_t n_threads);
+
+/* ---- multi-GPU (new; the reference is single-GPU, F6) ------------------------------------ */
+/* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by the host
+ * (torch.distributed / MPI / a file).  */
+int mfem_comm_unique_id(void* out128 /* [host] */);
+int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out);
+int mfem_comm_destroy(mfem_comm c);
+/* Attach to a context: subsequent mfem_solve calls on slab matrices all-reduce their scalars over
+ * the communicator and exchange one ghost plane of `plane_len` doubles per field with ranks +-1
+ * before each SpMV.  n_owned rows are [ghost_lo | owned | ghost_hi] in the local x. */
+int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t plane_len, int32_t n_fields);
+int mfem_allreduce_sum(mfem_context ctx, double* dev_scalars, int32_t count);
+int mfem_halo_exchange(mfem_context ctx, double* x_local);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METAFEM_MI355X_H */

@@ -1,0 +1,84 @@
+// Context management and error plumbing of the C ABI (include/metafem_mi355x.h).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void mfem_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int mfem_abi_version(void) { return MFEM_ABI_VERSION; }
+extern "C" const char* mfem_last_error(void) { return g_err; }
+
+extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) {
+  MFEM_REQUIRE(out != nullptr, "out is null");
+  int ndev = 0;
+  MFEM_CHECK_HIP(hipGetDeviceCount(&ndev));
+  MFEM_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
+  MFEM_CHECK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MFEM_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    mfem_set_error("libmetafem_mi355x is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
+    return MFEM_ERR_UNSUPPORTED;
+  }
+  mfem_context_s* c = new mfem_context_s();
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->num_cus = prop.multiProcessorCount;
+  MFEM_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(double) * MFEM_MAX_PARTIALS * 8));
+  MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * 256));
+  MFEM_CHECK_HIP(hipHostMalloc(&c->h_scalars, sizeof(double) * 256));
+  MFEM_CHECK_HIP(hipMalloc(&c->d_flags, sizeof(int32_t) * 16));
+  MFEM_CHECK_HIP(hipHostMalloc(&c->h_flags, sizeof(int32_t) * 16));
+  MFEM_CHECK_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * 256, c->stream));
+  MFEM_CHECK_HIP(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 16, c->stream));
+  MFEM_CHECK_HIP(hipEventCreate(&c->ev0));
+  MFEM_CHECK_HIP(hipEventCreate(&c->ev1));
+  *out = c;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_context_set_stream(mfem_context ctx, void* stream) {
+  MFEM_REQUIRE(ctx != nullptr, "ctx is null");
+  ctx->stream = (hipStream_t)stream;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_context_sync(mfem_context ctx) {
+  MFEM_REQUIRE(ctx != nullptr, "ctx is null");
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return MFEM_OK;
+}
+
+extern "C" int mfem_context_destroy(mfem_context ctx) {
+  if (!ctx) return MFEM_OK;
+  hipStreamSynchronize(ctx->stream);
+  hipFree(ctx->d_partials);
+  hipFree(ctx->d_scalars);
+  hipHostFree(ctx->h_scalars);
+  hipFree(ctx->d_flags);
+  hipHostFree(ctx->h_flags);
+  if (ctx->ws) hipFree(ctx->ws);
+  hipEventDestroy(ctx->ev0);
+  hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return MFEM_OK;
+}
+
+int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return MFEM_OK;
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) MFEM_CHECK_HIP(hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  MFEM_CHECK_HIP(hipMalloc(&ctx->ws, bytes));
+  ctx->ws_bytes = bytes;
+  return MFEM_OK;
+}

@@ -1,0 +1,419 @@
+// Fused hex-8 assembly: geometry update + element operators + scatter in ONE pass per quantity.
+// Replaces, for the constant-coefficient thermal / elasticity weak forms:
+//   update_BasicElements_3D + inv_Jac_3D + update_Basic_itgval_1_3D   mesh/unstructured_mesh/4_Update_Integrator.jl:2-33,90-154
+//   update_BasicBoundary_3D + tangents/normals                        :35-75,173-226
+//   _Var_Basic / _Kval_Basic / _Res_Basic                             solver/06_FEM_Kernel.jl:1-13,28-45,65-79
+//   the generated K_linear / K_nonlinear bodies                        solver/05_CodeGenerator.jl:52-154
+// The reference stores 4 KB of physical-space basis tables per element and launches one
+// thread-per-element kernel PER bilinear term with FP64 atomics into hash-ordered slots.  Here nothing
+// per-element is stored: a row-owner thread (one per control point) recomputes J, det, J^-1 and the
+// pushed-forward gradients of its <= 8 adjacent elements from nodal coordinates, accumulates its own
+// matrix row and writes it once -- race-free without atomics or colours, CSR order, nnz*8 B written
+// exactly once (the algorithmic minimum).  Thermal rows are staged in LDS and leave the CU as one
+// contiguous, fully coalesced stream per workgroup.
+#include "brick.h"
+
+// reference-cell tables for the tensor hex-8 on [0,1]^3 (spatial_discretization/102_Interpolations.jl:30-39,
+// 103_Integrations.jl:1-19): index [q][b], q = qx + ng*(qy + ng*qz) (x fastest), b = bx + 2*by + 4*bz.
+__constant__ double c_w[BRICK_MAX_Q];
+__constant__ double c_N[BRICK_MAX_Q][8];
+__constant__ double c_dN[BRICK_MAX_Q][8][3];
+// face tables: 2-D Gauss on [0,1]^2, bilinear face basis [q][c], c = c1 + 2*c2 (first tangential coord fastest)
+__constant__ double c_fw[BRICK_MAX_NG * BRICK_MAX_NG];
+__constant__ double c_fN[BRICK_MAX_NG * BRICK_MAX_NG][4];
+__constant__ double c_fdN[BRICK_MAX_NG * BRICK_MAX_NG][4][2];
+static int g_tables_ng = 0;
+
+static const double GP[4][4] = {{0.0, 0, 0, 0},
+                                {-0.57735026918962576451, 0.57735026918962576451, 0, 0},
+                                {-0.77459666924148337704, 0.0, 0.77459666924148337704, 0},
+                                {-0.86113631159405257522, -0.33998104358485626480, 0.33998104358485626480, 0.86113631159405257522}};
+static const double GW[4][4] = {{2.0, 0, 0, 0},
+                                {1.0, 1.0, 0, 0},
+                                {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0, 0},
+                                {0.34785484513745385737, 0.65214515486254614263, 0.65214515486254614263, 0.34785484513745385737}};
+
+int mfem_hex8_upload_tables(int ng) {
+  if (g_tables_ng == ng) return MFEM_OK;
+  double w[BRICK_MAX_Q], N[BRICK_MAX_Q][8], dN[BRICK_MAX_Q][8][3];
+  double fw[16], fN[16][4], fdN[16][4][2];
+  double gp[4], gw[4];
+  for (int i = 0; i < ng; ++i) {
+    gp[i] = GP[ng - 1][i] / 2.0 + 0.5;  // shift_gauss_point  103_Integrations.jl:1
+    gw[i] = GW[ng - 1][i] / 2.0;        // shift_gauss_weight :2
+  }
+  memset(w, 0, sizeof(w)); memset(N, 0, sizeof(N)); memset(dN, 0, sizeof(dN));
+  memset(fw, 0, sizeof(fw)); memset(fN, 0, sizeof(fN)); memset(fdN, 0, sizeof(fdN));
+  for (int qz = 0; qz < ng; ++qz)
+    for (int qy = 0; qy < ng; ++qy)
+      for (int qx = 0; qx < ng; ++qx) {
+        const int q = qx + ng * (qy + ng * qz);
+        const double xi[3] = {gp[qx], gp[qy], gp[qz]};
+        w[q] = gw[qx] * gw[qy] * gw[qz];
+        for (int b = 0; b < 8; ++b) {
+          double f[3], df[3];
+          for (int d = 0; d < 3; ++d) {
+            const int bd = (b >> d) & 1;
+            f[d] = bd ? xi[d] : 1.0 - xi[d];
+            df[d] = bd ? 1.0 : -1.0;
+          }
+          N[q][b] = f[0] * f[1] * f[2];
+          dN[q][b][0] = df[0] * f[1] * f[2];
+          dN[q][b][1] = f[0] * df[1] * f[2];
+          dN[q][b][2] = f[0] * f[1] * df[2];
+        }
+      }
+  for (int q2 = 0; q2 < ng; ++q2)
+    for (int q1 = 0; q1 < ng; ++q1) {
+      const int q = q1 + ng * q2;
+      fw[q] = gw[q1] * gw[q2];
+      const double xi[2] = {gp[q1], gp[q2]};
+      for (int c = 0; c < 4; ++c) {
+        const int c1 = c & 1, c2 = c >> 1;
+        const double f1 = c1 ? xi[0] : 1.0 - xi[0], f2 = c2 ? xi[1] : 1.0 - xi[1];
+        fN[q][c] = f1 * f2;
+        fdN[q][c][0] = (c1 ? 1.0 : -1.0) * f2;
+        fdN[q][c][1] = f1 * (c2 ? 1.0 : -1.0);
+      }
+    }
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_w), w, sizeof(w)));
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_N), N, sizeof(N)));
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_dN), dN, sizeof(dN)));
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fw), fw, sizeof(fw)));
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fN), fN, sizeof(fN)));
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fdN), fdN, sizeof(fdN)));
+  g_tables_ng = ng;
+  return MFEM_OK;
+}
+
+// ---- geometry at one Gauss point: J = dx/dxi, det, J^-1 (adjugate, inv_Jac_3D :90-121),
+//      physical gradients g[b][s] = sum_m dN_b/dxi_m Jinv[m][s] (:133-142); returns w_q * det (:30)
+__device__ __forceinline__ double hex8_geom(const double (&X)[8][3], int q, double (&g)[8][3]) {
+  double J[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      double s = 0.0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) s += c_dN[q][b][m] * X[b][i];
+      J[i][m] = s;
+    }
+  const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[0][1] * J[1][0] * J[2][2] +
+                     J[0][1] * J[1][2] * J[2][0] + J[0][2] * J[1][0] * J[2][1] - J[0][2] * J[1][1] * J[2][0];
+  const double id = 1.0 / det;
+  double I[3][3];
+  I[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id;
+  I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+  I[0][2] = (J[0][1] * J[1][2] - J[1][1] * J[0][2]) * id;
+  I[1][0] = (J[1][2] * J[2][0] - J[2][2] * J[1][0]) * id;
+  I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+  I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+  I[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id;
+  I[2][1] = (J[0][1] * J[2][0] - J[2][1] * J[0][0]) * id;
+  I[2][2] = (J[0][0] * J[1][1] - J[1][0] * J[0][1]) * id;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      g[b][s] = c_dN[q][b][0] * I[0][s] + c_dN[q][b][1] * I[1][s] + c_dN[q][b][2] * I[2][s];
+  return c_w[q] * det;
+}
+
+__device__ __forceinline__ void hex8_load_coords(const BrickView& B, int I, int J, int K, double (&X)[8][3]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int64_t c = brick_cindex(B, I + (b & 1), J + ((b >> 1) & 1), K + (b >> 2));
+    X[b][0] = B.X0[c];
+    X[b][1] = B.X1[c];
+    X[b][2] = B.X2[c];
+  }
+}
+
+// Face quadrature on the brick face with normal dim nd (0,1,2) -- tangential dims follow the reference
+// (103_Integrations.jl:37): nd=0 -> (1,2), nd=1 -> (2,0), nd=2 -> (0,1).  Xf[c][3] are the 4 face nodes,
+// c = c1 + 2*c2.  Returns w^s = w_q * |t1 x t2| (4_Update_Integrator.jl:71,210-226); `nrm` (optional) is
+// the OUTWARD unit normal: the first tangent is negated on the low face (103_Integrations.jl:45).
+__device__ __forceinline__ double face_geom(const double (&Xf)[4][3], int q, bool low_face, double* nrm) {
+  double t1[3], t2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a += c_fdN[q][c][0] * Xf[c][i];
+      b += c_fdN[q][c][1] * Xf[c][i];
+    }
+    t1[i] = low_face ? -a : a;
+    t2[i] = b;
+  }
+  const double r0 = t1[1] * t2[2] - t1[2] * t2[1];
+  const double r1 = -t1[0] * t2[2] + t1[2] * t2[0];
+  const double r2 = t1[0] * t2[1] - t1[1] * t2[0];
+  const double ld = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+  if (nrm) {
+    nrm[0] = r0 / ld;
+    nrm[1] = r1 / ld;
+    nrm[2] = r2 / ld;
+  }
+  return c_fw[q] * ld;
+}
+
+__device__ __forceinline__ int face_bit(int nd, int high) {
+  // reference local face ids (002_Initialization.jl:8): 1 z=0, 2 y=0, 3 x=L, 4 y=L, 5 x=0, 6 z=L
+  const int id = (nd == 0) ? (high ? 3 : 5) : (nd == 1) ? (high ? 4 : 2) : (high ? 6 : 1);
+  return 1 << (id - 1);
+}
+
+__device__ __forceinline__ void node_ijk(const BrickView& B, int64_t node, int& i, int& j, int& k) {
+  i = (int)(node / B.plane_len) + B.plo;
+  const int64_t rem = node % B.plane_len;
+  j = (int)(rem / B.m2);
+  k = (int)(rem % B.m2);
+}
+
+// =================================================================================================
+// Thermal K:  vals = sum_el sum_q w (-k) grad N_a . grad N_b  +  sum_facets sum_q w^s (-h) N_a N_b
+// One thread per owned control point; the workgroup's 256 rows are contiguous in CSR and are staged in
+// LDS (<= 256*27 doubles = 54 KiB), then stored as one coalesced stream.
+// =================================================================================================
+#define TH_ROWS MFEM_BLOCK
+#define TH_LDS (TH_ROWS * 27)
+
+__global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix(BrickView B, double kcond, double h, uint32_t robin,
+                                                                 double* __restrict__ vals) {
+  __shared__ double acc[TH_LDS];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * TH_ROWS;
+  const int64_t node = r0 + tid;
+  const bool valid = node < B.n_owned;
+  int i0, j0, k0;
+  node_ijk(B, r0, i0, j0, k0);
+  const int64_t pre0 = brick_prefix(B, i0, j0, k0);
+  int64_t cnt_total;
+  {
+    const int64_t r1 = (r0 + TH_ROWS < B.n_owned) ? r0 + TH_ROWS : B.n_owned;
+    if (r1 < B.n_owned) {
+      int i1, j1, k1;
+      node_ijk(B, r1, i1, j1, k1);
+      cnt_total = brick_prefix(B, i1, j1, k1) - pre0;
+    } else {
+      cnt_total = (B.P0[B.phi] - B.Pplo) * B.S1 * B.S2 - pre0;
+    }
+  }
+  for (int t = tid; t < (int)cnt_total; t += MFEM_BLOCK) acc[t] = 0.0;
+  __syncthreads();
+  if (valid) {
+    int i, j, k;
+    node_ijk(B, node, i, j, k);
+    const int base = (int)(brick_prefix(B, i, j, k) - pre0);
+    const int li = B.lo0[i], lj = B.lo1[j], lk = B.lo2[k];
+    const int cj = B.c1[j], ck = B.c2[k];
+    // ---- volume terms: adjacent elements (i-1+ex, j-1+ey, k-1+ez)
+    for (int e = 0; e < 8; ++e) {
+      const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
+      const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
+      if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
+      const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);  // my local basis id inside that element
+      double X[8][3];
+      hex8_load_coords(B, I, J, K, X);
+      double kab[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) kab[b] = 0.0;
+      const int nq = B.ng * B.ng * B.ng;
+      for (int q = 0; q < nq; ++q) {
+        double g[8][3];
+        const double wd = hex8_geom(X, q, g);
+        double ga0 = 0.0, ga1 = 0.0, ga2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const bool me = (b == a);
+          ga0 = me ? g[b][0] : ga0;
+          ga1 = me ? g[b][1] : ga1;
+          ga2 = me ? g[b][2] : ga2;
+        }
+        const double c = -kcond * wd;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) kab[b] += c * (ga0 * g[b][0] + ga1 * g[b][1] + ga2 * g[b][2]);
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
+        const int slot = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
+        acc[base + slot] += kab[b];
+      }
+    }
+    // ---- Robin faces: h*Bilinear(T, Tenv - T) contributes -h N_a N_b (3D_Script.jl:31)
+    if (h != 0.0 && robin != 0u) {
+      const int idx[3] = {i, j, k};
+      const int ne[3] = {B.ne0, B.ne1, B.ne2};
+      for (int nd = 0; nd < 3; ++nd) {
+        const int hi = (idx[nd] == ne[nd]) ? 1 : 0;
+        if (idx[nd] != 0 && !hi) continue;
+        for (int side = 0; side < 2; ++side) {  // a 1-element-thick dim touches both faces
+          const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
+          if (!on || !(robin & face_bit(nd, side))) continue;
+          const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+          for (int f = 0; f < 4; ++f) {
+            const int f1 = f & 1, f2 = f >> 1;
+            int E[3];
+            E[nd] = side ? ne[nd] - 1 : 0;
+            E[t1] = idx[t1] - 1 + f1;
+            E[t2] = idx[t2] - 1 + f2;
+            if (E[t1] < 0 || E[t1] >= ne[t1] || E[t2] < 0 || E[t2] >= ne[t2]) continue;
+            const int ca = (1 - f1) + 2 * (1 - f2);  // my id among the 4 face nodes
+            double Xf[4][3];
+            int fn[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              fn[c][nd] = idx[nd];
+              fn[c][t1] = E[t1] + (c & 1);
+              fn[c][t2] = E[t2] + (c >> 1);
+              const int64_t ci = brick_cindex(B, fn[c][0], fn[c][1], fn[c][2]);
+              Xf[c][0] = B.X0[ci];
+              Xf[c][1] = B.X1[ci];
+              Xf[c][2] = B.X2[ci];
+            }
+            double mab[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < B.ng * B.ng; ++q) {
+              const double ws = face_geom(Xf, q, side == 0, nullptr);
+              double na = 0.0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) na = (c == ca) ? c_fN[q][c] : na;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) mab[c] += -h * ws * na * c_fN[q][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int slot = ((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk);
+              acc[base + slot] += mab[c];
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double* out = vals + pre0;
+  for (int t = tid; t < (int)cnt_total; t += MFEM_BLOCK) out[t] = acc[t];
+}
+
+// =================================================================================================
+// Thermal residual (matrix-free, at x_star):
+//   R[a] = sum_q w (-k grad N_a . grad T + N_a s) + sum_q w^s N_a h (Tenv - T)
+// =================================================================================================
+__global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_residual(BrickView B, double kcond, double h, double Tenv,
+                                                                   uint32_t robin, const double* __restrict__ x,
+                                                                   const double* __restrict__ src,
+                                                                   double* __restrict__ res) {
+  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= B.n_owned) return;
+  int i, j, k;
+  node_ijk(B, node, i, j, k);
+  double r = 0.0;
+  for (int e = 0; e < 8; ++e) {
+    const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
+    const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
+    if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
+    const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
+    double X[8][3], T[8], S[8];
+    hex8_load_coords(B, I, J, K, X);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
+      const int64_t xi = brick_xindex(B, 0, ni, nj, nk);
+      T[b] = x[xi];
+      S[b] = src ? src[xi] : 0.0;
+    }
+    const int nq = B.ng * B.ng * B.ng;
+    for (int q = 0; q < nq; ++q) {
+      double g[8][3];
+      const double wd = hex8_geom(X, q, g);
+      double gT0 = 0.0, gT1 = 0.0, gT2 = 0.0, sq = 0.0, ga0 = 0.0, ga1 = 0.0, ga2 = 0.0, na = 0.0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        gT0 += g[b][0] * T[b];
+        gT1 += g[b][1] * T[b];
+        gT2 += g[b][2] * T[b];
+        sq += c_N[q][b] * S[b];
+        const bool me = (b == a);
+        ga0 = me ? g[b][0] : ga0;
+        ga1 = me ? g[b][1] : ga1;
+        ga2 = me ? g[b][2] : ga2;
+        na = me ? c_N[q][b] : na;
+      }
+      r += wd * (-kcond * (ga0 * gT0 + ga1 * gT1 + ga2 * gT2) + na * sq);
+    }
+  }
+  if (h != 0.0 && robin != 0u) {
+    const int idx[3] = {i, j, k};
+    const int ne[3] = {B.ne0, B.ne1, B.ne2};
+    for (int nd = 0; nd < 3; ++nd) {
+      for (int side = 0; side < 2; ++side) {
+        const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
+        if (!on || !(robin & face_bit(nd, side))) continue;
+        const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+        for (int f = 0; f < 4; ++f) {
+          const int f1 = f & 1, f2 = f >> 1;
+          int E1 = idx[t1] - 1 + f1, E2 = idx[t2] - 1 + f2;
+          if (E1 < 0 || E1 >= ne[t1] || E2 < 0 || E2 >= ne[t2]) continue;
+          const int ca = (1 - f1) + 2 * (1 - f2);
+          double Xf[4][3], Tf[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            int fn[3];
+            fn[nd] = idx[nd];
+            fn[t1] = E1 + (c & 1);
+            fn[t2] = E2 + (c >> 1);
+            const int64_t ci = brick_cindex(B, fn[0], fn[1], fn[2]);
+            Xf[c][0] = B.X0[ci];
+            Xf[c][1] = B.X1[ci];
+            Xf[c][2] = B.X2[ci];
+            Tf[c] = x[brick_xindex(B, 0, fn[0], fn[1], fn[2])];
+          }
+          for (int q = 0; q < B.ng * B.ng; ++q) {
+            const double ws = face_geom(Xf, q, side == 0, nullptr);
+            double na = 0.0, Tq = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              na = (c == ca) ? c_fN[q][c] : na;
+              Tq += c_fN[q][c] * Tf[c];
+            }
+            r += ws * na * h * (Tenv - Tq);
+          }
+        }
+      }
+    }
+  }
+  res[node] = r;
+}
+
+int mfem_hex8_upload_tables(int ng);
+
+extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
+                                           double* vals) {
+  MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
+  MFEM_REQUIRE(m->p == 1, "fused thermal assembly is implemented for hex-8 (itp_order 1); hex-27 uses the MFMA path");
+  MFEM_REQUIRE(A->n == m->n_owned, "pattern was not built for 1 field on this brick");
+  int rc = mfem_hex8_upload_tables(m->ng);
+  if (rc) return rc;
+  BrickView B = mfem_brick_view(m, 1);
+  const int grid = (int)((m->n_owned + TH_ROWS - 1) / TH_ROWS);
+  hipLaunchKernelGGL(k_thermal_matrix, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, p->h, p->robin_faces, vals);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
+extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const mfem_thermal_params* p,
+                                           const double* x_star, const double* s, double* residue) {
+  MFEM_REQUIRE(ctx && m && p && x_star && residue, "null argument");
+  MFEM_REQUIRE(m->p == 1, "fused thermal residual is implemented for hex-8 (itp_order 1)");
+  int rc = mfem_hex8_upload_tables(m->ng);
+  if (rc) return rc;
+  BrickView B = mfem_brick_view(m, 1);
+  const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
+  hipLaunchKernelGGL(k_thermal_residual, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, p->h, p->Tenv,
+                     p->robin_faces, x_star, s, residue);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}

@@ -1,0 +1,27 @@
+// Internal launch helpers shared by the solver translation units.
+#pragma once
+#include "common.h"
+
+int mfem_vec_grid(mfem_context_s* ctx, int64_t n);
+int mfem_dot_device(mfem_context_s* ctx, int64_t n, const double* x, const double* y, double* d_out);
+int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
+                     double alpha, double beta, const double* dotw, double* partials, int* n_partials);
+int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* d, int mode);
+int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count);
+int mfem_comm_halo(mfem_context_s* ctx, double* x_local);
+
+// Every thread of the workgroup returns sum(p[0..np)); deterministic order, identical in all
+// workgroups.  np <= MFEM_MAX_PARTIALS.  smem >= 4 doubles.
+__device__ __forceinline__ double reduce_partials_bcast(const double* __restrict__ p, int np, double* smem) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) acc += p[i];
+  acc = wave_reduce_sum(acc);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = acc;
+  __syncthreads();
+  double r = 0.0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) r += smem[i];
+  return r;
+}

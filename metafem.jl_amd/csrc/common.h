@@ -1,0 +1,106 @@
+// Shared internals of libmetafem_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/metafem_mi355x.h"
+
+#define MFEM_WAVE 64
+#define MFEM_BLOCK 256
+#define MFEM_MAX_PARTIALS 4096  // upper bound on per-launch partial sums of a fused reduction
+
+void mfem_set_error(const char* fmt, ...);
+
+#define MFEM_CHECK_HIP(expr)                                                                  \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      mfem_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));    \
+      return MFEM_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+#define MFEM_REQUIRE(cond, msg)                                      \
+  do {                                                               \
+    if (!(cond)) {                                                   \
+      mfem_set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond); \
+      return MFEM_ERR_INVALID;                                       \
+    }                                                                \
+  } while (0)
+
+#define MFEM_CHECK_LAUNCH() MFEM_CHECK_HIP(hipGetLastError())
+
+struct mfem_comm_s;
+
+struct mfem_context_s {
+  int device;
+  hipStream_t stream;
+  int num_cus;
+  // reduction scratch: partial sums (device) + a small block of device scalars + pinned host mirror
+  double* d_partials;   // [MFEM_MAX_PARTIALS * 8]
+  double* d_scalars;    // [256] device-resident Krylov scalars
+  double* h_scalars;    // pinned, [256]
+  int32_t* d_flags;     // [16] device flags (done, iteration count, ...)
+  int32_t* h_flags;     // pinned
+  // generic workspace (grown on demand, never shrunk)
+  void* ws;
+  size_t ws_bytes;
+  // optional user shadow vectors
+  const double* shadow;
+  int32_t shadow_count;
+  // multi-GPU
+  mfem_comm_s* comm;
+  int64_t halo_plane_len;
+  int32_t halo_fields;
+  hipEvent_t ev0, ev1;
+};
+
+struct mfem_csr_s {
+  mfem_context_s* ctx;
+  int64_t n, nnz;
+  const void* rowptr;
+  int rowptr_bits;
+  const int32_t* colidx;
+  int index_base;
+  // plan for the LDS-staged SpMV
+  int32_t max_row_nnz;
+  int32_t rows_per_block;  // power of two, 0 => long-row fallback
+  // owned storage (mfem_brick_pattern) -- freed in destroy
+  void* owned_rowptr;
+  void* owned_colidx;
+  // slab info (multi-GPU): rows = owned nodes, x has ghost planes; 0 for single GPU
+  int64_t x_offset;  // offset of the first owned entry inside the local x (per field)
+};
+
+int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes);
+
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, MFEM_WAVE);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == MFEM_BLOCK (4 waves). Result valid in thread 0.
+__device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 4 doubles */) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+static inline int mfem_grid_for(int64_t work_items, int per_block, int cap) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}

@@ -1,0 +1,470 @@
+// Device-resident Krylov drivers behind mfem_solve: the linear-solver seam
+//   delta_x = fem_domain.linear_solver(globalfield)           (reference solver/04_Time_Domain.jl:76)
+//   iterative_Solve!(globalfield; Sv_func!, Pr_func!, ...)    (linear_solver/02_Preconditioner.jl:32-76)
+// This file holds the restart wrapper and the added Jacobi-PCG (not in the reference, F5);
+// bicgstabl_GS! and idrs! live in krylov_bicgstabl.hip / krylov_idrs.hip.
+//
+// The reference returns every dot/norm to the host (CUBLAS scalar readback = one sync per reduction).
+// Here all recurrence scalars stay in ctx->d_scalars: a reduction leaves per-workgroup partial sums
+// and the NEXT kernel's workgroups each re-reduce those partials (<= 4096 doubles, L2 resident) in a
+// fixed order, so there is no finalize launch, no atomic and the result is bitwise reproducible.  The
+// convergence test of the reference (normalized_norm(r) <= tol || iter >= maxiter, evaluated every
+// iteration) is evaluated on device into a DONE flag that turns the remaining enqueued kernels into
+// no-ops; the host polls it every `check_every` iterations.
+#include "krylov.h"
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// generic small kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MFEM_BLOCK) void k_fill(int64_t n, double v, double* __restrict__ x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) x[i] = v;
+}
+
+// y = 1 / x  (only the first n entries; the pad stays 0)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_recip(int64_t n, const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = 1.0 / x[i];
+}
+
+// y = x ./ d
+__global__ __launch_bounds__(MFEM_BLOCK) void k_div(int64_t n, const double* __restrict__ x, const double* __restrict__ d,
+                                                      double* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i] / d[i];
+}
+
+int mfem_fill(mfem_context_s* ctx, int64_t n, double v, double* x) {
+  if (n == 0) return MFEM_OK;
+  hipLaunchKernelGGL(k_fill, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, v, x);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
+// r = b - A x  and  S[slot] = r.r   (start of every Sv body: mul!(r, A, x, -1.); r .+= b)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_resid_finish(int64_t n2, const d2_t* __restrict__ b, d2_t* __restrict__ r,
+                                                               double* __restrict__ partials) {
+  __shared__ double red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const d2_t v = r[i] + b[i];
+    r[i] = v;
+    acc += v.x * v.x + v.y * v.y;
+  }
+  const double s = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+int mfem_true_residual(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* b, const double* x,
+                       double* r, int64_t nv, double* d_rr) {
+  // r = -A x ; r += b ; *d_rr = r.r  (device scalar, all-reduced over ranks when a communicator is attached)
+  int rc;
+  if (ctx->comm) {
+    rc = mfem_comm_halo(ctx, const_cast<double*>(x));
+    if (rc) return rc;
+  }
+  rc = mfem_spmv_launch(ctx, A, vals, x, r, -1.0, 0.0, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  const int grid = mfem_vec_grid(ctx, nv);
+  hipLaunchKernelGGL(k_resid_finish, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, (const d2_t*)b, (d2_t*)r,
+                     ctx->d_partials);
+  MFEM_CHECK_LAUNCH();
+  rc = mfem_sum_partials(ctx, ctx->d_partials, grid, d_rr);
+        if (rc) return rc;
+  MFEM_CHECK_LAUNCH();
+  if (ctx->comm) return mfem_comm_allreduce(ctx, d_rr, 1);
+  return MFEM_OK;
+}
+
+int mfem_read_scalars(mfem_context_s* ctx, int first, int count) {
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + first, ctx->d_scalars + first, sizeof(double) * count,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return MFEM_OK;
+}
+
+int mfem_read_flags(mfem_context_s* ctx) {
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return MFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Jacobi-preconditioned CG (added solver; M = |diag K|).  Three kernels per iteration:
+//   SpMV (+ p.Ap partials) | x,r update (+ r.z, r.r partials) | p update (+ scalar bookkeeping)
+// ------------------------------------------------------------------------------------------
+struct CgArgs {
+  int64_t n2;       // padded length / 2
+  double n_inv;     // 1 / global n (for normalized_norm)
+  double tol;
+  int32_t maxiter;
+  int32_t fixed;    // benchmark mode: never converge
+};
+
+// z = r .* dinv ; p = z ; partials: [0,G) r.z  [G,2G) r.r
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init(CgArgs a, const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
+                                                          d2_t* __restrict__ p, double* __restrict__ partials) {
+  __shared__ double red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double rz = 0.0, rr = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
+    const d2_t rv = r[i];
+    const d2_t z = dinv ? rv * dinv[i] : rv;
+    p[i] = z;
+    rz += rv.x * z.x + rv.y * z.y;
+    rr += rv.x * rv.x + rv.y * rv.y;
+  }
+  const double s0 = block_reduce_sum(rz, red);
+  const double s1 = block_reduce_sum(rr, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = s0;
+    partials[gridDim.x + blockIdx.x] = s1;
+  }
+}
+
+// Single workgroup: fold the init partials into S[RZ0], S[RR]; iteration counter = 0; DONE if already converged.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init_fin(CgArgs a, const double* __restrict__ partials, int np,
+                                                              double* __restrict__ S, int32_t* __restrict__ flags) {
+  __shared__ double red[4];
+  const double rz = reduce_partials_bcast(partials, np, red);
+  const double rr = reduce_partials_bcast(partials + np, np, red);
+  if (threadIdx.x == 0) {
+    S[S_RZ0] = rz;
+    S[S_RR] = rr;
+    flags[F_ITER] = 0;
+    flags[F_DONE] = (!a.fixed && sqrt(rr * a.n_inv) <= a.tol) ? 1 : 0;
+  }
+}
+
+// alpha = rz / p.Ap ; x += alpha p ; r -= alpha Ap ; partials2: [0,G) r.z  [G,2G) r.r   (z = r .* dinv)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, const double* __restrict__ pap_partials,
+                                                            int np, const d2_t* __restrict__ p, const d2_t* __restrict__ Ap,
+                                                            const d2_t* __restrict__ dinv, d2_t* __restrict__ x,
+                                                            d2_t* __restrict__ r, const double* __restrict__ S,
+                                                            const int32_t* __restrict__ flags,
+                                                            double* __restrict__ partials2) {
+  __shared__ double red[4];
+  if (flags[F_DONE]) return;
+  const double pap = np > 0 ? reduce_partials_bcast(pap_partials, np, red) : S[S_PAP];
+  const double alpha = S[S_RZ0 + cur] / pap;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double rz = 0.0, rr = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
+    const d2_t pv = p[i], av = Ap[i];
+    x[i] = x[i] + alpha * pv;
+    const d2_t rv = r[i] - alpha * av;
+    r[i] = rv;
+    const d2_t z = dinv ? rv * dinv[i] : rv;
+    rz += rv.x * z.x + rv.y * z.y;
+    rr += rv.x * rv.x + rv.y * rv.y;
+  }
+  const double s0 = block_reduce_sum(rz, red);
+  const double s1 = block_reduce_sum(rr, red);
+  if (threadIdx.x == 0) {
+    partials2[blockIdx.x] = s0;
+    partials2[gridDim.x + blockIdx.x] = s1;
+  }
+}
+
+// beta = rz_new / rz_old ; p = z + beta p ; workgroup 0 also advances the scalar state / DONE flag.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, const double* __restrict__ partials2, int np,
+                                                             const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
+                                                             d2_t* __restrict__ p, double* __restrict__ S,
+                                                             int32_t* __restrict__ flags) {
+  __shared__ double red[4];
+  if (flags[F_DONE]) return;
+  double rz_new, rr;
+  if (np > 0) {
+    rz_new = reduce_partials_bcast(partials2, np, red);
+    rr = reduce_partials_bcast(partials2 + np, np, red);
+  } else {
+    rz_new = S[S_TMP0];
+    rr = S[S_TMP1];
+  }
+  const double beta = rz_new / S[S_RZ0 + cur];
+  const int iter = flags[F_ITER] + 1;
+  const bool done = (!a.fixed && sqrt(rr * a.n_inv) <= a.tol) || iter >= a.maxiter;
+  if (!done) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
+      const d2_t rv = r[i];
+      const d2_t z = dinv ? rv * dinv[i] : rv;
+      p[i] = z + beta * p[i];
+    }
+  }
+  // bookkeeping last: every workgroup has read flags/S before workgroup 0 can change them only if it
+  // reads first -- workgroup 0 reads above, writes here; other workgroups read slots this write does
+  // not touch (S[RZ0+cur], F_ITER is re-read only by the next kernel).
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S[S_RZ0 + (cur ^ 1)] = rz_new;
+    S[S_RR] = rr;
+  }
+}
+
+// F_ITER / F_DONE are advanced by a separate 1-thread kernel so that no workgroup of k_cg_pupdate can
+// observe a half-updated state (a late workgroup must still see the flags its siblings saw).
+__global__ void k_cg_advance(CgArgs a, double* __restrict__ S, int32_t* __restrict__ flags) {
+  if (flags[F_DONE]) return;
+  const int iter = flags[F_ITER] + 1;
+  flags[F_ITER] = iter;
+  if ((!a.fixed && sqrt(S[S_RR] * a.n_inv) <= a.tol) || iter >= a.maxiter) flags[F_DONE] = 1;
+}
+
+static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V,
+                         const mfem_solve_options* o, double tol, int64_t n_global, int* iters_out, int* spmv_out) {
+  // V.x (current iterate), V.b ; work: r, p, Ap, dinv
+  double* S = ctx->d_scalars;
+  int32_t* F = ctx->d_flags;
+  double* r = V.w[0];
+  double* p = V.w[1];
+  double* Ap = V.w[2];
+  const double* dinv = V.dinv;
+  const int64_t nv = V.nv;
+  CgArgs a;
+  a.n2 = nv / 2;
+  a.n_inv = 1.0 / (double)n_global;
+  a.tol = tol;
+  a.maxiter = o->maxiter;
+  a.fixed = o->fixed_iterations;
+  double* part1 = ctx->d_partials;                          // SpMV p.Ap partials
+  double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;       // 2 x G
+  int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
+  if (rc) return rc;
+  ++*spmv_out;
+  const int G = mfem_vec_grid(ctx, nv);
+  hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (const d2_t*)r, (const d2_t*)dinv, (d2_t*)p,
+                     part2);
+  MFEM_CHECK_LAUNCH();
+  if (ctx->comm) {
+    rc = mfem_sum_partials(ctx, part2, G, S + S_TMP0);
+        if (rc) return rc;
+    rc = mfem_sum_partials(ctx, part2 + G, G, S + S_TMP1);
+        if (rc) return rc;
+    MFEM_CHECK_LAUNCH();
+    rc = mfem_comm_allreduce(ctx, S + S_TMP0, 2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, a, S + S_TMP0, 1, S, F);
+  } else {
+    hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, a, part2, G, S, F);
+  }
+  MFEM_CHECK_LAUNCH();
+  const int check = o->check_every > 0 ? o->check_every : 32;
+  int it = 0;
+  for (;;) {
+    if (!o->fixed_iterations || it == 0) {
+      rc = mfem_read_flags(ctx);
+      if (rc) return rc;
+      if (ctx->h_flags[F_DONE]) break;
+    }
+    const int burst = (o->maxiter - it) < check ? (o->maxiter - it) : check;
+    if (burst <= 0) break;
+    for (int k = 0; k < burst; ++k, ++it) {
+      const int cur = it & 1;
+      int np1 = 0;
+      if (ctx->comm) {
+        rc = mfem_comm_halo(ctx, p);
+        if (rc) return rc;
+      }
+      rc = mfem_spmv_launch(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1);
+      if (rc) return rc;
+      ++*spmv_out;
+      int np2 = G;
+      if (ctx->comm) {
+        rc = mfem_sum_partials(ctx, part1, np1, S + S_PAP);
+        if (rc) return rc;
+        MFEM_CHECK_LAUNCH();
+        rc = mfem_comm_allreduce(ctx, S + S_PAP, 1);
+        if (rc) return rc;
+        np1 = 0;
+      }
+      hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, (const d2_t*)p,
+                         (const d2_t*)Ap, (const d2_t*)dinv, (d2_t*)V.x, (d2_t*)r, S, F, part2);
+      MFEM_CHECK_LAUNCH();
+      if (ctx->comm) {
+        rc = mfem_sum_partials(ctx, part2, G, S + S_TMP0);
+        if (rc) return rc;
+        rc = mfem_sum_partials(ctx, part2 + G, G, S + S_TMP1);
+        if (rc) return rc;
+        MFEM_CHECK_LAUNCH();
+        rc = mfem_comm_allreduce(ctx, S + S_TMP0, 2);
+        if (rc) return rc;
+        np2 = 0;
+      }
+      hipLaunchKernelGGL(k_cg_pupdate, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part2, np2, (const d2_t*)r,
+                         (const d2_t*)dinv, (d2_t*)p, S, F);
+      hipLaunchKernelGGL(k_cg_advance, dim3(1), dim3(1), 0, ctx->stream, a, S, F);
+      MFEM_CHECK_LAUNCH();
+    }
+  }
+  rc = mfem_read_flags(ctx);
+  if (rc) return rc;
+  *iters_out = ctx->h_flags[F_ITER];
+  return MFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// iterative_Solve! wrapper
+// ------------------------------------------------------------------------------------------
+extern "C" int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int32_t count) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  MFEM_REQUIRE(count >= 0, "negative count");
+  ctx->shadow = shadow;
+  ctx->shadow_count = shadow ? count : 0;
+  return MFEM_OK;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
+                          const mfem_solve_options* o, mfem_solve_stats* stats) {
+  MFEM_REQUIRE(ctx && A && o, "null argument");
+  MFEM_REQUIRE(A->n == 0 || (vals && b && x_out), "null array");
+  MFEM_REQUIRE(o->maxiter >= 0 && o->max_pass >= 1, "maxiter >= 0 and max_pass >= 1 required");
+  MFEM_REQUIRE(o->method >= MFEM_SOLVER_CG && o->method <= MFEM_SOLVER_CGS2, "unknown method");
+  MFEM_REQUIRE(o->precond >= MFEM_PRECOND_NONE && o->precond <= MFEM_PRECOND_JACOBI_RIGHT_COLNORM, "unknown precond");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const int64_t n = A->n;
+  if (n == 0) return MFEM_OK;
+  const int s_param = o->l_or_s > 0 ? o->l_or_s : (o->method == MFEM_SOLVER_IDRS ? 4 : 2);
+  MFEM_REQUIRE(s_param <= MFEM_MAX_S, "l_or_s too large");
+  // x may carry ghost entries behind the owned rows (slab decomposition)
+  const int64_t ghosts = ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0;
+  const int64_t nv = (int64_t)align_up((size_t)(n + ghosts), 32);  // padded vector length (even => d2 kernels)
+  int nwork = 0;
+  switch (o->method) {
+    case MFEM_SOLVER_CG: nwork = 3; break;
+    case MFEM_SOLVER_BICGSTABL_GS: nwork = 2 * (s_param + 1) + 1; break;
+    case MFEM_SOLVER_IDRS: nwork = 3 * s_param + 4; break;
+    case MFEM_SOLVER_CGS2: nwork = 9; break;
+  }
+  const bool is_cg = o->method == MFEM_SOLVER_CG;
+  const bool jac = o->precond != MFEM_PRECOND_NONE;
+  const bool need_copy = jac && !is_cg && !o->scale_in_place;
+  // workspace: x, b (padded copies), d, dinv, work vectors, optional matrix copy
+  const size_t vec_bytes = (size_t)nv * sizeof(double);
+  size_t total = vec_bytes * (4 + nwork) + (need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0);
+  int rc = mfem_ws_reserve(ctx, total);
+  if (rc) return rc;
+  char* base = (char*)ctx->ws;
+  MFEM_CHECK_HIP(hipMemsetAsync(base, 0, vec_bytes * (4 + nwork), ctx->stream));
+  KrylovVecs V;
+  V.n = n;
+  V.nv = nv;
+  V.x = (double*)(base);
+  V.b = (double*)(base + vec_bytes);
+  V.d = (double*)(base + 2 * vec_bytes);
+  double* dinv_buf = (double*)(base + 3 * vec_bytes);
+  for (int i = 0; i < nwork; ++i) V.w[i] = (double*)(base + (4 + i) * vec_bytes);
+  V.nwork = nwork;
+  double* vals_work = vals;
+  if (need_copy) {
+    vals_work = (double*)(base + vec_bytes * (4 + nwork));
+    MFEM_CHECK_HIP(hipMemcpyAsync(vals_work, vals, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  MFEM_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  MFEM_CHECK_HIP(hipMemcpyAsync(V.b, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+
+  // Pr = Pr_func!(A)   (02_Preconditioner.jl:38, 103-120)
+  V.dinv = nullptr;
+  if (jac) {
+    if (o->precond == MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !is_cg) {
+      rc = mfem_jacobi2_by_column(ctx, A, vals_work, V.d);
+    } else {
+      rc = mfem_fill(ctx, n, 1.0, V.d);
+      if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
+    }
+    if (rc) return rc;
+    if (is_cg) {
+      hipLaunchKernelGGL(k_recip, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.d, dinv_buf);
+      MFEM_CHECK_LAUNCH();
+      V.dinv = dinv_buf;
+    } else {
+      if (ctx->comm) {  // ghost columns need their owners' d
+        rc = mfem_comm_halo(ctx, V.d);
+        if (rc) return rc;
+      }
+      rc = mfem_mat_div_jacobi(ctx, A, vals_work, V.d);
+      if (rc) return rc;
+    }
+  }
+
+  int64_t n_global = n;
+  if (ctx->comm) {
+    ctx->h_scalars[S_TMP0] = (double)n;
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->d_scalars + S_TMP0, ctx->h_scalars + S_TMP0, sizeof(double), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    rc = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
+    if (rc) return rc;
+    rc = mfem_read_scalars(ctx, S_TMP0, 1);
+    if (rc) return rc;
+    n_global = (int64_t)(ctx->h_scalars[S_TMP0] + 0.5);
+  }
+  const double n_inv = 1.0 / (double)n_global;
+
+  // initial residual for the report: b itself since x0 = 0 (:42-45)
+  rc = mfem_dot_device(ctx, n, V.b, V.b, ctx->d_scalars + S_TMP0);
+  if (rc) return rc;
+  if (ctx->comm) {
+    rc = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
+    if (rc) return rc;
+  }
+  rc = mfem_read_scalars(ctx, S_TMP0, 1);
+  if (rc) return rc;
+  const double res0 = sqrt(ctx->h_scalars[S_TMP0] * n_inv);
+
+  int pass = 1, total_iters = 0, spmvs = 0;
+  double res = res0;
+  const double tol_factor = 1.0;  // left preconditioners (the only users of tol_factor, :57-59) are out of scope
+  for (;;) {
+    int it = 0;
+    switch (o->method) {
+      case MFEM_SOLVER_CG:
+        rc = cg_solve_pass(ctx, A, vals_work, V, o, tol_factor * o->converge_tol, n_global, &it, &spmvs);
+        break;
+      case MFEM_SOLVER_BICGSTABL_GS:
+        rc = mfem_bicgstabl_pass(ctx, A, vals_work, V, o, s_param, tol_factor * o->converge_tol, n_global, &it, &spmvs);
+        break;
+      case MFEM_SOLVER_IDRS:
+        rc = mfem_idrs_pass(ctx, A, vals_work, V, o, s_param, tol_factor * o->converge_tol, n_global, &it, &spmvs);
+        break;
+      default:
+        mfem_set_error("solver method %d is not implemented yet", o->method);
+        rc = MFEM_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    total_iters += it;
+    // true residual between passes (:53-55)
+    rc = mfem_true_residual(ctx, A, vals_work, V.b, V.x, V.w[0], nv, ctx->d_scalars + S_RR);
+    if (rc) return rc;
+    ++spmvs;
+    rc = mfem_read_scalars(ctx, S_RR, 1);
+    if (rc) return rc;
+    res = sqrt(ctx->h_scalars[S_RR] * n_inv);
+    if (o->fixed_iterations || res < o->converge_tol || pass >= o->max_pass) break;
+    ++pass;
+  }
+  // return Pr(x) = x ./ d  (:75, 93-96)
+  if (jac && !is_cg) {
+    hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.x, V.d, x_out);
+    MFEM_CHECK_LAUNCH();
+  } else {
+    MFEM_CHECK_HIP(hipMemcpyAsync(x_out, V.x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  MFEM_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  MFEM_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  MFEM_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (stats) {
+    stats->passes = pass;
+    stats->iterations = total_iters;
+    stats->final_res = res;
+    stats->initial_res = res0;
+    stats->solve_ms = ms;
+    stats->converged = res < o->converge_tol ? 1 : 0;
+    stats->spmv_count = spmvs;
+  }
+  return MFEM_OK;
+}

@@ -1,0 +1,322 @@
+// CSR SpMV for gfx950: replaces CUSPARSE mv!('N') behind mul! (reference misc/04_GPU_Utils.jl:131).
+//
+// Design (HBM-bound: 12 B per nonzero + 16 B per row):
+//   * a workgroup owns a run of R consecutive rows whose nonzeros fit an LDS tile (CAP doubles);
+//     R is a power of two chosen from the pattern's longest row, so FEM matrices with 27 / 81 /
+//     125-wide rows all take this path;
+//   * phase 1 streams val/col of the tile with 16-byte (val) + 8-byte (col) per-lane loads that
+//     are contiguous across the whole workgroup -- coalescing does not depend on row length --
+//     gathers x[col] (L2-resident: a hex mesh row touches 3 node planes) and parks the products
+//     in LDS;
+//   * phase 2 gives each row 256/R lanes that sum the row's products from LDS and combine with a
+//     sub-wave shuffle; y is written once, coalesced;
+//   * an optional fused dot product (w . y) is reduced per workgroup into ctx partials so the
+//     Krylov loop needs no separate dot kernel or host sync for p.Ap;
+//   * the grid is persistent (<= MFEM_MAX_PARTIALS workgroups, grid-stride over row tiles) and
+//     the tile -> workgroup map is XCD-aware: workgroups with equal blockIdx % 8 share an XCD L2
+//     (dispatch is round-robin over the 8 XCDs), so each XCD walks its own contiguous eighth of
+//     the rows and x planes are fetched into one L2 instead of eight.
+#include "common.h"
+
+#define SPMV_CAP 4096        // doubles of product tile (32 KiB LDS) -> 4-5 workgroups per CU
+#define SPMV_UNROLL 4
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
+
+template <typename RP>
+__global__ void k_max_row_nnz(int64_t n, const RP* __restrict__ rowptr, int32_t* __restrict__ out) {
+  int m = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    int len = (int)(rowptr[r + 1] - rowptr[r]);
+    m = len > m ? len : m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_down(m, off, MFEM_WAVE);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__device__ __forceinline__ int64_t tile_of(int64_t it, int64_t ntiles, int xcd_aware) {
+  // it = logical sequence number of this workgroup's next tile in dispatch order
+  if (!xcd_aware) return it;
+  const int64_t xcd = it & 7, local = it >> 3;
+  const int64_t per = (ntiles + 7) >> 3;
+  return xcd * per + local;  // may be >= ntiles for the last XCD: caller skips
+}
+
+template <typename RP, bool VEC>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
+    int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
+    double beta, int base, int R, int tpr_log2, int64_t ntiles, int64_t ntiles_padded, int xcd_aware,
+    const double* __restrict__ dotw, double* __restrict__ partials) {
+  __shared__ double prod[SPMV_CAP + 4];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2;
+  double dot_acc = 0.0;
+
+  for (int64_t it = blockIdx.x; it < ntiles_padded; it += gridDim.x) {
+    const int64_t tile = tile_of(it, ntiles, xcd_aware);
+    if (tile >= ntiles) continue;  // uniform per workgroup
+    const int64_t r0 = tile * R;
+    const int64_t r1 = (r0 + R < n) ? r0 + R : n;
+    const int64_t s = (int64_t)rowptr[r0] - base;
+    const int64_t e = (int64_t)rowptr[r1] - base;
+
+    if (VEC) {
+      const int64_t sa = s & ~(int64_t)1;  // 16-byte aligned start (vals/col bases are 16-B aligned)
+      const int cnt = (int)(e - sa);
+      for (int i0 = 2 * tid; i0 < cnt; i0 += 2 * MFEM_BLOCK * SPMV_UNROLL) {
+        d2_t v[SPMV_UNROLL];
+        i2_t c[SPMV_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; ++u) {
+          const int i = i0 + u * 2 * MFEM_BLOCK;
+          v[u] = (d2_t){0.0, 0.0};
+          c[u] = (i2_t){base, base};
+          if (i < cnt) {
+            if (sa + i + 1 < nnz) {
+              v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(vals + sa + i));
+              c[u] = __builtin_nontemporal_load(reinterpret_cast<const i2_t*>(col + sa + i));
+            } else {  // last odd entry of the whole matrix
+              v[u].x = vals[sa + i];
+              c[u].x = col[sa + i];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; ++u) {
+          const int i = i0 + u * 2 * MFEM_BLOCK;
+          if (i < cnt) {
+            // entry i+1 may belong to the next tile (i + 1 == cnt): its product is never read
+            const double x0 = x[c[u].x - base];
+            const double x1 = (i + 1 < cnt) ? x[c[u].y - base] : 0.0;
+            *reinterpret_cast<d2_t*>(&prod[i]) = (d2_t){v[u].x * x0, v[u].y * x1};
+          }
+        }
+      }
+      __syncthreads();
+      // phase 2: tpr lanes per row
+      const int g = tid & (tpr - 1);
+      for (int64_t r = r0 + (tid >> tpr_log2); r < r1; r += (MFEM_BLOCK >> tpr_log2)) {
+        const int lo = (int)((int64_t)rowptr[r] - base - sa);
+        const int hi = (int)((int64_t)rowptr[r + 1] - base - sa);
+        double sum = 0.0;
+        for (int j = lo + g; j < hi; j += tpr) sum += prod[j];
+        for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
+        if (g == 0) {
+          double yv = alpha * sum;
+          if (beta != 0.0) yv += beta * y[r];
+          y[r] = yv;
+          if (dotw) dot_acc += yv * dotw[r];
+        }
+      }
+      __syncthreads();
+    } else {
+      const int cnt = (int)(e - s);
+      for (int i0 = tid; i0 < cnt; i0 += MFEM_BLOCK * SPMV_UNROLL) {
+        double v[SPMV_UNROLL];
+        int c[SPMV_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; ++u) {
+          const int i = i0 + u * MFEM_BLOCK;
+          v[u] = 0.0;
+          c[u] = base;
+          if (i < cnt) {
+            v[u] = vals[s + i];
+            c[u] = col[s + i];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; ++u) {
+          const int i = i0 + u * MFEM_BLOCK;
+          if (i < cnt) prod[i] = v[u] * x[c[u] - base];
+        }
+      }
+      __syncthreads();
+      const int g = tid & (tpr - 1);
+      for (int64_t r = r0 + (tid >> tpr_log2); r < r1; r += (MFEM_BLOCK >> tpr_log2)) {
+        const int lo = (int)((int64_t)rowptr[r] - base - s);
+        const int hi = (int)((int64_t)rowptr[r + 1] - base - s);
+        double sum = 0.0;
+        for (int j = lo + g; j < hi; j += tpr) sum += prod[j];
+        for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
+        if (g == 0) {
+          double yv = alpha * sum;
+          if (beta != 0.0) yv += beta * y[r];
+          y[r] = yv;
+          if (dotw) dot_acc += yv * dotw[r];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (tid == 0) partials[blockIdx.x] = b;
+  }
+}
+
+// Fallback for patterns whose longest row does not fit the LDS tile: one wave per row.
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
+    int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ vals,
+    const double* __restrict__ x, double* __restrict__ y, double alpha, double beta, int base,
+    const double* __restrict__ dotw, double* __restrict__ partials) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double dot_acc = 0.0;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+    double sum = 0.0;
+    for (int64_t j = lo + lane; j < hi; j += 64) sum += vals[j] * x[col[j] - base];
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) {
+      double yv = alpha * sum;
+      if (beta != 0.0) yv += beta * y[r];
+      y[r] = yv;
+      if (dotw) dot_acc += yv * dotw[r];
+    }
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = b;
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static int g_spmv_xcd_aware = 1;
+static int g_spmv_grid_mult = 5;  // workgroups per CU of the persistent grid
+
+extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
+  g_spmv_xcd_aware = xcd_aware;
+  if (grid_mult > 0) g_spmv_grid_mult = grid_mult;
+  return MFEM_OK;
+}
+
+int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  int32_t* d_max = ctx->d_flags + 8;
+  MFEM_CHECK_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
+  const int grid = mfem_grid_for(A->n, MFEM_BLOCK, 4096);
+  if (A->n > 0) {
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_max_row_nnz<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
+                         (const int64_t*)A->rowptr, d_max);
+    else
+      hipLaunchKernelGGL(k_max_row_nnz<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
+                         (const int32_t*)A->rowptr, d_max);
+    MFEM_CHECK_LAUNCH();
+  }
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 8, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  A->max_row_nnz = ctx->h_flags[8];
+  int R = 0;
+  if (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP - 2) {
+    R = MFEM_BLOCK;
+    while (R > 1 && (int64_t)R * A->max_row_nnz > SPMV_CAP - 2) R >>= 1;
+    if ((int64_t)R * A->max_row_nnz > SPMV_CAP - 2) R = 0;
+  }
+  A->rows_per_block = R;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
+                               const int32_t* colidx, int index_base, mfem_csr* out) {
+  MFEM_REQUIRE(ctx && out, "null argument");
+  MFEM_REQUIRE(n >= 0 && nnz >= 0, "negative size");
+  MFEM_REQUIRE(rowptr_bits == 32 || rowptr_bits == 64, "rowptr_bits must be 32 or 64");
+  MFEM_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  MFEM_REQUIRE(n == 0 || (rowptr && (nnz == 0 || colidx)), "null pattern arrays");
+  MFEM_REQUIRE(rowptr_bits == 64 || nnz < ((int64_t)1 << 31), "nnz >= 2^31 needs 64-bit rowptr");
+  mfem_csr_s* A = new mfem_csr_s();
+  memset(A, 0, sizeof(*A));
+  A->ctx = ctx;
+  A->n = n;
+  A->nnz = nnz;
+  A->rowptr = rowptr;
+  A->rowptr_bits = rowptr_bits;
+  A->colidx = colidx;
+  A->index_base = index_base;
+  int rc = mfem_csr_plan(ctx, A);
+  if (rc != MFEM_OK) {
+    delete A;
+    return rc;
+  }
+  *out = A;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_csr_destroy(mfem_csr A) {
+  if (!A) return MFEM_OK;
+  if (A->owned_rowptr) hipFree(A->owned_rowptr);
+  if (A->owned_colidx) hipFree(A->owned_colidx);
+  delete A;
+  return MFEM_OK;
+}
+
+extern "C" const int64_t* mfem_csr_rowptr64(mfem_csr A) {
+  return (A && A->rowptr_bits == 64) ? (const int64_t*)A->rowptr : nullptr;
+}
+extern "C" const int32_t* mfem_csr_colidx(mfem_csr A) { return A ? A->colidx : nullptr; }
+extern "C" int64_t mfem_csr_nnz(mfem_csr A) { return A ? A->nnz : -1; }
+extern "C" int64_t mfem_csr_n(mfem_csr A) { return A ? A->n : -1; }
+
+// Internal launcher: y = alpha*A*x + beta*y, optionally partial sums of (dotw . y) into `partials`
+// (*n_partials receives the number written).
+int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
+                     double alpha, double beta, const double* dotw, double* partials, int* n_partials) {
+  if (n_partials) *n_partials = 0;
+  if (A->n == 0) return MFEM_OK;
+  const int base = A->index_base;
+  if (A->rows_per_block > 0) {
+    const int R = A->rows_per_block;
+    int tpr_log2 = 0;
+    while ((MFEM_BLOCK >> (tpr_log2 + 1)) >= R) ++tpr_log2;  // tpr = 256 / R
+    const int64_t ntiles = (A->n + R - 1) / R;
+    int cap = ctx->num_cus * g_spmv_grid_mult;
+    if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+    cap &= ~7;  // multiple of 8 so blockIdx % 8 is a stable XCD label along the grid-stride loop
+    if (cap < 8) cap = 8;
+    int grid = (int)(ntiles < cap ? ((ntiles + 7) & ~(int64_t)7) : cap);
+    const int xcd = g_spmv_xcd_aware && ntiles >= 64;
+    const int64_t per = (ntiles + 7) >> 3;
+    const int64_t ntiles_padded = xcd ? per * 8 : ntiles;
+    const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
+#define LAUNCH_LDS(RP, VEC)                                                                               \
+  hipLaunchKernelGGL((k_spmv_lds<RP, VEC>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->nnz,   \
+                     (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2, ntiles, \
+                     ntiles_padded, xcd, dotw, partials)
+    if (A->rowptr_bits == 64) {
+      if (vec) LAUNCH_LDS(int64_t, true); else LAUNCH_LDS(int64_t, false);
+    } else {
+      if (vec) LAUNCH_LDS(int32_t, true); else LAUNCH_LDS(int32_t, false);
+    }
+#undef LAUNCH_LDS
+    MFEM_CHECK_LAUNCH();
+    if (n_partials && partials) *n_partials = grid;
+  } else {
+    const int grid = mfem_grid_for(A->n, 4, ctx->num_cus * 8 < MFEM_MAX_PARTIALS ? ctx->num_cus * 8 : MFEM_MAX_PARTIALS);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_spmv_wave_per_row<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
+                         (const int64_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials);
+    else
+      hipLaunchKernelGGL(k_spmv_wave_per_row<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
+                         (const int32_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials);
+    MFEM_CHECK_LAUNCH();
+    if (n_partials && partials) *n_partials = grid;
+  }
+  return MFEM_OK;
+}
+
+extern "C" int mfem_spmv_csr(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y,
+                             double alpha, double beta) {
+  MFEM_REQUIRE(ctx && A, "null handle");
+  MFEM_REQUIRE(A->n == 0 || (x && y && (A->nnz == 0 || vals)), "null vector");
+  return mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr);
+}

@@ -1,0 +1,25 @@
+// Entry points declared in include/metafem_mi355x.h whose kernels are not written yet: they fail
+// loudly (MFEM_ERR_UNSUPPORTED + message) instead of falling back to anything.
+#include "krylov.h"
+
+#define UNSUP(name)                                   \
+  do {                                                \
+    mfem_set_error(name " is not implemented yet");   \
+    return MFEM_ERR_UNSUPPORTED;                      \
+  } while (0)
+
+extern "C" int mfem_brick_assemble_elasticity(mfem_context, mfem_brick, mfem_csr, const mfem_elasticity_params*, double*) { UNSUP("mfem_brick_assemble_elasticity"); }
+extern "C" int mfem_brick_residual_elasticity(mfem_context, mfem_brick, const mfem_elasticity_params*, const double*, double*) { UNSUP("mfem_brick_residual_elasticity"); }
+extern "C" int mfem_op_var(mfem_context, const mfem_op_layout*, const double*, int32_t, int64_t, const int32_t*, const double*, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_var"); }
+extern "C" int mfem_op_kval(mfem_context, const mfem_op_layout*, const double*, int32_t, int32_t, const double*, const int32_t*, int64_t, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_kval"); }
+extern "C" int mfem_op_res(mfem_context, const mfem_op_layout*, const double*, int32_t, const double*, int64_t, const int32_t*, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_res"); }
+extern "C" int mfem_comm_unique_id(void*) { UNSUP("mfem_comm_unique_id"); }
+extern "C" int mfem_comm_create(mfem_context, int32_t, int32_t, const void*, mfem_comm*) { UNSUP("mfem_comm_create"); }
+extern "C" int mfem_comm_destroy(mfem_comm) { return MFEM_OK; }
+extern "C" int mfem_context_set_comm(mfem_context, mfem_comm, int64_t, int32_t) { UNSUP("mfem_context_set_comm"); }
+extern "C" int mfem_allreduce_sum(mfem_context, double*, int32_t) { UNSUP("mfem_allreduce_sum"); }
+extern "C" int mfem_halo_exchange(mfem_context, double*) { UNSUP("mfem_halo_exchange"); }
+int mfem_comm_allreduce(mfem_context_s*, double*, int) { UNSUP("comm allreduce"); }
+int mfem_comm_halo(mfem_context_s*, double*) { UNSUP("comm halo"); }
+int mfem_bicgstabl_pass(mfem_context_s*, mfem_csr_s*, const double*, KrylovVecs&, const mfem_solve_options*, int, double, int64_t, int*, int*) { UNSUP("bicgstabl_GS"); }
+int mfem_idrs_pass(mfem_context_s*, mfem_csr_s*, const double*, KrylovVecs&, const mfem_solve_options*, int, double, int64_t, int*, int*) { UNSUP("idrs"); }

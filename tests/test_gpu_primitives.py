@@ -1,0 +1,140 @@
+"""GPU parity: S1 primitives (SpMV / dot / axpby / rand / Jacobi kernels) against the oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_csr(n, avg, rng, ragged=True, empty_rows=True):
+    lens = rng.integers(0 if empty_rows else 1, 2 * avg, size=n) if ragged else np.full(n, avg)
+    lens = np.minimum(lens, n)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]) if rowptr[-1] else np.zeros(0, int)
+    vals = rng.standard_normal(rowptr[-1])
+    return rowptr, cols.astype(np.int32), vals
+
+
+@pytest.mark.parametrize("n,avg,bits,base", [(1, 1, 32, 0), (37, 3, 32, 1), (1000, 27, 64, 0), (5000, 27, 32, 1),
+                                             (3000, 81, 64, 1), (257, 130, 32, 0)])
+def test_spmv_matches_oracle(mf, n, avg, bits, base):
+    import torch
+    from oracle import solvers
+
+    rng = np.random.default_rng(n * 7 + avg)
+    rowptr, cols, vals = _random_csr(n, avg, rng)
+    x = rng.standard_normal(n)
+    y0 = rng.standard_normal(n)
+    A_or = solvers.csr(rowptr, cols, vals, n)
+    rp_t = torch.tensor(rowptr + base, dtype=torch.int64 if bits == 64 else torch.int32, device="cuda")
+    A = mf.FEM_SpMat_CSR(rp_t, torch.tensor(cols + base, dtype=torch.int32, device="cuda"), n, index_base=base)
+    v_t, x_t = torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda")
+    scale = np.abs(A_or).dot(np.abs(x)) + np.abs(y0) + 1e-300
+    for alpha, beta in [(1.0, 0.0), (-1.0, 0.0), (0.5, 2.0)]:
+        y_t = torch.tensor(y0, device="cuda")
+        mf.mul_(y_t, A, v_t, x_t, alpha, beta)
+        ref = solvers.mul(y0.copy(), A_or, x, alpha, beta)
+        assert np.max(np.abs(y_t.cpu().numpy() - ref) / scale) < 1e-14
+
+
+def test_spmv_long_rows_fallback(mf):
+    """Rows longer than the LDS tile take the wave-per-row path."""
+    import torch
+    from oracle import solvers
+
+    rng = np.random.default_rng(5)
+    n = 6000
+    lens = np.full(n, 3)
+    lens[17] = 5000
+    lens[n - 1] = 4500
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]).astype(np.int32)
+    vals = rng.standard_normal(rowptr[-1])
+    x = rng.standard_normal(n)
+    A = mf.FEM_SpMat_CSR(torch.tensor(rowptr, device="cuda"), torch.tensor(cols, device="cuda"), n)
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    mf.mul_(y, A, torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda"))
+    ref = solvers.csr(rowptr, cols, vals, n) @ x
+    scale = np.abs(solvers.csr(rowptr, cols, np.abs(vals), n) @ np.abs(x)) + 1e-300
+    assert np.max(np.abs(y.cpu().numpy() - ref) / scale) < 1e-14
+
+
+def test_spmv_unaligned_values_pointer(mf):
+    """A values array that is not 16-byte aligned must take the scalar path, not fault."""
+    import torch
+    from oracle import solvers
+
+    rng = np.random.default_rng(11)
+    rowptr, cols, vals = _random_csr(2000, 27, rng)
+    x = rng.standard_normal(2000)
+    buf = torch.zeros(vals.size + 1, dtype=torch.float64, device="cuda")
+    buf[1:] = torch.tensor(vals, device="cuda")
+    A = mf.FEM_SpMat_CSR(torch.tensor(rowptr, device="cuda"), torch.tensor(cols, device="cuda"), 2000)
+    y = torch.zeros(2000, dtype=torch.float64, device="cuda")
+    mf.mul_(y, A, buf[1:], torch.tensor(x, device="cuda"))
+    ref = solvers.csr(rowptr, cols, vals, 2000) @ x
+    assert np.allclose(y.cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1 << 20, (1 << 20) + 3])
+def test_dot_nrm2_axpby(mf, n):
+    import torch
+
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    xt, yt = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    assert abs(mf.dot(xt, yt) - x @ y) <= 1e-13 * (np.abs(x) @ np.abs(y))
+    assert abs(mf.nrm2(xt) - np.linalg.norm(x)) <= 1e-13 * np.linalg.norm(x)
+    mf.axpby_(0.3, xt, -1.7, yt)
+    assert np.allclose(yt.cpu().numpy(), 0.3 * x - 1.7 * y, rtol=1e-15, atol=1e-15)
+    # odd-offset (8-byte aligned only) views
+    if n > 2:
+        a, b = xt[1:], yt[1:]
+        ref = x[1:] @ (0.3 * x - 1.7 * y)[1:]
+        assert abs(mf.dot(a, b) - ref) <= 1e-12 * max(1.0, abs(ref))
+
+
+def test_rand_is_bitwise_the_oracle_generator(mf):
+    from oracle import solvers
+
+    for seed, stream, n in [(0x5EED, 0, 1000), (1, 3, 4097), (2 ** 63 + 5, 7, 64)]:
+        got = mf.FEM_rand(n, seed, stream).cpu().numpy()
+        assert np.array_equal(got, solvers.fem_rand(seed, stream, n))
+        assert got.min() >= 0.0 and got.max() < 1.0
+
+
+def test_jacobi_kernels(mf):
+    import torch
+    from oracle import solvers
+
+    rng = np.random.default_rng(3)
+    n = 3000
+    rowptr, cols, vals = _random_csr(n, 20, rng)
+    # make sure most rows have a diagonal
+    M = solvers.csr(rowptr, cols, vals, n) + sp.diags(rng.standard_normal(n) + 3.0)
+    M = M.tocsr()
+    M.sort_indices()
+    # knock the diagonal out of a few rows: those keep d = 1 (02_Preconditioner.jl:110,122-130)
+    A = mf.FEM_SpMat_CSR(torch.tensor(M.indptr.astype(np.int32), device="cuda"),
+                         torch.tensor(M.indices.astype(np.int32), device="cuda"), n)
+    v = torch.tensor(M.data, device="cuda")
+    assert np.array_equal(mf.jacobi_by_diagonal(A, v).cpu().numpy(), solvers.jacobi_by_diagonal(M))
+    col = np.sqrt(np.asarray(M.multiply(M).sum(axis=0)).ravel())
+    row = np.sqrt(np.asarray(M.multiply(M).sum(axis=1)).ravel())
+    assert np.allclose(mf.jacobi2_by_column(A, v).cpu().numpy(), col, rtol=1e-13)
+    assert np.allclose(mf.jacobi_by_row(A, v).cpu().numpy(), row, rtol=1e-13)
+    d = solvers.jacobi_by_diagonal(M)
+    mf.mat_div_jacobi_(A, v, torch.tensor(d, device="cuda"))
+    assert np.array_equal(v.cpu().numpy(), M.data / d[M.indices])
+
+
+def test_errors_are_reported_not_thrown(mf):
+    import torch
+
+    with pytest.raises(mf.MetaFEMError):
+        mf.FEM_SpMat_CSR(torch.zeros(3, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"),
+                         2, index_base=5)
+    with pytest.raises(mf.MetaFEMError):
+        mf.dot(torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda"))  # float32 tensors

@@ -1,0 +1,127 @@
+"""GPU parity: structured hex-8 thermal path (pattern, K, residual, CG solve, Newton step) vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K_COND, H, TENV, SRC = 0.6, 25.0, 293.15, 1600.0  # examples/thermal_conduction/3D_Script.jl:21-25,56
+
+
+def _oracle_domain(x, n, itg_order=3, distort=None, faces=None):
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, itg_order)
+    msh = om.lattice_mesh(x, n, disc)
+    if distort is not None:
+        msh.coords[:] = distort(msh.coords)
+    fac = om.boundary_facets_structured(x, n, 3)
+    if faces is not None:
+        fac = fac.select(np.isin(fac.element_eindex, faces))
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, K_COND), [(fac, problems.thermal_convection(H, TENV))])
+    od.controlpoints["s"] = np.full(msh.ncp, SRC)
+    return od
+
+
+def _distort(c):
+    out = c.copy()
+    out[:, 0] += 0.03 * np.sin(3 * c[:, 1]) * np.cos(2 * c[:, 2])
+    out[:, 1] += 0.02 * np.sin(2 * c[:, 0] + c[:, 2])
+    out[:, 2] += 0.025 * c[:, 0] * c[:, 1]
+    return out
+
+
+@pytest.mark.parametrize("n", [(1, 1, 1), (2, 1, 3), (4, 4, 4), (7, 5, 3)])
+def test_pattern_is_the_oracle_csr(mf, n):
+    x = (1.0, 2.0, 0.5)
+    od = _oracle_domain(x, n)
+    A = mf.make_Brick(x, n).pattern(1)
+    assert A.n == od.pattern.n and A.nnz == od.pattern.nnz
+    assert np.array_equal(A.rowptr.cpu().numpy(), od.pattern.rowptr)
+    assert np.array_equal(A.colidx.cpu().numpy(), od.pattern.colidx)
+
+
+@pytest.mark.parametrize("n,itg,distorted,faces", [((1, 1, 1), 3, False, None), ((4, 4, 4), 3, False, None),
+                                                   ((5, 3, 6), 3, True, None), ((3, 4, 2), 5, True, [0, 2, 4]),
+                                                   ((6, 6, 6), 1, False, [5]), ((9, 8, 7), 7, True, None)])
+def test_thermal_matrix_and_residual(mf, n, itg, distorted, faces):
+    import torch
+
+    x = (1.0, 1.5, 0.75)
+    od = _oracle_domain(x, n, itg, _distort if distorted else None, faces)
+    od.update_time()
+    od.K_linear_func()
+    rng = np.random.default_rng(1)
+    od.x_star[:] = 300.0 + 20.0 * rng.standard_normal(od.basicfield_size)
+    od.K_nonlinear_func()
+
+    brick = mf.make_Brick(x, n, 1, itg)
+    if distorted:
+        for d in range(3):
+            brick.coords_view(d).copy_(torch.tensor(od.mesh.coords[:, d], device="cuda"))
+    bits = 0x3F if faces is None else sum(1 << f for f in faces)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, bits).cpu().numpy()
+    assert np.max(np.abs(K - od.K_linear)) <= 1e-13 * np.max(np.abs(od.K_linear))
+    s = torch.full((brick.ncp,), SRC, dtype=torch.float64, device="cuda")
+    R = brick.residual_thermal(torch.tensor(od.x_star, device="cuda"), K_COND, H, TENV, bits, s=s).cpu().numpy()
+    assert np.max(np.abs(R - od.residue)) <= 1e-12 * np.max(np.abs(od.residue))
+
+
+def test_cg_solve_matches_direct_solve(mf):
+    """Linear problem: 1e-10 relative solution parity (BASELINE.json north_star) vs solver_LU_CPU == spsolve."""
+    import torch
+    from oracle import solvers
+
+    x, n = (1.0, 1.0, 1.0), (12, 10, 8)
+    od = _oracle_domain(x, n)
+    od.converge_tol = 1e-9
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    od.update_one_step()
+
+    dom = mf.ThermalDomain(mf.make_Brick(x, n), K_COND, H, TENV)
+    dom.s.fill_(SRC)
+    dom.converge_tol = 1e-9
+    stats = []
+
+    def solver(gf):
+        dx, st = mf.iterative_Solve(gf.A, gf.K_total, gf.residue, 1e-13, Sv_func=mf.cg_, maxiter=2000, max_pass=3)
+        stats.append(st)
+        return dx
+
+    dom.linear_solver = solver
+    hist = dom.update_OneStep()
+    got = dom.x.cpu().numpy()
+    assert len(hist) == 2 and hist[1] < 1e-9  # linear: one solve, two residual evaluations
+    assert stats[0].converged == 1
+    assert np.max(np.abs(got - od.x)) <= 1e-10 * np.max(np.abs(od.x))
+
+
+def test_cg_iterates_match_oracle_cg(mf):
+    """Same algorithm, same arithmetic order up to reductions: iteration counts and iterates agree."""
+    import torch
+    from oracle import solvers
+
+    od = _oracle_domain((1.0, 1.0, 1.0), (8, 8, 8))
+    od.update_time()
+    od.K_linear_func()
+    od.update_x_star()
+    od.K_nonlinear_func()
+    info = solvers.SolveInfo()
+    ref = solvers.solve_cg_jacobi(od.pattern.rowptr, od.pattern.colidx, od.K_total, od.residue, 1e-8, 1000, info=info)
+    A = mf.FEM_SpMat_CSR(torch.tensor(od.pattern.rowptr, device="cuda"), torch.tensor(od.pattern.colidx, device="cuda"),
+                         od.pattern.n)
+    dx, st = mf.iterative_Solve(A, torch.tensor(od.K_total, device="cuda"), torch.tensor(od.residue, device="cuda"), 1e-8,
+                                Sv_func=mf.cg_, maxiter=1000, max_pass=1, check_every=7)
+    assert st.iterations == info.iters
+    assert np.max(np.abs(dx.cpu().numpy() - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
+def test_cg_fixed_iterations_mode(mf):
+    import torch
+
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (16, 16, 16))
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    b = torch.ones(A.n, dtype=torch.float64, device="cuda")
+    _, st = mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=37, max_pass=1, fixed_iterations=True)
+    assert st.iterations == 37 and st.passes == 1 and st.spmv_count == 37 + 2
