@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X MetaFEM backend (contract: see task prompt / DESIGN.md §Measurement).
+
+Metric (BASELINE.json): DOF-updates/s = n_DOF x Krylov iterations / (t_assembly + t_solve) on 3-D thermal
+conduction, linear hex-8.  One *step* = one pass of the hot path over one synthetic mesh:
+    K_linear_func  (fused hex-8 assembly of K, CSR order)           mfem_brick_assemble_thermal
+  + K_nonlinear_func (matrix-free residual R at x* = 0)              mfem_brick_residual_thermal
+  + `--iters` Jacobi-PCG iterations on K delta = R (fixed count)     mfem_solve(fixed_iterations)
+N = 1 workload: configs[1] of BASELINE.json, 256^3 elements (16 974 593 DOF, nnz 454 756 609).
+N > 1: weak scaling -- every rank owns a 256-element-thick slab of a (256 N) x 256 x 256 mesh (slab
+decomposition along i, one ghost node plane per neighbour, RCCL all-reduce of the CG scalars).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_COND, H, TENV, SRC = 0.6, 25.0, 293.15, 1600.0  # examples/thermal_conduction/3D_Script.jl:21-25,56
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(n_cpu: int, iters: int):
+    """Reference algorithm restated in C/OpenMP (oracle/c), timed on this box's host cores."""
+    import numpy as np  # noqa: F401
+    from oracle import cport
+
+    prob = cport.CThermal((n_cpu, n_cpu, n_cpu), k=K_COND, h=H, Tenv=TENV, src=SRC).setup()
+    prob.timed_step(2)  # warm caches / page in
+    ta, ts = prob.timed_step(iters)
+    cores = cport.lib().orc_num_threads()
+    return {
+        "value": prob.mesh.ncp * iters / (ta + ts),
+        "unit": "DOF-updates/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"hex-8 {n_cpu}^3 thermal ({prob.mesh.ncp} DOF): 1 step = term-by-term assembly "
+                  f"({ta:.2f} s) + {iters} Jacobi-CG iterations ({ts:.2f} s); C/OpenMP restatement of the "
+                  f"reference algorithm (oracle/c/oracle.c), {cores} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=256, help="elements per side of the per-GPU mesh")
+    ap.add_argument("--iters", type=int, default=200, help="CG iterations per step")
+    ap.add_argument("--cpu-n", type=int, default=160, help="elements per side of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch
+
+    import metafem_jl_amd as mf
+    from metafem_jl_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    ctx = mf.Context(local_rank)
+    N = args.n
+    nx_global = N * world
+    brick = mf.Brick((float(world), 1.0, 1.0), (nx_global, N, N), 1, 3, ctx=ctx)
+    if world > 1:
+        from metafem_jl_amd import parallel
+
+        plo, phi = parallel.slab_planes(nx_global + 1, world, rank)
+        brick.set_slab(plo, phi)
+        comm = parallel.SlabComm(ctx, brick, rank, world, n_fields=1)
+    A = brick.pattern(1)
+    n_local = A.n
+    dev = f"cuda:{local_rank}"
+    K = torch.empty(A.nnz, dtype=torch.float64, device=dev)
+    xlen = n_local + (2 * brick.m[1] * brick.m[2] if world > 1 else 0)
+    x_star = torch.zeros(xlen, dtype=torch.float64, device=dev)
+    s = torch.full((xlen,), SRC, dtype=torch.float64, device=dev)
+    R = torch.empty(n_local, dtype=torch.float64, device=dev)
+
+    n_global = (nx_global + 1) * (N + 1) * (N + 1)
+
+    def step():
+        brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES, out=K)
+        brick.residual_thermal(x_star, K_COND, H, TENV, mf.ALL_FACES, s=s, out=R)
+        _, st = mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, Pr_func=mf.Pr_Jacobi_, maxiter=args.iters,
+                                   max_pass=1, fixed_iterations=True)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import ctypes as C
+
+    _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 1))
+    tot, cnt = C.c_double(), C.c_int64()
+    _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
+    barrier()
+    t0 = time.perf_counter()
+    solve_ms = 0.0
+    iters_done = 0
+    for _ in range(args.steps):
+        st = step()
+        solve_ms += st.solve_ms
+        iters_done += st.iterations
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
+    _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 0))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        assert iters_done == args.iters * args.steps, (iters_done, args.iters, args.steps)
+        value = n_global * args.iters * args.steps / elapsed
+        spmv_ms = tot.value / max(cnt.value, 1)
+        spmv_bytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8  # val 8 + col 4 per nz; x, y 8 each per row; i64 rowptr
+        achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(tpath) and N == 256:
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "DOF-updates/sec (assembly+CG iter) on 3D hex thermal conduction",
+            "value": value,
+            "unit": "DOF-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"3D thermal conduction, linear hex-8, {nx_global}x{N}x{N} structured mesh "
+                            f"(make_Brick), Robin on 6 faces: fused assembly (K + R) + {args.iters} Jacobi-CG iterations per step",
+                "n_dof": n_global, "nnz_per_gpu": A.nnz, "cg_iters_per_step": args.iters,
+                "parallelism": "single GPU" if world == 1 else f"slab decomposition x{world} (RCCL halo + all-reduce)",
+                "solve_ms_per_step": solve_ms / args.steps,
+            },
+            "roofline": {
+                "kernel": "k_spmv_lds (CSR SpMV, i64 rowptr / i32 col / f64 val)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms, "launches": cnt.value,
+            },
+        }
+        if world == 1 and args.cpu_n > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_iters)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,14 @@ int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double* vals, dou
 int mfem_jacobi_by_row(mfem_context ctx, mfem_csr A, const double* vals, double* d);        /* :170-177 */
 int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double* d);       /* :141-148, in place */
 
+/* Tuning hook (benchmarks/profiling only): XCD-aware tile map on/off, persistent workgroups per CU. */
+int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
+
+/* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
+ * read: total device ms and launch count since the last reset. */
+int mfem_prof_spmv_enable(mfem_context ctx, int on);
+int mfem_prof_spmv_read(mfem_context ctx, double* total_ms /* [host] */, int64_t* launches /* [host] */, int reset);
+
 /* ---- S1: the linear solver seam  fem_domain.linear_solver(globalfield) -------------------- */
 typedef enum {
   MFEM_SOLVER_CG = 0,          /* added (not in the reference, F5); symmetric definite K only */

@@ -78,6 +78,9 @@ SIGNATURES = {
     "mfem_jacobi2_by_column": (c_int, [P, P, P, P]),
     "mfem_jacobi_by_row": (c_int, [P, P, P, P]),
     "mfem_mat_div_jacobi": (c_int, [P, P, P, P]),
+    "mfem_debug_set_spmv": (c_int, [c_int, c_int]),
+    "mfem_prof_spmv_enable": (c_int, [P, c_int]),
+    "mfem_prof_spmv_read": (c_int, [P, C.POINTER(c_double), C.POINTER(c_int64), c_int]),
     "mfem_solve": (c_int, [P, P, P, P, P, C.POINTER(SolveOptions), C.POINTER(SolveStats)]),
     "mfem_solve_set_shadow": (c_int, [P, P, c_int32]),
     "mfem_brick_create": (c_int, [P, c_int32, c_int32, c_int32, c_double, c_double, c_double, c_int32, c_int32,

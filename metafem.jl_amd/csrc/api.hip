@@ -66,9 +66,53 @@ extern "C" int mfem_context_destroy(mfem_context ctx) {
   hipFree(ctx->d_flags);
   hipHostFree(ctx->h_flags);
   if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->prof_ev) {
+    for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i) hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
+  }
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   delete ctx;
+  return MFEM_OK;
+}
+
+int mfem_prof_flush(mfem_context_s* ctx) {
+  if (ctx->prof_used == 0) return MFEM_OK;
+  MFEM_CHECK_HIP(hipEventSynchronize(ctx->prof_ev[2 * ctx->prof_used - 1]));
+  for (int k = 0; k < ctx->prof_used; ++k) {
+    float ms = 0.f;
+    MFEM_CHECK_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]));
+    ctx->prof_ms += ms;
+  }
+  ctx->prof_count += ctx->prof_used;
+  ctx->prof_used = 0;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_prof_spmv_enable(mfem_context ctx, int on) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  if (on && !ctx->prof_ev) {
+    ctx->prof_ev = new hipEvent_t[2 * MFEM_PROF_PAIRS];
+    for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i) MFEM_CHECK_HIP(hipEventCreate(&ctx->prof_ev[i]));
+  }
+  if (!on) {
+    int rc = mfem_prof_flush(ctx);
+    if (rc) return rc;
+  }
+  ctx->prof_on = on ? 1 : 0;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_prof_spmv_read(mfem_context ctx, double* total_ms, int64_t* launches, int reset) {
+  MFEM_REQUIRE(ctx && total_ms && launches, "null argument");
+  int rc = mfem_prof_flush(ctx);
+  if (rc) return rc;
+  *total_ms = ctx->prof_ms;
+  *launches = ctx->prof_count;
+  if (reset) {
+    ctx->prof_ms = 0.0;
+    ctx->prof_count = 0;
+  }
   return MFEM_OK;
 }
 

@@ -55,7 +55,15 @@ struct mfem_context_s {
   int64_t halo_plane_len;
   int32_t halo_fields;
   hipEvent_t ev0, ev1;
+  // optional per-launch timing of the SpMV kernel (bench.py roofline): event pairs on ctx->stream
+  int prof_on;
+  int prof_used;
+  hipEvent_t* prof_ev;      // [2 * MFEM_PROF_PAIRS]
+  double prof_ms;
+  int64_t prof_count;
 };
+#define MFEM_PROF_PAIRS 1024
+int mfem_prof_flush(mfem_context_s* ctx);
 
 struct mfem_csr_s {
   mfem_context_s* ctx;

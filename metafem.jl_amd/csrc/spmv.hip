@@ -18,8 +18,9 @@
 //     the rows and x planes are fetched into one L2 instead of eight.
 #include "common.h"
 
-#define SPMV_CAP 4096        // doubles of product tile (32 KiB LDS) -> 4-5 workgroups per CU
-#define SPMV_UNROLL 4
+// Tile variants: CAP doubles of LDS product tile, UNROLL = 16-byte loads in flight per lane and batch.
+// 4032 doubles = 31.5 KiB -> 5 workgroups per CU; 2016 -> 8 (wave-limited).
+#define SPMV_CAP_MAX 4032
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
@@ -47,7 +48,7 @@ __device__ __forceinline__ int64_t tile_of(int64_t it, int64_t ntiles, int xcd_a
   return xcd * per + local;  // may be >= ntiles for the last XCD: caller skips
 }
 
-template <typename RP, bool VEC>
+template <typename RP, bool VEC, int SPMV_CAP, int SPMV_UNROLL>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
@@ -70,6 +71,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
     if (VEC) {
       const int64_t sa = s & ~(int64_t)1;  // 16-byte aligned start (vals/col bases are 16-B aligned)
       const int cnt = (int)(e - sa);
+      // phase-2 row bounds of this lane's first row: issued now so the HBM latency hides under phase 1
+      const int64_t rmine = r0 + (tid >> tpr_log2);
+      int lo_pre = 0, hi_pre = 0;
+      if (rmine < r1) {
+        lo_pre = (int)((int64_t)rowptr[rmine] - base - sa);
+        hi_pre = (int)((int64_t)rowptr[rmine + 1] - base - sa);
+      }
       for (int i0 = 2 * tid; i0 < cnt; i0 += 2 * MFEM_BLOCK * SPMV_UNROLL) {
         d2_t v[SPMV_UNROLL];
         i2_t c[SPMV_UNROLL];
@@ -102,9 +110,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
       __syncthreads();
       // phase 2: tpr lanes per row
       const int g = tid & (tpr - 1);
-      for (int64_t r = r0 + (tid >> tpr_log2); r < r1; r += (MFEM_BLOCK >> tpr_log2)) {
-        const int lo = (int)((int64_t)rowptr[r] - base - sa);
-        const int hi = (int)((int64_t)rowptr[r + 1] - base - sa);
+      for (int64_t r = rmine; r < r1; r += (MFEM_BLOCK >> tpr_log2)) {
+        const int lo = (r == rmine) ? lo_pre : (int)((int64_t)rowptr[r] - base - sa);
+        const int hi = (r == rmine) ? hi_pre : (int)((int64_t)rowptr[r + 1] - base - sa);
         double sum = 0.0;
         for (int j = lo + g; j < hi; j += tpr) sum += prod[j];
         for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
@@ -191,11 +199,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 }
 
 // ---- host side ----------------------------------------------------------------------------
-static int g_spmv_xcd_aware = 1;
-static int g_spmv_grid_mult = 5;  // workgroups per CU of the persistent grid
+// Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
+// beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
+static int g_spmv_xcd_aware = 0;
+static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
+static int g_spmv_variant = 1;    // 0: CAP 4032 x4, 1: CAP 4032 x8, 2: CAP 2016 x4, 3: CAP 2016 x2
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
-  g_spmv_xcd_aware = xcd_aware;
+  g_spmv_xcd_aware = xcd_aware & 1;
+  g_spmv_variant = (xcd_aware >> 4) & 3;
   if (grid_mult > 0) g_spmv_grid_mult = grid_mult;
   return MFEM_OK;
 }
@@ -216,13 +228,7 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 8, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->max_row_nnz = ctx->h_flags[8];
-  int R = 0;
-  if (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP - 2) {
-    R = MFEM_BLOCK;
-    while (R > 1 && (int64_t)R * A->max_row_nnz > SPMV_CAP - 2) R >>= 1;
-    if ((int64_t)R * A->max_row_nnz > SPMV_CAP - 2) R = 0;
-  }
-  A->rows_per_block = R;
+  A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
   return MFEM_OK;
 }
 
@@ -269,13 +275,34 @@ extern "C" int64_t mfem_csr_n(mfem_csr A) { return A ? A->n : -1; }
 
 // Internal launcher: y = alpha*A*x + beta*y, optionally partial sums of (dotw . y) into `partials`
 // (*n_partials receives the number written).
+static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
+                             double alpha, double beta, const double* dotw, double* partials, int* n_partials);
+
 int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
                      double alpha, double beta, const double* dotw, double* partials, int* n_partials) {
+  if (!ctx->prof_on) return spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials);
+  if (ctx->prof_used == MFEM_PROF_PAIRS) {
+    int rc = mfem_prof_flush(ctx);
+    if (rc) return rc;
+  }
+  const int k = ctx->prof_used;
+  MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k], ctx->stream));
+  int rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials);
+  if (rc) return rc;
+  MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k + 1], ctx->stream));
+  ctx->prof_used = k + 1;
+  return MFEM_OK;
+}
+
+static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
+                             double alpha, double beta, const double* dotw, double* partials, int* n_partials) {
   if (n_partials) *n_partials = 0;
   if (A->n == 0) return MFEM_OK;
   const int base = A->index_base;
+  const int cap_doubles = (g_spmv_variant >= 2 && A->max_row_nnz <= 2016 - 2) ? 2016 : 4032;
   if (A->rows_per_block > 0) {
-    const int R = A->rows_per_block;
+    int R = MFEM_BLOCK;
+    while (R > 1 && (int64_t)R * A->max_row_nnz > cap_doubles - 2) R >>= 1;
     int tpr_log2 = 0;
     while ((MFEM_BLOCK >> (tpr_log2 + 1)) >= R) ++tpr_log2;  // tpr = 256 / R
     const int64_t ntiles = (A->n + R - 1) / R;
@@ -288,15 +315,20 @@ int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, con
     const int64_t per = (ntiles + 7) >> 3;
     const int64_t ntiles_padded = xcd ? per * 8 : ntiles;
     const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
-#define LAUNCH_LDS(RP, VEC)                                                                               \
-  hipLaunchKernelGGL((k_spmv_lds<RP, VEC>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->nnz,   \
-                     (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2, ntiles, \
-                     ntiles_padded, xcd, dotw, partials)
-    if (A->rowptr_bits == 64) {
-      if (vec) LAUNCH_LDS(int64_t, true); else LAUNCH_LDS(int64_t, false);
-    } else {
-      if (vec) LAUNCH_LDS(int32_t, true); else LAUNCH_LDS(int32_t, false);
-    }
+#define LAUNCH_LDS(RP, VEC, CAP, UNR)                                                                      \
+  hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,  \
+                     A->nnz, (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2,  \
+                     ntiles, ntiles_padded, xcd, dotw, partials)
+#define LAUNCH_VARIANT(RP)                                                   \
+  do {                                                                       \
+    if (!vec) LAUNCH_LDS(RP, false, 4032, 4);                                \
+    else if (cap_doubles == 2016 && g_spmv_variant == 2) LAUNCH_LDS(RP, true, 2016, 4); \
+    else if (cap_doubles == 2016) LAUNCH_LDS(RP, true, 2016, 2);             \
+    else if (g_spmv_variant == 1) LAUNCH_LDS(RP, true, 4032, 8);             \
+    else LAUNCH_LDS(RP, true, 4032, 4);                                      \
+  } while (0)
+    if (A->rowptr_bits == 64) LAUNCH_VARIANT(int64_t); else LAUNCH_VARIANT(int32_t);
+#undef LAUNCH_VARIANT
 #undef LAUNCH_LDS
     MFEM_CHECK_LAUNCH();
     if (n_partials && partials) *n_partials = grid;
