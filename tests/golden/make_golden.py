@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/ (run in the BUILD container, where
+/root/reference is mounted; the GPU box has neither /root/reference nor a need to rerun this).
+
+1. ceramic_strip_T.npz -- DATA taken from the reference's own committed result file
+   examples/thermal_conduction/2D_Ceramic_Strip.vtk (POINTS 2521 + SCALARS T): coordinates and
+   temperatures only, no source text.  This is the pin of the oracle.
+2. oracle_*.npz -- outputs of the oracle itself on small meshes (K, R, x, reference tables) used as
+   regression vectors by the CPU suite and as fixed-size golden vectors by the GPU suite.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import fem, mesh as om, problems, reference_element as re_, solvers, vtk  # noqa: E402
+
+REF = "/root/reference"
+
+
+def strip():
+    pts, sc = vtk.read_vtk_points_scalars(os.path.join(REF, "examples/thermal_conduction/2D_Ceramic_Strip.vtk"))
+    np.savez_compressed(os.path.join(HERE, "ceramic_strip_T.npz"), xy=pts[:, :2], T=sc["T"],
+                        featool_y=np.array([0.0001, 0.001, 0.002, 0.003, 0.004, 0.005, 0.006, 0.007, 0.008, 0.009, 0.0099]),
+                        featool_T=np.array([1086.84, 1086, 1082.73, 1077.63, 1070.24, 1060.78, 1048.83, 1034.63, 1017.81,
+                                            998.843, 979.249]))  # examples/thermal_conduction/2D_Script.jl:95-96
+
+
+def tables():
+    out = {}
+    for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
+                       "hex27": (3, "CUBE", 2, 1, 5, "Lagrange"), "hex20": (3, "CUBE", 2, 1, 5, "Serendipity")}.items():
+        d = re_.initialize_classical_element(*args[:5], itp_type=args[5])
+        out[f"{name}_ref"] = d.ref_itp_vals
+        out[f"{name}_w"] = d.itg_weight
+        out[f"{name}_pos"] = d.itp_pos
+        for f, (r, t) in enumerate(zip(d.bdy_ref_itp_vals, d.bdy_tangent_directions)):
+            out[f"{name}_bref{f}"] = r
+            out[f"{name}_btan{f}"] = t
+    np.savez_compressed(os.path.join(HERE, "oracle_tables.npz"), **out)
+
+
+def thermal_hex8():
+    x, n = (1.0, 1.5, 0.75), (4, 4, 4)
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh(x, n, disc)
+    fac = om.boundary_facets_structured(x, n, 3)
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6), [(fac, problems.thermal_convection(25.0, 293.15))])
+    od.controlpoints["s"] = np.full(msh.ncp, 1600.0)
+    od.converge_tol = 1e-9
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    od.update_time()
+    od.K_linear_func()
+    od.update_x_star()
+    od.K_nonlinear_func()
+    K, R0 = od.K_linear.copy(), od.residue.copy()
+    od.t = 0.0
+    od.update_one_step()
+    np.savez_compressed(os.path.join(HERE, "oracle_thermal_hex8_4x4x4.npz"), x=np.array(x), n=np.array(n), rowptr=od.pattern.rowptr,
+                        colidx=od.pattern.colidx, K=K, R0=R0, T=od.x)
+
+
+def elasticity_hex8():
+    x, n = (3.0, 1.0, 1.0), (3, 2, 2)
+    E, nu = 1.0, 0.3
+    lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh(x, n, disc)
+    fac = om.boundary_facets_structured(x, n, 3)
+    fixed = fac.select(fac.element_eindex == 4)  # x = 0
+    load = fac.select(fac.element_eindex == 3)  # y = L
+    sig = [[0.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]
+    od = fem.FEMDomain(msh, disc, 3, problems.elasticity_domain(3, lam, mu),
+                       [(fixed, problems.elasticity_penalty(3, 1000.0 * E)), (load, problems.elasticity_traction(3, sig))])
+    od.converge_tol = 1e-10
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    od.update_time()
+    od.K_linear_func()
+    od.update_x_star()
+    od.K_nonlinear_func()
+    K, R0 = od.K_linear.copy(), od.residue.copy()
+    od.t = 0.0
+    od.update_one_step()
+    np.savez_compressed(os.path.join(HERE, "oracle_elasticity_hex8_3x2x2.npz"), x=np.array(x), n=np.array(n), lam=lam, mu=mu,
+                        tau=1000.0 * E, rowptr=od.pattern.rowptr, colidx=od.pattern.colidx, K=K, R0=R0, d=od.x)
+
+
+def thermal_hex27():
+    x, n = (1.0, 1.0, 1.0), (2, 2, 2)
+    disc = re_.initialize_classical_element(3, "CUBE", 2, 1, 5)
+    msh = om.lattice_mesh(x, n, disc)
+    fac = om.boundary_facets_structured(x, n, 3)
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6), [(fac, problems.thermal_convection(25.0, 293.15))])
+    od.controlpoints["s"] = np.full(msh.ncp, 1600.0)
+    od.converge_tol = 1e-9
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    od.update_time()
+    od.K_linear_func()
+    od.update_x_star()
+    od.K_nonlinear_func()
+    K, R0 = od.K_linear.copy(), od.residue.copy()
+    od.t = 0.0
+    od.update_one_step()
+    np.savez_compressed(os.path.join(HERE, "oracle_thermal_hex27_2x2x2.npz"), x=np.array(x), n=np.array(n), rowptr=od.pattern.rowptr,
+                        colidx=od.pattern.colidx, K=K, R0=R0, T=od.x)
+
+
+if __name__ == "__main__":
+    if os.path.isdir(REF):
+        strip()
+    tables()
+    thermal_hex8()
+    elasticity_hex8()
+    thermal_hex27()
+    print("fixtures written to", HERE)
