@@ -33,11 +33,11 @@ extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) 
   c->stream = (hipStream_t)stream;
   c->num_cus = prop.multiProcessorCount;
   MFEM_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(double) * MFEM_MAX_PARTIALS * 8));
-  MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * 256));
-  MFEM_CHECK_HIP(hipHostMalloc(&c->h_scalars, sizeof(double) * 256));
+  MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * MFEM_NSCALARS));
+  MFEM_CHECK_HIP(hipHostMalloc(&c->h_scalars, sizeof(double) * MFEM_NSCALARS));
   MFEM_CHECK_HIP(hipMalloc(&c->d_flags, sizeof(int32_t) * 16));
   MFEM_CHECK_HIP(hipHostMalloc(&c->h_flags, sizeof(int32_t) * 16));
-  MFEM_CHECK_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * 256, c->stream));
+  MFEM_CHECK_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * MFEM_NSCALARS, c->stream));
   MFEM_CHECK_HIP(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 16, c->stream));
   MFEM_CHECK_HIP(hipEventCreate(&c->ev0));
   MFEM_CHECK_HIP(hipEventCreate(&c->ev1));

@@ -5,7 +5,8 @@
 int mfem_vec_grid(mfem_context_s* ctx, int64_t n);
 int mfem_dot_device(mfem_context_s* ctx, int64_t n, const double* x, const double* y, double* d_out);
 int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
-                     double alpha, double beta, const double* dotw, double* partials, int* n_partials);
+                     double alpha, double beta, const double* dotw, double* partials, int* n_partials,
+                     const int32_t* done_flag = nullptr);
 int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* d, int mode);
 int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count);
 int mfem_comm_halo(mfem_context_s* ctx, double* x_local);

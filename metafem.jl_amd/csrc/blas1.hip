@@ -109,12 +109,12 @@ extern "C" int mfem_dot(mfem_context ctx, int64_t n, const double* x, const doub
     return MFEM_OK;
   }
   MFEM_REQUIRE(x && y, "null vector");
-  int rc = mfem_dot_device(ctx, n, x, y, ctx->d_scalars + 255);
+  int rc = mfem_dot_device(ctx, n, x, y, ctx->d_scalars + MFEM_NSCALARS - 1);
   if (rc) return rc;
-  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + 255, ctx->d_scalars + 255, sizeof(double), hipMemcpyDeviceToHost,
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + MFEM_NSCALARS - 1, ctx->d_scalars + MFEM_NSCALARS - 1, sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  *out = ctx->h_scalars[255];
+  *out = ctx->h_scalars[MFEM_NSCALARS - 1];
   return MFEM_OK;
 }
 

@@ -9,7 +9,8 @@
 
 #define MFEM_WAVE 64
 #define MFEM_BLOCK 256
-#define MFEM_MAX_PARTIALS 4096  // upper bound on per-launch partial sums of a fused reduction
+#define MFEM_MAX_PARTIALS 4096
+#define MFEM_NSCALARS 4096       // device-resident Krylov scalars (doubles)  // upper bound on per-launch partial sums of a fused reduction
 
 void mfem_set_error(const char* fmt, ...);
 

@@ -268,7 +268,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         rc = mfem_comm_halo(ctx, p);
         if (rc) return rc;
       }
-      rc = mfem_spmv_launch(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1);
+      rc = mfem_spmv_launch(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1, F);
       if (rc) return rc;
       ++*spmv_out;
       int np2 = G;

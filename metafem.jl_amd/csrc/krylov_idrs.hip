@@ -1,0 +1,220 @@
+// idrs!  -- bi-orthogonal IDR(s) (reference linear_solver/04_IDRs.jl:26-95, modify_Omega :1-8; default s = 4,
+// the examples pass s = 8 / 20).  This is the reference's default Sv_func! (02_Preconditioner.jl:32).
+//
+// The reference solves the small lower-triangular system M c = f on the HOST every inner step (:47) and
+// reads every dot back; here M, f, c, omega, alpha, beta live in ctx->d_scalars, the triangular solve is a
+// one-thread device kernel, and the vector work of an inner step is fused:
+//   V = sum c_i G_i ; Q = sum c_i U_i ; V = r - V ; U_k = Q + omega V     -> ONE kernel (ki_combine)
+//   G_k -= alpha G_i ; U_k -= alpha U_i                                    -> ONE kernel (kk_axpy2)
+//   x += beta U_k ; r -= beta G_k                                          -> ONE kernel (kk_axpy2)
+//   M[k:s,k] = P[k:s]' G_k and the s dots f = P' r                          -> batched multi-dot passes
+// The stop test after every inner step (:79) is evaluated on device into the DONE flag.
+#include "krylov_kernels.h"
+
+#define IS_MAXS MFEM_MAX_S
+enum {
+  I_OMEGA = S_SOLVER + 0, I_ALPHA, I_BETA, I_SP0, I_SP1, I_SP2,
+  I_DOT = S_SOLVER + 8,          // batched dot scratch [KK_MAX_DOTS]
+  I_F = I_DOT + KK_MAX_DOTS,     // f [IS_MAXS]
+  I_C = I_F + IS_MAXS,           // c [IS_MAXS]
+  I_M = I_C + IS_MAXS            // M [IS_MAXS * IS_MAXS], M[i + IS_MAXS*j]
+};
+
+struct IdArgs {
+  double n_inv, tol;
+  int32_t maxiter, fixed, s;
+};
+
+__global__ void ki_init(IdArgs a, double* __restrict__ S, int32_t* __restrict__ F) {
+  for (int j = 0; j < a.s; ++j)
+    for (int i = 0; i < a.s; ++i) S[I_M + i + IS_MAXS * j] = (i == j) ? 1.0 : 0.0;  // M = I (:38)
+  for (int i = 0; i < a.s; ++i) S[I_F + i] = S[I_C + i] = 0.0;
+  S[I_OMEGA] = 1.0;
+  F[F_ITER] = 1;
+  const bool conv = !a.fixed && sqrt(S[S_RR] * a.n_inv) <= a.tol;
+  F[F_DONE] = conv ? 1 : 0;
+  if (conv) F[F_ITER] = 0;
+}
+// f[first + t] = dots[t]
+__global__ void ki_store(int dst, int m, double* __restrict__ S, const int32_t* __restrict__ F) {
+  if (F[F_DONE]) return;
+  for (int t = 0; t < m; ++t) S[dst + t] = S[I_DOT + t];
+}
+// c = LowerTriangular(M[k:s, k:s]) \ f[k:s]   (:47)
+__global__ void ki_solve_c(int k, int s, double* __restrict__ S, const int32_t* __restrict__ F) {
+  if (F[F_DONE]) return;
+  for (int i = k; i < s; ++i) {
+    double v = S[I_F + i];
+    for (int j = k; j < i; ++j) v -= S[I_M + i + IS_MAXS * j] * S[I_C + j - k];
+    S[I_C + i - k] = v / S[I_M + i + IS_MAXS * i];
+  }
+}
+// alpha = dot(P[i], G[k]) / M[i,i]   (:62)
+__global__ void ki_alpha(int i, double* __restrict__ S, const int32_t* __restrict__ F) {
+  if (F[F_DONE]) return;
+  S[I_ALPHA] = S[I_DOT] / S[I_M + i + IS_MAXS * i];
+}
+// beta = f[k] / M[k,k]   (:73)
+__global__ void ki_beta(int k, double* __restrict__ S, const int32_t* __restrict__ F) {
+  if (F[F_DONE]) return;
+  S[I_BETA] = S[I_F + k] / S[I_M + k + IS_MAXS * k];
+}
+// stop test after the inner step, then f[k+1:] -= beta*M[k+1:,k]; iter += 1   (:79-81); S[I_DOT] = r.r
+__global__ void ki_step_end(IdArgs a, int k, double* __restrict__ S, int32_t* __restrict__ F) {
+  if (F[F_DONE]) return;
+  S[S_RR] = S[I_DOT];
+  const int iter = F[F_ITER];
+  if ((!a.fixed && sqrt(S[I_DOT] * a.n_inv) <= a.tol) || iter >= a.maxiter) {
+    F[F_DONE] = 1;
+    return;
+  }
+  if (k >= 0) {
+    const double beta = S[I_BETA];
+    for (int i = k + 1; i < a.s; ++i) S[I_F + i] -= beta * S[I_M + i + IS_MAXS * k];
+  }
+  F[F_ITER] = iter + 1;
+}
+// omega = modify_Omega(Ar, r) (:1-8); dots: [0] Ar.Ar  [1] r.r  [2] Ar.r
+__global__ void ki_omega(double* __restrict__ S, const int32_t* __restrict__ F) {
+  if (F[F_DONE]) return;
+  const double angle = 0.70710678118654752440;  // sqrt(2)/2
+  const double n1 = sqrt(S[I_DOT]), n2 = sqrt(S[I_DOT + 1]), d = S[I_DOT + 2];
+  const double rho = fabs(d / (n1 * n2));
+  const double omega = d / (n1 * n1);
+  S[I_OMEGA] = (rho < angle) ? omega * angle / rho : omega;
+}
+
+struct CombineList {
+  const d2_t* G[IS_MAXS];
+  const d2_t* U[IS_MAXS];
+  int m;  // number of terms (s - k)
+};
+// U_k = sum_t c[t] U[k+t] + omega * (r - sum_t c[t] G[k+t])      (:49-58)
+__global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList L, const d2_t* __restrict__ r, d2_t* Uk,
+                                                          const double* __restrict__ S, const int32_t* __restrict__ F) {
+  __shared__ double c[IS_MAXS];
+  if (F[F_DONE]) return;
+  if (threadIdx.x < L.m) c[threadIdx.x] = S[I_C + threadIdx.x];
+  __syncthreads();
+  const double omega = S[I_OMEGA];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+    d2_t v = c[0] * L.G[0][i];
+    d2_t q = c[0] * L.U[0][i];
+    for (int t = 1; t < L.m; ++t) {
+      v += c[t] * L.G[t][i];
+      q += c[t] * L.U[t][i];
+    }
+    v = r[i] - v;
+    Uk[i] = q + omega * v;
+  }
+}
+
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+#define K1(kernel, ...)                                                       \
+  do {                                                                        \
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(1), 0, ctx->stream, __VA_ARGS__); \
+    MFEM_CHECK_LAUNCH();                                                      \
+  } while (0)
+
+int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V, const mfem_solve_options* o,
+                   int s, double tol, int64_t n_global, int* iters_out, int* spmv_out) {
+  MFEM_REQUIRE(s >= 1 && s <= IS_MAXS, "idrs: 1 <= s <= 32 supported");
+  double* S = ctx->d_scalars;
+  int32_t* F = ctx->d_flags;
+  const int64_t nv = V.nv;
+  double* r = V.w[0];
+  double* Ar = V.w[1];
+  double** P = V.w + 4;
+  double** U = V.w + 4 + s;
+  double** G = V.w + 4 + 2 * s;
+  KK k{ctx, nv, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
+  IdArgs a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations, s};
+
+  RC(mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR));  // :27-29
+  ++*spmv_out;
+  K1(ki_init, a, S, F);
+  for (int i = 0; i < s; ++i) {  // P = FEM_rand (:35)
+    if (ctx->shadow && ctx->shadow_count >= s)
+      MFEM_CHECK_HIP(hipMemcpyAsync(P[i], ctx->shadow + (int64_t)i * V.n, sizeof(double) * V.n, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+      RC(mfem_rand(ctx, V.n, o->seed, (uint32_t)i, P[i]));
+    MFEM_CHECK_HIP(hipMemsetAsync(U[i], 0, sizeof(double) * nv, ctx->stream));
+    MFEM_CHECK_HIP(hipMemsetAsync(G[i], 0, sizeof(double) * nv, ctx->stream));
+  }
+  MFEM_CHECK_HIP(hipMemsetAsync(Ar, 0, sizeof(double) * nv, ctx->stream));
+
+  const int check = o->check_every > 0 ? o->check_every : 32;
+  int since_poll = 0, host_iter = 1;
+  RC(mfem_read_flags(ctx));
+  while (!ctx->h_flags[F_DONE]) {
+    // f = P' r  (:43-45)
+    for (int i0 = 0; i0 < s; i0 += KK_MAX_DOTS) {
+      DotList L;
+      L.m = (s - i0) < KK_MAX_DOTS ? (s - i0) : KK_MAX_DOTS;
+      for (int t = 0; t < L.m; ++t) {
+        L.x[t] = (const d2_t*)P[i0 + t];
+        L.y[t] = (const d2_t*)r;
+      }
+      RC(k.dots(L, I_DOT));
+      K1(ki_store, I_F + i0, L.m, S, F);
+    }
+    for (int kk = 0; kk < s; ++kk) {
+      K1(ki_solve_c, kk, s, S, F);
+      CombineList C;
+      C.m = s - kk;
+      for (int t = 0; t < C.m; ++t) {
+        C.G[t] = (const d2_t*)G[kk + t];
+        C.U[t] = (const d2_t*)U[kk + t];
+      }
+      hipLaunchKernelGGL(ki_combine, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, (const d2_t*)r, (d2_t*)U[kk], S, F);
+      MFEM_CHECK_LAUNCH();
+      RC(k.spmv(A, vals, U[kk], G[kk], spmv_out));  // :59
+      for (int i = 0; i < kk; ++i) {                 // bi-orthogonalise (:62-66)
+        RC(k.dot1(P[i], G[kk], I_DOT));
+        K1(ki_alpha, i, S, F);
+        RC(k.axpy2(coef_dev(I_ALPHA, -1.0), G[i], G[kk], coef_dev(I_ALPHA, -1.0), U[i], U[kk]));
+      }
+      for (int i0 = kk; i0 < s; i0 += KK_MAX_DOTS) {  // M[k:s, k] = P[k:s]' G[k]  (:69-71)
+        DotList L;
+        L.m = (s - i0) < KK_MAX_DOTS ? (s - i0) : KK_MAX_DOTS;
+        for (int t = 0; t < L.m; ++t) {
+          L.x[t] = (const d2_t*)P[i0 + t];
+          L.y[t] = (const d2_t*)G[kk];
+        }
+        RC(k.dots(L, I_DOT));
+        K1(ki_store, I_M + i0 + IS_MAXS * kk, L.m, S, F);
+      }
+      K1(ki_beta, kk, S, F);
+      RC(k.axpy2(coef_dev(I_BETA), U[kk], V.x, coef_dev(I_BETA, -1.0), G[kk], r));  // :75-76
+      RC(k.dot1(r, r, I_DOT));
+      K1(ki_step_end, a, kk, S, F);
+      ++host_iter;
+    }
+    // r in G_j+1  (:85-93)
+    RC(k.spmv(A, vals, r, Ar, spmv_out));
+    DotList L;
+    L.m = 3;
+    L.x[0] = (const d2_t*)Ar; L.y[0] = (const d2_t*)Ar;
+    L.x[1] = (const d2_t*)r;  L.y[1] = (const d2_t*)r;
+    L.x[2] = (const d2_t*)Ar; L.y[2] = (const d2_t*)r;
+    RC(k.dots(L, I_DOT));
+    K1(ki_omega, S, F);
+    RC(k.axpy2(coef_dev(I_OMEGA), r, V.x, coef_dev(I_OMEGA, -1.0), Ar, r));  // x += omega r ; r -= omega Ar
+    RC(k.dot1(r, r, I_DOT));
+    K1(ki_step_end, a, -1, S, F);
+    ++host_iter;
+    since_poll += s + 1;
+    if (since_poll >= check || host_iter >= o->maxiter) {
+      RC(mfem_read_flags(ctx));
+      since_poll = 0;
+    }
+  }
+  RC(mfem_read_flags(ctx));
+  *iters_out = ctx->h_flags[F_ITER];
+  return MFEM_OK;
+}

@@ -1,0 +1,148 @@
+// Building blocks shared by the BiCGStab(l) and IDR(s) drivers: vector updates whose coefficients
+// live in device memory, multi-dot reductions, and the DONE-flag guard.  All vectors are padded to an
+// even length and 16-byte aligned (see mfem_solve), so every kernel streams d2 (16 B / lane).
+#pragma once
+#include "krylov.h"
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// coefficient = sign * S[slot]  (slot >= 0)   or   the immediate `value` (slot < 0)
+struct Coef {
+  double value;
+  double sign;
+  int slot;
+};
+static inline Coef coef_imm(double v) { return Coef{v, 1.0, -1}; }
+static inline Coef coef_dev(int slot, double sign = 1.0) { return Coef{0.0, sign, slot}; }
+__device__ __forceinline__ double coef_get(const Coef& c, const double* __restrict__ S) {
+  return c.slot >= 0 ? c.sign * S[c.slot] : c.value;
+}
+
+// y = a*x + b*y
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_axpby(int64_t n2, Coef a, const d2_t* __restrict__ x, Coef b,
+                                                               d2_t* __restrict__ y, const double* __restrict__ S,
+                                                               const int32_t* __restrict__ flags) {
+  if (flags[F_DONE]) return;
+  const double ca = coef_get(a, S), cb = coef_get(b, S);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) y[i] = ca * x[i] + cb * y[i];
+}
+
+// z = a*x + b*y   (z may alias x or y)
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_lin2(int64_t n2, Coef a, const d2_t* x, Coef b, const d2_t* y,
+                                                              d2_t* z, const double* __restrict__ S,
+                                                              const int32_t* __restrict__ flags) {
+  if (flags[F_DONE]) return;
+  const double ca = coef_get(a, S), cb = coef_get(b, S);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) z[i] = ca * x[i] + cb * y[i];
+}
+
+// Two updates in one pass, in this order per element:  y1 += a1*x1 ;  y2 += a2*x2   (x1 may alias y2)
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_axpy2(int64_t n2, Coef a1, const d2_t* x1, d2_t* y1, Coef a2,
+                                                               const d2_t* x2, d2_t* y2,
+                                                               const double* __restrict__ S,
+                                                               const int32_t* __restrict__ flags) {
+  if (flags[F_DONE]) return;
+  const double c1 = coef_get(a1, S), c2 = coef_get(a2, S);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+    y1[i] = y1[i] + c1 * x1[i];
+    y2[i] = y2[i] + c2 * x2[i];
+  }
+}
+
+#define KK_MAX_DOTS 8
+struct DotList {
+  const d2_t* x[KK_MAX_DOTS];
+  const d2_t* y[KK_MAX_DOTS];
+  int m;
+};
+
+// partials[k*G + blockIdx] = partial of x_k . y_k  for k < m   (one pass over memory per distinct vector read)
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n2, DotList L, double* __restrict__ partials,
+                                                                   const int32_t* __restrict__ flags) {
+  __shared__ double red[4];
+  if (flags[F_DONE]) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc[KK_MAX_DOTS];
+#pragma unroll
+  for (int k = 0; k < KK_MAX_DOTS; ++k) acc[k] = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+#pragma unroll
+    for (int k = 0; k < KK_MAX_DOTS; ++k)
+      if (k < L.m) {
+        const d2_t a = L.x[k][i], b = L.y[k][i];
+        acc[k] += a.x * b.x + a.y * b.y;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < KK_MAX_DOTS; ++k)
+    if (k < L.m) {
+      const double s = block_reduce_sum(acc[k], red);
+      if (threadIdx.x == 0) partials[(int64_t)k * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// Single workgroup: S[out + k] = sum(partials[k*G .. (k+1)*G)) for k < m
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_fold(const double* __restrict__ partials, int G, int m, int out,
+                                                              double* __restrict__ S, const int32_t* __restrict__ flags) {
+  __shared__ double red[4];
+  if (flags[F_DONE]) return;
+  for (int k = 0; k < m; ++k) {
+    const double v = reduce_partials_bcast(partials + (int64_t)k * G, G, red);
+    if (threadIdx.x == 0) S[out + k] = v;
+    __syncthreads();
+  }
+}
+
+struct KK {
+  mfem_context_s* ctx;
+  int64_t nv;
+  int G;
+  double* S;
+  int32_t* F;
+  hipStream_t st;
+
+  int axpby(Coef a, const double* x, Coef b, double* y) const {
+    hipLaunchKernelGGL(kk_axpby, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, a, (const d2_t*)x, b, (d2_t*)y, S, F);
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  }
+  int lin2(Coef a, const double* x, Coef b, const double* y, double* z) const {
+    hipLaunchKernelGGL(kk_lin2, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, a, (const d2_t*)x, b, (const d2_t*)y, (d2_t*)z, S, F);
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  }
+  int axpy2(Coef a1, const double* x1, double* y1, Coef a2, const double* x2, double* y2) const {
+    hipLaunchKernelGGL(kk_axpy2, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, a1, (const d2_t*)x1, (d2_t*)y1, a2,
+                       (const d2_t*)x2, (d2_t*)y2, S, F);
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  }
+  // S[out + k] = x_k . y_k (all-reduced over ranks when a communicator is attached)
+  int dots(const DotList& L, int out) const {
+    double* part = ctx->d_partials;
+    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, L, part, F);
+    MFEM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kk_fold, dim3(1), dim3(MFEM_BLOCK), 0, st, part, G, L.m, out, S, F);
+    MFEM_CHECK_LAUNCH();
+    if (ctx->comm) return mfem_comm_allreduce(ctx, S + out, L.m);
+    return MFEM_OK;
+  }
+  int dot1(const double* x, const double* y, int out) const {
+    DotList L;
+    L.m = 1;
+    L.x[0] = (const d2_t*)x;
+    L.y[0] = (const d2_t*)y;
+    return dots(L, out);
+  }
+  int spmv(mfem_csr_s* A, const double* vals, double* x, double* y, int* spmv_count) const {
+    if (ctx->comm) {
+      int rc = mfem_comm_halo(ctx, x);
+      if (rc) return rc;
+    }
+    ++*spmv_count;
+    return mfem_spmv_launch(ctx, A, vals, x, y, 1.0, 0.0, nullptr, nullptr, nullptr, F);
+  }
+};

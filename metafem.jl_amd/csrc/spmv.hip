@@ -53,9 +53,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, int64_t ntiles_padded, int xcd_aware,
-    const double* __restrict__ dotw, double* __restrict__ partials) {
+    const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
   __shared__ double prod[SPMV_CAP + 4];
   __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
   const int tid = threadIdx.x;
   const int tpr = 1 << tpr_log2;
   double dot_acc = 0.0;
@@ -174,8 +175,9 @@ template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
     int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ vals,
     const double* __restrict__ x, double* __restrict__ y, double alpha, double beta, int base,
-    const double* __restrict__ dotw, double* __restrict__ partials) {
+    const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
   __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -276,18 +278,20 @@ extern "C" int64_t mfem_csr_n(mfem_csr A) { return A ? A->n : -1; }
 // Internal launcher: y = alpha*A*x + beta*y, optionally partial sums of (dotw . y) into `partials`
 // (*n_partials receives the number written).
 static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
-                             double alpha, double beta, const double* dotw, double* partials, int* n_partials);
+                             double alpha, double beta, const double* dotw, double* partials, int* n_partials,
+                             const int32_t* done_flag);
 
 int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
-                     double alpha, double beta, const double* dotw, double* partials, int* n_partials) {
-  if (!ctx->prof_on) return spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials);
+                     double alpha, double beta, const double* dotw, double* partials, int* n_partials,
+                     const int32_t* done_flag) {
+  if (!ctx->prof_on) return spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
   if (ctx->prof_used == MFEM_PROF_PAIRS) {
     int rc = mfem_prof_flush(ctx);
     if (rc) return rc;
   }
   const int k = ctx->prof_used;
   MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k], ctx->stream));
-  int rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials);
+  int rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
   if (rc) return rc;
   MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k + 1], ctx->stream));
   ctx->prof_used = k + 1;
@@ -295,7 +299,8 @@ int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, con
 }
 
 static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
-                             double alpha, double beta, const double* dotw, double* partials, int* n_partials) {
+                             double alpha, double beta, const double* dotw, double* partials, int* n_partials,
+                             const int32_t* done_flag) {
   if (n_partials) *n_partials = 0;
   if (A->n == 0) return MFEM_OK;
   const int base = A->index_base;
@@ -318,7 +323,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
 #define LAUNCH_LDS(RP, VEC, CAP, UNR)                                                                      \
   hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,  \
                      A->nnz, (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2,  \
-                     ntiles, ntiles_padded, xcd, dotw, partials)
+                     ntiles, ntiles_padded, xcd, dotw, partials, done_flag)
 #define LAUNCH_VARIANT(RP)                                                   \
   do {                                                                       \
     if (!vec) LAUNCH_LDS(RP, false, 4032, 4);                                \
@@ -336,10 +341,10 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     const int grid = mfem_grid_for(A->n, 4, ctx->num_cus * 8 < MFEM_MAX_PARTIALS ? ctx->num_cus * 8 : MFEM_MAX_PARTIALS);
     if (A->rowptr_bits == 64)
       hipLaunchKernelGGL(k_spmv_wave_per_row<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
-                         (const int64_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials);
+                         (const int64_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials, done_flag);
     else
       hipLaunchKernelGGL(k_spmv_wave_per_row<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
-                         (const int32_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials);
+                         (const int32_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials, done_flag);
     MFEM_CHECK_LAUNCH();
     if (n_partials && partials) *n_partials = grid;
   }
@@ -350,5 +355,5 @@ extern "C" int mfem_spmv_csr(mfem_context ctx, mfem_csr A, const double* vals, c
                              double alpha, double beta) {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(A->n == 0 || (x && y && (A->nnz == 0 || vals)), "null vector");
-  return mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr);
+  return mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr, nullptr);
 }

@@ -21,5 +21,3 @@ extern "C" int mfem_allreduce_sum(mfem_context, double*, int32_t) { UNSUP("mfem_
 extern "C" int mfem_halo_exchange(mfem_context, double*) { UNSUP("mfem_halo_exchange"); }
 int mfem_comm_allreduce(mfem_context_s*, double*, int) { UNSUP("comm allreduce"); }
 int mfem_comm_halo(mfem_context_s*, double*) { UNSUP("comm halo"); }
-int mfem_bicgstabl_pass(mfem_context_s*, mfem_csr_s*, const double*, KrylovVecs&, const mfem_solve_options*, int, double, int64_t, int*, int*) { UNSUP("bicgstabl_GS"); }
-int mfem_idrs_pass(mfem_context_s*, mfem_csr_s*, const double*, KrylovVecs&, const mfem_solve_options*, int, double, int64_t, int*, int*) { UNSUP("idrs"); }

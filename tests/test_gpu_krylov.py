@@ -1,0 +1,141 @@
+"""GPU parity: iterative_Solve! with bicgstabl_GS! / idrs! against the oracle restatement and the direct solve."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _thermal_system(n=(7, 6, 5), distort=True):
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    x = (1.0, 1.0, 1.0)
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh(x, n, disc)
+    if distort:
+        c = msh.coords
+        msh.coords = c + 0.02 * np.stack([np.sin(3 * c[:, 1]), np.sin(2 * c[:, 2]), c[:, 0] * c[:, 1]], axis=1)
+    fac = om.boundary_facets_structured(x, n, 3)
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6), [(fac, problems.thermal_convection(25.0, 293.15))])
+    od.controlpoints["s"] = np.full(msh.ncp, 1600.0)
+    od.update_time(); od.K_linear_func(); od.update_x_star(); od.K_nonlinear_func()
+    return od.pattern.rowptr, od.pattern.colidx, od.K_total.copy(), od.residue.copy()
+
+
+def _nonsymmetric_system():
+    """C1's first Newton system: quad-8 serendipity, Nitsche Dirichlet => nonsymmetric K."""
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    L1, L2, nx, ny = 0.02, 0.01, 16, 8
+    disc = re_.initialize_classical_element(2, "CUBE", 2, 1, 5, itp_type="Serendipity")
+    vert, conn = om.make_square((L1, L2), (nx, ny))
+    mesh = om.mesh_classical(vert, conn, disc)
+    fac = om.boundary_facets(mesh)
+    err = (L1 / nx) * 0.01
+    lr = (np.abs(fac.centroid[:, 0]) < err) | (np.abs(fac.centroid[:, 0] - L1) < err)
+    top = np.abs(fac.centroid[:, 1] - L2) < err
+    dom = fem.FEMDomain(mesh, disc, 1, problems.thermal_domain(2, 3),
+                        [(fac.select(lr), problems.thermal_fixed(2, 1000.0, 1173.15, 3)),
+                         (fac.select(top), problems.thermal_convection(50, 323.15, 0.7, 5.669e-8))])
+    dom.controlpoints["s"] = np.zeros(mesh.ncp)
+    dom.update_time(); dom.K_linear_func(); dom.update_x_star(); dom.K_nonlinear_func()
+    return dom.pattern.rowptr, dom.pattern.colidx, dom.K_total.copy(), dom.residue.copy()
+
+
+def _gpu_solve(mf, sysm, **kw):
+    import torch
+
+    rowptr, col, K, b = sysm
+    A = mf.FEM_SpMat_CSR(torch.tensor(rowptr, device="cuda"), torch.tensor(col, device="cuda"), b.size)
+    Kt = torch.tensor(K, device="cuda")
+    dx, st = mf.iterative_Solve(A, Kt, torch.tensor(b, device="cuda"), **kw)
+    return dx.cpu().numpy(), st, Kt.cpu().numpy()
+
+
+@pytest.mark.parametrize("system", ["thermal", "nonsym"])
+@pytest.mark.parametrize("method,s", [("bicgstabl_gs", 2), ("bicgstabl_gs", 4), ("idrs", 4), ("idrs", 8), ("idrs", 11)])
+def test_solver_matches_oracle_and_direct(mf, system, method, s):
+    from oracle import solvers
+
+    sysm = _thermal_system() if system == "thermal" else _nonsymmetric_system()
+    rowptr, col, K, b = sysm
+    ref = solvers.solver_lu_cpu(rowptr, col, K, b)
+    tol = 1e-10 * solvers.normalized_norm(b)
+    info = solvers.SolveInfo()
+    xo = solvers.iterative_solve(rowptr, col, K, b, tol, Sv_func=getattr(solvers, method), maxiter=600, max_pass=6, s=s,
+                                 seed=0x5EED, info=info)
+    sv = mf.bicgstabl_GS_ if method == "bicgstabl_gs" else mf.idrs_
+    x, st, K_after = _gpu_solve(mf, sysm, converge_tol=tol, Sv_func=sv, maxiter=600, max_pass=6, s=s, seed=0x5EED, check_every=5)
+    assert st.converged == 1 and st.final_res < tol
+    assert np.array_equal(K_after, K)  # scale_in_place = False: the caller's K_total is untouched
+    scale = np.abs(ref).max()
+    assert np.abs(x - ref).max() <= 1e-8 * scale
+    assert np.abs(x - xo).max() <= 1e-8 * scale
+    # same algorithm + same shadow vectors: iteration counts agree up to round-off at the stop test
+    # (the recurrence residual can cross `tol` one step earlier/later, which may cost or save a restart pass)
+    assert abs(st.passes - info.passes) <= 1
+    if st.passes == info.passes:
+        assert abs(st.iterations - info.iters) <= max(4, s + 1), (st.iterations, info.iters)
+
+
+def test_first_sweep_iterates_are_identical_to_the_oracle(mf):
+    """One BiCGStab(2) sweep / a few IDR steps from x0 = 0 with the same shadow vectors: agreement to round-off."""
+    from oracle import solvers
+
+    sysm = _thermal_system((5, 5, 5), distort=False)
+    rowptr, col, K, b = sysm
+    for method, sv, s, maxiter in [("bicgstabl_gs", mf.bicgstabl_GS_, 2, 3), ("idrs", mf.idrs_, 4, 4)]:
+        xo = solvers.iterative_solve(rowptr, col, K, b, 1e-300, Sv_func=getattr(solvers, method), maxiter=maxiter, max_pass=1,
+                                     s=s, seed=7)
+        x, st, _ = _gpu_solve(mf, sysm, converge_tol=1e-300, Sv_func=sv, maxiter=maxiter, max_pass=1, s=s, seed=7)
+        assert np.abs(x - xo).max() <= 1e-11 * np.abs(xo).max(), method
+
+
+def test_user_shadow_vectors_and_scale_in_place(mf):
+    import torch
+    from oracle import solvers
+
+    sysm = _thermal_system((5, 4, 4))
+    rowptr, col, K, b = sysm
+    rng = np.random.default_rng(9)
+    shadow = rng.random(b.size)
+    tol = 1e-9 * solvers.normalized_norm(b)
+    xo = solvers.iterative_solve(rowptr, col, K, b, tol, Sv_func=solvers.bicgstabl_gs, maxiter=400, max_pass=4, s=2, shadow=shadow)
+    x, st, K_after = _gpu_solve(mf, sysm, converge_tol=tol, Sv_func=mf.bicgstabl_GS_, maxiter=400, max_pass=4, s=2,
+                                shadow=torch.tensor(shadow, device="cuda"), scale_in_place=True)
+    assert np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()
+    # Pr_Jacobi! semantics: the matrix handed in is column-scaled in place (02_Preconditioner.jl:118,141-148)
+    A = solvers.csr(rowptr, col, K.copy(), b.size)
+    solvers.pr_jacobi(A)
+    assert np.allclose(K_after, A.data, rtol=1e-15)
+
+
+@pytest.mark.parametrize("precond", ["none", "colnorm"])
+def test_other_right_preconditioners(mf, precond):
+    from oracle import solvers
+
+    sysm = _thermal_system((4, 4, 4))
+    rowptr, col, K, b = sysm
+    ref = solvers.solver_lu_cpu(rowptr, col, K, b)
+    tol = 1e-10 * solvers.normalized_norm(b)
+    pr = {"none": mf.Identity, "colnorm": mf.Pr_Jacobi_colnorm_}[precond]
+    x, st, _ = _gpu_solve(mf, sysm, converge_tol=tol, Sv_func=mf.idrs_, Pr_func=pr, maxiter=800, max_pass=6, s=8)
+    assert st.converged == 1
+    assert np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_zero_rhs_returns_zero_iterations(mf):
+    import torch
+
+    rowptr, col, K, b = _thermal_system((3, 3, 3))
+    for sv in (mf.cg_, mf.bicgstabl_GS_, mf.idrs_):
+        x, st, _ = _gpu_solve(mf, (rowptr, col, K, np.zeros_like(b)), converge_tol=1e-12, Sv_func=sv, maxiter=50, max_pass=2)
+        assert st.iterations == 0 and st.passes == 1 and np.all(x == 0.0)
+
+
+def test_maxiter_and_max_pass_are_honoured(mf):
+    sysm = _thermal_system((6, 6, 6))
+    x, st, _ = _gpu_solve(mf, sysm, converge_tol=1e-30, Sv_func=mf.idrs_, maxiter=10, max_pass=3, s=4)
+    assert st.passes == 3 and st.converged == 0
+    assert 3 * 10 <= st.iterations <= 3 * 11  # idrs! returns at iter >= maxiter (04_IDRs.jl:79,92)
+    x, st, _ = _gpu_solve(mf, sysm, converge_tol=1e-30, Sv_func=mf.bicgstabl_GS_, maxiter=9, max_pass=2, s=2)
+    assert st.passes == 2 and st.iterations == 2 * 9  # iter = 1, 3, 5, 7, 9 (03_BiCGstabl.jl:93-94)
