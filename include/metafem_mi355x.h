@@ -229,10 +229,11 @@ int mfem_op_res(mfem_context ctx, const mfem_op_layout* L, const double* itp_val
 int mfem_comm_unique_id(void* out128 /* [host] */);
 int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out);
 int mfem_comm_destroy(mfem_comm c);
-/* Attach to a context: subsequent mfem_solve calls on slab matrices all-reduce their scalars over
- * the communicator and exchange one ghost plane of `plane_len` doubles per field with ranks +-1
- * before each SpMV.  n_owned rows are [ghost_lo | owned | ghost_hi] in the local x. */
-int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t plane_len, int32_t n_fields);
+/* Attach to a context (c = NULL detaches): subsequent mfem_solve calls on slab matrices all-reduce their
+ * scalars over the communicator and, before each SpMV, exchange one ghost plane of `plane_len` doubles per
+ * field with ranks +-1.  Local vectors are [owned: n_fields x n_owned_nodes, field-major |
+ * ghosts: (field 0 lo, field 0 hi, field 1 lo, ...) x plane_len]  (see mfem_brick_set_slab). */
+int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_owned_nodes, int64_t plane_len, int32_t n_fields);
 int mfem_allreduce_sum(mfem_context ctx, double* dev_scalars, int32_t count);
 int mfem_halo_exchange(mfem_context ctx, double* x_local);
 

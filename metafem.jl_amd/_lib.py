@@ -105,7 +105,7 @@ SIGNATURES = {
     "mfem_comm_unique_id": (c_int, [P]),
     "mfem_comm_create": (c_int, [P, c_int32, c_int32, P, C.POINTER(P)]),
     "mfem_comm_destroy": (c_int, [P]),
-    "mfem_context_set_comm": (c_int, [P, P, c_int64, c_int32]),
+    "mfem_context_set_comm": (c_int, [P, P, c_int64, c_int64, c_int32]),
     "mfem_allreduce_sum": (c_int, [P, P, c_int32]),
     "mfem_halo_exchange": (c_int, [P, P]),
 }

@@ -13,11 +13,3 @@ extern "C" int mfem_brick_residual_elasticity(mfem_context, mfem_brick, const mf
 extern "C" int mfem_op_var(mfem_context, const mfem_op_layout*, const double*, int32_t, int64_t, const int32_t*, const double*, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_var"); }
 extern "C" int mfem_op_kval(mfem_context, const mfem_op_layout*, const double*, int32_t, int32_t, const double*, const int32_t*, int64_t, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_kval"); }
 extern "C" int mfem_op_res(mfem_context, const mfem_op_layout*, const double*, int32_t, const double*, int64_t, const int32_t*, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_res"); }
-extern "C" int mfem_comm_unique_id(void*) { UNSUP("mfem_comm_unique_id"); }
-extern "C" int mfem_comm_create(mfem_context, int32_t, int32_t, const void*, mfem_comm*) { UNSUP("mfem_comm_create"); }
-extern "C" int mfem_comm_destroy(mfem_comm) { return MFEM_OK; }
-extern "C" int mfem_context_set_comm(mfem_context, mfem_comm, int64_t, int32_t) { UNSUP("mfem_context_set_comm"); }
-extern "C" int mfem_allreduce_sum(mfem_context, double*, int32_t) { UNSUP("mfem_allreduce_sum"); }
-extern "C" int mfem_halo_exchange(mfem_context, double*) { UNSUP("mfem_halo_exchange"); }
-int mfem_comm_allreduce(mfem_context_s*, double*, int) { UNSUP("comm allreduce"); }
-int mfem_comm_halo(mfem_context_s*, double*) { UNSUP("comm halo"); }

@@ -1,0 +1,95 @@
+"""Slab domain decomposition host logic (new; the reference is single-GPU).
+
+A structured lattice of m0 x m1 x m2 control points is cut along i into `world` contiguous runs of node
+planes.  Rank r owns planes [lo, hi): its matrix rows are its owned nodes (field-major), assembled from
+the element planes touching them (the interface element plane is evaluated on both sides, so assembly
+needs no communication).  A local vector is laid out as
+
+    [ field 0 owned | field 1 owned | ... | f0 ghost_lo | f0 ghost_hi | f1 ghost_lo | f1 ghost_hi | ... ]
+
+with one ghost plane (m1*m2 entries) per side and field; the ghost block is always allocated, edge ranks
+simply never reference their outer half.  `slab_local_index` is the host restatement of the device
+numbering (csrc/brick.h::brick_xindex) and is what the CPU (gloo) tests exercise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def slab_planes(m0: int, world: int, rank: int) -> Tuple[int, int]:
+    """Owned node planes [lo, hi) of `rank`: m0 planes split as evenly as possible, extras to the low ranks."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    if m0 < world:
+        raise ValueError("fewer node planes than ranks")
+    base, rem = divmod(m0, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def slab_local_index(i, j, k, f, lo: int, hi: int, m1: int, m2: int, n_fields: int):
+    """Local vector index of field f at lattice node (i, j, k) for the slab [lo, hi); i in [lo-1, hi]."""
+    i, j, k = np.asarray(i), np.asarray(j), np.asarray(k)
+    pl = m1 * m2
+    n_owned = (hi - lo) * pl
+    inplane = j * m2 + k
+    owned = (i >= lo) & (i < hi)
+    side = np.where(i < lo, 0, 1)
+    return np.where(owned, f * n_owned + (i - lo) * pl + inplane, n_fields * n_owned + (f * 2 + side) * pl + inplane)
+
+
+def local_vector_length(lo: int, hi: int, m1: int, m2: int, n_fields: int) -> int:
+    return n_fields * ((hi - lo) + 2) * m1 * m2
+
+
+class SlabComm:
+    """RCCL communicator of the C ABI (mfem_comm_*) bootstrapped through torch.distributed: rank 0 creates the
+    128-byte unique id, the default process group broadcasts it."""
+
+    def __init__(self, ctx, brick, rank: int, world: int, n_fields: int = 1):
+        import torch.distributed as dist
+
+        self.ctx, self.rank, self.world = ctx, rank, world
+        dev = f"cuda:{ctx.device}"
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            check(lib.mfem_comm_unique_id(buf))
+            uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        raw = bytes(uid.cpu().tolist())
+        self._h = C.c_void_p()
+        check(lib.mfem_comm_create(ctx._h, rank, world, raw, C.byref(self._h)))
+        self.plane_len = brick.m[1] * brick.m[2]
+        self.n_owned_nodes = brick.n_owned
+        self.n_fields = n_fields
+        check(lib.mfem_context_set_comm(ctx._h, self._h, self.n_owned_nodes, self.plane_len, n_fields))
+
+    def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
+        check(lib.mfem_allreduce_sum(self.ctx._h, t.data_ptr(), t.numel()))
+        return t
+
+    def halo_(self, x_local: torch.Tensor) -> torch.Tensor:
+        check(lib.mfem_halo_exchange(self.ctx._h, x_local.data_ptr()))
+        return x_local
+
+    def close(self):
+        if self._h:
+            lib.mfem_context_set_comm(self.ctx._h, None, 0, 0, 0)
+            lib.mfem_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
