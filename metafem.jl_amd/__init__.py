@@ -286,6 +286,24 @@ class Brick:
         check(lib.mfem_brick_residual_thermal(self.ctx._h, self._h, C.byref(p), _ptr(x_star), _ptr(s), _ptr(res)))
         return res
 
+    def assemble_elasticity(self, A: FEM_SpMat_CSR, lam: float, mu: float, tau: float = 0.0, penalty_faces: int = 0,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """K_linear_func of -Bilinear(eps{i,j}, sigma{i,j}) + tau*Bilinear(d{i}, dw{i} - d{i}), dw = 0
+        (examples/linear_elasticity/cantilever/3D_Script.jl:52-60): the reference's 21 + 3 _Kval_Basic launches."""
+        vals = out if out is not None else torch.empty(A.nnz, dtype=torch.float64, device=f"cuda:{self.ctx.device}")
+        p = ElasticityParams(lam, mu, tau, penalty_faces, 0, (C.c_double * 6)(*([0.0] * 6)))
+        check(lib.mfem_brick_assemble_elasticity(self.ctx._h, self._h, A._h, C.byref(p), _ptr(vals)))
+        return vals
+
+    def residual_elasticity(self, x_star: torch.Tensor, lam: float, mu: float, tau: float = 0.0, penalty_faces: int = 0,
+                            traction_faces: int = 0, sig=(0.0,) * 6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """sig = constant symmetric tensor (11, 22, 33, 23, 13, 12) of Bilinear(d{i}, sig{i,j}*n{j}) (:61)."""
+        _need(x_star, torch.float64, "x_star", 3 * self.n_owned)
+        res = out if out is not None else torch.empty(3 * self.n_owned, dtype=torch.float64, device=x_star.device)
+        p = ElasticityParams(lam, mu, tau, penalty_faces, traction_faces, (C.c_double * 6)(*sig))
+        check(lib.mfem_brick_residual_elasticity(self.ctx._h, self._h, C.byref(p), _ptr(x_star), _ptr(res)))
+        return res
+
     def close(self):
         if self._h:
             lib.mfem_brick_destroy(self._h)

@@ -388,6 +388,230 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_residual(BrickView B, do
   res[node] = r;
 }
 
+
+// =================================================================================================
+// Boundary-face visitor: for an owned node (i,j,k), every element face that (a) lies on a brick face
+// selected in `mask` and (b) contains the node.  f(nd, side, ca, fn, Xf): nd normal dim, side 0 low /
+// 1 high, ca = the node's id among the 4 face nodes, fn[c][3] lattice ids and Xf[c][3] coordinates.
+// =================================================================================================
+template <typename Fn>
+__device__ __forceinline__ void visit_boundary_faces(const BrickView& B, int i, int j, int k, uint32_t mask, Fn f) {
+  if (mask == 0u) return;
+  const int idx[3] = {i, j, k};
+  const int ne[3] = {B.ne0, B.ne1, B.ne2};
+  for (int nd = 0; nd < 3; ++nd) {
+    for (int side = 0; side < 2; ++side) {
+      const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
+      if (!on || !(mask & face_bit(nd, side))) continue;
+      const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int f1 = q4 & 1, f2 = q4 >> 1;
+        const int E1 = idx[t1] - 1 + f1, E2 = idx[t2] - 1 + f2;
+        if (E1 < 0 || E1 >= ne[t1] || E2 < 0 || E2 >= ne[t2]) continue;
+        const int ca = (1 - f1) + 2 * (1 - f2);
+        int fn[4][3];
+        double Xf[4][3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          fn[c][nd] = idx[nd];
+          fn[c][t1] = E1 + (c & 1);
+          fn[c][t2] = E2 + (c >> 1);
+          const int64_t ci = brick_cindex(B, fn[c][0], fn[c][1], fn[c][2]);
+          Xf[c][0] = B.X0[ci];
+          Xf[c][1] = B.X1[ci];
+          Xf[c][2] = B.X2[ci];
+        }
+        f(nd, side, ca, fn, Xf);
+      }
+    }
+  }
+}
+
+// =================================================================================================
+// Linear elasticity (examples/linear_elasticity/cantilever/3D_Script.jl:52-63), 3 fields, field-major:
+//   K[(i,a),(k,b)] = -sum_q w [ lam d_iN_a d_kN_b + mu d_kN_a d_iN_b + mu delta_ik gradN_a.gradN_b ]
+//                    - tau sum_q w^s N_a N_b delta_ik   on penalty faces
+// i.e. the 21 _Kval_Basic launches of the reference in one pass.  Row-owner: a thread
+// owns the 3 rows of its control point and accumulates them in place (exclusive => no atomics); `vals`
+// must be zero on entry (the launcher memsets it).
+// =================================================================================================
+__global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, double lam, double mu, double tau,
+                                                                    uint32_t penalty, int64_t T,
+                                                                    double* __restrict__ vals) {
+  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= B.n_owned) return;
+  int i, j, k;
+  node_ijk(B, node, i, j, k);
+  const int li = B.lo0[i], lj = B.lo1[j], lk = B.lo2[k];
+  const int cj = B.c1[j], ck = B.c2[k];
+  const int64_t cn = (int64_t)B.c0[i] * cj * ck;
+  const int64_t pre = brick_prefix(B, i, j, k);
+  // row (f,node) starts at f*3*T + 3*pre; block g at + g*cn
+  double* row[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) row[f] = vals + (int64_t)f * 3 * T + 3 * pre;
+  for (int e = 0; e < 8; ++e) {
+    const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
+    const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
+    if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
+    const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
+    double X[8][3];
+    hex8_load_coords(B, I, J, K, X);
+    // G[b][s][t] = sum_q w d_sN_a d_tN_b
+    double G[8][3][3];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) G[b][s][t] = 0.0;
+    const int nq = B.ng * B.ng * B.ng;
+    for (int q = 0; q < nq; ++q) {
+      double g[8][3];
+      const double wd = hex8_geom(X, q, g);
+      double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool me = (b == a);
+        ga[0] = me ? g[b][0] : ga[0];
+        ga[1] = me ? g[b][1] : ga[1];
+        ga[2] = me ? g[b][2] : ga[2];
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) G[b][s][t] += wd * ga[s] * g[b][t];
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
+      const int slot = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
+      const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
+#pragma unroll
+      for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+        for (int fk = 0; fk < 3; ++fk) {
+          double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
+          if (fi == fk) v += mu * tr;
+          row[fi][fk * cn + slot] -= v;
+        }
+    }
+  }
+  if (tau != 0.0 && penalty != 0u) {
+    visit_boundary_faces(B, i, j, k, penalty, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
+      double mab[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int q = 0; q < B.ng * B.ng; ++q) {
+        const double ws = face_geom(Xf, q, side == 0, nullptr);
+        double na = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) na = (c == ca) ? c_fN[q][c] : na;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mab[c] += ws * na * c_fN[q][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int slot = ((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk);
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) row[fi][fi * cn + slot] -= tau * mab[c];
+      }
+    });
+  }
+}
+
+// Residual at x_star (matrix-free):
+//   R[(i,a)] = -sum_q w sigma_ij(u) d_jN_a + sum_q w^s N_a [ tau (0 - u_i) |penalty faces + sig_ij n_j |traction faces ]
+__global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_residual(BrickView B, double lam, double mu, double tau,
+                                                                      uint32_t penalty, uint32_t traction,
+                                                                      double s11, double s22, double s33, double s23,
+                                                                      double s13, double s12,
+                                                                      const double* __restrict__ x,
+                                                                      double* __restrict__ res) {
+  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= B.n_owned) return;
+  int i, j, k;
+  node_ijk(B, node, i, j, k);
+  double r[3] = {0.0, 0.0, 0.0};
+  for (int e = 0; e < 8; ++e) {
+    const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
+    const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
+    if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
+    const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
+    double X[8][3], u[8][3];
+    hex8_load_coords(B, I, J, K, X);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
+#pragma unroll
+      for (int f = 0; f < 3; ++f) u[b][f] = x[brick_xindex(B, f, ni, nj, nk)];
+    }
+    const int nq = B.ng * B.ng * B.ng;
+    for (int q = 0; q < nq; ++q) {
+      double g[8][3];
+      const double wd = hex8_geom(X, q, g);
+      double du[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // du[i][j] = d_j u_i
+      double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+          for (int fj = 0; fj < 3; ++fj) du[fi][fj] += u[b][fi] * g[b][fj];
+        const bool me = (b == a);
+        ga[0] = me ? g[b][0] : ga[0];
+        ga[1] = me ? g[b][1] : ga[1];
+        ga[2] = me ? g[b][2] : ga[2];
+      }
+      const double tr = du[0][0] + du[1][1] + du[2][2];
+#pragma unroll
+      for (int fi = 0; fi < 3; ++fi) {
+        double acc = 0.0;
+#pragma unroll
+        for (int fj = 0; fj < 3; ++fj) {
+          double sg = mu * (du[fi][fj] + du[fj][fi]);
+          if (fi == fj) sg += lam * tr;
+          acc += sg * ga[fj];
+        }
+        r[fi] -= wd * acc;
+      }
+    }
+  }
+  const uint32_t both = penalty | traction;
+  if (both != 0u) {
+    const double sg[3][3] = {{s11, s12, s13}, {s12, s22, s23}, {s13, s23, s33}};
+    visit_boundary_faces(B, i, j, k, both, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
+      const bool pen = (penalty & face_bit(nd, side)) != 0u && tau != 0.0;
+      const bool tra = (traction & face_bit(nd, side)) != 0u;
+      double uf[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) uf[c][f] = x[brick_xindex(B, f, fn[c][0], fn[c][1], fn[c][2])];
+      for (int q = 0; q < B.ng * B.ng; ++q) {
+        double nrm[3];
+        const double ws = face_geom(Xf, q, side == 0, nrm);
+        double na = 0.0, uq[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          na = (c == ca) ? c_fN[q][c] : na;
+#pragma unroll
+          for (int f = 0; f < 3; ++f) uq[f] += c_fN[q][c] * uf[c][f];
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          double v = 0.0;
+          if (pen) v += tau * (0.0 - uq[f]);
+          if (tra) v += sg[f][0] * nrm[0] + sg[f][1] * nrm[1] + sg[f][2] * nrm[2];
+          r[f] += ws * na * v;
+        }
+      }
+    });
+  }
+#pragma unroll
+  for (int f = 0; f < 3; ++f) res[(int64_t)f * B.n_owned + node] = r[f];
+}
+
 int mfem_hex8_upload_tables(int ng);
 
 extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
@@ -414,6 +638,38 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
   const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
   hipLaunchKernelGGL(k_thermal_residual, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, p->h, p->Tenv,
                      p->robin_faces, x_star, s, residue);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
+extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_elasticity_params* p,
+                                              double* vals) {
+  MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
+  MFEM_REQUIRE(m->p == 1, "fused elasticity assembly is implemented for hex-8 (itp_order 1)");
+  MFEM_REQUIRE(A->n == 3 * m->n_owned, "pattern was not built for 3 fields on this brick");
+  int rc = mfem_hex8_upload_tables(m->ng);
+  if (rc) return rc;
+  BrickView B = mfem_brick_view(m, 3);
+  const int64_t T = A->nnz / 9;
+  MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)A->nnz, ctx->stream));
+  const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
+  hipLaunchKernelGGL(k_elasticity_matrix, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,
+                     p->penalty_faces, T, vals);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
+extern "C" int mfem_brick_residual_elasticity(mfem_context ctx, mfem_brick m, const mfem_elasticity_params* p,
+                                              const double* x_star, double* residue) {
+  MFEM_REQUIRE(ctx && m && p && x_star && residue, "null argument");
+  MFEM_REQUIRE(m->p == 1, "fused elasticity residual is implemented for hex-8 (itp_order 1)");
+  int rc = mfem_hex8_upload_tables(m->ng);
+  if (rc) return rc;
+  BrickView B = mfem_brick_view(m, 3);
+  const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
+  hipLaunchKernelGGL(k_elasticity_residual, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,
+                     p->penalty_faces, p->traction_faces, p->sig[0], p->sig[1], p->sig[2], p->sig[3], p->sig[4], p->sig[5],
+                     x_star, residue);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
 }

@@ -8,8 +8,6 @@
     return MFEM_ERR_UNSUPPORTED;                      \
   } while (0)
 
-extern "C" int mfem_brick_assemble_elasticity(mfem_context, mfem_brick, mfem_csr, const mfem_elasticity_params*, double*) { UNSUP("mfem_brick_assemble_elasticity"); }
-extern "C" int mfem_brick_residual_elasticity(mfem_context, mfem_brick, const mfem_elasticity_params*, const double*, double*) { UNSUP("mfem_brick_residual_elasticity"); }
 extern "C" int mfem_op_var(mfem_context, const mfem_op_layout*, const double*, int32_t, int64_t, const int32_t*, const double*, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_var"); }
 extern "C" int mfem_op_kval(mfem_context, const mfem_op_layout*, const double*, int32_t, int32_t, const double*, const int32_t*, int64_t, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_kval"); }
 extern "C" int mfem_op_res(mfem_context, const mfem_op_layout*, const double*, int32_t, const double*, int64_t, const int32_t*, double*, const int32_t*, const int32_t*, int64_t) { UNSUP("mfem_op_res"); }

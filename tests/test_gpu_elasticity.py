@@ -1,0 +1,73 @@
+"""GPU parity: fused hex-8 linear elasticity (3 DOF/node, field-major) vs the oracle's 21-term assembly."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+E_MOD, NU = 1.0, 0.3
+LAM, MU = E_MOD * NU / ((1 + NU) * (1 - 2 * NU)), E_MOD / (2 * (1 + NU))
+TAU = 1000.0 * E_MOD
+SIG = [[0.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]  # sigma_22 = 1 on the y = L face
+
+
+def _oracle(x, n, distort=False, itg=3):
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, itg)
+    msh = om.lattice_mesh(x, n, disc)
+    if distort:
+        c = msh.coords
+        msh.coords = c + 0.03 * np.stack([np.sin(2 * c[:, 1]), np.cos(2 * c[:, 2]) - 1, c[:, 0] * c[:, 1] / x[0]], axis=1)
+    fac = om.boundary_facets_structured(x, n, 3)
+    fixed = fac.select(fac.element_eindex == 4)  # x = 0  (face id 5)
+    load = fac.select(fac.element_eindex == 3)   # y = L  (face id 4)
+    od = fem.FEMDomain(msh, disc, 3, problems.elasticity_domain(3, LAM, MU),
+                       [(fixed, problems.elasticity_penalty(3, TAU)), (load, problems.elasticity_traction(3, SIG))])
+    od.update_time()
+    od.K_linear_func()
+    return od
+
+
+@pytest.mark.parametrize("n,distort,itg", [((1, 1, 1), False, 3), ((3, 2, 2), False, 3), ((4, 3, 5), True, 3), ((3, 3, 2), True, 5)])
+def test_elasticity_pattern_matrix_residual(mf, n, distort, itg):
+    import torch
+
+    x = (3.0, 1.0, 1.0)
+    od = _oracle(x, n, distort, itg)
+    rng = np.random.default_rng(2)
+    od.x_star[:] = 0.01 * rng.standard_normal(od.basicfield_size)
+    od.K_nonlinear_func()
+    brick = mf.make_Brick(x, n, 1, itg)
+    if distort:
+        for d in range(3):
+            brick.coords_view(d).copy_(torch.tensor(od.mesh.coords[:, d], device="cuda"))
+    A = brick.pattern(3)
+    assert np.array_equal(A.rowptr.cpu().numpy(), od.pattern.rowptr)
+    assert np.array_equal(A.colidx.cpu().numpy(), od.pattern.colidx)
+    K = brick.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"]).cpu().numpy()
+    assert np.max(np.abs(K - od.K_linear)) <= 2e-13 * np.max(np.abs(od.K_linear))
+    R = brick.residual_elasticity(torch.tensor(od.x_star, device="cuda"), LAM, MU, TAU, mf.FACE_BITS["x0"],
+                                  mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.0)).cpu().numpy()
+    assert np.max(np.abs(R - od.residue)) <= 1e-12 * np.max(np.abs(od.residue))
+
+
+def test_against_committed_golden_fixture(mf):
+    import torch
+
+    z = np.load(os.path.join(GOLD, "oracle_elasticity_hex8_3x2x2.npz"))
+    brick = mf.make_Brick(tuple(z["x"]), tuple(int(v) for v in z["n"]))
+    A = brick.pattern(3)
+    K = brick.assemble_elasticity(A, float(z["lam"]), float(z["mu"]), float(z["tau"]), mf.FACE_BITS["x0"])
+    assert np.max(np.abs(K.cpu().numpy() - z["K"])) <= 2e-13 * np.abs(z["K"]).max()
+    R0 = brick.residual_elasticity(torch.zeros(A.n, dtype=torch.float64, device="cuda"), float(z["lam"]), float(z["mu"]),
+                                   float(z["tau"]), mf.FACE_BITS["x0"], mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.0))
+    assert np.max(np.abs(R0.cpu().numpy() - z["R0"])) <= 1e-13 * np.abs(z["R0"]).max()
+    # Newton step: solve K delta = R, d = -delta (04_Time_Domain.jl:76-79); linear => 1e-10 parity
+    for sv, s in ((mf.idrs_, 8), (mf.bicgstabl_GS_, 2), (mf.cg_, 0)):
+        dx, st = mf.iterative_Solve(A, K, R0, 1e-13 * float(np.linalg.norm(z["R0"])) / np.sqrt(A.n), Sv_func=sv, maxiter=3000,
+                                    max_pass=10, s=s)
+        assert st.converged == 1
+        assert np.max(np.abs(-dx.cpu().numpy() - z["d"])) <= 1e-9 * np.abs(z["d"]).max(), sv
