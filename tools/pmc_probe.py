@@ -1,0 +1,17 @@
+"""PMC probe: a known-byte copy (calibration) followed by SpMV launches (standalone and inside CG)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import metafem_jl_amd as mf
+N = 256
+brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N))
+A = brick.pattern(1)
+K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+# calibration: device copy of nnz doubles (reads nnz*8, writes nnz*8)
+a = torch.empty_like(K)
+for _ in range(3):
+    a.copy_(K)
+torch.cuda.synchronize()
+b = torch.ones(A.n, dtype=torch.float64, device="cuda")
+_, st = mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=20, max_pass=1, fixed_iterations=True)
+print("nnz", A.nnz, "n", A.n, "ms/it", st.solve_ms / 20)
