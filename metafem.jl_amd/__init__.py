@@ -228,6 +228,43 @@ def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tenso
     return x, st
 
 
+def _op_layout(itg, itp, n_sd, n_host, index_base, colour_offsets):
+    if colour_offsets is None:
+        return OpLayout(itg, itp, n_sd, n_host, index_base, 0, None), None
+    arr = (C.c_int64 * len(colour_offsets))(*[int(v) for v in colour_offsets])
+    return OpLayout(itg, itp, n_sd, n_host, index_base, len(colour_offsets) - 1, arr), arr
+
+
+def _Var_Basic(itp_vals, sd, cpID_shift, el_g_cpIDs, x, target, itg_hostIDs, elIDs, *, dims, index_base=1, ctx=None):
+    """_Var_Basic(itp_vals, sd_IDs, cpID_shift, el_g_cpIDs, x_star, target, itg_hostIDs, elIDs) (06_FEM_Kernel.jl:1-13).
+    dims = (itg, itp, n_sd, n_host); `sd` is the flat 0-based slot of the reference's sd_IDs tuple."""
+    ctx = ctx or default_context()
+    L, _keep = _op_layout(*dims, index_base, None)
+    check(lib.mfem_op_var(ctx._h, C.byref(L), _ptr(itp_vals), sd, cpID_shift, _ptr(el_g_cpIDs), _ptr(x), _ptr(target),
+                          _ptr(itg_hostIDs), _ptr(elIDs), elIDs.numel()))
+    return target
+
+
+def _Kval_Basic(itp_vals, dual_sd, base_sd, vals, sparse_IDs_by_el, sparse_ID_shift, K_val, itg_hostIDs, elIDs, *, dims,
+                index_base=1, colour_offsets=None, ctx=None):
+    """_Kval_Basic(...) (06_FEM_Kernel.jl:28-45); colour_offsets = None -> FP64 atomics like the reference."""
+    ctx = ctx or default_context()
+    L, _keep = _op_layout(*dims, index_base, colour_offsets)
+    check(lib.mfem_op_kval(ctx._h, C.byref(L), _ptr(itp_vals), dual_sd, base_sd, _ptr(vals), _ptr(sparse_IDs_by_el),
+                           sparse_ID_shift, _ptr(K_val), _ptr(itg_hostIDs), _ptr(elIDs), elIDs.numel()))
+    return K_val
+
+
+def _Res_Basic(itp_vals, dual_sd, vals, cpID_shift, el_g_cpIDs, residue, itg_hostIDs, elIDs, *, dims, index_base=1,
+               colour_offsets=None, ctx=None):
+    """_Res_Basic(...) (06_FEM_Kernel.jl:65-79)."""
+    ctx = ctx or default_context()
+    L, _keep = _op_layout(*dims, index_base, colour_offsets)
+    check(lib.mfem_op_res(ctx._h, C.byref(L), _ptr(itp_vals), dual_sd, _ptr(vals), cpID_shift, _ptr(el_g_cpIDs),
+                          _ptr(residue), _ptr(itg_hostIDs), _ptr(elIDs), elIDs.numel()))
+    return residue
+
+
 class Brick:
     """make_Brick(x, n, :CUBE) + mesh_Classical(itp_type=:Lagrange, itp_order, itg_order) + update_Mesh
     on device (201_Helper_TM.jl:36-51; 2_Interface.jl:7,98-108)."""

@@ -40,12 +40,14 @@ __global__ void k_max_row_nnz(int64_t n, const RP* __restrict__ rowptr, int32_t*
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-__device__ __forceinline__ int64_t tile_of(int64_t it, int64_t ntiles, int xcd_aware) {
-  // it = logical sequence number of this workgroup's next tile in dispatch order
-  if (!xcd_aware) return it;
+__device__ __forceinline__ int64_t tile_of(int64_t it, int64_t ntiles, int xcd_chunk) {
+  // it = logical sequence number of this workgroup's next tile in dispatch order.  Workgroups with equal
+  // it % 8 share an XCD (round-robin dispatch); give each XCD runs of `xcd_chunk` consecutive tiles, the
+  // runs of the 8 XCDs interleaved so the chip as a whole still walks one contiguous window of the matrix.
+  if (xcd_chunk <= 0) return it;
   const int64_t xcd = it & 7, local = it >> 3;
-  const int64_t per = (ntiles + 7) >> 3;
-  return xcd * per + local;  // may be >= ntiles for the last XCD: caller skips
+  const int64_t run = local / xcd_chunk, within = local % xcd_chunk;
+  return (run * 8 + xcd) * xcd_chunk + within;  // may be >= ntiles near the end: caller skips
 }
 
 template <typename RP, bool VEC, int SPMV_CAP, int SPMV_UNROLL>
@@ -208,8 +210,8 @@ static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
 static int g_spmv_variant = 1;    // 0: CAP 4032 x4, 1: CAP 4032 x8, 2: CAP 2016 x4, 3: CAP 2016 x2
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
-  g_spmv_xcd_aware = xcd_aware & 1;
-  g_spmv_variant = (xcd_aware >> 4) & 3;
+  g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
+  g_spmv_variant = (xcd_aware >> 16) & 3;
   if (grid_mult > 0) g_spmv_grid_mult = grid_mult;
   return MFEM_OK;
 }
@@ -316,9 +318,9 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     cap &= ~7;  // multiple of 8 so blockIdx % 8 is a stable XCD label along the grid-stride loop
     if (cap < 8) cap = 8;
     int grid = (int)(ntiles < cap ? ((ntiles + 7) & ~(int64_t)7) : cap);
-    const int xcd = g_spmv_xcd_aware && ntiles >= 64;
-    const int64_t per = (ntiles + 7) >> 3;
-    const int64_t ntiles_padded = xcd ? per * 8 : ntiles;
+    const int xcd = (ntiles >= 64) ? g_spmv_xcd_aware : 0;
+    const int64_t span = (int64_t)8 * (xcd > 0 ? xcd : 1);
+    const int64_t ntiles_padded = xcd ? (ntiles + span - 1) / span * span : ntiles;
     const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
 #define LAUNCH_LDS(RP, VEC, CAP, UNR)                                                                      \
   hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,  \

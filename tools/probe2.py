@@ -1,0 +1,46 @@
+"""Why is SpMV slower inside CG than standalone?  Per-launch event timing (mfem_prof_spmv_*) of three loops."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import metafem_jl_amd as mf
+from metafem_jl_amd import _lib
+lib = _lib.lib
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N))
+A = brick.pattern(1)
+K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+ctx = brick.ctx
+x = mf.FEM_rand(A.n, 1, 0); y = torch.empty_like(x)
+u = [mf.FEM_rand(A.n, 2, i) for i in range(4)]
+bytes_spmv = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
+def read():
+    tot, cnt = C.c_double(), C.c_int64()
+    _lib.check(lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
+    return tot.value / max(cnt.value, 1)
+_lib.check(lib.mfem_prof_spmv_enable(ctx._h, 1))
+b = torch.ones(A.n, dtype=torch.float64, device="cuda")
+for ch in (0, 4, 16, 32, 64, 128, 256, 1024, 4096):
+    lib.mfem_debug_set_spmv(ch | (1 << 16), 8)
+    for _ in range(10): mf.mul_(y, A, K, x)
+    read()
+    for _ in range(30): mf.mul_(y, A, K, x)
+    ms = read()
+    mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=60, max_pass=1, fixed_iterations=True)
+    ms2 = read()
+    print(f"xcd chunk {ch}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
+lib.mfem_debug_set_spmv(0 | (1 << 16), 8)
+for _ in range(30): mf.mul_(y, A, K, x)
+read()
+for _ in range(50): mf.mul_(y, A, K, x)
+ms = read(); print(f"standalone: {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
+for _ in range(50):
+    mf.mul_(y, A, K, x)
+    mf.axpby_(0.5, u[0], 0.5, u[1]); mf.axpby_(0.5, u[2], 0.5, u[3]); mf.axpby_(0.5, u[1], 0.5, u[2])
+ms = read(); print(f"with 3 axpby between: {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
+for _ in range(50):
+    mf.mul_(y, A, K, x)
+    mf.axpby_(0.5, y, 0.5, x)   # x rewritten each time like p in CG
+ms = read(); print(f"x rewritten between: {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
+b = torch.ones(A.n, dtype=torch.float64, device="cuda")
+mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=100, max_pass=1, fixed_iterations=True)
+ms = read(); print(f"inside CG (fused dot): {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
