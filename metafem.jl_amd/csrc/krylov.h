@@ -30,5 +30,7 @@ int mfem_read_scalars(mfem_context_s* ctx, int first, int count);
 int mfem_read_flags(mfem_context_s* ctx);
 int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V,
                         const mfem_solve_options* o, int l, double tol, int64_t n_global, int* iters_out, int* spmv_out);
+int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V, const mfem_solve_options* o,
+                   double tol, int64_t n_global, int* iters_out, int* spmv_out);
 int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V, const mfem_solve_options* o,
                    int s, double tol, int64_t n_global, int* iters_out, int* spmv_out);

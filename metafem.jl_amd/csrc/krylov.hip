@@ -430,9 +430,12 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
       case MFEM_SOLVER_IDRS:
         rc = mfem_idrs_pass(ctx, A, vals_work, V, o, s_param, tol_factor * o->converge_tol, n_global, &it, &spmvs);
         break;
+      case MFEM_SOLVER_CGS2:
+        rc = mfem_cgs2_pass(ctx, A, vals_work, V, o, tol_factor * o->converge_tol, n_global, &it, &spmvs);
+        break;
       default:
-        mfem_set_error("solver method %d is not implemented yet", o->method);
-        rc = MFEM_ERR_UNSUPPORTED;
+        mfem_set_error("unknown solver method %d", o->method);
+        rc = MFEM_ERR_INVALID;
     }
     if (rc) return rc;
     total_iters += it;

@@ -52,7 +52,8 @@ def _gpu_solve(mf, sysm, **kw):
 
 
 @pytest.mark.parametrize("system", ["thermal", "nonsym"])
-@pytest.mark.parametrize("method,s", [("bicgstabl_gs", 2), ("bicgstabl_gs", 4), ("idrs", 4), ("idrs", 8), ("idrs", 11)])
+@pytest.mark.parametrize("method,s", [("bicgstabl_gs", 2), ("bicgstabl_gs", 4), ("idrs", 4), ("idrs", 8), ("idrs", 11),
+                                      ("cgs2", 0)])
 def test_solver_matches_oracle_and_direct(mf, system, method, s):
     from oracle import solvers
 
@@ -63,7 +64,7 @@ def test_solver_matches_oracle_and_direct(mf, system, method, s):
     info = solvers.SolveInfo()
     xo = solvers.iterative_solve(rowptr, col, K, b, tol, Sv_func=getattr(solvers, method), maxiter=600, max_pass=6, s=s,
                                  seed=0x5EED, info=info)
-    sv = mf.bicgstabl_GS_ if method == "bicgstabl_gs" else mf.idrs_
+    sv = {"bicgstabl_gs": mf.bicgstabl_GS_, "idrs": mf.idrs_, "cgs2": mf.cgs2_}[method]
     x, st, K_after = _gpu_solve(mf, sysm, converge_tol=tol, Sv_func=sv, maxiter=600, max_pass=6, s=s, seed=0x5EED, check_every=5)
     assert st.converged == 1 and st.final_res < tol
     assert np.array_equal(K_after, K)  # scale_in_place = False: the caller's K_total is untouched
@@ -83,7 +84,7 @@ def test_first_sweep_iterates_are_identical_to_the_oracle(mf):
 
     sysm = _thermal_system((5, 5, 5), distort=False)
     rowptr, col, K, b = sysm
-    for method, sv, s, maxiter in [("bicgstabl_gs", mf.bicgstabl_GS_, 2, 3), ("idrs", mf.idrs_, 4, 4)]:
+    for method, sv, s, maxiter in [("bicgstabl_gs", mf.bicgstabl_GS_, 2, 3), ("idrs", mf.idrs_, 4, 4), ("cgs2", mf.cgs2_, 0, 3)]:
         xo = solvers.iterative_solve(rowptr, col, K, b, 1e-300, Sv_func=getattr(solvers, method), maxiter=maxiter, max_pass=1,
                                      s=s, seed=7)
         x, st, _ = _gpu_solve(mf, sysm, converge_tol=1e-300, Sv_func=sv, maxiter=maxiter, max_pass=1, s=s, seed=7)
@@ -127,7 +128,7 @@ def test_zero_rhs_returns_zero_iterations(mf):
     import torch
 
     rowptr, col, K, b = _thermal_system((3, 3, 3))
-    for sv in (mf.cg_, mf.bicgstabl_GS_, mf.idrs_):
+    for sv in (mf.cg_, mf.bicgstabl_GS_, mf.idrs_, mf.cgs2_):
         x, st, _ = _gpu_solve(mf, (rowptr, col, K, np.zeros_like(b)), converge_tol=1e-12, Sv_func=sv, maxiter=50, max_pass=2)
         assert st.iterations == 0 and st.passes == 1 and np.all(x == 0.0)
 
