@@ -1,0 +1,466 @@
+// hex-27 (Lagrange order 2) thermal assembly: the one place in this backend where the work is a dense GEMM,
+//   Ke = B^T D B,   B[(q,s), a] = dN_a/dx_s (q)  (81 x 27),   D = diag(-k w_q det J_q),
+// so it runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), one wave per element:
+//   * the element's 27 nodal coordinates and its row descriptors are staged in per-wave LDS;
+//   * quadrature points are processed in chunks of 9 (27 rows of B + 1 zero row = 7 MFMA k-steps); for each
+//     chunk the wave builds J (81 entries over 64 lanes), inverts it (adjugate, inv_Jac_3D), and writes the
+//     chunk of B = dN/dxi * J^-1 into a 28 x 32 LDS tile whose two 16-column halves are XOR-swapped on odd rows
+//     (conflict-free ds_read_b64 of MFMA fragments);
+//   * Ke (27 x 27 padded to 32 x 32) = 2 x 2 accumulator tiles; the lower-left tile is the transpose of the
+//     upper-right one and is not computed: 3 tiles x 21 k-steps = 63 MFMAs per element;
+//   * scatter into the global CSR is race-free WITHOUT atomics through the parity colouring of the structured
+//     element grid (8 colours: same-colour elements share no control point), one launch per colour -- the
+//     colour-partitioned ordering BASELINE.json's north_star asks for.
+// Replaces for this element type: update_BasicElements_3D (4_Update_Integrator.jl:2-33,90-154) + the three
+// _Kval_Basic launches of the thermal form (06_FEM_Kernel.jl:28-45) + their 46.7 KB/element basis tables (F7).
+// The matrix-free residual and the Robin faces use the same wave-per-element / thread-per-face structure with
+// plain FP64 FMAs (matrix-vector work, not GEMM).
+#include "brick.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+#define H27_QC 9            // quadrature points per chunk
+#define H27_BROWS 28        // 3*QC rows + 1 zero row
+#define H27_BCOLS 32
+#define H27_MAXQ 64
+
+struct Hex27Tables {        // device-global, filled once per ng
+  double dN[H27_MAXQ][27][3];
+  double N[H27_MAXQ][27];
+  double w[H27_MAXQ];
+  // face tables: 2-D Lagrange-2 on [0,1]^2 at ng x ng Gauss points, c = c1 + 3*c2
+  double fN[16][9];
+  double fdN[16][9][2];
+  double fw[16];
+};
+static Hex27Tables* g_tab = nullptr;
+static int g_tab_ng = 0;
+
+static const double GP27[4][4] = {{0.0, 0, 0, 0},
+                                  {-0.57735026918962576451, 0.57735026918962576451, 0, 0},
+                                  {-0.77459666924148337704, 0.0, 0.77459666924148337704, 0},
+                                  {-0.86113631159405257522, -0.33998104358485626480, 0.33998104358485626480, 0.86113631159405257522}};
+static const double GW27[4][4] = {{2.0, 0, 0, 0},
+                                  {1.0, 1.0, 0, 0},
+                                  {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0, 0},
+                                  {0.34785484513745385737, 0.65214515486254614263, 0.65214515486254614263, 0.34785484513745385737}};
+
+static void lag2(double x, double* L, double* dL) {  // nodes 0, 1/2, 1 (102_Interpolations.jl:3-23)
+  L[0] = 2.0 * (x - 0.5) * (x - 1.0);
+  L[1] = -4.0 * x * (x - 1.0);
+  L[2] = 2.0 * x * (x - 0.5);
+  dL[0] = 4.0 * x - 3.0;
+  dL[1] = -8.0 * x + 4.0;
+  dL[2] = 4.0 * x - 1.0;
+}
+
+static int hex27_upload_tables(int ng) {
+  if (g_tab && g_tab_ng == ng) return MFEM_OK;
+  Hex27Tables* h = new Hex27Tables();
+  memset(h, 0, sizeof(*h));
+  double gp[4], gw[4];
+  for (int i = 0; i < ng; ++i) {
+    gp[i] = GP27[ng - 1][i] / 2.0 + 0.5;
+    gw[i] = GW27[ng - 1][i] / 2.0;
+  }
+  for (int qz = 0; qz < ng; ++qz)
+    for (int qy = 0; qy < ng; ++qy)
+      for (int qx = 0; qx < ng; ++qx) {
+        const int q = qx + ng * (qy + ng * qz);
+        double L[3][3], dL[3][3];
+        lag2(gp[qx], L[0], dL[0]);
+        lag2(gp[qy], L[1], dL[1]);
+        lag2(gp[qz], L[2], dL[2]);
+        h->w[q] = gw[qx] * gw[qy] * gw[qz];
+        for (int a = 0; a < 27; ++a) {
+          const int ax = a % 3, ay = (a / 3) % 3, az = a / 9;
+          h->N[q][a] = L[0][ax] * L[1][ay] * L[2][az];
+          h->dN[q][a][0] = dL[0][ax] * L[1][ay] * L[2][az];
+          h->dN[q][a][1] = L[0][ax] * dL[1][ay] * L[2][az];
+          h->dN[q][a][2] = L[0][ax] * L[1][ay] * dL[2][az];
+        }
+      }
+  for (int q2 = 0; q2 < ng; ++q2)
+    for (int q1 = 0; q1 < ng; ++q1) {
+      const int q = q1 + ng * q2;
+      double L1[3], d1[3], L2[3], d2[3];
+      lag2(gp[q1], L1, d1);
+      lag2(gp[q2], L2, d2);
+      h->fw[q] = gw[q1] * gw[q2];
+      for (int c = 0; c < 9; ++c) {
+        const int c1 = c % 3, c2 = c / 3;
+        h->fN[q][c] = L1[c1] * L2[c2];
+        h->fdN[q][c][0] = d1[c1] * L2[c2];
+        h->fdN[q][c][1] = L1[c1] * d2[c2];
+      }
+    }
+  if (!g_tab) MFEM_CHECK_HIP(hipMalloc(&g_tab, sizeof(Hex27Tables)));
+  MFEM_CHECK_HIP(hipMemcpy(g_tab, h, sizeof(Hex27Tables), hipMemcpyHostToDevice));
+  delete h;
+  g_tab_ng = ng;
+  return MFEM_OK;
+}
+
+// per-wave LDS carve-up (doubles)
+#define W_X 0                       // X[27][3]
+#define W_J (W_X + 84)              // J / Jinv [QC][9]
+#define W_D (W_J + 84)              // d[QC] (-k w det), padded to 12
+#define W_G (W_D + 12)              // gT[27] (+ pad)
+#define W_T (W_G + 28)              // nodal T[27], s[27]
+#define W_B (W_T + 56)              // Bc[28][32]
+#define W_INFO (W_B + H27_BROWS * H27_BCOLS)   // int64 rowbase[27] + int32 (lo0,lo1,lo2,c1,c2,gi,gj,gk)[27]
+#define W_SIZE (W_INFO + 27 + 27 * 4 + 1)      // 27 int64 + 27*8 int32 = 27 + 108 doubles
+
+struct Hex27Args {
+  BrickView B;
+  const Hex27Tables* tab;
+  double kcond;
+  int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
+  int nq;
+};
+
+__device__ __forceinline__ int swz(int r, int col) { return col ^ ((r & 1) << 4); }
+
+// Element of this colour with running index e -> (I,J,K); returns false past the end.
+__device__ __forceinline__ bool colour_element(const BrickView& B, int colour, int64_t e, int& I, int& J, int& K) {
+  const int cx = colour & 1, cy = (colour >> 1) & 1, cz = colour >> 2;
+  const int n0 = (B.ne0 - cx + 1) >> 1, n1 = (B.ne1 - cy + 1) >> 1, n2 = (B.ne2 - cz + 1) >> 1;
+  if (n0 <= 0 || n1 <= 0 || n2 <= 0 || e >= (int64_t)n0 * n1 * n2) return false;
+  K = 2 * (int)(e % n2) + cz;
+  J = 2 * (int)((e / n2) % n1) + cy;
+  I = 2 * (int)(e / ((int64_t)n1 * n2)) + cx;
+  return true;
+}
+
+template <bool MATRIX>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
+                                                       const double* __restrict__ src, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  // block-shared tables
+  double* s_dN = lds;                           // [nq][27][3]
+  double* s_N = s_dN + A.nq * 81;               // [nq][27]   (residual only)
+  double* s_w = s_N + (MATRIX ? 0 : A.nq * 27); // [nq]
+  double* wave_base = s_w + ((A.nq + 1) & ~1);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < A.nq * 81; i += MFEM_BLOCK) s_dN[i] = (&A.tab->dN[0][0][0])[i];
+  if (!MATRIX)
+    for (int i = tid; i < A.nq * 27; i += MFEM_BLOCK) s_N[i] = (&A.tab->N[0][0])[i];
+  for (int i = tid; i < A.nq; i += MFEM_BLOCK) s_w[i] = A.tab->w[i];
+  double* W = wave_base + (size_t)wv * W_SIZE;
+  for (int i = lane; i < H27_BROWS * H27_BCOLS; i += 64) W[W_B + i] = 0.0;  // pads stay zero forever
+  __syncthreads();
+  const BrickView& B = A.B;
+  int64_t* rowbase = reinterpret_cast<int64_t*>(W + W_INFO);
+  int32_t* info = reinterpret_cast<int32_t*>(W + W_INFO + 27);
+  const int nwaves = gridDim.x * (MFEM_BLOCK / 64);
+  const int nchunk = (A.nq + H27_QC - 1) / H27_QC;
+
+  for (int64_t e = (int64_t)blockIdx.x * (MFEM_BLOCK / 64) + wv;; e += nwaves) {
+    int I, J, K;
+    if (!colour_element(B, A.colour, e, I, J, K)) break;  // wave-uniform
+    // ---- 1. nodes: coordinates + row descriptors
+    if (lane < 27) {
+      const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
+      const int64_t c = brick_cindex(B, gi, gj, gk);
+      W[W_X + 3 * lane + 0] = B.X0[c];
+      W[W_X + 3 * lane + 1] = B.X1[c];
+      W[W_X + 3 * lane + 2] = B.X2[c];
+      if (MATRIX) {
+        rowbase[lane] = brick_prefix(B, gi, gj, gk);
+        int32_t* in = info + 8 * lane;
+        in[0] = B.lo0[gi]; in[1] = B.lo1[gj]; in[2] = B.lo2[gk];
+        in[3] = B.c1[gj];  in[4] = B.c2[gk];
+        in[5] = gi; in[6] = gj; in[7] = gk;
+      } else {
+        const int64_t xi = brick_xindex(B, 0, gi, gj, gk);
+        W[W_T + lane] = xstar[xi];
+        W[W_T + 28 + lane] = src ? src[xi] : 0.0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    d4_t C00 = {0, 0, 0, 0}, C01 = {0, 0, 0, 0}, C11 = {0, 0, 0, 0};
+    double fe = 0.0;  // residual entry of node `lane` (< 27)
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int q0 = ch * H27_QC;
+      const int nqc = (A.nq - q0) < H27_QC ? (A.nq - q0) : H27_QC;
+      // ---- 2a. J[q][i][m] = sum_a dN[q][a][m] X[a][i]   (81 entries over 64 lanes)
+      for (int t = lane; t < nqc * 9; t += 64) {
+        const int ql = t / 9, im = t % 9, i = im / 3, m = im % 3;
+        const double* dn = s_dN + (q0 + ql) * 81 + m;
+        double acc = 0.0;
+#pragma unroll 9
+        for (int a = 0; a < 27; ++a) acc += dn[3 * a] * W[W_X + 3 * a + i];
+        W[W_J + ql * 9 + im] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- 2b. det, inverse (adjugate), d = -k w det ; Jinv overwrites J as [m][s]
+      if (lane < nqc) {
+        double* Jm = W + W_J + lane * 9;
+        const double j00 = Jm[0], j01 = Jm[1], j02 = Jm[2], j10 = Jm[3], j11 = Jm[4], j12 = Jm[5], j20 = Jm[6], j21 = Jm[7],
+                     j22 = Jm[8];
+        const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+        const double id = 1.0 / det;
+        Jm[0] = (j11 * j22 - j12 * j21) * id;
+        Jm[1] = (j02 * j21 - j01 * j22) * id;
+        Jm[2] = (j01 * j12 - j11 * j02) * id;
+        Jm[3] = (j12 * j20 - j22 * j10) * id;
+        Jm[4] = (j00 * j22 - j02 * j20) * id;
+        Jm[5] = (j02 * j10 - j00 * j12) * id;
+        Jm[6] = (j10 * j21 - j11 * j20) * id;
+        Jm[7] = (j01 * j20 - j21 * j00) * id;
+        Jm[8] = (j00 * j11 - j10 * j01) * id;
+        W[W_D + lane] = s_w[q0 + lane] * det;  // w_q det J (the -k factor is applied where it is used)
+      } else if (lane < H27_QC) {
+        W[W_D + lane] = 0.0;
+        for (int z = 0; z < 9; ++z) W[W_J + lane * 9 + z] = 0.0;  // rows of a short last chunk contribute nothing
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- 2c. Bc[(ql,s)][a] = sum_m dN[q][a][m] Jinv[q][m][s]
+      for (int t = lane; t < H27_QC * 3 * 27; t += 64) {
+        const int r = t / 27, a = t % 27, ql = r / 3, s = r % 3;
+        double v = 0.0;
+        if (ql < nqc) {
+          const double* dn = s_dN + (q0 + ql) * 81 + 3 * a;
+          const double* Ji = W + W_J + ql * 9;
+          v = dn[0] * Ji[0 + s] + dn[1] * Ji[3 + s] + dn[2] * Ji[6 + s];
+        }
+        W[W_B + r * H27_BCOLS + swz(r, a)] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (MATRIX) {
+        // ---- 3. Ke += Bc^T D Bc on the matrix cores: 7 k-steps x 3 tiles
+#pragma unroll
+        for (int ks = 0; ks < H27_BROWS / 4; ++ks) {
+          const int r = 4 * ks + (lane >> 4);
+          const int c = lane & 15;
+          const double v0 = W[W_B + r * H27_BCOLS + swz(r, c)];
+          const double v1 = W[W_B + r * H27_BCOLS + swz(r, c + 16)];
+          const double dr = (r < 27) ? -A.kcond * W[W_D + r / 3] : 0.0;
+          const double a0 = v0 * dr, a1 = v1 * dr;
+          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
+          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
+          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
+        }
+      } else {
+        // ---- 3'. residual: fe[a] += sum_q w det ( -k gradN_a . gradT + N_a s_q )
+        if (lane < 27) {  // lanes (ql, m): gxi = sum_b dN[q][b][m] T_b
+          const int ql = lane / 3, m = lane % 3;
+          double acc = 0.0;
+          if (ql < nqc) {
+            const double* dn = s_dN + (q0 + ql) * 81 + m;
+#pragma unroll 9
+            for (int b = 0; b < 27; ++b) acc += dn[3 * b] * W[W_T + b];
+          }
+          W[W_G + lane] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        double gT = 0.0, sq = 0.0;
+        if (lane < 27) {  // lanes (ql, s): gradT_s = sum_m gxi_m Jinv[m][s], scaled by -k w det
+          const int ql = lane / 3, s = lane % 3;
+          const double* Ji = W + W_J + ql * 9;
+          gT = W[W_G + 3 * ql + 0] * Ji[0 + s] + W[W_G + 3 * ql + 1] * Ji[3 + s] + W[W_G + 3 * ql + 2] * Ji[6 + s];
+          gT *= -A.kcond * W[W_D + ql];
+        }
+        if (lane < nqc) {  // lanes ql: source at the quadrature point, times w det
+          const double* nn = s_N + (q0 + lane) * 27;
+          for (int b = 0; b < 27; ++b) sq += nn[b] * W[W_T + 28 + b];
+          sq *= W[W_D + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 27) W[W_G + lane] = gT;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 27) {
+          double acc = 0.0;
+          for (int r = 0; r < 3 * nqc; ++r) acc += W[W_B + r * H27_BCOLS + swz(r, lane)] * W[W_G + r];
+          fe += acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < H27_QC) W[W_G + lane] = (lane < nqc) ? sq : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 27) {
+          double acc = 0.0;
+          for (int ql = 0; ql < nqc; ++ql) acc += s_N[(q0 + ql) * 27 + lane] * W[W_G + ql];
+          fe += acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // ---- 4. colour-safe scatter (plain read-modify-write: no other element of this launch shares a node)
+    if (MATRIX) {
+      const int c = lane & 15, rq = lane >> 4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ra = rq + 4 * reg;  // row inside the 16 x 16 tile (f64 MFMA C/D map: row = (lane>>4) + 4*reg)
+        // tile (0,0): a = ra, b = c ; tile (0,1): a = ra, b = 16 + c (and its transpose) ; tile (1,1): a = 16+ra, b = 16+c
+        const double v00 = C00[reg], v01 = C01[reg], v11 = C11[reg];
+#define H27_ADD(aa, bb, vv)                                                                                    \
+  do {                                                                                                         \
+    const int _a = (aa), _b = (bb);                                                                            \
+    if (_a < 27 && _b < 27) {                                                                                  \
+      const int32_t* ia = info + 8 * _a;                                                                       \
+      const int32_t* ib = info + 8 * _b;                                                                       \
+      const int64_t slot = rowbase[_a] + ((int64_t)(ib[5] - ia[0]) * ia[3] + (ib[6] - ia[1])) * ia[4] + (ib[7] - ia[2]); \
+      out[slot] += (vv);                                                                                       \
+    }                                                                                                          \
+  } while (0)
+        H27_ADD(ra, c, v00);
+        H27_ADD(ra, 16 + c, v01);
+        H27_ADD(16 + c, ra, v01);  // lower-left tile = transpose of the upper-right one
+        H27_ADD(16 + ra, 16 + c, v11);
+#undef H27_ADD
+      }
+    } else if (lane < 27) {
+      const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
+      if (gi >= B.plo && gi < B.phi) out[(int64_t)(gi - B.plo) * B.plane_len + (int64_t)gj * B.m2 + gk] += fe;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- Robin faces (hex-27): one thread per boundary face element, 9 face nodes, ng x ng Gauss points.
+// colour = parity of the face element in its two tangential directions (4 launches per brick face).
+struct Face27Args {
+  BrickView B;
+  const Hex27Tables* tab;
+  double h, Tenv;
+  int nd, side, colour, ng;
+};
+
+template <bool MATRIX>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const double* __restrict__ xstar,
+                                                              double* __restrict__ out) {
+  const BrickView& B = A.B;
+  const int ne[3] = {B.ne0, B.ne1, B.ne2};
+  const int t1 = (A.nd + 1) % 3, t2 = (A.nd + 2) % 3;
+  const int c1 = A.colour & 1, c2 = A.colour >> 1;
+  const int n1 = (ne[t1] - c1 + 1) >> 1, n2 = (ne[t2] - c2 + 1) >> 1;
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n1 <= 0 || n2 <= 0 || f >= (int64_t)n1 * n2) return;
+  int E[3];
+  E[A.nd] = A.side ? ne[A.nd] - 1 : 0;
+  E[t1] = 2 * (int)(f % n1) + c1;
+  E[t2] = 2 * (int)(f / n1) + c2;
+  int g[9][3];
+  double Xf[9][3], Tf[9];
+  for (int c = 0; c < 9; ++c) {
+    g[c][A.nd] = A.side ? 2 * ne[A.nd] : 0;
+    g[c][t1] = 2 * E[t1] + c % 3;
+    g[c][t2] = 2 * E[t2] + c / 3;
+    const int64_t ci = brick_cindex(B, g[c][0], g[c][1], g[c][2]);
+    Xf[c][0] = B.X0[ci];
+    Xf[c][1] = B.X1[ci];
+    Xf[c][2] = B.X2[ci];
+    if (!MATRIX) Tf[c] = xstar[brick_xindex(B, 0, g[c][0], g[c][1], g[c][2])];
+  }
+  for (int a = 0; a < 9; ++a) {
+    if (g[a][0] < B.plo || g[a][0] >= B.phi) continue;  // only owned rows
+    double macc[9];
+    for (int b = 0; b < 9; ++b) macc[b] = 0.0;
+    double racc = 0.0;
+    for (int q = 0; q < A.ng * A.ng; ++q) {
+      double ta[3] = {0, 0, 0}, tb[3] = {0, 0, 0};
+      for (int c = 0; c < 9; ++c)
+        for (int i = 0; i < 3; ++i) {
+          ta[i] += A.tab->fdN[q][c][0] * Xf[c][i];
+          tb[i] += A.tab->fdN[q][c][1] * Xf[c][i];
+        }
+      const double r0 = ta[1] * tb[2] - ta[2] * tb[1], r1 = -ta[0] * tb[2] + ta[2] * tb[0], r2 = ta[0] * tb[1] - ta[1] * tb[0];
+      const double ws = A.tab->fw[q] * sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+      const double na = A.tab->fN[q][a];
+      if (MATRIX) {
+        for (int b = 0; b < 9; ++b) macc[b] += -A.h * ws * na * A.tab->fN[q][b];
+      } else {
+        double Tq = 0.0;
+        for (int c = 0; c < 9; ++c) Tq += A.tab->fN[q][c] * Tf[c];
+        racc += ws * na * A.h * (A.Tenv - Tq);
+      }
+    }
+    if (MATRIX) {
+      const int gi = g[a][0], gj = g[a][1], gk = g[a][2];
+      const int64_t base = brick_prefix(B, gi, gj, gk);
+      const int lo0 = B.lo0[gi], lo1 = B.lo1[gj], lo2 = B.lo2[gk], cc1 = B.c1[gj], cc2 = B.c2[gk];
+      for (int b = 0; b < 9; ++b)
+        out[base + ((int64_t)(g[b][0] - lo0) * cc1 + (g[b][1] - lo1)) * cc2 + (g[b][2] - lo2)] += macc[b];
+    } else {
+      out[(int64_t)(g[a][0] - B.plo) * B.plane_len + (int64_t)g[a][1] * B.m2 + g[a][2]] += racc;
+    }
+  }
+}
+
+static size_t hex27_lds_bytes(int nq, bool matrix) {
+  return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + 4 * (size_t)W_SIZE);
+}
+
+static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix, double h, double Tenv, uint32_t robin,
+                              const double* xstar, double* out) {
+  if (h == 0.0 || robin == 0u) return MFEM_OK;
+  BrickView B = mfem_brick_view(m, 1);
+  for (int nd = 0; nd < 3; ++nd)
+    for (int side = 0; side < 2; ++side) {
+      const int id = (nd == 0) ? (side ? 3 : 5) : (nd == 1) ? (side ? 4 : 2) : (side ? 6 : 1);
+      if (!(robin & (1u << (id - 1)))) continue;
+      const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+      for (int colour = 0; colour < 4; ++colour) {
+        const int n1 = (m->ne[t1] - (colour & 1) + 1) >> 1, n2 = (m->ne[t2] - (colour >> 1) + 1) >> 1;
+        if (n1 <= 0 || n2 <= 0) continue;
+        Face27Args A{B, g_tab, h, Tenv, nd, side, colour, m->ng};
+        const int grid = (int)(((int64_t)n1 * n2 + MFEM_BLOCK - 1) / MFEM_BLOCK);
+        if (matrix)
+          hipLaunchKernelGGL(k_hex27_faces<true>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A, xstar, out);
+        else
+          hipLaunchKernelGGL(k_hex27_faces<false>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A, xstar, out);
+        MFEM_CHECK_LAUNCH();
+      }
+    }
+  return MFEM_OK;
+}
+
+int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s* Acsr, const mfem_thermal_params* p,
+                                double* vals) {
+  MFEM_REQUIRE(m->plo == 0 && m->phi == m->m[0], "hex-27 assembly does not support slabs yet");
+  const int nq = m->ng * m->ng * m->ng;
+  int rc = hex27_upload_tables(m->ng);
+  if (rc) return rc;
+  const size_t lds = hex27_lds_bytes(nq, true);
+  MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
+  BrickView B = mfem_brick_view(m, 1);
+  for (int colour = 0; colour < 8; ++colour) {
+    const int64_t n0 = (m->ne[0] - (colour & 1) + 1) >> 1, n1 = (m->ne[1] - ((colour >> 1) & 1) + 1) >> 1,
+                  n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
+    const int64_t ne = n0 * n1 * n2;
+    if (ne <= 0) continue;
+    Hex27Args A{B, g_tab, p->k, colour, nq};
+    int64_t grid = (ne + 3) / 4;
+    const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (8 waves) per CU, persistent over the colour's elements
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(MFEM_BLOCK), lds, ctx->stream, A, nullptr, nullptr, vals);
+    MFEM_CHECK_LAUNCH();
+  }
+  return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
+}
+
+int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem_thermal_params* p, const double* x_star,
+                                const double* s, double* residue) {
+  MFEM_REQUIRE(m->plo == 0 && m->phi == m->m[0], "hex-27 residual does not support slabs yet");
+  const int nq = m->ng * m->ng * m->ng;
+  int rc = hex27_upload_tables(m->ng);
+  if (rc) return rc;
+  const size_t lds = hex27_lds_bytes(nq, false);
+  MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MFEM_CHECK_HIP(hipMemsetAsync(residue, 0, sizeof(double) * (size_t)m->n_owned, ctx->stream));
+  BrickView B = mfem_brick_view(m, 1);
+  for (int colour = 0; colour < 8; ++colour) {
+    const int64_t n0 = (m->ne[0] - (colour & 1) + 1) >> 1, n1 = (m->ne[1] - ((colour >> 1) & 1) + 1) >> 1,
+                  n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
+    const int64_t ne = n0 * n1 * n2;
+    if (ne <= 0) continue;
+    Hex27Args A{B, g_tab, p->k, colour, nq};
+    int64_t grid = (ne + 3) / 4;
+    const int64_t cap = (int64_t)ctx->num_cus * 2;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_hex27<false>, dim3((int)grid), dim3(MFEM_BLOCK), lds, ctx->stream, A, x_star, s, residue);
+    MFEM_CHECK_LAUNCH();
+  }
+  return hex27_launch_faces(ctx, m, false, p->h, p->Tenv, p->robin_faces, x_star, residue);
+}

@@ -613,12 +613,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_residual(BrickView B,
 }
 
 int mfem_hex8_upload_tables(int ng);
+int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s* A, const mfem_thermal_params* p, double* vals);
+int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem_thermal_params* p, const double* x_star,
+                                const double* s, double* residue);
 
 extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
                                            double* vals) {
   MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
-  MFEM_REQUIRE(m->p == 1, "fused thermal assembly is implemented for hex-8 (itp_order 1); hex-27 uses the MFMA path");
   MFEM_REQUIRE(A->n == m->n_owned, "pattern was not built for 1 field on this brick");
+  if (m->p == 2) return mfem_hex27_assemble_thermal(ctx, m, A, p, vals);  // FP64 MFMA Ke = B^T D B path
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
@@ -631,7 +634,7 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
 extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const mfem_thermal_params* p,
                                            const double* x_star, const double* s, double* residue) {
   MFEM_REQUIRE(ctx && m && p && x_star && residue, "null argument");
-  MFEM_REQUIRE(m->p == 1, "fused thermal residual is implemented for hex-8 (itp_order 1)");
+  if (m->p == 2) return mfem_hex27_residual_thermal(ctx, m, p, x_star, s, residue);
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);

@@ -1,0 +1,77 @@
+"""GPU parity: hex-27 (Lagrange-2) thermal path -- FP64 MFMA Ke = B^T D B with colour-partitioned scatter."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+K_COND, H, TENV, SRC = 0.6, 25.0, 293.15, 1600.0
+
+
+def _oracle(x, n, itg=5, distort=False, faces=None):
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    disc = re_.initialize_classical_element(3, "CUBE", 2, 1, itg)
+    msh = om.lattice_mesh(x, n, disc)
+    if distort:
+        c = msh.coords
+        msh.coords = c + 0.02 * np.stack([np.sin(3 * c[:, 1]) * np.cos(c[:, 2]), np.sin(2 * c[:, 0] + c[:, 2]), c[:, 0] * c[:, 1]], axis=1)
+    fac = om.boundary_facets_structured(x, n, 3)
+    if faces is not None:
+        fac = fac.select(np.isin(fac.element_eindex, faces))
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, K_COND), [(fac, problems.thermal_convection(H, TENV))])
+    od.controlpoints["s"] = np.full(msh.ncp, SRC)
+    od.update_time()
+    od.K_linear_func()
+    return od
+
+
+@pytest.mark.parametrize("n,itg,distort,faces", [((1, 1, 1), 5, False, None), ((2, 2, 2), 5, False, None), ((3, 2, 4), 5, True, None),
+                                                 ((2, 3, 1), 4, True, [0, 3, 5]), ((3, 3, 3), 3, True, None), ((2, 1, 2), 7, True, None)])
+def test_hex27_pattern_matrix_residual(mf, n, itg, distort, faces):
+    import torch
+
+    x = (1.0, 1.5, 0.75)
+    od = _oracle(x, n, itg, distort, faces)
+    rng = np.random.default_rng(3)
+    od.x_star[:] = 300.0 + 10.0 * rng.standard_normal(od.basicfield_size)
+    od.K_nonlinear_func()
+    brick = mf.make_Brick(x, n, 2, itg)
+    if distort:
+        for d in range(3):
+            brick.coords_view(d).copy_(torch.tensor(od.mesh.coords[:, d], device="cuda"))
+    A = brick.pattern(1)
+    assert np.array_equal(A.rowptr.cpu().numpy(), od.pattern.rowptr)
+    assert np.array_equal(A.colidx.cpu().numpy(), od.pattern.colidx)
+    bits = 0x3F if faces is None else sum(1 << f for f in faces)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, bits).cpu().numpy()
+    assert np.max(np.abs(K - od.K_linear)) <= 1e-12 * np.max(np.abs(od.K_linear))
+    s = torch.full((brick.ncp,), SRC, dtype=torch.float64, device="cuda")
+    R = brick.residual_thermal(torch.tensor(od.x_star, device="cuda"), K_COND, H, TENV, bits, s=s).cpu().numpy()
+    assert np.max(np.abs(R - od.residue)) <= 1e-11 * np.max(np.abs(od.residue))
+
+
+def test_hex27_golden_fixture_and_solve(mf):
+    import torch
+
+    z = np.load(os.path.join(GOLD, "oracle_thermal_hex27_2x2x2.npz"))
+    brick = mf.make_Brick(tuple(z["x"]), tuple(int(v) for v in z["n"]), 2, 5)
+    dom = mf.ThermalDomain(brick, K_COND, H, TENV)
+    dom.s.fill_(SRC)
+    dom.converge_tol = 1e-9
+    dom.linear_solver = lambda gf: mf.iterative_Solve(gf.A, gf.K_total, gf.residue, 1e-13, Sv_func=mf.cg_, maxiter=2000, max_pass=3)[0]
+    hist = dom.update_OneStep()
+    assert np.max(np.abs(dom.K_linear.cpu().numpy() - z["K"])) <= 1e-12 * np.abs(z["K"]).max()
+    assert len(hist) == 2 and hist[1] < 1e-9
+    assert np.max(np.abs(dom.x.cpu().numpy() - z["T"])) <= 1e-10 * np.abs(z["T"]).max()
+
+
+def test_hex27_matrix_is_symmetric(mf):
+    import scipy.sparse as sp
+
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (4, 3, 3), 2, 5)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F).cpu().numpy()
+    M = sp.csr_matrix((K, A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=(A.n, A.n))
+    assert abs(M - M.T).max() <= 1e-13 * abs(M).max()
