@@ -2,10 +2,10 @@
 //   Ke = B^T D B,   B[(q,s), a] = dN_a/dx_s (q)  (81 x 27),   D = diag(-k w_q det J_q),
 // so it runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), one wave per element:
 //   * the element's 27 nodal coordinates and its row descriptors are staged in per-wave LDS;
-//   * quadrature points are processed in chunks of 9 (27 rows of B + 1 zero row = 7 MFMA k-steps); for each
-//     chunk the wave builds J (81 entries over 64 lanes), inverts it (adjugate, inv_Jac_3D), and writes the
-//     chunk of B = dN/dxi * J^-1 into a 28 x 32 LDS tile whose two 16-column halves are XOR-swapped on odd rows
-//     (conflict-free ds_read_b64 of MFMA fragments);
+//   * the wave builds J at all quadrature points (one (q,i) row per lane), inverts it (adjugate, inv_Jac_3D),
+//     and forms each MFMA fragment of B = dN/dxi * J^-1 on the fly from the reference table in LDS (3 FMAs per
+//     fragment element) -- B itself is never materialised, which keeps the per-wave LDS footprint at ~9 KB
+//     and lets 16 waves share a CU;
 //   * Ke (27 x 27 padded to 32 x 32) = 2 x 2 accumulator tiles; the lower-left tile is the transpose of the
 //     upper-right one and is not computed: 3 tiles x 21 k-steps = 63 MFMAs per element;
 //   * scatter into the global CSR is race-free WITHOUT atomics through the parity colouring of the structured
@@ -19,9 +19,6 @@
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-#define H27_QC 9            // quadrature points per chunk
-#define H27_BROWS 28        // 3*QC rows + 1 zero row
-#define H27_BCOLS 32
 #define H27_MAXQ 64
 
 struct Hex27Tables {        // device-global, filled once per ng
@@ -101,15 +98,18 @@ static int hex27_upload_tables(int ng) {
   return MFEM_OK;
 }
 
-// per-wave LDS carve-up (doubles)
-#define W_X 0                       // X[27][3]
-#define W_J (W_X + 84)              // J / Jinv [QC][9]
-#define W_D (W_J + 84)              // d[QC] (-k w det), padded to 12
-#define W_G (W_D + 12)              // gT[27] (+ pad)
-#define W_T (W_G + 28)              // nodal T[27], s[27]
-#define W_B (W_T + 56)              // Bc[28][32]
-#define W_INFO (W_B + H27_BROWS * H27_BCOLS)   // int64 rowbase[27] + int32 (lo0,lo1,lo2,c1,c2,gi,gj,gk)[27]
-#define W_SIZE (W_INFO + 27 + 27 * 4 + 1)      // 27 int64 + 27*8 int32 = 27 + 108 doubles
+// per-wave LDS carve-up (doubles), sized from nq (even-padded): X[27][3] | J->Jinv [nq][9] | w det [nq] |
+// residual scratch [nq][3] + source [nq] | nodal T[28], s[28] | int64 rowbase[27] + int32 info[27][8]
+__host__ __device__ inline int h27_pad(int v) { return (v + 1) & ~1; }
+#define W_X 0
+#define W_J (W_X + 84)
+#define W_D (W_J + h27_pad(nq * 9))
+#define W_G (W_D + h27_pad(nq))
+#define W_T (W_G + 4 * h27_pad(nq))
+#define W_INFO (W_T + 56)
+#define W_SIZE (W_INFO + 27 + 27 * 4 + 1)
+#define H27_WAVES 8                  // waves per workgroup (they share the reference tables in LDS)
+#define H27_THREADS (64 * H27_WAVES)
 
 struct Hex27Args {
   BrickView B;
@@ -119,46 +119,46 @@ struct Hex27Args {
   int nq;
 };
 
-__device__ __forceinline__ int swz(int r, int col) { return col ^ ((r & 1) << 4); }
-
 // Element of this colour with running index e -> (I,J,K); returns false past the end.
 __device__ __forceinline__ bool colour_element(const BrickView& B, int colour, int64_t e, int& I, int& J, int& K) {
   const int cx = colour & 1, cy = (colour >> 1) & 1, cz = colour >> 2;
   const int n0 = (B.ne0 - cx + 1) >> 1, n1 = (B.ne1 - cy + 1) >> 1, n2 = (B.ne2 - cz + 1) >> 1;
   if (n0 <= 0 || n1 <= 0 || n2 <= 0 || e >= (int64_t)n0 * n1 * n2) return false;
-  K = 2 * (int)(e % n2) + cz;
-  J = 2 * (int)((e / n2) % n1) + cy;
-  I = 2 * (int)(e / ((int64_t)n1 * n2)) + cx;
+  const int ei = (int)e;  // element counts fit int32 (control-point ids do)
+  K = 2 * (ei % n2) + cz;
+  J = 2 * ((ei / n2) % n1) + cy;
+  I = 2 * (ei / (n1 * n2)) + cx;
   return true;
 }
 
 template <bool MATRIX>
-__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
-                                                       const double* __restrict__ src, double* __restrict__ out) {
+__global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
+                                                        const double* __restrict__ src, double* __restrict__ out) {
   extern __shared__ double lds[];
-  // block-shared tables
+  // workgroup-shared reference tables
   double* s_dN = lds;                           // [nq][27][3]
   double* s_N = s_dN + A.nq * 81;               // [nq][27]   (residual only)
   double* s_w = s_N + (MATRIX ? 0 : A.nq * 27); // [nq]
   double* wave_base = s_w + ((A.nq + 1) & ~1);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < A.nq * 81; i += MFEM_BLOCK) s_dN[i] = (&A.tab->dN[0][0][0])[i];
+  const int nq = A.nq;
+  for (int i = tid; i < nq * 81; i += H27_THREADS) s_dN[i] = (&A.tab->dN[0][0][0])[i];
   if (!MATRIX)
-    for (int i = tid; i < A.nq * 27; i += MFEM_BLOCK) s_N[i] = (&A.tab->N[0][0])[i];
-  for (int i = tid; i < A.nq; i += MFEM_BLOCK) s_w[i] = A.tab->w[i];
+    for (int i = tid; i < nq * 27; i += H27_THREADS) s_N[i] = (&A.tab->N[0][0])[i];
+  for (int i = tid; i < nq; i += H27_THREADS) s_w[i] = A.tab->w[i];
   double* W = wave_base + (size_t)wv * W_SIZE;
-  for (int i = lane; i < H27_BROWS * H27_BCOLS; i += 64) W[W_B + i] = 0.0;  // pads stay zero forever
   __syncthreads();
   const BrickView& B = A.B;
   int64_t* rowbase = reinterpret_cast<int64_t*>(W + W_INFO);
   int32_t* info = reinterpret_cast<int32_t*>(W + W_INFO + 27);
-  const int nwaves = gridDim.x * (MFEM_BLOCK / 64);
-  const int nchunk = (A.nq + H27_QC - 1) / H27_QC;
+  const int nwaves = gridDim.x * H27_WAVES;
+  const int nrows = 3 * nq;                  // rows of B
+  const int nksteps = (nrows + 3) >> 2;      // MFMA k-steps (4 rows each; rows >= nrows contribute zero)
 
-  for (int64_t e = (int64_t)blockIdx.x * (MFEM_BLOCK / 64) + wv;; e += nwaves) {
+  for (int64_t e = (int64_t)blockIdx.x * H27_WAVES + wv;; e += nwaves) {
     int I, J, K;
     if (!colour_element(B, A.colour, e, I, J, K)) break;  // wave-uniform
-    // ---- 1. nodes: coordinates + row descriptors
+    // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
     if (lane < 27) {
       const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
       const int64_t c = brick_cindex(B, gi, gj, gk);
@@ -178,140 +178,134 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27(Hex27Args A, const double*
       }
     }
     __builtin_amdgcn_wave_barrier();
-    d4_t C00 = {0, 0, 0, 0}, C01 = {0, 0, 0, 0}, C11 = {0, 0, 0, 0};
-    double fe = 0.0;  // residual entry of node `lane` (< 27)
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int q0 = ch * H27_QC;
-      const int nqc = (A.nq - q0) < H27_QC ? (A.nq - q0) : H27_QC;
-      // ---- 2a. J[q][i][m] = sum_a dN[q][a][m] X[a][i]   (81 entries over 64 lanes)
-      for (int t = lane; t < nqc * 9; t += 64) {
-        const int ql = t / 9, im = t % 9, i = im / 3, m = im % 3;
-        const double* dn = s_dN + (q0 + ql) * 81 + m;
-        double acc = 0.0;
+    // ---- 2a. J[q][i][0..2] = sum_a dN[q][a][0..2] X[a][i] : one (q,i) pair per lane and pass
+    for (int t = lane; t < nq * 3; t += 64) {
+      const int q = t / 3, i = t - 3 * q;
+      const double* dn = s_dN + q * 81;
+      double j0 = 0.0, j1 = 0.0, j2 = 0.0;
 #pragma unroll 9
-        for (int a = 0; a < 27; ++a) acc += dn[3 * a] * W[W_X + 3 * a + i];
-        W[W_J + ql * 9 + im] = acc;
+      for (int a = 0; a < 27; ++a) {
+        const double xa = W[W_X + 3 * a + i];
+        j0 += dn[3 * a + 0] * xa;
+        j1 += dn[3 * a + 1] * xa;
+        j2 += dn[3 * a + 2] * xa;
       }
-      __builtin_amdgcn_wave_barrier();
-      // ---- 2b. det, inverse (adjugate), d = -k w det ; Jinv overwrites J as [m][s]
-      if (lane < nqc) {
-        double* Jm = W + W_J + lane * 9;
-        const double j00 = Jm[0], j01 = Jm[1], j02 = Jm[2], j10 = Jm[3], j11 = Jm[4], j12 = Jm[5], j20 = Jm[6], j21 = Jm[7],
-                     j22 = Jm[8];
-        const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
-        const double id = 1.0 / det;
-        Jm[0] = (j11 * j22 - j12 * j21) * id;
-        Jm[1] = (j02 * j21 - j01 * j22) * id;
-        Jm[2] = (j01 * j12 - j11 * j02) * id;
-        Jm[3] = (j12 * j20 - j22 * j10) * id;
-        Jm[4] = (j00 * j22 - j02 * j20) * id;
-        Jm[5] = (j02 * j10 - j00 * j12) * id;
-        Jm[6] = (j10 * j21 - j11 * j20) * id;
-        Jm[7] = (j01 * j20 - j21 * j00) * id;
-        Jm[8] = (j00 * j11 - j10 * j01) * id;
-        W[W_D + lane] = s_w[q0 + lane] * det;  // w_q det J (the -k factor is applied where it is used)
-      } else if (lane < H27_QC) {
-        W[W_D + lane] = 0.0;
-        for (int z = 0; z < 9; ++z) W[W_J + lane * 9 + z] = 0.0;  // rows of a short last chunk contribute nothing
-      }
-      __builtin_amdgcn_wave_barrier();
-      // ---- 2c. Bc[(ql,s)][a] = sum_m dN[q][a][m] Jinv[q][m][s]
-      for (int t = lane; t < H27_QC * 3 * 27; t += 64) {
-        const int r = t / 27, a = t % 27, ql = r / 3, s = r % 3;
-        double v = 0.0;
-        if (ql < nqc) {
-          const double* dn = s_dN + (q0 + ql) * 81 + 3 * a;
-          const double* Ji = W + W_J + ql * 9;
-          v = dn[0] * Ji[0 + s] + dn[1] * Ji[3 + s] + dn[2] * Ji[6 + s];
-        }
-        W[W_B + r * H27_BCOLS + swz(r, a)] = v;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (MATRIX) {
-        // ---- 3. Ke += Bc^T D Bc on the matrix cores: 7 k-steps x 3 tiles
-#pragma unroll
-        for (int ks = 0; ks < H27_BROWS / 4; ++ks) {
-          const int r = 4 * ks + (lane >> 4);
-          const int c = lane & 15;
-          const double v0 = W[W_B + r * H27_BCOLS + swz(r, c)];
-          const double v1 = W[W_B + r * H27_BCOLS + swz(r, c + 16)];
-          const double dr = (r < 27) ? -A.kcond * W[W_D + r / 3] : 0.0;
-          const double a0 = v0 * dr, a1 = v1 * dr;
-          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
-          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
-          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
-        }
-      } else {
-        // ---- 3'. residual: fe[a] += sum_q w det ( -k gradN_a . gradT + N_a s_q )
-        if (lane < 27) {  // lanes (ql, m): gxi = sum_b dN[q][b][m] T_b
-          const int ql = lane / 3, m = lane % 3;
-          double acc = 0.0;
-          if (ql < nqc) {
-            const double* dn = s_dN + (q0 + ql) * 81 + m;
-#pragma unroll 9
-            for (int b = 0; b < 27; ++b) acc += dn[3 * b] * W[W_T + b];
-          }
-          W[W_G + lane] = acc;
-        }
-        __builtin_amdgcn_wave_barrier();
-        double gT = 0.0, sq = 0.0;
-        if (lane < 27) {  // lanes (ql, s): gradT_s = sum_m gxi_m Jinv[m][s], scaled by -k w det
-          const int ql = lane / 3, s = lane % 3;
-          const double* Ji = W + W_J + ql * 9;
-          gT = W[W_G + 3 * ql + 0] * Ji[0 + s] + W[W_G + 3 * ql + 1] * Ji[3 + s] + W[W_G + 3 * ql + 2] * Ji[6 + s];
-          gT *= -A.kcond * W[W_D + ql];
-        }
-        if (lane < nqc) {  // lanes ql: source at the quadrature point, times w det
-          const double* nn = s_N + (q0 + lane) * 27;
-          for (int b = 0; b < 27; ++b) sq += nn[b] * W[W_T + 28 + b];
-          sq *= W[W_D + lane];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 27) W[W_G + lane] = gT;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 27) {
-          double acc = 0.0;
-          for (int r = 0; r < 3 * nqc; ++r) acc += W[W_B + r * H27_BCOLS + swz(r, lane)] * W[W_G + r];
-          fe += acc;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < H27_QC) W[W_G + lane] = (lane < nqc) ? sq : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 27) {
-          double acc = 0.0;
-          for (int ql = 0; ql < nqc; ++ql) acc += s_N[(q0 + ql) * 27 + lane] * W[W_G + ql];
-          fe += acc;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+      W[W_J + q * 9 + 3 * i + 0] = j0;
+      W[W_J + q * 9 + 3 * i + 1] = j1;
+      W[W_J + q * 9 + 3 * i + 2] = j2;
     }
-    // ---- 4. colour-safe scatter (plain read-modify-write: no other element of this launch shares a node)
+    __builtin_amdgcn_wave_barrier();
+    // ---- 2b. det, inverse (adjugate, inv_Jac_3D), w det ; Jinv overwrites J as [m][s]
+    for (int q = lane; q < nq; q += 64) {
+      double* Jm = W + W_J + q * 9;
+      const double j00 = Jm[0], j01 = Jm[1], j02 = Jm[2], j10 = Jm[3], j11 = Jm[4], j12 = Jm[5], j20 = Jm[6], j21 = Jm[7],
+                   j22 = Jm[8];
+      const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+      const double id = 1.0 / det;
+      Jm[0] = (j11 * j22 - j12 * j21) * id;
+      Jm[1] = (j02 * j21 - j01 * j22) * id;
+      Jm[2] = (j01 * j12 - j11 * j02) * id;
+      Jm[3] = (j12 * j20 - j22 * j10) * id;
+      Jm[4] = (j00 * j22 - j02 * j20) * id;
+      Jm[5] = (j02 * j10 - j00 * j12) * id;
+      Jm[6] = (j10 * j21 - j11 * j20) * id;
+      Jm[7] = (j01 * j20 - j21 * j00) * id;
+      Jm[8] = (j00 * j11 - j10 * j01) * id;
+      W[W_D + q] = s_w[q] * det;
+    }
+    __builtin_amdgcn_wave_barrier();
     if (MATRIX) {
-      const int c = lane & 15, rq = lane >> 4;
+      // ---- 3. Ke = B^T D B on the matrix cores.  MFMA fragments are formed on the fly:
+      //      lane (k = lane>>4, c = lane&15) of k-step ks holds row r = 4 ks + k of B at columns c and c + 16,
+      //      B[(q,s)][a] = sum_m dN[q][a][m] Jinv[q][m][s]; the A operand is the same row scaled by -k w det.
+      d4_t C00 = {0, 0, 0, 0}, C01 = {0, 0, 0, 0}, C11 = {0, 0, 0, 0};
+      const int c = lane & 15, kl = lane >> 4;
+      const bool hi_ok = (c + 16) < 27;
+      for (int ks = 0; ks < nksteps; ++ks) {
+        const int r = 4 * ks + kl;
+        double v0 = 0.0, v1 = 0.0, dr = 0.0;
+        if (r < nrows) {
+          const int q = r / 3, sidx = r - 3 * q;
+          const double* Ji = W + W_J + q * 9 + sidx;
+          const double i0 = Ji[0], i1 = Ji[3], i2 = Ji[6];
+          const double* dn = s_dN + q * 81 + 3 * c;
+          v0 = dn[0] * i0 + dn[1] * i1 + dn[2] * i2;
+          if (hi_ok) v1 = dn[48] * i0 + dn[49] * i1 + dn[50] * i2;
+          dr = -A.kcond * W[W_D + q];
+        }
+        const double a0 = v0 * dr, a1 = v1 * dr;
+        C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
+        C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
+        C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
+      }
+      // ---- 4. colour-safe scatter: 16 entries per lane; all slots of one element are distinct, so the loads
+      //      are issued together, then the stores (plain read-modify-write, no atomics).
+      const int rq = kl;
+      int64_t slot[16];
+      double val[16];
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int ra = rq + 4 * reg;  // row inside the 16 x 16 tile (f64 MFMA C/D map: row = (lane>>4) + 4*reg)
-        // tile (0,0): a = ra, b = c ; tile (0,1): a = ra, b = 16 + c (and its transpose) ; tile (1,1): a = 16+ra, b = 16+c
-        const double v00 = C00[reg], v01 = C01[reg], v11 = C11[reg];
-#define H27_ADD(aa, bb, vv)                                                                                    \
-  do {                                                                                                         \
-    const int _a = (aa), _b = (bb);                                                                            \
-    if (_a < 27 && _b < 27) {                                                                                  \
-      const int32_t* ia = info + 8 * _a;                                                                       \
-      const int32_t* ib = info + 8 * _b;                                                                       \
-      const int64_t slot = rowbase[_a] + ((int64_t)(ib[5] - ia[0]) * ia[3] + (ib[6] - ia[1])) * ia[4] + (ib[7] - ia[2]); \
-      out[slot] += (vv);                                                                                       \
-    }                                                                                                          \
-  } while (0)
-        H27_ADD(ra, c, v00);
-        H27_ADD(ra, 16 + c, v01);
-        H27_ADD(16 + c, ra, v01);  // lower-left tile = transpose of the upper-right one
-        H27_ADD(16 + ra, 16 + c, v11);
-#undef H27_ADD
+        const int ra = rq + 4 * reg;  // f64 MFMA C/D map: row = (lane>>4) + 4*reg, col = lane & 15
+        const int aa[4] = {ra, ra, 16 + c, 16 + ra};
+        const int bb[4] = {c, 16 + c, ra, 16 + c};  // tiles (0,0), (0,1), (1,0) = transpose of (0,1), (1,1)
+        const double vv[4] = {C00[reg], C01[reg], C01[reg], C11[reg]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int _a = aa[t], _b = bb[t];
+          int64_t sl = -1;
+          if (_a < 27 && _b < 27) {
+            const int32_t* ia = info + 8 * _a;
+            const int32_t* ib = info + 8 * _b;
+            sl = rowbase[_a] + ((int64_t)(ib[5] - ia[0]) * ia[3] + (ib[6] - ia[1])) * ia[4] + (ib[7] - ia[2]);
+          }
+          slot[4 * reg + t] = sl;
+          val[4 * reg + t] = vv[t];
+        }
       }
-    } else if (lane < 27) {
-      const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
-      if (gi >= B.plo && gi < B.phi) out[(int64_t)(gi - B.plo) * B.plane_len + (int64_t)gj * B.m2 + gk] += fe;
+      double old[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) old[t] = slot[t] >= 0 ? out[slot[t]] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (slot[t] >= 0) out[slot[t]] = old[t] + val[t];
+    } else {
+      // ---- 3'. residual: fe[a] = sum_q w det ( -k gradN_a . gradT + N_a s_q )
+      //      gradN_a . gradT = sum_m dN[q][a][m] h[q][m],  h = Jinv (Jinv^T gxi),  gxi[m] = sum_b dN[q][b][m] T_b
+      for (int t = lane; t < nq * 3; t += 64) {  // lanes (q, m): gxi
+        const int q = t / 3, m = t - 3 * q;
+        const double* dn = s_dN + q * 81 + m;
+        double acc = 0.0;
+#pragma unroll 9
+        for (int b = 0; b < 27; ++b) acc += dn[3 * b] * W[W_T + b];
+        W[W_G + t] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int q = lane; q < nq; q += 64) {  // lanes q: gradT = Jinv^T gxi ; h = -k w det * Jinv gradT ; source
+        const double* Ji = W + W_J + q * 9;
+        const double g0 = W[W_G + 3 * q], g1 = W[W_G + 3 * q + 1], g2 = W[W_G + 3 * q + 2];
+        const double t0 = g0 * Ji[0] + g1 * Ji[3] + g2 * Ji[6];
+        const double t1 = g0 * Ji[1] + g1 * Ji[4] + g2 * Ji[7];
+        const double t2 = g0 * Ji[2] + g1 * Ji[5] + g2 * Ji[8];
+        const double sc = -A.kcond * W[W_D + q];
+        W[W_G + 3 * q + 0] = sc * (Ji[0] * t0 + Ji[1] * t1 + Ji[2] * t2);
+        W[W_G + 3 * q + 1] = sc * (Ji[3] * t0 + Ji[4] * t1 + Ji[5] * t2);
+        W[W_G + 3 * q + 2] = sc * (Ji[6] * t0 + Ji[7] * t1 + Ji[8] * t2);
+        const double* nn = s_N + q * 27;
+        double sq = 0.0;
+        for (int b = 0; b < 27; ++b) sq += nn[b] * W[W_T + 28 + b];
+        W[W_G + 3 * h27_pad(nq) + q] = sq * W[W_D + q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 27) {
+        double fe = 0.0;
+        for (int q = 0; q < nq; ++q) {
+          const double* dn = s_dN + q * 81 + 3 * lane;
+          fe += dn[0] * W[W_G + 3 * q] + dn[1] * W[W_G + 3 * q + 1] + dn[2] * W[W_G + 3 * q + 2] +
+                s_N[q * 27 + lane] * W[W_G + 3 * h27_pad(nq) + q];
+        }
+        const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
+        if (gi >= B.plo && gi < B.phi) out[(int64_t)(gi - B.plo) * B.plane_len + (int64_t)gj * B.m2 + gk] += fe;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -388,7 +382,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 }
 
 static size_t hex27_lds_bytes(int nq, bool matrix) {
-  return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + 4 * (size_t)W_SIZE);
+  return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + H27_WAVES * (size_t)(W_SIZE));
 }
 
 static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix, double h, double Tenv, uint32_t robin,
@@ -431,10 +425,10 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
     Hex27Args A{B, g_tab, p->k, colour, nq};
-    int64_t grid = (ne + 3) / 4;
-    const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (8 waves) per CU, persistent over the colour's elements
+    int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
+    const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(MFEM_BLOCK), lds, ctx->stream, A, nullptr, nullptr, vals);
+    hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, vals);
     MFEM_CHECK_LAUNCH();
   }
   return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
@@ -456,10 +450,10 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
     Hex27Args A{B, g_tab, p->k, colour, nq};
-    int64_t grid = (ne + 3) / 4;
+    int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_hex27<false>, dim3((int)grid), dim3(MFEM_BLOCK), lds, ctx->stream, A, x_star, s, residue);
+    hipLaunchKernelGGL(k_hex27<false>, dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, x_star, s, residue);
     MFEM_CHECK_LAUNCH();
   }
   return hex27_launch_faces(ctx, m, false, p->h, p->Tenv, p->robin_faces, x_star, residue);
