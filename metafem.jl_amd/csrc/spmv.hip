@@ -64,7 +64,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
   double dot_acc = 0.0;
 
   for (int64_t it = blockIdx.x; it < ntiles_padded; it += gridDim.x) {
-    const int64_t tile = tile_of(it, ntiles, xcd_aware);
+    const int64_t tile = tile_of(it, ntiles, xcd_aware & 0xFFFF);
     if (tile >= ntiles) continue;  // uniform per workgroup
     const int64_t r0 = tile * R;
     const int64_t r1 = (r0 + R < n) ? r0 + R : n;
@@ -104,8 +104,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
           const int i = i0 + u * 2 * MFEM_BLOCK;
           if (i < cnt) {
             // entry i+1 may belong to the next tile (i + 1 == cnt): its product is never read
-            const double x0 = x[c[u].x - base];
-            const double x1 = (i + 1 < cnt) ? x[c[u].y - base] : 0.0;
+            double x0, x1;
+            if (xcd_aware & (1 << 30)) {  // timing probe: no gather
+              x0 = (double)c[u].x;
+              x1 = (double)c[u].y;
+            } else {
+              x0 = x[c[u].x - base];
+              x1 = (i + 1 < cnt) ? x[c[u].y - base] : 0.0;
+            }
             *reinterpret_cast<d2_t*>(&prod[i]) = (d2_t){v[u].x * x0, v[u].y * x1};
           }
         }
@@ -208,10 +214,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 static int g_spmv_xcd_aware = 0;
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
 static int g_spmv_variant = 1;    // 0: CAP 4032 x4, 1: CAP 4032 x8, 2: CAP 2016 x4, 3: CAP 2016 x2
+static int g_spmv_nogather = 0;   // diagnostic only: replace x[col] by col-derived constants (WRONG results, timing probe)
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 3;
+  g_spmv_nogather = (xcd_aware >> 20) & 1;
   if (grid_mult > 0) g_spmv_grid_mult = grid_mult;
   return MFEM_OK;
 }
@@ -318,9 +326,11 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     cap &= ~7;  // multiple of 8 so blockIdx % 8 is a stable XCD label along the grid-stride loop
     if (cap < 8) cap = 8;
     int grid = (int)(ntiles < cap ? ((ntiles + 7) & ~(int64_t)7) : cap);
-    const int xcd = (ntiles >= 64) ? g_spmv_xcd_aware : 0;
-    const int64_t span = (int64_t)8 * (xcd > 0 ? xcd : 1);
-    const int64_t ntiles_padded = xcd ? (ntiles + span - 1) / span * span : ntiles;
+    int xcd = (ntiles >= 64) ? g_spmv_xcd_aware : 0;
+    const int xch = xcd & 0xFFFF;
+    const int64_t span = (int64_t)8 * (xch > 0 ? xch : 1);
+    const int64_t ntiles_padded = xch ? (ntiles + span - 1) / span * span : ntiles;
+    if (g_spmv_nogather) xcd |= (1 << 30);
     const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
 #define LAUNCH_LDS(RP, VEC, CAP, UNR)                                                                      \
   hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,  \

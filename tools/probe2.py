@@ -19,15 +19,15 @@ def read():
     return tot.value / max(cnt.value, 1)
 _lib.check(lib.mfem_prof_spmv_enable(ctx._h, 1))
 b = torch.ones(A.n, dtype=torch.float64, device="cuda")
-for ch in (0, 4, 16, 32, 64, 128, 256, 1024, 4096):
-    lib.mfem_debug_set_spmv(ch | (1 << 16), 8)
+for ch, pipe, mult in ((0, 0, 8), (0, 1, 8), (0, 0, 8)):
+    lib.mfem_debug_set_spmv(ch | (1 << 16) | (pipe << 20), mult)
     for _ in range(10): mf.mul_(y, A, K, x)
     read()
     for _ in range(30): mf.mul_(y, A, K, x)
     ms = read()
     mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=60, max_pass=1, fixed_iterations=True)
     ms2 = read()
-    print(f"xcd chunk {ch}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
+    print(f"nogather {pipe} mult {mult}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
 lib.mfem_debug_set_spmv(0 | (1 << 16), 8)
 for _ in range(30): mf.mul_(y, A, K, x)
 read()
