@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=200)
     args = ap.parse_args()
 
+    import ctypes as C
+
     import torch
 
     import metafem_jl_amd as mf
@@ -80,17 +82,28 @@ def main():
     N = args.n
     nx_global = N * world
     brick = mf.Brick((float(world), 1.0, 1.0), (nx_global, N, N), 1, 3, ctx=ctx)
-    if world > 1:
+    use_comm = world > 1 or os.environ.get("MFEM_BENCH_FORCE_COMM") == "1"  # the env var exercises the RCCL path at N = 1
+    if use_comm:
         from metafem_jl_amd import parallel
 
         plo, phi = parallel.slab_planes(nx_global + 1, world, rank)
         brick.set_slab(plo, phi)
-        comm = parallel.SlabComm(ctx, brick, rank, world, n_fields=1)
+        # RCCL prints a version banner / warnings through C stdio on stdout: send them to stderr so that stdout
+        # carries only the JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = parallel.SlabComm(ctx, brick, rank, world, n_fields=1)  # noqa: F841 (kept alive for the run)
+            C.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     A = brick.pattern(1)
     n_local = A.n
     dev = f"cuda:{local_rank}"
     K = torch.empty(A.nnz, dtype=torch.float64, device=dev)
-    xlen = n_local + (2 * brick.m[1] * brick.m[2] if world > 1 else 0)
+    xlen = n_local + (2 * brick.m[1] * brick.m[2] if use_comm else 0)
     x_star = torch.zeros(xlen, dtype=torch.float64, device=dev)
     s = torch.full((xlen,), SRC, dtype=torch.float64, device=dev)
     R = torch.empty(n_local, dtype=torch.float64, device=dev)
@@ -111,8 +124,6 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-
-    import ctypes as C
 
     _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 1))
     tot, cnt = C.c_double(), C.c_int64()
@@ -178,6 +189,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_iters)
         else:
             out["cpu_baseline"] = None
+        C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
