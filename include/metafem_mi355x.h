@@ -159,6 +159,13 @@ int mfem_brick_set_slab(mfem_brick m, int32_t plane_lo, int32_t plane_hi);
  * analytic row-sorted CSR, no hash table, no COO sort.  Outputs are library-owned device arrays
  * valid until mfem_csr_destroy: rowptr is int64, 0-based. */
 int mfem_brick_pattern(mfem_context ctx, mfem_brick m, int32_t n_fields, mfem_csr* out);
+/* The same for UNSTRUCTURED connectivity: controlpoint_IDs[itp, nel] (column-major, ids per index_base) ->
+ * row-sorted CSR of n_fields field-major blocks (radix sort + unique of the packed (cp_i, cp_j) keys; no hash
+ * table).  sparse_IDs_by_el (optional, device, [n_fields^2][itp, itp, nel] int32, ids per index_base) receives
+ * the CSR slot of every element entry for every (dual, base) field block u = dual*n_fields + base -- what
+ * `sparse_IDs_by_el + sparse_mapping[(dual,base)]*sparse_unitsize` addresses in the reference (:111-118,148-151). */
+int mfem_pattern_build(mfem_context ctx, int32_t itp, int64_t nel, int64_t ncp, const int32_t* controlpoint_IDs,
+                       int32_t index_base, int32_t n_fields, mfem_csr* out, int32_t* sparse_IDs_by_el);
 const int64_t* mfem_csr_rowptr64(mfem_csr A);
 const int32_t* mfem_csr_colidx(mfem_csr A);
 int64_t mfem_csr_nnz(mfem_csr A);

@@ -228,6 +228,25 @@ def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tenso
     return x, st
 
 
+def assemble_SparseID(controlpoint_IDs: torch.Tensor, ncp: int, n_fields: int = 1, index_base: int = 1,
+                      with_slots: bool = True, ctx: Optional[Context] = None):
+    """assemble_SparseID! (03_GlobalAssembly.jl:77-140) for unstructured connectivity.
+    controlpoint_IDs: int32 device tensor of shape (nel, itp) in C order == [itp, nel] column-major.
+    Returns (FEM_SpMat_CSR, sparse_IDs_by_el) with sparse_IDs_by_el of shape (n_fields^2, nel, itp_b, itp_a)."""
+    ctx = ctx or default_context()
+    _need(controlpoint_IDs, torch.int32, "controlpoint_IDs")
+    nel, itp = controlpoint_IDs.shape
+    slots = torch.empty((n_fields * n_fields, nel, itp, itp), dtype=torch.int32, device=controlpoint_IDs.device) if with_slots else None
+    h = C.c_void_p()
+    check(lib.mfem_pattern_build(ctx._h, itp, nel, ncp, _ptr(controlpoint_IDs), index_base, n_fields, C.byref(h), _ptr(slots)))
+    A = FEM_SpMat_CSR.__new__(FEM_SpMat_CSR)
+    A.ctx, A._h, A._owned, A.index_base = ctx, h, True, 0
+    A.n, A.nnz = int(lib.mfem_csr_n(h)), int(lib.mfem_csr_nnz(h))
+    A.rowptr = _tensor_from_ptr(lib.mfem_csr_rowptr64(h), A.n + 1, torch.int64, ctx.device, owner=A)
+    A.colidx = _tensor_from_ptr(lib.mfem_csr_colidx(h), A.nnz, torch.int32, ctx.device, owner=A)
+    return A, slots
+
+
 def _op_layout(itg, itp, n_sd, n_host, index_base, colour_offsets):
     if colour_offsets is None:
         return OpLayout(itg, itp, n_sd, n_host, index_base, 0, None), None

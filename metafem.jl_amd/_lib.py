@@ -91,6 +91,7 @@ SIGNATURES = {
     "mfem_brick_coords": (P, [P, c_int32]),
     "mfem_brick_set_slab": (c_int, [P, c_int32, c_int32]),
     "mfem_brick_pattern": (c_int, [P, P, c_int32, C.POINTER(P)]),
+    "mfem_pattern_build": (c_int, [P, c_int32, c_int64, c_int64, P, c_int32, c_int32, C.POINTER(P), P]),
     "mfem_csr_rowptr64": (P, [P]),
     "mfem_csr_colidx": (P, [P]),
     "mfem_csr_nnz": (c_int64, [P]),
