@@ -29,21 +29,41 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 def cpu_baseline(n_cpu: int, iters: int):
     """Reference algorithm restated in C/OpenMP (oracle/c), timed on this box's host cores."""
+    # size and pin the OpenMP team before the runtime starts (must precede loading liboracle.so): the container may
+    # see every host CPU but own only a cgroup quota of them -- oversubscribing the quota throttles all threads
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        ncpu = min(ncpu, int(os.environ.get("OMP_NUM_THREADS", ncpu)))
+    except ValueError:
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(ncpu)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
     import numpy as np  # noqa: F401
     from oracle import cport
 
+    cport.lib().orc_set_num_threads(ncpu)  # the OpenMP runtime may already be initialised (torch / numpy import it)
     prob = cport.CThermal((n_cpu, n_cpu, n_cpu), k=K_COND, h=H, Tenv=TENV, src=SRC).setup()
     prob.timed_step(2)  # warm caches / page in
-    ta, ts = prob.timed_step(iters)
+    reps = 3
+    ta = ts = 0.0
+    for _ in range(reps):
+        a, b = prob.timed_step(iters)
+        ta, ts = ta + a / reps, ts + b / reps
     cores = cport.lib().orc_num_threads()
     return {
         "value": prob.mesh.ncp * iters / (ta + ts),
         "unit": "DOF-updates/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"hex-8 {n_cpu}^3 thermal ({prob.mesh.ncp} DOF): 1 step = term-by-term assembly "
+        "sample": f"hex-8 {n_cpu}^3 thermal ({prob.mesh.ncp} DOF), mean of {reps} steps: 1 step = term-by-term assembly "
                   f"({ta:.2f} s) + {iters} Jacobi-CG iterations ({ts:.2f} s); C/OpenMP restatement of the "
-                  f"reference algorithm (oracle/c/oracle.c), {cores} threads",
+                  f"reference algorithm (oracle/c/oracle.c), {cores} threads (cgroup CPU quota of the box)",
     }
 
 
@@ -54,8 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=256, help="elements per side of the per-GPU mesh")
     ap.add_argument("--iters", type=int, default=200, help="CG iterations per step")
-    ap.add_argument("--cpu-n", type=int, default=160, help="elements per side of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=200)
+    ap.add_argument("--cpu-n", type=int, default=192, help="elements per side of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=400)
     args = ap.parse_args()
 
     import ctypes as C

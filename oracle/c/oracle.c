@@ -25,12 +25,39 @@
 #include <omp.h>
 #endif
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
 #else
   return 1;
 #endif
+}
+
+/* First-touch helpers: numpy allocates and fills on the main thread, which homes every page on one NUMA node.
+ * Re-homing the big arrays with the same static schedule the kernels use keeps the CPU baseline from being
+ * limited by a single memory controller on multi-socket hosts. */
+void orc_parallel_copy(void* dst, const void* src, int64_t nbytes) {
+  const int64_t n = nbytes / 8;
+  int64_t* d = (int64_t*)dst;
+  const int64_t* s = (const int64_t*)src;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) d[i] = s[i];
+  memcpy((char*)dst + n * 8, (const char*)src + n * 8, (size_t)(nbytes - n * 8));
+}
+void orc_parallel_zero(void* dst, int64_t nbytes) {
+  const int64_t n = nbytes / 8;
+  int64_t* d = (int64_t*)dst;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) d[i] = 0;
+  memset((char*)dst + n * 8, 0, (size_t)(nbytes - n * 8));
 }
 
 /* ---- geometry: integral_vals[q, a, s, e] (s = 0 value, 1..3 d/dx_s), integral_weights[q, e] ------- */

@@ -25,6 +25,9 @@ def lib():
             raise ImportError(f"{_LIB} missing: run `make -C oracle/c` (or __graft_entry__.build())")
         L = C.CDLL(_LIB)
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_parallel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_parallel_zero.argtypes = [C.c_void_p, C.c_int64]
         L.orc_update_basic_elements_3d.argtypes = [C.c_int, C.c_int, C.c_int64, f64p, f64p, f64p, C.c_int64, i64p, f64p, f64p]
         L.orc_var_basic.argtypes = [C.c_int, C.c_int, C.c_int, f64p, C.c_int, C.c_int64, i64p, f64p, f64p, i64p, i64p, C.c_int64]
         L.orc_kval_basic.argtypes = [C.c_int, C.c_int, C.c_int, f64p, C.c_int, C.c_int, f64p, i64p, C.c_int64, f64p, i64p, i64p, C.c_int64]
@@ -38,6 +41,19 @@ def lib():
         L.orc_cg_jacobi.restype = C.c_int
         _lib = L
     return _lib
+
+
+def rehome(a: np.ndarray) -> np.ndarray:
+    """Copy `a` into freshly allocated memory whose pages are first touched by the OpenMP team (NUMA first-touch)."""
+    out = np.empty_like(a)
+    lib().orc_parallel_copy(out.ctypes.data, a.ctypes.data, a.nbytes)
+    return out
+
+
+def pzeros(n: int, dtype=np.float64) -> np.ndarray:
+    out = np.empty(n, dtype=dtype)
+    lib().orc_parallel_zero(out.ctypes.data, out.nbytes)
+    return out
 
 
 def _ref_vals_flat(disc) -> np.ndarray:
@@ -69,8 +85,9 @@ class CThermal:
         nel, ncp = self.mesh.nel, self.mesh.ncp
         self.cp_ids = np.ascontiguousarray(self.mesh.cp_ids.T).ravel()  # [a + itp*e]
         self.coords = np.ascontiguousarray(self.mesh.coords.T).ravel()  # SoA x|y|z
-        self.ivals = np.empty(self.itg * self.itp * 4 * nel)
-        self.w = np.empty(self.itg * nel)
+        self.cp_ids, self.coords = rehome(self.cp_ids), rehome(self.coords)
+        self.ivals = pzeros(self.itg * self.itp * 4 * nel)
+        self.w = pzeros(self.itg * nel)
         L.orc_update_basic_elements_3d(self.itg, self.itp, nel, _ref_vals_flat(self.disc), self.disc.itg_weight.copy(),
                                        self.coords, ncp, self.cp_ids, self.ivals, self.w)
         # boundary (surface only): numpy geometry, C operators
@@ -84,22 +101,23 @@ class CThermal:
         # pattern + slot table
         self.rowptr = np.empty(ncp + 1, dtype=np.int64)
         nnz = L.orc_pattern(self.itp, nel, ncp, self.cp_ids, self.rowptr, None, None)
-        self.colidx = np.empty(nnz, dtype=np.int32)
-        self.slots = np.empty(self.itp * self.itp * nel, dtype=np.int64)
+        self.colidx = pzeros(nnz, np.int32)
+        self.slots = pzeros(self.itp * self.itp * nel, np.int64)
         L.orc_pattern(self.itp, nel, ncp, self.cp_ids, self.rowptr, self.colidx.ctypes.data, self.slots.ctypes.data)
-        self.el_ids = np.arange(nel, dtype=np.int64)
-        self.K = np.zeros(nnz)
-        self.residue = np.zeros(ncp)
-        self.xstar = np.zeros(ncp)
-        self.s = np.full(ncp, self.src)
-        self._vals = np.empty(self.itg * nel)
-        self._fvals = np.empty(self.f_itg * len(self.facets))
+        self.rowptr = rehome(self.rowptr)
+        self.el_ids = rehome(np.arange(nel, dtype=np.int64))
+        self.K = pzeros(nnz)
+        self.residue = pzeros(ncp)
+        self.xstar = pzeros(ncp)
+        self.s = rehome(np.full(ncp, self.src))
+        self._vals = pzeros(self.itg * nel)
+        self._fvals = pzeros(self.f_itg * len(self.facets))
         return self
 
     def K_linear_func(self):
         L = lib()
         nel = self.mesh.nel
-        self.K[:] = 0.0
+        L.orc_parallel_zero(self.K.ctypes.data, self.K.nbytes)
         for d in range(3):  # three _Kval_Basic launches: (T;d, T;d) with coefficient -k
             L.orc_scale_weights(self.itg, -self.k, self.w, self.el_ids, nel, self._vals)
             L.orc_kval_basic(self.itg, self.itp, 4, self.ivals, 1 + d, 1 + d, self._vals, self.slots, 0, self.K,
@@ -112,14 +130,14 @@ class CThermal:
     def K_nonlinear_func(self):
         L = lib()
         nel, nf = self.mesh.nel, len(self.facets)
-        self.residue[:] = 0.0
+        L.orc_parallel_zero(self.residue.ctypes.data, self.residue.nbytes)
         for d in range(3):  # T;d word, then residual term -k*T;d on dual T;d
-            buf = np.zeros(self.itg * nel)
+            buf = pzeros(self.itg * nel)
             L.orc_var_basic(self.itg, self.itp, 4, self.ivals, 1 + d, 0, self.cp_ids, self.xstar, buf, self.el_ids, self.el_ids, nel)
             buf *= -self.k
             buf *= self.w
             L.orc_res_basic(self.itg, self.itp, 4, self.ivals, 1 + d, buf, 0, self.cp_ids, self.residue, self.el_ids, self.el_ids, nel)
-        buf = np.zeros(self.itg * nel)  # external s
+        buf = pzeros(self.itg * nel)  # external s
         L.orc_var_basic(self.itg, self.itp, 4, self.ivals, 0, 0, self.cp_ids, self.s, buf, self.el_ids, self.el_ids, nel)
         buf *= self.w
         L.orc_res_basic(self.itg, self.itp, 4, self.ivals, 0, buf, 0, self.cp_ids, self.residue, self.el_ids, self.el_ids, nel)
@@ -130,7 +148,7 @@ class CThermal:
 
     def solve_cg(self, tol: float, maxiter: int, fixed: bool = False):
         L = lib()
-        x = np.zeros(self.mesh.ncp)
+        x = pzeros(self.mesh.ncp)
         res = C.c_double()
         it = L.orc_cg_jacobi(self.mesh.ncp, self.rowptr, self.colidx, self.K, self.residue, x, tol, maxiter, 1 if fixed else 0,
                              C.byref(res))

@@ -58,6 +58,52 @@ def test_slab_rows_equal_global_rows(mf, n, lo, hi):
     assert np.allclose(y.cpu().numpy(), gy.cpu().numpy()[r0:r1], rtol=1e-14, atol=1e-10)
 
 
+@pytest.mark.parametrize("lo,hi", [(0, 2), (2, 5), (3, 6)])
+def test_elasticity_slab_rows_equal_global_rows(mf, lo, hi):
+    """3 fields, field-major: slab rows (f, owned node) and ghost columns behind all owned entries."""
+    import torch
+    from metafem_jl_amd import parallel as par
+
+    x, n = (2.0, 1.0, 1.0), (5, 2, 3)
+    lam, mu, tau = 0.5769, 0.3846, 1000.0
+    m1, m2 = n[1] + 1, n[2] + 1
+    pl = m1 * m2
+    ncp = (n[0] + 1) * pl
+    gb = mf.make_Brick(x, n)
+    gA = gb.pattern(3)
+    gK = gb.assemble_elasticity(gA, lam, mu, tau, mf.FACE_BITS["x0"]).cpu().numpy()
+    grp, gcol = gA.rowptr.cpu().numpy(), gA.colidx.cpu().numpy()
+    gx = 0.01 * np.random.default_rng(1).standard_normal(3 * ncp)
+    sig = (0.0, 1.0, 0.0, 0.0, 0.0, 0.3)
+    gR = gb.residual_elasticity(torch.tensor(gx, device="cuda"), lam, mu, tau, mf.FACE_BITS["x0"], mf.FACE_BITS["y1"], sig).cpu().numpy()
+    sb = mf.make_Brick(x, n)
+    sb.set_slab(lo, hi)
+    sA = sb.pattern(3)
+    n_owned = (hi - lo) * pl
+    assert sA.n == 3 * n_owned
+    sK = sb.assemble_elasticity(sA, lam, mu, tau, mf.FACE_BITS["x0"]).cpu().numpy()
+    srp, scol = sA.rowptr.cpu().numpy(), sA.colidx.cpu().numpy()
+    nloc = par.local_vector_length(lo, hi, m1, m2, 3)
+    xl = np.zeros(nloc)
+    for f in range(3):
+        rows_g = f * ncp + np.arange(lo * pl, hi * pl)
+        for r_loc, r_g in zip(f * n_owned + np.arange(n_owned), rows_g):
+            a, b = grp[r_g], grp[r_g + 1]
+            assert srp[r_loc + 1] - srp[r_loc] == b - a
+            cg = gcol[a:b]
+            g, node = cg // ncp, cg % ncp
+            expect = par.slab_local_index(node // pl, (node % pl) // m2, node % m2, g, lo, hi, m1, m2, 3)
+            assert np.array_equal(scol[srp[r_loc]:srp[r_loc + 1]], expect)
+            assert np.array_equal(sK[srp[r_loc]:srp[r_loc + 1]], gK[a:b])
+        for i in range(max(lo - 1, 0), min(hi + 1, n[0] + 1)):
+            jj, kk = np.meshgrid(np.arange(m1), np.arange(m2), indexing="ij")
+            li = par.slab_local_index(np.full(jj.size, i), jj.ravel(), kk.ravel(), f, lo, hi, m1, m2, 3)
+            xl[li] = gx[f * ncp + i * pl + jj.ravel() * m2 + kk.ravel()]
+    sR = sb.residual_elasticity(torch.tensor(xl, device="cuda"), lam, mu, tau, mf.FACE_BITS["x0"], mf.FACE_BITS["y1"], sig).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(sR[f * n_owned:(f + 1) * n_owned], gR[f * ncp + lo * pl:f * ncp + hi * pl])
+
+
 def test_rccl_world1_solve_equals_plain_solve(mf):
     import torch
     from metafem_jl_amd import parallel as par
