@@ -82,6 +82,10 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
 
 /* Tuning hook (benchmarks/profiling only): XCD-aware tile map on/off, persistent workgroups per CU. */
 int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
+/* Inspector-executor SpMV plan (x window in LDS + 16-bit local indices, built inside mfem_csr_create /
+ * mfem_brick_pattern / mfem_pattern_build): enable = 0 keeps the plain CSR kernel; cap = 4032 | 2016 tile size
+ * for plans created afterwards. */
+int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
 
 /* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */

@@ -81,7 +81,17 @@ struct mfem_csr_s {
   void* owned_colidx;
   // slab info (multi-GPU): rows = owned nodes, x has ghost planes; 0 for single GPU
   int64_t x_offset;  // offset of the first owned entry inside the local x (per field)
+  // inspector-executor plan of spmv_window.hip (x window in LDS + 16-bit local indices)
+  int win_ready, win_cap, win_R, win_lstride;
+  int64_t win_xlen;
+  int32_t* win_nlines;
+  uint32_t* win_lines;
+  uint16_t* win_idx;
 };
+int mfem_spmv_window_plan(mfem_context_s* ctx, mfem_csr_s* A);
+void mfem_spmv_window_free(mfem_csr_s* A);
+int mfem_spmv_window_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
+                            double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
 
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes);
 

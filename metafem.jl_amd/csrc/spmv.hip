@@ -241,7 +241,7 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->max_row_nnz = ctx->h_flags[8];
   A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
-  return MFEM_OK;
+  return mfem_spmv_window_plan(ctx, A);
 }
 
 extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
@@ -272,6 +272,7 @@ extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const v
 
 extern "C" int mfem_csr_destroy(mfem_csr A) {
   if (!A) return MFEM_OK;
+  mfem_spmv_window_free(A);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);
   if (A->owned_colidx) hipFree(A->owned_colidx);
   delete A;
@@ -313,6 +314,10 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
                              const int32_t* done_flag) {
   if (n_partials) *n_partials = 0;
   if (A->n == 0) return MFEM_OK;
+  {
+    const int w = mfem_spmv_window_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
+    if (w != 0) return w < 0 ? w : MFEM_OK;
+  }
   const int base = A->index_base;
   const int cap_doubles = (g_spmv_variant >= 2 && A->max_row_nnz <= 2016 - 2) ? 2016 : 4032;
   if (A->rows_per_block > 0) {

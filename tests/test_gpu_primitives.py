@@ -38,6 +38,53 @@ def test_spmv_matches_oracle(mf, n, avg, bits, base):
         assert np.max(np.abs(y_t.cpu().numpy() - ref) / scale) < 1e-14
 
 
+@pytest.mark.parametrize("cap", [4032, 2016])
+@pytest.mark.parametrize("kind", ["hex8", "hex8x3", "hex27", "quad8", "banded_shift"])
+def test_spmv_window_plan_equals_plain_kernel(mf, kind, cap):
+    """Inspector-executor path (x window in LDS + 16-bit indices) vs the plain CSR kernel vs the oracle."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import mesh as om, operators as oo, reference_element as re_, solvers
+
+    rng = np.random.default_rng(7)
+    if kind == "banded_shift":  # 1-based, int32 rowptr, odd tile starts, empty rows
+        n = 5000
+        lens = rng.integers(0, 40, size=n)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum(lens)
+        cols = np.concatenate([np.sort(rng.choice(np.arange(max(0, r - 60), min(n, r + 60)), size=l, replace=False))
+                               for r, l in enumerate(lens)]).astype(np.int32)
+        base, bits = 1, 32
+    else:
+        F = 3 if kind == "hex8x3" else 1
+        if kind == "quad8":
+            disc = re_.initialize_classical_element(2, "CUBE", 2, 1, 5, itp_type="Serendipity")
+            vert, conn = om.make_square((2.0, 1.0), (40, 25))
+            m = om.mesh_classical(vert, conn, disc)
+        else:
+            order = 2 if kind == "hex27" else 1
+            disc = re_.initialize_classical_element(3, "CUBE", order, 1, 3)
+            m = om.lattice_mesh((1.0, 1.0, 1.0), (9, 7, 11) if order == 1 else (4, 3, 5), disc)
+        pat = oo.assemble_sparse_id(m.cp_ids, m.ncp, [(i, j) for i in range(F) for j in range(F)])
+        rowptr, cols, n = pat.rowptr, pat.colidx, pat.n
+        base, bits = 0, 64
+    vals = rng.standard_normal(rowptr[-1])
+    x = rng.standard_normal(n + 5)  # x longer than n: the window fill must respect max col, not n
+    ref = solvers.csr(rowptr, cols, vals, n) @ x[:n]
+    scale = np.abs(solvers.csr(rowptr, cols, np.abs(vals), n) @ np.abs(x[:n])) + 1e-300
+    out = {}
+    for enable in (1, 0):
+        _lib.lib.mfem_debug_set_spmv_window(enable, cap, 8)
+        A = mf.FEM_SpMat_CSR(torch.tensor(rowptr + base, dtype=torch.int64 if bits == 64 else torch.int32, device="cuda"),
+                             torch.tensor(cols + base, dtype=torch.int32, device="cuda"), n, index_base=base)
+        y = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+        mf.mul_(y, A, torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda"), 2.0, -1.0)
+        out[enable] = y.cpu().numpy()
+        assert np.max(np.abs(out[enable] - (2.0 * ref - 3.0)) / (2 * scale + 3.0)) < 1e-14
+    _lib.lib.mfem_debug_set_spmv_window(0, 4032, 8)  # library default: plain kernel
+    assert np.max(np.abs(out[1] - out[0]) / (2 * scale + 3.0)) < 1e-14
+
+
 def test_spmv_long_rows_fallback(mf):
     """Rows longer than the LDS tile take the wave-per-row path."""
     import torch

@@ -1,4 +1,4 @@
-"""Why is SpMV slower inside CG than standalone?  Per-launch event timing (mfem_prof_spmv_*) of three loops."""
+"""Per-launch event timing (mfem_prof_spmv_*) of the SpMV variants: plain CSR kernel vs inspector-executor window plan."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,6 @@ A = brick.pattern(1)
 K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
 ctx = brick.ctx
 x = mf.FEM_rand(A.n, 1, 0); y = torch.empty_like(x)
-u = [mf.FEM_rand(A.n, 2, i) for i in range(4)]
 bytes_spmv = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
 def read():
     tot, cnt = C.c_double(), C.c_int64()
@@ -19,28 +18,16 @@ def read():
     return tot.value / max(cnt.value, 1)
 _lib.check(lib.mfem_prof_spmv_enable(ctx._h, 1))
 b = torch.ones(A.n, dtype=torch.float64, device="cuda")
-for ch, pipe, mult in ((0, 0, 8), (0, 1, 8), (0, 0, 8)):
-    lib.mfem_debug_set_spmv(ch | (1 << 16) | (pipe << 20), mult)
-    for _ in range(10): mf.mul_(y, A, K, x)
-    read()
-    for _ in range(30): mf.mul_(y, A, K, x)
-    ms = read()
-    mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=60, max_pass=1, fixed_iterations=True)
-    ms2 = read()
-    print(f"nogather {pipe} mult {mult}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
 lib.mfem_debug_set_spmv(0 | (1 << 16), 8)
-for _ in range(30): mf.mul_(y, A, K, x)
-read()
-for _ in range(50): mf.mul_(y, A, K, x)
-ms = read(); print(f"standalone: {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
-for _ in range(50):
-    mf.mul_(y, A, K, x)
-    mf.axpby_(0.5, u[0], 0.5, u[1]); mf.axpby_(0.5, u[2], 0.5, u[3]); mf.axpby_(0.5, u[1], 0.5, u[2])
-ms = read(); print(f"with 3 axpby between: {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
-for _ in range(50):
-    mf.mul_(y, A, K, x)
-    mf.axpby_(0.5, y, 0.5, x)   # x rewritten each time like p in CG
-ms = read(); print(f"x rewritten between: {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
-b = torch.ones(A.n, dtype=torch.float64, device="cuda")
-mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=100, max_pass=1, fixed_iterations=True)
-ms = read(); print(f"inside CG (fused dot): {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s")
+for en, cap, mult in ((0, 4032, 8), (1, 4032, 3), (1, 2016, 5), (1, 2016, 6), (1, 2016, 7), (1, 2016, 8), (1, 2016, 12)):
+    lib.mfem_debug_set_spmv_window(en, cap, mult)
+    A2 = brick.pattern(1)
+    for _ in range(10): mf.mul_(y, A2, K, x)
+    read()
+    for _ in range(30): mf.mul_(y, A2, K, x)
+    ms = read()
+    mf.iterative_Solve(A2, K, b, 1e-30, Sv_func=mf.cg_, maxiter=60, max_pass=1, fixed_iterations=True)
+    ms2 = read()
+    print(f"window {en} cap {cap} mult {mult}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
+    del A2
+lib.mfem_debug_set_spmv_window(0, 4032, 8)
