@@ -112,3 +112,59 @@ def elasticity_traction(dim: int, sig) -> AssembleWeakform:
         if any(sig[i][j] != 0.0 for j in range(dim)):
             wf.residues.append(ResTerm(i, 0, lambda env, i=i: sum(sig[i][j] * env[f"n{j}"] for j in range(dim))))
     return wf
+
+
+# -- incompressible flow, lid-driven cavity ---------------------------------------------------------
+def cavity_weakforms(rho: float, mu: float, tau_b: float, dim: int = 2):
+    """examples/incompressible_flow/lid_driven_cavity_flow/2D_Script.jl:47-72 -- SUPG/PSPG stabilised
+    Navier-Stokes with weakly imposed (Nitsche-type) wall and lid conditions.  Fields sorted by symbol:
+    p, u1, u2 (positions 0, 1, 2).  Second derivatives u{i;m,m} are dropped (explicit_max_sd_order = 1, :78).
+    Returns (domain, boundary_fix, boundary_top) AssembleWeakforms."""
+    from . import symform
+
+    fields = ["p"] + [f"u{i + 1}" for i in range(dim)]
+    R = range(dim)
+
+    def build(kind):
+        W = symform.Words(dim, fields)
+        u = [W.val(f"u{i + 1}") for i in R]
+        du = [[W.d(f"u{i + 1}", j) for j in R] for i in R]  # du[i][j] = u{i;j}
+        p, dp = W.val("p"), [W.d("p", j) for j in R]
+        B = []
+        if kind == "domain":
+            taum, tauc = W.ext("taum"), W.ext("tauc")
+            Rc = sum(du[m][m] for m in R)                                                    # :51
+            Rm = [sum(u[m] * du[i][m] for m in R) + dp[i] / rho for i in R]                  # :52 (u{i;m,m} dropped)
+            for i in R:
+                for j in R:
+                    B.append((du[i][j], -rho * u[i] * u[j]))                                 # -rho Bilinear(u{i;j}, u{i} u{j})
+                    B.append((du[i][j], mu * du[i][j]))                                      # mu Bilinear(u{i;j}, u{i;j})
+                    B.append((du[i][j], taum * rho * Rm[i] * u[j]))                          # SUPG
+                B.append((du[i][i], -p))                                                     # -Bilinear(u{i;i}, p)
+                B.append((p, du[i][i]))                                                      # Bilinear(p, u{i;i})
+                B.append((dp[i], taum * Rm[i]))                                              # PSPG
+                B.append((du[i][i], tauc * rho * Rc))                                        # LSIC
+        else:
+            n = [W.n(j) for j in R]
+            for i in R:                                                                      # NS_boundary_BASE :59
+                B.append((u[i], rho * u[i] * sum(u[j] * n[j] for j in R)))
+                B.append((u[i], p * n[i]))
+                B.append((u[i], -mu * sum(du[i][j] * n[j] for j in R)))
+            if kind == "top":                                                                # NS_boundary_DISP :61-62
+                uw = [W.ext(f"uw{i + 1}") for i in R]
+                for i in R:
+                    B.append((u[i], rho * sum((uw[i] * uw[j] - u[i] * u[j]) * n[j] for j in R)))
+                    B.append((p, (uw[i] - u[i]) * n[i]))
+                    for j in R:
+                        B.append((du[i][j], mu * (uw[i] - u[i]) * n[j]))
+                    B.append((u[i], tau_b * rho * (u[i] - uw[i])))
+            else:                                                                            # NS_boundary_FIX :64-65
+                for i in R:
+                    B.append((u[i], -rho * u[i] * sum(u[j] * n[j] for j in R)))
+                    B.append((p, -u[i] * n[i]))
+                    for j in R:
+                        B.append((du[i][j], -mu * u[i] * n[j]))
+                    B.append((u[i], tau_b * rho * u[i]))
+        return symform.assemble(W, B)
+
+    return build("domain"), build("fix"), build("top")

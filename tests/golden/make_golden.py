@@ -30,6 +30,18 @@ def strip():
                                             998.843, 979.249]))  # examples/thermal_conduction/2D_Script.jl:95-96
 
 
+def cavity():
+    """DATA from the reference's committed result examples/incompressible_flow/lid_driven_cavity_flow/2D_Cavity_Flow.vtk
+    (POINTS 4961, SCALARS u1/u2/p; Re = 1000 via solver_LU_CPU, 2D_Script.jl:188-215) + its Ghia et al. table."""
+    import csv
+
+    base = os.path.join(REF, "examples/incompressible_flow/lid_driven_cavity_flow")
+    pts, sc = vtk.read_vtk_points_scalars(os.path.join(base, "2D_Cavity_Flow.vtk"))
+    g = [(float(r["y"]), float(r["u"])) for r in csv.DictReader(open(os.path.join(base, "Ghia_Re1000.csv")))]
+    np.savez_compressed(os.path.join(HERE, "cavity_flow_Re1000.npz"), xy=pts[:, :2], u1=sc["u1"], u2=sc["u2"], p=sc["p"],
+                        ghia_y=np.array([a for a, _ in g]), ghia_u=np.array([b for _, b in g]))
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -112,6 +124,7 @@ def thermal_hex27():
 if __name__ == "__main__":
     if os.path.isdir(REF):
         strip()
+        cavity()
     tables()
     thermal_hex8()
     elasticity_hex8()

@@ -76,3 +76,31 @@ def test_dirichlet_value_on_left_edge():
     mesh, dom, _ = _run(H_PENALTY_OF_VTK)
     i = np.argmin(np.linalg.norm(mesh.coords, axis=1))
     assert abs(dom.x[i] - z["T"][0]) < 1e-4
+
+
+# ---- second pin: lid-driven cavity (nonlinear Newton, 3 fields, SUPG/PSPG, Nitsche walls, load stepping) ---------
+# The committed VTK was written with C_b = 8 -- one of the alternatives the script lists in its comment
+# (`Cᵇ = 128 # 8, 16, 32`, 2D_Script.jl:45): scan over {8, 16, 32, 64, 128} gives max |du| = 8e-5 at 8 vs 0.16, 0.27,
+# 0.35, 0.40 for the others.  Pressure is determined up to a constant (no pressure pin in the weak form; the reference's
+# LU returned an offset of -7e5), so p is compared after removing the mean.
+CB_OF_VTK = 8.0
+
+
+def test_oracle_reproduces_reference_cavity_vtk():
+    from oracle import cavity
+
+    z = np.load(os.path.join(GOLD, "cavity_flow_Re1000.npz"))
+    dom, hists = cavity.run_cavity(40, 1000.0, CB_OF_VTK)  # 2D_Script.jl:188-215: Re = 1000, tmax = 10, LU, tol 1e-5
+    assert dom.mesh.ncp == 4961 == z["u1"].size and dom.basicfield_size == 14883
+    assert all(h[-1] < 1e-5 for h in hists)
+    d, idx = cKDTree(dom.mesh.coords).query(z["xy"])
+    assert d.max() < 1e-7
+    for name in ("u1", "u2"):
+        assert np.abs(dom.controlpoints[name][idx] - z[name]).max() < 5e-4  # lid speed 1; reference Newton tol 1e-5
+    pa, pb = dom.controlpoints["p"][idx], z["p"]
+    assert np.abs((pa - pa.mean()) - (pb - pb.mean())).max() < 5e-4 * (pb.max() - pb.min())
+    # Ghia et al. (1982) centre-line profile shipped with the example: plot-level agreement
+    mid = np.abs(dom.mesh.coords[:, 0] - 0.5) < 1e-6
+    o = np.argsort(dom.mesh.coords[mid, 1])
+    u = np.interp(z["ghia_y"], dom.mesh.coords[mid, 1][o], dom.controlpoints["u1"][mid][o])
+    assert np.abs(u - z["ghia_u"]).max() < 0.02
