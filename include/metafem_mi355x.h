@@ -208,6 +208,26 @@ int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mfem_csr A, c
 int mfem_brick_residual_elasticity(mfem_context ctx, mfem_brick m, const mfem_elasticity_params* p,
                                    const double* x_star, double* residue);
 
+/* ---- generic geometry update (the tables the S3 operators consume; not used by the fused fast paths) -------- */
+/* update_BasicElements_{2,3}D + inv_Jac + update_Basic_itgval_1 (mesh/unstructured_mesh/4_Update_Integrator.jl:2-33,
+ * 77-154).  ref_itp_vals[itg, itp, 1+dim]: reference value (slot 0) and first derivatives d/dxi_m (slot 1+m);
+ * coords: SoA x1|x2|x3, ncp each; controlpoint_IDs[itp, nel].  Outputs (column-major, caller-allocated):
+ * integral_vals[itg, itp, 1+dim, nel] (slot 0 value, 1+s = d/dx_s), integral_weights[itg, nel] = w_q det J. */
+int mfem_update_basic_elements(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                               const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                               const int32_t* controlpoint_IDs, int32_t index_base, double* integral_vals,
+                               double* integral_weights);
+/* update_BasicBoundary_{2,3}D + tangents + normals (:35-75, 163-227) for facets bound to (element_ID, element_eindex).
+ * Per local face id f (n_face_ids of them, contiguous): bdy_ref_itp_vals[f][itg_b, itp, 1+dim], bdy_itg_weights[f][itg_b],
+ * bdy_tangent_directions[f][itg_b, dim, dim-1].  Outputs: integral_vals[itg_b, itp, 1+dim, nf],
+ * integral_weights[itg_b, nf] = w_q * surface det, normal_directions[itg_b, dim, nf] (outward unit normal). */
+int mfem_update_basic_boundary(mfem_context ctx, int32_t dim, int32_t itg_b, int32_t itp, int32_t n_face_ids,
+                               int64_t n_facets, int64_t ncp, const double* bdy_ref_itp_vals,
+                               const double* bdy_itg_weights, const double* bdy_tangent_directions, const double* coords,
+                               const int32_t* controlpoint_IDs, const int32_t* element_ID, const int32_t* element_eindex,
+                               int32_t index_base, double* integral_vals, double* integral_weights,
+                               double* normal_directions);
+
 /* ---- S3 generic element operators (reference signatures, accumulate semantics) ----------- */
 /* itp_vals is integral_vals[itg, itp, n_sd, n_host] column-major with the derivative hyper-cube
  * flattened to n_sd slots; *_sd are flat 0-based slot offsets (the reference's sd_IDs tuple).

@@ -101,6 +101,9 @@ SIGNATURES = {
     "mfem_brick_residual_thermal": (c_int, [P, P, C.POINTER(ThermalParams), P, P, P]),
     "mfem_brick_assemble_elasticity": (c_int, [P, P, P, C.POINTER(ElasticityParams), P]),
     "mfem_brick_residual_elasticity": (c_int, [P, P, C.POINTER(ElasticityParams), P, P]),
+    "mfem_update_basic_elements": (c_int, [P, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, c_int32, P, P]),
+    "mfem_update_basic_boundary": (c_int, [P, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, P, P, P,
+                                          c_int32, P, P, P]),
     "mfem_op_var": (c_int, [P, C.POINTER(OpLayout), P, c_int32, c_int64, P, P, P, P, P, c_int64]),
     "mfem_op_kval": (c_int, [P, C.POINTER(OpLayout), P, c_int32, c_int32, P, P, c_int64, P, P, P, c_int64]),
     "mfem_op_res": (c_int, [P, C.POINTER(OpLayout), P, c_int32, P, c_int64, P, P, P, P, c_int64]),

@@ -1,0 +1,240 @@
+"""Generic (unstructured, any weak form) path of the MI355X backend: the host-side mirror of what
+`compile_Updater_GPU` emits and `update_OneStep!` drives in the reference, executed with the C-ABI kernels.
+
+  update_Mesh                         -> mfem_update_basic_elements / mfem_update_basic_boundary   (4_Update_Integrator.jl)
+  assemble_Global_Variables!          -> mfem_pattern_build (+ vectors)                             (03_GlobalAssembly.jl:6-140)
+  update_K_Linear_<id>                -> mfem_op_var (externals), coefficient broadcasts, mfem_op_kval   (05_CodeGenerator.jl:52-91)
+  update_K_NonLinear_<id>             -> mfem_op_var, broadcasts, mfem_op_res, mfem_op_kval               (:93-154, 282-283)
+  update_OneStep!                     -> Newton loop                                                  (04_Time_Domain.jl:59-80)
+
+The coefficient expressions of a weak form (`vals = @. expr * K_params * w[:, ids]`, 05_CodeGenerator.jl:75,110,136)
+are elementwise broadcasts over [itg, n_items] arrays; the reference evaluates them as Julia GPU broadcasts and so
+does this mirror with torch elementwise ops on device tensors -- no kernel of the hot path is written in torch.
+In the Julia integration those callables are the generated `@.` expressions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+@dataclass
+class ResTerm:
+    dual_pos: int
+    dual_s: int  # 0 value, 1 + d = d/dx_d
+    fn: Callable
+
+
+@dataclass
+class GradTerm:
+    dual_pos: int
+    dual_s: int
+    base_pos: int
+    base_s: int
+    fn: Callable
+    td_order: int = 0
+
+
+@dataclass
+class WeakForm:
+    """AssembleWeakform (02_LocalAssembly.jl:30-58): what the symbolic layer hands to the code generator."""
+    inner_vars: List[Tuple[str, int, int, int]] = field(default_factory=list)  # (name, basic_pos, s, td_order)
+    cp_ext_vars: List[Tuple[str, str, int]] = field(default_factory=list)  # (name, controlpoint symbol, s)
+    normals: List[Tuple[str, int]] = field(default_factory=list)  # (name, component)
+    residues: List[ResTerm] = field(default_factory=list)
+    linear_gradients: List[GradTerm] = field(default_factory=list)
+    nonlinear_gradients: List[GradTerm] = field(default_factory=list)
+
+    def sparse_positions(self):
+        return {(g.dual_pos, g.base_pos) for g in self.linear_gradients + self.nonlinear_gradients}
+
+
+class _Group:
+    """Integration hosts of one launch family (the elements, or the facets of one boundary group)."""
+
+    def __init__(self, vals, weights, host_ids, el_ids, itg, normals=None, colour_offsets=None):
+        self.vals, self.weights, self.host_ids, self.el_ids, self.itg = vals, weights, host_ids, el_ids, itg
+        self.normals, self.colour_offsets = normals, colour_offsets
+        self.n = el_ids.numel()
+
+
+class GenericDomain:
+    """FEM_Domain with one workpiece + GlobalField, static problems (max_time_level = 0)."""
+
+    def __init__(self, ctx, space, coords: np.ndarray, cp_ids: np.ndarray, n_fields: int, domain_wf: WeakForm,
+                 boundaries: Sequence[Tuple[np.ndarray, np.ndarray, WeakForm]],
+                 element_colours: Optional[np.ndarray] = None):
+        """coords [ncp, dim]; cp_ids [itp, nel] 0-based (controlpoint_IDs in basis order); boundaries =
+        [(element_ID[nf], element_eindex[nf] 0-based local face ids, WeakForm)].  element_colours (optional):
+        a colour per element such that same-colour elements share no control point -> atomics-free scatter;
+        without it the operators use FP64 atomics like the reference."""
+        self.ctx, self.space, self.n_fields = ctx, space, n_fields
+        dev = f"cuda:{ctx.device}"
+        self.dev = dev
+        dim = space.dim
+        itp, nel = cp_ids.shape
+        ncp = coords.shape[0]
+        self.ncp, self.nel, self.itp, self.dim = ncp, nel, itp, dim
+        self.domain_wf = domain_wf
+        self.bwfs = [b[2] for b in boundaries]
+        f64 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+        i32 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.int32, device=dev)
+        self.coords = f64(coords.T)  # SoA x1|x2|x3
+        self.cp = i32(cp_ids.T + 1)  # (nel, itp) C order == [itp, nel] column-major, 1-based like the reference
+        # ---- update_Mesh
+        nsd = 1 + dim
+        ref = f64(space.ref_itp_vals.ravel(order="F"))
+        vals = torch.empty(space.itg * itp * nsd * nel, dtype=torch.float64, device=dev)
+        w = torch.empty(space.itg * nel, dtype=torch.float64, device=dev)
+        check(lib.mfem_update_basic_elements(ctx._h, dim, space.itg, itp, nel, ncp, ref.data_ptr(), f64(space.itg_weight).data_ptr(),
+                                             self.coords.data_ptr(), self.cp.data_ptr(), 1, vals.data_ptr(), w.data_ptr()))
+        if element_colours is not None:
+            order = np.argsort(element_colours, kind="stable")
+            offs = np.concatenate([[0], np.cumsum(np.bincount(element_colours, minlength=int(element_colours.max()) + 1))])
+        else:
+            order, offs = np.arange(nel), None
+        ids = i32(order + 1)
+        self.groups = [_Group(vals, w, ids, ids, space.itg, colour_offsets=offs)]
+        nface = space.bdy_ref_itp_vals.shape[0]
+        bref = f64(np.concatenate([space.bdy_ref_itp_vals[f].ravel(order="F") for f in range(nface)]))
+        bw = f64(space.bdy_itg_weights.ravel())
+        btan = f64(np.concatenate([space.bdy_tangent_directions[f].ravel(order="F") for f in range(nface)]))
+        for el, eidx, _ in boundaries:
+            nf = len(el)
+            fv = torch.empty(space.itg_b * itp * nsd * nf, dtype=torch.float64, device=dev)
+            fw = torch.empty(space.itg_b * nf, dtype=torch.float64, device=dev)
+            fn = torch.empty(space.itg_b * dim * nf, dtype=torch.float64, device=dev)
+            eld, eid = i32(np.asarray(el) + 1), i32(np.asarray(eidx) + 1)
+            check(lib.mfem_update_basic_boundary(ctx._h, dim, space.itg_b, itp, nface, nf, ncp, bref.data_ptr(), bw.data_ptr(),
+                                                 btan.data_ptr(), self.coords.data_ptr(), self.cp.data_ptr(), eld.data_ptr(),
+                                                 eid.data_ptr(), 1, fv.data_ptr(), fw.data_ptr(), fn.data_ptr()))
+            host = i32(np.arange(nf) + 1)
+            self.groups.append(_Group(fv, fw, host, eld, space.itg_b, normals=fn.view(nf, dim, space.itg_b)))
+        # ---- assemble_Global_Variables!
+        from . import assemble_SparseID  # late import: package root defines it
+
+        self.variable_size = ncp
+        self.basicfield_size = n_fields * ncp
+        self.A, self.slots = assemble_SparseID(self.cp, ncp, n_fields=n_fields, index_base=1, ctx=ctx)
+        n = self.basicfield_size
+        z = lambda m: torch.zeros(m, dtype=torch.float64, device=dev)
+        self.x, self.dx, self.x_star, self.residue = z(n), z(n), z(n), z(n)
+        self.K_linear, self.K_total = z(self.A.nnz), z(self.A.nnz)
+        self.controlpoints: Dict[str, torch.Tensor] = {}
+        self.converge_tol = 1e-6
+        self.K_params = [1.0]  # static: alpha_0 * beta_0 (04_Time_Domain.jl:13-17)
+        self.t, self.dt = 0.0, 1.0
+        self.linear_solver: Optional[Callable] = None
+        self.history: List[float] = []
+
+    # -- assemble_X! / dessemble_X! (03_GlobalAssembly.jl:44-75)
+    def assemble_X(self, infos):
+        for sym, pos, td in infos:
+            self.x[pos * self.ncp:(pos + 1) * self.ncp] = self.controlpoints[sym]
+
+    def dessemble_X(self, infos):
+        for sym, pos, td in infos:
+            self.controlpoints[sym] = self.x[pos * self.ncp:(pos + 1) * self.ncp].clone()
+
+    # -- operator wrappers ------------------------------------------------------------------------
+    def _layout(self, g: _Group, colours: bool):
+        offs = g.colour_offsets if colours else None
+        if offs is None:
+            return _lib.OpLayout(g.itg, self.itp, 1 + self.dim, g.weights.numel() // g.itg, 1, 0, None), None
+        arr = (C.c_int64 * len(offs))(*[int(v) for v in offs])
+        return _lib.OpLayout(g.itg, self.itp, 1 + self.dim, g.weights.numel() // g.itg, 1, len(offs) - 1, arr), arr
+
+    def _var(self, g: _Group, s: int, shift: int, x: torch.Tensor) -> torch.Tensor:
+        tgt = torch.zeros(g.n * g.itg, dtype=torch.float64, device=self.dev)  # FEM_buffer zeros (05_CodeGenerator.jl:4)
+        L, _k = self._layout(g, False)
+        check(lib.mfem_op_var(self.ctx._h, C.byref(L), g.vals.data_ptr(), s, shift, self.cp.data_ptr(), x.data_ptr(), tgt.data_ptr(),
+                              g.host_ids.data_ptr(), g.el_ids.data_ptr(), g.n))
+        return tgt.view(g.n, g.itg)
+
+    def _w(self, g: _Group) -> torch.Tensor:
+        """local_integral_weights[:, local_itg_hostIDs] as [n_items, itg]."""
+        return g.weights.view(-1, g.itg)[(g.host_ids - 1).long()]
+
+    def _kval(self, g: _Group, t: GradTerm, vals: torch.Tensor, K: torch.Tensor):
+        u = t.dual_pos * self.n_fields + t.base_pos
+        L, _k = self._layout(g, True)
+        check(lib.mfem_op_kval(self.ctx._h, C.byref(L), g.vals.data_ptr(), t.dual_s, t.base_s, vals.data_ptr(),
+                               self.slots[u].data_ptr(), 0, K.data_ptr(), g.host_ids.data_ptr(), g.el_ids.data_ptr(), g.n))
+
+    def _res(self, g: _Group, t: ResTerm, vals: torch.Tensor):
+        L, _k = self._layout(g, True)
+        check(lib.mfem_op_res(self.ctx._h, C.byref(L), g.vals.data_ptr(), t.dual_s, vals.data_ptr(), t.dual_pos * self.ncp,
+                              self.cp.data_ptr(), self.residue.data_ptr(), g.host_ids.data_ptr(), g.el_ids.data_ptr(), g.n))
+
+    def _externals(self, wf: WeakForm, g: _Group, env: dict):
+        for name, sym, s in wf.cp_ext_vars:  # declare_Extervar_GPU (05_CodeGenerator.jl:15-50)
+            env[name] = self._var(g, s, 0, self.controlpoints[sym])
+        for name, comp in wf.normals:
+            env[name] = g.normals[:, comp, :][(g.host_ids - 1).long()]
+        env["t"], env["dt"] = self.t, self.dt
+
+    def _vals(self, fn, env, w, scale=1.0) -> torch.Tensor:
+        v = fn(env)
+        if not torch.is_tensor(v):
+            v = torch.full_like(w, float(v))
+        return (v * scale * w).contiguous()
+
+    def _parts(self):
+        yield self.domain_wf, self.groups[0]
+        for wf, g in zip(self.bwfs, self.groups[1:]):
+            yield wf, g
+
+    # -- generated updater bodies -------------------------------------------------------------------
+    def K_linear_func(self):
+        self.K_linear.zero_()
+        for wf, g in self._parts():
+            if not wf.linear_gradients:
+                continue
+            env: dict = {}
+            self._externals(wf, g, env)
+            w = self._w(g)
+            for t in wf.linear_gradients:
+                self._kval(g, t, self._vals(t.fn, env, w, self.K_params[t.td_order]), self.K_linear)
+
+    def K_nonlinear_func(self):
+        self.residue.zero_()
+        self.K_total.copy_(self.K_linear)  # 05_CodeGenerator.jl:282-283
+        for wf, g in self._parts():
+            env: dict = {}
+            for name, pos, s, td in wf.inner_vars:  # declare_Innervar_GPU (:1-13)
+                env[name] = self._var(g, s, td * self.basicfield_size + pos * self.ncp, self.x_star)
+            self._externals(wf, g, env)
+            w = self._w(g)
+            for t in wf.residues:
+                self._res(g, t, self._vals(t.fn, env, w))
+            for t in wf.nonlinear_gradients:
+                self._kval(g, t, self._vals(t.fn, env, w, self.K_params[t.td_order]), self.K_total)
+
+    def update_OneStep(self, max_iter: int = 4):
+        """update_OneStep! (04_Time_Domain.jl:59-80), static (max_time_level = 0)."""
+        from . import normalized_norm
+
+        self.t += self.dt
+        self.dx.zero_()
+        self.K_linear_func()
+        counter = -1
+        self.history = []
+        while True:
+            torch.add(self.x, self.dx, out=self.x_star)
+            self.K_nonlinear_func()
+            res = normalized_norm(self.residue, self.ctx)
+            counter += 1
+            self.history.append(res)
+            if res < self.converge_tol or counter > max_iter:
+                break
+            delta_x = self.linear_solver(self)
+            self.dx -= delta_x
+        self.x += self.dx
+        return self.history

@@ -1,0 +1,174 @@
+"""GPU end-to-end on the GENERIC path (device geometry + pattern + S3 operators + Krylov), checked against the oracle AND
+against the reference's own committed outputs:
+  C1  examples/thermal_conduction/2D_Script.jl            -> 2D_Ceramic_Strip.vtk
+  C5  examples/incompressible_flow/lid_driven_cavity_flow  -> 2D_Cavity_Flow.vtk (Re = 1000)
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _to_product_wf(mf, wf):
+    from metafem_jl_amd import generic as G
+
+    return G.WeakForm(inner_vars=list(wf.inner_vars), cp_ext_vars=list(wf.cp_ext_vars), normals=list(wf.normals),
+                      residues=[G.ResTerm(r.dual_pos, r.dual_s, r.fn) for r in wf.residues],
+                      linear_gradients=[G.GradTerm(g.dual_pos, g.dual_s, g.base_pos, g.base_s, g.fn, g.td_order) for g in wf.linear_gradients],
+                      nonlinear_gradients=[G.GradTerm(g.dual_pos, g.dual_s, g.base_pos, g.base_s, g.fn, g.td_order) for g in wf.nonlinear_gradients])
+
+
+def _gpu_domain(mf, od, itp_type, order, itg, colours=None):
+    """Build the product's GenericDomain from an oracle FEMDomain's mesh + weak forms (the weak forms are data)."""
+    from metafem_jl_amd import element, generic as G
+
+    space = element.classical_space(od.disc.dim, itp_type, order, itg)
+    bnd = [(f.element_ID, f.element_eindex, _to_product_wf(mf, wf)) for f, wf in od.boundaries]
+    return G.GenericDomain(mf.default_context(), space, od.mesh.coords, od.mesh.cp_ids, od.n_fields, _to_product_wf(mf, od.domain_wf),
+                           bnd, element_colours=colours)
+
+
+@pytest.mark.parametrize("kind", ["quad8", "hex8", "hex27", "hex20"])
+def test_device_geometry_update_matches_oracle(mf, kind):
+    import torch
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    if kind == "quad8":
+        disc = re_.initialize_classical_element(2, "CUBE", 2, 1, 5, itp_type="Serendipity")
+        vert, conn = om.make_square((2.0, 1.0), (5, 4))
+        args = ("Serendipity", 2, 5)
+    else:
+        order, t = {"hex8": (1, "Lagrange"), "hex27": (2, "Lagrange"), "hex20": (2, "Serendipity")}[kind]
+        disc = re_.initialize_classical_element(3, "CUBE", order, 1, 5, itp_type=t)
+        vert, conn = om.make_brick((1.0, 2.0, 1.5), (3, 2, 2))
+        args = (t, order, 5)
+    msh = om.mesh_classical(vert, conn, disc)
+    c = msh.coords
+    msh.coords = c + 0.03 * np.sin(2.0 * c[:, ::-1] + 0.3)
+    fac = om.boundary_facets(msh)
+    dim = disc.dim
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(dim, 1.0), [(fac, problems.thermal_convection(1.0, 0.0))])
+    gd = _gpu_domain(mf, od, *args)
+    g0 = gd.groups[0]
+    nel, itp, itg = msh.nel, disc.itp_func_num, disc.itg_func_num
+    v = g0.vals.cpu().numpy().reshape(nel, 1 + dim, itp, itg).transpose(3, 2, 1, 0)
+    assert np.allclose(v, od.elgeo.integral_vals, rtol=0, atol=1e-12 * np.abs(od.elgeo.integral_vals).max())
+    assert np.allclose(g0.weights.cpu().numpy().reshape(nel, itg).T, od.elgeo.integral_weights, rtol=1e-13)
+    g1, fg = gd.groups[1], od.fgeo[0]
+    nf, itb = len(fac), disc.bdy_itg_func_num
+    fv = g1.vals.cpu().numpy().reshape(nf, 1 + dim, itp, itb).transpose(3, 2, 1, 0)
+    assert np.allclose(fv, fg.integral_vals, rtol=0, atol=1e-12 * np.abs(fg.integral_vals).max())
+    assert np.allclose(g1.weights.cpu().numpy().reshape(nf, itb).T, fg.integral_weights, rtol=1e-13)
+    assert np.allclose(g1.normals.cpu().numpy().transpose(2, 1, 0), fg.normal_directions, rtol=0, atol=1e-13)
+
+
+def test_c1_thermal_strip_on_gpu_reproduces_reference_vtk(mf):
+    """The reference example, generic GPU path, the reference's own solver choice (idrs!, s = 8)."""
+    import torch
+    from oracle import fem, mesh as om, problems, reference_element as re_, solvers
+
+    L1, L2, nx, ny = 0.02, 0.01, 40, 20
+    disc = re_.initialize_classical_element(2, "CUBE", 2, 1, 5, itp_type="Serendipity")
+    vert, conn = om.make_square((L1, L2), (nx, ny))
+    mesh = om.mesh_classical(vert, conn, disc)
+    fac = om.boundary_facets(mesh)
+    err = (L1 / nx) * 0.01
+    lr = (np.abs(fac.centroid[:, 0]) < err) | (np.abs(fac.centroid[:, 0] - L1) < err)
+    top = np.abs(fac.centroid[:, 1] - L2) < err
+    od = fem.FEMDomain(mesh, disc, 1, problems.thermal_domain(2, 3),
+                       [(fac.select(lr), problems.thermal_fixed(2, 1.0e5, 1173.15, 3)),  # h_penalty of the VTK, see test_oracle_golden
+                        (fac.select(top), problems.thermal_convection(50, 323.15, 0.7, 5.669e-8))])
+    od.controlpoints["s"] = np.zeros(mesh.ncp)
+    od.converge_tol = 1e-6
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    od.update_one_step()
+
+    gd = _gpu_domain(mf, od, "Serendipity", 2, 5)
+    gd.controlpoints["s"] = torch.zeros(mesh.ncp, dtype=torch.float64, device="cuda")
+    gd.converge_tol = 1e-6
+    gd.linear_solver = lambda g: mf.iterative_Solve(g.A, g.K_total, g.residue, 1e-3 * g.converge_tol, Sv_func=mf.idrs_, maxiter=2000,
+                                                    max_pass=10, s=8)[0]
+    hist = gd.update_OneStep()
+    assert hist[-1] < 1e-6 and len(hist) <= 6
+    T = gd.x.cpu().numpy()
+    assert np.abs(T - od.x).max() <= 1e-7 * np.abs(od.x).max()          # vs the oracle (same Newton path)
+    z = np.load(os.path.join(GOLD, "ceramic_strip_T.npz"))
+    d, idx = cKDTree(mesh.coords).query(z["xy"])
+    assert (np.abs(T[idx] - z["T"]) / np.abs(z["T"])).max() < 1e-5       # vs the reference's committed result
+
+
+def test_c5_cavity_newton_steps_match_oracle(mf):
+    """Two load steps on a 10 x 10 cavity: 3 fields, 9 sparse blocks, SUPG/PSPG nonlinear gradients, Nitsche walls."""
+    import torch
+    from oracle import cavity, solvers
+
+    od = cavity.build_cavity(10, Cb=128.0)
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    gd = _gpu_domain(mf, od, "Serendipity", 2, 5)
+    gd.converge_tol = od.converge_tol = 1e-8
+    for sv, s in ((mf.bicgstabl_GS_, 4), (mf.idrs_, 8)):
+        od.x[:] = 0.0
+        od.dessemble_x(cavity.INNER_INFOS)
+        gd.x.zero_()
+        # tolerance relative to the right-hand side: an absolute 1e-12 is below what FP64 can reach on this matrix
+        gd.linear_solver = lambda g, sv=sv, s=s: mf.iterative_Solve(g.A, g.K_total, g.residue, 1e-10 * mf.normalized_norm(g.residue),
+                                                                     Sv_func=sv, maxiter=4000, max_pass=20, s=s)[0]
+        for step in (1, 2):
+            cavity.set_step_parameters(od, 0.05 * step)
+            for k in ("uw1", "uw2", "taum", "tauc"):
+                gd.controlpoints[k] = torch.tensor(od.controlpoints[k], device="cuda")
+            gd.dt = od.dt
+            ho = od.update_one_step(max_iter=6)
+            od.dessemble_x(cavity.INNER_INFOS)
+            hg = gd.update_OneStep(max_iter=6)
+            assert len(hg) == len(ho)
+            assert np.allclose(hg[:2], ho[:2], rtol=1e-8)
+            got = gd.x.cpu().numpy()
+            n = od.mesh.ncp
+            for f in (1, 2):  # velocities
+                assert np.abs(got[f * n:(f + 1) * n] - od.x[f * n:(f + 1) * n]).max() <= 1e-7 * 0.1
+            pg, po = got[:n], od.x[:n]  # pressure: up to the unpinned constant
+            assert np.abs((pg - pg.mean()) - (po - po.mean())).max() <= 1e-6 * (po.max() - po.min() + 1e-30)
+
+
+def test_c5_cavity_re1000_on_gpu_reproduces_reference_vtk(mf):
+    """configs[4] at the reference's size: 40 x 40 quad-8, 14 883 DOF, Re = 1000, ten load steps, with the script's own
+    solver choice cgs2! (2D_Script.jl:97: maxiter = 5000, max_pass = 20)."""
+    import torch
+    from oracle import cavity
+
+    z = np.load(os.path.join(GOLD, "cavity_flow_Re1000.npz"))
+    od = cavity.build_cavity(40, Cb=8.0)  # only used for mesh + term lists + the parameter formulas of the script
+    gd = _gpu_domain(mf, od, "Serendipity", 2, 5)
+    gd.converge_tol = 1e-5
+    stats = []
+
+    def solver(g):
+        dx, st = mf.iterative_Solve(g.A, g.K_total, g.residue, 1e-3 * g.converge_tol, Sv_func=mf.cgs2_, maxiter=5000, max_pass=20)
+        stats.append(st)
+        return dx
+
+    gd.linear_solver = solver
+    P = od.params
+    n = od.mesh.ncp
+    u_st = 1000.0 / P["L"] * P["mu"] / P["rho"]
+    od.controlpoints["u1"], od.controlpoints["u2"] = np.zeros(n), np.zeros(n)
+    for i in range(1, 11):
+        cavity.set_step_parameters(od, u_st * i / 10)  # host-side parameter formulas (2D_Script.jl:122-127)
+        for k in ("uw1", "uw2", "taum", "tauc"):
+            gd.controlpoints[k] = torch.tensor(od.controlpoints[k], device="cuda")
+        gd.dt = od.dt
+        hist = gd.update_OneStep(max_iter=6)
+        assert hist[-1] < 1e-5, (i, hist)
+        x = gd.x.cpu().numpy()
+        od.controlpoints["u1"], od.controlpoints["u2"] = x[n:2 * n], x[2 * n:3 * n]  # dessemble_X!
+    assert all(s.converged for s in stats)
+    d, idx = cKDTree(od.mesh.coords).query(z["xy"])
+    assert np.abs(x[n:2 * n][idx] - z["u1"]).max() < 5e-4
+    assert np.abs(x[2 * n:][idx] - z["u2"]).max() < 5e-4
+    pa, pb = x[:n][idx], z["p"]
+    assert np.abs((pa - pa.mean()) - (pb - pb.mean())).max() < 5e-4 * (pb.max() - pb.min())
