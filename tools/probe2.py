@@ -19,15 +19,13 @@ def read():
 _lib.check(lib.mfem_prof_spmv_enable(ctx._h, 1))
 b = torch.ones(A.n, dtype=torch.float64, device="cuda")
 lib.mfem_debug_set_spmv(0 | (1 << 16), 8)
-for en, cap, mult in ((0, 4032, 8), (1, 4032, 3), (1, 2016, 5), (1, 2016, 6), (1, 2016, 7), (1, 2016, 8), (1, 2016, 12)):
-    lib.mfem_debug_set_spmv_window(en, cap, mult)
-    A2 = brick.pattern(1)
-    for _ in range(10): mf.mul_(y, A2, K, x)
+for vm, mult in ((0, 8), (2, 8), (2, 16), (1, 8), (1, 16), (3, 8), (2, 32)):
+    lib.mfem_debug_set_spmv((1 << 16) | (vm << 24), mult)
+    for _ in range(10): mf.mul_(y, A, K, x)
     read()
-    for _ in range(30): mf.mul_(y, A2, K, x)
+    for _ in range(30): mf.mul_(y, A, K, x)
     ms = read()
-    mf.iterative_Solve(A2, K, b, 1e-30, Sv_func=mf.cg_, maxiter=60, max_pass=1, fixed_iterations=True)
+    mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=60, max_pass=1, fixed_iterations=True)
     ms2 = read()
-    print(f"window {en} cap {cap} mult {mult}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
-    del A2
-lib.mfem_debug_set_spmv_window(0, 4032, 8)
+    print(f"vecmode {vm} (lanes/row {0 if vm == 0 else 1 << (vm + 2)}) mult {mult}: standalone {ms:.4f} ms {bytes_spmv/ms/1e6:.0f} GB/s | in CG {ms2:.4f} ms {bytes_spmv/ms2/1e6:.0f} GB/s", flush=True)
+lib.mfem_debug_set_spmv(1 << 16, 8)
