@@ -173,177 +173,227 @@ __device__ __forceinline__ void node_ijk(const BrickView& B, int64_t node, int& 
 }
 
 // =================================================================================================
-// Thermal K:  vals = sum_el sum_q w (-k) grad N_a . grad N_b  +  sum_facets sum_q w^s (-h) N_a N_b
-// One thread per owned control point; the workgroup's 256 rows are contiguous in CSR and are staged in
-// LDS (<= 256*27 doubles = 54 KiB), then stored as one coalesced stream.
+// Boundary-face visitor: for an owned node (i,j,k), every element face that (a) lies on a brick face
+// selected in `mask` and (b) contains the node.  f(nd, side, ca, fn, Xf): nd normal dim, side 0 low /
+// 1 high, ca = the node's id among the 4 face nodes, fn[c][3] lattice ids and Xf[c][3] coordinates.
 // =================================================================================================
-#define TH_ROWS MFEM_BLOCK
-#define TH_LDS (TH_ROWS * 27)
-
-__global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix(BrickView B, double kcond, double h, uint32_t robin,
-                                                                 double* __restrict__ vals) {
-  __shared__ double acc[TH_LDS];
-  const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * TH_ROWS;
-  const int64_t node = r0 + tid;
-  const bool valid = node < B.n_owned;
-  int i0, j0, k0;
-  node_ijk(B, r0, i0, j0, k0);
-  const int64_t pre0 = brick_prefix(B, i0, j0, k0);
-  int64_t cnt_total;
-  {
-    const int64_t r1 = (r0 + TH_ROWS < B.n_owned) ? r0 + TH_ROWS : B.n_owned;
-    if (r1 < B.n_owned) {
-      int i1, j1, k1;
-      node_ijk(B, r1, i1, j1, k1);
-      cnt_total = brick_prefix(B, i1, j1, k1) - pre0;
-    } else {
-      cnt_total = (B.P0[B.phi] - B.Pplo) * B.S1 * B.S2 - pre0;
-    }
-  }
-  for (int t = tid; t < (int)cnt_total; t += MFEM_BLOCK) acc[t] = 0.0;
-  __syncthreads();
-  if (valid) {
-    int i, j, k;
-    node_ijk(B, node, i, j, k);
-    const int base = (int)(brick_prefix(B, i, j, k) - pre0);
-    const int li = B.lo0[i], lj = B.lo1[j], lk = B.lo2[k];
-    const int cj = B.c1[j], ck = B.c2[k];
-    // ---- volume terms: adjacent elements (i-1+ex, j-1+ey, k-1+ez)
-    for (int e = 0; e < 8; ++e) {
-      const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
-      const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
-      if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
-      const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);  // my local basis id inside that element
-      double X[8][3];
-      hex8_load_coords(B, I, J, K, X);
-      double kab[8];
+template <typename Fn>
+__device__ __forceinline__ void visit_boundary_faces(const BrickView& B, int i, int j, int k, uint32_t mask, Fn f) {
+  if (mask == 0u) return;
+  const int idx[3] = {i, j, k};
+  const int ne[3] = {B.ne0, B.ne1, B.ne2};
+  for (int nd = 0; nd < 3; ++nd) {
+    for (int side = 0; side < 2; ++side) {
+      const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
+      if (!on || !(mask & face_bit(nd, side))) continue;
+      const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int f1 = q4 & 1, f2 = q4 >> 1;
+        const int E1 = idx[t1] - 1 + f1, E2 = idx[t2] - 1 + f2;
+        if (E1 < 0 || E1 >= ne[t1] || E2 < 0 || E2 >= ne[t2]) continue;
+        const int ca = (1 - f1) + 2 * (1 - f2);
+        int fn[4][3];
+        double Xf[4][3];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) kab[b] = 0.0;
-      const int nq = B.ng * B.ng * B.ng;
-      for (int q = 0; q < nq; ++q) {
-        double g[8][3];
-        const double wd = hex8_geom(X, q, g);
-        double ga0 = 0.0, ga1 = 0.0, ga2 = 0.0;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const bool me = (b == a);
-          ga0 = me ? g[b][0] : ga0;
-          ga1 = me ? g[b][1] : ga1;
-          ga2 = me ? g[b][2] : ga2;
+        for (int c = 0; c < 4; ++c) {
+          fn[c][nd] = idx[nd];
+          fn[c][t1] = E1 + (c & 1);
+          fn[c][t2] = E2 + (c >> 1);
+          const int64_t ci = brick_cindex(B, fn[c][0], fn[c][1], fn[c][2]);
+          Xf[c][0] = B.X0[ci];
+          Xf[c][1] = B.X1[ci];
+          Xf[c][2] = B.X2[ci];
         }
-        const double c = -kcond * wd;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) kab[b] += c * (ga0 * g[b][0] + ga1 * g[b][1] + ga2 * g[b][2]);
-      }
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
-        const int slot = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
-        acc[base + slot] += kab[b];
-      }
-    }
-    // ---- Robin faces: h*Bilinear(T, Tenv - T) contributes -h N_a N_b (3D_Script.jl:31)
-    if (h != 0.0 && robin != 0u) {
-      const int idx[3] = {i, j, k};
-      const int ne[3] = {B.ne0, B.ne1, B.ne2};
-      for (int nd = 0; nd < 3; ++nd) {
-        const int hi = (idx[nd] == ne[nd]) ? 1 : 0;
-        if (idx[nd] != 0 && !hi) continue;
-        for (int side = 0; side < 2; ++side) {  // a 1-element-thick dim touches both faces
-          const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
-          if (!on || !(robin & face_bit(nd, side))) continue;
-          const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
-          for (int f = 0; f < 4; ++f) {
-            const int f1 = f & 1, f2 = f >> 1;
-            int E[3];
-            E[nd] = side ? ne[nd] - 1 : 0;
-            E[t1] = idx[t1] - 1 + f1;
-            E[t2] = idx[t2] - 1 + f2;
-            if (E[t1] < 0 || E[t1] >= ne[t1] || E[t2] < 0 || E[t2] >= ne[t2]) continue;
-            const int ca = (1 - f1) + 2 * (1 - f2);  // my id among the 4 face nodes
-            double Xf[4][3];
-            int fn[4][3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              fn[c][nd] = idx[nd];
-              fn[c][t1] = E[t1] + (c & 1);
-              fn[c][t2] = E[t2] + (c >> 1);
-              const int64_t ci = brick_cindex(B, fn[c][0], fn[c][1], fn[c][2]);
-              Xf[c][0] = B.X0[ci];
-              Xf[c][1] = B.X1[ci];
-              Xf[c][2] = B.X2[ci];
-            }
-            double mab[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int q = 0; q < B.ng * B.ng; ++q) {
-              const double ws = face_geom(Xf, q, side == 0, nullptr);
-              double na = 0.0;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) na = (c == ca) ? c_fN[q][c] : na;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) mab[c] += -h * ws * na * c_fN[q][c];
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const int slot = ((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk);
-              acc[base + slot] += mab[c];
-            }
-          }
-        }
+        f(nd, side, ca, fn, Xf);
       }
     }
   }
-  __syncthreads();
-  double* out = vals + pre0;
-  for (int t = tid; t < (int)cnt_total; t += MFEM_BLOCK) out[t] = acc[t];
 }
 
 // =================================================================================================
-// Thermal residual (matrix-free, at x_star):
-//   R[a] = sum_q w (-k grad N_a . grad T + N_a s) + sum_q w^s N_a h (Tenv - T)
+// Thermal K:  vals = sum_el sum_q w (-k) grad N_a . grad N_b  +  sum_facets sum_q w^s (-h) N_a N_b
+// Row-owner with element sharing: a workgroup owns a 4 x 4 x 8 tile of control points (128 threads).
+//   phase A: the 5 x 5 x 9 elements touching the tile are integrated ONCE each (one thread per element: J, det,
+//            J^-1, gradients at every Gauss point -> the 36 unique entries of the symmetric 8 x 8 Ke) into LDS;
+//   phase B: every control point gathers its row from the <= 8 adjacent Ke (64 statically indexed adds) and
+//            writes its <= 27 CSR values once -- no atomics, no colours, nnz*8 B written exactly once.
+// Geometry is evaluated 225/128 = 1.76x per element instead of 8x in the plain row-owner form.
 // =================================================================================================
-__global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_residual(BrickView B, double kcond, double h, double Tenv,
-                                                                   uint32_t robin, const double* __restrict__ x,
-                                                                   const double* __restrict__ src,
-                                                                   double* __restrict__ res) {
-  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= B.n_owned) return;
-  int i, j, k;
-  node_ijk(B, node, i, j, k);
-  double r = 0.0;
+#define TT_NI 4
+#define TT_NJ 4
+#define TT_NK 8
+#define TT_THREADS (TT_NI * TT_NJ * TT_NK)
+#define TT_EI (TT_NI + 1)
+#define TT_EJ (TT_NJ + 1)
+#define TT_EK (TT_NK + 1)
+#define TT_NEL (TT_EI * TT_EJ * TT_EK)
+#define TT_KSTRIDE 37  // 36 unique entries + 1 pad (LDS bank spread)
+
+__device__ __forceinline__ constexpr int sym36(int a, int b) {  // upper-triangular packing of a symmetric 8 x 8
+  return a <= b ? a * 8 - (a * (a - 1)) / 2 + (b - a) : b * 8 - (b * (b - 1)) / 2 + (a - b);
+}
+
+struct TileGeom {
+  int ti, tj, tk;  // first control point of the tile (global lattice ids)
+};
+__device__ __forceinline__ TileGeom tile_origin(const BrickView& B, int64_t tile) {
+  const int ntk = (B.m2 + TT_NK - 1) / TT_NK, ntj = (B.m1 + TT_NJ - 1) / TT_NJ;
+  TileGeom t;
+  t.tk = (int)(tile % ntk) * TT_NK;
+  t.tj = (int)((tile / ntk) % ntj) * TT_NJ;
+  t.ti = (int)(tile / ((int64_t)ntk * ntj)) * TT_NI + B.plo;
+  return t;
+}
+
+__global__ __launch_bounds__(TT_THREADS) void k_thermal_matrix(BrickView B, double kcond, double* __restrict__ vals) {
+  __shared__ double Ke[TT_NEL * TT_KSTRIDE];
+  const int tid = threadIdx.x;
+  const TileGeom T = tile_origin(B, blockIdx.x);
+  // ---- phase A: one thread per element of the halo'd tile
+  for (int e = tid; e < TT_NEL; e += TT_THREADS) {
+    const int ek = e % TT_EK, ej = (e / TT_EK) % TT_EJ, ei = e / (TT_EK * TT_EJ);
+    const int I = T.ti - 1 + ei, J = T.tj - 1 + ej, K = T.tk - 1 + ek;
+    // elements needed by owned rows only: I in [plo-1, phi-1]
+    if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2 || I < B.plo - 1 || I > B.phi - 1) continue;
+    double X[8][3];
+    hex8_load_coords(B, I, J, K, X);
+    double k36[36];
+#pragma unroll
+    for (int t = 0; t < 36; ++t) k36[t] = 0.0;
+    const int nq = B.ng * B.ng * B.ng;
+    for (int q = 0; q < nq; ++q) {
+      double g[8][3];
+      const double c = -kcond * hex8_geom(X, q, g);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = a; b < 8; ++b) k36[sym36(a, b)] += c * (g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2]);
+    }
+#pragma unroll
+    for (int t = 0; t < 36; ++t) Ke[e * TT_KSTRIDE + t] = k36[t];
+  }
+  __syncthreads();
+  // ---- phase B: one thread per control point
+  const int lk = tid % TT_NK, lj = (tid / TT_NK) % TT_NJ, li = tid / (TT_NK * TT_NJ);
+  const int i = T.ti + li, j = T.tj + lj, k = T.tk + lk;
+  if (i >= B.phi || j >= B.m1 || k >= B.m2) return;
+  double acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.0;
+#pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
     const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
     if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
     const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
-    double X[8][3], T[8], S[8];
+    const double* ke = Ke + ((li + ex) * (TT_EJ * TT_EK) + (lj + ey) * TT_EK + (lk + ez)) * TT_KSTRIDE;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int di = ex + (b & 1), dj = ey + ((b >> 1) & 1), dk = ez + (b >> 2);  // 0..2 = neighbour offset + 1
+      acc[(di * 3 + dj) * 3 + dk] += ke[sym36(a, b)];
+    }
+  }
+  const int li0 = B.lo0[i], lj0 = B.lo1[j], lk0 = B.lo2[k];
+  const int cj = B.c1[j], ck = B.c2[k];
+  double* row = vals + brick_prefix(B, i, j, k);
+#pragma unroll
+  for (int di = 0; di < 3; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 3; ++dk) {
+        const int ni = i - 1 + di, nj = j - 1 + dj, nk = k - 1 + dk;
+        if (ni < 0 || ni >= B.m0 || nj < 0 || nj >= B.m1 || nk < 0 || nk >= B.m2) continue;
+        row[((ni - li0) * cj + (nj - lj0)) * ck + (nk - lk0)] = acc[(di * 3 + dj) * 3 + dk];
+      }
+}
+
+// Robin faces: h*Bilinear(T, Tenv - T) contributes -h N_a N_b (3D_Script.jl:31).  One thread per control point; only
+// boundary points do work; a point read-modify-writes its OWN row (row owner => race-free), after k_thermal_matrix.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix_robin(BrickView B, double h, uint32_t robin,
+                                                                       double* __restrict__ vals) {
+  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= B.n_owned) return;
+  int i, j, k;
+  node_ijk(B, node, i, j, k);
+  if (i != 0 && i != B.ne0 && j != 0 && j != B.ne1 && k != 0 && k != B.ne2) return;
+  const int li = B.lo0[i], lj = B.lo1[j], lk = B.lo2[k];
+  const int cj = B.c1[j], ck = B.c2[k];
+  double* row = vals + brick_prefix(B, i, j, k);
+  visit_boundary_faces(B, i, j, k, robin, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
+    double mab[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < B.ng * B.ng; ++q) {
+      const double ws = face_geom(Xf, q, side == 0, nullptr);
+      double na = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) na = (c == ca) ? c_fN[q][c] : na;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mab[c] += -h * ws * na * c_fN[q][c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row[((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk)] += mab[c];
+  });
+}
+
+// =================================================================================================
+// Thermal residual (matrix-free, at x_star):
+//   R[a] = sum_q w (-k grad N_a . grad T + N_a s) + sum_q w^s N_a h (Tenv - T)
+// Same tiling as k_thermal_matrix: the element load vectors fe[8] of the 5 x 5 x 9 elements touching a 4 x 4 x 8
+// tile of control points are integrated once each into LDS, then every control point sums its <= 8 entries and adds
+// its own Robin face terms.
+// =================================================================================================
+__global__ __launch_bounds__(TT_THREADS) void k_thermal_residual(BrickView B, double kcond, double h, double Tenv,
+                                                                   uint32_t robin, const double* __restrict__ x,
+                                                                   const double* __restrict__ src,
+                                                                   double* __restrict__ res) {
+  __shared__ double Fe[TT_NEL * 9];
+  const int tid = threadIdx.x;
+  const TileGeom T = tile_origin(B, blockIdx.x);
+  for (int e = tid; e < TT_NEL; e += TT_THREADS) {
+    const int ek = e % TT_EK, ej = (e / TT_EK) % TT_EJ, ei = e / (TT_EK * TT_EJ);
+    const int I = T.ti - 1 + ei, J = T.tj - 1 + ej, K = T.tk - 1 + ek;
+    if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2 || I < B.plo - 1 || I > B.phi - 1) continue;
+    double X[8][3], Tn[8], Sn[8], fe[8];
     hex8_load_coords(B, I, J, K, X);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
-      const int64_t xi = brick_xindex(B, 0, ni, nj, nk);
-      T[b] = x[xi];
-      S[b] = src ? src[xi] : 0.0;
+      const int64_t xi = brick_xindex(B, 0, I + (b & 1), J + ((b >> 1) & 1), K + (b >> 2));
+      Tn[b] = x[xi];
+      Sn[b] = src ? src[xi] : 0.0;
+      fe[b] = 0.0;
     }
     const int nq = B.ng * B.ng * B.ng;
     for (int q = 0; q < nq; ++q) {
       double g[8][3];
       const double wd = hex8_geom(X, q, g);
-      double gT0 = 0.0, gT1 = 0.0, gT2 = 0.0, sq = 0.0, ga0 = 0.0, ga1 = 0.0, ga2 = 0.0, na = 0.0;
+      double gT0 = 0.0, gT1 = 0.0, gT2 = 0.0, sq = 0.0;
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        gT0 += g[b][0] * T[b];
-        gT1 += g[b][1] * T[b];
-        gT2 += g[b][2] * T[b];
-        sq += c_N[q][b] * S[b];
-        const bool me = (b == a);
-        ga0 = me ? g[b][0] : ga0;
-        ga1 = me ? g[b][1] : ga1;
-        ga2 = me ? g[b][2] : ga2;
-        na = me ? c_N[q][b] : na;
+        gT0 += g[b][0] * Tn[b];
+        gT1 += g[b][1] * Tn[b];
+        gT2 += g[b][2] * Tn[b];
+        sq += c_N[q][b] * Sn[b];
       }
-      r += wd * (-kcond * (ga0 * gT0 + ga1 * gT1 + ga2 * gT2) + na * sq);
+      const double c = -kcond * wd;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) fe[a] += c * (g[a][0] * gT0 + g[a][1] * gT1 + g[a][2] * gT2) + wd * c_N[q][a] * sq;
     }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) Fe[e * 9 + a] = fe[a];
+  }
+  __syncthreads();
+  const int lk = tid % TT_NK, lj = (tid / TT_NK) % TT_NJ, li = tid / (TT_NK * TT_NJ);
+  const int i = T.ti + li, j = T.tj + lj, k = T.tk + lk;
+  if (i >= B.phi || j >= B.m1 || k >= B.m2) return;
+  const int64_t node = (int64_t)(i - B.plo) * B.plane_len + (int64_t)j * B.m2 + k;
+  double r = 0.0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
+    const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
+    if (I < 0 || I >= B.ne0 || J < 0 || J >= B.ne1 || K < 0 || K >= B.ne2) continue;
+    const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
+    r += Fe[((li + ex) * (TT_EJ * TT_EK) + (lj + ey) * TT_EK + (lk + ez)) * 9 + a];
   }
   if (h != 0.0 && robin != 0u) {
     const int idx[3] = {i, j, k};
@@ -388,44 +438,6 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_residual(BrickView B, do
   res[node] = r;
 }
 
-
-// =================================================================================================
-// Boundary-face visitor: for an owned node (i,j,k), every element face that (a) lies on a brick face
-// selected in `mask` and (b) contains the node.  f(nd, side, ca, fn, Xf): nd normal dim, side 0 low /
-// 1 high, ca = the node's id among the 4 face nodes, fn[c][3] lattice ids and Xf[c][3] coordinates.
-// =================================================================================================
-template <typename Fn>
-__device__ __forceinline__ void visit_boundary_faces(const BrickView& B, int i, int j, int k, uint32_t mask, Fn f) {
-  if (mask == 0u) return;
-  const int idx[3] = {i, j, k};
-  const int ne[3] = {B.ne0, B.ne1, B.ne2};
-  for (int nd = 0; nd < 3; ++nd) {
-    for (int side = 0; side < 2; ++side) {
-      const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
-      if (!on || !(mask & face_bit(nd, side))) continue;
-      const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int f1 = q4 & 1, f2 = q4 >> 1;
-        const int E1 = idx[t1] - 1 + f1, E2 = idx[t2] - 1 + f2;
-        if (E1 < 0 || E1 >= ne[t1] || E2 < 0 || E2 >= ne[t2]) continue;
-        const int ca = (1 - f1) + 2 * (1 - f2);
-        int fn[4][3];
-        double Xf[4][3];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          fn[c][nd] = idx[nd];
-          fn[c][t1] = E1 + (c & 1);
-          fn[c][t2] = E2 + (c >> 1);
-          const int64_t ci = brick_cindex(B, fn[c][0], fn[c][1], fn[c][2]);
-          Xf[c][0] = B.X0[ci];
-          Xf[c][1] = B.X1[ci];
-          Xf[c][2] = B.X2[ci];
-        }
-        f(nd, side, ca, fn, Xf);
-      }
-    }
-  }
-}
 
 // =================================================================================================
 // Linear elasticity (examples/linear_elasticity/cantilever/3D_Script.jl:52-63), 3 fields, field-major:
@@ -625,9 +637,14 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
-  const int grid = (int)((m->n_owned + TH_ROWS - 1) / TH_ROWS);
-  hipLaunchKernelGGL(k_thermal_matrix, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, p->h, p->robin_faces, vals);
+  const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
+  hipLaunchKernelGGL(k_thermal_matrix, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, vals);
   MFEM_CHECK_LAUNCH();
+  if (p->h != 0.0 && p->robin_faces != 0u) {
+    const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
+    hipLaunchKernelGGL(k_thermal_matrix_robin, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->h, p->robin_faces, vals);
+    MFEM_CHECK_LAUNCH();
+  }
   return MFEM_OK;
 }
 
@@ -638,9 +655,9 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
-  const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
-  hipLaunchKernelGGL(k_thermal_residual, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, p->h, p->Tenv,
-                     p->robin_faces, x_star, s, residue);
+  const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
+  hipLaunchKernelGGL(k_thermal_residual, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, p->h,
+                     p->Tenv, p->robin_faces, x_star, s, residue);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
 }
