@@ -86,6 +86,9 @@ int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
  * mfem_brick_pattern / mfem_pattern_build): enable = 0 keeps the plain CSR kernel; cap = 4032 | 2016 tile size
  * for plans created afterwards. */
 int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
+/* hex-27 matrix assembly variant: 0 (default) = colour-partitioned read-modify-write scatter straight from the MFMA
+ * accumulators; 1 = MFMA Ke -> element-major scratch + row-owner gather (every CSR value written once; slower today). */
+int mfem_debug_set_hex27(int two_pass);
 
 /* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */

@@ -121,6 +121,14 @@ struct Hex27Args {
 
 // Element of this colour with running index e -> (I,J,K); returns false past the end.
 __device__ __forceinline__ bool colour_element(const BrickView& B, int colour, int64_t e, int& I, int& J, int& K) {
+  if (colour < 0) {  // no colouring: plain lexicographic element order (the scratch path)
+    if (e >= (int64_t)B.ne0 * B.ne1 * B.ne2) return false;
+    const int ei = (int)e;
+    K = ei % B.ne2;
+    J = (ei / B.ne2) % B.ne1;
+    I = ei / (B.ne1 * B.ne2);
+    return true;
+  }
   const int cx = colour & 1, cy = (colour >> 1) & 1, cz = colour >> 2;
   const int n0 = (B.ne0 - cx + 1) >> 1, n1 = (B.ne1 - cy + 1) >> 1, n2 = (B.ne2 - cz + 1) >> 1;
   if (n0 <= 0 || n1 <= 0 || n2 <= 0 || e >= (int64_t)n0 * n1 * n2) return false;
@@ -165,11 +173,15 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
       W[W_X + 3 * lane + 0] = B.X0[c];
       W[W_X + 3 * lane + 1] = B.X1[c];
       W[W_X + 3 * lane + 2] = B.X2[c];
-      if (MATRIX) {
-        rowbase[lane] = brick_prefix(B, gi, gj, gk);
+      if (MATRIX && A.colour < 0) {
+        // two-pass path: no row descriptors needed
+      } else if (MATRIX) {
+        // slot(a, b) = rowbase[a] + gi_b * s1_a + gj_b * s2_a + gk_b   with the row's box origin folded into rowbase
+        const int c1 = B.c1[gj], c2 = B.c2[gk];
+        const int64_t s1 = (int64_t)c1 * c2;
+        rowbase[lane] = brick_prefix(B, gi, gj, gk) - ((int64_t)B.lo0[gi] * s1 + (int64_t)B.lo1[gj] * c2 + B.lo2[gk]);
         int32_t* in = info + 8 * lane;
-        in[0] = B.lo0[gi]; in[1] = B.lo1[gj]; in[2] = B.lo2[gk];
-        in[3] = B.c1[gj];  in[4] = B.c2[gk];
+        in[0] = (int32_t)s1; in[1] = c2;
         in[5] = gi; in[6] = gj; in[7] = gk;
       } else {
         const int64_t xi = brick_xindex(B, 0, gi, gj, gk);
@@ -221,11 +233,11 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
       d4_t C00 = {0, 0, 0, 0}, C01 = {0, 0, 0, 0}, C11 = {0, 0, 0, 0};
       const int c = lane & 15, kl = lane >> 4;
       const bool hi_ok = (c + 16) < 27;
-      for (int ks = 0; ks < nksteps; ++ks) {
-        const int r = 4 * ks + kl;
+      // row r = 4 ks + kl = 3 q + sidx advances by 4 per k-step: (q, sidx) -> (q + 1, sidx + 1) with carry
+      int q = kl / 3, sidx = kl - 3 * q, r = kl;
+      for (int ks = 0; ks < nksteps; ++ks, r += 4) {
         double v0 = 0.0, v1 = 0.0, dr = 0.0;
         if (r < nrows) {
-          const int q = r / 3, sidx = r - 3 * q;
           const double* Ji = W + W_J + q * 9 + sidx;
           const double i0 = Ji[0], i1 = Ji[3], i2 = Ji[6];
           const double* dn = s_dN + q * 81 + 3 * c;
@@ -233,10 +245,35 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
           if (hi_ok) v1 = dn[48] * i0 + dn[49] * i1 + dn[50] * i2;
           dr = -A.kcond * W[W_D + q];
         }
+        sidx += 1;
+        q += 1;
+        if (sidx == 3) {
+          sidx = 0;
+          q += 1;
+        }
         const double a0 = v0 * dr, a1 = v1 * dr;
         C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
         C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
         C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
+      }
+      if (A.colour < 0) {
+        // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
+        //      row-owner gather kernel below turns it into CSR rows.
+        double* ke = out + (int64_t)e * 729;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ra = kl + 4 * reg;
+          if (ra < 27) {
+            ke[ra * 27 + c] = C00[reg];
+            if (hi_ok) {
+              ke[ra * 27 + 16 + c] = C01[reg];
+              ke[(16 + c) * 27 + ra] = C01[reg];
+            }
+          }
+          if (16 + ra < 27 && hi_ok) ke[(16 + ra) * 27 + 16 + c] = C11[reg];
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
       }
       // ---- 4. colour-safe scatter: 16 entries per lane; all slots of one element are distinct, so the loads
       //      are issued together, then the stores (plain read-modify-write, no atomics).
@@ -256,7 +293,7 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
           if (_a < 27 && _b < 27) {
             const int32_t* ia = info + 8 * _a;
             const int32_t* ib = info + 8 * _b;
-            sl = rowbase[_a] + ((int64_t)(ib[5] - ia[0]) * ia[3] + (ib[6] - ia[1])) * ia[4] + (ib[7] - ia[2]);
+            sl = rowbase[_a] + (int64_t)ib[5] * ia[0] + (int64_t)ib[6] * ia[1] + ib[7];
           }
           slot[4 * reg + t] = sl;
           val[4 * reg + t] = vv[t];
@@ -308,6 +345,60 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Pass 2 of the two-pass assembly: one wave per CSR row (control point); lane t owns slot t, t + 64, ...; for every
+// adjacent element that contains both the row node and the slot's node it adds Ke_e[la][lb] from the scratch.
+// Reads 729*8 B per element once (each Ke row segment is a contiguous 216-byte run), writes every CSR value once.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather(BrickView B, const double* __restrict__ ke,
+                                                               double* __restrict__ vals) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t row = wave; row < B.n_owned; row += nwaves) {
+    int g[3];
+    g[0] = (int)(row / B.plane_len) + B.plo;
+    const int64_t rem = row % B.plane_len;
+    g[1] = (int)(rem / B.m2);
+    g[2] = (int)(rem % B.m2);
+    const int lo0 = B.lo0[g[0]], lo1 = B.lo1[g[1]], lo2 = B.lo2[g[2]];
+    const int c1 = B.c1[g[1]], c2 = B.c2[g[2]];
+    const int len = B.c0[g[0]] * c1 * c2;
+    const int ne[3] = {B.ne0, B.ne1, B.ne2};
+    int e0[3], cnt[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (g[d] & 1) {  // mid node of one element
+        e0[d] = (g[d] - 1) >> 1;
+        cnt[d] = 1;
+      } else {         // element-boundary node: elements g/2 - 1 and g/2
+        e0[d] = (g[d] >> 1) - 1;
+        cnt[d] = 2;
+      }
+    }
+    double* out = vals + brick_prefix(B, g[0], g[1], g[2]);
+    for (int t = lane; t < len; t += 64) {
+      const int nk = lo2 + t % c2, nj = lo1 + (t / c2) % c1, ni = lo0 + t / (c1 * c2);
+      double sum = 0.0;
+      for (int ex = 0; ex < cnt[0]; ++ex) {
+        const int E0 = e0[0] + ex;
+        if (E0 < 0 || E0 >= ne[0] || ni < 2 * E0 || ni > 2 * E0 + 2) continue;
+        for (int ey = 0; ey < cnt[1]; ++ey) {
+          const int E1 = e0[1] + ey;
+          if (E1 < 0 || E1 >= ne[1] || nj < 2 * E1 || nj > 2 * E1 + 2) continue;
+          for (int ez = 0; ez < cnt[2]; ++ez) {
+            const int E2 = e0[2] + ez;
+            if (E2 < 0 || E2 >= ne[2] || nk < 2 * E2 || nk > 2 * E2 + 2) continue;
+            const int la = (g[0] - 2 * E0) + 3 * (g[1] - 2 * E1) + 9 * (g[2] - 2 * E2);
+            const int lb = (ni - 2 * E0) + 3 * (nj - 2 * E1) + 9 * (nk - 2 * E2);
+            const int64_t eid = ((int64_t)E0 * ne[1] + E1) * ne[2] + E2;
+            sum += ke[(eid * 27 + la) * 27 + lb];
+          }
+        }
+      }
+      out[t] = sum;
+    }
   }
 }
 
@@ -381,6 +472,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
   }
 }
 
+// 0 (default): colour-partitioned RMW scatter; 1: Ke -> element-major scratch (MFMA kernel, no colours, no RMW) +
+// row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
+// (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
+static int g_hex27_two_pass = 0;
+extern "C" int mfem_debug_set_hex27(int two_pass) {
+  g_hex27_two_pass = two_pass ? 1 : 0;
+  return MFEM_OK;
+}
+
 static size_t hex27_lds_bytes(int nq, bool matrix) {
   return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + H27_WAVES * (size_t)(W_SIZE));
 }
@@ -417,8 +517,23 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   if (rc) return rc;
   const size_t lds = hex27_lds_bytes(nq, true);
   MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
   BrickView B = mfem_brick_view(m, 1);
+  if (g_hex27_two_pass) {
+    // pass 1: every element's Ke on the matrix cores -> element-major scratch; pass 2: row-owner gather -> CSR
+    const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
+    rc = mfem_ws_reserve(ctx, sizeof(double) * 729 * (size_t)nel);
+    if (rc) return rc;
+    Hex27Args A{B, g_tab, p->k, -1, nq};
+    int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
+    const int64_t cap = (int64_t)ctx->num_cus * 2;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)ctx->ws);
+    MFEM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_hex27_gather, dim3(ctx->num_cus * 8), dim3(MFEM_BLOCK), 0, ctx->stream, B, (const double*)ctx->ws, vals);
+    MFEM_CHECK_LAUNCH();
+    return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
+  }
+  MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
   for (int colour = 0; colour < 8; ++colour) {
     const int64_t n0 = (m->ne[0] - (colour & 1) + 1) >> 1, n1 = (m->ne[1] - ((colour >> 1) & 1) + 1) >> 1,
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;

@@ -27,9 +27,19 @@ def _oracle(x, n, itg=5, distort=False, faces=None):
     return od
 
 
+@pytest.fixture(params=[0, 1], ids=["colour_scatter", "two_pass_gather"])
+def variant(request):
+    """Both matrix-assembly variants: colour-partitioned RMW scatter (default) and MFMA Ke -> scratch + row-owner gather."""
+    from metafem_jl_amd import _lib
+
+    _lib.lib.mfem_debug_set_hex27(request.param)
+    yield request.param
+    _lib.lib.mfem_debug_set_hex27(0)
+
+
 @pytest.mark.parametrize("n,itg,distort,faces", [((1, 1, 1), 5, False, None), ((2, 2, 2), 5, False, None), ((3, 2, 4), 5, True, None),
                                                  ((2, 3, 1), 4, True, [0, 3, 5]), ((3, 3, 3), 3, True, None), ((2, 1, 2), 7, True, None)])
-def test_hex27_pattern_matrix_residual(mf, n, itg, distort, faces):
+def test_hex27_pattern_matrix_residual(mf, variant, n, itg, distort, faces):
     import torch
 
     x = (1.0, 1.5, 0.75)
@@ -52,7 +62,7 @@ def test_hex27_pattern_matrix_residual(mf, n, itg, distort, faces):
     assert np.max(np.abs(R - od.residue)) <= 1e-11 * np.max(np.abs(od.residue))
 
 
-def test_hex27_golden_fixture_and_solve(mf):
+def test_hex27_golden_fixture_and_solve(mf, variant):
     import torch
 
     z = np.load(os.path.join(GOLD, "oracle_thermal_hex27_2x2x2.npz"))
@@ -67,7 +77,7 @@ def test_hex27_golden_fixture_and_solve(mf):
     assert np.max(np.abs(dom.x.cpu().numpy() - z["T"])) <= 1e-10 * np.abs(z["T"]).max()
 
 
-def test_hex27_matrix_is_symmetric(mf):
+def test_hex27_matrix_is_symmetric(mf, variant):
     import scipy.sparse as sp
 
     brick = mf.make_Brick((1.0, 1.0, 1.0), (4, 3, 3), 2, 5)

@@ -16,8 +16,13 @@ brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 2, 5)
 A = brick.pattern(1)
 print(f"hex27 N={N} n={A.n} nnz={A.nnz}", flush=True)
 K = torch.empty(A.nnz, dtype=torch.float64, device="cuda")
-ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
+from metafem_jl_amd import _lib
 flops = brick.nel * (2 * 27 * 27 * 81)
+_lib.lib.mfem_debug_set_hex27(1)
+ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
+print(f"assemble two-pass (scratch + gather) {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful", flush=True)
+_lib.lib.mfem_debug_set_hex27(0)
+ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
 print(f"assemble (MFMA) {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful Ke (2*27*27*81 per element), {A.nnz*8/ms/1e6:.0f} GB/s of nnz*8", flush=True)
 x = mf.FEM_rand(A.n, 1, 0); y = torch.empty_like(x)
 ms = timeit(lambda: brick.residual_thermal(x, 0.6, 25.0, 293.15, 0x3F, s=x, out=y), reps=3)
