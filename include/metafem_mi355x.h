@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MFEM_ABI_VERSION 1
+#define MFEM_ABI_VERSION 2
 
 typedef enum {
   MFEM_OK = 0,
@@ -109,6 +109,12 @@ typedef enum {
   MFEM_PRECOND_JACOBI_RIGHT_COLNORM = 2 /* Pr_Jacobi!(normalized_by_column=true) */
 } mfem_precond_kind;
 
+typedef enum {
+  MFEM_LEFT_NONE = 0,         /* Pl_func = Identity (iterative_Solve! default) */
+  MFEM_LEFT_JACOBI_DIAG = 1,  /* Pl_Jacobi(A), 02_Preconditioner.jl:155-168: b ./= |diag| of the (already Pr-scaled) matrix */
+  MFEM_LEFT_JACOBI_ROWNORM = 2/* Pl_Jacobi(A; normalized_by_row = true), :160-162,170-177 */
+} mfem_left_precond_kind;
+
 typedef struct {
   int32_t method;        /* mfem_solver_kind */
   int32_t precond;       /* mfem_precond_kind.  For CG, JACOBI_* means M = |diag K| (standard PCG). */
@@ -122,6 +128,11 @@ typedef struct {
   int32_t scale_in_place;   /* !=0: Pr_Jacobi! semantics -- `vals` is overwritten by the column-scaled matrix
                                (the reference scales its private gather K_total[K_val_ids], :35,118).
                                ==0: the library scales a private copy (nnz*8 B of workspace). */
+  int32_t left_precond;     /* mfem_left_precond_kind (Pl_func).  The reference applies Pl to every mat-vec result inside
+                               the Krylov body; here the rows of the working matrix and b are scaled once, which is the
+                               same operator.  The restart wrapper follows :57-60 (true residual un-scaled, tol_factor).
+                               Not valid with MFEM_SOLVER_CG (it would break symmetry). */
+  int32_t reserved;
 } mfem_solve_options;
 
 typedef struct {

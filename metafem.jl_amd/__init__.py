@@ -35,6 +35,7 @@ __all__ = ["Context", "FEM_SpMat_CSR", "mul_", "dot", "nrm2", "axpby_", "FEM_ran
 # solver / preconditioner selectors (the reference passes Julia functions: Sv_func! = idrs! ...)
 cg_, bicgstabl_GS_, idrs_, cgs2_ = 0, 1, 2, 3
 Identity, Pr_Jacobi_, Pr_Jacobi_colnorm_ = 0, 1, 2
+Pl_Jacobi_, Pl_Jacobi_rownorm_ = 1, 2  # Pl_func selectors (02_Preconditioner.jl:155-168)
 
 # reference local face ids (ref_geometry/002_Initialization.jl:8): 1 z=0, 2 y=0, 3 x=L, 4 y=L, 5 x=0, 6 z=L
 FACE_BITS = {"z0": 1 << 0, "y0": 1 << 1, "x1": 1 << 2, "y1": 1 << 3, "x0": 1 << 4, "z1": 1 << 5}
@@ -202,11 +203,13 @@ def mat_div_jacobi_(A: FEM_SpMat_CSR, vals: torch.Tensor, d: torch.Tensor) -> to
 
 
 def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tensor, converge_tol: float, *,
-                    Sv_func: int = idrs_, Pr_func: int = Pr_Jacobi_, max_pass: int = 4, maxiter: int = 2000,
+                    Sv_func: int = idrs_, Pr_func: int = Pr_Jacobi_, Pl_func: int = Identity, max_pass: int = 4,
+                    maxiter: int = 2000,
                     s: int = 0, seed: int = 0x5EED, check_every: int = 32, fixed_iterations: bool = False,
                     scale_in_place: bool = False, shadow: Optional[torch.Tensor] = None
                     ) -> Tuple[torch.Tensor, SolveStats]:
-    """iterative_Solve!(globalfield; Sv_func!, Pr_func!, max_pass, maxiter, s) (02_Preconditioner.jl:32-76).
+    """iterative_Solve!(globalfield; Sv_func!, Pr_func!, Pl_func, max_pass, maxiter, s) (02_Preconditioner.jl:32-76).
+    Pl_func: Identity, Pl_Jacobi_ (:155-168) or Pl_Jacobi_rownorm_ (normalized_by_row = true).
 
     Returns (delta_x, stats); delta_x is a NEW device vector like the reference's return value.
     """
@@ -215,7 +218,8 @@ def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tenso
     x = torch.empty(A.n, dtype=torch.float64, device=residue.device)
     o = SolveOptions(method=Sv_func, precond=Pr_func, l_or_s=s, maxiter=maxiter, max_pass=max_pass,
                      check_every=check_every, converge_tol=converge_tol, seed=seed,
-                     fixed_iterations=1 if fixed_iterations else 0, scale_in_place=1 if scale_in_place else 0)
+                     fixed_iterations=1 if fixed_iterations else 0, scale_in_place=1 if scale_in_place else 0,
+                     left_precond=Pl_func)
     st = SolveStats()
     if shadow is not None:
         _need(shadow, torch.float64, "shadow")

@@ -36,7 +36,8 @@ c_void_p, c_int, c_int32, c_int64, c_double, c_uint64, c_uint32 = (
 class SolveOptions(C.Structure):
     _fields_ = [("method", c_int32), ("precond", c_int32), ("l_or_s", c_int32), ("maxiter", c_int32),
                 ("max_pass", c_int32), ("check_every", c_int32), ("converge_tol", c_double), ("seed", c_uint64),
-                ("fixed_iterations", c_int32), ("scale_in_place", c_int32)]
+                ("fixed_iterations", c_int32), ("scale_in_place", c_int32), ("left_precond", c_int32),
+                ("reserved", c_int32)]
 
 
 class SolveStats(C.Structure):

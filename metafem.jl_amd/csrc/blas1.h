@@ -8,6 +8,7 @@ int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, con
                      double alpha, double beta, const double* dotw, double* partials, int* n_partials,
                      const int32_t* done_flag = nullptr);
 int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* d, int mode);
+int mfem_mat_div_rows(mfem_context_s* ctx, mfem_csr_s* A, double* vals, const double* d);
 int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count);
 int mfem_comm_halo(mfem_context_s* ctx, double* x_local);
 

@@ -73,6 +73,33 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mat_div_jacobi(int64_t nnz, cons
   }
 }
 
+// vals[j] /= d[row(j)]  (left Jacobi folded into the matrix; 8 lanes per row like k_jacobi_rows)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_mat_div_rows(int64_t n, const RP* __restrict__ rowptr, double* __restrict__ vals,
+                                                               const double* __restrict__ d, int base) {
+  const int g = threadIdx.x & 7;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 3;
+  for (int64_t r = grp; r < n; r += ngrp) {
+    const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+    const double dr = d[r];
+    for (int64_t j = lo + g; j < hi; j += 8) vals[j] /= dr;
+  }
+}
+
+int mfem_mat_div_rows(mfem_context_s* ctx, mfem_csr_s* A, double* vals, const double* d) {
+  if (A->n == 0) return MFEM_OK;
+  const int grid = mfem_grid_for(A->n * 8, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_mat_div_rows<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
+                       (const int64_t*)A->rowptr, vals, d, A->index_base);
+  else
+    hipLaunchKernelGGL(k_mat_div_rows<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
+                       (const int32_t*)A->rowptr, vals, d, A->index_base);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
 int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* d, int mode) {
   if (A->n == 0) return MFEM_OK;
   const int grid = mfem_grid_for(A->n * 8, MFEM_BLOCK, ctx->num_cus * 16);

@@ -30,10 +30,17 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_recip(int64_t n, const double* _
 }
 
 // y = x ./ d
-__global__ __launch_bounds__(MFEM_BLOCK) void k_div(int64_t n, const double* __restrict__ x, const double* __restrict__ d,
-                                                      double* __restrict__ y) {
+__global__ __launch_bounds__(MFEM_BLOCK) void k_div(int64_t n, const double* x, const double* __restrict__ d,
+                                                      double* y) {  // y may alias x
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i] / d[i];
+}
+
+// y = x .* d
+__global__ __launch_bounds__(MFEM_BLOCK) void k_mul(int64_t n, const double* x, const double* __restrict__ d,
+                                                      double* y) {  // y may alias x
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i] * d[i];
 }
 
 int mfem_fill(mfem_context_s* ctx, int64_t n, double v, double* x) {
@@ -325,6 +332,8 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
   MFEM_REQUIRE(o->maxiter >= 0 && o->max_pass >= 1, "maxiter >= 0 and max_pass >= 1 required");
   MFEM_REQUIRE(o->method >= MFEM_SOLVER_CG && o->method <= MFEM_SOLVER_CGS2, "unknown method");
   MFEM_REQUIRE(o->precond >= MFEM_PRECOND_NONE && o->precond <= MFEM_PRECOND_JACOBI_RIGHT_COLNORM, "unknown precond");
+  MFEM_REQUIRE(o->left_precond >= MFEM_LEFT_NONE && o->left_precond <= MFEM_LEFT_JACOBI_ROWNORM, "unknown left_precond");
+  MFEM_REQUIRE(!(o->left_precond && o->method == MFEM_SOLVER_CG), "left Jacobi would break the symmetry CG needs");
   if (stats) memset(stats, 0, sizeof(*stats));
   const int64_t n = A->n;
   if (n == 0) return MFEM_OK;
@@ -342,8 +351,9 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
   }
   const bool is_cg = o->method == MFEM_SOLVER_CG;
   const bool jac = o->precond != MFEM_PRECOND_NONE;
-  const bool need_copy = jac && !is_cg && !o->scale_in_place;
-  // workspace: x, b (padded copies), d, dinv, work vectors, optional matrix copy
+  const bool left = o->left_precond != MFEM_LEFT_NONE;
+  const bool need_copy = ((jac && !is_cg) || left) && !o->scale_in_place;
+  // workspace: x, b (padded copies), d, dinv (CG) / left scaling dl, work vectors, optional matrix copy
   const size_t vec_bytes = (size_t)nv * sizeof(double);
   size_t total = vec_bytes * (4 + nwork) + (need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0);
   int rc = mfem_ws_reserve(ctx, total);
@@ -391,6 +401,22 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
     }
   }
 
+  // Pl = Pl_func(A)   (:40, 155-168), taken from the matrix Pr has already scaled.  D_l^-1 (A v) == (D_l^-1 A) v, so the
+  // rows of the working matrix and b are divided once instead of dividing every mat-vec result.
+  double* dl = dinv_buf;
+  if (left) {
+    if (o->left_precond == MFEM_LEFT_JACOBI_ROWNORM) {
+      rc = mfem_jacobi_diag_launch(ctx, A, vals_work, dl, 1);
+    } else {
+      rc = mfem_fill(ctx, n, 1.0, dl);
+      if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, dl, 0);
+    }
+    if (!rc) rc = mfem_mat_div_rows(ctx, A, vals_work, dl);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.b, dl, V.b);
+    MFEM_CHECK_LAUNCH();
+  }
+
   int64_t n_global = n;
   if (ctx->comm) {
     ctx->h_scalars[S_TMP0] = (double)n;
@@ -405,7 +431,7 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
   const double n_inv = 1.0 / (double)n_global;
 
   // initial residual for the report: b itself since x0 = 0 (:42-45)
-  rc = mfem_dot_device(ctx, n, V.b, V.b, ctx->d_scalars + S_TMP0);
+  rc = mfem_dot_device(ctx, n, b, b, ctx->d_scalars + S_TMP0);
   if (rc) return rc;
   if (ctx->comm) {
     rc = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
@@ -417,7 +443,7 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
 
   int pass = 1, total_iters = 0, spmvs = 0;
   double res = res0;
-  const double tol_factor = 1.0;  // left preconditioners (the only users of tol_factor, :57-59) are out of scope
+  double tol_factor = 1.0;  // only a left preconditioner moves it (:57-59)
   for (;;) {
     int it = 0;
     switch (o->method) {
@@ -446,6 +472,22 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
     rc = mfem_read_scalars(ctx, S_RR, 1);
     if (rc) return rc;
     res = sqrt(ctx->h_scalars[S_RR] * n_inv);
+    if (left) {
+      // w0 holds the row-scaled residual Pl(r): res above is the preconditioned one; the true one is ||D_l w0|| (:57-59)
+      const double pres = res;
+      hipLaunchKernelGGL(k_mul, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.w[0], dl, V.w[0]);
+      MFEM_CHECK_LAUNCH();
+      rc = mfem_dot_device(ctx, n, V.w[0], V.w[0], ctx->d_scalars + S_RR);
+      if (rc) return rc;
+      if (ctx->comm) {
+        rc = mfem_comm_allreduce(ctx, ctx->d_scalars + S_RR, 1);
+        if (rc) return rc;
+      }
+      rc = mfem_read_scalars(ctx, S_RR, 1);
+      if (rc) return rc;
+      res = sqrt(ctx->h_scalars[S_RR] * n_inv);
+      tol_factor = res > 0.0 ? fmin(pres / res, 1.0) : 1.0;
+    }
     if (o->fixed_iterations || res < o->converge_tol || pass >= o->max_pass) break;
     ++pass;
   }

@@ -66,11 +66,11 @@ class _Group:
 
 
 class GenericDomain:
-    """FEM_Domain with one workpiece + GlobalField, static problems (max_time_level = 0)."""
+    """FEM_Domain with one workpiece + GlobalField; static (max_time_level = 0) or generalised-alpha transient."""
 
     def __init__(self, ctx, space, coords: np.ndarray, cp_ids: np.ndarray, n_fields: int, domain_wf: WeakForm,
                  boundaries: Sequence[Tuple[np.ndarray, np.ndarray, WeakForm]],
-                 element_colours: Optional[np.ndarray] = None):
+                 element_colours: Optional[np.ndarray] = None, max_time_level: int = 0, dissipative: bool = True):
         """coords [ncp, dim]; cp_ids [itp, nel] 0-based (controlpoint_IDs in basis order); boundaries =
         [(element_ID[nf], element_eindex[nf] 0-based local face ids, WeakForm)].  element_colours (optional):
         a colour per element such that same-colour elements share no control point -> atomics-free scatter;
@@ -125,10 +125,17 @@ class GenericDomain:
         self.A, self.slots = assemble_SparseID(self.cp, ncp, n_fields=n_fields, index_base=1, ctx=ctx)
         n = self.basicfield_size
         z = lambda m: torch.zeros(m, dtype=torch.float64, device=dev)
-        self.x, self.dx, self.x_star, self.residue = z(n), z(n), z(n), z(n)
+        # x, dx, x_star hold max_time_level + 1 blocks of basicfield_size (03_GlobalAssembly.jl:27-31)
+        self.max_time_level = max_time_level
+        nglob = (max_time_level + 1) * n
+        self.x, self.dx, self.x_star, self.residue = z(nglob), z(nglob), z(nglob), z(n)
         self.K_linear, self.K_total = z(self.A.nnz), z(self.A.nnz)
         self.controlpoints: Dict[str, torch.Tensor] = {}
         self.converge_tol = 1e-6
+        # GeneralAlpha (04_Time_Domain.jl:1-7); FEM_Domain builds it with dissipative = true (01_Types.jl:168)
+        self.alpha_params = (1.0, 1.0, 1.0)
+        self.gamma_params = (1.0, 1.0) if dissipative else (0.5, 0.5)
+        self.beta_params = [1.0]
         self.K_params = [1.0]  # static: alpha_0 * beta_0 (04_Time_Domain.jl:13-17)
         self.t, self.dt = 0.0, 1.0
         self.linear_solver: Optional[Callable] = None
@@ -137,11 +144,13 @@ class GenericDomain:
     # -- assemble_X! / dessemble_X! (03_GlobalAssembly.jl:44-75)
     def assemble_X(self, infos):
         for sym, pos, td in infos:
-            self.x[pos * self.ncp:(pos + 1) * self.ncp] = self.controlpoints[sym]
+            o = pos * self.ncp + td * self.basicfield_size
+            self.x[o:o + self.ncp] = self.controlpoints[sym]
 
     def dessemble_X(self, infos):
         for sym, pos, td in infos:
-            self.controlpoints[sym] = self.x[pos * self.ncp:(pos + 1) * self.ncp].clone()
+            o = pos * self.ncp + td * self.basicfield_size
+            self.controlpoints[sym] = self.x[o:o + self.ncp].clone()
 
     # -- operator wrappers ------------------------------------------------------------------------
     def _layout(self, g: _Group, colours: bool):
@@ -217,17 +226,45 @@ class GenericDomain:
             for t in wf.nonlinear_gradients:
                 self._kval(g, t, self._vals(t.fn, env, w, self.K_params[t.td_order]), self.K_total)
 
+    # -- time domain (04_Time_Domain.jl:9-49) ---------------------------------------------------------
+    def update_Time(self):
+        L = self.max_time_level
+        self.t += self.dt
+        prod_gamma = [float(np.prod(self.gamma_params[:i])) for i in range(L + 1)]
+        self.beta_params = [1.0 / (prod_gamma[i] * self.dt ** i) for i in range(L + 1)]
+        self.K_params = [self.alpha_params[i] * self.beta_params[i] for i in range(L + 1)]
+
+    def _level(self, v: torch.Tensor, lvl: int) -> torch.Tensor:
+        n = self.basicfield_size
+        return v[lvl * n:(lvl + 1) * n]
+
+    def initialize_dx(self):
+        self.dx.zero_()
+        for lvl in range(self.max_time_level, 0, -1):  # predictor: dx[l-1] = dt (x[l] + gamma_l dx[l])
+            torch.add(self._level(self.x, lvl), self._level(self.dx, lvl), alpha=self.gamma_params[lvl - 1],
+                      out=self._level(self.dx, lvl - 1))
+            self._level(self.dx, lvl - 1).mul_(self.dt)
+
+    def update_dx(self, delta_x: torch.Tensor):
+        for lvl in range(self.max_time_level + 1):
+            self._level(self.dx, lvl).add_(delta_x, alpha=self.beta_params[lvl])
+
+    def update_x_star(self):
+        for lvl in range(self.max_time_level + 1):
+            torch.add(self._level(self.x, lvl), self._level(self.dx, lvl), alpha=self.alpha_params[lvl],
+                      out=self._level(self.x_star, lvl))
+
     def update_OneStep(self, max_iter: int = 4):
-        """update_OneStep! (04_Time_Domain.jl:59-80), static (max_time_level = 0)."""
+        """update_OneStep! (04_Time_Domain.jl:59-80)."""
         from . import normalized_norm
 
-        self.t += self.dt
-        self.dx.zero_()
+        self.update_Time()
+        self.initialize_dx()
         self.K_linear_func()
         counter = -1
         self.history = []
         while True:
-            torch.add(self.x, self.dx, out=self.x_star)
+            self.update_x_star()
             self.K_nonlinear_func()
             res = normalized_norm(self.residue, self.ctx)
             counter += 1
@@ -235,6 +272,6 @@ class GenericDomain:
             if res < self.converge_tol or counter > max_iter:
                 break
             delta_x = self.linear_solver(self)
-            self.dx -= delta_x
+            self.update_dx(-delta_x)
         self.x += self.dx
         return self.history

@@ -16,10 +16,15 @@ from .fem import AssembleWeakform, GradTerm, ResTerm
 
 
 # -- thermal conduction ------------------------------------------------------------------
-def thermal_domain(dim: int, k: float, alpha: float = 0.0, Tenv: float = 0.0) -> AssembleWeakform:
+def thermal_domain(dim: int, k: float, alpha: float = 0.0, Tenv: float = 0.0, C: float = 0.0) -> AssembleWeakform:
     """heat_dissipation = -k*Bilinear(T{;i},T{;i}) + Bilinear(T, s + alpha*(Tenv - T))
-    (examples/thermal_conduction/2D_Script.jl:56, 3D_Script.jl:30)."""
+    (examples/thermal_conduction/2D_Script.jl:56, 3D_Script.jl:30); C != 0 adds the transient term
+    -C*Bilinear(T, T{;t}) of 3D_Script_Dynamics.jl:32 (needs max_time_level >= 1)."""
     wf = AssembleWeakform()
+    if C != 0.0:
+        wf.inner_vars.append(("T_t", 0, 0, 1))
+        wf.residues.append(ResTerm(0, 0, lambda env: -C * env["T_t"]))
+        wf.linear_gradients.append(GradTerm(0, 0, 0, 0, lambda env: -C, td_order=1))
     for d in range(dim):
         wf.inner_vars.append((f"T_{d}", 0, 1 + d, 0))
         wf.residues.append(ResTerm(0, 1 + d, lambda env, d=d: -k * env[f"T_{d}"]))
@@ -85,6 +90,37 @@ def elasticity_domain(dim: int, lam: float, mu: float) -> AssembleWeakform:
                     if c != 0.0:
                         wf.linear_gradients.append(GradTerm(i, 1 + j, kk, 1 + l, lambda env, c=c: -c))
     return wf
+
+
+def elasticity_inertia(dim: int, rho: float, c: float = 0.0) -> AssembleWeakform:
+    """-Bilinear(d{i}, rho*(c*d{i;t} + d{i;t,t})): the damping + inertia term of
+    examples/hypo_elastic_plasticity/J2Plasticity.jl:59 in the sign convention of Elastrostatic_Domain above
+    (needs max_time_level = 2).  Returned separately; merge into a domain weak form with `merge`."""
+    wf = AssembleWeakform()
+    for i in range(dim):
+        wf.inner_vars.append((f"d{i}_tt", i, 0, 2))
+        wf.linear_gradients.append(GradTerm(i, 0, i, 0, lambda env: -rho, td_order=2))
+        if c != 0.0:
+            wf.inner_vars.append((f"d{i}_t", i, 0, 1))
+            wf.linear_gradients.append(GradTerm(i, 0, i, 0, lambda env: -rho * c, td_order=1))
+            wf.residues.append(ResTerm(i, 0, lambda env, i=i: -rho * (c * env[f"d{i}_t"] + env[f"d{i}_tt"])))
+        else:
+            wf.residues.append(ResTerm(i, 0, lambda env, i=i: -rho * env[f"d{i}_tt"]))
+    return wf
+
+
+def merge(*wfs: AssembleWeakform) -> AssembleWeakform:
+    """Sum of weak forms on the same integration domain (Bilinear + Bilinear)."""
+    out = AssembleWeakform()
+    for wf in wfs:
+        for a in ("inner_vars", "cp_ext_vars", "normals"):
+            for item in getattr(wf, a):
+                if item not in getattr(out, a):
+                    getattr(out, a).append(item)
+        out.residues += wf.residues
+        out.linear_gradients += wf.linear_gradients
+        out.nonlinear_gradients += wf.nonlinear_gradients
+    return out
 
 
 def elasticity_penalty(dim: int, tau: float, wall_syms: Optional[Sequence[str]] = None) -> AssembleWeakform:

@@ -42,6 +42,13 @@ def cavity():
                         ghia_y=np.array([a for a, _ in g]), ghia_u=np.array([b for _, b in g]))
 
 
+def cantilever():
+    """DATA from the reference's committed result examples/linear_elasticity/cantilever/3D_Cantilever.vtk
+    (POINTS 1865 = hex-20 20x4x4, SCALARS d1/d2/d3: the last load case of 3D_Script.jl:139-141)."""
+    pts, sc = vtk.read_vtk_points_scalars(os.path.join(REF, "examples/linear_elasticity/cantilever/3D_Cantilever.vtk"))
+    np.savez_compressed(os.path.join(HERE, "cantilever_hex20.npz"), xyz=pts, d1=sc["d1"], d2=sc["d2"], d3=sc["d3"])
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -125,6 +132,7 @@ if __name__ == "__main__":
     if os.path.isdir(REF):
         strip()
         cavity()
+        cantilever()
     tables()
     thermal_hex8()
     elasticity_hex8()

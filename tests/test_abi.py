@@ -31,7 +31,8 @@ def test_ctypes_binding_covers_the_header(mf):
     from metafem_jl_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.lib.mfem_abi_version() == 1
+    hdr = open(HEADER).read()
+    assert _lib.lib.mfem_abi_version() == int(re.search(r"#define MFEM_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_no_gpu_means_loud_failure_not_fallback(mf):

@@ -29,7 +29,8 @@ def _gpu_domain(mf, od, itp_type, order, itg, colours=None):
     space = element.classical_space(od.disc.dim, itp_type, order, itg)
     bnd = [(f.element_ID, f.element_eindex, _to_product_wf(mf, wf)) for f, wf in od.boundaries]
     return G.GenericDomain(mf.default_context(), space, od.mesh.coords, od.mesh.cp_ids, od.n_fields, _to_product_wf(mf, od.domain_wf),
-                           bnd, element_colours=colours)
+                           bnd, element_colours=colours, max_time_level=od.max_time_level,
+                           dissipative=od.time.gamma_params[0] == 1.0)
 
 
 @pytest.mark.parametrize("kind", ["quad8", "hex8", "hex27", "hex20"])
@@ -172,3 +173,114 @@ def test_c5_cavity_re1000_on_gpu_reproduces_reference_vtk(mf):
     assert np.abs(x[2 * n:][idx] - z["u2"]).max() < 5e-4
     pa, pb = x[:n][idx], z["p"]
     assert np.abs((pa - pa.mean()) - (pb - pb.mean())).max() < 5e-4 * (pb.max() - pb.min())
+
+
+def test_cantilever_hex20_on_gpu_reproduces_reference_vtk(mf):
+    """examples/linear_elasticity/cantilever/3D_Script.jl on the generic GPU path: hex-20 serendipity, 3 fields (9 sparse
+    blocks, 21 linear gradient launches), nodal symmetric-tensor externals, facet normals, the script's idrs!(s = 8)."""
+    import torch
+    from oracle import cantilever as cl
+
+    z = np.load(os.path.join(GOLD, "cantilever_hex20.npz"))
+    od = cl.build_cantilever()
+    od.linear_solver = cl.lu
+    gd = _gpu_domain(mf, od, "Serendipity", 2, 5)
+    gd.converge_tol = od.converge_tol
+    stats = []
+
+    def solver(g):
+        # globalfield.converge_tol itself, like the reference (02_Preconditioner.jl:33): with K ~ 1e11 the FP64 floor of
+        # ||r||/sqrt(n) is ~1e-7, so a tighter absolute tolerance would be unreachable
+        dx, st = mf.iterative_Solve(g.A, g.K_total, g.residue, 0.5 * g.converge_tol, Sv_func=mf.idrs_, maxiter=2000, max_pass=20, s=8)
+        stats.append(st)
+        return dx
+
+    gd.linear_solver = solver
+    n = od.mesh.ncp
+    for case in (1, 2, 3):
+        cl.set_load(od, case)
+        for k, v in od.controlpoints.items():
+            gd.controlpoints[k] = torch.tensor(v, device="cuda")
+        ho = od.update_one_step()
+        hg = gd.update_OneStep()
+        assert hg[-1] < gd.converge_tol and np.isclose(hg[0], ho[0], rtol=1e-9)
+        got = gd.x.cpu().numpy()
+        assert np.abs(got - od.x).max() <= 1e-7 * np.abs(od.x).max()
+    assert all(s.converged for s in stats)
+    d, idx = cKDTree(od.mesh.coords).query(z["xyz"])
+    scale = np.abs(z["d2"]).max()
+    for f, nm in enumerate(("d1", "d2", "d3")):
+        assert np.abs(got[f * n:(f + 1) * n][idx] - z[nm]).max() < 1e-6 * scale, nm
+
+
+@pytest.mark.parametrize("dissipative", [True, False])
+def test_transient_thermal_generalised_alpha_matches_oracle(mf, dissipative):
+    """3D_Script_Dynamics.jl's weak form (-C Bilinear(T, T{;t}) + conduction + source, convective boundary) on hex-8,
+    max_time_level = 1: K_params, predictor, x*/dx updates of 04_Time_Domain.jl:9-49 over several steps."""
+    import torch
+    from oracle import fem, mesh as om, problems, reference_element as re_, solvers
+
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh((1.0, 0.8, 0.6), (5, 4, 3), disc)
+    fac = om.boundary_facets_structured((1.0, 0.8, 0.6), (5, 4, 3), 3)
+    T0 = 293.15
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6, C=4.184e3), [(fac, problems.thermal_convection(25.0, T0))],
+                       max_time_level=1, dissipative=dissipative)
+    od.controlpoints["s"] = 1600.0 * (1.0 + msh.coords[:, 0])
+    od.controlpoints["T"] = np.full(msh.ncp, T0)
+    od.assemble_x([("T", 0, 0)])
+    od.dt = 40.0
+    od.converge_tol = 1e-8
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    gd = _gpu_domain(mf, od, "Lagrange", 1, 3)
+    gd.controlpoints["s"] = torch.tensor(od.controlpoints["s"], device="cuda")
+    gd.controlpoints["T"] = torch.tensor(od.controlpoints["T"], device="cuda")
+    gd.assemble_X([("T", 0, 0)])
+    gd.dt, gd.converge_tol = od.dt, od.converge_tol
+    gd.linear_solver = lambda g: mf.iterative_Solve(g.A, g.K_total, g.residue, 1e-4 * g.converge_tol, Sv_func=mf.idrs_, maxiter=500,
+                                                    max_pass=10, s=8)[0]
+    for step in range(4):
+        ho, hg = od.update_one_step(), gd.update_OneStep()
+        assert len(ho) == len(hg) and np.isclose(hg[0], ho[0], rtol=1e-9)
+        assert np.allclose(gd.K_params, od.time.K_params)
+        got = gd.x.cpu().numpy()
+        n = msh.ncp
+        assert np.abs(got[:n] - od.x[:n]).max() <= 1e-9 * np.abs(od.x[:n]).max()
+        assert np.abs(got[n:] - od.x[n:]).max() <= 1e-8 * np.abs(od.x[n:]).max()
+    assert od.x[:n].max() > T0 + 1.0  # it did heat up
+
+
+def test_elastodynamics_two_time_levels_matches_oracle(mf):
+    """max_time_level = 2: -Bilinear(eps, sigma) - Bilinear(d{i}, rho (c d{i;t} + d{i;t,t})) (J2Plasticity.jl:59 without the
+    plasticity), penalty-fixed end, suddenly applied traction: three implicit steps against the oracle."""
+    import torch
+    from oracle import fem, mesh as om, problems, reference_element as re_, solvers
+
+    size, nel = (2.0, 0.5, 0.5), (6, 2, 2)
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh(size, nel, disc)
+    fac = om.boundary_facets_structured(size, nel, 3)
+    c = fac.centroid
+    left, right = np.abs(c[:, 0]) < 1e-9, np.abs(c[:, 0] - size[0]) < 1e-9
+    E, nu, rho = 100.0, 0.3, 2.0
+    lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    sig = [[0.0, 0.3, 0.0], [0.3, 0.0, 0.0], [0.0, 0.0, 0.0]]
+    od = fem.FEMDomain(msh, disc, 3, problems.merge(problems.elasticity_domain(3, lam, mu), problems.elasticity_inertia(3, rho, 0.4)),
+                       [(fac.select(left), problems.elasticity_penalty(3, 1000.0 * E)), (fac.select(right), problems.elasticity_traction(3, sig))],
+                       max_time_level=2)
+    od.dt = 0.05
+    od.converge_tol = 1e-9
+    od.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    gd = _gpu_domain(mf, od, "Lagrange", 1, 3)
+    gd.dt, gd.converge_tol = od.dt, od.converge_tol
+    gd.linear_solver = lambda g: mf.iterative_Solve(g.A, g.K_total, g.residue, 1e-3 * g.converge_tol, Sv_func=mf.bicgstabl_GS_,
+                                                    maxiter=2000, max_pass=10, s=4)[0]
+    for step in range(3):
+        ho, hg = od.update_one_step(), gd.update_OneStep()
+        assert np.isclose(hg[0], ho[0], rtol=1e-9) and hg[-1] < gd.converge_tol
+        got = gd.x.cpu().numpy()
+        n = od.basicfield_size
+        for lvl in range(3):
+            ref = od.x[lvl * n:(lvl + 1) * n]
+            assert np.abs(got[lvl * n:(lvl + 1) * n] - ref).max() <= 1e-7 * np.abs(ref).max(), (step, lvl)
+    assert np.abs(od.x[:n]).max() > 1e-6

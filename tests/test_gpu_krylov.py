@@ -124,6 +124,47 @@ def test_other_right_preconditioners(mf, precond):
     assert np.abs(x - ref).max() <= 1e-8 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("pr", ["none", "diag"])
+@pytest.mark.parametrize("pl", ["diag", "rownorm"])
+@pytest.mark.parametrize("method,s", [("idrs", 8), ("bicgstabl_gs", 2), ("cgs2", 0)])
+def test_left_jacobi_matches_oracle(mf, pr, pl, method, s):
+    """Pl_func = Pl_Jacobi (02_Preconditioner.jl:155-168; the cylinder-flow script's choice) with and without Pr_Jacobi!."""
+    from functools import partial
+    from oracle import solvers
+
+    sysm = _nonsymmetric_system()
+    rowptr, col, K, b = sysm
+    ref = solvers.solver_lu_cpu(rowptr, col, K, b)
+    tol = 1e-9 * solvers.normalized_norm(b)
+    info = solvers.SolveInfo()
+    xo = solvers.iterative_solve(rowptr, col, K, b, tol, Sv_func=getattr(solvers, method), maxiter=600, max_pass=6, s=s, seed=3,
+                                 Pr_func=solvers.pr_jacobi if pr == "diag" else None,
+                                 Pl_func=partial(solvers.pl_jacobi, normalized_by_row=(pl == "rownorm")), info=info)
+    sv = {"bicgstabl_gs": mf.bicgstabl_GS_, "idrs": mf.idrs_, "cgs2": mf.cgs2_}[method]
+    x, st, K_after = _gpu_solve(mf, sysm, converge_tol=tol, Sv_func=sv, maxiter=600, max_pass=6, s=s, seed=3, check_every=5,
+                                Pr_func=mf.Pr_Jacobi_ if pr == "diag" else mf.Identity,
+                                Pl_func=mf.Pl_Jacobi_ if pl == "diag" else mf.Pl_Jacobi_rownorm_)
+    assert st.converged == 1 and st.final_res < tol
+    assert np.array_equal(K_after, K)
+    scale = np.abs(ref).max()
+    assert np.abs(x - ref).max() <= 1e-7 * scale
+    assert np.abs(x - xo).max() <= 1e-7 * scale
+    assert abs(st.passes - info.passes) <= 1
+
+
+def test_left_jacobi_first_iterates_and_cg_refusal(mf):
+    from oracle import solvers
+
+    sysm = _nonsymmetric_system()
+    rowptr, col, K, b = sysm
+    xo = solvers.iterative_solve(rowptr, col, K, b, 1e-300, Sv_func=solvers.idrs, maxiter=5, max_pass=1, s=4, seed=7,
+                                 Pl_func=solvers.pl_jacobi)
+    x, st, _ = _gpu_solve(mf, sysm, converge_tol=1e-300, Sv_func=mf.idrs_, maxiter=5, max_pass=1, s=4, seed=7, Pl_func=mf.Pl_Jacobi_)
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    with pytest.raises(mf.MetaFEMError):
+        _gpu_solve(mf, sysm, converge_tol=1e-9, Sv_func=mf.cg_, maxiter=5, max_pass=1, Pl_func=mf.Pl_Jacobi_)
+
+
 def test_zero_rhs_returns_zero_iterations(mf):
     import torch
 

@@ -159,3 +159,51 @@ def test_fem_rand_range_and_determinism():
     assert np.array_equal(a, solvers.fem_rand(0x5EED, 0, 1000))
     assert a.min() >= 0 and a.max() < 1 and abs(a.mean() - 0.5) < 0.05
     assert not np.array_equal(a, solvers.fem_rand(0x5EED, 1, 1000))
+
+
+# ---- generalised-alpha transient path (04_Time_Domain.jl:9-49), the 3D_Script_Dynamics.jl weak form ----
+def test_transient_lumped_heating_is_exact_under_backward_euler():
+    """No boundary terms, uniform source: C dT/dt = s  =>  T(t) = T0 + s t / C, which backward Euler (gamma = alpha = 1)
+    integrates exactly; the mass term also makes the otherwise singular conduction matrix invertible."""
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh((1.0, 0.5, 0.25), (3, 2, 2), disc)
+    Cv, s0, T0 = 4.184e3, 1600.0, 293.15
+    dom = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6, C=Cv), [], max_time_level=1)
+    dom.controlpoints["s"] = np.full(msh.ncp, s0)
+    dom.controlpoints["T"] = np.full(msh.ncp, T0)
+    dom.assemble_x([("T", 0, 0)])
+    dom.dt = 0.5
+    dom.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    for step in range(1, 4):
+        hist = dom.update_one_step()
+        assert hist[-1] < dom.converge_tol
+        n = msh.ncp
+        assert np.allclose(dom.x[:n], T0 + s0 * dom.t / Cv, rtol=1e-12)
+        assert np.allclose(dom.x[n:], s0 / Cv, rtol=1e-9)  # the rate level
+    assert np.isclose(dom.t, 1.5)
+    assert np.allclose(dom.time.K_params, [1.0, 1.0 / dom.dt])
+
+
+def test_transient_conduction_mode_decays_at_the_backward_euler_rate():
+    """Insulated bar, T0 = cos(pi x): the consistent-mass hex-8 semi-discretisation keeps the nodal cosine an
+    eigenvector, so one backward-Euler step multiplies it by 1 / (1 + dt*lam_h) with the 1-D linear-element
+    eigenvalue lam_h = (k/C) * (6/h^2) * (1 - c) / (2 + c), c = cos(pi h)."""
+    nx, k, Cv, dt = 16, 0.6, 50.0, 0.3
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh((1.0, 0.2, 0.2), (nx, 1, 1), disc)
+    dom = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, k, C=Cv), [], max_time_level=1)
+    dom.controlpoints["s"] = np.zeros(msh.ncp)
+    mode = np.cos(np.pi * msh.coords[:, 0])
+    dom.controlpoints["T"] = mode.copy()
+    dom.assemble_x([("T", 0, 0)])
+    dom.dt = dt
+    dom.converge_tol = 1e-12
+    dom.linear_solver = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    h = 1.0 / nx
+    c = np.cos(np.pi * h)
+    lam = (k / Cv) * (6.0 / h ** 2) * (1 - c) / (2 + c)
+    amp = 1.0
+    for _ in range(3):
+        dom.update_one_step()
+        amp /= 1.0 + dt * lam
+        assert np.allclose(dom.x[:msh.ncp], amp * mode, atol=1e-10)

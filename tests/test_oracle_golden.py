@@ -104,3 +104,31 @@ def test_oracle_reproduces_reference_cavity_vtk():
     o = np.argsort(dom.mesh.coords[mid, 1])
     u = np.interp(z["ghia_y"], dom.mesh.coords[mid, 1][o], dom.controlpoints["u1"][mid][o])
     assert np.abs(u - z["ghia_u"]).max() < 0.02
+
+
+# ---- third pin: examples/linear_elasticity/cantilever/3D_Script.jl -> 3D_Cantilever.vtk (hex-20 serendipity, 3 fields) ----
+def test_oracle_reproduces_reference_cantilever_vtk():
+    """The committed VTK predates the current script in two constants, both read off the file itself: 1865 points /
+    320 cells = a 20x4x4 mesh (the script now builds 10x4x4), and E = 210e9 (the displacements are the E = 1 result
+    divided by 2.1e11 to 8 digits; nu = 0.001 and tau_b = 1000 E as written).  It holds the last load case (:139-141)."""
+    from oracle import cantilever as cl
+
+    z = np.load(os.path.join(GOLD, "cantilever_hex20.npz"))
+    dom = cl.build_cantilever()
+    assert dom.mesh.ncp == 1865 == z["d2"].size
+    dom.linear_solver = cl.lu
+    for case in (1, 2, 3):  # the script solves the three load cases in sequence on the same x (:109-141)
+        cl.set_load(dom, case)
+        hist = dom.update_one_step()
+        assert hist[-1] < dom.converge_tol
+        ids = cl.midline(dom)
+        x = dom.mesh.coords[ids, 0]
+        ana = cl.beam_deflection(case, x, dom.params["L"], dom.params["l"], dom.params["E"])
+        num = dom.x[dom.mesh.ncp + ids]
+        assert np.abs(num - ana).max() < 0.02 * ana.max()  # the script's plot-level check (:116-147)
+    d, idx = cKDTree(dom.mesh.coords).query(z["xyz"])
+    assert d.max() < 1e-6
+    n = dom.mesh.ncp
+    scale = np.abs(z["d2"]).max()
+    for f, nm in enumerate(("d1", "d2", "d3")):
+        assert np.abs(dom.x[f * n:(f + 1) * n][idx] - z[nm]).max() < 1e-6 * scale, nm
