@@ -5,6 +5,10 @@ evaluate_Itp_Funcs).  The reference builds the shape functions with a polynomial
 is a product of linear factors, so here a basis function is stored as (scale, [(alpha, beta), ...]) meaning
 scale * prod_k (alpha_k . x + beta_k), from which values and first derivatives follow by the product rule.
 
+SIMPLEX elements (triangle / tetrahedron, `init_Interpolation_Simplex_Lagrange` 102_Interpolations.jl:46-62, Gauss rules
+103_Integrations.jl:60-241) use the same representation: every Lagrange simplex basis is a product of barycentric
+linear factors.
+
 Conventions: reference cell [0,1]^dim; Gauss points/weights shifted to [0,1]; tensor orders with the
 FIRST coordinate fastest; Lagrange nodes in tensor order; serendipity nodes = corners (tensor order) then mid-edge
 nodes by edge direction; local face ids 2-D (4 2; 1 3), 3-D (5 3; 2 4; 1 6) = (low, high) per normal dimension.
@@ -36,6 +40,8 @@ def gauss_cube(itg_order: int, dim: int):
     g = int(math.ceil((itg_order + 1) / 2))
     if dim == 0:
         return np.zeros((1, 0)), np.ones(1)
+    if not 1 <= g <= len(_GP):
+        raise ValueError(f"itg_order {itg_order} needs {g} Gauss points; tables hold 1..{len(_GP)} (103_Integrations.jl:3-9)")
     P = [x / 2.0 + 0.5 for x in _GP[g - 1]]
     W = [w / 2.0 for w in _GW[g - 1]]
     pos = [[P[i] for i in ids] for ids in _first_fastest([range(g)] * dim)]
@@ -142,6 +148,7 @@ class ClassicalSpace:
     bdy_ref_itp_vals: np.ndarray  # [nface, itg_b, itp, 1+dim]
     bdy_tangent_directions: np.ndarray  # [nface, itg_b, dim, dim-1]
     funcs: list = field(default_factory=list, repr=False)
+    shape: str = "CUBE"
 
     @property
     def itp(self):
@@ -156,8 +163,132 @@ class ClassicalSpace:
         return self.bdy_itg_weights.shape[1]
 
 
-def classical_space(dim: int, itp_type: str = "Lagrange", itp_order: int = 1, itg_order: int = 3) -> ClassicalSpace:
-    """initialize_Classical_Element(dim, :CUBE, itp_order, max_sd_order = 1, itg_order; itp_type)."""
+# ---- SIMPLEX (103_Integrations.jl:60-80): symmetric rules given by their orbit generators -------------------------
+_TRI_POS = (((0.10128650732345633880098736191512383,), (0.47014206410511508977044120951344760,), ()),
+            ((0.06308901449150222834033160287081916,), (0.24928674517091042129163855310701908,),
+             (0.05314504984481694735324967163139815, 0.31035245103378440541660773395655215)),
+            ((), (0.17056930775176020662229350149146450,), (0.05054722831703097545842355059659895,),
+             (0.45929258829272315602881551449416932,),
+             (0.26311282963463811342178578628464359, 0.00839477740995760533721383453929445)))
+_TRI_W = ((0.12593918054482715259568394550018133, 0.13239415278850618073764938783315200, 9.0 / 40.0),
+          (0.05084490637020681692093680910686898, 0.11678627572637936602528961138557944,
+           0.08285107561837357519355345642044245),
+          (0.14431560767778716825109111048906462, 0.10321737053471825028179155029212903,
+           0.03245849762319808031092592834178060, 0.09509163426728462479389610438858432,
+           0.02723031417443499426484469007390892))
+_TET_POS = (((0.31088591926330060979734573376345783,), (0.09273525031089122640232391373703061,),
+             (-0.04550370412564964949188052627933943,)),
+            ((0.21460287125915202928883921938628499,), (0.04067395853461135311557944895641006,),
+             (0.32233789014227551034399447076249213,),
+             (0.06366100187501752529923552760572698, 0.60300566479164914136743113906093969)),
+            ((0.03967542307038990126507132953938949,), (0.31448780069809631378416056269714830,),
+             (0.10198669306270330000000000000000000,), (0.18420369694919151227594641734890918,),
+             (-0.06343628775453989240514123870189827,),
+             (0.02169016206772800480266248262493018, 0.71993192203946593588943495335273478),
+             (0.20448008063679571424133557487274534, 0.58057719012880922417539817139062041)))
+_TET_W = ((0.11268792571801585079918565233328633, 0.07349304311636194954371020548632750,
+           0.04254602077708146643806942812025744),
+          (0.03992275025816749209969062755747998, 0.01007721105532064294801323744593686,
+           0.05535718154365472209515327785372602, 27.0 / 560.0),
+          (0.00639714777990232132145142033517302, 0.04019044802096617248816115847981783,
+           0.02430797550477032117486910877192260, 0.05485889241369744046692412399039144,
+           0.03571961223409918246495096899661762, 0.00718319069785253940945110521980376,
+           0.01637218194531911754093813975611913))
+SIMPLEX_FACE_VERTS = {2: ((0, 1), (1, 2), (2, 0)), 3: ((0, 1, 2), (0, 1, 3), (3, 1, 2), (0, 2, 3))}
+
+
+def _simplex_bary(itg_order: int, nv: int):
+    """Barycentric points (origin weight first) + weights summing to 1; orbits expanded in the reference's order."""
+    rid = 0 if itg_order <= 5 else 1 if itg_order <= 6 else 2 if itg_order <= 8 else None
+    if rid is None:
+        raise ValueError("Wrong integral order")
+    gens, ws = (_TRI_POS, _TRI_W) if nv == 3 else (_TET_POS, _TET_W)
+    pts, wts = [], []
+    for g, w in zip(gens[rid], ws[rid]):
+        orbit = []
+        if len(g) == 0:
+            orbit.append((1.0 / nv,) * nv)
+        elif len(g) == 1 and g[0] >= 0:
+            a = g[0]
+            orbit += [tuple(1 - (nv - 1) * a if k == i else a for k in range(nv)) for i in range(nv)]
+        elif len(g) == 1:  # tetrahedron only: two entries 1/2 - b, two entries b
+            b = -g[0]
+            for i, j in _first_fastest([range(4)] * 2):
+                if i < j:
+                    orbit.append(tuple(0.5 - b if k in (i, j) else b for k in range(4)))
+        elif nv == 3:
+            src = (g[0], g[1], 1.0 - g[0] - g[1])
+            orbit += [(src[i], src[j], src[3 - i - j]) for i, j in _first_fastest([range(3)] * 2) if i != j]
+        else:
+            a, b = g
+            c = 1 - 2 * a - b
+            for i, j in _first_fastest([range(4)] * 2):
+                if i != j:
+                    orbit.append(tuple(b if k == i else c if k == j else a for k in range(4)))
+        pts += orbit
+        wts += [w] * len(orbit)
+    return np.array(pts, dtype=np.float64), np.array(wts, dtype=np.float64)
+
+
+def gauss_simplex(itg_order: int, dim: int):
+    b, w = _simplex_bary(itg_order, dim + 1)
+    return b[:, 1:].copy(), w / math.factorial(dim)
+
+
+def lagrange_simplex(order: int, dim: int):
+    lam = [(_axis(dim, i), 0.0) for i in range(dim)] + [(-np.ones(dim), 1.0)]  # barycentric coordinates, origin last
+    funcs, pos = [], []
+    for ip in _first_fastest([range(order + 1)] * dim):
+        rest = order - sum(ip)
+        if rest < 0:
+            continue
+        fac, scale = [], 1.0
+        for (al, be), m in zip(lam, list(ip) + [rest]):
+            for k in range(m):  # Phi_m(l) = prod_{k<m} (p l - k) / (m - k)
+                fac.append((order * al, order * be - k))
+                scale /= (m - k)
+        funcs.append(Basis(scale, fac))
+        pos.append([i / order for i in ip])
+    return funcs, np.array(pos)
+
+
+def _simplex_boundary(itg_order: int, dim: int):
+    V = np.vstack([np.zeros(dim), np.eye(dim)])
+    if dim == 2:
+        p1, w1 = gauss_cube(itg_order, 1)
+        a = p1[:, 0]
+        pos = [np.outer(1 - a, V[s]) + np.outer(a, V[e]) for s, e in SIMPLEX_FACE_VERTS[2]]
+        ws = [w1.copy(), w1 * math.sqrt(2.0), w1.copy()]
+        tans = [np.array([[1.0], [0.0]]), np.array([[-1.0], [1.0]]) / math.sqrt(2.0), np.array([[0.0], [-1.0]])]
+    else:
+        b, w = _simplex_bary(itg_order, 3)
+        pos = [b[:, [0]] * V[c0] + b[:, [1]] * V[c1] + b[:, [2]] * V[c2] for c0, c1, c2 in SIMPLEX_FACE_VERTS[3]]
+        ws = [w * 0.5, w * 0.5, w * 0.5 * math.sqrt(3.0), w * 0.5]
+        r2, r6 = math.sqrt(2.0), math.sqrt(6.0)
+        tans = [np.array([[-1.0, 0.0], [0.0, 1.0], [0.0, 0.0]]), np.array([[0.0, 1.0], [0.0, 0.0], [-1.0, 0.0]]),
+                np.array([[-1.0 / r2, -1.0 / r6], [1.0 / r2, -1.0 / r6], [0.0, 2.0 / r6]]),
+                np.array([[0.0, 0.0], [-1.0, 0.0], [0.0, 1.0]])]
+    return pos, ws, tans
+
+
+def _simplex_space(dim, itp_type, itp_order, itg_order) -> ClassicalSpace:
+    funcs, pos = lagrange_simplex(itp_order, dim)  # :Serendipity on a SIMPLEX is the same basis (01_Classical_DIscretization.jl:72)
+    qp, qw = gauss_simplex(itg_order, dim)
+    bpos, bws, tans = _simplex_boundary(itg_order, dim)
+    nq = bpos[0].shape[0]
+    bref = np.stack([_tables(funcs, p, dim) for p in bpos])
+    btan = np.stack([np.tile(t[None], (nq, 1, 1)) for t in tans])
+    return ClassicalSpace(dim, itp_type, itp_order, itg_order, pos, qw, _tables(funcs, qp, dim), np.stack(bws), bref, btan, funcs,
+                          shape="SIMPLEX")
+
+
+def classical_space(dim: int, itp_type: str = "Lagrange", itp_order: int = 1, itg_order: int = 3,
+                    shape: str = "CUBE") -> ClassicalSpace:
+    """initialize_Classical_Element(dim, shape, itp_order, max_sd_order = 1, itg_order; itp_type)."""
+    if shape == "SIMPLEX":
+        return _simplex_space(dim, itp_type, itp_order, itg_order)
+    if shape != "CUBE":
+        raise ValueError(shape)
     if itp_type == "Lagrange":
         funcs, pos = lagrange_cube(itp_order, dim)
     elif itp_type == "Serendipity":

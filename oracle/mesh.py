@@ -25,6 +25,29 @@ from .reference_element import CUBE_FACE_IDS, ClassicalDiscretization
 VERTEX_CP_IDS = {2: (0, 1, 3, 2), 3: (0, 1, 3, 2, 4, 5, 7, 6)}
 
 
+def simplex_split(cube_conn: np.ndarray, n) -> np.ndarray:
+    """The :SIMPLEX branches of make_Square / make_Brick (201_Helper_TM.jl:20-29, 55-76), written as the loops they are."""
+    ncell = cube_conn.shape[1]
+    if cube_conn.shape[0] == 4:
+        out = np.zeros((3, 2 * ncell), dtype=np.int64)
+        for e in range(ncell):
+            out[:, e] = cube_conn[[0, 1, 3], e]
+            out[:, e + ncell] = cube_conn[[2, 3, 1], e]  # "OK but all minus" (:27)
+        return out
+    out = np.zeros((4, 5 * ncell), dtype=np.int64)
+    fwd = [[1, 2, 4, 5], [3, 4, 2, 7], [8, 7, 5, 4], [6, 5, 7, 2], [4, 7, 5, 2]]
+    bwd = [[5, 8, 6, 1], [2, 1, 6, 3], [7, 6, 8, 3], [4, 1, 3, 8], [1, 3, 8, 6]]
+    e = 0
+    for i in range(1, n[0] + 1):
+        for j in range(1, n[1] + 1):
+            for k in range(1, n[2] + 1):
+                pick = fwd if (i + j + k) % 2 == 1 else bwd
+                for t in range(5):
+                    out[:, e + t * ncell] = cube_conn[[v - 1 for v in pick[t]], e]
+                e += 1
+    return out
+
+
 def make_square(x: Tuple[float, float], n: Tuple[int, int]):
     """201_Helper_TM.jl:7-33 (CUBE).  -> coors[2, nv], connections[4, nel] (0-based)."""
     dx = (x[0] / n[0], x[1] / n[1])
@@ -92,6 +115,8 @@ def mesh_classical(vert: np.ndarray, conn: np.ndarray, disc: ClassicalDiscretiza
     vertices (``segment_cp_pos``/``face_cp_pos``/``block_cp_pos``).
     """
     dim = disc.dim
+    if disc.shape == "SIMPLEX":
+        return _mesh_classical_simplex(vert, conn, disc)
     assert disc.shape == "CUBE"
     nel = conn.shape[1]
     nv = vert.shape[1]
@@ -142,6 +167,52 @@ def mesh_classical(vert: np.ndarray, conn: np.ndarray, disc: ClassicalDiscretiza
             cp_ids[a, e] = cid
     return ClassicalMesh(dim=dim, coords=np.array(coords, dtype=np.float64), cp_ids=cp_ids,
                          vert_conn=conn.copy(), n_vertices=nv)
+
+
+def _mesh_classical_simplex(vert: np.ndarray, conn: np.ndarray, disc: ClassicalDiscretization) -> ClassicalMesh:
+    """SIMPLEX control points (3_InitializeMesh.jl:1-163 with init_Structure_Triangle/Tetrahedron_Lagrange,
+    101_Structures.jl:93-196): connectivity vertex j is reference vertex j (origin, e1, e2[, e3]); a lattice node
+    belongs to the entity spanned by the vertices with non-zero barycentric weight."""
+    dim, itp = disc.dim, disc.itp_func_num
+    nel, nv = conn.shape[1], vert.shape[1]
+    cp_ids = np.zeros((itp, nel), dtype=np.int64)
+    coords: List[np.ndarray] = [vert[:, v].copy() for v in range(nv)]
+    table: Dict[tuple, int] = {}
+    info = []
+    for a in range(itp):
+        xi = disc.itp_pos[a]
+        bary = np.concatenate([[1.0 - xi.sum()], xi])
+        nz = [v for v in range(dim + 1) if bary[v] > 1e-12]
+        info.append((nz, bary[nz]))
+    for e in range(nel):
+        ev = conn[:, e]
+        for a in range(itp):
+            nz, w = info[a]
+            gv = [int(ev[v]) for v in nz]
+            if len(nz) == 1:
+                cp_ids[a, e] = gv[0]
+                continue
+            if len(nz) == 2:
+                lo, hi = (gv[0], gv[1]) if gv[0] < gv[1] else (gv[1], gv[0])
+                t = w[1] if gv[0] < gv[1] else w[0]
+                key = (lo, hi, round(float(t), 9))
+            elif len(nz) == dim + 1:
+                key = ("b", e, a)
+            else:
+                if disc.itp_order > 3:
+                    raise NotImplementedError("face control point matching (3_InitializeMesh.jl:133)")
+                key = tuple(sorted(gv))
+            cid = table.get(key)
+            if cid is None:
+                cid = len(coords)
+                table[key] = cid
+                coords.append(sum(wi * vert[:, v] for wi, v in zip(w, gv)))
+            cp_ids[a, e] = cid
+    return ClassicalMesh(dim=dim, coords=np.array(coords, dtype=np.float64), cp_ids=cp_ids, vert_conn=conn.copy(),
+                         n_vertices=nv)
+
+
+SIMPLEX_FACE_VERTS = {2: ((0, 1), (1, 2), (2, 0)), 3: ((0, 1, 2), (0, 1, 3), (3, 1, 2), (0, 2, 3))}  # 002_Initialization.jl:1-7
 
 
 def lattice_mesh(x, n, disc: ClassicalDiscretization) -> ClassicalMesh:
@@ -197,7 +268,10 @@ def boundary_facets(mesh: ClassicalMesh) -> Facets:
     dim = mesh.dim
     corner_idx = _corner_to_conn_index(dim)
     face_corners = {}
-    for nd in range(dim):
+    simplex = mesh.vert_conn.shape[0] == dim + 1
+    if simplex:
+        face_corners = {fid: list(vs) for fid, vs in enumerate(SIMPLEX_FACE_VERTS[dim])}
+    for nd in range(0 if simplex else dim):
         for outward in (0, 1):
             fid = CUBE_FACE_IDS[dim][nd][outward] - 1
             cs = []

@@ -49,6 +49,30 @@ def cantilever():
     np.savez_compressed(os.path.join(HERE, "cantilever_hex20.npz"), xyz=pts, d1=sc["d1"], d2=sc["d2"], d3=sc["d3"])
 
 
+def stress_concentration():
+    """DATA from examples/linear_elasticity/stress_concentration: the Abaqus meshes 2D_Mesh.inp / 3D_Mesh.inp (first-order
+    CUBE connectivity, read with oracle.readers.read_inp) and the committed results 2D_MetaFEM.vtk / 3D_MetaFEM.vtk."""
+    from oracle import readers
+
+    base = os.path.join(REF, "examples/linear_elasticity/stress_concentration")
+    for dim in (2, 3):
+        vert, conn = readers.read_inp(os.path.join(base, f"{dim}D_Mesh.inp"))
+        pts, sc = vtk.read_vtk_points_scalars(os.path.join(base, f"{dim}D_MetaFEM.vtk"))
+        np.savez_compressed(os.path.join(HERE, f"stress_concentration_{dim}d.npz"), vert=vert, conn=conn.astype(np.int32),
+                            xyz=pts[:, :dim], **{f"d{i + 1}": sc[f"d{i + 1}"] for i in range(dim)})
+
+
+def pikachu():
+    """DATA from examples/thermal_conduction: 3D_COMSOL_Mesh.mphtxt (3405 vertices, 15334 tetrahedra; oracle.readers.read_mphtxt)
+    and the committed tet-10 result 3D_MetaFEM_Result.vtk (23703 points, SCALARS T) of 3D_Script.jl."""
+    from oracle import readers
+
+    base = os.path.join(REF, "examples/thermal_conduction")
+    vert, conn = readers.read_mphtxt(os.path.join(base, "3D_COMSOL_Mesh.mphtxt"))
+    pts, sc = vtk.read_vtk_points_scalars(os.path.join(base, "3D_MetaFEM_Result.vtk"))
+    np.savez_compressed(os.path.join(HERE, "pikachu_tet10.npz"), vert=vert, conn=conn.astype(np.int32), xyz=pts, T=sc["T"])
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -133,6 +157,8 @@ if __name__ == "__main__":
         strip()
         cavity()
         cantilever()
+        stress_concentration()
+        pikachu()
     tables()
     thermal_hex8()
     elasticity_hex8()

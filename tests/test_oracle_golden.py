@@ -132,3 +132,65 @@ def test_oracle_reproduces_reference_cantilever_vtk():
     scale = np.abs(z["d2"]).max()
     for f, nm in enumerate(("d1", "d2", "d3")):
         assert np.abs(dom.x[f * n:(f + 1) * n][idx] - z[nm]).max() < 1e-6 * scale, nm
+
+
+# ---- pins 4-6: unstructured meshes from the reference's example folders (fixtures = their mesh files + committed results) ----
+def test_oracle_reproduces_stress_concentration_2d_vtk():
+    """examples/linear_elasticity/stress_concentration/2D_Script.jl: Abaqus quad mesh (.inp) -> quad-8, component-wise
+    penalty on the symmetry lines, sigl{2,2} n{2} traction; every constant as written in the script."""
+    from oracle import stress_concentration as scn
+
+    z = np.load(os.path.join(GOLD, "stress_concentration_2d.npz"))
+    dom = scn.build(z["vert"], z["conn"].astype(np.int64))
+    assert dom.mesh.ncp == 1399 == z["d1"].size
+    dom.linear_solver = scn.lu
+    hist = dom.update_one_step()
+    assert hist[-1] < dom.converge_tol
+    d, idx = cKDTree(dom.mesh.coords).query(z["xyz"])
+    assert d.max() < 1e-7
+    n, scale = dom.mesh.ncp, np.abs(z["d2"]).max()
+    for f in range(2):
+        assert np.abs(dom.x[f * n:(f + 1) * n][idx] - z[f"d{f + 1}"]).max() < 1e-6 * scale
+
+
+def test_oracle_reproduces_stress_concentration_3d_vtk():
+    """3D_Script.jl: Abaqus hex mesh -> hex-20 (15 645 control points, 46 935 DOF), solved like the script with
+    idrs!(s = 20, maxiter = 2000, max_pass = 20) at converge_tol 1e-8."""
+    from oracle import stress_concentration as scn
+
+    z = np.load(os.path.join(GOLD, "stress_concentration_3d.npz"))
+    dom = scn.build(z["vert"], z["conn"].astype(np.int64))
+    assert dom.mesh.ncp == 15645 == z["d1"].size
+    dom.linear_solver = lambda d: solvers.iterative_solve(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue, d.converge_tol,
+                                                          Sv_func=solvers.idrs, maxiter=2000, max_pass=20, s=20)
+    hist = dom.update_one_step()
+    assert hist[-1] < dom.converge_tol
+    d, idx = cKDTree(dom.mesh.coords).query(z["xyz"])
+    assert d.max() < 1e-7
+    n, scale = dom.mesh.ncp, np.abs(z["d2"]).max()
+    for f in range(3):
+        assert np.abs(dom.x[f * n:(f + 1) * n][idx] - z[f"d{f + 1}"]).max() < 1e-5 * scale  # two IDR solves at tol 1e-8
+
+
+def test_oracle_reproduces_tet10_thermal_vtk():
+    """examples/thermal_conduction/3D_Script.jl: COMSOL tetrahedral mesh (.mphtxt) -> tet-10, SIMPLEX Gauss rules, convective
+    boundary on all 3120 boundary triangles.  Besides the field comparison, the reference's own field is inserted into
+    the oracle's discrete system: its residual is below the reference's stopping tolerance."""
+    from oracle import thermal_3d
+
+    z = np.load(os.path.join(GOLD, "pikachu_tet10.npz"))
+    dom = thermal_3d.build(z["vert"], z["conn"].astype(np.int64))
+    assert dom.mesh.ncp == 23703 == z["T"].size and dom.mesh.nel == 15334
+    dom.linear_solver = thermal_3d.lu
+    hist = dom.update_one_step()
+    assert hist[-1] < dom.converge_tol
+    d, idx = cKDTree(dom.mesh.coords * 100.0).query(z["xyz"])  # write_VTK(...; scale = 100)
+    assert d.max() < 1e-4
+    assert (np.abs(dom.x[idx] - z["T"]) / z["T"]).max() < 1e-5
+    inv = np.empty_like(idx)
+    inv[idx] = np.arange(idx.size)
+    dom.x[:] = z["T"][inv]
+    dom.dx[:] = 0.0
+    dom.update_x_star()
+    dom.K_nonlinear_func()
+    assert np.linalg.norm(dom.residue) / np.sqrt(dom.residue.size) < 1e-6  # the script's converge_tol

@@ -1,0 +1,134 @@
+"""Host-side mesh entry points of the product (metafem.jl_amd/mesh.py, element.py SIMPLEX tables) against the oracle's
+loop-style restatement of the same reference functions (CPU; no device needed)."""
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+import metafem_jl_amd  # noqa: F401  (loads the package under its importable alias)
+from metafem_jl_amd import element, mesh as pm
+from oracle import mesh as om, readers, reference_element as re_
+
+INP = """*Heading
+** Job name: tiny Model name: Model-1
+*Preprint, echo=NO, model=NO,
+ history=NO, contact=NO
+**
+*Part, name=Part-1
+*Node
+      1,           4.,           0.
+      2,           0.,           0.
+     10,           2.,           0.
+      4,           4.,           2.
+      5,           0.,           2.
+      7,           2.,          2.5
+*Element, type=CPS4R
+  1, 2, 10, 7, 5
+  2, 10, 1, 4, 7
+*Nset, nset=Set-3, generate
+ 1, 7, 1
+*End Part
+"""
+
+MPHTXT = """# Created by COMSOL Multiphysics.
+
+# Major & minor version
+0 1
+1 # number of tags
+# Tags
+5 mesh1
+1 # number of types
+# Types
+3 obj
+
+# --------- Object 0 ----------
+
+0 0 1
+4 Mesh # class
+4 # version
+3 # sdim
+5 # number of mesh points
+1 # lowest mesh point index
+
+# Mesh point coordinates
+0 0 0
+1 0 0
+0 1 0
+0 0 1
+1 1 1
+
+1 # number of element types
+
+# Type #0
+
+3 tet # type name
+
+
+4 # number of nodes per element
+2 # number of elements
+# Elements
+1 2 3 4
+2 3 4 5
+
+2 # number of geometric entity indices
+# Geometric entity indices
+1
+1
+"""
+
+
+def test_read_mesh_inp_and_mphtxt(tmp_path):
+    a, b = tmp_path / "m.inp", tmp_path / "m.mphtxt"
+    a.write_text(INP)
+    b.write_text(MPHTXT)
+    for path in (str(a), str(b)):
+        vo, co = readers.read_mesh(path)
+        vp, cp = pm.read_Mesh(path)
+        assert np.array_equal(vo, vp) and np.array_equal(co, cp)
+    v, c = pm.read_Mesh(str(a))
+    assert v.shape == (2, 6) and c.tolist() == [[1, 2], [2, 0], [5, 3], [4, 5]]  # labels 1,2,10,4,5,7 -> file positions
+    v, c = pm.read_Mesh(str(b))
+    assert v.shape == (3, 5) and c.T.tolist() == [[0, 1, 2, 3], [1, 2, 3, 4]]
+    with pytest.raises(ValueError):
+        pm.read_Mesh(str(tmp_path / "m.xyz"))
+
+
+@pytest.mark.parametrize("shape", ["CUBE", "SIMPLEX"])
+def test_generators_match_the_loop_restatement(shape):
+    v2, c2 = pm.make_Square((2.0, 1.0), (3, 2), shape)
+    vo, co = om.make_square((2.0, 1.0), (3, 2))
+    assert np.array_equal(v2, vo) and np.array_equal(c2, co if shape == "CUBE" else om.simplex_split(co, (3, 2)))
+    v3, c3 = pm.make_Brick((1.0, 2.0, 1.5), (2, 3, 2), shape)
+    vo, co = om.make_brick((1.0, 2.0, 1.5), (2, 3, 2))
+    assert np.array_equal(v3, vo) and np.array_equal(c3, co if shape == "CUBE" else om.simplex_split(co, (2, 3, 2)))
+    if shape == "SIMPLEX":  # the 5-tet split fills every cell: volumes add up
+        p = v3.T[c3]
+        vol = np.abs(np.einsum("ei,ei->e", np.cross(p[1] - p[0], p[2] - p[0]), p[3] - p[0])) / 6
+        assert np.isclose(vol.sum(), 3.0)
+
+
+CASES = [("CUBE", 2, "Serendipity", 2), ("CUBE", 2, "Lagrange", 2), ("CUBE", 3, "Serendipity", 2), ("CUBE", 3, "Lagrange", 2),
+         ("CUBE", 3, "Lagrange", 1), ("SIMPLEX", 2, "Serendipity", 2), ("SIMPLEX", 3, "Serendipity", 2), ("SIMPLEX", 3, "Lagrange", 3),
+         ("SIMPLEX", 2, "Lagrange", 1)]
+
+
+@pytest.mark.parametrize("shape,dim,itp_type,order", CASES)
+def test_mesh_classical_and_boundary_match_oracle(shape, dim, itp_type, order):
+    n = (3, 2) if dim == 2 else (2, 3, 2)
+    x = (2.0, 1.0) if dim == 2 else (1.0, 2.0, 1.5)
+    vert, conn = (pm.make_Square if dim == 2 else pm.make_Brick)(x, n, shape)
+    rng = np.random.default_rng(3)
+    vert = vert + 0.05 * rng.standard_normal(vert.shape)  # generic positions: coordinates identify control points
+    perm = rng.permutation(conn.shape[1])
+    conn = conn[:, perm]
+    space = element.classical_space(dim, itp_type, order, 5, shape=shape)
+    disc = re_.initialize_classical_element(dim, shape, order, 1, 5, itp_type=itp_type)
+    mp = pm.mesh_Classical(vert, conn, space)
+    mo = om.mesh_classical(vert, conn, disc)
+    assert mp.ncp == mo.ncp and mp.cp_ids.shape == mo.cp_ids.shape
+    assert np.array_equal(mp.cp_ids[:, 0] < mp.n_vertices, mo.cp_ids[:, 0] < mo.n_vertices)
+    d, idx = cKDTree(mo.coords).query(mp.coords)
+    assert d.max() < 1e-12 and np.unique(idx).size == mp.ncp  # same set of control points
+    assert np.array_equal(idx[mp.cp_ids], mo.cp_ids)  # same element -> node incidence in basis order
+    fp, fo = pm.get_BoundaryMesh(mp), om.boundary_facets(mo)
+    assert np.array_equal(fp.element_ID, fo.element_ID) and np.array_equal(fp.element_eindex, fo.element_eindex)
+    assert np.allclose(fp.centroid, fo.centroid, atol=1e-14)
