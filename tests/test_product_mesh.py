@@ -132,3 +132,42 @@ def test_mesh_classical_and_boundary_match_oracle(shape, dim, itp_type, order):
     fp, fo = pm.get_BoundaryMesh(mp), om.boundary_facets(mo)
     assert np.array_equal(fp.element_ID, fo.element_ID) and np.array_equal(fp.element_eindex, fo.element_eindex)
     assert np.allclose(fp.centroid, fo.centroid, atol=1e-14)
+
+
+VTK_EDGES = {23: ((0, 1), (1, 2), (2, 3), (3, 0)), 22: ((0, 1), (1, 2), (2, 0)),
+             25: ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)),
+             24: ((0, 1), (1, 2), (2, 0), (0, 3), (1, 3), (2, 3))}
+
+
+@pytest.mark.parametrize("shape,dim,itp_type,order", [c for c in CASES if c[3] <= 2])
+def test_write_vtk_layout_and_node_order(tmp_path, shape, dim, itp_type, order):
+    """Reads back through the oracle's reader (the one that parses the reference's committed VTKs) and checks VTK's
+    corner / mid-edge convention geometrically: mid-edge node k of a quadratic cell is the midpoint of VTK edge k."""
+    from metafem_jl_amd import vtk as pv
+    from oracle import vtk as ov
+
+    n = (3, 2) if dim == 2 else (2, 2, 2)
+    x = (2.0, 1.0) if dim == 2 else (1.0, 2.0, 1.5)
+    vert, conn = (pm.make_Square if dim == 2 else pm.make_Brick)(x, n, shape)
+    space = element.classical_space(dim, itp_type, order, 5, shape=shape)
+    msh = pm.mesh_Classical(vert, conn, space)
+    rng = np.random.default_rng(1)
+    fields = {"T": rng.standard_normal(msh.ncp), "d2": rng.standard_normal(msh.ncp) * 1e-9}
+    path = str(tmp_path / "out.vtk")
+    pv.write_VTK(path, msh.coords, msh.cp_ids, space, fields, scale=100.0)
+    pts, sc = ov.read_vtk_points_scalars(path)
+    assert np.array_equal(pts[:, :dim], msh.coords * 100.0) and list(sc) == ["T", "d2"]
+    assert all(np.array_equal(sc[k], fields[k]) for k in fields)  # repr round-trips Float64 exactly
+    lines = open(path).read().split("\n")
+    assert lines[0] == "# vtk DataFile Version 3.0" and lines[2:4] == ["ASCII", "DATASET UNSTRUCTURED_GRID"]
+    c0 = lines.index(next(l for l in lines if l.startswith("CELLS")))
+    cell_type, nodes = pv.vtk_cell(dim, shape, itp_type, order)
+    assert lines[c0].split() == ["CELLS", str(msh.nel), str(msh.nel * (1 + len(nodes)))]
+    cells = np.array([[int(t) for t in lines[c0 + 1 + e].split()] for e in range(msh.nel)])
+    assert np.all(cells[:, 0] == len(nodes)) and lines[c0 + 1 + msh.nel].split() == ["CELL_TYPES", str(msh.nel)]
+    assert set(lines[c0 + 2 + msh.nel:c0 + 2 + 2 * msh.nel]) == {str(cell_type)}
+    if cell_type in VTK_EDGES:
+        ncorner = len(nodes) - len(VTK_EDGES[cell_type])
+        for k, (a, b) in enumerate(VTK_EDGES[cell_type]):
+            mid = 0.5 * (msh.coords[cells[:, 1 + a]] + msh.coords[cells[:, 1 + b]])
+            assert np.allclose(msh.coords[cells[:, 1 + ncorner + k]], mid, atol=1e-13)
