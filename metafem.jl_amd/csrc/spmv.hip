@@ -50,14 +50,14 @@ __device__ __forceinline__ int64_t tile_of(int64_t it, int64_t ntiles, int xcd_c
   return (run * 8 + xcd) * xcd_chunk + within;  // may be >= ntiles near the end: caller skips
 }
 
-template <typename RP, bool VEC, int SPMV_CAP, int SPMV_UNROLL>
-__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
+template <typename RP, bool VEC, int SPMV_CAP, int SPMV_UNROLL, int BLK = MFEM_BLOCK>
+__global__ __launch_bounds__(BLK) void k_spmv_lds(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, int64_t ntiles_padded, int xcd_aware,
     const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
   __shared__ double prod[SPMV_CAP + 4];
-  __shared__ double red[4];
+  __shared__ double red[BLK / 64];
   if (done_flag && done_flag[0]) return;
   const int tid = threadIdx.x;
   const int tpr = 1 << tpr_log2;
@@ -81,12 +81,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
         lo_pre = (int)((int64_t)rowptr[rmine] - base - sa);
         hi_pre = (int)((int64_t)rowptr[rmine + 1] - base - sa);
       }
-      for (int i0 = 2 * tid; i0 < cnt; i0 += 2 * MFEM_BLOCK * SPMV_UNROLL) {
+      for (int i0 = 2 * tid; i0 < cnt; i0 += 2 * BLK * SPMV_UNROLL) {
         d2_t v[SPMV_UNROLL];
         i2_t c[SPMV_UNROLL];
 #pragma unroll
         for (int u = 0; u < SPMV_UNROLL; ++u) {
-          const int i = i0 + u * 2 * MFEM_BLOCK;
+          const int i = i0 + u * 2 * BLK;
           v[u] = (d2_t){0.0, 0.0};
           c[u] = (i2_t){base, base};
           if (i < cnt) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
         }
 #pragma unroll
         for (int u = 0; u < SPMV_UNROLL; ++u) {
-          const int i = i0 + u * 2 * MFEM_BLOCK;
+          const int i = i0 + u * 2 * BLK;
           if (i < cnt) {
             // entry i+1 may belong to the next tile (i + 1 == cnt): its product is never read
             double x0, x1;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
       __syncthreads();
       // phase 2: tpr lanes per row
       const int g = tid & (tpr - 1);
-      for (int64_t r = rmine; r < r1; r += (MFEM_BLOCK >> tpr_log2)) {
+      for (int64_t r = rmine; r < r1; r += (BLK >> tpr_log2)) {
         const int lo = (r == rmine) ? lo_pre : (int)((int64_t)rowptr[r] - base - sa);
         const int hi = (r == rmine) ? hi_pre : (int)((int64_t)rowptr[r + 1] - base - sa);
         double sum = 0.0;
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
       __syncthreads();
     } else {
       const int cnt = (int)(e - s);
-      for (int i0 = tid; i0 < cnt; i0 += MFEM_BLOCK * SPMV_UNROLL) {
+      for (int i0 = tid; i0 < cnt; i0 += BLK * SPMV_UNROLL) {
         double v[SPMV_UNROLL];
         int c[SPMV_UNROLL];
 #pragma unroll
         for (int u = 0; u < SPMV_UNROLL; ++u) {
-          const int i = i0 + u * MFEM_BLOCK;
+          const int i = i0 + u * BLK;
           v[u] = 0.0;
           c[u] = base;
           if (i < cnt) {
@@ -150,13 +150,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_lds(
         }
 #pragma unroll
         for (int u = 0; u < SPMV_UNROLL; ++u) {
-          const int i = i0 + u * MFEM_BLOCK;
+          const int i = i0 + u * BLK;
           if (i < cnt) prod[i] = v[u] * x[c[u] - base];
         }
       }
       __syncthreads();
       const int g = tid & (tpr - 1);
-      for (int64_t r = r0 + (tid >> tpr_log2); r < r1; r += (MFEM_BLOCK >> tpr_log2)) {
+      for (int64_t r = r0 + (tid >> tpr_log2); r < r1; r += (BLK >> tpr_log2)) {
         const int lo = (int)((int64_t)rowptr[r] - base - s);
         const int hi = (int)((int64_t)rowptr[r + 1] - base - s);
         double sum = 0.0;
@@ -213,12 +213,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
-static int g_spmv_variant = 1;    // 0: CAP 4032 x4, 1: CAP 4032 x8, 2: CAP 2016 x4, 3: CAP 2016 x2
+// 0: CAP 4032 x4, 1: CAP 4032 x8 (256 threads);  2: CAP 2016 x8, 128 threads;  3: CAP 2016 x8, 64 threads;  7: CAP 1008 x8,
+// 64 threads (wave-private tiles: the barrier degenerates);  4: CAP 4032 x4, 5: CAP 4032 x2 with 512 threads,  6: CAP 4032 x2
+// with 1024 threads (same LDS tile shared by more waves: the tile kernel is LDS-limited to 4 workgroups per CU)
+static int g_spmv_variant = 1;
 static int g_spmv_nogather = 0;   // diagnostic only: replace x[col] by col-derived constants (WRONG results, timing probe)
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
-  g_spmv_variant = (xcd_aware >> 16) & 3;
+  g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_nogather = (xcd_aware >> 20) & 1;
   if (grid_mult > 0) g_spmv_grid_mult = grid_mult;
   return MFEM_OK;
@@ -319,12 +322,17 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     if (w != 0) return w < 0 ? w : MFEM_OK;
   }
   const int base = A->index_base;
-  const int cap_doubles = (g_spmv_variant >= 2 && A->max_row_nnz <= 2016 - 2) ? 2016 : 4032;
+  const int cap_doubles = (g_spmv_variant == 7 && A->max_row_nnz <= 1008 - 2) ? 1008
+                          : ((g_spmv_variant == 2 || g_spmv_variant == 3) && A->max_row_nnz <= 2016 - 2) ? 2016 : 4032;
   if (A->rows_per_block > 0) {
-    int R = MFEM_BLOCK;
+    const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
+    const int blk = !vec ? MFEM_BLOCK : g_spmv_variant == 6 ? 1024 : (g_spmv_variant == 4 || g_spmv_variant == 5) ? 512
+                    : (g_spmv_variant == 7 && cap_doubles == 1008) ? 64 : (g_spmv_variant == 3 && cap_doubles == 2016) ? 64
+                    : (g_spmv_variant == 2 && cap_doubles == 2016) ? 128 : MFEM_BLOCK;
+    int R = blk;
     while (R > 1 && (int64_t)R * A->max_row_nnz > cap_doubles - 2) R >>= 1;
     int tpr_log2 = 0;
-    while ((MFEM_BLOCK >> (tpr_log2 + 1)) >= R) ++tpr_log2;  // tpr = 256 / R
+    while ((blk >> (tpr_log2 + 1)) >= R) ++tpr_log2;  // tpr = blk / R
     const int64_t ntiles = (A->n + R - 1) / R;
     int cap = ctx->num_cus * g_spmv_grid_mult;
     if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
@@ -336,18 +344,21 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     const int64_t span = (int64_t)8 * (xch > 0 ? xch : 1);
     const int64_t ntiles_padded = xch ? (ntiles + span - 1) / span * span : ntiles;
     if (g_spmv_nogather) xcd |= (1 << 30);
-    const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
-#define LAUNCH_LDS(RP, VEC, CAP, UNR)                                                                      \
-  hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,  \
+#define LAUNCH_LDS(RP, VEC, CAP, UNR, BLK)                                                                 \
+  hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR, BLK>), dim3(grid), dim3(BLK), 0, ctx->stream, A->n,    \
                      A->nnz, (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2,  \
                      ntiles, ntiles_padded, xcd, dotw, partials, done_flag)
 #define LAUNCH_VARIANT(RP)                                                   \
   do {                                                                       \
-    if (!vec) LAUNCH_LDS(RP, false, 4032, 4);                                \
-    else if (cap_doubles == 2016 && g_spmv_variant == 2) LAUNCH_LDS(RP, true, 2016, 4); \
-    else if (cap_doubles == 2016) LAUNCH_LDS(RP, true, 2016, 2);             \
-    else if (g_spmv_variant == 1) LAUNCH_LDS(RP, true, 4032, 8);             \
-    else LAUNCH_LDS(RP, true, 4032, 4);                                      \
+    if (!vec) LAUNCH_LDS(RP, false, 4032, 4, MFEM_BLOCK);                    \
+    else if (cap_doubles == 1008) LAUNCH_LDS(RP, true, 1008, 8, 64);          \
+    else if (cap_doubles == 2016 && g_spmv_variant == 2) LAUNCH_LDS(RP, true, 2016, 8, 128); \
+    else if (cap_doubles == 2016) LAUNCH_LDS(RP, true, 2016, 8, 64);         \
+    else if (g_spmv_variant == 1) LAUNCH_LDS(RP, true, 4032, 8, MFEM_BLOCK); \
+    else if (g_spmv_variant == 4) LAUNCH_LDS(RP, true, 4032, 4, 512);        \
+    else if (g_spmv_variant == 5) LAUNCH_LDS(RP, true, 4032, 2, 512);        \
+    else if (g_spmv_variant == 6) LAUNCH_LDS(RP, true, 4032, 2, 1024);       \
+    else LAUNCH_LDS(RP, true, 4032, 4, MFEM_BLOCK);                          \
   } while (0)
     if (A->rowptr_bits == 64) LAUNCH_VARIANT(int64_t); else LAUNCH_VARIANT(int32_t);
 #undef LAUNCH_VARIANT
