@@ -87,7 +87,9 @@ int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
  * for plans created afterwards. */
 int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
 /* hex-27 matrix assembly variant: 0 (default) = colour-partitioned read-modify-write scatter straight from the MFMA
- * accumulators; 1 = MFMA Ke -> element-major scratch + row-owner gather (every CSR value written once; slower today). */
+ * accumulators; 1 = MFMA Ke -> element-major scratch + row-owner gather (every CSR value written once; slower today).
+ * Bits 8-11 are a timing probe that leaves kernel phases out (results are then WRONG): 0x100 node loads, 0x200 Jacobians,
+ * 0x400 MFMA loop, 0x800 scatter. */
 int mfem_debug_set_hex27(int two_pass);
 
 /* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).

@@ -117,6 +117,7 @@ struct Hex27Args {
   double kcond;
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
   int nq;
+  int skip;          // timing probe only (WRONG results): 1 no node loads, 2 no J / inverse, 4 no MFMA loop, 8 no scatter
 };
 
 // Element of this colour with running index e -> (I,J,K); returns false past the end.
@@ -139,8 +140,10 @@ __device__ __forceinline__ bool colour_element(const BrickView& B, int colour, i
   return true;
 }
 
+// __launch_bounds__(512, 4) (second argument = waves per SIMD in HIP): two workgroups must fit a CU, i.e. <= 128 VGPRs per lane; without it the
+// scatter epilogue pushed the kernel to 145 VGPRs and only ONE workgroup (2 waves per SIMD) was resident.
 template <bool MATRIX>
-__global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
+__global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
                                                         const double* __restrict__ src, double* __restrict__ out) {
   extern __shared__ double lds[];
   // workgroup-shared reference tables
@@ -163,25 +166,51 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
   const int nrows = 3 * nq;                  // rows of B
   const int nksteps = (nrows + 3) >> 2;      // MFMA k-steps (4 rows each; rows >= nrows contribute zero)
 
-  for (int64_t e = (int64_t)blockIdx.x * H27_WAVES + wv;; e += nwaves) {
-    int I, J, K;
-    if (!colour_element(B, A.colour, e, I, J, K)) break;  // wave-uniform
-    // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
-    if (lane < 27) {
+  // Node data of an element (lane a < 27: coordinates of node a and, for the scatter, its CSR row descriptor).  The loads
+  // of element e + nwaves are issued while element e is still being integrated and land in registers; they are written
+  // to the wave's LDS block at the top of the next iteration, so their latency (three dependent table lookups + the
+  // coordinate loads) never sits on the wave's critical path.
+  struct NodePre {
+    double x0, x1, x2;
+    int64_t rb;
+    int32_t s1, c2;
+  };
+  auto fetch_nodes = [&](int I, int J, int K) -> NodePre {
+    NodePre n{0.0, 0.0, 0.0, 0, 0, 0};
+    if (lane < 27 && !(A.skip & 1)) {
       const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
       const int64_t c = brick_cindex(B, gi, gj, gk);
-      W[W_X + 3 * lane + 0] = B.X0[c];
-      W[W_X + 3 * lane + 1] = B.X1[c];
-      W[W_X + 3 * lane + 2] = B.X2[c];
-      if (MATRIX && A.colour < 0) {
+      n.x0 = B.X0[c];
+      n.x1 = B.X1[c];
+      n.x2 = B.X2[c];
+      if (MATRIX && A.colour != -1) {
+        // slot(a, b) = rowbase[a] + gi_b * s1_a + gj_b * s2_a + gk_b   with the row's box origin folded into rowbase
+        const int c1 = B.c1[gj];
+        n.c2 = B.c2[gk];
+        const int64_t s1 = (int64_t)c1 * n.c2;
+        n.s1 = (int32_t)s1;
+        n.rb = brick_prefix(B, gi, gj, gk) - ((int64_t)B.lo0[gi] * s1 + (int64_t)B.lo1[gj] * n.c2 + B.lo2[gk]);
+      }
+    }
+    return n;
+  };
+  int I, J, K;
+  int64_t e = (int64_t)blockIdx.x * H27_WAVES + wv;
+  bool have = colour_element(B, A.colour, e, I, J, K);  // wave-uniform
+  NodePre cur = have ? fetch_nodes(I, J, K) : NodePre{0.0, 0.0, 0.0, 0, 0, 0};
+  while (have) {
+    // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
+    if (lane < 27) {
+      W[W_X + 3 * lane + 0] = cur.x0;
+      W[W_X + 3 * lane + 1] = cur.x1;
+      W[W_X + 3 * lane + 2] = cur.x2;
+      const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
+      if (MATRIX && A.colour == -1) {
         // two-pass path: no row descriptors needed
       } else if (MATRIX) {
-        // slot(a, b) = rowbase[a] + gi_b * s1_a + gj_b * s2_a + gk_b   with the row's box origin folded into rowbase
-        const int c1 = B.c1[gj], c2 = B.c2[gk];
-        const int64_t s1 = (int64_t)c1 * c2;
-        rowbase[lane] = brick_prefix(B, gi, gj, gk) - ((int64_t)B.lo0[gi] * s1 + (int64_t)B.lo1[gj] * c2 + B.lo2[gk]);
+        rowbase[lane] = cur.rb;
         int32_t* in = info + 8 * lane;
-        in[0] = (int32_t)s1; in[1] = c2;
+        in[0] = cur.s1; in[1] = cur.c2;
         in[5] = gi; in[6] = gj; in[7] = gk;
       } else {
         const int64_t xi = brick_xindex(B, 0, gi, gj, gk);
@@ -189,9 +218,15 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
         W[W_T + 28 + lane] = src ? src[xi] : 0.0;
       }
     }
+    // next element of this wave: issue its node loads now
+    const int Ic = I, Jc = J, Kc = K;
+    const int64_t ec = e;
+    e += nwaves;
+    have = colour_element(B, A.colour, e, I, J, K);
+    if (have) cur = fetch_nodes(I, J, K);
     __builtin_amdgcn_wave_barrier();
     // ---- 2a. J[q][i][0..2] = sum_a dN[q][a][0..2] X[a][i] : one (q,i) pair per lane and pass
-    for (int t = lane; t < nq * 3; t += 64) {
+    for (int t = lane; t < nq * 3 && !(A.skip & 2); t += 64) {
       const int q = t / 3, i = t - 3 * q;
       const double* dn = s_dN + q * 81;
       double j0 = 0.0, j1 = 0.0, j2 = 0.0;
@@ -208,7 +243,7 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 2b. det, inverse (adjugate, inv_Jac_3D), w det ; Jinv overwrites J as [m][s]
-    for (int q = lane; q < nq; q += 64) {
+    for (int q = lane; q < nq && !(A.skip & 2); q += 64) {
       double* Jm = W + W_J + q * 9;
       const double j00 = Jm[0], j01 = Jm[1], j02 = Jm[2], j10 = Jm[3], j11 = Jm[4], j12 = Jm[5], j20 = Jm[6], j21 = Jm[7],
                    j22 = Jm[8];
@@ -235,7 +270,7 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
       const bool hi_ok = (c + 16) < 27;
       // row r = 4 ks + kl = 3 q + sidx advances by 4 per k-step: (q, sidx) -> (q + 1, sidx + 1) with carry
       int q = kl / 3, sidx = kl - 3 * q, r = kl;
-      for (int ks = 0; ks < nksteps; ++ks, r += 4) {
+      for (int ks = 0; ks < ((A.skip & 4) ? 1 : nksteps); ++ks, r += 4) {
         double v0 = 0.0, v1 = 0.0, dr = 0.0;
         if (r < nrows) {
           const double* Ji = W + W_J + q * 9 + sidx;
@@ -256,10 +291,10 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
         C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
         C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
       }
-      if (A.colour < 0) {
+      if (A.colour == -1) {
         // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
         //      row-owner gather kernel below turns it into CSR rows.
-        double* ke = out + (int64_t)e * 729;
+        double* ke = out + ec * 729;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ra = kl + 4 * reg;
@@ -275,36 +310,53 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
         __builtin_amdgcn_wave_barrier();
         continue;
       }
-      // ---- 4. colour-safe scatter: 16 entries per lane; all slots of one element are distinct, so the loads
-      //      are issued together, then the stores (plain read-modify-write, no atomics).
+      // ---- 4. colour-safe scatter: 16 entries per lane in two batches of 8 (register budget: 128 VGPRs = 4 waves per
+      //      SIMD); all slots of one element are distinct, so a batch's loads are issued together, then its stores
+      //      (plain read-modify-write, no atomics).
       const int rq = kl;
-      int64_t slot[16];
-      double val[16];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int ra = rq + 4 * reg;  // f64 MFMA C/D map: row = (lane>>4) + 4*reg, col = lane & 15
-        const int aa[4] = {ra, ra, 16 + c, 16 + ra};
-        const int bb[4] = {c, 16 + c, ra, 16 + c};  // tiles (0,0), (0,1), (1,0) = transpose of (0,1), (1,1)
-        const double vv[4] = {C00[reg], C01[reg], C01[reg], C11[reg]};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int _a = aa[t], _b = bb[t];
-          int64_t sl = -1;
-          if (_a < 27 && _b < 27) {
-            const int32_t* ia = info + 8 * _a;
-            const int32_t* ib = info + 8 * _b;
-            sl = rowbase[_a] + (int64_t)ib[5] * ia[0] + (int64_t)ib[6] * ia[1] + ib[7];
-          }
-          slot[4 * reg + t] = sl;
-          val[4 * reg + t] = vv[t];
-        }
+      if (A.skip & 8) {
+        if (C00[0] + C01[1] + C11[2] == 1.2345) out[0] = 1.0;  // keeps the accumulators alive
+        continue;
       }
-      double old[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) old[t] = slot[t] >= 0 ? out[slot[t]] : 0.0;
+      for (int half = 0; half < 2; ++half) {
+        int64_t slot[8];
+        double val[8];
 #pragma unroll
-      for (int t = 0; t < 16; ++t)
-        if (slot[t] >= 0) out[slot[t]] = old[t] + val[t];
+        for (int rr = 0; rr < 2; ++rr) {
+          const int reg = 2 * half + rr;
+          const int ra = rq + 4 * reg;  // f64 MFMA C/D map: row = (lane>>4) + 4*reg, col = lane & 15
+          const int aa[4] = {ra, ra, 16 + c, 16 + ra};
+          const int bb[4] = {c, 16 + c, ra, 16 + c};  // tiles (0,0), (0,1), (1,0) = transpose of (0,1), (1,1)
+          const double vv[4] = {C00[reg], C01[reg], C01[reg], C11[reg]};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int _a = aa[t], _b = bb[t];
+            int64_t sl = -1;
+            if (_a < 27 && _b < 27) {
+              const int32_t* ia = info + 8 * _a;
+              const int32_t* ib = info + 8 * _b;
+              sl = rowbase[_a] + (int64_t)ib[5] * ia[0] + (int64_t)ib[6] * ia[1] + ib[7];
+            }
+            slot[4 * rr + t] = sl;
+            val[4 * rr + t] = vv[t];
+          }
+        }
+        if (A.colour == -2) {
+          // atomics variant (what the reference's _Kval_Basic does, 06_FEM_Kernel.jl:41): all elements in one launch,
+          // FP64 adds resolved in L2, nothing returns to the wave; summation order (and so the last bit) is not fixed
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (slot[t] >= 0) unsafeAtomicAdd(out + slot[t], val[t]);
+          continue;
+        }
+        double old[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) old[t] = slot[t] >= 0 ? out[slot[t]] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (slot[t] >= 0) out[slot[t]] = old[t] + val[t];
+      }
     } else {
       // ---- 3'. residual: fe[a] = sum_q w det ( -k gradN_a . gradT + N_a s_q )
       //      gradN_a . gradT = sum_m dN[q][a][m] h[q][m],  h = Jinv (Jinv^T gxi),  gxi[m] = sum_b dN[q][b][m] T_b
@@ -340,7 +392,7 @@ __global__ __launch_bounds__(H27_THREADS) void k_hex27(Hex27Args A, const double
           fe += dn[0] * W[W_G + 3 * q] + dn[1] * W[W_G + 3 * q + 1] + dn[2] * W[W_G + 3 * q + 2] +
                 s_N[q * 27 + lane] * W[W_G + 3 * h27_pad(nq) + q];
         }
-        const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
+        const int gi = 2 * Ic + lane % 3, gj = 2 * Jc + (lane / 3) % 3, gk = 2 * Kc + lane / 9;
         if (gi >= B.plo && gi < B.phi) out[(int64_t)(gi - B.plo) * B.plane_len + (int64_t)gj * B.m2 + gk] += fe;
       }
     }
@@ -402,8 +454,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather(BrickView B, const 
   }
 }
 
-// ---- Robin faces (hex-27): one thread per boundary face element, 9 face nodes, ng x ng Gauss points.
-// colour = parity of the face element in its two tangential directions (4 launches per brick face).
+// ---- Robin faces (hex-27): one thread per (boundary face element, face node a) = one row of the 9 x 9 face matrix;
+// 9 face nodes, ng x ng Gauss points.  colour = parity of the face element in its two tangential directions; the two
+// opposite faces of a direction share no node and go into the same launch (side = -1): 4 launches per direction.
 struct Face27Args {
   BrickView B;
   const Hex27Tables* tab;
@@ -419,16 +472,23 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
   const int t1 = (A.nd + 1) % 3, t2 = (A.nd + 2) % 3;
   const int c1 = A.colour & 1, c2 = A.colour >> 1;
   const int n1 = (ne[t1] - c1 + 1) >> 1, n2 = (ne[t2] - c2 + 1) >> 1;
-  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = (int)(tid % 9);
+  int64_t f = tid / 9;
+  int side = A.side;
+  if (side < 0) {
+    side = (int)(f & 1);
+    f >>= 1;
+  }
   if (n1 <= 0 || n2 <= 0 || f >= (int64_t)n1 * n2) return;
   int E[3];
-  E[A.nd] = A.side ? ne[A.nd] - 1 : 0;
+  E[A.nd] = side ? ne[A.nd] - 1 : 0;
   E[t1] = 2 * (int)(f % n1) + c1;
   E[t2] = 2 * (int)(f / n1) + c2;
   int g[9][3];
   double Xf[9][3], Tf[9];
   for (int c = 0; c < 9; ++c) {
-    g[c][A.nd] = A.side ? 2 * ne[A.nd] : 0;
+    g[c][A.nd] = side ? 2 * ne[A.nd] : 0;
     g[c][t1] = 2 * E[t1] + c % 3;
     g[c][t2] = 2 * E[t2] + c / 3;
     const int64_t ci = brick_cindex(B, g[c][0], g[c][1], g[c][2]);
@@ -437,8 +497,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
     Xf[c][2] = B.X2[ci];
     if (!MATRIX) Tf[c] = xstar[brick_xindex(B, 0, g[c][0], g[c][1], g[c][2])];
   }
-  for (int a = 0; a < 9; ++a) {
-    if (g[a][0] < B.plo || g[a][0] >= B.phi) continue;  // only owned rows
+  {
+    if (g[a][0] < B.plo || g[a][0] >= B.phi) return;  // only owned rows
     double macc[9];
     for (int b = 0; b < 9; ++b) macc[b] = 0.0;
     double racc = 0.0;
@@ -476,8 +536,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
 static int g_hex27_two_pass = 0;
+static int g_hex27_skip = 0;
 extern "C" int mfem_debug_set_hex27(int two_pass) {
-  g_hex27_two_pass = two_pass ? 1 : 0;
+  g_hex27_two_pass = two_pass & 3;  // 0 colours, 1 two-pass, 2 FP64 atomics
+  g_hex27_skip = (two_pass >> 8) & 15;  // timing probe (tools/probe_hex27.py): phases left out, results WRONG
   return MFEM_OK;
 }
 
@@ -489,16 +551,26 @@ static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix,
                               const double* xstar, double* out) {
   if (h == 0.0 || robin == 0u) return MFEM_OK;
   BrickView B = mfem_brick_view(m, 1);
-  for (int nd = 0; nd < 3; ++nd)
-    for (int side = 0; side < 2; ++side) {
-      const int id = (nd == 0) ? (side ? 3 : 5) : (nd == 1) ? (side ? 4 : 2) : (side ? 6 : 1);
-      if (!(robin & (1u << (id - 1)))) continue;
+  for (int nd = 0; nd < 3; ++nd) {
+    const int id_lo = (nd == 0) ? 5 : (nd == 1) ? 2 : 1, id_hi = (nd == 0) ? 3 : (nd == 1) ? 4 : 6;
+    const bool lo = robin & (1u << (id_lo - 1)), hi = robin & (1u << (id_hi - 1));
+    // both faces of the direction in one launch (side = -1) when both carry the condition
+    for (int pass = 0; pass < 2; ++pass) {
+      int side;
+      if (lo && hi) {
+        if (pass) break;
+        side = -1;
+      } else {
+        side = pass;
+        if (!(side ? hi : lo)) continue;
+      }
       const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
       for (int colour = 0; colour < 4; ++colour) {
         const int n1 = (m->ne[t1] - (colour & 1) + 1) >> 1, n2 = (m->ne[t2] - (colour >> 1) + 1) >> 1;
         if (n1 <= 0 || n2 <= 0) continue;
         Face27Args A{B, g_tab, h, Tenv, nd, side, colour, m->ng};
-        const int grid = (int)(((int64_t)n1 * n2 + MFEM_BLOCK - 1) / MFEM_BLOCK);
+        const int64_t nthreads = (int64_t)n1 * n2 * 9 * (side < 0 ? 2 : 1);
+        const int grid = (int)((nthreads + MFEM_BLOCK - 1) / MFEM_BLOCK);
         if (matrix)
           hipLaunchKernelGGL(k_hex27_faces<true>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A, xstar, out);
         else
@@ -506,6 +578,7 @@ static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix,
         MFEM_CHECK_LAUNCH();
       }
     }
+  }
   return MFEM_OK;
 }
 
@@ -518,12 +591,23 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   const size_t lds = hex27_lds_bytes(nq, true);
   MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   BrickView B = mfem_brick_view(m, 1);
-  if (g_hex27_two_pass) {
+  if (g_hex27_two_pass == 2) {
+    MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
+    const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
+    Hex27Args A{B, g_tab, p->k, -2, nq, g_hex27_skip};
+    int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
+    const int64_t cap = (int64_t)ctx->num_cus * 2;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, vals);
+    MFEM_CHECK_LAUNCH();
+    return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
+  }
+  if (g_hex27_two_pass == 1) {
     // pass 1: every element's Ke on the matrix cores -> element-major scratch; pass 2: row-owner gather -> CSR
     const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
     rc = mfem_ws_reserve(ctx, sizeof(double) * 729 * (size_t)nel);
     if (rc) return rc;
-    Hex27Args A{B, g_tab, p->k, -1, nq};
+    Hex27Args A{B, g_tab, p->k, -1, nq, g_hex27_skip};
     int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
@@ -539,7 +623,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq};
+    Hex27Args A{B, g_tab, p->k, colour, nq, g_hex27_skip};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
@@ -564,7 +648,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq};
+    Hex27Args A{B, g_tab, p->k, colour, nq, 0};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;

@@ -27,7 +27,7 @@ def _oracle(x, n, itg=5, distort=False, faces=None):
     return od
 
 
-@pytest.fixture(params=[0, 1], ids=["colour_scatter", "two_pass_gather"])
+@pytest.fixture(params=[0, 1, 2], ids=["colour_scatter", "two_pass_gather", "fp64_atomics"])
 def variant(request):
     """Both matrix-assembly variants: colour-partitioned RMW scatter (default) and MFMA Ke -> scratch + row-owner gather."""
     from metafem_jl_amd import _lib
