@@ -270,6 +270,41 @@ int mfem_op_res(mfem_context ctx, const mfem_op_layout* L, const double* itp_val
                 int64_t cpID_shift, const int32_t* el_g_cpIDs, double* residue, const int32_t* itg_hostIDs,
                 const int32_t* elIDs, int64_t n_threads);
 
+/* ---- batched forms of the three operators (new) ------------------------------------------------
+ * The generated updaters of the reference launch _Kval_Basic / _Res_Basic / _Var_Basic once per term and re-read the
+ * item's whole basis table every time (21 launches for 3-D elasticity, 05_CodeGenerator.jl:52-154).  These entry points
+ * take the term list of one integration domain at once: the item's table is staged in LDS once, terms that hit the same
+ * sparse block / dual field are summed in registers before the single accumulate into K / residue.  Semantics are the
+ * sum of the corresponding single-term calls (to round-off: the summation order over terms differs).
+ * Term arrays are [host]; `vals` / `targets` are term-major: term t at + t * itg * n_threads. */
+#define MFEM_MAX_BATCH_TERMS 48
+typedef struct {
+  int32_t dual_sd, base_sd; /* flat derivative ids of the dual / base word */
+  int32_t block;            /* sparse block u = sparse_mapping[(dual_pos, base_pos)]; terms must be sorted by block */
+  int32_t reserved;
+} mfem_kval_term;
+/* slot(a, b, el; u) = sparse_IDs_by_el[u * slot_block_stride + a + itp*(b + itp*el)] + u * sparse_ID_shift_unit */
+int mfem_op_kval_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
+                       const mfem_kval_term* terms, const double* vals, const int32_t* sparse_IDs_by_el,
+                       int64_t slot_block_stride, int64_t sparse_ID_shift_unit, double* K_val, const int32_t* itg_hostIDs,
+                       const int32_t* elIDs, int64_t n_threads);
+typedef struct {
+  int32_t dual_sd, reserved;
+  int64_t cpID_shift;       /* dual_pos * variable_size; terms must be sorted by cpID_shift */
+} mfem_res_term;
+int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
+                      const mfem_res_term* terms, const double* vals, const int32_t* el_g_cpIDs, double* residue,
+                      const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads);
+typedef struct {
+  int32_t sd, reserved;
+  int64_t cpID_shift;
+  const double* x;          /* [device] source vector of this word (x_star, or a control-point array for externals) */
+} mfem_var_term;
+/* targets[t][q, item] = sum_a N[q,a,sd_t,host] x_t[cp[a,el] + shift_t]   (OVERWRITES: the reference passes fresh zeros) */
+int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
+                      const mfem_var_term* terms, const int32_t* el_g_cpIDs, double* targets, const int32_t* itg_hostIDs,
+                      const int32_t* elIDs, int64_t n_threads);
+
 /* ---- multi-GPU (new; the reference is single-GPU, F6) ------------------------------------ */
 /* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by the host
  * (torch.distributed / MPI / a file).  */

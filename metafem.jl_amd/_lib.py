@@ -54,6 +54,21 @@ class ElasticityParams(C.Structure):
                 ("traction_faces", c_uint32), ("sig", c_double * 6)]
 
 
+class KvalTerm(C.Structure):
+    _fields_ = [("dual_sd", c_int32), ("base_sd", c_int32), ("block", c_int32), ("reserved", c_int32)]
+
+
+class ResBatchTerm(C.Structure):
+    _fields_ = [("dual_sd", c_int32), ("reserved", c_int32), ("cpID_shift", c_int64)]
+
+
+class VarBatchTerm(C.Structure):
+    _fields_ = [("sd", c_int32), ("reserved", c_int32), ("cpID_shift", c_int64), ("x", C.c_void_p)]
+
+
+MAX_BATCH_TERMS = 48
+
+
 class OpLayout(C.Structure):
     _fields_ = [("itg", c_int32), ("itp", c_int32), ("n_sd", c_int32), ("n_host", c_int64), ("index_base", c_int32),
                 ("n_colours", c_int32), ("colour_offsets", C.POINTER(c_int64))]
@@ -109,6 +124,9 @@ SIGNATURES = {
     "mfem_op_var": (c_int, [P, C.POINTER(OpLayout), P, c_int32, c_int64, P, P, P, P, P, c_int64]),
     "mfem_op_kval": (c_int, [P, C.POINTER(OpLayout), P, c_int32, c_int32, P, P, c_int64, P, P, P, c_int64]),
     "mfem_op_res": (c_int, [P, C.POINTER(OpLayout), P, c_int32, P, c_int64, P, P, P, P, c_int64]),
+    "mfem_op_kval_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(KvalTerm), P, P, c_int64, c_int64, P, P, P, c_int64]),
+    "mfem_op_res_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(ResBatchTerm), P, P, P, P, P, c_int64]),
+    "mfem_op_var_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(VarBatchTerm), P, P, P, P, c_int64]),
     "mfem_comm_unique_id": (c_int, [P]),
     "mfem_comm_create": (c_int, [P, c_int32, c_int32, P, C.POINTER(P)]),
     "mfem_comm_destroy": (c_int, [P]),

@@ -194,3 +194,218 @@ extern "C" int mfem_op_kval(mfem_context ctx, const mfem_op_layout* L, const dou
     return MFEM_OK;
   });
 }
+
+
+// =====================================================================================================
+// Batched operators: all terms of one integration domain in one launch (see include/metafem_mi355x.h).
+// =====================================================================================================
+struct KvalTerms {
+  int n;
+  mfem_kval_term t[MFEM_MAX_BATCH_TERMS];
+};
+struct ResTerms {
+  int n;
+  mfem_res_term t[MFEM_MAX_BATCH_TERMS];
+};
+struct VarTerms {
+  int n;
+  mfem_var_term t[MFEM_MAX_BATCH_TERMS];
+};
+
+// WPI waves per item (1, 2 or 4: large elements spread their itp^2 pairs over several waves that share one LDS copy of the
+// table).  LDS per item: the item's whole table [itg, itp, n_sd] + vals of all terms [itg, n_terms].
+template <bool ATOMIC>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_op_kval_batch(OpView V, KvalTerms T, int wpi, const double* __restrict__ vals,
+                                                                int64_t term_stride, const int32_t* __restrict__ slots,
+                                                                int64_t block_stride, int64_t shift_unit, double* __restrict__ K,
+                                                                const int32_t* __restrict__ host_ids,
+                                                                const int32_t* __restrict__ el_ids, int64_t t0, int64_t t1) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ipw = (blockDim.x >> 6) / wpi;  // items per workgroup
+  const int item = w / wpi, sub = w - item * wpi;
+  const int sz = V.itg * V.itp;
+  double* N = lds + (size_t)item * ((size_t)V.n_sd * sz + (size_t)T.n * V.itg);
+  double* vq = N + (size_t)V.n_sd * sz;
+  const int64_t t = t0 + (int64_t)blockIdx.x * ipw + item;
+  const bool valid = t < t1;
+  int64_t el = 0;
+  if (valid) {
+    el = (int64_t)el_ids[t] - V.base;
+    const int64_t host = (int64_t)host_ids[t] - V.base;
+    const double* g = slab(V, 0, host);
+    for (int i = sub * 64 + lane; i < V.n_sd * sz; i += 64 * wpi) N[i] = g[i];
+    for (int i = sub * 64 + lane; i < T.n * V.itg; i += 64 * wpi) {
+      const int term = i / V.itg, q = i - term * V.itg;
+      vq[i] = vals[term * term_stride + q + (int64_t)V.itg * t];
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  const int npair = V.itp * V.itp;
+  for (int p = sub * 64 + lane; p < npair; p += 64 * wpi) {
+    const int a = p % V.itp, b = p / V.itp;
+    int i = 0;
+    while (i < T.n) {  // runs of terms with the same block: one accumulate per run
+      const int block = T.t[i].block;
+      double sum = 0.0;
+      for (; i < T.n && T.t[i].block == block; ++i) {
+        const double* Nd = N + (size_t)T.t[i].dual_sd * sz + V.itg * a;
+        const double* Nb = N + (size_t)T.t[i].base_sd * sz + V.itg * b;
+        const double* v = vq + i * V.itg;
+        for (int q = 0; q < V.itg; ++q) sum += Nd[q] * Nb[q] * v[q];
+      }
+      double* dst = K + ((int64_t)slots[block * block_stride + (int64_t)npair * el + p] + block * shift_unit - V.base);
+      if (ATOMIC) atomicAdd(dst, sum); else *dst += sum;
+    }
+  }
+}
+
+// GROUP lanes per item, lane -> a; terms with the same cpID_shift (dual field) are summed before the accumulate.
+template <int GROUP, bool ATOMIC>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_op_res_batch(OpView V, ResTerms T, const double* __restrict__ vals, int64_t term_stride,
+                                                               const int32_t* __restrict__ cp, double* __restrict__ residue,
+                                                               const int32_t* __restrict__ host_ids,
+                                                               const int32_t* __restrict__ el_ids, int64_t t0, int64_t t1) {
+  const int g = threadIdx.x % GROUP;
+  const int64_t t = t0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+  if (t >= t1) return;
+  const int64_t el = (int64_t)el_ids[t] - V.base, host = (int64_t)host_ids[t] - V.base;
+  for (int a = g; a < V.itp; a += GROUP) {
+    const int64_t node = (int64_t)cp[a + (int64_t)V.itp * el] - V.base;
+    int i = 0;
+    while (i < T.n) {
+      const int64_t shift = T.t[i].cpID_shift;
+      double acc = 0.0;
+      for (; i < T.n && T.t[i].cpID_shift == shift; ++i) {
+        const double* Ns = slab(V, T.t[i].dual_sd, host) + V.itg * a;
+        const double* v = vals + i * term_stride + (int64_t)V.itg * t;
+        for (int q = 0; q < V.itg; ++q) acc += Ns[q] * v[q];
+      }
+      double* dst = residue + node + shift;
+      if (ATOMIC) atomicAdd(dst, acc); else *dst += acc;
+    }
+  }
+}
+
+// GROUP lanes per item, lane -> q; every term writes its own target array.
+template <int GROUP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_op_var_batch(OpView V, VarTerms T, const int32_t* __restrict__ cp,
+                                                               double* __restrict__ targets, int64_t term_stride,
+                                                               const int32_t* __restrict__ host_ids,
+                                                               const int32_t* __restrict__ el_ids, int64_t n) {
+  const int g = threadIdx.x % GROUP;
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+  if (t >= n) return;
+  const int64_t el = (int64_t)el_ids[t] - V.base, host = (int64_t)host_ids[t] - V.base;
+  const int32_t* cpe = cp + (int64_t)V.itp * el;
+  for (int i = 0; i < T.n; ++i) {
+    const double* Ns = slab(V, T.t[i].sd, host);
+    const double* x = T.t[i].x + T.t[i].cpID_shift - V.base;
+    for (int q = g; q < V.itg; q += GROUP) {
+      double acc = 0.0;
+      for (int a = 0; a < V.itp; ++a) acc += Ns[q + V.itg * a] * x[cpe[a]];
+      targets[i * term_stride + q + (int64_t)V.itg * t] = acc;
+    }
+  }
+}
+
+extern "C" int mfem_op_kval_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
+                                  const mfem_kval_term* terms, const double* vals, const int32_t* sparse_IDs_by_el,
+                                  int64_t slot_block_stride, int64_t sparse_ID_shift_unit, double* K_val,
+                                  const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  int rc = check_layout(L);
+  if (rc) return rc;
+  if (n_threads == 0 || n_terms == 0) return MFEM_OK;
+  MFEM_REQUIRE(n_threads > 0 && n_terms > 0 && n_terms <= MFEM_MAX_BATCH_TERMS, "n_terms must be 1..MFEM_MAX_BATCH_TERMS");
+  MFEM_REQUIRE(terms && itp_vals && vals && sparse_IDs_by_el && K_val && itg_hostIDs && elIDs, "null array");
+  KvalTerms T;
+  T.n = n_terms;
+  for (int i = 0; i < n_terms; ++i) {
+    MFEM_REQUIRE(terms[i].dual_sd >= 0 && terms[i].dual_sd < L->n_sd && terms[i].base_sd >= 0 && terms[i].base_sd < L->n_sd, "sd out of range");
+    MFEM_REQUIRE(terms[i].block >= 0 && (i == 0 || terms[i].block >= terms[i - 1].block), "terms must be sorted by block");
+    T.t[i] = terms[i];
+  }
+  OpView V{L->itg, L->itp, L->n_sd, L->index_base, itp_vals};
+  const size_t per_item = sizeof(double) * ((size_t)L->n_sd * L->itg * L->itp + (size_t)n_terms * L->itg);
+  const int npair = L->itp * L->itp;
+  const int wpi = npair > 128 ? 4 : npair > 64 ? 2 : 1;  // waves per item
+  const int waves = 4, ipw = waves / wpi;
+  MFEM_REQUIRE(per_item * ipw <= 64 * 1024, "element table too large for the LDS-staged batched operator");
+  const size_t lds = per_item * ipw;
+  const int64_t term_stride = (int64_t)L->itg * n_threads;
+  const bool atomic = L->n_colours == 0;
+  return for_each_batch(L, n_threads, [&](int64_t a, int64_t b) -> int {
+    const int grid = (int)((b - a + ipw - 1) / ipw);
+    if (atomic)
+      hipLaunchKernelGGL(k_op_kval_batch<true>, dim3(grid), dim3(64 * waves), lds, ctx->stream, V, T, wpi, vals, term_stride,
+                         sparse_IDs_by_el, slot_block_stride, sparse_ID_shift_unit, K_val, itg_hostIDs, elIDs, a, b);
+    else
+      hipLaunchKernelGGL(k_op_kval_batch<false>, dim3(grid), dim3(64 * waves), lds, ctx->stream, V, T, wpi, vals, term_stride,
+                         sparse_IDs_by_el, slot_block_stride, sparse_ID_shift_unit, K_val, itg_hostIDs, elIDs, a, b);
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  });
+}
+
+extern "C" int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
+                                 const mfem_res_term* terms, const double* vals, const int32_t* el_g_cpIDs, double* residue,
+                                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  int rc = check_layout(L);
+  if (rc) return rc;
+  if (n_threads == 0 || n_terms == 0) return MFEM_OK;
+  MFEM_REQUIRE(n_threads > 0 && n_terms > 0 && n_terms <= MFEM_MAX_BATCH_TERMS, "n_terms must be 1..MFEM_MAX_BATCH_TERMS");
+  MFEM_REQUIRE(terms && itp_vals && vals && el_g_cpIDs && residue && itg_hostIDs && elIDs, "null array");
+  ResTerms T;
+  T.n = n_terms;
+  for (int i = 0; i < n_terms; ++i) {
+    MFEM_REQUIRE(terms[i].dual_sd >= 0 && terms[i].dual_sd < L->n_sd, "sd out of range");
+    MFEM_REQUIRE(i == 0 || terms[i].cpID_shift >= terms[i - 1].cpID_shift, "terms must be sorted by cpID_shift");
+    T.t[i] = terms[i];
+  }
+  OpView V{L->itg, L->itp, L->n_sd, L->index_base, itp_vals};
+  const int G = group_for(L->itp);
+  const int per_block = MFEM_BLOCK / G;
+  const int64_t term_stride = (int64_t)L->itg * n_threads;
+  const bool atomic = L->n_colours == 0;
+  return for_each_batch(L, n_threads, [&](int64_t a, int64_t b) -> int {
+    const int grid = (int)((b - a + per_block - 1) / per_block);
+#define LAUNCH_RESB(GG, AT) hipLaunchKernelGGL((k_op_res_batch<GG, AT>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, V, T, vals, \
+                                               term_stride, el_g_cpIDs, residue, itg_hostIDs, elIDs, a, b)
+    if (atomic) { if (G == 8) LAUNCH_RESB(8, true); else if (G == 16) LAUNCH_RESB(16, true); else if (G == 32) LAUNCH_RESB(32, true); else LAUNCH_RESB(64, true); }
+    else        { if (G == 8) LAUNCH_RESB(8, false); else if (G == 16) LAUNCH_RESB(16, false); else if (G == 32) LAUNCH_RESB(32, false); else LAUNCH_RESB(64, false); }
+#undef LAUNCH_RESB
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  });
+}
+
+extern "C" int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
+                                 const mfem_var_term* terms, const int32_t* el_g_cpIDs, double* targets,
+                                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  int rc = check_layout(L);
+  if (rc) return rc;
+  if (n_threads == 0 || n_terms == 0) return MFEM_OK;
+  MFEM_REQUIRE(n_threads > 0 && n_terms > 0 && n_terms <= MFEM_MAX_BATCH_TERMS, "n_terms must be 1..MFEM_MAX_BATCH_TERMS");
+  MFEM_REQUIRE(terms && itp_vals && el_g_cpIDs && targets && itg_hostIDs && elIDs, "null array");
+  VarTerms T;
+  T.n = n_terms;
+  for (int i = 0; i < n_terms; ++i) {
+    MFEM_REQUIRE(terms[i].sd >= 0 && terms[i].sd < L->n_sd && terms[i].x, "sd out of range or null x");
+    T.t[i] = terms[i];
+  }
+  OpView V{L->itg, L->itp, L->n_sd, L->index_base, itp_vals};
+  const int G = group_for(L->itg);
+  const int per_block = MFEM_BLOCK / G;
+  const int grid = (int)((n_threads + per_block - 1) / per_block);
+  const int64_t term_stride = (int64_t)L->itg * n_threads;
+#define LAUNCH_VARB(GG) hipLaunchKernelGGL(k_op_var_batch<GG>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, V, T, el_g_cpIDs, targets, \
+                                           term_stride, itg_hostIDs, elIDs, n_threads)
+  if (G == 8) LAUNCH_VARB(8); else if (G == 16) LAUNCH_VARB(16); else if (G == 32) LAUNCH_VARB(32); else LAUNCH_VARB(64);
+#undef LAUNCH_VARB
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}

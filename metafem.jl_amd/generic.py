@@ -70,12 +70,16 @@ class GenericDomain:
 
     def __init__(self, ctx, space, coords: np.ndarray, cp_ids: np.ndarray, n_fields: int, domain_wf: WeakForm,
                  boundaries: Sequence[Tuple[np.ndarray, np.ndarray, WeakForm]],
-                 element_colours: Optional[np.ndarray] = None, max_time_level: int = 0, dissipative: bool = True):
+                 element_colours: Optional[np.ndarray] = None, max_time_level: int = 0, dissipative: bool = True,
+                 batched: bool = True):
         """coords [ncp, dim]; cp_ids [itp, nel] 0-based (controlpoint_IDs in basis order); boundaries =
         [(element_ID[nf], element_eindex[nf] 0-based local face ids, WeakForm)].  element_colours (optional):
         a colour per element such that same-colour elements share no control point -> atomics-free scatter;
         without it the operators use FP64 atomics like the reference."""
         self.ctx, self.space, self.n_fields = ctx, space, n_fields
+        # batched = True: one mfem_op_*_batch launch per integration domain; False: one launch per term, the literal
+        # call sequence of the reference's generated updaters (kept for parity tests of the single-term seam)
+        self.batched = batched
         dev = f"cuda:{ctx.device}"
         self.dev = dev
         dim = space.dim
@@ -182,9 +186,56 @@ class GenericDomain:
         check(lib.mfem_op_res(self.ctx._h, C.byref(L), g.vals.data_ptr(), t.dual_s, vals.data_ptr(), t.dual_pos * self.ncp,
                               self.cp.data_ptr(), self.residue.data_ptr(), g.host_ids.data_ptr(), g.el_ids.data_ptr(), g.n))
 
+    # -- batched operator wrappers (mfem_op_*_batch): all terms of one integration domain per launch ------------------
+    def _var_many(self, g: _Group, words) -> List[torch.Tensor]:
+        """words: [(sd, shift, x tensor)] -> list of [n_items, itg] tensors."""
+        out: List[torch.Tensor] = []
+        L, _k = self._layout(g, False)
+        for c0 in range(0, len(words), _lib.MAX_BATCH_TERMS):
+            chunk = words[c0:c0 + _lib.MAX_BATCH_TERMS]
+            tgt = torch.empty((len(chunk), g.n, g.itg), dtype=torch.float64, device=self.dev)
+            terms = (_lib.VarBatchTerm * len(chunk))(*[_lib.VarBatchTerm(sd, 0, shift, x.data_ptr()) for sd, shift, x in chunk])
+            check(lib.mfem_op_var_batch(self.ctx._h, C.byref(L), g.vals.data_ptr(), len(chunk), terms, self.cp.data_ptr(),
+                                        tgt.data_ptr(), g.host_ids.data_ptr(), g.el_ids.data_ptr(), g.n))
+            out += [tgt[i] for i in range(len(chunk))]
+        return out
+
+    def _kval_many(self, g: _Group, terms, env, w, K: torch.Tensor):
+        """terms: GradTerms; coefficient tensors are evaluated here, stacked term-major, sorted by sparse block."""
+        if not terms:
+            return
+        order = sorted(range(len(terms)), key=lambda i: terms[i].dual_pos * self.n_fields + terms[i].base_pos)
+        L, _k = self._layout(g, True)
+        stride = self.nel * self.itp * self.itp
+        for c0 in range(0, len(order), _lib.MAX_BATCH_TERMS):
+            ids = order[c0:c0 + _lib.MAX_BATCH_TERMS]
+            vals = torch.stack([self._vals(terms[i].fn, env, w, self.K_params[terms[i].td_order]) for i in ids])
+            arr = (_lib.KvalTerm * len(ids))(*[_lib.KvalTerm(terms[i].dual_s, terms[i].base_s,
+                                                             terms[i].dual_pos * self.n_fields + terms[i].base_pos, 0) for i in ids])
+            check(lib.mfem_op_kval_batch(self.ctx._h, C.byref(L), g.vals.data_ptr(), len(ids), arr, vals.data_ptr(),
+                                         self.slots.data_ptr(), stride, 0, K.data_ptr(), g.host_ids.data_ptr(),
+                                         g.el_ids.data_ptr(), g.n))
+
+    def _res_many(self, g: _Group, terms, env, w):
+        if not terms:
+            return
+        order = sorted(range(len(terms)), key=lambda i: terms[i].dual_pos)
+        L, _k = self._layout(g, True)
+        for c0 in range(0, len(order), _lib.MAX_BATCH_TERMS):
+            ids = order[c0:c0 + _lib.MAX_BATCH_TERMS]
+            vals = torch.stack([self._vals(terms[i].fn, env, w) for i in ids])
+            arr = (_lib.ResBatchTerm * len(ids))(*[_lib.ResBatchTerm(terms[i].dual_s, 0, terms[i].dual_pos * self.ncp) for i in ids])
+            check(lib.mfem_op_res_batch(self.ctx._h, C.byref(L), g.vals.data_ptr(), len(ids), arr, vals.data_ptr(),
+                                        self.cp.data_ptr(), self.residue.data_ptr(), g.host_ids.data_ptr(), g.el_ids.data_ptr(), g.n))
+
     def _externals(self, wf: WeakForm, g: _Group, env: dict):
-        for name, sym, s in wf.cp_ext_vars:  # declare_Extervar_GPU (05_CodeGenerator.jl:15-50)
-            env[name] = self._var(g, s, 0, self.controlpoints[sym])
+        if self.batched and wf.cp_ext_vars:
+            tg = self._var_many(g, [(s, 0, self.controlpoints[sym]) for _, sym, s in wf.cp_ext_vars])
+            for (name, _, _), t in zip(wf.cp_ext_vars, tg):
+                env[name] = t
+        else:
+            for name, sym, s in wf.cp_ext_vars:  # declare_Extervar_GPU (05_CodeGenerator.jl:15-50)
+                env[name] = self._var(g, s, 0, self.controlpoints[sym])
         for name, comp in wf.normals:
             env[name] = g.normals[:, comp, :][(g.host_ids - 1).long()]
         env["t"], env["dt"] = self.t, self.dt
@@ -209,6 +260,9 @@ class GenericDomain:
             env: dict = {}
             self._externals(wf, g, env)
             w = self._w(g)
+            if self.batched:
+                self._kval_many(g, wf.linear_gradients, env, w, self.K_linear)
+                continue
             for t in wf.linear_gradients:
                 self._kval(g, t, self._vals(t.fn, env, w, self.K_params[t.td_order]), self.K_linear)
 
@@ -217,6 +271,15 @@ class GenericDomain:
         self.K_total.copy_(self.K_linear)  # 05_CodeGenerator.jl:282-283
         for wf, g in self._parts():
             env: dict = {}
+            if self.batched:
+                tg = self._var_many(g, [(s, td * self.basicfield_size + pos * self.ncp, self.x_star) for _, pos, s, td in wf.inner_vars])
+                for (name, _, _, _), t in zip(wf.inner_vars, tg):
+                    env[name] = t
+                self._externals(wf, g, env)
+                w = self._w(g)
+                self._res_many(g, wf.residues, env, w)
+                self._kval_many(g, wf.nonlinear_gradients, env, w, self.K_total)
+                continue
             for name, pos, s, td in wf.inner_vars:  # declare_Innervar_GPU (:1-13)
                 env[name] = self._var(g, s, td * self.basicfield_size + pos * self.ncp, self.x_star)
             self._externals(wf, g, env)

@@ -284,3 +284,58 @@ def test_elastodynamics_two_time_levels_matches_oracle(mf):
             ref = od.x[lvl * n:(lvl + 1) * n]
             assert np.abs(got[lvl * n:(lvl + 1) * n] - ref).max() <= 1e-7 * np.abs(ref).max(), (step, lvl)
     assert np.abs(od.x[:n]).max() > 1e-6
+
+
+@pytest.mark.parametrize("case", ["cavity", "cantilever", "thermal_hex8_coloured"])
+def test_batched_operators_equal_the_per_term_call_sequence(mf, case):
+    """mfem_op_{var,kval,res}_batch (one launch per integration domain) against the reference's one-launch-per-term
+    sequence through mfem_op_{var,kval,res}: same K_linear, K_total and residue to round-off (the order in which the terms
+    of a block are summed differs)."""
+    import torch
+    from oracle import cantilever as cl, cavity, fem, mesh as om, problems, reference_element as re_
+
+    colours = None
+    if case == "cavity":
+        od = cavity.build_cavity(8, Cb=8.0)
+        od.controlpoints["u1"], od.controlpoints["u2"] = np.zeros(od.mesh.ncp), np.zeros(od.mesh.ncp)
+        cavity.set_step_parameters(od, 0.3)
+        args = ("Serendipity", 2, 5)
+    elif case == "cantilever":
+        od = cl.build_cantilever(ne_x=6, e_number=2)
+        cl.set_load(od, 3)
+        args = ("Serendipity", 2, 5)
+    else:
+        disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+        n = (5, 4, 3)
+        msh = om.lattice_mesh((1.0, 0.8, 0.6), n, disc)
+        fac = om.boundary_facets_structured((1.0, 0.8, 0.6), n, 3)
+        od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6, alpha=2.0, Tenv=300.0), [(fac, problems.thermal_convection(25.0, 293.15, 0.7, 5.669e-8))])
+        od.controlpoints["s"] = 1600.0 * (1.0 + msh.coords[:, 1])
+        eg = np.meshgrid(*[np.arange(k) for k in n], indexing="ij")
+        colours = ((eg[0] & 1) + 2 * (eg[1] & 1) + 4 * (eg[2] & 1)).ravel()
+        args = ("Lagrange", 1, 3)
+    doms = []
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal(od.x.size) * 0.1 + (300.0 if case == "thermal_hex8_coloured" else 0.0)
+    for batched in (True, False):
+        from metafem_jl_amd import element, generic as G
+
+        space = element.classical_space(od.disc.dim, *args)
+        bnd = [(f.element_ID, f.element_eindex, _to_product_wf(mf, wf)) for f, wf in od.boundaries]
+        gd = G.GenericDomain(mf.default_context(), space, od.mesh.coords, od.mesh.cp_ids, od.n_fields, _to_product_wf(mf, od.domain_wf), bnd,
+                             element_colours=colours, batched=batched)
+        for k, v in od.controlpoints.items():
+            gd.controlpoints[k] = torch.tensor(np.asarray(v, dtype=np.float64), device="cuda")
+        gd.dt = od.dt
+        gd.x.copy_(torch.tensor(x0, device="cuda"))
+        gd.update_Time()
+        gd.initialize_dx()
+        gd.K_linear_func()
+        gd.update_x_star()
+        gd.K_nonlinear_func()
+        doms.append(gd)
+    a, b = doms
+    for name in ("K_linear", "K_total", "residue"):
+        va, vb = getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()
+        assert np.abs(va).max() > 0
+        assert np.abs(va - vb).max() <= 1e-12 * np.abs(vb).max(), name

@@ -55,6 +55,22 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const int* __restrict
           if (MODE == 5) acc += x[(r0 & ~63) + lane + (cc.x & 1)] + x[(r0 & ~63) + 64 + lane + (cc.y & 1)];
         }
       }
+    } else if (MODE == 6) {
+      // CSR order, but a pair of consecutive columns is fetched with ONE 16-byte load (2/3 of the pairs of the stencil)
+      typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll 9
+      for (int it = 0; it < 27; it += 2) {
+        const int p = it * 64 + 2 * lane;
+        if (p + 1 < 1728) {
+          const int2 cc = *reinterpret_cast<const int2*>(c + p);
+          if (cc.y == cc.x + 1) {
+            const d2 v = *reinterpret_cast<const d2*>(x + cc.x);
+            acc += v.x + v.y;
+          } else {
+            acc += x[cc.x] + x[cc.y];
+          }
+        }
+      }
     } else if (MODE == 1) {
 #pragma unroll 9
       for (int s = 0; s < 27; ++s) acc += x[c[lane * 27 + s]];
@@ -84,7 +100,7 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(k_build, dim3(4096), dim3(256), 0, 0, N1, n, col);
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int mode = 0; mode < 6; ++mode) {
+  for (int mode = 0; mode < 7; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0));
       for (int t = 0; t < 10; ++t) {
@@ -94,6 +110,7 @@ int main(int argc, char** argv) {
         if (mode == 3) hipLaunchKernelGGL(k_gather<3>, dim3(grid), dim3(256), 0, 0, n, col, x, out);
         if (mode == 4) hipLaunchKernelGGL(k_gather<4>, dim3(grid), dim3(256), 0, 0, n, col, x, out);
         if (mode == 5) hipLaunchKernelGGL(k_gather<5>, dim3(grid), dim3(256), 0, 0, n, col, x, out);
+        if (mode == 6) hipLaunchKernelGGL(k_gather<6>, dim3(grid), dim3(256), 0, 0, n, col, x, out);
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
