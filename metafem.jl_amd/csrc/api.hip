@@ -72,6 +72,9 @@ extern "C" int mfem_context_destroy(mfem_context ctx) {
   }
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
+  if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph_ev) hipEventDestroy(ctx->graph_ev);
+  if (ctx->graph_stream) hipStreamDestroy(ctx->graph_stream);
   delete ctx;
   return MFEM_OK;
 }

@@ -62,6 +62,14 @@ struct mfem_context_s {
   hipEvent_t* prof_ev;      // [2 * MFEM_PROF_PAIRS]
   double prof_ms;
   int64_t prof_count;
+  // hipGraph replay of launch-bound Krylov cycles (krylov.h: mfem_cycle_run): one cached executable graph, keyed by a
+  // hash of everything its kernel arguments depend on; graph_stream stands in for the legacy null stream, which cannot
+  // be captured
+  hipGraphExec_t graph_exec;
+  uint64_t graph_key;
+  hipStream_t graph_stream;
+  hipEvent_t graph_ev;
+  int graph_active;   // set by mfem_solve for the duration of a solve when cycles may be captured
 };
 #define MFEM_PROF_PAIRS 1024
 int mfem_prof_flush(mfem_context_s* ctx);

@@ -34,3 +34,54 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
                    double tol, int64_t n_global, int* iters_out, int* spmv_out);
 int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V, const mfem_solve_options* o,
                    int s, double tol, int64_t n_global, int* iters_out, int* spmv_out);
+
+// ---- hipGraph replay of one solver cycle -------------------------------------------------------------------------
+// The Krylov drivers keep every recurrence scalar on the device and guard their kernels with the DONE flag, so the kernel
+// sequence of one cycle (an IDR(s) cycle of s + 1 steps, a BiCGStab(l) sweep, a CGS2 step, a CG iteration pair) has
+// constant arguments and no host dependency: it is captured once and replayed.  On small systems (the reference's
+// examples: 1e3 - 1e5 unknowns) a cycle is 10 - 200 kernels of a few microseconds each and the host launch rate, not
+// the GPU, sets the time per iteration.
+inline uint64_t mfem_hash_bytes(uint64_t h, const void* data, size_t bytes) {  // FNV-1a
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < bytes; ++i) h = (h ^ p[i]) * 1099511628211ull;
+  return h;
+}
+template <typename T>
+inline uint64_t mfem_hash(uint64_t h, const T& v) { return mfem_hash_bytes(h, &v, sizeof(T)); }
+#define MFEM_HASH_SEED 1469598103934665603ull
+
+template <class Body>
+inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
+  if (!ctx->graph_active) return body();
+  if (ctx->graph_exec && ctx->graph_key == key) {
+    MFEM_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    return MFEM_OK;
+  }
+  if (ctx->graph_exec) {
+    hipGraphExecDestroy(ctx->graph_exec);
+    ctx->graph_exec = nullptr;
+  }
+  MFEM_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (rc) {
+    if (g) hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess || !g) {
+    mfem_set_error("hipStreamEndCapture: %s", hipGetErrorString(e));
+    return MFEM_ERR_HIP;
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (ei != hipSuccess) {
+    mfem_set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
+    return MFEM_ERR_HIP;
+  }
+  ctx->graph_exec = exec;
+  ctx->graph_key = key;
+  MFEM_CHECK_HIP(hipGraphLaunch(exec, ctx->stream));
+  return MFEM_OK;
+}

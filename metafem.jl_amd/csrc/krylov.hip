@@ -259,6 +259,10 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   }
   MFEM_CHECK_LAUNCH();
   const int check = o->check_every > 0 ? o->check_every : 32;
+  uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
+  key = mfem_hash(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
+  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int it = 0;
   for (;;) {
     if (!o->fixed_iterations || it == 0) {
@@ -268,16 +272,16 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     }
     const int burst = (o->maxiter - it) < check ? (o->maxiter - it) : check;
     if (burst <= 0) break;
-    for (int k = 0; k < burst; ++k, ++it) {
-      const int cur = it & 1;
+    auto iteration = [&](int it_) -> int {
+      const int cur = it_ & 1;
       int np1 = 0;
+      int rc = MFEM_OK;
       if (ctx->comm) {
         rc = mfem_comm_halo(ctx, p);
         if (rc) return rc;
       }
       rc = mfem_spmv_launch(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1, F);
       if (rc) return rc;
-      ++*spmv_out;
       int np2 = G;
       if (ctx->comm) {
         rc = mfem_sum_partials(ctx, part1, np1, S + S_PAP);
@@ -304,6 +308,23 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
                          (const d2_t*)dinv, (d2_t*)p, S, F);
       hipLaunchKernelGGL(k_cg_advance, dim3(1), dim3(1), 0, ctx->stream, a, S, F);
       MFEM_CHECK_LAUNCH();
+      return MFEM_OK;
+    };
+    // iterations alternate between two scalar slots (cur = it & 1): an even/odd PAIR has constant arguments and is the
+    // unit that is captured and replayed (mfem_cycle_run); a trailing odd iteration is launched directly
+    int k = 0;
+    for (; k + 2 <= burst && (it & 1) == 0; k += 2, it += 2) {
+      rc = mfem_cycle_run(ctx, key, [&]() -> int {
+        int r2 = iteration(0);
+        return r2 ? r2 : iteration(1);
+      });
+      if (rc) return rc;
+      *spmv_out += 2;
+    }
+    for (; k < burst; ++k, ++it) {
+      rc = iteration(it);
+      if (rc) return rc;
+      ++*spmv_out;
     }
   }
   rc = mfem_read_flags(ctx);
@@ -325,9 +346,48 @@ extern "C" int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+static int g_graphs = 1;             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
+static int64_t g_graph_max_n = 4000000;  // above this size kernels are long enough that launch latency is hidden anyway
+extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) {
+  g_graphs = on ? 1 : 0;
+  if (max_n > 0) g_graph_max_n = max_n;
+  return MFEM_OK;
+}
+
+static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
+                       const mfem_solve_options* o, mfem_solve_stats* stats);
+
 extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
                           const mfem_solve_options* o, mfem_solve_stats* stats) {
   MFEM_REQUIRE(ctx && A && o, "null argument");
+  // Cycle graphs: not with a communicator (RCCL calls inside the cycle), not while per-launch SpMV timing is on (event
+  // records inside the cycle), not in benchmark mode on large systems.  The legacy null stream cannot be captured: the
+  // solve then runs on a private stream, ordered after / before the caller's stream work through events.
+  const bool graphs = g_graphs && !ctx->comm && !ctx->prof_on && A->n > 0 && A->n <= g_graph_max_n;
+  if (!graphs) return solve_inner(ctx, A, vals, b, x_out, o, stats);
+  hipStream_t user = ctx->stream;
+  if (user == nullptr) {
+    if (!ctx->graph_stream) {
+      MFEM_CHECK_HIP(hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking));
+      MFEM_CHECK_HIP(hipEventCreateWithFlags(&ctx->graph_ev, hipEventDisableTiming));
+    }
+    MFEM_CHECK_HIP(hipEventRecord(ctx->graph_ev, user));
+    MFEM_CHECK_HIP(hipStreamWaitEvent(ctx->graph_stream, ctx->graph_ev, 0));
+    ctx->stream = ctx->graph_stream;
+  }
+  ctx->graph_active = 1;
+  const int rc = solve_inner(ctx, A, vals, b, x_out, o, stats);
+  ctx->graph_active = 0;
+  if (user == nullptr) {
+    hipEventRecord(ctx->graph_ev, ctx->graph_stream);
+    hipStreamWaitEvent(user, ctx->graph_ev, 0);
+    ctx->stream = user;
+  }
+  return rc;
+}
+
+static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
+                       const mfem_solve_options* o, mfem_solve_stats* stats) {
   MFEM_REQUIRE(A->n == 0 || (vals && b && x_out), "null array");
   MFEM_REQUIRE(o->maxiter >= 0 && o->max_pass >= 1, "maxiter >= 0 and max_pass >= 1 required");
   MFEM_REQUIRE(o->method >= MFEM_SOLVER_CG && o->method <= MFEM_SOLVER_CGS2, "unknown method");

@@ -132,18 +132,24 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
   int sweeps_since_poll = 0;
   RC(mfem_read_flags(ctx));
   int host_iter = 1;
-  while (!ctx->h_flags[F_DONE]) {
+  uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_BICGSTABL_GS);
+  key = mfem_hash(key, l); key = mfem_hash(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
+  key = mfem_hash(key, V.x); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
+  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
+  int dummy_spmv = 0;
+  int* const spmv_cnt = &dummy_spmv;
+  auto sweep = [&]() -> int {  // one BiCGStab(l) sweep: 2 l SpMVs, constant kernel arguments
     K1(kb_sweep_begin, S, F);
     // ---- BiCG part (:43-62)
     for (int j = 0; j < l; ++j) {
       RC(k.dot1(shadow, R[j], B_DOT));
       K1(kb_beta, S, F);
       for (int i = 0; i <= j; ++i) RC(k.lin2(coef_imm(1.0), R[i], coef_dev(B_BETA, -1.0), U[i], U[i]));  // U[i] = R[i] - beta U[i]
-      RC(k.spmv(A, vals, U[j], U[j + 1], spmv_out));
+      RC(k.spmv(A, vals, U[j], U[j + 1], spmv_cnt));
       RC(k.dot1(shadow, U[j + 1], B_DOT));
       K1(kb_alpha, S, F);
       for (int i = 0; i <= j; ++i) RC(k.axpby(coef_dev(B_ALPHA, -1.0), U[i + 1], coef_imm(1.0), R[i]));  // R[i] -= alpha U[i+1]
-      RC(k.spmv(A, vals, R[j], R[j + 1], spmv_out));
+      RC(k.spmv(A, vals, R[j], R[j + 1], spmv_cnt));
       RC(k.axpby(coef_dev(B_ALPHA), U[0], coef_imm(1.0), V.x));  // x += alpha U[1]
     }
     // ---- MR part, modified Gram-Schmidt (:64-71)
@@ -172,6 +178,11 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
     }
     RC(k.dot1(R[0], R[0], B_DOT));
     K1(kb_sweep_end, a, S, F);
+    return MFEM_OK;
+  };
+  while (!ctx->h_flags[F_DONE]) {
+    RC(mfem_cycle_run(ctx, key, sweep));
+    *spmv_out += 2 * l;
     host_iter += l;
     if (++sweeps_since_poll * l >= check || host_iter >= o->maxiter) {
       RC(mfem_read_flags(ctx));

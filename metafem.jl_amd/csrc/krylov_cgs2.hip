@@ -106,7 +106,13 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   const int check = o->check_every > 0 ? o->check_every : 32;
   int since = 0, host_iter = 1;
   RC(mfem_read_flags(ctx));
-  while (!ctx->h_flags[F_DONE]) {
+  uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CGS2);
+  key = mfem_hash(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, V.b); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
+  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
+  int dummy_spmv = 0;
+  int* const spmv_cnt = &dummy_spmv;
+  auto step = [&]() -> int {  // one CGS2 step: 2 SpMVs + the true-residual SpMV, constant kernel arguments
     DotList L;
     L.m = 2;
     L.x[0] = (const d2_t*)r; L.y[0] = (const d2_t*)r0;
@@ -116,7 +122,7 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
     hipLaunchKernelGGL(kc_half1, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, (const d2_t*)r, (const d2_t*)u,
                        (const d2_t*)s, (d2_t*)v, (d2_t*)t, (d2_t*)w, S, F);
     MFEM_CHECK_LAUNCH();
-    RC(k.spmv(A, vals, w, c, spmv_out));
+    RC(k.spmv(A, vals, w, c, spmv_cnt));
     L.x[0] = (const d2_t*)c; L.y[0] = (const d2_t*)r0;
     L.x[1] = (const d2_t*)c; L.y[1] = (const d2_t*)s0;
     RC(k.dots(L, C_DOT));
@@ -127,8 +133,12 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
     // r = b - A x (:96-98).  The kernels below are not DONE-guarded, which is harmless: once DONE is set x no longer
     // changes, so they recompute the same r.
     RC(mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR));
-    ++*spmv_out;
     K1(kc_end, a, S, F);
+    return MFEM_OK;
+  };
+  while (!ctx->h_flags[F_DONE]) {
+    RC(mfem_cycle_run(ctx, key, step));
+    *spmv_out += 2;
     ++host_iter;
     if (++since >= check || host_iter > o->maxiter) {
       RC(mfem_read_flags(ctx));

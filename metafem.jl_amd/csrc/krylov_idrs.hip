@@ -151,7 +151,13 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   const int check = o->check_every > 0 ? o->check_every : 32;
   int since_poll = 0, host_iter = 1;
   RC(mfem_read_flags(ctx));
-  while (!ctx->h_flags[F_DONE]) {
+  uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_IDRS);
+  key = mfem_hash(key, s); key = mfem_hash(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
+  key = mfem_hash(key, V.x); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
+  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
+  int dummy_spmv = 0;
+  // one IDR cycle = s steps in G_j + the step into G_j+1: s + 1 SpMVs, constant kernel arguments
+  auto cycle = [&](int* spmv_cnt) -> int {
     // f = P' r  (:43-45)
     for (int i0 = 0; i0 < s; i0 += KK_MAX_DOTS) {
       DotList L;
@@ -173,7 +179,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
       }
       hipLaunchKernelGGL(ki_combine, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, (const d2_t*)r, (d2_t*)U[kk], S, F);
       MFEM_CHECK_LAUNCH();
-      RC(k.spmv(A, vals, U[kk], G[kk], spmv_out));  // :59
+      RC(k.spmv(A, vals, U[kk], G[kk], spmv_cnt));  // :59
       for (int i = 0; i < kk; ++i) {                 // bi-orthogonalise (:62-66)
         RC(k.dot1(P[i], G[kk], I_DOT));
         K1(ki_alpha, i, S, F);
@@ -193,10 +199,9 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
       RC(k.axpy2(coef_dev(I_BETA), U[kk], V.x, coef_dev(I_BETA, -1.0), G[kk], r));  // :75-76
       RC(k.dot1(r, r, I_DOT));
       K1(ki_step_end, a, kk, S, F);
-      ++host_iter;
     }
     // r in G_j+1  (:85-93)
-    RC(k.spmv(A, vals, r, Ar, spmv_out));
+    RC(k.spmv(A, vals, r, Ar, spmv_cnt));
     DotList L;
     L.m = 3;
     L.x[0] = (const d2_t*)Ar; L.y[0] = (const d2_t*)Ar;
@@ -207,7 +212,12 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
     RC(k.axpy2(coef_dev(I_OMEGA), r, V.x, coef_dev(I_OMEGA, -1.0), Ar, r));  // x += omega r ; r -= omega Ar
     RC(k.dot1(r, r, I_DOT));
     K1(ki_step_end, a, -1, S, F);
-    ++host_iter;
+    return MFEM_OK;
+  };
+  while (!ctx->h_flags[F_DONE]) {
+    RC(mfem_cycle_run(ctx, key, [&]() -> int { return cycle(&dummy_spmv); }));
+    *spmv_out += s + 1;
+    host_iter += s + 1;
     since_poll += s + 1;
     if (since_poll >= check || host_iter >= o->maxiter) {
       RC(mfem_read_flags(ctx));
