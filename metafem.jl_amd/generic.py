@@ -74,8 +74,9 @@ class GenericDomain:
                  batched: bool = True):
         """coords [ncp, dim]; cp_ids [itp, nel] 0-based (controlpoint_IDs in basis order); boundaries =
         [(element_ID[nf], element_eindex[nf] 0-based local face ids, WeakForm)].  element_colours (optional):
-        a colour per element such that same-colour elements share no control point -> atomics-free scatter;
-        without it the operators use FP64 atomics like the reference."""
+        a colour per element such that same-colour elements share no control point -> atomics-free scatter with a fixed
+        summation order; "auto" computes one with mesh.colour_Elements (elements and boundary facets); without it the
+        operators use FP64 atomics like the reference (order of the additions, hence the last bits, not reproducible)."""
         self.ctx, self.space, self.n_fields = ctx, space, n_fields
         # batched = True: one mfem_op_*_batch launch per integration domain; False: one launch per term, the literal
         # call sequence of the reference's generated updaters (kept for parity tests of the single-term seam)
@@ -99,6 +100,13 @@ class GenericDomain:
         w = torch.empty(space.itg * nel, dtype=torch.float64, device=dev)
         check(lib.mfem_update_basic_elements(ctx._h, dim, space.itg, itp, nel, ncp, ref.data_ptr(), f64(space.itg_weight).data_ptr(),
                                              self.coords.data_ptr(), self.cp.data_ptr(), 1, vals.data_ptr(), w.data_ptr()))
+        auto_colours = isinstance(element_colours, str)
+        if auto_colours:
+            if element_colours != "auto":
+                raise ValueError("element_colours: an array, None or 'auto'")
+            from .mesh import colour_Elements
+
+            element_colours = colour_Elements(cp_ids)
         if element_colours is not None:
             order = np.argsort(element_colours, kind="stable")
             offs = np.concatenate([[0], np.cumsum(np.bincount(element_colours, minlength=int(element_colours.max()) + 1))])
@@ -119,6 +127,16 @@ class GenericDomain:
             check(lib.mfem_update_basic_boundary(ctx._h, dim, space.itg_b, itp, nface, nf, ncp, bref.data_ptr(), bw.data_ptr(),
                                                  btan.data_ptr(), self.coords.data_ptr(), self.cp.data_ptr(), eld.data_ptr(),
                                                  eid.data_ptr(), 1, fv.data_ptr(), fw.data_ptr(), fn.data_ptr()))
+            if auto_colours and nf > 0:
+                # boundary operators touch every node of the host element (05_CodeGenerator.jl:175-189): colour the facets
+                # by their hosts' node sets (two facets of one element conflict automatically)
+                fcol = colour_Elements(cp_ids[:, np.asarray(el)])
+                forder = np.argsort(fcol, kind="stable")
+                foffs = np.concatenate([[0], np.cumsum(np.bincount(fcol, minlength=int(fcol.max()) + 1))])
+                host = i32(forder + 1)
+                self.groups.append(_Group(fv, fw, host, i32(np.asarray(el)[forder] + 1), space.itg_b,
+                                          normals=fn.view(nf, dim, space.itg_b), colour_offsets=foffs))
+                continue
             host = i32(np.arange(nf) + 1)
             self.groups.append(_Group(fv, fw, host, eld, space.itg_b, normals=fn.view(nf, dim, space.itg_b)))
         # ---- assemble_Global_Variables!

@@ -289,3 +289,34 @@ def get_BoundaryMesh(mesh: ClassicalMesh) -> Facets:
     cen = mesh.coords[K[single]].mean(axis=1)
     order = np.lexsort((fi, el))
     return Facets(el[order], fi[order], cen[order])
+
+
+# ---- colouring -------------------------------------------------------------------------------------------------------
+def colour_Elements(cp_ids: np.ndarray, seed: int = 0x5EED) -> np.ndarray:
+    """Greedy element colouring of an unstructured mesh: elements of one colour share no control point, so the S3 operators
+    (and any scatter into K / residue) can accumulate without atomics and with a fixed summation order -- the
+    colour-partitioned ordering of SURVEY.md §8 (b) for meshes without lattice structure (structured bricks use the
+    closed-form parity colouring).  Each colour is a MAXIMAL independent set grown by rounds of random-priority
+    selection (an element joins when it holds the highest priority at every one of its nodes), all elements at once.
+    Returns colour[nel] (int64, 0-based, colours in order of creation)."""
+    itp, nel = cp_ids.shape
+    ncp = int(cp_ids.max()) + 1
+    prio = np.random.default_rng(seed).permutation(nel).astype(np.int64)
+    colour = np.full(nel, -1, dtype=np.int64)
+    c = 0
+    while (colour < 0).any():
+        blocked = np.zeros(ncp, dtype=bool)
+        avail = colour < 0
+        while True:
+            cand = avail & ~blocked[cp_ids].any(axis=0)
+            ids = np.nonzero(cand)[0]
+            if ids.size == 0:
+                break
+            nodemax = np.full(ncp, -1, dtype=np.int64)
+            np.maximum.at(nodemax, cp_ids[:, ids].ravel(), np.tile(prio[ids], itp))
+            sel = ids[(nodemax[cp_ids[:, ids]] == prio[ids][None, :]).all(axis=0)]
+            colour[sel] = c
+            blocked[cp_ids[:, sel].ravel()] = True
+            avail[sel] = False
+        c += 1
+    return colour

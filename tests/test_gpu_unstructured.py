@@ -108,3 +108,31 @@ def test_tet10_thermal_on_gpu_reproduces_reference_vtk(mf):
         assert torch.all(cur >= prev - 1e-9) and float(cur.max()) < float(gd.x.max())
         prev = cur.clone()
     assert float(prev.max()) > T0 + 0.5
+
+
+def test_auto_colouring_gives_bitwise_reproducible_assembly_equal_to_atomics(mf):
+    """mesh.colour_Elements on the tetrahedral example mesh (50 colours): coloured accumulation is identical run to run and
+    agrees with the FP64-atomics accumulation of the same operators to round-off."""
+    import torch
+    from metafem_jl_amd import element, generic as G, mesh as pm
+    from oracle import problems
+
+    z = np.load(os.path.join(GOLD, "pikachu_tet10.npz"))
+    space = element.classical_space(3, "Serendipity", 2, 5, shape="SIMPLEX")
+    msh = pm.mesh_Classical(z["vert"] / 100.0, z["conn"].astype(np.int64), space)
+    fac = pm.get_BoundaryMesh(msh)
+    out = {}
+    for mode in ("auto", "auto", None):
+        gd = G.GenericDomain(mf.default_context(), space, msh.coords, msh.cp_ids, 1, _wf(problems.thermal_domain(3, 0.6, alpha=3.0, Tenv=290.0)),
+                             [(fac.element_ID, fac.element_eindex, _wf(problems.thermal_convection(25.0, 293.15, 0.7, 5.669e-8)))],
+                             element_colours=mode)
+        gd.controlpoints["s"] = torch.full((msh.ncp,), 1600.0, dtype=torch.float64, device="cuda")
+        gd.x.copy_(torch.tensor(300.0 + 5.0 * np.sin(40.0 * msh.coords[:, 0]), device="cuda"))
+        gd.update_Time(); gd.initialize_dx(); gd.K_linear_func(); gd.update_x_star(); gd.K_nonlinear_func()
+        out.setdefault(mode, []).append((gd.K_total.cpu().numpy(), gd.residue.cpu().numpy()))
+        if mode == "auto":
+            assert gd.groups[0].colour_offsets is not None and gd.groups[1].colour_offsets is not None
+    (K1, R1), (K2, R2) = out["auto"]
+    assert np.array_equal(K1, K2) and np.array_equal(R1, R2)
+    Ka, Ra = out[None][0]
+    assert np.abs(K1 - Ka).max() <= 1e-13 * np.abs(Ka).max() and np.abs(R1 - Ra).max() <= 1e-12 * np.abs(Ra).max()

@@ -171,3 +171,20 @@ def test_write_vtk_layout_and_node_order(tmp_path, shape, dim, itp_type, order):
         for k, (a, b) in enumerate(VTK_EDGES[cell_type]):
             mid = 0.5 * (msh.coords[cells[:, 1 + a]] + msh.coords[cells[:, 1 + b]])
             assert np.allclose(msh.coords[cells[:, 1 + ncorner + k]], mid, atol=1e-13)
+
+
+@pytest.mark.parametrize("shape,dim,itp_type,order", [("CUBE", 3, "Serendipity", 2), ("SIMPLEX", 3, "Serendipity", 2), ("CUBE", 2, "Lagrange", 2)])
+def test_element_colouring_is_conflict_free_and_compact(shape, dim, itp_type, order):
+    n = (6, 5) if dim == 2 else (4, 3, 3)
+    vert, conn = (pm.make_Square if dim == 2 else pm.make_Brick)((1.0,) * dim, n, shape)
+    space = element.classical_space(dim, itp_type, order, 5, shape=shape)
+    msh = pm.mesh_Classical(vert, conn, space)
+    col = pm.colour_Elements(msh.cp_ids)
+    assert col.min() == 0 and (col >= 0).all()
+    for c in range(col.max() + 1):
+        nodes = msh.cp_ids[:, col == c].ravel()
+        assert np.unique(nodes).size == nodes.size  # no control point twice within a colour
+    # a colour cannot be smaller than the largest number of elements around one node; greedy stays within 2x of that bound
+    deg = np.bincount(msh.cp_ids.ravel()).max()
+    assert deg <= col.max() + 1 <= 2 * deg + 2
+    assert np.array_equal(col, pm.colour_Elements(msh.cp_ids))  # seeded: reproducible
