@@ -94,6 +94,8 @@ int mfem_debug_set_hex27(int two_pass);
 
 /* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */
+/* Slot-major (ELL) copy of the working values inside mfem_solve for matrices with near-uniform rows (default on). */
+int mfem_debug_set_ell(int enable);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
  * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */

@@ -95,7 +95,20 @@ struct mfem_csr_s {
   int32_t* win_nlines;
   uint32_t* win_lines;
   uint16_t* win_idx;
+  // slot-major padded copy for near-uniform rows (spmv_ell.hip): ell_state 0 = not planned, -1 = not eligible, 1 = ready
+  int ell_state, ell_K;
+  int64_t ell_npad;
+  int32_t* ell_cols;        // owned, [K][npad], 0-based
+  const double* ell_src;    // the CSR-ordered values the bound copy mirrors (identity of the `vals` argument)
+  double* ell_vals;         // not owned (solver workspace), [K][npad]
 };
+int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
+size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
+int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);
+void mfem_ell_unbind(mfem_csr_s* A);
+void mfem_ell_free(mfem_csr_s* A);
+int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
+                         double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
 int mfem_spmv_window_plan(mfem_context_s* ctx, mfem_csr_s* A);
 void mfem_spmv_window_free(mfem_csr_s* A);
 int mfem_spmv_window_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,

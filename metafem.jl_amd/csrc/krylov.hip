@@ -260,7 +260,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   MFEM_CHECK_LAUNCH();
   const int check = o->check_every > 0 ? o->check_every : 32;
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
-  key = mfem_hash(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int it = 0;
@@ -415,7 +415,12 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const bool need_copy = ((jac && !is_cg) || left) && !o->scale_in_place;
   // workspace: x, b (padded copies), d, dinv (CG) / left scaling dl, work vectors, optional matrix copy
   const size_t vec_bytes = (size_t)nv * sizeof(double);
-  size_t total = vec_bytes * (4 + nwork) + (need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0);
+  // slot-major copy of the working values for near-uniform rows (spmv_ell.hip), made once per solve after the scaling
+  int rc_plan = mfem_ell_plan(ctx, A);
+  if (rc_plan) return rc_plan;
+  const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
+  const size_t ell_bytes = mfem_ell_vals_bytes(A);
+  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes;
   int rc = mfem_ws_reserve(ctx, total);
   if (rc) return rc;
   char* base = (char*)ctx->ws;
@@ -476,6 +481,16 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.b, dl, V.b);
     MFEM_CHECK_LAUNCH();
   }
+
+  // bind the slot-major copy: every mfem_spmv_launch(A, vals_work, ...) below runs the ELL kernel
+  if (ell_bytes) {
+    rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+    if (rc) return rc;
+  }
+  struct EllGuard {
+    mfem_csr_s* A;
+    ~EllGuard() { mfem_ell_unbind(A); }
+  } ell_guard{A};
 
   int64_t n_global = n;
   if (ctx->comm) {

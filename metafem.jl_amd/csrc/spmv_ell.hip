@@ -1,0 +1,228 @@
+// Inspector-executor SpMV for matrices whose rows have (nearly) the same length -- every matrix the structured assembly
+// produces (27 entries per row for hex-8 thermal, 81 for 3-field elasticity, fewer only on the boundary).
+//
+// The caller's contract is unchanged: CSR pattern + values in CSR order (`mul!(b, A, x)`, 04_GPU_Utils.jl:131).  The
+// reference's own linear solver starts every solve with a gather copy of the values (K_total[K_val_ids],
+// 02_Preconditioner.jl:35); here that one pass per solve transposes the (already preconditioner-scaled) values into a
+// slot-major padded layout  ell_vals[s][row]  next to a column table  ell_cols[s][row]  built once per pattern.
+// In the Krylov loop lane <-> row, the slot loop runs in registers:
+//   * the value / column streams are unit-stride across the lanes of a wave (512-byte and 256-byte runs), no LDS
+//     staging, no workgroup barrier, no cross-lane reduction;
+//   * the gather x[col] of one slot touches 64 CONSECUTIVE-ish entries (neighbouring rows have neighbouring columns):
+//     4-5 cache lines per instruction instead of ~12 in CSR order (tools/gather_probe.hip, modes 0 vs 5);
+//   * the row sum is accumulated in slot order = the plain sequential CSR row sum (deterministic).
+// Padding entries carry value 0 and the row's own index as column.  Eligible when padding <= 10 % of nnz and
+// max_row_nnz <= 128; hex-27 (27..125 entries per row) stays on the LDS-tile CSR kernel.
+#include "blas1.h"
+
+static int g_ell_enable = 1;
+// kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
+// Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
+// workgroup counts that are not fully resident (10, 12 per CU) lose 15 %.
+static int g_ell_variant = 6;
+static int g_ell_grid_mult = 6;
+extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: kernel variant; bits 8-15: workgroups per CU
+  g_ell_enable = enable & 1;
+  g_ell_variant = (enable >> 4) & 15;
+  if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
+  return MFEM_OK;
+}
+
+// cols[s][r] (0-based) for s < K; pad: the row index itself
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_ell_cols(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, int base, int32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < npad; r += stride) {
+    int64_t lo = 0;
+    int len = 0;
+    if (r < n) {
+      lo = (int64_t)rowptr[r] - base;
+      len = (int)((int64_t)rowptr[r + 1] - base - lo);
+    }
+    const int32_t self = (int32_t)(r < n ? r : 0);
+    for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? col[lo + s] - base : self;
+  }
+}
+
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
+                                                           const double* __restrict__ vals, int base, double* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < npad; r += stride) {
+    int64_t lo = 0;
+    int len = 0;
+    if (r < n) {
+      lo = (int64_t)rowptr[r] - base;
+      len = (int)((int64_t)rowptr[r + 1] - base - lo);
+    }
+    for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? vals[lo + s] : 0.0;
+  }
+}
+
+typedef double e_d2 __attribute__((ext_vector_type(2)));
+typedef int e_i2 __attribute__((ext_vector_type(2)));
+
+// RPT rows per lane (1: 8-byte value / 4-byte column loads; 2: 16-byte / 8-byte loads of two neighbouring rows), U slots in
+// flight per batch.  npad is a multiple of 64, so row pairs (even r) are 16-byte aligned in every slot plane.
+template <int RPT, int U>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad, int K, const int32_t* __restrict__ cols,
+                                                           const double* __restrict__ vals, const double* __restrict__ x,
+                                                           double* __restrict__ y, double alpha, double beta,
+                                                           const double* __restrict__ dotw, double* __restrict__ partials,
+                                                           const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
+  for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * RPT; r < n; r += stride) {
+    const double* v = vals + r;
+    const int32_t* c = cols + r;
+    if (RPT == 1) {
+      double acc = 0.0;
+      int s = 0;
+      for (; s + U <= K; s += U) {
+        double vv[U];
+        int32_t cc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          vv[u] = __builtin_nontemporal_load(v + (int64_t)(s + u) * npad);
+          cc[u] = __builtin_nontemporal_load(c + (int64_t)(s + u) * npad);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += vv[u] * x[cc[u]];
+      }
+      for (; s < K; ++s) acc += __builtin_nontemporal_load(v + (int64_t)s * npad) * x[__builtin_nontemporal_load(c + (int64_t)s * npad)];
+      double yv = alpha * acc;
+      if (beta != 0.0) yv += beta * y[r];
+      y[r] = yv;
+      if (dotw) dot_acc += yv * dotw[r];
+    } else {
+      // rows r, r + 1 (r even; row r + 1 may be the pad row n when n is odd: its slots are zero-valued and point at row 0)
+      e_d2 acc = {0.0, 0.0};
+      int s = 0;
+      for (; s + U <= K; s += U) {
+        e_d2 vv[U];
+        e_i2 cc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          vv[u] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)(s + u) * npad));
+          cc[u] = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (int64_t)(s + u) * npad));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc.x += vv[u].x * x[cc[u].x];
+          acc.y += vv[u].y * x[cc[u].y];
+        }
+      }
+      for (; s < K; ++s) {
+        const e_d2 v1 = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)s * npad));
+        const e_i2 c1 = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (int64_t)s * npad));
+        acc.x += v1.x * x[c1.x];
+        acc.y += v1.y * x[c1.y];
+      }
+      double y0 = alpha * acc.x, y1 = alpha * acc.y;
+      const bool two = r + 1 < n;
+      if (beta != 0.0) {
+        y0 += beta * y[r];
+        if (two) y1 += beta * y[r + 1];
+      }
+      y[r] = y0;
+      if (two) y[r + 1] = y1;
+      if (dotw) {
+        dot_acc += y0 * dotw[r];
+        if (two) dot_acc += y1 * dotw[r + 1];
+      }
+    }
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = b;
+  }
+}
+
+// Decide eligibility and build the column table (once per pattern).  A->max_row_nnz must be known (mfem_csr_plan).
+int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  if (A->ell_state != 0) return MFEM_OK;
+  A->ell_state = -1;
+  const int K = A->max_row_nnz;
+  if (A->n < 1 || K < 1 || K > 128) return MFEM_OK;
+  const int64_t npad = (A->n + 63) & ~(int64_t)63;
+  if ((double)K * (double)npad > 1.10 * (double)A->nnz + 64.0 * K) return MFEM_OK;  // > 10 % padding
+  MFEM_CHECK_HIP(hipMalloc(&A->ell_cols, sizeof(int32_t) * (size_t)K * (size_t)npad));
+  const int grid = mfem_grid_for(npad, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_ell_cols<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, npad, K, (const int64_t*)A->rowptr,
+                       A->colidx, A->index_base, A->ell_cols);
+  else
+    hipLaunchKernelGGL(k_ell_cols<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, npad, K, (const int32_t*)A->rowptr,
+                       A->colidx, A->index_base, A->ell_cols);
+  MFEM_CHECK_LAUNCH();
+  A->ell_K = K;
+  A->ell_npad = npad;
+  A->ell_state = 1;
+  return MFEM_OK;
+}
+
+size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
+  return (A->ell_state == 1 && g_ell_enable) ? sizeof(double) * (size_t)A->ell_K * (size_t)A->ell_npad : 0;
+}
+
+// Transpose CSR-ordered values into `buf` and route subsequent mfem_spmv_launch calls with these `vals` to the ELL kernel.
+int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
+  A->ell_vals = nullptr;
+  A->ell_src = nullptr;
+  if (A->ell_state != 1 || !g_ell_enable || !buf) return MFEM_OK;
+  const int grid = mfem_grid_for(A->ell_npad, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_ell_vals<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K,
+                       (const int64_t*)A->rowptr, vals, A->index_base, buf);
+  else
+    hipLaunchKernelGGL(k_ell_vals<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K,
+                       (const int32_t*)A->rowptr, vals, A->index_base, buf);
+  MFEM_CHECK_LAUNCH();
+  A->ell_vals = buf;
+  A->ell_src = vals;
+  return MFEM_OK;
+}
+
+void mfem_ell_unbind(mfem_csr_s* A) {
+  A->ell_vals = nullptr;
+  A->ell_src = nullptr;
+}
+
+void mfem_ell_free(mfem_csr_s* A) {
+  if (A->ell_cols) hipFree(A->ell_cols);
+  A->ell_cols = nullptr;
+  A->ell_state = 0;
+}
+
+// returns 1 if launched, 0 if the CSR kernel should be used, <0 on error
+int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
+                         double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
+  if (!A->ell_vals || vals != A->ell_src) return 0;
+  int cap = ctx->num_cus * g_ell_grid_mult;
+  if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+  const int rpt = (g_ell_variant == 0 || g_ell_variant == 2 || g_ell_variant == 4) ? 1 : 2;
+  const int grid = mfem_grid_for((A->n + rpt - 1) / rpt, MFEM_BLOCK, cap);
+#define LAUNCH_ELL(RPT, U)                                                                                               \
+  hipLaunchKernelGGL((k_spmv_ell<RPT, U>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K,     \
+                     A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag)
+  switch (g_ell_variant) {
+    case 1: LAUNCH_ELL(2, 9); break;
+    case 2: LAUNCH_ELL(1, 27); break;
+    case 3: LAUNCH_ELL(2, 27); break;
+    case 4: LAUNCH_ELL(1, 3); break;
+    case 5: LAUNCH_ELL(2, 3); break;
+    case 6: LAUNCH_ELL(2, 1); break;
+    case 7: LAUNCH_ELL(2, 2); break;
+    case 8: LAUNCH_ELL(2, 4); break;
+    case 9: LAUNCH_ELL(2, 5); break;
+    case 10: LAUNCH_ELL(2, 6); break;
+    default: LAUNCH_ELL(1, 9); break;
+  }
+#undef LAUNCH_ELL
+  MFEM_CHECK_LAUNCH();
+  if (n_partials && partials) *n_partials = grid;
+  return 1;
+}
