@@ -199,7 +199,7 @@ def main():
                 "solve_ms_per_step": solve_ms / args.steps,
             },
             "roofline": {
-                "kernel": "k_spmv_lds (CSR SpMV, i64 rowptr / i32 col / f64 val)",
+                "kernel": "k_spmv_ell<2,1> (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms, "launches": cnt.value,

@@ -45,18 +45,32 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_cols(int64_t n, int64_t npad
   }
 }
 
+// Transposition of the values through LDS: a wave owns 64 consecutive rows, whose CSR values are one contiguous run -> read with
+// unit-stride lanes into the wave's LDS block, written out slot by slot with lane <-> row (both sides coalesced).
 template <typename RP>
-__global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
-                                                           const double* __restrict__ vals, int base, double* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < npad; r += stride) {
+__global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals_lds(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
+                                                               const double* __restrict__ vals, int base, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double* T = lds + (size_t)w * 64 * K;
+  const int64_t ntiles = npad >> 6;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    const int64_t r0 = tile << 6, r = r0 + lane;
+    const int64_t rend = (r0 + 64 < n) ? r0 + 64 : n;
     int64_t lo = 0;
     int len = 0;
     if (r < n) {
       lo = (int64_t)rowptr[r] - base;
       len = (int)((int64_t)rowptr[r + 1] - base - lo);
     }
-    for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? vals[lo + s] : 0.0;
+    const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
+    const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= 64 K
+    for (int i = lane; i < cnt; i += 64) T[i] = vals[s0 + i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const int off = (int)(lo - s0);
+    for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? T[off + s] : 0.0;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -173,12 +187,17 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
   if (A->ell_state != 1 || !g_ell_enable || !buf) return MFEM_OK;
-  const int grid = mfem_grid_for(A->ell_npad, MFEM_BLOCK, ctx->num_cus * 16);
+  int waves = 4;
+  while (waves > 1 && sizeof(double) * 64 * (size_t)A->ell_K * waves > 64 * 1024) waves >>= 1;
+  const size_t lds = sizeof(double) * 64 * (size_t)A->ell_K * waves;
+  const int64_t ntiles = A->ell_npad >> 6;
+  int grid = (int)((ntiles + waves - 1) / waves);
+  if (grid > ctx->num_cus * 16) grid = ctx->num_cus * 16;
   if (A->rowptr_bits == 64)
-    hipLaunchKernelGGL(k_ell_vals<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K,
+    hipLaunchKernelGGL(k_ell_vals_lds<int64_t>, dim3(grid), dim3(64 * waves), lds, ctx->stream, A->n, A->ell_npad, A->ell_K,
                        (const int64_t*)A->rowptr, vals, A->index_base, buf);
   else
-    hipLaunchKernelGGL(k_ell_vals<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K,
+    hipLaunchKernelGGL(k_ell_vals_lds<int32_t>, dim3(grid), dim3(64 * waves), lds, ctx->stream, A->n, A->ell_npad, A->ell_K,
                        (const int32_t*)A->rowptr, vals, A->index_base, buf);
   MFEM_CHECK_LAUNCH();
   A->ell_vals = buf;

@@ -181,3 +181,42 @@ def test_maxiter_and_max_pass_are_honoured(mf):
     assert 3 * 10 <= st.iterations <= 3 * 11  # idrs! returns at iter >= maxiter (04_IDRs.jl:79,92)
     x, st, _ = _gpu_solve(mf, sysm, converge_tol=1e-30, Sv_func=mf.bicgstabl_GS_, maxiter=9, max_pass=2, s=2)
     assert st.passes == 2 and st.iterations == 2 * 9  # iter = 1, 3, 5, 7, 9 (03_BiCGstabl.jl:93-94)
+
+
+@pytest.mark.parametrize("case", ["thermal_odd_n", "elasticity_3_fields", "hex27_not_eligible"])
+def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
+    """mfem_solve transposes the working values into a slot-major padded copy when the rows are near-uniform (spmv_ell.hip);
+    same Krylov iterates as with the CSR tile kernel up to the summation order inside a row."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    if case == "thermal_odd_n":
+        brick = mf.make_Brick((1.0, 1.0, 1.0), (6, 4, 4))  # n = 175: odd, exercises the pad row of the 2-rows-per-lane kernel
+        A = brick.pattern(1)
+        K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    elif case == "elasticity_3_fields":
+        brick = mf.make_Brick((1.0, 1.0, 1.0), (5, 4, 3))
+        A = brick.pattern(3)
+        K = brick.assemble_elasticity(A, 0.5769, 0.3846, 1000.0, 0x10)
+    else:
+        brick = mf.make_Brick((1.0, 1.0, 1.0), (3, 3, 3), 2, 5)
+        A = brick.pattern(1)
+        K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    b = mf.FEM_rand(A.n, 3, 1) - 0.5
+    out = {}
+    for ell in (1, 0):
+        _lib.lib.mfem_debug_set_ell(ell | (6 << 4))
+        try:
+            for sv, s in ((mf.idrs_, 4), (mf.bicgstabl_GS_, 2), (mf.cgs2_, 0)):
+                x, st = mf.iterative_Solve(A, K, b, 1e-300, Sv_func=sv, maxiter=6, max_pass=1, s=s, seed=11)
+                out[(ell, sv)] = x.cpu().numpy()
+            if case != "elasticity_3_fields":  # -K of the thermal form is symmetric positive definite
+                x, st = mf.iterative_Solve(A, -K, -b, 1e-9 * float(mf.normalized_norm(b)), Sv_func=mf.cg_, maxiter=2000, max_pass=4)
+                assert st.converged == 1
+                out[(ell, "cg")] = x.cpu().numpy()
+        finally:
+            _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
+    for key in [k for k in out if k[0] == 1]:
+        a, c = out[key], out[(0, key[1])]
+        tol = 1e-7 if key[1] == "cg" else 1e-10
+        assert np.abs(a - c).max() <= tol * np.abs(c).max(), key
