@@ -169,13 +169,27 @@ def main():
         assert iters_done == args.iters * args.steps, (iters_done, args.iters, args.steps)
         value = n_global * args.iters * args.steps / elapsed
         spmv_ms = tot.value / max(cnt.value, 1)
-        spmv_bytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8  # val 8 + col 4 per nz; x, y 8 each per row; i64 rowptr
+        csr_bytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8  # val 8 + col 4 per nz; x, y 8 each per row; i64 rowptr
+        mode, slots, npad, reg = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
+        if mode.value == 2:
+            # diagonal-slotted blocks read no column stream: 8 B per nonzero + x, y; rows in generic blocks also read 4 B columns
+            kernel = "k_spmv_dia<2,3> (SpMV on the slot-major copy of the CSR matrix made once per solve; diagonal-slotted blocks)"
+            spmv_bytes = A.nnz * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
+        elif mode.value == 1:
+            kernel = "k_spmv_ell<2,1> (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)"
+            spmv_bytes = A.nnz * 12 + A.n * 16
+        else:
+            kernel = "k_spmv_lds (CSR SpMV, i64 rowptr / i32 col / f64 val)"
+            spmv_bytes = csr_bytes
         achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+        csr_equiv = csr_bytes / (spmv_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(tpath) and N == 256:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch") if tj.get("solver_layout_mode") == mode.value else None
             except Exception:
                 traffic = None
         out = {
@@ -199,10 +213,13 @@ def main():
                 "solve_ms_per_step": solve_ms / args.steps,
             },
             "roofline": {
-                "kernel": "k_spmv_ell<2,1> (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)",
+                "kernel": kernel,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms, "launches": cnt.value,
+                "csr_equivalent": {"bytes_per_launch": csr_bytes, "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
+                                   "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
+                                           "kernel would have to sustain to match this time"},
             },
         }
         if world == 1 and args.cpu_n > 0:

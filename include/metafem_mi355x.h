@@ -94,7 +94,16 @@ int mfem_debug_set_hex27(int two_pass);
 
 /* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */
-/* Slot-major (ELL) copy of the working values inside mfem_solve for matrices with near-uniform rows (default on). */
+/* Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
+ *   mode 0  the CSR tile kernel (irregular rows, e.g. hex-27)
+ *   mode 1  slot-major padded copy of the working values + explicit columns (rows of near-uniform length)
+ *   mode 2  as 1, and 128-row blocks whose entries all sit on <= 32 common diagonals store their values by diagonal and
+ *           do not read columns at all (any lattice stencil; detected from the CSR pattern, nothing is assumed)
+ * The copy is made once per solve from the caller's CSR-ordered values, like the reference's K_total[K_val_ids] gather
+ * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks. */
+int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
+                           int64_t* regular_rows);
+/* bit 0: slot-major copies on/off; bit 1: never use diagonal slots; bits 4-7 / 16-19: kernel variants; bits 8-15: workgroups per CU */
 int mfem_debug_set_ell(int enable);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to

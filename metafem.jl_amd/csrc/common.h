@@ -101,6 +101,12 @@ struct mfem_csr_s {
   int32_t* ell_cols;        // owned, [K][npad], 0-based
   const double* ell_src;    // the CSR-ordered values the bound copy mirrors (identity of the `vals` argument)
   double* ell_vals;         // not owned (solver workspace), [K][npad]
+  // diagonal-slotted variant (all entries on <= 32 diagonals): dia_state 0 = not inspected, -1 = no, 1 = yes
+  int dia_state, dia_D;
+  int32_t dia_off[32];
+  int32_t* dia_flags;       // owned, one int per 128-row block: 1 = regular (diagonal-slotted), 0 = explicit columns
+  int32_t dia_regular_blocks;
+  int ell_bound_mode;       // 0 none, 1 slot-major with explicit columns, 2 diagonal-slotted
 };
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);

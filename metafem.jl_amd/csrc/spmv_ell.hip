@@ -16,6 +16,8 @@
 #include "blas1.h"
 
 static int g_ell_enable = 1;
+static int g_dia_enable = 1;
+static int g_dia_variant = 0;  // 0 (default): 2 rows x3; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
 // workgroup counts that are not fully resident (10, 12 per CU) lose 15 %.
@@ -23,6 +25,8 @@ static int g_ell_variant = 6;
 static int g_ell_grid_mult = 6;
 extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: kernel variant; bits 8-15: workgroups per CU
   g_ell_enable = enable & 1;
+  g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
+  g_dia_variant = (enable >> 16) & 15;
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
   return MFEM_OK;
@@ -155,6 +159,190 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Diagonal-slotted blocks.  When every entry of the matrix sits on one of D <= 32 diagonals (col - row in a fixed sorted
+// offset list: any lattice stencil -- 27 for the hex-8 scalar operator), slot s of a row is "the entry on diagonal s"
+// (zero if the row has none) instead of "the s-th entry".  A 128-row block whose rows only touch in-range positions is
+// then REGULAR: the column of (row r, slot s) is r + off[s], the column stream is not read at all, and the gather is a
+// unit-stride 16-byte load.  Blocks that contain rows pointing outside [0, n_x) on some diagonal (first / last rows) or
+// entries off the diagonal list (ghost columns of a slab) stay on the generic slot-major path with explicit columns.
+// The detection is an inspection of the caller's CSR pattern; nothing about the mesh is assumed.
+// ---------------------------------------------------------------------------------------------------------------
+#define DIA_MAXD 32
+struct DiaOffsets {
+  int D;
+  int32_t off[DIA_MAXD];
+};
+
+// candidate offsets = the diagonals of one (longest) row.  flags[b] = 1 when every row of the 128-row block b is regular:
+// all its entries sit on listed diagonals and r + off[s] is a valid x index for EVERY listed diagonal (so the kernel may
+// load x there even where the row has no entry).  nreg counts the regular blocks.
+template <typename RP>
+__global__ __launch_bounds__(128) void k_dia_flags(int64_t n, int64_t nx, const RP* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, int base, DiaOffsets O,
+                                                     int32_t* __restrict__ flags, int32_t* __restrict__ nreg) {
+  __shared__ int bad;
+  for (int64_t blk = blockIdx.x; blk * 128 < n; blk += gridDim.x) {
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const int64_t r = blk * 128 + threadIdx.x;
+    int fail = 0;
+    if (r < n) {
+      if (r + O.off[0] < 0 || r + O.off[O.D - 1] >= nx) fail = 1;
+      const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+      int s = 0;
+      for (int64_t j = lo; j < hi && !fail; ++j) {  // columns ascending, offsets ascending: merge
+        const int64_t d = (int64_t)col[j] - base - r;
+        while (s < O.D && O.off[s] < d) ++s;
+        if (s == O.D || O.off[s] != d) fail = 1;
+      }
+    } else {
+      fail = 1;  // partial last block: generic path
+    }
+    if (fail) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      flags[blk] = bad ? 0 : 1;
+      if (!bad) atomicAdd(nreg, 1);
+    }
+    __syncthreads();
+  }
+}
+
+// values in diagonal slots + per-block regular flag (regular: every row r of the block has 0 <= r + off[s] < nx for all s)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, const double* __restrict__ vals,
+                                                           int base, DiaOffsets O, const int32_t* __restrict__ flags,
+                                                           double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double* T = lds + (size_t)w * 64 * O.D;
+  int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * 64 * O.D) + (size_t)w * 64 * O.D;
+  const int64_t ntiles = npad >> 6;
+  for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    const int64_t r0 = tile << 6, r = r0 + lane;
+    const int64_t rend = (r0 + 64 < n) ? r0 + 64 : n;
+    int64_t lo = 0;
+    int len = 0;
+    if (r < n) {
+      lo = (int64_t)rowptr[r] - base;
+      len = (int)((int64_t)rowptr[r + 1] - base - lo);
+    }
+    const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
+    const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= 64 D
+    for (int i = lane; i < cnt; i += 64) {
+      T[i] = vals[s0 + i];
+      Tc[i] = col[s0 + i] - base;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const int off0 = (int)(lo - s0);
+    if (flags[tile >> 1]) {  // regular 128-row block: slot s = diagonal s
+      int j = 0;
+      for (int s = 0; s < O.D; ++s) {
+        double v = 0.0;
+        if (j < len && (int64_t)Tc[off0 + j] - r == O.off[s]) {
+          v = T[off0 + j];
+          ++j;
+        }
+        out[(int64_t)s * npad + r] = v;
+      }
+    } else {                 // generic block: slot s = s-th entry, columns come from ell_cols
+      for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? T[off0 + s] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+typedef double u_d2 __attribute__((ext_vector_type(2), aligned(8)));
+// lane <-> RPT (2 or 4) neighbouring rows; a wave covers one aligned block of 64 RPT rows; U diagonals per batch
+template <int RPT, int U>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad, int K, DiaOffsets O,
+                                                           const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
+                                                           const double* __restrict__ vals, const double* __restrict__ x,
+                                                           double* __restrict__ y, double alpha, double beta,
+                                                           const double* __restrict__ dotw, double* __restrict__ partials,
+                                                           const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  constexpr int H = RPT / 2;  // 16-byte pairs per lane
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
+  for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * RPT; r < n; r += stride) {
+    const double* v = vals + r;
+    e_d2 acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = (e_d2){0.0, 0.0};
+    // the wave's rows [b0, b0 + 64 RPT) are RPT / 2 aligned 128-row blocks: regular only if all of them are (wave-uniform)
+    const int64_t blk = r / (64 * RPT) * (RPT / 2);
+    bool interior = flags[blk] != 0;
+    if (RPT == 4) interior = interior && ((blk + 1) * 128 < npad) && flags[blk + 1] != 0;
+    if (interior) {
+      int s = 0;
+      for (; s + U <= O.D; s += U) {
+        e_d2 vv[U][H];
+        u_d2 xx[U][H];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            vv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)(s + u) * npad) + h);
+            xx[u][h] = *(reinterpret_cast<const u_d2*>(x + r + O.off[s + u]) + h);
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            // a zero slot stands for "no entry": it must not pick up a non-finite x from a position the CSR row never reads
+            acc[h].x += vv[u][h].x != 0.0 ? vv[u][h].x * xx[u][h].x : 0.0;
+            acc[h].y += vv[u][h].y != 0.0 ? vv[u][h].y * xx[u][h].y : 0.0;
+          }
+      }
+      for (; s < O.D; ++s)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)s * npad) + h);
+          const u_d2 xx = *(reinterpret_cast<const u_d2*>(x + r + O.off[s]) + h);
+          acc[h].x += vv.x != 0.0 ? vv.x * xx.x : 0.0;
+          acc[h].y += vv.y != 0.0 ? vv.y * xx.y : 0.0;
+        }
+    } else {  // generic block (boundary rows, ghost columns): explicit columns, compact slots
+      const int32_t* c = cols + r;
+      for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          if (r + 2 * h >= npad) continue;
+          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)s * npad) + h);
+          const e_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (int64_t)s * npad) + h);
+          acc[h].x += vv.x * x[cc.x];
+          acc[h].y += vv.y * x[cc.y];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int64_t rr = r + 2 * h;
+      if (rr >= n) break;
+      double y0 = alpha * acc[h].x, y1 = alpha * acc[h].y;
+      const bool two = rr + 1 < n;
+      if (beta != 0.0) {
+        y0 += beta * y[rr];
+        if (two) y1 += beta * y[rr + 1];
+      }
+      y[rr] = y0;
+      if (two) y[rr + 1] = y1;
+      if (dotw) {
+        dot_acc += y0 * dotw[rr];
+        if (two) dot_acc += y1 * dotw[rr + 1];
+      }
+    }
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = b;
+  }
+}
+
 // Decide eligibility and build the column table (once per pattern).  A->max_row_nnz must be known (mfem_csr_plan).
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->ell_state != 0) return MFEM_OK;
@@ -175,6 +363,56 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   A->ell_K = K;
   A->ell_npad = npad;
   A->ell_state = 1;
+  // diagonal structure?  candidate diagonals = those of the middle row; per-128-row-block flags say where they hold
+  A->dia_state = -1;
+  if (K <= DIA_MAXD) {
+    int64_t rp[2];
+    const int64_t rm = A->n / 2;
+    if (A->rowptr_bits == 64) {
+      MFEM_CHECK_HIP(hipMemcpyAsync(rp, (const char*)A->rowptr + rm * 8, 16, hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+      int32_t rp32[2];
+      MFEM_CHECK_HIP(hipMemcpyAsync(rp32, (const char*)A->rowptr + rm * 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      rp[0] = rp32[0];
+      rp[1] = rp32[1];
+    }
+    const int len = (int)(rp[1] - rp[0]);
+    if (len == K) {
+      int32_t cbuf[DIA_MAXD];
+      MFEM_CHECK_HIP(hipMemcpyAsync(cbuf, A->colidx + (rp[0] - A->index_base), sizeof(int32_t) * len, hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      DiaOffsets O;
+      O.D = len;
+      for (int i = 0; i < len; ++i) O.off[i] = (int32_t)((int64_t)cbuf[i] - A->index_base - rm);
+      const int64_t nblk = (npad / 64 + 1) / 2;
+      const int64_t nx = A->n + (ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0);  // length of the local x
+      MFEM_CHECK_HIP(hipMalloc(&A->dia_flags, sizeof(int32_t) * (size_t)nblk));
+      MFEM_CHECK_HIP(hipMemsetAsync(A->dia_flags, 0, sizeof(int32_t) * (size_t)nblk, ctx->stream));
+      int32_t* d_cnt = ctx->d_flags + 9;
+      MFEM_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+      const int g2 = (int)(nblk < (int64_t)ctx->num_cus * 64 ? nblk : (int64_t)ctx->num_cus * 64);
+      if (A->rowptr_bits == 64)
+        hipLaunchKernelGGL(k_dia_flags<int64_t>, dim3(g2), dim3(128), 0, ctx->stream, A->n, nx, (const int64_t*)A->rowptr, A->colidx,
+                           A->index_base, O, A->dia_flags, d_cnt);
+      else
+        hipLaunchKernelGGL(k_dia_flags<int32_t>, dim3(g2), dim3(128), 0, ctx->stream, A->n, nx, (const int32_t*)A->rowptr, A->colidx,
+                           A->index_base, O, A->dia_flags, d_cnt);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if ((double)ctx->h_flags[9] >= 0.8 * (double)nblk) {  // worth it when most blocks take the diagonal path
+        A->dia_state = 1;
+        A->dia_D = len;
+        A->dia_regular_blocks = ctx->h_flags[9];
+        for (int i = 0; i < len; ++i) A->dia_off[i] = O.off[i];
+      } else {
+        hipFree(A->dia_flags);
+        A->dia_flags = nullptr;
+      }
+    }
+  }
   return MFEM_OK;
 }
 
@@ -186,7 +424,30 @@ size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
 int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
+  A->ell_bound_mode = 0;
   if (A->ell_state != 1 || !g_ell_enable || !buf) return MFEM_OK;
+  if (A->dia_state == 1 && g_dia_enable) {
+    DiaOffsets O;
+    O.D = A->dia_D;
+    for (int i = 0; i < O.D; ++i) O.off[i] = A->dia_off[i];
+    int wv = 4;
+    while (wv > 1 && 12 * 64 * (size_t)A->ell_K * wv > 64 * 1024) wv >>= 1;
+    const size_t ldsb = 12 * 64 * (size_t)A->ell_K * wv;  // 8 B value + 4 B column per staged entry (<= 64 K per tile)
+    const int64_t nt = A->ell_npad >> 6;
+    int g = (int)((nt + wv - 1) / wv);
+    if (g > ctx->num_cus * 16) g = ctx->num_cus * 16;
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_dia_vals<int64_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
+                         (const int64_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf);
+    else
+      hipLaunchKernelGGL(k_dia_vals<int32_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
+                         (const int32_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf);
+    MFEM_CHECK_LAUNCH();
+    A->ell_vals = buf;
+    A->ell_src = vals;
+    A->ell_bound_mode = 2;
+    return MFEM_OK;
+  }
   int waves = 4;
   while (waves > 1 && sizeof(double) * 64 * (size_t)A->ell_K * waves > 64 * 1024) waves >>= 1;
   const size_t lds = sizeof(double) * 64 * (size_t)A->ell_K * waves;
@@ -202,18 +463,23 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   MFEM_CHECK_LAUNCH();
   A->ell_vals = buf;
   A->ell_src = vals;
+  A->ell_bound_mode = 1;
   return MFEM_OK;
 }
 
 void mfem_ell_unbind(mfem_csr_s* A) {
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
+  A->ell_bound_mode = 0;
 }
 
 void mfem_ell_free(mfem_csr_s* A) {
   if (A->ell_cols) hipFree(A->ell_cols);
+  if (A->dia_flags) hipFree(A->dia_flags);
   A->ell_cols = nullptr;
+  A->dia_flags = nullptr;
   A->ell_state = 0;
+  A->dia_state = 0;
 }
 
 // returns 1 if launched, 0 if the CSR kernel should be used, <0 on error
@@ -222,6 +488,28 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   if (!A->ell_vals || vals != A->ell_src) return 0;
   int cap = ctx->num_cus * g_ell_grid_mult;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+  if (A->ell_bound_mode == 2) {
+    DiaOffsets O;
+    O.D = A->dia_D;
+    for (int i = 0; i < O.D; ++i) O.off[i] = A->dia_off[i];
+    const int drpt = (g_dia_variant >= 4) ? 4 : 2;
+    const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
+#define LAUNCH_DIA(RPT, U)                                                                                                \
+  hipLaunchKernelGGL((k_spmv_dia<RPT, U>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,          \
+                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag)
+    switch (g_dia_variant) {
+      case 1: LAUNCH_DIA(2, 2); break;
+      case 3: LAUNCH_DIA(2, 9); break;
+      case 4: LAUNCH_DIA(4, 1); break;
+      case 5: LAUNCH_DIA(4, 3); break;
+      case 6: LAUNCH_DIA(2, 1); break;
+      default: LAUNCH_DIA(2, 3); break;
+    }
+#undef LAUNCH_DIA
+    MFEM_CHECK_LAUNCH();
+    if (n_partials && partials) *n_partials = gd;
+    return 1;
+  }
   const int rpt = (g_ell_variant == 0 || g_ell_variant == 2 || g_ell_variant == 4) ? 1 : 2;
   const int grid = mfem_grid_for((A->n + rpt - 1) / rpt, MFEM_BLOCK, cap);
 #define LAUNCH_ELL(RPT, U)                                                                                               \
@@ -244,4 +532,20 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   return 1;
+}
+
+// What the Krylov loop of the next mfem_solve will run on this pattern: 0 = CSR tile kernel, 1 = slot-major copy with explicit
+// columns, 2 = slot-major copy with diagonal-slotted regular blocks.  Plans the pattern if that has not happened yet.
+extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
+                                      int64_t* regular_rows) {
+  MFEM_REQUIRE(ctx && A, "null handle");
+  int rc = mfem_ell_plan(ctx, A);
+  if (rc) return rc;
+  int m = 0;
+  if (A->ell_state == 1 && g_ell_enable) m = (A->dia_state == 1 && g_dia_enable) ? 2 : 1;
+  if (mode) *mode = m;
+  if (slots) *slots = m ? A->ell_K : 0;
+  if (padded_rows) *padded_rows = m ? A->ell_npad : 0;
+  if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
+  return MFEM_OK;
 }
