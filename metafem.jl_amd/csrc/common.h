@@ -106,6 +106,7 @@ struct mfem_csr_s {
   int32_t dia_off[32];
   int32_t* dia_flags;       // owned, one int per 128-row block: 1 = regular (diagonal-slotted), 0 = explicit columns
   int32_t dia_regular_blocks;
+  int dia_triples;          // the diagonals come in runs of three consecutive offsets
   int ell_bound_mode;       // 0 none, 1 slot-major with explicit columns, 2 diagonal-slotted
 };
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);

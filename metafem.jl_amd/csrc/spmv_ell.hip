@@ -15,9 +15,18 @@
 // max_row_nnz <= 128; hex-27 (27..125 entries per row) stays on the LDS-tile CSR kernel.
 #include "blas1.h"
 
+// Blocked slot-major layout ("sliced ELL"): rows are grouped in blocks of ELL_B = 128 (the rows of one wave at two rows per
+// lane); block b stores its K slots one after the other, element (row r, slot s) at  b * K * 128 + s * 128 + (r & 127).
+// A wave therefore reads ONE contiguous K-kilobyte chunk per block and the kernel as a whole walks memory front to back
+// like a copy, instead of K streams a full vector length apart.
+#define ELL_B 128
+__host__ __device__ __forceinline__ int64_t ell_base(int64_t r, int K) { return (r >> 7) * ((int64_t)K * ELL_B) + (r & (ELL_B - 1)); }
+
 static int g_ell_enable = 1;
 static int g_dia_enable = 1;
-static int g_dia_variant = 0;  // 0 (default): 2 rows x3; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
+// 0 (default): 2 rows x 3 diagonals, sharing the x loads of a run of three consecutive offsets when the diagonals come in such
+// runs; 8: 2 rows x3 without that sharing; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
+static int g_dia_variant = 0;
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
 // workgroup counts that are not fully resident (10, 12 per CU) lose 15 %.
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_cols(int64_t n, int64_t npad
       len = (int)((int64_t)rowptr[r + 1] - base - lo);
     }
     const int32_t self = (int32_t)(r < n ? r : 0);
-    for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? col[lo + s] - base : self;
+    for (int s = 0; s < K; ++s) out[ell_base(r, K) + s * ELL_B] = s < len ? col[lo + s] - base : self;
   }
 }
 
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals_lds(int64_t n, int64_t 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int off = (int)(lo - s0);
-    for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? T[off + s] : 0.0;
+    for (int s = 0; s < K; ++s) out[ell_base(r, K) + s * ELL_B] = s < len ? T[off + s] : 0.0;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -94,8 +103,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
   double dot_acc = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
   for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * RPT; r < n; r += stride) {
-    const double* v = vals + r;
-    const int32_t* c = cols + r;
+    const double* v = vals + ell_base(r, K);
+    const int32_t* c = cols + ell_base(r, K);
     if (RPT == 1) {
       double acc = 0.0;
       int s = 0;
@@ -104,13 +113,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
         int32_t cc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          vv[u] = __builtin_nontemporal_load(v + (int64_t)(s + u) * npad);
-          cc[u] = __builtin_nontemporal_load(c + (int64_t)(s + u) * npad);
+          vv[u] = __builtin_nontemporal_load(v + (s + u) * ELL_B);
+          cc[u] = __builtin_nontemporal_load(c + (s + u) * ELL_B);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc += vv[u] * x[cc[u]];
       }
-      for (; s < K; ++s) acc += __builtin_nontemporal_load(v + (int64_t)s * npad) * x[__builtin_nontemporal_load(c + (int64_t)s * npad)];
+      for (; s < K; ++s) acc += __builtin_nontemporal_load(v + s * ELL_B) * x[__builtin_nontemporal_load(c + s * ELL_B)];
       double yv = alpha * acc;
       if (beta != 0.0) yv += beta * y[r];
       y[r] = yv;
@@ -124,8 +133,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
         e_i2 cc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          vv[u] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)(s + u) * npad));
-          cc[u] = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (int64_t)(s + u) * npad));
+          vv[u] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + u) * ELL_B));
+          cc[u] = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (s + u) * ELL_B));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -134,8 +143,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
         }
       }
       for (; s < K; ++s) {
-        const e_d2 v1 = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)s * npad));
-        const e_i2 c1 = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (int64_t)s * npad));
+        const e_d2 v1 = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
+        const e_i2 c1 = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + s * ELL_B));
         acc.x += v1.x * x[c1.x];
         acc.y += v1.y * x[c1.y];
       }
@@ -246,10 +255,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
           v = T[off0 + j];
           ++j;
         }
-        out[(int64_t)s * npad + r] = v;
+        out[ell_base(r, K) + s * ELL_B] = v;
       }
     } else {                 // generic block: slot s = s-th entry, columns come from ell_cols
-      for (int s = 0; s < K; ++s) out[(int64_t)s * npad + r] = s < len ? T[off0 + s] : 0.0;
+      for (int s = 0; s < K; ++s) out[ell_base(r, K) + s * ELL_B] = s < len ? T[off0 + s] : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
 
 typedef double u_d2 __attribute__((ext_vector_type(2), aligned(8)));
 // lane <-> RPT (2 or 4) neighbouring rows; a wave covers one aligned block of 64 RPT rows; U diagonals per batch
-template <int RPT, int U>
+template <int RPT, int U, bool TRIPLES = false>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad, int K, DiaOffsets O,
                                                            const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
                                                            const double* __restrict__ vals, const double* __restrict__ x,
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
   constexpr int H = RPT / 2;  // 16-byte pairs per lane
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
   for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * RPT; r < n; r += stride) {
-    const double* v = vals + r;
+    const double* v = vals + ell_base(r, K);
     e_d2 acc[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) acc[h] = (e_d2){0.0, 0.0};
@@ -278,7 +287,23 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
     const int64_t blk = r / (64 * RPT) * (RPT / 2);
     bool interior = flags[blk] != 0;
     if (RPT == 4) interior = interior && ((blk + 1) * 128 < npad) && flags[blk + 1] != 0;
-    if (interior) {
+    if (interior && TRIPLES && RPT == 2) {
+      // the diagonals come in runs of three consecutive offsets (o - 1, o, o + 1: the fastest lattice direction): the two
+      // rows of the lane need x[r + o - 1 .. r + o + 2] for the whole run -- two 16-byte loads instead of three
+      for (int s = 0; s < O.D; s += 3) {
+        const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
+        const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
+        const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
+        const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + O.off[s]);
+        const u_d2 xa = xp[0], xb = xp[1];
+        acc[0].x += va.x != 0.0 ? va.x * xa.x : 0.0;
+        acc[0].y += va.y != 0.0 ? va.y * xa.y : 0.0;
+        acc[0].x += vb.x != 0.0 ? vb.x * xa.y : 0.0;
+        acc[0].y += vb.y != 0.0 ? vb.y * xb.x : 0.0;
+        acc[0].x += vc.x != 0.0 ? vc.x * xb.x : 0.0;
+        acc[0].y += vc.y != 0.0 ? vc.y * xb.y : 0.0;
+      }
+    } else if (interior) {
       int s = 0;
       for (; s + U <= O.D; s += U) {
         e_d2 vv[U][H];
@@ -287,7 +312,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
         for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            vv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)(s + u) * npad) + h);
+            vv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + u) * ELL_B) + h);
             xx[u][h] = *(reinterpret_cast<const u_d2*>(x + r + O.off[s + u]) + h);
           }
 #pragma unroll
@@ -302,19 +327,19 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
       for (; s < O.D; ++s)
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)s * npad) + h);
+          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
           const u_d2 xx = *(reinterpret_cast<const u_d2*>(x + r + O.off[s]) + h);
           acc[h].x += vv.x != 0.0 ? vv.x * xx.x : 0.0;
           acc[h].y += vv.y != 0.0 ? vv.y * xx.y : 0.0;
         }
     } else {  // generic block (boundary rows, ghost columns): explicit columns, compact slots
-      const int32_t* c = cols + r;
+      const int32_t* c = cols + ell_base(r, K);
       for (int s = 0; s < K; ++s)
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           if (r + 2 * h >= npad) continue;
-          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (int64_t)s * npad) + h);
-          const e_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + (int64_t)s * npad) + h);
+          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
+          const e_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + s * ELL_B) + h);
           acc[h].x += vv.x * x[cc.x];
           acc[h].y += vv.y * x[cc.y];
         }
@@ -349,7 +374,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   A->ell_state = -1;
   const int K = A->max_row_nnz;
   if (A->n < 1 || K < 1 || K > 128) return MFEM_OK;
-  const int64_t npad = (A->n + 63) & ~(int64_t)63;
+  const int64_t npad = (A->n + ELL_B - 1) & ~(int64_t)(ELL_B - 1);
   if ((double)K * (double)npad > 1.10 * (double)A->nnz + 64.0 * K) return MFEM_OK;  // > 10 % padding
   MFEM_CHECK_HIP(hipMalloc(&A->ell_cols, sizeof(int32_t) * (size_t)K * (size_t)npad));
   const int grid = mfem_grid_for(npad, MFEM_BLOCK, ctx->num_cus * 16);
@@ -406,6 +431,9 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
         A->dia_state = 1;
         A->dia_D = len;
         A->dia_regular_blocks = ctx->h_flags[9];
+        A->dia_triples = (len % 3 == 0);
+        for (int i = 0; i + 2 < len && A->dia_triples; i += 3)
+          if (O.off[i + 1] != O.off[i] + 1 || O.off[i + 2] != O.off[i] + 2) A->dia_triples = 0;
         for (int i = 0; i < len; ++i) A->dia_off[i] = O.off[i];
       } else {
         hipFree(A->dia_flags);
@@ -503,6 +531,15 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       case 4: LAUNCH_DIA(4, 1); break;
       case 5: LAUNCH_DIA(4, 3); break;
       case 6: LAUNCH_DIA(2, 1); break;
+      case 0:
+      case 7:
+        if (A->dia_triples && g_dia_variant != 8) {
+          hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
+                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag);
+        } else {
+          LAUNCH_DIA(2, 3);
+        }
+        break;
       default: LAUNCH_DIA(2, 3); break;
     }
 #undef LAUNCH_DIA

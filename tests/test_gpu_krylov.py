@@ -187,11 +187,13 @@ def test_maxiter_and_max_pass_are_honoured(mf):
 def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
     """mfem_solve transposes the working values into a slot-major padded copy when the rows are near-uniform (spmv_ell.hip);
     same Krylov iterates as with the CSR tile kernel up to the summation order inside a row."""
+    import ctypes as C
+
     import torch
     from metafem_jl_amd import _lib
 
     if case == "thermal_odd_n":
-        brick = mf.make_Brick((1.0, 1.0, 1.0), (6, 4, 4))  # n = 175: odd, exercises the pad row of the 2-rows-per-lane kernel
+        brick = mf.make_Brick((1.0, 1.0, 1.0), (24, 24, 24))  # n = 25^3 = 15625: odd, exercises the pad row of the 2-rows-per-lane kernels
         A = brick.pattern(1)
         K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
     elif case == "elasticity_3_fields":
@@ -204,7 +206,9 @@ def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
         K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
     b = mf.FEM_rand(A.n, 3, 1) - 0.5
     out = {}
-    for ell in (1, 3, 0):  # 1: slot-major copy, diagonal-slotted when the pattern allows; 3: explicit columns only; 0: CSR kernel
+    # 1: slot-major copy, diagonal-slotted when the pattern allows (default kernel); 1 | 8 << 16: the same without the shared x
+    # loads of consecutive diagonals; 3: explicit columns only; 0: CSR tile kernel
+    for ell in (1, 1 | (8 << 16), 3, 0):
         _lib.lib.mfem_debug_set_ell(ell | (6 << 4))
         try:
             for sv, s in ((mf.idrs_, 4), (mf.bicgstabl_GS_, 2), (mf.cgs2_, 0)):
@@ -216,7 +220,46 @@ def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
                 out[(ell, "cg")] = x.cpu().numpy()
         finally:
             _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
+    if case == "thermal_odd_n":
+        mode = C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(brick.ctx._h, A._h, C.byref(mode), None, None, None))
+        assert mode.value == 2  # (smaller bricks have too many boundary rows: > 10 % padding keeps them on the CSR kernel)
     for key in [k for k in out if k[0] != 0]:
         a, c = out[key], out[(0, key[1])]
         tol = 1e-7 if key[1] == "cg" else 1e-10
         assert np.abs(a - c).max() <= tol * np.abs(c).max(), key
+
+
+def test_solver_layout_inspector(mf):
+    """mfem_csr_solver_layout: lattice stencil -> diagonal-slotted (mode 2), 3-field blocks -> explicit columns (mode 1),
+    hex-27 rows of 27..125 entries -> CSR tile kernel (mode 0); and a diagonal-slotted solve at a size with many regular
+    blocks equals the CSR-kernel solve."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib
+
+    def layout(brick, A):
+        mode, slots, npad, reg = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(brick.ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
+        return mode.value, slots.value, npad.value, reg.value
+
+    b1 = mf.make_Brick((1.0, 1.0, 1.0), (24, 24, 24))
+    A1 = b1.pattern(1)
+    m, slots, npad, reg = layout(b1, A1)
+    assert (m, slots) == (2, 27) and npad % 128 == 0 and npad >= A1.n and 0.8 * A1.n <= reg <= A1.n
+    assert layout(b1, b1.pattern(3))[:2] == (1, 81)  # 135 distinct diagonals for 81 entries per row: explicit columns
+    b3 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
+    assert layout(b3, b3.pattern(1))[0] == 0        # small brick: boundary rows would need > 10 % padding
+    b27 = mf.make_Brick((1.0, 1.0, 1.0), (4, 4, 4), 2, 5)
+    assert layout(b27, b27.pattern(1))[0] == 0
+    K = b1.assemble_thermal(A1, 0.6, 25.0, 293.15, 0x3F)
+    rhs = mf.FEM_rand(A1.n, 5, 0) - 0.5
+    res = {}
+    for ell in (1, 0):
+        _lib.lib.mfem_debug_set_ell(ell | (6 << 4))
+        try:
+            res[ell] = mf.iterative_Solve(A1, K, rhs, 1e-300, Sv_func=mf.bicgstabl_GS_, maxiter=8, max_pass=1, s=2, seed=3)[0].cpu().numpy()
+        finally:
+            _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
+    assert np.abs(res[1] - res[0]).max() <= 1e-10 * np.abs(res[0]).max()
