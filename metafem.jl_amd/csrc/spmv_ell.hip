@@ -13,6 +13,8 @@
 //   * the row sum is accumulated in slot order = the plain sequential CSR row sum (deterministic).
 // Padding entries carry value 0 and the row's own index as column.  Eligible when padding <= 10 % of nnz and
 // max_row_nnz <= 128; hex-27 (27..125 entries per row) stays on the LDS-tile CSR kernel.
+#include <vector>
+
 #include "blas1.h"
 
 // Blocked slot-major layout ("sliced ELL"): rows are grouped in blocks of ELL_B = 128 (the rows of one wave at two rows per
@@ -391,20 +393,32 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   // diagonal structure?  candidate diagonals = those of the middle row; per-128-row-block flags say where they hold
   A->dia_state = -1;
   if (K <= DIA_MAXD) {
-    int64_t rp[2];
-    const int64_t rm = A->n / 2;
-    if (A->rowptr_bits == 64) {
-      MFEM_CHECK_HIP(hipMemcpyAsync(rp, (const char*)A->rowptr + rm * 8, 16, hipMemcpyDeviceToHost, ctx->stream));
-      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-      int32_t rp32[2];
-      MFEM_CHECK_HIP(hipMemcpyAsync(rp32, (const char*)A->rowptr + rm * 4, 8, hipMemcpyDeviceToHost, ctx->stream));
-      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-      rp[0] = rp32[0];
-      rp[1] = rp32[1];
+    // candidate = the first full-length row in a window around the middle of the matrix
+    int64_t rp[2] = {0, 0};
+    int64_t rm = -1;
+    {
+      const int64_t w0 = A->n / 2 > 2048 ? A->n / 2 - 2048 : 0;
+      const int64_t wn = (A->n - w0) < 4096 ? (A->n - w0) : 4096;  // rows in the window
+      std::vector<int64_t> win((size_t)wn + 1);
+      if (A->rowptr_bits == 64) {
+        MFEM_CHECK_HIP(hipMemcpyAsync(win.data(), (const char*)A->rowptr + w0 * 8, (size_t)(wn + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      } else {
+        std::vector<int32_t> w32((size_t)wn + 1);
+        MFEM_CHECK_HIP(hipMemcpyAsync(w32.data(), (const char*)A->rowptr + w0 * 4, (size_t)(wn + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i <= wn; ++i) win[(size_t)i] = w32[(size_t)i];
+      }
+      for (int64_t i = 0; i < wn; ++i)
+        if (win[(size_t)i + 1] - win[(size_t)i] == K) {
+          rm = w0 + i;
+          rp[0] = win[(size_t)i];
+          rp[1] = win[(size_t)i + 1];
+          break;
+        }
     }
     const int len = (int)(rp[1] - rp[0]);
-    if (len == K) {
+    if (rm >= 0 && len == K) {
       int32_t cbuf[DIA_MAXD];
       MFEM_CHECK_HIP(hipMemcpyAsync(cbuf, A->colidx + (rp[0] - A->index_base), sizeof(int32_t) * len, hipMemcpyDeviceToHost, ctx->stream));
       MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));

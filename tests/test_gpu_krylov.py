@@ -263,3 +263,56 @@ def test_solver_layout_inspector(mf):
         finally:
             _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
     assert np.abs(res[1] - res[0]).max() <= 1e-10 * np.abs(res[0]).max()
+
+
+@pytest.mark.parametrize("rp_dtype,base", [("int32", 1), ("int64", 1), ("int32", 0)])
+def test_slot_major_layouts_on_caller_supplied_csr(mf, rp_dtype, base):
+    """The reference hands CUSPARSE a 1-based Int32 CSR (04_GPU_Utils.jl:131).  A lattice matrix supplied that way takes the
+    diagonal-slotted layout, a randomly perturbed (but still near-uniform) pattern the explicit-column layout; both solve
+    like scipy."""
+    import ctypes as C
+
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import torch
+    from metafem_jl_amd import _lib
+
+    m = 28
+    n = m ** 3
+    idx = np.arange(n).reshape(m, m, m)
+    rows, cols, vals = [], [], []
+    rng = np.random.default_rng(0)
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for dk in (-1, 0, 1):
+                src = idx[max(0, -di):m - max(0, di), max(0, -dj):m - max(0, dj), max(0, -dk):m - max(0, dk)]
+                dst = idx[max(0, di):m - max(0, -di), max(0, dj):m - max(0, -dj), max(0, dk):m - max(0, -dk)]
+                rows.append(src.ravel()); cols.append(dst.ravel())
+                vals.append(np.full(src.size, 30.0 if (di, dj, dk) == (0, 0, 0) else -1.0 + 0.2 * rng.random(src.size)))
+    M = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    M.sort_indices()
+    b = rng.standard_normal(n)
+    for perturb in (False, True):
+        A_ = M.copy()
+        if perturb:  # swap one neighbour of every 7th row for a far column: rows stay 27 long but leave the diagonals
+            A_ = A_.tolil()
+            for r in range(0, n, 7):
+                c_old = A_.rows[r][0]
+                c_new = (r + n // 2) % n
+                if c_new not in A_.rows[r]:
+                    A_[r, c_new] = A_[r, c_old]
+                    A_[r, c_old] = 0.0
+            A_ = A_.tocsr()
+            A_.eliminate_zeros()
+            A_.sort_indices()
+        ref = spl.spsolve(A_.tocsc(), b)
+        rp = torch.tensor(A_.indptr + base, dtype=getattr(torch, rp_dtype), device="cuda")
+        ci = torch.tensor(A_.indices + base, dtype=torch.int32, device="cuda")
+        A = mf.FEM_SpMat_CSR(rp, ci, n, index_base=base)
+        mode = C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(A.ctx._h, A._h, C.byref(mode), None, None, None))
+        assert mode.value == (1 if perturb else 2)
+        x, st = mf.iterative_Solve(A, torch.tensor(A_.data, device="cuda"), torch.tensor(b, device="cuda"),
+                                   1e-12 * float(np.linalg.norm(b) / np.sqrt(n)), Sv_func=mf.bicgstabl_GS_, maxiter=500, max_pass=5, s=2)
+        assert st.converged == 1
+        assert np.abs(x.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
