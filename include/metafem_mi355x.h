@@ -97,8 +97,9 @@ int mfem_debug_set_hex27(int two_pass);
 /* Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
  *   mode 0  the CSR tile kernel (irregular rows, e.g. hex-27)
  *   mode 1  slot-major padded copy of the working values + explicit columns (rows of near-uniform length)
- *   mode 2  as 1, and 128-row blocks whose entries all sit on <= 32 common diagonals store their values by diagonal and
- *           do not read columns at all (any lattice stencil; detected from the CSR pattern, nothing is assumed)
+ *   mode 2  as 1, and 128-row blocks whose entries all sit on a common list of <= 96 diagonals store their values by
+ *           diagonal and do not read columns at all (any lattice stencil; up to 4 lists, e.g. one per row field of a
+ *           field-major multi-field matrix; detected from the CSR pattern, nothing is assumed)
  * The copy is made once per solve from the caller's CSR-ordered values, like the reference's K_total[K_val_ids] gather
  * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks. */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,

@@ -102,8 +102,8 @@ struct mfem_csr_s {
   const double* ell_src;    // the CSR-ordered values the bound copy mirrors (identity of the `vals` argument)
   double* ell_vals;         // not owned (solver workspace), [K][npad]
   // diagonal-slotted variant (all entries on <= 32 diagonals): dia_state 0 = not inspected, -1 = no, 1 = yes
-  int dia_state, dia_D;
-  int32_t dia_off[32];
+  int dia_state, dia_classes;
+  void* dia_dev;            // owned, device copy of the diagonal lists (DiaOffsets, spmv_ell.hip)
   int32_t* dia_flags;       // owned, one int per 128-row block: 1 = regular (diagonal-slotted), 0 = explicit columns
   int32_t dia_regular_blocks;
   int dia_triples;          // the diagonals come in runs of three consecutive offsets

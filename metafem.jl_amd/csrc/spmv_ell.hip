@@ -179,42 +179,51 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
 // entries off the diagonal list (ghost columns of a slab) stay on the generic slot-major path with explicit columns.
 // The detection is an inspection of the caller's CSR pattern; nothing about the mesh is assumed.
 // ---------------------------------------------------------------------------------------------------------------
-#define DIA_MAXD 32
+// Several diagonal lists ("classes") may coexist: a 3-field matrix in field-major numbering has one list per row field
+// ((g - f) * n_nodes + stencil offset).  Each regular block belongs to one class.
+#define DIA_MAXD 96
+#define DIA_MAXC 4
 struct DiaOffsets {
-  int D;
-  int32_t off[DIA_MAXD];
+  int ncls;
+  int D[DIA_MAXC];
+  int32_t off[DIA_MAXC][DIA_MAXD];
 };
 
-// candidate offsets = the diagonals of one (longest) row.  flags[b] = 1 when every row of the 128-row block b is regular:
-// all its entries sit on listed diagonals and r + off[s] is a valid x index for EVERY listed diagonal (so the kernel may
-// load x there even where the row has no entry).  nreg counts the regular blocks.
+// flags[b] = c + 1 when every row of the 128-row block b is regular for class c: all its entries sit on the class's
+// diagonals and r + off[s] is a valid x index for EVERY listed diagonal (so the kernel may load x there even where the
+// row has no entry); 0 otherwise.  nreg counts the regular blocks.
 template <typename RP>
 __global__ __launch_bounds__(128) void k_dia_flags(int64_t n, int64_t nx, const RP* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ col, int base, DiaOffsets O,
-                                                     int32_t* __restrict__ flags, int32_t* __restrict__ nreg) {
-  __shared__ int bad;
+                                                     const int32_t* __restrict__ col, int base,
+                                                     const DiaOffsets* __restrict__ Op, int32_t* __restrict__ flags,
+                                                     int32_t* __restrict__ nreg) {
+  const DiaOffsets& O = *Op;
+  __shared__ int ok_mask;
   for (int64_t blk = blockIdx.x; blk * 128 < n; blk += gridDim.x) {
-    if (threadIdx.x == 0) bad = 0;
+    if (threadIdx.x == 0) ok_mask = (1 << O.ncls) - 1;
     __syncthreads();
     const int64_t r = blk * 128 + threadIdx.x;
-    int fail = 0;
+    int mask = 0;
     if (r < n) {
-      if (r + O.off[0] < 0 || r + O.off[O.D - 1] >= nx) fail = 1;
       const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
-      int s = 0;
-      for (int64_t j = lo; j < hi && !fail; ++j) {  // columns ascending, offsets ascending: merge
-        const int64_t d = (int64_t)col[j] - base - r;
-        while (s < O.D && O.off[s] < d) ++s;
-        if (s == O.D || O.off[s] != d) fail = 1;
+      for (int c = 0; c < O.ncls; ++c) {
+        const int D = O.D[c];
+        bool ok = r + O.off[c][0] >= 0 && r + O.off[c][D - 1] < nx;
+        int s = 0;
+        for (int64_t j = lo; j < hi && ok; ++j) {  // columns ascending, offsets ascending: merge
+          const int64_t d = (int64_t)col[j] - base - r;
+          while (s < D && O.off[c][s] < d) ++s;
+          if (s == D || O.off[c][s] != d) ok = false;
+        }
+        if (ok) mask |= 1 << c;
       }
-    } else {
-      fail = 1;  // partial last block: generic path
-    }
-    if (fail) bad = 1;
+    }  // rows past n (partial last block): mask 0 -> generic path
+    atomicAnd(&ok_mask, mask);
     __syncthreads();
     if (threadIdx.x == 0) {
-      flags[blk] = bad ? 0 : 1;
-      if (!bad) atomicAdd(nreg, 1);
+      const int m = ok_mask;
+      flags[blk] = m ? __ffs(m) : 0;
+      if (m) atomicAdd(nreg, 1);
     }
     __syncthreads();
   }
@@ -224,12 +233,13 @@ __global__ __launch_bounds__(128) void k_dia_flags(int64_t n, int64_t nx, const 
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
-                                                           int base, DiaOffsets O, const int32_t* __restrict__ flags,
-                                                           double* __restrict__ out) {
+                                                           int base, const DiaOffsets* __restrict__ Op,
+                                                           const int32_t* __restrict__ flags, double* __restrict__ out) {
+  const DiaOffsets& O = *Op;
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  double* T = lds + (size_t)w * 64 * O.D;
-  int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * 64 * O.D) + (size_t)w * 64 * O.D;
+  double* T = lds + (size_t)w * 64 * K;
+  int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * 64 * K) + (size_t)w * 64 * K;
   const int64_t ntiles = npad >> 6;
   for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
     const int64_t r0 = tile << 6, r = r0 + lane;
@@ -249,11 +259,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int off0 = (int)(lo - s0);
-    if (flags[tile >> 1]) {  // regular 128-row block: slot s = diagonal s
+    const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> 1]) - 1;
+    if (cls >= 0) {  // regular 128-row block of class cls: slot s = diagonal s
       int j = 0;
-      for (int s = 0; s < O.D; ++s) {
+      const int D = O.D[cls];
+      for (int s = 0; s < D; ++s) {
         double v = 0.0;
-        if (j < len && (int64_t)Tc[off0 + j] - r == O.off[s]) {
+        if (j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][s]) {
           v = T[off0 + j];
           ++j;
         }
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
 typedef double u_d2 __attribute__((ext_vector_type(2), aligned(8)));
 // lane <-> RPT (2 or 4) neighbouring rows; a wave covers one aligned block of 64 RPT rows; U diagonals per batch
 template <int RPT, int U, bool TRIPLES = false>
-__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad, int K, DiaOffsets O,
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
                                                            const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
@@ -277,6 +289,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
                                                            const int32_t* __restrict__ done_flag) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
+  const DiaOffsets& O = *Op;
   double dot_acc = 0.0;
   constexpr int H = RPT / 2;  // 16-byte pairs per lane
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
@@ -287,16 +300,19 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
     for (int h = 0; h < H; ++h) acc[h] = (e_d2){0.0, 0.0};
     // the wave's rows [b0, b0 + 64 RPT) are RPT / 2 aligned 128-row blocks: regular only if all of them are (wave-uniform)
     const int64_t blk = r / (64 * RPT) * (RPT / 2);
-    bool interior = flags[blk] != 0;
-    if (RPT == 4) interior = interior && ((blk + 1) * 128 < npad) && flags[blk + 1] != 0;
+    const int cls = __builtin_amdgcn_readfirstlane(flags[blk]) - 1;  // wave-uniform: keeps the offset reads scalar
+    bool interior = cls >= 0;
+    if (RPT == 4) interior = interior && ((blk + 1) * 128 < npad) && flags[blk + 1] == cls + 1;
+    const int32_t* off = O.off[cls < 0 ? 0 : cls];
+    const int D = O.D[cls < 0 ? 0 : cls];
     if (interior && TRIPLES && RPT == 2) {
       // the diagonals come in runs of three consecutive offsets (o - 1, o, o + 1: the fastest lattice direction): the two
       // rows of the lane need x[r + o - 1 .. r + o + 2] for the whole run -- two 16-byte loads instead of three
-      for (int s = 0; s < O.D; s += 3) {
+      for (int s = 0; s < D; s += 3) {
         const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
         const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
         const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
-        const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + O.off[s]);
+        const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
         const u_d2 xa = xp[0], xb = xp[1];
         acc[0].x += va.x != 0.0 ? va.x * xa.x : 0.0;
         acc[0].y += va.y != 0.0 ? va.y * xa.y : 0.0;
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
       }
     } else if (interior) {
       int s = 0;
-      for (; s + U <= O.D; s += U) {
+      for (; s + U <= D; s += U) {
         e_d2 vv[U][H];
         u_d2 xx[U][H];
 #pragma unroll
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             vv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + u) * ELL_B) + h);
-            xx[u][h] = *(reinterpret_cast<const u_d2*>(x + r + O.off[s + u]) + h);
+            xx[u][h] = *(reinterpret_cast<const u_d2*>(x + r + off[s + u]) + h);
           }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -326,11 +342,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
             acc[h].y += vv[u][h].y != 0.0 ? vv[u][h].y * xx[u][h].y : 0.0;
           }
       }
-      for (; s < O.D; ++s)
+      for (; s < D; ++s)
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
-          const u_d2 xx = *(reinterpret_cast<const u_d2*>(x + r + O.off[s]) + h);
+          const u_d2 xx = *(reinterpret_cast<const u_d2*>(x + r + off[s]) + h);
           acc[h].x += vv.x != 0.0 ? vv.x * xx.x : 0.0;
           acc[h].y += vv.y != 0.0 ? vv.y * xx.y : 0.0;
         }
@@ -390,15 +406,17 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   A->ell_K = K;
   A->ell_npad = npad;
   A->ell_state = 1;
-  // diagonal structure?  candidate diagonals = those of the middle row; per-128-row-block flags say where they hold
+  // diagonal structure?  Candidate diagonal lists come from full-length rows sampled in 8 windows along the matrix (a
+  // field-major multi-field matrix has one list per field); per-128-row-block flags say which list, if any, a block obeys.
   A->dia_state = -1;
   if (K <= DIA_MAXD) {
-    // candidate = the first full-length row in a window around the middle of the matrix
-    int64_t rp[2] = {0, 0};
-    int64_t rm = -1;
-    {
-      const int64_t w0 = A->n / 2 > 2048 ? A->n / 2 - 2048 : 0;
-      const int64_t wn = (A->n - w0) < 4096 ? (A->n - w0) : 4096;  // rows in the window
+    DiaOffsets O;
+    memset(&O, 0, sizeof(O));
+    for (int wdw = 0; wdw < 8 && O.ncls < DIA_MAXC; ++wdw) {
+      const int64_t centre = A->n * (2 * wdw + 1) / 16;
+      const int64_t w0 = centre > 1024 ? centre - 1024 : 0;
+      const int64_t wn = (A->n - w0) < 2048 ? (A->n - w0) : 2048;  // rows in the window
+      if (wn <= 0) continue;
       std::vector<int64_t> win((size_t)wn + 1);
       if (A->rowptr_bits == 64) {
         MFEM_CHECK_HIP(hipMemcpyAsync(win.data(), (const char*)A->rowptr + w0 * 8, (size_t)(wn + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -409,49 +427,55 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
         MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         for (int64_t i = 0; i <= wn; ++i) win[(size_t)i] = w32[(size_t)i];
       }
-      for (int64_t i = 0; i < wn; ++i)
-        if (win[(size_t)i + 1] - win[(size_t)i] == K) {
-          rm = w0 + i;
-          rp[0] = win[(size_t)i];
-          rp[1] = win[(size_t)i + 1];
-          break;
-        }
-    }
-    const int len = (int)(rp[1] - rp[0]);
-    if (rm >= 0 && len == K) {
+      int64_t rm = -1;
+      for (int64_t i = 0; i < wn && rm < 0; ++i)
+        if (win[(size_t)i + 1] - win[(size_t)i] == K) rm = i;
+      if (rm < 0) continue;
       int32_t cbuf[DIA_MAXD];
-      MFEM_CHECK_HIP(hipMemcpyAsync(cbuf, A->colidx + (rp[0] - A->index_base), sizeof(int32_t) * len, hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipMemcpyAsync(cbuf, A->colidx + (win[(size_t)rm] - A->index_base), sizeof(int32_t) * K, hipMemcpyDeviceToHost, ctx->stream));
       MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-      DiaOffsets O;
-      O.D = len;
-      for (int i = 0; i < len; ++i) O.off[i] = (int32_t)((int64_t)cbuf[i] - A->index_base - rm);
-      const int64_t nblk = (npad / 64 + 1) / 2;
+      int32_t cand[DIA_MAXD];
+      for (int i = 0; i < K; ++i) cand[i] = (int32_t)((int64_t)cbuf[i] - A->index_base - (w0 + rm));
+      bool seen = false;
+      for (int c = 0; c < O.ncls && !seen; ++c) seen = memcmp(O.off[c], cand, sizeof(int32_t) * K) == 0;
+      if (!seen) {
+        memcpy(O.off[O.ncls], cand, sizeof(int32_t) * K);
+        O.D[O.ncls] = K;
+        ++O.ncls;
+      }
+    }
+    if (O.ncls > 0) {
+      const int64_t nblk = npad / ELL_B;
       const int64_t nx = A->n + (ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0);  // length of the local x
       MFEM_CHECK_HIP(hipMalloc(&A->dia_flags, sizeof(int32_t) * (size_t)nblk));
+      MFEM_CHECK_HIP(hipMalloc(&A->dia_dev, sizeof(DiaOffsets)));
+      MFEM_CHECK_HIP(hipMemcpyAsync(A->dia_dev, &O, sizeof(DiaOffsets), hipMemcpyHostToDevice, ctx->stream));
       MFEM_CHECK_HIP(hipMemsetAsync(A->dia_flags, 0, sizeof(int32_t) * (size_t)nblk, ctx->stream));
       int32_t* d_cnt = ctx->d_flags + 9;
       MFEM_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
       const int g2 = (int)(nblk < (int64_t)ctx->num_cus * 64 ? nblk : (int64_t)ctx->num_cus * 64);
       if (A->rowptr_bits == 64)
         hipLaunchKernelGGL(k_dia_flags<int64_t>, dim3(g2), dim3(128), 0, ctx->stream, A->n, nx, (const int64_t*)A->rowptr, A->colidx,
-                           A->index_base, O, A->dia_flags, d_cnt);
+                           A->index_base, (const DiaOffsets*)A->dia_dev, A->dia_flags, d_cnt);
       else
         hipLaunchKernelGGL(k_dia_flags<int32_t>, dim3(g2), dim3(128), 0, ctx->stream, A->n, nx, (const int32_t*)A->rowptr, A->colidx,
-                           A->index_base, O, A->dia_flags, d_cnt);
+                           A->index_base, (const DiaOffsets*)A->dia_dev, A->dia_flags, d_cnt);
       MFEM_CHECK_LAUNCH();
       MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // also orders the H2D copy of the stack object O
       if ((double)ctx->h_flags[9] >= 0.8 * (double)nblk) {  // worth it when most blocks take the diagonal path
         A->dia_state = 1;
-        A->dia_D = len;
+        A->dia_classes = O.ncls;
         A->dia_regular_blocks = ctx->h_flags[9];
-        A->dia_triples = (len % 3 == 0);
-        for (int i = 0; i + 2 < len && A->dia_triples; i += 3)
-          if (O.off[i + 1] != O.off[i] + 1 || O.off[i + 2] != O.off[i] + 2) A->dia_triples = 0;
-        for (int i = 0; i < len; ++i) A->dia_off[i] = O.off[i];
+        A->dia_triples = (K % 3 == 0);
+        for (int c = 0; c < O.ncls && A->dia_triples; ++c)
+          for (int i = 0; i + 2 < K && A->dia_triples; i += 3)
+            if (O.off[c][i + 1] != O.off[c][i] + 1 || O.off[c][i + 2] != O.off[c][i] + 2) A->dia_triples = 0;
       } else {
         hipFree(A->dia_flags);
+        hipFree(A->dia_dev);
         A->dia_flags = nullptr;
+        A->dia_dev = nullptr;
       }
     }
   }
@@ -469,9 +493,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   A->ell_bound_mode = 0;
   if (A->ell_state != 1 || !g_ell_enable || !buf) return MFEM_OK;
   if (A->dia_state == 1 && g_dia_enable) {
-    DiaOffsets O;
-    O.D = A->dia_D;
-    for (int i = 0; i < O.D; ++i) O.off[i] = A->dia_off[i];
+    const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
     int wv = 4;
     while (wv > 1 && 12 * 64 * (size_t)A->ell_K * wv > 64 * 1024) wv >>= 1;
     const size_t ldsb = 12 * 64 * (size_t)A->ell_K * wv;  // 8 B value + 4 B column per staged entry (<= 64 K per tile)
@@ -518,8 +540,10 @@ void mfem_ell_unbind(mfem_csr_s* A) {
 void mfem_ell_free(mfem_csr_s* A) {
   if (A->ell_cols) hipFree(A->ell_cols);
   if (A->dia_flags) hipFree(A->dia_flags);
+  if (A->dia_dev) hipFree(A->dia_dev);
   A->ell_cols = nullptr;
   A->dia_flags = nullptr;
+  A->dia_dev = nullptr;
   A->ell_state = 0;
   A->dia_state = 0;
 }
@@ -531,9 +555,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   int cap = ctx->num_cus * g_ell_grid_mult;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   if (A->ell_bound_mode == 2) {
-    DiaOffsets O;
-    O.D = A->dia_D;
-    for (int i = 0; i < O.D; ++i) O.off[i] = A->dia_off[i];
+    const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
     const int drpt = (g_dia_variant >= 4) ? 4 : 2;
     const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
 #define LAUNCH_DIA(RPT, U)                                                                                                \
