@@ -104,6 +104,9 @@ int mfem_debug_set_hex27(int two_pass);
  * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks. */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
                            int64_t* regular_rows);
+/* y = alpha A x + beta y through that layout, conversion of `vals` included (diagnostic: what the Krylov loop computes). */
+int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
+                            double beta);
 /* bit 0: slot-major copies on/off; bit 1: never use diagonal slots; bits 4-7 / 16-19: kernel variants; bits 8-15: workgroups per CU */
 int mfem_debug_set_ell(int enable);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)

@@ -463,7 +463,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
       MFEM_CHECK_LAUNCH();
       MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
       MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // also orders the H2D copy of the stack object O
-      if ((double)ctx->h_flags[9] >= 0.8 * (double)nblk) {  // worth it when most blocks take the diagonal path
+      if ((double)ctx->h_flags[9] >= 0.5 * (double)nblk) {  // the other blocks run the explicit-column loop, as in mode 1
         A->dia_state = 1;
         A->dia_classes = O.ncls;
         A->dia_regular_blocks = ctx->h_flags[9];
@@ -621,4 +621,25 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
   if (padded_rows) *padded_rows = m ? A->ell_npad : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
+}
+
+// y = alpha A x + beta y through the layout mfem_solve would use for this pattern (the one-off conversion of `vals` included):
+// a test / diagnostic entry point -- production SpMVs of caller-supplied values go through mfem_spmv_csr.
+extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
+                                       double beta) {
+  MFEM_REQUIRE(ctx && A, "null handle");
+  MFEM_REQUIRE(A->n == 0 || (x && y && (A->nnz == 0 || vals)), "null vector");
+  if (A->n == 0) return MFEM_OK;
+  int rc = mfem_ell_plan(ctx, A);
+  if (rc) return rc;
+  const size_t bytes = mfem_ell_vals_bytes(A);
+  if (bytes) {
+    rc = mfem_ws_reserve(ctx, bytes);
+    if (rc) return rc;
+    rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws);
+    if (rc) return rc;
+  }
+  rc = mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr, nullptr);
+  mfem_ell_unbind(A);
+  return rc;
 }

@@ -126,3 +126,35 @@ def test_rccl_world1_solve_equals_plain_solve(mf):
         assert torch.equal(x, ref)
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 9), (9, 21), (21, 33)])
+def test_solver_layout_spmv_on_slabs_with_ghost_columns(mf, lo, hi):
+    """The layout mfem_solve runs its SpMVs on (diagonal-slotted blocks + explicit-column blocks for the planes that touch
+    ghost columns) against the CSR kernel on a first, a middle and a last slab of a 32 x 24 x 24 brick: the middle slab
+    has ghost planes on both sides, the layout every rank except the two end ranks of a multi-GPU run uses."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib, parallel as par
+
+    n = (32, 24, 24)
+    m1, m2 = n[1] + 1, n[2] + 1
+    sb = mf.make_Brick((2.0, 1.0, 1.0), n)
+    sb.set_slab(lo, hi)
+    A = sb.pattern(1)
+    K = sb.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    nloc = par.local_vector_length(lo, hi, m1, m2, 1)
+    x = mf.FEM_rand(nloc, 3, 0) - 0.5
+    mode, reg = C.c_int32(), C.c_int64()
+    _lib.check(_lib.lib.mfem_csr_solver_layout(sb.ctx._h, A._h, C.byref(mode), None, None, C.byref(reg)))
+    assert mode.value == 2 and 0 < reg.value < A.n  # the planes next to a ghost plane stay on explicit columns
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(sb.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+    assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+    # alpha / beta form
+    y2 = y0.clone()
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(sb.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y2.data_ptr(), -0.5, 2.0))
+    assert float((y2 - 1.5 * y0).abs().max()) <= 1e-12 * float(y0.abs().max())
