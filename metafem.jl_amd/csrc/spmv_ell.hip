@@ -210,8 +210,11 @@ __global__ __launch_bounds__(128) void k_dia_flags(int64_t n, int64_t nx, const 
         const int D = O.D[c];
         bool ok = r + O.off[c][0] >= 0 && r + O.off[c][D - 1] < nx;
         int s = 0;
-        for (int64_t j = lo; j < hi && ok; ++j) {  // columns ascending, offsets ascending: merge
+        int64_t last = INT64_MIN;
+        for (int64_t j = lo; j < hi && ok; ++j) {  // columns strictly ascending, offsets ascending: merge
           const int64_t d = (int64_t)col[j] - base - r;
+          if (d <= last) ok = false;  // unsorted or duplicate columns: only the explicit-column path sums every entry
+          last = d;
           while (s < D && O.off[c][s] < d) ++s;
           if (s == D || O.off[c][s] != d) ok = false;
         }
