@@ -113,6 +113,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
 int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);
 void mfem_ell_unbind(mfem_csr_s* A);
+int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d);
 void mfem_ell_free(mfem_csr_s* A);
 int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);

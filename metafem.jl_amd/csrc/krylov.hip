@@ -442,11 +442,27 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   MFEM_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   MFEM_CHECK_HIP(hipMemcpyAsync(V.b, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
 
+  struct EllGuard {  // whatever gets bound below is released on every way out of this function
+    mfem_csr_s* A;
+    ~EllGuard() { mfem_ell_unbind(A); }
+  } ell_guard{A};
+
   // Pr = Pr_func!(A)   (02_Preconditioner.jl:38, 103-120)
   V.dinv = nullptr;
+  bool ell_bound = false;
   if (jac) {
     if (o->precond == MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !is_cg) {
       rc = mfem_jacobi2_by_column(ctx, A, vals_work, V.d);
+    } else if (is_cg && ell_bytes) {
+      // CG does not scale the matrix: transpose first and read |diag| from the copy (n values instead of all nonzeros)
+      rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+      if (!rc && A->ell_vals) {
+        ell_bound = true;
+        rc = mfem_ell_diag(ctx, A, V.d);
+      } else if (!rc) {
+        rc = mfem_fill(ctx, n, 1.0, V.d);
+        if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
+      }
     } else {
       rc = mfem_fill(ctx, n, 1.0, V.d);
       if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
@@ -483,15 +499,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   }
 
   // bind the slot-major copy: every mfem_spmv_launch(A, vals_work, ...) below runs the ELL kernel
-  if (ell_bytes) {
+  if (ell_bytes && !ell_bound) {
     rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
     if (rc) return rc;
   }
-  struct EllGuard {
-    mfem_csr_s* A;
-    ~EllGuard() { mfem_ell_unbind(A); }
-  } ell_guard{A};
-
   int64_t n_global = n;
   if (ctx->comm) {
     ctx->h_scalars[S_TMP0] = (double)n;

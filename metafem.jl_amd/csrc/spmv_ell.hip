@@ -80,7 +80,19 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals_lds(int64_t n, int64_t 
     }
     const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
     const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= 64 K
-    for (int i = lane; i < cnt; i += 64) T[i] = vals[s0 + i];
+    for (int i0 = lane; i0 < cnt; i0 += 64 * 8) {
+      double tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        tv[u] = i < cnt ? vals[s0 + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < cnt) T[i] = tv[u];
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int off = (int)(lo - s0);
@@ -255,9 +267,24 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     }
     const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
     const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= 64 D
-    for (int i = lane; i < cnt; i += 64) {
-      T[i] = vals[s0 + i];
-      Tc[i] = col[s0 + i] - base;
+    // staging: all loads of a lane are issued before the first LDS store (cnt <= 64 K: a handful of batches of 8)
+    for (int i0 = lane; i0 < cnt; i0 += 64 * 8) {
+      double tv[8];
+      int32_t tc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        tv[u] = i < cnt ? vals[s0 + i] : 0.0;
+        tc[u] = i < cnt ? col[s0 + i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < cnt) {
+          T[i] = tv[u];
+          Tc[i] = tc[u] - base;
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -531,6 +558,45 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   A->ell_vals = buf;
   A->ell_src = vals;
   A->ell_bound_mode = 1;
+  return MFEM_OK;
+}
+
+// d[r] = |A_rr| read from the bound slot-major copy (n values instead of a scan of all nonzeros); rows without a stored
+// diagonal keep 1.0 (Jacobi_By_Diagonal, 02_Preconditioner.jl:122-130)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_ell_diag(int64_t n, int K, const DiaOffsets* __restrict__ Op,
+                                                           const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
+                                                           const double* __restrict__ vals, double* __restrict__ d) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
+    const int64_t b = ell_base(r, K);
+    const int cls = flags ? flags[r >> 7] - 1 : -1;
+    double out = 1.0;
+    if (cls >= 0) {
+      const int D = Op->D[cls];
+      for (int s = 0; s < D; ++s)
+        if (Op->off[cls][s] == 0) {
+          const double v = vals[b + s * ELL_B];
+          if (v != 0.0) out = fabs(v);
+          break;
+        }
+    } else {
+      for (int s = 0; s < K; ++s)
+        if (cols[b + s * ELL_B] == (int32_t)r) {
+          const double v = vals[b + s * ELL_B];
+          if (v != 0.0) out = fabs(v);  // a padding slot (col = self, value 0) is not a stored diagonal
+          break;
+        }
+    }
+    d[r] = out;
+  }
+}
+
+int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d) {
+  if (!A->ell_vals) return MFEM_ERR_INVALID;
+  const int grid = mfem_grid_for(A->n, MFEM_BLOCK, ctx->num_cus * 16);
+  hipLaunchKernelGGL(k_ell_diag, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_K, (const DiaOffsets*)A->dia_dev,
+                     A->ell_bound_mode == 2 ? A->dia_flags : nullptr, A->ell_cols, A->ell_vals, d);
+  MFEM_CHECK_LAUNCH();
   return MFEM_OK;
 }
 
