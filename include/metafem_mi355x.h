@@ -94,6 +94,9 @@ int mfem_debug_set_hex27(int two_pass);
 
 /* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */
+/* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
+ * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
+int mfem_debug_set_elasticity(int variant);
 /* Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
  *   mode 0  the CSR tile kernel (irregular rows, e.g. hex-27)
  *   mode 1  slot-major padded copy of the working values + explicit columns (rows of near-uniform length)

@@ -532,6 +532,119 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, d
   }
 }
 
+// Same operator, one thread per (control point, adjacent element): a workgroup owns 32 consecutive control points, its
+// 256 threads integrate the 8 adjacent elements of each of them concurrently (the row-owner kernel above walks them one after
+// the other and read-modify-writes global memory 576 times per thread).  The three rows of a control point are accumulated
+// in LDS in eight ordered phases (element 0 .. 7: the same summation order as the row-owner kernel, so the results are bitwise
+// identical) and leave as contiguous runs, every CSR value written exactly once -- no memset, no atomics, no colours.
+#define EL2_NODES 32
+#define EL2_ROW 244  // 3 fields x 81 slots, padded
+__global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix_lds(BrickView B, double lam, double mu, double tau,
+                                                                        uint32_t penalty, int64_t T, double* __restrict__ vals) {
+  __shared__ double rows[EL2_NODES * EL2_ROW];
+  __shared__ int64_t s_pre[EL2_NODES];
+  __shared__ int32_t s_cn[EL2_NODES];
+  const int tid = threadIdx.x, nl = tid >> 3, e = tid & 7;
+  const int64_t node = (int64_t)blockIdx.x * EL2_NODES + nl;
+  const bool live = node < B.n_owned;
+  for (int t = tid; t < EL2_NODES * EL2_ROW; t += MFEM_BLOCK) rows[t] = 0.0;
+  int i = 0, j = 0, k = 0, li = 0, lj = 0, lk = 0, cj = 1, ck = 1, cn = 0;
+  if (live) {
+    node_ijk(B, node, i, j, k);
+    li = B.lo0[i]; lj = B.lo1[j]; lk = B.lo2[k];
+    cj = B.c1[j]; ck = B.c2[k];
+    cn = B.c0[i] * cj * ck;
+    if (e == 0) {
+      s_pre[nl] = brick_prefix(B, i, j, k);
+      s_cn[nl] = cn;
+    }
+  } else if (e == 0) {
+    s_pre[nl] = 0;
+    s_cn[nl] = 0;
+  }
+  const int ex = e & 1, ey = (e >> 1) & 1, ez = e >> 2;
+  const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
+  const bool valid = live && I >= 0 && I < B.ne0 && J >= 0 && J < B.ne1 && K >= 0 && K < B.ne2;
+  double G[8][3][3];
+  if (valid) {
+    const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
+    double X[8][3];
+    hex8_load_coords(B, I, J, K, X);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) G[b][s][t] = 0.0;
+    const int nq = B.ng * B.ng * B.ng;
+    for (int q = 0; q < nq; ++q) {
+      double g[8][3];
+      const double wd = hex8_geom(X, q, g);
+      double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool me = (b == a);
+        ga[0] = me ? g[b][0] : ga[0];
+        ga[1] = me ? g[b][1] : ga[1];
+        ga[2] = me ? g[b][2] : ga[2];
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) G[b][s][t] += wd * ga[s] * g[b][t];
+    }
+  }
+  __syncthreads();
+  double* R = rows + nl * EL2_ROW;  // [field fi][block fk * cn + slot]
+  for (int ph = 0; ph < 8; ++ph) {
+    if (valid && e == ph) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
+        const int slot = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
+        const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+          for (int fk = 0; fk < 3; ++fk) {
+            double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
+            if (fi == fk) v += mu * tr;
+            R[fi * 81 + fk * cn + slot] -= v;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (live && e == 0 && tau != 0.0 && penalty != 0u) {
+    visit_boundary_faces(B, i, j, k, penalty, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
+      double mab[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int q = 0; q < B.ng * B.ng; ++q) {
+        const double ws = face_geom(Xf, q, side == 0, nullptr);
+        double na = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) na = (c == ca) ? c_fN[q][c] : na;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mab[c] += ws * na * c_fN[q][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int slot = ((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk);
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) R[fi * 81 + fi * cn + slot] -= tau * mab[c];
+      }
+    });
+  }
+  __syncthreads();
+  // write-out: row (f, node) = 3 cn contiguous values at f * 3 T + 3 pre(node)
+  for (int idx = tid; idx < EL2_NODES * 243; idx += MFEM_BLOCK) {
+    const int n2 = idx / 243, rem = idx - n2 * 243, f = rem / 81, o = rem - f * 81;
+    const int c3 = 3 * s_cn[n2];
+    if (o < c3) vals[(int64_t)f * 3 * T + 3 * s_pre[n2] + o] = rows[n2 * EL2_ROW + f * 81 + o];
+  }
+}
+
 // Residual at x_star (matrix-free):
 //   R[(i,a)] = -sum_q w sigma_ij(u) d_jN_a + sum_q w^s N_a [ tau (0 - u_i) |penalty faces + sig_ij n_j |traction faces ]
 __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_residual(BrickView B, double lam, double mu, double tau,
@@ -662,6 +775,12 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
   return MFEM_OK;
 }
 
+static int g_elasticity_variant = 0;  // 1: the row-owner kernel with in-place global accumulation (kept for comparison)
+extern "C" int mfem_debug_set_elasticity(int variant) {
+  g_elasticity_variant = variant ? 1 : 0;
+  return MFEM_OK;
+}
+
 extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_elasticity_params* p,
                                               double* vals) {
   MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
@@ -671,6 +790,13 @@ extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mf
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 3);
   const int64_t T = A->nnz / 9;
+  if (g_elasticity_variant == 0) {  // one thread per (control point, element), rows accumulated in LDS, written once
+    const int grid = (int)((m->n_owned + EL2_NODES - 1) / EL2_NODES);
+    hipLaunchKernelGGL(k_elasticity_matrix_lds, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,
+                       p->penalty_faces, T, vals);
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  }
   MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)A->nnz, ctx->stream));
   const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
   hipLaunchKernelGGL(k_elasticity_matrix, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,

@@ -19,7 +19,12 @@ E, nu = 1.0, 0.3
 lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
 K = torch.empty(A.nnz, dtype=torch.float64, device="cuda")
 print(f"C3 N={N} n={A.n} nnz={A.nnz}")
-print(f"assemble elasticity {timeit(lambda: brick.assemble_elasticity(A, lam, mu, 1000.0 * E, mf.FACE_BITS['x0'], out=K)):.2f} ms")
+for var in (1, 0):
+    _lib.lib.mfem_debug_set_elasticity(var)
+    ms = timeit(lambda: brick.assemble_elasticity(A, lam, mu, 1000.0 * E, mf.FACE_BITS['x0'], out=K))
+    print(f"assemble elasticity ({'row-owner, global accumulation' if var else 'thread per (node, element), LDS rows'}) {ms:.2f} ms = {A.nnz*8/ms/1e6:.0f} GB/s of nnz*8")
+    if var: K1 = K.clone()
+print("variants bitwise equal:", bool(torch.equal(K1, K)))
 b = mf.FEM_rand(A.n, 1, 0) - 0.5
 bytes_csr = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
 x = torch.empty_like(b)
