@@ -29,6 +29,7 @@ static int g_dia_enable = 1;
 // 0 (default): 2 rows x 3 diagonals, sharing the x loads of a run of three consecutive offsets when the diagonals come in such
 // runs; 8: 2 rows x3 without that sharing; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
 static int g_dia_variant = 0;
+static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
 // workgroup counts that are not fully resident (10, 12 per CU) lose 15 %.
@@ -38,6 +39,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_ell_enable = enable & 1;
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
   g_dia_variant = (enable >> 16) & 15;
+  g_dia_xcd = (enable >> 20) & 1;
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
   return MFEM_OK;
@@ -316,14 +318,26 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
                                                            const double* __restrict__ dotw, double* __restrict__ partials,
-                                                           const int32_t* __restrict__ done_flag) {
+                                                           const int32_t* __restrict__ done_flag, int xcd) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   const DiaOffsets& O = *Op;
   double dot_acc = 0.0;
   constexpr int H = RPT / 2;  // 16-byte pairs per lane
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
-  for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * RPT; r < n; r += stride) {
+  // xcd > 0: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch); XCD x walks its own contiguous eighth of
+  // the rows, so the x window an L2 has to hold is an eighth of the vector instead of all of it
+  const int64_t rows_per_wg = (int64_t)blockDim.x * RPT;
+  const int64_t nchunks = (n + rows_per_wg - 1) / rows_per_wg;
+  int64_t chunk = blockIdx.x, chunk_end = nchunks, chunk_step = gridDim.x;
+  if (xcd > 0) {
+    const int64_t per = (nchunks + 7) / 8;
+    chunk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    chunk_end = ((blockIdx.x & 7) + 1) * per < nchunks ? ((blockIdx.x & 7) + 1) * per : nchunks;
+    chunk_step = gridDim.x >> 3;
+  }
+  for (; chunk < chunk_end; chunk += chunk_step) {
+    const int64_t r = chunk * rows_per_wg + (int64_t)threadIdx.x * RPT;
+    if (r >= n) continue;
     const double* v = vals + ell_base(r, K);
     e_d2 acc[H];
 #pragma unroll
@@ -629,7 +643,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
 #define LAUNCH_DIA(RPT, U)                                                                                                \
   hipLaunchKernelGGL((k_spmv_dia<RPT, U>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,          \
-                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag)
+                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd)
     switch (g_dia_variant) {
       case 1: LAUNCH_DIA(2, 2); break;
       case 3: LAUNCH_DIA(2, 9); break;
@@ -640,7 +654,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       case 7:
         if (A->dia_triples && g_dia_variant != 8) {
           hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag);
+                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd);
         } else {
           LAUNCH_DIA(2, 3);
         }
