@@ -211,6 +211,10 @@ def main():
                 "n_dof": n_global, "nnz_per_gpu": A.nnz, "cg_iters_per_step": args.iters,
                 "parallelism": "single GPU" if world == 1 else f"slab decomposition x{world} (RCCL halo + all-reduce)",
                 "solve_ms_per_step": solve_ms / args.steps,
+                # the two halves of the metric on their own (whole job, all ranks)
+                "assembly_ms_per_step": elapsed / args.steps * 1e3 - solve_ms / args.steps,
+                "assembly_dof_per_s": n_global / max(elapsed / args.steps - solve_ms / args.steps * 1e-3, 1e-12),
+                "solve_dof_updates_per_s": n_global * args.iters / (solve_ms / args.steps * 1e-3),
             },
             "roofline": {
                 "kernel": kernel,
