@@ -98,11 +98,13 @@ int mfem_debug_set_hex27(int two_pass);
  * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
 int mfem_debug_set_elasticity(int variant);
 /* Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
- *   mode 0  the CSR tile kernel (irregular rows, e.g. hex-27)
+ *   mode 0  the CSR tile kernel (matrices with fewer than 128 rows, or mode 3 switched off)
  *   mode 1  slot-major padded copy of the working values + explicit columns (rows of near-uniform length)
  *   mode 2  as 1, and 128-row blocks whose entries all sit on a common list of <= 96 diagonals store their values by
  *           diagonal and do not read columns at all (any lattice stencil; up to 4 lists, e.g. one per row field of a
  *           field-major multi-field matrix; detected from the CSR pattern, nothing is assumed)
+ *   mode 3  rows of uneven length (hex-27, unstructured meshes): rows stably sorted by decreasing length, sliced ELL with
+ *           a slot count per 128-row block (SELL-128); y is written through the row permutation
  * The copy is made once per solve from the caller's CSR-ordered values, like the reference's K_total[K_val_ids] gather
  * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks. */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
@@ -110,6 +112,10 @@ int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t*
 /* y = alpha A x + beta y through that layout, conversion of `vals` included (diagnostic: what the Krylov loop computes). */
 int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
                             double beta);
+int mfem_debug_set_sell(int enable);
+/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems are
+ * launch-bound and stay on the CSR tile kernel.  Tests set both to 0. */
+int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);   /* mode 3 on/off (off: the CSR tile kernel runs the Krylov loop on such matrices) */
 /* bit 0: slot-major copies on/off; bit 1: never use diagonal slots; bits 4-7 / 16-19: kernel variants; bits 8-15: workgroups per CU */
 int mfem_debug_set_ell(int enable);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)

@@ -108,7 +108,22 @@ struct mfem_csr_s {
   int32_t dia_regular_blocks;
   int dia_triples;          // the diagonals come in runs of three consecutive offsets
   int ell_bound_mode;       // 0 none, 1 slot-major with explicit columns, 2 diagonal-slotted
+  // row-sorted sliced ELL for rows of uneven length (spmv_sell.hip): sell_state 0 = not planned, -1 = no, 1 = ready
+  int sell_state;
+  int64_t sell_total, sell_nblk;
+  int32_t* sell_rowid;      // owned: sorted position -> row
+  int64_t* sell_ptr;        // owned: [nblk + 1] start of each 128-row block in the sliced arrays
+  int32_t* sell_cols;       // owned, [sell_total], 0-based
+  const double* sell_src;
+  double* sell_vals;        // not owned (solver workspace), [sell_total]
 };
+int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A);
+size_t mfem_sell_vals_bytes(const mfem_csr_s* A);
+int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);
+void mfem_sell_unbind(mfem_csr_s* A);
+void mfem_sell_free(mfem_csr_s* A);
+int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
+                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
 int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);

@@ -260,7 +260,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   MFEM_CHECK_LAUNCH();
   const int check = o->check_every > 0 ? o->check_every : 32;
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
-  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int it = 0;
@@ -420,7 +420,13 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   if (rc_plan) return rc_plan;
   const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
   const size_t ell_bytes = mfem_ell_vals_bytes(A);
-  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes;
+  size_t sell_bytes = 0;
+  if (!ell_bytes && A->ell_state != 1) {  // rows of uneven length: row-sorted sliced layout
+    rc_plan = mfem_sell_plan(ctx, A);
+    if (rc_plan) return rc_plan;
+    sell_bytes = mfem_sell_vals_bytes(A);
+  }
+  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes + sell_bytes;
   int rc = mfem_ws_reserve(ctx, total);
   if (rc) return rc;
   char* base = (char*)ctx->ws;
@@ -444,7 +450,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
 
   struct EllGuard {  // whatever gets bound below is released on every way out of this function
     mfem_csr_s* A;
-    ~EllGuard() { mfem_ell_unbind(A); }
+    ~EllGuard() {
+      mfem_ell_unbind(A);
+      mfem_sell_unbind(A);
+    }
   } ell_guard{A};
 
   // Pr = Pr_func!(A)   (02_Preconditioner.jl:38, 103-120)
@@ -501,6 +510,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // bind the slot-major copy: every mfem_spmv_launch(A, vals_work, ...) below runs the ELL kernel
   if (ell_bytes && !ell_bound) {
     rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+    if (rc) return rc;
+  }
+  if (sell_bytes) {
+    rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
     if (rc) return rc;
   }
   int64_t n_global = n;

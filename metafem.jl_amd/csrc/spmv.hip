@@ -277,6 +277,7 @@ extern "C" int mfem_csr_destroy(mfem_csr A) {
   if (!A) return MFEM_OK;
   mfem_spmv_window_free(A);
   mfem_ell_free(A);
+  mfem_sell_free(A);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);
   if (A->owned_colidx) hipFree(A->owned_colidx);
   delete A;
@@ -321,6 +322,8 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   {
     const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
     if (e != 0) return e < 0 ? e : MFEM_OK;
+    const int sl = mfem_spmv_sell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
+    if (sl != 0) return sl < 0 ? sl : MFEM_OK;
     const int w = mfem_spmv_window_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
     if (w != 0) return w < 0 ? w : MFEM_OK;
   }

@@ -24,6 +24,17 @@
 #define ELL_B 128
 __host__ __device__ __forceinline__ int64_t ell_base(int64_t r, int K) { return (r >> 7) * ((int64_t)K * ELL_B) + (r & (ELL_B - 1)); }
 
+// Size thresholds: below them the Krylov loop is launch-bound and the CSR tile kernel, which spreads the nonzeros of few rows
+// over many lanes, is as fast or faster than a lane-per-row layout whose slots are walked one dependent batch after the other
+// (tools/probe_ell.py, tools/probe_small_solve.py: crossover ~3e5 rows with diagonal slots, ~1e6 rows with explicit columns).
+int64_t g_layout_min_rows_dia = 262144;
+int64_t g_layout_min_rows_cols = 1000000;
+extern "C" int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns) {
+  g_layout_min_rows_dia = diagonal_slots;
+  g_layout_min_rows_cols = explicit_columns;
+  return MFEM_OK;
+}
+
 static int g_ell_enable = 1;
 static int g_dia_enable = 1;
 // 0 (default): 2 rows x 3 diagonals, sharing the x loads of a run of three consecutive offsets when the diagonals come in such
@@ -433,6 +444,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
 // Decide eligibility and build the column table (once per pattern).  A->max_row_nnz must be known (mfem_csr_plan).
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->ell_state != 0) return MFEM_OK;
+  if (A->n < g_layout_min_rows_dia && A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes: CSR tile kernel
   A->ell_state = -1;
   const int K = A->max_row_nnz;
   if (A->n < 1 || K < 1 || K > 128) return MFEM_OK;
@@ -527,7 +539,10 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
 }
 
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
-  return (A->ell_state == 1 && g_ell_enable) ? sizeof(double) * (size_t)A->ell_K * (size_t)A->ell_npad : 0;
+  if (A->ell_state != 1 || !g_ell_enable) return 0;
+  const bool dia = A->dia_state == 1 && g_dia_enable;
+  if (A->n < (dia ? g_layout_min_rows_dia : g_layout_min_rows_cols)) return 0;
+  return sizeof(double) * (size_t)A->ell_K * (size_t)A->ell_npad;
 }
 
 // Transpose CSR-ordered values into `buf` and route subsequent mfem_spmv_launch calls with these `vals` to the ELL kernel.
@@ -698,10 +713,15 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
   int rc = mfem_ell_plan(ctx, A);
   if (rc) return rc;
   int m = 0;
-  if (A->ell_state == 1 && g_ell_enable) m = (A->dia_state == 1 && g_dia_enable) ? 2 : 1;
+  if (mfem_ell_vals_bytes(A)) m = (A->dia_state == 1 && g_dia_enable) ? 2 : 1;
+  if (m == 0 && !(A->ell_state == 1 && g_ell_enable)) {
+    rc = mfem_sell_plan(ctx, A);
+    if (rc) return rc;
+    if (mfem_sell_vals_bytes(A)) m = 3;
+  }
   if (mode) *mode = m;
-  if (slots) *slots = m ? A->ell_K : 0;
-  if (padded_rows) *padded_rows = m ? A->ell_npad : 0;
+  if (slots) *slots = (m == 1 || m == 2) ? A->ell_K : m == 3 ? A->max_row_nnz : 0;
+  if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
 }
@@ -721,8 +741,19 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     if (rc) return rc;
     rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws);
     if (rc) return rc;
+  } else {
+    rc = mfem_sell_plan(ctx, A);
+    if (rc) return rc;
+    const size_t sb = mfem_sell_vals_bytes(A);
+    if (sb) {
+      rc = mfem_ws_reserve(ctx, sb);
+      if (rc) return rc;
+      rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws);
+      if (rc) return rc;
+    }
   }
   rc = mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr, nullptr);
   mfem_ell_unbind(A);
+  mfem_sell_unbind(A);
   return rc;
 }

@@ -1,0 +1,253 @@
+// Row-sorted sliced ELL (SELL-128-sigma with sigma = n) for the Krylov loop on matrices whose rows are NOT of near-uniform
+// length -- hex-27 (27 / 45 / 75 / 125 entries per row depending on the node type) and every unstructured mesh.  Solver layout
+// mode 3; the uniform case is spmv_ell.hip (modes 1 and 2), the caller-facing contract stays CSR.
+//
+//   * inspector (once per pattern): rows are stably sorted by decreasing length (hipCUB radix sort of (max_len - len, row));
+//     rows of equal length keep their mesh order, so the x gathers of a 128-row block stay as local as in CSR order.  Block b
+//     stores K_b = its longest (= first) row's length slots, slot-major: element (row r', slot s) at ptr[b] + s * 128 + (r' & 127).
+//     Padding is what is left of length changes inside a block: 0.0-0.3 % for hex-27.
+//   * per solve: the working values are copied into that layout (one pass, like the reference's K_total[K_val_ids] gather).
+//   * SpMV: a wave owns a block, a lane two neighbouring sorted rows; value / column streams are unit-stride 16-byte / 8-byte
+//     loads, the row sum runs in registers in slot (= column) order, and y is written through the row permutation.
+#include <hipcub/hipcub.hpp>
+
+#include "blas1.h"
+
+#define SELL_B 128
+typedef double s_d2 __attribute__((ext_vector_type(2)));
+typedef int s_i2 __attribute__((ext_vector_type(2)));
+
+extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
+static int g_sell_enable = 1;
+extern "C" int mfem_debug_set_sell(int enable) {
+  g_sell_enable = enable ? 1 : 0;
+  return MFEM_OK;
+}
+
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* __restrict__ rowptr, int maxlen,
+                                                            int32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
+    keys[r] = maxlen - (int32_t)((int64_t)rowptr[r + 1] - (int64_t)rowptr[r]);
+    ids[r] = (int32_t)r;
+  }
+}
+
+// K_b * 128 for every block (first row of the block is its longest)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_block_sizes(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ rowid, int64_t* __restrict__ sizes) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblk; b += stride) {
+    const int64_t r = rowid[b * SELL_B];
+    sizes[b] = ((int64_t)rowptr[r + 1] - (int64_t)rowptr[r]) * SELL_B;
+  }
+}
+
+// columns (0-based; padding = the row itself) or values (padding = 0) into the sliced layout; lane <-> sorted row
+template <typename RP, typename T, bool COLS>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ rowid, const int64_t* __restrict__ ptr,
+                                                            const T* __restrict__ src, int base, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < 2 * nblk; t += nwaves) {  // a wave fills one half (64 rows) of a block
+    const int64_t b = t >> 1;
+    const int64_t rs = b * SELL_B + (t & 1) * 64 + lane;  // sorted row
+    const int64_t p0 = ptr[b];
+    const int Kb = (int)((ptr[b + 1] - p0) / SELL_B);
+    int64_t lo = 0;
+    int len = 0;
+    T pad = (T)0;
+    if (rs < n) {
+      const int64_t r = rowid[rs];
+      lo = (int64_t)rowptr[r] - base;
+      len = (int)((int64_t)rowptr[r + 1] - base - lo);
+      if (COLS) pad = (T)r;
+    }
+    T* o = out + p0 + (rs & (SELL_B - 1));
+    for (int s = 0; s < Kb; ++s) o[(int64_t)s * SELL_B] = s < len ? (COLS ? (T)(src[lo + s] - base) : src[lo + s]) : pad;
+  }
+}
+
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nblk, const int64_t* __restrict__ ptr,
+                                                            const int32_t* __restrict__ rowid, const int32_t* __restrict__ cols,
+                                                            const double* __restrict__ vals, const double* __restrict__ x,
+                                                            double* __restrict__ y, double alpha, double beta,
+                                                            const double* __restrict__ dotw, double* __restrict__ partials,
+                                                            const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < nblk; b += nwaves) {
+    const int64_t p0 = ptr[b];
+    const int Kb = (int)((ptr[b + 1] - p0) / SELL_B);
+    const int64_t rs = b * SELL_B + 2 * lane;
+    const double* v = vals + p0 + 2 * lane;
+    const int32_t* c = cols + p0 + 2 * lane;
+    s_d2 acc = {0.0, 0.0};
+    for (int s = 0; s < Kb; ++s) {
+      const s_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const s_d2*>(v + (int64_t)s * SELL_B));
+      const s_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const s_i2*>(c + (int64_t)s * SELL_B));
+      acc.x += vv.x * x[cc.x];
+      acc.y += vv.y * x[cc.y];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (rs + h < n) {
+        const int64_t r = rowid[rs + h];
+        double yv = alpha * (h ? acc.y : acc.x);
+        if (beta != 0.0) yv += beta * y[r];
+        y[r] = yv;
+        if (dotw) dot_acc += yv * dotw[r];
+      }
+    }
+  }
+  if (partials) {
+    const double bsum = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bsum;
+  }
+}
+
+#define SELL_CHECK(expr)                                                                    \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      mfem_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+      rc = MFEM_ERR_HIP;                                                                    \
+      goto done;                                                                            \
+    }                                                                                       \
+  } while (0)
+
+// sell_state: 0 not planned, -1 not eligible, 1 ready
+int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  if (A->sell_state != 0) return MFEM_OK;
+  if (A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel: do not even sort
+  A->sell_state = -1;
+  if (A->n < SELL_B || A->nnz < 1 || A->max_row_nnz < 1 || A->n >= ((int64_t)1 << 31)) return MFEM_OK;
+  int rc = MFEM_OK;
+  const int64_t n = A->n, nblk = (n + SELL_B - 1) / SELL_B;
+  int32_t *keys = nullptr, *ids = nullptr, *keys2 = nullptr, *rowid = nullptr;
+  int64_t *sizes = nullptr, *ptr = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0, tb2 = 0;
+  int64_t total = 0;
+  const int grid = mfem_grid_for(n, MFEM_BLOCK, ctx->num_cus * 16);
+  SELL_CHECK(hipMalloc(&keys, sizeof(int32_t) * (size_t)n));
+  SELL_CHECK(hipMalloc(&ids, sizeof(int32_t) * (size_t)n));
+  SELL_CHECK(hipMalloc(&keys2, sizeof(int32_t) * (size_t)n));
+  SELL_CHECK(hipMalloc(&rowid, sizeof(int32_t) * (size_t)n));
+  SELL_CHECK(hipMalloc(&sizes, sizeof(int64_t) * (size_t)(nblk + 1)));
+  SELL_CHECK(hipMalloc(&ptr, sizeof(int64_t) * (size_t)(nblk + 1)));
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_sell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int64_t*)A->rowptr,
+                       A->max_row_nnz, keys, ids);
+  else
+    hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr,
+                       A->max_row_nnz, keys, ids);
+  {
+    int bits = 1;
+    while ((1 << bits) <= A->max_row_nnz && bits < 31) ++bits;
+    SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, ids, rowid, (int)n, 0, bits, ctx->stream));
+    SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, sizes, ptr, (int)(nblk + 1), ctx->stream));
+    if (tb2 > tb) tb = tb2;
+    SELL_CHECK(hipMalloc(&tmp, tb));
+    SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, ids, rowid, (int)n, 0, bits, ctx->stream));  // stable
+  }
+  SELL_CHECK(hipMemsetAsync(sizes, 0, sizeof(int64_t) * (size_t)(nblk + 1), ctx->stream));
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_sell_block_sizes<int64_t>, dim3(mfem_grid_for(nblk, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK), 0,
+                       ctx->stream, n, nblk, (const int64_t*)A->rowptr, rowid, sizes);
+  else
+    hipLaunchKernelGGL(k_sell_block_sizes<int32_t>, dim3(mfem_grid_for(nblk, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK), 0,
+                       ctx->stream, n, nblk, (const int32_t*)A->rowptr, rowid, sizes);
+  SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sizes, ptr, (int)(nblk + 1), ctx->stream));
+  SELL_CHECK(hipMemcpyAsync(&total, ptr + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  SELL_CHECK(hipStreamSynchronize(ctx->stream));
+  if ((double)total <= 1.15 * (double)A->nnz + 128.0 * A->max_row_nnz) {
+    SELL_CHECK(hipMalloc(&A->sell_cols, sizeof(int32_t) * (size_t)total));
+    const int g2 = mfem_grid_for(2 * nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL((k_sell_fill<int64_t, int32_t, true>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, n, nblk,
+                         (const int64_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols);
+    else
+      hipLaunchKernelGGL((k_sell_fill<int32_t, int32_t, true>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, n, nblk,
+                         (const int32_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols);
+    if (hipGetLastError() != hipSuccess) {
+      mfem_set_error("k_sell_fill launch failed");
+      rc = MFEM_ERR_HIP;
+      goto done;
+    }
+    A->sell_rowid = rowid;
+    A->sell_ptr = ptr;
+    A->sell_total = total;
+    A->sell_nblk = nblk;
+    A->sell_state = 1;
+    rowid = nullptr;
+    ptr = nullptr;
+  }
+done:
+  if (keys) hipFree(keys);
+  if (ids) hipFree(ids);
+  if (keys2) hipFree(keys2);
+  if (rowid) hipFree(rowid);
+  if (sizes) hipFree(sizes);
+  if (ptr) hipFree(ptr);
+  if (tmp) hipFree(tmp);
+  return rc;
+}
+
+size_t mfem_sell_vals_bytes(const mfem_csr_s* A) {
+  return (A->sell_state == 1 && g_sell_enable && A->n >= g_layout_min_rows_cols) ? sizeof(double) * (size_t)A->sell_total : 0;
+}
+
+int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
+  A->sell_vals = nullptr;
+  A->sell_src = nullptr;
+  if (A->sell_state != 1 || !g_sell_enable || !buf) return MFEM_OK;
+  const int g2 = mfem_grid_for(2 * A->sell_nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL((k_sell_fill<int64_t, double, false>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk,
+                       (const int64_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf);
+  else
+    hipLaunchKernelGGL((k_sell_fill<int32_t, double, false>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk,
+                       (const int32_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf);
+  MFEM_CHECK_LAUNCH();
+  A->sell_vals = buf;
+  A->sell_src = vals;
+  return MFEM_OK;
+}
+
+void mfem_sell_unbind(mfem_csr_s* A) {
+  A->sell_vals = nullptr;
+  A->sell_src = nullptr;
+}
+
+void mfem_sell_free(mfem_csr_s* A) {
+  if (A->sell_cols) hipFree(A->sell_cols);
+  if (A->sell_rowid) hipFree(A->sell_rowid);
+  if (A->sell_ptr) hipFree(A->sell_ptr);
+  A->sell_cols = nullptr;
+  A->sell_rowid = nullptr;
+  A->sell_ptr = nullptr;
+  A->sell_state = 0;
+}
+
+// returns 1 if launched, 0 if another kernel should be used, <0 on error
+int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
+                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
+  if (!A->sell_vals || vals != A->sell_src) return 0;
+  int cap = ctx->num_cus * 8;
+  if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+  const int grid = mfem_grid_for(A->sell_nblk * 64, MFEM_BLOCK, cap);
+  hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk, A->sell_ptr, A->sell_rowid,
+                     A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw, partials, done_flag);
+  MFEM_CHECK_LAUNCH();
+  if (n_partials && partials) *n_partials = grid;
+  return 1;
+}

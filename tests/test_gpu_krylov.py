@@ -207,9 +207,11 @@ def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
     b = mf.FEM_rand(A.n, 3, 1) - 0.5
     out = {}
     # 1: slot-major copy, diagonal-slotted when the pattern allows (default kernel); 1 | 8 << 16: the same without the shared x
-    # loads of consecutive diagonals; 3: explicit columns only; 0: CSR tile kernel
-    for ell in (1, 1 | (8 << 16), 3, 0):
-        _lib.lib.mfem_debug_set_ell(ell | (6 << 4))
+    # loads of consecutive diagonals; 3: explicit columns only; 4: no uniform layouts -> row-sorted sliced ELL; 0: CSR tile kernel
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)  # the layouts are reserved for large systems by default
+    for ell in (1, 1 | (8 << 16), 3, 4, 0):
+        _lib.lib.mfem_debug_set_ell((ell & ~4) | (6 << 4))
+        _lib.lib.mfem_debug_set_sell(0 if ell == 0 else 1)
         try:
             for sv, s in ((mf.idrs_, 4), (mf.bicgstabl_GS_, 2), (mf.cgs2_, 0)):
                 x, st = mf.iterative_Solve(A, K, b, 1e-300, Sv_func=sv, maxiter=6, max_pass=1, s=s, seed=11)
@@ -220,10 +222,12 @@ def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
                 out[(ell, "cg")] = x.cpu().numpy()
         finally:
             _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
+            _lib.lib.mfem_debug_set_sell(1)
     if case == "thermal_odd_n":
         mode = C.c_int32()
         _lib.check(_lib.lib.mfem_csr_solver_layout(brick.ctx._h, A._h, C.byref(mode), None, None, None))
-        assert mode.value == 2  # (smaller bricks have too many boundary rows: > 10 % padding keeps them on the CSR kernel)
+        assert mode.value == 2  # (smaller bricks have too many boundary rows: > 10 % padding rules the uniform layouts out)
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
     for key in [k for k in out if k[0] != 0]:
         a, c = out[key], out[(0, key[1])]
         tol = 1e-7 if key[1] == "cg" else 1e-10
@@ -244,24 +248,32 @@ def test_solver_layout_inspector(mf):
         _lib.check(_lib.lib.mfem_csr_solver_layout(brick.ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
         return mode.value, slots.value, npad.value, reg.value
 
+    b0 = mf.make_Brick((1.0, 1.0, 1.0), (24, 24, 24))
+    assert layout(b0, b0.pattern(1))[0] == 0        # default thresholds: 15 625 rows are launch-bound -> CSR tile kernel
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
     b1 = mf.make_Brick((1.0, 1.0, 1.0), (24, 24, 24))
     A1 = b1.pattern(1)
     m, slots, npad, reg = layout(b1, A1)
     assert (m, slots) == (2, 27) and npad % 128 == 0 and npad >= A1.n and 0.5 * A1.n <= reg <= A1.n
     assert layout(b1, b1.pattern(3))[:2] == (2, 81)  # field-major 3-field matrix: one diagonal list per row field
     b3 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
-    assert layout(b3, b3.pattern(1))[0] == 0        # small brick: boundary rows would need > 10 % padding
+    assert layout(b3, b3.pattern(1))[0] == 3        # small brick: boundary rows would need > 10 % padding in a uniform layout
     b27 = mf.make_Brick((1.0, 1.0, 1.0), (4, 4, 4), 2, 5)
-    assert layout(b27, b27.pattern(1))[0] == 0
+    assert layout(b27, b27.pattern(1))[0] == 3      # 27 / 45 / 75 / 125 entries per row: row-sorted sliced ELL
+    b2 = mf.make_Brick((1.0, 1.0, 1.0), (3, 3, 3))
+    assert layout(b2, b2.pattern(1))[0] == 0        # 64 rows: less than one block, CSR tile kernel
     K = b1.assemble_thermal(A1, 0.6, 25.0, 293.15, 0x3F)
     rhs = mf.FEM_rand(A1.n, 5, 0) - 0.5
     res = {}
     for ell in (1, 0):
         _lib.lib.mfem_debug_set_ell(ell | (6 << 4))
+        _lib.lib.mfem_debug_set_sell(ell)
         try:
             res[ell] = mf.iterative_Solve(A1, K, rhs, 1e-300, Sv_func=mf.bicgstabl_GS_, maxiter=8, max_pass=1, s=2, seed=3)[0].cpu().numpy()
         finally:
             _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
+            _lib.lib.mfem_debug_set_sell(1)
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
     assert np.abs(res[1] - res[0]).max() <= 1e-10 * np.abs(res[0]).max()
 
 
@@ -292,6 +304,7 @@ def test_slot_major_layouts_on_caller_supplied_csr(mf, rp_dtype, base):
     M = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
     M.sort_indices()
     b = rng.standard_normal(n)
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
     for perturb in (False, True):
         A_ = M.copy()
         if perturb:  # swap one neighbour of every 7th row for a far column: rows stay 27 long but leave the diagonals
@@ -316,3 +329,4 @@ def test_slot_major_layouts_on_caller_supplied_csr(mf, rp_dtype, base):
                                    1e-12 * float(np.linalg.norm(b) / np.sqrt(n)), Sv_func=mf.bicgstabl_GS_, maxiter=500, max_pass=5, s=2)
         assert st.converged == 1
         assert np.abs(x.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)

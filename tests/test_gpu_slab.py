@@ -147,6 +147,7 @@ def test_solver_layout_spmv_on_slabs_with_ghost_columns(mf, lo, hi):
     nloc = par.local_vector_length(lo, hi, m1, m2, 1)
     x = mf.FEM_rand(nloc, 3, 0) - 0.5
     mode, reg = C.c_int32(), C.c_int64()
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
     _lib.check(_lib.lib.mfem_csr_solver_layout(sb.ctx._h, A._h, C.byref(mode), None, None, C.byref(reg)))
     assert mode.value == 2 and 0 < reg.value < A.n  # the planes next to a ghost plane stay on explicit columns
     y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
@@ -157,4 +158,5 @@ def test_solver_layout_spmv_on_slabs_with_ghost_columns(mf, lo, hi):
     # alpha / beta form
     y2 = y0.clone()
     _lib.check(_lib.lib.mfem_spmv_solver_layout(sb.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y2.data_ptr(), -0.5, 2.0))
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
     assert float((y2 - 1.5 * y0).abs().max()) <= 1e-12 * float(y0.abs().max())

@@ -43,5 +43,8 @@ b = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
 ms = timeit(lambda: mf.mul_(y, A, K, x), reps=10, warm=2)
 print(f"spmv {ms:.3f} ms {b/ms/1e6:.0f} GB/s ({b/ms/1e6/80:.1f}% of 8 TB/s)", flush=True)
 rhs = torch.ones(A.n, dtype=torch.float64, device="cuda")
-_, st = mf.iterative_Solve(A, K, rhs, 1e-30, Sv_func=mf.cg_, maxiter=50, max_pass=1, fixed_iterations=True)
-print(f"CG {st.solve_ms/50:.3f} ms/it", flush=True)
+for sell in (0, 1):
+    _lib.lib.mfem_debug_set_sell(sell)
+    mf.iterative_Solve(A, K, rhs, 1e-30, Sv_func=mf.cg_, maxiter=50, max_pass=1, fixed_iterations=True)
+    _, st = mf.iterative_Solve(A, K, rhs, 1e-30, Sv_func=mf.cg_, maxiter=50, max_pass=1, fixed_iterations=True)
+    print(f"CG ({'row-sorted sliced ELL' if sell else 'CSR tile kernel'} in the loop) {st.solve_ms/50:.3f} ms/it", flush=True)

@@ -24,9 +24,10 @@ gd.controlpoints["s"] = torch.full((msh.ncp,), 1600.0, dtype=torch.float64, devi
 gd.update_Time(); gd.initialize_dx(); gd.K_linear_func(); gd.update_x_star(); gd.K_nonlinear_func()
 print("n", gd.A.n, "nnz", gd.A.nnz)
 from metafem_jl_amd import _lib
-for graphs in (0, 1):
+for graphs, sell in ((0, 0), (1, 0), (1, 1)):
   _lib.lib.mfem_debug_set_graphs(graphs, 0)
-  print("hipGraph replay of solver cycles:", "on" if graphs else "off")
+  _lib.lib.mfem_debug_set_sell(sell)
+  print("hipGraph replay of solver cycles:", "on" if graphs else "off", "| row-sorted sliced ELL:", "on" if sell else "off")
   for name, sv, s in (("cg", mf.cg_, 0), ("bicgstabl(2)", mf.bicgstabl_GS_, 2), ("idrs(8)", mf.idrs_, 8), ("cgs2", mf.cgs2_, 0)):
     Kc = gd.K_total.clone() if sv != mf.cg_ else -gd.K_total
     b = gd.residue if sv != mf.cg_ else -gd.residue
