@@ -12,6 +12,8 @@ void mfem_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int mfem_debug_epoch = 0;
+
 extern "C" int mfem_abi_version(void) { return MFEM_ABI_VERSION; }
 extern "C" const char* mfem_last_error(void) { return g_err; }
 

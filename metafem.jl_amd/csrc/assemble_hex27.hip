@@ -538,6 +538,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 static int g_hex27_two_pass = 0;
 static int g_hex27_skip = 0;
 extern "C" int mfem_debug_set_hex27(int two_pass) {
+  ++mfem_debug_epoch;
   g_hex27_two_pass = two_pass & 3;  // 0 colours, 1 two-pass, 2 FP64 atomics
   g_hex27_skip = (two_pass >> 8) & 15;  // timing probe (tools/probe_hex27.py): phases left out, results WRONG
   return MFEM_OK;

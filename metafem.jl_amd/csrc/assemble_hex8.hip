@@ -777,6 +777,7 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
 
 static int g_elasticity_variant = 0;  // 1: the row-owner kernel with in-place global accumulation (kept for comparison)
 extern "C" int mfem_debug_set_elasticity(int variant) {
+  ++mfem_debug_epoch;
   g_elasticity_variant = variant ? 1 : 0;
   return MFEM_OK;
 }

@@ -114,6 +114,9 @@ struct mfem_csr_s {
   int32_t* sell_rowid;      // owned: sorted position -> row
   int64_t* sell_ptr;        // owned: [nblk + 1] start of each 128-row block in the sliced arrays
   int32_t* sell_cols;       // owned, [sell_total], 0-based
+  int32_t* sell_flags;      // owned, [nblk]: 1 = all 128 rows share one diagonal list
+  int32_t* sell_off;        // owned, [sell_total / 128]: that list, at ptr[b] / 128
+  int32_t sell_regular_blocks;
   const double* sell_src;
   double* sell_vals;        // not owned (solver workspace), [sell_total]
 };
@@ -138,6 +141,7 @@ int mfem_spmv_window_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* va
                             double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
 
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes);
+extern int mfem_debug_epoch;  // bumped by every mfem_debug_set_*: part of the cycle-graph cache key (api.hip)
 
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ double wave_reduce_sum(double v) {

@@ -260,7 +260,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   MFEM_CHECK_LAUNCH();
   const int check = o->check_every > 0 ? o->check_every : 32;
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
-  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int it = 0;
@@ -349,6 +349,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int g_graphs = 1;             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
 static int64_t g_graph_max_n = 4000000;  // above this size kernels are long enough that launch latency is hidden anyway
 extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) {
+  ++mfem_debug_epoch;
   g_graphs = on ? 1 : 0;
   if (max_n > 0) g_graph_max_n = max_n;
   return MFEM_OK;

@@ -220,6 +220,7 @@ static int g_spmv_variant = 1;
 static int g_spmv_nogather = 0;   // diagnostic only: replace x[col] by col-derived constants (WRONG results, timing probe)
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
+  ++mfem_debug_epoch;
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_nogather = (xcd_aware >> 20) & 1;

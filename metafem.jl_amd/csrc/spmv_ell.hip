@@ -30,6 +30,7 @@ __host__ __device__ __forceinline__ int64_t ell_base(int64_t r, int K) { return 
 int64_t g_layout_min_rows_dia = 262144;
 int64_t g_layout_min_rows_cols = 1000000;
 extern "C" int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns) {
+  ++mfem_debug_epoch;
   g_layout_min_rows_dia = diagonal_slots;
   g_layout_min_rows_cols = explicit_columns;
   return MFEM_OK;
@@ -47,6 +48,7 @@ static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the r
 static int g_ell_variant = 6;
 static int g_ell_grid_mult = 6;
 extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: kernel variant; bits 8-15: workgroups per CU
+  ++mfem_debug_epoch;
   g_ell_enable = enable & 1;
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
   g_dia_variant = (enable >> 16) & 15;

@@ -6,6 +6,9 @@
 //     rows of equal length keep their mesh order, so the x gathers of a 128-row block stay as local as in CSR order.  Block b
 //     stores K_b = its longest (= first) row's length slots, slot-major: element (row r', slot s) at ptr[b] + s * 128 + (r' & 127).
 //     Padding is what is left of length changes inside a block: 0.0-0.3 % for hex-27.
+//     Rows of equal length are further grouped by the signature of their diagonal list (a hash of col - row over the row): a
+//     block whose 128 rows share ONE list stores that list once (K_b relative offsets) and its column stream is never read --
+//     col = row + off[s].  For hex-27 that is every block away from the mesh boundary (8 node types = 8 lists).
 //   * per solve: the working values are copied into that layout (one pass, like the reference's K_total[K_val_ids] gather).
 //   * SpMV: a wave owns a block, a lane two neighbouring sorted rows; value / column streams are unit-stride 16-byte / 8-byte
 //     loads, the row sum runs in registers in slot (= column) order, and y is written through the row permutation.
@@ -19,18 +22,70 @@ typedef int s_i2 __attribute__((ext_vector_type(2)));
 
 extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
 static int g_sell_enable = 1;
-extern "C" int mfem_debug_set_sell(int enable) {
-  g_sell_enable = enable ? 1 : 0;
+static int g_sell_offsets = 1;  // blocks with one diagonal list skip their column stream
+extern "C" int mfem_debug_set_sell(int enable) {  // bit 0: layout on/off; bit 1: always read explicit columns
+  ++mfem_debug_epoch;
+  g_sell_enable = enable & 1;
+  g_sell_offsets = (enable & 2) ? 0 : 1;
   return MFEM_OK;
 }
 
 template <typename RP>
-__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* __restrict__ rowptr, int maxlen,
-                                                            int32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            int base, int maxlen, uint64_t* __restrict__ keys,
+                                                            int32_t* __restrict__ ids) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
-    keys[r] = maxlen - (int32_t)((int64_t)rowptr[r + 1] - (int64_t)rowptr[r]);
+    const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+    uint32_t h = 2166136261u;  // FNV-1a over the diagonal list col - row
+    for (int64_t j = lo; j < hi; ++j) {
+      uint32_t d = (uint32_t)((int64_t)col[j] - base - r);
+      for (int k = 0; k < 4; ++k) {
+        h = (h ^ (d & 255u)) * 16777619u;
+        d >>= 8;
+      }
+    }
+    keys[r] = ((uint64_t)(uint32_t)(maxlen - (int32_t)(hi - lo)) << 32) | h;
     ids[r] = (int32_t)r;
+  }
+}
+
+// flags[b] = 1 and off[ptr[b] / 128 + s] = the common diagonal list when all 128 rows of block b have the list of its first row
+template <typename RP>
+__global__ __launch_bounds__(SELL_B) void k_sell_block_flags(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col, int base,
+                                                               const int32_t* __restrict__ rowid, const int64_t* __restrict__ ptr,
+                                                               int32_t* __restrict__ flags, int32_t* __restrict__ off,
+                                                               int32_t* __restrict__ nreg) {
+  __shared__ int bad;
+  for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const int64_t rs = b * SELL_B + threadIdx.x;
+    const int64_t r0 = rowid[b * SELL_B];
+    const int64_t lo0 = (int64_t)rowptr[r0] - base;
+    const int K = (int)((int64_t)rowptr[r0 + 1] - base - lo0);
+    int fail = 0;
+    if (rs < n) {
+      const int64_t r = rowid[rs];
+      const int64_t lo = (int64_t)rowptr[r] - base;
+      if ((int)((int64_t)rowptr[r + 1] - base - lo) != K) fail = 1;
+      for (int s = 0; s < K && !fail; ++s)
+        if ((int64_t)col[lo + s] - r != (int64_t)col[lo0 + s] - r0) fail = 1;
+    } else {
+      fail = 1;
+    }
+    if (fail) bad = 1;
+    __syncthreads();
+    if (!bad) {
+      const int64_t o0 = ptr[b] / SELL_B;
+      for (int s = threadIdx.x; s < K; s += SELL_B) off[o0 + s] = (int32_t)((int64_t)col[lo0 + s] - base - r0);
+    }
+    if (threadIdx.x == 0) {
+      flags[b] = bad ? 0 : 1;
+      if (!bad) atomicAdd(nreg, 1);
+    }
+    __syncthreads();
   }
 }
 
@@ -73,7 +128,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nbl
 }
 
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nblk, const int64_t* __restrict__ ptr,
-                                                            const int32_t* __restrict__ rowid, const int32_t* __restrict__ cols,
+                                                            const int32_t* __restrict__ rowid, const int32_t* __restrict__ flags,
+                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ cols,
                                                             const double* __restrict__ vals, const double* __restrict__ x,
                                                             double* __restrict__ y, double alpha, double beta,
                                                             const double* __restrict__ dotw, double* __restrict__ partials,
@@ -91,16 +147,30 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nbl
     const double* v = vals + p0 + 2 * lane;
     const int32_t* c = cols + p0 + 2 * lane;
     s_d2 acc = {0.0, 0.0};
-    for (int s = 0; s < Kb; ++s) {
-      const s_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const s_d2*>(v + (int64_t)s * SELL_B));
-      const s_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const s_i2*>(c + (int64_t)s * SELL_B));
-      acc.x += vv.x * x[cc.x];
-      acc.y += vv.y * x[cc.y];
+    const bool regular = flags && __builtin_amdgcn_readfirstlane(flags[b]) != 0;  // full block, one diagonal list
+    int64_t rid[2] = {0, 0};
+    if (rs < n) rid[0] = rowid[rs];
+    if (rs + 1 < n) rid[1] = rowid[rs + 1];
+    if (regular) {
+      const int32_t* ob = off + __builtin_amdgcn_readfirstlane((int)(p0 / SELL_B));
+      for (int s = 0; s < Kb; ++s) {
+        const s_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const s_d2*>(v + (int64_t)s * SELL_B));
+        const int64_t o = ob[s];
+        acc.x += vv.x * x[rid[0] + o];
+        acc.y += vv.y * x[rid[1] + o];
+      }
+    } else {
+      for (int s = 0; s < Kb; ++s) {
+        const s_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const s_d2*>(v + (int64_t)s * SELL_B));
+        const s_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const s_i2*>(c + (int64_t)s * SELL_B));
+        acc.x += vv.x * x[cc.x];
+        acc.y += vv.y * x[cc.y];
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (rs + h < n) {
-        const int64_t r = rowid[rs + h];
+        const int64_t r = rid[h];
         double yv = alpha * (h ? acc.y : acc.x);
         if (beta != 0.0) yv += beta * y[r];
         y[r] = yv;
@@ -132,27 +202,29 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->n < SELL_B || A->nnz < 1 || A->max_row_nnz < 1 || A->n >= ((int64_t)1 << 31)) return MFEM_OK;
   int rc = MFEM_OK;
   const int64_t n = A->n, nblk = (n + SELL_B - 1) / SELL_B;
-  int32_t *keys = nullptr, *ids = nullptr, *keys2 = nullptr, *rowid = nullptr;
+  uint64_t *keys = nullptr, *keys2 = nullptr;
+  int32_t *ids = nullptr, *rowid = nullptr;
   int64_t *sizes = nullptr, *ptr = nullptr;
   void* tmp = nullptr;
   size_t tb = 0, tb2 = 0;
   int64_t total = 0;
   const int grid = mfem_grid_for(n, MFEM_BLOCK, ctx->num_cus * 16);
-  SELL_CHECK(hipMalloc(&keys, sizeof(int32_t) * (size_t)n));
+  SELL_CHECK(hipMalloc(&keys, sizeof(uint64_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&ids, sizeof(int32_t) * (size_t)n));
-  SELL_CHECK(hipMalloc(&keys2, sizeof(int32_t) * (size_t)n));
+  SELL_CHECK(hipMalloc(&keys2, sizeof(uint64_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&rowid, sizeof(int32_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&sizes, sizeof(int64_t) * (size_t)(nblk + 1)));
   SELL_CHECK(hipMalloc(&ptr, sizeof(int64_t) * (size_t)(nblk + 1)));
   if (A->rowptr_bits == 64)
-    hipLaunchKernelGGL(k_sell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int64_t*)A->rowptr,
-                       A->max_row_nnz, keys, ids);
+    hipLaunchKernelGGL(k_sell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int64_t*)A->rowptr, A->colidx,
+                       A->index_base, A->max_row_nnz, keys, ids);
   else
-    hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr,
-                       A->max_row_nnz, keys, ids);
+    hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr, A->colidx,
+                       A->index_base, A->max_row_nnz, keys, ids);
   {
     int bits = 1;
     while ((1 << bits) <= A->max_row_nnz && bits < 31) ++bits;
+    bits += 32;  // the low word is the signature of the diagonal list
     SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, ids, rowid, (int)n, 0, bits, ctx->stream));
     SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, sizes, ptr, (int)(nblk + 1), ctx->stream));
     if (tb2 > tb) tb = tb2;
@@ -182,6 +254,23 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
       mfem_set_error("k_sell_fill launch failed");
       rc = MFEM_ERR_HIP;
       goto done;
+    }
+    // blocks with a single diagonal list
+    {
+      int32_t* d_cnt = ctx->d_flags + 9;
+      SELL_CHECK(hipMalloc(&A->sell_flags, sizeof(int32_t) * (size_t)nblk));
+      SELL_CHECK(hipMalloc(&A->sell_off, sizeof(int32_t) * (size_t)(total / SELL_B + 1)));
+      SELL_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+      const int g3 = (int)(nblk < (int64_t)ctx->num_cus * 64 ? nblk : (int64_t)ctx->num_cus * 64);
+      if (A->rowptr_bits == 64)
+        hipLaunchKernelGGL(k_sell_block_flags<int64_t>, dim3(g3), dim3(SELL_B), 0, ctx->stream, n, nblk, (const int64_t*)A->rowptr,
+                           A->colidx, A->index_base, rowid, ptr, A->sell_flags, A->sell_off, d_cnt);
+      else
+        hipLaunchKernelGGL(k_sell_block_flags<int32_t>, dim3(g3), dim3(SELL_B), 0, ctx->stream, n, nblk, (const int32_t*)A->rowptr,
+                           A->colidx, A->index_base, rowid, ptr, A->sell_flags, A->sell_off, d_cnt);
+      SELL_CHECK(hipMemcpyAsync(ctx->h_flags + 9, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      SELL_CHECK(hipStreamSynchronize(ctx->stream));
+      A->sell_regular_blocks = ctx->h_flags[9];
     }
     A->sell_rowid = rowid;
     A->sell_ptr = ptr;
@@ -232,6 +321,10 @@ void mfem_sell_free(mfem_csr_s* A) {
   if (A->sell_cols) hipFree(A->sell_cols);
   if (A->sell_rowid) hipFree(A->sell_rowid);
   if (A->sell_ptr) hipFree(A->sell_ptr);
+  if (A->sell_flags) hipFree(A->sell_flags);
+  if (A->sell_off) hipFree(A->sell_off);
+  A->sell_flags = nullptr;
+  A->sell_off = nullptr;
   A->sell_cols = nullptr;
   A->sell_rowid = nullptr;
   A->sell_ptr = nullptr;
@@ -246,7 +339,7 @@ int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = mfem_grid_for(A->sell_nblk * 64, MFEM_BLOCK, cap);
   hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk, A->sell_ptr, A->sell_rowid,
-                     A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw, partials, done_flag);
+                     g_sell_offsets ? A->sell_flags : nullptr, A->sell_off, A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw, partials, done_flag);
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   return 1;

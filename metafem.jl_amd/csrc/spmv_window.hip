@@ -218,6 +218,7 @@ static int g_win_cap = 4032;
 static int g_win_grid_mult = 8;
 
 extern "C" int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult) {
+  ++mfem_debug_epoch;
   g_win_enable = enable;
   if (cap == 4032 || cap == 2016) g_win_cap = cap;
   if (grid_mult > 0) g_win_grid_mult = grid_mult;

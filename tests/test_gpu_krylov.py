@@ -209,9 +209,9 @@ def test_slot_major_copy_gives_the_same_solves_as_the_csr_kernel(mf, case):
     # 1: slot-major copy, diagonal-slotted when the pattern allows (default kernel); 1 | 8 << 16: the same without the shared x
     # loads of consecutive diagonals; 3: explicit columns only; 4: no uniform layouts -> row-sorted sliced ELL; 0: CSR tile kernel
     _lib.lib.mfem_debug_set_layout_min_rows(0, 0)  # the layouts are reserved for large systems by default
-    for ell in (1, 1 | (8 << 16), 3, 4, 0):
-        _lib.lib.mfem_debug_set_ell((ell & ~4) | (6 << 4))
-        _lib.lib.mfem_debug_set_sell(0 if ell == 0 else 1)
+    for ell in (1, 1 | (8 << 16), 3, 4, 12, 0):  # 12: sliced ELL reading explicit columns even in single-list blocks
+        _lib.lib.mfem_debug_set_ell((ell & ~12) | (6 << 4))
+        _lib.lib.mfem_debug_set_sell(0 if ell == 0 else (3 if ell == 12 else 1))
         try:
             for sv, s in ((mf.idrs_, 4), (mf.bicgstabl_GS_, 2), (mf.cgs2_, 0)):
                 x, st = mf.iterative_Solve(A, K, b, 1e-300, Sv_func=sv, maxiter=6, max_pass=1, s=s, seed=11)
