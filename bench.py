@@ -186,7 +186,7 @@ def main():
         csr_equiv = csr_bytes / (spmv_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-        if os.path.exists(tpath) and N == 256:
+        if os.path.exists(tpath) and N == 256 and world == 1:  # PMC traffic was measured on this single-GPU workload
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch") if tj.get("solver_layout_mode") == mode.value else None
