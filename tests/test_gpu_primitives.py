@@ -185,3 +185,39 @@ def test_errors_are_reported_not_thrown(mf):
                          2, index_base=5)
     with pytest.raises(mf.MetaFEMError):
         mf.dot(torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda"))  # float32 tensors
+
+
+@pytest.mark.parametrize("dims,order,fields,slab", [
+    ((37, 29, 53), 1, 1, None), ((37, 29, 53), 1, 1, (5, 21)), ((19, 23, 17), 1, 3, None), ((19, 23, 17), 1, 3, (7, 14)),
+    ((40, 9, 11), 1, 1, (0, 17)), ((11, 13, 9), 2, 1, None), ((64, 5, 5), 1, 1, (30, 65)), ((5, 5, 260), 1, 1, None),
+    ((128, 3, 3), 1, 3, None)])
+def test_solver_layouts_agree_with_the_csr_kernel_on_odd_shapes(mf, dims, order, fields, slab):
+    """Every solver layout the inspector can pick (diagonal slots incl. several lists, explicit columns, row-sorted sliced ELL
+    with and without block offset lists) against the CSR tile kernel on bricks with awkward extents, 1 and 3 fields, slabs with
+    ghost columns, hex-8 and hex-27 patterns; random values and a random x that includes the ghost entries."""
+    import torch
+    from metafem_jl_amd import _lib, parallel as par
+
+    b = mf.make_Brick((1.0, 1.0, 1.0), dims, order, 3 if order == 1 else 5)
+    m1, m2 = order * dims[1] + 1, order * dims[2] + 1
+    if slab is not None:
+        b.set_slab(*slab)
+    A = b.pattern(fields)
+    nloc = A.n if slab is None else par.local_vector_length(slab[0], slab[1], m1, m2, fields)
+    K = mf.FEM_rand(A.nnz, 11, 0) - 0.5
+    x = mf.FEM_rand(nloc, 12, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    scale = float(y0.abs().max())
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        for ell, sell in ((1, 1), (3, 1), (0, 1), (0, 3)):
+            _lib.lib.mfem_debug_set_ell(ell | (6 << 4))
+            _lib.lib.mfem_debug_set_sell(sell)
+            y1 = torch.full((A.n,), 3.0, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+            assert float((y0 - y1).abs().max()) <= 1e-13 * scale, (ell, sell)
+    finally:
+        _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
+        _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)

@@ -25,6 +25,10 @@ for var in (1, 0):
     print(f"assemble elasticity ({'row-owner, global accumulation' if var else 'thread per (node, element), LDS rows'}) {ms:.2f} ms = {A.nnz*8/ms/1e6:.0f} GB/s of nnz*8")
     if var: K1 = K.clone()
 print("variants bitwise equal:", bool(torch.equal(K1, K)))
+xs = mf.FEM_rand(A.n, 2, 0) - 0.5
+R = torch.empty(A.n, dtype=torch.float64, device="cuda")
+ms = timeit(lambda: brick.residual_elasticity(xs, lam, mu, 1000.0 * E, mf.FACE_BITS['x0'], mf.FACE_BITS['y1'], [0, 1.0, 0, 0, 0, 0], out=R))
+print(f"residual elasticity {ms:.2f} ms")
 b = mf.FEM_rand(A.n, 1, 0) - 0.5
 bytes_csr = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
 x = torch.empty_like(b)
