@@ -52,7 +52,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_ell_enable = enable & 1;
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
   g_dia_variant = (enable >> 16) & 15;
-  g_dia_xcd = (enable >> 20) & 1;
+  g_dia_xcd = (enable >> 20) & 3;  // bit 20: XCD-contiguous chunks; bit 21: timing probe without x loads
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
   return MFEM_OK;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
   const int64_t rows_per_wg = (int64_t)blockDim.x * RPT;
   const int64_t nchunks = (n + rows_per_wg - 1) / rows_per_wg;
   int64_t chunk = blockIdx.x, chunk_end = nchunks, chunk_step = gridDim.x;
-  if (xcd > 0) {
+  if (xcd & 1) {
     const int64_t per = (nchunks + 7) / 8;
     chunk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     chunk_end = ((blockIdx.x & 7) + 1) * per < nchunks ? ((blockIdx.x & 7) + 1) * per : nchunks;
@@ -369,8 +369,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
         const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
         const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
         const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
-        const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
-        const u_d2 xa = xp[0], xb = xp[1];
+        u_d2 xa, xb;
+        if (xcd & 2) {  // timing probe (bit 21 of mfem_debug_set_ell): no x loads, WRONG results
+          xa = (u_d2){1.0, 1.0};
+          xb = xa;
+        } else {
+          const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
+          xa = xp[0];
+          xb = xp[1];
+        }
         acc[0].x += va.x != 0.0 ? va.x * xa.x : 0.0;
         acc[0].y += va.y != 0.0 ? va.y * xa.y : 0.0;
         acc[0].x += vb.x != 0.0 ? vb.x * xa.y : 0.0;
