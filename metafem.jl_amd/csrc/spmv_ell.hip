@@ -353,6 +353,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
     if (r >= n) continue;
     const double* v = vals + ell_base(r, K);
     e_d2 acc[H];
+    double xself0 = 0.0, xself1 = 0.0;  // x[r], x[r + 1] when the kernel has loaded them anyway (fused w.y with w == x, as in CG)
+    bool have_self = false;
 #pragma unroll
     for (int h = 0; h < H; ++h) acc[h] = (e_d2){0.0, 0.0};
     // the wave's rows [b0, b0 + 64 RPT) are RPT / 2 aligned 128-row blocks: regular only if all of them are (wave-uniform)
@@ -384,6 +386,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
         acc[0].y += vb.y != 0.0 ? vb.y * xb.x : 0.0;
         acc[0].x += vc.x != 0.0 ? vc.x * xb.x : 0.0;
         acc[0].y += vc.y != 0.0 ? vc.y * xb.y : 0.0;
+        if (off[s + 1] == 0) {  // the main diagonal's run: x[r], x[r + 1] are the lane's own entries (wave-uniform test)
+          xself0 = xa.y;
+          xself1 = xb.x;
+          have_self = true;
+        }
       }
     } else if (interior) {
       int s = 0;
@@ -439,8 +446,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad
       y[rr] = y0;
       if (two) y[rr + 1] = y1;
       if (dotw) {
-        dot_acc += y0 * dotw[rr];
-        if (two) dot_acc += y1 * dotw[rr + 1];
+        if (RPT == 2 && have_self && dotw == x) {  // p.Ap of CG: p[r], p[r + 1] are already in registers
+          dot_acc += y0 * xself0;
+          if (two) dot_acc += y1 * xself1;
+        } else {
+          dot_acc += y0 * dotw[rr];
+          if (two) dot_acc += y1 * dotw[rr + 1];
+        }
       }
     }
   }
