@@ -80,48 +80,51 @@ int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double* vals, dou
 int mfem_jacobi_by_row(mfem_context ctx, mfem_csr A, const double* vals, double* d);        /* :170-177 */
 int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double* d);       /* :141-148, in place */
 
-/* Tuning hook (benchmarks/profiling only): XCD-aware tile map on/off, persistent workgroups per CU. */
-int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
-/* Inspector-executor SpMV plan (x window in LDS + 16-bit local indices, built inside mfem_csr_create /
- * mfem_brick_pattern / mfem_pattern_build): enable = 0 keeps the plain CSR kernel; cap = 4032 | 2016 tile size
- * for plans created afterwards. */
-int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
-/* hex-27 matrix assembly variant: 0 (default) = colour-partitioned read-modify-write scatter straight from the MFMA
- * accumulators; 1 = MFMA Ke -> element-major scratch + row-owner gather (every CSR value written once; slower today).
- * Bits 8-11 are a timing probe that leaves kernel phases out (results are then WRONG): 0x100 node loads, 0x200 Jacobians,
- * 0x400 MFMA loop, 0x800 scatter. */
-int mfem_debug_set_hex27(int two_pass);
-
-/* Per-launch timing of the SpMV kernel with hip events on the context stream (bench.py's roofline).
- * read: total device ms and launch count since the last reset. */
-/* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
- * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
-int mfem_debug_set_elasticity(int variant);
-/* Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
- *   mode 0  the CSR tile kernel (matrices with fewer than 128 rows, or mode 3 switched off)
+/* ---- solver layouts (inspector-executor; internal to mfem_solve, the caller's contract stays CSR) ------------------
+ * Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
+ *   mode 0  the CSR tile kernel (small systems -- see mfem_debug_set_layout_min_rows -- and matrices with < 128 rows)
  *   mode 1  slot-major padded copy of the working values + explicit columns (rows of near-uniform length)
  *   mode 2  as 1, and 128-row blocks whose entries all sit on a common list of <= 96 diagonals store their values by
  *           diagonal and do not read columns at all (any lattice stencil; up to 4 lists, e.g. one per row field of a
  *           field-major multi-field matrix; detected from the CSR pattern, nothing is assumed)
- *   mode 3  rows of uneven length (hex-27, unstructured meshes): rows stably sorted by decreasing length, sliced ELL with
- *           a slot count per 128-row block (SELL-128); y is written through the row permutation
+ *   mode 3  rows of uneven length (hex-27, unstructured meshes): rows stably sorted by decreasing length and diagonal-list
+ *           signature, sliced ELL with a slot count per 128-row block (SELL-128); blocks whose rows share one diagonal
+ *           list store it once instead of columns; y is written through the row permutation
  * The copy is made once per solve from the caller's CSR-ordered values, like the reference's K_total[K_val_ids] gather
- * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks. */
+ * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks (mode 2). */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
                            int64_t* regular_rows);
 /* y = alpha A x + beta y through that layout, conversion of `vals` included (diagnostic: what the Krylov loop computes). */
 int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
                             double beta);
-int mfem_debug_set_sell(int enable);
-/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems are
- * launch-bound and stay on the CSR tile kernel.  Tests set both to 0. */
-int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);   /* mode 3 on/off (off: the CSR tile kernel runs the Krylov loop on such matrices) */
-/* bit 0: slot-major copies on/off; bit 1: never use diagonal slots; bits 4-7 / 16-19: kernel variants; bits 8-15: workgroups per CU */
+
+/* ---- tuning / diagnostic hooks (benchmarks, profiling and tests only; process-wide) -------------------------------- */
+/* CSR tile kernel: tiles per XCD run (0 = dispatcher round-robin) | variant << 16, persistent workgroups per CU. */
+int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
+/* x-window variant of the CSR kernel (x window in LDS + 16-bit local indices; off by default): enable, tile size, grid. */
+int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
+/* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
+ * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results). */
 int mfem_debug_set_ell(int enable);
+/* mode 3: bit 0 on/off; bit 1 always read explicit columns. */
+int mfem_debug_set_sell(int enable);
+/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
+ * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
+int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
  * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */
 int mfem_debug_set_graphs(int on, int64_t max_n);
+/* hex-27 matrix assembly: bits 0-1: 0 (default) colour-partitioned read-modify-write scatter straight from the MFMA
+ * accumulators, 1 MFMA Ke -> element-major scratch + row-owner gather, 2 FP64 atomics in one launch (both slower).
+ * Bits 8-11: timing probe that leaves kernel phases out (results WRONG): 0x100 node loads, 0x200 Jacobians, 0x400 MFMA
+ * loop, 0x800 scatter. */
+int mfem_debug_set_hex27(int two_pass);
+/* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
+ * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
+int mfem_debug_set_elasticity(int variant);
+/* Per-launch timing of the solver's SpMV kernel with hip events on the context stream (bench.py's roofline).
+ * read: total device ms and launch count since the last reset. */
 int mfem_prof_spmv_enable(mfem_context ctx, int on);
 int mfem_prof_spmv_read(mfem_context ctx, double* total_ms /* [host] */, int64_t* launches /* [host] */, int reset);
 
