@@ -12,7 +12,8 @@
 //     4-5 cache lines per instruction instead of ~12 in CSR order (tools/gather_probe.hip, modes 0 vs 5);
 //   * the row sum is accumulated in slot order = the plain sequential CSR row sum (deterministic).
 // Padding entries carry value 0 and the row's own index as column.  Eligible when padding <= 10 % of nnz and
-// max_row_nnz <= 128; hex-27 (27..125 entries per row) stays on the LDS-tile CSR kernel.
+// max_row_nnz <= 128; rows of uneven length (hex-27: 27..125 entries) take the row-sorted sliced layout of spmv_sell.hip,
+// small systems stay on the LDS-tile CSR kernel of spmv.hip (size thresholds below).
 #include <vector>
 
 #include "blas1.h"

@@ -18,7 +18,7 @@ def read():
 res = {}
 names = {0: "1 row x9", 1: "2 rows x9", 2: "1 row x27", 3: "2 rows x27", 4: "1 row x3", 5: "2 rows x3", 6: "2 rows x1", 7: "2 rows x2",
          8: "2 rows x4", 9: "2 rows x5", 10: "2 rows x6", 11: "4 rows x1 nt", 12: "4 rows x1", 13: "2 rows pipelined"}
-cfgs = [0, 1 | (6 << 4) | (6 << 8), 1 | (6 << 4) | (8 << 8)]
+cfgs = [0, 1 | (6 << 4) | (6 << 8), 1 | (6 << 4) | (8 << 8), 1 | (6 << 4) | (6 << 8) | (4 << 20), 1 | (6 << 4) | (8 << 8) | (4 << 20)]
 lib.mfem_debug_set_graphs(0, 0)
 for ell in cfgs:
     lib.mfem_debug_set_ell(ell)
