@@ -74,7 +74,8 @@ extern "C" int mfem_context_destroy(mfem_context ctx) {
   }
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
-  if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+  for (int i = 0; i < MFEM_GRAPH_SLOTS; ++i)
+    if (ctx->graph_exec[i]) hipGraphExecDestroy(ctx->graph_exec[i]);
   if (ctx->graph_ev) hipEventDestroy(ctx->graph_ev);
   if (ctx->graph_stream) hipStreamDestroy(ctx->graph_stream);
   delete ctx;

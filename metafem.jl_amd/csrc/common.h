@@ -35,6 +35,7 @@ void mfem_set_error(const char* fmt, ...);
 
 struct mfem_comm_s;
 
+#define MFEM_GRAPH_SLOTS 4
 struct mfem_context_s {
   int device;
   hipStream_t stream;
@@ -65,8 +66,9 @@ struct mfem_context_s {
   // hipGraph replay of launch-bound Krylov cycles (krylov.h: mfem_cycle_run): one cached executable graph, keyed by a
   // hash of everything its kernel arguments depend on; graph_stream stands in for the legacy null stream, which cannot
   // be captured
-  hipGraphExec_t graph_exec;
-  uint64_t graph_key;
+  hipGraphExec_t graph_exec[MFEM_GRAPH_SLOTS];   // small cache: a coupled problem alternates between a few matrices / solvers
+  uint64_t graph_key[MFEM_GRAPH_SLOTS];
+  int graph_next;                                // round-robin replacement
   hipStream_t graph_stream;
   hipEvent_t graph_ev;
   int graph_active;   // set by mfem_solve for the duration of a solve when cycles may be captured

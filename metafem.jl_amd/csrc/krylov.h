@@ -53,13 +53,16 @@ inline uint64_t mfem_hash(uint64_t h, const T& v) { return mfem_hash_bytes(h, &v
 template <class Body>
 inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
   if (!ctx->graph_active) return body();
-  if (ctx->graph_exec && ctx->graph_key == key) {
-    MFEM_CHECK_HIP(hipGraphLaunch(ctx->graph_exec, ctx->stream));
-    return MFEM_OK;
-  }
-  if (ctx->graph_exec) {
-    hipGraphExecDestroy(ctx->graph_exec);
-    ctx->graph_exec = nullptr;
+  for (int i = 0; i < MFEM_GRAPH_SLOTS; ++i)
+    if (ctx->graph_exec[i] && ctx->graph_key[i] == key) {
+      MFEM_CHECK_HIP(hipGraphLaunch(ctx->graph_exec[i], ctx->stream));
+      return MFEM_OK;
+    }
+  const int slot = ctx->graph_next;
+  ctx->graph_next = (slot + 1) % MFEM_GRAPH_SLOTS;
+  if (ctx->graph_exec[slot]) {
+    hipGraphExecDestroy(ctx->graph_exec[slot]);
+    ctx->graph_exec[slot] = nullptr;
   }
   MFEM_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   const int rc = body();
@@ -80,8 +83,8 @@ inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
     mfem_set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
     return MFEM_ERR_HIP;
   }
-  ctx->graph_exec = exec;
-  ctx->graph_key = key;
+  ctx->graph_exec[slot] = exec;
+  ctx->graph_key[slot] = key;
   MFEM_CHECK_HIP(hipGraphLaunch(exec, ctx->stream));
   return MFEM_OK;
 }
