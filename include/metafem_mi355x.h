@@ -115,6 +115,8 @@ int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_colu
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
  * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */
 int mfem_debug_set_graphs(int on, int64_t max_n);
+/* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
+int mfem_debug_set_vec_grid(int workgroups_per_cu);
 /* hex-27 matrix assembly: bits 0-1: 0 (default) colour-partitioned read-modify-write scatter straight from the MFMA
  * accumulators, 1 MFMA Ke -> element-major scratch + row-owner gather, 2 FP64 atomics in one launch (both slower).
  * Bits 8-11: timing probe that leaves kernel phases out (results WRONG): 0x100 node loads, 0x200 Jacobians, 0x400 MFMA

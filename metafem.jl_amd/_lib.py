@@ -128,6 +128,7 @@ SIGNATURES = {
     "mfem_debug_set_ell": (c_int, [c_int]),
     "mfem_debug_set_elasticity": (c_int, [c_int]),
     "mfem_debug_set_sell": (c_int, [c_int]),
+    "mfem_debug_set_vec_grid": (c_int, [c_int]),
     "mfem_debug_set_layout_min_rows": (c_int, [c_int64, c_int64]),
     "mfem_spmv_solver_layout": (c_int, [P, P, P, P, P, c_double, c_double]),
     "mfem_csr_solver_layout": (c_int, [P, P, C.POINTER(c_int32), C.POINTER(c_int32), C.POINTER(c_int64), C.POINTER(c_int64)]),

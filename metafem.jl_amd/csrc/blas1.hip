@@ -69,9 +69,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_rand(int64_t n, uint64_t seed, u
     x[i] = mfem_u01(seed, stream_id, (uint64_t)i);
 }
 
+// 3 workgroups per CU: CG iteration at 256^3 1.057 ms vs 1.078 ms with 8 (fewer partial sums for the consumer kernels to
+// re-reduce, longer unit-stride runs per workgroup); 1: 1.138, 2: 1.059, 4: 1.062, 5: 1.074, 16: 1.095 (tools/probe_vecgrid.py)
+static int g_vec_grid_mult = 3;
+extern "C" int mfem_debug_set_vec_grid(int workgroups_per_cu) {
+  ++mfem_debug_epoch;
+  if (workgroups_per_cu > 0) g_vec_grid_mult = workgroups_per_cu;
+  return MFEM_OK;
+}
+
 int mfem_vec_grid(mfem_context_s* ctx, int64_t n) {
-  // 16 B per lane; persistent grid of at most 8 workgroups per CU
-  int cap = ctx->num_cus * 8;
+  // 16 B per lane; persistent grid of at most g_vec_grid_mult workgroups per CU
+  int cap = ctx->num_cus * g_vec_grid_mult;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   return mfem_grid_for((n + 1) / 2, MFEM_BLOCK, cap);
 }

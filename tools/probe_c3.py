@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metafem_jl_amd as mf
 from metafem_jl_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+if len(sys.argv) > 2:
+    _lib.lib.mfem_debug_set_vec_grid(int(sys.argv[2]))
 def timeit(fn, reps=3, warm=1):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
