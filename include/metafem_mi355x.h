@@ -104,7 +104,8 @@ int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
 /* x-window variant of the CSR kernel (x window in LDS + 16-bit local indices; off by default): enable, tile size, grid. */
 int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
- * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results). */
+ * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results); bits 24-25 workgroup size of the
+ * diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
 int mfem_debug_set_ell(int enable);
 /* mode 3: bit 0 on/off; bit 1 always read explicit columns. */
 int mfem_debug_set_sell(int enable);

@@ -42,6 +42,7 @@ static int g_dia_enable = 1;
 // 0 (default): 2 rows x 3 diagonals, sharing the x loads of a run of three consecutive offsets when the diagonals come in such
 // runs; 8: 2 rows x3 without that sharing; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
 static int g_dia_variant = 0;
+static int g_dia_block = MFEM_BLOCK;  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
 static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
@@ -53,7 +54,8 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_ell_enable = enable & 1;
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
   g_dia_variant = (enable >> 16) & 15;
-  g_dia_xcd = (enable >> 20) & 3;  // bit 20: XCD-contiguous chunks; bit 21: timing probe without x loads
+  g_dia_xcd = (enable >> 20) & 3;
+  g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks; bit 21: timing probe without x loads
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
   return MFEM_OK;
@@ -327,13 +329,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
 typedef double u_d2 __attribute__((ext_vector_type(2), aligned(8)));
 // lane <-> RPT (2 or 4) neighbouring rows; a wave covers one aligned block of 64 RPT rows; U diagonals per batch
 template <int RPT, int U, bool TRIPLES = false>
-__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
+__global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
                                                            const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
                                                            const double* __restrict__ dotw, double* __restrict__ partials,
                                                            const int32_t* __restrict__ done_flag, int xcd) {
-  __shared__ double red[4];
+  __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   const DiaOffsets& O = *Op;
   double dot_acc = 0.0;
@@ -676,7 +678,8 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   if (A->ell_bound_mode == 2) {
     const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
-    const int drpt = (g_dia_variant >= 4) ? 4 : 2;
+    const int drpt = (g_dia_variant == 4 || g_dia_variant == 5) ? 4 : 2;
+    const int gdb = mfem_grid_for((A->n + 1) / 2, g_dia_block, cap * MFEM_BLOCK / g_dia_block);
     const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
 #define LAUNCH_DIA(RPT, U)                                                                                                \
   hipLaunchKernelGGL((k_spmv_dia<RPT, U>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,          \
@@ -690,7 +693,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       case 0:
       case 7:
         if (A->dia_triples && g_dia_variant != 8) {
-          hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
+          hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gdb), dim3(g_dia_block), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
                              A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd);
         } else {
           LAUNCH_DIA(2, 3);
@@ -700,7 +703,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     }
 #undef LAUNCH_DIA
     MFEM_CHECK_LAUNCH();
-    if (n_partials && partials) *n_partials = gd;
+    if (n_partials && partials) *n_partials = (g_dia_variant == 0 || g_dia_variant == 7) && A->dia_triples ? gdb : gd;
     return 1;
   }
   const int rpt = (g_ell_variant == 0 || g_ell_variant == 2 || g_ell_variant == 4) ? 1 : 2;

@@ -18,7 +18,7 @@ def read():
 res = {}
 names = {0: "1 row x9", 1: "2 rows x9", 2: "1 row x27", 3: "2 rows x27", 4: "1 row x3", 5: "2 rows x3", 6: "2 rows x1", 7: "2 rows x2",
          8: "2 rows x4", 9: "2 rows x5", 10: "2 rows x6", 11: "4 rows x1 nt", 12: "4 rows x1", 13: "2 rows pipelined"}
-cfgs = [0, 1 | (6 << 4) | (6 << 8), 1 | (6 << 4) | (8 << 8), 1 | (6 << 4) | (6 << 8) | (4 << 20), 1 | (6 << 4) | (8 << 8) | (4 << 20)]
+cfgs = [0] + [1 | (6 << 4) | (m << 8) | (b << 24) for b in (0, 1, 2, 3) for m in (6, 8)]
 lib.mfem_debug_set_graphs(0, 0)
 for ell in cfgs:
     lib.mfem_debug_set_ell(ell)
@@ -29,6 +29,6 @@ for ell in cfgs:
     x2, st2 = mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=200, max_pass=1, fixed_iterations=True)
     ms = read()
     res[ell & 1] = x
-    print(f"ell={ell & 1} dia={0 if ell & 2 or not ell & 1 else 1} variant {names[(ell >> 4) & 15]} dia-variant {(ell >> 16) & 15} grid x{(ell >> 8) & 255}: solve {st.solve_ms:.1f} ms for 200 CG iterations = {st.solve_ms/200:.4f} ms/it | SpMV in CG {ms:.4f} ms = {bytes_spmv/ms/1e6:.0f} GB/s "
+    print(f"ell={ell & 1} dia={0 if ell & 2 or not ell & 1 else 1} variant {names[(ell >> 4) & 15]} dia-variant {(ell >> 16) & 15} block-code {(ell >> 24) & 3} grid x{(ell >> 8) & 255}: solve {st.solve_ms:.1f} ms for 200 CG iterations = {st.solve_ms/200:.4f} ms/it | SpMV in CG {ms:.4f} ms = {bytes_spmv/ms/1e6:.0f} GB/s "
           f"({bytes_spmv/ms/1e6/80:.1f}% of 8 TB/s)", flush=True)
 print("max rel diff of the 200-iteration iterate:", float((res[0] - res[1]).abs().max() / res[0].abs().max()))
