@@ -221,3 +221,43 @@ def test_solver_layouts_agree_with_the_csr_kernel_on_odd_shapes(mf, dims, order,
         _lib.lib.mfem_debug_set_ell(1 | (6 << 4))
         _lib.lib.mfem_debug_set_sell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+def test_solver_layouts_on_degenerate_matrices(mf):
+    """Empty rows, a matrix smaller than one block, a single dense row among short ones, n = 0: the inspector must fall back
+    (or pad) without touching memory it does not own, and the result must equal the CSR kernel."""
+    import ctypes as C
+
+    import scipy.sparse as sp
+    import torch
+    from metafem_jl_amd import _lib
+
+    rng = np.random.default_rng(4)
+    mats = []
+    n = 700
+    M = sp.random(n, n, density=0.01, random_state=1, format="lil")
+    M[5, :] = 0.0                      # an empty row
+    M[9, :] = rng.standard_normal(n)   # one dense row (700 entries) among rows of ~7
+    mats.append(M.tocsr())
+    mats.append(sp.random(40, 40, density=0.2, random_state=2, format="csr"))       # less than one 128-row block
+    mats.append(sp.csr_matrix((300, 300)))                                             # no entries at all
+    mats.append(sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(1000, 1000)).tocsr())  # tridiagonal: 3 diagonals, short rows at the ends
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        for M in mats:
+            M.sort_indices()
+            nn = M.shape[0]
+            rp = torch.tensor(M.indptr, dtype=torch.int64, device="cuda")
+            ci = torch.tensor(M.indices if M.nnz else np.zeros(1, dtype=np.int32), dtype=torch.int32, device="cuda")
+            vals = torch.tensor(M.data if M.nnz else np.zeros(1), dtype=torch.float64, device="cuda")
+            A = mf.FEM_SpMat_CSR(rp, ci[:M.nnz] if M.nnz else ci[:0], nn)
+            x = torch.tensor(rng.standard_normal(nn), device="cuda")
+            y0 = torch.full((nn,), 5.0, dtype=torch.float64, device="cuda")
+            y1 = y0.clone()
+            mf.mul_(y0, A, vals[:M.nnz], x, 2.0, -1.0)
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(A.ctx._h, A._h, vals.data_ptr(), x.data_ptr(), y1.data_ptr(), 2.0, -1.0))
+            ref = 2.0 * (M @ x.cpu().numpy()) - 5.0
+            assert np.allclose(y0.cpu().numpy(), ref, rtol=1e-13, atol=1e-12)
+            assert np.allclose(y1.cpu().numpy(), ref, rtol=1e-13, atol=1e-12)
+    finally:
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
