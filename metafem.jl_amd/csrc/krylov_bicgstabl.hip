@@ -45,25 +45,33 @@ __global__ void kb_sweep_begin(double* __restrict__ S, const int32_t* __restrict
   S[B_RHO0] *= -S[B_OMEGA];  // :41
 }
 // rho1 = dot(r_shadow, R[j]) in S[B_DOT]; beta = alpha*rho1/rho0; rho0 = rho1  (:44-46)
-__global__ void kb_beta(double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void kb_beta(FoldArg fa, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   const double rho1 = S[B_DOT];
   S[B_BETA] = S[B_ALPHA] * rho1 / S[B_RHO0];
   S[B_RHO0] = rho1;
 }
 // alpha = rho0 / dot(r_shadow, U[j+1])  (:53)
-__global__ void kb_alpha(double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void kb_alpha(FoldArg fa, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[B_ALPHA] = S[B_RHO0] / S[B_DOT];
 }
 // tau[i,j] = dot(R[i+1], R[j+1]) / sigma[i]  (:66)
-__global__ void kb_tau(int i, int j, double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void kb_tau(FoldArg fa, int i, int j, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[B_TAU + i + BL_MAXL * j] = S[B_DOT] / S[B_SIG + i];
 }
 // sigma[j] = dot(R[j+1],R[j+1]) ; gamma'[j] = dot(R[1],R[j+1]) / sigma[j]  (:69-70)
-__global__ void kb_sigma(int j, double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void kb_sigma(FoldArg fa, int j, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[B_SIG + j] = S[B_DOT];
   S[B_GP + j] = S[B_DOT + 1] / S[B_DOT];
 }
@@ -84,8 +92,10 @@ __global__ void kb_gamma(int l, double* __restrict__ S, const int32_t* __restric
   }
 }
 // iter += l; stop test on R[1] (:93-94); S[B_DOT] = R[1].R[1]
-__global__ void kb_sweep_end(BlArgs a, double* __restrict__ S, int32_t* __restrict__ F) {
+__global__ void kb_sweep_end(FoldArg fa, BlArgs a, double* __restrict__ S, int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   const int iter = F[F_ITER] + a.l;
   F[F_ITER] = iter;
   S[S_RR] = S[B_DOT];
@@ -96,6 +106,11 @@ __global__ void kb_sweep_end(BlArgs a, double* __restrict__ S, int32_t* __restri
   do {                   \
     int _rc = (x);       \
     if (_rc) return _rc; \
+  } while (0)
+#define K1F(kernel, ...)                                                               \
+  do {                                                                                 \
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, __VA_ARGS__); \
+    MFEM_CHECK_LAUNCH();                                                               \
   } while (0)
 #define K1(kernel, ...)                                                       \
   do {                                                                        \
@@ -142,12 +157,13 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
     K1(kb_sweep_begin, S, F);
     // ---- BiCG part (:43-62)
     for (int j = 0; j < l; ++j) {
-      RC(k.dot1(shadow, R[j], B_DOT));
-      K1(kb_beta, S, F);
+      FoldArg fa;
+      RC(k.dot1_partials(shadow, R[j], B_DOT, &fa));
+      K1F(kb_beta, fa, S, F);
       for (int i = 0; i <= j; ++i) RC(k.lin2(coef_imm(1.0), R[i], coef_dev(B_BETA, -1.0), U[i], U[i]));  // U[i] = R[i] - beta U[i]
       RC(k.spmv(A, vals, U[j], U[j + 1], spmv_cnt));
-      RC(k.dot1(shadow, U[j + 1], B_DOT));
-      K1(kb_alpha, S, F);
+      RC(k.dot1_partials(shadow, U[j + 1], B_DOT, &fa));
+      K1F(kb_alpha, fa, S, F);
       for (int i = 0; i <= j; ++i) RC(k.axpby(coef_dev(B_ALPHA, -1.0), U[i + 1], coef_imm(1.0), R[i]));  // R[i] -= alpha U[i+1]
       RC(k.spmv(A, vals, R[j], R[j + 1], spmv_cnt));
       RC(k.axpby(coef_dev(B_ALPHA), U[0], coef_imm(1.0), V.x));  // x += alpha U[1]
@@ -155,16 +171,18 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
     // ---- MR part, modified Gram-Schmidt (:64-71)
     for (int j = 0; j < l; ++j) {
       for (int i = 0; i < j; ++i) {
-        RC(k.dot1(R[i + 1], R[j + 1], B_DOT));
-        K1(kb_tau, i, j, S, F);
+        FoldArg ft;
+        RC(k.dot1_partials(R[i + 1], R[j + 1], B_DOT, &ft));
+        K1F(kb_tau, ft, i, j, S, F);
         RC(k.axpby(coef_dev(B_TAU + i + BL_MAXL * j, -1.0), R[i + 1], coef_imm(1.0), R[j + 1]));
       }
       DotList L;
       L.m = 2;
       L.x[0] = (const d2_t*)R[j + 1]; L.y[0] = (const d2_t*)R[j + 1];
       L.x[1] = (const d2_t*)R[0];     L.y[1] = (const d2_t*)R[j + 1];
-      RC(k.dots(L, B_DOT));
-      K1(kb_sigma, j, S, F);
+      FoldArg fs;
+      RC(k.dots_partials(L, B_DOT, &fs));
+      K1F(kb_sigma, fs, j, S, F);
     }
     K1(kb_gamma, l, S, F);
     // ---- updates (:82-91)
@@ -176,8 +194,9 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
       RC(k.axpby(coef_dev(B_GPP + j), R[j + 1], coef_imm(1.0), V.x));
       RC(k.axpby(coef_dev(B_GP + j, -1.0), R[j + 1], coef_imm(1.0), R[0]));
     }
-    RC(k.dot1(R[0], R[0], B_DOT));
-    K1(kb_sweep_end, a, S, F);
+    FoldArg fe;
+    RC(k.dot1_partials(R[0], R[0], B_DOT, &fe));
+    K1F(kb_sweep_end, fe, a, S, F);
     return MFEM_OK;
   };
   while (!ctx->h_flags[F_DONE]) {

@@ -20,16 +20,20 @@ __global__ void kc_init(C2Args a, double* __restrict__ S, int32_t* __restrict__ 
   if (conv) F[F_ITER] = 0;
 }
 // rho = r.r0, rhobar = r.s0 ; beta = 1/alphabar * rho/sigma ; betabar = 1/alpha * rhobar/sigmabar  (:75-81)
-__global__ void kc_betas(double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void kc_betas(FoldArg fa, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[C_RHO] = S[C_DOT];
   S[C_RHOBAR] = S[C_DOT + 1];
   S[C_BETA] = 1.0 / S[C_ALPHABAR] * S[C_RHO] / S[C_SIGMA];
   S[C_BETABAR] = 1.0 / S[C_ALPHA] * S[C_RHOBAR] / S[C_SIGMABAR];
 }
 // sigma = c.r0, alpha = rho/sigma ; sigmabar = c.s0, alphabar = rhobar/sigmabar  (:87-92)
-__global__ void kc_alphas(double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void kc_alphas(FoldArg fa, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[C_SIGMA] = S[C_DOT];
   S[C_ALPHA] = S[C_RHO] / S[C_SIGMA];
   S[C_SIGMABAR] = S[C_DOT + 1];
@@ -80,6 +84,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void kc_half2(int64_t n2, const d2_t* _
     int _rc = (x);       \
     if (_rc) return _rc; \
   } while (0)
+#define K1F(kernel, ...)                                                               \
+  do {                                                                                 \
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, __VA_ARGS__); \
+    MFEM_CHECK_LAUNCH();                                                               \
+  } while (0)
 #define K1(kernel, ...)                                                       \
   do {                                                                        \
     hipLaunchKernelGGL(kernel, dim3(1), dim3(1), 0, ctx->stream, __VA_ARGS__); \
@@ -117,16 +126,17 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
     L.m = 2;
     L.x[0] = (const d2_t*)r; L.y[0] = (const d2_t*)r0;
     L.x[1] = (const d2_t*)r; L.y[1] = (const d2_t*)s0;
-    RC(k.dots(L, C_DOT));
-    K1(kc_betas, S, F);
+    FoldArg fa;
+    RC(k.dots_partials(L, C_DOT, &fa));
+    K1F(kc_betas, fa, S, F);
     hipLaunchKernelGGL(kc_half1, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, (const d2_t*)r, (const d2_t*)u,
                        (const d2_t*)s, (d2_t*)v, (d2_t*)t, (d2_t*)w, S, F);
     MFEM_CHECK_LAUNCH();
     RC(k.spmv(A, vals, w, c, spmv_cnt));
     L.x[0] = (const d2_t*)c; L.y[0] = (const d2_t*)r0;
     L.x[1] = (const d2_t*)c; L.y[1] = (const d2_t*)s0;
-    RC(k.dots(L, C_DOT));
-    K1(kc_alphas, S, F);
+    RC(k.dots_partials(L, C_DOT, &fa));
+    K1F(kc_alphas, fa, S, F);
     hipLaunchKernelGGL(kc_half2, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, (const d2_t*)t, (const d2_t*)c,
                        (const d2_t*)v, (d2_t*)s, (d2_t*)u, (d2_t*)V.x, S, F);
     MFEM_CHECK_LAUNCH();

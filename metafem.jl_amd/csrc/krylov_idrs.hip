@@ -36,8 +36,10 @@ __global__ void ki_init(IdArgs a, double* __restrict__ S, int32_t* __restrict__ 
   if (conv) F[F_ITER] = 0;
 }
 // f[first + t] = dots[t]
-__global__ void ki_store(int dst, int m, double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void ki_store(FoldArg fa, int dst, int m, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   for (int t = 0; t < m; ++t) S[dst + t] = S[I_DOT + t];
 }
 // c = LowerTriangular(M[k:s, k:s]) \ f[k:s]   (:47)
@@ -50,8 +52,10 @@ __global__ void ki_solve_c(int k, int s, double* __restrict__ S, const int32_t* 
   }
 }
 // alpha = dot(P[i], G[k]) / M[i,i]   (:62)
-__global__ void ki_alpha(int i, double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void ki_alpha(FoldArg fa, int i, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[I_ALPHA] = S[I_DOT] / S[I_M + i + IS_MAXS * i];
 }
 // beta = f[k] / M[k,k]   (:73)
@@ -60,8 +64,10 @@ __global__ void ki_beta(int k, double* __restrict__ S, const int32_t* __restrict
   S[I_BETA] = S[I_F + k] / S[I_M + k + IS_MAXS * k];
 }
 // stop test after the inner step, then f[k+1:] -= beta*M[k+1:,k]; iter += 1   (:79-81); S[I_DOT] = r.r
-__global__ void ki_step_end(IdArgs a, int k, double* __restrict__ S, int32_t* __restrict__ F) {
+__global__ void ki_step_end(FoldArg fa, IdArgs a, int k, double* __restrict__ S, int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   S[S_RR] = S[I_DOT];
   const int iter = F[F_ITER];
   if ((!a.fixed && sqrt(S[I_DOT] * a.n_inv) <= a.tol) || iter >= a.maxiter) {
@@ -75,8 +81,10 @@ __global__ void ki_step_end(IdArgs a, int k, double* __restrict__ S, int32_t* __
   F[F_ITER] = iter + 1;
 }
 // omega = modify_Omega(Ar, r) (:1-8); dots: [0] Ar.Ar  [1] r.r  [2] Ar.r
-__global__ void ki_omega(double* __restrict__ S, const int32_t* __restrict__ F) {
+__global__ void ki_omega(FoldArg fa, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
+  kk_fold_dev(fa, S);
+  if (threadIdx.x != 0) return;
   const double angle = 0.70710678118654752440;  // sqrt(2)/2
   const double n1 = sqrt(S[I_DOT]), n2 = sqrt(S[I_DOT + 1]), d = S[I_DOT + 2];
   const double rho = fabs(d / (n1 * n2));
@@ -114,6 +122,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList
   do {                   \
     int _rc = (x);       \
     if (_rc) return _rc; \
+  } while (0)
+#define K1F(kernel, ...)                                                               \
+  do {                                                                                 \
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, __VA_ARGS__); \
+    MFEM_CHECK_LAUNCH();                                                               \
   } while (0)
 #define K1(kernel, ...)                                                       \
   do {                                                                        \
@@ -166,8 +179,9 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
         L.x[t] = (const d2_t*)P[i0 + t];
         L.y[t] = (const d2_t*)r;
       }
-      RC(k.dots(L, I_DOT));
-      K1(ki_store, I_F + i0, L.m, S, F);
+      FoldArg fa;
+      RC(k.dots_partials(L, I_DOT, &fa));
+      K1F(ki_store, fa, I_F + i0, L.m, S, F);
     }
     for (int kk = 0; kk < s; ++kk) {
       K1(ki_solve_c, kk, s, S, F);
@@ -181,8 +195,9 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
       MFEM_CHECK_LAUNCH();
       RC(k.spmv(A, vals, U[kk], G[kk], spmv_cnt));  // :59
       for (int i = 0; i < kk; ++i) {                 // bi-orthogonalise (:62-66)
-        RC(k.dot1(P[i], G[kk], I_DOT));
-        K1(ki_alpha, i, S, F);
+        FoldArg fa;
+        RC(k.dot1_partials(P[i], G[kk], I_DOT, &fa));
+        K1F(ki_alpha, fa, i, S, F);
         RC(k.axpy2(coef_dev(I_ALPHA, -1.0), G[i], G[kk], coef_dev(I_ALPHA, -1.0), U[i], U[kk]));
       }
       for (int i0 = kk; i0 < s; i0 += KK_MAX_DOTS) {  // M[k:s, k] = P[k:s]' G[k]  (:69-71)
@@ -192,13 +207,15 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
           L.x[t] = (const d2_t*)P[i0 + t];
           L.y[t] = (const d2_t*)G[kk];
         }
-        RC(k.dots(L, I_DOT));
-        K1(ki_store, I_M + i0 + IS_MAXS * kk, L.m, S, F);
+        FoldArg fa;
+        RC(k.dots_partials(L, I_DOT, &fa));
+        K1F(ki_store, fa, I_M + i0 + IS_MAXS * kk, L.m, S, F);
       }
       K1(ki_beta, kk, S, F);
       RC(k.axpy2(coef_dev(I_BETA), U[kk], V.x, coef_dev(I_BETA, -1.0), G[kk], r));  // :75-76
-      RC(k.dot1(r, r, I_DOT));
-      K1(ki_step_end, a, kk, S, F);
+      FoldArg fe;
+      RC(k.dot1_partials(r, r, I_DOT, &fe));
+      K1F(ki_step_end, fe, a, kk, S, F);
     }
     // r in G_j+1  (:85-93)
     RC(k.spmv(A, vals, r, Ar, spmv_cnt));
@@ -207,11 +224,13 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
     L.x[0] = (const d2_t*)Ar; L.y[0] = (const d2_t*)Ar;
     L.x[1] = (const d2_t*)r;  L.y[1] = (const d2_t*)r;
     L.x[2] = (const d2_t*)Ar; L.y[2] = (const d2_t*)r;
-    RC(k.dots(L, I_DOT));
-    K1(ki_omega, S, F);
+    FoldArg fo;
+    RC(k.dots_partials(L, I_DOT, &fo));
+    K1F(ki_omega, fo, S, F);
     RC(k.axpy2(coef_dev(I_OMEGA), r, V.x, coef_dev(I_OMEGA, -1.0), Ar, r));  // x += omega r ; r -= omega Ar
-    RC(k.dot1(r, r, I_DOT));
-    K1(ki_step_end, a, -1, S, F);
+    FoldArg fe;
+    RC(k.dot1_partials(r, r, I_DOT, &fe));
+    K1F(ki_step_end, fe, a, -1, S, F);
     return MFEM_OK;
   };
   while (!ctx->h_flags[F_DONE]) {

@@ -96,6 +96,21 @@ static __global__ __launch_bounds__(MFEM_BLOCK) void kk_fold(const double* __res
   }
 }
 
+// A reduction whose partial sums are folded by the scalar kernel that consumes it (one launch less per dot): the consumer is
+// launched with a full workgroup, sums the partials in a fixed order into S[out + k] and continues on thread 0.
+struct FoldArg {
+  const double* part;
+  int G, m, out;
+};
+__device__ __forceinline__ void kk_fold_dev(const FoldArg& f, double* __restrict__ S) {
+  __shared__ double fold_red[MFEM_BLOCK / 64];
+  for (int k = 0; k < f.m; ++k) {
+    const double v = reduce_partials_bcast(f.part + (int64_t)k * f.G, f.G, fold_red);
+    if (threadIdx.x == 0) S[f.out + k] = v;
+    __syncthreads();
+  }
+}
+
 struct KK {
   mfem_context_s* ctx;
   int64_t nv;
@@ -129,6 +144,28 @@ struct KK {
     MFEM_CHECK_LAUNCH();
     if (ctx->comm) return mfem_comm_allreduce(ctx, S + out, L.m);
     return MFEM_OK;
+  }
+  // partial sums only; the returned descriptor goes to the scalar kernel that uses the result (launch it with K1F).  With a
+  // communicator the fold + all-reduce happen here and the descriptor is empty.
+  int dots_partials(const DotList& L, int out, FoldArg* fa) const {
+    double* part = ctx->d_partials;
+    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, L, part, F);
+    MFEM_CHECK_LAUNCH();
+    *fa = FoldArg{part, G, L.m, out};
+    if (ctx->comm) {
+      hipLaunchKernelGGL(kk_fold, dim3(1), dim3(MFEM_BLOCK), 0, st, part, G, L.m, out, S, F);
+      MFEM_CHECK_LAUNCH();
+      fa->m = 0;
+      return mfem_comm_allreduce(ctx, S + out, L.m);
+    }
+    return MFEM_OK;
+  }
+  int dot1_partials(const double* x, const double* y, int out, FoldArg* fa) const {
+    DotList L;
+    L.m = 1;
+    L.x[0] = (const d2_t*)x;
+    L.y[0] = (const d2_t*)y;
+    return dots_partials(L, out, fa);
   }
   int dot1(const double* x, const double* y, int out) const {
     DotList L;
