@@ -42,15 +42,6 @@ __global__ void ki_store(FoldArg fa, int dst, int m, double* __restrict__ S, con
   if (threadIdx.x != 0) return;
   for (int t = 0; t < m; ++t) S[dst + t] = S[I_DOT + t];
 }
-// c = LowerTriangular(M[k:s, k:s]) \ f[k:s]   (:47)
-__global__ void ki_solve_c(int k, int s, double* __restrict__ S, const int32_t* __restrict__ F) {
-  if (F[F_DONE]) return;
-  for (int i = k; i < s; ++i) {
-    double v = S[I_F + i];
-    for (int j = k; j < i; ++j) v -= S[I_M + i + IS_MAXS * j] * S[I_C + j - k];
-    S[I_C + i - k] = v / S[I_M + i + IS_MAXS * i];
-  }
-}
 // alpha = dot(P[i], G[k]) / M[i,i]   (:62)
 __global__ void ki_alpha(FoldArg fa, int i, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
@@ -98,11 +89,27 @@ struct CombineList {
   int m;  // number of terms (s - k)
 };
 // U_k = sum_t c[t] U[k+t] + omega * (r - sum_t c[t] G[k+t])      (:49-58)
-__global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList L, const d2_t* __restrict__ r, d2_t* Uk,
+// The coefficients c = LowerTriangular(M[k:s, k:s]) \ f[k:s] (:47; a host solve in the reference) are computed by every
+// workgroup for itself from a shared-memory copy of the m x m block (m <= 32: a few hundred flops) -- no separate 1-thread kernel.
+__global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList L, int k, const d2_t* __restrict__ r, d2_t* Uk,
                                                           const double* __restrict__ S, const int32_t* __restrict__ F) {
   __shared__ double c[IS_MAXS];
+  __shared__ double Ms[IS_MAXS * IS_MAXS];
+  __shared__ double fs[IS_MAXS];
   if (F[F_DONE]) return;
-  if (threadIdx.x < L.m) c[threadIdx.x] = S[I_C + threadIdx.x];
+  const int m = L.m;  // = s - k
+  for (int t = threadIdx.x; t < m * m; t += blockDim.x) {
+    const int i = t % m, j = t / m;
+    Ms[i + IS_MAXS * j] = S[I_M + (k + i) + IS_MAXS * (k + j)];
+  }
+  if (threadIdx.x < m) fs[threadIdx.x] = S[I_F + k + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 0; i < m; ++i) {
+      double v = fs[i];
+      for (int j = 0; j < i; ++j) v -= Ms[i + IS_MAXS * j] * c[j];
+      c[i] = v / Ms[i + IS_MAXS * i];
+    }
   __syncthreads();
   const double omega = S[I_OMEGA];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -184,14 +191,13 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
       K1F(ki_store, fa, I_F + i0, L.m, S, F);
     }
     for (int kk = 0; kk < s; ++kk) {
-      K1(ki_solve_c, kk, s, S, F);
       CombineList C;
       C.m = s - kk;
       for (int t = 0; t < C.m; ++t) {
         C.G[t] = (const d2_t*)G[kk + t];
         C.U[t] = (const d2_t*)U[kk + t];
       }
-      hipLaunchKernelGGL(ki_combine, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, (const d2_t*)r, (d2_t*)U[kk], S, F);
+      hipLaunchKernelGGL(ki_combine, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, kk, (const d2_t*)r, (d2_t*)U[kk], S, F);
       MFEM_CHECK_LAUNCH();
       RC(k.spmv(A, vals, U[kk], G[kk], spmv_cnt));  // :59
       for (int i = 0; i < kk; ++i) {                 // bi-orthogonalise (:62-66)
