@@ -36,11 +36,13 @@ __global__ void ki_init(IdArgs a, double* __restrict__ S, int32_t* __restrict__ 
   if (conv) F[F_ITER] = 0;
 }
 // f[first + t] = dots[t]
-__global__ void ki_store(FoldArg fa, int dst, int m, double* __restrict__ S, const int32_t* __restrict__ F) {
+// beta_k >= 0: this was the last chunk of column k of M -> also beta = f[k] / M[k,k]   (:73)
+__global__ void ki_store(FoldArg fa, int dst, int m, int beta_k, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
   kk_fold_dev(fa, S);
   if (threadIdx.x != 0) return;
   for (int t = 0; t < m; ++t) S[dst + t] = S[I_DOT + t];
+  if (beta_k >= 0) S[I_BETA] = S[I_F + beta_k] / S[I_M + beta_k + IS_MAXS * beta_k];
 }
 // alpha = dot(P[i], G[k]) / M[i,i]   (:62)
 __global__ void ki_alpha(FoldArg fa, int i, double* __restrict__ S, const int32_t* __restrict__ F) {
@@ -48,11 +50,6 @@ __global__ void ki_alpha(FoldArg fa, int i, double* __restrict__ S, const int32_
   kk_fold_dev(fa, S);
   if (threadIdx.x != 0) return;
   S[I_ALPHA] = S[I_DOT] / S[I_M + i + IS_MAXS * i];
-}
-// beta = f[k] / M[k,k]   (:73)
-__global__ void ki_beta(int k, double* __restrict__ S, const int32_t* __restrict__ F) {
-  if (F[F_DONE]) return;
-  S[I_BETA] = S[I_F + k] / S[I_M + k + IS_MAXS * k];
 }
 // stop test after the inner step, then f[k+1:] -= beta*M[k+1:,k]; iter += 1   (:79-81); S[I_DOT] = r.r
 __global__ void ki_step_end(FoldArg fa, IdArgs a, int k, double* __restrict__ S, int32_t* __restrict__ F) {
@@ -188,7 +185,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
       }
       FoldArg fa;
       RC(k.dots_partials(L, I_DOT, &fa));
-      K1F(ki_store, fa, I_F + i0, L.m, S, F);
+      K1F(ki_store, fa, I_F + i0, L.m, -1, S, F);
     }
     for (int kk = 0; kk < s; ++kk) {
       CombineList C;
@@ -215,9 +212,8 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
         }
         FoldArg fa;
         RC(k.dots_partials(L, I_DOT, &fa));
-        K1F(ki_store, fa, I_M + i0 + IS_MAXS * kk, L.m, S, F);
+        K1F(ki_store, fa, I_M + i0 + IS_MAXS * kk, L.m, (i0 + KK_MAX_DOTS >= s) ? kk : -1, S, F);
       }
-      K1(ki_beta, kk, S, F);
       RC(k.axpy2(coef_dev(I_BETA), U[kk], V.x, coef_dev(I_BETA, -1.0), G[kk], r));  // :75-76
       FoldArg fe;
       RC(k.dot1_partials(r, r, I_DOT, &fe));
