@@ -22,9 +22,10 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define H27_MAXQ 64
 
 struct Hex27Tables {        // device-global, filled once per ng
-  double dN[H27_MAXQ][27][3];
+  double dN[H27_MAXQ][3][27];  // [q][m][a]: lanes that differ in a (or in (q, m)) read different LDS banks
   double N[H27_MAXQ][27];
   double w[H27_MAXQ];
+  double tab1[2][4][4];       // 1-D Lagrange-2 values (k = 0) and derivatives (k = 1) at the ng Gauss points: [k][q][a], rows padded to 4
   // face tables: 2-D Lagrange-2 on [0,1]^2 at ng x ng Gauss points, c = c1 + 3*c2
   double fN[16][9];
   double fdN[16][9][2];
@@ -60,6 +61,7 @@ static int hex27_upload_tables(int ng) {
     gp[i] = GP27[ng - 1][i] / 2.0 + 0.5;
     gw[i] = GW27[ng - 1][i] / 2.0;
   }
+  for (int q1 = 0; q1 < ng; ++q1) lag2(gp[q1], h->tab1[0][q1], h->tab1[1][q1]);
   for (int qz = 0; qz < ng; ++qz)
     for (int qy = 0; qy < ng; ++qy)
       for (int qx = 0; qx < ng; ++qx) {
@@ -72,9 +74,9 @@ static int hex27_upload_tables(int ng) {
         for (int a = 0; a < 27; ++a) {
           const int ax = a % 3, ay = (a / 3) % 3, az = a / 9;
           h->N[q][a] = L[0][ax] * L[1][ay] * L[2][az];
-          h->dN[q][a][0] = dL[0][ax] * L[1][ay] * L[2][az];
-          h->dN[q][a][1] = L[0][ax] * dL[1][ay] * L[2][az];
-          h->dN[q][a][2] = L[0][ax] * L[1][ay] * dL[2][az];
+          h->dN[q][0][a] = dL[0][ax] * L[1][ay] * L[2][az];
+          h->dN[q][1][a] = L[0][ax] * dL[1][ay] * L[2][az];
+          h->dN[q][2][a] = L[0][ax] * L[1][ay] * dL[2][az];
         }
       }
   for (int q2 = 0; q2 < ng; ++q2)
@@ -98,25 +100,38 @@ static int hex27_upload_tables(int ng) {
   return MFEM_OK;
 }
 
-// per-wave LDS carve-up (doubles), sized from nq (even-padded): X[27][3] | J->Jinv [nq][9] | w det [nq] |
-// residual scratch [nq][3] + source [nq] | nodal T[28], s[28] | int64 rowbase[27] + int32 info[27][8]
+// per-wave LDS carve-up (doubles), sized from ng / nq = ng^3 (even-padded):
+//   X[27][3] | T1 [2][ng][9][3] (first sum-factorisation stage)          -- both dead once stage 2 has run, so
+//   J -> Jinv [nq][9] overlays them                                        -- (written by stage 3)
+//   T2 [3][ng][ng][3][3] (second stage); the residual's scratch [nq][3] + source [nq] overlays it later
+//   w det [nq] | nodal T[28], s[28] | int64 rowbase[27] + int32 info[27][8]
 __host__ __device__ inline int h27_pad(int v) { return (v + 1) & ~1; }
+__host__ __device__ inline int h27_max(int a, int b) { return a > b ? a : b; }
 #define W_X 0
-#define W_J (W_X + 84)
-#define W_D (W_J + h27_pad(nq * 9))
-#define W_G (W_D + h27_pad(nq))
-#define W_T (W_G + 4 * h27_pad(nq))
+#define W_T1 84
+#define W_J 0
+#define W_T2 h27_max(84 + h27_pad(54 * ng), h27_pad(9 * nq))
+#define W_G W_T2
+#define W_D (W_T2 + h27_max(h27_pad(27 * ng * ng), 4 * h27_pad(nq)))
+#define W_T (W_D + h27_pad(nq))
 #define W_INFO (W_T + 56)
 #define W_SIZE (W_INFO + 27 + 27 * 4 + 1)
+// workgroup-shared decode table of the sum-factorised Jacobian (int32 words): 54 ng + 27 ng^2 + 9 ng^3 entries
+#define H27_NDEC (54 * ng + 27 * ng * ng + 9 * nq)
 #define H27_WAVES 8                  // waves per workgroup (they share the reference tables in LDS)
 #define H27_THREADS (64 * H27_WAVES)
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 
 struct Hex27Args {
   BrickView B;
   const Hex27Tables* tab;
   double kcond;
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
-  int nq;
+  int nq, ng;
   int skip;          // timing probe only (WRONG results): 1 no node loads, 2 no J / inverse, 4 no MFMA loop, 8 no scatter
 };
 
@@ -142,21 +157,42 @@ __device__ __forceinline__ bool colour_element(const BrickView& B, int colour, i
 
 // __launch_bounds__(512, 4) (second argument = waves per SIMD in HIP): two workgroups must fit a CU, i.e. <= 128 VGPRs per lane; without it the
 // scatter epilogue pushed the kernel to 145 VGPRs and only ONE workgroup (2 waves per SIMD) was resident.
-template <bool MATRIX>
+// SCRATCH: the two-pass variant (Ke -> element-major scratch) is its own instantiation, free of the scatter's registers.
+template <bool MATRIX, bool SCRATCH = false>
 __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
                                                         const double* __restrict__ src, double* __restrict__ out) {
   extern __shared__ double lds[];
   // workgroup-shared reference tables
-  double* s_dN = lds;                           // [nq][27][3]
+  double* s_dN = lds;                           // [nq][3][27]
   double* s_N = s_dN + A.nq * 81;               // [nq][27]   (residual only)
   double* s_w = s_N + (MATRIX ? 0 : A.nq * 27); // [nq]
-  double* wave_base = s_w + ((A.nq + 1) & ~1);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int nq = A.nq;
+  const int nq = A.nq, ng = A.ng;
+  double* s_tab1 = s_w + ((A.nq + 1) & ~1);     // [2][ng][4]
+  int32_t* s_dec = reinterpret_cast<int32_t*>(s_tab1 + 8 * ng);
+  double* wave_base = s_tab1 + 8 * ng + (h27_pad(H27_NDEC) >> 1);
+  const int n1 = 54 * ng, n2 = 27 * ng * ng, n3 = 9 * nq;
   for (int i = tid; i < nq * 81; i += H27_THREADS) s_dN[i] = (&A.tab->dN[0][0][0])[i];
   if (!MATRIX)
     for (int i = tid; i < nq * 27; i += H27_THREADS) s_N[i] = (&A.tab->N[0][0])[i];
   for (int i = tid; i < nq; i += H27_THREADS) s_w[i] = A.tab->w[i];
+  for (int i = tid; i < 8 * ng; i += H27_THREADS) s_tab1[i] = A.tab->tab1[i / (4 * ng)][(i >> 2) % ng][i & 3];
+  // decode words of the three sum-factorisation stages: low half = offset of the first of the 3 operands (stride 3),
+  // high half = offset of the 1-D table row
+  for (int t = tid; t < n1; t += H27_THREADS) {   // T1[k][q0][a12][i] = sum_a0 tab1[k][q0][a0] X[a0 + 3 a12][i]
+    const int i = t % 3, a12 = (t / 3) % 9, kq = t / 27;
+    s_dec[t] = (9 * a12 + i) | ((4 * kq) << 16);
+  }
+  for (int t = tid; t < n2; t += H27_THREADS) {   // T2[kk][q0][q1][a2][i] = sum_a1 tab1[kt][q1][a1] T1[k][q0][a1 + 3 a2][i]
+    const int i = t % 3, a2 = (t / 3) % 3, q1 = (t / 9) % ng, q0 = (t / (9 * ng)) % ng, kk = t / (9 * ng * ng);
+    const int k = kk == 0 ? 1 : 0, kt = kk == 1 ? 1 : 0;  // kk = 0: d/dxi0, 1: d/dxi1, 2: values in both (for d/dxi2)
+    s_dec[n1 + t] = (((k * ng + q0) * 9 + 3 * a2) * 3 + i) | ((4 * (kt * ng + q1)) << 16);
+  }
+  for (int t = tid; t < n3; t += H27_THREADS) {   // J[q][i][m] = sum_a2 tab1[m == 2][q2][a2] T2[m][q0][q1][a2][i]
+    const int m = t % 3, i = (t / 3) % 3, q = t / 9;
+    const int q0 = q % ng, q1 = (q / ng) % ng, q2 = q / (ng * ng);
+    s_dec[n1 + n2 + t] = ((((m * ng + q0) * ng + q1) * 3) * 3 + i) | ((4 * ((m == 2 ? 1 : 0) * ng + q2)) << 16);
+  }
   double* W = wave_base + (size_t)wv * W_SIZE;
   __syncthreads();
   const BrickView& B = A.B;
@@ -183,7 +219,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       n.x0 = B.X0[c];
       n.x1 = B.X1[c];
       n.x2 = B.X2[c];
-      if (MATRIX && A.colour != -1) {
+      if (MATRIX && !SCRATCH) {
         // slot(a, b) = rowbase[a] + gi_b * s1_a + gj_b * s2_a + gk_b   with the row's box origin folded into rowbase
         const int c1 = B.c1[gj];
         n.c2 = B.c2[gk];
@@ -205,7 +241,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       W[W_X + 3 * lane + 1] = cur.x1;
       W[W_X + 3 * lane + 2] = cur.x2;
       const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
-      if (MATRIX && A.colour == -1) {
+      if (MATRIX && SCRATCH) {
         // two-pass path: no row descriptors needed
       } else if (MATRIX) {
         rowbase[lane] = cur.rb;
@@ -225,21 +261,31 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     have = colour_element(B, A.colour, e, I, J, K);
     if (have) cur = fetch_nodes(I, J, K);
     __builtin_amdgcn_wave_barrier();
-    // ---- 2a. J[q][i][0..2] = sum_a dN[q][a][0..2] X[a][i] : one (q,i) pair per lane and pass
-    for (int t = lane; t < nq * 3 && !(A.skip & 2); t += 64) {
-      const int q = t / 3, i = t - 3 * q;
-      const double* dn = s_dN + q * 81;
-      double j0 = 0.0, j1 = 0.0, j2 = 0.0;
-#pragma unroll 9
-      for (int a = 0; a < 27; ++a) {
-        const double xa = W[W_X + 3 * a + i];
-        j0 += dn[3 * a + 0] * xa;
-        j1 += dn[3 * a + 1] * xa;
-        j2 += dn[3 * a + 2] * xa;
+    // ---- 2a. J[q][i][m] = sum_a dN[q][a][m] X[a][i], sum-factorised over the tensor-product basis
+    //      (dN[q][a][0] = D(q0,a0) L(q1,a1) L(q2,a2), ...): three stages of 3-term sums through the wave's LDS block,
+    //      ~2000 multiply-adds per element instead of 6561 -- FP64 VALU work runs on the same pipe as the FP64 MFMAs
+    //      on this chip (the phase ablation is additive), so every VALU instruction saved here is matrix-core time.
+    if (!(A.skip & 2)) {
+      for (int t = lane; t < n1; t += 64) {
+        const int d = s_dec[t];
+        const double* x = W + W_X + (d & 0xffff);
+        const double* tb = s_tab1 + (d >> 16);
+        W[W_T1 + t] = tb[0] * x[0] + tb[1] * x[3] + tb[2] * x[6];
       }
-      W[W_J + q * 9 + 3 * i + 0] = j0;
-      W[W_J + q * 9 + 3 * i + 1] = j1;
-      W[W_J + q * 9 + 3 * i + 2] = j2;
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < n2; t += 64) {
+        const int d = s_dec[n1 + t];
+        const double* x = W + W_T1 + (d & 0xffff);
+        const double* tb = s_tab1 + (d >> 16);
+        W[W_T2 + t] = tb[0] * x[0] + tb[1] * x[3] + tb[2] * x[6];
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < n3; t += 64) {
+        const int d = s_dec[n1 + n2 + t];
+        const double* x = W + W_T2 + (d & 0xffff);
+        const double* tb = s_tab1 + (d >> 16);
+        W[W_J + t] = tb[0] * x[0] + tb[1] * x[3] + tb[2] * x[6];
+      }
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 2b. det, inverse (adjugate, inv_Jac_3D), w det ; Jinv overwrites J as [m][s]
@@ -268,33 +314,47 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       d4_t C00 = {0, 0, 0, 0}, C01 = {0, 0, 0, 0}, C11 = {0, 0, 0, 0};
       const int c = lane & 15, kl = lane >> 4;
       const bool hi_ok = (c + 16) < 27;
-      // row r = 4 ks + kl = 3 q + sidx advances by 4 per k-step: (q, sidx) -> (q + 1, sidx + 1) with carry
-      int q = kl / 3, sidx = kl - 3 * q, r = kl;
-      for (int ks = 0; ks < ((A.skip & 4) ? 1 : nksteps); ++ks, r += 4) {
-        double v0 = 0.0, v1 = 0.0, dr = 0.0;
-        if (r < nrows) {
-          const double* Ji = W + W_J + q * 9 + sidx;
-          const double i0 = Ji[0], i1 = Ji[3], i2 = Ji[6];
-          const double* dn = s_dN + q * 81 + 3 * c;
-          v0 = dn[0] * i0 + dn[1] * i1 + dn[2] * i2;
-          if (hi_ok) v1 = dn[48] * i0 + dn[49] * i1 + dn[50] * i2;
+      // The order of the 3 nq rows along k is free: k-steps 3 g + s (s = 0..2) carry the rows (q = 4 g + kl, s), so a lane
+      // keeps one Gauss point for three steps and reads its six table entries, the 3 x 3 inverse and w det once per group
+      // (16 LDS words per group instead of 30).
+      const int ngroups = (A.skip & 4) ? 1 : (nq + 3) >> 2;
+      for (int g = 0; g < ngroups; ++g) {
+        const int q = 4 * g + kl;
+        double d00 = 0.0, d01 = 0.0, d02 = 0.0, d10 = 0.0, d11 = 0.0, d12 = 0.0, dr = 0.0;
+        double ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (q < nq) {
+          const double* dn = s_dN + q * 81 + c;
+          d00 = dn[0];
+          d01 = dn[27];
+          d02 = dn[54];
+          if (hi_ok) {
+            d10 = dn[16];
+            d11 = dn[43];
+            d12 = dn[70];
+          }
+          const double* Ji = W + W_J + q * 9;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) ji[t] = Ji[t];
           dr = -A.kcond * W[W_D + q];
         }
-        sidx += 1;
-        q += 1;
-        if (sidx == 3) {
-          sidx = 0;
-          q += 1;
+#pragma unroll
+        for (int sidx = 0; sidx < 3; ++sidx) {
+          const double v0 = d00 * ji[sidx] + d01 * ji[3 + sidx] + d02 * ji[6 + sidx];
+          const double v1 = d10 * ji[sidx] + d11 * ji[3 + sidx] + d12 * ji[6 + sidx];
+          const double a0 = v0 * dr, a1 = v1 * dr;
+          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
+          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
+          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
         }
-        const double a0 = v0 * dr, a1 = v1 * dr;
-        C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
-        C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
-        C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
       }
-      if (A.colour == -1) {
+      if (SCRATCH) {
         // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
         //      row-owner gather kernel below turns it into CSR rows.
         double* ke = out + ec * 729;
+        if (A.skip & 8) {
+          if (C00[0] + C01[1] + C11[2] == 1.2345) out[0] = 1.0;  // keeps the accumulators alive
+          continue;
+        }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ra = kl + 4 * reg;
@@ -362,10 +422,10 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       //      gradN_a . gradT = sum_m dN[q][a][m] h[q][m],  h = Jinv (Jinv^T gxi),  gxi[m] = sum_b dN[q][b][m] T_b
       for (int t = lane; t < nq * 3; t += 64) {  // lanes (q, m): gxi
         const int q = t / 3, m = t - 3 * q;
-        const double* dn = s_dN + q * 81 + m;
+        const double* dn = s_dN + t * 27;
         double acc = 0.0;
 #pragma unroll 9
-        for (int b = 0; b < 27; ++b) acc += dn[3 * b] * W[W_T + b];
+        for (int b = 0; b < 27; ++b) acc += dn[b] * W[W_T + b];
         W[W_G + t] = acc;
       }
       __builtin_amdgcn_wave_barrier();
@@ -388,8 +448,8 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       if (lane < 27) {
         double fe = 0.0;
         for (int q = 0; q < nq; ++q) {
-          const double* dn = s_dN + q * 81 + 3 * lane;
-          fe += dn[0] * W[W_G + 3 * q] + dn[1] * W[W_G + 3 * q + 1] + dn[2] * W[W_G + 3 * q + 2] +
+          const double* dn = s_dN + q * 81 + lane;
+          fe += dn[0] * W[W_G + 3 * q] + dn[27] * W[W_G + 3 * q + 1] + dn[54] * W[W_G + 3 * q + 2] +
                 s_N[q * 27 + lane] * W[W_G + 3 * h27_pad(nq) + q];
         }
         const int gi = 2 * Ic + lane % 3, gj = 2 * Jc + (lane / 3) % 3, gk = 2 * Kc + lane / 9;
@@ -451,6 +511,92 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather(BrickView B, const 
       }
       out[t] = sum;
     }
+  }
+}
+
+// Pass 2, second version: the workgroup owns 32 consecutive control points and builds their CSR rows in LDS.
+//   A. thread (row, e) works out the row's e-th candidate element (a mid node has one element per dimension, an
+//      element-boundary node two), the offset of the 27-entry run Ke_e[la][0..26] in the scratch and the LDS slot of the
+//      element's first node;
+//   B. half-waves stream the runs in: lane lb < 27 of a half-wave loads entry lb (one contiguous 216-byte read per run, eight
+//      runs in flight per lane) and adds it to the row buffer at the slot of node lb.  A row's runs are taken by one
+//      half-wave in element order e = 0..7, so the summation order is fixed;
+//   C. the rows leave as one contiguous stream.
+// No index arithmetic per CSR slot, every scratch entry read once, every value written once.
+#define G27_NODES 32
+#define G27_ROW 126  // up to 125 entries per row, padded
+__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather_lds(BrickView B, const double* __restrict__ ke, double* __restrict__ vals) {
+  __shared__ double rows[G27_NODES * G27_ROW];
+  __shared__ int64_t s_pre[G27_NODES];
+  __shared__ int64_t s_src[G27_NODES * 8];
+  __shared__ int32_t s_b0[G27_NODES * 8];
+  __shared__ int32_t s_len[G27_NODES], s_c1[G27_NODES], s_c2[G27_NODES];
+  const int tid = threadIdx.x;
+  {
+    const int nl = tid >> 3, e = tid & 7;
+    const int64_t row = (int64_t)blockIdx.x * G27_NODES + nl;
+    const bool live = row < B.n_owned;
+    for (int t = tid; t < G27_NODES * G27_ROW; t += MFEM_BLOCK) rows[t] = 0.0;
+    int g[3] = {0, 0, 0}, lo0 = 0, lo1 = 0, lo2 = 0, c1 = 1, c2 = 1;
+    if (live) {
+      g[0] = (int)(row / B.plane_len) + B.plo;
+      const int64_t rem = row % B.plane_len;
+      g[1] = (int)(rem / B.m2);
+      g[2] = (int)(rem % B.m2);
+      lo0 = B.lo0[g[0]]; lo1 = B.lo1[g[1]]; lo2 = B.lo2[g[2]];
+      c1 = B.c1[g[1]]; c2 = B.c2[g[2]];
+    }
+    if (e == 0) {
+      s_pre[nl] = live ? brick_prefix(B, g[0], g[1], g[2]) : 0;
+      s_len[nl] = live ? B.c0[g[0]] * c1 * c2 : 0;
+      s_c1[nl] = c1;
+      s_c2[nl] = c2;
+    }
+    const int ed[3] = {e & 1, (e >> 1) & 1, e >> 2};
+    const int ne[3] = {B.ne0, B.ne1, B.ne2};
+    int E[3];
+    bool valid = live;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (g[d] & 1) {
+        E[d] = (g[d] - 1) >> 1;
+        valid = valid && ed[d] == 0;
+      } else {
+        E[d] = (g[d] >> 1) - 1 + ed[d];
+      }
+      valid = valid && E[d] >= 0 && E[d] < ne[d];
+    }
+    const int la = (g[0] - 2 * E[0]) + 3 * (g[1] - 2 * E[1]) + 9 * (g[2] - 2 * E[2]);
+    const int64_t eid = ((int64_t)E[0] * ne[1] + E[1]) * ne[2] + E[2];
+    s_src[tid] = valid ? (eid * 27 + la) * 27 : -1;
+    s_b0[tid] = nl * G27_ROW + ((2 * E[0] - lo0) * c1 + (2 * E[1] - lo1)) * c2 + (2 * E[2] - lo2);  // the element's first node
+  }
+  __syncthreads();
+  {
+    const int lane = tid & 63, lb = lane & 31;
+    const int first = (tid >> 6) * 64 + (lane >> 5) * 32;  // this half-wave's 32 (row, e) pairs = 4 rows
+    const bool active = lb < 27;
+    const int bx = lb % 3, by = (lb / 3) % 3, bz = lb / 9;
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+      double v[8];
+      int sl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pair = first + i0 + j, nl = pair >> 3;
+        const int64_t src = s_src[pair];
+        const bool ok = active && src >= 0;
+        v[j] = ok ? ke[src + lb] : 0.0;
+        sl[j] = ok ? s_b0[pair] + (bx * s_c1[nl] + by) * s_c2[nl] + bz : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (sl[j] >= 0) rows[sl[j]] += v[j];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G27_NODES * 125; idx += MFEM_BLOCK) {
+    const int n2 = idx / 125, o = idx - n2 * 125;
+    if (o < s_len[n2]) vals[s_pre[n2] + o] = rows[n2 * G27_ROW + o];
   }
 }
 
@@ -537,15 +683,19 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
 static int g_hex27_two_pass = 0;
 static int g_hex27_skip = 0;
+static int g_hex27_gather_v1 = 0;  // bit 2 of mfem_debug_set_hex27: the first (wave-per-row) gather kernel
 extern "C" int mfem_debug_set_hex27(int two_pass) {
   ++mfem_debug_epoch;
   g_hex27_two_pass = two_pass & 3;  // 0 colours, 1 two-pass, 2 FP64 atomics
-  g_hex27_skip = (two_pass >> 8) & 15;  // timing probe (tools/probe_hex27.py): phases left out, results WRONG
+  g_hex27_gather_v1 = (two_pass >> 2) & 1;
+  g_hex27_skip = (two_pass >> 8) & 31;  // timing probe (tools/probe_hex27.py): phases left out, results WRONG
   return MFEM_OK;
 }
 
-static size_t hex27_lds_bytes(int nq, bool matrix) {
-  return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + H27_WAVES * (size_t)(W_SIZE));
+static size_t hex27_lds_bytes(int ng, bool matrix) {
+  const int nq = ng * ng * ng;
+  return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + 8 * ng + (h27_pad(H27_NDEC) >> 1) +
+                           H27_WAVES * (size_t)(W_SIZE));
 }
 
 static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix, double h, double Tenv, uint32_t robin,
@@ -589,13 +739,13 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   const int nq = m->ng * m->ng * m->ng;
   int rc = hex27_upload_tables(m->ng);
   if (rc) return rc;
-  const size_t lds = hex27_lds_bytes(nq, true);
+  const size_t lds = hex27_lds_bytes(m->ng, true);
   MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   BrickView B = mfem_brick_view(m, 1);
   if (g_hex27_two_pass == 2) {
     MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
     const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
-    Hex27Args A{B, g_tab, p->k, -2, nq, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, -2, nq, m->ng, g_hex27_skip};
     int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
@@ -608,13 +758,18 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
     rc = mfem_ws_reserve(ctx, sizeof(double) * 729 * (size_t)nel);
     if (rc) return rc;
-    Hex27Args A{B, g_tab, p->k, -1, nq, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, g_hex27_skip};
     int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)ctx->ws);
+    MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_hex27<true, true>), dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)ctx->ws);
     MFEM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_hex27_gather, dim3(ctx->num_cus * 8), dim3(MFEM_BLOCK), 0, ctx->stream, B, (const double*)ctx->ws, vals);
+    if (g_hex27_gather_v1)
+      hipLaunchKernelGGL(k_hex27_gather, dim3(ctx->num_cus * 8), dim3(MFEM_BLOCK), 0, ctx->stream, B, (const double*)ctx->ws, vals);
+    else
+      hipLaunchKernelGGL(k_hex27_gather_lds, dim3((unsigned)((m->n_owned + G27_NODES - 1) / G27_NODES)), dim3(MFEM_BLOCK), 0,
+                         ctx->stream, B, (const double*)ctx->ws, vals);
     MFEM_CHECK_LAUNCH();
     return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
   }
@@ -624,7 +779,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, g_hex27_skip};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
@@ -640,7 +795,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
   const int nq = m->ng * m->ng * m->ng;
   int rc = hex27_upload_tables(m->ng);
   if (rc) return rc;
-  const size_t lds = hex27_lds_bytes(nq, false);
+  const size_t lds = hex27_lds_bytes(m->ng, false);
   MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   MFEM_CHECK_HIP(hipMemsetAsync(residue, 0, sizeof(double) * (size_t)m->n_owned, ctx->stream));
   BrickView B = mfem_brick_view(m, 1);
@@ -649,7 +804,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, 0};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, 0};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
