@@ -118,10 +118,11 @@ int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_colu
 int mfem_debug_set_graphs(int on, int64_t max_n);
 /* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
 int mfem_debug_set_vec_grid(int workgroups_per_cu);
-/* hex-27 matrix assembly: bits 0-1: 0 (default) colour-partitioned read-modify-write scatter straight from the MFMA
- * accumulators, 1 MFMA Ke -> element-major scratch + row-owner gather, 2 FP64 atomics in one launch (both slower).
- * Bits 8-11: timing probe that leaves kernel phases out (results WRONG): 0x100 node loads, 0x200 Jacobians, 0x400 MFMA
- * loop, 0x800 scatter. */
+/* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
+ * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
+ * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
+ * 16 GiB scratch budget).  Bits 8-12: timing probe that leaves kernel phases out (results WRONG): 0x100 node loads,
+ * 0x200 Jacobians, 0x400 MFMA loop, 0x800 scatter / scratch store. */
 int mfem_debug_set_hex27(int two_pass);
 /* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
  * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */

@@ -126,34 +126,65 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {  // l wave-uni
   return __hiloint2double(hi, lo);
 }
 
+// Row order of an element's Ke in the scratch: dimension-2 index fastest (a = a0 + 3 a1 + 9 a2 -> a2 + 3 a1 + 9 a0).  The
+// gather walks the control points with dimension 2 fastest, so the three rows an element gives to one wave are one
+// contiguous 648-byte piece and the nine rows of a dimension-0 layer (1944 bytes) are used within a few workgroups of each
+// other -- whole cache lines get used while they are resident.
+__device__ __forceinline__ int scratch_row(int a) { return a / 9 + 3 * ((a / 3) % 3) + 9 * (a % 3); }
+
 struct Hex27Args {
   BrickView B;
   const Hex27Tables* tab;
   double kcond;
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
   int nq, ng;
+  int e_lo, e_cnt, ring;  // scratch variant: element planes [e_lo, e_lo + e_cnt) of dimension 0, plane I kept in ring slot I % ring
   int skip;          // timing probe only (WRONG results): 1 no node loads, 2 no J / inverse, 4 no MFMA loop, 8 no scatter
 };
 
-// Element of this colour with running index e -> (I,J,K); returns false past the end.
-__device__ __forceinline__ bool colour_element(const BrickView& B, int colour, int64_t e, int& I, int& J, int& K) {
-  if (colour < 0) {  // no colouring: plain lexicographic element order (the scratch path)
-    if (e >= (int64_t)B.ne0 * B.ne1 * B.ne2) return false;
-    const int ei = (int)e;
-    K = ei % B.ne2;
-    J = (ei / B.ne2) % B.ne1;
-    I = ei / (B.ne1 * B.ne2);
-    return true;
+// Walk of one wave over its elements: the elements of a launch form an n0 x n1 x n2 grid (one colour's sub-lattice, or the
+// planes [e_lo, e_lo + e_cnt) of the whole mesh for the scratch path); the wave starts at running index e and advances by
+// the number of waves.  The mixed-radix step is worked out once, so an advance is a few adds instead of three integer
+// divisions per element.
+struct ElemWalk {
+  int ci, cj, ck;      // position in the launch's grid
+  int si, sj, sk;      // mixed-radix digits of the stride
+  int n0, n1, n2;
+  int mul, o0, o1, o2; // element (I, J, K) = mul * (ci, cj, ck) + (o0, o1, o2)
+  __device__ __forceinline__ void init(const BrickView& B, int colour, int e_lo, int e_cnt, int64_t e, int stride) {
+    if (colour < 0) {
+      n0 = e_cnt; n1 = B.ne1; n2 = B.ne2;
+      mul = 1; o0 = e_lo; o1 = 0; o2 = 0;
+    } else {
+      o0 = colour & 1; o1 = (colour >> 1) & 1; o2 = colour >> 2;
+      n0 = (B.ne0 - o0 + 1) >> 1; n1 = (B.ne1 - o1 + 1) >> 1; n2 = (B.ne2 - o2 + 1) >> 1;
+      mul = 2;
+    }
+    if (n0 <= 0 || n1 <= 0 || n2 <= 0) {
+      ci = 0; n0 = 0; cj = ck = si = sj = sk = 0;
+      return;
+    }
+    const int64_t n12 = (int64_t)n1 * n2;
+    ci = (int)(e / n12 < n0 ? e / n12 : n0);
+    cj = (int)((e % n12) / n2);
+    ck = (int)(e % n2);
+    const int64_t sI = stride / n12;
+    si = (int)(sI < n0 ? sI : n0);
+    sj = (int)((stride % n12) / n2);
+    sk = (int)(stride % n2);
   }
-  const int cx = colour & 1, cy = (colour >> 1) & 1, cz = colour >> 2;
-  const int n0 = (B.ne0 - cx + 1) >> 1, n1 = (B.ne1 - cy + 1) >> 1, n2 = (B.ne2 - cz + 1) >> 1;
-  if (n0 <= 0 || n1 <= 0 || n2 <= 0 || e >= (int64_t)n0 * n1 * n2) return false;
-  const int ei = (int)e;  // element counts fit int32 (control-point ids do)
-  K = 2 * (ei % n2) + cz;
-  J = 2 * ((ei / n2) % n1) + cy;
-  I = 2 * (ei / (n1 * n2)) + cx;
-  return true;
-}
+  __device__ __forceinline__ bool have() const { return ci < n0; }
+  __device__ __forceinline__ void get(int& I, int& J, int& K) const {
+    I = mul * ci + o0; J = mul * cj + o1; K = mul * ck + o2;
+  }
+  __device__ __forceinline__ void advance() {
+    ck += sk;
+    if (ck >= n2) { ck -= n2; cj += 1; }
+    cj += sj;
+    if (cj >= n1) { cj -= n1; ci += 1; }
+    ci += si;
+  }
+};
 
 // __launch_bounds__(512, 4) (second argument = waves per SIMD in HIP): two workgroups must fit a CU, i.e. <= 128 VGPRs per lane; without it the
 // scatter epilogue pushed the kernel to 145 VGPRs and only ONE workgroup (2 waves per SIMD) was resident.
@@ -199,8 +230,6 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   int64_t* rowbase = reinterpret_cast<int64_t*>(W + W_INFO);
   int32_t* info = reinterpret_cast<int32_t*>(W + W_INFO + 27);
   const int nwaves = gridDim.x * H27_WAVES;
-  const int nrows = 3 * nq;                  // rows of B
-  const int nksteps = (nrows + 3) >> 2;      // MFMA k-steps (4 rows each; rows >= nrows contribute zero)
 
   // Node data of an element (lane a < 27: coordinates of node a and, for the scatter, its CSR row descriptor).  The loads
   // of element e + nwaves are issued while element e is still being integrated and land in registers; they are written
@@ -230,9 +259,11 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     }
     return n;
   };
-  int I, J, K;
-  int64_t e = (int64_t)blockIdx.x * H27_WAVES + wv;
-  bool have = colour_element(B, A.colour, e, I, J, K);  // wave-uniform
+  int I = 0, J = 0, K = 0;
+  ElemWalk walk;
+  walk.init(B, A.colour, A.e_lo, A.e_cnt, (int64_t)blockIdx.x * H27_WAVES + wv, nwaves);
+  bool have = walk.have();  // wave-uniform
+  if (have) walk.get(I, J, K);
   NodePre cur = have ? fetch_nodes(I, J, K) : NodePre{0.0, 0.0, 0.0, 0, 0, 0};
   while (have) {
     // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
@@ -256,9 +287,9 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     }
     // next element of this wave: issue its node loads now
     const int Ic = I, Jc = J, Kc = K;
-    const int64_t ec = e;
-    e += nwaves;
-    have = colour_element(B, A.colour, e, I, J, K);
+    walk.advance();
+    have = walk.have();
+    if (have) walk.get(I, J, K);
     if (have) cur = fetch_nodes(I, J, K);
     __builtin_amdgcn_wave_barrier();
     // ---- 2a. J[q][i][m] = sum_a dN[q][a][m] X[a][i], sum-factorised over the tensor-product basis
@@ -294,6 +325,20 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       const double j00 = Jm[0], j01 = Jm[1], j02 = Jm[2], j10 = Jm[3], j11 = Jm[4], j12 = Jm[5], j20 = Jm[6], j21 = Jm[7],
                    j22 = Jm[8];
       const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+      if (MATRIX) {
+        // matrix: only G = -k w det Jinv Jinv^T (symmetric 3 x 3) is needed: Ke = sum_q dN_q G_q dN_q^T
+        const double c00 = j11 * j22 - j12 * j21, c01 = j02 * j21 - j01 * j22, c02 = j01 * j12 - j11 * j02;
+        const double c10 = j12 * j20 - j22 * j10, c11 = j00 * j22 - j02 * j20, c12 = j02 * j10 - j00 * j12;
+        const double c20 = j10 * j21 - j11 * j20, c21 = j01 * j20 - j21 * j00, c22 = j00 * j11 - j10 * j01;
+        const double sc = -A.kcond * s_w[q] / det;
+        Jm[0] = sc * (c00 * c00 + c01 * c01 + c02 * c02);
+        Jm[1] = sc * (c00 * c10 + c01 * c11 + c02 * c12);
+        Jm[2] = sc * (c00 * c20 + c01 * c21 + c02 * c22);
+        Jm[3] = sc * (c10 * c10 + c11 * c11 + c12 * c12);
+        Jm[4] = sc * (c10 * c20 + c11 * c21 + c12 * c22);
+        Jm[5] = sc * (c20 * c20 + c21 * c21 + c22 * c22);
+        continue;
+      }
       const double id = 1.0 / det;
       Jm[0] = (j11 * j22 - j12 * j21) * id;
       Jm[1] = (j02 * j21 - j01 * j22) * id;
@@ -314,58 +359,63 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       d4_t C00 = {0, 0, 0, 0}, C01 = {0, 0, 0, 0}, C11 = {0, 0, 0, 0};
       const int c = lane & 15, kl = lane >> 4;
       const bool hi_ok = (c + 16) < 27;
-      // The order of the 3 nq rows along k is free: k-steps 3 g + s (s = 0..2) carry the rows (q = 4 g + kl, s), so a lane
-      // keeps one Gauss point for three steps and reads its six table entries, the 3 x 3 inverse and w det once per group
-      // (16 LDS words per group instead of 30).
+      // Ke = sum_q dN_q G_q dN_q^T: k-row (q, n) has the B operand dN[q][b][n] straight from the table and the A operand
+      // sum_m dN[q][a][m] G_q[m][n] (3 FMAs).  The order of the 3 nq rows along k is free: k-steps 3 g + n (n = 0..2) carry
+      // the rows (q = 4 g + kl, n), so a lane keeps one Gauss point for three steps and reads its six table entries and the
+      // six entries of G once per group (12 LDS words per group; the first version read 30).
       const int ngroups = (A.skip & 4) ? 1 : (nq + 3) >> 2;
       for (int g = 0; g < ngroups; ++g) {
         const int q = 4 * g + kl;
-        double d00 = 0.0, d01 = 0.0, d02 = 0.0, d10 = 0.0, d11 = 0.0, d12 = 0.0, dr = 0.0;
-        double ji[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double d0[3] = {0.0, 0.0, 0.0}, d1[3] = {0.0, 0.0, 0.0};
+        double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         if (q < nq) {
           const double* dn = s_dN + q * 81 + c;
-          d00 = dn[0];
-          d01 = dn[27];
-          d02 = dn[54];
+          d0[0] = dn[0];
+          d0[1] = dn[27];
+          d0[2] = dn[54];
           if (hi_ok) {
-            d10 = dn[16];
-            d11 = dn[43];
-            d12 = dn[70];
+            d1[0] = dn[16];
+            d1[1] = dn[43];
+            d1[2] = dn[70];
           }
-          const double* Ji = W + W_J + q * 9;
-#pragma unroll
-          for (int t = 0; t < 9; ++t) ji[t] = Ji[t];
-          dr = -A.kcond * W[W_D + q];
+          const double* Gq = W + W_J + q * 9;
+          G[0][0] = Gq[0];
+          G[0][1] = G[1][0] = Gq[1];
+          G[0][2] = G[2][0] = Gq[2];
+          G[1][1] = Gq[3];
+          G[1][2] = G[2][1] = Gq[4];
+          G[2][2] = Gq[5];
         }
 #pragma unroll
-        for (int sidx = 0; sidx < 3; ++sidx) {
-          const double v0 = d00 * ji[sidx] + d01 * ji[3 + sidx] + d02 * ji[6 + sidx];
-          const double v1 = d10 * ji[sidx] + d11 * ji[3 + sidx] + d12 * ji[6 + sidx];
-          const double a0 = v0 * dr, a1 = v1 * dr;
-          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v0, C00, 0, 0, 0);
-          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v1, C01, 0, 0, 0);
-          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v1, C11, 0, 0, 0);
+        for (int n = 0; n < 3; ++n) {
+          const double a0 = d0[0] * G[0][n] + d0[1] * G[1][n] + d0[2] * G[2][n];
+          const double a1 = d1[0] * G[0][n] + d1[1] * G[1][n] + d1[2] * G[2][n];
+          C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d0[n], C00, 0, 0, 0);
+          C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d1[n], C01, 0, 0, 0);
+          C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d1[n], C11, 0, 0, 0);
         }
       }
       if (SCRATCH) {
         // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
         //      row-owner gather kernel below turns it into CSR rows.
-        double* ke = out + ec * 729;
+        double* ke = out + (((int64_t)(Ic % A.ring) * B.ne1 + Jc) * B.ne2 + Kc) * 729;
         if (A.skip & 8) {
           if (C00[0] + C01[1] + C11[2] == 1.2345) out[0] = 1.0;  // keeps the accumulators alive
           continue;
         }
+        const int rc_hi = scratch_row(16 + c > 26 ? 26 : 16 + c);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ra = kl + 4 * reg;
           if (ra < 27) {
-            ke[ra * 27 + c] = C00[reg];
+            const int r0 = scratch_row(ra);
+            ke[r0 * 27 + c] = C00[reg];
             if (hi_ok) {
-              ke[ra * 27 + 16 + c] = C01[reg];
-              ke[(16 + c) * 27 + ra] = C01[reg];
+              ke[r0 * 27 + 16 + c] = C01[reg];
+              ke[rc_hi * 27 + ra] = C01[reg];
             }
           }
-          if (16 + ra < 27 && hi_ok) ke[(16 + ra) * 27 + 16 + c] = C11[reg];
+          if (16 + ra < 27 && hi_ok) ke[scratch_row(16 + ra) * 27 + 16 + c] = C11[reg];
         }
         __builtin_amdgcn_wave_barrier();
         continue;
@@ -421,7 +471,6 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       // ---- 3'. residual: fe[a] = sum_q w det ( -k gradN_a . gradT + N_a s_q )
       //      gradN_a . gradT = sum_m dN[q][a][m] h[q][m],  h = Jinv (Jinv^T gxi),  gxi[m] = sum_b dN[q][b][m] T_b
       for (int t = lane; t < nq * 3; t += 64) {  // lanes (q, m): gxi
-        const int q = t / 3, m = t - 3 * q;
         const double* dn = s_dN + t * 27;
         double acc = 0.0;
 #pragma unroll 9
@@ -460,89 +509,40 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   }
 }
 
-// Pass 2 of the two-pass assembly: one wave per CSR row (control point); lane t owns slot t, t + 64, ...; for every
-// adjacent element that contains both the row node and the slot's node it adds Ke_e[la][lb] from the scratch.
-// Reads 729*8 B per element once (each Ke row segment is a contiguous 216-byte run), writes every CSR value once.
-__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather(BrickView B, const double* __restrict__ ke,
-                                                               double* __restrict__ vals) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t row = wave; row < B.n_owned; row += nwaves) {
-    int g[3];
-    g[0] = (int)(row / B.plane_len) + B.plo;
-    const int64_t rem = row % B.plane_len;
-    g[1] = (int)(rem / B.m2);
-    g[2] = (int)(rem % B.m2);
-    const int lo0 = B.lo0[g[0]], lo1 = B.lo1[g[1]], lo2 = B.lo2[g[2]];
-    const int c1 = B.c1[g[1]], c2 = B.c2[g[2]];
-    const int len = B.c0[g[0]] * c1 * c2;
-    const int ne[3] = {B.ne0, B.ne1, B.ne2};
-    int e0[3], cnt[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (g[d] & 1) {  // mid node of one element
-        e0[d] = (g[d] - 1) >> 1;
-        cnt[d] = 1;
-      } else {         // element-boundary node: elements g/2 - 1 and g/2
-        e0[d] = (g[d] >> 1) - 1;
-        cnt[d] = 2;
-      }
-    }
-    double* out = vals + brick_prefix(B, g[0], g[1], g[2]);
-    for (int t = lane; t < len; t += 64) {
-      const int nk = lo2 + t % c2, nj = lo1 + (t / c2) % c1, ni = lo0 + t / (c1 * c2);
-      double sum = 0.0;
-      for (int ex = 0; ex < cnt[0]; ++ex) {
-        const int E0 = e0[0] + ex;
-        if (E0 < 0 || E0 >= ne[0] || ni < 2 * E0 || ni > 2 * E0 + 2) continue;
-        for (int ey = 0; ey < cnt[1]; ++ey) {
-          const int E1 = e0[1] + ey;
-          if (E1 < 0 || E1 >= ne[1] || nj < 2 * E1 || nj > 2 * E1 + 2) continue;
-          for (int ez = 0; ez < cnt[2]; ++ez) {
-            const int E2 = e0[2] + ez;
-            if (E2 < 0 || E2 >= ne[2] || nk < 2 * E2 || nk > 2 * E2 + 2) continue;
-            const int la = (g[0] - 2 * E0) + 3 * (g[1] - 2 * E1) + 9 * (g[2] - 2 * E2);
-            const int lb = (ni - 2 * E0) + 3 * (nj - 2 * E1) + 9 * (nk - 2 * E2);
-            const int64_t eid = ((int64_t)E0 * ne[1] + E1) * ne[2] + E2;
-            sum += ke[(eid * 27 + la) * 27 + lb];
-          }
-        }
-      }
-      out[t] = sum;
-    }
-  }
-}
-
-// Pass 2, second version: the workgroup owns 32 consecutive control points and builds their CSR rows in LDS.
-//   A. thread (row, e) works out the row's e-th candidate element (a mid node has one element per dimension, an
+// Pass 2 of the two-pass assembly: a wave owns 8 consecutive control points and builds their CSR rows in LDS (four waves
+// per workgroup, no workgroup barrier -- the waves never exchange data).
+//   A. lane (row, e) works out the row's e-th candidate element (a mid node has one element per dimension, an
 //      element-boundary node two), the offset of the 27-entry run Ke_e[la][0..26] in the scratch and the LDS slot of the
-//      element's first node;
-//   B. half-waves stream the runs in: lane lb < 27 of a half-wave loads entry lb (one contiguous 216-byte read per run, eight
-//      runs in flight per lane) and adds it to the row buffer at the slot of node lb.  A row's runs are taken by one
-//      half-wave in element order e = 0..7, so the summation order is fixed;
-//   C. the rows leave as one contiguous stream.
+//      element's first node; a ballot gives the wave the set of (row, e) pairs that exist (3.4 of 8 on average);
+//   B. each half-wave streams the runs of its 4 rows in: lane lb < 27 loads entry lb (one contiguous 216-byte read per
+//      run, up to sixteen runs in flight per lane) and adds it to the row buffer at the slot of node lb.  A row's runs are taken by
+//      one half-wave in element order e = 0..7, so the summation order is fixed;
+//   C. the rows leave as contiguous streams.
 // No index arithmetic per CSR slot, every scratch entry read once, every value written once.
 #define G27_NODES 32
 #define G27_ROW 126  // up to 125 entries per row, padded
-__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather_lds(BrickView B, const double* __restrict__ ke, double* __restrict__ vals) {
+#define G27_FLIGHT 16 // runs a lane has in flight (the kernel is latency-bound: 4 -> 5.8 ms, 8 -> 5.1 ms at 128^3)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather_lds(BrickView B, const double* __restrict__ ke, double* __restrict__ vals, int64_t row_lo,
+                                                                  int64_t row_hi, int ring) {
   __shared__ double rows[G27_NODES * G27_ROW];
   __shared__ int64_t s_pre[G27_NODES];
   __shared__ int64_t s_src[G27_NODES * 8];
   __shared__ int32_t s_b0[G27_NODES * 8];
   __shared__ int32_t s_len[G27_NODES], s_c1[G27_NODES], s_c2[G27_NODES];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int t = lane; t < 8 * G27_ROW; t += 64) rows[wv * 8 * G27_ROW + t] = 0.0;
+  uint64_t pairs;
   {
     const int nl = tid >> 3, e = tid & 7;
-    const int64_t row = (int64_t)blockIdx.x * G27_NODES + nl;
-    const bool live = row < B.n_owned;
-    for (int t = tid; t < G27_NODES * G27_ROW; t += MFEM_BLOCK) rows[t] = 0.0;
+    const int64_t row = row_lo + (int64_t)blockIdx.x * G27_NODES + nl;
+    const bool live = row < row_hi;
     int g[3] = {0, 0, 0}, lo0 = 0, lo1 = 0, lo2 = 0, c1 = 1, c2 = 1;
     if (live) {
-      g[0] = (int)(row / B.plane_len) + B.plo;
-      const int64_t rem = row % B.plane_len;
-      g[1] = (int)(rem / B.m2);
-      g[2] = (int)(rem % B.m2);
+      const uint32_t r32 = (uint32_t)row, pl = (uint32_t)B.plane_len, m2 = (uint32_t)B.m2;  // control-point ids fit int32
+      const uint32_t q0 = r32 / pl, rem = r32 - q0 * pl, q1 = rem / m2;
+      g[0] = (int)q0 + B.plo;
+      g[1] = (int)q1;
+      g[2] = (int)(rem - q1 * m2);
       lo0 = B.lo0[g[0]]; lo1 = B.lo1[g[1]]; lo2 = B.lo2[g[2]];
       c1 = B.c1[g[1]]; c2 = B.c2[g[2]];
     }
@@ -567,36 +567,44 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather_lds(BrickView B, co
       valid = valid && E[d] >= 0 && E[d] < ne[d];
     }
     const int la = (g[0] - 2 * E[0]) + 3 * (g[1] - 2 * E[1]) + 9 * (g[2] - 2 * E[2]);
-    const int64_t eid = ((int64_t)E[0] * ne[1] + E[1]) * ne[2] + E[2];
-    s_src[tid] = valid ? (eid * 27 + la) * 27 : -1;
+    const int64_t eid = ((int64_t)(valid ? E[0] % ring : 0) * ne[1] + E[1]) * ne[2] + E[2];
+    s_src[tid] = valid ? (eid * 27 + scratch_row(valid ? la : 0)) * 27 : 0;
     s_b0[tid] = nl * G27_ROW + ((2 * E[0] - lo0) * c1 + (2 * E[1] - lo1)) * c2 + (2 * E[2] - lo2);  // the element's first node
+    pairs = __ballot(valid);
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   {
-    const int lane = tid & 63, lb = lane & 31;
-    const int first = (tid >> 6) * 64 + (lane >> 5) * 32;  // this half-wave's 32 (row, e) pairs = 4 rows
+    const int lb = lane & 31;
+    const int first = wv * 64 + (lane >> 5) * 32;  // this half-wave's 32 (row, e) pairs = 4 rows
     const bool active = lb < 27;
     const int bx = lb % 3, by = (lb / 3) % 3, bz = lb / 9;
-    for (int i0 = 0; i0 < 32; i0 += 8) {
-      double v[8];
-      int sl[8];
+    uint32_t todo = (lane >> 5) ? (uint32_t)(pairs >> 32) : (uint32_t)pairs;
+    while (todo) {
+      double v[G27_FLIGHT];
+      int sl[G27_FLIGHT];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int pair = first + i0 + j, nl = pair >> 3;
-        const int64_t src = s_src[pair];
-        const bool ok = active && src >= 0;
-        v[j] = ok ? ke[src + lb] : 0.0;
-        sl[j] = ok ? s_b0[pair] + (bx * s_c1[nl] + by) * s_c2[nl] + bz : -1;
+      for (int j = 0; j < G27_FLIGHT; ++j) {
+        sl[j] = -1;
+        v[j] = 0.0;
+        if (todo) {
+          const int pair = first + __builtin_ctz(todo), nl = pair >> 3;
+          todo &= todo - 1;
+          if (active) {
+            v[j] = ke[s_src[pair] + lb];
+            sl[j] = s_b0[pair] + (bx * s_c1[nl] + by) * s_c2[nl] + bz;
+          }
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < G27_FLIGHT; ++j)
         if (sl[j] >= 0) rows[sl[j]] += v[j];
     }
   }
-  __syncthreads();
-  for (int idx = tid; idx < G27_NODES * 125; idx += MFEM_BLOCK) {
-    const int n2 = idx / 125, o = idx - n2 * 125;
-    if (o < s_len[n2]) vals[s_pre[n2] + o] = rows[n2 * G27_ROW + o];
+  __builtin_amdgcn_wave_barrier();
+  for (int r = 0; r < 8; ++r) {
+    const int n2 = wv * 8 + r, len = s_len[n2];
+    const int64_t pre = s_pre[n2];
+    for (int o = lane; o < len; o += 64) vals[pre + o] = rows[n2 * G27_ROW + o];
   }
 }
 
@@ -681,13 +689,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // 0 (default): colour-partitioned RMW scatter; 1: Ke -> element-major scratch (MFMA kernel, no colours, no RMW) +
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
-static int g_hex27_two_pass = 0;
+static int g_hex27_two_pass = 1;
 static int g_hex27_skip = 0;
-static int g_hex27_gather_v1 = 0;  // bit 2 of mfem_debug_set_hex27: the first (wave-per-row) gather kernel
+static int g_hex27_chunk_planes = 0;  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
+static size_t g_hex27_scratch_budget = (size_t)16 << 30;
 extern "C" int mfem_debug_set_hex27(int two_pass) {
   ++mfem_debug_epoch;
-  g_hex27_two_pass = two_pass & 3;  // 0 colours, 1 two-pass, 2 FP64 atomics
-  g_hex27_gather_v1 = (two_pass >> 2) & 1;
+  g_hex27_two_pass = (two_pass & 3) == 0 ? 1 : (two_pass & 3);  // 0 / 1 two-pass (default), 2 FP64 atomics, 3 colour scatter
+  g_hex27_chunk_planes = (two_pass >> 16) & 255;
   g_hex27_skip = (two_pass >> 8) & 31;  // timing probe (tools/probe_hex27.py): phases left out, results WRONG
   return MFEM_OK;
 }
@@ -745,7 +754,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   if (g_hex27_two_pass == 2) {
     MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
     const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
-    Hex27Args A{B, g_tab, p->k, -2, nq, m->ng, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, -2, nq, m->ng, 0, m->ne[0], 1, g_hex27_skip};
     int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
@@ -754,23 +763,34 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
   }
   if (g_hex27_two_pass == 1) {
-    // pass 1: every element's Ke on the matrix cores -> element-major scratch; pass 2: row-owner gather -> CSR
-    const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
-    rc = mfem_ws_reserve(ctx, sizeof(double) * 729 * (size_t)nel);
+    // pass 1: every element's Ke on the matrix cores -> element-major scratch; pass 2: row-owner gather -> CSR.
+    // The scratch is a ring of element planes (dimension 0): a chunk computes planes [a, b) and gathers the control-point
+    // planes [2a, 2b) (the last chunk also 2b), which need element planes a-1 .. b-1 -- plane a-1 is still in the ring.
+    const int64_t plane_el = (int64_t)m->ne[1] * m->ne[2];
+    const size_t plane_bytes = sizeof(double) * 729 * (size_t)plane_el;
+    int P = m->ne[0];
+    if (g_hex27_chunk_planes > 0) P = g_hex27_chunk_planes;
+    else if (plane_bytes * (size_t)m->ne[0] > g_hex27_scratch_budget) P = (int)(g_hex27_scratch_budget / plane_bytes) - 1;
+    if (P < 1) P = 1;
+    if (P > m->ne[0]) P = m->ne[0];
+    const int ring = P >= m->ne[0] ? m->ne[0] : P + 1;
+    rc = mfem_ws_reserve(ctx, plane_bytes * (size_t)ring);
     if (rc) return rc;
-    Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, g_hex27_skip};
-    int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
-    const int64_t cap = (int64_t)ctx->num_cus * 2;
-    if (grid > cap) grid = cap;
     MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_hex27<true, true>), dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)ctx->ws);
-    MFEM_CHECK_LAUNCH();
-    if (g_hex27_gather_v1)
-      hipLaunchKernelGGL(k_hex27_gather, dim3(ctx->num_cus * 8), dim3(MFEM_BLOCK), 0, ctx->stream, B, (const double*)ctx->ws, vals);
-    else
-      hipLaunchKernelGGL(k_hex27_gather_lds, dim3((unsigned)((m->n_owned + G27_NODES - 1) / G27_NODES)), dim3(MFEM_BLOCK), 0,
-                         ctx->stream, B, (const double*)ctx->ws, vals);
-    MFEM_CHECK_LAUNCH();
+    const int64_t plane_rows = B.plane_len;
+    for (int a = 0; a < m->ne[0]; a += P) {
+      const int b = a + P < m->ne[0] ? a + P : m->ne[0];
+      Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, a, b - a, ring, g_hex27_skip};
+      int64_t grid = ((b - a) * plane_el + H27_WAVES - 1) / H27_WAVES;
+      const int64_t cap = (int64_t)ctx->num_cus * 2;
+      if (grid > cap) grid = cap;
+      hipLaunchKernelGGL((k_hex27<true, true>), dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)ctx->ws);
+      MFEM_CHECK_LAUNCH();
+      const int64_t row_lo = 2 * (int64_t)a * plane_rows, row_hi = b == m->ne[0] ? m->n_owned : 2 * (int64_t)b * plane_rows;
+      hipLaunchKernelGGL(k_hex27_gather_lds, dim3((unsigned)((row_hi - row_lo + G27_NODES - 1) / G27_NODES)), dim3(MFEM_BLOCK), 0,
+                         ctx->stream, B, (const double*)ctx->ws, vals, row_lo, row_hi, ring);
+      MFEM_CHECK_LAUNCH();
+    }
     return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
   }
   MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
@@ -779,7 +799,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, 0, 0, 1, g_hex27_skip};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
@@ -804,7 +824,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
                   n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
     const int64_t ne = n0 * n1 * n2;
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, 0};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, 0, 0, 1, 0};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;

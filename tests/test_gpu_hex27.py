@@ -27,9 +27,10 @@ def _oracle(x, n, itg=5, distort=False, faces=None):
     return od
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["colour_scatter", "two_pass_gather", "fp64_atomics"])
+@pytest.fixture(params=[0, 1 | (1 << 16), 1 | (3 << 16), 2, 3],
+                ids=["two_pass_gather", "two_pass_ring_1_plane", "two_pass_ring_3_planes", "fp64_atomics", "colour_scatter"])
 def variant(request):
-    """Both matrix-assembly variants: colour-partitioned RMW scatter (default) and MFMA Ke -> scratch + row-owner gather."""
+    """All matrix-assembly variants: MFMA Ke -> scratch ring + LDS row-building gather (default), FP64 atomics, colour-partitioned RMW scatter."""
     from metafem_jl_amd import _lib
 
     _lib.lib.mfem_debug_set_hex27(request.param)

@@ -21,15 +21,22 @@ flops = brick.nel * (2 * 27 * 27 * 81)
 _lib.lib.mfem_debug_set_hex27(1)
 ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
 print(f"assemble two-pass (scratch + gather) {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful", flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "chunks":  # element planes per scratch chunk (ring of planes)
+    for P in (1, 2, 3, 4, 6, 8, 16, 32, 64, 128):
+        _lib.lib.mfem_debug_set_hex27(1 | (P << 16))
+        ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
+        print(f"  two-pass, {P} element planes per chunk: {ms:.2f} ms", flush=True)
+    sys.exit(0)
 _lib.lib.mfem_debug_set_hex27(2)
 ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
 Ka = K.clone()
 print(f"assemble FP64-atomics {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful", flush=True)
-_lib.lib.mfem_debug_set_hex27(0)
+_lib.lib.mfem_debug_set_hex27(3)
 ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
 print("atomics vs colours max rel diff", float((Ka - K).abs().max() / K.abs().max()))
-print(f"assemble (MFMA) {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful Ke (2*27*27*81 per element), {A.nnz*8/ms/1e6:.0f} GB/s of nnz*8", flush=True)
+print(f"assemble colour scatter {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful Ke (2*27*27*81 per element), {A.nnz*8/ms/1e6:.0f} GB/s of nnz*8", flush=True)
 VARIANT = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+_lib.lib.mfem_debug_set_hex27(0)
 if len(sys.argv) > 2:  # phase ablation (timing only; the skipped phases make the values wrong)
     for name, skip in (("all phases", 0), ("no scatter", 8), ("no scatter, no MFMA loop", 12), ("no scatter, no MFMA, no Jacobians", 14),
                        ("nothing but the loop skeleton", 15), ("no MFMA loop only", 4), ("no node loads only", 1), ("no Jacobians only", 2), ("no readlanes only", 16)):
