@@ -206,7 +206,9 @@ int64_t mfem_brick_num_elements(mfem_brick m);
 double* mfem_brick_coords(mfem_brick m, int32_t dim_id);
 /* Slab restriction for domain decomposition along i: this handle then owns node
  * planes [i_lo, i_hi) of the global lattice and assembles only those rows; columns refer to the
- * LOCAL numbering [ghost_lo | owned | ghost_hi].  Default = whole mesh. */
+ * LOCAL numbering [owned | ghosts] with itp_order ghost planes per side and field (a row couples to control points up
+ * to itp_order planes away; see mfem_context_set_comm).  Slabs of an order-2 lattice start and end on element
+ * boundaries (even plane index, or the last plane) and own at least 2 planes.  Default = whole mesh. */
 int mfem_brick_set_slab(mfem_brick m, int32_t plane_lo, int32_t plane_hi);
 
 /* assemble_SparseID! + sort + generate_J_ptr (solver/03_GlobalAssembly.jl:77-140;
@@ -347,8 +349,9 @@ int mfem_comm_unique_id(void* out128 /* [host] */);
 int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out);
 int mfem_comm_destroy(mfem_comm c);
 /* Attach to a context (c = NULL detaches): subsequent mfem_solve calls on slab matrices all-reduce their
- * scalars over the communicator and, before each SpMV, exchange one ghost plane of `plane_len` doubles per
- * field with ranks +-1.  Local vectors are [owned: n_fields x n_owned_nodes, field-major |
+ * scalars over the communicator and, before each SpMV, exchange one ghost block of `plane_len` doubles per
+ * field with ranks +-1 (the first / last plane_len owned entries of the field go out).  plane_len = itp_order control-
+ * point planes: m1*m2 for hex-8, 2*m1*m2 for hex-27.  Local vectors are [owned: n_fields x n_owned_nodes, field-major |
  * ghosts: (field 0 lo, field 0 hi, field 1 lo, ...) x plane_len]  (see mfem_brick_set_slab). */
 int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_owned_nodes, int64_t plane_len, int32_t n_fields);
 int mfem_allreduce_sum(mfem_context ctx, double* dev_scalars, int32_t count);

@@ -313,8 +313,9 @@ class Brick:
 
     def coords_view(self, d: int) -> torch.Tensor:
         """Device view of controlpoints.x{d+1} (library-owned memory) as a torch tensor."""
-        clo = max(self.slab[0] - 1, 0) if self.slab != (0, self.m[0]) else 0
-        chi = min(self.slab[1] + 1, self.m[0]) if self.slab != (0, self.m[0]) else self.m[0]
+        gw = self.itp_order  # ghost planes per side
+        clo = max(self.slab[0] - gw, 0) if self.slab != (0, self.m[0]) else 0
+        chi = min(self.slab[1] + gw, self.m[0]) if self.slab != (0, self.m[0]) else self.m[0]
         ncoord = (chi - clo) * self.m[1] * self.m[2]
         ptr = lib.mfem_brick_coords(self._h, d)
         return _tensor_from_ptr(ptr, ncoord, torch.float64, self.ctx.device, owner=self)

@@ -138,7 +138,7 @@ struct Hex27Args {
   double kcond;
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
   int nq, ng;
-  int e_lo, e_cnt, ring;  // scratch variant: element planes [e_lo, e_lo + e_cnt) of dimension 0, plane I kept in ring slot I % ring
+  int e_lo, e_cnt, ring;  // element planes [e_lo, e_lo + e_cnt) of dimension 0 this launch covers; scratch variant: plane I kept in ring slot I % ring
   int skip;          // timing probe only (WRONG results): 1 no node loads, 2 no J / inverse, 4 no MFMA loop, 8 no scatter
 };
 
@@ -156,8 +156,9 @@ struct ElemWalk {
       n0 = e_cnt; n1 = B.ne1; n2 = B.ne2;
       mul = 1; o0 = e_lo; o1 = 0; o2 = 0;
     } else {
-      o0 = colour & 1; o1 = (colour >> 1) & 1; o2 = colour >> 2;
-      n0 = (B.ne0 - o0 + 1) >> 1; n1 = (B.ne1 - o1 + 1) >> 1; n2 = (B.ne2 - o2 + 1) >> 1;
+      o0 = e_lo + (((colour & 1) - e_lo) & 1);  // first plane of the range with the colour's parity
+      o1 = (colour >> 1) & 1; o2 = colour >> 2;
+      n0 = (e_lo + e_cnt - o0 + 1) >> 1; n1 = (B.ne1 - o1 + 1) >> 1; n2 = (B.ne2 - o2 + 1) >> 1;
       mul = 2;
     }
     if (n0 <= 0 || n1 <= 0 || n2 <= 0) {
@@ -639,6 +640,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
   E[A.nd] = side ? ne[A.nd] - 1 : 0;
   E[t1] = 2 * (int)(f % n1) + c1;
   E[t2] = 2 * (int)(f / n1) + c2;
+  if (A.nd == 0) {  // slab: the face lies in one control-point plane, the tangential faces span three
+    const int gp = side ? 2 * ne[0] : 0;
+    if (gp < B.plo || gp >= B.phi) return;
+  } else if (2 * E[0] + 2 < B.plo || 2 * E[0] >= B.phi) {
+    return;
+  }
   int g[9][3];
   double Xf[9][3], Tf[9];
   for (int c = 0; c < 9; ++c) {
@@ -742,9 +749,26 @@ static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix,
   return MFEM_OK;
 }
 
+// Element planes (dimension 0) that touch the owned control-point planes [plo, phi) of a slab.  Slabs start and end on
+// element boundaries (mfem_brick_set_slab), so the first owned plane also needs the element plane below it.
+static void hex27_element_planes(const mfem_brick_s* m, int* elo, int* ehi) {
+  *elo = m->plo / 2 - 1 < 0 ? 0 : m->plo / 2 - 1;
+  *ehi = m->phi / 2 > m->ne[0] ? m->ne[0] : m->phi / 2;
+}
+// elements of one parity colour within the element planes [elo, ehi)
+static int64_t hex27_colour_count(const mfem_brick_s* m, int colour, int elo, int ehi) {
+  const int o0 = elo + (((colour & 1) - elo) & 1);
+  const int64_t n0 = o0 < ehi ? (ehi - o0 + 1) >> 1 : 0, n1 = (m->ne[1] - ((colour >> 1) & 1) + 1) >> 1,
+                n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
+  return n0 * n1 * n2;
+}
+
 int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s* Acsr, const mfem_thermal_params* p,
                                 double* vals) {
-  MFEM_REQUIRE(m->plo == 0 && m->phi == m->m[0], "hex-27 assembly does not support slabs yet");
+  const bool slab = !(m->plo == 0 && m->phi == m->m[0]);
+  MFEM_REQUIRE(!slab || g_hex27_two_pass == 1, "hex-27 slabs are assembled by the two-pass variant only");
+  int elo, ehi;
+  hex27_element_planes(m, &elo, &ehi);
   const int nq = m->ng * m->ng * m->ng;
   int rc = hex27_upload_tables(m->ng);
   if (rc) return rc;
@@ -768,25 +792,29 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     // planes [2a, 2b) (the last chunk also 2b), which need element planes a-1 .. b-1 -- plane a-1 is still in the ring.
     const int64_t plane_el = (int64_t)m->ne[1] * m->ne[2];
     const size_t plane_bytes = sizeof(double) * 729 * (size_t)plane_el;
-    int P = m->ne[0];
+    const int npl = ehi - elo;
+    int P = npl;
     if (g_hex27_chunk_planes > 0) P = g_hex27_chunk_planes;
-    else if (plane_bytes * (size_t)m->ne[0] > g_hex27_scratch_budget) P = (int)(g_hex27_scratch_budget / plane_bytes) - 1;
+    else if (plane_bytes * (size_t)npl > g_hex27_scratch_budget) P = (int)(g_hex27_scratch_budget / plane_bytes) - 1;
     if (P < 1) P = 1;
-    if (P > m->ne[0]) P = m->ne[0];
-    const int ring = P >= m->ne[0] ? m->ne[0] : P + 1;
+    if (P > npl) P = npl;
+    const int ring = P >= npl ? npl : P + 1;
     rc = mfem_ws_reserve(ctx, plane_bytes * (size_t)ring);
     if (rc) return rc;
     MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t plane_rows = B.plane_len;
-    for (int a = 0; a < m->ne[0]; a += P) {
-      const int b = a + P < m->ne[0] ? a + P : m->ne[0];
+    for (int a = elo; a < ehi; a += P) {
+      const int b = a + P < ehi ? a + P : ehi;
       Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, a, b - a, ring, g_hex27_skip};
       int64_t grid = ((b - a) * plane_el + H27_WAVES - 1) / H27_WAVES;
       const int64_t cap = (int64_t)ctx->num_cus * 2;
       if (grid > cap) grid = cap;
       hipLaunchKernelGGL((k_hex27<true, true>), dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)ctx->ws);
       MFEM_CHECK_LAUNCH();
-      const int64_t row_lo = 2 * (int64_t)a * plane_rows, row_hi = b == m->ne[0] ? m->n_owned : 2 * (int64_t)b * plane_rows;
+      // control-point planes [2a, 2b) (the last chunk: up to phi), clipped to the owned planes
+      const int gp_lo = 2 * a < m->plo ? m->plo : 2 * a, gp_hi = b == ehi ? m->phi : 2 * b;
+      const int64_t row_lo = (int64_t)(gp_lo - m->plo) * plane_rows, row_hi = (int64_t)(gp_hi - m->plo) * plane_rows;
+      if (row_hi <= row_lo) continue;
       hipLaunchKernelGGL(k_hex27_gather_lds, dim3((unsigned)((row_hi - row_lo + G27_NODES - 1) / G27_NODES)), dim3(MFEM_BLOCK), 0,
                          ctx->stream, B, (const double*)ctx->ws, vals, row_lo, row_hi, ring);
       MFEM_CHECK_LAUNCH();
@@ -795,11 +823,9 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   }
   MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
   for (int colour = 0; colour < 8; ++colour) {
-    const int64_t n0 = (m->ne[0] - (colour & 1) + 1) >> 1, n1 = (m->ne[1] - ((colour >> 1) & 1) + 1) >> 1,
-                  n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
-    const int64_t ne = n0 * n1 * n2;
+    const int64_t ne = hex27_colour_count(m, colour, elo, ehi);
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, 0, 0, 1, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1, g_hex27_skip};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
@@ -811,7 +837,8 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
 
 int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem_thermal_params* p, const double* x_star,
                                 const double* s, double* residue) {
-  MFEM_REQUIRE(m->plo == 0 && m->phi == m->m[0], "hex-27 residual does not support slabs yet");
+  int elo, ehi;
+  hex27_element_planes(m, &elo, &ehi);
   const int nq = m->ng * m->ng * m->ng;
   int rc = hex27_upload_tables(m->ng);
   if (rc) return rc;
@@ -820,11 +847,9 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
   MFEM_CHECK_HIP(hipMemsetAsync(residue, 0, sizeof(double) * (size_t)m->n_owned, ctx->stream));
   BrickView B = mfem_brick_view(m, 1);
   for (int colour = 0; colour < 8; ++colour) {
-    const int64_t n0 = (m->ne[0] - (colour & 1) + 1) >> 1, n1 = (m->ne[1] - ((colour >> 1) & 1) + 1) >> 1,
-                  n2 = (m->ne[2] - (colour >> 2) + 1) >> 1;
-    const int64_t ne = n0 * n1 * n2;
+    const int64_t ne = hex27_colour_count(m, colour, elo, ehi);
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, 0, 0, 1, 0};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1, 0};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;

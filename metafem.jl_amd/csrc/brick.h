@@ -42,6 +42,7 @@ struct BrickView {  // POD passed to kernels
   int32_t m0, m1, m2;
   int32_t p, ng;
   int32_t plo, phi, clo, chi;
+  int32_t gw;         // ghost planes per side of a slab = interpolation order (a row couples to nodes up to p planes away)
   int64_t plane_len, n_owned;
   const double* X0;
   const double* X1;
@@ -56,12 +57,14 @@ struct BrickView {  // POD passed to kernels
 BrickView mfem_brick_view(const mfem_brick_s* m, int nfields);
 
 // node (i,j,k) -> index into the local solution vector of a field-major slab vector
-//   owned: f*n_owned + (i-plo)*PL + j*m2 + k ; ghosts behind all owned entries
+//   owned: f*n_owned + (i-plo)*PL + j*m2 + k ; ghosts behind all owned entries, per field a low block (planes plo-gw .. plo-1)
+//   and a high block (planes phi .. phi+gw-1) of gw planes each
 __device__ __forceinline__ int64_t brick_xindex(const BrickView& B, int f, int i, int j, int k) {
   const int64_t inplane = (int64_t)j * B.m2 + k;
   if (i >= B.plo && i < B.phi) return (int64_t)f * B.n_owned + (int64_t)(i - B.plo) * B.plane_len + inplane;
   const int side = (i < B.plo) ? 0 : 1;
-  return (int64_t)B.nfields * B.n_owned + (int64_t)(f * 2 + side) * B.plane_len + inplane;
+  const int off = side ? i - B.phi : i - (B.plo - B.gw);
+  return (int64_t)B.nfields * B.n_owned + ((int64_t)(f * 2 + side) * B.gw + off) * B.plane_len + inplane;
 }
 __device__ __forceinline__ int64_t brick_cindex(const BrickView& B, int i, int j, int k) {
   return (int64_t)(i - B.clo) * B.plane_len + (int64_t)j * B.m2 + k;

@@ -18,6 +18,7 @@ BrickView mfem_brick_view(const mfem_brick_s* m, int nfields) {
   B.m0 = m->m[0]; B.m1 = m->m[1]; B.m2 = m->m[2];
   B.p = m->p; B.ng = m->ng;
   B.plo = m->plo; B.phi = m->phi; B.clo = m->clo; B.chi = m->chi;
+  B.gw = m->p;
   B.plane_len = m->plane_len; B.n_owned = m->n_owned;
   B.X0 = m->coords[0]; B.X1 = m->coords[1]; B.X2 = m->coords[2];
   B.lo0 = m->d_lo[0]; B.lo1 = m->d_lo[1]; B.lo2 = m->d_lo[2];
@@ -141,12 +142,17 @@ extern "C" double* mfem_brick_coords(mfem_brick b, int32_t d) { return (b && d >
 
 extern "C" int mfem_brick_set_slab(mfem_brick b, int32_t plane_lo, int32_t plane_hi) {
   MFEM_REQUIRE(b, "null brick");
-  MFEM_REQUIRE(b->p == 1, "slab decomposition is implemented for order-1 lattices");
   MFEM_REQUIRE(plane_lo >= 0 && plane_hi <= b->m[0] && plane_lo < plane_hi, "bad plane range");
+  const int gw = b->p;  // ghost planes per side
+  // order 2: a slab starts and ends on element boundaries (even planes), so that the interface element plane is evaluated
+  // on both sides and every owned row finds its columns within two planes
+  MFEM_REQUIRE(b->p == 1 || (plane_lo % b->p == 0 && (plane_hi % b->p == 0 || plane_hi == b->m[0])),
+               "slabs of an order-p lattice start and end on element boundaries (plane index divisible by p)");
+  MFEM_REQUIRE((plane_lo == 0 && plane_hi == b->m[0]) || plane_hi - plane_lo >= gw, "a slab owns at least p planes");
   b->plo = plane_lo;
   b->phi = plane_hi;
-  b->clo = plane_lo - 1 < 0 ? 0 : plane_lo - 1;
-  b->chi = plane_hi + 1 > b->m[0] ? b->m[0] : plane_hi + 1;
+  b->clo = plane_lo - gw < 0 ? 0 : plane_lo - gw;
+  b->chi = plane_hi + gw > b->m[0] ? b->m[0] : plane_hi + gw;
   b->n_owned = (int64_t)(plane_hi - plane_lo) * b->plane_len;
   int64_t pplo = 0;
   MFEM_CHECK_HIP(hipMemcpy(&pplo, b->d_P[0] + plane_lo, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -194,7 +200,7 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   const int64_t T = (Pphi - b->Pplo) * b->S[1] * b->S[2];
   const int64_t n = (int64_t)n_fields * b->n_owned;
   const int64_t nnz = (int64_t)n_fields * n_fields * T;
-  const int64_t xlen = n + (int64_t)2 * n_fields * b->plane_len;
+  const int64_t xlen = n + (int64_t)2 * n_fields * b->p * b->plane_len;
   MFEM_REQUIRE(xlen < ((int64_t)1 << 31), "local column ids must fit int32");
   mfem_csr_s* A = new mfem_csr_s();
   memset(A, 0, sizeof(*A));

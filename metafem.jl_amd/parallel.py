@@ -7,8 +7,10 @@ needs no communication).  A local vector is laid out as
 
     [ field 0 owned | field 1 owned | ... | f0 ghost_lo | f0 ghost_hi | f1 ghost_lo | f1 ghost_hi | ... ]
 
-with one ghost plane (m1*m2 entries) per side and field; the ghost block is always allocated, edge ranks
-simply never reference their outer half.  `slab_local_index` is the host restatement of the device
+with `order` ghost planes (order * m1*m2 entries: a row couples to control points up to `order` planes away) per
+side and field -- a low block holding planes lo-order .. lo-1 and a high block holding hi .. hi+order-1; the ghost
+block is always allocated, edge ranks simply never reference their outer half.  Slabs of an order-2 lattice start
+and end on element boundaries (even planes).  `slab_local_index` is the host restatement of the device
 numbering (csrc/brick.h::brick_xindex) and is what the CPU (gloo) tests exercise.
 """
 from __future__ import annotations
@@ -23,10 +25,22 @@ from . import _lib
 from ._lib import check, lib
 
 
-def slab_planes(m0: int, world: int, rank: int) -> Tuple[int, int]:
-    """Owned node planes [lo, hi) of `rank`: m0 planes split as evenly as possible, extras to the low ranks."""
+def slab_planes(m0: int, world: int, rank: int, order: int = 1) -> Tuple[int, int]:
+    """Owned node planes [lo, hi) of `rank`.  order 1: m0 planes split as evenly as possible, extras to the low ranks.
+    order p: the (m0 - 1) / p element planes are split that way and a slab is the planes [p * e_lo, p * e_hi) -- it starts
+    and ends on an element boundary; the last rank also owns the closing plane m0 - 1."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
+    if order > 1:
+        if (m0 - 1) % order:
+            raise ValueError("m0 is not order * n_elements + 1")
+        ne = (m0 - 1) // order
+        if ne < world:
+            raise ValueError("fewer element planes than ranks")
+        base, rem = divmod(ne, world)
+        elo = rank * base + min(rank, rem)
+        ehi = elo + base + (1 if rank < rem else 0)
+        return order * elo, (m0 if rank == world - 1 else order * ehi)
     if m0 < world:
         raise ValueError("fewer node planes than ranks")
     base, rem = divmod(m0, world)
@@ -35,19 +49,21 @@ def slab_planes(m0: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def slab_local_index(i, j, k, f, lo: int, hi: int, m1: int, m2: int, n_fields: int):
-    """Local vector index of field f at lattice node (i, j, k) for the slab [lo, hi); i in [lo-1, hi]."""
+def slab_local_index(i, j, k, f, lo: int, hi: int, m1: int, m2: int, n_fields: int, order: int = 1):
+    """Local vector index of field f at lattice node (i, j, k) for the slab [lo, hi); i in [lo-order, hi+order)."""
     i, j, k = np.asarray(i), np.asarray(j), np.asarray(k)
     pl = m1 * m2
     n_owned = (hi - lo) * pl
     inplane = j * m2 + k
     owned = (i >= lo) & (i < hi)
     side = np.where(i < lo, 0, 1)
-    return np.where(owned, f * n_owned + (i - lo) * pl + inplane, n_fields * n_owned + (f * 2 + side) * pl + inplane)
+    off = np.where(i < lo, i - (lo - order), i - hi)
+    return np.where(owned, f * n_owned + (i - lo) * pl + inplane,
+                    n_fields * n_owned + ((f * 2 + side) * order + off) * pl + inplane)
 
 
-def local_vector_length(lo: int, hi: int, m1: int, m2: int, n_fields: int) -> int:
-    return n_fields * ((hi - lo) + 2) * m1 * m2
+def local_vector_length(lo: int, hi: int, m1: int, m2: int, n_fields: int, order: int = 1) -> int:
+    return n_fields * ((hi - lo) + 2 * order) * m1 * m2
 
 
 class SlabComm:
@@ -69,7 +85,8 @@ class SlabComm:
         raw = bytes(uid.cpu().tolist())
         self._h = C.c_void_p()
         check(lib.mfem_comm_create(ctx._h, rank, world, raw, C.byref(self._h)))
-        self.plane_len = brick.m[1] * brick.m[2]
+        # the halo is `itp_order` control-point planes thick: the exchange moves that many first / last owned planes per field
+        self.plane_len = brick.itp_order * brick.m[1] * brick.m[2]
         self.n_owned_nodes = brick.n_owned
         self.n_fields = n_fields
         check(lib.mfem_context_set_comm(ctx._h, self._h, self.n_owned_nodes, self.plane_len, n_fields))

@@ -26,11 +26,11 @@ def _free_port():
     return p
 
 
-def _global_system(n):
+def _global_system(n, order=1):
     from oracle import fem, mesh as om, problems, reference_element as re_
 
     x = (2.0, 1.0, 1.0)
-    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    disc = re_.initialize_classical_element(3, "CUBE", order, 1, 3 if order == 1 else 5)
     msh = om.lattice_mesh(x, n, disc)
     fac = om.boundary_facets_structured(x, n, 3)
     od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6), [(fac, problems.thermal_convection(25.0, 293.15))])
@@ -39,7 +39,7 @@ def _global_system(n):
     return od
 
 
-def _worker(rank, world, port, n, out_q):
+def _worker(rank, world, port, n, out_q, order=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -47,18 +47,19 @@ def _worker(rank, world, port, n, out_q):
     import metafem_jl_amd.parallel as par  # host logic only; no device call is made
     from oracle import solvers
 
-    od = _global_system(n)
-    m0, m1, m2 = n[0] + 1, n[1] + 1, n[2] + 1
+    od = _global_system(n, order)
+    m0, m1, m2 = order * n[0] + 1, order * n[1] + 1, order * n[2] + 1
     pl = m1 * m2
-    lo, hi = par.slab_planes(m0, world, rank)
+    hp = order * pl  # halo thickness: `order` planes per side
+    lo, hi = par.slab_planes(m0, world, rank, order)
     n_owned = (hi - lo) * pl
     A = solvers.csr(od.pattern.rowptr, od.pattern.colidx, od.K_total, od.pattern.n)
     rows = np.arange(lo * pl, hi * pl)
     Aloc = A[rows].tocoo()
     gi, gj, gk = Aloc.col // pl, (Aloc.col % pl) // m2, Aloc.col % m2
-    assert gi.min() >= lo - 1 and gi.max() <= hi  # one ghost plane per side suffices for hex-8
-    lcol = par.slab_local_index(gi, gj, gk, 0, lo, hi, m1, m2, 1)
-    nloc = par.local_vector_length(lo, hi, m1, m2, 1)
+    assert gi.min() >= lo - order and gi.max() <= hi + order - 1  # `order` ghost planes per side suffice
+    lcol = par.slab_local_index(gi, gj, gk, 0, lo, hi, m1, m2, 1, order)
+    nloc = par.local_vector_length(lo, hi, m1, m2, 1, order)
     import scipy.sparse as sp
 
     Al = sp.csr_matrix((Aloc.data, (Aloc.row, lcol)), shape=(n_owned, nloc))
@@ -72,19 +73,19 @@ def _worker(rank, world, port, n, out_q):
 
     def halo(v):  # the ncclSend/ncclRecv group of csrc/comm.hip::mfem_comm_halo
         reqs = []
-        lo_buf, hi_buf = torch.zeros(pl, dtype=torch.float64), torch.zeros(pl, dtype=torch.float64)
+        lo_buf, hi_buf = torch.zeros(hp, dtype=torch.float64), torch.zeros(hp, dtype=torch.float64)
         if rank > 0:
-            reqs.append(dist.isend(torch.tensor(v[:pl].copy()), rank - 1))
+            reqs.append(dist.isend(torch.tensor(v[:hp].copy()), rank - 1))
             reqs.append(dist.irecv(lo_buf, rank - 1))
         if rank < world - 1:
-            reqs.append(dist.isend(torch.tensor(v[n_owned - pl:n_owned].copy()), rank + 1))
+            reqs.append(dist.isend(torch.tensor(v[n_owned - hp:n_owned].copy()), rank + 1))
             reqs.append(dist.irecv(hi_buf, rank + 1))
         for r in reqs:
             r.wait()
         if rank > 0:
-            v[n_owned:n_owned + pl] = lo_buf.numpy()
+            v[n_owned:n_owned + hp] = lo_buf.numpy()
         if rank < world - 1:
-            v[n_owned + pl:n_owned + 2 * pl] = hi_buf.numpy()
+            v[n_owned + hp:n_owned + 2 * hp] = hi_buf.numpy()
 
     n_glob = int(allreduce(float(n_owned))[0])
     x = np.zeros(nloc); r = np.zeros(nloc); p = np.zeros(nloc)
@@ -115,15 +116,16 @@ def _worker(rank, world, port, n, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, (6, 3, 4)), (3, (7, 2, 2))])
-def test_distributed_cg_matches_single_rank(world, n):
+@pytest.mark.parametrize("world,n,order", [(2, (6, 3, 4), 1), (3, (7, 2, 2), 1), (2, (3, 2, 2), 2), (3, (4, 1, 2), 2)])
+def test_distributed_cg_matches_single_rank(world, n, order):
+    """order 2 = hex-27: slabs on element boundaries, two ghost planes per side in the same send/recv group."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, order)) for r in range(world)]
     for p in procs:
         p.start()
-    err, its, its_ref = q.get(timeout=240)
+    err, its, its_ref = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -141,6 +143,14 @@ def test_slab_planes_cover_without_overlap():
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     with pytest.raises(ValueError):
         par.slab_planes(3, 4, 0)
+    # order 2: slabs start and end on element boundaries (even planes), the last rank owns the closing plane
+    for m0, world in [(257, 1), (257, 2), (257, 8), (9, 4), (11, 3)]:
+        spans = [par.slab_planes(m0, world, r, 2) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == m0
+        assert all(spans[r][1] == spans[r + 1][0] and spans[r][1] % 2 == 0 for r in range(world - 1))
+        assert all(h - l >= 2 for l, h in spans)
+    with pytest.raises(ValueError):
+        par.slab_planes(5, 3, 0, 2)
 
 
 def test_local_index_layout():
@@ -158,3 +168,16 @@ def test_local_index_layout():
     assert seen == set(range(par.local_vector_length(lo, hi, m1, m2, F)))
     assert int(par.slab_local_index(lo, 0, 0, 1, lo, hi, m1, m2, F)) == (hi - lo) * pl  # field-major owned block
     assert int(par.slab_local_index(lo - 1, 0, 0, 0, lo, hi, m1, m2, F)) == F * (hi - lo) * pl  # ghosts behind owned
+    # two ghost planes per side (order-2 lattices): still a bijection, low block = planes lo-2, lo-1 in that order
+    seen = set()
+    for f in range(F):
+        for i in range(lo - 2, hi + 2):
+            for j in range(m1):
+                for k in range(m2):
+                    seen.add(int(par.slab_local_index(i, j, k, f, lo, hi, m1, m2, F, 2)))
+    assert seen == set(range(par.local_vector_length(lo, hi, m1, m2, F, 2)))
+    base = F * (hi - lo) * pl
+    assert int(par.slab_local_index(lo - 2, 0, 0, 0, lo, hi, m1, m2, F, 2)) == base
+    assert int(par.slab_local_index(lo - 1, 0, 0, 0, lo, hi, m1, m2, F, 2)) == base + pl
+    assert int(par.slab_local_index(hi, 0, 0, 0, lo, hi, m1, m2, F, 2)) == base + 2 * pl
+    assert int(par.slab_local_index(hi + 1, 0, 0, 1, lo, hi, m1, m2, F, 2)) == base + 7 * pl
