@@ -104,11 +104,12 @@ def test_elasticity_slab_rows_equal_global_rows(mf, lo, hi):
         assert np.array_equal(sR[f * n_owned:(f + 1) * n_owned], gR[f * ncp + lo * pl:f * ncp + hi * pl])
 
 
-def test_rccl_world1_solve_equals_plain_solve(mf):
+@pytest.mark.parametrize("order", [1, 2])
+def test_rccl_world1_solve_equals_plain_solve(mf, order):
     import torch
     from metafem_jl_amd import parallel as par
 
-    brick = mf.make_Brick((1.0, 1.0, 1.0), (10, 9, 8))
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (10, 9, 8) if order == 1 else (5, 4, 4), order, 3 if order == 1 else 5)
     A = brick.pattern(1)
     K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
     b = mf.FEM_rand(A.n, 3, 0)
