@@ -23,17 +23,23 @@ typedef int s_i2 __attribute__((ext_vector_type(2)));
 extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
 static int g_sell_enable = 1;
 static int g_sell_offsets = 1;  // blocks with one diagonal list skip their column stream
+static int g_sell_window_log2 = 0;
+static int g_sell_unroll = 5;   // slots in flight per lane (bits 16-20 of mfem_debug_set_sell; 0 = default)
+static int g_sell_wg_per_cu = 8;
 extern "C" int mfem_debug_set_sell(int enable) {  // bit 0: layout on/off; bit 1: always read explicit columns
   ++mfem_debug_epoch;
   g_sell_enable = enable & 1;
   g_sell_offsets = (enable & 2) ? 0 : 1;
+  g_sell_window_log2 = (enable >> 8) & 63;
+  g_sell_unroll = ((enable >> 16) & 31) ? ((enable >> 16) & 31) : 5;
+  g_sell_wg_per_cu = ((enable >> 24) & 31) ? ((enable >> 24) & 31) : 8;  // rows are sorted within windows of 2^w consecutive rows (0 = over the whole matrix)
   return MFEM_OK;
 }
 
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                            int base, int maxlen, uint64_t* __restrict__ keys,
-                                                            int32_t* __restrict__ ids) {
+                                                            int base, int maxlen, int wshift, int lenbits,
+                                                            uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* _
         d >>= 8;
       }
     }
-    keys[r] = ((uint64_t)(uint32_t)(maxlen - (int32_t)(hi - lo)) << 32) | h;
+    keys[r] = ((uint64_t)(r >> wshift) << (32 + lenbits)) | ((uint64_t)(uint32_t)(maxlen - (int32_t)(hi - lo)) << 32) | h;
     ids[r] = (int32_t)r;
   }
 }
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nbl
   }
 }
 
+template <int SELL_U>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nblk, const int64_t* __restrict__ ptr,
                                                             const int32_t* __restrict__ rowid, const int32_t* __restrict__ flags,
                                                             const int32_t* __restrict__ off, const int32_t* __restrict__ cols,
@@ -143,35 +150,69 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nbl
   for (int64_t b = wave; b < nblk; b += nwaves) {
     const int64_t p0 = ptr[b];
     const int Kb = (int)((ptr[b + 1] - p0) / SELL_B);
-    const int64_t rs = b * SELL_B + 2 * lane;
-    const double* v = vals + p0 + 2 * lane;
-    const int32_t* c = cols + p0 + 2 * lane;
-    s_d2 acc = {0.0, 0.0};
+    // lane l owns the block's rows l and l + 64: the value loads of a slot are two unit-stride 512-byte runs, and the x
+    // loads of same-type rows (stride 2 along the fastest lattice direction for hex-27) touch half as many lines as with
+    // two consecutive rows per lane
+    const int64_t rs0 = b * SELL_B + lane, rs1 = rs0 + 64;
+    const double* v = vals + p0 + lane;
+    const int32_t* c = cols + p0 + lane;
+    double acc0 = 0.0, acc1 = 0.0;
     const bool regular = flags && __builtin_amdgcn_readfirstlane(flags[b]) != 0;  // full block, one diagonal list
-    int64_t rid[2] = {0, 0};
-    if (rs < n) rid[0] = rowid[rs];
-    if (rs + 1 < n) rid[1] = rowid[rs + 1];
+    int64_t rid0 = 0, rid1 = 0;
+    if (rs0 < n) rid0 = rowid[rs0];
+    if (rs1 < n) rid1 = rowid[rs1];
+    // SELL_U slots in flight per lane (the kernel is latency-bound without: one slot at a time ran at 3.0 TB/s)
     if (regular) {
       const int32_t* ob = off + __builtin_amdgcn_readfirstlane((int)(p0 / SELL_B));
-      for (int s = 0; s < Kb; ++s) {
-        const s_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const s_d2*>(v + (int64_t)s * SELL_B));
+      int s = 0;
+      for (; s + SELL_U <= Kb; s += SELL_U) {
+        double v0[SELL_U], v1[SELL_U], x0[SELL_U], x1[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u) {
+          v0[u] = __builtin_nontemporal_load(v + (int64_t)(s + u) * SELL_B);
+          v1[u] = __builtin_nontemporal_load(v + (int64_t)(s + u) * SELL_B + 64);
+          const int64_t o = ob[s + u];
+          x0[u] = x[rid0 + o];
+          x1[u] = x[rid1 + o];
+        }
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u) {
+          acc0 += v0[u] * x0[u];
+          acc1 += v1[u] * x1[u];
+        }
+      }
+      for (; s < Kb; ++s) {
         const int64_t o = ob[s];
-        acc.x += vv.x * x[rid[0] + o];
-        acc.y += vv.y * x[rid[1] + o];
+        acc0 += __builtin_nontemporal_load(v + (int64_t)s * SELL_B) * x[rid0 + o];
+        acc1 += __builtin_nontemporal_load(v + (int64_t)s * SELL_B + 64) * x[rid1 + o];
       }
     } else {
-      for (int s = 0; s < Kb; ++s) {
-        const s_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const s_d2*>(v + (int64_t)s * SELL_B));
-        const s_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const s_i2*>(c + (int64_t)s * SELL_B));
-        acc.x += vv.x * x[cc.x];
-        acc.y += vv.y * x[cc.y];
+      int s = 0;
+      for (; s + SELL_U <= Kb; s += SELL_U) {
+        double v0[SELL_U], v1[SELL_U], x0[SELL_U], x1[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u) {
+          v0[u] = __builtin_nontemporal_load(v + (int64_t)(s + u) * SELL_B);
+          v1[u] = __builtin_nontemporal_load(v + (int64_t)(s + u) * SELL_B + 64);
+          x0[u] = x[__builtin_nontemporal_load(c + (int64_t)(s + u) * SELL_B)];
+          x1[u] = x[__builtin_nontemporal_load(c + (int64_t)(s + u) * SELL_B + 64)];
+        }
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u) {
+          acc0 += v0[u] * x0[u];
+          acc1 += v1[u] * x1[u];
+        }
+      }
+      for (; s < Kb; ++s) {
+        acc0 += __builtin_nontemporal_load(v + (int64_t)s * SELL_B) * x[c[(int64_t)s * SELL_B]];
+        acc1 += __builtin_nontemporal_load(v + (int64_t)s * SELL_B + 64) * x[c[(int64_t)s * SELL_B + 64]];
       }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (rs + h < n) {
-        const int64_t r = rid[h];
-        double yv = alpha * (h ? acc.y : acc.x);
+      if ((h ? rs1 : rs0) < n) {
+        const int64_t r = h ? rid1 : rid0;
+        double yv = alpha * (h ? acc1 : acc0);
         if (beta != 0.0) yv += beta * y[r];
         y[r] = yv;
         if (dotw) dot_acc += yv * dotw[r];
@@ -209,6 +250,9 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   size_t tb = 0, tb2 = 0;
   int64_t total = 0;
   const int grid = mfem_grid_for(n, MFEM_BLOCK, ctx->num_cus * 16);
+  int lenbits = 1;
+  while ((1 << lenbits) <= A->max_row_nnz && lenbits < 31) ++lenbits;
+  const int wshift = g_sell_window_log2 > 0 ? g_sell_window_log2 : 63;
   SELL_CHECK(hipMalloc(&keys, sizeof(uint64_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&ids, sizeof(int32_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&keys2, sizeof(uint64_t) * (size_t)n));
@@ -217,14 +261,14 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   SELL_CHECK(hipMalloc(&ptr, sizeof(int64_t) * (size_t)(nblk + 1)));
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_sell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int64_t*)A->rowptr, A->colidx,
-                       A->index_base, A->max_row_nnz, keys, ids);
+                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids);
   else
     hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr, A->colidx,
-                       A->index_base, A->max_row_nnz, keys, ids);
+                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids);
   {
-    int bits = 1;
-    while ((1 << bits) <= A->max_row_nnz && bits < 31) ++bits;
-    bits += 32;  // the low word is the signature of the diagonal list
+    int bits = 32 + lenbits;  // the low word is the signature of the diagonal list
+    if (wshift < 63)
+      while (bits < 64 && ((uint64_t)(n - 1) >> wshift) >> (bits - 32 - lenbits)) ++bits;  // window index on top
     SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, ids, rowid, (int)n, 0, bits, ctx->stream));
     SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, sizes, ptr, (int)(nblk + 1), ctx->stream));
     if (tb2 > tb) tb = tb2;
@@ -335,11 +379,22 @@ void mfem_sell_free(mfem_csr_s* A) {
 int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
                           double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
   if (!A->sell_vals || vals != A->sell_src) return 0;
-  int cap = ctx->num_cus * 8;
+  int cap = ctx->num_cus * g_sell_wg_per_cu;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = mfem_grid_for(A->sell_nblk * 64, MFEM_BLOCK, cap);
-  hipLaunchKernelGGL(k_spmv_sell, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk, A->sell_ptr, A->sell_rowid,
-                     g_sell_offsets ? A->sell_flags : nullptr, A->sell_off, A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw, partials, done_flag);
+#define SELL_LAUNCH(U)                                                                                                            \
+  hipLaunchKernelGGL(k_spmv_sell<U>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk, A->sell_ptr, A->sell_rowid, \
+                     g_sell_offsets ? A->sell_flags : nullptr, A->sell_off, A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw,   \
+                     partials, done_flag)
+  switch (g_sell_unroll) {
+    case 4: SELL_LAUNCH(4); break;
+    case 8: SELL_LAUNCH(8); break;
+    case 9: SELL_LAUNCH(9); break;
+    case 10: SELL_LAUNCH(10); break;
+    case 15: SELL_LAUNCH(15); break;
+    default: SELL_LAUNCH(5); break;
+  }
+#undef SELL_LAUNCH
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   return 1;
