@@ -107,7 +107,8 @@ int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
  * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results); bits 24-25 workgroup size of the
  * diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
 int mfem_debug_set_ell(int enable);
-/* mode 3: bit 0 on/off; bit 1 always read explicit columns. */
+/* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
+ * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
 int mfem_debug_set_sell(int enable);
 /* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
  * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
