@@ -100,24 +100,34 @@ static int hex27_upload_tables(int ng) {
   return MFEM_OK;
 }
 
-// per-wave LDS carve-up (doubles), sized from ng / nq = ng^3 (even-padded):
-//   X[27][3] | T1 [2][ng][9][3] (first sum-factorisation stage)          -- both dead once stage 2 has run, so
-//   J -> Jinv [nq][9] overlays them                                        -- (written by stage 3)
-//   T2 [3][ng][ng][3][3] (second stage); the residual's scratch [nq][3] + source [nq] overlays it later
-//   w det [nq] | nodal T[28], s[28] | int64 rowbase[27] + int32 info[27][8]
+// per-wave LDS carve-up (doubles), sized from ng / nq = ng^3 (even-padded).  NI = components pushed through the
+// sum-factorised interpolation: 3 (x1, x2, x3) for the matrix, 5 (+ nodal T and nodal source s) for the residual.
+//   X[27][NI] | T1 [2][ng][9][NI] (first stage)                         -- both dead once stage 2 has run, so
+//   J -> Jinv [nq][9] | grad_xi T [nq][3] | s at the Gauss points [nq]  -- (written by stage 3) overlay them; the
+//                                                                           residual's transposed stages reuse this space again
+//   T2 [3][ng][ng][3][NI] (second stage); the residual's flux [nq][3] + source [nq] overlays it later
+//   w det [nq] | int64 rowbase[27] + int32 info[27][8] (colour-scatter matrix variant only)
 __host__ __device__ inline int h27_pad(int v) { return (v + 1) & ~1; }
 __host__ __device__ inline int h27_max(int a, int b) { return a > b ? a : b; }
+#define H27_N1 (18 * ng * NI)
+#define H27_N2 (9 * ng * ng * NI)
+#define H27_N3 ((NI == 3 ? 9 : 13) * nq)
+#define H27_NA (9 * ng * ng)     // residual, transposed stage A: [3][ng][ng][3]
+#define H27_NB (18 * ng)         // residual, transposed stage B: [2][ng][9]
 #define W_X 0
-#define W_T1 84
+#define W_T1 h27_pad(27 * NI)
 #define W_J 0
-#define W_T2 h27_max(84 + h27_pad(54 * ng), h27_pad(9 * nq))
+#define W_GX (9 * nq)
+#define W_SV (12 * nq)
+#define W_VA 0
+#define W_WB h27_pad(H27_NA)
+#define W_T2 h27_max(W_T1 + h27_pad(H27_N1), h27_pad(H27_N3))
 #define W_G W_T2
-#define W_D (W_T2 + h27_max(h27_pad(27 * ng * ng), 4 * h27_pad(nq)))
-#define W_T (W_D + h27_pad(nq))
-#define W_INFO (W_T + 56)
-#define W_SIZE (W_INFO + 27 + 27 * 4 + 1)
-// workgroup-shared decode table of the sum-factorised Jacobian (int32 words): 54 ng + 27 ng^2 + 9 ng^3 entries
-#define H27_NDEC (54 * ng + 27 * ng * ng + 9 * nq)
+#define W_D (W_T2 + h27_max(h27_pad(H27_N2), 4 * h27_pad(nq)))
+#define W_INFO (W_D + h27_pad(nq))
+#define W_SIZE(with_info) (W_INFO + ((with_info) ? 27 + 27 * 4 + 1 : 0))
+// workgroup-shared decode table of the sum-factorised stages (int32 words)
+#define H27_NDEC (H27_N1 + H27_N2 + H27_N3 + (NI == 3 ? 0 : H27_NA + H27_NB))
 #define H27_WAVES 8                  // waves per workgroup (they share the reference tables in LDS)
 #define H27_THREADS (64 * H27_WAVES)
 
@@ -194,38 +204,59 @@ template <bool MATRIX, bool SCRATCH = false>
 __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const double* __restrict__ xstar,
                                                         const double* __restrict__ src, double* __restrict__ out) {
   extern __shared__ double lds[];
+  constexpr int NI = MATRIX ? 3 : 5;
   // workgroup-shared reference tables
-  double* s_dN = lds;                           // [nq][3][27]
-  double* s_N = s_dN + A.nq * 81;               // [nq][27]   (residual only)
-  double* s_w = s_N + (MATRIX ? 0 : A.nq * 27); // [nq]
+  double* s_dN = lds;                           // [nq][3][27]   (matrix only: MFMA operands)
+  double* s_w = s_dN + (MATRIX ? A.nq * 81 : 0); // [nq]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nq = A.nq, ng = A.ng;
   double* s_tab1 = s_w + ((A.nq + 1) & ~1);     // [2][ng][4]
   int32_t* s_dec = reinterpret_cast<int32_t*>(s_tab1 + 8 * ng);
   double* wave_base = s_tab1 + 8 * ng + (h27_pad(H27_NDEC) >> 1);
-  const int n1 = 54 * ng, n2 = 27 * ng * ng, n3 = 9 * nq;
-  for (int i = tid; i < nq * 81; i += H27_THREADS) s_dN[i] = (&A.tab->dN[0][0][0])[i];
-  if (!MATRIX)
-    for (int i = tid; i < nq * 27; i += H27_THREADS) s_N[i] = (&A.tab->N[0][0])[i];
+  const int n1 = H27_N1, n2 = H27_N2, n3 = H27_N3;
+  if (MATRIX)
+    for (int i = tid; i < nq * 81; i += H27_THREADS) s_dN[i] = (&A.tab->dN[0][0][0])[i];
   for (int i = tid; i < nq; i += H27_THREADS) s_w[i] = A.tab->w[i];
   for (int i = tid; i < 8 * ng; i += H27_THREADS) s_tab1[i] = A.tab->tab1[i / (4 * ng)][(i >> 2) % ng][i & 3];
-  // decode words of the three sum-factorisation stages: low half = offset of the first of the 3 operands (stride 3),
+  // decode words of the three sum-factorisation stages: low half = offset of the first of the 3 operands (stride NI),
   // high half = offset of the 1-D table row
   for (int t = tid; t < n1; t += H27_THREADS) {   // T1[k][q0][a12][i] = sum_a0 tab1[k][q0][a0] X[a0 + 3 a12][i]
-    const int i = t % 3, a12 = (t / 3) % 9, kq = t / 27;
-    s_dec[t] = (9 * a12 + i) | ((4 * kq) << 16);
+    const int i = t % NI, a12 = (t / NI) % 9, kq = t / (9 * NI);
+    s_dec[t] = (3 * a12 * NI + i) | ((4 * kq) << 16);
   }
   for (int t = tid; t < n2; t += H27_THREADS) {   // T2[kk][q0][q1][a2][i] = sum_a1 tab1[kt][q1][a1] T1[k][q0][a1 + 3 a2][i]
-    const int i = t % 3, a2 = (t / 3) % 3, q1 = (t / 9) % ng, q0 = (t / (9 * ng)) % ng, kk = t / (9 * ng * ng);
-    const int k = kk == 0 ? 1 : 0, kt = kk == 1 ? 1 : 0;  // kk = 0: d/dxi0, 1: d/dxi1, 2: values in both (for d/dxi2)
-    s_dec[n1 + t] = (((k * ng + q0) * 9 + 3 * a2) * 3 + i) | ((4 * (kt * ng + q1)) << 16);
+    const int i = t % NI, a2 = (t / NI) % 3, q1 = (t / (3 * NI)) % ng, q0 = (t / (3 * NI * ng)) % ng, kk = t / (3 * NI * ng * ng);
+    const int k = kk == 0 ? 1 : 0, kt = kk == 1 ? 1 : 0;  // kk = 0: d/dxi0, 1: d/dxi1, 2: values in both (for d/dxi2 and values)
+    s_dec[n1 + t] = (((k * ng + q0) * 9 + 3 * a2) * NI + i) | ((4 * (kt * ng + q1)) << 16);
   }
-  for (int t = tid; t < n3; t += H27_THREADS) {   // J[q][i][m] = sum_a2 tab1[m == 2][q2][a2] T2[m][q0][q1][a2][i]
-    const int m = t % 3, i = (t / 3) % 3, q = t / 9;
+  for (int t = tid; t < n3; t += H27_THREADS) {
+    // t < 9 nq:   J[q][i][m]     = sum_a2 tab1[m == 2][q2][a2] T2[m][q0][q1][a2][i]        (i < 3)
+    // then 3 nq:  grad_xi T[q][m] = the same with component 3; then nq: s[q] = sum_a2 L[q2][a2] T2[2][q0][q1][a2][4]
+    int m, i, q;
+    if (t < 9 * nq) {
+      m = t % 3; i = (t / 3) % 3; q = t / 9;
+    } else if (t < 12 * nq) {
+      m = (t - 9 * nq) % 3; i = 3; q = (t - 9 * nq) / 3;
+    } else {
+      m = 3; i = 4; q = t - 12 * nq;
+    }
     const int q0 = q % ng, q1 = (q / ng) % ng, q2 = q / (ng * ng);
-    s_dec[n1 + n2 + t] = ((((m * ng + q0) * ng + q1) * 3) * 3 + i) | ((4 * ((m == 2 ? 1 : 0) * ng + q2)) << 16);
+    const int kk = m == 3 ? 2 : m, kt = m == 2 ? 1 : 0;
+    s_dec[n1 + n2 + t] = ((((kk * ng + q0) * ng + q1) * 3) * NI + i) | ((4 * (kt * ng + q2)) << 16);
   }
-  double* W = wave_base + (size_t)wv * W_SIZE;
+  if (!MATRIX) {
+    // transposed stages of the residual: fe[a] = sum_q ( dN[q][a][m] h[q][m] + N[q][a] sq[q] )
+    for (int t = tid; t < H27_NA; t += H27_THREADS) {  // VA[v][q0][q1][a2] = sum_q2 tab[q2][a2] h_v[q]  (v = 2: D h_2 + L sq)
+      const int a2 = t % 3, q1 = (t / 3) % ng, q0 = (t / (3 * ng)) % ng, v = t / (3 * ng * ng);
+      const int qb = q0 + ng * q1;
+      s_dec[n1 + n2 + n3 + t] = (3 * qb + v) | (a2 << 12) | ((v == 2 ? 1 : 0) << 14) | (qb << 16);
+    }
+    for (int t = tid; t < H27_NB; t += H27_THREADS) {  // WB[w][q0][a12] = sum_q1 tab[q1][a1] VA[..]  (w = 1: D VA_1 + L VA_2)
+      const int a12 = t % 9, a1 = a12 % 3, a2 = a12 / 3, q0 = (t / 9) % ng, w = t / (9 * ng);
+      s_dec[n1 + n2 + n3 + H27_NA + t] = (((w * ng + q0) * ng) * 3 + a2) | (a1 << 12) | (w << 14);
+    }
+  }
+  double* W = wave_base + (size_t)wv * W_SIZE(MATRIX && !SCRATCH);
   __syncthreads();
   const BrickView& B = A.B;
   int64_t* rowbase = reinterpret_cast<int64_t*>(W + W_INFO);
@@ -269,9 +300,9 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   while (have) {
     // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
     if (lane < 27) {
-      W[W_X + 3 * lane + 0] = cur.x0;
-      W[W_X + 3 * lane + 1] = cur.x1;
-      W[W_X + 3 * lane + 2] = cur.x2;
+      W[W_X + NI * lane + 0] = cur.x0;
+      W[W_X + NI * lane + 1] = cur.x1;
+      W[W_X + NI * lane + 2] = cur.x2;
       const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
       if (MATRIX && SCRATCH) {
         // two-pass path: no row descriptors needed
@@ -282,8 +313,8 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
         in[5] = gi; in[6] = gj; in[7] = gk;
       } else {
         const int64_t xi = brick_xindex(B, 0, gi, gj, gk);
-        W[W_T + lane] = xstar[xi];
-        W[W_T + 28 + lane] = src ? src[xi] : 0.0;
+        W[W_X + NI * lane + 3] = xstar[xi];
+        W[W_X + NI * lane + (NI - 1)] = src ? src[xi] : 0.0;
       }
     }
     // next element of this wave: issue its node loads now
@@ -302,21 +333,21 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
         const int d = s_dec[t];
         const double* x = W + W_X + (d & 0xffff);
         const double* tb = s_tab1 + (d >> 16);
-        W[W_T1 + t] = tb[0] * x[0] + tb[1] * x[3] + tb[2] * x[6];
+        W[W_T1 + t] = tb[0] * x[0] + tb[1] * x[NI] + tb[2] * x[2 * NI];
       }
       __builtin_amdgcn_wave_barrier();
       for (int t = lane; t < n2; t += 64) {
         const int d = s_dec[n1 + t];
         const double* x = W + W_T1 + (d & 0xffff);
         const double* tb = s_tab1 + (d >> 16);
-        W[W_T2 + t] = tb[0] * x[0] + tb[1] * x[3] + tb[2] * x[6];
+        W[W_T2 + t] = tb[0] * x[0] + tb[1] * x[NI] + tb[2] * x[2 * NI];
       }
       __builtin_amdgcn_wave_barrier();
       for (int t = lane; t < n3; t += 64) {
         const int d = s_dec[n1 + n2 + t];
         const double* x = W + W_T2 + (d & 0xffff);
         const double* tb = s_tab1 + (d >> 16);
-        W[W_J + t] = tb[0] * x[0] + tb[1] * x[3] + tb[2] * x[6];
+        W[W_J + t] = tb[0] * x[0] + tb[1] * x[NI] + tb[2] * x[2 * NI];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -470,38 +501,55 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       }
     } else {
       // ---- 3'. residual: fe[a] = sum_q w det ( -k gradN_a . gradT + N_a s_q )
-      //      gradN_a . gradT = sum_m dN[q][a][m] h[q][m],  h = Jinv (Jinv^T gxi),  gxi[m] = sum_b dN[q][b][m] T_b
-      for (int t = lane; t < nq * 3; t += 64) {  // lanes (q, m): gxi
-        const double* dn = s_dN + t * 27;
-        double acc = 0.0;
-#pragma unroll 9
-        for (int b = 0; b < 27; ++b) acc += dn[b] * W[W_T + b];
-        W[W_G + t] = acc;
-      }
-      __builtin_amdgcn_wave_barrier();
+      //      gradN_a . gradT = sum_m dN[q][a][m] h[q][m],  h = Jinv (Jinv^T gxi),  gxi[m] = sum_b dN[q][b][m] T_b.
+      //      gxi and s at the Gauss points came out of the sum-factorised stages above (components 3 and 4).
       for (int q = lane; q < nq; q += 64) {  // lanes q: gradT = Jinv^T gxi ; h = -k w det * Jinv gradT ; source
         const double* Ji = W + W_J + q * 9;
-        const double g0 = W[W_G + 3 * q], g1 = W[W_G + 3 * q + 1], g2 = W[W_G + 3 * q + 2];
+        const double g0 = W[W_GX + 3 * q], g1 = W[W_GX + 3 * q + 1], g2 = W[W_GX + 3 * q + 2];
         const double t0 = g0 * Ji[0] + g1 * Ji[3] + g2 * Ji[6];
         const double t1 = g0 * Ji[1] + g1 * Ji[4] + g2 * Ji[7];
         const double t2 = g0 * Ji[2] + g1 * Ji[5] + g2 * Ji[8];
-        const double sc = -A.kcond * W[W_D + q];
+        const double wd = W[W_D + q], sc = -A.kcond * wd;
         W[W_G + 3 * q + 0] = sc * (Ji[0] * t0 + Ji[1] * t1 + Ji[2] * t2);
         W[W_G + 3 * q + 1] = sc * (Ji[3] * t0 + Ji[4] * t1 + Ji[5] * t2);
         W[W_G + 3 * q + 2] = sc * (Ji[6] * t0 + Ji[7] * t1 + Ji[8] * t2);
-        const double* nn = s_N + q * 27;
-        double sq = 0.0;
-        for (int b = 0; b < 27; ++b) sq += nn[b] * W[W_T + 28 + b];
-        W[W_G + 3 * h27_pad(nq) + q] = sq * W[W_D + q];
+        W[W_G + 3 * h27_pad(nq) + q] = W[W_SV + q] * wd;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // the contraction with dN / N, transposed sum factorisation: over q2, then q1, then q0
+      const int oA = n1 + n2 + n3, oB = oA + H27_NA, ngg = ng * ng;
+      for (int t = lane; t < H27_NA; t += 64) {
+        const int d = s_dec[oA + t];
+        const int a2 = (d >> 12) & 3, v2 = (d >> 14) & 1;
+        const double* hp = W + W_G + (d & 0xfff);
+        const double* sp = W + W_G + 3 * h27_pad(nq) + (d >> 16);
+        double acc = 0.0;
+        for (int q2 = 0; q2 < ng; ++q2) {
+          const double L = s_tab1[q2 * 4 + a2], D = s_tab1[(ng + q2) * 4 + a2];
+          acc += (v2 ? D : L) * hp[3 * ngg * q2];
+          if (v2) acc += L * sp[ngg * q2];
+        }
+        W[W_VA + t] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < H27_NB; t += 64) {
+        const int d = s_dec[oB + t];
+        const int a1 = (d >> 12) & 3, w = (d >> 14) & 1;
+        const double* va = W + W_VA + (d & 0xfff);
+        double acc = 0.0;
+        for (int q1 = 0; q1 < ng; ++q1) {
+          const double L = s_tab1[q1 * 4 + a1], D = s_tab1[(ng + q1) * 4 + a1];
+          acc += (w ? D : L) * va[3 * q1];
+          if (w) acc += L * va[3 * ngg + 3 * q1];
+        }
+        W[W_WB + t] = acc;
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < 27) {
+        const int a0 = lane % 3, a12 = lane / 3;
         double fe = 0.0;
-        for (int q = 0; q < nq; ++q) {
-          const double* dn = s_dN + q * 81 + lane;
-          fe += dn[0] * W[W_G + 3 * q] + dn[27] * W[W_G + 3 * q + 1] + dn[54] * W[W_G + 3 * q + 2] +
-                s_N[q * 27 + lane] * W[W_G + 3 * h27_pad(nq) + q];
-        }
+        for (int q0 = 0; q0 < ng; ++q0)
+          fe += s_tab1[(ng + q0) * 4 + a0] * W[W_WB + q0 * 9 + a12] + s_tab1[q0 * 4 + a0] * W[W_WB + (ng + q0) * 9 + a12];
         const int gi = 2 * Ic + lane % 3, gj = 2 * Jc + (lane / 3) % 3, gk = 2 * Kc + lane / 9;
         if (gi >= B.plo && gi < B.phi) out[(int64_t)(gi - B.plo) * B.plane_len + (int64_t)gj * B.m2 + gk] += fe;
       }
@@ -708,10 +756,11 @@ extern "C" int mfem_debug_set_hex27(int two_pass) {
   return MFEM_OK;
 }
 
-static size_t hex27_lds_bytes(int ng, bool matrix) {
-  const int nq = ng * ng * ng;
-  return sizeof(double) * ((size_t)nq * (81 + (matrix ? 0 : 27)) + ((nq + 1) & ~1) + 8 * ng + (h27_pad(H27_NDEC) >> 1) +
-                           H27_WAVES * (size_t)(W_SIZE));
+// mode: 0 residual, 1 matrix with colour scatter / atomics (row descriptors per wave), 2 matrix -> scratch
+static size_t hex27_lds_bytes(int ng, int mode) {
+  const int nq = ng * ng * ng, NI = mode == 0 ? 5 : 3;
+  return sizeof(double) * ((size_t)(mode == 0 ? 0 : nq * 81) + ((nq + 1) & ~1) + 8 * ng + (h27_pad(H27_NDEC) >> 1) +
+                           H27_WAVES * (size_t)(W_SIZE(mode == 1)));
 }
 
 static int hex27_launch_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix, double h, double Tenv, uint32_t robin,
@@ -772,7 +821,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   const int nq = m->ng * m->ng * m->ng;
   int rc = hex27_upload_tables(m->ng);
   if (rc) return rc;
-  const size_t lds = hex27_lds_bytes(m->ng, true);
+  const size_t lds = hex27_lds_bytes(m->ng, g_hex27_two_pass == 1 ? 2 : 1);
   MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   BrickView B = mfem_brick_view(m, 1);
   if (g_hex27_two_pass == 2) {
@@ -842,7 +891,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
   const int nq = m->ng * m->ng * m->ng;
   int rc = hex27_upload_tables(m->ng);
   if (rc) return rc;
-  const size_t lds = hex27_lds_bytes(m->ng, false);
+  const size_t lds = hex27_lds_bytes(m->ng, 0);
   MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   MFEM_CHECK_HIP(hipMemsetAsync(residue, 0, sizeof(double) * (size_t)m->n_owned, ctx->stream));
   BrickView B = mfem_brick_view(m, 1);
