@@ -39,7 +39,7 @@ VARIANT = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 _lib.lib.mfem_debug_set_hex27(0)
 if len(sys.argv) > 2:  # phase ablation (timing only; the skipped phases make the values wrong)
     for name, skip in (("all phases", 0), ("no scatter", 8), ("no scatter, no MFMA loop", 12), ("no scatter, no MFMA, no Jacobians", 14),
-                       ("nothing but the loop skeleton", 15), ("no MFMA loop only", 4), ("no node loads only", 1), ("no Jacobians only", 2), ("no readlanes only", 16)):
+                       ("nothing but the loop skeleton", 15), ("no MFMA loop only", 4), ("no node loads only", 1), ("no Jacobians only", 2)):
         _lib.lib.mfem_debug_set_hex27((skip << 8) | VARIANT)
         ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
         print(f"  ablation [{name}]: {ms:.2f} ms", flush=True)
