@@ -94,6 +94,14 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
  * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks (mode 2). */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
                            int64_t* regular_rows);
+/* Symmetric sweep (mode 2, 27-point lattice stencil, one field): when the values of a solve are bitwise symmetric where it
+ * matters (checked once per solve on the slot-major copy), a row's entries on the 13 lower diagonals are taken from the mirror
+ * entry of the neighbouring row -- kept in LDS by a workgroup that sweeps an in-plane tile of 512 rows through consecutive
+ * lattice planes -- instead of from memory: same products, same summation order, bitwise the same y as the plain kernel,
+ * about 2/3 of its matrix traffic.  entries = 8-byte matrix values one SpMV of the planned layout reads from memory
+ * (symmetric_sweep = 1: assuming the values pass the check).  mfem_debug_sym_spmv_count: launches of that kernel so far. */
+int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep);
+int64_t mfem_debug_sym_spmv_count(void);
 /* y = alpha A x + beta y through that layout, conversion of `vals` included (diagnostic: what the Krylov loop computes). */
 int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
                             double beta);
@@ -104,8 +112,8 @@ int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
 /* x-window variant of the CSR kernel (x window in LDS + 16-bit local indices; off by default): enable, tile size, grid. */
 int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
- * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results); bits 24-25 workgroup size of the
- * diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
+ * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results); bit 22 symmetric sweep kernel off;
+ * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
 int mfem_debug_set_ell(int enable);
 /* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix_robin(BrickView B
 #pragma unroll
       for (int c = 0; c < 4; ++c) na = (c == ca) ? c_fN[q][c] : na;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) mab[c] += -h * ws * na * c_fN[q][c];
+      for (int c = 0; c < 4; ++c) mab[c] += (-h * ws) * (na * c_fN[q][c]);  // N_a N_c first: entry (a, c) == entry (c, a) bitwise
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) row[((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk)] += mab[c];

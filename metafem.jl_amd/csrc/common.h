@@ -109,6 +109,13 @@ struct mfem_csr_s {
   int32_t* dia_flags;       // owned, one int per 128-row block: 1 = regular (diagonal-slotted), 0 = explicit columns
   int32_t dia_regular_blocks;
   int dia_triples;          // the diagonals come in runs of three consecutive offsets
+  // symmetric sweep variant of the diagonal-slotted SpMV (27-point lattice stencil): sym_state 0 = not inspected, -1 = no, 1 = structure ok
+  int sym_state;
+  int64_t sym_c0, sym_c1;   // chunks (512 rows) [c0, c1) whose blocks are all regular
+  int sym_cls;              // the diagonal list (class) with the lattice form
+  int sym_S;                // chunks per lattice plane (rounded): a workgroup sweeps chunks c, c + S, c + 2 S, ...
+  int sym_bound;            // 1 = the bound values passed the bitwise symmetry check of this bind
+  int64_t sym_mx, sym_myz;  // matrix entries per chunk the sweep kernel takes from LDS: previous-plane diagonals / in-chunk -y, -z
   int ell_bound_mode;       // 0 none, 1 slot-major with explicit columns, 2 diagonal-slotted
   // row-sorted sliced ELL for rows of uneven length (spmv_sell.hip): sell_state 0 = not planned, -1 = no, 1 = ready
   int sell_state;

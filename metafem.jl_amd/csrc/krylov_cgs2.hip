@@ -116,7 +116,7 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   int since = 0, host_iter = 1;
   RC(mfem_read_flags(ctx));
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CGS2);
-  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, V.b); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int dummy_spmv = 0;

@@ -43,6 +43,7 @@ static int g_dia_enable = 1;
 // runs; 8: 2 rows x3 without that sharing; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
 static int g_dia_variant = 0;
 static int g_dia_block = MFEM_BLOCK;  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
+static int g_dia_sym = 1;      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernel off
 static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
@@ -55,6 +56,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
   g_dia_variant = (enable >> 16) & 15;
   g_dia_xcd = (enable >> 20) & 3;
+  g_dia_sym = ((enable >> 22) & 1) ? 0 : 1;
   g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks; bit 21: timing probe without x loads
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
                                                            const double* __restrict__ dotw, double* __restrict__ partials,
-                                                           const int32_t* __restrict__ done_flag, int xcd) {
+                                                           const int32_t* __restrict__ done_flag, int xcd, int64_t skip_lo, int64_t skip_hi) {
   __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   const DiaOffsets& O = *Op;
@@ -351,8 +353,14 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
     chunk_end = ((blockIdx.x & 7) + 1) * per < nchunks ? ((blockIdx.x & 7) + 1) * per : nchunks;
     chunk_step = gridDim.x >> 3;
   }
+  const int64_t skip_c0 = skip_lo / rows_per_wg, skip_c1 = skip_hi / rows_per_wg;  // chunks the symmetric sweep kernel covers
   for (; chunk < chunk_end; chunk += chunk_step) {
-    const int64_t r = chunk * rows_per_wg + (int64_t)threadIdx.x * RPT;
+    int64_t ch = chunk;
+    if (xcd & 4) {  // running index over the chunks outside [skip_c0, skip_c1) only
+      if (ch >= skip_c0) ch += skip_c1 - skip_c0;
+      if (ch >= nchunks) break;
+    }
+    const int64_t r = ch * rows_per_wg + (int64_t)threadIdx.x * RPT;
     if (r >= n) continue;
     const double* v = vals + ell_base(r, K);
     e_d2 acc[H];
@@ -465,6 +473,151 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric sweep kernel for the 27-point lattice stencil (offsets di PL + dj m2 + dk).  For a symmetric matrix the entry of
+// row r on a lower diagonal -o equals the entry of row r - o on the upper diagonal +o.  A workgroup owns an in-plane tile
+// of 512 rows and sweeps it through consecutive lattice planes (chunks c, c + S, c + 2 S, ...): the nine upper diagonals
+// that point to the next plane are kept in LDS when they are loaded, and the next plane's rows read their nine
+// previous-plane (lower) diagonals from there instead of from HBM.  Same products, same summation order as the plain
+// diagonal-slotted kernel: the result is bitwise the same whenever the matrix is bitwise symmetric (checked at bind time).
+// ---------------------------------------------------------------------------------------------------------------
+#define SYM_ROWS 512
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sym27(int64_t n, int K, const DiaOffsets* __restrict__ Op,
+                                                             const double* __restrict__ vals, const double* __restrict__ x,
+                                                             double* __restrict__ y, double alpha, double beta,
+                                                             const double* __restrict__ dotw, double* __restrict__ partials,
+                                                             const int32_t* __restrict__ done_flag, int64_t c0, int64_t c1, int S, int nsteps, int cls) {
+  __shared__ __attribute__((aligned(16))) double hist[9][SYM_ROWS];  // diagonals 18..26 (into the next plane) of the previous chunk
+  __shared__ __attribute__((aligned(16))) double exch[4][SYM_ROWS];  // diagonals 14..17 (+z, +y) of this chunk
+  __shared__ double red[16];
+  if (done_flag && done_flag[0]) return;
+  const int32_t* off = Op->off[cls];
+  // gridDim.x workgroups over S tiles: tile t is swept by nseg (+ 1 for the first gridDim.x % S tiles) workgroups, each
+  // taking a contiguous range of the tile's nsteps plane steps
+  const int tile = blockIdx.x % S, seg = blockIdx.x / S;
+  const int nseg = gridDim.x / S + (tile < (int)(gridDim.x % S) ? 1 : 0);
+  const int seg_len = (nsteps + nseg - 1) / nseg;
+  const int tid = threadIdx.x;
+  double dot_acc = 0.0;
+  bool have_hist = false;
+  for (int it = 0; it < seg_len; ++it) {
+    const int step = seg * seg_len + it;
+    const int64_t chunk = c0 + tile + (int64_t)S * step;
+    if (step >= nsteps || chunk >= c1) break;  // workgroup-uniform
+    const int64_t r = chunk * SYM_ROWS + 2 * tid;
+    const double* v = vals + ell_base(r, K);
+    e_d2 acc = {0.0, 0.0};
+    // ---- the lane's own +z / +y diagonals first: the rows behind it in this chunk read them as their -z / -y diagonals
+    e_d2 up[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      up[u] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (14 + u) * ELL_B));
+      *reinterpret_cast<e_d2*>(&exch[u][2 * tid]) = up[u];
+    }
+    __syncthreads();  // exch complete; also: every wave has finished writing the previous chunk's history
+    // a slot's value pair, mirrored from LDS (row `lp` of table `tab`) when both source rows are in it, else from the row itself
+    auto slot = [&](int s, const double* tab, int lp, bool ok) -> e_d2 {
+      e_d2 w;
+      if (ok && lp >= 0 && lp + 1 < SYM_ROWS) {
+        w.x = tab[lp];
+        w.y = tab[lp + 1];
+      } else {
+        w = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
+      }
+      return w;
+    };
+#define SYM_RUN(va, vb, vc, s0)                                          \
+  {                                                                      \
+    const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s0]);     \
+    const u_d2 xa = xp[0], xb = xp[1];                                   \
+    acc.x += va.x != 0.0 ? va.x * xa.x : 0.0;                            \
+    acc.y += va.y != 0.0 ? va.y * xa.y : 0.0;                            \
+    acc.x += vb.x != 0.0 ? vb.x * xa.y : 0.0;                            \
+    acc.y += vb.y != 0.0 ? vb.y * xb.x : 0.0;                            \
+    acc.x += vc.x != 0.0 ? vc.x * xb.x : 0.0;                            \
+    acc.y += vc.y != 0.0 ? vc.y * xb.y : 0.0;                            \
+    if (s0 == 12) {                                                      \
+      xself0 = xa.y;                                                     \
+      xself1 = xb.x;                                                     \
+    }                                                                    \
+  }
+    double xself0 = 0.0, xself1 = 0.0;
+    // ---- the nine diagonals into the previous plane: entry (r, r + o) = entry (r + o, r) on diagonal 26 - s of row r + o,
+    //      kept in `hist` if that row was in the previous chunk of this sweep
+    const int lph = 2 * tid + S * SYM_ROWS;
+#pragma unroll
+    for (int s = 0; s < 9; s += 3) {
+      const e_d2 va = slot(s, hist[8 - s], lph + off[s], have_hist);
+      const e_d2 vb = slot(s + 1, hist[7 - s], lph + off[s + 1], have_hist);
+      const e_d2 vc = slot(s + 2, hist[6 - s], lph + off[s + 2], have_hist);
+      SYM_RUN(va, vb, vc, s);
+    }
+    {  // -y diagonals 9..11 <- +y diagonals 17..15 of the rows one lattice line behind, if those are in this chunk
+      const e_d2 va = slot(9, exch[3], 2 * tid + off[9], true);
+      const e_d2 vb = slot(10, exch[2], 2 * tid + off[10], true);
+      const e_d2 vc = slot(11, exch[1], 2 * tid + off[11], true);
+      SYM_RUN(va, vb, vc, 9);
+    }
+    {  // -z (12) <- +z (14) of the row before; main diagonal 13; +z from the registers
+      e_d2 va;
+      va.y = up[0].x;  // row r + 1: entry (r + 1, r) = entry (r, r + 1)
+      if (tid > 0) va.x = exch[0][2 * tid - 1];
+      else va.x = v[12 * ELL_B];
+      const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + 13 * ELL_B));
+      SYM_RUN(va, vb, up[0], 12);
+    }
+    SYM_RUN(up[1], up[2], up[3], 15);
+    __syncthreads();  // every wave is done reading hist and exch
+    // ---- the nine diagonals into the next plane: they also go to LDS for the next chunk of the sweep
+#pragma unroll
+    for (int s = 18; s < 27; s += 3) {
+      const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
+      const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
+      const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
+      SYM_RUN(va, vb, vc, s);
+      *reinterpret_cast<e_d2*>(&hist[s - 18][2 * tid]) = va;
+      *reinterpret_cast<e_d2*>(&hist[s - 17][2 * tid]) = vb;
+      *reinterpret_cast<e_d2*>(&hist[s - 16][2 * tid]) = vc;
+    }
+#undef SYM_RUN
+    have_hist = true;
+    double y0 = alpha * acc.x, y1 = alpha * acc.y;
+    if (beta != 0.0) {
+      y0 += beta * y[r];
+      y1 += beta * y[r + 1];
+    }
+    y[r] = y0;
+    y[r + 1] = y1;
+    if (dotw) {
+      if (dotw == x) dot_acc += y0 * xself0 + y1 * xself1;
+      else dot_acc += y0 * dotw[r] + y1 * dotw[r + 1];
+    }
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = b;
+  }
+}
+
+// bad[0] |= 1 unless, for every row r of the regular chunk range and every lower diagonal s < 13 whose source row r + off[s]
+// is in the range too, entry (r, s) equals entry (r + off[s], 26 - s) bitwise: exactly the substitutions k_spmv_sym27 makes
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffsets* __restrict__ Op, const double* __restrict__ vals,
+                                                              int64_t row_lo, int64_t row_hi, int cls, int32_t* __restrict__ bad) {
+  const int32_t* off = Op->off[cls];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int fail = 0;
+  for (int64_t r = row_lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < row_hi; r += stride) {
+    const double* v = vals + ell_base(r, K);
+    for (int s = 0; s < 13; ++s) {
+      const int64_t rs = r + off[s];
+      if (rs < row_lo) continue;
+      const double a = v[s * ELL_B], b = vals[ell_base(rs, K) + (26 - s) * ELL_B];
+      if (__double_as_longlong(a) != __double_as_longlong(b) && !(a == 0.0 && b == 0.0)) fail = 1;
+    }
+  }
+  if (fail) atomicOr(bad, 1);
+}
+
 // Decide eligibility and build the column table (once per pattern).  A->max_row_nnz must be known (mfem_csr_plan).
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->ell_state != 0) return MFEM_OK;
@@ -551,6 +704,60 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
         for (int c = 0; c < O.ncls && A->dia_triples; ++c)
           for (int i = 0; i + 2 < K && A->dia_triples; i += 3)
             if (O.off[c][i + 1] != O.off[c][i] + 1 || O.off[c][i + 2] != O.off[c][i] + 2) A->dia_triples = 0;
+        // 27-point lattice stencil with one class: candidate for the symmetric sweep kernel
+        A->sym_state = -1;
+        int lc = -1;  // the class with the lattice form (a slab has further classes for the rows next to its ghost planes)
+        int64_t m2 = 0, PL = 0;
+        for (int c = 0; c < O.ncls && lc < 0 && K == 27; ++c) {
+          if (O.D[c] != 27 || O.off[c][13] != 0 || O.off[c][14] != 1) continue;
+          m2 = O.off[c][16];
+          PL = O.off[c][22];
+          bool lattice = m2 > 2 && PL > 2 * m2;
+          for (int q = 0; q < 27 && lattice; ++q)
+            if (O.off[c][q] != (q / 9 - 1) * PL + ((q / 3) % 3 - 1) * m2 + (q % 3 - 1)) lattice = false;
+          if (lattice) lc = c;
+        }
+        if (lc >= 0) {
+          const bool lattice = true;
+          const int64_t Sc = (PL + SYM_ROWS / 2) / SYM_ROWS, delta = PL - Sc * SYM_ROWS;
+          if (lattice && Sc >= 8 && delta >= -64 && delta <= 64 && m2 + 2 < SYM_ROWS) {
+            std::vector<int32_t> hf((size_t)nblk);
+            MFEM_CHECK_HIP(hipMemcpy(hf.data(), A->dia_flags, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
+            // longest run of regular blocks, cut to whole chunks (4 blocks)
+            int64_t best_lo = 0, best_hi = 0, lo = -1;
+            for (int64_t b = 0; b <= nblk; ++b) {
+              const bool reg = b < nblk && hf[(size_t)b] == lc + 1 && (b + 1) * ELL_B <= A->n;
+              if (reg && lo < 0) lo = b;
+              if (!reg && lo >= 0) {
+                if (b - lo > best_hi - best_lo) { best_lo = lo; best_hi = b; }
+                lo = -1;
+              }
+            }
+            const int64_t c0 = (best_lo + 3) / 4, c1 = best_hi / 4;
+            if (c1 - c0 >= 4 * Sc) {
+              A->sym_state = 1;
+              A->sym_c0 = c0;
+              A->sym_c1 = c1;
+              A->sym_S = (int)Sc;
+              A->sym_cls = lc;
+              // entries per chunk that k_spmv_sym27 mirrors instead of loading (same lane pattern in every chunk)
+              int64_t mx = 0, myz = 0;
+              for (int t = 0; t < SYM_ROWS / 2; ++t) {
+                for (int q = 0; q < 9; ++q) {
+                  const int64_t lp = 2 * t + Sc * SYM_ROWS + O.off[lc][q];
+                  if (lp >= 0 && lp + 1 < SYM_ROWS) mx += 2;
+                }
+                for (int q = 9; q < 12; ++q) {
+                  const int64_t lp = 2 * t + O.off[lc][q];
+                  if (lp >= 0 && lp + 1 < SYM_ROWS) myz += 2;
+                }
+                myz += t > 0 ? 2 : 1;
+              }
+              A->sym_mx = mx;
+              A->sym_myz = myz;
+            }
+          }
+        }
       } else {
         hipFree(A->dia_flags);
         hipFree(A->dia_dev);
@@ -561,6 +768,24 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   }
   return MFEM_OK;
 }
+
+static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* nsteps_out) {
+  // 53 KB of LDS per workgroup: three per CU; equal segments for every tile and all workgroups resident in one round
+  // (645 workgroups of 51 steps beat 768 of 43 / 51 at 256^3: the longest segment sets the time)
+  const int64_t nsteps = (A->sym_c1 - A->sym_c0 + A->sym_S - 1) / A->sym_S;
+  int nseg = (3 * ctx->num_cus) / A->sym_S;
+  if (nseg > nsteps / 8) nseg = (int)(nsteps / 8);  // a segment's first step has no history: keep segments >= 8 steps long
+  if (nseg < 1) nseg = 1;
+  if (nsteps_out) *nsteps_out = nsteps;
+  return A->sym_S * nseg;
+}
+static int64_t g_sym_launches = 0;
+// the sweep kernel needs ~2 workgroups per CU of >= 8 steps each to beat the plain kernel: chunk ranges below this stay on the
+// plain kernel (mfem_debug_set_layout_min_rows(0, ...) lifts the limit for the parity tests)
+static bool sym27_wanted(const mfem_csr_s* A) {
+  return A->sym_state == 1 && g_dia_sym && A->dia_triples && (g_layout_min_rows_dia == 0 || A->sym_c1 - A->sym_c0 >= 4096);
+}
+extern "C" int64_t mfem_debug_sym_spmv_count(void) { return g_sym_launches; }
 
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
   if (A->ell_state != 1 || !g_ell_enable) return 0;
@@ -574,6 +799,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
   A->ell_bound_mode = 0;
+  A->sym_bound = 0;
   if (A->ell_state != 1 || !g_ell_enable || !buf) return MFEM_OK;
   if (A->dia_state == 1 && g_dia_enable) {
     const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
@@ -593,6 +819,17 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     A->ell_vals = buf;
     A->ell_src = vals;
     A->ell_bound_mode = 2;
+    A->sym_bound = 0;
+    if (sym27_wanted(A)) {  // are these values bitwise symmetric where the sweep kernel would mirror them?
+      int32_t* d_bad = ctx->d_flags + 9;
+      MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
+      hipLaunchKernelGGL(k_sym27_check, dim3(ctx->num_cus * 8), dim3(MFEM_BLOCK), 0, ctx->stream, A->ell_K, O, (const double*)buf,
+                         A->sym_c0 * SYM_ROWS, A->sym_c1 * SYM_ROWS, A->sym_cls, d_bad);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      A->sym_bound = ctx->h_flags[9] ? 0 : 1;
+    }
     return MFEM_OK;
   }
   int waves = 4;
@@ -654,6 +891,7 @@ int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d) {
 }
 
 void mfem_ell_unbind(mfem_csr_s* A) {
+  A->sym_bound = 0;
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
   A->ell_bound_mode = 0;
@@ -683,7 +921,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
 #define LAUNCH_DIA(RPT, U)                                                                                                \
   hipLaunchKernelGGL((k_spmv_dia<RPT, U>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,          \
-                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd)
+                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd, 0, 0)
     switch (g_dia_variant) {
       case 1: LAUNCH_DIA(2, 2); break;
       case 3: LAUNCH_DIA(2, 9); break;
@@ -692,9 +930,27 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       case 6: LAUNCH_DIA(2, 1); break;
       case 0:
       case 7:
+        if (g_dia_variant != 8 && sym27_wanted(A) && A->sym_bound == 1 && g_dia_block == MFEM_BLOCK) {
+          // rows of the regular chunk range: symmetric sweep kernel; the rest: the plain kernel with that range skipped
+          int64_t nsteps = 0;
+          const int gs = sym27_grid(ctx, A, &nsteps);
+          ++g_sym_launches;
+          const int64_t nchunks = (A->n + SYM_ROWS - 1) / SYM_ROWS;
+          int64_t g1l = A->sym_c0 + (nchunks - A->sym_c1);  // one workgroup per chunk outside the regular range
+          if (g1l + gs > MFEM_MAX_PARTIALS) g1l = MFEM_MAX_PARTIALS - gs;
+          const int g1 = (int)(g1l < 1 ? 1 : g1l);
+          hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(g1), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
+                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, 4,
+                             A->sym_c0 * SYM_ROWS, A->sym_c1 * SYM_ROWS);
+          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_K, O, A->ell_vals, x, y, alpha,
+                             beta, dotw, partials ? partials + g1 : nullptr, done_flag, A->sym_c0, A->sym_c1, A->sym_S, (int)nsteps, A->sym_cls);
+          MFEM_CHECK_LAUNCH();
+          if (n_partials && partials) *n_partials = g1 + gs;
+          return 1;
+        }
         if (A->dia_triples && g_dia_variant != 8) {
           hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gdb), dim3(g_dia_block), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd);
+                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd, 0, 0);
         } else {
           LAUNCH_DIA(2, 3);
         }
@@ -728,6 +984,28 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   return 1;
+}
+
+// Matrix entries (8-byte values) one SpMV of the planned solver layout reads from memory: K * padded rows for the slot-major
+// layouts, less what the symmetric sweep kernel takes from LDS when the bound values are symmetric (*symmetric_sweep = 1 if the
+// structure allows that kernel; whether it runs is decided per solve by the bitwise symmetry check of the values).
+extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep) {
+  MFEM_REQUIRE(ctx && A, "null argument");
+  int32_t mode = 0;
+  int rc = mfem_csr_solver_layout(ctx, A, &mode, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  int64_t e = A->nnz;
+  int sym = 0;
+  if (mode == 1 || mode == 2) e = (int64_t)A->ell_K * A->ell_npad;
+  if (mode == 2 && sym27_wanted(A)) {
+    sym = 1;
+    const int gs = sym27_grid(ctx, A, nullptr);
+    const int64_t nch = A->sym_c1 - A->sym_c0;
+    e -= (nch - gs) * A->sym_mx + nch * A->sym_myz;
+  }
+  if (entries) *entries = e;
+  if (symmetric_sweep) *symmetric_sweep = sym;
+  return MFEM_OK;
 }
 
 // What the Krylov loop of the next mfem_solve will run on this pattern: 0 = CSR tile kernel, 1 = slot-major copy with explicit

@@ -330,3 +330,107 @@ def test_slot_major_layouts_on_caller_supplied_csr(mf, rp_dtype, base):
         assert st.converged == 1
         assert np.abs(x.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
     _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+def _sym_brick(mf, slab=None):
+    """21 x 64 x 64 control points: a lattice plane is 4096 rows = 8 chunks of 512, so the symmetric sweep kernel applies."""
+    brick = mf.make_Brick((1.0, 2.0, 1.5), (20, 63, 63))
+    if slab is not None:
+        brick.set_slab(*slab)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    return brick, A, K
+
+
+@pytest.mark.parametrize("slab", [None, (5, 17)])
+def test_symmetric_sweep_spmv_is_bitwise_the_plain_kernel(mf, slab):
+    """27-point lattice stencil + bitwise symmetric values: the sweep kernel (lower diagonals mirrored through LDS) must give the
+    same y as the plain diagonal-slotted kernel bit for bit, on the whole mesh and on a slab with ghost planes on both sides."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib, parallel as par
+
+    brick, A, K = _sym_brick(mf, slab)
+    nloc = A.n if slab is None else par.local_vector_length(slab[0], slab[1], 64, 64, 1)
+    x = mf.FEM_rand(nloc, 5, 0) - 0.5
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        ent, sym = C.c_int64(), C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout_entries(brick.ctx._h, A._h, C.byref(ent), C.byref(sym)))
+        assert sym.value == 1 and ent.value < 0.8 * 27 * A.n  # about a third of the entries come from LDS
+        ys = []
+        for knob in (1 << 22, 0):  # plain kernel, then sweep kernel
+            _lib.lib.mfem_debug_set_ell(1 | knob)
+            before = _lib.lib.mfem_debug_sym_spmv_count()
+            y = torch.full((A.n,), 3.0, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+            assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob == 0)
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+        yc = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        _lib.lib.mfem_debug_set_ell(0)
+        mf.mul_(yc, A, K, x)  # CSR kernel
+        assert float((yc - ys[1]).abs().max()) <= 1e-13 * float(yc.abs().max())
+        # alpha / beta form
+        _lib.lib.mfem_debug_set_ell(1)
+        y2 = ys[1].clone()
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y2.data_ptr(), -0.5, 2.0))
+        assert float((y2 - 1.5 * ys[1]).abs().max()) <= 1e-12 * float(yc.abs().max())
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+def test_symmetric_sweep_is_refused_for_unsymmetric_values(mf):
+    """One entry changed by one ulp: the per-solve check fails, the plain kernel runs, and the result is the unsymmetric product."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick, A, K = _sym_brick(mf)
+    x = mf.FEM_rand(A.n, 7, 0) - 0.5
+    rp = A.rowptr.cpu().numpy()
+    row = 9 * 4096 + 31 * 64 + 17  # an interior control point
+    K2 = K.clone()
+    K2[int(rp[row]) + 20] = torch.nextafter(K2[int(rp[row]) + 20], torch.tensor(float("inf"), dtype=torch.float64, device="cuda"))
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        before = _lib.lib.mfem_debug_sym_spmv_count()
+        y = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K2.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+        assert _lib.lib.mfem_debug_sym_spmv_count() == before
+        yc = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        _lib.lib.mfem_debug_set_ell(0)
+        mf.mul_(yc, A, K2, x)
+        assert float((yc - y).abs().max()) <= 1e-13 * float(yc.abs().max())
+        # and the symmetric values of the same pattern go through the sweep kernel again
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+        assert _lib.lib.mfem_debug_sym_spmv_count() > before
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+def test_cg_with_symmetric_sweep_matches_plain_kernel(mf):
+    """Same CG, SpMVs on the sweep kernel vs the plain kernel: identical iteration count, solutions equal to round-off."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick, A, K = _sym_brick(mf)
+    b = mf.FEM_rand(A.n, 11, 0)
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        out = []
+        for knob in (1 << 22, 0):
+            _lib.lib.mfem_debug_set_ell(1 | knob)
+            before = _lib.lib.mfem_debug_sym_spmv_count()
+            x, st = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=mf.cg_, maxiter=2000, max_pass=2)
+            assert st.converged == 1
+            assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob == 0)
+            out.append((x, st.iterations))
+        assert abs(out[0][1] - out[1][1]) <= 1
+        assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-9 * float(out[0][0].abs().max())
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
