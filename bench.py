@@ -148,6 +148,7 @@ def main():
     _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 1))
     tot, cnt = C.c_double(), C.c_int64()
     _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
+    sym_count0 = int(_lib.lib.mfem_debug_sym_spmv_count())
     barrier()
     t0 = time.perf_counter()
     solve_ms = 0.0
@@ -172,10 +173,22 @@ def main():
         csr_bytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8  # val 8 + col 4 per nz; x, y 8 each per row; i64 rowptr
         mode, slots, npad, reg = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
         _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
+        sym_used = False
         if mode.value == 2:
             # diagonal-slotted blocks read no column stream: 8 B per nonzero + x, y; rows in generic blocks also read 4 B columns
             kernel = "k_spmv_dia<2,3> (SpMV on the slot-major copy of the CSR matrix made once per solve; diagonal-slotted blocks)"
             spmv_bytes = A.nnz * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
+            ent, symf = C.c_int64(), C.c_int32()
+            _lib.check(_lib.lib.mfem_csr_solver_layout_entries(ctx._h, A._h, C.byref(ent), C.byref(symf)))
+            sym_used = bool(symf.value) and int(_lib.lib.mfem_debug_sym_spmv_count()) > sym_count0
+            if sym_used:
+                # symmetric sweep: the lower-diagonal entries a workgroup still holds in LDS are not read again; `ent` = 8-byte
+                # matrix values one SpMV reads from memory (27 slots per padded row minus the mirrored ones)
+                kernel = ("k_spmv_sym27 (+ k_spmv_dia<2,3> on the two boundary planes): SpMV on the slot-major copy of the CSR matrix "
+                          "made once per solve; the values passed the per-solve bitwise symmetry check, so lower-diagonal entries "
+                          "are mirrored through LDS (bitwise the same y as the plain diagonal-slotted kernel)")
+                plain_bytes = spmv_bytes
+                spmv_bytes = ent.value * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
         elif mode.value == 1:
             kernel = "k_spmv_ell<2,1> (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)"
             spmv_bytes = A.nnz * 12 + A.n * 16
@@ -189,7 +202,8 @@ def main():
         if os.path.exists(tpath) and N == 256 and world == 1:  # PMC traffic was measured on this single-GPU workload
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch") if tj.get("solver_layout_mode") == mode.value else None
+                same = tj.get("solver_layout_mode") == mode.value and bool(tj.get("symmetric_sweep", False)) == sym_used
+                traffic = tj.get("hbm_bytes_per_launch") if same else None
             except Exception:
                 traffic = None
         out = {
@@ -221,6 +235,10 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms, "launches": cnt.value,
+                **({"plain_diagonal_kernel_bytes_per_launch": plain_bytes,
+                    "note": "algorithmic bytes = what this kernel design reads: 8 B per matrix entry not mirrored from LDS "
+                            "(about 18.6 of 27 per row) + x + y; the plain diagonal-slotted kernel reads "
+                            "plain_diagonal_kernel_bytes_per_launch"} if sym_used else {}),
                 "csr_equivalent": {"bytes_per_launch": csr_bytes, "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
                                    "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
                                            "kernel would have to sustain to match this time"},

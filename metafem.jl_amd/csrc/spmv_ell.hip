@@ -328,8 +328,123 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
   }
 }
 
-typedef double u_d2 __attribute__((ext_vector_type(2), aligned(8)));
 // lane <-> RPT (2 or 4) neighbouring rows; a wave covers one aligned block of 64 RPT rows; U diagonals per batch
+typedef double u_d2 __attribute__((ext_vector_type(2), aligned(8)));
+// The RPT rows r .. r + RPT - 1 of one lane (r a multiple of RPT; a wave covers aligned 128-row blocks): regular blocks by
+// diagonal, the others through their explicit columns.  Shared by the plain kernel and the symmetric sweep kernel (which
+// sends the chunks outside its regular range here).
+template <int RPT, int U, bool TRIPLES>
+__device__ __forceinline__ void dia_rows(int64_t r, int64_t n, int64_t npad, int K, const DiaOffsets& O,
+                                         const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
+                                         const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y,
+                                         double alpha, double beta, const double* __restrict__ dotw, int xcd, double& dot_acc) {
+  constexpr int H = RPT / 2;  // 16-byte pairs per lane
+  const double* v = vals + ell_base(r, K);
+  e_d2 acc[H];
+  double xself0 = 0.0, xself1 = 0.0;  // x[r], x[r + 1] when the kernel has loaded them anyway (fused w.y with w == x, as in CG)
+  bool have_self = false;
+#pragma unroll
+  for (int h = 0; h < H; ++h) acc[h] = (e_d2){0.0, 0.0};
+  // the wave's rows [b0, b0 + 64 RPT) are RPT / 2 aligned 128-row blocks: regular only if all of them are (wave-uniform)
+  const int64_t blk = r / (64 * RPT) * (RPT / 2);
+  const int cls = __builtin_amdgcn_readfirstlane(flags[blk]) - 1;  // wave-uniform: keeps the offset reads scalar
+  bool interior = cls >= 0;
+  if (RPT == 4) interior = interior && ((blk + 1) * 128 < npad) && flags[blk + 1] == cls + 1;
+  const int32_t* off = O.off[cls < 0 ? 0 : cls];
+  const int D = O.D[cls < 0 ? 0 : cls];
+  if (interior && TRIPLES && RPT == 2) {
+    // the diagonals come in runs of three consecutive offsets (o - 1, o, o + 1: the fastest lattice direction): the two
+    // rows of the lane need x[r + o - 1 .. r + o + 2] for the whole run -- two 16-byte loads instead of three
+    for (int s = 0; s < D; s += 3) {
+      const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
+      const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
+      const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
+      u_d2 xa, xb;
+      if (xcd & 2) {  // timing probe (bit 21 of mfem_debug_set_ell): no x loads, WRONG results
+        xa = (u_d2){1.0, 1.0};
+        xb = xa;
+      } else {
+        const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
+        xa = xp[0];
+        xb = xp[1];
+      }
+      acc[0].x += va.x != 0.0 ? va.x * xa.x : 0.0;
+      acc[0].y += va.y != 0.0 ? va.y * xa.y : 0.0;
+      acc[0].x += vb.x != 0.0 ? vb.x * xa.y : 0.0;
+      acc[0].y += vb.y != 0.0 ? vb.y * xb.x : 0.0;
+      acc[0].x += vc.x != 0.0 ? vc.x * xb.x : 0.0;
+      acc[0].y += vc.y != 0.0 ? vc.y * xb.y : 0.0;
+      if (off[s + 1] == 0) {  // the main diagonal's run: x[r], x[r + 1] are the lane's own entries (wave-uniform test)
+        xself0 = xa.y;
+        xself1 = xb.x;
+        have_self = true;
+      }
+    }
+  } else if (interior) {
+    int s = 0;
+    for (; s + U <= D; s += U) {
+      e_d2 vv[U][H];
+      u_d2 xx[U][H];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          vv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + u) * ELL_B) + h);
+          xx[u][h] = *(reinterpret_cast<const u_d2*>(x + r + off[s + u]) + h);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          // a zero slot stands for "no entry": it must not pick up a non-finite x from a position the CSR row never reads
+          acc[h].x += vv[u][h].x != 0.0 ? vv[u][h].x * xx[u][h].x : 0.0;
+          acc[h].y += vv[u][h].y != 0.0 ? vv[u][h].y * xx[u][h].y : 0.0;
+        }
+    }
+    for (; s < D; ++s)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
+        const u_d2 xx = *(reinterpret_cast<const u_d2*>(x + r + off[s]) + h);
+        acc[h].x += vv.x != 0.0 ? vv.x * xx.x : 0.0;
+        acc[h].y += vv.y != 0.0 ? vv.y * xx.y : 0.0;
+      }
+  } else {  // generic block (boundary rows, ghost columns): explicit columns, compact slots
+    const int32_t* c = cols + ell_base(r, K);
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        if (r + 2 * h >= npad) continue;
+        const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
+        const e_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + s * ELL_B) + h);
+        acc[h].x += vv.x * x[cc.x];
+        acc[h].y += vv.y * x[cc.y];
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int64_t rr = r + 2 * h;
+    if (rr >= n) break;
+    double y0 = alpha * acc[h].x, y1 = alpha * acc[h].y;
+    const bool two = rr + 1 < n;
+    if (beta != 0.0) {
+      y0 += beta * y[rr];
+      if (two) y1 += beta * y[rr + 1];
+    }
+    y[rr] = y0;
+    if (two) y[rr + 1] = y1;
+    if (dotw) {
+      if (RPT == 2 && have_self && dotw == x) {  // p.Ap of CG: p[r], p[r + 1] are already in registers
+        dot_acc += y0 * xself0;
+        if (two) dot_acc += y1 * xself1;
+      } else {
+        dot_acc += y0 * dotw[rr];
+        if (two) dot_acc += y1 * dotw[rr + 1];
+      }
+    }
+  }
+}
+
 template <int RPT, int U, bool TRIPLES = false>
 __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
                                                            const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
@@ -341,7 +456,6 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
   if (done_flag && done_flag[0]) return;
   const DiaOffsets& O = *Op;
   double dot_acc = 0.0;
-  constexpr int H = RPT / 2;  // 16-byte pairs per lane
   // xcd > 0: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch); XCD x walks its own contiguous eighth of
   // the rows, so the x window an L2 has to hold is an eighth of the vector instead of all of it
   const int64_t rows_per_wg = (int64_t)blockDim.x * RPT;
@@ -362,110 +476,7 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
     }
     const int64_t r = ch * rows_per_wg + (int64_t)threadIdx.x * RPT;
     if (r >= n) continue;
-    const double* v = vals + ell_base(r, K);
-    e_d2 acc[H];
-    double xself0 = 0.0, xself1 = 0.0;  // x[r], x[r + 1] when the kernel has loaded them anyway (fused w.y with w == x, as in CG)
-    bool have_self = false;
-#pragma unroll
-    for (int h = 0; h < H; ++h) acc[h] = (e_d2){0.0, 0.0};
-    // the wave's rows [b0, b0 + 64 RPT) are RPT / 2 aligned 128-row blocks: regular only if all of them are (wave-uniform)
-    const int64_t blk = r / (64 * RPT) * (RPT / 2);
-    const int cls = __builtin_amdgcn_readfirstlane(flags[blk]) - 1;  // wave-uniform: keeps the offset reads scalar
-    bool interior = cls >= 0;
-    if (RPT == 4) interior = interior && ((blk + 1) * 128 < npad) && flags[blk + 1] == cls + 1;
-    const int32_t* off = O.off[cls < 0 ? 0 : cls];
-    const int D = O.D[cls < 0 ? 0 : cls];
-    if (interior && TRIPLES && RPT == 2) {
-      // the diagonals come in runs of three consecutive offsets (o - 1, o, o + 1: the fastest lattice direction): the two
-      // rows of the lane need x[r + o - 1 .. r + o + 2] for the whole run -- two 16-byte loads instead of three
-      for (int s = 0; s < D; s += 3) {
-        const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
-        const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
-        const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
-        u_d2 xa, xb;
-        if (xcd & 2) {  // timing probe (bit 21 of mfem_debug_set_ell): no x loads, WRONG results
-          xa = (u_d2){1.0, 1.0};
-          xb = xa;
-        } else {
-          const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
-          xa = xp[0];
-          xb = xp[1];
-        }
-        acc[0].x += va.x != 0.0 ? va.x * xa.x : 0.0;
-        acc[0].y += va.y != 0.0 ? va.y * xa.y : 0.0;
-        acc[0].x += vb.x != 0.0 ? vb.x * xa.y : 0.0;
-        acc[0].y += vb.y != 0.0 ? vb.y * xb.x : 0.0;
-        acc[0].x += vc.x != 0.0 ? vc.x * xb.x : 0.0;
-        acc[0].y += vc.y != 0.0 ? vc.y * xb.y : 0.0;
-        if (off[s + 1] == 0) {  // the main diagonal's run: x[r], x[r + 1] are the lane's own entries (wave-uniform test)
-          xself0 = xa.y;
-          xself1 = xb.x;
-          have_self = true;
-        }
-      }
-    } else if (interior) {
-      int s = 0;
-      for (; s + U <= D; s += U) {
-        e_d2 vv[U][H];
-        u_d2 xx[U][H];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int h = 0; h < H; ++h) {
-            vv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + u) * ELL_B) + h);
-            xx[u][h] = *(reinterpret_cast<const u_d2*>(x + r + off[s + u]) + h);
-          }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int h = 0; h < H; ++h) {
-            // a zero slot stands for "no entry": it must not pick up a non-finite x from a position the CSR row never reads
-            acc[h].x += vv[u][h].x != 0.0 ? vv[u][h].x * xx[u][h].x : 0.0;
-            acc[h].y += vv[u][h].y != 0.0 ? vv[u][h].y * xx[u][h].y : 0.0;
-          }
-      }
-      for (; s < D; ++s)
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
-          const u_d2 xx = *(reinterpret_cast<const u_d2*>(x + r + off[s]) + h);
-          acc[h].x += vv.x != 0.0 ? vv.x * xx.x : 0.0;
-          acc[h].y += vv.y != 0.0 ? vv.y * xx.y : 0.0;
-        }
-    } else {  // generic block (boundary rows, ghost columns): explicit columns, compact slots
-      const int32_t* c = cols + ell_base(r, K);
-      for (int s = 0; s < K; ++s)
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          if (r + 2 * h >= npad) continue;
-          const e_d2 vv = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B) + h);
-          const e_i2 cc = __builtin_nontemporal_load(reinterpret_cast<const e_i2*>(c + s * ELL_B) + h);
-          acc[h].x += vv.x * x[cc.x];
-          acc[h].y += vv.y * x[cc.y];
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int64_t rr = r + 2 * h;
-      if (rr >= n) break;
-      double y0 = alpha * acc[h].x, y1 = alpha * acc[h].y;
-      const bool two = rr + 1 < n;
-      if (beta != 0.0) {
-        y0 += beta * y[rr];
-        if (two) y1 += beta * y[rr + 1];
-      }
-      y[rr] = y0;
-      if (two) y[rr + 1] = y1;
-      if (dotw) {
-        if (RPT == 2 && have_self && dotw == x) {  // p.Ap of CG: p[r], p[r + 1] are already in registers
-          dot_acc += y0 * xself0;
-          if (two) dot_acc += y1 * xself1;
-        } else {
-          dot_acc += y0 * dotw[rr];
-          if (two) dot_acc += y1 * dotw[rr + 1];
-        }
-      }
-    }
+    dia_rows<RPT, U, TRIPLES>(r, n, npad, K, O, flags, cols, vals, x, y, alpha, beta, dotw, xcd, dot_acc);
   }
   if (partials) {
     const double b = block_reduce_sum(dot_acc, red);
@@ -482,23 +493,41 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
 // diagonal-slotted kernel: the result is bitwise the same whenever the matrix is bitwise symmetric (checked at bind time).
 // ---------------------------------------------------------------------------------------------------------------
 #define SYM_ROWS 512
-__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sym27(int64_t n, int K, const DiaOffsets* __restrict__ Op,
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sym27(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
+                                                             const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
                                                              const double* __restrict__ vals, const double* __restrict__ x,
                                                              double* __restrict__ y, double alpha, double beta,
                                                              const double* __restrict__ dotw, double* __restrict__ partials,
-                                                             const int32_t* __restrict__ done_flag, int64_t c0, int64_t c1, int S, int nsteps, int cls) {
+                                                             const int32_t* __restrict__ done_flag, int64_t c0, int64_t c1, int S, int nsteps, int cls, int gs) {
   __shared__ __attribute__((aligned(16))) double hist[9][SYM_ROWS];  // diagonals 18..26 (into the next plane) of the previous chunk
   __shared__ __attribute__((aligned(16))) double exch[4][SYM_ROWS];  // diagonals 14..17 (+z, +y) of this chunk
   __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   const int32_t* off = Op->off[cls];
-  // gridDim.x workgroups over S tiles: tile t is swept by nseg (+ 1 for the first gridDim.x % S tiles) workgroups, each
-  // taking a contiguous range of the tile's nsteps plane steps
-  const int tile = blockIdx.x % S, seg = blockIdx.x / S;
-  const int nseg = gridDim.x / S + (tile < (int)(gridDim.x % S) ? 1 : 0);
-  const int seg_len = (nsteps + nseg - 1) / nseg;
   const int tid = threadIdx.x;
   double dot_acc = 0.0;
+  if ((int)blockIdx.x >= gs) {
+    // the workgroups behind the sweeps take the chunks outside the regular range (first / last lattice planes, ghost planes of
+    // a slab) through the plain per-row code; dispatching them first instead delays the equally long sweeps (0.954 vs 0.928 ms
+    // per CG iteration at 256^3)
+    const int64_t nchunks = (n + SYM_ROWS - 1) / SYM_ROWS;
+    for (int64_t q = (int64_t)blockIdx.x - gs; ; q += (int64_t)gridDim.x - gs) {
+      const int64_t ch = q < c0 ? q : c1 + (q - c0);
+      if (ch >= nchunks) break;
+      const int64_t r = ch * SYM_ROWS + 2 * tid;
+      if (r < n) dia_rows<2, 3, true>(r, n, npad, K, *Op, flags, cols, vals, x, y, alpha, beta, dotw, 0, dot_acc);
+    }
+    if (partials) {
+      const double b = block_reduce_sum(dot_acc, red);
+      if (threadIdx.x == 0) partials[blockIdx.x] = b;
+    }
+    return;
+  }
+  // gs workgroups over S tiles: tile t is swept by nseg (+ 1 for the first gs % S tiles) workgroups, each taking a contiguous
+  // range of the tile's nsteps plane steps
+  const int tile = blockIdx.x % S, seg = blockIdx.x / S;
+  const int nseg = gs / S + (tile < gs % S ? 1 : 0);
+  const int seg_len = (nsteps + nseg - 1) / nseg;
   bool have_hist = false;
   for (int it = 0; it < seg_len; ++it) {
     const int step = seg * seg_len + it;
@@ -939,11 +968,9 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
           int64_t g1l = A->sym_c0 + (nchunks - A->sym_c1);  // one workgroup per chunk outside the regular range
           if (g1l + gs > MFEM_MAX_PARTIALS) g1l = MFEM_MAX_PARTIALS - gs;
           const int g1 = (int)(g1l < 1 ? 1 : g1l);
-          hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(g1), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, 4,
-                             A->sym_c0 * SYM_ROWS, A->sym_c1 * SYM_ROWS);
-          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_K, O, A->ell_vals, x, y, alpha,
-                             beta, dotw, partials ? partials + g1 : nullptr, done_flag, A->sym_c0, A->sym_c1, A->sym_S, (int)nsteps, A->sym_cls);
+          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs + g1), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
+                             A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, A->sym_c0, A->sym_c1, A->sym_S,
+                             (int)nsteps, A->sym_cls, gs);
           MFEM_CHECK_LAUNCH();
           if (n_partials && partials) *n_partials = g1 + gs;
           return 1;

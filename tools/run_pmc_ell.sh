@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_ell_$c -o out --output-format csv -- python3 $R/tools/pmc_ell.py > $R/gpurun_out/pmc_ell_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_ell_$c -o out --output-format csv -- python3 $R/tools/pmc_sym.py > $R/gpurun_out/pmc_ell_$c.log 2>&1
 done
 python3 - <<PY
 import csv, collections, json
