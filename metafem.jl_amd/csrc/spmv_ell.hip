@@ -750,7 +750,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
         if (lc >= 0) {
           const bool lattice = true;
           const int64_t Sc = (PL + SYM_ROWS / 2) / SYM_ROWS, delta = PL - Sc * SYM_ROWS;
-          if (lattice && Sc >= 8 && delta >= -64 && delta <= 64 && m2 + 2 < SYM_ROWS) {
+          if (lattice && Sc >= 8 && delta >= -64 && delta <= 64) {
             std::vector<int32_t> hf((size_t)nblk);
             MFEM_CHECK_HIP(hipMemcpy(hf.data(), A->dia_flags, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
             // longest run of regular blocks, cut to whole chunks (4 blocks)
@@ -764,14 +764,9 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
               }
             }
             const int64_t c0 = (best_lo + 3) / 4, c1 = best_hi / 4;
+            // entries per chunk that k_spmv_sym27 mirrors instead of loading (same lane pattern in every chunk)
+            int64_t mx = 0, myz = 0;
             if (c1 - c0 >= 4 * Sc) {
-              A->sym_state = 1;
-              A->sym_c0 = c0;
-              A->sym_c1 = c1;
-              A->sym_S = (int)Sc;
-              A->sym_cls = lc;
-              // entries per chunk that k_spmv_sym27 mirrors instead of loading (same lane pattern in every chunk)
-              int64_t mx = 0, myz = 0;
               for (int t = 0; t < SYM_ROWS / 2; ++t) {
                 for (int q = 0; q < 9; ++q) {
                   const int64_t lp = 2 * t + Sc * SYM_ROWS + O.off[lc][q];
@@ -783,6 +778,15 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
                 }
                 myz += t > 0 ? 2 : 1;
               }
+            }
+            // worth it when most of the 13 lower diagonals can be mirrored: the 512-row tile has to span about two lattice lines
+            // (hex-8 256^3: 65 %; 512^3, 513-point lines: 31 % and too few tiles in flight -- measured slower than the plain kernel)
+            if (c1 - c0 >= 4 * Sc && 20 * (mx + myz) >= 11 * 13 * SYM_ROWS) {
+              A->sym_state = 1;
+              A->sym_c0 = c0;
+              A->sym_c1 = c1;
+              A->sym_S = (int)Sc;
+              A->sym_cls = lc;
               A->sym_mx = mx;
               A->sym_myz = myz;
             }
