@@ -492,9 +492,11 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
 // previous-plane (lower) diagonals from there instead of from HBM.  Same products, same summation order as the plain
 // diagonal-slotted kernel: the result is bitwise the same whenever the matrix is bitwise symmetric (checked at bind time).
 // ---------------------------------------------------------------------------------------------------------------
-#define SYM_ROWS 512
+#define SYM_ROWS 512                 // rows of a tile = 4 blocks of 128 (768 rows / 384 threads / 2 workgroups per CU mirror more but run at 1.07 instead of 0.93 ms per CG iteration)
+#define SYM_THREADS (SYM_ROWS / 2)
+#define SYM_WG_PER_CU 3              // 53 KB of LDS per workgroup
 #define SYM_LD(p) __builtin_nontemporal_load(p)  // plain loads measured slower: 0.954 vs 0.928 ms per CG iteration at 256^3
-__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sym27(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
+__global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
                                                              const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
                                                              const double* __restrict__ vals, const double* __restrict__ x,
                                                              double* __restrict__ y, double alpha, double beta,
@@ -763,7 +765,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
                 lo = -1;
               }
             }
-            const int64_t c0 = (best_lo + 3) / 4, c1 = best_hi / 4;
+            const int64_t bpc = SYM_ROWS / ELL_B, c0 = (best_lo + bpc - 1) / bpc, c1 = best_hi / bpc;
             // entries per chunk that k_spmv_sym27 mirrors instead of loading (same lane pattern in every chunk)
             int64_t mx = 0, myz = 0;
             if (c1 - c0 >= 4 * Sc) {
@@ -807,7 +809,7 @@ static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* n
   // 53 KB of LDS per workgroup: three per CU; equal segments for every tile and all workgroups resident in one round
   // (645 workgroups of 51 steps beat 768 of 43 / 51 at 256^3: the longest segment sets the time)
   const int64_t nsteps = (A->sym_c1 - A->sym_c0 + A->sym_S - 1) / A->sym_S;
-  int nseg = (3 * ctx->num_cus) / A->sym_S;
+  int nseg = (SYM_WG_PER_CU * ctx->num_cus) / A->sym_S;
   if (nseg > nsteps / 8) nseg = (int)(nsteps / 8);  // a segment's first step has no history: keep segments >= 8 steps long
   if (nseg < 1) nseg = 1;
   if (nsteps_out) *nsteps_out = nsteps;
@@ -973,7 +975,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
           int64_t g1l = A->sym_c0 + (nchunks - A->sym_c1);  // one workgroup per chunk outside the regular range
           if (g1l + gs > MFEM_MAX_PARTIALS) g1l = MFEM_MAX_PARTIALS - gs;
           const int g1 = (int)(g1l < 1 ? 1 : g1l);
-          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs + g1), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
+          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs + g1), dim3(SYM_THREADS), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
                              A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, A->sym_c0, A->sym_c1, A->sym_S,
                              (int)nsteps, A->sym_cls, gs);
           MFEM_CHECK_LAUNCH();
