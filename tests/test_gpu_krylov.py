@@ -434,3 +434,33 @@ def test_cg_with_symmetric_sweep_matches_plain_kernel(mf):
     finally:
         _lib.lib.mfem_debug_set_ell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+def test_cg_graph_cache_follows_the_symmetry_of_the_values(mf):
+    """Same buffers, first symmetric then unsymmetric values: the cached CG cycle graph of the sweep kernel must not be replayed
+    on the unsymmetric matrix (the graph key carries the outcome of the per-solve symmetry check)."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick, A, K = _sym_brick(mf)
+    b = mf.FEM_rand(A.n, 13, 0)
+    rp = A.rowptr.cpu().numpy()
+    row = 7 * 4096 + 20 * 64 + 33
+    Kw = K.clone()
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        c0 = _lib.lib.mfem_debug_sym_spmv_count()
+        x1, st1 = mf.iterative_Solve(A, Kw, b, 1e-30, Sv_func=mf.cg_, maxiter=40, max_pass=1, fixed_iterations=True)
+        c1 = _lib.lib.mfem_debug_sym_spmv_count()
+        assert c1 > c0
+        # break the symmetry visibly (BiCGStab-type perturbation is irrelevant here: CG just iterates 40 times)
+        Kw[int(rp[row]) + 20] *= 1.0 + 1e-3
+        x2, st2 = mf.iterative_Solve(A, Kw, b, 1e-30, Sv_func=mf.cg_, maxiter=40, max_pass=1, fixed_iterations=True)
+        assert _lib.lib.mfem_debug_sym_spmv_count() == c1  # plain kernel
+        _lib.lib.mfem_debug_set_ell(1 | (1 << 22))
+        x3, st3 = mf.iterative_Solve(A, Kw, b, 1e-30, Sv_func=mf.cg_, maxiter=40, max_pass=1, fixed_iterations=True)
+        assert float((x2 - x3).abs().max()) <= 1e-12 * float(x3.abs().max())
+        assert float((x2 - x1).abs().max()) > 0.0
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
