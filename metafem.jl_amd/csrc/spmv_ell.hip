@@ -532,6 +532,15 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
   const int nseg = gs / S + (tile < gs % S ? 1 : 0);
   const int seg_len = (nsteps + nseg - 1) / nseg;
   bool have_hist = false;
+  e_d2 up_next[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+  {
+    const int64_t chunk = c0 + tile + (int64_t)S * ((int64_t)seg * seg_len);
+    if (seg * seg_len < nsteps && chunk < c1) {
+      const double* v = vals + ell_base(chunk * SYM_ROWS + 2 * tid, K);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) up_next[u] = SYM_LD(reinterpret_cast<const e_d2*>(v + (14 + u) * ELL_B));
+    }
+  }
   for (int it = 0; it < seg_len; ++it) {
     const int step = seg * seg_len + it;
     const int64_t chunk = c0 + tile + (int64_t)S * step;
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
     e_d2 up[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      up[u] = SYM_LD(reinterpret_cast<const e_d2*>(v + (14 + u) * ELL_B));
+      up[u] = up_next[u];  // requested during the previous chunk (or before the loop)
       *reinterpret_cast<e_d2*>(&exch[u][2 * tid]) = up[u];
     }
     __syncthreads();  // exch complete; also: every wave has finished writing the previous chunk's history
@@ -599,6 +608,11 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
       SYM_RUN(va, vb, up[0], 12);
     }
     SYM_RUN(up[1], up[2], up[3], 15);
+    if (it + 1 < seg_len && step + 1 < nsteps && chunk + S < c1) {  // the next chunk's +z / +y diagonals: their latency hides behind
+      const double* vn = vals + ell_base((chunk + S) * SYM_ROWS + 2 * tid, K);  // the rest of this chunk
+#pragma unroll
+      for (int u = 0; u < 4; ++u) up_next[u] = SYM_LD(reinterpret_cast<const e_d2*>(vn + (14 + u) * ELL_B));
+    }
     __syncthreads();  // every wave is done reading hist and exch
     // ---- the nine diagonals into the next plane: they also go to LDS for the next chunk of the sweep
 #pragma unroll
