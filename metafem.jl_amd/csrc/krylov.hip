@@ -148,8 +148,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init_fin(CgArgs a, const doub
 
 // alpha = rz / p.Ap ; x += alpha p ; r -= alpha Ap ; partials2: [0,G) r.z  [G,2G) r.r   (z = r .* dinv)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, const double* __restrict__ pap_partials,
-                                                            int np, const d2_t* __restrict__ p, const d2_t* __restrict__ Ap,
-                                                            const d2_t* __restrict__ dinv, d2_t* __restrict__ x,
+                                                            int np, const d2_t* __restrict__ Ap,
+                                                            const d2_t* __restrict__ dinv,
                                                             d2_t* __restrict__ r, const double* __restrict__ S,
                                                             const int32_t* __restrict__ flags,
                                                             double* __restrict__ partials2) {
@@ -160,8 +160,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double rz = 0.0, rr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
-    const d2_t pv = p[i], av = Ap[i];
-    x[i] = x[i] + alpha * pv;
+    const d2_t av = Ap[i];  // x += alpha p happens in k_cg_pupdate, which reads p anyway (one vector stream less per iteration)
     const d2_t rv = r[i] - alpha * av;
     r[i] = rv;
     const d2_t z = dinv ? rv * dinv[i] : rv;
@@ -176,13 +175,17 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
   }
 }
 
-// beta = rz_new / rz_old ; p = z + beta p ; workgroup 0 also advances the scalar state / DONE flag.
-__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, const double* __restrict__ partials2, int np,
+// x += alpha p (the alpha of k_cg_update, recomputed from the same partials) ; beta = rz_new / rz_old ; p = z + beta p ;
+// workgroup 0 also advances the scalar state.  x gets this iteration's update even when the iteration turns out to be the last.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, const double* __restrict__ pap_partials, int np1,
+                                                             const double* __restrict__ partials2, int np,
                                                              const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
-                                                             d2_t* __restrict__ p, double* __restrict__ S,
+                                                             d2_t* __restrict__ p, d2_t* __restrict__ x, double* __restrict__ S,
                                                              int32_t* __restrict__ flags) {
   __shared__ double red[4];
   if (flags[F_DONE]) return;
+  const double pap = np1 > 0 ? reduce_partials_bcast(pap_partials, np1, red) : S[S_PAP];
+  const double alpha = S[S_RZ0 + cur] / pap;
   double rz_new, rr;
   if (np > 0) {
     rz_new = reduce_partials_bcast(partials2, np, red);
@@ -194,13 +197,16 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, co
   const double beta = rz_new / S[S_RZ0 + cur];
   const int iter = flags[F_ITER] + 1;
   const bool done = (!a.fixed && sqrt(rr * a.n_inv) <= a.tol) || iter >= a.maxiter;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (!done) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
-      const d2_t rv = r[i];
+      const d2_t rv = r[i], pv = p[i];
+      x[i] = x[i] + alpha * pv;
       const d2_t z = dinv ? rv * dinv[i] : rv;
-      p[i] = z + beta * p[i];
+      p[i] = z + beta * pv;
     }
+  } else {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) x[i] = x[i] + alpha * p[i];
   }
   // bookkeeping last: every workgroup has read flags/S before workgroup 0 can change them only if it
   // reads first -- workgroup 0 reads above, writes here; other workgroups read slots this write does
@@ -291,8 +297,8 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         if (rc) return rc;
         np1 = 0;
       }
-      hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, (const d2_t*)p,
-                         (const d2_t*)Ap, (const d2_t*)dinv, (d2_t*)V.x, (d2_t*)r, S, F, part2);
+      hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1,
+                         (const d2_t*)Ap, (const d2_t*)dinv, (d2_t*)r, S, F, part2);
       MFEM_CHECK_LAUNCH();
       if (ctx->comm) {
         rc = mfem_sum_partials(ctx, part2, G, S + S_TMP0);
@@ -304,8 +310,8 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         if (rc) return rc;
         np2 = 0;
       }
-      hipLaunchKernelGGL(k_cg_pupdate, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part2, np2, (const d2_t*)r,
-                         (const d2_t*)dinv, (d2_t*)p, S, F);
+      hipLaunchKernelGGL(k_cg_pupdate, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, part2, np2, (const d2_t*)r,
+                         (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F);
       hipLaunchKernelGGL(k_cg_advance, dim3(1), dim3(1), 0, ctx->stream, a, S, F);
       MFEM_CHECK_LAUNCH();
       return MFEM_OK;

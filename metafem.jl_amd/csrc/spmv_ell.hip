@@ -451,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
                                                            const double* __restrict__ dotw, double* __restrict__ partials,
-                                                           const int32_t* __restrict__ done_flag, int xcd, int64_t skip_lo, int64_t skip_hi) {
+                                                           const int32_t* __restrict__ done_flag, int xcd) {
   __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   const DiaOffsets& O = *Op;
@@ -467,14 +467,8 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
     chunk_end = ((blockIdx.x & 7) + 1) * per < nchunks ? ((blockIdx.x & 7) + 1) * per : nchunks;
     chunk_step = gridDim.x >> 3;
   }
-  const int64_t skip_c0 = skip_lo / rows_per_wg, skip_c1 = skip_hi / rows_per_wg;  // chunks the symmetric sweep kernel covers
   for (; chunk < chunk_end; chunk += chunk_step) {
-    int64_t ch = chunk;
-    if (xcd & 4) {  // running index over the chunks outside [skip_c0, skip_c1) only
-      if (ch >= skip_c0) ch += skip_c1 - skip_c0;
-      if (ch >= nchunks) break;
-    }
-    const int64_t r = ch * rows_per_wg + (int64_t)threadIdx.x * RPT;
+    const int64_t r = chunk * rows_per_wg + (int64_t)threadIdx.x * RPT;
     if (r >= n) continue;
     dia_rows<RPT, U, TRIPLES>(r, n, npad, K, O, flags, cols, vals, x, y, alpha, beta, dotw, xcd, dot_acc);
   }
@@ -971,7 +965,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
 #define LAUNCH_DIA(RPT, U)                                                                                                \
   hipLaunchKernelGGL((k_spmv_dia<RPT, U>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,          \
-                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd, 0, 0)
+                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd)
     switch (g_dia_variant) {
       case 1: LAUNCH_DIA(2, 2); break;
       case 3: LAUNCH_DIA(2, 9); break;
@@ -998,7 +992,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         }
         if (A->dia_triples && g_dia_variant != 8) {
           hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gdb), dim3(g_dia_block), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd, 0, 0);
+                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd);
         } else {
           LAUNCH_DIA(2, 3);
         }
