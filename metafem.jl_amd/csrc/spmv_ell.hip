@@ -760,7 +760,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
         if (lc >= 0) {
           const bool lattice = true;
           const int64_t Sc = (PL + SYM_ROWS / 2) / SYM_ROWS, delta = PL - Sc * SYM_ROWS;
-          if (lattice && Sc >= 8 && delta >= -64 && delta <= 64) {
+          if (lattice && Sc >= 8 && delta >= -256 && delta <= 256) {  // any drift: the mirrored-fraction rule below decides
             std::vector<int32_t> hf((size_t)nblk);
             MFEM_CHECK_HIP(hipMemcpy(hf.data(), A->dia_flags, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
             // longest run of regular blocks, cut to whole chunks (4 blocks)

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metafem_jl_amd as mf
 from metafem_jl_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+if len(sys.argv) > 2:  # lift the size thresholds of the solver layouts (small meshes)
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
 brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N))
 A = brick.pattern(1)
 K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
