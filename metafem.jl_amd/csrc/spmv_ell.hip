@@ -824,10 +824,10 @@ static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* n
   return A->sym_S * nseg;
 }
 static int64_t g_sym_launches = 0;
-// the sweep kernel needs ~2 workgroups per CU of >= 8 steps each to beat the plain kernel: chunk ranges below this stay on the
+// the sweep kernel needs ~2 workgroups per CU of >= 8 steps each to beat the plain kernel: chunk ranges below ~2700 chunks (1.4 M rows) stay on the
 // plain kernel (mfem_debug_set_layout_min_rows(0, ...) lifts the limit for the parity tests)
 static bool sym27_wanted(const mfem_csr_s* A) {
-  return A->sym_state == 1 && g_dia_sym && A->dia_triples && (g_layout_min_rows_dia == 0 || A->sym_c1 - A->sym_c0 >= 4096);
+  return A->sym_state == 1 && g_dia_sym && A->dia_triples && (g_layout_min_rows_dia == 0 || A->sym_c1 - A->sym_c0 >= 2700);  // measured crossover between 96^3 and 112^3
 }
 extern "C" int64_t mfem_debug_sym_spmv_count(void) { return g_sym_launches; }
 
