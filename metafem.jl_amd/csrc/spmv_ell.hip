@@ -789,9 +789,9 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
                 myz += t > 0 ? 2 : 1;
               }
             }
-            // worth it when most of the 13 lower diagonals can be mirrored: the 512-row tile has to span about two lattice lines
-            // (hex-8 256^3: 65 %; 512^3, 513-point lines: 31 % and too few tiles in flight -- measured slower than the plain kernel)
-            if (c1 - c0 >= 4 * Sc && 20 * (mx + myz) >= 11 * 13 * SYM_ROWS) {
+            // worth it from a quarter of the 13 lower diagonals mirrored (hex-8 256^3: 65 %; 512^3, where a 513-point lattice line is
+            // longer than the tile and only the dj = 0 and -z diagonals qualify: 31 %, CG iteration 8.70 -> 7.91 ms)
+            if (c1 - c0 >= 4 * Sc && 20 * (mx + myz) >= 5 * 13 * SYM_ROWS) {
               A->sym_state = 1;
               A->sym_c0 = c0;
               A->sym_c1 = c1;
@@ -817,7 +817,13 @@ static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* n
   // 53 KB of LDS per workgroup: three per CU; equal segments for every tile and all workgroups resident in one round
   // (645 workgroups of 51 steps beat 768 of 43 / 51 at 256^3: the longest segment sets the time)
   const int64_t nsteps = (A->sym_c1 - A->sym_c0 + A->sym_S - 1) / A->sym_S;
-  int nseg = (SYM_WG_PER_CU * ctx->num_cus) / A->sym_S;
+  const int resident = SYM_WG_PER_CU * ctx->num_cus;
+  int nseg = resident / A->sym_S;
+  if (nseg < 1) nseg = 1;
+  // tiles that cannot fill the resident slots in whole rounds (512^3: 514 tiles on 768 slots) are cut into ~2.7 rounds of shorter
+  // segments instead: 8.92 -> 7.91 ms per CG iteration there; at 256^3 (645 of 768) more segments change nothing
+  if ((int64_t)A->sym_S * nseg * 10 < (int64_t)resident * 8) nseg = (8 * ctx->num_cus + A->sym_S - 1) / A->sym_S;
+  while (nseg > 1 && (int64_t)A->sym_S * nseg > 3072) --nseg;  // partial sums: gs + boundary workgroups <= MFEM_MAX_PARTIALS
   if (nseg > nsteps / 8) nseg = (int)(nsteps / 8);  // a segment's first step has no history: keep segments >= 8 steps long
   if (nseg < 1) nseg = 1;
   if (nsteps_out) *nsteps_out = nsteps;
