@@ -503,23 +503,6 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
   const int32_t* off = Op->off[cls];
   const int tid = threadIdx.x;
   double dot_acc = 0.0;
-  if ((int)blockIdx.x >= gs) {
-    // the workgroups behind the sweeps take the chunks outside the regular range (first / last lattice planes, ghost planes of
-    // a slab) through the plain per-row code; dispatching them first instead delays the equally long sweeps (0.954 vs 0.928 ms
-    // per CG iteration at 256^3)
-    const int64_t nchunks = (n + SYM_ROWS - 1) / SYM_ROWS;
-    for (int64_t q = (int64_t)blockIdx.x - gs; ; q += (int64_t)gridDim.x - gs) {
-      const int64_t ch = q < c0 ? q : c1 + (q - c0);
-      if (ch >= nchunks) break;
-      const int64_t r = ch * SYM_ROWS + 2 * tid;
-      if (r < n) dia_rows<2, 3, true>(r, n, npad, K, *Op, flags, cols, vals, x, y, alpha, beta, dotw, 0, dot_acc);
-    }
-    if (partials) {
-      const double b = block_reduce_sum(dot_acc, red);
-      if (threadIdx.x == 0) partials[blockIdx.x] = b;
-    }
-    return;
-  }
   // gs workgroups over S tiles: tile t is swept by nseg (+ 1 for the first gs % S tiles) workgroups, each taking a contiguous
   // range of the tile's nsteps plane steps
   const int tile = blockIdx.x % S, seg = blockIdx.x / S;
@@ -631,6 +614,17 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
     if (dotw) {
       if (dotw == x) dot_acc += y0 * xself0 + y1 * xself1;
       else dot_acc += y0 * dotw[r] + y1 * dotw[r + 1];
+    }
+  }
+  // after its sweep every workgroup takes a share of the chunks outside the regular range (first / last lattice planes, ghost
+  // planes of a slab) through the plain per-row code: no extra workgroups, no tail behind the sweeps
+  {
+    const int64_t nchunks = (n + SYM_ROWS - 1) / SYM_ROWS;
+    for (int64_t q = blockIdx.x;; q += gridDim.x) {
+      const int64_t ch = q < c0 ? q : c1 + (q - c0);
+      if (ch >= nchunks) break;
+      const int64_t r = ch * SYM_ROWS + 2 * tid;
+      if (r < n) dia_rows<2, 3, true>(r, n, npad, K, *Op, flags, cols, vals, x, y, alpha, beta, dotw, 0, dot_acc);
     }
   }
   if (partials) {
@@ -759,8 +753,8 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
         }
         if (lc >= 0) {
           const bool lattice = true;
-          const int64_t Sc = (PL + SYM_ROWS / 2) / SYM_ROWS, delta = PL - Sc * SYM_ROWS;
-          if (lattice && Sc >= 8 && delta >= -256 && delta <= 256) {  // any drift: the mirrored-fraction rule below decides
+          const int64_t Sc = (PL + SYM_ROWS / 2) / SYM_ROWS;  // chunks per plane, rounded: the tiles drift by PL - Sc * 512 rows per plane
+          if (lattice && Sc >= 8 && Sc <= MFEM_MAX_PARTIALS / 2) {  // any drift between tile and plane: the mirrored-fraction rule below decides
             std::vector<int32_t> hf((size_t)nblk);
             MFEM_CHECK_HIP(hipMemcpy(hf.data(), A->dia_flags, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
             // longest run of regular blocks, cut to whole chunks (4 blocks)
@@ -823,7 +817,7 @@ static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* n
   // tiles that cannot fill the resident slots in whole rounds (512^3: 514 tiles on 768 slots) are cut into ~2.7 rounds of shorter
   // segments instead: 8.92 -> 7.91 ms per CG iteration there; at 256^3 (645 of 768) more segments change nothing
   if ((int64_t)A->sym_S * nseg * 10 < (int64_t)resident * 8) nseg = (8 * ctx->num_cus + A->sym_S - 1) / A->sym_S;
-  while (nseg > 1 && (int64_t)A->sym_S * nseg > 3072) --nseg;  // partial sums: gs + boundary workgroups <= MFEM_MAX_PARTIALS
+  while (nseg > 1 && (int64_t)A->sym_S * nseg > MFEM_MAX_PARTIALS) --nseg;  // one partial sum per workgroup
   if (nseg > nsteps / 8) nseg = (int)(nsteps / 8);  // a segment's first step has no history: keep segments >= 8 steps long
   if (nseg < 1) nseg = 1;
   if (nsteps_out) *nsteps_out = nsteps;
@@ -985,15 +979,11 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
           int64_t nsteps = 0;
           const int gs = sym27_grid(ctx, A, &nsteps);
           ++g_sym_launches;
-          const int64_t nchunks = (A->n + SYM_ROWS - 1) / SYM_ROWS;
-          int64_t g1l = A->sym_c0 + (nchunks - A->sym_c1);  // one workgroup per chunk outside the regular range
-          if (g1l + gs > MFEM_MAX_PARTIALS) g1l = MFEM_MAX_PARTIALS - gs;
-          const int g1 = (int)(g1l < 1 ? 1 : g1l);
-          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs + g1), dim3(SYM_THREADS), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
+          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs), dim3(SYM_THREADS), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
                              A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, A->sym_c0, A->sym_c1, A->sym_S,
                              (int)nsteps, A->sym_cls, gs);
           MFEM_CHECK_LAUNCH();
-          if (n_partials && partials) *n_partials = g1 + gs;
+          if (n_partials && partials) *n_partials = gs;
           return 1;
         }
         if (A->dia_triples && g_dia_variant != 8) {
