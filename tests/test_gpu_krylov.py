@@ -464,3 +464,35 @@ def test_cg_graph_cache_follows_the_symmetry_of_the_values(mf):
     finally:
         _lib.lib.mfem_debug_set_ell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("n", [(20, 64, 64), (24, 70, 58), (12, 95, 47)])
+def test_symmetric_sweep_with_drifting_tiles(mf, n):
+    """Lattice planes that are not a whole number of 512-row tiles (4225 = 8.25 tiles, ...): the tiles drift against the plane from
+    step to step and the mirror lookups have to follow; also lattice lines of 48 .. 96 points.  y must equal the plain kernel's."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick = mf.make_Brick((1.0, 2.0, 1.5), n)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x2D)
+    x = mf.FEM_rand(A.n, 5, 0) - 0.5
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        ent, sym = C.c_int64(), C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout_entries(brick.ctx._h, A._h, C.byref(ent), C.byref(sym)))
+        assert sym.value == 1
+        ys = []
+        for knob in (1 << 22, 0):
+            _lib.lib.mfem_debug_set_ell(1 | knob)
+            before = _lib.lib.mfem_debug_sym_spmv_count()
+            y = torch.full((A.n,), -2.0, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+            assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob == 0)
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
