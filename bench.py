@@ -67,6 +67,31 @@ def cpu_baseline(n_cpu: int, iters: int):
     }
 
 
+def self_launch(n_ranks: int) -> int:
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +102,11 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=192, help="elements per side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=400)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as child processes and BEFORE anything here touches
+        # the GPU; rank 0's JSON line is the only thing that reaches stdout; a failing rank fails the run
+        sys.exit(self_launch(args.gpus))
 
     import ctypes as C
 
@@ -89,14 +119,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # functional check of the N > 1 path on a 1-GPU box: all ranks on cuda:0, host-callback communicator over gloo
+    # (never a measurement: the ranks share the GPU)
+    host_comm = os.environ.get("MFEM_BENCH_HOST_COMM") == "1"
+    if host_comm:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # type: ignore
 
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if host_comm:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     ctx = mf.Context(local_rank)
     N = args.n
@@ -114,7 +151,7 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            comm = parallel.SlabComm(ctx, brick, rank, world, n_fields=1)  # noqa: F841 (kept alive for the run)
+            comm = (parallel.HostSlabComm if host_comm else parallel.SlabComm)(ctx, brick, rank, world, n_fields=1)  # noqa: F841 (kept alive for the run)
             C.CDLL(None).fflush(None)
         finally:
             os.dup2(saved, 1)
@@ -162,7 +199,7 @@ def main():
     _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
     _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 0))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_comm else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

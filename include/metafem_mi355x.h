@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MFEM_ABI_VERSION 2
+#define MFEM_ABI_VERSION 3
 
 typedef enum {
   MFEM_OK = 0,
@@ -109,8 +109,6 @@ int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, co
 /* ---- tuning / diagnostic hooks (benchmarks, profiling and tests only; process-wide) -------------------------------- */
 /* CSR tile kernel: tiles per XCD run (0 = dispatcher round-robin) | variant << 16, persistent workgroups per CU. */
 int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
-/* x-window variant of the CSR kernel (x window in LDS + 16-bit local indices; off by default): enable, tile size, grid. */
-int mfem_debug_set_spmv_window(int enable, int cap, int grid_mult);
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
  * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results); bit 22 symmetric sweep kernel off;
  * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
@@ -127,6 +125,9 @@ int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_colu
 int mfem_debug_set_graphs(int on, int64_t max_n);
 /* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
 int mfem_debug_set_vec_grid(int workgroups_per_cu);
+/* Multi-rank SpMV: 1 (default) the halo exchange runs on a second stream beside the rows that read no ghost column and the
+ * boundary rows follow in a second launch; 0 the exchange completes before a single launch (same results bitwise). */
+int mfem_debug_set_halo_overlap(int on);
 /* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
  * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
  * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
@@ -178,7 +179,11 @@ typedef struct {
                                the Krylov body; here the rows of the working matrix and b are scaled once, which is the
                                same operator.  The restart wrapper follows :57-60 (true residual un-scaled, tol_factor).
                                Not valid with MFEM_SOLVER_CG (it would break symmetry). */
-  int32_t reserved;
+  int32_t cg_variant;       /* MFEM_SOLVER_CG only.  1: classic PCG recurrence (two dependent reduction groups per iteration:
+                               p.Ap, then r.z and r.r).  2: single-reduction form (Chronopoulos-Gear: s = A p carried by
+                               recurrence, so r.u, w.u and r.r are reduced together right after the SpMV -- one all-reduce per
+                               iteration on several GPUs; same iterates in exact arithmetic, round-off-level differences).
+                               0 = auto: 2 when a communicator with more than one rank is attached, else 1. */
 } mfem_solve_options;
 
 typedef struct {
@@ -236,6 +241,10 @@ const int64_t* mfem_csr_rowptr64(mfem_csr A);
 const int32_t* mfem_csr_colidx(mfem_csr A);
 int64_t mfem_csr_nnz(mfem_csr A);
 int64_t mfem_csr_n(mfem_csr A);
+/* Number of columns = length of the x (and of a per-column vector such as the Jacobi d) this pattern addresses: n for a
+ * square pattern; n + ghost entries for a slab pattern (mfem_brick_set_slab), whose ghost columns are numbered behind the
+ * owned ones.  mfem_jacobi2_by_column zeroes and fills that many entries of d; mfem_mat_div_jacobi reads them. */
+int64_t mfem_csr_ncols(mfem_csr A);
 
 /* ---- S2 fused assembly closures (constant-coefficient fast paths) ------------------------ */
 /* Faces of the brick in the reference's local face numbering (ref_geometry/002_Initialization.jl:8;
@@ -356,6 +365,26 @@ int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, const double* i
  * (torch.distributed / MPI / a file).  */
 int mfem_comm_unique_id(void* out128 /* [host] */);
 int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out);
+/* The same communicator behind host callbacks instead of RCCL: the library stages device data through pinned host memory
+ * and calls back for the actual exchange (gloo, MPI, ... -- whatever the host has).  Every solver code path is identical to
+ * the RCCL one (same kernels, same schedule: halo begin / interior rows / halo end / boundary rows, same reduction groups);
+ * only the transport differs.  For ranks that share one GPU (RCCL rejects duplicate devices: this is how the multi-rank
+ * path is tested on a single-GPU box) and for hosts without GPU-aware MPI.  Callbacks return 0 on success and are called on
+ * the thread that called into the library, with the context stream idle. */
+typedef struct {
+  void* user;
+  /* in-place sum over all ranks of `count` doubles in host memory */
+  int (*allreduce_sum)(void* user, double* buf, int32_t count);
+  /* one exchange with both slab neighbours: send_lo -> rank - 1, recv_lo <- rank - 1, send_hi -> rank + 1, recv_hi <- rank + 1,
+   * `count` doubles each; the pointers of a missing neighbour (first / last rank) are NULL.  Must not deadlock when all ranks
+   * call it at the same time (post the receives and sends, then wait). */
+  int (*neighbour_exchange)(void* user, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
+                            int64_t count);
+  uint32_t flags; /* MFEM_COMM_HOST_* */
+  uint32_t reserved;
+} mfem_comm_host_ops;
+#define MFEM_COMM_HOST_POISON_GHOSTS 1u /* test aid: ghost entries are NaN between halo begin and end */
+int mfem_comm_create_host(mfem_context ctx, int32_t rank, int32_t world, const mfem_comm_host_ops* ops, mfem_comm* out);
 int mfem_comm_destroy(mfem_comm c);
 /* Attach to a context (c = NULL detaches): subsequent mfem_solve calls on slab matrices all-reduce their
  * scalars over the communicator and, before each SpMV, exchange one ghost block of `plane_len` doubles per
@@ -365,6 +394,10 @@ int mfem_comm_destroy(mfem_comm c);
 int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_owned_nodes, int64_t plane_len, int32_t n_fields);
 int mfem_allreduce_sum(mfem_context ctx, double* dev_scalars, int32_t count);
 int mfem_halo_exchange(mfem_context ctx, double* x_local);
+/* Reverse exchange: the ghost blocks of x_local (contributions this rank accumulated for entries its neighbours own) are
+ * sent to the owners and ADDED to their first / last plane_len owned entries per field.  With it a column sum over a slab
+ * matrix (mfem_jacobi2_by_column on [owned | ghost] columns) becomes the global column sum. */
+int mfem_halo_reduce(mfem_context ctx, double* x_local);
 
 #ifdef __cplusplus
 }

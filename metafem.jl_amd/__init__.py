@@ -120,6 +120,11 @@ class FEM_SpMat_CSR:
         self.nnz = int(lib.mfem_csr_nnz(self._h))
         self.index_base = index_base
 
+    @property
+    def ncols(self) -> int:
+        """Columns the pattern addresses = length of x and of a per-column vector (n + ghost entries for a slab pattern)."""
+        return int(lib.mfem_csr_ncols(self._h))
+
     def close(self):
         if self._h:
             lib.mfem_csr_destroy(self._h)
@@ -180,13 +185,16 @@ def FEM_rand(n: int, seed: int = 0x5EED, stream_id: int = 0, ctx: Optional[Conte
 
 
 def jacobi_by_diagonal(A: FEM_SpMat_CSR, vals: torch.Tensor) -> torch.Tensor:
-    d = torch.ones(A.n, dtype=torch.float64, device=vals.device)
+    """d has A.ncols entries (owned | ghost columns of a slab pattern, the ghost part left at 1: fill it with halo_)."""
+    d = torch.ones(A.ncols, dtype=torch.float64, device=vals.device)
     check(lib.mfem_jacobi_by_diagonal(A.ctx._h, A._h, _ptr(vals), _ptr(d)))
     return d
 
 
 def jacobi2_by_column(A: FEM_SpMat_CSR, vals: torch.Tensor) -> torch.Tensor:
-    d = torch.zeros(A.n, dtype=torch.float64, device=vals.device)
+    """Column 2-norms, A.ncols entries.  On a slab pattern with a communicator attached the ghost-column contributions go to
+    their owners (mfem_halo_reduce) and the ghost entries come back as the owners' values: the GLOBAL column norms."""
+    d = torch.zeros(A.ncols, dtype=torch.float64, device=vals.device)
     check(lib.mfem_jacobi2_by_column(A.ctx._h, A._h, _ptr(vals), _ptr(d)))
     return d
 
@@ -206,10 +214,11 @@ def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tenso
                     Sv_func: int = idrs_, Pr_func: int = Pr_Jacobi_, Pl_func: int = Identity, max_pass: int = 4,
                     maxiter: int = 2000,
                     s: int = 0, seed: int = 0x5EED, check_every: int = 32, fixed_iterations: bool = False,
-                    scale_in_place: bool = False, shadow: Optional[torch.Tensor] = None
+                    scale_in_place: bool = False, shadow: Optional[torch.Tensor] = None, cg_variant: int = 0
                     ) -> Tuple[torch.Tensor, SolveStats]:
     """iterative_Solve!(globalfield; Sv_func!, Pr_func!, Pl_func, max_pass, maxiter, s) (02_Preconditioner.jl:32-76).
     Pl_func: Identity, Pl_Jacobi_ (:155-168) or Pl_Jacobi_rownorm_ (normalized_by_row = true).
+    cg_variant (cg_ only): 0 auto, 1 classic recurrence, 2 single reduction group per iteration (Chronopoulos-Gear).
 
     Returns (delta_x, stats); delta_x is a NEW device vector like the reference's return value.
     """
@@ -219,7 +228,7 @@ def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tenso
     o = SolveOptions(method=Sv_func, precond=Pr_func, l_or_s=s, maxiter=maxiter, max_pass=max_pass,
                      check_every=check_every, converge_tol=converge_tol, seed=seed,
                      fixed_iterations=1 if fixed_iterations else 0, scale_in_place=1 if scale_in_place else 0,
-                     left_precond=Pl_func)
+                     left_precond=Pl_func, cg_variant=cg_variant)
     st = SolveStats()
     if shadow is not None:
         _need(shadow, torch.float64, "shadow")

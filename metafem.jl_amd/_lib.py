@@ -37,7 +37,7 @@ class SolveOptions(C.Structure):
     _fields_ = [("method", c_int32), ("precond", c_int32), ("l_or_s", c_int32), ("maxiter", c_int32),
                 ("max_pass", c_int32), ("check_every", c_int32), ("converge_tol", c_double), ("seed", c_uint64),
                 ("fixed_iterations", c_int32), ("scale_in_place", c_int32), ("left_precond", c_int32),
-                ("reserved", c_int32)]
+                ("cg_variant", c_int32)]
 
 
 class SolveStats(C.Structure):
@@ -69,6 +69,18 @@ class VarBatchTerm(C.Structure):
 MAX_BATCH_TERMS = 48
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(c_int, c_void_p, C.POINTER(c_double), c_int32)
+EXCHANGE_CB = C.CFUNCTYPE(c_int, c_void_p, C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_double), c_int64)
+
+
+class CommHostOps(C.Structure):
+    _fields_ = [("user", c_void_p), ("allreduce_sum", ALLREDUCE_CB), ("neighbour_exchange", EXCHANGE_CB), ("flags", c_uint32),
+                ("reserved", c_uint32)]
+
+
+COMM_HOST_POISON_GHOSTS = 1
+
+
 class OpLayout(C.Structure):
     _fields_ = [("itg", c_int32), ("itp", c_int32), ("n_sd", c_int32), ("n_host", c_int64), ("index_base", c_int32),
                 ("n_colours", c_int32), ("colour_offsets", C.POINTER(c_int64))]
@@ -95,7 +107,6 @@ SIGNATURES = {
     "mfem_jacobi_by_row": (c_int, [P, P, P, P]),
     "mfem_mat_div_jacobi": (c_int, [P, P, P, P]),
     "mfem_debug_set_spmv": (c_int, [c_int, c_int]),
-    "mfem_debug_set_spmv_window": (c_int, [c_int, c_int, c_int]),
     "mfem_debug_set_hex27": (c_int, [c_int]),
     "mfem_prof_spmv_enable": (c_int, [P, c_int]),
     "mfem_prof_spmv_read": (c_int, [P, C.POINTER(c_double), C.POINTER(c_int64), c_int]),
@@ -143,6 +154,10 @@ SIGNATURES = {
     "mfem_context_set_comm": (c_int, [P, P, c_int64, c_int64, c_int32]),
     "mfem_allreduce_sum": (c_int, [P, P, c_int32]),
     "mfem_halo_exchange": (c_int, [P, P]),
+    "mfem_halo_reduce": (c_int, [P, P]),
+    "mfem_comm_create_host": (c_int, [P, c_int32, c_int32, C.POINTER(CommHostOps), C.POINTER(P)]),
+    "mfem_csr_ncols": (c_int64, [P]),
+    "mfem_debug_set_halo_overlap": (c_int, [c_int]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,6 +1,8 @@
 // Context management and error plumbing of the C ABI (include/metafem_mi355x.h).
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -120,6 +122,20 @@ extern "C" int mfem_prof_spmv_read(mfem_context ctx, double* total_ms, int64_t* 
     ctx->prof_count = 0;
   }
   return MFEM_OK;
+}
+
+uint64_t mfem_next_csr_serial() {
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1);
+}
+
+void mfem_graphs_invalidate(mfem_context_s* ctx) {
+  for (int i = 0; i < MFEM_GRAPH_SLOTS; ++i)
+    if (ctx->graph_exec[i]) {
+      hipGraphExecDestroy(ctx->graph_exec[i]);
+      ctx->graph_exec[i] = nullptr;
+      ctx->graph_key[i] = 0;
+    }
 }
 
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {

@@ -3,6 +3,12 @@
 #include "common.h"
 
 int mfem_vec_grid(mfem_context_s* ctx, int64_t n);
+struct FoldList {
+  const double* src[4];
+  int cnt[4];
+  int m;
+};
+int mfem_fold_list(mfem_context_s* ctx, const FoldList& L, double* d_out, const int32_t* done_flag = nullptr);
 int mfem_dot_device(mfem_context_s* ctx, int64_t n, const double* x, const double* y, double* d_out);
 int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
                      double alpha, double beta, const double* dotw, double* partials, int* n_partials,
@@ -11,6 +17,16 @@ int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* va
 int mfem_mat_div_rows(mfem_context_s* ctx, mfem_csr_s* A, double* vals, const double* d);
 int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count);
 int mfem_comm_halo(mfem_context_s* ctx, double* x_local);
+// split form: between begin and end the ghost entries of x must not be read and its boundary planes must not be written
+int mfem_comm_halo_begin(mfem_context_s* ctx, double* x_local);
+int mfem_comm_halo_end(mfem_context_s* ctx);
+int mfem_comm_halo_reduce(mfem_context_s* ctx, double* x_local);
+int mfem_comm_world(const mfem_context_s* ctx);
+int mfem_comm_rank(const mfem_context_s* ctx);
+int64_t mfem_comm_owned_nodes(const mfem_context_s* ctx);
+// SpMV with the halo exchange of x overlapped with the rows that need no ghost entry (spmv.hip)
+int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* x, double* y, double alpha, double beta,
+                   const double* dotw, double* partials, int* n_partials, const int32_t* done_flag = nullptr);
 
 // Every thread of the workgroup returns sum(p[0..np)); deterministic order, identical in all
 // workgroups.  np <= MFEM_MAX_PARTIALS.  smem >= 4 doubles.

@@ -52,6 +52,23 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dot_partials(int64_t n, const do
   if (threadIdx.x == 0) partials[blockIdx.x] = b;
 }
 
+// Single workgroup: out[k] = sum(src[k][0 .. cnt[k])) for k < m -- the local scalars of one reduction group, contiguous for the
+// all-reduce that follows when a communicator is attached
+__global__ __launch_bounds__(MFEM_BLOCK) void k_fold_list(FoldList L, double* __restrict__ out, const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  for (int k = 0; k < L.m; ++k) {
+    const double v = reduce_partials_bcast(L.src[k], L.cnt[k], red);
+    if (threadIdx.x == 0) out[k] = v;
+  }
+}
+
+int mfem_fold_list(mfem_context_s* ctx, const FoldList& L, double* d_out, const int32_t* done_flag) {
+  hipLaunchKernelGGL(k_fold_list, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, L, d_out, done_flag);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
 // Single workgroup: out[0] = sum(partials[0..np))
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sum_partials(const double* __restrict__ partials, int np,
                                                                double* __restrict__ out) {

@@ -209,6 +209,7 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   A->nnz = nnz;
   A->rowptr_bits = 64;
   A->index_base = 0;
+  A->ncols = (b->plo > 0 || b->phi < b->m[0]) ? xlen : n;
   MFEM_CHECK_HIP(hipMalloc(&A->owned_rowptr, sizeof(int64_t) * (n + 1)));
   MFEM_CHECK_HIP(hipMalloc(&A->owned_colidx, sizeof(int32_t) * (nnz > 0 ? nnz : 1)));
   A->rowptr = A->owned_rowptr;

@@ -1,18 +1,36 @@
-// Multi-GPU support (new: the reference is single-GPU): one process per GPU, RCCL over xGMI.
+// Multi-GPU support (new: the reference is single-GPU): one process per GPU.
 //   * slab decomposition along i: a rank owns a contiguous range of node planes, local vectors are
 //     [owned, field-major | ghost planes: (field 0 lo, field 0 hi, field 1 lo, ...)];
-//   * SpMV halo: one node plane per neighbour and field, ncclSend/ncclRecv inside one group on the
-//     context stream (point-to-point over a single xGMI link; planes are contiguous, no packing);
-//   * Krylov scalars: one ncclAllReduce(sum, f64) of <= 8 fused device scalars per reduction group --
-//     the scalars never visit the host.
+//   * SpMV halo: one block of `plane_len` doubles per neighbour and field (planes are contiguous, nothing is packed on the
+//     RCCL path).  The exchange is split into begin / end so that it runs on a second stream beside the SpMV of the rows
+//     that reference no ghost column (krylov_kernels.h: mfem_spmv_halo);
+//   * Krylov scalars: one all-reduce(sum, f64) of <= 8 fused device scalars per reduction group -- the scalars never
+//     visit the host on the RCCL path.
+// Two backends behind the same three operations (all-reduce, neighbour exchange, reverse exchange):
+//   0  RCCL over xGMI: ncclSend/ncclRecv inside one group on the halo stream, ncclAllReduce on the context stream;
+//   1  host-staged: device -> pinned host -> caller-supplied callbacks (gloo / MPI / anything) -> device.  It exists so that
+//      the very same solver code paths can be executed with several ranks where RCCL cannot run (ranks sharing one GPU:
+//      RCCL rejects duplicate devices) and for hosts whose MPI is not GPU-aware; it is not the fast path.
 #include <rccl/rccl.h>
+
+#include <limits>
 
 #include "krylov.h"
 
 struct mfem_comm_s {
+  int backend;
   ncclComm_t comm;
+  mfem_comm_host_ops host;
   int rank, world;
   int64_t n_owned_nodes;
+  int failed;
+  hipStream_t halo_stream;      // RCCL: the exchange runs here, fenced against the context stream by the two events
+  hipEvent_t ev_ready, ev_done;
+  double* h_stage;              // host-staged: pinned [send_lo | send_hi | recv_lo | recv_hi], each h_block doubles
+  size_t h_block;
+  double* d_stage;              // device staging of the reverse exchange [from_lo | from_hi], each d_block doubles
+  size_t d_block;
+  double* pending_x;            // begin() issued for this vector, end() not yet
 };
 
 #define MFEM_CHECK_NCCL(expr)                                                              \
@@ -24,6 +42,27 @@ struct mfem_comm_s {
     }                                                                                      \
   } while (0)
 
+// inside ncclGroupStart / ncclGroupEnd: a failing call must not leave the group open (the next collective on the
+// communicator would hang); the communicator is marked failed and every later operation on it fails fast
+#define MFEM_GROUP_NCCL(c, expr)                                                           \
+  do {                                                                                     \
+    ncclResult_t _r = (expr);                                                              \
+    if (_r != ncclSuccess) {                                                               \
+      mfem_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+      ncclGroupEnd();                                                                      \
+      (c)->failed = 1;                                                                     \
+      return MFEM_ERR_COMM;                                                                \
+    }                                                                                      \
+  } while (0)
+
+#define MFEM_COMM_ALIVE(c)                                                          \
+  do {                                                                              \
+    if ((c)->failed) {                                                              \
+      mfem_set_error("communicator is in a failed state (an earlier operation failed)"); \
+      return MFEM_ERR_COMM;                                                         \
+    }                                                                               \
+  } while (0)
+
 extern "C" int mfem_comm_unique_id(void* out128) {
   MFEM_REQUIRE(out128, "null buffer");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
@@ -33,29 +72,66 @@ extern "C" int mfem_comm_unique_id(void* out128) {
   return MFEM_OK;
 }
 
+static mfem_comm_s* comm_new(int backend, int rank, int world) {
+  mfem_comm_s* c = new mfem_comm_s();
+  memset(c, 0, sizeof(*c));
+  c->backend = backend;
+  c->rank = rank;
+  c->world = world;
+  return c;
+}
+
 extern "C" int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out) {
   MFEM_REQUIRE(ctx && unique_id128 && out, "null argument");
   MFEM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
   MFEM_CHECK_HIP(hipSetDevice(ctx->device));
   ncclUniqueId id;
   memcpy(&id, unique_id128, sizeof(id));
-  mfem_comm_s* c = new mfem_comm_s();
-  c->rank = rank;
-  c->world = world;
-  c->n_owned_nodes = 0;
+  mfem_comm_s* c = comm_new(0, rank, world);
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) {
     mfem_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
     delete c;
     return MFEM_ERR_COMM;
   }
+  // the exchange is a few hundred kilobytes per neighbour: give its stream priority so that its kernels are placed before
+  // the (persistent, chip-filling) SpMV workgroups of the interior rows that become ready at the same moment
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&c->halo_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+    mfem_set_error("could not create the halo stream / events");
+    ncclCommDestroy(c->comm);
+    delete c;
+    return MFEM_ERR_HIP;
+  }
+  *out = c;
+  return MFEM_OK;
+}
+
+extern "C" int mfem_comm_create_host(mfem_context ctx, int32_t rank, int32_t world, const mfem_comm_host_ops* ops,
+                                     mfem_comm* out) {
+  MFEM_REQUIRE(ctx && ops && out, "null argument");
+  MFEM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+  MFEM_REQUIRE(ops->allreduce_sum && ops->neighbour_exchange, "both callbacks are required");
+  mfem_comm_s* c = comm_new(1, rank, world);
+  c->host = *ops;
   *out = c;
   return MFEM_OK;
 }
 
 extern "C" int mfem_comm_destroy(mfem_comm c) {
   if (!c) return MFEM_OK;
-  ncclCommDestroy(c->comm);
+  if (c->backend == 0) {
+    if (c->halo_stream) hipStreamSynchronize(c->halo_stream);
+    ncclCommDestroy(c->comm);
+    if (c->ev_ready) hipEventDestroy(c->ev_ready);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->halo_stream) hipStreamDestroy(c->halo_stream);
+  }
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->d_stage) hipFree(c->d_stage);
   delete c;
   return MFEM_OK;
 }
@@ -77,32 +153,227 @@ extern "C" int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_ow
   return MFEM_OK;
 }
 
-int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count) {
-  if (!ctx->comm) return MFEM_OK;
-  MFEM_CHECK_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, ctx->comm->comm, ctx->stream));
+int mfem_comm_world(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->world : 1; }
+int mfem_comm_rank(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+int64_t mfem_comm_owned_nodes(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->n_owned_nodes : 0; }
+
+static int stage_reserve(mfem_context_s* ctx, mfem_comm_s* c, size_t block_doubles, bool device_too) {
+  if (c->backend == 1 && c->h_block < block_doubles) {
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (c->h_stage) MFEM_CHECK_HIP(hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_block = 0;
+    MFEM_CHECK_HIP(hipHostMalloc(&c->h_stage, sizeof(double) * 4 * block_doubles));
+    c->h_block = block_doubles;
+  }
+  if (device_too && c->d_block < block_doubles) {
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (c->d_stage) MFEM_CHECK_HIP(hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->d_block = 0;
+    MFEM_CHECK_HIP(hipMalloc(&c->d_stage, sizeof(double) * 2 * block_doubles));
+    c->d_block = block_doubles;
+  }
   return MFEM_OK;
 }
 
-// Fill the ghost planes of a local vector from the neighbours' boundary planes.
-int mfem_comm_halo(mfem_context_s* ctx, double* x) {
+int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count) {
+  mfem_comm_s* c = ctx->comm;
+  if (!c || count <= 0) return MFEM_OK;
+  MFEM_COMM_ALIVE(c);
+  if (c->backend == 0) {
+    MFEM_CHECK_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, c->comm, ctx->stream));
+    return MFEM_OK;
+  }
+  // host-staged: the scalars visit the host (one stream sync per reduction group)
+  int rc = stage_reserve(ctx, c, (size_t)(count > 64 ? count : 64), false);
+  if (rc) return rc;
+  MFEM_CHECK_HIP(hipMemcpyAsync(c->h_stage, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (c->world > 1) {
+    const int r = c->host.allreduce_sum(c->host.user, c->h_stage, count);
+    if (r != 0) {
+      mfem_set_error("host all-reduce callback returned %d", r);
+      c->failed = 1;
+      return MFEM_ERR_COMM;
+    }
+  }
+  MFEM_CHECK_HIP(hipMemcpyAsync(dev, c->h_stage, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next operation
+  return MFEM_OK;
+}
+
+__global__ __launch_bounds__(MFEM_BLOCK) void k_fill_nan(int64_t n, double* __restrict__ x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double q = __longlong_as_double(0x7ff8000000000000ll);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) x[i] = q;
+}
+
+__global__ __launch_bounds__(MFEM_BLOCK) void k_add_block(int64_t n, const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+// Start filling the ghost blocks of a local vector from the neighbours' boundary planes.  Until mfem_comm_halo_end the ghost
+// entries of x must not be read and its first / last plane_len owned entries per field must not be written.
+int mfem_comm_halo_begin(mfem_context_s* ctx, double* x) {
   mfem_comm_s* c = ctx->comm;
   if (!c || c->world == 1) return MFEM_OK;
+  MFEM_COMM_ALIVE(c);
+  MFEM_REQUIRE(!c->pending_x, "a halo exchange is already in flight on this communicator");
   const int64_t PL = ctx->halo_plane_len, NO = c->n_owned_nodes;
   const int F = ctx->halo_fields;
   double* ghost = x + (int64_t)F * NO;
-  MFEM_CHECK_NCCL(ncclGroupStart());
+  const bool lo = c->rank > 0, hi = c->rank < c->world - 1;
+  if (c->backend == 0) {
+    MFEM_CHECK_HIP(hipEventRecord(c->ev_ready, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamWaitEvent(c->halo_stream, c->ev_ready, 0));
+    MFEM_CHECK_NCCL(ncclGroupStart());
+    for (int f = 0; f < F; ++f) {
+      double* own = x + (int64_t)f * NO;
+      if (lo) {
+        MFEM_GROUP_NCCL(c, ncclSend(own, (size_t)PL, ncclDouble, c->rank - 1, c->comm, c->halo_stream));
+        MFEM_GROUP_NCCL(c, ncclRecv(ghost + (int64_t)(2 * f + 0) * PL, (size_t)PL, ncclDouble, c->rank - 1, c->comm, c->halo_stream));
+      }
+      if (hi) {
+        MFEM_GROUP_NCCL(c, ncclSend(own + NO - PL, (size_t)PL, ncclDouble, c->rank + 1, c->comm, c->halo_stream));
+        MFEM_GROUP_NCCL(c, ncclRecv(ghost + (int64_t)(2 * f + 1) * PL, (size_t)PL, ncclDouble, c->rank + 1, c->comm, c->halo_stream));
+      }
+    }
+    ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess) {
+      mfem_set_error("ncclGroupEnd (halo): %s", ncclGetErrorString(r));
+      c->failed = 1;
+      return MFEM_ERR_COMM;
+    }
+    MFEM_CHECK_HIP(hipEventRecord(c->ev_done, c->halo_stream));
+    c->pending_x = x;
+    return MFEM_OK;
+  }
+  const size_t blk = (size_t)F * (size_t)PL;
+  int rc = stage_reserve(ctx, c, blk > 64 ? blk : 64, false);
+  if (rc) return rc;
+  double* s_lo = c->h_stage;
+  double* s_hi = c->h_stage + c->h_block;
+  double* r_lo = c->h_stage + 2 * c->h_block;
+  double* r_hi = c->h_stage + 3 * c->h_block;
+  for (int f = 0; f < F; ++f) {
+    const double* own = x + (int64_t)f * NO;
+    if (lo) MFEM_CHECK_HIP(hipMemcpyAsync(s_lo + (size_t)f * PL, own, sizeof(double) * PL, hipMemcpyDeviceToHost, ctx->stream));
+    if (hi) MFEM_CHECK_HIP(hipMemcpyAsync(s_hi + (size_t)f * PL, own + NO - PL, sizeof(double) * PL, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (c->host.flags & MFEM_COMM_HOST_POISON_GHOSTS) {
+    // test aid: between begin and end the ghost entries are NaN, so a kernel that reads them too early is found out
+    hipLaunchKernelGGL(k_fill_nan, dim3(mfem_grid_for(2 * (int64_t)blk, MFEM_BLOCK, 64)), dim3(MFEM_BLOCK), 0, ctx->stream,
+                       2 * (int64_t)blk, ghost);
+    MFEM_CHECK_LAUNCH();
+  }
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  const int r = c->host.neighbour_exchange(c->host.user, lo ? s_lo : nullptr, lo ? r_lo : nullptr, hi ? s_hi : nullptr,
+                                           hi ? r_hi : nullptr, (int64_t)blk);
+  if (r != 0) {
+    mfem_set_error("host neighbour-exchange callback returned %d", r);
+    c->failed = 1;
+    return MFEM_ERR_COMM;
+  }
+  c->pending_x = x;
+  return MFEM_OK;
+}
+
+int mfem_comm_halo_end(mfem_context_s* ctx) {
+  mfem_comm_s* c = ctx->comm;
+  if (!c || c->world == 1 || !c->pending_x) return MFEM_OK;
+  double* x = c->pending_x;
+  c->pending_x = nullptr;
+  if (c->backend == 0) {
+    MFEM_CHECK_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+    return MFEM_OK;
+  }
+  const int64_t PL = ctx->halo_plane_len, NO = c->n_owned_nodes;
+  const int F = ctx->halo_fields;
+  double* ghost = x + (int64_t)F * NO;
+  const bool lo = c->rank > 0, hi = c->rank < c->world - 1;
+  const double* r_lo = c->h_stage + 2 * c->h_block;
+  const double* r_hi = c->h_stage + 3 * c->h_block;
+  for (int f = 0; f < F; ++f) {
+    if (lo)
+      MFEM_CHECK_HIP(hipMemcpyAsync(ghost + (int64_t)(2 * f + 0) * PL, r_lo + (size_t)f * PL, sizeof(double) * PL, hipMemcpyHostToDevice, ctx->stream));
+    if (hi)
+      MFEM_CHECK_HIP(hipMemcpyAsync(ghost + (int64_t)(2 * f + 1) * PL, r_hi + (size_t)f * PL, sizeof(double) * PL, hipMemcpyHostToDevice, ctx->stream));
+  }
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // the pinned staging buffer is reused by the next operation
+  return MFEM_OK;
+}
+
+int mfem_comm_halo(mfem_context_s* ctx, double* x) {
+  int rc = mfem_comm_halo_begin(ctx, x);
+  if (rc) return rc;
+  return mfem_comm_halo_end(ctx);
+}
+
+// Reverse exchange: what this rank accumulated in its ghost blocks (contributions to entries other ranks own) is sent to
+// the owners and ADDED to their first / last plane_len owned entries per field.  Used for column sums of a slab matrix
+// (Jacobi2_By_Colomn): the rows that hit a boundary column live on two ranks.
+int mfem_comm_halo_reduce(mfem_context_s* ctx, double* x) {
+  mfem_comm_s* c = ctx->comm;
+  if (!c || c->world == 1) return MFEM_OK;
+  MFEM_COMM_ALIVE(c);
+  MFEM_REQUIRE(!c->pending_x, "a halo exchange is in flight on this communicator");
+  const int64_t PL = ctx->halo_plane_len, NO = c->n_owned_nodes;
+  const int F = ctx->halo_fields;
+  double* ghost = x + (int64_t)F * NO;
+  const bool lo = c->rank > 0, hi = c->rank < c->world - 1;
+  const size_t blk = (size_t)F * (size_t)PL;
+  int rc = stage_reserve(ctx, c, blk > 64 ? blk : 64, true);
+  if (rc) return rc;
+  double* from_lo = c->d_stage;
+  double* from_hi = c->d_stage + c->d_block;
+  if (c->backend == 0) {
+    MFEM_CHECK_NCCL(ncclGroupStart());
+    for (int f = 0; f < F; ++f) {
+      if (lo) {
+        MFEM_GROUP_NCCL(c, ncclSend(ghost + (int64_t)(2 * f + 0) * PL, (size_t)PL, ncclDouble, c->rank - 1, c->comm, ctx->stream));
+        MFEM_GROUP_NCCL(c, ncclRecv(from_lo + (size_t)f * PL, (size_t)PL, ncclDouble, c->rank - 1, c->comm, ctx->stream));
+      }
+      if (hi) {
+        MFEM_GROUP_NCCL(c, ncclSend(ghost + (int64_t)(2 * f + 1) * PL, (size_t)PL, ncclDouble, c->rank + 1, c->comm, ctx->stream));
+        MFEM_GROUP_NCCL(c, ncclRecv(from_hi + (size_t)f * PL, (size_t)PL, ncclDouble, c->rank + 1, c->comm, ctx->stream));
+      }
+    }
+    ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess) {
+      mfem_set_error("ncclGroupEnd (reverse halo): %s", ncclGetErrorString(r));
+      c->failed = 1;
+      return MFEM_ERR_COMM;
+    }
+  } else {
+    double* s_lo = c->h_stage;
+    double* s_hi = c->h_stage + c->h_block;
+    double* r_lo = c->h_stage + 2 * c->h_block;
+    double* r_hi = c->h_stage + 3 * c->h_block;
+    for (int f = 0; f < F; ++f) {
+      if (lo) MFEM_CHECK_HIP(hipMemcpyAsync(s_lo + (size_t)f * PL, ghost + (int64_t)(2 * f + 0) * PL, sizeof(double) * PL, hipMemcpyDeviceToHost, ctx->stream));
+      if (hi) MFEM_CHECK_HIP(hipMemcpyAsync(s_hi + (size_t)f * PL, ghost + (int64_t)(2 * f + 1) * PL, sizeof(double) * PL, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const int r = c->host.neighbour_exchange(c->host.user, lo ? s_lo : nullptr, lo ? r_lo : nullptr, hi ? s_hi : nullptr,
+                                             hi ? r_hi : nullptr, (int64_t)blk);
+    if (r != 0) {
+      mfem_set_error("host neighbour-exchange callback returned %d", r);
+      c->failed = 1;
+      return MFEM_ERR_COMM;
+    }
+    if (lo) MFEM_CHECK_HIP(hipMemcpyAsync(from_lo, r_lo, sizeof(double) * blk, hipMemcpyHostToDevice, ctx->stream));
+    if (hi) MFEM_CHECK_HIP(hipMemcpyAsync(from_hi, r_hi, sizeof(double) * blk, hipMemcpyHostToDevice, ctx->stream));
+  }
   for (int f = 0; f < F; ++f) {
     double* own = x + (int64_t)f * NO;
-    if (c->rank > 0) {
-      MFEM_CHECK_NCCL(ncclSend(own, (size_t)PL, ncclDouble, c->rank - 1, c->comm, ctx->stream));
-      MFEM_CHECK_NCCL(ncclRecv(ghost + (int64_t)(2 * f + 0) * PL, (size_t)PL, ncclDouble, c->rank - 1, c->comm, ctx->stream));
-    }
-    if (c->rank < c->world - 1) {
-      MFEM_CHECK_NCCL(ncclSend(own + NO - PL, (size_t)PL, ncclDouble, c->rank + 1, c->comm, ctx->stream));
-      MFEM_CHECK_NCCL(ncclRecv(ghost + (int64_t)(2 * f + 1) * PL, (size_t)PL, ncclDouble, c->rank + 1, c->comm, ctx->stream));
-    }
+    const int g = mfem_grid_for(PL, MFEM_BLOCK, 256);
+    if (lo) hipLaunchKernelGGL(k_add_block, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, PL, from_lo + (size_t)f * PL, own);
+    if (hi) hipLaunchKernelGGL(k_add_block, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, PL, from_hi + (size_t)f * PL, own + NO - PL);
   }
-  MFEM_CHECK_NCCL(ncclGroupEnd());
+  MFEM_CHECK_LAUNCH();
+  if (c->backend == 1) MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return MFEM_OK;
 }
 
@@ -116,4 +387,10 @@ extern "C" int mfem_halo_exchange(mfem_context ctx, double* x_local) {
   MFEM_REQUIRE(ctx && x_local, "bad argument");
   MFEM_REQUIRE(ctx->comm, "no communicator attached (mfem_context_set_comm)");
   return mfem_comm_halo(ctx, x_local);
+}
+
+extern "C" int mfem_halo_reduce(mfem_context ctx, double* x_local) {
+  MFEM_REQUIRE(ctx && x_local, "bad argument");
+  MFEM_REQUIRE(ctx->comm, "no communicator attached (mfem_context_set_comm)");
+  return mfem_comm_halo_reduce(ctx, x_local);
 }

@@ -35,6 +35,24 @@ void mfem_set_error(const char* fmt, ...);
 
 struct mfem_comm_s;
 
+// Row split of a slab SpMV (multi-GPU): the rows that reference ghost columns -- the first / last halo_plane_len owned rows
+// of every field next to a neighbour rank ("boundary zones") -- against all other rows.  The interior part runs while the
+// halo exchange is in flight, the boundary part after it (spmv.hip: mfem_spmv_halo).  Kernels test whole work units
+// (tiles / chunks / a lane's rows): a unit that touches a zone belongs to the boundary part, so every row is computed once.
+#define MFEM_MAX_ZONES 8
+struct SpmvPart {
+  int part;  // 0 = all rows, 1 = interior units only, 2 = boundary units only
+  int nz;
+  int64_t lo[MFEM_MAX_ZONES], hi[MFEM_MAX_ZONES];
+};
+__host__ __device__ __forceinline__ bool spmv_part_skip(const SpmvPart& P, int64_t r0, int64_t r1) {
+  if (P.part == 0) return false;
+  bool bnd = false;
+  for (int z = 0; z < P.nz; ++z) bnd = bnd || (r0 < P.hi[z] && r1 > P.lo[z]);
+  return P.part == 1 ? bnd : !bnd;
+}
+
+
 #define MFEM_GRAPH_SLOTS 4
 struct mfem_context_s {
   int device;
@@ -78,6 +96,7 @@ int mfem_prof_flush(mfem_context_s* ctx);
 
 struct mfem_csr_s {
   mfem_context_s* ctx;
+  uint64_t serial;          // unique per created pattern (cycle-graph cache key)
   int64_t n, nnz;
   const void* rowptr;
   int rowptr_bits;
@@ -91,12 +110,7 @@ struct mfem_csr_s {
   void* owned_colidx;
   // slab info (multi-GPU): rows = owned nodes, x has ghost planes; 0 for single GPU
   int64_t x_offset;  // offset of the first owned entry inside the local x (per field)
-  // inspector-executor plan of spmv_window.hip (x window in LDS + 16-bit local indices)
-  int win_ready, win_cap, win_R, win_lstride;
-  int64_t win_xlen;
-  int32_t* win_nlines;
-  uint32_t* win_lines;
-  uint16_t* win_idx;
+  int64_t ncols;     // columns the pattern addresses: n, or n + ghost entries for a slab pattern (0 = n)
   // slot-major padded copy for near-uniform rows (spmv_ell.hip): ell_state 0 = not planned, -1 = not eligible, 1 = ready
   int ell_state, ell_K;
   int64_t ell_npad;
@@ -136,6 +150,7 @@ void mfem_sell_unbind(mfem_csr_s* A);
 void mfem_sell_free(mfem_csr_s* A);
 int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
                           double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
+bool mfem_sell_bound(const mfem_csr_s* A, const double* vals);  // the sliced layout (rows permuted: no row split) serves these values
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
 int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);
@@ -143,13 +158,12 @@ void mfem_ell_unbind(mfem_csr_s* A);
 int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d);
 void mfem_ell_free(mfem_csr_s* A);
 int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
-                         double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
-int mfem_spmv_window_plan(mfem_context_s* ctx, mfem_csr_s* A);
-void mfem_spmv_window_free(mfem_csr_s* A);
-int mfem_spmv_window_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
-                            double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
+                         double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag,
+                         const SpmvPart& part);
 
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes);
+uint64_t mfem_next_csr_serial();
+void mfem_graphs_invalidate(mfem_context_s* ctx);  // drops every cached cycle graph of the context (api.hip)
 extern int mfem_debug_epoch;  // bumped by every mfem_debug_set_*: part of the cycle-graph cache key (api.hip)
 
 // ---- device helpers ---------------------------------------------------------------------
@@ -163,6 +177,7 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
 __device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 4 doubles */) {
   v = wave_reduce_sum(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // a slower wave may still be reading smem from a preceding reduce_partials_bcast / block_reduce_sum
   if (lane == 0) smem[w] = v;
   __syncthreads();
   double r = 0.0;

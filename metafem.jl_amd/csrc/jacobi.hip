@@ -10,7 +10,9 @@
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 
-// mode 0: d[r] = |K_rr| (rows without a stored diagonal keep their preset value)
+// mode 0: d[r] = |K_rr| (rows without a stored diagonal keep their preset value; so do rows whose stored diagonal is exactly
+//         0 -- the reference would take |0| and divide by it; the solver layouts of spmv_ell.hip cannot tell a stored zero
+//         from a padding slot, so every layout applies this one guarded rule)
 // mode 1: d[r] = sqrt(sum_j K_rj^2)
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_jacobi_rows(int64_t n, const RP* __restrict__ rowptr,
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_jacobi_rows(int64_t n, const RP*
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
     if (mode == 0) {
       for (int64_t j = lo + g; j < hi; j += 8)
-        if ((int64_t)col[j] - base == r) d[r] = fabs(vals[j]);
+        if ((int64_t)col[j] - base == r && vals[j] != 0.0) d[r] = fabs(vals[j]);  // a stored ZERO diagonal keeps the preset too
     } else {
       double s = 0.0;
       for (int64_t j = lo + g; j < hi; j += 8) s += vals[j] * vals[j];
@@ -129,13 +131,23 @@ extern "C" int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double
   MFEM_REQUIRE(ctx && A, "null handle");
   if (A->n == 0) return MFEM_OK;
   MFEM_REQUIRE(vals && d, "null array");
-  MFEM_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(double) * A->n, ctx->stream));
+  // d has mfem_csr_ncols(A) entries: a slab pattern addresses ghost columns behind the owned ones
+  const int64_t ncols = A->ncols > 0 ? A->ncols : A->n;
+  MFEM_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(double) * ncols, ctx->stream));
   hipLaunchKernelGGL(k_jacobi2_by_column, dim3(mfem_grid_for(A->nnz, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK),
                      0, ctx->stream, A->nnz, A->colidx, vals, d, A->index_base);
   MFEM_CHECK_LAUNCH();
+  const bool slab = ncols > A->n && mfem_comm_world(ctx) > 1;
+  if (slab) {
+    // the rows that hit a column next to a slab interface live on two ranks: the squares this rank summed into its ghost
+    // columns go to the owners, who add them -- d becomes the column norm of the GLOBAL matrix, as on one GPU
+    int rc = mfem_comm_halo_reduce(ctx, d);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_sqrt_inplace, dim3(mfem_grid_for(A->n, MFEM_BLOCK, ctx->num_cus * 8)), dim3(MFEM_BLOCK), 0,
                      ctx->stream, A->n, d);
   MFEM_CHECK_LAUNCH();
+  if (slab) return mfem_comm_halo(ctx, d);  // ghost entries = the owners' d
   return MFEM_OK;
 }
 

@@ -50,6 +50,18 @@ template <typename T>
 inline uint64_t mfem_hash(uint64_t h, const T& v) { return mfem_hash_bytes(h, &v, sizeof(T)); }
 #define MFEM_HASH_SEED 1469598103934665603ull
 
+// Everything about the matrix a captured cycle's kernel arguments depend on.  The pattern is identified by a serial number
+// given at creation (never by the address of the handle: a destroyed pattern's address and the caller's value buffer are
+// routinely handed out again for the next pattern of the same size) plus the arrays and sizes the launches bake in.
+inline uint64_t mfem_csr_graph_key(uint64_t key, const mfem_csr_s* A) {
+  key = mfem_hash(key, A->serial); key = mfem_hash(key, A->rowptr); key = mfem_hash(key, A->colidx);
+  key = mfem_hash(key, A->n); key = mfem_hash(key, A->nnz); key = mfem_hash(key, A->max_row_nnz);
+  key = mfem_hash(key, A->index_base); key = mfem_hash(key, A->ell_vals);
+  key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound); key = mfem_hash(key, A->sell_vals);
+  key = mfem_hash(key, mfem_debug_epoch);
+  return key;
+}
+
 template <class Body>
 inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
   if (!ctx->graph_active) return body();

@@ -51,15 +51,23 @@ int mfem_fill(mfem_context_s* ctx, int64_t n, double v, double* x) {
 }
 
 // r = b - A x  and  S[slot] = r.r   (start of every Sv body: mul!(r, A, x, -1.); r .+= b)
-__global__ __launch_bounds__(MFEM_BLOCK) void k_resid_finish(int64_t n2, const d2_t* __restrict__ b, d2_t* __restrict__ r,
+// n = owned entries: behind them r may carry ghost entries (stale copies of neighbours' values) that must not be summed
+__global__ __launch_bounds__(MFEM_BLOCK) void k_resid_finish(int64_t n, const d2_t* __restrict__ b, d2_t* __restrict__ r,
                                                                double* __restrict__ partials) {
   __shared__ double red[4];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n2 = n >> 1;
   double acc = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
     const d2_t v = r[i] + b[i];
     r[i] = v;
     acc += v.x * v.x + v.y * v.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double* rs = reinterpret_cast<double*>(r);
+    const double v = rs[n - 1] + reinterpret_cast<const double*>(b)[n - 1];
+    rs[n - 1] = v;
+    acc += v * v;
   }
   const double s = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -67,21 +75,16 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_resid_finish(int64_t n2, const d
 
 int mfem_true_residual(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* b, const double* x,
                        double* r, int64_t nv, double* d_rr) {
+  (void)nv;
   // r = -A x ; r += b ; *d_rr = r.r  (device scalar, all-reduced over ranks when a communicator is attached)
-  int rc;
-  if (ctx->comm) {
-    rc = mfem_comm_halo(ctx, const_cast<double*>(x));
-    if (rc) return rc;
-  }
-  rc = mfem_spmv_launch(ctx, A, vals, x, r, -1.0, 0.0, nullptr, nullptr, nullptr);
+  int rc = mfem_spmv_halo(ctx, A, vals, const_cast<double*>(x), r, -1.0, 0.0, nullptr, nullptr, nullptr);
   if (rc) return rc;
-  const int grid = mfem_vec_grid(ctx, nv);
-  hipLaunchKernelGGL(k_resid_finish, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, (const d2_t*)b, (d2_t*)r,
+  const int grid = mfem_vec_grid(ctx, A->n);
+  hipLaunchKernelGGL(k_resid_finish, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const d2_t*)b, (d2_t*)r,
                      ctx->d_partials);
   MFEM_CHECK_LAUNCH();
   rc = mfem_sum_partials(ctx, ctx->d_partials, grid, d_rr);
-        if (rc) return rc;
-  MFEM_CHECK_LAUNCH();
+  if (rc) return rc;
   if (ctx->comm) return mfem_comm_allreduce(ctx, d_rr, 1);
   return MFEM_OK;
 }
@@ -252,11 +255,8 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
                      part2);
   MFEM_CHECK_LAUNCH();
   if (ctx->comm) {
-    rc = mfem_sum_partials(ctx, part2, G, S + S_TMP0);
-        if (rc) return rc;
-    rc = mfem_sum_partials(ctx, part2 + G, G, S + S_TMP1);
-        if (rc) return rc;
-    MFEM_CHECK_LAUNCH();
+    rc = mfem_fold_list(ctx, FoldList{{part2, part2 + G}, {G, G}, 2}, S + S_TMP0);
+    if (rc) return rc;
     rc = mfem_comm_allreduce(ctx, S + S_TMP0, 2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, a, S + S_TMP0, 1, S, F);
@@ -266,7 +266,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   MFEM_CHECK_LAUNCH();
   const int check = o->check_every > 0 ? o->check_every : 32;
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
-  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int it = 0;
@@ -281,18 +281,14 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     auto iteration = [&](int it_) -> int {
       const int cur = it_ & 1;
       int np1 = 0;
-      int rc = MFEM_OK;
-      if (ctx->comm) {
-        rc = mfem_comm_halo(ctx, p);
-        if (rc) return rc;
-      }
-      rc = mfem_spmv_launch(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1, F);
+      // with a communicator: the exchange of p's boundary planes runs beside the rows that need no ghost entry, and every
+      // reduction group is one fold kernel + one all-reduce
+      int rc = mfem_spmv_halo(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1, F);
       if (rc) return rc;
       int np2 = G;
       if (ctx->comm) {
-        rc = mfem_sum_partials(ctx, part1, np1, S + S_PAP);
+        rc = mfem_fold_list(ctx, FoldList{{part1}, {np1}, 1}, S + S_PAP, F);
         if (rc) return rc;
-        MFEM_CHECK_LAUNCH();
         rc = mfem_comm_allreduce(ctx, S + S_PAP, 1);
         if (rc) return rc;
         np1 = 0;
@@ -301,11 +297,8 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
                          (const d2_t*)Ap, (const d2_t*)dinv, (d2_t*)r, S, F, part2);
       MFEM_CHECK_LAUNCH();
       if (ctx->comm) {
-        rc = mfem_sum_partials(ctx, part2, G, S + S_TMP0);
+        rc = mfem_fold_list(ctx, FoldList{{part2, part2 + G}, {G, G}, 2}, S + S_TMP0, F);
         if (rc) return rc;
-        rc = mfem_sum_partials(ctx, part2 + G, G, S + S_TMP1);
-        if (rc) return rc;
-        MFEM_CHECK_LAUNCH();
         rc = mfem_comm_allreduce(ctx, S + S_TMP0, 2);
         if (rc) return rc;
         np2 = 0;
@@ -329,6 +322,191 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     }
     for (; k < burst; ++k, ++it) {
       rc = iteration(it);
+      if (rc) return rc;
+      ++*spmv_out;
+    }
+  }
+  rc = mfem_read_flags(ctx);
+  if (rc) return rc;
+  *iters_out = ctx->h_flags[F_ITER];
+  return MFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Jacobi-PCG with ONE reduction group per iteration (Chronopoulos & Gear 1989; the form used by pipelined Krylov solvers).
+// The classic recurrence needs p.Ap before it can update r and then (r.z, r.r) before it can update p: two dependent
+// all-reduces per iteration on several GPUs.  Carrying s = A p by recurrence (s = w + beta s with w = A u, u = M^-1 r) makes
+// all three scalars of an iteration -- gamma = r.u, delta = w.u, r.r -- available at the same point, right after the SpMV:
+//     p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = r ./ d      one pass, 11 vector streams
+//     w = A u  (+ delta partials)                                                       halo of u overlapped, as above
+//     all-reduce(gamma, r.r, delta) ; beta' = gamma'/gamma ; alpha' = gamma'/(delta' - beta' gamma'/alpha)
+// Same iterates as the classic CG in exact arithmetic (and the same stop rule, evaluated every iteration); in floating point
+// they differ at round-off level.  Default with a communicator of more than one rank; mfem_solve_options.cg_variant selects.
+// ------------------------------------------------------------------------------------------
+enum { S_CG_GAMMA = S_SOLVER + 0, S_CG_ALPHA = S_SOLVER + 1, S_CG_BETA = S_SOLVER + 2 };
+
+// u = r .* dinv ; partials: [0,G) r.u  [G,2G) r.r
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_init(CgArgs a, const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
+                                                            d2_t* __restrict__ u, double* __restrict__ partials) {
+  __shared__ double red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double ru = 0.0, rr = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
+    const d2_t rv = r[i];
+    const d2_t z = dinv ? rv * dinv[i] : rv;
+    u[i] = z;
+    ru += rv.x * z.x + rv.y * z.y;
+    rr += rv.x * rv.x + rv.y * rv.y;
+  }
+  const double s0 = block_reduce_sum(ru, red);
+  const double s1 = block_reduce_sum(rr, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = s0;
+    partials[gridDim.x + blockIdx.x] = s1;
+  }
+}
+
+// Single workgroup: the scalar step.  L.m == 3: fold the local partial sums (gamma', r.r, delta') here; L.m == 0: they are in
+// T[0..2] already (folded and all-reduced).  init != 0: first step (beta = 0, alpha = gamma / delta, iteration counter 0).
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_scal(CgArgs a, FoldList L, const double* __restrict__ T, int init,
+                                                            double* __restrict__ S, int32_t* __restrict__ flags) {
+  __shared__ double red[4];
+  if (!init && flags[F_DONE]) return;
+  double g, rr, dl;
+  if (L.m == 3) {
+    g = reduce_partials_bcast(L.src[0], L.cnt[0], red);
+    rr = reduce_partials_bcast(L.src[1], L.cnt[1], red);
+    dl = reduce_partials_bcast(L.src[2], L.cnt[2], red);
+  } else {
+    g = T[0];
+    rr = T[1];
+    dl = T[2];
+  }
+  if (threadIdx.x != 0) return;
+  S[S_RR] = rr;
+  if (init) {
+    S[S_CG_GAMMA] = g;
+    S[S_CG_ALPHA] = g / dl;
+    S[S_CG_BETA] = 0.0;
+    flags[F_ITER] = 0;
+    flags[F_DONE] = (!a.fixed && sqrt(rr * a.n_inv) <= a.tol) ? 1 : 0;
+    return;
+  }
+  const int iter = flags[F_ITER] + 1;
+  flags[F_ITER] = iter;
+  if ((!a.fixed && sqrt(rr * a.n_inv) <= a.tol) || iter >= a.maxiter) {
+    flags[F_DONE] = 1;
+    return;
+  }
+  const double beta = g / S[S_CG_GAMMA];
+  const double alpha = g / (dl - beta * g / S[S_CG_ALPHA]);
+  S[S_CG_GAMMA] = g;
+  S[S_CG_ALPHA] = alpha;
+  S[S_CG_BETA] = beta;
+}
+
+// p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = r .* dinv ; partials: [0,G) r.u  [G,2G) r.r
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_update(CgArgs a, const d2_t* __restrict__ w, const d2_t* __restrict__ dinv,
+                                                              d2_t* __restrict__ u, d2_t* __restrict__ p, d2_t* __restrict__ sv,
+                                                              d2_t* __restrict__ x, d2_t* __restrict__ r,
+                                                              const double* __restrict__ S, const int32_t* __restrict__ flags,
+                                                              double* __restrict__ partials) {
+  __shared__ double red[4];
+  if (flags[F_DONE]) return;
+  const double alpha = S[S_CG_ALPHA], beta = S[S_CG_BETA];
+  const bool first = beta == 0.0;  // p and s hold nothing yet (or leftovers of an earlier pass)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double ru = 0.0, rr = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
+    const d2_t uv = u[i], wv = w[i];
+    const d2_t pv = first ? uv : uv + beta * p[i];
+    const d2_t sn = first ? wv : wv + beta * sv[i];
+    p[i] = pv;
+    sv[i] = sn;
+    x[i] = x[i] + alpha * pv;
+    const d2_t rv = r[i] - alpha * sn;
+    r[i] = rv;
+    const d2_t z = dinv ? rv * dinv[i] : rv;
+    u[i] = z;
+    ru += rv.x * z.x + rv.y * z.y;
+    rr += rv.x * rv.x + rv.y * rv.y;
+  }
+  const double s0 = block_reduce_sum(ru, red);
+  const double s1 = block_reduce_sum(rr, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = s0;
+    partials[gridDim.x + blockIdx.x] = s1;
+  }
+}
+
+static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V,
+                           const mfem_solve_options* o, double tol, int64_t n_global, int* iters_out, int* spmv_out) {
+  double* S = ctx->d_scalars;
+  int32_t* F = ctx->d_flags;
+  double *r = V.w[0], *p = V.w[1], *sv = V.w[2], *u = V.w[3], *w = V.w[4];
+  const double* dinv = V.dinv;
+  const int64_t nv = V.nv;
+  CgArgs a;
+  a.n2 = nv / 2;
+  a.n_inv = 1.0 / (double)n_global;
+  a.tol = tol;
+  a.maxiter = o->maxiter;
+  a.fixed = o->fixed_iterations;
+  double* part1 = ctx->d_partials;                      // SpMV w.u partials
+  double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;   // 2 x G: r.u, r.r
+  double* T = S + S_TMP0;
+  int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
+  if (rc) return rc;
+  ++*spmv_out;
+  const int G = mfem_vec_grid(ctx, nv);
+  // the scalar step after an SpMV: fold (+ all-reduce) gamma', r.r, delta' and advance alpha / beta / the stop flags
+  auto scalars = [&](int np1, int init) -> int {
+    const FoldList L{{part2, part2 + G, part1}, {G, G, np1}, 3};
+    if (ctx->comm) {
+      int rc = mfem_fold_list(ctx, L, T, init ? nullptr : F);
+      if (rc) return rc;
+      rc = mfem_comm_allreduce(ctx, T, 3);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_cgcg_scal, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, a, FoldList{{nullptr}, {0}, 0}, T, init, S, F);
+    } else {
+      hipLaunchKernelGGL(k_cgcg_scal, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, a, L, T, init, S, F);
+    }
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  };
+  hipLaunchKernelGGL(k_cgcg_init, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (const d2_t*)r, (const d2_t*)dinv, (d2_t*)u, part2);
+  MFEM_CHECK_LAUNCH();
+  int np1 = 0;
+  rc = mfem_spmv_halo(ctx, A, vals, u, w, 1.0, 0.0, u, part1, &np1, nullptr);
+  if (rc) return rc;
+  ++*spmv_out;
+  rc = scalars(np1, 1);
+  if (rc) return rc;
+  const int check = o->check_every > 0 ? o->check_every : 32;
+  uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG + 64);
+  key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
+  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
+  auto iteration = [&]() -> int {
+    hipLaunchKernelGGL(k_cgcg_update, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (const d2_t*)w, (const d2_t*)dinv, (d2_t*)u,
+                       (d2_t*)p, (d2_t*)sv, (d2_t*)V.x, (d2_t*)r, S, F, part2);
+    MFEM_CHECK_LAUNCH();
+    int np = 0;
+    int rc = mfem_spmv_halo(ctx, A, vals, u, w, 1.0, 0.0, u, part1, &np, F);
+    if (rc) return rc;
+    return scalars(np, 0);
+  };
+  int it = 0;
+  for (;;) {
+    if (!o->fixed_iterations || it == 0) {
+      rc = mfem_read_flags(ctx);
+      if (rc) return rc;
+      if (ctx->h_flags[F_DONE]) break;
+    }
+    const int burst = (o->maxiter - it) < check ? (o->maxiter - it) : check;
+    if (burst <= 0) break;
+    for (int k = 0; k < burst; ++k, ++it) {
+      rc = mfem_cycle_run(ctx, key, iteration);  // every iteration has the same kernel arguments: one captured cycle
       if (rc) return rc;
       ++*spmv_out;
     }
@@ -405,13 +583,16 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const int64_t n = A->n;
   if (n == 0) return MFEM_OK;
   const int s_param = o->l_or_s > 0 ? o->l_or_s : (o->method == MFEM_SOLVER_IDRS ? 4 : 2);
+  MFEM_REQUIRE(o->cg_variant >= 0 && o->cg_variant <= 2, "cg_variant must be 0 (auto), 1 (classic) or 2 (single reduction)");
+  // one reduction group per CG iteration where a reduction costs an all-reduce; the classic recurrence otherwise
+  const bool cg_single = o->method == MFEM_SOLVER_CG && (o->cg_variant == 2 || (o->cg_variant == 0 && mfem_comm_world(ctx) > 1));
   MFEM_REQUIRE(s_param <= MFEM_MAX_S, "l_or_s too large");
   // x may carry ghost entries behind the owned rows (slab decomposition)
   const int64_t ghosts = ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0;
   const int64_t nv = (int64_t)align_up((size_t)(n + ghosts), 32);  // padded vector length (even => d2 kernels)
   int nwork = 0;
   switch (o->method) {
-    case MFEM_SOLVER_CG: nwork = 3; break;
+    case MFEM_SOLVER_CG: nwork = cg_single ? 5 : 3; break;
     case MFEM_SOLVER_BICGSTABL_GS: nwork = 2 * (s_param + 1) + 1; break;
     case MFEM_SOLVER_IDRS: nwork = 3 * s_param + 4; break;
     case MFEM_SOLVER_CGS2: nwork = 9; break;
@@ -489,8 +670,8 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       MFEM_CHECK_LAUNCH();
       V.dinv = dinv_buf;
     } else {
-      if (ctx->comm) {  // ghost columns need their owners' d
-        rc = mfem_comm_halo(ctx, V.d);
+      if (ctx->comm && o->precond != MFEM_PRECOND_JACOBI_RIGHT_COLNORM) {  // ghost columns need their owners' d (the column
+        rc = mfem_comm_halo(ctx, V.d);                                      // norm comes with them, mfem_jacobi2_by_column)
         if (rc) return rc;
       }
       rc = mfem_mat_div_jacobi(ctx, A, vals_work, V.d);
@@ -554,7 +735,8 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     int it = 0;
     switch (o->method) {
       case MFEM_SOLVER_CG:
-        rc = cg_solve_pass(ctx, A, vals_work, V, o, tol_factor * o->converge_tol, n_global, &it, &spmvs);
+        rc = cg_single ? cgcg_solve_pass(ctx, A, vals_work, V, o, tol_factor * o->converge_tol, n_global, &it, &spmvs)
+                       : cg_solve_pass(ctx, A, vals_work, V, o, tol_factor * o->converge_tol, n_global, &it, &spmvs);
         break;
       case MFEM_SOLVER_BICGSTABL_GS:
         rc = mfem_bicgstabl_pass(ctx, A, vals_work, V, o, s_param, tol_factor * o->converge_tol, n_global, &it, &spmvs);

@@ -127,7 +127,7 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
   double** R = V.w;              // R[0..l]
   double** U = V.w + (l + 1);    // U[0..l]
   double* shadow = V.w[2 * (l + 1)];
-  KK k{ctx, nv, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
+  KK k{ctx, nv, V.n, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
   BlArgs a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations, l};
 
   // r = b - A x ; Pl(r) (identity)   (:19-21)
@@ -148,7 +148,7 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
   RC(mfem_read_flags(ctx));
   int host_iter = 1;
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_BICGSTABL_GS);
-  key = mfem_hash(key, l); key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
+  key = mfem_hash(key, l); key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
   key = mfem_hash(key, V.x); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int dummy_spmv = 0;

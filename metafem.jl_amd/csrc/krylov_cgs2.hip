@@ -101,7 +101,7 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   int32_t* F = ctx->d_flags;
   const int64_t nv = V.nv;
   double *r = V.w[0], *r0 = V.w[1], *s0 = V.w[2], *u = V.w[3], *w = V.w[4], *s = V.w[5], *v = V.w[6], *t = V.w[7], *c = V.w[8];
-  KK k{ctx, nv, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
+  KK k{ctx, nv, V.n, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
   C2Args a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations};
   RC(mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR));
   ++*spmv_out;
@@ -116,7 +116,7 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   int since = 0, host_iter = 1;
   RC(mfem_read_flags(ctx));
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CGS2);
-  key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
+  key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, V.b); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int dummy_spmv = 0;

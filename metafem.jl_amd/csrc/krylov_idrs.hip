@@ -149,7 +149,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   double** P = V.w + 4;
   double** U = V.w + 4 + s;
   double** G = V.w + 4 + 2 * s;
-  KK k{ctx, nv, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
+  KK k{ctx, nv, V.n, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
   IdArgs a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations, s};
 
   RC(mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR));  // :27-29
@@ -169,7 +169,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   int since_poll = 0, host_iter = 1;
   RC(mfem_read_flags(ctx));
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_IDRS);
-  key = mfem_hash(key, s); key = mfem_hash(key, A); key = mfem_hash(key, A->ell_vals); key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, mfem_debug_epoch); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
+  key = mfem_hash(key, s); key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
   key = mfem_hash(key, V.x); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
   int dummy_spmv = 0;

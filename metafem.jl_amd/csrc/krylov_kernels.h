@@ -59,12 +59,15 @@ struct DotList {
   int m;
 };
 
-// partials[k*G + blockIdx] = partial of x_k . y_k  for k < m   (one pass over memory per distinct vector read)
-static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n2, DotList L, double* __restrict__ partials,
+// partials[k*G + blockIdx] = partial of x_k . y_k  for k < m   (one pass over memory per distinct vector read).
+// Only the first n entries count: behind them a slab vector carries ghost entries (copies of the neighbours' values, which
+// their owners sum) and every vector carries padding.
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n, DotList L, double* __restrict__ partials,
                                                                    const int32_t* __restrict__ flags) {
   __shared__ double red[4];
   if (flags[F_DONE]) return;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n2 = n >> 1;
   double acc[KK_MAX_DOTS];
 #pragma unroll
   for (int k = 0; k < KK_MAX_DOTS; ++k) acc[k] = 0.0;
@@ -75,6 +78,11 @@ static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n2, Do
         const d2_t a = L.x[k][i], b = L.y[k][i];
         acc[k] += a.x * b.x + a.y * b.y;
       }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd n: the last entry shares its 16 bytes with the first ghost / pad entry
+#pragma unroll
+    for (int k = 0; k < KK_MAX_DOTS; ++k)
+      if (k < L.m) acc[k] += L.x[k][n2].x * L.y[k][n2].x;
   }
 #pragma unroll
   for (int k = 0; k < KK_MAX_DOTS; ++k)
@@ -113,7 +121,8 @@ __device__ __forceinline__ void kk_fold_dev(const FoldArg& f, double* __restrict
 
 struct KK {
   mfem_context_s* ctx;
-  int64_t nv;
+  int64_t nv;   // padded vector length (owned + ghost + pad): what the vector updates stream over
+  int64_t n;    // owned entries: what the dot products sum over
   int G;
   double* S;
   int32_t* F;
@@ -138,7 +147,7 @@ struct KK {
   // S[out + k] = x_k . y_k (all-reduced over ranks when a communicator is attached)
   int dots(const DotList& L, int out) const {
     double* part = ctx->d_partials;
-    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, L, part, F);
+    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F);
     MFEM_CHECK_LAUNCH();
     hipLaunchKernelGGL(kk_fold, dim3(1), dim3(MFEM_BLOCK), 0, st, part, G, L.m, out, S, F);
     MFEM_CHECK_LAUNCH();
@@ -149,7 +158,7 @@ struct KK {
   // communicator the fold + all-reduce happen here and the descriptor is empty.
   int dots_partials(const DotList& L, int out, FoldArg* fa) const {
     double* part = ctx->d_partials;
-    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, nv / 2, L, part, F);
+    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F);
     MFEM_CHECK_LAUNCH();
     *fa = FoldArg{part, G, L.m, out};
     if (ctx->comm) {
@@ -175,11 +184,7 @@ struct KK {
     return dots(L, out);
   }
   int spmv(mfem_csr_s* A, const double* vals, double* x, double* y, int* spmv_count) const {
-    if (ctx->comm) {
-      int rc = mfem_comm_halo(ctx, x);
-      if (rc) return rc;
-    }
-    ++*spmv_count;
-    return mfem_spmv_launch(ctx, A, vals, x, y, 1.0, 0.0, nullptr, nullptr, nullptr, F);
+    ++*spmv_count;  // with a communicator: the halo exchange of x runs beside the rows that need no ghost entry
+    return mfem_spmv_halo(ctx, A, vals, x, y, 1.0, 0.0, nullptr, nullptr, nullptr, F);
   }
 };

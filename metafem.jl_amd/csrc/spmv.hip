@@ -16,7 +16,7 @@
 //     the tile -> workgroup map is XCD-aware: workgroups with equal blockIdx % 8 share an XCD L2
 //     (dispatch is round-robin over the 8 XCDs), so each XCD walks its own contiguous eighth of
 //     the rows and x planes are fetched into one L2 instead of eight.
-#include "common.h"
+#include "blas1.h"
 
 // Tile variants: CAP doubles of LDS product tile, UNROLL = 16-byte loads in flight per lane and batch.
 // 4032 doubles = 31.5 KiB -> 5 workgroups per CU; 2016 -> 8 (wave-limited).
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_lds(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, int64_t ntiles_padded, int xcd_aware,
-    const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+    const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
   __shared__ double prod[SPMV_CAP + 4];
   __shared__ double red[BLK / 64];
   if (done_flag && done_flag[0]) return;
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_lds(
     if (tile >= ntiles) continue;  // uniform per workgroup
     const int64_t r0 = tile * R;
     const int64_t r1 = (r0 + R < n) ? r0 + R : n;
+    if (spmv_part_skip(part, r0, r1)) continue;  // uniform per workgroup
     const int64_t s = (int64_t)rowptr[r0] - base;
     const int64_t e = (int64_t)rowptr[r1] - base;
 
@@ -183,7 +184,7 @@ template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
     int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ vals,
     const double* __restrict__ x, double* __restrict__ y, double alpha, double beta, int base,
-    const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+    const double* __restrict__ dotw, double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   const int lane = threadIdx.x & 63;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot_acc = 0.0;
   for (int64_t r = wave; r < n; r += nwaves) {
+    if (spmv_part_skip(part, r, r + 1)) continue;
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
     double sum = 0.0;
     for (int64_t j = lo + lane; j < hi; j += 64) sum += vals[j] * x[col[j] - base];
@@ -229,6 +231,7 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
 }
 
 int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  A->serial = mfem_next_csr_serial();  // every creation path (mfem_csr_create, mfem_brick_pattern, mfem_pattern_build) plans once
   int32_t* d_max = ctx->d_flags + 8;
   MFEM_CHECK_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
   const int grid = mfem_grid_for(A->n, MFEM_BLOCK, 4096);
@@ -245,7 +248,7 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->max_row_nnz = ctx->h_flags[8];
   A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
-  return mfem_spmv_window_plan(ctx, A);
+  return MFEM_OK;
 }
 
 extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
@@ -276,7 +279,8 @@ extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const v
 
 extern "C" int mfem_csr_destroy(mfem_csr A) {
   if (!A) return MFEM_OK;
-  mfem_spmv_window_free(A);
+  // a cached cycle graph holds this pattern's arrays in its kernel arguments
+  if (A->ctx) mfem_graphs_invalidate(A->ctx);
   mfem_ell_free(A);
   mfem_sell_free(A);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);
@@ -291,42 +295,117 @@ extern "C" const int64_t* mfem_csr_rowptr64(mfem_csr A) {
 extern "C" const int32_t* mfem_csr_colidx(mfem_csr A) { return A ? A->colidx : nullptr; }
 extern "C" int64_t mfem_csr_nnz(mfem_csr A) { return A ? A->nnz : -1; }
 extern "C" int64_t mfem_csr_n(mfem_csr A) { return A ? A->n : -1; }
+extern "C" int64_t mfem_csr_ncols(mfem_csr A) { return A ? (A->ncols > 0 ? A->ncols : A->n) : -1; }
 
 // Internal launcher: y = alpha*A*x + beta*y, optionally partial sums of (dotw . y) into `partials`
 // (*n_partials receives the number written).
 static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
                              double alpha, double beta, const double* dotw, double* partials, int* n_partials,
-                             const int32_t* done_flag);
+                             const int32_t* done_flag, const SpmvPart& part);
+
+static const SpmvPart kAllRows = {0, 0, {0}, {0}};
+
+struct ProfScope {  // optional hip-event bracket around one SpMV (bench.py's roofline): a split SpMV counts as one launch
+  mfem_context_s* ctx;
+  int k;
+  int begin() {
+    k = -1;
+    if (!ctx->prof_on) return MFEM_OK;
+    if (ctx->prof_used == MFEM_PROF_PAIRS) {
+      int rc = mfem_prof_flush(ctx);
+      if (rc) return rc;
+    }
+    k = ctx->prof_used;
+    MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k], ctx->stream));
+    return MFEM_OK;
+  }
+  int end() {
+    if (k < 0) return MFEM_OK;
+    MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k + 1], ctx->stream));
+    ctx->prof_used = k + 1;
+    return MFEM_OK;
+  }
+};
 
 int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
                      double alpha, double beta, const double* dotw, double* partials, int* n_partials,
                      const int32_t* done_flag) {
-  if (!ctx->prof_on) return spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
-  if (ctx->prof_used == MFEM_PROF_PAIRS) {
-    int rc = mfem_prof_flush(ctx);
+  ProfScope prof{ctx, -1};
+  int rc = prof.begin();
+  if (rc) return rc;
+  rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, kAllRows);
+  if (rc) return rc;
+  return prof.end();
+}
+
+// The SpMV of a Krylov loop on a slab: y = alpha A x + beta y where x carries ghost blocks that the neighbours' boundary
+// planes must fill first.  The exchange is started on the communicator's stream, the rows that reference no ghost column
+// run beside it, the few planes of rows that do run after it has arrived (one extra small launch).  Layouts without a row
+// split (the row-sorted sliced layout) wait for the exchange first.  Without a communicator this is mfem_spmv_launch.
+static int g_halo_overlap = 1;
+extern "C" int mfem_debug_set_halo_overlap(int on) {
+  ++mfem_debug_epoch;
+  g_halo_overlap = on ? 1 : 0;
+  return MFEM_OK;
+}
+
+int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* x, double* y, double alpha, double beta,
+                   const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
+  if (mfem_comm_world(ctx) == 1) return mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
+  ProfScope prof{ctx, -1};
+  int rc = prof.begin();
+  if (rc) return rc;
+  rc = mfem_comm_halo_begin(ctx, x);
+  if (rc) return rc;
+  SpmvPart P;
+  memset(&P, 0, sizeof(P));
+  const int F = ctx->halo_fields;
+  const bool split = g_halo_overlap && A->n > 0 && 2 * F <= MFEM_MAX_ZONES && !mfem_sell_bound(A, vals) &&
+                     A->n == (int64_t)F * mfem_comm_owned_nodes(ctx);
+  if (split) {
+    const int64_t NO = mfem_comm_owned_nodes(ctx), PL = ctx->halo_plane_len;
+    const int rank = mfem_comm_rank(ctx), world = mfem_comm_world(ctx);
+    for (int f = 0; f < F; ++f) {
+      if (rank > 0) { P.lo[P.nz] = f * NO; P.hi[P.nz] = f * NO + PL; ++P.nz; }
+      if (rank < world - 1) { P.lo[P.nz] = (f + 1) * NO - PL; P.hi[P.nz] = (f + 1) * NO; ++P.nz; }
+    }
+    int np1 = 0, np2 = 0;
+    P.part = 1;
+    rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, &np1, done_flag, P);
+    if (rc) return rc;
+    rc = mfem_comm_halo_end(ctx);
+    if (rc) return rc;
+    P.part = 2;
+    rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials ? partials + np1 : nullptr, &np2, done_flag, P);
+    if (rc) return rc;
+    if (n_partials) *n_partials = np1 + np2;
+    if (np1 + np2 > MFEM_MAX_PARTIALS) {
+      mfem_set_error("split SpMV wrote %d partial sums (> %d)", np1 + np2, MFEM_MAX_PARTIALS);
+      return MFEM_ERR_INVALID;
+    }
+  } else {
+    rc = mfem_comm_halo_end(ctx);
+    if (rc) return rc;
+    rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, kAllRows);
     if (rc) return rc;
   }
-  const int k = ctx->prof_used;
-  MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k], ctx->stream));
-  int rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
-  if (rc) return rc;
-  MFEM_CHECK_HIP(hipEventRecord(ctx->prof_ev[2 * k + 1], ctx->stream));
-  ctx->prof_used = k + 1;
-  return MFEM_OK;
+  return prof.end();
 }
 
 static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y,
                              double alpha, double beta, const double* dotw, double* partials, int* n_partials,
-                             const int32_t* done_flag) {
+                             const int32_t* done_flag, const SpmvPart& part) {
   if (n_partials) *n_partials = 0;
   if (A->n == 0) return MFEM_OK;
   {
-    const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
+    const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part);
     if (e != 0) return e < 0 ? e : MFEM_OK;
+    if (part.part != 0 && mfem_sell_bound(A, vals)) {
+      mfem_set_error("the row-sorted sliced layout has no row split");
+      return MFEM_ERR_UNSUPPORTED;
+    }
     const int sl = mfem_spmv_sell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
     if (sl != 0) return sl < 0 ? sl : MFEM_OK;
-    const int w = mfem_spmv_window_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
-    if (w != 0) return w < 0 ? w : MFEM_OK;
   }
   const int base = A->index_base;
   const int cap_doubles = (g_spmv_variant == 7 && A->max_row_nnz <= 1008 - 2) ? 1008
@@ -343,6 +422,13 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     const int64_t ntiles = (A->n + R - 1) / R;
     int cap = ctx->num_cus * g_spmv_grid_mult;
     if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+    if (part.part != 0) cap /= 2;  // the two parts of a split SpMV share one partial-sum array
+    if (part.part == 2) {
+      int64_t rows = 0;
+      for (int z = 0; z < part.nz; ++z) rows += part.hi[z] - part.lo[z];
+      const int64_t want = rows / R + 2 * part.nz + 8;
+      if (want < cap) cap = (int)want;
+    }
     cap &= ~7;  // multiple of 8 so blockIdx % 8 is a stable XCD label along the grid-stride loop
     if (cap < 8) cap = 8;
     int grid = (int)(ntiles < cap ? ((ntiles + 7) & ~(int64_t)7) : cap);
@@ -354,7 +440,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
 #define LAUNCH_LDS(RP, VEC, CAP, UNR, BLK)                                                                 \
   hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR, BLK>), dim3(grid), dim3(BLK), 0, ctx->stream, A->n,    \
                      A->nnz, (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2,  \
-                     ntiles, ntiles_padded, xcd, dotw, partials, done_flag)
+                     ntiles, ntiles_padded, xcd, dotw, partials, done_flag, part)
 #define LAUNCH_VARIANT(RP)                                                   \
   do {                                                                       \
     if (!vec) LAUNCH_LDS(RP, false, 4032, 4, MFEM_BLOCK);                    \
@@ -376,10 +462,10 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     const int grid = mfem_grid_for(A->n, 4, ctx->num_cus * 8 < MFEM_MAX_PARTIALS ? ctx->num_cus * 8 : MFEM_MAX_PARTIALS);
     if (A->rowptr_bits == 64)
       hipLaunchKernelGGL(k_spmv_wave_per_row<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
-                         (const int64_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials, done_flag);
+                         (const int64_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials, done_flag, part);
     else
       hipLaunchKernelGGL(k_spmv_wave_per_row<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,
-                         (const int32_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials, done_flag);
+                         (const int32_t*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, dotw, partials, done_flag, part);
     MFEM_CHECK_LAUNCH();
     if (n_partials && partials) *n_partials = grid;
   }

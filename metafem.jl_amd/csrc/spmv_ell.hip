@@ -131,12 +131,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_ell(int64_t n, int64_t npad
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
                                                            const double* __restrict__ dotw, double* __restrict__ partials,
-                                                           const int32_t* __restrict__ done_flag) {
+                                                           const int32_t* __restrict__ done_flag, SpmvPart part) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * RPT;
   for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * RPT; r < n; r += stride) {
+    if (spmv_part_skip(part, r, r + RPT)) continue;
     const double* v = vals + ell_base(r, K);
     const int32_t* c = cols + ell_base(r, K);
     if (RPT == 1) {
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
                                                            const double* __restrict__ vals, const double* __restrict__ x,
                                                            double* __restrict__ y, double alpha, double beta,
                                                            const double* __restrict__ dotw, double* __restrict__ partials,
-                                                           const int32_t* __restrict__ done_flag, int xcd) {
+                                                           const int32_t* __restrict__ done_flag, int xcd, SpmvPart part) {
   __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   const DiaOffsets& O = *Op;
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(1024) void k_spmv_dia(int64_t n, int64_t npad, int 
   for (; chunk < chunk_end; chunk += chunk_step) {
     const int64_t r = chunk * rows_per_wg + (int64_t)threadIdx.x * RPT;
     if (r >= n) continue;
+    if (spmv_part_skip(part, chunk * rows_per_wg, (chunk + 1) * rows_per_wg)) continue;  // workgroup-uniform
     dia_rows<RPT, U, TRIPLES>(r, n, npad, K, O, flags, cols, vals, x, y, alpha, beta, dotw, xcd, dot_acc);
   }
   if (partials) {
@@ -495,7 +497,8 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
                                                              const double* __restrict__ vals, const double* __restrict__ x,
                                                              double* __restrict__ y, double alpha, double beta,
                                                              const double* __restrict__ dotw, double* __restrict__ partials,
-                                                             const int32_t* __restrict__ done_flag, int64_t c0, int64_t c1, int S, int nsteps, int cls, int gs) {
+                                                             const int32_t* __restrict__ done_flag, int64_t c0, int64_t c1, int S, int nsteps, int cls, int gs,
+                                                             int part) {  // 0: sweep + the chunks outside it; 1: sweep only; 2: only the chunks outside the sweep (every row that reads a ghost column of a slab is among them)
   __shared__ __attribute__((aligned(16))) double hist[9][SYM_ROWS];  // diagonals 18..26 (into the next plane) of the previous chunk
   __shared__ __attribute__((aligned(16))) double exch[4][SYM_ROWS];  // diagonals 14..17 (+z, +y) of this chunk
   __shared__ double red[16];
@@ -507,12 +510,12 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
   // range of the tile's nsteps plane steps
   const int tile = blockIdx.x % S, seg = blockIdx.x / S;
   const int nseg = gs / S + (tile < gs % S ? 1 : 0);
-  const int seg_len = (nsteps + nseg - 1) / nseg;
+  const int seg_len = part == 2 ? 0 : (nsteps + nseg - 1) / nseg;
   bool have_hist = false;
   e_d2 up_next[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
   {
     const int64_t chunk = c0 + tile + (int64_t)S * ((int64_t)seg * seg_len);
-    if (seg * seg_len < nsteps && chunk < c1) {
+    if (part != 2 && seg * seg_len < nsteps && chunk < c1) {
       const double* v = vals + ell_base(chunk * SYM_ROWS + 2 * tid, K);
 #pragma unroll
       for (int u = 0; u < 4; ++u) up_next[u] = SYM_LD(reinterpret_cast<const e_d2*>(v + (14 + u) * ELL_B));
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(SYM_THREADS) void k_spmv_sym27(int64_t n, int64_t n
   }
   // after its sweep every workgroup takes a share of the chunks outside the regular range (first / last lattice planes, ghost
   // planes of a slab) through the plain per-row code: no extra workgroups, no tail behind the sweeps
-  {
+  if (part != 1) {
     const int64_t nchunks = (n + SYM_ROWS - 1) / SYM_ROWS;
     for (int64_t q = blockIdx.x;; q += gridDim.x) {
       const int64_t ch = q < c0 ? q : c1 + (q - c0);
@@ -817,7 +820,7 @@ static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* n
   // tiles that cannot fill the resident slots in whole rounds (512^3: 514 tiles on 768 slots) are cut into ~2.7 rounds of shorter
   // segments instead: 8.92 -> 7.91 ms per CG iteration there; at 256^3 (645 of 768) more segments change nothing
   if ((int64_t)A->sym_S * nseg * 10 < (int64_t)resident * 8) nseg = (8 * ctx->num_cus + A->sym_S - 1) / A->sym_S;
-  while (nseg > 1 && (int64_t)A->sym_S * nseg > MFEM_MAX_PARTIALS) --nseg;  // one partial sum per workgroup
+  while (nseg > 1 && (int64_t)A->sym_S * nseg > MFEM_MAX_PARTIALS - 512) --nseg;  // one partial sum per workgroup (+ <= 512 of the boundary part of a split SpMV)
   if (nseg > nsteps / 8) nseg = (int)(nsteps / 8);  // a segment's first step has no history: keep segments >= 8 steps long
   if (nseg < 1) nseg = 1;
   if (nsteps_out) *nsteps_out = nsteps;
@@ -954,10 +957,18 @@ void mfem_ell_free(mfem_csr_s* A) {
 
 // returns 1 if launched, 0 if the CSR kernel should be used, <0 on error
 int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
-                         double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
+                         double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag,
+                         const SpmvPart& part) {
   if (!A->ell_vals || vals != A->ell_src) return 0;
   int cap = ctx->num_cus * g_ell_grid_mult;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+  if (part.part != 0) cap /= 2;  // the two parts of a split SpMV share one partial-sum array
+  if (part.part == 2) {          // a few planes of rows: no point in a chip-filling persistent grid
+    int64_t rows = 0;
+    for (int z = 0; z < part.nz; ++z) rows += part.hi[z] - part.lo[z];
+    const int64_t want = rows / 512 + 2 * part.nz + 1;
+    if (want < cap) cap = (int)want;
+  }
   if (A->ell_bound_mode == 2) {
     const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
     const int drpt = (g_dia_variant == 4 || g_dia_variant == 5) ? 4 : 2;
@@ -965,7 +976,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
     const int gd = mfem_grid_for((A->n + drpt - 1) / drpt, MFEM_BLOCK, cap);
 #define LAUNCH_DIA(RPT, U)                                                                                                \
   hipLaunchKernelGGL((k_spmv_dia<RPT, U>), dim3(gd), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,          \
-                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd)
+                     A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd, part)
     switch (g_dia_variant) {
       case 1: LAUNCH_DIA(2, 2); break;
       case 3: LAUNCH_DIA(2, 9); break;
@@ -978,17 +989,20 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
           // rows of the regular chunk range: symmetric sweep kernel; the rest: the plain kernel with that range skipped
           int64_t nsteps = 0;
           const int gs = sym27_grid(ctx, A, &nsteps);
-          ++g_sym_launches;
-          hipLaunchKernelGGL(k_spmv_sym27, dim3(gs), dim3(SYM_THREADS), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
+          // part 2 (the chunks outside the sweep, after the halo has arrived): as many workgroups as there are such chunks
+          const int64_t outside = (A->n + SYM_ROWS - 1) / SYM_ROWS - (A->sym_c1 - A->sym_c0);
+          const int gl = part.part == 2 ? (int)(outside < 1 ? 1 : outside < 512 ? outside : 512) : gs;
+          if (part.part != 2) ++g_sym_launches;
+          hipLaunchKernelGGL(k_spmv_sym27, dim3(gl), dim3(SYM_THREADS), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O, A->dia_flags,
                              A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, A->sym_c0, A->sym_c1, A->sym_S,
-                             (int)nsteps, A->sym_cls, gs);
+                             (int)nsteps, A->sym_cls, gs, part.part);
           MFEM_CHECK_LAUNCH();
-          if (n_partials && partials) *n_partials = gs;
+          if (n_partials && partials) *n_partials = gl;
           return 1;
         }
         if (A->dia_triples && g_dia_variant != 8) {
           hipLaunchKernelGGL((k_spmv_dia<2, 3, true>), dim3(gdb), dim3(g_dia_block), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd);
+                             A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, g_dia_xcd, part);
         } else {
           LAUNCH_DIA(2, 3);
         }
@@ -1004,7 +1018,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   const int grid = mfem_grid_for((A->n + rpt - 1) / rpt, MFEM_BLOCK, cap);
 #define LAUNCH_ELL(RPT, U)                                                                                               \
   hipLaunchKernelGGL((k_spmv_ell<RPT, U>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K,     \
-                     A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag)
+                     A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, partials, done_flag, part)
   switch (g_ell_variant) {
     case 1: LAUNCH_ELL(2, 9); break;
     case 2: LAUNCH_ELL(1, 27); break;

@@ -356,6 +356,8 @@ int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   return MFEM_OK;
 }
 
+bool mfem_sell_bound(const mfem_csr_s* A, const double* vals) { return A->sell_vals && vals == A->sell_src; }
+
 void mfem_sell_unbind(mfem_csr_s* A) {
   A->sell_vals = nullptr;
   A->sell_src = nullptr;

@@ -99,6 +99,10 @@ class SlabComm:
         check(lib.mfem_halo_exchange(self.ctx._h, x_local.data_ptr()))
         return x_local
 
+    def halo_reduce_(self, x_local: torch.Tensor) -> torch.Tensor:
+        check(lib.mfem_halo_reduce(self.ctx._h, x_local.data_ptr()))
+        return x_local
+
     def close(self):
         if self._h:
             lib.mfem_context_set_comm(self.ctx._h, None, 0, 0, 0)
@@ -110,3 +114,69 @@ class SlabComm:
             self.close()
         except Exception:
             pass
+
+
+class HostSlabComm:
+    """The same communicator behind host callbacks (mfem_comm_create_host): the library stages device data through pinned
+    host memory and torch.distributed (any backend that moves CPU tensors: gloo) does the exchange.  Every solver code path
+    is the RCCL one; only the transport differs.  This is how the multi-rank path runs with several ranks on ONE GPU
+    (RCCL rejects duplicate devices) -- tests/test_gpu_multirank.py -- and what a host without GPU-aware MPI would use.
+    poison = True: ghost entries are NaN between halo begin and end (a kernel that reads them too early is found out)."""
+
+    def __init__(self, ctx, brick, rank: int, world: int, n_fields: int = 1, group=None, poison: bool = False):
+        import numpy as _np
+        import torch.distributed as dist
+
+        self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
+        self.calls = {"allreduce": 0, "exchange": 0}
+
+        def _tensor(ptr, count):
+            return torch.from_numpy(_np.ctypeslib.as_array(ptr, shape=(count,)))
+
+        def _allreduce(_user, buf, count):
+            try:
+                self.calls["allreduce"] += 1
+                dist.all_reduce(_tensor(buf, count), group=self.group)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                self.error = e
+                return 1
+
+        def _exchange(_user, s_lo, r_lo, s_hi, r_hi, count):
+            try:
+                self.calls["exchange"] += 1
+                reqs = []
+                if r_lo:
+                    reqs.append(dist.irecv(_tensor(r_lo, count), self.rank - 1, group=self.group))
+                if r_hi:
+                    reqs.append(dist.irecv(_tensor(r_hi, count), self.rank + 1, group=self.group))
+                if s_lo:
+                    reqs.append(dist.isend(_tensor(s_lo, count), self.rank - 1, group=self.group))
+                if s_hi:
+                    reqs.append(dist.isend(_tensor(s_hi, count), self.rank + 1, group=self.group))
+                for q in reqs:
+                    q.wait()
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
+        self.error = None
+        self._cb = (_lib.ALLREDUCE_CB(_allreduce), _lib.EXCHANGE_CB(_exchange))  # keep the thunks alive
+        ops = _lib.CommHostOps(None, self._cb[0], self._cb[1], _lib.COMM_HOST_POISON_GHOSTS if poison else 0, 0)
+        self._h = C.c_void_p()
+        check(lib.mfem_comm_create_host(ctx._h, rank, world, C.byref(ops), C.byref(self._h)))
+        self.plane_len = brick.itp_order * brick.m[1] * brick.m[2]
+        self.n_owned_nodes = brick.n_owned
+        self.n_fields = n_fields
+        check(lib.mfem_context_set_comm(ctx._h, self._h, self.n_owned_nodes, self.plane_len, n_fields))
+
+    allreduce_ = SlabComm.allreduce_
+    halo_ = SlabComm.halo_
+
+    def halo_reduce_(self, x_local: torch.Tensor) -> torch.Tensor:
+        check(lib.mfem_halo_reduce(self.ctx._h, x_local.data_ptr()))
+        return x_local
+
+    close = SlabComm.close
+    __del__ = SlabComm.__del__

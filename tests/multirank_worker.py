@@ -1,0 +1,191 @@
+"""One rank of the multi-rank GPU tests (tests/test_gpu_multirank.py starts `world` of these on cuda:0).
+
+Every rank builds its slab of a structured problem, attaches the host-callback communicator (gloo moves the data: several
+ranks share ONE GPU here, which RCCL refuses) and runs the product's own multi-rank code paths -- mfem_halo_exchange,
+mfem_halo_reduce, the Jacobi vectors, mfem_solve with CG (classic and single-reduction), BiCGStab(2), IDR(8) -- against the
+single-rank solve of the global problem, which the rank computes itself on a second context.  Exit code 0 = all checks passed.
+
+usage: multirank_worker.py <case> <world> <rank> <port>
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+K_COND, H, TENV, SRC = 0.6, 25.0, 293.15, 1600.0
+LAM, MU, TAU = 0.5769, 0.3846, 1000.0
+
+CASES = {
+    # name: (elements, order, itg_order, fields)
+    "thermal_hex8": ((30, 63, 63), 1, 3, 1),      # planes of 64 x 64 nodes: the symmetric sweep kernel is eligible on every slab
+    "thermal_hex8_small": ((11, 5, 4), 1, 3, 1),  # CSR tile kernel (default thresholds), uneven slabs
+    "elasticity_hex8": ((12, 6, 5), 1, 3, 3),
+    "thermal_hex27": ((8, 4, 3), 2, 5, 1),
+}
+
+
+def main():
+    case, world, rank, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    import metafem_jl_amd as mf
+    from metafem_jl_amd import _lib, parallel as par
+
+    n, order, itg, F = CASES[case]
+    x_len = (2.0, 1.0, 1.0)
+    dev = "cuda:0"
+    force_layouts = case != "thermal_hex8_small"
+    if force_layouts:
+        _lib.lib.mfem_debug_set_layout_min_rows(0, 0)  # solver layouts (diagonal slots / symmetric sweep / sliced) on these small systems
+    report = {"case": case, "world": world, "rank": rank, "checks": {}}
+    ok = True
+
+    def check(name, cond, **info):
+        nonlocal ok
+        report["checks"][name] = {"ok": bool(cond), **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in info.items()}}
+        ok = ok and bool(cond)
+
+    # ---- global problem on its own context (no communicator): the single-rank reference ------------------------------
+    gctx = mf.Context(0)
+    gb = mf.Brick(x_len, n, order, itg, ctx=gctx)
+    gA = gb.pattern(F)
+    m0, m1, m2 = gb.m
+    pl = m1 * m2
+    ncp = m0 * pl
+    if F == 1:
+        gK = gb.assemble_thermal(gA, K_COND, H, TENV, 0x3F)
+        gs = torch.full((gA.n,), SRC, dtype=torch.float64, device=dev)
+        gR = gb.residual_thermal(torch.zeros(gA.n, dtype=torch.float64, device=dev), K_COND, H, TENV, 0x3F, s=gs)
+    else:
+        gK = gb.assemble_elasticity(gA, LAM, MU, TAU, mf.FACE_BITS["x0"])
+        gR = gb.residual_elasticity(torch.zeros(gA.n, dtype=torch.float64, device=dev), LAM, MU, TAU, mf.FACE_BITS["x0"],
+                                    mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.3))
+    g_d = mf.jacobi_by_diagonal(gA, gK).cpu().numpy()
+    g_dc = mf.jacobi2_by_column(gA, gK).cpu().numpy()
+    g_shadow = mf.FEM_rand(8 * gA.n, 0x5EED, 7, ctx=gctx)  # shadow vectors of BiCGStab / IDR(8): the SAME global vectors on every layout
+
+    def gsolve(sv, **kw):
+        sh = g_shadow[:gA.n] if sv == mf.bicgstabl_GS_ else g_shadow if sv == mf.idrs_ else None
+        return mf.iterative_Solve(gA, gK, gR, 1e-11, Sv_func=sv, maxiter=4000, max_pass=3, shadow=sh, **kw)
+
+    # ---- this rank's slab -----------------------------------------------------------------------------------------------
+    ctx = mf.Context(0)
+    sb = mf.Brick(x_len, n, order, itg, ctx=ctx)
+    lo, hi = par.slab_planes(m0, world, rank, order)
+    sb.set_slab(lo, hi)
+    A = sb.pattern(F)
+    n_owned = (hi - lo) * pl
+    nloc = par.local_vector_length(lo, hi, m1, m2, F, order)
+    assert A.n == F * n_owned and A.ncols == (nloc if world > 1 and (lo > 0 or hi < m0) else A.n), (A.n, A.ncols, nloc)
+    comm = par.HostSlabComm(ctx, sb, rank, world, n_fields=F, poison=True)
+    if F == 1:
+        K = sb.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+        s_loc = torch.full((nloc,), SRC, dtype=torch.float64, device=dev)
+        R = sb.residual_thermal(torch.zeros(nloc, dtype=torch.float64, device=dev), K_COND, H, TENV, 0x3F, s=s_loc)
+    else:
+        K = sb.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+        R = sb.residual_elasticity(torch.zeros(nloc, dtype=torch.float64, device=dev), LAM, MU, TAU, mf.FACE_BITS["x0"],
+                                   mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.3))
+
+    def owned(gvec):  # the entries of a global field-major vector this rank owns, in local order
+        gvec = np.asarray(gvec)
+        return np.concatenate([gvec[f * ncp + lo * pl:f * ncp + hi * pl] for f in range(F)])
+
+    def expected_local(gvec):  # [owned | ghosts] with the ghost blocks this rank's neighbours fill
+        gvec = np.asarray(gvec)
+        out = np.full(nloc, np.nan)
+        out[:F * n_owned] = owned(gvec)
+        jj, kk = np.meshgrid(np.arange(m1), np.arange(m2), indexing="ij")
+        for f in range(F):
+            for i in list(range(max(lo - order, 0), lo)) + list(range(hi, min(hi + order, m0))):
+                li = par.slab_local_index(np.full(jj.size, i), jj.ravel(), kk.ravel(), f, lo, hi, m1, m2, F, order)
+                out[li] = gvec[f * ncp + i * pl + jj.ravel() * m2 + kk.ravel()]
+        return out
+
+    assert np.array_equal(R.cpu().numpy(), owned(gR.cpu().numpy())), "slab residual differs from the global rows"
+
+    # ---- halo exchange: ghost planes bitwise equal to the neighbours' planes ------------------------------------------
+    gv = np.random.default_rng(5).standard_normal(F * ncp)
+    exp = expected_local(gv)
+    xl = torch.full((nloc,), -7.0, dtype=torch.float64, device=dev)
+    xl[:F * n_owned] = torch.tensor(owned(gv), device=dev)
+    comm.halo_(xl)
+    got = xl.cpu().numpy()
+    filled = ~np.isnan(exp)
+    check("halo_ghost_planes_bitwise", np.array_equal(got[filled], exp[filled]), unreferenced=int((~filled).sum()))
+
+    # ---- Jacobi vectors: |diag| with halo, column norms with reverse halo -------------------------------------------------
+    d = mf.jacobi_by_diagonal(A, K)
+    comm.halo_(d)
+    dl = d.cpu().numpy()
+    e = expected_local(g_d)
+    check("jacobi_diag_with_halo_bitwise", np.array_equal(dl[filled], e[filled]))
+    dc = mf.jacobi2_by_column(A, K).cpu().numpy()
+    e = expected_local(g_dc)
+    err = np.abs(dc[filled] - e[filled]).max() / np.abs(e[filled]).max()
+    check("jacobi_colnorm_is_global", err < 1e-14, rel_err=err)
+
+    # ---- all-reduce of device scalars -----------------------------------------------------------------------------------
+    t = torch.tensor([1.0 + rank, 0.5], dtype=torch.float64, device=dev)
+    comm.allreduce_(t)
+    check("allreduce", t.cpu().tolist() == [world * (world + 1) / 2.0, 0.5 * world])
+
+    # ---- the solvers -------------------------------------------------------------------------------------------------------
+    shadow_loc = {mf.bicgstabl_GS_: torch.tensor(owned(g_shadow[:gA.n].cpu().numpy()), device=dev),
+                  mf.idrs_: torch.cat([torch.tensor(owned(g_shadow[k * gA.n:(k + 1) * gA.n].cpu().numpy()), device=dev) for k in range(8)])}
+
+    def lsolve(sv, **kw):
+        return mf.iterative_Solve(A, K, R, 1e-11, Sv_func=sv, maxiter=4000, max_pass=3, shadow=shadow_loc.get(sv), **kw)
+
+    def relerr(xl_, xg_):
+        xg_o = owned(xg_.cpu().numpy())
+        scale = np.abs(xg_.cpu().numpy()).max()
+        return float(np.abs(xl_.cpu().numpy() - xg_o).max() / scale)
+
+    sym0 = int(_lib.lib.mfem_debug_sym_spmv_count())
+    for overlap in (1, 0):
+        _lib.lib.mfem_debug_set_halo_overlap(overlap)
+        tag = "overlap" if overlap else "blocking"
+        xg, sg = gsolve(mf.cg_, cg_variant=1)
+        x1, s1 = lsolve(mf.cg_, cg_variant=1)
+        check(f"cg_classic_{tag}", s1.converged == 1 and s1.iterations == sg.iterations and relerr(x1, xg) <= 1e-12,
+              iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
+        x2, s2 = lsolve(mf.cg_)  # auto: single-reduction form with world > 1
+        check(f"cg_single_reduction_{tag}", s2.converged == 1 and abs(s2.iterations - sg.iterations) <= 2 and relerr(x2, xg) <= 1e-10,
+              iters=(s2.iterations, sg.iterations), rel_err=relerr(x2, xg))
+        xg2, sg2 = gsolve(mf.cg_, cg_variant=2)  # the single-reduction form on one rank
+        check(f"cg_single_reduction_one_rank_{tag}", sg2.converged == 1 and relerr(owned_t(xg2, owned, dev), xg) <= 1e-10,
+              iters=(sg2.iterations, sg.iterations))
+    _lib.lib.mfem_debug_set_halo_overlap(1)
+    if case == "thermal_hex8":
+        check("symmetric_sweep_kernel_ran", int(_lib.lib.mfem_debug_sym_spmv_count()) > sym0)
+    for sv, name, s_par in ((mf.bicgstabl_GS_, "bicgstabl2", 2), (mf.idrs_, "idrs8", 8)):
+        for pr, pname in ((mf.Pr_Jacobi_, "diag"), (mf.Pr_Jacobi_colnorm_, "colnorm")):
+            xg, sg = gsolve(sv, s=s_par, Pr_func=pr)
+            x1, s1 = lsolve(sv, s=s_par, Pr_func=pr)
+            # same recurrences on the same shadow vectors: the iterates agree to round-off, so do the iteration counts (+- a few
+            # when the stop test sits on the edge)
+            check(f"{name}_{pname}", s1.converged == 1 and sg.converged == 1 and relerr(x1, xg) <= 1e-8 and
+                  abs(s1.iterations - sg.iterations) <= max(4, sg.iterations // 10),
+                  iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
+    check("callbacks_ran", comm.calls["exchange"] > 10 and comm.calls["allreduce"] > 10, **comm.calls)
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("MULTIRANK_REPORT " + json.dumps(report), flush=True)
+    sys.exit(0 if ok else 1)
+
+
+def owned_t(xg, owned, dev):
+    import torch
+    return torch.tensor(owned(xg.cpu().numpy()), device=dev)
+
+
+if __name__ == "__main__":
+    main()

@@ -38,10 +38,12 @@ def test_spmv_matches_oracle(mf, n, avg, bits, base):
         assert np.max(np.abs(y_t.cpu().numpy() - ref) / scale) < 1e-14
 
 
-@pytest.mark.parametrize("cap", [4032, 2016])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("kind", ["hex8", "hex8x3", "hex27", "quad8", "banded_shift"])
-def test_spmv_window_plan_equals_plain_kernel(mf, kind, cap):
-    """Inspector-executor path (x window in LDS + 16-bit indices) vs the plain CSR kernel vs the oracle."""
+def test_spmv_csr_kernel_variants_equal_oracle(mf, kind, variant):
+    """Every tile variant of the CSR kernel behind mul! (mfem_debug_set_spmv: 0 = row-transposing tile kernel (default), 1-3 =
+    product-tile kernel with different tile sizes) against the oracle, incl. 1-based int32 row pointers, empty rows, odd tile
+    starts and an x longer than n."""
     import torch
     from metafem_jl_amd import _lib
     from oracle import mesh as om, operators as oo, reference_element as re_, solvers
@@ -69,20 +71,19 @@ def test_spmv_window_plan_equals_plain_kernel(mf, kind, cap):
         rowptr, cols, n = pat.rowptr, pat.colidx, pat.n
         base, bits = 0, 64
     vals = rng.standard_normal(rowptr[-1])
-    x = rng.standard_normal(n + 5)  # x longer than n: the window fill must respect max col, not n
+    x = rng.standard_normal(n + 5)  # x longer than n
     ref = solvers.csr(rowptr, cols, vals, n) @ x[:n]
     scale = np.abs(solvers.csr(rowptr, cols, np.abs(vals), n) @ np.abs(x[:n])) + 1e-300
-    out = {}
-    for enable in (1, 0):
-        _lib.lib.mfem_debug_set_spmv_window(enable, cap, 8)
+    _lib.lib.mfem_debug_set_spmv(variant << 16, 0)
+    try:
         A = mf.FEM_SpMat_CSR(torch.tensor(rowptr + base, dtype=torch.int64 if bits == 64 else torch.int32, device="cuda"),
                              torch.tensor(cols + base, dtype=torch.int32, device="cuda"), n, index_base=base)
         y = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
         mf.mul_(y, A, torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda"), 2.0, -1.0)
-        out[enable] = y.cpu().numpy()
-        assert np.max(np.abs(out[enable] - (2.0 * ref - 3.0)) / (2 * scale + 3.0)) < 1e-14
-    _lib.lib.mfem_debug_set_spmv_window(0, 4032, 8)  # library default: plain kernel
-    assert np.max(np.abs(out[1] - out[0]) / (2 * scale + 3.0)) < 1e-14
+        got = y.cpu().numpy()
+    finally:
+        _lib.lib.mfem_debug_set_spmv(0, 0)  # library default
+    assert np.max(np.abs(got - (2.0 * ref - 3.0)) / (2 * scale + 3.0)) < 1e-14
 
 
 def test_spmv_long_rows_fallback(mf):
