@@ -83,9 +83,15 @@ def self_launch(n_ranks: int) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    # stdout carries the JSON line only (RCCL / gloo banners that reached rank 0's stdout go to stderr)
+    lines = out0.decode(errors="replace").splitlines()
+    json_lines = [ln for ln in lines if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in lines:
+        if not json_lines or ln is not json_lines[-1]:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0] + ([] if json_lines else [(0, "no JSON line")])
     if bad:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1

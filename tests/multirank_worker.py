@@ -148,13 +148,17 @@ def main():
         scale = np.abs(xg_.cpu().numpy()).max()
         return float(np.abs(xl_.cpu().numpy() - xg_o).max() / scale)
 
+    # classic CG runs the same recurrence on every layout; what differs between 1 and `world` ranks is the order in which the
+    # partial sums of the dot products are added.  1e-12 of max|x| for the thermal operators; the penalty-constrained
+    # elasticity operator (tau = 1000) is worse conditioned and amplifies that round-off to a few 1e-12.
+    tol_classic = 1e-11 if F == 3 else 1e-12
     sym0 = int(_lib.lib.mfem_debug_sym_spmv_count())
     for overlap in (1, 0):
         _lib.lib.mfem_debug_set_halo_overlap(overlap)
         tag = "overlap" if overlap else "blocking"
         xg, sg = gsolve(mf.cg_, cg_variant=1)
         x1, s1 = lsolve(mf.cg_, cg_variant=1)
-        check(f"cg_classic_{tag}", s1.converged == 1 and s1.iterations == sg.iterations and relerr(x1, xg) <= 1e-12,
+        check(f"cg_classic_{tag}", s1.converged == 1 and s1.iterations == sg.iterations and relerr(x1, xg) <= tol_classic,
               iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
         x2, s2 = lsolve(mf.cg_)  # auto: single-reduction form with world > 1
         check(f"cg_single_reduction_{tag}", s2.converged == 1 and abs(s2.iterations - sg.iterations) <= 2 and relerr(x2, xg) <= 1e-10,
