@@ -63,14 +63,33 @@ __global__ __launch_bounds__(BLK) void k_spmv_lds(
   const int tpr = 1 << tpr_log2;
   double dot_acc = 0.0;
 
+  // the row-pointer pair of a tile is requested one tile ahead: otherwise every tile starts with a dependent HBM round trip
+  // (rowptr -> addresses of the value / column streams) that nothing in the workgroup can hide
+  int64_t s_next = 0, e_next = 0;
+  {
+    const int64_t tile = tile_of(blockIdx.x, ntiles, xcd_aware & 0xFFFF);
+    if (blockIdx.x < ntiles_padded && tile < ntiles) {
+      const int64_t r0 = tile * R, r1 = (r0 + R < n) ? r0 + R : n;
+      s_next = (int64_t)rowptr[r0] - base;
+      e_next = (int64_t)rowptr[r1] - base;
+    }
+  }
   for (int64_t it = blockIdx.x; it < ntiles_padded; it += gridDim.x) {
     const int64_t tile = tile_of(it, ntiles, xcd_aware & 0xFFFF);
+    const int64_t s = s_next, e = e_next;
+    {
+      const int64_t itn = it + gridDim.x;
+      const int64_t tn = tile_of(itn, ntiles, xcd_aware & 0xFFFF);
+      if (itn < ntiles_padded && tn < ntiles) {
+        const int64_t q0 = tn * R, q1 = (q0 + R < n) ? q0 + R : n;
+        s_next = (int64_t)rowptr[q0] - base;
+        e_next = (int64_t)rowptr[q1] - base;
+      }
+    }
     if (tile >= ntiles) continue;  // uniform per workgroup
     const int64_t r0 = tile * R;
     const int64_t r1 = (r0 + R < n) ? r0 + R : n;
     if (spmv_part_skip(part, r0, r1)) continue;  // uniform per workgroup
-    const int64_t s = (int64_t)rowptr[r0] - base;
-    const int64_t e = (int64_t)rowptr[r1] - base;
 
     if (VEC) {
       const int64_t sa = s & ~(int64_t)1;  // 16-byte aligned start (vals/col bases are 16-B aligned)
@@ -179,6 +198,237 @@ __global__ __launch_bounds__(BLK) void k_spmv_lds(
   }
 }
 
+// Row-transposing tile kernel.  The product-tile kernel above gathers x[col] in CSR order: the 128 nonzeros of one wave
+// instruction span ~5 rows x 27 entries, i.e. ~12 different cache lines of x per instruction, and that instruction stream --
+// not bytes -- is what it loses its time on (tools/gather_probe.hip).  Here the tile's val/col streams are staged RAW in LDS
+// (same coalesced 16-byte / 8-byte loads), and after the barrier a lane walks ITS ROW's entries from LDS: the lanes of a wave
+// then hold neighbouring rows at the same position of the row, whose columns are neighbouring entries of x (2-4 cache lines
+// per gather instruction) -- the access order of the slot-major solver layouts, without a copy of the matrix.  tpr lanes
+// share a row (entries lo + g, lo + g + tpr, ...) and combine by sub-wave shuffle; rows of any length (general CSR).
+template <typename RP, int CAP, int BLK, int GU>
+__global__ __launch_bounds__(BLK) void k_spmv_csr_t(
+    int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
+    double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
+  __shared__ __attribute__((aligned(16))) double sv[CAP + 4];
+  __shared__ __attribute__((aligned(16))) int32_t sc[CAP + 4];
+  __shared__ double red[BLK / 64 < 4 ? 4 : BLK / 64];
+  if (done_flag && done_flag[0]) return;
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2;
+  const int g = tid & (tpr - 1);
+  constexpr int LU = (CAP / 2 + BLK - 1) / BLK;  // 16-byte loads per lane that cover a full tile
+  double dot_acc = 0.0;
+  int64_t s_next = 0, e_next = 0;  // row-pointer pair of the next tile, requested one tile ahead
+  if (blockIdx.x < ntiles) {
+    const int64_t r0 = (int64_t)blockIdx.x * R, r1 = (r0 + R < n) ? r0 + R : n;
+    s_next = (int64_t)rowptr[r0] - base;
+    e_next = (int64_t)rowptr[r1] - base;
+  }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * R;
+    const int64_t r1 = (r0 + R < n) ? r0 + R : n;
+    const int64_t s = s_next, e = e_next;
+    if (tile + gridDim.x < ntiles) {
+      const int64_t q0 = (tile + gridDim.x) * R, q1 = (q0 + R < n) ? q0 + R : n;
+      s_next = (int64_t)rowptr[q0] - base;
+      e_next = (int64_t)rowptr[q1] - base;
+    }
+    if (spmv_part_skip(part, r0, r1)) continue;  // uniform per workgroup
+    const int64_t sa = s & ~(int64_t)1;  // 16-byte aligned start (vals / col bases are 16-byte / 8-byte aligned)
+    const int cnt = (int)(e - sa);
+    const int64_t rmine = r0 + (tid >> tpr_log2);
+    int lo_pre = 0, hi_pre = 0;
+    if (rmine < r1) {  // requested now: the latency hides under the tile loads
+      lo_pre = (int)((int64_t)rowptr[rmine] - base - sa);
+      hi_pre = (int)((int64_t)rowptr[rmine + 1] - base - sa);
+    }
+    {
+      d2_t v[LU];
+      i2_t c[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int i = 2 * tid + u * 2 * BLK;
+        v[u] = (d2_t){0.0, 0.0};
+        c[u] = (i2_t){base, base};
+        if (i < cnt) {
+          if (sa + i + 1 < nnz) {
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(vals + sa + i));
+            c[u] = __builtin_nontemporal_load(reinterpret_cast<const i2_t*>(col + sa + i));
+          } else {  // last odd entry of the whole matrix
+            v[u].x = vals[sa + i];
+            c[u].x = col[sa + i];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int i = 2 * tid + u * 2 * BLK;
+        if (i < cnt) {
+          *reinterpret_cast<d2_t*>(&sv[i]) = v[u];
+          *reinterpret_cast<i2_t*>(&sc[i]) = c[u];
+        }
+      }
+    }
+    __syncthreads();
+    for (int64_t r = rmine; r < r1; r += (BLK >> tpr_log2)) {
+      const int lo = (r == rmine) ? lo_pre : (int)((int64_t)rowptr[r] - base - sa);
+      const int hi = (r == rmine) ? hi_pre : (int)((int64_t)rowptr[r + 1] - base - sa);
+      double sum = 0.0;
+      int j = lo + g;
+      for (; j + (GU - 1) * tpr < hi; j += GU * tpr) {
+        double vv[GU], xx[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          vv[u] = sv[j + u * tpr];
+          xx[u] = x[sc[j + u * tpr] - base];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) sum += vv[u] * xx[u];
+      }
+      for (; j < hi; j += tpr) sum += sv[j] * x[sc[j] - base];
+      for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
+      if (g == 0) {
+        double yv = alpha * sum;
+        if (beta != 0.0) yv += beta * y[r];
+        y[r] = yv;
+        if (dotw) dot_acc += yv * dotw[r];
+      }
+    }
+    __syncthreads();
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (tid == 0) partials[blockIdx.x] = b;
+  }
+}
+
+// Wave-private row-transposing tiles.  What bounds the two kernels above is the texture addresser: a 64-lane gather costs
+// ~17 cycles when the lanes read consecutive entries of x and ~100 cycles in CSR order with a nonzero pair per lane (42 distinct
+// cache lines per instruction; tools/ta_probe.hip), i.e. ~1.2 ms of addresser time per SpMV at 256^3.  Here a WAVE owns a run
+// of R = 64 / tpr consecutive rows: it stages their val / col streams raw in its own LDS block (coalesced 16-byte / 8-byte
+// loads, CSR order) and then lane l walks row l / tpr -- with tpr = 1 (rows of <= 31 entries) the 64 lanes of a gather hold
+// the same position of 64 consecutive rows, which for a mesh matrix are consecutive entries of x.  No workgroup barrier, no
+// cross-lane reduction for tpr = 1, y written unit-stride.
+template <typename RP, int CAPW, int WAVES, int NG>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void k_spmv_csr_w(
+    int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
+    double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
+  constexpr int LU = (CAPW / 2 + 63) / 64;  // (16 B + 8 B) loads per lane that cover a full tile
+  // NG = gathers a lane issues up front (rows of up to NG * tpr entries have none left over)
+  __shared__ __attribute__((aligned(16))) double sv_all[WAVES][CAPW + 2];
+  __shared__ __attribute__((aligned(16))) int32_t sc_all[WAVES][CAPW + 4];
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* sv = sv_all[w];
+  int32_t* sc = sc_all[w];
+  const int tpr = 1 << tpr_log2;
+  const int g = lane & (tpr - 1);
+  double dot_acc = 0.0;
+  const int64_t tstride = (int64_t)gridDim.x * WAVES;
+  // x as a buffer resource (byte offsets are 32-bit: the host side uses this kernel only while 8 * columns < 4 GiB)
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0xFFFFFFFF, 0x00020000);
+  // Software pipeline per wave: the tile after the current one sits in registers (requested while the current tile's
+  // gathers were in flight), the row-pointer pair of the tile after that is requested one step earlier still.
+  d2_t pv[LU];
+  i2_t pc[LU];
+  int64_t t_cur = (int64_t)blockIdx.x * WAVES + w;
+  // skip tiles that belong to the other part of a split SpMV (wave-uniform)
+  auto next_tile = [&](int64_t t) -> int64_t {
+    while (t < ntiles && spmv_part_skip(part, t * R, (t * R + R < n) ? t * R + R : n)) t += tstride;
+    return t;
+  };
+  t_cur = next_tile(t_cur);
+  int64_t sa_cur = 0;
+  int cnt_cur = 0, lo_cur = 0, hi_cur = 0;
+  auto uniform64 = [](int64_t v) -> int64_t {  // the value is the same in every lane: keep it in scalar registers
+    const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi32 << 32) | lo32);
+  };
+  auto request = [&](int64_t t, int64_t& sa, int& cnt, int& lo, int& hi) {  // issue the loads of tile t into pv / pc
+    const int64_t r0 = t * R, r1 = (r0 + R < n) ? r0 + R : n;
+    const int64_t s = uniform64((int64_t)rowptr[r0] - base), e = uniform64((int64_t)rowptr[r1] - base);
+    sa = s & ~(int64_t)1;
+    cnt = (int)(e - sa);
+    const int64_t r = r0 + (lane >> tpr_log2);
+    lo = hi = 0;
+    if (r < r1) {
+      lo = (int)((int64_t)rowptr[r] - base - sa);
+      hi = (int)((int64_t)rowptr[r + 1] - base - sa);
+    }
+    // the tile's two streams as bounds-checked buffers (base in scalar registers, one offset register per lane, entries past
+    // the tile's end read as zero): no per-load address pairs, no masks
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(vals + sa), 0, cnt * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(col + sa), 0, cnt * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      pv[u] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(vr, lane * 16, u * 1024, 2));
+      pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
+    }
+  };
+  if (t_cur < ntiles) request(t_cur, sa_cur, cnt_cur, lo_cur, hi_cur);
+  while (t_cur < ntiles) {
+    // ---- the requested tile goes to the wave's LDS block
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = 2 * lane + u * 128;  // < CAPW: entries past the tile's end are zeros nobody reads
+      *reinterpret_cast<d2_t*>(&sv[i]) = pv[u];
+      *reinterpret_cast<i2_t*>(&sc[i]) = pc[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS stores have landed
+    __builtin_amdgcn_wave_barrier();
+    const int64_t r0 = t_cur * R, r1 = (r0 + R < n) ? r0 + R : n;
+    const int64_t r = r0 + (lane >> tpr_log2);
+    const int lo = lo_cur, hi = hi_cur;
+    // ---- all gathers of the lane's row first ...
+    double xx[NG];
+    const int j0 = lo + g;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int j = j0 + u * tpr;
+      xx[u] = 0.0;
+      // buffer form of the load: one 32-bit offset register per gather instead of a 64-bit address pair (28 gathers in flight)
+      if (j < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, (sc[j] - base) * 8, 0, 0));
+    }
+    // ---- ... then the request for the next tile: it returns behind the gathers (loads return in order), so the row sums
+    //      below do not wait for it, and it is in flight while they run
+    const int64_t t_next = next_tile(t_cur + tstride);
+    int64_t sa_n = 0;
+    int cnt_n = 0, lo_n = 0, hi_n = 0;
+    // (the LDS block is still being read below: the next tile stays in registers until the top of the loop)
+    if (t_next < ntiles) request(t_next, sa_n, cnt_n, lo_n, hi_n);
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int j = j0 + u * tpr;
+      sum += (j < hi ? sv[j] : 0.0) * xx[u];
+    }
+    for (int j = j0 + NG * tpr; j < hi; j += tpr) sum += sv[j] * x[sc[j] - base];  // rows longer than NG * tpr entries
+    for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
+    if (g == 0 && r < r1) {
+      double yv = alpha * sum;
+      if (beta != 0.0) yv += beta * y[r];
+      y[r] = yv;
+      if (dotw) dot_acc += yv * dotw[r];
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane is done reading the block before the next tile's stores
+    t_cur = t_next;
+    sa_cur = sa_n;
+    cnt_cur = cnt_n;
+    lo_cur = lo_n;
+    hi_cur = hi_n;
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = b;
+  }
+}
+
 // Fallback for patterns whose longest row does not fit the LDS tile: one wave per row.
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
@@ -215,18 +465,24 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
-// 0: CAP 4032 x4, 1: CAP 4032 x8 (256 threads);  2: CAP 2016 x8, 128 threads;  3: CAP 2016 x8, 64 threads;  7: CAP 1008 x8,
-// 64 threads (wave-private tiles: the barrier degenerates);  4: CAP 4032 x4, 5: CAP 4032 x2 with 512 threads,  6: CAP 4032 x2
-// with 1024 threads (same LDS tile shared by more waves: the tile kernel is LDS-limited to 4 workgroups per CU)
-static int g_spmv_variant = 1;
-static int g_spmv_nogather = 0;   // diagnostic only: replace x[col] by col-derived constants (WRONG results, timing probe)
+static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
+// Kernel variant (bits 16-18 of mfem_debug_set_spmv's first argument):
+//   0 library default
+//   1 product tile, CAP 4032, a nonzero PAIR per lane and load (16-byte / 8-byte loads), 8 pairs in flight, 256 threads
+//   (2, 3: as 1; a product tile with ONE nonzero per lane and load -- gathers over 64 consecutive nonzeros -- measured 1.48-1.58 ms
+//   against 1.19 ms and was removed)
+//   4 row-transposing workgroup tile, CAP 4032, 256 threads
+//   6 wave-private row-transposing tiles (1792 / 2048 entries per wave), 2 waves per workgroup   7 (and 5) the same, 1 wave
+static int g_spmv_variant = 0;
+static int g_spmv_nogather = 0;   // diagnostic only (tools/): replace x[col] by col-derived constants (WRONG results, timing probe)
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
   ++mfem_debug_epoch;
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_nogather = (xcd_aware >> 20) & 1;
-  if (grid_mult > 0) g_spmv_grid_mult = grid_mult;
+  g_spmv_grid_mult_set = grid_mult > 0;
+  g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
 }
 
@@ -408,13 +664,72 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     if (sl != 0) return sl < 0 ? sl : MFEM_OK;
   }
   const int base = A->index_base;
-  const int cap_doubles = (g_spmv_variant == 7 && A->max_row_nnz <= 1008 - 2) ? 1008
-                          : ((g_spmv_variant == 2 || g_spmv_variant == 3) && A->max_row_nnz <= 2016 - 2) ? 2016 : 4032;
+  // default: wave-private row-transposing tiles when a wave's 64 / tpr rows fill its LDS block reasonably (rows of near-uniform
+  // length: 256^3 hex-8 1.06 ms against 1.19 ms); the product tile otherwise (hex-27's 27..125-entry rows fill half a block:
+  // 3.9 ms against 3.5 ms)
+  int variant = g_spmv_variant;
+  if (variant == 0) {
+    variant = 1;
+    if (A->max_row_nnz > 0 && A->max_row_nnz <= 2048 - 2) {
+      int tl = 0;
+      while (tl < 6 && (int64_t)(64 >> tl) * A->max_row_nnz > 1792 - 2) ++tl;
+      const double fill = (double)(64 >> tl) * ((double)A->nnz / (double)A->n) / 1792.0;
+      if (tl <= 3 && fill >= 0.65) variant = 7;
+    }
+  }
   if (A->rows_per_block > 0) {
     const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
-    const int blk = !vec ? MFEM_BLOCK : g_spmv_variant == 6 ? 1024 : (g_spmv_variant == 4 || g_spmv_variant == 5) ? 512
-                    : (g_spmv_variant == 7 && cap_doubles == 1008) ? 64 : (g_spmv_variant == 3 && cap_doubles == 2016) ? 64
-                    : (g_spmv_variant == 2 && cap_doubles == 2016) ? 128 : MFEM_BLOCK;
+    if (vec && variant >= 5 && A->max_row_nnz <= 2048 - 2 && (A->ncols > 0 ? A->ncols : A->n) < ((int64_t)1 << 29)) {
+      // wave-private tiles: R = 64 / tpr rows per wave, tpr the smallest power of two with R * max_row_nnz <= capacity - 2.
+      // 1792 entries per wave (21.5 KB of LDS, 7 waves per CU) unless 2048 (24.6 KB, 6 waves) lets a wave own twice the rows.
+      auto tpr_for = [&](int capw) {
+        int tl = 0;
+        while (tl < 6 && (int64_t)(64 >> tl) * A->max_row_nnz > capw - 2) ++tl;
+        return tl;
+      };
+      const bool big = tpr_for(2048) < tpr_for(1792);
+      const int tl = big ? tpr_for(2048) : tpr_for(1792);
+      const int Rw = 64 >> tl;
+      const int64_t ntw = (A->n + Rw - 1) / Rw;
+      const int waves = variant == 6 ? 2 : 1;
+      // persistent grid = what is resident at once (LDS-limited; other counts leave a ragged last round: 8 per CU measured
+      // 1.43 ms against 1.06 ms with 7 or 14 at 256^3)
+      const int resident = (big ? 6 : 7) / waves;
+      int capw = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult : resident);
+      if (capw > MFEM_MAX_PARTIALS) capw = MFEM_MAX_PARTIALS;
+      if (part.part != 0 && capw > MFEM_MAX_PARTIALS / 2) capw = MFEM_MAX_PARTIALS / 2;
+      if (part.part == 2) {
+        int64_t rows = 0;
+        for (int z = 0; z < part.nz; ++z) rows += part.hi[z] - part.lo[z];
+        const int64_t want = rows / (Rw * waves) + 2 * part.nz + 8;
+        if (want < capw) capw = (int)want;
+      }
+      const int gridw = (int)((ntw + waves - 1) / waves < capw ? (ntw + waves - 1) / waves : capw);
+#define LAUNCH_W(RP, CAPW, WV, NG)                                                                               \
+  hipLaunchKernelGGL((k_spmv_csr_w<RP, CAPW, WV, NG>), dim3(gridw), dim3(64 * WV), 0, ctx->stream, A->n, A->nnz, \
+                     (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, Rw, tl, ntw, dotw, partials, \
+                     done_flag, part)
+#define LAUNCH_WV(RP)                                   \
+  do {                                                  \
+    if (big && waves == 2) LAUNCH_W(RP, 2048, 2, 32);   \
+    else if (big) LAUNCH_W(RP, 2048, 1, 32);            \
+    else if (waves == 2) LAUNCH_W(RP, 1792, 2, 28);     \
+    else LAUNCH_W(RP, 1792, 1, 28);                     \
+  } while (0)
+      if (A->rowptr_bits == 64) LAUNCH_WV(int64_t); else LAUNCH_WV(int32_t);
+#undef LAUNCH_WV
+#undef LAUNCH_W
+      MFEM_CHECK_LAUNCH();
+      if (n_partials && partials) *n_partials = gridw;
+      return MFEM_OK;
+    }
+    const bool transposing = vec && variant >= 4;
+    int cap_doubles = 4032, blk = MFEM_BLOCK;
+    if (vec) switch (variant) {
+        default: break;
+      }
+    while (cap_doubles < 4032 && A->max_row_nnz > cap_doubles - 2) cap_doubles *= 2;  // the longest row must fit the tile
+    if (cap_doubles == 4032 && blk < 128) blk = MFEM_BLOCK;
     int R = blk;
     while (R > 1 && (int64_t)R * A->max_row_nnz > cap_doubles - 2) R >>= 1;
     int tpr_log2 = 0;
@@ -441,20 +756,19 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR, BLK>), dim3(grid), dim3(BLK), 0, ctx->stream, A->n,    \
                      A->nnz, (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2,  \
                      ntiles, ntiles_padded, xcd, dotw, partials, done_flag, part)
-#define LAUNCH_VARIANT(RP)                                                   \
-  do {                                                                       \
-    if (!vec) LAUNCH_LDS(RP, false, 4032, 4, MFEM_BLOCK);                    \
-    else if (cap_doubles == 1008) LAUNCH_LDS(RP, true, 1008, 8, 64);          \
-    else if (cap_doubles == 2016 && g_spmv_variant == 2) LAUNCH_LDS(RP, true, 2016, 8, 128); \
-    else if (cap_doubles == 2016) LAUNCH_LDS(RP, true, 2016, 8, 64);         \
-    else if (g_spmv_variant == 1) LAUNCH_LDS(RP, true, 4032, 8, MFEM_BLOCK); \
-    else if (g_spmv_variant == 4) LAUNCH_LDS(RP, true, 4032, 4, 512);        \
-    else if (g_spmv_variant == 5) LAUNCH_LDS(RP, true, 4032, 2, 512);        \
-    else if (g_spmv_variant == 6) LAUNCH_LDS(RP, true, 4032, 2, 1024);       \
-    else LAUNCH_LDS(RP, true, 4032, 4, MFEM_BLOCK);                          \
+#define LAUNCH_T(RP, CAP, BLK)                                                                              \
+  hipLaunchKernelGGL((k_spmv_csr_t<RP, CAP, BLK, 7>), dim3(grid), dim3(BLK), 0, ctx->stream, A->n, A->nnz,  \
+                     (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2, ntiles, dotw, \
+                     partials, done_flag, part)
+#define LAUNCH_VARIANT(RP)                                                          \
+  do {                                                                              \
+    if (!vec) LAUNCH_LDS(RP, false, 4032, 4, MFEM_BLOCK);                           \
+    else if (transposing) LAUNCH_T(RP, 4032, MFEM_BLOCK);                           \
+    else LAUNCH_LDS(RP, true, 4032, 8, MFEM_BLOCK);                                 \
   } while (0)
     if (A->rowptr_bits == 64) LAUNCH_VARIANT(int64_t); else LAUNCH_VARIANT(int32_t);
 #undef LAUNCH_VARIANT
+#undef LAUNCH_T
 #undef LAUNCH_LDS
     MFEM_CHECK_LAUNCH();
     if (n_partials && partials) *n_partials = grid;
