@@ -360,6 +360,60 @@ int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, const double* i
                       const mfem_var_term* terms, const int32_t* el_g_cpIDs, double* targets, const int32_t* itg_hostIDs,
                       const int32_t* elIDs, int64_t n_threads);
 
+/* ---- fused assembly on unstructured meshes (constant-coefficient terms; new) ------------------------------------------
+ * The generic path above stores every element's physical basis table (update_BasicElements: hex-20 with 27 Gauss points =
+ * 17 KB per element) and re-reads it once per term.  For terms whose coefficient is a constant -- every linear gradient of
+ * the thermal, elasticity, inertia, convection and penalty forms of the example scripts -- these entry points do geometry,
+ * all terms of the integration domain and the scatter in one launch per colour (one launch with atomics): a wave owns an
+ * element (facet), builds J, det, J^-1 and the physical table in LDS and accumulates, per node pair (a, b),
+ *     M_ab[s][s'] = sum_q w_q det_q D^s N_a(q) D^s' N_b(q)      (s = 0 value, 1 + j = d/dx_j)
+ * once; term t then adds coef_t * M_ab[dual_sd_t][base_sd_t] to K at slot(a, b, el; block_t).  Semantics = the sum of
+ * the corresponding _Kval_Basic calls with vals = coef * w (06_FEM_Kernel.jl:28-45; 05_CodeGenerator.jl:52-91), to
+ * round-off.  Works for any classical element the host has reference tables for (itg * itp * (1 + dim) doubles <= 64 KB).
+ * elIDs / facetIDs (optional, ids per index_base): the item each work unit processes, e.g. elements sorted by colour;
+ * n_colours = 0 -> FP64 atomics, else colour_offsets[n_colours + 1] [host] partitions the n_items work units. */
+typedef struct {
+  int32_t dual_sd, base_sd; /* 0 = value, 1 + j = d/dx_j */
+  int32_t block;            /* sparse block u = dual_pos * n_fields + base_pos; terms sorted by block */
+  int32_t reserved;
+  double coef;              /* the constant coefficient, K_params factor included */
+} mfem_const_term;
+int mfem_mesh_assemble_elements(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                const mfem_const_term* terms, const int32_t* sparse_IDs_by_el, int64_t slot_block_stride,
+                                double* K_val, const int32_t* elIDs, int64_t n_items, int32_t n_colours,
+                                const int64_t* colour_offsets);
+/* Row-owner form of the same element assembly (large meshes: scattering a hex-20 elasticity element matrix is 3600
+ * read-modify-writes of 8 bytes, each its own memory sector).  Pass 1 writes the element matrices to a library-owned
+ * element-major scratch (unit-stride stores), pass 2 gives every CSR row (dual field, node) to a wave that walks the node's
+ * adjacency list in ascending element order and adds the contiguous scratch runs at the row's columns: no atomics, no
+ * colours, a fixed summation order (bitwise reproducible), K read and written once, contiguously.  K_val is ACCUMULATED
+ * into (zero it first; facet terms are added by mfem_mesh_assemble_facets before or after).
+ * adj_ptr [ncp + 1], adj [nel * itp]: for every control point the (element * itp + local node id) pairs that reference it,
+ * 0-based, ascending.  A = the pattern of mfem_pattern_build for n_fields fields.  MFEM_ERR_UNSUPPORTED if a row is longer
+ * than 2048 entries or the scratch (nel * itp^2 * blocks * 8 B) exceeds 16 GiB: use mfem_mesh_assemble_elements then. */
+int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                     const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                     const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                     const mfem_const_term* terms, int32_t n_fields, mfem_csr A, const int64_t* adj_ptr,
+                                     const int32_t* adj, const uint16_t* ranks, double* K_val);
+/* ranks [nel * itp * itp] (device, once per pattern): for adjacency entry j = (node i <- element el, local a) and local node
+ * b, the position of node(el, b) among the control points coupled to i -- the column offset inside every field segment of a
+ * row of node i (the role the reference's sparse_IDs_by_el plays for its scatter, read unit-stride by the row-owner pass). */
+int mfem_mesh_row_ranks(mfem_context ctx, int32_t itp, int64_t nel, int64_t ncp, int32_t n_fields, mfem_csr A,
+                        const int64_t* adj_ptr, const int32_t* adj, const int32_t* controlpoint_IDs, int32_t index_base,
+                        uint16_t* ranks);
+/* The same on boundary facets (element_ID, element_eindex as in mfem_update_basic_boundary): the basis of ALL nodes of the
+ * host element evaluated on the face (05_CodeGenerator.jl:175-189), weight = w_q * surface det. */
+int mfem_mesh_assemble_facets(mfem_context ctx, int32_t dim, int32_t itg_b, int32_t itp, int32_t n_face_ids, int64_t n_facets,
+                              int64_t ncp, const double* bdy_ref_itp_vals, const double* bdy_itg_weights,
+                              const double* bdy_tangent_directions, const double* coords, const int32_t* controlpoint_IDs,
+                              const int32_t* element_ID, const int32_t* element_eindex, int32_t index_base, int32_t n_terms,
+                              const mfem_const_term* terms, const int32_t* sparse_IDs_by_el, int64_t slot_block_stride,
+                              double* K_val, const int32_t* facetIDs, int64_t n_items, int32_t n_colours,
+                              const int64_t* colour_offsets);
+
 /* ---- multi-GPU (new; the reference is single-GPU, F6) ------------------------------------ */
 /* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by the host
  * (torch.distributed / MPI / a file).  */

@@ -66,6 +66,10 @@ class VarBatchTerm(C.Structure):
     _fields_ = [("sd", c_int32), ("reserved", c_int32), ("cpID_shift", c_int64), ("x", C.c_void_p)]
 
 
+class ConstTerm(C.Structure):
+    _fields_ = [("dual_sd", c_int32), ("base_sd", c_int32), ("block", c_int32), ("reserved", c_int32), ("coef", c_double)]
+
+
 MAX_BATCH_TERMS = 48
 
 
@@ -148,6 +152,13 @@ SIGNATURES = {
     "mfem_op_kval_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(KvalTerm), P, P, c_int64, c_int64, P, P, P, c_int64]),
     "mfem_op_res_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(ResBatchTerm), P, P, P, P, P, c_int64]),
     "mfem_op_var_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(VarBatchTerm), P, P, P, P, c_int64]),
+    "mfem_mesh_assemble_elements": (c_int, [P, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, c_int32, c_int32,
+                                            C.POINTER(ConstTerm), P, c_int64, P, P, c_int64, c_int32, C.POINTER(c_int64)]),
+    "mfem_mesh_assemble_elements_rows": (c_int, [P, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, c_int32, c_int32,
+                                                 C.POINTER(ConstTerm), c_int32, P, P, P, P, P]),
+    "mfem_mesh_row_ranks": (c_int, [P, c_int32, c_int64, c_int64, c_int32, P, P, P, P, c_int32, P]),
+    "mfem_mesh_assemble_facets": (c_int, [P, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, P, P, P, c_int32,
+                                          c_int32, C.POINTER(ConstTerm), P, c_int64, P, P, c_int64, c_int32, C.POINTER(c_int64)]),
     "mfem_comm_unique_id": (c_int, [P]),
     "mfem_comm_create": (c_int, [P, c_int32, c_int32, P, C.POINTER(P)]),
     "mfem_comm_destroy": (c_int, [P]),

@@ -1,0 +1,511 @@
+// Fused assembly of constant-coefficient bilinear forms on UNSTRUCTURED classical meshes (any cube / simplex element the
+// host hands reference tables for: quad-4/8, hex-8/20/27, tri-3/6, tet-4/10, ...): geometry on the fly + every term of an
+// integration domain + scatter in one launch per colour (or one launch with FP64 atomics).  Replaces, for terms whose
+// coefficient is a constant,
+//   update_BasicElements / update_BasicBoundary + inv_Jac + update_Basic_itgval_1   mesh/unstructured_mesh/4_Update_Integrator.jl:2-154,163-227
+//   the `vals = @. coeff * K_params * w[:, ids]` broadcasts and one _Kval_Basic launch per term    solver/05_CodeGenerator.jl:52-91, 06_FEM_Kernel.jl:28-45
+// The reference stores the physical basis table of every element (hex-20 with 27 Gauss points: 17 KB per element) and
+// re-reads it once per term (21 launches for 3-D elasticity).  Here a WAVE owns an element (or boundary facet):
+//   1. the nodes' coordinates go to the wave's LDS block;
+//   2. J, det, J^-1 (facets: tangents, surface det) per Gauss point from the reference table; the physical table
+//      T[q][a][s] (s = value, d/dx_1.. d/dx_dim) is built in LDS and never leaves it;
+//   3. every node pair (a, b) -- pairs spread over the lanes -- accumulates the small matrix
+//      M_ab[s][s'] = sum_q w_q det_q T[q][a][s] T[q][b][s'], and each term is then  coef * M_ab[dual_s][base_s]:
+//      the q loop runs once per pair, not once per term;
+//   4. the sums of the terms of one sparse block are added to K through the slot table of mfem_pattern_build --
+//      plain read-modify-write inside a colour (no two elements of a colour share a control point), FP64 atomics otherwise.
+#include "common.h"
+
+#define MA_MAX_TERMS 48
+struct ConstTerms {
+  int n;
+  int32_t ds[MA_MAX_TERMS], bs[MA_MAX_TERMS], block[MA_MAX_TERMS];
+  double coef[MA_MAX_TERMS];
+};
+
+struct MeshItems {
+  int itg, itp;
+  int64_t ncp;
+  const double* ref;     // [n_face_ids][itg, itp, 1 + dim]
+  int64_t ref_stride;
+  const double* wq;      // [n_face_ids][itg]
+  int64_t w_stride;
+  const double* tan;     // facets: [n_face_ids][itg, dim, dim - 1]; elements: nullptr
+  int64_t tan_stride;
+  const double* coords;  // SoA
+  const int32_t* cp;     // [itp, nel]
+  const int32_t* host_el;   // facets: element of item h; elements: nullptr
+  const int32_t* eindex;    // facets: local face id of item h
+  const int32_t* order;     // item processed by work unit t (colour order); nullptr = identity
+  int base;
+};
+
+template <int DIM>
+__device__ __forceinline__ double ma_inv(const double (&J)[3][3], double (&I)[3][3]) {
+  if (DIM == 2) {
+    const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    I[0][0] = J[1][1] / det;
+    I[0][1] = -J[0][1] / det;
+    I[1][0] = -J[1][0] / det;
+    I[1][1] = J[0][0] / det;
+    return det;
+  }
+  const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[0][1] * J[1][0] * J[2][2] +
+                     J[0][1] * J[1][2] * J[2][0] + J[0][2] * J[1][0] * J[2][1] - J[0][2] * J[1][1] * J[2][0];
+  I[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det;
+  I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+  I[0][2] = (J[0][1] * J[1][2] - J[1][1] * J[0][2]) / det;
+  I[1][0] = (J[1][2] * J[2][0] - J[2][2] * J[1][0]) / det;
+  I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+  I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+  I[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det;
+  I[2][1] = (J[0][1] * J[2][0] - J[2][1] * J[0][0]) / det;
+  I[2][2] = (J[0][0] * J[1][1] - J[1][0] * J[0][1]) / det;
+  return det;
+}
+
+// S0 = first physical-table slot the terms use (0 value, 1 first derivative), NS = number of consecutive slots from S0:
+// (0, 1 + DIM) everything, (1, DIM) gradients only, (0, 1) values only.
+// OUT: 0 = add into K through the slot table (plain read-modify-write: colour batches), 1 = the same with FP64 atomics,
+//      2 = write the element matrix to an element-major scratch  S[((el * itp + a) * nb + k) * itp + b]  (k = index of the
+//          term run / sparse block): unit-stride stores, read back row by row by k_mesh_gather.
+template <int DIM, int S0, int NS, int OUT>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, ConstTerms T, const int32_t* __restrict__ slots,
+                                                                int64_t block_stride, double* __restrict__ K, int64_t t0,
+                                                                int64_t t1, int nb) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int itg = V.itg, itp = V.itp;
+  // (staging the elements' shared reference table in LDS once per workgroup was measured slower: 1.25 ms against 0.91 ms for
+  // hex-20 elasticity 32^3 -- the table is L2-resident and the extra 17 KB cost a resident workgroup's worth of overlap)
+  const size_t per_wave = (size_t)itg * itp * NS + (size_t)itg * (1 + DIM * DIM) + (size_t)itp * DIM;
+  double* Tt = lds + (size_t)w * per_wave;  // [itg][itp][NS]
+  double* wd = Tt + (size_t)itg * itp * NS;     // [itg]
+  double* Ji = wd + itg;                        // [itg][DIM*DIM]  J^-1
+  double* X = Ji + (size_t)itg * DIM * DIM;     // [itp][DIM]
+  const int64_t t = t0 + (int64_t)blockIdx.x * nw + w;
+  if (t >= t1) return;  // wave-uniform; no workgroup barrier below
+  const int64_t h = V.order ? (int64_t)V.order[t] - V.base : t;
+  const int64_t el = V.host_el ? (int64_t)V.host_el[h] - V.base : h;
+  const int f = V.eindex ? V.eindex[h] - V.base : 0;
+  const double* R = V.ref + (int64_t)f * V.ref_stride;
+  const int32_t* cpe = V.cp + (int64_t)itp * el;
+  for (int i = lane; i < itp * DIM; i += 64) {
+    const int a = i / DIM, d = i - a * DIM;
+    X[i] = V.coords[((int64_t)cpe[a] - V.base) + (int64_t)d * V.ncp];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  // ---- geometry per Gauss point (lane <-> q)
+  for (int q = lane; q < itg; q += 64) {
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int a = 0; a < itp; ++a) {
+#pragma unroll
+      for (int m = 0; m < DIM; ++m) {
+        const double r = R[q + itg * (a + itp * (1 + m))];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) J[i][m] += r * X[a * DIM + i];
+      }
+    }
+    double I[3][3];
+    const double det = ma_inv<DIM>(J, I);
+#pragma unroll
+    for (int m = 0; m < DIM; ++m)
+#pragma unroll
+      for (int s = 0; s < DIM; ++s) Ji[q * DIM * DIM + m * DIM + s] = I[m][s];
+    if (!V.eindex) {
+      wd[q] = V.wq[q] * det;
+    } else {  // surface weight: |J t1 x J t2| (3-D) or |J t1| (2-D)   4_Update_Integrator.jl:163-227
+      const double* Tn = V.tan + (int64_t)f * V.tan_stride;
+      double tg[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+#pragma unroll
+        for (int k = 0; k < DIM - 1; ++k)
+#pragma unroll
+          for (int m = 0; m < DIM; ++m) tg[i][k] += J[i][m] * Tn[q + itg * (m + DIM * k)];
+      double ld;
+      if (DIM == 2) {
+        ld = sqrt(tg[0][0] * tg[0][0] + tg[1][0] * tg[1][0]);
+      } else {
+        const double r0 = tg[1][0] * tg[2][1] - tg[2][0] * tg[1][1];
+        const double r1 = -tg[0][0] * tg[2][1] + tg[2][0] * tg[0][1];
+        const double r2 = tg[0][0] * tg[1][1] - tg[1][0] * tg[0][1];
+        ld = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+      }
+      wd[q] = V.wq[(int64_t)f * V.w_stride + q] * ld;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  // ---- physical table T[q][a][s - S0]  (lane <-> (q, a))
+  for (int i = lane; i < itg * itp; i += 64) {
+    const int q = i % itg, a = i / itg;
+    double* o = Tt + ((size_t)q * itp + a) * NS;
+    if (S0 == 0) o[0] = R[q + itg * a];
+    if (NS > 1 || S0 == 1) {
+      double r[3];
+#pragma unroll
+      for (int m = 0; m < DIM; ++m) r[m] = R[q + itg * (a + itp * (1 + m))];
+#pragma unroll
+      for (int s = 0; s < DIM; ++s) {
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) v += r[m] * Ji[q * DIM * DIM + m * DIM + s];
+        o[(1 - S0) + s] = v;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  // ---- node pairs over the lanes
+  const int npair = itp * itp;
+  for (int p = lane; p < npair; p += 64) {
+    // slot table order: a fastest; scratch order: b fastest (the lanes' stores are unit-stride)
+    const int a = OUT == 2 ? p / itp : p % itp, b = OUT == 2 ? p % itp : p / itp;
+    double M[NS * NS];
+#pragma unroll
+    for (int s = 0; s < NS * NS; ++s) M[s] = 0.0;
+    {
+      const double* ta = Tt + a * NS;  // 32-bit LDS offsets; one pointer bump per Gauss point
+      const double* tb = Tt + b * NS;
+      const int qs = itp * NS;
+#pragma unroll 3
+      for (int q = 0; q < itg; ++q, ta += qs, tb += qs) {
+        const double wq_ = wd[q];
+        double va[NS], vb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          va[s] = ta[s] * wq_;
+          vb[s] = tb[s];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int u = 0; u < NS; ++u) M[s * NS + u] += va[s] * vb[u];
+      }
+    }
+    int i = 0, krun = 0;
+    while (i < T.n) {  // runs of terms with the same sparse block: one accumulate per run
+      const int block = T.block[i];
+      double sum = 0.0;
+      for (; i < T.n && T.block[i] == block; ++i) {
+        const int sel = (T.ds[i] - S0) * NS + (T.bs[i] - S0);  // wave-uniform: a scalar branch, not a select chain
+        double m = 0.0;
+        switch (sel) {
+#define MA_CASE(c) case c: if (c < NS * NS) m = M[c < NS * NS ? c : 0]; break;
+          MA_CASE(0) MA_CASE(1) MA_CASE(2) MA_CASE(3) MA_CASE(4) MA_CASE(5) MA_CASE(6) MA_CASE(7)
+          MA_CASE(8) MA_CASE(9) MA_CASE(10) MA_CASE(11) MA_CASE(12) MA_CASE(13) MA_CASE(14) MA_CASE(15)
+#undef MA_CASE
+          default: break;
+        }
+        sum += T.coef[i] * m;
+      }
+      if (OUT == 2) {
+        K[(((int64_t)el * itp + a) * nb + krun) * itp + b] = sum;
+      } else {
+        double* dst = K + ((int64_t)slots[block * block_stride + (int64_t)npair * el + p] - V.base);
+        if (OUT == 1) atomicAdd(dst, sum); else *dst += sum;
+      }
+      ++krun;
+    }
+  }
+}
+
+static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const ConstTerms& T, const int32_t* slots,
+                     int64_t block_stride, double* K, int64_t n_items, int n_colours, const int64_t* colour_offsets,
+                     int scratch_blocks = 0) {
+  int smin = 1 << 30, smax = -1;
+  for (int i = 0; i < T.n; ++i) {
+    smin = T.ds[i] < smin ? T.ds[i] : smin;
+    smin = T.bs[i] < smin ? T.bs[i] : smin;
+    smax = T.ds[i] > smax ? T.ds[i] : smax;
+    smax = T.bs[i] > smax ? T.bs[i] : smax;
+  }
+  const int mode = smax == 0 ? 2 : smin >= 1 ? 1 : 0;  // values only | gradients only | everything
+  const int NS = mode == 2 ? 1 : mode == 1 ? dim : 1 + dim;
+  const size_t per_wave = sizeof(double) * ((size_t)V.itg * V.itp * NS + (size_t)V.itg * (1 + dim * dim) + (size_t)V.itp * dim);
+  const size_t shared_ref = 0;
+  int waves = 4;
+  while (waves > 1 && shared_ref + per_wave * waves > 64 * 1024) waves >>= 1;
+  MFEM_REQUIRE(shared_ref + per_wave * waves <= 64 * 1024, "element table too large for the fused mesh assembly (about 2 * itg * itp * (1 + dim) doubles must fit 64 KB)");
+  const size_t ldsb = shared_ref + per_wave * waves;
+  const bool atomic = n_colours == 0;
+  const int out_mode = scratch_blocks > 0 ? 2 : atomic ? 1 : 0;
+  const int nbatch = atomic ? 1 : n_colours;
+  for (int c = 0; c < nbatch; ++c) {
+    const int64_t a = atomic ? 0 : colour_offsets[c], b = atomic ? n_items : colour_offsets[c + 1];
+    if (b <= a) continue;
+    const int grid = (int)((b - a + waves - 1) / waves);
+#define MA_LAUNCH(D, S0, NSS, AT)                                                                                      \
+  hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, AT>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots, \
+                     block_stride, K, a, b, scratch_blocks)
+#define MA_MODE(D, AT)                                  \
+  do {                                                  \
+    if (mode == 2) MA_LAUNCH(D, 0, 1, AT);              \
+    else if (mode == 1) MA_LAUNCH(D, 1, D, AT);         \
+    else MA_LAUNCH(D, 0, 1 + D, AT);                    \
+  } while (0)
+#define MA_OUT(D)                                  \
+  do {                                             \
+    if (out_mode == 2) MA_MODE(D, 2);              \
+    else if (out_mode == 1) MA_MODE(D, 1);         \
+    else MA_MODE(D, 0);                            \
+  } while (0)
+    if (dim == 2) MA_OUT(2); else MA_OUT(3);
+#undef MA_OUT
+#undef MA_MODE
+#undef MA_LAUNCH
+    MFEM_CHECK_LAUNCH();
+  }
+  return MFEM_OK;
+}
+
+static int ma_terms(int32_t n_terms, const mfem_const_term* terms, int dim, ConstTerms* out) {
+  MFEM_REQUIRE(n_terms > 0 && n_terms <= MA_MAX_TERMS && terms, "n_terms must be 1..48");
+  out->n = n_terms;
+  for (int i = 0; i < n_terms; ++i) {
+    MFEM_REQUIRE(terms[i].dual_sd >= 0 && terms[i].dual_sd <= dim && terms[i].base_sd >= 0 && terms[i].base_sd <= dim,
+                 "term words: 0 = value, 1 + j = d/dx_j");
+    MFEM_REQUIRE(terms[i].block >= 0 && (i == 0 || terms[i].block >= terms[i - 1].block), "terms must be sorted by block");
+    out->ds[i] = terms[i].dual_sd;
+    out->bs[i] = terms[i].base_sd;
+    out->block[i] = terms[i].block;
+    out->coef[i] = terms[i].coef;
+  }
+  return MFEM_OK;
+}
+
+extern "C" int mfem_mesh_assemble_elements(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                           const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                           const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                           const mfem_const_term* terms, const int32_t* sparse_IDs_by_el,
+                                           int64_t slot_block_stride, double* K_val, const int32_t* elIDs, int64_t n_items,
+                                           int32_t n_colours, const int64_t* colour_offsets) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+  MFEM_REQUIRE(itg > 0 && itp > 0 && nel >= 0 && ncp > 0 && n_items >= 0 && n_items <= nel, "bad sizes");
+  MFEM_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  MFEM_REQUIRE(n_colours >= 0 && (n_colours == 0 || colour_offsets), "colour_offsets missing");
+  if (n_items == 0) return MFEM_OK;
+  MFEM_REQUIRE(ref_itp_vals && itg_weight && coords && controlpoint_IDs && sparse_IDs_by_el && K_val, "null array");
+  MFEM_REQUIRE(n_colours == 0 || (colour_offsets[0] == 0 && colour_offsets[n_colours] == n_items), "colour_offsets must span the items");
+  ConstTerms T;
+  int rc = ma_terms(n_terms, terms, dim, &T);
+  if (rc) return rc;
+  MeshItems V{itg, itp, ncp, ref_itp_vals, 0, itg_weight, 0, nullptr, 0, coords, controlpoint_IDs, nullptr, nullptr, elIDs, index_base};
+  return ma_launch(ctx, dim, V, T, sparse_IDs_by_el, slot_block_stride, K_val, n_items, n_colours, colour_offsets);
+}
+
+// ---- row-owner form of the scatter -----------------------------------------------------------------------------------
+// Scattering an element matrix entry by entry is what the assembly of a large mesh spends its time on (hex-20 elasticity:
+// 3600 read-modify-writes of 8 bytes per element, each its own 64-byte sector).  Row-owner form: the element matrices go to
+// the element-major scratch (unit-stride stores), then a wave owns one CSR row (dual field fd, node i): it stages the row's
+// column list in LDS, walks the node's adjacency list (element, local id a) in ascending element order and, for every block
+// (fd, fb), adds the itp contiguous scratch entries  S[el][a][k][0 .. itp)  at the positions of the columns
+// fb * ncp + node(el, b) (binary search in the staged list) -- distinct positions within a step, steps in sequence: no
+// atomics, a fixed summation order (bitwise reproducible), every K entry read and written once, contiguously.
+#define MG_MAXROW 2048
+struct GatherBlocks {
+  int nf;          // fields
+  int nb;          // blocks in the scratch (runs of the term list)
+  int cnt[4];      // blocks with dual field fd
+  int k[4][4];     // their scratch index
+  int fb[4][4];    // their base field
+};
+
+// ranks[(j * itp) + b] = position of node(el, b) among the control points coupled to node i (ascending ids = the order of
+// the columns inside every field segment of a row of node i), for adjacency entry j = (i <- el, a).  Once per pattern.
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_row_ranks(int itp, int64_t ncp, int nf, const RP* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ colidx, int cbase,
+                                                                 const int64_t* __restrict__ adj_ptr, const int32_t* __restrict__ adj,
+                                                                 const int32_t* __restrict__ cp, int base, uint16_t* __restrict__ ranks) {
+  const int64_t total = adj_ptr[ncp] * itp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t j = t / itp;
+    const int b = (int)(t - j * itp);
+    const int32_t ea = adj[j];
+    const int64_t el = ea / itp;
+    const int a = ea - (int)el * itp;
+    const int64_t node = (int64_t)cp[el * itp + a] - base;
+    const int64_t lo = (int64_t)rowptr[node] - cbase;  // row (field 0, node): its first len / nf columns are field 0's
+    const int L = (int)(((int64_t)rowptr[node + 1] - cbase - lo) / nf);
+    const int32_t col = (int32_t)((int64_t)cp[el * itp + b] - base);
+    int l = 0, h = L - 1;
+    while (l < h) {
+      const int mid = (l + h) >> 1;
+      if (colidx[lo + mid] - cbase < col) l = mid + 1; else h = mid;
+    }
+    ranks[t] = (uint16_t)l;
+  }
+}
+
+extern "C" int mfem_mesh_row_ranks(mfem_context ctx, int32_t itp, int64_t nel, int64_t ncp, int32_t n_fields, mfem_csr A,
+                                   const int64_t* adj_ptr, const int32_t* adj, const int32_t* controlpoint_IDs,
+                                   int32_t index_base, uint16_t* ranks) {
+  MFEM_REQUIRE(ctx && A && adj_ptr && adj && controlpoint_IDs && ranks, "null argument");
+  MFEM_REQUIRE(itp > 0 && nel >= 0 && ncp > 0 && n_fields >= 1 && n_fields <= 4, "bad sizes");
+  MFEM_REQUIRE(A->n == (int64_t)n_fields * ncp, "pattern rows != n_fields * ncp");
+  MFEM_REQUIRE(A->max_row_nnz / n_fields < 65536, "more than 65535 coupled control points per row");
+  if (nel == 0) return MFEM_OK;
+  const int grid = mfem_grid_for(nel * itp * (int64_t)itp, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_mesh_row_ranks<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, itp, ncp, n_fields,
+                       (const int64_t*)A->rowptr, A->colidx, A->index_base, adj_ptr, adj, controlpoint_IDs, index_base, ranks);
+  else
+    hipLaunchKernelGGL(k_mesh_row_ranks<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, itp, ncp, n_fields,
+                       (const int32_t*)A->rowptr, A->colidx, A->index_base, adj_ptr, adj, controlpoint_IDs, index_base, ranks);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_gather(int itp, int64_t ncp, GatherBlocks B, const RP* __restrict__ rowptr,
+                                                              int cbase, const int64_t* __restrict__ adj_ptr,
+                                                              const int32_t* __restrict__ adj, const uint16_t* __restrict__ ranks,
+                                                              const double* __restrict__ S, double* __restrict__ K, int maxrow) {
+  extern __shared__ double gl[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double* vals = gl + (size_t)w * maxrow;
+  const int64_t nrows = (int64_t)B.nf * ncp;
+  for (int64_t r = (int64_t)blockIdx.x * nw + w; r < nrows; r += (int64_t)gridDim.x * nw) {
+    const int fd = (int)(r / ncp);
+    const int64_t node = r - (int64_t)fd * ncp;
+    const int64_t lo = (int64_t)rowptr[r] - cbase;
+    const int len = (int)((int64_t)rowptr[r + 1] - cbase - lo);
+    const int L = len / B.nf;  // columns per field segment
+    for (int t = lane; t < len; t += 64) vals[t] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const int nblk = B.cnt[fd];
+    const int work = nblk * itp;  // (block, b) pairs of one adjacency entry
+    // the scratch runs and ranks of up to 8 adjacency entries are requested before the first is used: a row waits for
+    // memory once per 8 elements, not once per element (a corner node of a hex mesh has 8)
+    const int64_t j0 = adj_ptr[node], j1 = adj_ptr[node + 1];
+    for (int64_t jb = j0; jb < j1; jb += 8) {
+      const int nj = (int)(j1 - jb < 8 ? j1 - jb : 8);
+      for (int u0 = 0; u0 < work; u0 += 64) {
+        const int u = u0 + lane;
+        const bool on = u < work;
+        const int kk = on ? u / itp : 0, b = on ? u - kk * itp : 0;
+        const int seg = B.fb[fd][kk] * L;
+        double v[8];
+        int pos[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          v[t] = 0.0;
+          pos[t] = 0;
+          if (t < nj && on) {
+            const int32_t ea = adj[jb + t];
+            const int64_t el = ea / itp;
+            const int a = ea - (int)el * itp;
+            v[t] = S[(((int64_t)el * itp + a) * B.nb + B.k[fd][kk]) * itp + b];
+            pos[t] = seg + ranks[(jb + t) * itp + b];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < nj) {  // wave-uniform; within a step the lanes hit distinct positions, the steps run in sequence
+            if (on) vals[pos[t]] += v[t];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    }
+    for (int t = lane; t < len; t += 64) K[lo + t] += vals[t];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                                const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                                const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                                const mfem_const_term* terms, int32_t n_fields, mfem_csr A,
+                                                const int64_t* adj_ptr, const int32_t* adj, const uint16_t* ranks,
+                                                double* K_val) {
+  MFEM_REQUIRE(ctx && A, "null handle");
+  MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+  MFEM_REQUIRE(itg > 0 && itp > 0 && nel >= 0 && ncp > 0, "bad sizes");
+  MFEM_REQUIRE(n_fields >= 1 && n_fields <= 4, "1..4 fields");
+  MFEM_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  MFEM_REQUIRE(A->n == (int64_t)n_fields * ncp, "pattern rows != n_fields * ncp");
+  if (nel == 0) return MFEM_OK;
+  MFEM_REQUIRE(ref_itp_vals && itg_weight && coords && controlpoint_IDs && adj_ptr && adj && ranks && K_val, "null array");
+  if (A->max_row_nnz > MG_MAXROW) {
+    mfem_set_error("rows of up to %d entries: the row-owner assembly stages a row in LDS (<= %d); use mfem_mesh_assemble_elements", A->max_row_nnz, MG_MAXROW);
+    return MFEM_ERR_UNSUPPORTED;
+  }
+  ConstTerms T;
+  int rc = ma_terms(n_terms, terms, dim, &T);
+  if (rc) return rc;
+  GatherBlocks B;
+  memset(&B, 0, sizeof(B));
+  B.nf = n_fields;
+  for (int i = 0; i < T.n; ++i) {
+    if (i > 0 && T.block[i] == T.block[i - 1]) continue;
+    const int fd = T.block[i] / n_fields, fb = T.block[i] % n_fields;
+    MFEM_REQUIRE(fd < n_fields, "block out of range");
+    B.k[fd][B.cnt[fd]] = B.nb;
+    B.fb[fd][B.cnt[fd]] = fb;
+    ++B.cnt[fd];
+    ++B.nb;
+  }
+  const size_t bytes = sizeof(double) * (size_t)nel * itp * B.nb * itp;
+  if (bytes > ((size_t)16 << 30)) {
+    mfem_set_error("element-matrix scratch of %zu bytes exceeds the 16 GiB budget; use mfem_mesh_assemble_elements", bytes);
+    return MFEM_ERR_UNSUPPORTED;
+  }
+  rc = mfem_ws_reserve(ctx, bytes);
+  if (rc) return rc;
+  double* S = (double*)ctx->ws;
+  MeshItems V{itg, itp, ncp, ref_itp_vals, 0, itg_weight, 0, nullptr, 0, coords, controlpoint_IDs, nullptr, nullptr, nullptr, index_base};
+  rc = ma_launch(ctx, dim, V, T, nullptr, 0, S, nel, 0, nullptr, B.nb);
+  if (rc) return rc;
+  const int64_t nrows = (int64_t)n_fields * ncp;
+  const int maxrow = (A->max_row_nnz + 15) & ~15;
+  const int waves = 4;
+  const size_t ldsb = sizeof(double) * (size_t)maxrow * waves;
+  const int grid = mfem_grid_for(nrows, waves, ctx->num_cus * 32);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_mesh_gather<int64_t>, dim3(grid), dim3(64 * waves), ldsb, ctx->stream, itp, ncp, B, (const int64_t*)A->rowptr,
+                       A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow);
+  else
+    hipLaunchKernelGGL(k_mesh_gather<int32_t>, dim3(grid), dim3(64 * waves), ldsb, ctx->stream, itp, ncp, B, (const int32_t*)A->rowptr,
+                       A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
+extern "C" int mfem_mesh_assemble_facets(mfem_context ctx, int32_t dim, int32_t itg_b, int32_t itp, int32_t n_face_ids,
+                                         int64_t n_facets, int64_t ncp, const double* bdy_ref_itp_vals,
+                                         const double* bdy_itg_weights, const double* bdy_tangent_directions,
+                                         const double* coords, const int32_t* controlpoint_IDs, const int32_t* element_ID,
+                                         const int32_t* element_eindex, int32_t index_base, int32_t n_terms,
+                                         const mfem_const_term* terms, const int32_t* sparse_IDs_by_el,
+                                         int64_t slot_block_stride, double* K_val, const int32_t* facetIDs, int64_t n_items,
+                                         int32_t n_colours, const int64_t* colour_offsets) {
+  MFEM_REQUIRE(ctx, "null ctx");
+  MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+  MFEM_REQUIRE(itg_b > 0 && itp > 0 && n_face_ids > 0 && n_facets >= 0 && ncp > 0 && n_items >= 0 && n_items <= n_facets, "bad sizes");
+  MFEM_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  MFEM_REQUIRE(n_colours >= 0 && (n_colours == 0 || colour_offsets), "colour_offsets missing");
+  if (n_items == 0) return MFEM_OK;
+  MFEM_REQUIRE(bdy_ref_itp_vals && bdy_itg_weights && bdy_tangent_directions && coords && controlpoint_IDs && element_ID &&
+                   element_eindex && sparse_IDs_by_el && K_val, "null array");
+  MFEM_REQUIRE(n_colours == 0 || (colour_offsets[0] == 0 && colour_offsets[n_colours] == n_items), "colour_offsets must span the items");
+  ConstTerms T;
+  int rc = ma_terms(n_terms, terms, dim, &T);
+  if (rc) return rc;
+  const int64_t rs = (int64_t)itg_b * itp * (1 + dim), ts = (int64_t)itg_b * dim * (dim - 1);
+  MeshItems V{itg_b, itp, ncp, bdy_ref_itp_vals, rs, bdy_itg_weights, (int64_t)itg_b, bdy_tangent_directions, ts, coords,
+              controlpoint_IDs, element_ID, element_eindex, facetIDs, index_base};
+  return ma_launch(ctx, dim, V, T, sparse_IDs_by_el, slot_block_stride, K_val, n_items, n_colours, colour_offsets);
+}

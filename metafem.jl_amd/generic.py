@@ -56,12 +56,43 @@ class WeakForm:
         return {(g.dual_pos, g.base_pos) for g in self.linear_gradients + self.nonlinear_gradients}
 
 
+class _NeedsEnv(Exception):
+    pass
+
+
+class _NoEnv(dict):
+    """Probe environment: a coefficient function that reads any inner variable / external / normal is not a constant."""
+
+    def __getitem__(self, key):
+        raise _NeedsEnv(key)
+
+    def get(self, key, default=None):
+        raise _NeedsEnv(key)
+
+
+def constant_coefficient(fn) -> Optional[float]:
+    """The value of a term's coefficient if it does not depend on the integration point, else None."""
+    try:
+        v = fn(_NoEnv())
+    except _NeedsEnv:
+        return None
+    except Exception:
+        return None
+    if torch.is_tensor(v) or isinstance(v, np.ndarray):
+        return None
+    try:
+        return float(v)
+    except Exception:
+        return None
+
+
 class _Group:
     """Integration hosts of one launch family (the elements, or the facets of one boundary group)."""
 
-    def __init__(self, vals, weights, host_ids, el_ids, itg, normals=None, colour_offsets=None):
+    def __init__(self, vals, weights, host_ids, el_ids, itg, normals=None, colour_offsets=None, facet_el=None, facet_eidx=None):
         self.vals, self.weights, self.host_ids, self.el_ids, self.itg = vals, weights, host_ids, el_ids, itg
         self.normals, self.colour_offsets = normals, colour_offsets
+        self.facet_el, self.facet_eidx = facet_el, facet_eidx  # boundary groups: element / local face id of every facet
         self.n = el_ids.numel()
 
 
@@ -71,7 +102,7 @@ class GenericDomain:
     def __init__(self, ctx, space, coords: np.ndarray, cp_ids: np.ndarray, n_fields: int, domain_wf: WeakForm,
                  boundaries: Sequence[Tuple[np.ndarray, np.ndarray, WeakForm]],
                  element_colours: Optional[np.ndarray] = None, max_time_level: int = 0, dissipative: bool = True,
-                 batched: bool = True):
+                 batched: bool = True, fused: bool = True, row_owner: bool = True):
         """coords [ncp, dim]; cp_ids [itp, nel] 0-based (controlpoint_IDs in basis order); boundaries =
         [(element_ID[nf], element_eindex[nf] 0-based local face ids, WeakForm)].  element_colours (optional):
         a colour per element such that same-colour elements share no control point -> atomics-free scatter with a fixed
@@ -81,6 +112,12 @@ class GenericDomain:
         # batched = True: one mfem_op_*_batch launch per integration domain; False: one launch per term, the literal
         # call sequence of the reference's generated updaters (kept for parity tests of the single-term seam)
         self.batched = batched
+        # fused = True: linear-gradient terms with constant coefficients go through mfem_mesh_assemble_elements / _facets
+        # (geometry on the fly, all such terms of a domain in one launch); the other terms keep the operator path
+        self.fused = fused
+        # row_owner = True: the fused element assembly runs in its row-owner form (mfem_mesh_assemble_elements_rows: element
+        # matrices -> scratch -> one wave per CSR row; no atomics, fixed summation order); False: scatter through the slot table
+        self.row_owner = row_owner
         dev = f"cuda:{ctx.device}"
         self.dev = dev
         dim = space.dim
@@ -96,6 +133,11 @@ class GenericDomain:
         # ---- update_Mesh
         nsd = 1 + dim
         ref = f64(space.ref_itp_vals.ravel(order="F"))
+        self._ref, self._itgw = ref, f64(space.itg_weight)
+        # adjacency of the row-owner assembly: for every control point the (element * itp + local id) pairs, ascending
+        flat = np.ascontiguousarray(cp_ids.T).ravel()
+        self._adj = i32(np.argsort(flat, kind="stable"))
+        self._adj_ptr = torch.tensor(np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=ncp))]), dtype=torch.int64, device=dev)
         vals = torch.empty(space.itg * itp * nsd * nel, dtype=torch.float64, device=dev)
         w = torch.empty(space.itg * nel, dtype=torch.float64, device=dev)
         check(lib.mfem_update_basic_elements(ctx._h, dim, space.itg, itp, nel, ncp, ref.data_ptr(), f64(space.itg_weight).data_ptr(),
@@ -118,6 +160,7 @@ class GenericDomain:
         bref = f64(np.concatenate([space.bdy_ref_itp_vals[f].ravel(order="F") for f in range(nface)]))
         bw = f64(space.bdy_itg_weights.ravel())
         btan = f64(np.concatenate([space.bdy_tangent_directions[f].ravel(order="F") for f in range(nface)]))
+        self._bref, self._bw, self._btan, self._nface = bref, bw, btan, nface
         for el, eidx, _ in boundaries:
             nf = len(el)
             fv = torch.empty(space.itg_b * itp * nsd * nf, dtype=torch.float64, device=dev)
@@ -135,10 +178,11 @@ class GenericDomain:
                 foffs = np.concatenate([[0], np.cumsum(np.bincount(fcol, minlength=int(fcol.max()) + 1))])
                 host = i32(forder + 1)
                 self.groups.append(_Group(fv, fw, host, i32(np.asarray(el)[forder] + 1), space.itg_b,
-                                          normals=fn.view(nf, dim, space.itg_b), colour_offsets=foffs))
+                                          normals=fn.view(nf, dim, space.itg_b), colour_offsets=foffs, facet_el=eld, facet_eidx=eid))
                 continue
             host = i32(np.arange(nf) + 1)
-            self.groups.append(_Group(fv, fw, host, eld, space.itg_b, normals=fn.view(nf, dim, space.itg_b)))
+            self.groups.append(_Group(fv, fw, host, eld, space.itg_b, normals=fn.view(nf, dim, space.itg_b), facet_el=eld,
+                                      facet_eidx=eid))
         # ---- assemble_Global_Variables!
         from . import assemble_SparseID  # late import: package root defines it
 
@@ -269,19 +313,70 @@ class GenericDomain:
         for wf, g in zip(self.bwfs, self.groups[1:]):
             yield wf, g
 
+    def _row_ranks(self) -> torch.Tensor:
+        """Column ranks of the row-owner assembly (mfem_mesh_row_ranks), built on first use."""
+        if getattr(self, "_ranks", None) is None:
+            self._ranks = torch.empty(self.nel * self.itp * self.itp, dtype=torch.int16, device=self.dev)
+            check(lib.mfem_mesh_row_ranks(self.ctx._h, self.itp, self.nel, self.ncp, self.n_fields, self.A._h, self._adj_ptr.data_ptr(),
+                                          self._adj.data_ptr(), self.cp.data_ptr(), 1, self._ranks.data_ptr()))
+        return self._ranks
+
+    def _assemble_const(self, g: _Group, cterms, K: torch.Tensor):
+        """cterms: [(GradTerm, coefficient)] -> one fused launch per colour (mfem_mesh_assemble_elements / _facets)."""
+        cterms = sorted(cterms, key=lambda tc: tc[0].dual_pos * self.n_fields + tc[0].base_pos)
+        offs = g.colour_offsets
+        ncol = 0 if offs is None else len(offs) - 1
+        carr = None if offs is None else (C.c_int64 * len(offs))(*[int(v) for v in offs])
+        stride = self.nel * self.itp * self.itp
+        for c0 in range(0, len(cterms), _lib.MAX_BATCH_TERMS):
+            chunk = cterms[c0:c0 + _lib.MAX_BATCH_TERMS]
+            arr = (_lib.ConstTerm * len(chunk))(*[_lib.ConstTerm(t.dual_s, t.base_s, t.dual_pos * self.n_fields + t.base_pos, 0,
+                                                                 c * self.K_params[t.td_order]) for t, c in chunk])
+            if g.facet_el is None and self.row_owner:
+                rc = lib.mfem_mesh_assemble_elements_rows(self.ctx._h, self.dim, self.space.itg, self.itp, self.nel, self.ncp,
+                                                          self._ref.data_ptr(), self._itgw.data_ptr(), self.coords.data_ptr(),
+                                                          self.cp.data_ptr(), 1, len(chunk), arr, self.n_fields, self.A._h,
+                                                          self._adj_ptr.data_ptr(), self._adj.data_ptr(), self._row_ranks().data_ptr(),
+                                                          K.data_ptr())
+                if rc == 0:
+                    continue
+                if rc != -3:  # MFEM_ERR_UNSUPPORTED (row too long / scratch too large) falls back to the scatter form
+                    check(rc)
+            if g.facet_el is None:
+                check(lib.mfem_mesh_assemble_elements(self.ctx._h, self.dim, self.space.itg, self.itp, self.nel, self.ncp,
+                                                      self._ref.data_ptr(), self._itgw.data_ptr(), self.coords.data_ptr(),
+                                                      self.cp.data_ptr(), 1, len(chunk), arr, self.slots.data_ptr(), stride,
+                                                      K.data_ptr(), g.host_ids.data_ptr(), g.n, ncol, carr))
+            else:
+                check(lib.mfem_mesh_assemble_facets(self.ctx._h, self.dim, self.space.itg_b, self.itp, self._nface,
+                                                    g.facet_el.numel(), self.ncp, self._bref.data_ptr(), self._bw.data_ptr(),
+                                                    self._btan.data_ptr(), self.coords.data_ptr(), self.cp.data_ptr(),
+                                                    g.facet_el.data_ptr(), g.facet_eidx.data_ptr(), 1, len(chunk), arr,
+                                                    self.slots.data_ptr(), stride, K.data_ptr(), g.host_ids.data_ptr(), g.n, ncol,
+                                                    carr))
+
     # -- generated updater bodies -------------------------------------------------------------------
     def K_linear_func(self):
         self.K_linear.zero_()
         for wf, g in self._parts():
             if not wf.linear_gradients:
                 continue
+            terms = wf.linear_gradients
+            if self.fused:
+                coefs = [constant_coefficient(t.fn) for t in terms]
+                cterms = [(t, c) for t, c in zip(terms, coefs) if c is not None]
+                terms = [t for t, c in zip(terms, coefs) if c is None]
+                if cterms:
+                    self._assemble_const(g, cterms, self.K_linear)
+                if not terms:
+                    continue
             env: dict = {}
             self._externals(wf, g, env)
             w = self._w(g)
             if self.batched:
-                self._kval_many(g, wf.linear_gradients, env, w, self.K_linear)
+                self._kval_many(g, terms, env, w, self.K_linear)
                 continue
-            for t in wf.linear_gradients:
+            for t in terms:
                 self._kval(g, t, self._vals(t.fn, env, w, self.K_params[t.td_order]), self.K_linear)
 
     def K_nonlinear_func(self):

