@@ -539,7 +539,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, d
 // identical) and leave as contiguous runs, every CSR value written exactly once -- no memset, no atomics, no colours.
 #define EL2_NODES 32
 #define EL2_ROW 244  // 3 fields x 81 slots, padded
-__global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix_lds(BrickView B, double lam, double mu, double tau,
+__global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_elasticity_matrix_lds(BrickView B, double lam, double mu, double tau,
                                                                         uint32_t penalty, int64_t T, double* __restrict__ vals) {
   __shared__ double rows[EL2_NODES * EL2_ROW];
   __shared__ int64_t s_pre[EL2_NODES];
@@ -600,19 +600,37 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix_lds(BrickView 
   double* R = rows + nl * EL2_ROW;  // [field fi][block fk * cn + slot]
   for (int ph = 0; ph < 8; ++ph) {
     if (valid && e == ph) {
+      // the entries of NB neighbours are read together and written together: one LDS round trip per batch instead of a chain
+      // of dependent read-modify-writes (the compiler cannot reorder them itself: dynamic indices).  Same order of additions
+      // per entry as before: distinct neighbours hit distinct entries.
+      constexpr int NB = 2;
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
-        const int slot = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
-        const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
+      for (int b0 = 0; b0 < 8; b0 += NB) {
+        double cur[NB][3][3];
+        int slot[NB];
 #pragma unroll
-        for (int fi = 0; fi < 3; ++fi)
+        for (int u = 0; u < NB; ++u) {
+          const int b = b0 + u;
+          const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
+          slot[u] = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
 #pragma unroll
-          for (int fk = 0; fk < 3; ++fk) {
-            double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
-            if (fi == fk) v += mu * tr;
-            R[fi * 81 + fk * cn + slot] -= v;
-          }
+          for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+            for (int fk = 0; fk < 3; ++fk) cur[u][fi][fk] = R[fi * 81 + fk * cn + slot[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int b = b0 + u;
+          const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
+#pragma unroll
+          for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+            for (int fk = 0; fk < 3; ++fk) {
+              double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
+              if (fi == fk) v += mu * tr;
+              R[fi * 81 + fk * cn + slot[u]] = cur[u][fi][fk] - v;
+            }
+        }
       }
     }
     __syncthreads();
