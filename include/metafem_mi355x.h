@@ -137,6 +137,9 @@ int mfem_debug_set_hex27(int two_pass);
 /* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
  * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
 int mfem_debug_set_elasticity(int variant);
+/* hex-8 thermal matrix / residual kernels: 0 (default) the plane-sweep kernels with sum-factorised element integration
+ * (2- and 3-point Gauss rules; other rules always use the tile kernels); 1 the 4 x 4 x 8 tile kernels with the table form. */
+int mfem_debug_set_hex8_thermal(int variant);
 /* Per-launch timing of the solver's SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */
 int mfem_prof_spmv_enable(mfem_context ctx, int on);

@@ -142,6 +142,7 @@ SIGNATURES = {
     "mfem_debug_set_graphs": (c_int, [c_int, c_int64]),
     "mfem_debug_set_ell": (c_int, [c_int]),
     "mfem_debug_set_elasticity": (c_int, [c_int]),
+    "mfem_debug_set_hex8_thermal": (c_int, [c_int]),
     "mfem_debug_set_sell": (c_int, [c_int]),
     "mfem_debug_set_vec_grid": (c_int, [c_int]),
     "mfem_debug_set_layout_min_rows": (c_int, [c_int64, c_int64]),

@@ -12,6 +12,7 @@
 // exactly once (the algorithmic minimum).  Thermal rows are staged in LDS and leave the CU as one
 // contiguous, fully coalesced stream per workgroup.
 #include "brick.h"
+#include "hex8_sumfac.h"
 
 // reference-cell tables for the tensor hex-8 on [0,1]^3 (spatial_discretization/102_Interpolations.jl:30-39,
 // 103_Integrations.jl:1-19): index [q][b], q = qx + ng*(qy + ng*qz) (x fastest), b = bx + 2*by + 4*bz.
@@ -308,15 +309,35 @@ __global__ __launch_bounds__(TT_THREADS) void k_thermal_matrix(BrickView B, doub
       }
 }
 
-// Robin faces: h*Bilinear(T, Tenv - T) contributes -h N_a N_b (3D_Script.jl:31).  One thread per control point; only
-// boundary points do work; a point read-modify-writes its OWN row (row owner => race-free), after k_thermal_matrix.
+// Boundary control points of the owned planes, enumerated compactly: blockIdx.y = owned plane, thread t of the plane = a point of
+// the whole plane on the first / last lattice plane, else a point of the plane's rim (2 m2 + 2 (m1 - 2) points).
+__device__ __forceinline__ bool boundary_point(const BrickView& B, int& i, int& j, int& k) {
+  i = B.plo + (int)blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 || i == B.ne0) {
+    if (t >= B.plane_len) return false;
+    j = (int)(t / B.m2);
+    k = (int)(t % B.m2);
+    return true;
+  }
+  if (t >= 2 * (int64_t)B.m2 + 2 * (int64_t)(B.m1 - 2)) return false;
+  if (t < 2 * (int64_t)B.m2) {
+    j = t < B.m2 ? 0 : B.ne1;
+    k = (int)(t < B.m2 ? t : t - B.m2);
+  } else {
+    const int u = (int)(t - 2 * (int64_t)B.m2);
+    j = 1 + (u >> 1);
+    k = (u & 1) ? B.ne2 : 0;
+  }
+  return true;
+}
+
+// Robin faces: h*Bilinear(T, Tenv - T) contributes -h N_a N_b (3D_Script.jl:31).  One thread per BOUNDARY control point, which
+// read-modify-writes its OWN row (row owner => race-free), after the matrix kernel.
 __global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix_robin(BrickView B, double h, uint32_t robin,
                                                                        double* __restrict__ vals) {
-  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= B.n_owned) return;
   int i, j, k;
-  node_ijk(B, node, i, j, k);
-  if (i != 0 && i != B.ne0 && j != 0 && j != B.ne1 && k != 0 && k != B.ne2) return;
+  if (!boundary_point(B, i, j, k)) return;
   const int li = B.lo0[i], lj = B.lo1[j], lk = B.lo2[k];
   const int cj = B.c1[j], ck = B.c2[k];
   double* row = vals + brick_prefix(B, i, j, k);
@@ -333,6 +354,59 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix_robin(BrickView B
 #pragma unroll
     for (int c = 0; c < 4; ++c) row[((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk)] += mab[c];
   });
+}
+
+// Robin face terms of the residual at an owned control point: sum_q w^s N_a h (Tenv - T)
+__device__ __forceinline__ double thermal_robin_residual(const BrickView& B, int i, int j, int k, double h, double Tenv,
+                                                         uint32_t robin, const double* __restrict__ x) {
+  double r = 0.0;
+  const int idx[3] = {i, j, k};
+  const int ne[3] = {B.ne0, B.ne1, B.ne2};
+  for (int nd = 0; nd < 3; ++nd) {
+    for (int side = 0; side < 2; ++side) {
+      const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
+      if (!on || !(robin & face_bit(nd, side))) continue;
+      const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+      for (int f = 0; f < 4; ++f) {
+        const int f1 = f & 1, f2 = f >> 1;
+        int E1 = idx[t1] - 1 + f1, E2 = idx[t2] - 1 + f2;
+        if (E1 < 0 || E1 >= ne[t1] || E2 < 0 || E2 >= ne[t2]) continue;
+        const int ca = (1 - f1) + 2 * (1 - f2);
+        double Xf[4][3], Tf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          int fn[3];
+          fn[nd] = idx[nd];
+          fn[t1] = E1 + (c & 1);
+          fn[t2] = E2 + (c >> 1);
+          const int64_t ci = brick_cindex(B, fn[0], fn[1], fn[2]);
+          Xf[c][0] = B.X0[ci];
+          Xf[c][1] = B.X1[ci];
+          Xf[c][2] = B.X2[ci];
+          Tf[c] = x[brick_xindex(B, 0, fn[0], fn[1], fn[2])];
+        }
+        for (int q = 0; q < B.ng * B.ng; ++q) {
+          const double ws = face_geom(Xf, q, side == 0, nullptr);
+          double na = 0.0, Tq = 0.0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            na = (c == ca) ? c_fN[q][c] : na;
+            Tq += c_fN[q][c] * Tf[c];
+          }
+          r += ws * na * h * (Tenv - Tq);
+        }
+      }
+    }
+  }
+  return r;
+}
+
+// the same terms as a kernel of their own over the boundary control points (after the sweep residual kernel)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_residual_robin(BrickView B, double h, double Tenv, uint32_t robin,
+                                                                         const double* __restrict__ x, double* __restrict__ res) {
+  int i, j, k;
+  if (!boundary_point(B, i, j, k)) return;
+  res[(int64_t)(i - B.plo) * B.plane_len + (int64_t)j * B.m2 + k] += thermal_robin_residual(B, i, j, k, h, Tenv, robin, x);
 }
 
 // =================================================================================================
@@ -395,47 +469,264 @@ __global__ __launch_bounds__(TT_THREADS) void k_thermal_residual(BrickView B, do
     const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
     r += Fe[((li + ex) * (TT_EJ * TT_EK) + (lj + ey) * TT_EK + (lk + ez)) * 9 + a];
   }
-  if (h != 0.0 && robin != 0u) {
-    const int idx[3] = {i, j, k};
-    const int ne[3] = {B.ne0, B.ne1, B.ne2};
-    for (int nd = 0; nd < 3; ++nd) {
-      for (int side = 0; side < 2; ++side) {
-        const bool on = side == 0 ? (idx[nd] == 0) : (idx[nd] == ne[nd]);
-        if (!on || !(robin & face_bit(nd, side))) continue;
-        const int t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
-        for (int f = 0; f < 4; ++f) {
-          const int f1 = f & 1, f2 = f >> 1;
-          int E1 = idx[t1] - 1 + f1, E2 = idx[t2] - 1 + f2;
-          if (E1 < 0 || E1 >= ne[t1] || E2 < 0 || E2 >= ne[t2]) continue;
-          const int ca = (1 - f1) + 2 * (1 - f2);
-          double Xf[4][3], Tf[4];
+  if (h != 0.0 && robin != 0u) r += thermal_robin_residual(B, i, j, k, h, Tenv, robin, x);
+  res[node] = r;
+}
+
+
+// =================================================================================================
+// Sweep form of the two thermal kernels (default for 2- and 3-point Gauss rules).
+// A workgroup of 256 threads owns a 15 x 15 tile of control points in (j, k) and sweeps it through a segment of lattice
+// planes along i.  Per element plane I (the elements between node planes I and I + 1):
+//   phase A  thread <-> element of the 16 x 16 element tile: the element's upper four nodes are loaded (the lower four are
+//            last step's upper ones, kept in registers), the element is integrated with the sum-factorised routines of
+//            hex8_sumfac.h and its fe[8] / 36 unique Ke entries go to LDS;
+//   phase B  thread <-> control point: the point of node plane I adds the four elements above it to what it carried over
+//            from the four elements below (element plane I - 1) and writes its residual entry / its <= 27 CSR values once;
+//            the same four elements' contributions to the point above it (node plane I + 1) become the next carry.
+// Element evaluations per control point: 256 / 225 x (L + 1) / L = 1.17 (L = 32 planes per segment) against 1.76 for the
+// 4 x 4 x 8 tiles, each at ~40 % of the table form's arithmetic.  Row-owner as before: no atomics, no colours, every value
+// written once; the sums over the shared elements of a mirrored pair of entries run in the same order, so the matrix stays
+// bitwise symmetric (the symmetric-sweep SpMV depends on that).
+// =================================================================================================
+#define SW_E 16
+#define SW_N (SW_E - 1)
+#define SW_THREADS (SW_E * SW_E)
+#define SW_KSTRIDE 37
+
+struct SweepTile {
+  int tj0, tk0, i0, i1;
+};
+__device__ __forceinline__ SweepTile sweep_tile(const BrickView& B, int L) {
+  const int ntk = (B.m2 + SW_N - 1) / SW_N, ntj = (B.m1 + SW_N - 1) / SW_N;
+  SweepTile t;
+  t.tk0 = (int)(blockIdx.x % ntk) * SW_N;
+  t.tj0 = (int)((blockIdx.x / ntk) % ntj) * SW_N;
+  t.i0 = B.plo + (int)(blockIdx.x / (ntk * ntj)) * L;
+  t.i1 = min(t.i0 + L, B.phi);
+  return t;
+}
+// the four nodes (J + by, K + bz) of lattice plane ip -> slot [bx] of the element's nodal arrays
+__device__ __forceinline__ void sweep_load_coords(const BrickView& B, int ip, int J, int K, int bx, double (&X)[3][2][4]) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            int fn[3];
-            fn[nd] = idx[nd];
-            fn[t1] = E1 + (c & 1);
-            fn[t2] = E2 + (c >> 1);
-            const int64_t ci = brick_cindex(B, fn[0], fn[1], fn[2]);
-            Xf[c][0] = B.X0[ci];
-            Xf[c][1] = B.X1[ci];
-            Xf[c][2] = B.X2[ci];
-            Tf[c] = x[brick_xindex(B, 0, fn[0], fn[1], fn[2])];
+  for (int c = 0; c < 4; ++c) {
+    const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+    X[0][bx][c] = B.X0[ci];
+    X[1][bx][c] = B.X1[ci];
+    X[2][bx][c] = B.X2[ci];
+  }
+}
+
+template <int NG>
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_residual_sweep(BrickView B, int L, double kcond, const double* __restrict__ x,
+                                                                         const double* __restrict__ src,
+                                                                         double* __restrict__ res) {
+  __shared__ double Fe[SW_THREADS * 9];
+  const int tid = threadIdx.x, ek = tid % SW_E, ej = tid / SW_E;
+  const SweepTile T = sweep_tile(B, L);
+  if (T.i0 >= T.i1) return;
+  const int J = T.tj0 - 1 + ej, K = T.tk0 - 1 + ek;  // phase A: this thread's element column
+  const bool el_ok = J >= 0 && J < B.ne1 && K >= 0 && K < B.ne2;
+  const int j = T.tj0 + ej, k = T.tk0 + ek;          // phase B: this thread's control point column
+  const bool nd_ok = ej < SW_N && ek < SW_N && j < B.m1 && k < B.m2;
+  const bool has_src = src != nullptr;
+  // nodal data of lattice plane ip at the element's four (j, k) corners
+  double Xn[3][4], Tq[4], Sq[4];  // the plane requested last (consumed at the top of the next step)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) Sq[c] = 0.0;
+  auto request = [&](int ip) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+      Xn[0][c] = B.X0[ci];
+      Xn[1][c] = B.X1[ci];
+      Xn[2][c] = B.X2[ci];
+      const int64_t xi = brick_xindex(B, 0, ip, J + (c & 1), K + (c >> 1));
+      Tq[c] = x[xi];
+      if (has_src) Sq[c] = src[xi];
+    }
+  };
+  double X[3][2][4], Tn[2][4], Sn[2][4];
+  const int Ifirst = max(T.i0 - 1, 0), Ilast = min(T.i1 - 1, B.ne0 - 1);  // element planes of this segment
+  if (el_ok) {
+    request(Ifirst);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      X[0][1][c] = Xn[0][c]; X[1][1][c] = Xn[1][c]; X[2][1][c] = Xn[2][c];
+      Tn[1][c] = Tq[c]; Sn[1][c] = Sq[c];
+    }
+    request(Ifirst + 1);
+  }
+  double carry = 0.0;
+  for (int I = T.i0 - 1; I < T.i1; ++I) {
+    const bool plane = I >= 0 && I < B.ne0;  // workgroup-uniform
+    if (plane && el_ok) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // last step's upper nodes are this step's lower ones; the requested plane arrives
+        X[0][0][c] = X[0][1][c]; X[1][0][c] = X[1][1][c]; X[2][0][c] = X[2][1][c];
+        Tn[0][c] = Tn[1][c]; Sn[0][c] = Sn[1][c];
+        X[0][1][c] = Xn[0][c]; X[1][1][c] = Xn[1][c]; X[2][1][c] = Xn[2][c];
+        Tn[1][c] = Tq[c]; Sn[1][c] = Sq[c];
+      }
+      double fe[2][4];
+      sf_thermal_fe<NG>(X, Tn, Sn, has_src, kcond, fe);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        Fe[tid * 9 + 2 * c] = fe[0][c];
+        Fe[tid * 9 + 2 * c + 1] = fe[1][c];
+      }
+      if (I < Ilast) request(I + 2);  // in flight during phase B and the two barriers
+    }
+    __syncthreads();
+    if (nd_ok) {
+      double lo = 0.0, up = 0.0;
+      if (plane) {
+#pragma unroll
+        for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+          for (int ey = 0; ey < 2; ++ey) {
+            const int Jn = j - 1 + ey, Kn = k - 1 + ez;
+            if (Jn < 0 || Jn >= B.ne1 || Kn < 0 || Kn >= B.ne2) continue;
+            const double* f = Fe + ((ej + ey) * SW_E + ek + ez) * 9 + 2 * ((1 - ey) + 2 * (1 - ez));
+            lo += f[0];
+            up += f[1];
           }
-          for (int q = 0; q < B.ng * B.ng; ++q) {
-            const double ws = face_geom(Xf, q, side == 0, nullptr);
-            double na = 0.0, Tq = 0.0;
+      }
+      if (I >= T.i0) res[(int64_t)(I - B.plo) * B.plane_len + (int64_t)j * B.m2 + k] = carry + lo;
+      carry = up;
+    }
+    __syncthreads();
+  }
+}
+
+template <int NG>
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals) {
+  __shared__ double Ke[SW_THREADS * SW_KSTRIDE];
+  const int tid = threadIdx.x, ek = tid % SW_E, ej = tid / SW_E;
+  const SweepTile T = sweep_tile(B, L);
+  if (T.i0 >= T.i1) return;
+  const int J = T.tj0 - 1 + ej, K = T.tk0 - 1 + ek;
+  const bool el_ok = J >= 0 && J < B.ne1 && K >= 0 && K < B.ne2;
+  const int j = T.tj0 + ej, k = T.tk0 + ek;
+  const bool nd_ok = ej < SW_N && ek < SW_N && j < B.m1 && k < B.m2;
+  int lj0 = 0, lk0 = 0, cj = 1, ck = 1;
+  if (nd_ok) {
+    lj0 = B.lo1[j];
+    lk0 = B.lo2[k];
+    cj = B.c1[j];
+    ck = B.c2[k];
+  }
+  const bool jk_inner = nd_ok && j > 0 && j < B.ne1 && k > 0 && k < B.ne2;  // all nine in-plane neighbours exist
+  double Xn[3][4];
+  auto request = [&](int ip) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              na = (c == ca) ? c_fN[q][c] : na;
-              Tq += c_fN[q][c] * Tf[c];
+    for (int c = 0; c < 4; ++c) {
+      const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+      Xn[0][c] = B.X0[ci];
+      Xn[1][c] = B.X1[ci];
+      Xn[2][c] = B.X2[ci];
+    }
+  };
+  double X[3][2][4];
+  const int Ifirst = max(T.i0 - 1, 0), Ilast = min(T.i1 - 1, B.ne0 - 1);
+  if (el_ok) {
+    request(Ifirst);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      X[0][1][c] = Xn[0][c]; X[1][1][c] = Xn[1][c]; X[2][1][c] = Xn[2][c];
+    }
+    request(Ifirst + 1);
+  }
+  double carry[18];
+#pragma unroll
+  for (int t = 0; t < 18; ++t) carry[t] = 0.0;
+  for (int I = T.i0 - 1; I < T.i1; ++I) {
+    const bool plane = I >= 0 && I < B.ne0;
+    if (plane && el_ok) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X[0][0][c] = X[0][1][c]; X[1][0][c] = X[1][1][c]; X[2][0][c] = X[2][1][c];
+        X[0][1][c] = Xn[0][c]; X[1][1][c] = Xn[1][c]; X[2][1][c] = Xn[2][c];
+      }
+      double k36[36];
+      sf_thermal_ke<NG>(X, kcond, k36);
+#pragma unroll
+      for (int t = 0; t < 36; ++t) Ke[tid * SW_KSTRIDE + t] = k36[t];
+      if (I < Ilast) request(I + 2);
+    }
+    __syncthreads();
+    if (nd_ok) {
+      // now[bx * 9 + dj * 3 + dk]: entries of this plane's point towards node plane I + bx; up[...]: entries of the point above it
+      // (node plane I + 1) towards node plane I + bx
+      double now[18], up[18];
+#pragma unroll
+      for (int t = 0; t < 18; ++t) now[t] = up[t] = 0.0;
+      if (plane) {
+#pragma unroll
+        for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+          for (int ey = 0; ey < 2; ++ey) {
+            const int Jn = j - 1 + ey, Kn = k - 1 + ez;
+            if (Jn < 0 || Jn >= B.ne1 || Kn < 0 || Kn >= B.ne2) continue;
+            const double* ke = Ke + ((ej + ey) * SW_E + ek + ez) * SW_KSTRIDE;
+            const int a0 = 2 * (1 - ey) + 4 * (1 - ez);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+              const int slot = (b & 1) * 9 + (ey + ((b >> 1) & 1)) * 3 + ez + (b >> 2);
+              now[slot] += ke[sym36(a0, b)];
+              up[slot] += ke[sym36(a0 + 1, b)];
             }
-            r += ws * na * h * (Tenv - Tq);
           }
+      }
+      if (I >= T.i0) {
+        double* row = vals + brick_prefix(B, I, j, k);
+        if (jk_inner && I > 0 && I < B.ne0) {  // the full 27-entry row is one contiguous run in (di, dj, dk) order
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            row[t] = carry[t];
+            row[9 + t] = carry[9 + t] + now[t];
+            row[18 + t] = now[9 + t];
+          }
+        } else {
+          const int li0 = B.lo0[I];
+#pragma unroll
+          for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+              for (int dk = 0; dk < 3; ++dk) {
+                const int ni = I - 1 + di, nj = j - 1 + dj, nk = k - 1 + dk;
+                if (ni < 0 || ni >= B.m0 || nj < 0 || nj >= B.m1 || nk < 0 || nk >= B.m2) continue;
+                const int t = dj * 3 + dk;
+                const double v = di == 0 ? carry[t] : di == 1 ? carry[9 + t] + now[t] : now[9 + t];
+                row[((ni - li0) * cj + (nj - lj0)) * ck + (nk - lk0)] = v;
+              }
         }
       }
+#pragma unroll
+      for (int t = 0; t < 18; ++t) carry[t] = up[t];
     }
+    __syncthreads();
   }
-  res[node] = r;
+}
+
+static dim3 boundary_grid(const mfem_brick_s* m) {  // boundary_point(): a plane's worth of threads per owned plane
+  return dim3((unsigned)((m->plane_len + MFEM_BLOCK - 1) / MFEM_BLOCK), (unsigned)(m->phi - m->plo));
+}
+static int g_thermal_variant = 0;  // 1: the 4 x 4 x 8 tile kernels for every Gauss order (kept: 1- and 4-point rules use them)
+extern "C" int mfem_debug_set_hex8_thermal(int variant) {
+  ++mfem_debug_epoch;
+  g_thermal_variant = variant ? 1 : 0;
+  return MFEM_OK;
+}
+// planes per sweep segment: 32, shorter when the (j, k) tiles alone cannot fill the chip
+static int sweep_planes(const mfem_brick_s* m, int64_t* grid) {
+  const int64_t ntj = (m->m[1] + SW_N - 1) / SW_N, ntk = (m->m[2] + SW_N - 1) / SW_N;
+  const int planes = m->phi - m->plo;
+  int L = 32;
+  while (L > 4 && ntj * ntk * ((planes + L - 1) / L) < 2048) L /= 2;
+  *grid = ntj * ntk * ((planes + L - 1) / L);
+  return L;
 }
 
 
@@ -768,12 +1059,20 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
-  const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
-  hipLaunchKernelGGL(k_thermal_matrix, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, vals);
+  if (g_thermal_variant == 0 && (m->ng == 2 || m->ng == 3)) {
+    int64_t grid;
+    const int L = sweep_planes(m, &grid);
+    if (m->ng == 2)
+      hipLaunchKernelGGL(k_thermal_matrix_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals);
+    else
+      hipLaunchKernelGGL(k_thermal_matrix_sweep<3>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals);
+  } else {
+    const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
+    hipLaunchKernelGGL(k_thermal_matrix, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, vals);
+  }
   MFEM_CHECK_LAUNCH();
   if (p->h != 0.0 && p->robin_faces != 0u) {
-    const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
-    hipLaunchKernelGGL(k_thermal_matrix_robin, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->h, p->robin_faces, vals);
+    hipLaunchKernelGGL(k_thermal_matrix_robin, boundary_grid(m), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->h, p->robin_faces, vals);
     MFEM_CHECK_LAUNCH();
   }
   return MFEM_OK;
@@ -786,9 +1085,25 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
-  const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
-  hipLaunchKernelGGL(k_thermal_residual, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, p->h,
-                     p->Tenv, p->robin_faces, x_star, s, residue);
+  if (g_thermal_variant == 0 && (m->ng == 2 || m->ng == 3)) {
+    int64_t grid;
+    const int L = sweep_planes(m, &grid);
+    if (m->ng == 2)
+      hipLaunchKernelGGL(k_thermal_residual_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, x_star, s,
+                         residue);
+    else
+      hipLaunchKernelGGL(k_thermal_residual_sweep<3>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, x_star, s,
+                         residue);
+    if (p->h != 0.0 && p->robin_faces != 0u) {
+      MFEM_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_thermal_residual_robin, boundary_grid(m), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->h, p->Tenv, p->robin_faces,
+                         x_star, residue);
+    }
+  } else {
+    const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
+    hipLaunchKernelGGL(k_thermal_residual, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, p->h,
+                       p->Tenv, p->robin_faces, x_star, s, residue);
+  }
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
 }

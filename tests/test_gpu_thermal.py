@@ -125,3 +125,38 @@ def test_cg_fixed_iterations_mode(mf):
     b = torch.ones(A.n, dtype=torch.float64, device="cuda")
     _, st = mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=37, max_pass=1, fixed_iterations=True)
     assert st.iterations == 37 and st.passes == 1 and st.spmv_count == 37 + 2
+
+
+@pytest.mark.parametrize("n,itg", [((9, 33, 17), 3), ((4, 16, 31), 3), ((3, 17, 5), 5)])
+def test_sweep_kernels_equal_tile_kernels_and_keep_K_bitwise_symmetric(mf, n, itg):
+    """The plane-sweep kernels (sum-factorised element integration, several (j, k) tiles and i segments) against the 4 x 4 x 8
+    tile kernels with the stored-table arithmetic on a distorted brick; K must stay bitwise symmetric (the symmetric-sweep
+    SpMV mirrors its lower diagonals only after checking exactly that)."""
+    import torch
+    import scipy.sparse as sp
+    from metafem_jl_amd import _lib
+
+    x = (1.0, 2.0, 1.5)
+    brick = mf.make_Brick(x, n, 1, itg)
+    rng = np.random.default_rng(3)
+    for d in range(3):
+        c = brick.coords_view(d)
+        c.add_(torch.tensor(0.2 * min(x[i] / n[i] for i in range(3)) * (rng.random(c.numel()) - 0.5), device="cuda"))
+    A = brick.pattern(1)
+    xs = torch.tensor(300.0 + 20.0 * rng.standard_normal(A.n), device="cuda")
+    s = torch.tensor(SRC * (1.0 + 0.1 * rng.standard_normal(A.n)), device="cuda")
+    out = {}
+    try:
+        for variant in (1, 0):
+            _lib.lib.mfem_debug_set_hex8_thermal(variant)
+            K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F).cpu().numpy()
+            R = brick.residual_thermal(xs, K_COND, H, TENV, 0x3F, s=s).cpu().numpy()
+            R0 = brick.residual_thermal(xs, K_COND, H, TENV, 0x3F).cpu().numpy()  # no source vector
+            out[variant] = (K, R, R0)
+    finally:
+        _lib.lib.mfem_debug_set_hex8_thermal(0)
+    for got, ref in zip(out[0], out[1]):
+        assert np.max(np.abs(got - ref)) <= 2e-13 * np.max(np.abs(ref))
+    M = sp.csr_matrix((out[0][0], A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=(A.n, A.n))
+    D = (M - M.T).tocoo()
+    assert D.nnz == 0 or np.max(np.abs(D.data)) == 0.0
