@@ -131,6 +131,15 @@ struct mfem_csr_s {
   int sym_bound;            // 1 = the bound values passed the bitwise symmetry check of this bind
   int64_t sym_mx, sym_myz;  // matrix entries per chunk the sweep kernel takes from LDS: previous-plane diagonals / in-chunk -y, -z
   int ell_bound_mode;       // 0 none, 1 slot-major with explicit columns, 2 diagonal-slotted
+  // wave-private (j, k)-patch form of the symmetric sweep (spmv_ell.hip: k_spmv_symp): symp_state 0 = not inspected, -1 = no, 1 = structure ok
+  int symp_state;
+  int symp_m1, symp_m2;     // lattice lines per plane, points per line
+  int64_t symp_PL;          // rows per lattice plane (m1 * m2)
+  int symp_p0, symp_p1;     // regular lattice planes [p0, p1) (plane = row / PL): the rows the sweep computes
+  int symp_NS, symp_NPk;    // strips of 4 lines, patches of 32 points per line
+  double* symp_vals;        // not owned (solver workspace, behind ell_vals): [plane - p0][patch][27][128]
+  int symp_bound;           // 1 = the bound values passed the bitwise symmetry check of the mirrored pairs
+  int64_t symp_pairs;       // value pairs (16 bytes) one SpMV of the sweep reads from memory (accounting)
   // row-sorted sliced ELL for rows of uneven length (spmv_sell.hip): sell_state 0 = not planned, -1 = no, 1 = ready
   int sell_state;
   int64_t sell_total, sell_nblk;

@@ -43,7 +43,8 @@ static int g_dia_enable = 1;
 // runs; 8: 2 rows x3 without that sharing; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
 static int g_dia_variant = 0;
 static int g_dia_block = MFEM_BLOCK;  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
-static int g_dia_sym = 1;      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernel off
+static int g_dia_sym = 1;      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernels off
+static int g_dia_symp = 1;     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
 static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
@@ -57,6 +58,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_dia_variant = (enable >> 16) & 15;
   g_dia_xcd = (enable >> 20) & 3;
   g_dia_sym = ((enable >> 22) & 1) ? 0 : 1;
+  g_dia_symp = ((enable >> 23) & 1) ? 0 : 1;
   g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks; bit 21: timing probe without x loads
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
@@ -338,7 +340,8 @@ template <int RPT, int U, bool TRIPLES>
 __device__ __forceinline__ void dia_rows(int64_t r, int64_t n, int64_t npad, int K, const DiaOffsets& O,
                                          const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
                                          const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y,
-                                         double alpha, double beta, const double* __restrict__ dotw, int xcd, double& dot_acc) {
+                                         double alpha, double beta, const double* __restrict__ dotw, int xcd, double& dot_acc,
+                                         int64_t skip_lo = 0, int64_t skip_hi = 0) {  // rows in [skip_lo, skip_hi) belong to another launch
   constexpr int H = RPT / 2;  // 16-byte pairs per lane
   const double* v = vals + ell_base(r, K);
   e_d2 acc[H];
@@ -427,19 +430,20 @@ __device__ __forceinline__ void dia_rows(int64_t r, int64_t n, int64_t npad, int
     const int64_t rr = r + 2 * h;
     if (rr >= n) break;
     double y0 = alpha * acc[h].x, y1 = alpha * acc[h].y;
-    const bool two = rr + 1 < n;
+    const bool one = rr < skip_lo || rr >= skip_hi;
+    const bool two = rr + 1 < n && (rr + 1 < skip_lo || rr + 1 >= skip_hi);
     if (beta != 0.0) {
-      y0 += beta * y[rr];
+      if (one) y0 += beta * y[rr];
       if (two) y1 += beta * y[rr + 1];
     }
-    y[rr] = y0;
+    if (one) y[rr] = y0;
     if (two) y[rr + 1] = y1;
     if (dotw) {
       if (RPT == 2 && have_self && dotw == x) {  // p.Ap of CG: p[r], p[r + 1] are already in registers
-        dot_acc += y0 * xself0;
+        if (one) dot_acc += y0 * xself0;
         if (two) dot_acc += y1 * xself1;
       } else {
-        dot_acc += y0 * dotw[rr];
+        if (one) dot_acc += y0 * dotw[rr];
         if (two) dot_acc += y1 * dotw[rr + 1];
       }
     }
@@ -655,6 +659,262 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
   if (fail) atomicOr(bad, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric sweep, wave-private patches (k_spmv_symp; default when the lattice form is recognised).  The workgroup-tile kernel
+// above cuts a lattice plane into contiguous 512-row ranges: a lattice line longer than the tile (512^3: 513 points) leaves
+// only the in-line diagonals mirrorable (31 %), and two workgroup barriers per chunk bound what three workgroups per CU can keep
+// in flight.  Here a WAVE owns a (j, k) patch of 4 lattice lines x 32 points (lane <-> two neighbouring points of one line) and
+// sweeps it through consecutive lattice planes with no workgroup barrier at all:
+//   * the matrix values of the swept planes live in a patch-major copy  pv[plane][patch][27 slots][128 rows]  (one
+//     contiguous 1 KB run per slot and step, made by k_symp_bind when the solve binds its values);
+//   * the upper diagonals of a step go to the wave's LDS block when they are loaded: +z / +y (slots 14..17) for the rows behind
+//     them in this plane, the nine next-plane diagonals (18..26) for the same patch one plane on -- 10.5 of the 13 lower
+//     diagonals of a row are mirrored from there whatever the line length (the rest: patch edges, read from the row's own slot);
+//   * x is staged per plane: the (4 + 2) x (32 + 2) neighbourhood of the patch enters LDS once and serves the 27 products of three
+//     consecutive steps -- four global loads per lane and step instead of eighteen gathers.
+// Same products, same summation order as the plain diagonal-slotted kernel: y is bitwise the same whenever the mirrored pairs
+// are bitwise equal (MODE 1 checks exactly those pairs when the values are bound).  Work is cut into equal runs of
+// (patch, plane) steps, one per wave, 8 one-wave workgroups per CU; a run's first step (and the first step of a patch) has no
+// history and reads all 27 slots.  Rows outside the swept planes (first / last lattice plane, planes next to the ghost planes of
+// a slab) are computed by k_spmv_dia_outside from the slot-major copy.
+// ---------------------------------------------------------------------------------------------------------------
+#define SP_L 4
+#define SP_W 32
+#define SP_ROWS (SP_L * SP_W)
+#define SP_XL (SP_L + 2)
+#define SP_XW 36  // 34 points (k0 - 1 .. k0 + 32) + 2: lines stay 16-byte aligned
+#define SP_XN (SP_XL * 34)
+#define SP_WG_PER_CU 8
+struct SympGeom {
+  int64_t PL, nx;
+  int m1, m2, p0, p1, NS, NPk;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __restrict__ pv, const double* __restrict__ x,
+                                                   double* __restrict__ y, double alpha, double beta,
+                                                   const double* __restrict__ dotw, double* __restrict__ partials,
+                                                   const int32_t* __restrict__ done_flag, int32_t* __restrict__ bad) {
+  __shared__ __attribute__((aligned(16))) double xs[3][SP_XL][SP_XW];
+  __shared__ __attribute__((aligned(16))) double hist[9][SP_ROWS];
+  __shared__ __attribute__((aligned(16))) double exch[4][SP_ROWS];
+  if (done_flag && done_flag[0]) return;
+  const int lane = threadIdx.x, lj = lane >> 4, pk = lane & 15, li = lj * SP_W + 2 * pk;
+  const int NP = Gm.NS * Gm.NPk, nplanes = Gm.p1 - Gm.p0;
+  const int64_t T = (int64_t)NP * nplanes;
+  const int64_t t0 = T * blockIdx.x / gridDim.x, t1 = T * (blockIdx.x + 1) / gridDim.x;
+  // lower slots whose mirror source (row + offset) is outside the patch for this lane: always read from the row's own slot
+  uint32_t memmask = 0;
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int dj = (s / 3) % 3 - 1, dk = s % 3 - 1;
+    const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < 15 : true);
+    if (!in) memmask |= 1u << s;
+  }
+  int cur_patch = -1, bp = 0, bc = 1, bn = 2;  // x ring: previous / current / next plane
+  bool have_hist = false, vx = false, vy = false;
+  int64_t rin = 0;       // in-plane row offset j * m2 + k of the lane's first row
+  int xo[4], xa[4];      // x staging: in-plane offset (may be negative) and LDS slot of the lane's four neighbourhood points
+  double dot_acc = 0.0;
+  int fail = 0;
+  auto stage_x = [&](int buf, int plane) {
+    double* dst = &xs[buf][0][0];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t idx = (int64_t)plane * Gm.PL + xo[u];
+      if (lane + 64 * u < SP_XN) dst[xa[u]] = (idx >= 0 && idx < Gm.nx) ? x[idx] : 0.0;
+    }
+  };
+  for (int64_t t = t0; t < t1; ++t) {
+    const int patch = (int)(t / nplanes), p = Gm.p0 + (int)(t - (int64_t)patch * nplanes);
+    if (patch != cur_patch) {  // wave-uniform
+      cur_patch = patch;
+      const int j0 = (patch / Gm.NPk) * SP_L, k0 = (patch % Gm.NPk) * SP_W;
+      const int j = j0 + lj, k = k0 + 2 * pk;
+      vx = j < Gm.m1 && k < Gm.m2;
+      vy = j < Gm.m1 && k + 1 < Gm.m2;
+      rin = (int64_t)j * Gm.m2 + k;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = lane + 64 * u, xl = tt / 34, xc = tt - 34 * xl;
+        xo[u] = (j0 - 1 + xl) * Gm.m2 + (k0 - 1 + xc);
+        xa[u] = xl * SP_XW + xc;
+      }
+      have_hist = false;
+      if (MODE == 0) {
+        __syncthreads();  // the previous patch's last products may still be reading the ring
+        stage_x(bp, p - 1);
+        stage_x(bc, p);
+      }
+    }
+    const double* v = pv + ((int64_t)(p - Gm.p0) * NP + patch) * (27 * SP_ROWS) + 2 * lane;
+    // ---- all global loads of the step up front
+    e_d2 cur[14], low[13];
+#pragma unroll
+    for (int u = 0; u < 14; ++u) cur[u] = vx ? SYM_LD(reinterpret_cast<const e_d2*>(v + (13 + u) * SP_ROWS)) : (e_d2){0.0, 0.0};
+    const uint32_t fetch = (MODE == 1 || !vx) ? (vx ? 0x1FFFu : 0u) : (have_hist ? memmask : (memmask | 0x1FFu));
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      low[s] = (e_d2){0.0, 0.0};
+      if ((fetch >> s) & 1u) low[s] = SYM_LD(reinterpret_cast<const e_d2*>(v + s * SP_ROWS));
+    }
+    double xr[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t idx = (int64_t)(p + 1) * Gm.PL + xo[u];
+        if (lane + 64 * u < SP_XN && idx >= 0 && idx < Gm.nx) xr[u] = x[idx];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<e_d2*>(&exch[u][li]) = cur[1 + u];
+    if (MODE == 0) {
+      double* dst = &xs[bn][0][0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < SP_XN) dst[xa[u]] = xr[u];
+    }
+    __syncthreads();  // one wave: orders its LDS writes before the reads of other lanes
+    // value pair of lower slot s: mirrored from LDS when the source rows are in the patch (and the history exists), else `low`
+    auto mirrored = [&](int s) -> e_d2 {
+      const int dj = (s / 3) % 3 - 1, dk = s % 3 - 1;
+      const double* tab = s < 9 ? hist[8 - s] : exch[12 - s];
+      const int src = li + dj * SP_W + dk;
+      e_d2 w;
+      w.x = tab[src];
+      w.y = tab[src + 1];
+      return w;
+    };
+    e_d2 acc = {0.0, 0.0};
+    double xself0 = 0.0, xself1 = 0.0;
+    auto run = [&](const e_d2& va, const e_d2& vb, const e_d2& vc, int buf, int dj, bool self) {
+      const double* xp = &xs[buf][lj + 1 + dj][2 * pk];
+      const e_d2 xa2 = *reinterpret_cast<const e_d2*>(xp), xb2 = *reinterpret_cast<const e_d2*>(xp + 2);
+      acc.x += va.x != 0.0 ? va.x * xa2.x : 0.0;
+      acc.y += va.y != 0.0 ? va.y * xa2.y : 0.0;
+      acc.x += vb.x != 0.0 ? vb.x * xa2.y : 0.0;
+      acc.y += vb.y != 0.0 ? vb.y * xb2.x : 0.0;
+      acc.x += vc.x != 0.0 ? vc.x * xb2.x : 0.0;
+      acc.y += vc.y != 0.0 ? vc.y * xb2.y : 0.0;
+      if (self) {
+        xself0 = xa2.y;
+        xself1 = xb2.x;
+      }
+    };
+    e_d2 lw[13];
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      const bool from_lds = !((memmask >> s) & 1u) && (s >= 9 || have_hist);
+      if (MODE == 1) {
+        if (from_lds && vx) {
+          const e_d2 m = mirrored(s);
+          if (__double_as_longlong(m.x) != __double_as_longlong(low[s].x) && !(m.x == 0.0 && low[s].x == 0.0)) fail = 1;
+          if (vy && __double_as_longlong(m.y) != __double_as_longlong(low[s].y) && !(m.y == 0.0 && low[s].y == 0.0)) fail = 1;
+        }
+      } else {
+        lw[s] = low[s];
+        if (from_lds && vx) lw[s] = mirrored(s);
+      }
+    }
+    if (MODE == 0) {
+      run(lw[0], lw[1], lw[2], bp, -1, false);
+      run(lw[3], lw[4], lw[5], bp, 0, false);
+      run(lw[6], lw[7], lw[8], bp, 1, false);
+      run(lw[9], lw[10], lw[11], bc, -1, false);
+      run(lw[12], cur[0], cur[1], bc, 0, true);
+      run(cur[2], cur[3], cur[4], bc, 1, false);
+    }
+    __syncthreads();  // every lane is done with hist and exch
+#pragma unroll
+    for (int u = 0; u < 9; ++u) *reinterpret_cast<e_d2*>(&hist[u][li]) = cur[5 + u];
+    have_hist = true;
+    if (MODE == 0) {
+      run(cur[5], cur[6], cur[7], bn, -1, false);
+      run(cur[8], cur[9], cur[10], bn, 0, false);
+      run(cur[11], cur[12], cur[13], bn, 1, false);
+      const int64_t r = (int64_t)p * Gm.PL + rin;
+      double y0 = alpha * acc.x, y1 = alpha * acc.y;
+      if (beta != 0.0) {
+        if (vx) y0 += beta * y[r];
+        if (vy) y1 += beta * y[r + 1];
+      }
+      if (vx) y[r] = y0;
+      if (vy) y[r + 1] = y1;
+      if (dotw) {
+        if (dotw == x) {
+          if (vx) dot_acc += y0 * xself0;
+          if (vy) dot_acc += y1 * xself1;
+        } else {
+          if (vx) dot_acc += y0 * dotw[r];
+          if (vy) dot_acc += y1 * dotw[r + 1];
+        }
+      }
+      const int b = bp;
+      bp = bc;
+      bc = bn;
+      bn = b;
+    }
+  }
+  if (MODE == 1) {
+    if (fail) atomicOr(bad, 1);
+  } else if (partials) {
+    const double w = wave_reduce_sum(dot_acc);
+    if (lane == 0) partials[blockIdx.x] = w;
+  }
+}
+
+// patch-major copy of the swept planes from the slot-major copy: pv[plane - p0][patch][s][128], zero where the patch sticks out of
+// the lattice; one wave per (plane, patch)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, const double* __restrict__ ell, double* __restrict__ pv) {
+  const int lane = threadIdx.x & 63, lj = lane >> 4, pk = lane & 15;
+  const int NP = Gm.NS * Gm.NPk;
+  const int64_t T = (int64_t)NP * (Gm.p1 - Gm.p0);
+  for (int64_t t = (int64_t)blockIdx.x * (MFEM_BLOCK / 64) + (threadIdx.x >> 6); t < T; t += (int64_t)gridDim.x * (MFEM_BLOCK / 64)) {
+    const int patch = (int)(t % NP), p = Gm.p0 + (int)(t / NP);
+    const int j = (patch / Gm.NPk) * SP_L + lj, k = (patch % Gm.NPk) * SP_W + 2 * pk;
+    const bool vx = j < Gm.m1 && k < Gm.m2, vy = j < Gm.m1 && k + 1 < Gm.m2;
+    const int64_t r = (int64_t)p * Gm.PL + (int64_t)j * Gm.m2 + k;
+    const int64_t b0 = ell_base(r, K), b1 = ell_base(r + 1, K);
+    double* out = pv + t * (27 * SP_ROWS) + 2 * lane;
+    for (int s0 = 0; s0 < 27; s0 += 9) {
+      e_d2 w[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        w[u].x = vx ? ell[b0 + (s0 + u) * ELL_B] : 0.0;
+        w[u].y = vy ? ell[b1 + (s0 + u) * ELL_B] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) *reinterpret_cast<e_d2*>(out + (s0 + u) * SP_ROWS) = w[u];
+    }
+  }
+}
+
+// the rows outside [skip_lo, skip_hi) through the plain per-row code on the slot-major copy (chunks that lie inside the range are not
+// visited, rows of straddling chunks are masked)
+template <bool TRIPLES>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia_outside(int64_t n, int64_t npad, int K, const DiaOffsets* __restrict__ Op,
+                                                                   const int32_t* __restrict__ flags, const int32_t* __restrict__ cols,
+                                                                   const double* __restrict__ vals, const double* __restrict__ x,
+                                                                   double* __restrict__ y, double alpha, double beta,
+                                                                   const double* __restrict__ dotw, double* __restrict__ partials,
+                                                                   const int32_t* __restrict__ done_flag, int64_t skip_lo, int64_t skip_hi) {
+  __shared__ double red[16];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int64_t R = 2 * MFEM_BLOCK, nchunks = (n + R - 1) / R;
+  int64_t cA = (skip_lo + R - 1) / R, cB = skip_hi / R;
+  if (cB < cA) cB = cA;
+  for (int64_t q = blockIdx.x; q < cA + (nchunks - cB); q += gridDim.x) {
+    const int64_t ch = q < cA ? q : cB + (q - cA);
+    const int64_t r = ch * R + 2 * (int64_t)threadIdx.x;
+    if (r < n) dia_rows<2, 3, TRIPLES>(r, n, npad, K, *Op, flags, cols, vals, x, y, alpha, beta, dotw, 0, dot_acc, skip_lo, skip_hi);
+  }
+  if (partials) {
+    const double b = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = b;
+  }
+}
+
 // Decide eligibility and build the column table (once per pattern).  A->max_row_nnz must be known (mfem_csr_plan).
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->ell_state != 0) return MFEM_OK;
@@ -798,6 +1058,35 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
               A->sym_myz = myz;
             }
           }
+          // wave-private patch sweep: the lattice planes that lie entirely in the longest run of regular blocks
+          A->symp_state = -1;
+          if (PL % m2 == 0 && PL / m2 >= 2 && PL < (int64_t)1 << 30) {
+            std::vector<int32_t> hf((size_t)nblk);
+            MFEM_CHECK_HIP(hipMemcpy(hf.data(), A->dia_flags, sizeof(int32_t) * (size_t)nblk, hipMemcpyDeviceToHost));
+            int64_t best_lo = 0, best_hi = 0, lo = -1;
+            for (int64_t b = 0; b <= nblk; ++b) {
+              const bool reg = b < nblk && hf[(size_t)b] == lc + 1 && (b + 1) * ELL_B <= A->n;
+              if (reg && lo < 0) lo = b;
+              if (!reg && lo >= 0) {
+                if (b - lo > best_hi - best_lo) { best_lo = lo; best_hi = b; }
+                lo = -1;
+              }
+            }
+            const int64_t p0 = (best_lo * ELL_B + PL - 1) / PL, p1 = best_hi * ELL_B / PL;
+            // a swept row reads x[r - PL - m2 - 1 .. r + PL + m2 + 1]: plane p0 >= 1 and p1 <= (rows / PL) - 1 follow from the
+            // regular-block test (r + off in [0, nx) for every row of the block)
+            if (p1 - p0 >= 4 && p0 >= 1) {
+              A->symp_state = 1;
+              A->symp_m2 = (int)m2;
+              A->symp_m1 = (int)(PL / m2);
+              A->symp_PL = PL;
+              A->symp_p0 = (int)p0;
+              A->symp_p1 = (int)p1;
+              A->symp_NS = (A->symp_m1 + SP_L - 1) / SP_L;
+              A->symp_NPk = (A->symp_m2 + SP_W - 1) / SP_W;
+              A->sym_cls = lc;
+            }
+          }
         }
       } else {
         hipFree(A->dia_flags);
@@ -834,11 +1123,73 @@ static bool sym27_wanted(const mfem_csr_s* A) {
 }
 extern "C" int64_t mfem_debug_sym_spmv_count(void) { return g_sym_launches; }
 
+// the patch sweep is used from the same size on as the workgroup-tile sweep was (launch-bound below; the parity tests lift the limit)
+static bool symp_wanted(const mfem_csr_s* A) {
+  // measured (first version): 512^3 5.54 -> 5.05 ms per SpMV, 256^3 0.61 -> 0.69 ms: for now only where a lattice line is longer than
+  // half a 512-row tile of the workgroup-tile sweep
+  return A->symp_state == 1 && g_dia_sym && g_dia_symp && A->dia_triples &&
+         (g_layout_min_rows_dia == 0 || ((int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL >= 1400000 && A->symp_m2 > 300));
+}
+static SympGeom symp_geom(const mfem_context_s* ctx, const mfem_csr_s* A) {
+  SympGeom G;
+  G.PL = A->symp_PL;
+  G.nx = A->n + (ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0);
+  G.m1 = A->symp_m1;
+  G.m2 = A->symp_m2;
+  G.p0 = A->symp_p0;
+  G.p1 = A->symp_p1;
+  G.NS = A->symp_NS;
+  G.NPk = A->symp_NPk;
+  return G;
+}
+static int64_t symp_steps(const mfem_csr_s* A) { return (int64_t)A->symp_NS * A->symp_NPk * (A->symp_p1 - A->symp_p0); }
+static int symp_grid(const mfem_context_s* ctx, const mfem_csr_s* A) {
+  int64_t g = (int64_t)SP_WG_PER_CU * ctx->num_cus;
+  const int64_t T = symp_steps(A);
+  if (g > T / 4) g = T / 4;  // runs of >= 4 steps: a run's first step has no history
+  if (g > MFEM_MAX_PARTIALS - 1024) g = MFEM_MAX_PARTIALS - 1024;
+  return g < 1 ? 1 : (int)g;
+}
+// value pairs (16 B) one sweep SpMV reads from memory with `grid` runs: 14 upper slots per valid lane and step + the lower slots whose
+// mirror source is outside the patch + the nine previous-plane slots wherever a run or a patch starts
+static int64_t symp_count_pairs(const mfem_csr_s* A, int grid) {
+  const int NP = A->symp_NS * A->symp_NPk, nplanes = A->symp_p1 - A->symp_p0;
+  const int64_t T = symp_steps(A);
+  std::vector<int64_t> lanes_valid((size_t)NP), edge((size_t)NP), prev9((size_t)NP);
+  for (int patch = 0; patch < NP; ++patch) {
+    int64_t nv = 0, ne = 0, n9 = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int lj = lane >> 4, pk = lane & 15;
+      const int j = (patch / A->symp_NPk) * SP_L + lj, k = (patch % A->symp_NPk) * SP_W + 2 * pk;
+      if (j >= A->symp_m1 || k >= A->symp_m2) continue;
+      ++nv;
+      for (int sl = 0; sl < 13; ++sl) {
+        const int dj = (sl / 3) % 3 - 1, dk = sl % 3 - 1;
+        const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < 15 : true);
+        if (!in) ++ne;
+        else if (sl < 9) ++n9;
+      }
+    }
+    lanes_valid[(size_t)patch] = nv;
+    edge[(size_t)patch] = ne;
+    prev9[(size_t)patch] = n9;
+  }
+  int64_t pairs = 0;
+  for (int patch = 0; patch < NP; ++patch) pairs += (14 * lanes_valid[(size_t)patch] + edge[(size_t)patch]) * nplanes + prev9[(size_t)patch];
+  for (int g = 1; g < grid; ++g) {  // run starts that are not patch starts
+    const int64_t t0 = T * g / grid;
+    if (t0 % nplanes != 0) pairs += prev9[(size_t)(t0 / nplanes)];
+  }
+  return pairs;
+}
+
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
   if (A->ell_state != 1 || !g_ell_enable) return 0;
   const bool dia = A->dia_state == 1 && g_dia_enable;
   if (A->n < (dia ? g_layout_min_rows_dia : g_layout_min_rows_cols)) return 0;
-  return sizeof(double) * (size_t)A->ell_K * (size_t)A->ell_npad;
+  size_t bytes = sizeof(double) * (size_t)A->ell_K * (size_t)A->ell_npad;
+  if (dia && symp_wanted(A)) bytes += sizeof(double) * 27 * SP_ROWS * (size_t)symp_steps(A);  // patch-major copy of the swept planes
+  return bytes;
 }
 
 // Transpose CSR-ordered values into `buf` and route subsequent mfem_spmv_launch calls with these `vals` to the ELL kernel.
@@ -867,6 +1218,28 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     A->ell_src = vals;
     A->ell_bound_mode = 2;
     A->sym_bound = 0;
+    A->symp_bound = 0;
+    A->symp_vals = nullptr;
+    if (symp_wanted(A)) {  // patch-major copy of the swept planes; are the pairs the sweep mirrors bitwise equal?
+      const SympGeom G = symp_geom(ctx, A);
+      double* pvals = buf + (size_t)A->ell_K * (size_t)A->ell_npad;
+      const int64_t T = symp_steps(A);
+      const int gb = (int)(T / 4 + 1 < (int64_t)ctx->num_cus * 32 ? T / 4 + 1 : (int64_t)ctx->num_cus * 32);
+      hipLaunchKernelGGL(k_symp_bind, dim3(gb), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->ell_K, (const double*)buf, pvals);
+      MFEM_CHECK_LAUNCH();
+      int32_t* d_bad = ctx->d_flags + 9;
+      MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
+      const int gs = symp_grid(ctx, A);
+      hipLaunchKernelGGL(k_spmv_symp<1>, dim3(gs), dim3(64), 0, ctx->stream, G, (const double*)pvals, (const double*)nullptr,
+                         (double*)nullptr, 0.0, 0.0, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, d_bad);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      A->symp_vals = pvals;
+      A->symp_bound = ctx->h_flags[9] ? 0 : 1;
+      A->symp_pairs = symp_count_pairs(A, gs);
+      if (A->symp_bound) return MFEM_OK;
+    }
     if (sym27_wanted(A)) {  // are these values bitwise symmetric where the sweep kernel would mirror them?
       int32_t* d_bad = ctx->d_flags + 9;
       MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
@@ -939,6 +1312,8 @@ int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d) {
 
 void mfem_ell_unbind(mfem_csr_s* A) {
   A->sym_bound = 0;
+  A->symp_bound = 0;
+  A->symp_vals = nullptr;
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
   A->ell_bound_mode = 0;
@@ -985,6 +1360,36 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       case 6: LAUNCH_DIA(2, 1); break;
       case 0:
       case 7:
+        if (symp_wanted(A) && A->symp_bound == 1 && A->symp_vals) {
+          // swept planes: wave-private patch sweep on the patch-major copy; the other rows: per-row code on the slot-major copy.
+          // part 1 of a split SpMV = the sweep (reads no ghost column), part 2 = the rest
+          const SympGeom G = symp_geom(ctx, A);
+          const int gs = symp_grid(ctx, A);
+          int np = 0;
+          if (part.part != 2) {
+            ++g_sym_launches;
+            hipLaunchKernelGGL(k_spmv_symp<0>, dim3(gs), dim3(64), 0, ctx->stream, G, (const double*)A->symp_vals, x, y, alpha, beta, dotw,
+                               partials, done_flag, (int32_t*)nullptr);
+            MFEM_CHECK_LAUNCH();
+            np = gs;
+          }
+          if (part.part != 1) {
+            const int64_t lo = (int64_t)G.p0 * G.PL, hi = (int64_t)G.p1 * G.PL;
+            const int64_t outside = (lo + 511) / 512 + (A->n - hi + 511) / 512 + 2;
+            const int go = (int)(outside < 1 ? 1 : outside < 1024 ? outside : 1024);
+            double* pp = partials ? partials + np : nullptr;
+            if (A->dia_triples)
+              hipLaunchKernelGGL(k_spmv_dia_outside<true>, dim3(go), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
+                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi);
+            else
+              hipLaunchKernelGGL(k_spmv_dia_outside<false>, dim3(go), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
+                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi);
+            MFEM_CHECK_LAUNCH();
+            np += go;
+          }
+          if (n_partials && partials) *n_partials = np;
+          return 1;
+        }
         if (g_dia_variant != 8 && sym27_wanted(A) && A->sym_bound == 1 && g_dia_block == MFEM_BLOCK) {
           // rows of the regular chunk range: symmetric sweep kernel; the rest: the plain kernel with that range skipped
           int64_t nsteps = 0;
@@ -1049,7 +1454,12 @@ extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int6
   int64_t e = A->nnz;
   int sym = 0;
   if (mode == 1 || mode == 2) e = (int64_t)A->ell_K * A->ell_npad;
-  if (mode == 2 && sym27_wanted(A)) {
+  if (mode == 2 && symp_wanted(A)) {
+    sym = 2;
+    // the rows outside the swept planes read their K slots; the sweep reads symp_pairs value pairs
+    const int64_t swept = (int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL;
+    e = (int64_t)A->ell_K * (A->ell_npad - swept) + 2 * symp_count_pairs(A, symp_grid(ctx, A));
+  } else if (mode == 2 && sym27_wanted(A)) {
     sym = 1;
     const int gs = sym27_grid(ctx, A, nullptr);
     const int64_t nch = A->sym_c1 - A->sym_c0;
