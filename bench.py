@@ -253,9 +253,15 @@ def main():
                 if sym_used:
                     # symmetric sweep: the lower-diagonal entries a workgroup still holds in LDS are not read again; `ent` = 8-byte
                     # matrix values one SpMV reads from memory (27 slots per padded row minus the mirrored ones)
-                    kernel = ("k_spmv_sym27 (+ k_spmv_dia<2,3> on the two boundary planes): SpMV on the slot-major copy of the CSR "
-                              "matrix made once per solve; the values passed the per-solve bitwise symmetry check, so lower-diagonal "
-                              "entries are mirrored through LDS (bitwise the same y as the plain diagonal-slotted kernel)")
+                    if symf.value == 2:
+                        kernel = ("k_spmv_symp<0> (+ k_spmv_dia_outside on the two boundary planes): symmetric sweep on wave-private "
+                                  "(j, k) patches of a patch-major copy of the CSR matrix made once per solve; the values passed the "
+                                  "per-solve bitwise symmetry check, so 10.5 of a row's 13 lower-diagonal entries are mirrored through "
+                                  "LDS (bitwise the same y as the plain diagonal-slotted kernel); x staged per lattice plane in LDS")
+                    else:
+                        kernel = ("k_spmv_sym27 (+ k_spmv_dia<2,3> on the two boundary planes): SpMV on the slot-major copy of the CSR "
+                                  "matrix made once per solve; the values passed the per-solve bitwise symmetry check, so lower-diagonal "
+                                  "entries are mirrored through LDS (bitwise the same y as the plain diagonal-slotted kernel)")
                     plain_bytes = spmv_bytes
                     spmv_bytes = ent.value * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
             elif mode.value == 1:
@@ -265,7 +271,7 @@ def main():
                 kernel = "mfem_spmv_csr kernel (CSR SpMV, i64 rowptr / i32 col / f64 val)"
                 spmv_bytes = csr_bytes
             res.update(kernel=kernel, spmv_bytes=spmv_bytes, csr_bytes=csr_bytes, mode=mode.value, sym_used=sym_used,
-                       plain_bytes=plain_bytes)
+                       sym_kind=(int(symf.value) if sym_used else 0), plain_bytes=plain_bytes)
             if want_csr and world == 1:
                 res["csr_kernel"] = csr_kernel_roofline(A, K)
         if comm is not None:
@@ -286,7 +292,7 @@ def main():
         if os.path.exists(tpath) and args.n == 256 and world == 1:  # PMC traffic was measured on this single-GPU workload
             try:
                 tj = json.load(open(tpath))
-                same = tj.get("solver_layout_mode") == r["mode"] and bool(tj.get("symmetric_sweep", False)) == r["sym_used"]
+                same = tj.get("solver_layout_mode") == r["mode"] and int(tj.get("symmetric_sweep", 0)) == r["sym_kind"]
                 traffic = tj.get("hbm_bytes_per_launch") if same else None
                 if traffic is not None:
                     traffic_source = ("profiles/spmv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on "
@@ -326,8 +332,9 @@ def main():
                 "algorithmic_bytes_per_launch": r["spmv_bytes"], "avg_launch_ms": r["spmv_ms"], "launches": r["spmv_launches"],
                 **({"plain_diagonal_kernel_bytes_per_launch": r["plain_bytes"],
                     "note": "algorithmic bytes = what this kernel design reads: 8 B per matrix entry not mirrored from LDS "
-                            "(about 18.6 of 27 per row) + x + y; the plain diagonal-slotted kernel reads "
-                            "plain_diagonal_kernel_bytes_per_launch"} if r["sym_used"] else {}),
+                            "(14 upper-diagonal entries per row + the patch-edge entries; workgroup-tile sweep: about 18.6 of 27) "
+                            "+ x + y; the plain diagonal-slotted kernel reads plain_diagonal_kernel_bytes_per_launch"}
+                   if r["sym_used"] else {}),
                 "csr_equivalent": {"bytes_per_launch": r["csr_bytes"], "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
                                    "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
                                            "kernel would have to sustain to match this time"},

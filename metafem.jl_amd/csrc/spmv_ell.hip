@@ -665,8 +665,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 // only the in-line diagonals mirrorable (31 %), and two workgroup barriers per chunk bound what three workgroups per CU can keep
 // in flight.  Here a WAVE owns a (j, k) patch of 4 lattice lines x 32 points (lane <-> two neighbouring points of one line) and
 // sweeps it through consecutive lattice planes with no workgroup barrier at all:
-//   * the matrix values of the swept planes live in a patch-major copy  pv[plane][patch][27 slots][128 rows]  (one
-//     contiguous 1 KB run per slot and step, made by k_symp_bind when the solve binds its values);
+//   * the matrix values of the swept planes live in a patch-major copy  pv[patch][plane][27 slots][128 rows]  (one
+//     contiguous 1 KB run per slot and step, a wave's whole run one contiguous piece; made by k_symp_bind when the solve
+//     binds its values);
 //   * the upper diagonals of a step go to the wave's LDS block when they are loaded: +z / +y (slots 14..17) for the rows behind
 //     them in this plane, the nine next-plane diagonals (18..26) for the same patch one plane on -- 10.5 of the 13 lower
 //     diagonals of a row are mirrored from there whatever the line length (the rest: patch edges, read from the row's own slot);
@@ -684,10 +685,51 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 #define SP_XL (SP_L + 2)
 #define SP_XW 36  // 34 points (k0 - 1 .. k0 + 32) + 2: lines stay 16-byte aligned
 #define SP_XN (SP_XL * 34)
-#define SP_WG_PER_CU 8
+#define SP_WG_PER_CU 7
+// Mirror tables: one per lower slot s = (di, dj, dk), holding slot 26 - s of the SOURCE rows (row + offset), indexed by source
+// cell (line lj + dj, column 2 pk + dk): lines of 36 doubles, column c at index c + 2 (column -1 and column 32 are halo cells), a
+// halo line on the side the slot points to.  A halo cell cannot be mirrored (its source row belongs to another patch): it
+// receives the referencing row's OWN slot-s entry from the step's edge block, so that the reads are the same two LDS loads for
+// every lane and slot.
+#define SP_LS 36
+__host__ __device__ constexpr int sp_dj(int s) { return (s / 3) % 3 - 1; }
+__host__ __device__ constexpr int sp_dk(int s) { return s % 3 - 1; }
+__host__ __device__ constexpr int sp_tsize(int s) { return (sp_dj(s) == 0 ? SP_L : SP_L + 1) * SP_LS; }
+__host__ __device__ constexpr int sp_tbase(int s) { return s == 0 ? 0 : sp_tbase(s - 1) + sp_tsize(s - 1); }
+__host__ __device__ constexpr int sp_adj(int s) { return sp_dj(s) == -1 ? 1 : 0; }  // table line of source line 0
+#define SP_TAB (sp_tbase(12) + sp_tsize(12))
+// edge block of a step: for s = 0..12 the halo cells of table s -- the halo line (32 cells) if dj != 0, then the halo column
+// (lines in ascending order) if dk != 0
+__host__ __device__ constexpr int sp_ecnt(int s) { return (sp_dj(s) != 0 ? SP_W : 0) + (sp_dk(s) != 0 ? (sp_dj(s) != 0 ? SP_L - 1 : SP_L) : 0); }
+__host__ __device__ constexpr int sp_ebase(int s) { return s == 0 ? 0 : sp_ebase(s - 1) + sp_ecnt(s - 1); }
+#define SP_NE (sp_ebase(12) + sp_ecnt(12))  // 318
+#define SP_EPAD 320
+#define SP_STEP (27 * SP_ROWS + SP_EPAD)    // doubles per (plane, patch) in the patch-major copy
+// entry e of the edge block: lower slot s, the referencing row's (line, column) in the patch, the LDS cell of table s it fills
+__host__ __device__ inline bool sp_edge(int e, int& s, int& line, int& col, int& cell) {
+  if (e >= SP_NE) return false;
+  s = 0;
+  while (e >= sp_ebase(s) + sp_ecnt(s)) ++s;
+  int q = e - sp_ebase(s);
+  const int dj = sp_dj(s), dk = sp_dk(s);
+  int sl, sc;
+  if (dj != 0 && q < SP_W) {
+    sl = dj < 0 ? -1 : SP_L;
+    sc = dk + q;
+  } else {
+    if (dj != 0) q -= SP_W;
+    sl = dj > 0 ? q + 1 : q;
+    sc = dk < 0 ? -1 : SP_W;
+  }
+  line = sl - dj;
+  col = sc - dk;
+  cell = sp_tbase(s) + (sl + sp_adj(s)) * SP_LS + sc + 2;
+  return true;
+}
 struct SympGeom {
   int64_t PL, nx;
   int m1, m2, p0, p1, NS, NPk;
+  int nseg;  // runs per patch: a run = one patch swept through nplanes / nseg consecutive planes
 };
 
 template <int MODE>
@@ -696,20 +738,21 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
                                                    const double* __restrict__ dotw, double* __restrict__ partials,
                                                    const int32_t* __restrict__ done_flag, int32_t* __restrict__ bad) {
   __shared__ __attribute__((aligned(16))) double xs[3][SP_XL][SP_XW];
-  __shared__ __attribute__((aligned(16))) double hist[9][SP_ROWS];
-  __shared__ __attribute__((aligned(16))) double exch[4][SP_ROWS];
+  __shared__ __attribute__((aligned(16))) double tab[SP_TAB + 2];
   if (done_flag && done_flag[0]) return;
-  const int lane = threadIdx.x, lj = lane >> 4, pk = lane & 15, li = lj * SP_W + 2 * pk;
+  const int lane = threadIdx.x, lj = lane >> 4, pk = lane & 15, lb = lj * SP_LS + 2 * pk;
   const int NP = Gm.NS * Gm.NPk, nplanes = Gm.p1 - Gm.p0;
-  const int64_t T = (int64_t)NP * nplanes;
-  const int64_t t0 = T * blockIdx.x / gridDim.x, t1 = T * (blockIdx.x + 1) / gridDim.x;
-  // lower slots whose mirror source (row + offset) is outside the patch for this lane: always read from the row's own slot
-  uint32_t memmask = 0;
+  // Runs and XCDs: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch; gridDim.x is a multiple of 8).  XCD c sweeps
+  // a contiguous eighth of the patches, segment by segment, so that the runs resident on it at any time are neighbouring patches at
+  // about the same plane: their overlapping x neighbourhoods meet in that XCD's L2.
+  const int xcd = blockIdx.x & 7, pc = NP / 8, prem = NP % 8, pcnt = pc + (xcd < prem ? 1 : 0), pfirst = xcd * pc + (xcd < prem ? xcd : prem);
+  // the LDS cells this lane fills from the edge block (5 entries per lane)
+  int ecell[5];
 #pragma unroll
-  for (int s = 0; s < 13; ++s) {
-    const int dj = (s / 3) % 3 - 1, dk = s % 3 - 1;
-    const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < 15 : true);
-    if (!in) memmask |= 1u << s;
+  for (int u = 0; u < 5; ++u) {
+    int s_, l_, c_, cell = -1;
+    if (!sp_edge(lane + 64 * u, s_, l_, c_, cell)) cell = SP_TAB;  // the block's two padding entries go to a spare cell
+    ecell[u] = cell;
   }
   int cur_patch = -1, bp = 0, bc = 1, bn = 2;  // x ring: previous / current / next plane
   bool have_hist = false, vx = false, vy = false;
@@ -717,17 +760,45 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   int xo[4], xa[4];      // x staging: in-plane offset (may be negative) and LDS slot of the lane's four neighbourhood points
   double dot_acc = 0.0;
   int fail = 0;
+  e_d2 cur[14];          // slots 13..26 of the step, requested one step ahead
+  double ed[5], xr[4];   // its edge block entries and the x neighbourhood of the plane after it
+  // x neighbourhood entry of plane `plane`: positions outside the vector's owned entries (beyond the last lattice line of the last
+  // plane) are only ever multiplied by structurally absent entries -- any finite value serves: clamp
+  auto xidx = [&](int plane, int u) -> int64_t {
+    int64_t idx = (int64_t)plane * Gm.PL + xo[u];
+    idx = idx < 0 ? 0 : idx;
+    return idx < Gm.nx ? idx : Gm.nx - 1;
+  };
+  auto request = [&](const double* v, int pnext) {
+    if (vx) {
+#pragma unroll
+      for (int u = 0; u < 14; ++u) cur[u] = SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + (13 + u) * SP_ROWS));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 14; ++u) cur[u] = (e_d2){0.0, 0.0};
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < 5; ++u) ed[u] = SYM_LD(v + 27 * SP_ROWS + lane + 64 * u);  // the block is padded to 320 entries
+#pragma unroll
+      for (int u = 0; u < 3; ++u) xr[u] = x[xidx(pnext, u)];
+      xr[3] = lane < SP_XN - 192 ? x[xidx(pnext, 3)] : 0.0;
+    }
+  };
   auto stage_x = [&](int buf, int plane) {
     double* dst = &xs[buf][0][0];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t idx = (int64_t)plane * Gm.PL + xo[u];
-      if (lane + 64 * u < SP_XN) dst[xa[u]] = (idx >= 0 && idx < Gm.nx) ? x[idx] : 0.0;
-    }
+    for (int u = 0; u < 3; ++u) dst[xa[u]] = x[xidx(plane, u)];
+    if (lane < SP_XN - 192) dst[xa[3]] = x[xidx(plane, 3)];
   };
+  for (int run = blockIdx.x >> 3; run < pcnt * Gm.nseg; run += gridDim.x >> 3) {
+  const int patch = pfirst + run % pcnt, seg = run / pcnt;
+  const int64_t t0 = (int64_t)patch * nplanes + (int64_t)nplanes * seg / Gm.nseg, t1 = (int64_t)patch * nplanes + (int64_t)nplanes * (seg + 1) / Gm.nseg;
+  cur_patch = -1;
   for (int64_t t = t0; t < t1; ++t) {
-    const int patch = (int)(t / nplanes), p = Gm.p0 + (int)(t - (int64_t)patch * nplanes);
-    if (patch != cur_patch) {  // wave-uniform
+    const int p = Gm.p0 + (int)(t - (int64_t)patch * nplanes);
+    const double* v = pv + t * SP_STEP;  // [patch][plane]: a run streams through one contiguous piece of the copy
+    if (patch != cur_patch) {  // wave-uniform: a run or a patch starts -- nothing was requested ahead, no history
       cur_patch = patch;
       const int j0 = (patch / Gm.NPk) * SP_L, k0 = (patch % Gm.NPk) * SP_W;
       const int j = j0 + lj, k = k0 + 2 * pk;
@@ -738,108 +809,112 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
       for (int u = 0; u < 4; ++u) {
         const int tt = lane + 64 * u, xl = tt / 34, xc = tt - 34 * xl;
         xo[u] = (j0 - 1 + xl) * Gm.m2 + (k0 - 1 + xc);
-        xa[u] = xl * SP_XW + xc;
+        xa[u] = xl * SP_XW + xc;  // (u = 3: only lanes < 12 belong to the neighbourhood)
       }
       have_hist = false;
+      __syncthreads();  // the previous patch's last products may still be reading the x ring
+      request(v, p + 1);
       if (MODE == 0) {
-        __syncthreads();  // the previous patch's last products may still be reading the ring
         stage_x(bp, p - 1);
         stage_x(bc, p);
+        // no history: the row's own previous-plane slots go where the mirror reads would look for them
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+          const e_d2 w = vx ? SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
+          double* c = tab + sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb;
+          c[0] = w.x;
+          c[1] = w.y;
+        }
       }
     }
-    const double* v = pv + ((int64_t)(p - Gm.p0) * NP + patch) * (27 * SP_ROWS) + 2 * lane;
-    // ---- all global loads of the step up front
-    e_d2 cur[14], low[13];
+    // ---- phase B: this step's +z / +y slots, its edge entries and the next plane's x go to LDS
 #pragma unroll
-    for (int u = 0; u < 14; ++u) cur[u] = vx ? SYM_LD(reinterpret_cast<const e_d2*>(v + (13 + u) * SP_ROWS)) : (e_d2){0.0, 0.0};
-    const uint32_t fetch = (MODE == 1 || !vx) ? (vx ? 0x1FFFu : 0u) : (have_hist ? memmask : (memmask | 0x1FFu));
-#pragma unroll
-    for (int s = 0; s < 13; ++s) {
-      low[s] = (e_d2){0.0, 0.0};
-      if ((fetch >> s) & 1u) low[s] = SYM_LD(reinterpret_cast<const e_d2*>(v + s * SP_ROWS));
-    }
-    double xr[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s = 9; s < 13; ++s) *reinterpret_cast<e_d2*>(tab + sp_tbase(s) + sp_adj(s) * SP_LS + 2 + lb) = cur[26 - s - 13];
+    e_d2 low[13];
     if (MODE == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t idx = (int64_t)(p + 1) * Gm.PL + xo[u];
-        if (lane + 64 * u < SP_XN && idx >= 0 && idx < Gm.nx) xr[u] = x[idx];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<e_d2*>(&exch[u][li]) = cur[1 + u];
-    if (MODE == 0) {
+      for (int u = 0; u < 5; ++u) tab[ecell[u]] = ed[u];
       double* dst = &xs[bn][0][0];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (lane + 64 * u < SP_XN) dst[xa[u]] = xr[u];
+      for (int u = 0; u < 3; ++u) dst[xa[u]] = xr[u];
+      if (lane < SP_XN - 192) dst[xa[3]] = xr[3];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 13; ++s) low[s] = vx ? SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
     }
+    // the step's own upper slots stay in `mine`; the next step of the same sweep is requested now and arrives during the products
+    e_d2 mine[14];
+#pragma unroll
+    for (int u = 0; u < 14; ++u) mine[u] = cur[u];
+    const bool more = t + 1 < t1 && p + 1 < Gm.p1;  // the next step continues this sweep
     __syncthreads();  // one wave: orders its LDS writes before the reads of other lanes
-    // value pair of lower slot s: mirrored from LDS when the source rows are in the patch (and the history exists), else `low`
+    if (more) request(v + SP_STEP, p + 2);
     auto mirrored = [&](int s) -> e_d2 {
-      const int dj = (s / 3) % 3 - 1, dk = s % 3 - 1;
-      const double* tab = s < 9 ? hist[8 - s] : exch[12 - s];
-      const int src = li + dj * SP_W + dk;
+      const double* c = tab + sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb;
       e_d2 w;
-      w.x = tab[src];
-      w.y = tab[src + 1];
+      w.x = c[0];
+      w.y = c[1];
       return w;
     };
     e_d2 acc = {0.0, 0.0};
     double xself0 = 0.0, xself1 = 0.0;
+    // products rounded, then added, in slot order: what the plain kernel computes.  A structurally absent entry is an explicit zero
+    // and every staged x is an owned entry of the vector (finite whenever x is), so its product is a signed zero that leaves the sum
+    // unchanged -- no select needed here.
     auto run = [&](const e_d2& va, const e_d2& vb, const e_d2& vc, int buf, int dj, bool self) {
+#pragma clang fp contract(off)  // v_mul_f64 + v_add_f64 like the plain kernel, not v_fma_f64
       const double* xp = &xs[buf][lj + 1 + dj][2 * pk];
       const e_d2 xa2 = *reinterpret_cast<const e_d2*>(xp), xb2 = *reinterpret_cast<const e_d2*>(xp + 2);
-      acc.x += va.x != 0.0 ? va.x * xa2.x : 0.0;
-      acc.y += va.y != 0.0 ? va.y * xa2.y : 0.0;
-      acc.x += vb.x != 0.0 ? vb.x * xa2.y : 0.0;
-      acc.y += vb.y != 0.0 ? vb.y * xb2.x : 0.0;
-      acc.x += vc.x != 0.0 ? vc.x * xb2.x : 0.0;
-      acc.y += vc.y != 0.0 ? vc.y * xb2.y : 0.0;
+      acc.x = acc.x + va.x * xa2.x;
+      acc.y = acc.y + va.y * xa2.y;
+      acc.x = acc.x + vb.x * xa2.y;
+      acc.y = acc.y + vb.y * xb2.x;
+      acc.x = acc.x + vc.x * xb2.x;
+      acc.y = acc.y + vc.y * xb2.y;
       if (self) {
         xself0 = xa2.y;
         xself1 = xb2.x;
       }
     };
-    e_d2 lw[13];
+    if (MODE == 1) {
+      // exactly the pairs the sweep mirrors: source rows inside the patch, previous-plane slots only where a history exists
 #pragma unroll
-    for (int s = 0; s < 13; ++s) {
-      const bool from_lds = !((memmask >> s) & 1u) && (s >= 9 || have_hist);
-      if (MODE == 1) {
-        if (from_lds && vx) {
+      for (int s = 0; s < 13; ++s) {
+        const int dj = sp_dj(s), dk = sp_dk(s);
+        const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < 15 : true);
+        if (in && vx && (s >= 9 || have_hist)) {
           const e_d2 m = mirrored(s);
           if (__double_as_longlong(m.x) != __double_as_longlong(low[s].x) && !(m.x == 0.0 && low[s].x == 0.0)) fail = 1;
           if (vy && __double_as_longlong(m.y) != __double_as_longlong(low[s].y) && !(m.y == 0.0 && low[s].y == 0.0)) fail = 1;
         }
-      } else {
-        lw[s] = low[s];
-        if (from_lds && vx) lw[s] = mirrored(s);
       }
+    } else {
+      run(mirrored(0), mirrored(1), mirrored(2), bp, -1, false);
+      run(mirrored(3), mirrored(4), mirrored(5), bp, 0, false);
+      run(mirrored(6), mirrored(7), mirrored(8), bp, 1, false);
+      run(mirrored(9), mirrored(10), mirrored(11), bc, -1, false);
+      run(mirrored(12), mine[0], mine[1], bc, 0, true);
+      run(mine[2], mine[3], mine[4], bc, 1, false);
     }
-    if (MODE == 0) {
-      run(lw[0], lw[1], lw[2], bp, -1, false);
-      run(lw[3], lw[4], lw[5], bp, 0, false);
-      run(lw[6], lw[7], lw[8], bp, 1, false);
-      run(lw[9], lw[10], lw[11], bc, -1, false);
-      run(lw[12], cur[0], cur[1], bc, 0, true);
-      run(cur[2], cur[3], cur[4], bc, 1, false);
-    }
-    __syncthreads();  // every lane is done with hist and exch
+    __syncthreads();  // every lane is done with the tables
 #pragma unroll
-    for (int u = 0; u < 9; ++u) *reinterpret_cast<e_d2*>(&hist[u][li]) = cur[5 + u];
+    for (int s = 0; s < 9; ++s) *reinterpret_cast<e_d2*>(tab + sp_tbase(s) + sp_adj(s) * SP_LS + 2 + lb) = mine[26 - s - 13];
     have_hist = true;
     if (MODE == 0) {
-      run(cur[5], cur[6], cur[7], bn, -1, false);
-      run(cur[8], cur[9], cur[10], bn, 0, false);
-      run(cur[11], cur[12], cur[13], bn, 1, false);
+      run(mine[5], mine[6], mine[7], bn, -1, false);
+      run(mine[8], mine[9], mine[10], bn, 0, false);
+      run(mine[11], mine[12], mine[13], bn, 1, false);
       const int64_t r = (int64_t)p * Gm.PL + rin;
       double y0 = alpha * acc.x, y1 = alpha * acc.y;
       if (beta != 0.0) {
         if (vx) y0 += beta * y[r];
         if (vy) y1 += beta * y[r + 1];
       }
-      if (vx) y[r] = y0;
-      if (vy) y[r + 1] = y1;
+      {
+        // one 16-byte store (8-byte aligned), non-temporal: 0.910 -> 0.896 ms per CG iteration at 256^3
+        if (vy) __builtin_nontemporal_store((u_d2){y0, y1}, reinterpret_cast<u_d2*>(y + r));
+        else if (vx) __builtin_nontemporal_store(y0, y + r);
+      }
       if (dotw) {
         if (dotw == x) {
           if (vx) dot_acc += y0 * xself0;
@@ -854,6 +929,8 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
       bc = bn;
       bn = b;
     }
+    if (!more) cur_patch = -1;  // nothing requested: the next step (if any) starts like a run
+  }
   }
   if (MODE == 1) {
     if (fail) atomicOr(bad, 1);
@@ -863,19 +940,20 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   }
 }
 
-// patch-major copy of the swept planes from the slot-major copy: pv[plane - p0][patch][s][128], zero where the patch sticks out of
-// the lattice; one wave per (plane, patch)
+// patch-major copy of the swept planes from the slot-major copy: pv[patch][plane - p0] = 27 slots x 128 rows + the edge block, zero
+// where the patch sticks out of the lattice; one wave per (plane, patch)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, const double* __restrict__ ell, double* __restrict__ pv) {
   const int lane = threadIdx.x & 63, lj = lane >> 4, pk = lane & 15;
   const int NP = Gm.NS * Gm.NPk;
   const int64_t T = (int64_t)NP * (Gm.p1 - Gm.p0);
   for (int64_t t = (int64_t)blockIdx.x * (MFEM_BLOCK / 64) + (threadIdx.x >> 6); t < T; t += (int64_t)gridDim.x * (MFEM_BLOCK / 64)) {
-    const int patch = (int)(t % NP), p = Gm.p0 + (int)(t / NP);
-    const int j = (patch / Gm.NPk) * SP_L + lj, k = (patch % Gm.NPk) * SP_W + 2 * pk;
+    const int nplanes = Gm.p1 - Gm.p0, patch = (int)(t / nplanes), p = Gm.p0 + (int)(t % nplanes);
+    const int j0 = (patch / Gm.NPk) * SP_L, k0 = (patch % Gm.NPk) * SP_W;
+    const int j = j0 + lj, k = k0 + 2 * pk;
     const bool vx = j < Gm.m1 && k < Gm.m2, vy = j < Gm.m1 && k + 1 < Gm.m2;
     const int64_t r = (int64_t)p * Gm.PL + (int64_t)j * Gm.m2 + k;
     const int64_t b0 = ell_base(r, K), b1 = ell_base(r + 1, K);
-    double* out = pv + t * (27 * SP_ROWS) + 2 * lane;
+    double* out = pv + t * SP_STEP;
     for (int s0 = 0; s0 < 27; s0 += 9) {
       e_d2 w[9];
 #pragma unroll
@@ -884,7 +962,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, co
         w[u].y = vy ? ell[b1 + (s0 + u) * ELL_B] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 9; ++u) *reinterpret_cast<e_d2*>(out + (s0 + u) * SP_ROWS) = w[u];
+      for (int u = 0; u < 9; ++u) *reinterpret_cast<e_d2*>(out + 2 * lane + (s0 + u) * SP_ROWS) = w[u];
+    }
+    for (int e = lane; e < SP_EPAD; e += 64) {
+      int s = 0, line = 0, col = 0, cell = 0;
+      double val = 0.0;
+      if (sp_edge(e, s, line, col, cell) && j0 + line < Gm.m1 && k0 + col < Gm.m2)
+        val = ell[ell_base((int64_t)p * Gm.PL + (int64_t)(j0 + line) * Gm.m2 + k0 + col, K) + s * ELL_B];
+      out[27 * SP_ROWS + e] = val;
     }
   }
 }
@@ -897,10 +982,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia_outside(int64_t n, int6
                                                                    const double* __restrict__ vals, const double* __restrict__ x,
                                                                    double* __restrict__ y, double alpha, double beta,
                                                                    const double* __restrict__ dotw, double* __restrict__ partials,
-                                                                   const int32_t* __restrict__ done_flag, int64_t skip_lo, int64_t skip_hi) {
+                                                                   const int32_t* __restrict__ done_flag, int64_t skip_lo, int64_t skip_hi,
+                                                                   const double* __restrict__ fold, int nfold) {
   __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
+  // workgroup 0 also folds the sweep launch's per-wave partial sums (fixed order), so that the consumers of this SpMV's dot product
+  // re-reduce a few hundred partials instead of a few thousand
+  if (blockIdx.x == 0 && partials)
+    for (int i = threadIdx.x; i < nfold; i += MFEM_BLOCK) dot_acc += fold[i];
   const int64_t R = 2 * MFEM_BLOCK, nchunks = (n + R - 1) / R;
   int64_t cA = (skip_lo + R - 1) / R, cB = skip_hi / R;
   if (cB < cA) cB = cA;
@@ -1124,63 +1214,67 @@ static bool sym27_wanted(const mfem_csr_s* A) {
 extern "C" int64_t mfem_debug_sym_spmv_count(void) { return g_sym_launches; }
 
 // the patch sweep is used from the same size on as the workgroup-tile sweep was (launch-bound below; the parity tests lift the limit)
+// Which sweep: measured CG iteration, workgroup-tile sweep / patch sweep (tools/probe_sym.py): 128^3 0.142 / 0.173 ms, 192^3 0.369 / 0.397,
+// 256^3 0.896 / 0.896, 320^3 1.82 / 1.72, 384^3 3.28 / 2.89, 512^3 7.95 / 6.66 -- the patch sweep from 2.4e7 swept rows on, or where a
+// lattice line no longer fits the 512-row tile twice (the parity tests lift all size limits and then always take it)
 static bool symp_wanted(const mfem_csr_s* A) {
-  // measured (first version): 512^3 5.54 -> 5.05 ms per SpMV, 256^3 0.61 -> 0.69 ms: for now only where a lattice line is longer than
-  // half a 512-row tile of the workgroup-tile sweep
-  return A->symp_state == 1 && g_dia_sym && g_dia_symp && A->dia_triples &&
-         (g_layout_min_rows_dia == 0 || ((int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL >= 1400000 && A->symp_m2 > 300));
+  if (!(A->symp_state == 1 && g_dia_sym && g_dia_symp && A->dia_triples)) return false;
+  if (g_layout_min_rows_dia == 0) return true;
+  return (int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL >= 24000000 || A->symp_m2 > 256;
 }
+static int symp_nseg(const mfem_context_s* ctx, const mfem_csr_s* A);
 static SympGeom symp_geom(const mfem_context_s* ctx, const mfem_csr_s* A) {
   SympGeom G;
   G.PL = A->symp_PL;
-  G.nx = A->n + (ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0);
+  G.nx = A->n;  // the sweep stages owned entries of x only (swept rows reference no ghost column)
   G.m1 = A->symp_m1;
   G.m2 = A->symp_m2;
   G.p0 = A->symp_p0;
   G.p1 = A->symp_p1;
   G.NS = A->symp_NS;
   G.NPk = A->symp_NPk;
+  G.nseg = symp_nseg(ctx, A);
   return G;
 }
 static int64_t symp_steps(const mfem_csr_s* A) { return (int64_t)A->symp_NS * A->symp_NPk * (A->symp_p1 - A->symp_p0); }
-static int symp_grid(const mfem_context_s* ctx, const mfem_csr_s* A) {
-  int64_t g = (int64_t)SP_WG_PER_CU * ctx->num_cus;
-  const int64_t T = symp_steps(A);
-  if (g > T / 4) g = T / 4;  // runs of >= 4 steps: a run's first step has no history
-  if (g > MFEM_MAX_PARTIALS - 1024) g = MFEM_MAX_PARTIALS - 1024;
-  return g < 1 ? 1 : (int)g;
+// runs per patch: the smallest count that fills >= 90 % of the resident one-wave workgroups in whole rounds (a run's first step has no
+// history: runs stay >= 16 planes long)
+static int symp_nseg(const mfem_context_s* ctx, const mfem_csr_s* A) {
+  const int64_t NP = (int64_t)A->symp_NS * A->symp_NPk, slots = (int64_t)SP_WG_PER_CU * ctx->num_cus;
+  const int nplanes = A->symp_p1 - A->symp_p0;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ns = 1; ns <= (nplanes / 16 > 1 ? nplanes / 16 : 1) && ns <= 64; ++ns) {
+    const int64_t R = NP * ns, rounds = (R + slots - 1) / slots;
+    const double eff = (double)R / (double)(rounds * slots);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = ns; }
+    if (eff >= 0.9) { best = ns; break; }
+  }
+  return best;
 }
-// value pairs (16 B) one sweep SpMV reads from memory with `grid` runs: 14 upper slots per valid lane and step + the lower slots whose
-// mirror source is outside the patch + the nine previous-plane slots wherever a run or a patch starts
-static int64_t symp_count_pairs(const mfem_csr_s* A, int grid) {
+static int symp_grid(const mfem_context_s* ctx, const mfem_csr_s* A) {
+  const int64_t NP = (int64_t)A->symp_NS * A->symp_NPk;
+  int64_t g = 8 * ((NP + 7) / 8) * symp_nseg(ctx, A);  // every XCD's share of the runs, padded to the largest share
+  int64_t cap = (int64_t)SP_WG_PER_CU * ctx->num_cus;
+  if (cap > MFEM_MAX_PARTIALS - 1024) cap = MFEM_MAX_PARTIALS - 1024;
+  cap &= ~(int64_t)7;
+  if (g > cap) g = cap;
+  return g < 8 ? 8 : (int)g;
+}
+// matrix values (8 B) one sweep SpMV reads from memory with `grid` runs: the 14 upper slots of every valid lane pair and the edge block
+// per step + the nine previous-plane slots wherever a run or a patch starts
+static int64_t symp_count_entries(const mfem_csr_s* A, int nseg) {
   const int NP = A->symp_NS * A->symp_NPk, nplanes = A->symp_p1 - A->symp_p0;
-  const int64_t T = symp_steps(A);
-  std::vector<int64_t> lanes_valid((size_t)NP), edge((size_t)NP), prev9((size_t)NP);
+  int64_t e = 0;
   for (int patch = 0; patch < NP; ++patch) {
-    int64_t nv = 0, ne = 0, n9 = 0;
+    int64_t nv = 0;
     for (int lane = 0; lane < 64; ++lane) {
-      const int lj = lane >> 4, pk = lane & 15;
-      const int j = (patch / A->symp_NPk) * SP_L + lj, k = (patch % A->symp_NPk) * SP_W + 2 * pk;
-      if (j >= A->symp_m1 || k >= A->symp_m2) continue;
-      ++nv;
-      for (int sl = 0; sl < 13; ++sl) {
-        const int dj = (sl / 3) % 3 - 1, dk = sl % 3 - 1;
-        const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < 15 : true);
-        if (!in) ++ne;
-        else if (sl < 9) ++n9;
-      }
+      const int j = (patch / A->symp_NPk) * SP_L + (lane >> 4), k = (patch % A->symp_NPk) * SP_W + 2 * (lane & 15);
+      if (j < A->symp_m1 && k < A->symp_m2) ++nv;
     }
-    lanes_valid[(size_t)patch] = nv;
-    edge[(size_t)patch] = ne;
-    prev9[(size_t)patch] = n9;
+    e += (28 * nv + SP_NE) * nplanes + 18 * nv * nseg;
   }
-  int64_t pairs = 0;
-  for (int patch = 0; patch < NP; ++patch) pairs += (14 * lanes_valid[(size_t)patch] + edge[(size_t)patch]) * nplanes + prev9[(size_t)patch];
-  for (int g = 1; g < grid; ++g) {  // run starts that are not patch starts
-    const int64_t t0 = T * g / grid;
-    if (t0 % nplanes != 0) pairs += prev9[(size_t)(t0 / nplanes)];
-  }
-  return pairs;
+  return e;
 }
 
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
@@ -1188,7 +1282,7 @@ size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
   const bool dia = A->dia_state == 1 && g_dia_enable;
   if (A->n < (dia ? g_layout_min_rows_dia : g_layout_min_rows_cols)) return 0;
   size_t bytes = sizeof(double) * (size_t)A->ell_K * (size_t)A->ell_npad;
-  if (dia && symp_wanted(A)) bytes += sizeof(double) * 27 * SP_ROWS * (size_t)symp_steps(A);  // patch-major copy of the swept planes
+  if (dia && symp_wanted(A)) bytes += sizeof(double) * SP_STEP * (size_t)symp_steps(A);  // patch-major copy of the swept planes
   return bytes;
 }
 
@@ -1237,7 +1331,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
       MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
       A->symp_vals = pvals;
       A->symp_bound = ctx->h_flags[9] ? 0 : 1;
-      A->symp_pairs = symp_count_pairs(A, gs);
+      A->symp_pairs = symp_count_entries(A, G.nseg);
       if (A->symp_bound) return MFEM_OK;
     }
     if (sym27_wanted(A)) {  // are these values bitwise symmetric where the sweep kernel would mirror them?
@@ -1366,24 +1460,28 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
           const SympGeom G = symp_geom(ctx, A);
           const int gs = symp_grid(ctx, A);
           int np = 0;
+          // unsplit SpMV: the sweep's partial sums go behind the outside launch's (<= 1024) and are folded by it
+          const bool folded = part.part == 0 && partials;
           if (part.part != 2) {
             ++g_sym_launches;
             hipLaunchKernelGGL(k_spmv_symp<0>, dim3(gs), dim3(64), 0, ctx->stream, G, (const double*)A->symp_vals, x, y, alpha, beta, dotw,
-                               partials, done_flag, (int32_t*)nullptr);
+                               folded ? partials + 1024 : partials, done_flag, (int32_t*)nullptr);
             MFEM_CHECK_LAUNCH();
-            np = gs;
+            np = folded ? 0 : gs;
           }
           if (part.part != 1) {
             const int64_t lo = (int64_t)G.p0 * G.PL, hi = (int64_t)G.p1 * G.PL;
             const int64_t outside = (lo + 511) / 512 + (A->n - hi + 511) / 512 + 2;
             const int go = (int)(outside < 1 ? 1 : outside < 1024 ? outside : 1024);
             double* pp = partials ? partials + np : nullptr;
+            const double* fold = folded ? partials + 1024 : nullptr;
+            const int nfold = folded ? gs : 0;
             if (A->dia_triples)
               hipLaunchKernelGGL(k_spmv_dia_outside<true>, dim3(go), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi);
+                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi, fold, nfold);
             else
               hipLaunchKernelGGL(k_spmv_dia_outside<false>, dim3(go), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi);
+                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi, fold, nfold);
             MFEM_CHECK_LAUNCH();
             np += go;
           }
@@ -1458,7 +1556,7 @@ extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int6
     sym = 2;
     // the rows outside the swept planes read their K slots; the sweep reads symp_pairs value pairs
     const int64_t swept = (int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL;
-    e = (int64_t)A->ell_K * (A->ell_npad - swept) + 2 * symp_count_pairs(A, symp_grid(ctx, A));
+    e = (int64_t)A->ell_K * (A->ell_npad - swept) + symp_count_entries(A, symp_nseg(ctx, A));
   } else if (mode == 2 && sym27_wanted(A)) {
     sym = 1;
     const int gs = sym27_grid(ctx, A, nullptr);
