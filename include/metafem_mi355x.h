@@ -106,11 +106,17 @@ int64_t mfem_debug_sym_spmv_count(void);
 int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
                             double beta);
 
-/* ---- tuning / diagnostic hooks (benchmarks, profiling and tests only; process-wide) -------------------------------- */
+/* ---- tuning / diagnostic hooks (benchmarks, profiling and tests only) ------------------------------------------------
+ * NOT part of the drop-in surface.  Every mfem_debug_set_* knob is PROCESS-WIDE state read at launch time: set it only while no
+ * call is in flight on any context of the process (the "one context per host thread" rule above covers the seams, not these
+ * knobs).  Each call bumps an epoch that is part of the cycle-graph cache key, so cached graphs never outlive a knob change.
+ * None of them changes results beyond round-off; kernel variants that compute WRONG results for timing purposes live in tools/,
+ * not in this library. */
 /* CSR tile kernel: tiles per XCD run (0 = dispatcher round-robin) | variant << 16, persistent workgroups per CU. */
 int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
- * bit 20 XCD-contiguous row chunks; bit 21 timing probe without x loads (WRONG results); bit 22 symmetric sweep kernel off;
+ * bit 20 XCD-contiguous row chunks; bit 22 symmetric sweep kernels off; bit 23 the workgroup-tile sweep (k_spmv_sym27) instead of
+ * the wave-private patch sweep (k_spmv_symp);
  * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
 int mfem_debug_set_ell(int enable);
 /* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
@@ -131,8 +137,7 @@ int mfem_debug_set_halo_overlap(int on);
 /* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
  * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
  * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
- * 16 GiB scratch budget).  Bits 8-12: timing probe that leaves kernel phases out (results WRONG): 0x100 node loads,
- * 0x200 Jacobians, 0x400 MFMA loop, 0x800 scatter / scratch store. */
+ * 16 GiB scratch budget). */
 int mfem_debug_set_hex27(int two_pass);
 /* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
  * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */

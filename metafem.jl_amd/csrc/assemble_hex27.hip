@@ -149,7 +149,6 @@ struct Hex27Args {
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
   int nq, ng;
   int e_lo, e_cnt, ring;  // element planes [e_lo, e_lo + e_cnt) of dimension 0 this launch covers; scratch variant: plane I kept in ring slot I % ring
-  int skip;          // timing probe only (WRONG results): 1 no node loads, 2 no J / inverse, 4 no MFMA loop, 8 no scatter
 };
 
 // Walk of one wave over its elements: the elements of a launch form an n0 x n1 x n2 grid (one colour's sub-lattice, or the
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   };
   auto fetch_nodes = [&](int I, int J, int K) -> NodePre {
     NodePre n{0.0, 0.0, 0.0, 0, 0, 0};
-    if (lane < 27 && !(A.skip & 1)) {
+    if (lane < 27) {
       const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
       const int64_t c = brick_cindex(B, gi, gj, gk);
       n.x0 = B.X0[c];
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     //      (dN[q][a][0] = D(q0,a0) L(q1,a1) L(q2,a2), ...): three stages of 3-term sums through the wave's LDS block,
     //      ~2000 multiply-adds per element instead of 6561 -- FP64 VALU work runs on the same pipe as the FP64 MFMAs
     //      on this chip (the phase ablation is additive), so every VALU instruction saved here is matrix-core time.
-    if (!(A.skip & 2)) {
+    {
       for (int t = lane; t < n1; t += 64) {
         const int d = s_dec[t];
         const double* x = W + W_X + (d & 0xffff);
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 2b. det, inverse (adjugate, inv_Jac_3D), w det ; Jinv overwrites J as [m][s]
-    for (int q = lane; q < nq && !(A.skip & 2); q += 64) {
+    for (int q = lane; q < nq; q += 64) {
       double* Jm = W + W_J + q * 9;
       const double j00 = Jm[0], j01 = Jm[1], j02 = Jm[2], j10 = Jm[3], j11 = Jm[4], j12 = Jm[5], j20 = Jm[6], j21 = Jm[7],
                    j22 = Jm[8];
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       // sum_m dN[q][a][m] G_q[m][n] (3 FMAs).  The order of the 3 nq rows along k is free: k-steps 3 g + n (n = 0..2) carry
       // the rows (q = 4 g + kl, n), so a lane keeps one Gauss point for three steps and reads its six table entries and the
       // six entries of G once per group (12 LDS words per group; the first version read 30).
-      const int ngroups = (A.skip & 4) ? 1 : (nq + 3) >> 2;
+      const int ngroups = (nq + 3) >> 2;
       for (int g = 0; g < ngroups; ++g) {
         const int q = 4 * g + kl;
         double d0[3] = {0.0, 0.0, 0.0}, d1[3] = {0.0, 0.0, 0.0};
@@ -431,10 +430,6 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
         // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
         //      row-owner gather kernel below turns it into CSR rows.
         double* ke = out + (((int64_t)(Ic % A.ring) * B.ne1 + Jc) * B.ne2 + Kc) * 729;
-        if (A.skip & 8) {
-          if (C00[0] + C01[1] + C11[2] == 1.2345) out[0] = 1.0;  // keeps the accumulators alive
-          continue;
-        }
         const int rc_hi = scratch_row(16 + c > 26 ? 26 : 16 + c);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -456,10 +451,6 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       //      SIMD); all slots of one element are distinct, so a batch's loads are issued together, then its stores
       //      (plain read-modify-write, no atomics).
       const int rq = kl;
-      if (A.skip & 8) {
-        if (C00[0] + C01[1] + C11[2] == 1.2345) out[0] = 1.0;  // keeps the accumulators alive
-        continue;
-      }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         int64_t slot[8];
@@ -745,14 +736,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
 static int g_hex27_two_pass = 1;
-static int g_hex27_skip = 0;
 static int g_hex27_chunk_planes = 0;  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
 static size_t g_hex27_scratch_budget = (size_t)16 << 30;
 extern "C" int mfem_debug_set_hex27(int two_pass) {
   ++mfem_debug_epoch;
   g_hex27_two_pass = (two_pass & 3) == 0 ? 1 : (two_pass & 3);  // 0 / 1 two-pass (default), 2 FP64 atomics, 3 colour scatter
   g_hex27_chunk_planes = (two_pass >> 16) & 255;
-  g_hex27_skip = (two_pass >> 8) & 31;  // timing probe (tools/probe_hex27.py): phases left out, results WRONG
   return MFEM_OK;
 }
 
@@ -827,7 +816,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   if (g_hex27_two_pass == 2) {
     MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
     const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
-    Hex27Args A{B, g_tab, p->k, -2, nq, m->ng, 0, m->ne[0], 1, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, -2, nq, m->ng, 0, m->ne[0], 1};
     int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
@@ -854,7 +843,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     const int64_t plane_rows = B.plane_len;
     for (int a = elo; a < ehi; a += P) {
       const int b = a + P < ehi ? a + P : ehi;
-      Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, a, b - a, ring, g_hex27_skip};
+      Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, a, b - a, ring};
       int64_t grid = ((b - a) * plane_el + H27_WAVES - 1) / H27_WAVES;
       const int64_t cap = (int64_t)ctx->num_cus * 2;
       if (grid > cap) grid = cap;
@@ -874,7 +863,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   for (int colour = 0; colour < 8; ++colour) {
     const int64_t ne = hex27_colour_count(m, colour, elo, ehi);
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1, g_hex27_skip};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
@@ -898,7 +887,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
   for (int colour = 0; colour < 8; ++colour) {
     const int64_t ne = hex27_colour_count(m, colour, elo, ehi);
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1, 0};
+    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;

@@ -124,14 +124,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_lds(
           const int i = i0 + u * 2 * BLK;
           if (i < cnt) {
             // entry i+1 may belong to the next tile (i + 1 == cnt): its product is never read
-            double x0, x1;
-            if (xcd_aware & (1 << 30)) {  // timing probe: no gather
-              x0 = (double)c[u].x;
-              x1 = (double)c[u].y;
-            } else {
-              x0 = x[c[u].x - base];
-              x1 = (i + 1 < cnt) ? x[c[u].y - base] : 0.0;
-            }
+            const double x0 = x[c[u].x - base];
+            const double x1 = (i + 1 < cnt) ? x[c[u].y - base] : 0.0;
             *reinterpret_cast<d2_t*>(&prod[i]) = (d2_t){v[u].x * x0, v[u].y * x1};
           }
         }
@@ -474,13 +468,11 @@ static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spm
 //   4 row-transposing workgroup tile, CAP 4032, 256 threads
 //   6 wave-private row-transposing tiles (1792 / 2048 entries per wave), 2 waves per workgroup   7 (and 5) the same, 1 wave
 static int g_spmv_variant = 0;
-static int g_spmv_nogather = 0;   // diagnostic only (tools/): replace x[col] by col-derived constants (WRONG results, timing probe)
 
 extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
   ++mfem_debug_epoch;
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
-  g_spmv_nogather = (xcd_aware >> 20) & 1;
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
@@ -751,7 +743,6 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     const int xch = xcd & 0xFFFF;
     const int64_t span = (int64_t)8 * (xch > 0 ? xch : 1);
     const int64_t ntiles_padded = xch ? (ntiles + span - 1) / span * span : ntiles;
-    if (g_spmv_nogather) xcd |= (1 << 30);
 #define LAUNCH_LDS(RP, VEC, CAP, UNR, BLK)                                                                 \
   hipLaunchKernelGGL((k_spmv_lds<RP, VEC, CAP, UNR, BLK>), dim3(grid), dim3(BLK), 0, ctx->stream, A->n,    \
                      A->nnz, (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, R, tpr_log2,  \

@@ -56,10 +56,10 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_ell_enable = enable & 1;
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
   g_dia_variant = (enable >> 16) & 15;
-  g_dia_xcd = (enable >> 20) & 3;
+  g_dia_xcd = (enable >> 20) & 1;
   g_dia_sym = ((enable >> 22) & 1) ? 0 : 1;
   g_dia_symp = ((enable >> 23) & 1) ? 0 : 1;
-  g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks; bit 21: timing probe without x loads
+  g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
   return MFEM_OK;
@@ -363,15 +363,8 @@ __device__ __forceinline__ void dia_rows(int64_t r, int64_t n, int64_t npad, int
       const e_d2 va = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + s * ELL_B));
       const e_d2 vb = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 1) * ELL_B));
       const e_d2 vc = __builtin_nontemporal_load(reinterpret_cast<const e_d2*>(v + (s + 2) * ELL_B));
-      u_d2 xa, xb;
-      if (xcd & 2) {  // timing probe (bit 21 of mfem_debug_set_ell): no x loads, WRONG results
-        xa = (u_d2){1.0, 1.0};
-        xb = xa;
-      } else {
-        const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
-        xa = xp[0];
-        xb = xp[1];
-      }
+      const u_d2* xp = reinterpret_cast<const u_d2*>(x + r + off[s]);
+      const u_d2 xa = xp[0], xb = xp[1];
       acc[0].x += va.x != 0.0 ? va.x * xa.x : 0.0;
       acc[0].y += va.y != 0.0 ? va.y * xa.y : 0.0;
       acc[0].x += vb.x != 0.0 ? vb.x * xa.y : 0.0;

@@ -20,7 +20,7 @@ out = {
     "workload": f"hex-8 256^3 thermal K (n={n}, nnz={nnz}), inside the CG loop",
     "FETCH_SIZE_KB_mean": {k: F[k]["mean_KB"] for k in ks}, "WRITE_SIZE_KB_mean": {k: W[k]["mean_KB"] for k in ks},
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced streaming reads (MI355X_MICROARCH.md HBM section); calibration in "
-                  f"the same run on k_cg_update: 5 vectors read = {5 * n * 8 / 1e6:.1f} MB, FETCH_SIZE x 2 = {F[cal]['mean_KB'] * 2048 / 1e6:.1f} MB; "
+                  f"the same run on k_cg_update: 3 vectors read = {3 * n * 8 / 1e6:.1f} MB, FETCH_SIZE x 2 = {F[cal]['mean_KB'] * 2048 / 1e6:.1f} MB; "
                   f"1 vector written = {n * 8 / 1e6:.1f} MB, WRITE_SIZE = {W[cal]['mean_KB'] * 1024 / 1e6:.1f} MB",
     "hbm_bytes_per_launch": fetch + write,
     "note": "tools/run_pmc_ell.sh + tools/make_spmv_traffic.py; separate --pmc passes for FETCH_SIZE and WRITE_SIZE",

@@ -35,15 +35,9 @@ _lib.lib.mfem_debug_set_hex27(3)
 ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
 print("atomics vs colours max rel diff", float((Ka - K).abs().max() / K.abs().max()))
 print(f"assemble colour scatter {ms:.2f} ms -> {flops/ms/1e9:.2f} TFLOP/s useful Ke (2*27*27*81 per element), {A.nnz*8/ms/1e6:.0f} GB/s of nnz*8", flush=True)
-VARIANT = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 _lib.lib.mfem_debug_set_hex27(0)
-if len(sys.argv) > 2:  # phase ablation (timing only; the skipped phases make the values wrong)
-    for name, skip in (("all phases", 0), ("no scatter", 8), ("no scatter, no MFMA loop", 12), ("no scatter, no MFMA, no Jacobians", 14),
-                       ("nothing but the loop skeleton", 15), ("no MFMA loop only", 4), ("no node loads only", 1), ("no Jacobians only", 2)):
-        _lib.lib.mfem_debug_set_hex27((skip << 8) | VARIANT)
-        ms = timeit(lambda: brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K), reps=3)
-        print(f"  ablation [{name}]: {ms:.2f} ms", flush=True)
-    _lib.lib.mfem_debug_set_hex27(0)
+# (the phase ablation of round 1 -- kernel phases left out, wrong values -- was a timing probe inside the product kernel; it was removed
+# from the library in round 2, its numbers are in profiles/r01_hex27_mfma_counters.txt)
 x = mf.FEM_rand(A.n, 1, 0); y = torch.empty_like(x)
 ms = timeit(lambda: brick.residual_thermal(x, 0.6, 25.0, 293.15, 0x3F, s=x, out=y), reps=3)
 print(f"residual {ms:.2f} ms", flush=True)
