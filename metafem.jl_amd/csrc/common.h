@@ -137,7 +137,7 @@ struct mfem_csr_s {
   int64_t symp_PL;          // rows per lattice plane (m1 * m2)
   int symp_p0, symp_p1;     // regular lattice planes [p0, p1) (plane = row / PL): the rows the sweep computes
   int symp_NS, symp_NPk;    // strips of 4 lines, patches of 32 points per line
-  double* symp_vals;        // not owned (solver workspace, behind ell_vals): [patch][plane - p0][27 x 128 + edge block]
+  double* symp_vals;        // not owned (solver workspace, behind ell_vals): [plane - p0][patch][27 x 128 + edge block]
   int symp_bound;           // 1 = the bound values passed the bitwise symmetry check of the mirrored pairs
   int64_t symp_pairs;       // value pairs (16 bytes) one SpMV of the sweep reads from memory (accounting)
   // row-sorted sliced ELL for rows of uneven length (spmv_sell.hip): sell_state 0 = not planned, -1 = no, 1 = ready

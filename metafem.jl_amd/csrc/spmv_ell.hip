@@ -658,19 +658,30 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 // only the in-line diagonals mirrorable (31 %), and two workgroup barriers per chunk bound what three workgroups per CU can keep
 // in flight.  Here a WAVE owns a (j, k) patch of 4 lattice lines x 32 points (lane <-> two neighbouring points of one line) and
 // sweeps it through consecutive lattice planes with no workgroup barrier at all:
-//   * the matrix values of the swept planes live in a patch-major copy  pv[patch][plane][27 slots][128 rows]  (one
-//     contiguous 1 KB run per slot and step, a wave's whole run one contiguous piece; made by k_symp_bind when the solve
-//     binds its values);
+//   * the matrix values of the swept planes live in a patch-major copy  pv[plane][patch][27 slots x 128 rows + edge block]  (one
+//     contiguous 1 KB run per slot and step; made by k_symp_bind when the solve binds its values);
 //   * the upper diagonals of a step go to the wave's LDS block when they are loaded: +z / +y (slots 14..17) for the rows behind
 //     them in this plane, the nine next-plane diagonals (18..26) for the same patch one plane on -- 10.5 of the 13 lower
 //     diagonals of a row are mirrored from there whatever the line length (the rest: patch edges, read from the row's own slot);
 //   * x is staged per plane: the (4 + 2) x (32 + 2) neighbourhood of the patch enters LDS once and serves the 27 products of three
 //     consecutive steps -- four global loads per lane and step instead of eighteen gathers.
-// Same products, same summation order as the plain diagonal-slotted kernel: y is bitwise the same whenever the mirrored pairs
-// are bitwise equal (MODE 1 checks exactly those pairs when the values are bound).  Work is cut into equal runs of
-// (patch, plane) steps, one per wave, 8 one-wave workgroups per CU; a run's first step (and the first step of a patch) has no
-// history and reads all 27 slots.  Rows outside the swept planes (first / last lattice plane, planes next to the ghost planes of
-// a slab) are computed by k_spmv_dia_outside from the slot-major copy.
+// Same products, same summation order as the plain diagonal-slotted kernel (v_mul_f64 + v_add_f64, no contraction): y is bitwise the
+// same whenever the mirrored pairs are bitwise equal (MODE 1 checks exactly those pairs when the values are bound).
+//   * A halo cell of a mirror table (its source row belongs to another patch) is filled from the step's EDGE BLOCK -- the own
+//     slot-s entries of the rows at the patch rim, 318 doubles stored behind the step's 27 slots -- so that every lane reads every
+//     lower slot with the same two LDS loads; a step reads 14 slots x 1 KB + 2.5 KB of edge block + 1.6 KB of x.
+//   * Everything a step needs from memory is requested one step ahead into registers (its loads are in flight during the products
+//     of the current step); two wave-level barriers per step order the LDS phases.
+//   * Runs: a run = one patch through nplanes / nseg consecutive planes, one wave (one-wave workgroups, 7 per CU: 22.8 KB of LDS
+//     each); a run's first step has no history and fills the previous-plane tables from the rows' own slots.  XCD c (workgroups
+//     with blockIdx % 8 == c) sweeps a contiguous eighth of the patches, segment by segment, so neighbouring patches advance
+//     through the planes together on one L2 (512^3: CG iteration 7.29 -> 6.66 ms against arbitrary equal cuts of the step list).
+//   * Rows outside the swept planes (first / last lattice plane, planes next to the ghost planes of a slab) are computed by
+//     k_spmv_dia_outside from the slot-major copy; it also folds the sweep's per-wave partial sums of a fused dot product.
+// Measured (CG iteration, tools/probe_sym.py): see symp_wanted().  What bounds it: 2.78 GB of fabric traffic per SpMV at 256^3
+// (2.61 GB by the count above) in 0.59 ms = 4.7 TB/s; the time does not depend on the number of resident waves (2 .. 7 per CU), the
+// y stores cost 0.1 ms of it (non-temporal 16-byte stores: -1.5 %), the edge block 0.07 ms, the x staging 0.03 ms
+// (profiles/r02_symp_experiments.txt).
 // ---------------------------------------------------------------------------------------------------------------
 #define SP_L 4
 #define SP_W 32
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   cur_patch = -1;
   for (int64_t t = t0; t < t1; ++t) {
     const int p = Gm.p0 + (int)(t - (int64_t)patch * nplanes);
-    const double* v = pv + t * SP_STEP;  // [patch][plane]: a run streams through one contiguous piece of the copy
+    const double* v = pv + ((int64_t)(p - Gm.p0) * NP + patch) * SP_STEP;  // [plane][patch]: the runs of a segment advance plane by plane together
     if (patch != cur_patch) {  // wave-uniform: a run or a patch starts -- nothing was requested ahead, no history
       cur_patch = patch;
       const int j0 = (patch / Gm.NPk) * SP_L, k0 = (patch % Gm.NPk) * SP_W;
@@ -841,7 +852,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
     for (int u = 0; u < 14; ++u) mine[u] = cur[u];
     const bool more = t + 1 < t1 && p + 1 < Gm.p1;  // the next step continues this sweep
     __syncthreads();  // one wave: orders its LDS writes before the reads of other lanes
-    if (more) request(v + SP_STEP, p + 2);
+    if (more) request(v + (int64_t)NP * SP_STEP, p + 2);
     auto mirrored = [&](int s) -> e_d2 {
       const double* c = tab + sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb;
       e_d2 w;
@@ -933,7 +944,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   }
 }
 
-// patch-major copy of the swept planes from the slot-major copy: pv[patch][plane - p0] = 27 slots x 128 rows + the edge block, zero
+// patch-major copy of the swept planes from the slot-major copy: pv[plane - p0][patch] = 27 slots x 128 rows + the edge block, zero
 // where the patch sticks out of the lattice; one wave per (plane, patch)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, const double* __restrict__ ell, double* __restrict__ pv) {
   const int lane = threadIdx.x & 63, lj = lane >> 4, pk = lane & 15;
@@ -946,7 +957,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, co
     const bool vx = j < Gm.m1 && k < Gm.m2, vy = j < Gm.m1 && k + 1 < Gm.m2;
     const int64_t r = (int64_t)p * Gm.PL + (int64_t)j * Gm.m2 + k;
     const int64_t b0 = ell_base(r, K), b1 = ell_base(r + 1, K);
-    double* out = pv + t * SP_STEP;
+    double* out = pv + ((int64_t)(p - Gm.p0) * NP + patch) * SP_STEP;
     for (int s0 = 0; s0 < 27; s0 += 9) {
       e_d2 w[9];
 #pragma unroll
