@@ -263,7 +263,9 @@ def main():
                                   "matrix made once per solve; the values passed the per-solve bitwise symmetry check, so lower-diagonal "
                                   "entries are mirrored through LDS (bitwise the same y as the plain diagonal-slotted kernel)")
                     plain_bytes = spmv_bytes
-                    spmv_bytes = ent.value * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
+                    byts = C.c_int64()
+                    _lib.check(_lib.lib.mfem_csr_solver_layout_bytes(ctx._h, A._h, C.byref(byts)))
+                    spmv_bytes = byts.value  # matrix entries read + columns of generic blocks + x as staged / read by design + y
             elif mode.value == 1:
                 kernel = "k_spmv_ell<2,1> (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)"
                 spmv_bytes = A.nnz * 12 + A.n * 16
@@ -333,7 +335,9 @@ def main():
                 **({"plain_diagonal_kernel_bytes_per_launch": r["plain_bytes"],
                     "note": "algorithmic bytes = what this kernel design reads: 8 B per matrix entry not mirrored from LDS "
                             "(14 upper-diagonal entries per row + the patch-edge entries; workgroup-tile sweep: about 18.6 of 27) "
-                            "+ x + y; the plain diagonal-slotted kernel reads plain_diagonal_kernel_bytes_per_launch"}
+                            "+ x as the kernel stages it (patch sweep: overlapping patch neighbourhoods, 1.6 n entries) + y "
+                            "(mfem_csr_solver_layout_bytes); the plain diagonal-slotted kernel reads "
+                            "plain_diagonal_kernel_bytes_per_launch"}
                    if r["sym_used"] else {}),
                 "csr_equivalent": {"bytes_per_launch": r["csr_bytes"], "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
                                    "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "

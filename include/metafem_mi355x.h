@@ -95,12 +95,17 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
                            int64_t* regular_rows);
 /* Symmetric sweep (mode 2, 27-point lattice stencil, one field): when the values of a solve are bitwise symmetric where it
- * matters (checked once per solve on the slot-major copy), a row's entries on the 13 lower diagonals are taken from the mirror
- * entry of the neighbouring row -- kept in LDS by a workgroup that sweeps an in-plane tile of 512 rows through consecutive
- * lattice planes -- instead of from memory: same products, same summation order, bitwise the same y as the plain kernel,
- * about 2/3 of its matrix traffic.  entries = 8-byte matrix values one SpMV of the planned layout reads from memory
- * (symmetric_sweep = 1: assuming the values pass the check).  mfem_debug_sym_spmv_count: launches of that kernel so far. */
+ * matters (checked once per solve), a row's entries on the 13 lower diagonals are taken from the mirror entry of the neighbouring
+ * row, kept in LDS, instead of from memory: same products, same summation order, bitwise the same y as the plain kernel.  Two
+ * forms: 1 = a workgroup sweeps an in-plane tile of 512 rows through consecutive lattice planes (about 2/3 of the matrix traffic
+ * while a lattice line fits the tile twice); 2 = a wave sweeps a (j, k) patch of 4 lattice lines x 32 points on a patch-major copy
+ * (14 of a row's 27 entries + the patch-rim entries, whatever the line length; x staged per plane in LDS) -- used from 2.4e7 rows /
+ * 257-point lines on.  entries = 8-byte matrix values one SpMV of the planned layout reads from memory, bytes (may be NULL) = all
+ * bytes the planned kernel reads and writes per SpMV by design: those entries, 4-byte columns of rows in generic blocks, x as
+ * often as the kernel stages / gathers it from memory by design (form 2: the patch neighbourhoods overlap, 1.6 n entries), y.
+ * symmetric_sweep = 0 / 1 / 2 (assuming the values pass the check).  mfem_debug_sym_spmv_count: launches of those kernels so far. */
 int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep);
+int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes);
 int64_t mfem_debug_sym_spmv_count(void);
 /* y = alpha A x + beta y through that layout, conversion of `vals` included (diagnostic: what the Krylov loop computes). */
 int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,

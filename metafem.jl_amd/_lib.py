@@ -149,6 +149,7 @@ SIGNATURES = {
     "mfem_spmv_solver_layout": (c_int, [P, P, P, P, P, c_double, c_double]),
     "mfem_csr_solver_layout": (c_int, [P, P, C.POINTER(c_int32), C.POINTER(c_int32), C.POINTER(c_int64), C.POINTER(c_int64)]),
     "mfem_csr_solver_layout_entries": (c_int, [P, P, C.POINTER(c_int64), C.POINTER(c_int32)]),
+    "mfem_csr_solver_layout_bytes": (c_int, [P, P, C.POINTER(c_int64)]),
     "mfem_debug_sym_spmv_count": (c_int64, []),
     "mfem_op_kval_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(KvalTerm), P, P, c_int64, c_int64, P, P, P, c_int64]),
     "mfem_op_res_batch": (c_int, [P, C.POINTER(OpLayout), P, c_int32, C.POINTER(ResBatchTerm), P, P, P, P, P, c_int64]),

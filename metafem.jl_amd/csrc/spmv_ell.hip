@@ -683,53 +683,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 // y stores cost 0.1 ms of it (non-temporal 16-byte stores: -1.5 %), the edge block 0.07 ms, the x staging 0.03 ms
 // (profiles/r02_symp_experiments.txt).
 // ---------------------------------------------------------------------------------------------------------------
-#define SP_L 4
-#define SP_W 32
-#define SP_ROWS (SP_L * SP_W)
-#define SP_XL (SP_L + 2)
-#define SP_XW 36  // 34 points (k0 - 1 .. k0 + 32) + 2: lines stay 16-byte aligned
-#define SP_XN (SP_XL * 34)
-#define SP_WG_PER_CU 7
-// Mirror tables: one per lower slot s = (di, dj, dk), holding slot 26 - s of the SOURCE rows (row + offset), indexed by source
-// cell (line lj + dj, column 2 pk + dk): lines of 36 doubles, column c at index c + 2 (column -1 and column 32 are halo cells), a
-// halo line on the side the slot points to.  A halo cell cannot be mirrored (its source row belongs to another patch): it
-// receives the referencing row's OWN slot-s entry from the step's edge block, so that the reads are the same two LDS loads for
-// every lane and slot.
-#define SP_LS 36
-__host__ __device__ constexpr int sp_dj(int s) { return (s / 3) % 3 - 1; }
-__host__ __device__ constexpr int sp_dk(int s) { return s % 3 - 1; }
-__host__ __device__ constexpr int sp_tsize(int s) { return (sp_dj(s) == 0 ? SP_L : SP_L + 1) * SP_LS; }
-__host__ __device__ constexpr int sp_tbase(int s) { return s == 0 ? 0 : sp_tbase(s - 1) + sp_tsize(s - 1); }
-__host__ __device__ constexpr int sp_adj(int s) { return sp_dj(s) == -1 ? 1 : 0; }  // table line of source line 0
-#define SP_TAB (sp_tbase(12) + sp_tsize(12))
-// edge block of a step: for s = 0..12 the halo cells of table s -- the halo line (32 cells) if dj != 0, then the halo column
-// (lines in ascending order) if dk != 0
-__host__ __device__ constexpr int sp_ecnt(int s) { return (sp_dj(s) != 0 ? SP_W : 0) + (sp_dk(s) != 0 ? (sp_dj(s) != 0 ? SP_L - 1 : SP_L) : 0); }
-__host__ __device__ constexpr int sp_ebase(int s) { return s == 0 ? 0 : sp_ebase(s - 1) + sp_ecnt(s - 1); }
-#define SP_NE (sp_ebase(12) + sp_ecnt(12))  // 318
-#define SP_EPAD 320
-#define SP_STEP (27 * SP_ROWS + SP_EPAD)    // doubles per (plane, patch) in the patch-major copy
-// entry e of the edge block: lower slot s, the referencing row's (line, column) in the patch, the LDS cell of table s it fills
-__host__ __device__ inline bool sp_edge(int e, int& s, int& line, int& col, int& cell) {
-  if (e >= SP_NE) return false;
-  s = 0;
-  while (e >= sp_ebase(s) + sp_ecnt(s)) ++s;
-  int q = e - sp_ebase(s);
-  const int dj = sp_dj(s), dk = sp_dk(s);
-  int sl, sc;
-  if (dj != 0 && q < SP_W) {
-    sl = dj < 0 ? -1 : SP_L;
-    sc = dk + q;
-  } else {
-    if (dj != 0) q -= SP_W;
-    sl = dj > 0 ? q + 1 : q;
-    sc = dk < 0 ? -1 : SP_W;
-  }
-  line = sl - dj;
-  col = sc - dk;
-  cell = sp_tbase(s) + (sl + sp_adj(s)) * SP_LS + sc + 2;
-  return true;
-}
+#include "spmv_symp.h"
 struct SympGeom {
   int64_t PL, nx;
   int m1, m2, p0, p1, NS, NPk;
@@ -1569,6 +1523,30 @@ extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int6
   }
   if (entries) *entries = e;
   if (symmetric_sweep) *symmetric_sweep = sym;
+  return MFEM_OK;
+}
+
+// Bytes one SpMV of the planned solver layout moves by design (bench.py's roofline numerator): matrix entries, 4-byte columns where the
+// kernel reads them, x as often as the kernel fetches it from memory by design, y once.
+extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes) {
+  MFEM_REQUIRE(ctx && A && bytes, "null argument");
+  int32_t mode = 0, slots = 0, sym = 0;
+  int64_t npad = 0, reg = 0, ent = 0;
+  int rc = mfem_csr_solver_layout(ctx, A, &mode, &slots, &npad, &reg);
+  if (rc) return rc;
+  rc = mfem_csr_solver_layout_entries(ctx, A, &ent, &sym);
+  if (rc) return rc;
+  int64_t b = ent * 8 + A->n * 16;
+  if (mode == 0) b = A->nnz * 12 + A->n * 16 + (A->n + 1) * (A->rowptr_bits / 8);
+  if (mode == 1 || mode == 3) b = ent * 12 + A->n * 16;
+  if (mode == 2) {
+    b += (A->n > reg ? A->n - reg : 0) * (int64_t)slots * 4;  // rows in generic blocks read their columns
+    if (sym == 2) {  // the sweep stages a (4 + 2) x (32 + 2) neighbourhood of x per step instead of reading each swept entry once
+      const int64_t swept = (int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL;
+      b += symp_steps(A) * (int64_t)SP_XN * 8 - swept * 8;
+    }
+  }
+  *bytes = b;
   return MFEM_OK;
 }
 
