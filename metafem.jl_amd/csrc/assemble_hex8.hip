@@ -309,18 +309,29 @@ __global__ __launch_bounds__(TT_THREADS) void k_thermal_matrix(BrickView B, doub
       }
 }
 
-// Boundary control points of the owned planes, enumerated compactly: blockIdx.y = owned plane, thread t of the plane = a point of
-// the whole plane on the first / last lattice plane, else a point of the plane's rim (2 m2 + 2 (m1 - 2) points).
+// Boundary control points of the owned planes, enumerated compactly by one 1-D grid: the whole first lattice plane (if owned), the whole
+// last one (if owned), then the rim (2 m2 + 2 (m1 - 2) points) of every other owned plane.
+__host__ __device__ __forceinline__ int64_t boundary_count(int plo, int phi, int ne0, int64_t plane_len, int m1, int m2) {
+  const int64_t rim = 2 * (int64_t)m2 + 2 * (int64_t)(m1 - 2);
+  const int f0 = plo == 0 ? 1 : 0, f1 = phi - 1 == ne0 ? 1 : 0;
+  return (f0 + f1) * plane_len + (int64_t)(phi - plo - f0 - f1) * rim;
+}
 __device__ __forceinline__ bool boundary_point(const BrickView& B, int& i, int& j, int& k) {
-  i = B.plo + (int)blockIdx.y;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 || i == B.ne0) {
-    if (t >= B.plane_len) return false;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int f0 = B.plo == 0 ? 1 : 0, f1 = B.phi - 1 == B.ne0 ? 1 : 0;
+  if (t < (f0 + f1) * B.plane_len) {
+    i = (f0 && t < B.plane_len) ? 0 : B.ne0;
+    if (f0 && t >= B.plane_len) t -= B.plane_len;
     j = (int)(t / B.m2);
     k = (int)(t % B.m2);
     return true;
   }
-  if (t >= 2 * (int64_t)B.m2 + 2 * (int64_t)(B.m1 - 2)) return false;
+  t -= (f0 + f1) * B.plane_len;
+  const int64_t rim = 2 * (int64_t)B.m2 + 2 * (int64_t)(B.m1 - 2);
+  const int64_t pl = t / rim;
+  if (pl >= B.phi - B.plo - f0 - f1) return false;
+  i = B.plo + f0 + (int)pl;
+  t -= pl * rim;
   if (t < 2 * (int64_t)B.m2) {
     j = t < B.m2 ? 0 : B.ne1;
     k = (int)(t < B.m2 ? t : t - B.m2);
@@ -710,8 +721,9 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   }
 }
 
-static dim3 boundary_grid(const mfem_brick_s* m) {  // boundary_point(): a plane's worth of threads per owned plane
-  return dim3((unsigned)((m->plane_len + MFEM_BLOCK - 1) / MFEM_BLOCK), (unsigned)(m->phi - m->plo));
+static dim3 boundary_grid(const mfem_brick_s* m) {  // boundary_point(): one thread per boundary control point of the owned planes
+  const int64_t cnt = boundary_count(m->plo, m->phi, m->ne[0], m->plane_len, m->m[1], m->m[2]);
+  return dim3((unsigned)((cnt + MFEM_BLOCK - 1) / MFEM_BLOCK > 0 ? (cnt + MFEM_BLOCK - 1) / MFEM_BLOCK : 1));
 }
 static int g_thermal_variant = 0;  // 1: the 4 x 4 x 8 tile kernels for every Gauss order (kept: 1- and 4-point rules use them)
 extern "C" int mfem_debug_set_hex8_thermal(int variant) {
