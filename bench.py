@@ -254,7 +254,7 @@ def main():
                     # symmetric sweep: the lower-diagonal entries a workgroup still holds in LDS are not read again; `ent` = 8-byte
                     # matrix values one SpMV reads from memory (27 slots per padded row minus the mirrored ones)
                     if symf.value == 2:
-                        kernel = ("k_spmv_symp<0> (+ k_spmv_dia_outside on the two boundary planes): symmetric sweep on wave-private "
+                        kernel = ("k_spmv_symp<0> (one launch: the sweep, then the two boundary planes row by row): symmetric sweep on wave-private "
                                   "(j, k) patches of a patch-major copy of the CSR matrix made once per solve; the values passed the "
                                   "per-solve bitwise symmetry check, so 10.5 of a row's 13 lower-diagonal entries are mirrored through "
                                   "LDS (bitwise the same y as the plain diagonal-slotted kernel); x staged per lattice plane in LDS")

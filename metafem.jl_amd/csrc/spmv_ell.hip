@@ -44,6 +44,7 @@ static int g_dia_enable = 1;
 static int g_dia_variant = 0;
 static int g_dia_block = MFEM_BLOCK;  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
 static int g_dia_sym = 1;      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernels off
+static int g_symp_tail = 1;    // bit 26: 0 = the rows outside the swept planes in a launch of their own (as in a split SpMV)
 static int g_dia_symp = 1;     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
 static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
@@ -59,6 +60,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_dia_xcd = (enable >> 20) & 1;
   g_dia_sym = ((enable >> 22) & 1) ? 0 : 1;
   g_dia_symp = ((enable >> 23) & 1) ? 0 : 1;
+  g_symp_tail = ((enable >> 26) & 1) ? 0 : 1;
   g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
@@ -676,8 +678,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 //     each); a run's first step has no history and fills the previous-plane tables from the rows' own slots.  XCD c (workgroups
 //     with blockIdx % 8 == c) sweeps a contiguous eighth of the patches, segment by segment, so neighbouring patches advance
 //     through the planes together on one L2 (512^3: CG iteration 7.29 -> 6.66 ms against arbitrary equal cuts of the step list).
-//   * Rows outside the swept planes (first / last lattice plane, planes next to the ghost planes of a slab) are computed by
-//     k_spmv_dia_outside from the slot-major copy; it also folds the sweep's per-wave partial sums of a fused dot product.
+//   * Rows outside the swept planes (first / last lattice plane, the planes next to the ghost planes of a slab) come from the slot-major
+//     copy through the per-row code: the sweep's waves take them in 128-row units after their runs (unsplit SpMV: one launch, no tail);
+//     in a split (multi-rank) SpMV they are the boundary part, a launch of their own (k_spmv_dia_outside) after the halo has arrived.
 // Measured (CG iteration, tools/probe_sym.py): see symp_wanted().  What bounds it: 2.78 GB of fabric traffic per SpMV at 256^3
 // (2.61 GB by the count above) in 0.59 ms = 4.7 TB/s; the time does not depend on the number of resident waves (2 .. 7 per CU), the
 // y stores cost 0.1 ms of it (non-temporal 16-byte stores: -1.5 %), the edge block 0.07 ms, the x staging 0.03 ms
@@ -690,11 +693,20 @@ struct SympGeom {
   int nseg;  // runs per patch: a run = one patch swept through nplanes / nseg consecutive planes
 };
 
+// the rows outside the swept planes, taken by the sweep's waves after their runs (unsplit SpMV): per-row code on the slot-major copy
+struct SympTail {
+  int on, K;
+  int64_t n, npad, lo, hi;  // rows [lo, hi) are the sweep's
+  const DiaOffsets* Op;
+  const int32_t* flags;
+  const int32_t* cols;
+  const double* ell;
+};
 template <int MODE>
 __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __restrict__ pv, const double* __restrict__ x,
                                                    double* __restrict__ y, double alpha, double beta,
                                                    const double* __restrict__ dotw, double* __restrict__ partials,
-                                                   const int32_t* __restrict__ done_flag, int32_t* __restrict__ bad) {
+                                                   const int32_t* __restrict__ done_flag, int32_t* __restrict__ bad, SympTail tail) {
   __shared__ __attribute__((aligned(16))) double xs[3][SP_XL][SP_XW];
   __shared__ __attribute__((aligned(16))) double tab[SP_TAB + 2];
   if (done_flag && done_flag[0]) return;
@@ -890,6 +902,16 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
     if (!more) cur_patch = -1;  // nothing requested: the next step (if any) starts like a run
   }
   }
+  if (MODE == 0 && tail.on) {
+    // 128-row units in front of and behind the swept planes (a unit straddling the boundary is masked row by row), shared among the waves
+    const int64_t UA = (tail.lo + 127) / 128, ub = tail.hi / 128, UB = (tail.n + 127) / 128 - ub;
+    for (int64_t u = blockIdx.x; u < UA + UB; u += gridDim.x) {
+      const int64_t r = (u < UA ? u : ub + (u - UA)) * 128 + 2 * lane;
+      if (r < tail.n)
+        dia_rows<2, 3, true>(r, tail.n, tail.npad, tail.K, *tail.Op, tail.flags, tail.cols, tail.ell, x, y, alpha, beta, dotw, 0, dot_acc,
+                             tail.lo, tail.hi);
+    }
+  }
   if (MODE == 1) {
     if (fail) atomicOr(bad, 1);
   } else if (partials) {
@@ -940,15 +962,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia_outside(int64_t n, int6
                                                                    const double* __restrict__ vals, const double* __restrict__ x,
                                                                    double* __restrict__ y, double alpha, double beta,
                                                                    const double* __restrict__ dotw, double* __restrict__ partials,
-                                                                   const int32_t* __restrict__ done_flag, int64_t skip_lo, int64_t skip_hi,
-                                                                   const double* __restrict__ fold, int nfold) {
+                                                                   const int32_t* __restrict__ done_flag, int64_t skip_lo, int64_t skip_hi) {
   __shared__ double red[16];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
-  // workgroup 0 also folds the sweep launch's per-wave partial sums (fixed order), so that the consumers of this SpMV's dot product
-  // re-reduce a few hundred partials instead of a few thousand
-  if (blockIdx.x == 0 && partials)
-    for (int i = threadIdx.x; i < nfold; i += MFEM_BLOCK) dot_acc += fold[i];
   const int64_t R = 2 * MFEM_BLOCK, nchunks = (n + R - 1) / R;
   int64_t cA = (skip_lo + R - 1) / R, cB = skip_hi / R;
   if (cB < cA) cB = cA;
@@ -1283,7 +1300,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
       MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
       const int gs = symp_grid(ctx, A);
       hipLaunchKernelGGL(k_spmv_symp<1>, dim3(gs), dim3(64), 0, ctx->stream, G, (const double*)pvals, (const double*)nullptr,
-                         (double*)nullptr, 0.0, 0.0, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, d_bad);
+                         (double*)nullptr, 0.0, 0.0, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, d_bad, SympTail{});
       MFEM_CHECK_LAUNCH();
       MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
       MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1418,28 +1435,39 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
           const SympGeom G = symp_geom(ctx, A);
           const int gs = symp_grid(ctx, A);
           int np = 0;
-          // unsplit SpMV: the sweep's partial sums go behind the outside launch's (<= 1024) and are folded by it
-          const bool folded = part.part == 0 && partials;
+          const int64_t lo = (int64_t)G.p0 * G.PL, hi = (int64_t)G.p1 * G.PL;
+          // unsplit SpMV: the rows outside the swept planes are taken by the sweep's waves after their runs (no second launch, no tail);
+          // split SpMV (multi-rank): part 1 = the sweep alone (it reads no ghost column), part 2 = the other rows in a launch of their own
+          SympTail tl{};
+          if (part.part == 0 && g_symp_tail) {
+            tl.on = 1;
+            tl.K = A->ell_K;
+            tl.n = A->n;
+            tl.npad = A->ell_npad;
+            tl.lo = lo;
+            tl.hi = hi;
+            tl.Op = O;
+            tl.flags = A->dia_flags;
+            tl.cols = A->ell_cols;
+            tl.ell = A->ell_vals;
+          }
           if (part.part != 2) {
             ++g_sym_launches;
             hipLaunchKernelGGL(k_spmv_symp<0>, dim3(gs), dim3(64), 0, ctx->stream, G, (const double*)A->symp_vals, x, y, alpha, beta, dotw,
-                               folded ? partials + 1024 : partials, done_flag, (int32_t*)nullptr);
+                               partials, done_flag, (int32_t*)nullptr, tl);
             MFEM_CHECK_LAUNCH();
-            np = folded ? 0 : gs;
+            np = gs;
           }
-          if (part.part != 1) {
-            const int64_t lo = (int64_t)G.p0 * G.PL, hi = (int64_t)G.p1 * G.PL;
+          if (part.part == 2 || (part.part == 0 && !tl.on)) {
             const int64_t outside = (lo + 511) / 512 + (A->n - hi + 511) / 512 + 2;
             const int go = (int)(outside < 1 ? 1 : outside < 1024 ? outside : 1024);
             double* pp = partials ? partials + np : nullptr;
-            const double* fold = folded ? partials + 1024 : nullptr;
-            const int nfold = folded ? gs : 0;
             if (A->dia_triples)
               hipLaunchKernelGGL(k_spmv_dia_outside<true>, dim3(go), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi, fold, nfold);
+                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi);
             else
               hipLaunchKernelGGL(k_spmv_dia_outside<false>, dim3(go), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->ell_npad, A->ell_K, O,
-                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi, fold, nfold);
+                                 A->dia_flags, A->ell_cols, A->ell_vals, x, y, alpha, beta, dotw, pp, done_flag, lo, hi);
             MFEM_CHECK_LAUNCH();
             np += go;
           }

@@ -15,7 +15,7 @@ write = sum(W[k]["mean_KB"] for k in ks) * 1024
 cal = pick("k_cg_update")[0]
 n, nnz = 16974593, 454756609
 out = {
-    "kernel": " + ".join(k.split("(")[0] for k in ks) + " (per SpMV: the sweep launch + the rows outside the swept planes)",
+    "kernel": " + ".join(k.split("(")[0] for k in ks) + " (per SpMV: the sweep launch incl. the rows outside the swept planes)",
     "solver_layout_mode": 2, "symmetric_sweep": kind,
     "workload": f"hex-8 256^3 thermal K (n={n}, nnz={nnz}), inside the CG loop",
     "FETCH_SIZE_KB_mean": {k: F[k]["mean_KB"] for k in ks}, "WRITE_SIZE_KB_mean": {k: W[k]["mean_KB"] for k in ks},
