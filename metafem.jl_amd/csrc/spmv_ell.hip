@@ -660,8 +660,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 // only the in-line diagonals mirrorable (31 %), and two workgroup barriers per chunk bound what three workgroups per CU can keep
 // in flight.  Here a WAVE owns a (j, k) patch of 4 lattice lines x 32 points (lane <-> two neighbouring points of one line) and
 // sweeps it through consecutive lattice planes with no workgroup barrier at all:
-//   * the matrix values of the swept planes live in a patch-major copy  pv[plane][patch][27 slots x 128 rows + edge block]  (one
-//     contiguous 1 KB run per slot and step; made by k_symp_bind when the solve binds its values);
+//   * the matrix values of the swept planes live in a patch-major copy, made by k_symp_bind when the solve binds its values: what every
+//     step reads -- slots 13..26 and the edge block, 16.9 KB -- contiguous per step [plane][patch], the lower slots (read where a run
+//     starts and by the symmetry check) behind;
 //   * the upper diagonals of a step go to the wave's LDS block when they are loaded: +z / +y (slots 14..17) for the rows behind
 //     them in this plane, the nine next-plane diagonals (18..26) for the same patch one plane on -- 10.5 of the 13 lower
 //     diagonals of a row are mirrored from there whatever the line length (the rest: patch edges, read from the row's own slot);
@@ -742,14 +743,14 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   auto request = [&](const double* v, int pnext) {
     if (vx) {
 #pragma unroll
-      for (int u = 0; u < 14; ++u) cur[u] = SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + (13 + u) * SP_ROWS));
+      for (int u = 0; u < 14; ++u) cur[u] = SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + u * SP_ROWS));
     } else {
 #pragma unroll
       for (int u = 0; u < 14; ++u) cur[u] = (e_d2){0.0, 0.0};
     }
     if (MODE == 0) {
 #pragma unroll
-      for (int u = 0; u < 5; ++u) ed[u] = SYM_LD(v + 27 * SP_ROWS + lane + 64 * u);  // the block is padded to 320 entries
+      for (int u = 0; u < 5; ++u) ed[u] = SYM_LD(v + 14 * SP_ROWS + lane + 64 * u);  // the block is padded to 320 entries
 #pragma unroll
       for (int u = 0; u < 3; ++u) xr[u] = x[xidx(pnext, u)];
       xr[3] = lane < SP_XN - 192 ? x[xidx(pnext, 3)] : 0.0;
@@ -767,7 +768,9 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   cur_patch = -1;
   for (int64_t t = t0; t < t1; ++t) {
     const int p = Gm.p0 + (int)(t - (int64_t)patch * nplanes);
-    const double* v = pv + ((int64_t)(p - Gm.p0) * NP + patch) * SP_STEP;  // [plane][patch]: the runs of a segment advance plane by plane together
+    const int64_t step = (int64_t)(p - Gm.p0) * NP + patch;  // [plane][patch]: the runs of a segment advance plane by plane together
+    const double* v = pv + step * SP_MAIN;                                         // slots 13..26 + edge block of the step
+    const double* vlow = pv + (int64_t)NP * nplanes * SP_MAIN + step * SP_LOW;    // its slots 0..12
     if (patch != cur_patch) {  // wave-uniform: a run or a patch starts -- nothing was requested ahead, no history
       cur_patch = patch;
       const int j0 = (patch / Gm.NPk) * SP_L, k0 = (patch % Gm.NPk) * SP_W;
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
         // no history: the row's own previous-plane slots go where the mirror reads would look for them
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-          const e_d2 w = vx ? SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
+          const e_d2 w = vx ? SYM_LD(reinterpret_cast<const e_d2*>(vlow + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
           double* c = tab + sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb;
           c[0] = w.x;
           c[1] = w.y;
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
       if (lane < SP_XN - 192) dst[xa[3]] = xr[3];
     } else {
 #pragma unroll
-      for (int s = 0; s < 13; ++s) low[s] = vx ? SYM_LD(reinterpret_cast<const e_d2*>(v + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
+      for (int s = 0; s < 13; ++s) low[s] = vx ? SYM_LD(reinterpret_cast<const e_d2*>(vlow + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
     }
     // the step's own upper slots stay in `mine`; the next step of the same sweep is requested now and arrives during the products
     e_d2 mine[14];
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
     for (int u = 0; u < 14; ++u) mine[u] = cur[u];
     const bool more = t + 1 < t1 && p + 1 < Gm.p1;  // the next step continues this sweep
     __syncthreads();  // one wave: orders its LDS writes before the reads of other lanes
-    if (more) request(v + (int64_t)NP * SP_STEP, p + 2);
+    if (more) request(v + (int64_t)NP * SP_MAIN, p + 2);
     auto mirrored = [&](int s) -> e_d2 {
       const double* c = tab + sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb;
       e_d2 w;
@@ -920,7 +923,8 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   }
 }
 
-// patch-major copy of the swept planes from the slot-major copy: pv[plane - p0][patch] = 27 slots x 128 rows + the edge block, zero
+// patch-major copy of the swept planes from the slot-major copy: per step [plane - p0][patch] the slots 13..26 + the edge block (main
+// part) and, behind all main parts, the slots 0..12 (low part), zero
 // where the patch sticks out of the lattice; one wave per (plane, patch)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, const double* __restrict__ ell, double* __restrict__ pv) {
   const int lane = threadIdx.x & 63, lj = lane >> 4, pk = lane & 15;
@@ -933,7 +937,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, co
     const bool vx = j < Gm.m1 && k < Gm.m2, vy = j < Gm.m1 && k + 1 < Gm.m2;
     const int64_t r = (int64_t)p * Gm.PL + (int64_t)j * Gm.m2 + k;
     const int64_t b0 = ell_base(r, K), b1 = ell_base(r + 1, K);
-    double* out = pv + ((int64_t)(p - Gm.p0) * NP + patch) * SP_STEP;
+    const int64_t step = (int64_t)(p - Gm.p0) * NP + patch;
+    double* out = pv + step * SP_MAIN;
+    double* outlow = pv + T * SP_MAIN + step * SP_LOW;
     for (int s0 = 0; s0 < 27; s0 += 9) {
       e_d2 w[9];
 #pragma unroll
@@ -942,14 +948,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, co
         w[u].y = vy ? ell[b1 + (s0 + u) * ELL_B] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 9; ++u) *reinterpret_cast<e_d2*>(out + 2 * lane + (s0 + u) * SP_ROWS) = w[u];
+      for (int u = 0; u < 9; ++u) {
+        const int sl = s0 + u;  // slots 0..12 to the low part, 13..26 to the main part
+        double* dst = sl < 13 ? outlow + sl * SP_ROWS : out + (sl - 13) * SP_ROWS;
+        *reinterpret_cast<e_d2*>(dst + 2 * lane) = w[u];
+      }
     }
     for (int e = lane; e < SP_EPAD; e += 64) {
       int s = 0, line = 0, col = 0, cell = 0;
       double val = 0.0;
       if (sp_edge(e, s, line, col, cell) && j0 + line < Gm.m1 && k0 + col < Gm.m2)
         val = ell[ell_base((int64_t)p * Gm.PL + (int64_t)(j0 + line) * Gm.m2 + k0 + col, K) + s * ELL_B];
-      out[27 * SP_ROWS + e] = val;
+      out[14 * SP_ROWS + e] = val;
     }
   }
 }

@@ -30,7 +30,9 @@ __host__ __device__ constexpr int sp_ecnt(int s) { return (sp_dj(s) != 0 ? SP_W 
 __host__ __device__ constexpr int sp_ebase(int s) { return s == 0 ? 0 : sp_ebase(s - 1) + sp_ecnt(s - 1); }
 #define SP_NE (sp_ebase(12) + sp_ecnt(12))  // 318
 #define SP_EPAD 320
-#define SP_STEP (27 * SP_ROWS + SP_EPAD)    // doubles per (plane, patch) in the patch-major copy
+#define SP_STEP (27 * SP_ROWS + SP_EPAD)    // doubles per (plane, patch) in the patch-major copy, in two parts:
+#define SP_MAIN (14 * SP_ROWS + SP_EPAD)    //   what every step reads -- slots 13..26 and the edge block -- contiguous per step, steps [plane][patch]
+#define SP_LOW (13 * SP_ROWS)               //   the lower slots 0..12 (read where a run starts and by the symmetry check), behind all main parts
 // entry e of the edge block: lower slot s, the referencing row's (line, column) in the patch, the LDS cell of table s it fills
 __host__ __device__ inline bool sp_edge(int e, int& s, int& line, int& col, int& cell) {
   if (e >= SP_NE) return false;
