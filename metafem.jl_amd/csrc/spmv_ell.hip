@@ -703,6 +703,20 @@ struct SympTail {
   const int32_t* cols;
   const double* ell;
 };
+__constant__ int32_t c_sp_ecell[SP_EPAD];  // edge block entry -> LDS cell of its mirror table (the two padding entries: a spare cell)
+static int symp_upload_tables(int device) {  // __constant__ data is per device
+  static bool done[64] = {};
+  if (device >= 0 && device < 64 && done[device]) return MFEM_OK;
+  int32_t h[SP_EPAD];
+  for (int e = 0; e < SP_EPAD; ++e) {
+    int s_, l_, c_, cell = 0;
+    h[e] = sp_edge(e, s_, l_, c_, cell) ? cell : SP_TAB;
+  }
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_sp_ecell), h, sizeof(h)));
+  if (device >= 0 && device < 64) done[device] = true;
+  return MFEM_OK;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __restrict__ pv, const double* __restrict__ x,
                                                    double* __restrict__ y, double alpha, double beta,
@@ -717,14 +731,11 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   // a contiguous eighth of the patches, segment by segment, so that the runs resident on it at any time are neighbouring patches at
   // about the same plane: their overlapping x neighbourhoods meet in that XCD's L2.
   const int xcd = blockIdx.x & 7, pc = NP / 8, prem = NP % 8, pcnt = pc + (xcd < prem ? 1 : 0), pfirst = xcd * pc + (xcd < prem ? xcd : prem);
-  // the LDS cells this lane fills from the edge block (5 entries per lane)
+  // the LDS cells this lane fills from the edge block (5 entries per lane; table made on the host once: decoding 320 entries with
+  // sp_edge() at the top of every launch cost every wave a few thousand instructions)
   int ecell[5];
 #pragma unroll
-  for (int u = 0; u < 5; ++u) {
-    int s_, l_, c_, cell = -1;
-    if (!sp_edge(lane + 64 * u, s_, l_, c_, cell)) cell = SP_TAB;  // the block's two padding entries go to a spare cell
-    ecell[u] = cell;
-  }
+  for (int u = 0; u < 5; ++u) ecell[u] = c_sp_ecell[lane + 64 * u];
   int cur_patch = -1, bp = 0, bc = 1, bn = 2;  // x ring: previous / current / next plane
   bool have_hist = false, vx = false, vy = false;
   int64_t rin = 0;       // in-plane row offset j * m2 + k of the lane's first row
@@ -1300,6 +1311,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     A->symp_bound = 0;
     A->symp_vals = nullptr;
     if (symp_wanted(A)) {  // patch-major copy of the swept planes; are the pairs the sweep mirrors bitwise equal?
+      { const int rt = symp_upload_tables(ctx->device); if (rt) return rt; }
       const SympGeom G = symp_geom(ctx, A);
       double* pvals = buf + (size_t)A->ell_K * (size_t)A->ell_npad;
       const int64_t T = symp_steps(A);
