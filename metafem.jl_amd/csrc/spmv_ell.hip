@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   __shared__ __attribute__((aligned(16))) double xs[3][SP_XL][SP_XW];
   __shared__ __attribute__((aligned(16))) double tab[SP_TAB + 2];
   if (done_flag && done_flag[0]) return;
-  const int lane = threadIdx.x, lj = lane >> 4, pk = lane & 15, lb = lj * SP_LS + 2 * pk;
+  const int lane = threadIdx.x, lj = lane / SP_PW, pk = lane % SP_PW, lb = lj * SP_LS + 2 * pk;
   const int NP = Gm.NS * Gm.NPk, nplanes = Gm.p1 - Gm.p0;
   // Runs and XCDs: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch; gridDim.x is a multiple of 8).  XCD c sweeps
   // a contiguous eighth of the patches, segment by segment, so that the runs resident on it at any time are neighbouring patches at
@@ -733,17 +733,17 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
   const int xcd = blockIdx.x & 7, pc = NP / 8, prem = NP % 8, pcnt = pc + (xcd < prem ? 1 : 0), pfirst = xcd * pc + (xcd < prem ? xcd : prem);
   // the LDS cells this lane fills from the edge block (5 entries per lane; table made on the host once: decoding 320 entries with
   // sp_edge() at the top of every launch cost every wave a few thousand instructions)
-  int ecell[5];
+  int ecell[SP_EU];
 #pragma unroll
-  for (int u = 0; u < 5; ++u) ecell[u] = c_sp_ecell[lane + 64 * u];
+  for (int u = 0; u < SP_EU; ++u) ecell[u] = c_sp_ecell[lane + 64 * u];
   int cur_patch = -1, bp = 0, bc = 1, bn = 2;  // x ring: previous / current / next plane
   bool have_hist = false, vx = false, vy = false;
   int64_t rin = 0;       // in-plane row offset j * m2 + k of the lane's first row
-  int xo[4], xa[4];      // x staging: in-plane offset (may be negative) and LDS slot of the lane's four neighbourhood points
+  int xo[SP_XU], xa[SP_XU];  // x staging: in-plane offset (may be negative) and LDS slot of the lane's neighbourhood points
   double dot_acc = 0.0;
   int fail = 0;
   e_d2 cur[14];          // slots 13..26 of the step, requested one step ahead
-  double ed[5], xr[4];   // its edge block entries and the x neighbourhood of the plane after it
+  double ed[SP_EU], xr[SP_XU];  // its edge block entries and the x neighbourhood of the plane after it
   // x neighbourhood entry of plane `plane`: positions outside the vector's owned entries (beyond the last lattice line of the last
   // plane) are only ever multiplied by structurally absent entries -- any finite value serves: clamp
   auto xidx = [&](int plane, int u) -> int64_t {
@@ -761,17 +761,17 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
     }
     if (MODE == 0) {
 #pragma unroll
-      for (int u = 0; u < 5; ++u) ed[u] = SYM_LD(v + 14 * SP_ROWS + lane + 64 * u);  // the block is padded to 320 entries
+      for (int u = 0; u < SP_EU; ++u) ed[u] = SYM_LD(v + 14 * SP_ROWS + lane + 64 * u);  // the block is padded to SP_EPAD entries
 #pragma unroll
-      for (int u = 0; u < 3; ++u) xr[u] = x[xidx(pnext, u)];
-      xr[3] = lane < SP_XN - 192 ? x[xidx(pnext, 3)] : 0.0;
+      for (int u = 0; u < SP_XU - 1; ++u) xr[u] = x[xidx(pnext, u)];
+      xr[SP_XU - 1] = lane < SP_XN - 64 * (SP_XU - 1) ? x[xidx(pnext, SP_XU - 1)] : 0.0;
     }
   };
   auto stage_x = [&](int buf, int plane) {
     double* dst = &xs[buf][0][0];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) dst[xa[u]] = x[xidx(plane, u)];
-    if (lane < SP_XN - 192) dst[xa[3]] = x[xidx(plane, 3)];
+    for (int u = 0; u < SP_XU - 1; ++u) dst[xa[u]] = x[xidx(plane, u)];
+    if (lane < SP_XN - 64 * (SP_XU - 1)) dst[xa[SP_XU - 1]] = x[xidx(plane, SP_XU - 1)];
   };
   for (int run = blockIdx.x >> 3; run < pcnt * Gm.nseg; run += gridDim.x >> 3) {
   const int patch = pfirst + run % pcnt, seg = run / pcnt;
@@ -790,8 +790,8 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
       vy = j < Gm.m1 && k + 1 < Gm.m2;
       rin = (int64_t)j * Gm.m2 + k;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int tt = lane + 64 * u, xl = tt / 34, xc = tt - 34 * xl;
+      for (int u = 0; u < SP_XU; ++u) {
+        const int tt = lane + 64 * u, xl = tt / SP_XC, xc = tt - SP_XC * xl;
         xo[u] = (j0 - 1 + xl) * Gm.m2 + (k0 - 1 + xc);
         xa[u] = xl * SP_XW + xc;  // (u = 3: only lanes < 12 belong to the neighbourhood)
       }
@@ -817,11 +817,11 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
     e_d2 low[13];
     if (MODE == 0) {
 #pragma unroll
-      for (int u = 0; u < 5; ++u) tab[ecell[u]] = ed[u];
+      for (int u = 0; u < SP_EU; ++u) tab[ecell[u]] = ed[u];
       double* dst = &xs[bn][0][0];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) dst[xa[u]] = xr[u];
-      if (lane < SP_XN - 192) dst[xa[3]] = xr[3];
+      for (int u = 0; u < SP_XU - 1; ++u) dst[xa[u]] = xr[u];
+      if (lane < SP_XN - 64 * (SP_XU - 1)) dst[xa[SP_XU - 1]] = xr[SP_XU - 1];
     } else {
 #pragma unroll
       for (int s = 0; s < 13; ++s) low[s] = vx ? SYM_LD(reinterpret_cast<const e_d2*>(vlow + 2 * lane + s * SP_ROWS)) : (e_d2){0.0, 0.0};
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
 #pragma unroll
       for (int s = 0; s < 13; ++s) {
         const int dj = sp_dj(s), dk = sp_dk(s);
-        const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < 15 : true);
+        const bool in = lj + dj >= 0 && lj + dj < SP_L && (dk < 0 ? pk > 0 : dk > 0 ? pk < SP_PW - 1 : true);
         if (in && vx && (s >= 9 || have_hist)) {
           const e_d2 m = mirrored(s);
           if (__double_as_longlong(m.x) != __double_as_longlong(low[s].x) && !(m.x == 0.0 && low[s].x == 0.0)) fail = 1;
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(64) void k_spmv_symp(SympGeom Gm, const double* __r
 // part) and, behind all main parts, the slots 0..12 (low part), zero
 // where the patch sticks out of the lattice; one wave per (plane, patch)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, const double* __restrict__ ell, double* __restrict__ pv) {
-  const int lane = threadIdx.x & 63, lj = lane >> 4, pk = lane & 15;
+  const int lane = threadIdx.x & 63, lj = lane / SP_PW, pk = lane % SP_PW;
   const int NP = Gm.NS * Gm.NPk;
   const int64_t T = (int64_t)NP * (Gm.p1 - Gm.p0);
   for (int64_t t = (int64_t)blockIdx.x * (MFEM_BLOCK / 64) + (threadIdx.x >> 6); t < T; t += (int64_t)gridDim.x * (MFEM_BLOCK / 64)) {
@@ -1265,7 +1265,7 @@ static int64_t symp_count_entries(const mfem_csr_s* A, int nseg) {
   for (int patch = 0; patch < NP; ++patch) {
     int64_t nv = 0;
     for (int lane = 0; lane < 64; ++lane) {
-      const int j = (patch / A->symp_NPk) * SP_L + (lane >> 4), k = (patch % A->symp_NPk) * SP_W + 2 * (lane & 15);
+      const int j = (patch / A->symp_NPk) * SP_L + lane / SP_PW, k = (patch % A->symp_NPk) * SP_W + 2 * (lane % SP_PW);
       if (j < A->symp_m1 && k < A->symp_m2) ++nv;
     }
     e += (28 * nv + SP_NE) * nplanes + 18 * nv * nseg;

@@ -5,31 +5,35 @@
 #define __host__
 #define __device__
 #endif
-#define SP_L 4
-#define SP_W 32
+#define SP_L 4            // lattice lines per patch (8 x 16: 5 % fewer bytes -- rim and x halo -- but no faster: 0.885 against 0.878 ms per CG iteration at 256^3)
+#define SP_W 32           // lattice points per line segment; a lane owns two neighbouring points: SP_L * SP_W / 2 = 64 lanes
+#define SP_PW (SP_W / 2)  // lane pairs per line
 #define SP_ROWS (SP_L * SP_W)
 #define SP_XL (SP_L + 2)
-#define SP_XW 36  // 34 points (k0 - 1 .. k0 + 32) + 2: lines stay 16-byte aligned
-#define SP_XN (SP_XL * 34)
+#define SP_XC (SP_W + 2)  // staged x points per line: k0 - 1 .. k0 + SP_W
+#define SP_XW (SP_W + 4)  // line stride of the x tile: lines stay 16-byte aligned
+#define SP_XN (SP_XL * SP_XC)
+#define SP_XU ((SP_XN + 63) / 64)  // x entries per lane and plane
 #define SP_WG_PER_CU 7
 // Mirror tables: one per lower slot s = (di, dj, dk), holding slot 26 - s of the SOURCE rows (row + offset), indexed by source
-// cell (line lj + dj, column 2 pk + dk): lines of 36 doubles, column c at index c + 2 (column -1 and column 32 are halo cells), a
+// cell (line lj + dj, column 2 pk + dk): lines of SP_W + 4 doubles, column c at index c + 2 (column -1 and column SP_W are halo cells), a
 // halo line on the side the slot points to.  A halo cell cannot be mirrored (its source row belongs to another patch): it
 // receives the referencing row's OWN slot-s entry from the step's edge block, so that the reads are the same two LDS loads for
 // every lane and slot.
-#define SP_LS 36
+#define SP_LS (SP_W + 4)
 __host__ __device__ constexpr int sp_dj(int s) { return (s / 3) % 3 - 1; }
 __host__ __device__ constexpr int sp_dk(int s) { return s % 3 - 1; }
 __host__ __device__ constexpr int sp_tsize(int s) { return (sp_dj(s) == 0 ? SP_L : SP_L + 1) * SP_LS; }
 __host__ __device__ constexpr int sp_tbase(int s) { return s == 0 ? 0 : sp_tbase(s - 1) + sp_tsize(s - 1); }
 __host__ __device__ constexpr int sp_adj(int s) { return sp_dj(s) == -1 ? 1 : 0; }  // table line of source line 0
 #define SP_TAB (sp_tbase(12) + sp_tsize(12))
-// edge block of a step: for s = 0..12 the halo cells of table s -- the halo line (32 cells) if dj != 0, then the halo column
+// edge block of a step: for s = 0..12 the halo cells of table s -- the halo line (SP_W cells) if dj != 0, then the halo column
 // (lines in ascending order) if dk != 0
 __host__ __device__ constexpr int sp_ecnt(int s) { return (sp_dj(s) != 0 ? SP_W : 0) + (sp_dk(s) != 0 ? (sp_dj(s) != 0 ? SP_L - 1 : SP_L) : 0); }
 __host__ __device__ constexpr int sp_ebase(int s) { return s == 0 ? 0 : sp_ebase(s - 1) + sp_ecnt(s - 1); }
-#define SP_NE (sp_ebase(12) + sp_ecnt(12))  // 318
-#define SP_EPAD 320
+#define SP_NE (sp_ebase(12) + sp_ecnt(12))  // 318 for 4 x 32 patches (210 for 8 x 16)
+#define SP_EU ((SP_NE + 63) / 64)            // edge entries per lane
+#define SP_EPAD (64 * SP_EU)
 #define SP_STEP (27 * SP_ROWS + SP_EPAD)    // doubles per (plane, patch) in the patch-major copy, in two parts:
 #define SP_MAIN (14 * SP_ROWS + SP_EPAD)    //   what every step reads -- slots 13..26 and the edge block -- contiguous per step, steps [plane][patch]
 #define SP_LOW (13 * SP_ROWS)               //   the lower slots 0..12 (read where a run starts and by the symmetry check), behind all main parts

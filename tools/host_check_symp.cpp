@@ -45,10 +45,10 @@ int main() {
     if (!halo.insert(cell).second) { printf("edge %d: cell %d filled twice\n", e, cell); ++bad; }
     if (line < 0 || line >= SP_L || col < 0 || col >= SP_W) { printf("edge %d: referencing row outside the patch\n", e); ++bad; }
   }
-  if ((int)halo.size() != SP_NE || SP_NE != 318) { printf("edge block has %zu cells, SP_NE = %d\n", halo.size(), SP_NE); ++bad; }
+  if ((int)halo.size() != SP_NE) { printf("edge block has %zu cells, SP_NE = %d\n", halo.size(), SP_NE); ++bad; }
   for (int s = 0; s < 13; ++s)
     for (int lane = 0; lane < 64; ++lane) {
-      const int lj = lane >> 4, pk = lane & 15, lb = lj * SP_LS + 2 * pk;
+      const int lj = lane / SP_PW, pk = lane % SP_PW, lb = lj * SP_LS + 2 * pk;
       const int w = sp_tbase(s) + sp_adj(s) * SP_LS + 2 + lb;  // the two interior cells the lane writes
       if (halo.count(w) || halo.count(w + 1)) { printf("slot %d lane %d: interior cell is a halo cell\n", s, lane); ++bad; }
       if (w + 1 >= sp_tbase(s) + sp_tsize(s)) { printf("slot %d lane %d: interior cell outside its table\n", s, lane); ++bad; }
@@ -69,7 +69,7 @@ int main() {
         bool have_hist = false;
         for (int p = start; p < m0 - 1; ++p) {
           auto rowof = [&](int lane, int h, bool& valid) -> int64_t {
-            const int j = j0 + (lane >> 4), k = k0 + 2 * (lane & 15) + h;
+            const int j = j0 + (lane / SP_PW), k = k0 + 2 * (lane % SP_PW) + h;
             valid = j < m1 && k < m2;
             return (int64_t)p * PL + (int64_t)j * m2 + k;
           };
@@ -79,7 +79,7 @@ int main() {
                 for (int h = 0; h < 2; ++h) {
                   bool v;
                   const int64_t r = rowof(lane, h, v);
-                  const int lb = (lane >> 4) * SP_LS + 2 * (lane & 15);
+                  const int lb = (lane / SP_PW) * SP_LS + 2 * (lane % SP_PW);
                   tab[sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb + h] = v ? entry(r, s) : 0.0;
                 }
           // phase B: +z / +y slots of this plane's rows, edge block
@@ -88,7 +88,7 @@ int main() {
               for (int h = 0; h < 2; ++h) {
                 bool v;
                 const int64_t r = rowof(lane, h, v);
-                const int lb = (lane >> 4) * SP_LS + 2 * (lane & 15);
+                const int lb = (lane / SP_PW) * SP_LS + 2 * (lane % SP_PW);
                 tab[sp_tbase(s) + sp_adj(s) * SP_LS + 2 + lb + h] = v ? entry(r, 26 - s) : 0.0;
               }
           for (int e = 0; e < SP_NE; ++e) {
@@ -104,7 +104,7 @@ int main() {
                 bool v;
                 const int64_t r = rowof(lane, h, v);
                 if (!v) continue;
-                const int lb = (lane >> 4) * SP_LS + 2 * (lane & 15);
+                const int lb = (lane / SP_PW) * SP_LS + 2 * (lane % SP_PW);
                 const double got = tab[sp_tbase(s) + (sp_dj(s) + sp_adj(s)) * SP_LS + sp_dk(s) + 2 + lb + h];
                 const double want = entry(r, s);
                 if (!(got == want)) {
@@ -118,7 +118,7 @@ int main() {
               for (int h = 0; h < 2; ++h) {
                 bool v;
                 const int64_t r = rowof(lane, h, v);
-                const int lb = (lane >> 4) * SP_LS + 2 * (lane & 15);
+                const int lb = (lane / SP_PW) * SP_LS + 2 * (lane % SP_PW);
                 tab[sp_tbase(s) + sp_adj(s) * SP_LS + 2 + lb + h] = v ? entry(r, 26 - s) : 0.0;
               }
           have_hist = true;
