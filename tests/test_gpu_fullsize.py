@@ -87,6 +87,35 @@ def test_c2_cg_solves_to_the_reference_tolerance(mf, c2):
     assert float(T.min()) > TENV  # heated body sits above ambient everywhere
 
 
+def test_c2_symmetric_patch_sweep_at_full_size_is_bitwise_the_plain_kernel(mf, c2):
+    """BASELINE configs[1] at its full size: the Krylov loop's SpMV takes the wave-private patch sweep (default from 257-point lattice
+    lines on, no debug knob involved), mirrors lower diagonals through LDS and must give bit for bit what the plain diagonal-slotted
+    kernel gives on the same copy; its design bytes are below 0.7 of the plain kernel's."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick, A, K = c2
+    x = mf.FEM_rand(A.n, 5, 0) - 0.5
+    ent, sym, byts = C.c_int64(), C.c_int32(), C.c_int64()
+    _lib.check(_lib.lib.mfem_csr_solver_layout_entries(brick.ctx._h, A._h, C.byref(ent), C.byref(sym)))
+    _lib.check(_lib.lib.mfem_csr_solver_layout_bytes(brick.ctx._h, A._h, C.byref(byts)))
+    assert sym.value == 2 and byts.value < 0.7 * (A.nnz * 8 + A.n * 16)
+    ys = []
+    try:
+        for knob in (1 << 22, 0):
+            _lib.lib.mfem_debug_set_ell(1 | knob)
+            before = _lib.lib.mfem_debug_sym_spmv_count()
+            y = torch.full((A.n,), 3.0, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+            assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob == 0)
+            ys.append(y)
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+    assert torch.equal(ys[0], ys[1])
+
+
 def test_c3_elasticity_128_symmetry_and_rigid_body(mf):
     """configs[2]: linear elasticity hex-8 (3 DOF/node), 128^3."""
     import torch
