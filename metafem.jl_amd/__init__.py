@@ -19,6 +19,7 @@ every call goes through the C ABI.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import math
 from dataclasses import dataclass
 from typing import Callable, Optional, Tuple
@@ -66,6 +67,9 @@ class Context:
         self.device = device
         torch.cuda.set_device(device)
         self._h = C.c_void_p()
+        # handles created on this context (patterns, bricks, communicators): closed before the context itself, whatever the order in
+        # which the interpreter drops the Python objects (a pattern destroyed after its context would touch freed memory)
+        self._children = weakref.WeakSet()
         stream = torch.cuda.current_stream(device).cuda_stream
         check(lib.mfem_context_create(device, C.c_void_p(stream), C.byref(self._h)))
 
@@ -77,6 +81,11 @@ class Context:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                try:
+                    child.close()
+                except Exception:
+                    pass
             lib.mfem_context_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -119,6 +128,7 @@ class FEM_SpMat_CSR:
         self.n = int(lib.mfem_csr_n(self._h))
         self.nnz = int(lib.mfem_csr_nnz(self._h))
         self.index_base = index_base
+        self.ctx._children.add(self)
 
     @property
     def ncols(self) -> int:
@@ -257,6 +267,7 @@ def assemble_SparseID(controlpoint_IDs: torch.Tensor, ncp: int, n_fields: int = 
     A.n, A.nnz = int(lib.mfem_csr_n(h)), int(lib.mfem_csr_nnz(h))
     A.rowptr = _tensor_from_ptr(lib.mfem_csr_rowptr64(h), A.n + 1, torch.int64, ctx.device, owner=A)
     A.colidx = _tensor_from_ptr(lib.mfem_csr_colidx(h), A.nnz, torch.int32, ctx.device, owner=A)
+    ctx._children.add(A)
     return A, slots
 
 
@@ -311,6 +322,7 @@ class Brick:
         self.nel = int(lib.mfem_brick_num_elements(self._h))
         self.m = tuple(itp_order * ni + 1 for ni in n)
         self.slab = (0, self.m[0])
+        self.ctx._children.add(self)
 
     def set_slab(self, plane_lo: int, plane_hi: int):
         check(lib.mfem_brick_set_slab(self._h, plane_lo, plane_hi))
@@ -339,6 +351,7 @@ class Brick:
         A.ctx, A._h, A._owned, A.n, A.nnz, A.index_base = self.ctx, h, True, n, nnz, 0
         A.rowptr = _tensor_from_ptr(lib.mfem_csr_rowptr64(h), n + 1, torch.int64, self.ctx.device, owner=A)
         A.colidx = _tensor_from_ptr(lib.mfem_csr_colidx(h), nnz, torch.int32, self.ctx.device, owner=A)
+        self.ctx._children.add(A)
         return A
 
     def assemble_thermal(self, A: FEM_SpMat_CSR, k: float, h: float = 0.0, Tenv: float = 0.0,

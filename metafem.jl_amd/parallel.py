@@ -90,6 +90,7 @@ class SlabComm:
         self.n_owned_nodes = brick.n_owned
         self.n_fields = n_fields
         check(lib.mfem_context_set_comm(ctx._h, self._h, self.n_owned_nodes, self.plane_len, n_fields))
+        ctx._children.add(self)
 
     def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
         check(lib.mfem_allreduce_sum(self.ctx._h, t.data_ptr(), t.numel()))
@@ -170,6 +171,7 @@ class HostSlabComm:
         self.n_owned_nodes = brick.n_owned
         self.n_fields = n_fields
         check(lib.mfem_context_set_comm(ctx._h, self._h, self.n_owned_nodes, self.plane_len, n_fields))
+        ctx._children.add(self)
 
     allreduce_ = SlabComm.allreduce_
     halo_ = SlabComm.halo_

@@ -501,3 +501,57 @@ def test_symmetric_sweep_with_drifting_tiles(mf, n):
     finally:
         _lib.lib.mfem_debug_set_ell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("rp_dtype,base", [("int32", 1), ("int64", 0)])
+def test_patch_sweep_on_a_caller_supplied_symmetric_lattice_matrix(mf, rp_dtype, base):
+    """A symmetric 27-point lattice operator handed over the way the reference hands matrices to CUSPARSE (1-based Int32 CSR,
+    04_GPU_Utils.jl:131), on a lattice with three different extents: the inspector recognises the lattice from the CSR pattern alone, CG
+    runs on the wave-private patch sweep (bitwise-symmetric values) and solves like scipy; with one entry changed by one ulp the solve
+    silently takes the plain kernel and still solves the (then unsymmetric) system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import torch
+    from metafem_jl_amd import _lib
+
+    m0, m1, m2 = 20, 19, 37
+    n = m0 * m1 * m2
+    idx = np.arange(n).reshape(m0, m1, m2)
+    rows, cols, vals = [], [], []
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for dk in (-1, 0, 1):
+                src = idx[max(0, -di):m0 - max(0, di), max(0, -dj):m1 - max(0, dj), max(0, -dk):m2 - max(0, dk)].ravel()
+                dst = idx[max(0, di):m0 - max(0, -di), max(0, dj):m1 - max(0, -dj), max(0, dk):m2 - max(0, -dk)].ravel()
+                lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+                w = -1.0 + 0.2 * (((lo * 2654435761 + hi * 40503) % 1000) / 1000.0)  # a function of the unordered pair: symmetric bit for bit
+                rows.append(src); cols.append(dst)
+                vals.append(np.where(src == dst, 30.0, w))
+    M = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    M.sort_indices()
+    assert (M - M.T).nnz == 0
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(n)
+    rp = torch.tensor(M.indptr + base, dtype=getattr(torch, rp_dtype), device="cuda")
+    ci = torch.tensor(M.indices + base, dtype=torch.int32, device="cuda")
+    tol = 1e-12 * float(np.linalg.norm(b) / np.sqrt(n))
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        A = mf.FEM_SpMat_CSR(rp, ci, n, index_base=base)
+        K = torch.tensor(M.data, device="cuda")
+        before = _lib.lib.mfem_debug_sym_spmv_count()
+        x, st = mf.iterative_Solve(A, K, torch.tensor(b, device="cuda"), tol, Sv_func=mf.cg_, maxiter=500, max_pass=3)
+        assert st.converged == 1 and _lib.lib.mfem_debug_sym_spmv_count() > before
+        ref = spl.spsolve(M.tocsc(), b)
+        assert np.abs(x.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+        # one ulp off the symmetry in a mirrored pair: no sweep, same quality of solution for the perturbed matrix
+        r = (9 * m1 + 9) * m2 + 17
+        k = int(M.indptr[r]) + 20
+        K2 = K.clone()
+        K2[k] = torch.nextafter(K2[k], torch.tensor(float("inf"), dtype=torch.float64, device="cuda"))
+        before = _lib.lib.mfem_debug_sym_spmv_count()
+        x2, st2 = mf.iterative_Solve(A, K2, torch.tensor(b, device="cuda"), tol, Sv_func=mf.cg_, maxiter=500, max_pass=3)
+        assert st2.converged == 1 and _lib.lib.mfem_debug_sym_spmv_count() == before
+        assert np.abs(x2.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+    finally:
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)

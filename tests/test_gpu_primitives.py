@@ -262,3 +262,22 @@ def test_solver_layouts_on_degenerate_matrices(mf):
             assert np.allclose(y1.cpu().numpy(), ref, rtol=1e-13, atol=1e-12)
     finally:
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+def test_closing_a_context_closes_the_handles_created_on_it(mf):
+    """A pattern / brick destroyed after its context would touch freed memory (mfem_csr_destroy invalidates the context's cached cycle
+    graphs): Context.close() closes its children first, so the order in which Python drops the objects does not matter."""
+    import torch
+
+    ctx = mf.Context(torch.cuda.current_device())
+    brick = mf.Brick((1.0, 1.0, 1.0), (3, 2, 2), 1, 3, ctx=ctx)
+    A = brick.pattern(1)
+    rp = torch.tensor([0, 1, 2], dtype=torch.int32, device="cuda")
+    ci = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    B = mf.FEM_SpMat_CSR(rp, ci, 2, ctx=ctx)
+    ctx.close()
+    assert not A._h and not B._h and not brick._h
+    A.close()      # closing again is a no-op
+    B.close()
+    brick.close()
+    ctx.close()
