@@ -53,6 +53,8 @@ const char* mfem_last_error(void);
 int mfem_context_create(int device, void* stream, mfem_context* out);
 int mfem_context_set_stream(mfem_context ctx, void* stream);
 int mfem_context_destroy(mfem_context ctx);
+/* Lifetimes: destroy patterns, bricks and communicators before the context they were created on.  A pattern that is destroyed
+ * after its context (finalisers of a garbage-collected host run in any order) only releases its own memory. */
 int mfem_context_sync(mfem_context ctx);
 
 /* ---- S1 primitives: the CUSPARSE/CUBLAS call sites of the Krylov loop -------------------- */

@@ -1,9 +1,19 @@
 // Context management and error plumbing of the C ABI (include/metafem_mi355x.h).
 #include <stdarg.h>
-
 #include <atomic>
 
+#include <mutex>
+#include <set>
+
 #include "common.h"
+
+// contexts that exist: a pattern handle destroyed after its context (host-language finalisers run in any order) must not touch it
+static std::mutex g_ctx_mutex;
+static std::set<mfem_context_s*> g_live_contexts;
+bool mfem_context_alive(mfem_context_s* ctx) {
+  std::lock_guard<std::mutex> lk(g_ctx_mutex);
+  return g_live_contexts.count(ctx) != 0;
+}
 
 static thread_local char g_err[1024] = "";
 
@@ -33,6 +43,10 @@ extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) 
   }
   mfem_context_s* c = new mfem_context_s();
   memset(c, 0, sizeof(*c));
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    g_live_contexts.insert(c);
+  }
   c->device = device;
   c->stream = (hipStream_t)stream;
   c->num_cus = prop.multiProcessorCount;
@@ -63,6 +77,10 @@ extern "C" int mfem_context_sync(mfem_context ctx) {
 
 extern "C" int mfem_context_destroy(mfem_context ctx) {
   if (!ctx) return MFEM_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    g_live_contexts.erase(ctx);
+  }
   hipStreamSynchronize(ctx->stream);
   hipFree(ctx->d_partials);
   hipFree(ctx->d_scalars);

@@ -172,6 +172,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
 
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes);
 uint64_t mfem_next_csr_serial();
+bool mfem_context_alive(mfem_context_s* ctx);       // false once mfem_context_destroy has run (api.hip)
 void mfem_graphs_invalidate(mfem_context_s* ctx);  // drops every cached cycle graph of the context (api.hip)
 extern int mfem_debug_epoch;  // bumped by every mfem_debug_set_*: part of the cycle-graph cache key (api.hip)
 

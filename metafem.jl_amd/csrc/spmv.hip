@@ -528,7 +528,7 @@ extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const v
 extern "C" int mfem_csr_destroy(mfem_csr A) {
   if (!A) return MFEM_OK;
   // a cached cycle graph holds this pattern's arrays in its kernel arguments
-  if (A->ctx) mfem_graphs_invalidate(A->ctx);
+  if (A->ctx && mfem_context_alive(A->ctx)) mfem_graphs_invalidate(A->ctx);
   mfem_ell_free(A);
   mfem_sell_free(A);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);

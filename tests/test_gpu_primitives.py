@@ -281,3 +281,11 @@ def test_closing_a_context_closes_the_handles_created_on_it(mf):
     B.close()
     brick.close()
     ctx.close()
+    # the C ABI itself tolerates the wrong order for patterns: destroyed after its context a pattern only frees its own memory
+    import ctypes as C
+    from metafem_jl_amd import _lib
+    h_ctx, h_csr = C.c_void_p(), C.c_void_p()
+    _lib.check(_lib.lib.mfem_context_create(torch.cuda.current_device(), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(h_ctx)))
+    _lib.check(_lib.lib.mfem_csr_create(h_ctx, 2, 2, C.c_void_p(rp.data_ptr()), 32, C.c_void_p(ci.data_ptr()), 0, C.byref(h_csr)))
+    _lib.check(_lib.lib.mfem_context_destroy(h_ctx))
+    _lib.check(_lib.lib.mfem_csr_destroy(h_csr))
