@@ -119,12 +119,14 @@ int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, co
  * knobs).  Each call bumps an epoch that is part of the cycle-graph cache key, so cached graphs never outlive a knob change.
  * None of them changes results beyond round-off; kernel variants that compute WRONG results for timing purposes live in tools/,
  * not in this library. */
-/* CSR tile kernel: tiles per XCD run (0 = dispatcher round-robin) | variant << 16, persistent workgroups per CU. */
+/* CSR tile kernel: tiles per XCD run (0 = dispatcher round-robin) | variant << 16 | bit 27: without the 2688-entry wave tile (rows of
+ * 64..83 entries then share 1792-entry tiles 16 at a time), persistent workgroups per CU. */
 int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
  * bit 20 XCD-contiguous row chunks; bit 22 symmetric sweep kernels off; bit 23 the workgroup-tile sweep (k_spmv_sym27) instead of
  * the wave-private patch sweep (k_spmv_symp);
- * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128). */
+ * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128); bit 26 rows outside the swept planes
+ * in a launch of their own; bit 27 the patch-major copy made from the slot-major copy in a second pass. */
 int mfem_debug_set_ell(int enable);
 /* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */

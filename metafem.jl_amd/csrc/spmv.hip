@@ -306,12 +306,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_csr_t(
 // the same position of 64 consecutive rows, which for a mesh matrix are consecutive entries of x.  No workgroup barrier, no
 // cross-lane reduction for tpr = 1, y written unit-stride.
 template <typename RP, int CAPW, int WAVES, int NG>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void k_spmv_csr_w(
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW > 2048 ? 1 : 2))) void k_spmv_csr_w(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
     double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
   constexpr int LU = (CAPW / 2 + 63) / 64;  // (16 B + 8 B) loads per lane that cover a full tile
+  static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
   // NG = gathers a lane issues up front (rows of up to NG * tpr entries have none left over)
   __shared__ __attribute__((aligned(16))) double sv_all[WAVES][CAPW + 2];
   __shared__ __attribute__((aligned(16))) int32_t sc_all[WAVES][CAPW + 4];
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
+static int g_spmv_tile2688 = 1;  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
 static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
 // Kernel variant (bits 16-18 of mfem_debug_set_spmv's first argument):
@@ -473,6 +475,7 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   ++mfem_debug_epoch;
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
+  g_spmv_tile2688 = ((xcd_aware >> 27) & 1) ? 0 : 1;
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
@@ -667,6 +670,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
       while (tl < 6 && (int64_t)(64 >> tl) * A->max_row_nnz > 1792 - 2) ++tl;
       const double fill = (double)(64 >> tl) * ((double)A->nnz / (double)A->n) / 1792.0;
       if (tl <= 3 && fill >= 0.65) variant = 7;
+      if (tl >= 1 && (int64_t)(128 >> tl) * A->max_row_nnz <= 2688 - 2 && 2.0 * fill * 1792.0 / 2688.0 >= 0.65) variant = 7;  // the 2688-entry tile
     }
   }
   if (A->rows_per_block > 0) {
@@ -680,13 +684,16 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
         return tl;
       };
       const bool big = tpr_for(2048) < tpr_for(1792);
-      const int tl = big ? tpr_for(2048) : tpr_for(1792);
+      // 2688 entries (32.3 KB, 4 waves): rows of 64..83 entries -- three fields on a 27-point stencil -- fill 0.99 of it with 32 rows,
+      // 0.72 of a 1792-entry block with 16
+      const bool huge = !big && g_spmv_tile2688 && tpr_for(2688) < tpr_for(1792);
+      const int tl = huge ? tpr_for(2688) : big ? tpr_for(2048) : tpr_for(1792);
       const int Rw = 64 >> tl;
       const int64_t ntw = (A->n + Rw - 1) / Rw;
       const int waves = variant == 6 ? 2 : 1;
       // persistent grid = what is resident at once (LDS-limited; other counts leave a ragged last round: 8 per CU measured
       // 1.43 ms against 1.06 ms with 7 or 14 at 256^3)
-      const int resident = (big ? 6 : 7) / waves;
+      const int resident = (huge ? 4 : big ? 6 : 7) / waves;  // the 2688-entry tile keeps 42 gathers + the next tile in registers: one wave per SIMD
       int capw = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult : resident);
       if (capw > MFEM_MAX_PARTIALS) capw = MFEM_MAX_PARTIALS;
       if (part.part != 0 && capw > MFEM_MAX_PARTIALS / 2) capw = MFEM_MAX_PARTIALS / 2;
@@ -703,7 +710,9 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
                      done_flag, part)
 #define LAUNCH_WV(RP)                                   \
   do {                                                  \
-    if (big && waves == 2) LAUNCH_W(RP, 2048, 2, 32);   \
+    if (huge && waves == 2) LAUNCH_W(RP, 2688, 2, 42);  \
+    else if (huge) LAUNCH_W(RP, 2688, 1, 42);           \
+    else if (big && waves == 2) LAUNCH_W(RP, 2048, 2, 32);   \
     else if (big) LAUNCH_W(RP, 2048, 1, 32);            \
     else if (waves == 2) LAUNCH_W(RP, 1792, 2, 28);     \
     else LAUNCH_W(RP, 1792, 1, 28);                     \

@@ -44,6 +44,7 @@ static int g_dia_enable = 1;
 static int g_dia_variant = 0;
 static int g_dia_block = MFEM_BLOCK;  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
 static int g_dia_sym = 1;      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernels off
+static int g_symp_direct = 1;  // bit 27: 0 = patch-major copy made from the slot-major copy in a second pass (k_symp_bind) instead of by k_dia_vals
 static int g_symp_tail = 1;    // bit 26: 0 = the rows outside the swept planes in a launch of their own (as in a split SpMV)
 static int g_dia_symp = 1;     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
 static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
@@ -61,6 +62,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_dia_sym = ((enable >> 22) & 1) ? 0 : 1;
   g_dia_symp = ((enable >> 23) & 1) ? 0 : 1;
   g_symp_tail = ((enable >> 26) & 1) ? 0 : 1;
+  g_symp_direct = ((enable >> 27) & 1) ? 0 : 1;
   g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
@@ -269,14 +271,29 @@ __global__ __launch_bounds__(128) void k_dia_flags(int64_t n, int64_t nx, const 
   }
 }
 
-// values in diagonal slots + per-block regular flag (regular: every row r of the block has 0 <= r + off[s] < nx for all s)
+// geometry of the wave-private patch sweep (k_spmv_symp below)
+#include "spmv_symp.h"
+struct SympGeom {
+  int64_t PL, nx;
+  int m1, m2, p0, p1, NS, NPk;
+  int nseg;  // runs per patch: a run = one patch swept through nplanes / nseg consecutive planes
+};
+
+// values in diagonal slots + per-block regular flag (regular: every row r of the block has 0 <= r + off[s] < nx for all s).
+// With pv != nullptr the rows of the swept lattice planes [Gm.p0, Gm.p1) go straight to the patch-major copy of the patch sweep (layout:
+// k_spmv_symp) -- their 27 slots, the edge block entries they own, and the diagonal alone to the slot-major copy (k_ell_diag reads it
+// there) -- instead of through the slot-major copy and a second pass (k_symp_bind): 1.97 + 1.85 ms -> one pass at 256^3.
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
                                                            int base, const DiaOffsets* __restrict__ Op,
-                                                           const int32_t* __restrict__ flags, double* __restrict__ out) {
+                                                           const int32_t* __restrict__ flags, double* __restrict__ out, SympGeom Gm,
+                                                           double* __restrict__ pv) {
   const DiaOffsets& O = *Op;
   extern __shared__ double lds[];
+  const int64_t slo = pv ? (int64_t)Gm.p0 * Gm.PL : 0, shi = pv ? (int64_t)Gm.p1 * Gm.PL : 0;  // swept rows
+  const int spNP = Gm.NS * Gm.NPk;
+  const int64_t spT = (int64_t)spNP * (Gm.p1 - Gm.p0);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   double* T = lds + (size_t)w * 64 * K;
   int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * 64 * K) + (size_t)w * 64 * K;
@@ -315,7 +332,39 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int off0 = (int)(lo - s0);
     const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> 1]) - 1;
-    if (cls >= 0) {  // regular 128-row block of class cls: slot s = diagonal s
+    if (cls >= 0 && r0 < shi && r0 + 64 > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
+      const bool sw = r >= slo && r < shi;
+      int line = 0, col = 0;
+      int64_t mainoff = 0, lowoff = 0, edgeoff = 0;
+      if (sw) {
+        const int p = (int)(r / Gm.PL), rem = (int)(r - (int64_t)p * Gm.PL), jj = rem / Gm.m2, kk = rem - jj * Gm.m2;
+        line = jj % SP_L;
+        col = kk % SP_W;
+        const int64_t step = (int64_t)(p - Gm.p0) * spNP + (jj / SP_L) * Gm.NPk + kk / SP_W;
+        mainoff = step * SP_MAIN + line * SP_W + col;
+        lowoff = spT * SP_MAIN + step * SP_LOW + line * SP_W + col;
+        edgeoff = step * SP_MAIN + 14 * SP_ROWS;
+      }
+      int j = 0;
+#pragma unroll
+      for (int s = 0; s < 27; ++s) {
+        double v = 0.0;
+        if (j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][s]) {
+          v = T[off0 + j];
+          ++j;
+        }
+        if (!sw) {
+          out[ell_base(r, K) + s * ELL_B] = v;
+        } else if (s < 13) {
+          pv[lowoff + s * SP_ROWS] = v;
+          const int e = sp_edge_of(s, line, col);
+          if (e >= 0) pv[edgeoff + e] = v;
+        } else {
+          pv[mainoff + (s - 13) * SP_ROWS] = v;
+          if (s == 13) out[ell_base(r, K) + 13 * ELL_B] = v;  // the diagonal (offset 0 is the 14th of the 27 lattice offsets)
+        }
+      }
+    } else if (cls >= 0) {  // regular 128-row block of class cls: slot s = diagonal s
       int j = 0;
       const int D = O.D[cls];
       for (int s = 0; s < D; ++s) {
@@ -687,12 +736,6 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sym27_check(int K, const DiaOffs
 // y stores cost 0.1 ms of it (non-temporal 16-byte stores: -1.5 %), the edge block 0.07 ms, the x staging 0.03 ms
 // (profiles/r02_symp_experiments.txt).
 // ---------------------------------------------------------------------------------------------------------------
-#include "spmv_symp.h"
-struct SympGeom {
-  int64_t PL, nx;
-  int m1, m2, p0, p1, NS, NPk;
-  int nseg;  // runs per patch: a run = one patch swept through nplanes / nseg consecutive planes
-};
 
 // the rows outside the swept planes, taken by the sweep's waves after their runs (unsplit SpMV): per-row code on the slot-major copy
 struct SympTail {
@@ -972,6 +1015,23 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_symp_bind(SympGeom Gm, int K, co
         val = ell[ell_base((int64_t)p * Gm.PL + (int64_t)(j0 + line) * Gm.m2 + k0 + col, K) + s * ELL_B];
       out[14 * SP_ROWS + e] = val;
     }
+  }
+}
+
+// lattice lines of odd length: the lane pair at the line's end holds the last point and a cell outside the lattice, which no row writes
+// and the sweep reads as a structurally absent entry -- an explicit zero in all 27 slots of every step of the last patch column
+__global__ __launch_bounds__(MFEM_BLOCK) void k_symp_zero_odd(SympGeom Gm, double* __restrict__ pv) {
+  const int NP = Gm.NS * Gm.NPk, nplanes = Gm.p1 - Gm.p0;
+  const int64_t T = (int64_t)NP * nplanes, cells = (int64_t)nplanes * Gm.NS * SP_L * 27;
+  const int col = Gm.m2 - (Gm.NPk - 1) * SP_W;  // first column past the line in the last patch column (odd, < SP_W)
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells; t += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(t % 27), line = (int)((t / 27) % SP_L);
+    const int64_t q = t / (27 * SP_L);
+    const int strip = (int)(q % Gm.NS), pl = (int)(q / Gm.NS);
+    const int64_t step = (int64_t)pl * NP + (int64_t)strip * Gm.NPk + (Gm.NPk - 1);
+    const int idx = line * SP_W + col;
+    if (s < 13) pv[T * SP_MAIN + step * SP_LOW + s * SP_ROWS + idx] = 0.0;
+    else pv[step * SP_MAIN + (s - 13) * SP_ROWS + idx] = 0.0;
   }
 }
 
@@ -1297,27 +1357,41 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     const int64_t nt = A->ell_npad >> 6;
     int g = (int)((nt + wv - 1) / wv);
     if (g > ctx->num_cus * 16) g = ctx->num_cus * 16;
-    if (A->rowptr_bits == 64)
-      hipLaunchKernelGGL(k_dia_vals<int64_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
-                         (const int64_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf);
-    else
-      hipLaunchKernelGGL(k_dia_vals<int32_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
-                         (const int32_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf);
-    MFEM_CHECK_LAUNCH();
+    // the slot-major copy; with the patch sweep wanted (and not the two-pass knob) the swept planes go straight to the patch-major copy
+    auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
+      if (A->rowptr_bits == 64)
+        hipLaunchKernelGGL(k_dia_vals<int64_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
+                           (const int64_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals);
+      else
+        hipLaunchKernelGGL(k_dia_vals<int32_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
+                           (const int32_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals);
+      MFEM_CHECK_LAUNCH();
+      return MFEM_OK;
+    };
+    const bool sweep = symp_wanted(A), direct = sweep && g_symp_direct && (g_dia_variant == 0 || g_dia_variant == 7);  // (the other variants read all rows from the slot-major copy)
+    double* pvals = buf + (size_t)A->ell_K * (size_t)A->ell_npad;
+    SympGeom G{};
+    if (sweep) G = symp_geom(ctx, A);
+    if (direct && (G.m2 & 1)) {
+      const int64_t cells = (int64_t)(G.p1 - G.p0) * G.NS * SP_L * 27;
+      hipLaunchKernelGGL(k_symp_zero_odd, dim3(mfem_grid_for(cells, MFEM_BLOCK, ctx->num_cus * 8)), dim3(MFEM_BLOCK), 0, ctx->stream, G, pvals);
+      MFEM_CHECK_LAUNCH();
+    }
+    { const int rt = dia_vals(G, direct ? pvals : nullptr); if (rt) return rt; }
     A->ell_vals = buf;
     A->ell_src = vals;
     A->ell_bound_mode = 2;
     A->sym_bound = 0;
     A->symp_bound = 0;
     A->symp_vals = nullptr;
-    if (symp_wanted(A)) {  // patch-major copy of the swept planes; are the pairs the sweep mirrors bitwise equal?
+    if (sweep) {  // patch-major copy of the swept planes; are the pairs the sweep mirrors bitwise equal?
       { const int rt = symp_upload_tables(ctx->device); if (rt) return rt; }
-      const SympGeom G = symp_geom(ctx, A);
-      double* pvals = buf + (size_t)A->ell_K * (size_t)A->ell_npad;
-      const int64_t T = symp_steps(A);
-      const int gb = (int)(T / 4 + 1 < (int64_t)ctx->num_cus * 32 ? T / 4 + 1 : (int64_t)ctx->num_cus * 32);
-      hipLaunchKernelGGL(k_symp_bind, dim3(gb), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->ell_K, (const double*)buf, pvals);
-      MFEM_CHECK_LAUNCH();
+      if (!direct) {
+        const int64_t T = symp_steps(A);
+        const int gb = (int)(T / 4 + 1 < (int64_t)ctx->num_cus * 32 ? T / 4 + 1 : (int64_t)ctx->num_cus * 32);
+        hipLaunchKernelGGL(k_symp_bind, dim3(gb), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->ell_K, (const double*)buf, pvals);
+        MFEM_CHECK_LAUNCH();
+      }
       int32_t* d_bad = ctx->d_flags + 9;
       MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
       const int gs = symp_grid(ctx, A);
@@ -1330,6 +1404,11 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
       A->symp_bound = ctx->h_flags[9] ? 0 : 1;
       A->symp_pairs = symp_count_entries(A, G.nseg);
       if (A->symp_bound) return MFEM_OK;
+      if (direct) {  // not symmetric: the plain kernel serves all rows from the slot-major copy -- the swept rows go there now
+        A->symp_vals = nullptr;
+        const int rt = dia_vals(SympGeom{}, nullptr);
+        if (rt) return rt;
+      }
     }
     if (sym27_wanted(A)) {  // are these values bitwise symmetric where the sweep kernel would mirror them?
       int32_t* d_bad = ctx->d_flags + 9;
@@ -1451,7 +1530,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       case 6: LAUNCH_DIA(2, 1); break;
       case 0:
       case 7:
-        if (symp_wanted(A) && A->symp_bound == 1 && A->symp_vals) {
+        if (A->symp_bound == 1 && A->symp_vals) {  // (decided when the values were bound: the swept rows may exist in the patch-major copy only)
           // swept planes: wave-private patch sweep on the patch-major copy; the other rows: per-row code on the slot-major copy.
           // part 1 of a split SpMV = the sweep (reads no ghost column), part 2 = the rest
           const SympGeom G = symp_geom(ctx, A);

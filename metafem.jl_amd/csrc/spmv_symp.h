@@ -58,3 +58,14 @@ __host__ __device__ inline bool sp_edge(int e, int& s, int& line, int& col, int&
   cell = sp_tbase(s) + (sl + sp_adj(s)) * SP_LS + sc + 2;
   return true;
 }
+// inverse of sp_edge for the row at (line, col) of its patch: the edge block entry that holds the row's own slot-s entry (s = 0..12), or
+// -1 when the row's slot-s neighbour lies inside the patch.  A row owns at most one entry per slot: the halo line takes the corner cells.
+__host__ __device__ constexpr int sp_edge_of(int s, int line, int col) {
+  const int dj = sp_dj(s), dk = sp_dk(s);
+  if (dj != 0 && line == (dj < 0 ? 0 : SP_L - 1)) return sp_ebase(s) + col;
+  if (dk != 0 && col == (dk < 0 ? 0 : SP_W - 1)) {
+    const int q = dj < 0 ? line - 1 : line;  // dj < 0: lines 1 .. SP_L - 1; dj > 0: lines 0 .. SP_L - 2; dj = 0: all lines
+    return sp_ebase(s) + (dj != 0 ? SP_W : 0) + q;
+  }
+  return -1;
+}

@@ -360,14 +360,14 @@ def test_symmetric_sweep_spmv_is_bitwise_the_plain_kernel(mf, slab):
         _lib.check(_lib.lib.mfem_csr_solver_layout_entries(brick.ctx._h, A._h, C.byref(ent), C.byref(sym)))
         assert sym.value == 2 and ent.value < 0.8 * 27 * A.n  # a third and more of the entries come from LDS (2 = wave-private patch sweep)
         ys = []
-        for knob in (1 << 22, 1 << 23, 0):  # plain kernel, workgroup-tile sweep, wave-private patch sweep
+        for knob in (1 << 22, 1 << 23, 0, 1 << 27):  # plain kernel, workgroup-tile sweep, wave-private patch sweep (values bound in one pass / in two)
             _lib.lib.mfem_debug_set_ell(1 | knob)
             before = _lib.lib.mfem_debug_sym_spmv_count()
             y = torch.full((A.n,), 3.0, dtype=torch.float64, device="cuda")
             _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
             assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob != 1 << 22)
             ys.append(y)
-        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+        assert all(torch.equal(ys[0], yy) for yy in ys[1:])
         yc = torch.zeros(A.n, dtype=torch.float64, device="cuda")
         _lib.lib.mfem_debug_set_ell(0)
         mf.mul_(yc, A, K, x)  # CSR kernel
@@ -422,7 +422,7 @@ def test_cg_with_symmetric_sweep_matches_plain_kernel(mf):
     _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
     try:
         out = []
-        for knob in (1 << 22, 1 << 23, 0):
+        for knob in (1 << 22, 1 << 23, 0, 1 << 27):
             _lib.lib.mfem_debug_set_ell(1 | knob)
             before = _lib.lib.mfem_debug_sym_spmv_count()
             x, st = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=mf.cg_, maxiter=2000, max_pass=2)
@@ -486,14 +486,14 @@ def test_symmetric_sweep_with_drifting_tiles(mf, n):
         _lib.check(_lib.lib.mfem_csr_solver_layout_entries(brick.ctx._h, A._h, C.byref(ent), C.byref(sym)))
         assert sym.value == 2
         ys = []
-        for knob in (1 << 22, 0):  # (the workgroup-tile sweep needs >= 8 tiles per plane: not all of these lattices qualify)
+        for knob in (1 << 22, 0, 1 << 27):  # (the workgroup-tile sweep needs >= 8 tiles per plane: not all of these lattices qualify)
             _lib.lib.mfem_debug_set_ell(1 | knob)
             before = _lib.lib.mfem_debug_sym_spmv_count()
             y = torch.full((A.n,), -2.0, dtype=torch.float64, device="cuda")
             _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
-            assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob == 0)
+            assert (_lib.lib.mfem_debug_sym_spmv_count() > before) == (knob != 1 << 22)
             ys.append(y)
-        assert torch.equal(ys[0], ys[1])
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
         # alpha / beta form through the same kernels
         y2 = ys[1].clone()
         _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y2.data_ptr(), -0.5, 2.0))

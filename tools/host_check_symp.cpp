@@ -45,6 +45,22 @@ int main() {
     if (!halo.insert(cell).second) { printf("edge %d: cell %d filled twice\n", e, cell); ++bad; }
     if (line < 0 || line >= SP_L || col < 0 || col >= SP_W) { printf("edge %d: referencing row outside the patch\n", e); ++bad; }
   }
+  {  // sp_edge_of is the inverse of sp_edge: every (slot, line, col) owns at most one entry, all SP_NE entries are owned
+    int owned = 0;
+    for (int s = 0; s < 13; ++s)
+      for (int line = 0; line < SP_L; ++line)
+        for (int col = 0; col < SP_W; ++col) {
+          const int e = sp_edge_of(s, line, col);
+          if (e < 0) continue;
+          ++owned;
+          int s2, l2, c2, cell2;
+          if (e >= SP_NE || !sp_edge(e, s2, l2, c2, cell2) || s2 != s || l2 != line || c2 != col) {
+            printf("sp_edge_of(%d, %d, %d) = %d does not decode back\n", s, line, col, e);
+            ++bad;
+          }
+        }
+    if (owned != SP_NE) { printf("sp_edge_of owns %d entries, SP_NE = %d\n", owned, SP_NE); ++bad; }
+  }
   if ((int)halo.size() != SP_NE) { printf("edge block has %zu cells, SP_NE = %d\n", halo.size(), SP_NE); ++bad; }
   for (int s = 0; s < 13; ++s)
     for (int lane = 0; lane < 64; ++lane) {
