@@ -105,6 +105,10 @@ struct mfem_csr_s {
   // plan for the LDS-staged SpMV
   int32_t max_row_nnz;
   int32_t rows_per_block;  // power of two, 0 => long-row fallback
+  // tiles cut by nonzeros for rows of uneven length (spmv.hip: k_spmv_csr_rb): rb_state 1 = planned, -1 = not used
+  int rb_state;
+  int64_t rb_ntiles;
+  int32_t* rb_rows;         // owned, [rb_ntiles + 1]: first row of every tile
   // owned storage (mfem_brick_pattern) -- freed in destroy
   void* owned_rowptr;
   void* owned_colidx;

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
-    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part, int parity) {
   constexpr int LU = (CAPW / 2 + 63) / 64;  // (16 B + 8 B) loads per lane that cover a full tile
   static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
   // NG = gathers a lane issues up front (rows of up to NG * tpr entries have none left over)
@@ -323,6 +323,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   int32_t* sc = sc_all[w];
   const int tpr = 1 << tpr_log2;
   const int g = lane & (tpr - 1);
+  // row of the tile this lane group walks; parity: even rows of the tile first, then the odd ones -- on an order-2 lattice (hex-27)
+  // neighbouring rows alternate between node types with different stencils while rows two apart share theirs, so the lanes of a
+  // gather instruction then hold the same stencil position of every second row: a few cache lines instead of one run per row
+  int rsel = lane >> tpr_log2;
+  if (parity) rsel = rsel < (R >> 1) ? 2 * rsel : 2 * (rsel - (R >> 1)) + 1;
   double dot_acc = 0.0;
   const int64_t tstride = (int64_t)gridDim.x * WAVES;
   // x as a buffer resource (byte offsets are 32-bit: the host side uses this kernel only while 8 * columns < 4 GiB)
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     const int64_t s = uniform64((int64_t)rowptr[r0] - base), e = uniform64((int64_t)rowptr[r1] - base);
     sa = s & ~(int64_t)1;
     cnt = (int)(e - sa);
-    const int64_t r = r0 + (lane >> tpr_log2);
+    const int64_t r = r0 + rsel;
     lo = hi = 0;
     if (r < r1) {
       lo = (int)((int64_t)rowptr[r] - base - sa);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS stores have landed
     __builtin_amdgcn_wave_barrier();
     const int64_t r0 = t_cur * R, r1 = (r0 + R < n) ? r0 + R : n;
-    const int64_t r = r0 + (lane >> tpr_log2);
+    const int64_t r = r0 + rsel;
     const int lo = lo_cur, hi = hi_cur;
     // ---- all gathers of the lane's row first ...
     double xx[NG];
@@ -424,6 +429,180 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   }
 }
 
+// Wave-private tiles cut by NONZEROS (rows of uneven length: hex-27's 27 / 45 / 75 / 125-entry rows, unstructured meshes).  The kernel
+// above spends about the same time on a tile whatever it holds (one round of staging loads + gathers per tile and wave), and tiles of
+// a fixed row count must be sized for the longest row: on the hex-27 matrix they are 0.3 - 0.5 full.  Here tile t holds the rows
+// [rs[t], rs[t + 1]) with rs[t] = first row whose nonzeros start at or behind t * C (mfem_csr_plan_rowblocks, once per pattern,
+// C = capacity - longest row - 2): every tile is C +- one row of nonzeros, 0.9+ full.  The rows of a tile are walked in groups of
+// 64 / tpr (tpr chosen per tile from its row count), a row by tpr lanes in chunks of NG gathers; the tile's row pointers are staged
+// in LDS next to its val / col streams.  Same software pipeline as above (next tile's streams requested behind the first chunk of
+// gathers); the tile's row range is requested one tile earlier still.
+#define RB_ROWS 128  // row pointers staged per tile (tiles with more rows -- runs of very short rows -- read the rest from memory)
+template <typename RP, int CAPW, int NG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CAPW > 2048 ? 1 : CAPW > 1024 ? 2 : 3))) void k_spmv_csr_rb(
+    int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
+    double beta, int base, int64_t ntiles, const int32_t* __restrict__ rs, const double* __restrict__ dotw,
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+  constexpr int LU = (CAPW / 2 + 63) / 64;
+  static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
+  __shared__ __attribute__((aligned(16))) double sv[CAPW + 2];
+  __shared__ __attribute__((aligned(16))) int32_t sc[CAPW + 4];
+  __shared__ int32_t srp[RB_ROWS];
+  __shared__ double sred[64];
+  if (done_flag && done_flag[0]) return;
+  const int lane = threadIdx.x;
+  double dot_acc = 0.0;
+  const int64_t tstride = gridDim.x;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0xFFFFFFFF, 0x00020000);
+  d2_t pv[LU];
+  i2_t pc[LU];
+  int32_t prp[2];  // row pointers r0 + lane, r0 + 64 + lane of the requested tile, relative to its first staged entry
+  auto uniform32 = [](int32_t v) -> int32_t { return __builtin_amdgcn_readfirstlane(v); };
+  auto uniform64 = [](int64_t v) -> int64_t {
+    const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi32 << 32) | lo32);
+  };
+  // request the streams of the tile with rows [r0, r1)
+  auto request = [&](int32_t r0, int32_t r1, int64_t& sa) {
+    const int64_t s = uniform64((int64_t)rowptr[r0] - base), e = uniform64((int64_t)rowptr[r1] - base);
+    sa = s & ~(int64_t)1;
+    const int cnt = (int)(e - sa);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t r = (int64_t)r0 + 64 * h + lane;
+      prp[h] = r <= r1 ? (int32_t)((int64_t)rowptr[r] - base - sa) : 0;
+    }
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(vals + sa), 0, cnt * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(col + sa), 0, cnt * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      pv[u] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(vr, lane * 16, u * 1024, 2));
+      pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
+    }
+  };
+  int64_t t_cur = blockIdx.x;
+  int32_t r0 = 0, r1 = 0, r0n = 0, r1n = 0;  // rows of the current tile / of the tile after it
+  int64_t sa_cur = 0;
+  if (t_cur < ntiles) {
+    r0 = uniform32(rs[t_cur]);
+    r1 = uniform32(rs[t_cur + 1]);
+    request(r0, r1, sa_cur);
+  }
+  if (t_cur + tstride < ntiles) {
+    r0n = uniform32(rs[t_cur + tstride]);
+    r1n = uniform32(rs[t_cur + tstride + 1]);
+  }
+  while (t_cur < ntiles) {
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int i = 2 * lane + u * 128;
+      *reinterpret_cast<d2_t*>(&sv[i]) = pv[u];
+      *reinterpret_cast<i2_t*>(&sc[i]) = pc[u];
+    }
+    srp[lane] = prp[0];
+    srp[64 + lane] = prp[1];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const int nr = r1 - r0;
+    // The rows of the tile in two passes -- rows 0, 2, 4, .. then 1, 3, 5, .. (on an order-2 lattice neighbouring rows alternate between
+    // node types with different stencil sizes, rows two apart share theirs) -- each pass with all 64 lanes: nc rows get tpr = 64 / nc
+    // lanes each (any quotient, not only powers of two), lane = g * nc + slot, so that the lanes of a gather instruction hold the same
+    // stencil position of neighbouring same-type rows and (almost) none of them idles while a longer row finishes.
+    const int64_t t_next = t_cur + tstride;
+    int64_t sa_n = 0;
+    bool requested = false;
+    for (int c = 0; c < 2; ++c) {
+      const int ncl = (nr + 1 - c) >> 1;  // rows c, c + 2, ...
+      for (int b0 = 0; b0 < ncl || !requested; b0 += 64) {
+        const int nc = ncl - b0 < 64 ? (ncl - b0 > 0 ? ncl - b0 : 1) : 64;
+        const int tpr = 64 / nc, g = lane / nc, slot = lane - g * nc;
+        const int ri = c + 2 * (b0 + slot);
+        int lo = 0, hi = 0;
+        if (g < tpr && b0 + slot < ncl) {
+          if (ri + 1 < RB_ROWS) {
+            lo = srp[ri];
+            hi = srp[ri + 1];
+          } else {  // beyond the staged row pointers
+            lo = (int)((int64_t)rowptr[(int64_t)r0 + ri] - base - sa_cur);
+            hi = (int)((int64_t)rowptr[(int64_t)r0 + ri + 1] - base - sa_cur);
+          }
+        }
+        double sum = 0.0;
+        int j = lo + g;
+        do {
+          double xx[NG];
+#pragma unroll
+          for (int u = 0; u < NG; ++u) {
+            const int jj = j + u * tpr;
+            xx[u] = 0.0;
+            if (jj < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, (sc[jj] - base) * 8, 0, 0));
+          }
+          if (!requested) {  // behind the tile's first gathers: the next tile's streams
+            requested = true;
+            if (t_next < ntiles) request(r0n, r1n, sa_n);
+          }
+#pragma unroll
+          for (int u = 0; u < NG; ++u) {
+            const int jj = j + u * tpr;
+            sum += (jj < hi ? sv[jj] : 0.0) * xx[u];
+          }
+          j += NG * tpr;
+        } while (__any(j < hi));
+        // the tpr partial sums of a row meet in LDS (tpr is any quotient: no butterfly)
+        __builtin_amdgcn_wave_barrier();
+        sred[lane] = sum;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nc && b0 + lane < ncl) {
+          double tot = 0.0;
+          for (int q = 0; q < tpr; ++q) tot += sred[q * nc + lane];
+          const int64_t r = (int64_t)r0 + c + 2 * (b0 + lane);
+          double yv = alpha * tot;
+          if (beta != 0.0) yv += beta * y[r];
+          y[r] = yv;
+          if (dotw) dot_acc += yv * dotw[r];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane is done reading the block before the next tile's stores
+    t_cur = t_next;
+    sa_cur = sa_n;
+    r0 = r0n;
+    r1 = r1n;
+    if (t_cur + tstride < ntiles) {
+      r0n = uniform32(rs[t_cur + tstride]);
+      r1n = uniform32(rs[t_cur + tstride + 1]);
+    }
+  }
+  if (partials) {
+    const double w = wave_reduce_sum(dot_acc);
+    if (lane == 0) partials[blockIdx.x] = w;
+  }
+}
+
+// rs[t] = first row whose nonzeros start at or behind t * C (t = 0 .. ntiles - 1), rs[ntiles] = n
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_csr_rowblocks(int64_t n, const RP* __restrict__ rowptr, int base, int64_t C, int64_t ntiles,
+                                                               int32_t* __restrict__ rs) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= ntiles; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t == ntiles) {
+      rs[t] = (int32_t)n;
+      continue;
+    }
+    const int64_t target = t * C;
+    int64_t lo = 0, hi = n;  // first r in [0, n] with rowptr[r] - base >= target
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)rowptr[mid] - base >= target) hi = mid;
+      else lo = mid + 1;
+    }
+    rs[t] = (int32_t)lo;
+  }
+}
+
 // Fallback for patterns whose longest row does not fit the LDS tile: one wave per row.
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
@@ -459,6 +638,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
+static int g_spmv_parity = 0;    // bit 28: lane groups take the even rows of a wave tile first, then the odd ones
 static int g_spmv_tile2688 = 1;  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
 static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
@@ -476,9 +656,23 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_tile2688 = ((xcd_aware >> 27) & 1) ? 0 : 1;
+  g_spmv_parity = (xcd_aware >> 28) & 1;
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
+}
+
+#define RB_CAP 2048  // entries per tile of the row-block kernel (25 KB of LDS: six one-wave workgroups per CU)
+#define RB_NG 16    // gathers a lane has in flight
+#define RB_WG_PER_CU 6
+// do wave tiles of a fixed row count fill their LDS block (>= 0.65)?  (rows of near-uniform length: k_spmv_csr_w)
+static bool csr_w_fills(const mfem_csr_s* A) {
+  if (!(A->max_row_nnz > 0 && A->max_row_nnz <= 2048 - 2) || A->n == 0) return false;
+  int tl = 0;
+  while (tl < 6 && (int64_t)(64 >> tl) * A->max_row_nnz > 1792 - 2) ++tl;
+  const double fill = (double)(64 >> tl) * ((double)A->nnz / (double)A->n) / 1792.0;
+  if (tl <= 3 && fill >= 0.65) return true;
+  return tl >= 1 && (int64_t)(128 >> tl) * A->max_row_nnz <= 2688 - 2 && 2.0 * fill * 1792.0 / 2688.0 >= 0.65;  // the 2688-entry tile
 }
 
 int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
@@ -499,6 +693,22 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->max_row_nnz = ctx->h_flags[8];
   A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
+  // rows of uneven length (tiles of a fixed row count would be less than 0.65 full): tiles cut by nonzeros, k_spmv_csr_rb
+  A->rb_state = -1;
+  if (A->rows_per_block > 0 && !csr_w_fills(A) && A->max_row_nnz <= RB_CAP / 4 && A->nnz >= 16 * A->n && A->n < ((int64_t)1 << 31) - 1) {
+    const int64_t C = RB_CAP - 2 - A->max_row_nnz, ntiles = (A->nnz + C - 1) / C;
+    MFEM_CHECK_HIP(hipMalloc(&A->rb_rows, sizeof(int32_t) * (size_t)(ntiles + 1)));
+    const int g = mfem_grid_for(ntiles + 1, MFEM_BLOCK, 4096);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_csr_rowblocks<int64_t>, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const int64_t*)A->rowptr, A->index_base, C,
+                         ntiles, A->rb_rows);
+    else
+      hipLaunchKernelGGL(k_csr_rowblocks<int32_t>, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const int32_t*)A->rowptr, A->index_base, C,
+                         ntiles, A->rb_rows);
+    MFEM_CHECK_LAUNCH();
+    A->rb_ntiles = ntiles;
+    A->rb_state = 1;
+  }
   return MFEM_OK;
 }
 
@@ -534,6 +744,7 @@ extern "C" int mfem_csr_destroy(mfem_csr A) {
   if (A->ctx && mfem_context_alive(A->ctx)) mfem_graphs_invalidate(A->ctx);
   mfem_ell_free(A);
   mfem_sell_free(A);
+  if (A->rb_rows) hipFree(A->rb_rows);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);
   if (A->owned_colidx) hipFree(A->owned_colidx);
   delete A;
@@ -663,16 +874,24 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   // length: 256^3 hex-8 1.06 ms against 1.19 ms); the product tile otherwise (hex-27's 27..125-entry rows fill half a block:
   // 3.9 ms against 3.5 ms)
   int variant = g_spmv_variant;
-  if (variant == 0) {
-    variant = 1;
-    if (A->max_row_nnz > 0 && A->max_row_nnz <= 2048 - 2) {
-      int tl = 0;
-      while (tl < 6 && (int64_t)(64 >> tl) * A->max_row_nnz > 1792 - 2) ++tl;
-      const double fill = (double)(64 >> tl) * ((double)A->nnz / (double)A->n) / 1792.0;
-      if (tl <= 3 && fill >= 0.65) variant = 7;
-      if (tl >= 1 && (int64_t)(128 >> tl) * A->max_row_nnz <= 2688 - 2 && 2.0 * fill * 1792.0 / 2688.0 >= 0.65) variant = 7;  // the 2688-entry tile
-    }
+  if (variant == 0) variant = csr_w_fills(A) ? 7 : 3;
+  if (variant == 3 && A->rb_state == 1 && part.part == 0 && ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0) &&
+      (A->ncols > 0 ? A->ncols : A->n) < ((int64_t)1 << 29)) {
+    // tiles cut by nonzeros (rows of uneven length); the grid is what is resident
+    int grid = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult : RB_WG_PER_CU);
+    if (grid > MFEM_MAX_PARTIALS) grid = MFEM_MAX_PARTIALS;
+    if ((int64_t)grid > A->rb_ntiles) grid = (int)A->rb_ntiles;
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL((k_spmv_csr_rb<int64_t, RB_CAP, RB_NG>), dim3(grid), dim3(64), 0, ctx->stream, A->n, A->nnz, (const int64_t*)A->rowptr,
+                         A->colidx, vals, x, y, alpha, beta, base, A->rb_ntiles, A->rb_rows, dotw, partials, done_flag);
+    else
+      hipLaunchKernelGGL((k_spmv_csr_rb<int32_t, RB_CAP, RB_NG>), dim3(grid), dim3(64), 0, ctx->stream, A->n, A->nnz, (const int32_t*)A->rowptr,
+                         A->colidx, vals, x, y, alpha, beta, base, A->rb_ntiles, A->rb_rows, dotw, partials, done_flag);
+    MFEM_CHECK_LAUNCH();
+    if (n_partials && partials) *n_partials = grid;
+    return MFEM_OK;
   }
+  if (variant == 3) variant = 1;  // (split SpMV, unaligned arrays, no row blocks planned: the product tile)
   if (A->rows_per_block > 0) {
     const bool vec = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0);
     if (vec && variant >= 5 && A->max_row_nnz <= 2048 - 2 && (A->ncols > 0 ? A->ncols : A->n) < ((int64_t)1 << 29)) {
@@ -707,7 +926,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
 #define LAUNCH_W(RP, CAPW, WV, NG)                                                                               \
   hipLaunchKernelGGL((k_spmv_csr_w<RP, CAPW, WV, NG>), dim3(gridw), dim3(64 * WV), 0, ctx->stream, A->n, A->nnz, \
                      (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, Rw, tl, ntw, dotw, partials, \
-                     done_flag, part)
+                     done_flag, part, (g_spmv_parity && Rw >= 2) ? 1 : 0)
 #define LAUNCH_WV(RP)                                   \
   do {                                                  \
     if (huge && waves == 2) LAUNCH_W(RP, 2688, 2, 42);  \

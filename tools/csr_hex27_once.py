@@ -3,6 +3,9 @@ import sys, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import metafem_jl_amd as mf
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+if len(sys.argv) > 2:  # mfem_debug_set_spmv knob (variant << 16 | bit 27 no 2688 tile | bit 28 parity order)
+    from metafem_jl_amd import _lib
+    _lib.lib.mfem_debug_set_spmv(int(sys.argv[2], 0), 0)
 b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 2, 5)
 A = b.pattern(1)
 K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
