@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
 // gathers); the tile's row range is requested one tile earlier still.
 #define RB_ROWS 128  // row pointers staged per tile (tiles with more rows -- runs of very short rows -- read the rest from memory)
 template <typename RP, int CAPW, int NG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CAPW > 2048 ? 1 : CAPW > 1024 ? 2 : 3))) void k_spmv_csr_rb(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_spmv_csr_rb(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int64_t ntiles, const int32_t* __restrict__ rs, const double* __restrict__ dotw,
@@ -662,9 +662,11 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   return MFEM_OK;
 }
 
-#define RB_CAP 2048  // entries per tile of the row-block kernel (25 KB of LDS: six one-wave workgroups per CU)
+// Measured on the hex-27 128^3 matrix (capacity, gathers in flight, workgroups per CU): (2048, 16, 6) 2.99 ms, (1792, 16, 7) 2.86,
+// (1536, 16, 8) 2.62, (1536, 20, 8) 3.02, (1280, 16, 8) 2.82, (1024, 12, 12) 4.47 -- two waves on every SIMD, the largest tile that allows it
+#define RB_CAP 1536  // entries per tile of the row-block kernel (19.5 KB of LDS: eight one-wave workgroups per CU)
 #define RB_NG 16    // gathers a lane has in flight
-#define RB_WG_PER_CU 6
+#define RB_WG_PER_CU 8
 // do wave tiles of a fixed row count fill their LDS block (>= 0.65)?  (rows of near-uniform length: k_spmv_csr_w)
 static bool csr_w_fills(const mfem_csr_s* A) {
   if (!(A->max_row_nnz > 0 && A->max_row_nnz <= 2048 - 2) || A->n == 0) return false;
@@ -695,7 +697,7 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
   // rows of uneven length (tiles of a fixed row count would be less than 0.65 full): tiles cut by nonzeros, k_spmv_csr_rb
   A->rb_state = -1;
-  if (A->rows_per_block > 0 && !csr_w_fills(A) && A->max_row_nnz <= RB_CAP / 4 && A->nnz >= 16 * A->n && A->n < ((int64_t)1 << 31) - 1) {
+  if (A->rows_per_block > 0 && (g_spmv_variant == 3 || !csr_w_fills(A)) && A->max_row_nnz <= RB_CAP / 4 && A->nnz >= 16 * A->n && A->n < ((int64_t)1 << 31) - 1) {
     const int64_t C = RB_CAP - 2 - A->max_row_nnz, ntiles = (A->nnz + C - 1) / C;
     MFEM_CHECK_HIP(hipMalloc(&A->rb_rows, sizeof(int32_t) * (size_t)(ntiles + 1)));
     const int g = mfem_grid_for(ntiles + 1, MFEM_BLOCK, 4096);

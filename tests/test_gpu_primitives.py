@@ -109,6 +109,41 @@ def test_spmv_long_rows_fallback(mf):
     assert np.max(np.abs(y.cpu().numpy() - ref) / scale) < 1e-14
 
 
+@pytest.mark.parametrize("bits,base", [(64, 0), (32, 1)])
+def test_spmv_row_block_kernel_on_ragged_rows(mf, bits, base):
+    """Rows of very uneven length take wave tiles cut by nonzeros (k_spmv_csr_rb): rows near the longest the plan admits, runs of
+    several hundred empty rows (more rows in a tile than row pointers staged in LDS), single-entry rows, trailing empty rows, alpha / beta
+    and the fused dot product's y."""
+    import torch
+    from oracle import solvers
+
+    rng = np.random.default_rng(11)
+    lens = []
+    while len(lens) < 6000:
+        kind = rng.integers(0, 5)
+        if kind == 0: lens += [0] * int(rng.integers(130, 400))            # a tile of > 128 rows
+        elif kind == 1: lens += [int(rng.integers(300, 384))] * int(rng.integers(1, 40))
+        elif kind == 2: lens += [1] * int(rng.integers(1, 300))
+        elif kind == 3: lens += list(rng.integers(20, 130, size=int(rng.integers(10, 200))))
+        else: lens += [125, 75] * int(rng.integers(5, 60))                 # alternating stencils, as on an order-2 lattice line
+    lens += [0] * 37                                                        # trailing empty rows
+    lens = np.array(lens)
+    n = len(lens)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    assert rowptr[-1] >= 16 * n and lens.max() <= 384                       # what the plan asks for
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens if l > 0]).astype(np.int32)
+    vals = rng.standard_normal(rowptr[-1])
+    x = rng.standard_normal(n)
+    ref = solvers.csr(rowptr, cols, vals, n) @ x
+    scale = np.abs(solvers.csr(rowptr, cols, np.abs(vals), n) @ np.abs(x)) + 1e-300
+    A = mf.FEM_SpMat_CSR(torch.tensor(rowptr + base, dtype=torch.int64 if bits == 64 else torch.int32, device="cuda"),
+                         torch.tensor(cols + base, dtype=torch.int32, device="cuda"), n, index_base=base)
+    y = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+    mf.mul_(y, A, torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda"), 2.0, -1.0)
+    assert np.max(np.abs(y.cpu().numpy() - (2.0 * ref - 3.0)) / (2 * scale + 3.0)) < 1e-14
+
+
 def test_spmv_unaligned_values_pointer(mf):
     """A values array that is not 16-byte aligned must take the scalar path, not fault."""
     import torch
