@@ -106,17 +106,20 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_block_sizes(int64_t n, int6
   }
 }
 
-// columns (0-based; padding = the row itself) or values (padding = 0) into the sliced layout; lane <-> sorted row
+// columns (0-based; padding = the row itself) or values (padding = 0) into the sliced layout.  Four lanes per sorted row, 16 rows per
+// wave pass: a lane quad reads 32 contiguous bytes of its row per step, so a row's cache line is used up by four consecutive loads of the
+// same wave (with a lane per row the 64 row cursors of a wave advance 8 bytes at a time over a 64 KB working set: 10.5 ms per bind of the
+// hex-27 128^3 matrix against 4.9 ms here); a store covers full 128-byte lines of four slots.
 template <typename RP, typename T, bool COLS>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
                                                             const int32_t* __restrict__ rowid, const int64_t* __restrict__ ptr,
                                                             const T* __restrict__ src, int base, T* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, g = lane & 3;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t t = wave; t < 2 * nblk; t += nwaves) {  // a wave fills one half (64 rows) of a block
-    const int64_t b = t >> 1;
-    const int64_t rs = b * SELL_B + (t & 1) * 64 + lane;  // sorted row
+  for (int64_t t = wave; t < 8 * nblk; t += nwaves) {  // a wave fills 16 rows of a block
+    const int64_t b = t >> 3;
+    const int64_t rs = b * SELL_B + (t & 7) * 16 + (lane >> 2);  // sorted row
     const int64_t p0 = ptr[b];
     const int Kb = (int)((ptr[b + 1] - p0) / SELL_B);
     int64_t lo = 0;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nbl
       if (COLS) pad = (T)r;
     }
     T* o = out + p0 + (rs & (SELL_B - 1));
-    for (int s = 0; s < Kb; ++s) o[(int64_t)s * SELL_B] = s < len ? (COLS ? (T)(src[lo + s] - base) : src[lo + s]) : pad;
+    for (int s = g; s < Kb; s += 4) o[(int64_t)s * SELL_B] = s < len ? (COLS ? (T)(src[lo + s] - base) : src[lo + s]) : pad;
   }
 }
 
@@ -287,7 +290,7 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   SELL_CHECK(hipStreamSynchronize(ctx->stream));
   if ((double)total <= 1.15 * (double)A->nnz + 128.0 * A->max_row_nnz) {
     SELL_CHECK(hipMalloc(&A->sell_cols, sizeof(int32_t) * (size_t)total));
-    const int g2 = mfem_grid_for(2 * nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
+    const int g2 = mfem_grid_for(8 * nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
     if (A->rowptr_bits == 64)
       hipLaunchKernelGGL((k_sell_fill<int64_t, int32_t, true>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, n, nblk,
                          (const int64_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols);
@@ -343,7 +346,7 @@ int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   A->sell_vals = nullptr;
   A->sell_src = nullptr;
   if (A->sell_state != 1 || !g_sell_enable || !buf) return MFEM_OK;
-  const int g2 = mfem_grid_for(2 * A->sell_nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
+  const int g2 = mfem_grid_for(8 * A->sell_nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL((k_sell_fill<int64_t, double, false>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk,
                        (const int64_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf);
