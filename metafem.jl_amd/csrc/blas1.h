@@ -15,6 +15,7 @@ int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, con
                      const int32_t* done_flag = nullptr);
 int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* d, int mode);
 int mfem_mat_div_rows(mfem_context_s* ctx, mfem_csr_s* A, double* vals, const double* d);
+int mfem_mat_div_jacobi_from(mfem_context_s* ctx, mfem_csr_s* A, const double* src, double* vals, const double* d);  // vals = src / d[col]
 int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count);
 int mfem_comm_halo(mfem_context_s* ctx, double* x_local);
 // split form: between begin and end the ghost entries of x must not be read and its boundary planes must not be written

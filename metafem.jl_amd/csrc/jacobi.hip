@@ -52,26 +52,28 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sqrt_inplace(int64_t n, double* 
 }
 
 // vals[j] /= d[col[j]] over the flat nonzero stream.
+// vals[j] = src[j] / d[col[j]] (src == vals: in place; the solver scales its working copy straight from the caller's values)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mat_div_jacobi(int64_t nnz, const int32_t* __restrict__ col,
-                                                                 double* __restrict__ vals,
+                                                                 const double* src, double* vals,
                                                                  const double* __restrict__ d, int base) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const bool al = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)col) & 7) == 0);
+  const bool al = ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)col) & 7) == 0);
   if (al) {
     const int64_t n2 = nnz >> 1;
     d2_t* v2 = reinterpret_cast<d2_t*>(vals);
+    const d2_t* s2 = reinterpret_cast<const d2_t*>(src);
     const i2_t* c2 = reinterpret_cast<const i2_t*>(col);
     for (int64_t i = tid; i < n2; i += stride) {
-      d2_t v = v2[i];
+      d2_t v = s2[i];
       const i2_t c = c2[i];
       v.x /= d[c.x - base];
       v.y /= d[c.y - base];
       v2[i] = v;
     }
-    if (tid == 0 && (nnz & 1)) vals[nnz - 1] /= d[col[nnz - 1] - base];
+    if (tid == 0 && (nnz & 1)) vals[nnz - 1] = src[nnz - 1] / d[col[nnz - 1] - base];
   } else {
-    for (int64_t j = tid; j < nnz; j += stride) vals[j] /= d[col[j] - base];
+    for (int64_t j = tid; j < nnz; j += stride) vals[j] = src[j] / d[col[j] - base];
   }
 }
 
@@ -151,12 +153,17 @@ extern "C" int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double
   return MFEM_OK;
 }
 
+int mfem_mat_div_jacobi_from(mfem_context_s* ctx, mfem_csr_s* A, const double* src, double* vals, const double* d) {
+  if (A->nnz == 0) return MFEM_OK;
+  hipLaunchKernelGGL(k_mat_div_jacobi, dim3(mfem_grid_for((A->nnz + 1) / 2, MFEM_BLOCK, ctx->num_cus * 16)),
+                     dim3(MFEM_BLOCK), 0, ctx->stream, A->nnz, A->colidx, src, vals, d, A->index_base);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+
 extern "C" int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double* d) {
   MFEM_REQUIRE(ctx && A, "null handle");
   if (A->nnz == 0) return MFEM_OK;
   MFEM_REQUIRE(vals && d, "null array");
-  hipLaunchKernelGGL(k_mat_div_jacobi, dim3(mfem_grid_for((A->nnz + 1) / 2, MFEM_BLOCK, ctx->num_cus * 16)),
-                     dim3(MFEM_BLOCK), 0, ctx->stream, A->nnz, A->colidx, vals, d, A->index_base);
-  MFEM_CHECK_LAUNCH();
-  return MFEM_OK;
+  return mfem_mat_div_jacobi_from(ctx, A, vals, vals, d);
 }

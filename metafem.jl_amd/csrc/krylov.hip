@@ -629,10 +629,13 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   for (int i = 0; i < nwork; ++i) V.w[i] = (double*)(base + (4 + i) * vec_bytes);
   V.nwork = nwork;
   double* vals_work = vals;
+  // right Jacobi scaling of a working copy: the scaling kernel writes the copy straight from the caller's values (no copy pass first)
+  const bool scaled_copy = need_copy && jac && !is_cg;
   if (need_copy) {
     vals_work = (double*)(base + vec_bytes * (4 + nwork));
-    MFEM_CHECK_HIP(hipMemcpyAsync(vals_work, vals, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (!scaled_copy) MFEM_CHECK_HIP(hipMemcpyAsync(vals_work, vals, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
+  const double* vals_src = scaled_copy ? vals : vals_work;  // what the scaling is computed from
   MFEM_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   MFEM_CHECK_HIP(hipMemcpyAsync(V.b, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
 
@@ -649,7 +652,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   bool ell_bound = false;
   if (jac) {
     if (o->precond == MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !is_cg) {
-      rc = mfem_jacobi2_by_column(ctx, A, vals_work, V.d);
+      rc = mfem_jacobi2_by_column(ctx, A, vals_src, V.d);
     } else if (is_cg && ell_bytes) {
       // CG does not scale the matrix: transpose first and read |diag| from the copy (n values instead of all nonzeros)
       rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
@@ -662,7 +665,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       }
     } else {
       rc = mfem_fill(ctx, n, 1.0, V.d);
-      if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
+      if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_src, V.d, 0);
     }
     if (rc) return rc;
     if (is_cg) {
@@ -674,7 +677,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
         rc = mfem_comm_halo(ctx, V.d);                                      // norm comes with them, mfem_jacobi2_by_column)
         if (rc) return rc;
       }
-      rc = mfem_mat_div_jacobi(ctx, A, vals_work, V.d);
+      rc = mfem_mat_div_jacobi_from(ctx, A, vals_src, vals_work, V.d);
       if (rc) return rc;
     }
   }
