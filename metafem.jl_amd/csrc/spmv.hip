@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
-    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part, int parity) {
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
   constexpr int LU = (CAPW / 2 + 63) / 64;  // (16 B + 8 B) loads per lane that cover a full tile
   static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
   // NG = gathers a lane issues up front (rows of up to NG * tpr entries have none left over)
@@ -323,11 +323,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   int32_t* sc = sc_all[w];
   const int tpr = 1 << tpr_log2;
   const int g = lane & (tpr - 1);
-  // row of the tile this lane group walks; parity: even rows of the tile first, then the odd ones -- on an order-2 lattice (hex-27)
-  // neighbouring rows alternate between node types with different stencils while rows two apart share theirs, so the lanes of a
-  // gather instruction then hold the same stencil position of every second row: a few cache lines instead of one run per row
-  int rsel = lane >> tpr_log2;
-  if (parity) rsel = rsel < (R >> 1) ? 2 * rsel : 2 * (rsel - (R >> 1)) + 1;
+  const int rsel = lane >> tpr_log2;  // row of the tile this lane group walks
   double dot_acc = 0.0;
   const int64_t tstride = (int64_t)gridDim.x * WAVES;
   // x as a buffer resource (byte offsets are 32-bit: the host side uses this kernel only while 8 * columns < 4 GiB)
@@ -638,15 +634,16 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
-static int g_spmv_parity = 0;    // bit 28: lane groups take the even rows of a wave tile first, then the odd ones
 static int g_spmv_tile2688 = 1;  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
 static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
 // Kernel variant (bits 16-18 of mfem_debug_set_spmv's first argument):
-//   0 library default
+//   0 library default: 7 where tiles of a fixed row count fill their LDS block, 3 otherwise
 //   1 product tile, CAP 4032, a nonzero PAIR per lane and load (16-byte / 8-byte loads), 8 pairs in flight, 256 threads
-//   (2, 3: as 1; a product tile with ONE nonzero per lane and load -- gathers over 64 consecutive nonzeros -- measured 1.48-1.58 ms
+//   (2: as 1; a product tile with ONE nonzero per lane and load -- gathers over 64 consecutive nonzeros -- measured 1.48-1.58 ms
 //   against 1.19 ms and was removed)
+//   3 wave tiles cut by nonzeros (k_spmv_csr_rb; set before the pattern is created, the row blocks are planned then); the product tile
+//     where they do not apply (split SpMV, unaligned arrays, fewer than 16 entries per row)
 //   4 row-transposing workgroup tile, CAP 4032, 256 threads
 //   6 wave-private row-transposing tiles (1792 / 2048 entries per wave), 2 waves per workgroup   7 (and 5) the same, 1 wave
 static int g_spmv_variant = 0;
@@ -656,7 +653,6 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_tile2688 = ((xcd_aware >> 27) & 1) ? 0 : 1;
-  g_spmv_parity = (xcd_aware >> 28) & 1;
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
@@ -928,7 +924,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
 #define LAUNCH_W(RP, CAPW, WV, NG)                                                                               \
   hipLaunchKernelGGL((k_spmv_csr_w<RP, CAPW, WV, NG>), dim3(gridw), dim3(64 * WV), 0, ctx->stream, A->n, A->nnz, \
                      (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, Rw, tl, ntw, dotw, partials, \
-                     done_flag, part, (g_spmv_parity && Rw >= 2) ? 1 : 0)
+                     done_flag, part)
 #define LAUNCH_WV(RP)                                   \
   do {                                                  \
     if (huge && waves == 2) LAUNCH_W(RP, 2688, 2, 42);  \

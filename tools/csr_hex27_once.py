@@ -3,7 +3,7 @@ import sys, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import metafem_jl_amd as mf
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-if len(sys.argv) > 2:  # mfem_debug_set_spmv knob (variant << 16 | bit 27 no 2688 tile | bit 28 parity order)
+if len(sys.argv) > 2:  # mfem_debug_set_spmv knob (variant << 16: 1 product tile, 3 row blocks, 7 wave tiles of a fixed row count | bit 27 no 2688-entry tile)
     from metafem_jl_amd import _lib
     _lib.lib.mfem_debug_set_spmv(int(sys.argv[2], 0), 0)
 b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 2, 5)
