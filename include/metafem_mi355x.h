@@ -201,7 +201,10 @@ typedef struct {
                                p.Ap, then r.z and r.r).  2: single-reduction form (Chronopoulos-Gear: s = A p carried by
                                recurrence, so r.u, w.u and r.r are reduced together right after the SpMV -- one all-reduce per
                                iteration on several GPUs; same iterates in exact arithmetic, round-off-level differences).
-                               0 = auto: 2 when a communicator with more than one rank is attached, else 1. */
+                               3: the classic recurrence carrying z = M^-1 r instead of r (z -= alpha M^-1 A p; r = M z only inside the
+                               kernel that needs r.z and r.r): the p update then reads neither r nor M^-1 -- 9 vector streams per
+                               iteration instead of 10; same iterates in exact arithmetic, round-off-level differences.
+                               0 = auto: 2 when a communicator with more than one rank is attached, else 3. */
 } mfem_solve_options;
 
 typedef struct {

@@ -112,10 +112,12 @@ struct CgArgs {
   double tol;
   int32_t maxiter;
   int32_t fixed;    // benchmark mode: never converge
+  int32_t zrec;     // the `r` array carries z = r .* dinv (cg_variant 3): k_cg_pupdate then reads neither r nor dinv -- 9 vector
+                    // streams per iteration instead of 10; r.z and r.r come from r = z ./ dinv in k_cg_update
 };
 
 // z = r .* dinv ; p = z ; partials: [0,G) r.z  [G,2G) r.r
-__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init(CgArgs a, const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
+__global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init(CgArgs a, d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
                                                           d2_t* __restrict__ p, double* __restrict__ partials) {
   __shared__ double red[4];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init(CgArgs a, const d2_t* __
     const d2_t rv = r[i];
     const d2_t z = dinv ? rv * dinv[i] : rv;
     p[i] = z;
+    if (a.zrec && dinv) r[i] = z;
     rz += rv.x * z.x + rv.y * z.y;
     rr += rv.x * rv.x + rv.y * rv.y;
   }
@@ -164,9 +167,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
   double rz = 0.0, rr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
     const d2_t av = Ap[i];  // x += alpha p happens in k_cg_pupdate, which reads p anyway (one vector stream less per iteration)
-    const d2_t rv = r[i] - alpha * av;
-    r[i] = rv;
-    const d2_t z = dinv ? rv * dinv[i] : rv;
+    d2_t rv, z;
+    if (a.zrec && dinv) {  // the array holds z: z -= alpha dinv .* Ap ; r = z ./ dinv for the two dot products only
+      const d2_t dv = dinv[i];
+      z = r[i] - alpha * (av * dv);
+      r[i] = z;
+      rv.x = dv.x != 0.0 ? z.x / dv.x : 0.0;  // (the padding behind the last entry has dinv = 0, z = 0)
+      rv.y = dv.y != 0.0 ? z.y / dv.y : 0.0;
+    } else {
+      rv = r[i] - alpha * av;
+      r[i] = rv;
+      z = dinv ? rv * dinv[i] : rv;
+    }
     rz += rv.x * z.x + rv.y * z.y;
     rr += rv.x * rv.x + rv.y * rv.y;
   }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, co
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
       const d2_t rv = r[i], pv = p[i];
       x[i] = x[i] + alpha * pv;
-      const d2_t z = dinv ? rv * dinv[i] : rv;
+      const d2_t z = (dinv && !a.zrec) ? rv * dinv[i] : rv;
       p[i] = z + beta * pv;
     }
   } else {
@@ -245,13 +257,14 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   a.tol = tol;
   a.maxiter = o->maxiter;
   a.fixed = o->fixed_iterations;
+  a.zrec = (o->cg_variant == 3 || (o->cg_variant == 0 && mfem_comm_world(ctx) <= 1)) ? 1 : 0;
   double* part1 = ctx->d_partials;                          // SpMV p.Ap partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;       // 2 x G
   int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
   if (rc) return rc;
   ++*spmv_out;
   const int G = mfem_vec_grid(ctx, nv);
-  hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (const d2_t*)r, (const d2_t*)dinv, (d2_t*)p,
+  hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (d2_t*)r, (const d2_t*)dinv, (d2_t*)p,
                      part2);
   MFEM_CHECK_LAUNCH();
   if (ctx->comm) {
@@ -268,7 +281,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
   key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
-  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
+  key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations); key = mfem_hash(key, a.zrec);
   int it = 0;
   for (;;) {
     if (!o->fixed_iterations || it == 0) {
@@ -452,6 +465,7 @@ static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   a.tol = tol;
   a.maxiter = o->maxiter;
   a.fixed = o->fixed_iterations;
+  a.zrec = 0;
   double* part1 = ctx->d_partials;                      // SpMV w.u partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;   // 2 x G: r.u, r.r
   double* T = S + S_TMP0;
@@ -583,7 +597,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const int64_t n = A->n;
   if (n == 0) return MFEM_OK;
   const int s_param = o->l_or_s > 0 ? o->l_or_s : (o->method == MFEM_SOLVER_IDRS ? 4 : 2);
-  MFEM_REQUIRE(o->cg_variant >= 0 && o->cg_variant <= 2, "cg_variant must be 0 (auto), 1 (classic) or 2 (single reduction)");
+  MFEM_REQUIRE(o->cg_variant >= 0 && o->cg_variant <= 3, "cg_variant must be 0 (auto), 1 (classic), 2 (single reduction) or 3 (classic, preconditioned residual carried)");
   // one reduction group per CG iteration where a reduction costs an all-reduce; the classic recurrence otherwise
   const bool cg_single = o->method == MFEM_SOLVER_CG && (o->cg_variant == 2 || (o->cg_variant == 0 && mfem_comm_world(ctx) > 1));
   MFEM_REQUIRE(s_param <= MFEM_MAX_S, "l_or_s too large");

@@ -412,6 +412,31 @@ def test_symmetric_sweep_is_refused_for_unsymmetric_values(mf):
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
 
 
+@pytest.mark.parametrize("n", [(9, 7, 11), (24, 20, 18)])
+def test_cg_carrying_the_preconditioned_residual_matches_the_classic_recurrence(mf, n):
+    """cg_variant 3 (the one-rank default) carries z = M^-1 r instead of r -- one vector stream less per iteration; same iterates
+    as the classic recurrence up to round-off: iteration counts within one, solutions to 1e-10, with and without the Jacobi
+    preconditioner, on vectors of odd and even length."""
+    import torch
+
+    brick = mf.make_Brick((1.0, 2.0, 1.5), n)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    b = mf.FEM_rand(A.n, 11, 0) - 0.5
+    for pr in (mf.Pr_Jacobi_, mf.Identity):
+        sol = {}
+        for var in (1, 3, 0):
+            x, st = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=mf.cg_, Pr_func=pr, maxiter=3000, max_pass=2, cg_variant=var)
+            assert st.converged == 1
+            sol[var] = (x, st.iterations)
+        assert abs(sol[1][1] - sol[3][1]) <= 1 and sol[0][1] == sol[3][1]
+        assert float((sol[1][0] - sol[3][0]).abs().max()) <= 1e-10 * float(sol[1][0].abs().max())
+        assert torch.equal(sol[0][0], sol[3][0])  # auto = 3 on one rank
+        r = b.clone()
+        mf.mul_(r, A, K, sol[3][0], -1.0, 1.0)
+        assert float(r.norm()) / A.n ** 0.5 <= 2e-11
+
+
 def test_cg_with_symmetric_sweep_matches_plain_kernel(mf):
     """Same CG, SpMVs on the sweep kernel vs the plain kernel: identical iteration count, solutions equal to round-off."""
     import torch
