@@ -112,6 +112,7 @@ struct CgArgs {
   double tol;
   int32_t maxiter;
   int32_t fixed;    // benchmark mode: never converge
+  int64_t n_owned;  // entries in front of the ghost entries / padding (zrec: dinv counts as 0 behind them, whatever the array holds there)
   int32_t zrec;     // the `r` array carries z = r .* dinv (cg_variant 3): k_cg_pupdate then reads neither r nor dinv -- 9 vector
                     // streams per iteration instead of 10; r.z and r.r come from r = z ./ dinv in k_cg_update
 };
@@ -169,10 +170,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
     const d2_t av = Ap[i];  // x += alpha p happens in k_cg_pupdate, which reads p anyway (one vector stream less per iteration)
     d2_t rv, z;
     if (a.zrec && dinv) {  // the array holds z: z -= alpha dinv .* Ap ; r = z ./ dinv for the two dot products only
-      const d2_t dv = dinv[i];
+      d2_t dv = dinv[i];
+      if (2 * i >= a.n_owned) dv.x = 0.0;  // ghost entries (a neighbour's values, its dinv) and padding take no part
+      if (2 * i + 1 >= a.n_owned) dv.y = 0.0;
       z = r[i] - alpha * (av * dv);
       r[i] = z;
-      rv.x = dv.x != 0.0 ? z.x / dv.x : 0.0;  // (the padding behind the last entry has dinv = 0, z = 0)
+      rv.x = dv.x != 0.0 ? z.x / dv.x : 0.0;
       rv.y = dv.y != 0.0 ? z.y / dv.y : 0.0;
     } else {
       rv = r[i] - alpha * av;
@@ -258,6 +261,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   a.maxiter = o->maxiter;
   a.fixed = o->fixed_iterations;
   a.zrec = (o->cg_variant == 3 || (o->cg_variant == 0 && mfem_comm_world(ctx) <= 1)) ? 1 : 0;
+  a.n_owned = V.n;
   double* part1 = ctx->d_partials;                          // SpMV p.Ap partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;       // 2 x G
   int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
@@ -350,7 +354,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
 // The classic recurrence needs p.Ap before it can update r and then (r.z, r.r) before it can update p: two dependent
 // all-reduces per iteration on several GPUs.  Carrying s = A p by recurrence (s = w + beta s with w = A u, u = M^-1 r) makes
 // all three scalars of an iteration -- gamma = r.u, delta = w.u, r.r -- available at the same point, right after the SpMV:
-//     p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = r ./ d      one pass, 11 vector streams
+//     p = u + beta p ; s = w + beta s ; x += alpha p ; u -= alpha s ./ d  (r = u .* d for the dot products only)    one pass, 10 vector streams
 //     w = A u  (+ delta partials)                                                       halo of u overlapped, as above
 //     all-reduce(gamma, r.r, delta) ; beta' = gamma'/gamma ; alpha' = gamma'/(delta' - beta' gamma'/alpha)
 // Same iterates as the classic CG in exact arithmetic (and the same stop rule, evaluated every iteration); in floating point
@@ -437,11 +441,24 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_update(CgArgs a, const d2_t
     p[i] = pv;
     sv[i] = sn;
     x[i] = x[i] + alpha * pv;
-    const d2_t rv = r[i] - alpha * sn;
-    r[i] = rv;
-    const d2_t z = dinv ? rv * dinv[i] : rv;
+    d2_t rv, z;
+    if (a.zrec && dinv) {  // u carries the recurrence (u -= alpha dinv .* s); r = u ./ dinv for the dot products only: r is neither read nor written
+      d2_t dv = dinv[i];
+      if (2 * i >= a.n_owned) dv.x = 0.0;  // ghost entries (u holds the neighbours' values there, dinv may hold theirs) and padding take no part
+      if (2 * i + 1 >= a.n_owned) dv.y = 0.0;
+      z = uv - alpha * (sn * dv);
+      rv.x = dv.x != 0.0 ? z.x / dv.x : 0.0;
+      rv.y = dv.y != 0.0 ? z.y / dv.y : 0.0;
+    } else {
+      rv = r[i] - alpha * sn;
+      r[i] = rv;
+      z = dinv ? rv * dinv[i] : rv;
+    }
     u[i] = z;
-    ru += rv.x * z.x + rv.y * z.y;
+    // ghost entries of u may hold anything (a neighbour's values; NaN while an exchange is in flight in the test transport): their
+    // r is 0 by the mask above, but 0 * NaN is NaN -- keep them out of the sums explicitly
+    if (2 * i < a.n_owned) ru += rv.x * z.x;
+    if (2 * i + 1 < a.n_owned) ru += rv.y * z.y;
     rr += rv.x * rv.x + rv.y * rv.y;
   }
   const double s0 = block_reduce_sum(ru, red);
@@ -465,7 +482,8 @@ static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   a.tol = tol;
   a.maxiter = o->maxiter;
   a.fixed = o->fixed_iterations;
-  a.zrec = 0;
+  a.zrec = 1;  // 10 vector streams in k_cgcg_update instead of 12
+  a.n_owned = V.n;
   double* part1 = ctx->d_partials;                      // SpMV w.u partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;   // 2 x G: r.u, r.r
   double* T = S + S_TMP0;

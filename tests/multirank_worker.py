@@ -160,6 +160,9 @@ def main():
         x1, s1 = lsolve(mf.cg_, cg_variant=1)
         check(f"cg_classic_{tag}", s1.converged == 1 and s1.iterations == sg.iterations and relerr(x1, xg) <= tol_classic,
               iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
+        x3, s3 = lsolve(mf.cg_, cg_variant=3)  # classic recurrence carrying z = M^-1 r (ghost entries masked)
+        check(f"cg_classic_z_carried_{tag}", s3.converged == 1 and abs(s3.iterations - sg.iterations) <= 1 and relerr(x3, xg) <= 1e-10,
+              iters=(s3.iterations, sg.iterations), rel_err=relerr(x3, xg))
         x2, s2 = lsolve(mf.cg_)  # auto: single-reduction form with world > 1
         check(f"cg_single_reduction_{tag}", s2.converged == 1 and abs(s2.iterations - sg.iterations) <= 2 and relerr(x2, xg) <= 1e-10,
               iters=(s2.iterations, sg.iterations), rel_err=relerr(x2, xg))
