@@ -97,7 +97,7 @@ int mfem_read_scalars(mfem_context_s* ctx, int first, int count) {
 }
 
 int mfem_read_flags(mfem_context_s* ctx) {
-  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, ctx->stream));  // two banks of 4 (classic CG alternates)
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return MFEM_OK;
 }
@@ -199,9 +199,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, co
                                                              const double* __restrict__ partials2, int np,
                                                              const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
                                                              d2_t* __restrict__ p, d2_t* __restrict__ x, double* __restrict__ S,
-                                                             int32_t* __restrict__ flags) {
+                                                             const int32_t* __restrict__ flags, int32_t* __restrict__ flags_next) {
   __shared__ double red[4];
-  if (flags[F_DONE]) return;
+  if (flags[F_DONE]) {  // the stop state moves on to the bank the next iteration reads
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags_next[F_DONE] = 1;
+      flags_next[F_ITER] = flags[F_ITER];
+    }
+    return;
+  }
   const double pap = np1 > 0 ? reduce_partials_bcast(pap_partials, np1, red) : S[S_PAP];
   const double alpha = S[S_RZ0 + cur] / pap;
   double rz_new, rr;
@@ -229,19 +235,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, co
   // bookkeeping last: every workgroup has read flags/S before workgroup 0 can change them only if it
   // reads first -- workgroup 0 reads above, writes here; other workgroups read slots this write does
   // not touch (S[RZ0+cur], F_ITER is re-read only by the next kernel).
+  // F_ITER / F_DONE of the NEXT iteration live in the other flag bank (iterations alternate between two banks, like the scalar
+  // slots): no workgroup of this kernel reads what is written here, so a late workgroup still sees the flags its siblings saw --
+  // and no separate 1-thread kernel per iteration is needed for it.
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S[S_RZ0 + (cur ^ 1)] = rz_new;
     S[S_RR] = rr;
+    flags_next[F_ITER] = iter;
+    flags_next[F_DONE] = done ? 1 : 0;
   }
-}
-
-// F_ITER / F_DONE are advanced by a separate 1-thread kernel so that no workgroup of k_cg_pupdate can
-// observe a half-updated state (a late workgroup must still see the flags its siblings saw).
-__global__ void k_cg_advance(CgArgs a, double* __restrict__ S, int32_t* __restrict__ flags) {
-  if (flags[F_DONE]) return;
-  const int iter = flags[F_ITER] + 1;
-  flags[F_ITER] = iter;
-  if ((!a.fixed && sqrt(S[S_RR] * a.n_inv) <= a.tol) || iter >= a.maxiter) flags[F_DONE] = 1;
 }
 
 static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V,
@@ -287,16 +289,19 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations); key = mfem_hash(key, a.zrec);
   int it = 0;
+  // flag banks: iteration `it` reads bank it & 1 (k_cg_init_fin fills bank 0) and leaves the next state in the other one
   for (;;) {
     if (!o->fixed_iterations || it == 0) {
       rc = mfem_read_flags(ctx);
       if (rc) return rc;
-      if (ctx->h_flags[F_DONE]) break;
+      if (ctx->h_flags[4 * (it & 1) + F_DONE]) break;
     }
     const int burst = (o->maxiter - it) < check ? (o->maxiter - it) : check;
     if (burst <= 0) break;
     auto iteration = [&](int it_) -> int {
       const int cur = it_ & 1;
+      int32_t* F = ctx->d_flags + 4 * cur;          // this iteration's bank
+      int32_t* Fn = ctx->d_flags + 4 * (cur ^ 1);   // the next one's
       int np1 = 0;
       // with a communicator: the exchange of p's boundary planes runs beside the rows that need no ghost entry, and every
       // reduction group is one fold kernel + one all-reduce
@@ -321,8 +326,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         np2 = 0;
       }
       hipLaunchKernelGGL(k_cg_pupdate, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, part2, np2, (const d2_t*)r,
-                         (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F);
-      hipLaunchKernelGGL(k_cg_advance, dim3(1), dim3(1), 0, ctx->stream, a, S, F);
+                         (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F, Fn);
       MFEM_CHECK_LAUNCH();
       return MFEM_OK;
     };
@@ -345,7 +349,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   }
   rc = mfem_read_flags(ctx);
   if (rc) return rc;
-  *iters_out = ctx->h_flags[F_ITER];
+  *iters_out = ctx->h_flags[4 * (it & 1) + F_ITER];
   return MFEM_OK;
 }
 
