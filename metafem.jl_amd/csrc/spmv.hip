@@ -868,9 +868,9 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     if (sl != 0) return sl < 0 ? sl : MFEM_OK;
   }
   const int base = A->index_base;
-  // default: wave-private row-transposing tiles when a wave's 64 / tpr rows fill its LDS block reasonably (rows of near-uniform
-  // length: 256^3 hex-8 1.06 ms against 1.19 ms); the product tile otherwise (hex-27's 27..125-entry rows fill half a block:
-  // 3.9 ms against 3.5 ms)
+  // default: wave-private row-transposing tiles of a fixed row count when a wave's 64 / tpr rows fill its LDS block reasonably (rows of
+  // near-uniform length: 256^3 hex-8 1.06 ms against 1.19 ms for the product tile); wave tiles cut by nonzeros otherwise (hex-27's
+  // 27..125-entry rows: 2.6 - 3.0 ms against 3.4 - 3.6)
   int variant = g_spmv_variant;
   if (variant == 0) variant = csr_w_fills(A) ? 7 : 3;
   if (variant == 3 && A->rb_state == 1 && part.part == 0 && ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0) &&
