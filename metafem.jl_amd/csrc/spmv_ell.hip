@@ -283,7 +283,7 @@ struct SympGeom {
 // With pv != nullptr the rows of the swept lattice planes [Gm.p0, Gm.p1) go straight to the patch-major copy of the patch sweep (layout:
 // k_spmv_symp) -- their 27 slots, the edge block entries they own, and the diagonal alone to the slot-major copy (k_ell_diag reads it
 // there) -- instead of through the slot-major copy and a second pass (k_symp_bind): 1.97 + 1.85 ms -> one pass at 256^3.
-template <typename RP>
+template <typename RP, int LPR>  // LPR = lanes per row: 1 (64 rows per wave tile) or 2 (32 rows)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
                                                            int base, const DiaOffsets* __restrict__ Op,
@@ -294,13 +294,19 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
   const int64_t slo = pv ? (int64_t)Gm.p0 * Gm.PL : 0, shi = pv ? (int64_t)Gm.p1 * Gm.PL : 0;  // swept rows
   const int spNP = Gm.NS * Gm.NPk;
   const int64_t spT = (int64_t)spNP * (Gm.p1 - Gm.p0);
+  // LPR = 2: a wave takes 32 rows at a time, two lanes per row -- lanes 0..31 walk their row's entries forward through the first half of
+  // the diagonal list, lanes 32..63 walk them backward through the second half.  A lane per row (64 rows per tile) needs 12 x 64 x K
+  // bytes of staging per wave: two waves per CU on 81-entry rows (4.0 ms per bind at C3 against 3.4 ms with two lanes); on 27-entry
+  // rows six waves per CU are enough and the lane per row is faster (2.4 against 2.7 ms at 256^3).
+  constexpr int RT = 64 / LPR, SH = LPR == 2 ? 5 : 6;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  double* T = lds + (size_t)w * 64 * K;
-  int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * 64 * K) + (size_t)w * 64 * K;
-  const int64_t ntiles = npad >> 6;
+  const int half = LPR == 2 ? lane >> 5 : 0, rl = lane & (RT - 1);
+  double* T = lds + (size_t)w * RT * K;
+  int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * RT * K) + (size_t)w * RT * K;
+  const int64_t ntiles = npad >> SH;
   for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
-    const int64_t r0 = tile << 6, r = r0 + lane;
-    const int64_t rend = (r0 + 64 < n) ? r0 + 64 : n;
+    const int64_t r0 = tile << SH, r = r0 + rl;
+    const int64_t rend = (r0 + RT < n) ? r0 + RT : n;
     int64_t lo = 0;
     int len = 0;
     if (r < n) {
@@ -308,8 +314,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
       len = (int)((int64_t)rowptr[r + 1] - base - lo);
     }
     const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
-    const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= 64 D
-    // staging: all loads of a lane are issued before the first LDS store (cnt <= 64 K: a handful of batches of 8)
+    const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= RT D
+    // staging: all loads of a lane are issued before the first LDS store (cnt <= RT K: a handful of batches of 8)
     for (int i0 = lane; i0 < cnt; i0 += 64 * 8) {
       double tv[8];
       int32_t tc[8];
@@ -331,52 +337,68 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int off0 = (int)(lo - s0);
-    const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> 1]) - 1;
-    if (cls >= 0 && r0 < shi && r0 + 64 > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
+    const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> (7 - SH)]) - 1;
+    const int dir = half ? -1 : 1;
+    if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
-      int line = 0, col = 0;
+      int line = 0, pcol = 0;
       int64_t mainoff = 0, lowoff = 0, edgeoff = 0;
       if (sw) {
         const int p = (int)(r / Gm.PL), rem = (int)(r - (int64_t)p * Gm.PL), jj = rem / Gm.m2, kk = rem - jj * Gm.m2;
         line = jj % SP_L;
-        col = kk % SP_W;
+        pcol = kk % SP_W;
         const int64_t step = (int64_t)(p - Gm.p0) * spNP + (jj / SP_L) * Gm.NPk + kk / SP_W;
-        mainoff = step * SP_MAIN + line * SP_W + col;
-        lowoff = spT * SP_MAIN + step * SP_LOW + line * SP_W + col;
+        mainoff = step * SP_MAIN + line * SP_W + pcol;
+        lowoff = spT * SP_MAIN + step * SP_LOW + line * SP_W + pcol;
         edgeoff = step * SP_MAIN + 14 * SP_ROWS;
       }
-      int j = 0;
+      int j = half ? len - 1 : 0;
 #pragma unroll
-      for (int s = 0; s < 27; ++s) {
+      for (int t = 0; t < (LPR == 2 ? 14 : 27); ++t) {  // forward lanes: slots 0..13 (all 27 with a lane per row), backward lanes: slots 26..14
+        const int sl = half ? 26 - t : t;
+        const bool act = half == 0 || t < 13;
         double v = 0.0;
-        if (j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][s]) {
+        if (act && j >= 0 && j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][sl]) {
           v = T[off0 + j];
-          ++j;
+          j += dir;
         }
+        if (!act) continue;
         if (!sw) {
-          out[ell_base(r, K) + s * ELL_B] = v;
-        } else if (s < 13) {
-          pv[lowoff + s * SP_ROWS] = v;
-          const int e = sp_edge_of(s, line, col);
-          if (e >= 0) pv[edgeoff + e] = v;
+          out[ell_base(r, K) + sl * ELL_B] = v;
         } else {
-          pv[mainoff + (s - 13) * SP_ROWS] = v;
-          if (s == 13) out[ell_base(r, K) + 13 * ELL_B] = v;  // the diagonal (offset 0 is the 14th of the 27 lattice offsets)
+          pv[sl < 13 ? lowoff + sl * SP_ROWS : mainoff + (sl - 13) * SP_ROWS] = v;
+          if (sl == 13) out[ell_base(r, K) + 13 * ELL_B] = v;  // the diagonal (offset 0 is the 14th of the 27 lattice offsets)
+          if (half == 0 && t < 13) {                           // the edge block entry the row owns for this lower slot, if any
+            const int e = sp_edge_of(t, line, pcol);
+            if (e >= 0) pv[edgeoff + e] = v;
+          }
         }
       }
     } else if (cls >= 0) {  // regular 128-row block of class cls: slot s = diagonal s
-      int j = 0;
-      const int D = O.D[cls];
-      for (int s = 0; s < D; ++s) {
-        double v = 0.0;
-        if (j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][s]) {
-          v = T[off0 + j];
-          ++j;
+      const int D = O.D[cls], Dh = LPR == 2 ? (D + 1) >> 1 : D;
+      if (half == 0) {
+        int j = 0;
+        for (int sl = 0; sl < Dh; ++sl) {
+          double v = 0.0;
+          if (j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][sl]) {
+            v = T[off0 + j];
+            ++j;
+          }
+          out[ell_base(r, K) + sl * ELL_B] = v;
         }
-        out[ell_base(r, K) + s * ELL_B] = v;
+      } else {
+        int j = len - 1;
+        for (int sl = D - 1; sl >= Dh; --sl) {
+          double v = 0.0;
+          if (j >= 0 && (int64_t)Tc[off0 + j] - r == O.off[cls][sl]) {
+            v = T[off0 + j];
+            --j;
+          }
+          out[ell_base(r, K) + sl * ELL_B] = v;
+        }
       }
     } else {                 // generic block: slot s = s-th entry, columns come from ell_cols
-      for (int s = 0; s < K; ++s) out[ell_base(r, K) + s * ELL_B] = s < len ? T[off0 + s] : 0.0;
+      for (int sl = half; sl < K; sl += LPR) out[ell_base(r, K) + sl * ELL_B] = sl < len ? T[off0 + sl] : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1351,20 +1373,27 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   if (A->ell_state != 1 || !g_ell_enable || !buf) return MFEM_OK;
   if (A->dia_state == 1 && g_dia_enable) {
     const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
+    // a lane per row while at least two waves of 64-row tiles fit 64 KB of staging (K <= 42: the 27-diagonal lattice); two lanes per row,
+    // 32-row tiles, beyond (the 81 diagonals of three fields)
+    const int lpr = 12 * 64 * (size_t)A->ell_K * 2 > 64 * 1024 ? 2 : 1;
+    const int rt = 64 / lpr;
     int wv = 4;
-    while (wv > 1 && 12 * 64 * (size_t)A->ell_K * wv > 64 * 1024) wv >>= 1;
-    const size_t ldsb = 12 * 64 * (size_t)A->ell_K * wv;  // 8 B value + 4 B column per staged entry (<= 64 K per tile)
-    const int64_t nt = A->ell_npad >> 6;
+    while (wv > 1 && 12 * rt * (size_t)A->ell_K * wv > 64 * 1024) wv >>= 1;
+    const size_t ldsb = 12 * rt * (size_t)A->ell_K * wv;  // 8 B value + 4 B column per staged entry (<= rt K per tile)
+    const int64_t nt = A->ell_npad / rt;
     int g = (int)((nt + wv - 1) / wv);
     if (g > ctx->num_cus * 16) g = ctx->num_cus * 16;
     // the slot-major copy; with the patch sweep wanted (and not the two-pass knob) the swept planes go straight to the patch-major copy
     auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
-      if (A->rowptr_bits == 64)
-        hipLaunchKernelGGL(k_dia_vals<int64_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
-                           (const int64_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals);
-      else
-        hipLaunchKernelGGL(k_dia_vals<int32_t>, dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K,
-                           (const int32_t*)A->rowptr, A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals);
+#define DV_LAUNCH(RP, LPR_)                                                                                                        \
+  hipLaunchKernelGGL((k_dia_vals<RP, LPR_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
+                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals)
+      if (A->rowptr_bits == 64) {
+        if (lpr == 2) DV_LAUNCH(int64_t, 2); else DV_LAUNCH(int64_t, 1);
+      } else {
+        if (lpr == 2) DV_LAUNCH(int32_t, 2); else DV_LAUNCH(int32_t, 1);
+      }
+#undef DV_LAUNCH
       MFEM_CHECK_LAUNCH();
       return MFEM_OK;
     };
