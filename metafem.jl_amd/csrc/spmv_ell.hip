@@ -315,6 +315,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     }
     const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
     const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= RT D
+    const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> (7 - SH)]) - 1;
+    // a tile of a regular block whose rows all have every diagonal of the class (cnt = RT D: away from the mesh boundary, nearly all
+    // tiles): entry s of a row IS its slot s -- the columns are not needed, a third of the kernel's reads
+    const bool full = cls >= 0 && cnt == RT * O.D[cls];
     // staging: all loads of a lane are issued before the first LDS store (cnt <= RT K: a handful of batches of 8)
     for (int i0 = lane; i0 < cnt; i0 += 64 * 8) {
       double tv[8];
@@ -323,21 +327,20 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 64 * u;
         tv[u] = i < cnt ? vals[s0 + i] : 0.0;
-        tc[u] = i < cnt ? col[s0 + i] : 0;
+        tc[u] = (i < cnt && !full) ? col[s0 + i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 64 * u;
         if (i < cnt) {
           T[i] = tv[u];
-          Tc[i] = tc[u] - base;
+          if (!full) Tc[i] = tc[u] - base;
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int off0 = (int)(lo - s0);
-    const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> (7 - SH)]) - 1;
     const int dir = half ? -1 : 1;
     if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         const int sl = half ? 26 - t : t;
         const bool act = half == 0 || t < 13;
         double v = 0.0;
-        if (act && j >= 0 && j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][sl]) {
+        if (act && j >= 0 && j < len && (full || (int64_t)Tc[off0 + j] - r == O.off[cls][sl])) {
           v = T[off0 + j];
           j += dir;
         }
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         int j = 0;
         for (int sl = 0; sl < Dh; ++sl) {
           double v = 0.0;
-          if (j < len && (int64_t)Tc[off0 + j] - r == O.off[cls][sl]) {
+          if (j < len && (full || (int64_t)Tc[off0 + j] - r == O.off[cls][sl])) {
             v = T[off0 + j];
             ++j;
           }
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         int j = len - 1;
         for (int sl = D - 1; sl >= Dh; --sl) {
           double v = 0.0;
-          if (j >= 0 && (int64_t)Tc[off0 + j] - r == O.off[cls][sl]) {
+          if (j >= 0 && (full || (int64_t)Tc[off0 + j] - r == O.off[cls][sl])) {
             v = T[off0 + j];
             --j;
           }
