@@ -157,6 +157,15 @@ def test_c4_hex27_128_symmetry_and_constants(mf):
     mf.mul_(Ax, A, K, x)
     mf.mul_(Az, A, K, z)
     assert abs(mf.dot(z, Ax) - mf.dot(x, Az)) <= 1e-10 * abs(mf.dot(z, Ax))
+    # mul! runs on wave tiles cut by nonzeros here (rows of 27 / 45 / 75 / 125 entries); the product-tile kernel must agree to round-off
+    from metafem_jl_amd import _lib
+    _lib.lib.mfem_debug_set_spmv(1 << 16, 0)
+    try:
+        Ax1 = torch.empty_like(x)
+        mf.mul_(Ax1, A, K, x)
+    finally:
+        _lib.lib.mfem_debug_set_spmv(0, 0)
+    assert float((Ax1 - Ax).abs().max()) <= 1e-13 * float(Ax.abs().max())
     s = torch.full((A.n,), SRC, dtype=torch.float64, device="cuda")
     T = torch.full((A.n,), TENV, dtype=torch.float64, device="cuda")
     R = brick.residual_thermal(T, K_COND, H, TENV, mf.ALL_FACES, s=s)
