@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int64_t ntiles, const int32_t* __restrict__ rs, const double* __restrict__ dotw,
-    double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, int xcd_runs) {
   constexpr int LU = (CAPW / 2 + 63) / 64;
   static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
   __shared__ __attribute__((aligned(16))) double sv[CAPW + 2];
@@ -449,7 +449,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   if (done_flag && done_flag[0]) return;
   const int lane = threadIdx.x;
   double dot_acc = 0.0;
-  const int64_t tstride = gridDim.x;
+  // xcd_runs: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch) and walk one contiguous eighth of the tiles
+  const int64_t tstride = xcd_runs ? gridDim.x >> 3 : gridDim.x;
+  const int64_t t_begin = xcd_runs ? ntiles * (blockIdx.x & 7) / 8 : 0, t_end = xcd_runs ? ntiles * ((blockIdx.x & 7) + 1) / 8 : ntiles;
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0xFFFFFFFF, 0x00020000);
   d2_t pv[LU];
   i2_t pc[LU];
@@ -477,19 +479,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
       pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
     }
   };
-  int64_t t_cur = blockIdx.x;
+  int64_t t_cur = xcd_runs ? t_begin + (blockIdx.x >> 3) : blockIdx.x;
   int32_t r0 = 0, r1 = 0, r0n = 0, r1n = 0;  // rows of the current tile / of the tile after it
   int64_t sa_cur = 0;
-  if (t_cur < ntiles) {
+  if (t_cur < t_end) {
     r0 = uniform32(rs[t_cur]);
     r1 = uniform32(rs[t_cur + 1]);
     request(r0, r1, sa_cur);
   }
-  if (t_cur + tstride < ntiles) {
+  if (t_cur + tstride < t_end) {
     r0n = uniform32(rs[t_cur + tstride]);
     r1n = uniform32(rs[t_cur + tstride + 1]);
   }
-  while (t_cur < ntiles) {
+  while (t_cur < t_end) {
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       const int i = 2 * lane + u * 128;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
           }
           if (!requested) {  // behind the tile's first gathers: the next tile's streams
             requested = true;
-            if (t_next < ntiles) request(r0n, r1n, sa_n);
+            if (t_next < t_end) request(r0n, r1n, sa_n);
           }
 #pragma unroll
           for (int u = 0; u < NG; ++u) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     sa_cur = sa_n;
     r0 = r0n;
     r1 = r1n;
-    if (t_cur + tstride < ntiles) {
+    if (t_cur + tstride < t_end) {
       r0n = uniform32(rs[t_cur + tstride]);
       r1n = uniform32(rs[t_cur + tstride + 1]);
     }
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
+static int g_rb_xcd = 1;  // row-block kernel: an XCD walks a contiguous eighth of the tiles (hex-27 128^3: 2.89 against 3.01 ms with round-robin tiles); bit 26 turns it off
 static int g_spmv_tile2688 = 1;  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
 static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
@@ -653,6 +656,7 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_tile2688 = ((xcd_aware >> 27) & 1) ? 0 : 1;
+  g_rb_xcd = ((xcd_aware >> 26) & 1) ? 0 : 1;
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
@@ -881,10 +885,10 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     if ((int64_t)grid > A->rb_ntiles) grid = (int)A->rb_ntiles;
     if (A->rowptr_bits == 64)
       hipLaunchKernelGGL((k_spmv_csr_rb<int64_t, RB_CAP, RB_NG>), dim3(grid), dim3(64), 0, ctx->stream, A->n, A->nnz, (const int64_t*)A->rowptr,
-                         A->colidx, vals, x, y, alpha, beta, base, A->rb_ntiles, A->rb_rows, dotw, partials, done_flag);
+                         A->colidx, vals, x, y, alpha, beta, base, A->rb_ntiles, A->rb_rows, dotw, partials, done_flag, (g_rb_xcd && (grid & 7) == 0) ? 1 : 0);
     else
       hipLaunchKernelGGL((k_spmv_csr_rb<int32_t, RB_CAP, RB_NG>), dim3(grid), dim3(64), 0, ctx->stream, A->n, A->nnz, (const int32_t*)A->rowptr,
-                         A->colidx, vals, x, y, alpha, beta, base, A->rb_ntiles, A->rb_rows, dotw, partials, done_flag);
+                         A->colidx, vals, x, y, alpha, beta, base, A->rb_ntiles, A->rb_rows, dotw, partials, done_flag, (g_rb_xcd && (grid & 7) == 0) ? 1 : 0);
     MFEM_CHECK_LAUNCH();
     if (n_partials && partials) *n_partials = grid;
     return MFEM_OK;

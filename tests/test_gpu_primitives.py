@@ -38,7 +38,7 @@ def test_spmv_matches_oracle(mf, n, avg, bits, base):
         assert np.max(np.abs(y_t.cpu().numpy() - ref) / scale) < 1e-14
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 2048, 2054])  # + 2048 (bit 27 of the knob): without the 2688-entry wave tile
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 2048, 2054, 1027])  # + 2048 (bit 27 of the knob): without the 2688-entry wave tile; + 1024 (bit 26): row-block tiles round-robin
 @pytest.mark.parametrize("kind", ["hex8", "hex8x3", "hex27", "quad8", "banded_shift"])
 def test_spmv_csr_kernel_variants_equal_oracle(mf, kind, variant):
     """Every tile variant of the CSR kernel behind mul! (mfem_debug_set_spmv: 0 = row-transposing tile kernel (default), 1-3 =
