@@ -677,6 +677,11 @@ static bool csr_w_fills(const mfem_csr_s* A) {
   return tl >= 1 && (int64_t)(128 >> tl) * A->max_row_nnz <= 2688 - 2 && 2.0 * fill * 1792.0 / 2688.0 >= 0.65;  // the 2688-entry tile
 }
 
+// the default kernel: wave tiles of a fixed row count where they fill AND the rows are short (<= 64 entries: hex-8 scalar, 256^3 1.21 ms
+// against 1.30 ms for the row blocks); row blocks for wide rows of uniform length too (three fields, 81 entries: 1.33 against 1.40 ms --
+// with more columns per row the x window of a tile range is what an XCD-contiguous walk keeps in one L2)
+static bool csr_w_default(const mfem_csr_s* A) { return csr_w_fills(A) && A->max_row_nnz <= 64; }
+
 int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   A->serial = mfem_next_csr_serial();  // every creation path (mfem_csr_create, mfem_brick_pattern, mfem_pattern_build) plans once
   int32_t* d_max = ctx->d_flags + 8;
@@ -697,7 +702,7 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
   // rows of uneven length (tiles of a fixed row count would be less than 0.65 full): tiles cut by nonzeros, k_spmv_csr_rb
   A->rb_state = -1;
-  if (A->rows_per_block > 0 && (g_spmv_variant == 3 || !csr_w_fills(A)) && A->max_row_nnz <= RB_CAP / 4 && A->nnz >= 16 * A->n && A->n < ((int64_t)1 << 31) - 1) {
+  if (A->rows_per_block > 0 && (g_spmv_variant == 3 || !csr_w_default(A)) && A->max_row_nnz <= RB_CAP / 4 && A->nnz >= 16 * A->n && A->n < ((int64_t)1 << 31) - 1) {
     const int64_t C = RB_CAP - 2 - A->max_row_nnz, ntiles = (A->nnz + C - 1) / C;
     MFEM_CHECK_HIP(hipMalloc(&A->rb_rows, sizeof(int32_t) * (size_t)(ntiles + 1)));
     const int g = mfem_grid_for(ntiles + 1, MFEM_BLOCK, 4096);
@@ -876,7 +881,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   // near-uniform length: 256^3 hex-8 1.06 ms against 1.19 ms for the product tile); wave tiles cut by nonzeros otherwise (hex-27's
   // 27..125-entry rows: 2.6 - 3.0 ms against 3.4 - 3.6)
   int variant = g_spmv_variant;
-  if (variant == 0) variant = csr_w_fills(A) ? 7 : 3;
+  if (variant == 0) variant = csr_w_default(A) ? 7 : 3;
   if (variant == 3 && A->rb_state == 1 && part.part == 0 && ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0) &&
       (A->ncols > 0 ? A->ncols : A->n) < ((int64_t)1 << 29)) {
     // tiles cut by nonzeros (rows of uneven length); the grid is what is resident
