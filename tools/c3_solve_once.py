@@ -1,11 +1,14 @@
 """One BiCGStab(2) (or IDR(8)) solve of config C3 (hex-8 elasticity 128^3) with a fixed number of iterations: for rocprofv3 --kernel-trace --stats.
-usage: c3_solve_once.py [bicgstabl|idrs] [N] [iterations]"""
+usage: c3_solve_once.py [bicgstabl|idrs] [N] [iterations] [mfem_debug_set_ell knob]"""
 import sys, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import metafem_jl_amd as mf
 which = sys.argv[1] if len(sys.argv) > 1 else "bicgstabl"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 its = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+if len(sys.argv) > 4:
+    from metafem_jl_amd import _lib
+    _lib.lib.mfem_debug_set_ell(1 | int(sys.argv[4], 0))
 brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N))
 A = brick.pattern(3)
 E, nu = 1.0, 0.3
