@@ -122,7 +122,8 @@ int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, co
 /* CSR kernels behind mul!: tiles per XCD run (0 = dispatcher round-robin) | variant << 16 (0 default, 1 product tile, 3 wave tiles cut by
  * nonzeros -- set before the pattern is created --, 4 workgroup-wide transposing tile, 6 / 7 wave tiles of a fixed row count) | bit 27:
  * without the 2688-entry wave tile (rows of 64..83 entries then share 1792-entry tiles 16 at a time) | bit 26: row-block tiles round-robin
- * over the XCDs instead of a contiguous eighth each, persistent workgroups per CU. */
+ * over the XCDs instead of a contiguous eighth each | bit 25: no column-offset inspection of the row-block tiles (before the pattern is
+ * created), persistent workgroups per CU. */
 int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
  * bit 20 XCD-contiguous row chunks; bit 22 symmetric sweep kernels off; bit 23 the workgroup-tile sweep (k_spmv_sym27) instead of

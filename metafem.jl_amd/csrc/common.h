@@ -108,6 +108,7 @@ struct mfem_csr_s {
   // tiles cut by nonzeros for rows of uneven length (spmv.hip: k_spmv_csr_rb): rb_state 1 = planned, -1 = not used
   int rb_state;
   int64_t rb_ntiles;
+  int64_t rb_elided;        // tiles of them whose columns the kernel derives from the tile's first two rows (bit 31 of rb_rows[t])
   int32_t* rb_rows;         // owned, [rb_ntiles + 1]: first row of every tile
   // owned storage (mfem_brick_pattern) -- freed in destroy
   void* owned_rowptr;

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     return (int64_t)(((uint64_t)hi32 << 32) | lo32);
   };
   // request the streams of the tile with rows [r0, r1)
-  auto request = [&](int32_t r0, int32_t r1, int64_t& sa) {
+  auto request = [&](int32_t r0, int32_t r1, int64_t& sa, int el) {
     const int64_t s = uniform64((int64_t)rowptr[r0] - base), e = uniform64((int64_t)rowptr[r1] - base);
     sa = s & ~(int64_t)1;
     const int cnt = (int)(e - sa);
@@ -476,27 +476,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       pv[u] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(vr, lane * 16, u * 1024, 2));
-      pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
+      // a tile whose rows repeat the column offsets of its first two rows (el): only those two rows' columns are read (<= 256 entries)
+      if (!el || u < 2) pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
     }
   };
   int64_t t_cur = xcd_runs ? t_begin + (blockIdx.x >> 3) : blockIdx.x;
   int32_t r0 = 0, r1 = 0, r0n = 0, r1n = 0;  // rows of the current tile / of the tile after it
+  int el = 0, eln = 0;                         // ... and their column-elision flags (bit 31 of rs[t])
   int64_t sa_cur = 0;
   if (t_cur < t_end) {
-    r0 = uniform32(rs[t_cur]);
-    r1 = uniform32(rs[t_cur + 1]);
-    request(r0, r1, sa_cur);
+    const uint32_t w0 = (uint32_t)uniform32(rs[t_cur]);
+    r0 = (int32_t)(w0 & 0x7fffffffu);
+    el = (int)(w0 >> 31);
+    r1 = uniform32(rs[t_cur + 1]) & 0x7fffffff;
+    request(r0, r1, sa_cur, el);
   }
   if (t_cur + tstride < t_end) {
-    r0n = uniform32(rs[t_cur + tstride]);
-    r1n = uniform32(rs[t_cur + tstride + 1]);
+    const uint32_t w0 = (uint32_t)uniform32(rs[t_cur + tstride]);
+    r0n = (int32_t)(w0 & 0x7fffffffu);
+    eln = (int)(w0 >> 31);
+    r1n = uniform32(rs[t_cur + tstride + 1]) & 0x7fffffff;
   }
   while (t_cur < t_end) {
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       const int i = 2 * lane + u * 128;
       *reinterpret_cast<d2_t*>(&sv[i]) = pv[u];
-      *reinterpret_cast<i2_t*>(&sc[i]) = pc[u];
+      if (!el || u < 2) *reinterpret_cast<i2_t*>(&sc[i]) = pc[u];
     }
     srp[lane] = prp[0];
     srp[64 + lane] = prp[1];
@@ -527,6 +533,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
             hi = (int)((int64_t)rowptr[(int64_t)r0 + ri + 1] - base - sa_cur);
           }
         }
+        const int cb = el ? srp[c] : 0, dcol = 2 * (b0 + slot);
         double sum = 0.0;
         int j = lo + g;
         do {
@@ -535,11 +542,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
           for (int u = 0; u < NG; ++u) {
             const int jj = j + u * tpr;
             xx[u] = 0.0;
-            if (jj < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, (sc[jj] - base) * 8, 0, 0));
+            // el: the column of entry e of row c + 2 m is that of entry e of row c (the first row of the parity class), + 2 m
+            if (jj < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, ((el ? sc[cb + (jj - lo)] + dcol : sc[jj]) - base) * 8, 0, 0));
           }
           if (!requested) {  // behind the tile's first gathers: the next tile's streams
             requested = true;
-            if (t_next < t_end) request(r0n, r1n, sa_n);
+            if (t_next < t_end) request(r0n, r1n, sa_n, eln);
           }
 #pragma unroll
           for (int u = 0; u < NG; ++u) {
@@ -570,9 +578,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     sa_cur = sa_n;
     r0 = r0n;
     r1 = r1n;
+    el = eln;
     if (t_cur + tstride < t_end) {
-      r0n = uniform32(rs[t_cur + tstride]);
-      r1n = uniform32(rs[t_cur + tstride + 1]);
+      const uint32_t w0 = (uint32_t)uniform32(rs[t_cur + tstride]);
+      r0n = (int32_t)(w0 & 0x7fffffffu);
+      eln = (int)(w0 >> 31);
+      r1n = uniform32(rs[t_cur + tstride + 1]) & 0x7fffffff;
     }
   }
   if (partials) {
@@ -598,6 +609,43 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_csr_rowblocks(int64_t n, const R
       else lo = mid + 1;
     }
     rs[t] = (int32_t)lo;
+  }
+}
+
+// Column elision: tile t is marked (bit 31 of rs[t]) when its rows of equal parity all repeat the column OFFSETS (col - row) of the
+// tile's first row of that parity -- interior rows of a lattice stencil do; rows next to the mesh boundary, or a tile that straddles two
+// lattice lines of different node types, do not.  The SpMV then reads the columns of the tile's first two rows only.  One wave per tile,
+// a lane per row; the pattern is read once when it is created.
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_csr_rb_elide(int64_t ntiles, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, int base,
+                                                              int32_t* __restrict__ rs, int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int32_t r0 = rs[t] & 0x7fffffff, r1 = rs[t + 1] & 0x7fffffff;
+    const int nr = r1 - r0;
+    bool ok = nr >= 1 && nr <= 64;  // (wave-uniform)
+    int64_t lo = 0;
+    int len = 0;
+    if (ok && lane < nr) {
+      lo = (int64_t)rowptr[r0 + lane] - base;
+      len = (int)((int64_t)rowptr[r0 + lane + 1] - base - lo);
+    }
+    const int c = lane & 1;
+    const int64_t lob = __shfl(lo, c, 64);
+    const int lenb = __shfl(len, c, 64);
+    const int len0 = __shfl(len, 0, 64), len1 = __shfl(len, 1, 64);
+    bool match = true;
+    if (ok && lane < nr) {
+      match = len == lenb;
+      const int d = lane - c;
+      for (int e = 0; match && e < len; ++e) match = col[lo + e] - col[lob + e] == d;
+    }
+    ok = ok && len0 + len1 <= 254 && __all(match);
+    if (ok && lane == 0) {
+      rs[t] = (int32_t)((uint32_t)r0 | 0x80000000u);
+      atomicAdd(count, 1);
+    }
   }
 }
 
@@ -636,6 +684,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
 static int g_spmv_xcd_aware = 0;
+static int g_rb_elide = 1;  // row-block kernel: tiles whose rows repeat the column offsets of their first two rows read only those columns; bit 25 turns the inspection off (set before the pattern is created)
 static int g_rb_xcd = 1;  // row-block kernel: an XCD walks a contiguous eighth of the tiles (hex-27 128^3: 2.89 against 3.01 ms with round-robin tiles); bit 26 turns it off
 static int g_spmv_tile2688 = 1;  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
 static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
@@ -657,6 +706,7 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   g_spmv_variant = (xcd_aware >> 16) & 7;
   g_spmv_tile2688 = ((xcd_aware >> 27) & 1) ? 0 : 1;
   g_rb_xcd = ((xcd_aware >> 26) & 1) ? 0 : 1;
+  g_rb_elide = ((xcd_aware >> 25) & 1) ? 0 : 1;
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
@@ -715,6 +765,22 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
     MFEM_CHECK_LAUNCH();
     A->rb_ntiles = ntiles;
     A->rb_state = 1;
+    A->rb_elided = 0;
+    if (g_rb_elide) {
+      int32_t* d_cnt = ctx->d_flags + 8;
+      MFEM_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+      const int ge = mfem_grid_for(ntiles * 64, MFEM_BLOCK, ctx->num_cus * 16);
+      if (A->rowptr_bits == 64)
+        hipLaunchKernelGGL(k_csr_rb_elide<int64_t>, dim3(ge), dim3(MFEM_BLOCK), 0, ctx->stream, ntiles, (const int64_t*)A->rowptr, A->colidx,
+                           A->index_base, A->rb_rows, d_cnt);
+      else
+        hipLaunchKernelGGL(k_csr_rb_elide<int32_t>, dim3(ge), dim3(MFEM_BLOCK), 0, ctx->stream, ntiles, (const int32_t*)A->rowptr, A->colidx,
+                           A->index_base, A->rb_rows, d_cnt);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 8, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      A->rb_elided = ctx->h_flags[8];
+    }
   }
   return MFEM_OK;
 }

@@ -144,6 +144,51 @@ def test_spmv_row_block_kernel_on_ragged_rows(mf, bits, base):
     assert np.max(np.abs(y.cpu().numpy() - (2.0 * ref - 3.0)) / (2 * scale + 3.0)) < 1e-14
 
 
+def test_spmv_row_block_kernel_column_elision(mf):
+    """Tiles whose rows of equal parity repeat the column offsets of the tile's first two rows read only those two rows' columns
+    (inspected once per pattern).  Alternating stencils as on an order-2 lattice line, clipped at both ends, with single rows whose
+    offsets deviate in the middle of otherwise regular stretches: the result equals the oracle's and is bitwise the one computed with the
+    inspection switched off."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import solvers
+
+    rng = np.random.default_rng(3)
+    n = 40000
+    even = np.array([-700, -699, -350, -2, -1, 0, 1, 2, 350, 699, 700] + list(range(-40, -10)) + list(range(10, 40)))
+    odd = np.array([-350, -1, 0, 1, 350] + list(range(-25, -5)) + list(range(5, 25)))
+    rows, cols = [], []
+    odd_one_out = set(rng.choice(np.arange(2000, n - 2000), size=40, replace=False).tolist())
+    for r in range(n):
+        off = np.sort(even if r % 2 == 0 else odd)
+        if r in odd_one_out:
+            off = np.sort(np.concatenate([off[off != 1], [3]]))  # same length, one offset moved
+        c = r + off
+        c = c[(c >= 0) & (c < n)]
+        rows.append(len(c))
+        cols.append(c)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(rows)
+    cols = np.concatenate(cols).astype(np.int32)
+    assert rowptr[-1] >= 16 * n
+    vals = rng.standard_normal(rowptr[-1])
+    x = rng.standard_normal(n)
+    ref = solvers.csr(rowptr, cols, vals, n) @ x
+    scale = np.abs(solvers.csr(rowptr, cols, np.abs(vals), n) @ np.abs(x)) + 1e-300
+    ys = []
+    try:
+        for knob in (3 << 16, (3 << 16) | (1 << 25)):  # row blocks with / without the column inspection (set before the pattern exists)
+            _lib.lib.mfem_debug_set_spmv(knob, 0)
+            A = mf.FEM_SpMat_CSR(torch.tensor(rowptr, device="cuda"), torch.tensor(cols, device="cuda"), n)
+            y = torch.zeros(n, dtype=torch.float64, device="cuda")
+            mf.mul_(y, A, torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda"))
+            ys.append(y)
+    finally:
+        _lib.lib.mfem_debug_set_spmv(0, 0)
+    assert np.max(np.abs(ys[0].cpu().numpy() - ref) / scale) < 1e-14
+    assert torch.equal(ys[0], ys[1])
+
+
 def test_spmv_unaligned_values_pointer(mf):
     """A values array that is not 16-byte aligned must take the scalar path, not fault."""
     import torch
