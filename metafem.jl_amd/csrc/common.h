@@ -110,6 +110,8 @@ struct mfem_csr_s {
   int64_t rb_ntiles;
   int64_t rb_elided;        // tiles of them whose columns the kernel derives from the tile's first two rows (bit 31 of rb_rows[t])
   int32_t* rb_rows;         // owned, [rb_ntiles + 1]: first row of every tile
+  uint8_t* cw_elide;        // owned: one flag per tile of cw_R rows of the fixed-row-count wave-tile kernel (k_spmv_csr_w): columns derivable from the tile's first row
+  int cw_R;
   // owned storage (mfem_brick_pattern) -- freed in destroy
   void* owned_rowptr;
   void* owned_colidx;

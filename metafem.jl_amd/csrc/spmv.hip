@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
-    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part) {
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part, const uint8_t* __restrict__ elide) {
   constexpr int LU = (CAPW / 2 + 63) / 64;  // (16 B + 8 B) loads per lane that cover a full tile
   static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
   // NG = gathers a lane issues up front (rows of up to NG * tpr entries have none left over)
@@ -345,11 +345,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
     return (int64_t)(((uint64_t)hi32 << 32) | lo32);
   };
-  auto request = [&](int64_t t, int64_t& sa, int& cnt, int& lo, int& hi) {  // issue the loads of tile t into pv / pc
+  // elide[t] != 0: every row of tile t repeats the column offsets of the tile's first row (inspected once per pattern, k_csr_w_elide): only
+  // that row's columns are read (the first 128 staged entries hold them)
+  auto request = [&](int64_t t, int64_t& sa, int& cnt, int& lo, int& hi, int& el) {  // issue the loads of tile t into pv / pc
     const int64_t r0 = t * R, r1 = (r0 + R < n) ? r0 + R : n;
     const int64_t s = uniform64((int64_t)rowptr[r0] - base), e = uniform64((int64_t)rowptr[r1] - base);
     sa = s & ~(int64_t)1;
     cnt = (int)(e - sa);
+    el = elide ? __builtin_amdgcn_readfirstlane((int)elide[t]) : 0;
     const int64_t r = r0 + rsel;
     lo = hi = 0;
     if (r < r1) {
@@ -363,17 +366,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       pv[u] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(vr, lane * 16, u * 1024, 2));
-      pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
+      if (!el || u == 0) pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
     }
   };
-  if (t_cur < ntiles) request(t_cur, sa_cur, cnt_cur, lo_cur, hi_cur);
+  int el_cur = 0;
+  if (t_cur < ntiles) request(t_cur, sa_cur, cnt_cur, lo_cur, hi_cur, el_cur);
   while (t_cur < ntiles) {
     // ---- the requested tile goes to the wave's LDS block
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       const int i = 2 * lane + u * 128;  // < CAPW: entries past the tile's end are zeros nobody reads
       *reinterpret_cast<d2_t*>(&sv[i]) = pv[u];
-      *reinterpret_cast<i2_t*>(&sc[i]) = pc[u];
+      if (!el_cur || u == 0) *reinterpret_cast<i2_t*>(&sc[i]) = pc[u];
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS stores have landed
@@ -381,6 +385,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     const int64_t r0 = t_cur * R, r1 = (r0 + R < n) ? r0 + R : n;
     const int64_t r = r0 + rsel;
     const int lo = lo_cur, hi = hi_cur;
+    const int el = el_cur, lo0 = __builtin_amdgcn_readfirstlane(lo_cur);  // (lane 0 walks the tile's first row)
+    // the column of entry j: staged, or -- el -- that of the same entry of the tile's first row, + the row's distance from it
+    auto colof = [&](int j) -> int { return el ? sc[lo0 + (j - lo)] + rsel : sc[j]; };
     // ---- all gathers of the lane's row first ...
     double xx[NG];
     const int j0 = lo + g;
@@ -389,22 +396,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
       const int j = j0 + u * tpr;
       xx[u] = 0.0;
       // buffer form of the load: one 32-bit offset register per gather instead of a 64-bit address pair (28 gathers in flight)
-      if (j < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, (sc[j] - base) * 8, 0, 0));
+      if (j < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, (colof(j) - base) * 8, 0, 0));
     }
     // ---- ... then the request for the next tile: it returns behind the gathers (loads return in order), so the row sums
     //      below do not wait for it, and it is in flight while they run
     const int64_t t_next = next_tile(t_cur + tstride);
     int64_t sa_n = 0;
-    int cnt_n = 0, lo_n = 0, hi_n = 0;
+    int cnt_n = 0, lo_n = 0, hi_n = 0, el_n = 0;
     // (the LDS block is still being read below: the next tile stays in registers until the top of the loop)
-    if (t_next < ntiles) request(t_next, sa_n, cnt_n, lo_n, hi_n);
+    if (t_next < ntiles) request(t_next, sa_n, cnt_n, lo_n, hi_n, el_n);
     double sum = 0.0;
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       const int j = j0 + u * tpr;
       sum += (j < hi ? sv[j] : 0.0) * xx[u];
     }
-    for (int j = j0 + NG * tpr; j < hi; j += tpr) sum += sv[j] * x[sc[j] - base];  // rows longer than NG * tpr entries
+    for (int j = j0 + NG * tpr; j < hi; j += tpr) sum += sv[j] * x[colof(j) - base];  // rows longer than NG * tpr entries
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
     if (g == 0 && r < r1) {
       double yv = alpha * sum;
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     cnt_cur = cnt_n;
     lo_cur = lo_n;
     hi_cur = hi_n;
+    el_cur = el_n;
   }
   if (partials) {
     const double b = block_reduce_sum(dot_acc, red);
@@ -649,6 +657,34 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_csr_rb_elide(int64_t ntiles, con
   }
 }
 
+// The same inspection for the tiles of a fixed row count (k_spmv_csr_w): flag[t] = 1 when every row of tile t repeats the column offsets
+// of the tile's first row (one stencil for all rows: hex-8 operators away from the lattice line ends).
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_csr_w_elide(int64_t n, int R, int64_t ntiles, const RP* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, int base, uint8_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t r0 = t * R, r1 = (r0 + R < n) ? r0 + R : n;
+    const int nr = (int)(r1 - r0);  // <= 64
+    int64_t lo = 0;
+    int len = 0;
+    if (lane < nr) {
+      lo = (int64_t)rowptr[r0 + lane] - base;
+      len = (int)((int64_t)rowptr[r0 + lane + 1] - base - lo);
+    }
+    const int64_t lo0 = __shfl(lo, 0, 64);
+    const int len0 = __shfl(len, 0, 64);
+    bool match = true;
+    if (lane < nr) {
+      match = len == len0;
+      for (int e = 0; match && e < len; ++e) match = col[lo + e] - col[lo0 + e] == lane;
+    }
+    const bool ok = len0 >= 1 && len0 <= 126 && __all(match);
+    if (lane == 0) flag[t] = ok ? 1 : 0;
+  }
+}
+
 // Fallback for patterns whose longest row does not fit the LDS tile: one wave per row.
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
@@ -782,6 +818,28 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
       A->rb_elided = ctx->h_flags[8];
     }
   }
+  // tiles of a fixed row count (the default for short rows of uniform length): the same inspection, one flag per tile of Rw rows
+  A->cw_R = 0;
+  if (g_rb_elide && A->rows_per_block > 0 && csr_w_default(A)) {
+    auto tpr_for = [&](int capw) {
+      int tl = 0;
+      while (tl < 6 && (int64_t)(64 >> tl) * A->max_row_nnz > capw - 2) ++tl;
+      return tl;
+    };
+    const bool big = tpr_for(2048) < tpr_for(1792);
+    const int Rw = 64 >> (big ? tpr_for(2048) : tpr_for(1792));  // (rows of up to 64 entries never take the 2688-entry tile)
+    const int64_t ntw = (A->n + Rw - 1) / Rw;
+    MFEM_CHECK_HIP(hipMalloc(&A->cw_elide, (size_t)ntw));
+    const int ge = mfem_grid_for(ntw * 64, MFEM_BLOCK, ctx->num_cus * 16);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_csr_w_elide<int64_t>, dim3(ge), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, Rw, ntw, (const int64_t*)A->rowptr, A->colidx,
+                         A->index_base, A->cw_elide);
+    else
+      hipLaunchKernelGGL(k_csr_w_elide<int32_t>, dim3(ge), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, Rw, ntw, (const int32_t*)A->rowptr, A->colidx,
+                         A->index_base, A->cw_elide);
+    MFEM_CHECK_LAUNCH();
+    A->cw_R = Rw;
+  }
   return MFEM_OK;
 }
 
@@ -818,6 +876,7 @@ extern "C" int mfem_csr_destroy(mfem_csr A) {
   mfem_ell_free(A);
   mfem_sell_free(A);
   if (A->rb_rows) hipFree(A->rb_rows);
+  if (A->cw_elide) hipFree(A->cw_elide);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);
   if (A->owned_colidx) hipFree(A->owned_colidx);
   delete A;
@@ -999,7 +1058,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
 #define LAUNCH_W(RP, CAPW, WV, NG)                                                                               \
   hipLaunchKernelGGL((k_spmv_csr_w<RP, CAPW, WV, NG>), dim3(gridw), dim3(64 * WV), 0, ctx->stream, A->n, A->nnz, \
                      (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, Rw, tl, ntw, dotw, partials, \
-                     done_flag, part)
+                     done_flag, part, (A->cw_elide && A->cw_R == Rw) ? A->cw_elide : nullptr)
 #define LAUNCH_WV(RP)                                   \
   do {                                                  \
     if (huge && waves == 2) LAUNCH_W(RP, 2688, 2, 42);  \

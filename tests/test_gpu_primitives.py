@@ -189,6 +189,46 @@ def test_spmv_row_block_kernel_column_elision(mf):
     assert torch.equal(ys[0], ys[1])
 
 
+def test_spmv_wave_tile_kernel_column_elision(mf):
+    """The same for the tiles of a fixed row count (rows of one 27-entry stencil, as of the hex-8 scalar operator): a tile whose 64 rows
+    all repeat the offsets of its first row reads that row's columns only; clipped ends and rows with a moved offset keep their tiles on
+    the full column stream."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import solvers
+
+    rng = np.random.default_rng(4)
+    n = 30000
+    sten = np.sort(np.array([a * 900 + b * 30 + c for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]))
+    moved = set(rng.choice(np.arange(1000, n - 1000), size=25, replace=False).tolist())
+    cols, lens = [], []
+    for r in range(n):
+        off = sten if r not in moved else np.sort(np.concatenate([sten[sten != 31], [33]]))
+        c = r + off
+        c = c[(c >= 0) & (c < n)]
+        cols.append(c)
+        lens.append(len(c))
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    cols = np.concatenate(cols).astype(np.int32)
+    vals = rng.standard_normal(rowptr[-1])
+    x = rng.standard_normal(n)
+    ref = solvers.csr(rowptr, cols, vals, n) @ x
+    scale = np.abs(solvers.csr(rowptr, cols, np.abs(vals), n) @ np.abs(x)) + 1e-300
+    ys = []
+    try:
+        for knob in (0, 1 << 25):  # default kernel for these rows = wave tiles of 64 rows; with / without the column inspection
+            _lib.lib.mfem_debug_set_spmv(knob, 0)
+            A = mf.FEM_SpMat_CSR(torch.tensor(rowptr + 1, dtype=torch.int32, device="cuda"), torch.tensor(cols + 1, device="cuda"), n, index_base=1)
+            y = torch.full((n,), 2.0, dtype=torch.float64, device="cuda")
+            mf.mul_(y, A, torch.tensor(vals, device="cuda"), torch.tensor(x, device="cuda"), -1.5, 0.5)
+            ys.append(y)
+    finally:
+        _lib.lib.mfem_debug_set_spmv(0, 0)
+    assert np.max(np.abs(ys[0].cpu().numpy() - (-1.5 * ref + 1.0)) / (1.5 * scale + 1.0)) < 1e-14
+    assert torch.equal(ys[0], ys[1])
+
+
 def test_spmv_unaligned_values_pointer(mf):
     """A values array that is not 16-byte aligned must take the scalar path, not fault."""
     import torch
