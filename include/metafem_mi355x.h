@@ -59,7 +59,9 @@ int mfem_context_sync(mfem_context ctx);
 
 /* ---- S1 primitives: the CUSPARSE/CUBLAS call sites of the Krylov loop -------------------- */
 /* CSR pattern (replaces FEM_SpMat_CSR(K_J_ptr, K_J, ...), misc/04_GPU_Utils.jl:120).  The
- * arrays are borrowed, not copied: they must outlive the handle.  rowptr_bits = 32 | 64. */
+ * arrays are borrowed, not copied: they must outlive the handle AND keep their contents -- the handle caches what it learnt from them
+ * when it was created (longest row, row blocks, which tiles of rows repeat one column-offset list; later the solver layouts), like the
+ * reference's K_J_ptr / K_J, which are written once by assemble_SparseID!.  A changed pattern needs a new handle.  rowptr_bits = 32 | 64. */
 int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
                     const int32_t* colidx, int index_base, mfem_csr* out);
 int mfem_csr_destroy(mfem_csr A);
