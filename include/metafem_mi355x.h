@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MFEM_ABI_VERSION 3
+#define MFEM_ABI_VERSION 4
 
 typedef enum {
   MFEM_OK = 0,
@@ -65,6 +65,11 @@ int mfem_context_sync(mfem_context ctx);
 int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
                     const int32_t* colidx, int index_base, mfem_csr* out);
 int mfem_csr_destroy(mfem_csr A);
+/* Re-run the inspection after the borrowed rowptr / colidx were rewritten IN PLACE (same n, nnz, addresses): drops everything the
+ * handle cached (row blocks, column-offset flags, solver layouts, cached solver graphs) and plans again.  The stream must have
+ * finished producing the arrays (the call synchronises the context stream).  assemble_SparseID! writes K_J_ptr / K_J once per mesh
+ * (03_GlobalAssembly.jl:77-140), so a reference-style host never needs it; it exists so that a stale cache cannot be the only option. */
+int mfem_csr_replan(mfem_context ctx, mfem_csr A);
 /* y = alpha*A*x + beta*y : mul!(b, A, x, alpha, beta), misc/04_GPU_Utils.jl:131 (CUSPARSE mv! 'N'). */
 int mfem_spmv_csr(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y,
                   double alpha, double beta);
@@ -107,62 +112,18 @@ int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t*
  * 257-point lines on.  entries = 8-byte matrix values one SpMV of the planned layout reads from memory, bytes (may be NULL) = all
  * bytes the planned kernel reads and writes per SpMV by design: those entries, 4-byte columns of rows in generic blocks, x as
  * often as the kernel stages / gathers it from memory by design (form 2: the patch neighbourhoods overlap, 1.6 n entries), y.
- * symmetric_sweep = 0 / 1 / 2 (assuming the values pass the check).  mfem_debug_sym_spmv_count: launches of those kernels so far. */
+ * symmetric_sweep = 0 / 1 / 2 (assuming the values pass the check). */
 int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep);
 int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes);
-int64_t mfem_debug_sym_spmv_count(void);
+/* The same accounting for the CSR kernel behind mul! (mfem_spmv_csr: the caller's arrays, no copy): bytes one launch moves BY DESIGN =
+ * nnz * 8 (values) + 4 * column_entries_read + n * 16 (x once, y once) + the row pointers + the tile table.  column_entries_read
+ * (may be NULL) < nnz where the inspection found tiles whose rows repeat the column offsets of their first row(s): the kernel reads
+ * only those rows' columns there.  SURVEY 8(d)'s CSR formula (nnz * 12 + n * 16 + row pointers) is what a kernel without that
+ * inspection moves; bench.py reports both. */
+int mfem_csr_spmv_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes, int64_t* column_entries_read);
 /* y = alpha A x + beta y through that layout, conversion of `vals` included (diagnostic: what the Krylov loop computes). */
 int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
                             double beta);
-
-/* ---- tuning / diagnostic hooks (benchmarks, profiling and tests only) ------------------------------------------------
- * NOT part of the drop-in surface.  Every mfem_debug_set_* knob is PROCESS-WIDE state read at launch time: set it only while no
- * call is in flight on any context of the process (the "one context per host thread" rule above covers the seams, not these
- * knobs).  Each call bumps an epoch that is part of the cycle-graph cache key, so cached graphs never outlive a knob change.
- * None of them changes results beyond round-off; kernel variants that compute WRONG results for timing purposes live in tools/,
- * not in this library. */
-/* CSR kernels behind mul!: tiles per XCD run (0 = dispatcher round-robin) | variant << 16 (0 default, 1 product tile, 3 wave tiles cut by
- * nonzeros -- set before the pattern is created --, 4 workgroup-wide transposing tile, 6 / 7 wave tiles of a fixed row count) | bit 27:
- * without the 2688-entry wave tile (rows of 64..83 entries then share 1792-entry tiles 16 at a time) | bit 26: row-block tiles round-robin
- * over the XCDs instead of a contiguous eighth each | bit 25: no column-offset inspection of the row-block tiles (before the pattern is
- * created), persistent workgroups per CU. */
-int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
-/* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
- * bit 20 XCD-contiguous row chunks; bit 22 symmetric sweep kernels off; bit 23 the workgroup-tile sweep (k_spmv_sym27) instead of
- * the wave-private patch sweep (k_spmv_symp);
- * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128); bit 26 rows outside the swept planes
- * in a launch of their own; bit 27 the patch-major copy made from the slot-major copy in a second pass. */
-int mfem_debug_set_ell(int enable);
-/* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
- * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
-int mfem_debug_set_sell(int enable);
-/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
- * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
-int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);
-/* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
- * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
- * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */
-int mfem_debug_set_graphs(int on, int64_t max_n);
-/* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
-int mfem_debug_set_vec_grid(int workgroups_per_cu);
-/* Multi-rank SpMV: 1 (default) the halo exchange runs on a second stream beside the rows that read no ghost column and the
- * boundary rows follow in a second launch; 0 the exchange completes before a single launch (same results bitwise). */
-int mfem_debug_set_halo_overlap(int on);
-/* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
- * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
- * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
- * 16 GiB scratch budget). */
-int mfem_debug_set_hex27(int two_pass);
-/* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
- * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
-int mfem_debug_set_elasticity(int variant);
-/* hex-8 thermal matrix / residual kernels: 0 (default) the plane-sweep kernels with sum-factorised element integration
- * (2- and 3-point Gauss rules; other rules always use the tile kernels); 1 the 4 x 4 x 8 tile kernels with the table form. */
-int mfem_debug_set_hex8_thermal(int variant);
-/* Per-launch timing of the solver's SpMV kernel with hip events on the context stream (bench.py's roofline).
- * read: total device ms and launch count since the last reset. */
-int mfem_prof_spmv_enable(mfem_context ctx, int on);
-int mfem_prof_spmv_read(mfem_context ctx, double* total_ms /* [host] */, int64_t* launches /* [host] */, int reset);
 
 /* ---- S1: the linear solver seam  fem_domain.linear_solver(globalfield) -------------------- */
 typedef enum {
@@ -425,7 +386,9 @@ int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, int32_t itg,
                                      const int32_t* adj, const uint16_t* ranks, double* K_val);
 /* ranks [nel * itp * itp] (device, once per pattern): for adjacency entry j = (node i <- element el, local a) and local node
  * b, the position of node(el, b) among the control points coupled to i -- the column offset inside every field segment of a
- * row of node i (the role the reference's sparse_IDs_by_el plays for its scatter, read unit-stride by the row-owner pass). */
+ * row of node i (the role the reference's sparse_IDs_by_el plays for its scatter, read unit-stride by the row-owner pass).
+ * MFEM_ERR_UNSUPPORTED when an element lists one control point twice (collapsed elements): the row-owner pass assumes distinct
+ * positions per element; use mfem_mesh_assemble_elements there. */
 int mfem_mesh_row_ranks(mfem_context ctx, int32_t itp, int64_t nel, int64_t ncp, int32_t n_fields, mfem_csr A,
                         const int64_t* adj_ptr, const int32_t* adj, const int32_t* controlpoint_IDs, int32_t index_base,
                         uint16_t* ranks);

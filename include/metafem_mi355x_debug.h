@@ -1,0 +1,77 @@
+/*
+ * metafem_mi355x_debug.h -- tuning / diagnostic hooks of libmetafem_mi355x.so.
+ *
+ * NOT part of the drop-in surface (that is include/metafem_mi355x.h, which a MetaFEM.jl maintainer binds): nothing here
+ * replaces a reference interface.  These are the knobs and probes the benchmarks (bench.py), the profiling scripts (tools/)
+ * and the parity tests use to select kernel variants and to time the solver's SpMV.
+ *
+ * Every mfem_debug_set_* knob is PROCESS-WIDE state read at launch time: set it only while no call is in flight on any
+ * context of the process (the "one context per host thread" rule of the main header covers the seams, not these knobs).
+ * Each call bumps an epoch that is part of the cycle-graph cache key, so cached graphs never outlive a knob change.
+ * None of them changes results beyond round-off; kernel variants that compute WRONG results for timing purposes live in
+ * tools/, not in this library.
+ */
+#ifndef METAFEM_MI355X_DEBUG_H
+#define METAFEM_MI355X_DEBUG_H
+
+#include "metafem_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* launches of the symmetric-sweep SpMV kernels (mfem_csr_solver_layout_entries) so far, process-wide */
+int64_t mfem_debug_sym_spmv_count(void);
+/* CSR kernels behind mul!: tiles per XCD run (0 = dispatcher round-robin) | variant << 16 (0 default, 1 product tile, 3 wave tiles cut by
+ * nonzeros -- set before the pattern is created --, 4 workgroup-wide transposing tile, 6 / 7 wave tiles of a fixed row count) | bit 27:
+ * without the 2688-entry wave tile (rows of 64..83 entries then share 1792-entry tiles 16 at a time) | bit 26: row-block tiles round-robin
+ * over the XCDs instead of a contiguous eighth each | bit 25: no column-offset inspection of the row-block tiles (before the pattern is
+ * created), persistent workgroups per CU. */
+int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
+/* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
+ * bit 20 XCD-contiguous row chunks; bit 22 symmetric sweep kernels off; bit 23 the workgroup-tile sweep (k_spmv_sym27) instead of
+ * the wave-private patch sweep (k_spmv_symp);
+ * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128); bit 26 rows outside the swept planes
+ * in a launch of their own; bit 27 the patch-major copy made from the slot-major copy in a second pass. */
+int mfem_debug_set_ell(int enable);
+/* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
+ * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
+int mfem_debug_set_sell(int enable);
+/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
+ * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
+int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);
+/* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
+ * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
+ * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */
+int mfem_debug_set_graphs(int on, int64_t max_n);
+/* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
+int mfem_debug_set_vec_grid(int workgroups_per_cu);
+/* Multi-rank SpMV: 1 (default) the halo exchange runs on a second stream beside the rows that read no ghost column and the
+ * boundary rows follow in a second launch; 0 the exchange completes before a single launch (same results bitwise). */
+int mfem_debug_set_halo_overlap(int on);
+/* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
+ * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
+ * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
+ * 16 GiB scratch budget). */
+int mfem_debug_set_hex27(int two_pass);
+/* hex-8 elasticity matrix kernel: 0 (default) thread per (control point, element) with the rows accumulated in LDS and
+ * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise). */
+int mfem_debug_set_elasticity(int variant);
+/* hex-8 thermal matrix / residual kernels: 0 (default) the plane-sweep kernels with sum-factorised element integration
+ * (2- and 3-point Gauss rules; other rules always use the tile kernels); 1 the 4 x 4 x 8 tile kernels with the table form. */
+int mfem_debug_set_hex8_thermal(int variant);
+/* Per-launch timing of the solver's SpMV kernel with hip events on the context stream (bench.py's roofline).
+ * read: total device ms and launch count since the last reset. */
+int mfem_prof_spmv_enable(mfem_context ctx, int on);
+int mfem_prof_spmv_read(mfem_context ctx, double* total_ms /* [host] */, int64_t* launches /* [host] */, int reset);
+/* RCCL transport check on the communicator attached to ctx (mfem_comm_create, not the host-callback one): `rounds` times the call
+ * sequence one overlapped SpMV + reduction group issues -- grouped ncclSend / ncclRecv of `count` doubles on the halo stream fenced
+ * by events, a kernel on the context stream beside it, the stream wait, ncclAllReduce of 3 scalars on the context stream with the
+ * same communicator -- on a RING (to rank + 1, from rank - 1, modulo world), so that a one-rank communicator runs every call as
+ * well (self send / receive).  MFEM_OK when every received entry and the reduced scalars are right. */
+int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METAFEM_MI355X_DEBUG_H */

@@ -108,7 +108,9 @@ def default_context() -> Context:
 
 class FEM_SpMat_CSR:
     """CSR pattern handle: FEM_SpMat_CSR(K_J_ptr, K_J, K_vals, dims) (04_GPU_Utils.jl:120) without the
-    values (they change every Newton step; pass them per call)."""
+    values (they change every Newton step; pass them per call).  `rowptr` / `colidx` are BORROWED by the library and FROZEN for
+    the lifetime of the handle: it keeps what it learnt from them at creation (row blocks, tiles that repeat one column-offset
+    list, later the solver layouts).  After rewriting them in place call `replan()`; a different pattern needs a new handle."""
 
     def __init__(self, rowptr: torch.Tensor, colidx: torch.Tensor, n: int, index_base: int = 0,
                  ctx: Optional[Context] = None, _handle=None):
@@ -134,6 +136,16 @@ class FEM_SpMat_CSR:
     def ncols(self) -> int:
         """Columns the pattern addresses = length of x and of a per-column vector (n + ghost entries for a slab pattern)."""
         return int(lib.mfem_csr_ncols(self._h))
+
+    def replan(self):
+        """Re-inspect the (rewritten in place) pattern arrays: mfem_csr_replan."""
+        check(lib.mfem_csr_replan(self.ctx._h, self._h))
+
+    def spmv_bytes(self):
+        """(bytes one mul_ launch moves by design, column entries it reads): mfem_csr_spmv_bytes."""
+        b, c = C.c_int64(), C.c_int64()
+        check(lib.mfem_csr_spmv_bytes(self.ctx._h, self._h, C.byref(b), C.byref(c)))
+        return b.value, c.value
 
     def close(self):
         if self._h:

@@ -90,7 +90,7 @@ class OpLayout(C.Structure):
                 ("n_colours", c_int32), ("colour_offsets", C.POINTER(c_int64))]
 
 
-# every symbol declared in include/metafem_mi355x.h: (name, restype, argtypes)
+# every symbol declared in include/metafem_mi355x.h and include/metafem_mi355x_debug.h: (name, restype, argtypes)
 P = c_void_p
 SIGNATURES = {
     "mfem_abi_version": (c_int, []),
@@ -171,6 +171,9 @@ SIGNATURES = {
     "mfem_comm_create_host": (c_int, [P, c_int32, c_int32, C.POINTER(CommHostOps), C.POINTER(P)]),
     "mfem_csr_ncols": (c_int64, [P]),
     "mfem_debug_set_halo_overlap": (c_int, [c_int]),
+    "mfem_csr_replan": (c_int, [P, P]),
+    "mfem_csr_spmv_bytes": (c_int, [P, P, C.POINTER(c_int64), C.POINTER(c_int64)]),
+    "mfem_debug_comm_selftest": (c_int, [P, c_int64, c_int32]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -29,6 +29,39 @@ int mfem_debug_epoch = 0;
 extern "C" int mfem_abi_version(void) { return MFEM_ABI_VERSION; }
 extern "C" const char* mfem_last_error(void) { return g_err; }
 
+static int context_allocate(mfem_context_s* c) {
+  MFEM_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(double) * MFEM_MAX_PARTIALS * 8));
+  MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * MFEM_NSCALARS));
+  MFEM_CHECK_HIP(hipHostMalloc(&c->h_scalars, sizeof(double) * MFEM_NSCALARS));
+  MFEM_CHECK_HIP(hipMalloc(&c->d_flags, sizeof(int32_t) * 16));
+  MFEM_CHECK_HIP(hipHostMalloc(&c->h_flags, sizeof(int32_t) * 16));
+  MFEM_CHECK_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * MFEM_NSCALARS, c->stream));
+  MFEM_CHECK_HIP(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 16, c->stream));
+  MFEM_CHECK_HIP(hipEventCreate(&c->ev0));
+  MFEM_CHECK_HIP(hipEventCreate(&c->ev1));
+  return MFEM_OK;
+}
+
+static void context_release(mfem_context_s* ctx) {
+  if (ctx->d_partials) hipFree(ctx->d_partials);
+  if (ctx->d_scalars) hipFree(ctx->d_scalars);
+  if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
+  if (ctx->d_flags) hipFree(ctx->d_flags);
+  if (ctx->h_flags) hipHostFree(ctx->h_flags);
+  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->prof_ev) {
+    for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i)
+      if (ctx->prof_ev[i]) hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
+  }
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  for (int i = 0; i < MFEM_GRAPH_SLOTS; ++i)
+    if (ctx->graph_exec[i]) hipGraphExecDestroy(ctx->graph_exec[i]);
+  if (ctx->graph_ev) hipEventDestroy(ctx->graph_ev);
+  if (ctx->graph_stream) hipStreamDestroy(ctx->graph_stream);
+}
+
 extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) {
   MFEM_REQUIRE(out != nullptr, "out is null");
   int ndev = 0;
@@ -43,22 +76,19 @@ extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) 
   }
   mfem_context_s* c = new mfem_context_s();
   memset(c, 0, sizeof(*c));
-  {
-    std::lock_guard<std::mutex> lk(g_ctx_mutex);
-    g_live_contexts.insert(c);
-  }
   c->device = device;
   c->stream = (hipStream_t)stream;
   c->num_cus = prop.multiProcessorCount;
-  MFEM_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(double) * MFEM_MAX_PARTIALS * 8));
-  MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * MFEM_NSCALARS));
-  MFEM_CHECK_HIP(hipHostMalloc(&c->h_scalars, sizeof(double) * MFEM_NSCALARS));
-  MFEM_CHECK_HIP(hipMalloc(&c->d_flags, sizeof(int32_t) * 16));
-  MFEM_CHECK_HIP(hipHostMalloc(&c->h_flags, sizeof(int32_t) * 16));
-  MFEM_CHECK_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * MFEM_NSCALARS, c->stream));
-  MFEM_CHECK_HIP(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 16, c->stream));
-  MFEM_CHECK_HIP(hipEventCreate(&c->ev0));
-  MFEM_CHECK_HIP(hipEventCreate(&c->ev1));
+  int rc = context_allocate(c);
+  if (rc != MFEM_OK) {  // release what the failed creation had got (hipFree / hipHostFree / hipEventDestroy of null are no-ops here)
+    context_release(c);
+    delete c;
+    return rc;
+  }
+  {  // registered only once it is complete: a failed creation leaves nothing behind in the registry
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    g_live_contexts.insert(c);
+  }
   *out = c;
   return MFEM_OK;
 }
@@ -82,22 +112,7 @@ extern "C" int mfem_context_destroy(mfem_context ctx) {
     g_live_contexts.erase(ctx);
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_partials);
-  hipFree(ctx->d_scalars);
-  hipHostFree(ctx->h_scalars);
-  hipFree(ctx->d_flags);
-  hipHostFree(ctx->h_flags);
-  if (ctx->ws) hipFree(ctx->ws);
-  if (ctx->prof_ev) {
-    for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i) hipEventDestroy(ctx->prof_ev[i]);
-    delete[] ctx->prof_ev;
-  }
-  hipEventDestroy(ctx->ev0);
-  hipEventDestroy(ctx->ev1);
-  for (int i = 0; i < MFEM_GRAPH_SLOTS; ++i)
-    if (ctx->graph_exec[i]) hipGraphExecDestroy(ctx->graph_exec[i]);
-  if (ctx->graph_ev) hipEventDestroy(ctx->graph_ev);
-  if (ctx->graph_stream) hipStreamDestroy(ctx->graph_stream);
+  context_release(ctx);
   delete ctx;
   return MFEM_OK;
 }
@@ -118,7 +133,7 @@ int mfem_prof_flush(mfem_context_s* ctx) {
 extern "C" int mfem_prof_spmv_enable(mfem_context ctx, int on) {
   MFEM_REQUIRE(ctx, "null ctx");
   if (on && !ctx->prof_ev) {
-    ctx->prof_ev = new hipEvent_t[2 * MFEM_PROF_PAIRS];
+    ctx->prof_ev = new hipEvent_t[2 * MFEM_PROF_PAIRS]();
     for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i) MFEM_CHECK_HIP(hipEventCreate(&ctx->prof_ev[i]));
   }
   if (!on) {

@@ -323,7 +323,8 @@ template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_row_ranks(int itp, int64_t ncp, int nf, const RP* __restrict__ rowptr,
                                                                  const int32_t* __restrict__ colidx, int cbase,
                                                                  const int64_t* __restrict__ adj_ptr, const int32_t* __restrict__ adj,
-                                                                 const int32_t* __restrict__ cp, int base, uint16_t* __restrict__ ranks) {
+                                                                 const int32_t* __restrict__ cp, int base, uint16_t* __restrict__ ranks,
+                                                                 int32_t* __restrict__ repeated) {
   const int64_t total = adj_ptr[ncp] * itp;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -342,6 +343,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_row_ranks(int itp, int64_t 
       if (colidx[lo + mid] - cbase < col) l = mid + 1; else h = mid;
     }
     ranks[t] = (uint16_t)l;
+    // an element that lists one control point twice (collapsed / degenerate elements) would make two lanes of the gather add at
+    // the same position of a row: found here once per pattern (entries with a == 0 visit every element exactly once)
+    if (a == 0) {
+      bool rep = false;
+      for (int b2 = b + 1; b2 < itp; ++b2) rep |= (int32_t)((int64_t)cp[el * itp + b2] - base) == col;
+      if (rep) *repeated = 1;
+    }
   }
 }
 
@@ -353,14 +361,23 @@ extern "C" int mfem_mesh_row_ranks(mfem_context ctx, int32_t itp, int64_t nel, i
   MFEM_REQUIRE(A->n == (int64_t)n_fields * ncp, "pattern rows != n_fields * ncp");
   MFEM_REQUIRE(A->max_row_nnz / n_fields < 65536, "more than 65535 coupled control points per row");
   if (nel == 0) return MFEM_OK;
+  int32_t* d_rep = ctx->d_flags + 11;
+  MFEM_CHECK_HIP(hipMemsetAsync(d_rep, 0, sizeof(int32_t), ctx->stream));
   const int grid = mfem_grid_for(nel * itp * (int64_t)itp, MFEM_BLOCK, ctx->num_cus * 16);
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_mesh_row_ranks<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, itp, ncp, n_fields,
-                       (const int64_t*)A->rowptr, A->colidx, A->index_base, adj_ptr, adj, controlpoint_IDs, index_base, ranks);
+                       (const int64_t*)A->rowptr, A->colidx, A->index_base, adj_ptr, adj, controlpoint_IDs, index_base, ranks, d_rep);
   else
     hipLaunchKernelGGL(k_mesh_row_ranks<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, itp, ncp, n_fields,
-                       (const int32_t*)A->rowptr, A->colidx, A->index_base, adj_ptr, adj, controlpoint_IDs, index_base, ranks);
+                       (const int32_t*)A->rowptr, A->colidx, A->index_base, adj_ptr, adj, controlpoint_IDs, index_base, ranks, d_rep);
   MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 11, d_rep, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_flags[11]) {
+    mfem_set_error("an element lists the same control point twice: the row-owner gather adds at distinct positions per element -- use "
+                   "mfem_mesh_assemble_elements (scatter through the slot table) for this mesh");
+    return MFEM_ERR_UNSUPPORTED;
+  }
   return MFEM_OK;
 }
 

@@ -394,3 +394,86 @@ extern "C" int mfem_halo_reduce(mfem_context ctx, double* x_local) {
   MFEM_REQUIRE(ctx->comm, "no communicator attached (mfem_context_set_comm)");
   return mfem_comm_halo_reduce(ctx, x_local);
 }
+
+// ---- diagnostic: the RCCL choreography of one overlapped SpMV + reduction group, on a ring ------------------------------------
+// What the solver issues per iteration with the RCCL transport -- grouped ncclSend / ncclRecv on the high-priority halo stream fenced
+// by two events, a kernel on the context stream beside it, the stream wait, then ncclAllReduce on the context stream with the SAME
+// communicator -- but with ring neighbours (rank + 1, rank - 1 modulo world), so that a one-rank communicator exercises every call
+// too (a self send / receive inside a group).  Returns MFEM_OK when every received entry and the reduced scalars are what the ring
+// must deliver.  mfem_debug_* : not part of the drop-in surface.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_ring_fill(int64_t n, double base, double* __restrict__ s) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) s[i] = base + (double)i;
+}
+__global__ __launch_bounds__(MFEM_BLOCK) void k_ring_check(int64_t n, double base, const double* __restrict__ r, int32_t* __restrict__ bad) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+    if (r[i] != base + (double)i) atomicAdd(bad, 1);
+}
+
+extern "C" int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds) {
+  MFEM_REQUIRE(ctx && count > 0 && rounds > 0, "bad argument");
+  mfem_comm_s* c = ctx->comm;
+  MFEM_REQUIRE(c && c->backend == 0, "needs an attached RCCL communicator (mfem_comm_create + mfem_context_set_comm)");
+  MFEM_COMM_ALIVE(c);
+  MFEM_REQUIRE(!c->pending_x, "a halo exchange is in flight on this communicator");
+  double *snd = nullptr, *rcv = nullptr;
+  MFEM_CHECK_HIP(hipMalloc(&snd, sizeof(double) * (size_t)count));
+  if (hipMalloc(&rcv, sizeof(double) * (size_t)count) != hipSuccess) {
+    hipFree(snd);
+    mfem_set_error("hipMalloc failed");
+    return MFEM_ERR_HIP;
+  }
+  int32_t* bad = ctx->d_flags + 10;
+  double* sc = ctx->d_scalars + (MFEM_NSCALARS - 8);
+  const int next = (c->rank + 1) % c->world, prev = (c->rank + c->world - 1) % c->world;
+  const int g = mfem_grid_for(count, MFEM_BLOCK, 1024);
+  int rc = MFEM_OK;
+  auto run = [&]() -> int {
+    MFEM_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), ctx->stream));
+    for (int r = 0; r < rounds; ++r) {
+      hipLaunchKernelGGL(k_ring_fill, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, count, 1e6 * c->rank + 1e3 * r, snd);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipEventRecord(c->ev_ready, ctx->stream));
+      MFEM_CHECK_HIP(hipStreamWaitEvent(c->halo_stream, c->ev_ready, 0));
+      MFEM_CHECK_NCCL(ncclGroupStart());
+      MFEM_GROUP_NCCL(c, ncclSend(snd, (size_t)count, ncclDouble, next, c->comm, c->halo_stream));
+      MFEM_GROUP_NCCL(c, ncclRecv(rcv, (size_t)count, ncclDouble, prev, c->comm, c->halo_stream));
+      ncclResult_t e = ncclGroupEnd();
+      if (e != ncclSuccess) {
+        mfem_set_error("ncclGroupEnd (ring): %s", ncclGetErrorString(e));
+        c->failed = 1;
+        return MFEM_ERR_COMM;
+      }
+      MFEM_CHECK_HIP(hipEventRecord(c->ev_done, c->halo_stream));
+      // "interior rows": work on the context stream that does not depend on the exchange
+      hipLaunchKernelGGL(k_ring_fill, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, (int64_t)3, (double)(c->rank + 1), sc);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+      hipLaunchKernelGGL(k_ring_check, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, count, 1e6 * prev + 1e3 * r, rcv, bad);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_NCCL(ncclAllReduce(sc, sc, 3, ncclDouble, ncclSum, c->comm, ctx->stream));
+    }
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 10, bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + (MFEM_NSCALARS - 8), sc, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(c->halo_stream));
+    if (ctx->h_flags[10] != 0) {
+      mfem_set_error("ring exchange delivered %d wrong entries", ctx->h_flags[10]);
+      return MFEM_ERR_COMM;
+    }
+    const double W = (double)c->world, tri = W * (W + 1.0) / 2.0;  // sum over ranks of (rank + 1 + i), i = 0..2
+    for (int i = 0; i < 3; ++i)
+      if (ctx->h_scalars[MFEM_NSCALARS - 8 + i] != tri + W * i) {
+        mfem_set_error("all-reduce delivered %g for scalar %d, expected %g", ctx->h_scalars[MFEM_NSCALARS - 8 + i], i, tri + W * i);
+        return MFEM_ERR_COMM;
+      }
+    return MFEM_OK;
+  };
+  rc = run();
+  hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(c->halo_stream);
+  hipFree(snd);
+  hipFree(rcv);
+  return rc;
+}

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/metafem_mi355x.h"
+#include "../../include/metafem_mi355x_debug.h"
 
 #define MFEM_WAVE 64
 #define MFEM_BLOCK 256

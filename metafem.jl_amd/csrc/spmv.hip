@@ -843,6 +843,23 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   return MFEM_OK;
 }
 
+// everything the handle derived from the borrowed pattern arrays (not the arrays themselves)
+static void csr_drop_plans(mfem_csr_s* A) {
+  mfem_ell_unbind(A);
+  mfem_sell_unbind(A);
+  mfem_ell_free(A);
+  mfem_sell_free(A);
+  A->sym_state = 0;
+  A->symp_state = 0;
+  if (A->rb_rows) hipFree(A->rb_rows);
+  if (A->cw_elide) hipFree(A->cw_elide);
+  A->rb_rows = nullptr;
+  A->cw_elide = nullptr;
+  A->rb_state = 0;
+  A->rb_ntiles = A->rb_elided = 0;
+  A->cw_R = 0;
+}
+
 extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
                                const int32_t* colidx, int index_base, mfem_csr* out) {
   MFEM_REQUIRE(ctx && out, "null argument");
@@ -862,10 +879,79 @@ extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const v
   A->index_base = index_base;
   int rc = mfem_csr_plan(ctx, A);
   if (rc != MFEM_OK) {
+    csr_drop_plans(A);  // whatever the failed plan step left behind (row blocks, elision flags)
     delete A;
     return rc;
   }
   *out = A;
+  return MFEM_OK;
+}
+
+// The handle caches what it learnt from the borrowed rowptr / colidx (longest row, row blocks, which tiles repeat one column-offset
+// list, the solver layouts).  A caller that has rewritten those arrays in place (same n, same nnz) re-runs the inspection here.
+extern "C" int mfem_csr_replan(mfem_context ctx, mfem_csr A) {
+  MFEM_REQUIRE(ctx && A, "null argument");
+  MFEM_REQUIRE(A->ctx == ctx, "the pattern belongs to another context");
+  mfem_graphs_invalidate(ctx);
+  csr_drop_plans(A);
+  return mfem_csr_plan(ctx, A);
+}
+
+// Column entries (4 bytes each) one launch of the default CSR kernel reads by design: all of them in a tile whose rows do not repeat one
+// offset list, the leading 128 / 256 staged entries (the first row / the first two rows) in a tile that does.
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_csr_cols_read(int64_t n, int64_t ntiles, int R, const int32_t* __restrict__ rs,
+                                                               const uint8_t* __restrict__ flag, const RP* __restrict__ rowptr, int base,
+                                                               unsigned long long* __restrict__ total) {
+  unsigned long long acc = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r0, r1;
+    int el, lead;
+    if (rs) {
+      const uint32_t w0 = (uint32_t)rs[t];
+      r0 = (int64_t)(w0 & 0x7fffffffu);
+      r1 = (int64_t)(rs[t + 1] & 0x7fffffff);
+      el = (int)(w0 >> 31);
+      lead = 256;
+    } else {
+      r0 = t * R;
+      r1 = (r0 + R < n) ? r0 + R : n;
+      el = flag ? (int)flag[t] : 0;
+      lead = 128;
+    }
+    const int64_t s = ((int64_t)rowptr[r0] - base) & ~(int64_t)1, e = (int64_t)rowptr[r1] - base;
+    const int64_t cnt = e - s;
+    acc += (unsigned long long)(el ? (cnt < lead ? cnt : lead) : cnt);
+  }
+  acc = (unsigned long long)wave_reduce_sum((double)acc);  // exact below 2^53
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
+}
+
+extern "C" int mfem_csr_spmv_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes, int64_t* column_entries_read) {
+  MFEM_REQUIRE(ctx && A && bytes, "null argument");
+  int64_t cols = A->nnz, table = 0;
+  const bool rb = A->rb_state == 1 && A->rb_rows, cw = !rb && A->cw_R > 0 && A->cw_elide;
+  if ((rb || cw) && A->n > 0) {
+    unsigned long long* d_tot = reinterpret_cast<unsigned long long*>(ctx->d_flags + 8);  // (8-byte aligned: d_flags is hipMalloc'ed)
+    MFEM_CHECK_HIP(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), ctx->stream));
+    const int64_t nt = rb ? A->rb_ntiles : (A->n + A->cw_R - 1) / A->cw_R;
+    const int g = mfem_grid_for(nt, MFEM_BLOCK, 4096);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_csr_cols_read<int64_t>, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, nt, A->cw_R, rb ? A->rb_rows : nullptr,
+                         rb ? nullptr : A->cw_elide, (const int64_t*)A->rowptr, A->index_base, d_tot);
+    else
+      hipLaunchKernelGGL(k_csr_cols_read<int32_t>, dim3(g), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, nt, A->cw_R, rb ? A->rb_rows : nullptr,
+                         rb ? nullptr : A->cw_elide, (const int32_t*)A->rowptr, A->index_base, d_tot);
+    MFEM_CHECK_LAUNCH();
+    unsigned long long h = 0;
+    MFEM_CHECK_HIP(hipMemcpyAsync(&h, d_tot, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    cols = (int64_t)h;
+    table = rb ? (nt + 1) * 4 : nt;  // the tile table itself (first rows + flag bit / one flag byte per tile)
+  }
+  if (column_entries_read) *column_entries_read = cols;
+  // values once, the columns the kernel reads, x once (gathers of one entry by several rows are cache hits by design), y once, row pointers once
+  *bytes = A->nnz * 8 + cols * 4 + A->n * 16 + (A->n + 1) * (A->rowptr_bits / 8) + table;
   return MFEM_OK;
 }
 
@@ -951,6 +1037,11 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   if (rc) return rc;
   rc = mfem_comm_halo_begin(ctx, x);
   if (rc) return rc;
+  // an error between begin and end must not leave the exchange "in flight": the communicator would refuse every later one
+  auto fail = [&](int code) {
+    mfem_comm_halo_end(ctx);
+    return code;
+  };
   SpmvPart P;
   memset(&P, 0, sizeof(P));
   const int F = ctx->halo_fields;
@@ -966,7 +1057,7 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
     int np1 = 0, np2 = 0;
     P.part = 1;
     rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, &np1, done_flag, P);
-    if (rc) return rc;
+    if (rc) return fail(rc);
     rc = mfem_comm_halo_end(ctx);
     if (rc) return rc;
     P.part = 2;

@@ -61,13 +61,16 @@ class _NeedsEnv(Exception):
 
 
 class _NoEnv(dict):
-    """Probe environment: a coefficient function that reads any inner variable / external / normal is not a constant."""
+    """Probe environment: a coefficient function that reads -- or merely asks about -- any inner variable / external / normal
+    is not a constant (every way of looking into the mapping raises, including `'x' in env`, iteration and len)."""
 
-    def __getitem__(self, key):
-        raise _NeedsEnv(key)
+    def _needs(self, *a, **k):
+        raise _NeedsEnv(a[0] if a else "env")
 
-    def get(self, key, default=None):
-        raise _NeedsEnv(key)
+    __getitem__ = get = __contains__ = __iter__ = __len__ = keys = values = items = setdefault = pop = _needs
+
+    def __bool__(self):
+        raise _NeedsEnv("env")
 
 
 def constant_coefficient(fn) -> Optional[float]:
@@ -316,9 +319,14 @@ class GenericDomain:
     def _row_ranks(self) -> torch.Tensor:
         """Column ranks of the row-owner assembly (mfem_mesh_row_ranks), built on first use."""
         if getattr(self, "_ranks", None) is None:
-            self._ranks = torch.empty(self.nel * self.itp * self.itp, dtype=torch.int16, device=self.dev)
-            check(lib.mfem_mesh_row_ranks(self.ctx._h, self.itp, self.nel, self.ncp, self.n_fields, self.A._h, self._adj_ptr.data_ptr(),
-                                          self._adj.data_ptr(), self.cp.data_ptr(), 1, self._ranks.data_ptr()))
+            ranks = torch.empty(self.nel * self.itp * self.itp, dtype=torch.int16, device=self.dev)
+            rc = lib.mfem_mesh_row_ranks(self.ctx._h, self.itp, self.nel, self.ncp, self.n_fields, self.A._h, self._adj_ptr.data_ptr(),
+                                         self._adj.data_ptr(), self.cp.data_ptr(), 1, ranks.data_ptr())
+            if rc == -3:  # MFEM_ERR_UNSUPPORTED: an element lists a control point twice -> the scatter form from now on
+                self.row_owner = False
+                return None
+            check(rc)
+            self._ranks = ranks
         return self._ranks
 
     def _assemble_const(self, g: _Group, cterms, K: torch.Tensor):
@@ -332,7 +340,7 @@ class GenericDomain:
             chunk = cterms[c0:c0 + _lib.MAX_BATCH_TERMS]
             arr = (_lib.ConstTerm * len(chunk))(*[_lib.ConstTerm(t.dual_s, t.base_s, t.dual_pos * self.n_fields + t.base_pos, 0,
                                                                  c * self.K_params[t.td_order]) for t, c in chunk])
-            if g.facet_el is None and self.row_owner:
+            if g.facet_el is None and self.row_owner and self._row_ranks() is not None:
                 rc = lib.mfem_mesh_assemble_elements_rows(self.ctx._h, self.dim, self.space.itg, self.itp, self.nel, self.ncp,
                                                           self._ref.data_ptr(), self._itgw.data_ptr(), self.coords.data_ptr(),
                                                           self.cp.data_ptr(), 1, len(chunk), arr, self.n_fields, self.A._h,

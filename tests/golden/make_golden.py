@@ -152,6 +152,31 @@ def thermal_hex27():
                         colidx=od.pattern.colidx, K=K, R0=R0, T=od.x)
 
 
+def c_header():
+    """The 4x4x4 hex-8 thermal fixture as C arrays for tests/c_abi_smoke.c (a plain-C consumer of include/metafem_mi355x.h):
+    the same numbers as oracle_thermal_hex8_4x4x4.npz, data only."""
+    d = np.load(os.path.join(HERE, "oracle_thermal_hex8_4x4x4.npz"))
+
+    def arr(ctype, name, a, fmt):
+        body = ",\n  ".join(", ".join(fmt(v) for v in a[i:i + 6]) for i in range(0, len(a), 6))
+        return f"static const {ctype} {name}[{len(a)}] = {{\n  {body}\n}};\n"
+
+    f = lambda v: float(v).hex()  # exact binary64 values (C99 hexadecimal floating constants)
+    i = lambda v: str(int(v))
+    with open(os.path.join(HERE, "oracle_thermal_hex8_4x4x4.h"), "w") as out:
+        out.write("/* generated by tests/golden/make_golden.py::c_header from oracle_thermal_hex8_4x4x4.npz (oracle output: 4x4x4 hex-8\n"
+                  " * Robin thermal problem, k = 0.6, h = 25, Tenv = 293.15, s = 1600; K in CSR order, R0 = residual at x* = 0, T = the\n"
+                  " * field after one update_OneStep!).  Data only. */\n")
+        out.write(f"#define GOLD_N {len(d['T'])}\n#define GOLD_NNZ {len(d['K'])}\n")
+        out.write(arr("double", "gold_size", d["x"], f))
+        out.write(arr("int", "gold_num", d["n"], i))
+        out.write(arr("long long", "gold_rowptr", d["rowptr"], i))
+        out.write(arr("int", "gold_colidx", d["colidx"], i))
+        out.write(arr("double", "gold_K", d["K"], f))
+        out.write(arr("double", "gold_R0", d["R0"], f))
+        out.write(arr("double", "gold_T", d["T"], f))
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF):
         strip()
@@ -163,4 +188,5 @@ if __name__ == "__main__":
     thermal_hex8()
     elasticity_hex8()
     thermal_hex27()
+    c_header()
     print("fixtures written to", HERE)

@@ -4,18 +4,30 @@ import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "metafem_mi355x.h")
+HEADER = os.path.join(ROOT, "include", "metafem_mi355x.h")  # the drop-in surface
+DEBUG_HEADER = os.path.join(ROOT, "include", "metafem_mi355x_debug.h")  # tuning / diagnostic hooks (tests, bench, tools)
 LIB = os.path.join(ROOT, "metafem.jl_amd", "libmetafem_mi355x.so")
 
 
-def _declared():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mfem_[a-z0-9_]+)\s*\(", src)))
+def _declared(headers=(HEADER, DEBUG_HEADER)):
+    names = set()
+    for h in headers:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(mfem_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_is_valid_c():
-    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER])
+    for h in (HEADER, DEBUG_HEADER):
+        subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", h])
+
+
+def test_drop_in_header_holds_no_diagnostic_knob():
+    """A maintainer binding include/metafem_mi355x.h gets the seams only; the process-wide knobs live in the debug header."""
+    main = _declared((HEADER,))
+    assert not [s for s in main if s.startswith(("mfem_debug_", "mfem_prof_"))]
+    dbg = _declared((DEBUG_HEADER,))
+    assert dbg and all(s.startswith(("mfem_debug_", "mfem_prof_")) for s in dbg), dbg
 
 
 def test_library_exports_every_declared_symbol():

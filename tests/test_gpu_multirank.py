@@ -31,19 +31,35 @@ def _free_port():
 
 
 def run_ranks(case, world, timeout=900):
+    """Start the ranks as fresh processes; their output goes to temporary FILES (a rank that fills a 64 KB pipe while rank 0 waits
+    for it in a collective would hang the test until its timeout), one deadline for the whole group."""
+    import tempfile
+    import time
+
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    logs = [tempfile.TemporaryFile() for _ in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), case, str(world), str(r), str(port)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
-    outs = []
+                              stdout=logs[r], stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    deadline = time.monotonic() + timeout
     try:
         for p in procs:
-            out, _ = p.communicate(timeout=timeout)
-            outs.append(out.decode(errors="replace"))
+            try:
+                p.wait(timeout=max(deadline - time.monotonic(), 0.1))
+            except subprocess.TimeoutExpired:
+                break
+            if p.returncode != 0:  # a dead rank leaves the others waiting in a collective: do not sit out the timeout
+                deadline = min(deadline, time.monotonic() + 20)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+                p.wait()
+    outs = []
+    for f in logs:
+        f.seek(0)
+        outs.append(f.read().decode(errors="replace"))
+        f.close()
     reports = []
     for r, (p, out) in enumerate(zip(procs, outs)):
         line = [ln for ln in out.splitlines() if ln.startswith("MULTIRANK_REPORT ")]

@@ -188,3 +188,19 @@ def test_element_colouring_is_conflict_free_and_compact(shape, dim, itp_type, or
     deg = np.bincount(msh.cp_ids.ravel()).max()
     assert deg <= col.max() + 1 <= 2 * deg + 2
     assert np.array_equal(col, pm.colour_Elements(msh.cp_ids))  # seeded: reproducible
+
+
+def test_constant_coefficient_probe_traps_every_look_into_the_environment(mf):
+    """generic.constant_coefficient decides which terms take the fused constant-coefficient assembly: a coefficient function that
+    reads, tests membership in, iterates or measures the environment is NOT a constant."""
+    from metafem_jl_amd.generic import constant_coefficient
+
+    assert constant_coefficient(lambda env: 0.6) == 0.6
+    assert constant_coefficient(lambda env: -2 * 3.5) == -7.0
+    assert constant_coefficient(lambda env: env["T"] * 2.0) is None
+    assert constant_coefficient(lambda env: env.get("T", 1.0)) is None
+    assert constant_coefficient(lambda env: 1.0 if "x" in env else 2.0) is None
+    assert constant_coefficient(lambda env: float(len(env))) is None
+    assert constant_coefficient(lambda env: 1.0 if env else 2.0) is None
+    assert constant_coefficient(lambda env: sum(1.0 for _ in env)) is None
+    assert constant_coefficient(lambda env: float(len(list(env.keys())))) is None
