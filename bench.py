@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X MetaFEM backend (contract: see task prompt / DESIGN.md §Measurement).
+"""bench.py -- headline benchmark of the MI355X MetaFEM backend (contract: see task prompt / DESIGN.md section 5).
 
-Metric (BASELINE.json): DOF-updates/s = n_DOF x Krylov iterations / (t_assembly + t_solve) on 3-D thermal
-conduction, linear hex-8.  One *step* = one pass of the hot path over one synthetic mesh:
-    K_linear_func  (fused hex-8 assembly of K, CSR order)           mfem_brick_assemble_thermal
-  + K_nonlinear_func (matrix-free residual R at x* = 0)              mfem_brick_residual_thermal
-  + `--iters` Jacobi-PCG iterations on K delta = R (fixed count)     mfem_solve(fixed_iterations)
-N = 1 workload: configs[1] of BASELINE.json, 256^3 elements (16 974 593 DOF, nnz 454 756 609).
-N > 1: weak scaling -- every rank owns a 256-element-thick slab of a (256 N) x 256 x 256 mesh (slab
-decomposition along i, one ghost node plane per neighbour, RCCL all-reduce of the CG scalars).
+Metric (BASELINE.json): DOF-updates/s = n_DOF x Krylov iterations / (t_assembly + t_solve).  One *step* = one pass of the hot
+path over one synthetic mesh, i.e. what update_OneStep! (solver/04_Time_Domain.jl:59-80) runs for one Newton step with a capped
+solver:
+    K_linear_func    (fused assembly of K, CSR order)              mfem_brick_assemble_*
+  + K_nonlinear_func (matrix-free residual R at x* = 0)            mfem_brick_residual_*
+  + `--iters` Krylov iterations on K delta = R (fixed count)       mfem_solve
+
+--config c2 (default): 3-D thermal conduction, linear hex-8, Jacobi-PCG.  N = 1 workload: the configuration the north_star's
+    target is quoted on, 512^3 elements (135 005 697 DOF, nnz 3 630 961 153, int64 row pointers, 45 GB); configs[1] of
+    BASELINE.json (256^3) runs in the same invocation as the `secondary_256` object.
+--config c3: configs[2], linear elasticity hex-8 (3 DOF per node), 128^3 per GPU, BiCGStab(2) (bicgstabl_GS!).
+--config c4: configs[3], thermal conduction on quadratic hex-27 (FP64-MFMA Ke), 128^3 per GPU, Jacobi-PCG.
+N > 1 (every config): weak scaling -- every rank owns an `--n`-element-thick slab of an (n N) x n x n mesh (slab decomposition
+along i, `order` ghost node planes per neighbour exchanged over RCCL beside the interior rows, one all-reduce per reduction group).
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,7 +30,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_COND, H, TENV, SRC = 0.6, 25.0, 293.15, 1600.0  # examples/thermal_conduction/3D_Script.jl:21-25,56
+E_MOD, NU = 1.0, 0.3                               # examples/linear_elasticity/cantilever/3D_Script.jl:52-63 (E = 1, nu = 0.3)
+LAM, MU = E_MOD * NU / ((1 + NU) * (1 - 2 * NU)), E_MOD / (2 * (1 + NU))
+TAU = 1000.0 * E_MOD
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+CONFIGS = {
+    "c2": dict(title="3D thermal conduction, linear hex-8", order=1, itg=3, fields=1, n=512, solver="cg",
+               metric="DOF-updates/sec (assembly+CG iter) on 3D hex thermal conduction"),
+    "c3": dict(title="linear elasticity, hex-8, 3 DOF per node (penalty on x = 0, traction on y = L)", order=1, itg=3, fields=3, n=128,
+               solver="bicgstabl2", metric="DOF-updates/sec (assembly+BiCGStab(2) SpMV-steps) on 3D hex-8 linear elasticity"),
+    "c4": dict(title="3D thermal conduction, quadratic hex-27 (FP64-MFMA Ke)", order=2, itg=5, fields=1, n=128, solver="cg",
+               metric="DOF-updates/sec (assembly+CG iter) on 3D hex-27 thermal conduction"),
+}
 
 
 def cpu_baseline(n_cpu: int, iters: int, repeats: int = 3):
@@ -59,9 +77,12 @@ def cpu_baseline(n_cpu: int, iters: int, repeats: int = 3):
         "unit": "DOF-updates/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"hex-8 {n_cpu}^3 thermal ({prob.mesh.ncp} DOF = {prob.mesh.ncp / 16974593:.3f} of the 256^3 workload), median of "
+        "sample": f"hex-8 {n_cpu}^3 thermal ({prob.mesh.ncp} DOF = {prob.mesh.ncp / 135005697:.4f} of the 512^3 workload, "
+                  f"{prob.mesh.ncp / 16974593:.3f} of the 256^3 one), median of "
                   f"{len(times)} steps: 1 step = term-by-term assembly ({ta:.2f} s) + {iters} Jacobi-CG iterations ({ts:.2f} s) -- the "
-                  f"GPU leg's iterations per assembly; C/OpenMP restatement of the reference algorithm (oracle/c/oracle.c), "
+                  f"GPU leg's iterations per assembly; C/OpenMP restatement of the reference algorithm and DATA LAYOUT (oracle/c/oracle.c: "
+                  f"stored per-element basis tables, 2 KB + 0.5 KB of slot ids per hex-8 element -- 512^3 would need 340 GB of host "
+                  f"memory and 256^3 55 GB, so the sample stays at {n_cpu}^3 = 25 GB and the ratio below is a per-DOF throughput ratio), "
                   f"{cores} threads (cgroup CPU quota of the box)",
         "all_step_seconds": [round(a + b, 3) for a, b in times],
     }
@@ -98,19 +119,33 @@ def self_launch(n_ranks: int) -> int:
     return 0
 
 
+def load_traffic():
+    """profiles/r03_traffic.json: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950 x2
+    FETCH correction, calibrated in the same run) of THIS tree's kernels, keyed by '<kernel key>@<workload key>'.  Collected by
+    tools/run_pmc_r03.sh, not in this run (the line says so in `traffic_source`)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=256, help="elements per side of the per-GPU mesh")
-    ap.add_argument("--iters", type=int, default=200, help="CG iterations per step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--n", type=int, default=0, help="elements per side of the per-GPU mesh (0 = the config's size: 512 / 128 / 128)")
+    ap.add_argument("--iters", type=int, default=200, help="Krylov iterations per step (BiCGStab(2): SpMV-equivalent steps)")
     ap.add_argument("--cpu-n", type=int, default=192, help="elements per side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-repeats", type=int, default=3, help="timed CPU steps (the median is reported)")
-    ap.add_argument("--target-n", type=int, default=512, help="also run this mesh size for a few steps at N = 1 (0 = skip)")
-    ap.add_argument("--target-steps", type=int, default=2)
-    ap.add_argument("--hex27-n", type=int, default=128, help="CSR-kernel roofline on the hex-27 matrix of this size (0 = skip)")
+    ap.add_argument("--secondary-n", type=int, default=256, help="c2 at N = 1: also run this mesh size (configs[1]) for a few steps (0 = skip)")
+    ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--hex27-n", type=int, default=128, help="c2 at N = 1: CSR-kernel roofline on the hex-27 matrix of this size (0 = skip)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.n <= 0:
+        args.n = cfg["n"]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as child processes and BEFORE anything here touches
@@ -122,7 +157,7 @@ def main():
     import torch
 
     import metafem_jl_amd as mf
-    from metafem_jl_amd import _lib
+    from metafem_jl_amd import _lib, parallel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,15 +182,27 @@ def main():
     ctx = mf.Context(local_rank)
     dev = f"cuda:{local_rank}"
     use_comm = world > 1 or os.environ.get("MFEM_BENCH_FORCE_COMM") == "1"  # the env var exercises the RCCL path at N = 1
+    traffic_db = load_traffic()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def csr_kernel_roofline(A, K, launches=20):
-        """The CSR kernel behind mul! (mfem_spmv_csr: caller's CSR arrays, no copy) on this matrix: live hip-event timing of
-        `launches` launches, priced with SURVEY 8(d)'s CSR bytes.  This is the north_star's 'CSR SpMV % of HBM roofline'."""
+    def traffic_of(key):
+        t = traffic_db.get(key)
+        if not t:
+            return None, None
+        return t.get("hbm_bytes_per_launch"), (f"profiles/r03_traffic.json['{key}']: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                               f"kernel on this workload (tree {t.get('tree', '?')}; gfx950 x2 FETCH_SIZE correction, calibrated "
+                                               f"in the same run), not collected in this run")
+
+    def csr_kernel_roofline(A, K, wkey, launches=20):
+        """The CSR kernel behind mul! (mfem_spmv_csr: caller's CSR arrays, no copy) on this matrix: live hip-event timing of `launches`
+        launches.  `achieved` / `frac` price the launch with the bytes the kernel moves BY DESIGN (mfem_csr_spmv_bytes: values, the
+        columns it reads -- tiles whose rows repeat one column-offset list read only their first rows' columns --, x, y, row pointers);
+        `csr_equivalent` with SURVEY 8(d)'s formula (12 B per nonzero), the north_star's 'CSR SpMV % of HBM roofline' of a kernel
+        without that inspection; `frac_actual` with the PMC-measured traffic of profiles/r03_traffic.json."""
         x = mf.FEM_rand(A.ncols, 0x5EED, 0, ctx=ctx)
         y = torch.empty(A.n, dtype=torch.float64, device=dev)
         for _ in range(3):
@@ -168,21 +215,31 @@ def main():
         _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
         _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 0))
         ms = tot.value / max(cnt.value, 1)
-        nbytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8  # val 8 + col 4 per nonzero; x, y 8 per row; i64 row pointers
-        return {"kernel": "mfem_spmv_csr (mul!): k_spmv_csr_w (rows of up to 64 entries, uniform length) / k_spmv_csr_rb (wide or uneven rows) on the caller's CSR arrays; tiles whose rows repeat the column offsets of their first row(s) -- found by an inspection when the pattern is created -- do not re-read their columns, so the kernel moves fewer bytes than the CSR formula this object is priced with",
-                "avg_launch_ms": ms, "launches": int(cnt.value), "algorithmic_bytes_per_launch": nbytes,
-                "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+        formula = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8  # val 8 + col 4 per nonzero; x, y 8 per row; i64 row pointers
+        design, cols_read = A.spmv_bytes()
+        gbs = lambda b: b / (ms * 1e-3) / 1e9
+        traffic, src = traffic_of(f"csr_kernel@{wkey}")
+        return {"kernel": "mfem_spmv_csr (mul!): k_spmv_csr_w (rows of up to 64 entries, uniform length) / k_spmv_csr_rb (wide or uneven rows) "
+                          "on the caller's CSR arrays, no copy",
+                "avg_launch_ms": ms, "launches": int(cnt.value), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": design, "column_entries_read": cols_read,
+                "achieved": gbs(design), "frac": gbs(design) / HBM_PEAK_GBS,
+                "csr_equivalent": {"bytes_per_launch": formula, "achieved": gbs(formula), "frac": gbs(formula) / HBM_PEAK_GBS,
+                                   "note": "SURVEY 8(d): nnz*12 + n*16 + (n+1)*8 -- what a CSR kernel that reads every column index moves"},
+                "traffic": traffic, "traffic_source": src,
+                "traffic_over_algorithmic": (traffic / design) if traffic else None,
+                "frac_actual": (gbs(traffic) / HBM_PEAK_GBS) if traffic else None,
                 "n": A.n, "nnz": A.nnz}
 
     def run_workload(N, steps, warmup, want_csr):
-        """One workload: the hex-8 thermal problem on an (N * world) x N x N mesh, `steps` timed steps."""
+        """One workload of the selected config on an (N * world) x N x N mesh, `steps` timed steps."""
+        order, F = cfg["order"], cfg["fields"]
         nx_global = N * world
-        brick = mf.Brick((float(world), 1.0, 1.0), (nx_global, N, N), 1, 3, ctx=ctx)
+        brick = mf.Brick((float(world), 1.0, 1.0), (nx_global, N, N), order, cfg["itg"], ctx=ctx)
+        m0, m1, m2 = brick.m
         comm = None
         if use_comm:
-            from metafem_jl_amd import parallel
-
-            plo, phi = parallel.slab_planes(nx_global + 1, world, rank)
+            plo, phi = parallel.slab_planes(m0, world, rank, order)
             brick.set_slab(plo, phi)
             # RCCL prints a version banner / warnings through C stdio on stdout: send them to stderr so that stdout
             # carries only the JSON line
@@ -190,26 +247,48 @@ def main():
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                comm = (parallel.HostSlabComm if host_comm else parallel.SlabComm)(ctx, brick, rank, world, n_fields=1)
+                comm = (parallel.HostSlabComm if host_comm else parallel.SlabComm)(ctx, brick, rank, world, n_fields=F)
+                if not host_comm and os.environ.get("MFEM_BENCH_SKIP_SELFTEST") != "1":
+                    # every RCCL call of the solver's schedule once, on a ring, before the timed region: a transport problem shows
+                    # up here with a message instead of as a hang inside the Krylov loop
+                    _lib.check(_lib.lib.mfem_debug_comm_selftest(ctx._h, order * m1 * m2, 2))
                 C.CDLL(None).fflush(None)
             finally:
                 os.dup2(saved, 1)
                 os.close(saved)
-        A = brick.pattern(1)
+        A = brick.pattern(F)
         n_local = A.n
         K = torch.empty(A.nnz, dtype=torch.float64, device=dev)
-        xlen = n_local + (2 * brick.m[1] * brick.m[2] if use_comm else 0)
+        xlen = parallel.local_vector_length(brick.slab[0], brick.slab[1], m1, m2, F, order) if use_comm else n_local
         x_star = torch.zeros(xlen, dtype=torch.float64, device=dev)
-        s = torch.full((xlen,), SRC, dtype=torch.float64, device=dev)
+        s = torch.full((xlen,), SRC, dtype=torch.float64, device=dev) if F == 1 else None
         R = torch.empty(n_local, dtype=torch.float64, device=dev)
-        n_global = (nx_global + 1) * (N + 1) * (N + 1)
+        n_global = F * m0 * m1 * m2
+        x0, y1 = mf.FACE_BITS["x0"], mf.FACE_BITS["y1"]
+
+        if F == 1:
+            def assemble():
+                brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES, out=K)
+                brick.residual_thermal(x_star, K_COND, H, TENV, mf.ALL_FACES, s=s, out=R)
+        else:
+            def assemble():
+                brick.assemble_elasticity(A, LAM, MU, TAU, x0, out=K)
+                brick.residual_elasticity(x_star, LAM, MU, TAU, x0, y1, (0.0, 1.0, 0.0, 0.0, 0.0, 0.0), out=R)
+
+        if cfg["solver"] == "cg":
+            def solve():
+                return mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, Pr_func=mf.Pr_Jacobi_, maxiter=args.iters, max_pass=1,
+                                          fixed_iterations=True)[1]
+        else:
+            # bicgstabl_GS! with s = 2 (03_BiCGstabl.jl:18-96): one sweep = 4 SpMVs and advances the solver's `iter` by s = 2
+            # (:93), so maxiter = iters / 2 gives `--iters` SpMV-equivalent steps per solve
+            def solve():
+                return mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.bicgstabl_GS_, Pr_func=mf.Pr_Jacobi_, maxiter=max(args.iters // 2, 2),
+                                          max_pass=1, s=2, fixed_iterations=True)[1]
 
         def step():
-            brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES, out=K)
-            brick.residual_thermal(x_star, K_COND, H, TENV, mf.ALL_FACES, s=s, out=R)
-            _, st = mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, Pr_func=mf.Pr_Jacobi_, maxiter=args.iters,
-                                       max_pass=1, fixed_iterations=True)
-            return st
+            assemble()
+            return solve()
 
         for _ in range(warmup):
             step()
@@ -220,11 +299,12 @@ def main():
         barrier()
         t0 = time.perf_counter()
         solve_ms = 0.0
-        iters_done = 0
+        iters_done = spmvs_done = 0
         for _ in range(steps):
             st = step()
             solve_ms += st.solve_ms
             iters_done += st.iterations
+            spmvs_done += st.spmv_count
         barrier()
         elapsed = time.perf_counter() - t0
         _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
@@ -233,77 +313,90 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_comm else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        # one "DOF update" = one Krylov step on one unknown: a CG iteration (1 SpMV), or one SpMV-equivalent step of BiCGStab(2)
+        updates = iters_done if cfg["solver"] == "cg" else spmvs_done
         res = {"N": N, "nx_global": nx_global, "n_global": n_global, "nnz": A.nnz, "n_local": A.n, "elapsed": elapsed,
-               "steps": steps, "solve_ms": solve_ms, "iters_done": iters_done, "spmv_ms": tot.value / max(cnt.value, 1),
-               "spmv_launches": int(cnt.value)}
+               "steps": steps, "solve_ms": solve_ms, "iters_done": iters_done, "spmvs_done": spmvs_done, "updates": updates,
+               "spmv_ms": tot.value / max(cnt.value, 1), "spmv_launches": int(cnt.value)}
         if rank == 0:
-            assert iters_done == args.iters * steps, (iters_done, args.iters, steps)
+            if cfg["solver"] == "cg":
+                assert iters_done == args.iters * steps, (iters_done, args.iters, steps)
             csr_bytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
             mode, slots, npad, reg = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
             _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
-            sym_used = False
+            ent, symf, byts = C.c_int64(), C.c_int32(), C.c_int64()
+            _lib.check(_lib.lib.mfem_csr_solver_layout_entries(ctx._h, A._h, C.byref(ent), C.byref(symf)))
+            _lib.check(_lib.lib.mfem_csr_solver_layout_bytes(ctx._h, A._h, C.byref(byts)))
+            sym_used = bool(symf.value) and int(_lib.lib.mfem_debug_sym_spmv_count()) > sym_count0
             plain_bytes = None
+            spmv_bytes = byts.value
             if mode.value == 2:
                 # diagonal-slotted blocks read no column stream: 8 B per nonzero + x, y; rows in generic blocks also read 4 B columns
-                kernel = "k_spmv_dia<2,3> (SpMV on the slot-major copy of the CSR matrix made once per solve; diagonal-slotted blocks)"
-                spmv_bytes = A.nnz * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
-                ent, symf = C.c_int64(), C.c_int32()
-                _lib.check(_lib.lib.mfem_csr_solver_layout_entries(ctx._h, A._h, C.byref(ent), C.byref(symf)))
-                sym_used = bool(symf.value) and int(_lib.lib.mfem_debug_sym_spmv_count()) > sym_count0
-                if sym_used:
-                    # symmetric sweep: the lower-diagonal entries a workgroup still holds in LDS are not read again; `ent` = 8-byte
-                    # matrix values one SpMV reads from memory (27 slots per padded row minus the mirrored ones)
-                    if symf.value == 2:
-                        kernel = ("k_spmv_symp<0> (one launch: the sweep, then the two boundary planes row by row): symmetric sweep on wave-private "
-                                  "(j, k) patches of a patch-major copy of the CSR matrix made once per solve; the values passed the "
-                                  "per-solve bitwise symmetry check, so 10.5 of a row's 13 lower-diagonal entries are mirrored through "
-                                  "LDS (bitwise the same y as the plain diagonal-slotted kernel); x staged per lattice plane in LDS")
-                    else:
-                        kernel = ("k_spmv_sym27 (+ k_spmv_dia<2,3> on the two boundary planes): SpMV on the slot-major copy of the CSR "
-                                  "matrix made once per solve; the values passed the per-solve bitwise symmetry check, so lower-diagonal "
-                                  "entries are mirrored through LDS (bitwise the same y as the plain diagonal-slotted kernel)")
-                    plain_bytes = spmv_bytes
-                    byts = C.c_int64()
-                    _lib.check(_lib.lib.mfem_csr_solver_layout_bytes(ctx._h, A._h, C.byref(byts)))
-                    spmv_bytes = byts.value  # matrix entries read + columns of generic blocks + x as staged / read by design + y
+                kernel, kkey = "k_spmv_dia (SpMV on the slot-major copy of the CSR matrix made once per solve; diagonal-slotted blocks)", "k_spmv_dia"
+                plain = A.nnz * 8 + A.n * 16 + max(A.n - reg.value, 0) * slots.value * 4
+                if sym_used and symf.value == 2:
+                    kernel = ("k_spmv_symp<0> (one launch: the sweep, then the two boundary planes row by row): symmetric sweep on wave-private "
+                              "(j, k) patches of a patch-major copy of the CSR matrix made once per solve; the values passed the "
+                              "per-solve bitwise symmetry check, so 10.5 of a row's 13 lower-diagonal entries are mirrored through "
+                              "LDS (bitwise the same y as the plain diagonal-slotted kernel); x staged per lattice plane in LDS")
+                    kkey, plain_bytes = "k_spmv_symp", plain
+                elif sym_used:
+                    kernel = ("k_spmv_sym27 (+ k_spmv_dia on the two boundary planes): SpMV on the slot-major copy of the CSR "
+                              "matrix made once per solve; the values passed the per-solve bitwise symmetry check, so lower-diagonal "
+                              "entries are mirrored through LDS (bitwise the same y as the plain diagonal-slotted kernel)")
+                    kkey, plain_bytes = "k_spmv_sym27", plain
+                else:
+                    spmv_bytes = plain
             elif mode.value == 1:
-                kernel = "k_spmv_ell<2,1> (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)"
-                spmv_bytes = A.nnz * 12 + A.n * 16
+                kernel, kkey = "k_spmv_ell (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)", "k_spmv_ell"
+            elif mode.value == 3:
+                kernel, kkey = ("k_spmv_sell (rows sorted by length and diagonal-list signature, SELL-128 copy made once per solve; blocks "
+                                "whose rows share one diagonal list read no columns)"), "k_spmv_sell"
             else:
-                kernel = "mfem_spmv_csr kernel (CSR SpMV, i64 rowptr / i32 col / f64 val)"
-                spmv_bytes = csr_bytes
-            res.update(kernel=kernel, spmv_bytes=spmv_bytes, csr_bytes=csr_bytes, mode=mode.value, sym_used=sym_used,
-                       sym_kind=(int(symf.value) if sym_used else 0), plain_bytes=plain_bytes)
+                kernel, kkey = "mfem_spmv_csr kernel (CSR SpMV, i64 rowptr / i32 col / f64 val)", "csr_kernel"
+                spmv_bytes = A.spmv_bytes()[0]
+            res.update(kernel=kernel, kernel_key=kkey, spmv_bytes=spmv_bytes, csr_bytes=csr_bytes, mode=mode.value, sym_used=sym_used,
+                       plain_bytes=plain_bytes)
             if want_csr and world == 1:
-                res["csr_kernel"] = csr_kernel_roofline(A, K)
+                res["csr_kernel"] = csr_kernel_roofline(A, K, f"{args.config}_{N}")
         if comm is not None:
             comm.close()
         del brick, A, K, x_star, s, R
         torch.cuda.empty_cache()
         return res
 
+    def solver_roofline(r, wkey):
+        achieved = r["spmv_bytes"] / (r["spmv_ms"] * 1e-3) / 1e9
+        csr_equiv = r["csr_bytes"] / (r["spmv_ms"] * 1e-3) / 1e9
+        traffic, src = traffic_of(f"{r['kernel_key']}@{wkey}") if world == 1 else (None, None)
+        return {
+            "kernel": r["kernel"],
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "traffic_over_algorithmic": (traffic / r["spmv_bytes"]) if traffic else None,
+            "frac_actual": (traffic / (r["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "algorithmic_bytes_per_launch": r["spmv_bytes"], "avg_launch_ms": r["spmv_ms"], "launches": r["spmv_launches"],
+            **({"plain_diagonal_kernel_bytes_per_launch": r["plain_bytes"],
+                "note": "algorithmic bytes = what this kernel design reads: 8 B per matrix entry not mirrored from LDS "
+                        "(14 upper-diagonal entries per row + the patch-edge entries; workgroup-tile sweep: about 18.6 of 27) "
+                        "+ x as the kernel stages it (patch sweep: overlapping patch neighbourhoods, 1.6 n entries) + y "
+                        "(mfem_csr_solver_layout_bytes); the plain diagonal-slotted kernel reads "
+                        "plain_diagonal_kernel_bytes_per_launch"}
+               if r["sym_used"] else {}),
+            "csr_equivalent": {"bytes_per_launch": r["csr_bytes"], "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
+                               "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
+                                       "kernel would have to sustain to match this time"},
+        }
+
     main_res = run_workload(args.n, args.steps, args.warmup, want_csr=True)
 
     if rank == 0:
         r = main_res
-        value = r["n_global"] * args.iters * r["steps"] / r["elapsed"]
-        achieved = r["spmv_bytes"] / (r["spmv_ms"] * 1e-3) / 1e9
-        csr_equiv = r["csr_bytes"] / (r["spmv_ms"] * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-        if os.path.exists(tpath) and args.n == 256 and world == 1:  # PMC traffic was measured on this single-GPU workload
-            try:
-                tj = json.load(open(tpath))
-                same = tj.get("solver_layout_mode") == r["mode"] and int(tj.get("symmetric_sweep", 0)) == r["sym_kind"]
-                traffic = tj.get("hbm_bytes_per_launch") if same else None
-                if traffic is not None:
-                    traffic_source = ("profiles/spmv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on "
-                                      "this workload (gfx950 x2 FETCH_SIZE correction), not collected in this run")
-            except Exception:
-                traffic = None
+        per_step_updates = r["updates"] / r["steps"]
+        value = r["n_global"] * r["updates"] / r["elapsed"]
         solve_ms_step = r["solve_ms"] / r["steps"]
         out = {
-            "metric": "DOF-updates/sec (assembly+CG iter) on 3D hex thermal conduction",
+            "metric": cfg["metric"],
             "value": value,
             "unit": "DOF-updates/s",
             "n_gpus": world,
@@ -316,66 +409,53 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"3D thermal conduction, linear hex-8, {r['nx_global']}x{args.n}x{args.n} structured mesh "
-                            f"(make_Brick), Robin on 6 faces: fused assembly (K + R) + {args.iters} Jacobi-CG iterations per step",
-                "n_dof": r["n_global"], "nnz_per_gpu": r["nnz"], "cg_iters_per_step": args.iters,
+                "workload": f"{cfg['title']}, {r['nx_global']}x{args.n}x{args.n} structured mesh (make_Brick): fused assembly (K + R) + "
+                            + (f"{args.iters} Jacobi-CG iterations per step" if cfg["solver"] == "cg" else
+                               f"{max(args.iters // 4, 1)} BiCGStab(2) sweeps (bicgstabl_GS!, right Jacobi) = {per_step_updates:.0f} SpMV-equivalent steps per step"),
+                "baseline_config": {"c2": "the north_star target size (512^3 hex-8, 1 GPU); configs[1] (256^3) is `secondary_256`",
+                                    "c3": "configs[2]", "c4": "configs[3]"}[args.config] if args.n == cfg["n"] else f"{args.config} at a non-default size",
+                "n_dof": r["n_global"], "nnz_per_gpu": r["nnz"], "krylov_steps_per_step": per_step_updates,
                 "parallelism": "single GPU" if world == 1 else f"slab decomposition x{world} (RCCL halo overlapped with the interior "
-                                                               f"rows + one all-reduce per CG iteration)",
+                                                               f"rows + one all-reduce per reduction group)",
                 "solve_ms_per_step": solve_ms_step,
                 # the two halves of the metric on their own (whole job, all ranks)
                 "assembly_ms_per_step": r["elapsed"] / r["steps"] * 1e3 - solve_ms_step,
                 "assembly_dof_per_s": r["n_global"] / max(r["elapsed"] / r["steps"] - solve_ms_step * 1e-3, 1e-12),
-                "solve_dof_updates_per_s": r["n_global"] * args.iters / (solve_ms_step * 1e-3),
+                "solve_dof_updates_per_s": r["n_global"] * per_step_updates / (solve_ms_step * 1e-3),
             },
-            "roofline": {
-                "kernel": r["kernel"],
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": r["spmv_bytes"], "avg_launch_ms": r["spmv_ms"], "launches": r["spmv_launches"],
-                **({"plain_diagonal_kernel_bytes_per_launch": r["plain_bytes"],
-                    "note": "algorithmic bytes = what this kernel design reads: 8 B per matrix entry not mirrored from LDS "
-                            "(14 upper-diagonal entries per row + the patch-edge entries; workgroup-tile sweep: about 18.6 of 27) "
-                            "+ x as the kernel stages it (patch sweep: overlapping patch neighbourhoods, 1.6 n entries) + y "
-                            "(mfem_csr_solver_layout_bytes); the plain diagonal-slotted kernel reads "
-                            "plain_diagonal_kernel_bytes_per_launch"}
-                   if r["sym_used"] else {}),
-                "csr_equivalent": {"bytes_per_launch": r["csr_bytes"], "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
-                                   "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
-                                           "kernel would have to sustain to match this time"},
-            },
+            "roofline": solver_roofline(r, f"{args.config}_{args.n}"),
         }
         if "csr_kernel" in r:
-            # the north_star's own number: the CSR kernel behind mul! on this matrix, SURVEY 8(d) bytes, measured in this run
+            # the north_star's own number: the CSR kernel behind mul! on this matrix, measured in this run
             out["roofline"]["csr_kernel"] = r["csr_kernel"]
-    if world == 1 and args.target_n > 0 and args.target_n != args.n:
-        # the configuration the north_star's target is quoted on (512^3 hex-8, 135 M DOF, int64 row pointers): a short run
-        t = run_workload(args.target_n, args.target_steps, 1, want_csr=True)
-        tv = t["n_global"] * args.iters * t["steps"] / t["elapsed"]
-        out["target_512" if args.target_n == 512 else f"target_{args.target_n}"] = {
-            "workload": f"3D thermal conduction, linear hex-8, {args.target_n}^3, {t['steps']} timed steps after 1 warm-up, same step as above",
+    if world == 1 and args.config == "c2" and args.secondary_n > 0 and args.secondary_n != args.n:
+        # configs[1] of BASELINE.json (256^3 hex-8; also the matrix the round-1 / round-2 lines were quoted on)
+        t = run_workload(args.secondary_n, args.secondary_steps, 1, want_csr=True)
+        tv = t["n_global"] * t["updates"] / t["elapsed"]
+        out[f"secondary_{args.secondary_n}"] = {
+            "workload": f"{cfg['title']}, {args.secondary_n}^3 (BASELINE.json configs[1]), {t['steps']} timed steps after 1 warm-up, same step as above",
             "value": tv, "unit": "DOF-updates/s", "n_dof": t["n_global"], "nnz": t["nnz"], "ms_per_step": t["elapsed"] / t["steps"] * 1e3,
-            "solver_spmv": {"kernel": t["kernel"], "avg_launch_ms": t["spmv_ms"], "algorithmic_bytes_per_launch": t["spmv_bytes"],
-                            "frac": t["spmv_bytes"] / (t["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "csr_equivalent_frac": t["csr_bytes"] / (t["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": solver_roofline(t, f"c2_{args.secondary_n}"),
             "csr_kernel": t.get("csr_kernel"),
         }
-    if rank == 0 and world == 1 and args.hex27_n > 0:
+    if rank == 0 and world == 1 and args.config == "c2" and args.hex27_n > 0:
         # the CSR kernel on the other matrix shape of the configs: hex-27 (27..125 entries per row), configs[3]'s size
         try:
             b27 = mf.Brick((1.0, 1.0, 1.0), (args.hex27_n,) * 3, 2, 5, ctx=ctx)
             A27 = b27.pattern(1)
             K27 = b27.assemble_thermal(A27, K_COND, H, TENV, mf.ALL_FACES)
-            out["roofline"]["csr_kernel_hex27"] = dict(csr_kernel_roofline(A27, K27), matrix=f"hex-27 thermal {args.hex27_n}^3")
+            out["roofline"]["csr_kernel_hex27"] = dict(csr_kernel_roofline(A27, K27, f"c4_{args.hex27_n}"), matrix=f"hex-27 thermal {args.hex27_n}^3")
             del b27, A27, K27
             torch.cuda.empty_cache()
         except Exception as e:  # never lose the line over a side measurement
             out["roofline"]["csr_kernel_hex27"] = {"error": repr(e)}
     if rank == 0:
-        if world == 1 and args.cpu_n > 0:
+        if world == 1 and args.config == "c2" and args.cpu_n > 0:
             cb = cpu_baseline(args.cpu_n, args.iters, args.cpu_repeats)
             out["cpu_baseline"] = cb
+            sk = f"secondary_{args.secondary_n}"
             out["vs_cpu_baseline"] = {"main_workload": out["value"] / cb["value"],
-                                      **({"target_512": out["target_512"]["value"] / cb["value"]} if "target_512" in out else {}),
+                                      **({sk: out[sk]["value"] / cb["value"]} if sk in out else {}),
                                       "note": "GPU whole-step throughput / CPU-port whole-step throughput (same step definition, same CG "
                                               "iterations per assembly; the CPU sample is a smaller mesh, see cpu_baseline.sample)"}
         else:

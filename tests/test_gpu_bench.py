@@ -1,0 +1,80 @@
+"""bench.py end to end on one GPU, as child processes (started before they touch the GPU; never re-exec'ed): the single-GPU line, the
+N > 1 launch path with the ranks sharing cuda:0 through the host-callback communicator (functional, not a measurement), the RCCL path
+with world = 1 (communicator, ring self-test, split SpMV schedule), and the c3 / c4 legs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "0", "--secondary-n", "0", "--cpu-n", "0", "--hex27-n", "0"]
+
+
+def run_bench(args, env=None, timeout=900):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=e,
+                       cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0, f"rc={r.returncode}\n--- stdout ---\n{r.stdout[-2000:]}\n--- stderr ---\n{r.stderr[-4000:]}"
+    assert len(lines) == 1, f"stdout must carry ONE JSON line, got {len(lines)}:\n{r.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+def _common(out, n_gpus, steps=1):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == n_gpus and out["steps"] == steps and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["dtype"] == "f64" and out["vs_baseline"] is None and "workload" in out["config"]
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert 0 < rf["frac"] < 1.0
+
+
+def test_single_gpu_line_has_every_object():
+    out = run_bench(["--n", "40", "--steps", "2", "--warmup", "1", "--secondary-n", "24", "--secondary-steps", "1", "--hex27-n", "8", "--cpu-n", "12",
+                     "--cpu-repeats", "1", "--iters", "30"])
+    _common(out, 1, steps=2)
+    assert out["config"]["n_dof"] == 41 ** 3 and out["config"]["krylov_steps_per_step"] == 30
+    ck = out["roofline"]["csr_kernel"]
+    assert ck["column_entries_read"] <= ck["nnz"] and ck["algorithmic_bytes_per_launch"] <= ck["csr_equivalent"]["bytes_per_launch"]
+    assert ck["frac"] <= ck["csr_equivalent"]["frac"] and "frac_actual" in ck and "traffic_over_algorithmic" in ck
+    assert "csr_kernel_hex27" in out["roofline"] and "error" not in out["roofline"]["csr_kernel_hex27"]
+    sec = out["secondary_24"]
+    assert sec["n_dof"] == 25 ** 3 and sec["value"] > 0 and 0 < sec["roofline"]["frac"] < 1
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert out["vs_cpu_baseline"]["main_workload"] > 0
+
+
+def test_two_ranks_on_one_gpu_through_the_host_transport():
+    out = run_bench(["--gpus", "2", "--n", "48"] + SMALL, env={"MFEM_BENCH_HOST_COMM": "1"})
+    _common(out, 2)
+    assert out["config"]["n_dof"] == 97 * 49 * 49 and "slab decomposition x2" in out["config"]["parallelism"]
+    assert out["cpu_baseline"] is None
+
+
+def test_rccl_world1_through_the_whole_bench_path():
+    out = run_bench(["--gpus", "1", "--n", "48"] + SMALL, env={"MFEM_BENCH_FORCE_COMM": "1"})
+    _common(out, 1)
+    assert out["config"]["n_dof"] == 49 ** 3
+
+
+@pytest.mark.parametrize("config,n,iters,ndof", [("c3", 16, 40, 3 * 33 * 17 * 17), ("c4", 8, 20, 33 * 17 * 17)])
+def test_c3_c4_legs_with_two_ranks(config, n, iters, ndof):
+    out = run_bench(["--config", config, "--gpus", "2", "--n", str(n), "--iters", str(iters)] + SMALL, env={"MFEM_BENCH_HOST_COMM": "1"})
+    _common(out, 2)
+    assert out["config"]["n_dof"] == ndof
+    assert out["config"]["krylov_steps_per_step"] >= iters * 0.9
+
+
+@pytest.mark.parametrize("config,n,ndof", [("c3", 24, 3 * 25 ** 3), ("c4", 12, 25 ** 3)])
+def test_c3_c4_legs_single_gpu(config, n, ndof):
+    out = run_bench(["--config", config, "--n", str(n), "--iters", "40"] + SMALL)
+    _common(out, 1)
+    assert out["config"]["n_dof"] == ndof and "csr_kernel" in out["roofline"]

@@ -1,0 +1,47 @@
+"""One workload for the rocprofv3 --pmc passes of round 3 (tools/run_pmc_r03.sh): build the matrix of a BASELINE config, run its
+assembly kernels, a few launches of the CSR kernel behind mul!, one short solve on the solver layout and a calibration kernel of
+known bytes (mfem_axpby: 2 vectors read, 1 written).
+usage: pmc_leg.py c2_256 | c2_512 | c3_128 | c4_128 [launches]"""
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import metafem_jl_amd as mf
+
+leg = sys.argv[1]
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cfg, N = leg.split("_")
+N = int(N)
+lam, mu = 0.5769230769230769, 0.38461538461538464
+if cfg == "c2":
+    b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 1, 3)
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    s = torch.full((A.n,), 1600.0, dtype=torch.float64, device="cuda")
+    R = b.residual_thermal(torch.zeros(A.n, dtype=torch.float64, device="cuda"), 0.6, 25.0, 293.15, 0x3F, s=s)
+    solve = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, maxiter=20, max_pass=1, fixed_iterations=True)
+elif cfg == "c3":
+    b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 1, 3)
+    A = b.pattern(3)
+    K = b.assemble_elasticity(A, lam, mu, 1000.0, mf.FACE_BITS["x0"])
+    R = b.residual_elasticity(torch.zeros(A.n, dtype=torch.float64, device="cuda"), lam, mu, 1000.0, mf.FACE_BITS["x0"], mf.FACE_BITS["y1"],
+                              (0.0, 1.0, 0.0, 0.0, 0.0, 0.0))
+    solve = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.bicgstabl_GS_, maxiter=12, max_pass=1, s=2, fixed_iterations=True)
+else:
+    b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 2, 5)
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    s = torch.full((A.n,), 1600.0, dtype=torch.float64, device="cuda")
+    R = b.residual_thermal(torch.zeros(A.n, dtype=torch.float64, device="cuda"), 0.6, 25.0, 293.15, 0x3F, s=s)
+    solve = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, maxiter=20, max_pass=1, fixed_iterations=True)
+x = mf.FEM_rand(A.n, 3, 0)
+y = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+for _ in range(L):
+    mf.mul_(y, A, K, x)
+for _ in range(3):
+    mf.axpby_(0.5, x, 0.25, y)  # calibration: 2 n doubles read, n written
+solve()
+torch.cuda.synchronize()
+byts, cols = A.spmv_bytes()
+print("LEG", leg, "n", A.n, "nnz", A.nnz, "csr_design_bytes", byts, "cols_read", cols)
