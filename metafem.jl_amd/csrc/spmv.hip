@@ -919,9 +919,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_csr_cols_read(int64_t n, int64_t
       el = flag ? (int)flag[t] : 0;
       lead = 128;
     }
-    const int64_t s = ((int64_t)rowptr[r0] - base) & ~(int64_t)1, e = (int64_t)rowptr[r1] - base;
-    const int64_t cnt = e - s;
-    acc += (unsigned long long)(el ? (cnt < lead ? cnt : lead) : cnt);
+    const int64_t s0 = (int64_t)rowptr[r0] - base, e = (int64_t)rowptr[r1] - base;
+    const int64_t staged = e - (s0 & ~(int64_t)1);  // the staged run starts on an even entry
+    acc += (unsigned long long)(el ? (staged < lead ? staged : lead) : e - s0);
   }
   acc = (unsigned long long)wave_reduce_sum((double)acc);  // exact below 2^53
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);

@@ -8,23 +8,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _lattice_csr(m, shift=0):
-    """27-point stencil pattern on an m^3 lattice (k fastest); `shift` != 0 drops one in-line neighbour of every row instead."""
-    idx = np.arange(m ** 3).reshape(m, m, m)
+def _lattice_csr(m):
+    """27-point stencil pattern on an m[0] x m[1] x m[2] lattice (last index fastest)."""
+    import scipy.sparse as sp
+
+    if isinstance(m, int):
+        m = (m, m, m)
+    m0, m1, m2 = m
+    idx = np.arange(m0 * m1 * m2).reshape(m0, m1, m2)
     rows, cols = [], []
     for di in (-1, 0, 1):
         for dj in (-1, 0, 1):
             for dk in (-1, 0, 1):
-                if shift and (di, dj, dk) == (0, 0, shift):
-                    continue
-                src = idx[max(0, -di):m - max(0, di), max(0, -dj):m - max(0, dj), max(0, -dk):m - max(0, dk)]
-                dst = idx[max(0, di):m - max(0, -di), max(0, dj):m - max(0, -dj), max(0, dk):m - max(0, -dk)]
+                src = idx[max(0, -di):m0 - max(0, di), max(0, -dj):m1 - max(0, dj), max(0, -dk):m2 - max(0, dk)]
+                dst = idx[max(0, di):m0 - max(0, -di), max(0, dj):m1 - max(0, -dj), max(0, dk):m2 - max(0, -dk)]
                 rows.append(src.ravel())
                 cols.append(dst.ravel())
-    import scipy.sparse as sp
-
     rows, cols = np.concatenate(rows), np.concatenate(cols)
-    M = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(m ** 3, m ** 3))
+    M = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(idx.size, idx.size))
     M.sort_indices()
     return M.indptr.astype(np.int64), M.indices.astype(np.int32)
 
@@ -34,9 +35,8 @@ def test_spmv_bytes_counts_the_columns_the_kernel_reads(mf):
     mfem_csr_spmv_bytes says how many (bench.py prices the launch with it)."""
     import torch
 
-    m = 40
-    rowptr, cols = _lattice_csr(m)
-    n, nnz = m ** 3, cols.size
+    rowptr, cols = _lattice_csr((9, 10, 300))  # 300-point lattice lines: 64-row tiles inside a line repeat one offset list
+    n, nnz = 9 * 10 * 300, cols.size
     A = mf.FEM_SpMat_CSR(torch.tensor(rowptr, device="cuda"), torch.tensor(cols, device="cuda"), n)
     byts, cread = A.spmv_bytes()
     assert 0 < cread < nnz  # some tiles elided ...
@@ -119,14 +119,18 @@ def test_row_owner_assembly_refuses_collapsed_elements_and_the_host_falls_back(m
     coords = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [2.0, 0.5]])
     cp = np.array([[0, 1, 2, 3], [1, 4, 3, 4]]).T  # [itp, nel], basis (tensor) order
     wf = physics.thermal_domain(2, 0.6)
+    zero_s = lambda d: d.controlpoints.__setitem__("s", torch.zeros(5, dtype=torch.float64, device="cuda"))
     dom = generic.GenericDomain(ctx, space, coords, cp, 1, wf, [], row_owner=True)
+    zero_s(dom)
     dom.K_linear_func()
     K_rows = dom.K_linear.cpu().numpy().copy()
     assert dom.row_owner is False  # fell back
     dom2 = generic.GenericDomain(ctx, space, coords, cp, 1, wf, [], row_owner=False)
+    zero_s(dom2)
     dom2.K_linear_func()
     assert np.allclose(K_rows, dom2.K_linear.cpu().numpy(), rtol=1e-13, atol=1e-15)
     dom3 = generic.GenericDomain(ctx, space, coords, cp, 1, wf, [], fused=False)
+    zero_s(dom3)
     dom3.K_linear_func()
     assert np.allclose(K_rows, dom3.K_linear.cpu().numpy(), rtol=1e-12, atol=1e-14)
     assert np.abs(K_rows).max() > 0

@@ -43,7 +43,7 @@ KEYS = [  # (kernel key of bench.py, substrings of the kernels one "launch" cons
 ASSEMBLY = ["k_thermal_matrix", "k_thermal_residual", "k_elasticity_matrix", "k_elasticity_residual", "k_elast", "k_hex27", "k_dia_vals", "k_ell_vals",
             "k_sell_vals", "k_symp_bind", "k_jacobi", "k_ell_diag", "k_sell_diag", "k_mat_div"]
 out = {}
-legs = sorted({os.path.basename(p).rsplit("_", 1)[0] for p in glob.glob(os.path.join(src, "*_FETCH_SIZE"))})
+legs = sorted({os.path.basename(p)[:-len("_FETCH_SIZE")] for p in glob.glob(os.path.join(src, "*_FETCH_SIZE"))})
 for leg in legs:
     F = means(os.path.join(src, leg + "_FETCH_SIZE"))
     W = means(os.path.join(src, leg + "_WRITE_SIZE"))
