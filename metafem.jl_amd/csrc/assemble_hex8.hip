@@ -966,6 +966,44 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   }
 }
 
+// Surface terms of the elasticity residual at control point (i, j, k): tau (0 - u_i) on penalty faces, sig_ij n_j on traction faces
+// (cantilever/3D_Script.jl:60-61), added to r[3].
+__device__ __forceinline__ void elasticity_face_residual(const BrickView& B, int i, int j, int k, double tau, uint32_t penalty, uint32_t traction,
+                                                         double s11, double s22, double s33, double s23, double s13, double s12,
+                                                         const double* __restrict__ x, double (&r)[3]) {
+  const uint32_t both = penalty | traction;
+  if (both != 0u) {
+    const double sg[3][3] = {{s11, s12, s13}, {s12, s22, s23}, {s13, s23, s33}};
+    visit_boundary_faces(B, i, j, k, both, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
+      const bool pen = (penalty & face_bit(nd, side)) != 0u && tau != 0.0;
+      const bool tra = (traction & face_bit(nd, side)) != 0u;
+      double uf[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) uf[c][f] = x[brick_xindex(B, f, fn[c][0], fn[c][1], fn[c][2])];
+      for (int q = 0; q < B.ng * B.ng; ++q) {
+        double nrm[3];
+        const double ws = face_geom(Xf, q, side == 0, nrm);
+        double na = 0.0, uq[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          na = (c == ca) ? c_fN[q][c] : na;
+#pragma unroll
+          for (int f = 0; f < 3; ++f) uq[f] += c_fN[q][c] * uf[c][f];
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          double v = 0.0;
+          if (pen) v += tau * (0.0 - uq[f]);
+          if (tra) v += sg[f][0] * nrm[0] + sg[f][1] * nrm[1] + sg[f][2] * nrm[2];
+          r[f] += ws * na * v;
+        }
+      }
+    });
+  }
+}
+
 // Residual at x_star (matrix-free):
 //   R[(i,a)] = -sum_q w sigma_ij(u) d_jN_a + sum_q w^s N_a [ tau (0 - u_i) |penalty faces + sig_ij n_j |traction faces ]
 __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_residual(BrickView B, double lam, double mu, double tau,
@@ -1023,39 +1061,117 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_residual(BrickView B,
       }
     }
   }
-  const uint32_t both = penalty | traction;
-  if (both != 0u) {
-    const double sg[3][3] = {{s11, s12, s13}, {s12, s22, s23}, {s13, s23, s33}};
-    visit_boundary_faces(B, i, j, k, both, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
-      const bool pen = (penalty & face_bit(nd, side)) != 0u && tau != 0.0;
-      const bool tra = (traction & face_bit(nd, side)) != 0u;
-      double uf[4][3];
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int f = 0; f < 3; ++f) uf[c][f] = x[brick_xindex(B, f, fn[c][0], fn[c][1], fn[c][2])];
-      for (int q = 0; q < B.ng * B.ng; ++q) {
-        double nrm[3];
-        const double ws = face_geom(Xf, q, side == 0, nrm);
-        double na = 0.0, uq[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          na = (c == ca) ? c_fN[q][c] : na;
-#pragma unroll
-          for (int f = 0; f < 3; ++f) uq[f] += c_fN[q][c] * uf[c][f];
-        }
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-          double v = 0.0;
-          if (pen) v += tau * (0.0 - uq[f]);
-          if (tra) v += sg[f][0] * nrm[0] + sg[f][1] * nrm[1] + sg[f][2] * nrm[2];
-          r[f] += ws * na * v;
-        }
-      }
-    });
-  }
+  elasticity_face_residual(B, i, j, k, tau, penalty, traction, s11, s22, s33, s23, s13, s12, x, r);
 #pragma unroll
   for (int f = 0; f < 3; ++f) res[(int64_t)f * B.n_owned + node] = r[f];
+}
+
+// The same residual in the plane-sweep form of the thermal kernels (k_thermal_residual_sweep): a workgroup owns a 15 x 15 tile of
+// control points in (j, k) and sweeps it through a segment of lattice planes; per element plane, phase A: thread <-> element of the
+// 16 x 16 element tile -- ONE sum-factorised integration per element (sf_elasticity_fe; the kernel above integrates an element once
+// per adjacent control point: 8 x the geometry), fe[3][8] to LDS; phase B: thread <-> control point adds the four elements above
+// it to what it carried over from the four below.  Fixed summation order (elements (ey, ez) ascending, lower plane first), so a slab
+// computes bitwise what the global mesh computes.  Surface terms: k_elasticity_residual_faces, one thread per boundary control point.
+#define ESW_STRIDE 25
+template <int NG>
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_elasticity_residual_sweep(BrickView B, int L, double lam, double mu,
+                                                                                                                 const double* __restrict__ x,
+                                                                                                                 double* __restrict__ res) {
+  __shared__ double Fe[SW_THREADS * ESW_STRIDE];
+  const int tid = threadIdx.x, ek = tid % SW_E, ej = tid / SW_E;
+  const SweepTile T = sweep_tile(B, L);
+  if (T.i0 >= T.i1) return;
+  const int J = T.tj0 - 1 + ej, K = T.tk0 - 1 + ek;  // phase A: this thread's element column
+  const bool el_ok = J >= 0 && J < B.ne1 && K >= 0 && K < B.ne2;
+  const int j = T.tj0 + ej, k = T.tk0 + ek;          // phase B: this thread's control point column
+  const bool nd_ok = ej < SW_N && ek < SW_N && j < B.m1 && k < B.m2;
+  double Xn[3][4], Un[3][4];  // the plane requested last (consumed at the top of the next step)
+  auto request = [&](int ip) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+      Xn[0][c] = B.X0[ci];
+      Xn[1][c] = B.X1[ci];
+      Xn[2][c] = B.X2[ci];
+#pragma unroll
+      for (int f = 0; f < 3; ++f) Un[f][c] = x[brick_xindex(B, f, ip, J + (c & 1), K + (c >> 1))];
+    }
+  };
+  double X[3][2][4], U[3][2][4];
+  const int Ifirst = max(T.i0 - 1, 0), Ilast = min(T.i1 - 1, B.ne0 - 1);  // element planes of this segment
+  if (el_ok) {
+    request(Ifirst);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X[d][1][c] = Xn[d][c];
+        U[d][1][c] = Un[d][c];
+      }
+    request(Ifirst + 1);
+  }
+  double carry[3] = {0.0, 0.0, 0.0};
+  for (int I = T.i0 - 1; I < T.i1; ++I) {
+    const bool plane = I >= 0 && I < B.ne0;  // workgroup-uniform
+    if (plane && el_ok) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // last step's upper nodes are this step's lower ones; the requested plane arrives
+          X[d][0][c] = X[d][1][c];
+          U[d][0][c] = U[d][1][c];
+          X[d][1][c] = Xn[d][c];
+          U[d][1][c] = Un[d][c];
+        }
+      double fe[3][2][4];
+      sf_elasticity_fe<NG>(X, U, lam, mu, fe);
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          Fe[tid * ESW_STRIDE + f * 8 + 2 * c] = fe[f][0][c];
+          Fe[tid * ESW_STRIDE + f * 8 + 2 * c + 1] = fe[f][1][c];
+        }
+      if (I < Ilast) request(I + 2);  // in flight during phase B and the two barriers
+    }
+    __syncthreads();
+    if (nd_ok) {
+      double lo[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 0.0, 0.0};
+      if (plane) {
+#pragma unroll
+        for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+          for (int ey = 0; ey < 2; ++ey) {
+            const int Jn = j - 1 + ey, Kn = k - 1 + ez;
+            if (Jn < 0 || Jn >= B.ne1 || Kn < 0 || Kn >= B.ne2) continue;
+            const double* fp = Fe + ((ej + ey) * SW_E + ek + ez) * ESW_STRIDE + 2 * ((1 - ey) + 2 * (1 - ez));
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+              lo[f] += fp[f * 8];
+              up[f] += fp[f * 8 + 1];
+            }
+          }
+      }
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        if (I >= T.i0) res[(int64_t)f * B.n_owned + (int64_t)(I - B.plo) * B.plane_len + (int64_t)j * B.m2 + k] = carry[f] + lo[f];
+        carry[f] = up[f];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_residual_faces(BrickView B, double tau, uint32_t penalty, uint32_t traction,
+                                                                            double s11, double s22, double s33, double s23, double s13,
+                                                                            double s12, const double* __restrict__ x, double* __restrict__ res) {
+  int i, j, k;
+  if (!boundary_point(B, i, j, k)) return;
+  double r[3] = {0.0, 0.0, 0.0};
+  elasticity_face_residual(B, i, j, k, tau, penalty, traction, s11, s22, s33, s23, s13, s12, x, r);
+  const int64_t node = (int64_t)(i - B.plo) * B.plane_len + (int64_t)j * B.m2 + k;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) res[(int64_t)f * B.n_owned + node] += r[f];
 }
 
 int mfem_hex8_upload_tables(int ng);
@@ -1120,10 +1236,10 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
   return MFEM_OK;
 }
 
-static int g_elasticity_variant = 0;  // 1: the row-owner kernel with in-place global accumulation (kept for comparison)
+static int g_elasticity_variant = 0;  // bit 0: the matrix row-owner kernel with in-place global accumulation; bit 1: the residual kernel that integrates per adjacent control point (both kept for comparison)
 extern "C" int mfem_debug_set_elasticity(int variant) {
   ++mfem_debug_epoch;
-  g_elasticity_variant = variant ? 1 : 0;
+  g_elasticity_variant = variant & 3;
   return MFEM_OK;
 }
 
@@ -1136,7 +1252,7 @@ extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mf
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 3);
   const int64_t T = A->nnz / 9;
-  if (g_elasticity_variant == 0) {  // one thread per (control point, element), rows accumulated in LDS, written once
+  if (!(g_elasticity_variant & 1)) {  // one thread per (control point, element), rows accumulated in LDS, written once
     const int grid = (int)((m->n_owned + EL2_NODES - 1) / EL2_NODES);
     hipLaunchKernelGGL(k_elasticity_matrix_lds, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,
                        p->penalty_faces, T, vals);
@@ -1158,6 +1274,20 @@ extern "C" int mfem_brick_residual_elasticity(mfem_context ctx, mfem_brick m, co
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 3);
+  // plane sweep, one integration per element: the 2-point rule (itg_order 2-3, every BASELINE config); the 3-point rule's 27 Gauss points
+  // of three fields do not fit the register file of this form (it spills 2 KB per lane) and keep the kernel below
+  if (!(g_elasticity_variant & 2) && m->ng == 2) {
+    int64_t grid;
+    const int L = sweep_planes(m, &grid);
+    hipLaunchKernelGGL(k_elasticity_residual_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->lambda, p->mu, x_star, residue);
+    MFEM_CHECK_LAUNCH();
+    if (((p->penalty_faces && p->tau != 0.0) || p->traction_faces) != 0) {
+      hipLaunchKernelGGL(k_elasticity_residual_faces, boundary_grid(m), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->tau, p->penalty_faces,
+                         p->traction_faces, p->sig[0], p->sig[1], p->sig[2], p->sig[3], p->sig[4], p->sig[5], x_star, residue);
+      MFEM_CHECK_LAUNCH();
+    }
+    return MFEM_OK;
+  }
   const int grid = (int)((m->n_owned + MFEM_BLOCK - 1) / MFEM_BLOCK);
   hipLaunchKernelGGL(k_elasticity_residual, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,
                      p->penalty_faces, p->traction_faces, p->sig[0], p->sig[1], p->sig[2], p->sig[3], p->sig[4], p->sig[5],

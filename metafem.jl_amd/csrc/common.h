@@ -151,6 +151,7 @@ struct mfem_csr_s {
   // row-sorted sliced ELL for rows of uneven length (spmv_sell.hip): sell_state 0 = not planned, -1 = no, 1 = ready
   int sell_state;
   int64_t sell_total, sell_nblk;
+  int64_t sell_nb_int;      // leading blocks without a ghost-reading row (= sell_nblk for a pattern without ghost columns): the interior part of a split SpMV
   int32_t* sell_rowid;      // owned: sorted position -> row
   int64_t* sell_ptr;        // owned: [nblk + 1] start of each 128-row block in the sliced arrays
   int32_t* sell_cols;       // owned, [sell_total], 0-based
@@ -166,8 +167,8 @@ int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
 void mfem_sell_unbind(mfem_csr_s* A);
 void mfem_sell_free(mfem_csr_s* A);
 int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
-                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag);
-bool mfem_sell_bound(const mfem_csr_s* A, const double* vals);  // the sliced layout (rows permuted: no row split) serves these values
+                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part);
+bool mfem_sell_bound(const mfem_csr_s* A, const double* vals);  // the sliced layout (rows permuted; ghost-reading rows sorted last) serves these values
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
 int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);

@@ -287,6 +287,63 @@ SF_HD void sf_thermal_fe(const double (&X)[3][2][4], const double (&T)[2][4], co
   if (has_src) sf_ref_interp_T<NG>(S, fe);
 }
 
+// ---- elasticity residual of one element (examples/linear_elasticity/cantilever/3D_Script.jl:52-58, domain part):
+//   fe[i][a] = -sum_q w det sigma_ij(u) d_jN_a,   sigma = lam tr(eps) I + 2 mu eps,  eps = sym(grad u)
+// U[i] = nodal values of displacement component i.  Contracted in reference coordinates like the thermal residual: with R = adj J
+// (rows of det J^-1), grad u_i = R^T d(u_i)/dxi / det and fe[i][a] = sum_q sum_m dN_a/dxi_m(q) F_i[m][q] with F_i[m] = -w sum_j R[m][j] sigma_ij.
+template <int NG>
+SF_HD void sf_elasticity_fe(const double (&X)[3][2][4], const double (&U)[3][2][4], double lam, double mu, double (&fe)[3][2][4]) {
+  SfCols<NG> C;
+  sf_columns<NG>(X, C);
+  double u0[3][NG][NG], u1[3][NG][NG], u2[3][NG][NG];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sf_ref_grads<NG>(U[i], u0[i], u1[i], u2[i]);
+  // NG <= 2: all three fields in one pass over the Gauss points (F = 9 NG^3 doubles); larger rules: one field per pass, so that only
+  // 3 NG^3 doubles are live (grad u is recomputed per pass; the products are the same, so are the results)
+  constexpr int NP = NG <= 2 ? 1 : 3, NF = NG <= 2 ? 3 : 1;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    double F[NF][3][NG][NG][NG];  // [field][m]
+#pragma unroll
+    for (int qx = 0; qx < NG; ++qx)
+#pragma unroll
+      for (int qy = 0; qy < NG; ++qy)
+#pragma unroll
+        for (int qz = 0; qz < NG; ++qz) {
+          double R[3][3];
+          const double det = sf_adjugate<NG>(C, qx, qy, qz, R);
+          const double w = sf_w<NG>(qx) * sf_w<NG>(qy) * sf_w<NG>(qz);
+          const double idet = 1.0 / det;
+          double du[3][3];  // du[i][j] = d u_i / d x_j
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) du[i][j] = (R[0][j] * u0[i][qy][qz] + R[1][j] * u1[i][qx][qz] + R[2][j] * u2[i][qx][qy]) * idet;
+          const double tr = du[0][0] + du[1][1] + du[2][2];
+          // fe[i][a] = -sum_q w det sum_j sigma_ij (1/det) sum_m R[m][j] dN_a/dxi_m = sum_q sum_m dN_a/dxi_m ( -w sum_j R[m][j] sigma_ij )
+#pragma unroll
+          for (int fi = 0; fi < NF; ++fi) {
+            const int i = NP == 1 ? fi : pass;
+            double sg[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sg[j] = mu * (du[i][j] + du[j][i]);
+            sg[i] += lam * tr;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) F[fi][m][qx][qy][qz] = -w * (R[m][0] * sg[0] + R[m][1] * sg[1] + R[m][2] * sg[2]);
+          }
+        }
+#pragma unroll
+    for (int fi = 0; fi < NF; ++fi) {
+      const int i = NP == 1 ? fi : pass;
+#pragma unroll
+      for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fe[i][bx][c] = 0.0;
+      sf_ref_grads_T<NG>(F[fi], fe[i]);
+    }
+  }
+}
+
 // ---- thermal element matrix, the 36 unique entries of the symmetric 8 x 8 Ke = sum_q w det (-k) grad N_a . grad N_b.
 // Node a = ax + 2 ay + 4 az (tensor order, x fastest = c_dN's order); packing ke36[sym36(a, b)] of assemble_hex8.hip.
 SF_HD constexpr int sf_sym36(int a, int b) {

@@ -1020,8 +1020,9 @@ int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, con
 
 // The SpMV of a Krylov loop on a slab: y = alpha A x + beta y where x carries ghost blocks that the neighbours' boundary
 // planes must fill first.  The exchange is started on the communicator's stream, the rows that reference no ghost column
-// run beside it, the few planes of rows that do run after it has arrived (one extra small launch).  Layouts without a row
-// split (the row-sorted sliced layout) wait for the exchange first.  Without a communicator this is mfem_spmv_launch.
+// run beside it, the few planes of rows that do run after it has arrived (one extra small launch).  The row-sorted sliced layout
+// splits by blocks instead of zones: its ghost-reading rows are sorted behind all others when the pattern is planned.  Without a
+// communicator this is mfem_spmv_launch.
 static int g_halo_overlap = 1;
 extern "C" int mfem_debug_set_halo_overlap(int on) {
   ++mfem_debug_epoch;
@@ -1045,8 +1046,7 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   SpmvPart P;
   memset(&P, 0, sizeof(P));
   const int F = ctx->halo_fields;
-  const bool split = g_halo_overlap && A->n > 0 && 2 * F <= MFEM_MAX_ZONES && !mfem_sell_bound(A, vals) &&
-                     A->n == (int64_t)F * mfem_comm_owned_nodes(ctx);
+  const bool split = g_halo_overlap && A->n > 0 && 2 * F <= MFEM_MAX_ZONES && A->n == (int64_t)F * mfem_comm_owned_nodes(ctx);
   if (split) {
     const int64_t NO = mfem_comm_owned_nodes(ctx), PL = ctx->halo_plane_len;
     const int rank = mfem_comm_rank(ctx), world = mfem_comm_world(ctx);
@@ -1085,11 +1085,8 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   {
     const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part);
     if (e != 0) return e < 0 ? e : MFEM_OK;
-    if (part.part != 0 && mfem_sell_bound(A, vals)) {
-      mfem_set_error("the row-sorted sliced layout has no row split");
-      return MFEM_ERR_UNSUPPORTED;
-    }
-    const int sl = mfem_spmv_sell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag);
+    // (the sliced layout splits by BLOCKS: its ghost-reading rows are sorted behind all others, whatever the zones say)
+    const int sl = mfem_spmv_sell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part.part);
     if (sl != 0) return sl < 0 ? sl : MFEM_OK;
   }
   const int base = A->index_base;

@@ -1699,7 +1699,11 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
   if (rc) return rc;
   int64_t b = ent * 8 + A->n * 16;
   if (mode == 0) b = A->nnz * 12 + A->n * 16 + (A->n + 1) * (A->rowptr_bits / 8);
-  if (mode == 1 || mode == 3) b = ent * 12 + A->n * 16;
+  if (mode == 1) b = ent * 12 + A->n * 16;
+  if (mode == 3) {  // sliced layout: padded slots; blocks whose 128 rows share one diagonal list read it instead of their column stream
+    const double reg = A->sell_nblk > 0 ? (double)A->sell_regular_blocks / (double)A->sell_nblk : 0.0;
+    b = A->sell_total * 8 + (int64_t)((1.0 - reg) * (double)A->sell_total) * 4 + A->n * 16 + A->n * 4;  // + the row permutation
+  }
   if (mode == 2) {
     b += (A->n > reg ? A->n - reg : 0) * (int64_t)slots * 4;  // rows in generic blocks read their columns
     if (sym == 2) {  // the sweep stages a (4 + 2) x (32 + 2) neighbourhood of x per step instead of reading each swept entry once

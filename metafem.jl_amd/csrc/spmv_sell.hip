@@ -39,20 +39,27 @@ extern "C" int mfem_debug_set_sell(int enable) {  // bit 0: layout on/off; bit 1
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                             int base, int maxlen, int wshift, int lenbits,
-                                                            uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
+                                                            uint64_t* __restrict__ keys, int32_t* __restrict__ ids,
+                                                            int32_t* __restrict__ n_ghost_rows) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
     uint32_t h = 2166136261u;  // FNV-1a over the diagonal list col - row
+    bool ghost = false;        // the row reads a ghost column of a slab pattern (columns numbered behind the n owned ones)
     for (int64_t j = lo; j < hi; ++j) {
-      uint32_t d = (uint32_t)((int64_t)col[j] - base - r);
+      const int64_t c = (int64_t)col[j] - base;
+      ghost = ghost || c >= n;
+      uint32_t d = (uint32_t)(c - r);
       for (int k = 0; k < 4; ++k) {
         h = (h ^ (d & 255u)) * 16777619u;
         d >>= 8;
       }
     }
-    keys[r] = ((uint64_t)(r >> wshift) << (32 + lenbits)) | ((uint64_t)(uint32_t)(maxlen - (int32_t)(hi - lo)) << 32) | h;
+    // ghost-reading rows sort behind all others (bit 63): the leading blocks can run while the halo exchange is in flight
+    keys[r] = ((uint64_t)(ghost ? 1 : 0) << 63) | ((uint64_t)(r >> wshift) << (32 + lenbits)) |
+              ((uint64_t)(uint32_t)(maxlen - (int32_t)(hi - lo)) << 32) | h;
     ids[r] = (int32_t)r;
+    if (ghost) atomicAdd(n_ghost_rows, 1);
   }
 }
 
@@ -95,14 +102,20 @@ __global__ __launch_bounds__(SELL_B) void k_sell_block_flags(int64_t n, int64_t 
   }
 }
 
-// K_b * 128 for every block (first row of the block is its longest)
+// K_b * 128 for every block, K_b = its longest row: the first row, except in the one block where the ghost-reading rows (sorted behind
+// all others, again by decreasing length) begin
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_block_sizes(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ rowid, int64_t* __restrict__ sizes) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblk; b += stride) {
-    const int64_t r = rowid[b * SELL_B];
-    sizes[b] = ((int64_t)rowptr[r + 1] - (int64_t)rowptr[r]) * SELL_B;
+    int64_t K = 0;
+    for (int64_t rs = b * SELL_B; rs < (b + 1) * SELL_B && rs < n; ++rs) {
+      const int64_t r = rowid[rs];
+      const int64_t len = (int64_t)rowptr[r + 1] - (int64_t)rowptr[r];
+      K = len > K ? len : K;
+    }
+    sizes[b] = K * SELL_B;
   }
 }
 
@@ -143,14 +156,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nbl
                                                             const double* __restrict__ vals, const double* __restrict__ x,
                                                             double* __restrict__ y, double alpha, double beta,
                                                             const double* __restrict__ dotw, double* __restrict__ partials,
-                                                            const int32_t* __restrict__ done_flag) {
+                                                            const int32_t* __restrict__ done_flag, int64_t b_lo, int64_t b_hi) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t b = wave; b < nblk; b += nwaves) {
+  for (int64_t b = b_lo + wave; b < b_hi; b += nwaves) {  // [b_lo, b_hi): all blocks, or one part of a split (multi-rank) SpMV
     const int64_t p0 = ptr[b];
     const int Kb = (int)((ptr[b + 1] - p0) / SELL_B);
     // lane l owns the block's rows l and l + 64: the value loads of a slot are two unit-stride 512-byte runs, and the x
@@ -252,6 +265,9 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   void* tmp = nullptr;
   size_t tb = 0, tb2 = 0;
   int64_t total = 0;
+  int32_t n_ghost = 0;
+  int32_t* d_ghost = ctx->d_flags + 9;
+  const bool has_ghosts = A->ncols > A->n;
   const int grid = mfem_grid_for(n, MFEM_BLOCK, ctx->num_cus * 16);
   int lenbits = 1;
   while ((1 << lenbits) <= A->max_row_nnz && lenbits < 31) ++lenbits;
@@ -262,16 +278,19 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   SELL_CHECK(hipMalloc(&rowid, sizeof(int32_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&sizes, sizeof(int64_t) * (size_t)(nblk + 1)));
   SELL_CHECK(hipMalloc(&ptr, sizeof(int64_t) * (size_t)(nblk + 1)));
+  SELL_CHECK(hipMemsetAsync(d_ghost, 0, sizeof(int32_t), ctx->stream));
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_sell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int64_t*)A->rowptr, A->colidx,
-                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids);
+                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost);
   else
     hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr, A->colidx,
-                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids);
+                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost);
+  SELL_CHECK(hipMemcpyAsync(ctx->h_flags + 9, d_ghost, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   {
     int bits = 32 + lenbits;  // the low word is the signature of the diagonal list
     if (wshift < 63)
       while (bits < 64 && ((uint64_t)(n - 1) >> wshift) >> (bits - 32 - lenbits)) ++bits;  // window index on top
+    if (has_ghosts) bits = 64;  // ... and the ghost-reading rows behind everything else
     SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, ids, rowid, (int)n, 0, bits, ctx->stream));
     SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, sizes, ptr, (int)(nblk + 1), ctx->stream));
     if (tb2 > tb) tb = tb2;
@@ -288,7 +307,9 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sizes, ptr, (int)(nblk + 1), ctx->stream));
   SELL_CHECK(hipMemcpyAsync(&total, ptr + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   SELL_CHECK(hipStreamSynchronize(ctx->stream));
-  if ((double)total <= 1.15 * (double)A->nnz + 128.0 * A->max_row_nnz) {
+  n_ghost = ctx->h_flags[9];
+  // (padding: up to one block of the longest rows at the tail; with ghost-reading rows sorted last, one more where they begin)
+  if ((double)total <= 1.15 * (double)A->nnz + (has_ghosts ? 256.0 : 128.0) * A->max_row_nnz) {
     SELL_CHECK(hipMalloc(&A->sell_cols, sizeof(int32_t) * (size_t)total));
     const int g2 = mfem_grid_for(8 * nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
     if (A->rowptr_bits == 64)
@@ -323,6 +344,9 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
     A->sell_ptr = ptr;
     A->sell_total = total;
     A->sell_nblk = nblk;
+    // the rows that read ghost columns are the last n_ghost sorted rows: the blocks in front of the first of them form the interior part
+    // of a split SpMV (the block that holds both kinds belongs to the boundary part)
+    A->sell_nb_int = has_ghosts ? (n - (int64_t)n_ghost) / SELL_B : nblk;
     A->sell_state = 1;
     rowid = nullptr;
     ptr = nullptr;
@@ -382,15 +406,20 @@ void mfem_sell_free(mfem_csr_s* A) {
 
 // returns 1 if launched, 0 if another kernel should be used, <0 on error
 int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
-                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
+                          double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part) {
   if (!A->sell_vals || vals != A->sell_src) return 0;
+  // part 1: the leading blocks, whose rows read no ghost column; part 2: the rest (mfem_spmv_halo)
+  const int64_t b_lo = part == 2 ? A->sell_nb_int : 0, b_hi = part == 1 ? A->sell_nb_int : A->sell_nblk;
+  if (n_partials) *n_partials = 0;
+  if (b_hi <= b_lo) return 1;
   int cap = ctx->num_cus * g_sell_wg_per_cu;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
-  const int grid = mfem_grid_for(A->sell_nblk * 64, MFEM_BLOCK, cap);
+  if (part != 0) cap /= 2;  // the two parts of a split SpMV share one partial-sum array
+  const int grid = mfem_grid_for((b_hi - b_lo) * 64, MFEM_BLOCK, cap);
 #define SELL_LAUNCH(U)                                                                                                            \
   hipLaunchKernelGGL(k_spmv_sell<U>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk, A->sell_ptr, A->sell_rowid, \
                      g_sell_offsets ? A->sell_flags : nullptr, A->sell_off, A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw,   \
-                     partials, done_flag)
+                     partials, done_flag, b_lo, b_hi)
   switch (g_sell_unroll) {
     case 4: SELL_LAUNCH(4); break;
     case 8: SELL_LAUNCH(8); break;

@@ -22,6 +22,12 @@ static double check(unsigned seed) {
   double fe[2][4], ke[36];
   sf_thermal_fe<NG>(X, T, S, true, kc, fe);
   sf_thermal_ke<NG>(X, kc, ke);
+  // elasticity residual: nodal displacements, lam / mu of E = 1, nu = 0.3
+  const double lam = 0.5769230769230769, mu = 0.38461538461538464;
+  double U[3][2][4], fel[3][2][4], felr[3][8] = {{0}};
+  for (int i = 0; i < 3; ++i)
+    for (int b = 0; b < 8; ++b) U[i][b & 1][b >> 1] = 0.1 * rnd();
+  sf_elasticity_fe<NG>(X, U, lam, mu, fel);
   // table form
   double fr[8] = {0}, kr[8][8] = {{0}};
   for (int qz = 0; qz < NG; ++qz)
@@ -64,6 +70,17 @@ static double check(unsigned seed) {
           for (int s = 0; s < 3; ++s) gT[s] += g[b][s] * T[b & 1][b >> 1];
           sq += N[b] * S[b & 1][b >> 1];
         }
+        double du[3][3] = {{0}};
+        for (int b = 0; b < 8; ++b)
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) du[i][j] += U[i][b & 1][b >> 1] * g[b][j];
+        const double tr = du[0][0] + du[1][1] + du[2][2];
+        for (int a = 0; a < 8; ++a)
+          for (int i = 0; i < 3; ++i) {
+            double acc = 0;
+            for (int j = 0; j < 3; ++j) acc += (mu * (du[i][j] + du[j][i]) + (i == j ? lam * tr : 0.0)) * g[a][j];
+            felr[i][a] -= w * det * acc;  // k_elasticity_residual: r[fi] -= wd * acc
+          }
         for (int a = 0; a < 8; ++a) {
           fr[a] += w * det * (-kc * (g[a][0] * gT[0] + g[a][1] * gT[1] + g[a][2] * gT[2]) + N[a] * sq);
           for (int b = 0; b < 8; ++b) kr[a][b] += -kc * w * det * (g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2]);
@@ -78,8 +95,14 @@ static double check(unsigned seed) {
       nk = fmax(nk, fabs(kr[a][b]));
     }
   }
-  printf("NG=%d seed=%u  fe rel err %.2e   ke rel err %.2e\n", NG, seed, err / nf, ek / nk);
-  return fmax(err / nf, ek / nk);
+  double ee = 0, ne = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int a = 0; a < 8; ++a) {
+      ee = fmax(ee, fabs(felr[i][a] - fel[i][a & 1][a >> 1]));
+      ne = fmax(ne, fabs(felr[i][a]));
+    }
+  printf("NG=%d seed=%u  fe rel err %.2e   ke rel err %.2e   elasticity fe rel err %.2e\n", NG, seed, err / nf, ek / nk, ee / ne);
+  return fmax(fmax(err / nf, ek / nk), ee / ne);
 }
 int main() {
   double e = 0;
