@@ -847,7 +847,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   __shared__ double rows[EL2_NODES * EL2_ROW];
   __shared__ int64_t s_pre[EL2_NODES];
   __shared__ int32_t s_cn[EL2_NODES];
-  const int tid = threadIdx.x, nl = tid >> 3, e = tid & 7;
+  // lane <-> control point, half-wave <-> adjacent element: the 32 threads of an accumulation phase (one element slot e) are one half of
+  // a wave -- full LDS instructions instead of 8 scattered lanes in each of the four waves -- and neighbouring lanes load neighbouring
+  // elements' coordinates
+  const int tid = threadIdx.x, nl = tid & (EL2_NODES - 1), e = tid / EL2_NODES;
   const int64_t node = (int64_t)blockIdx.x * EL2_NODES + nl;
   const bool live = node < B.n_owned;
   for (int t = tid; t < EL2_NODES * EL2_ROW; t += MFEM_BLOCK) rows[t] = 0.0;

@@ -113,6 +113,8 @@ struct mfem_csr_s {
   int32_t* rb_rows;         // owned, [rb_ntiles + 1]: first row of every tile
   uint8_t* cw_elide;        // owned: one flag per tile of cw_R rows of the fixed-row-count wave-tile kernel (k_spmv_csr_w): columns derivable from the tile's first row
   int cw_R;
+  uint16_t* diag_off;       // owned, [n], built on first use: offset of the diagonal entry inside its row (0xFFFF = none stored): |diag| is then an
+                            // n-sized gather instead of a scan of all nonzeros (Jacobi_By_Diagonal of every solve)
   // owned storage (mfem_brick_pattern) -- freed in destroy
   void* owned_rowptr;
   void* owned_colidx;
@@ -163,7 +165,7 @@ struct mfem_csr_s {
 };
 int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_sell_vals_bytes(const mfem_csr_s* A);
-int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);
+int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);
 void mfem_sell_unbind(mfem_csr_s* A);
 void mfem_sell_free(mfem_csr_s* A);
 int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
@@ -171,7 +173,7 @@ int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 bool mfem_sell_bound(const mfem_csr_s* A, const double* vals);  // the sliced layout (rows permuted; ghost-reading rows sorted last) serves these values
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
-int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);
+int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);
 void mfem_ell_unbind(mfem_csr_s* A);
 int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d);
 void mfem_ell_free(mfem_csr_s* A);

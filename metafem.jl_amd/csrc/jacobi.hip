@@ -104,8 +104,67 @@ int mfem_mat_div_rows(mfem_context_s* ctx, mfem_csr_s* A, double* vals, const do
   return MFEM_OK;
 }
 
+// off[r] = offset of row r's diagonal entry inside the row (0xFFFF: none stored); one scan of the pattern, once per handle
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_diag_offsets(int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               int base, uint16_t* __restrict__ off) {
+  const int g = threadIdx.x & 7;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 3;
+  for (int64_t r = grp; r < n; r += ngrp) {
+    const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+    int found = 0xFFFF;
+    for (int64_t j = lo + g; j < hi; j += 8)
+      if ((int64_t)col[j] - base == r) found = (int)(j - lo);  // (a row lists a column once)
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      const int o = __shfl_xor(found, m, MFEM_WAVE);
+      found = o < found ? o : found;
+    }
+    if (g == 0) off[r] = (uint16_t)found;
+  }
+}
+// d[r] = |K_rr| through the table (same guarded rule as k_jacobi_rows mode 0: no stored diagonal, or a stored zero, keeps the preset)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_jacobi_diag_table(int64_t n, const RP* __restrict__ rowptr, const uint16_t* __restrict__ off,
+                                                                    const double* __restrict__ vals, double* __restrict__ d, int base) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
+    const int o = off[r];
+    if (o == 0xFFFF) continue;
+    const double v = vals[(int64_t)rowptr[r] - base + o];
+    if (v != 0.0) d[r] = fabs(v);
+  }
+}
+
 int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* d, int mode) {
   if (A->n == 0) return MFEM_OK;
+  if (mode == 0 && A->max_row_nnz > 0 && A->max_row_nnz < 0xFFFF) {
+    // |diag|: an n-sized gather through a per-pattern table of diagonal positions (built by the first call: one scan of the pattern, what
+    // every call used to cost)
+    if (!A->diag_off) {
+      uint16_t* t = nullptr;
+      MFEM_CHECK_HIP(hipMalloc(&t, sizeof(uint16_t) * (size_t)A->n));
+      const int g8 = mfem_grid_for(A->n * 8, MFEM_BLOCK, ctx->num_cus * 16);
+      if (A->rowptr_bits == 64)
+        hipLaunchKernelGGL(k_diag_offsets<int64_t>, dim3(g8), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const int64_t*)A->rowptr, A->colidx, A->index_base, t);
+      else
+        hipLaunchKernelGGL(k_diag_offsets<int32_t>, dim3(g8), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const int32_t*)A->rowptr, A->colidx, A->index_base, t);
+      if (hipGetLastError() != hipSuccess) {
+        hipFree(t);
+        mfem_set_error("k_diag_offsets launch failed");
+        return MFEM_ERR_HIP;
+      }
+      A->diag_off = t;
+    }
+    const int g1 = mfem_grid_for(A->n, MFEM_BLOCK, ctx->num_cus * 16);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_jacobi_diag_table<int64_t>, dim3(g1), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const int64_t*)A->rowptr, A->diag_off, vals, d, A->index_base);
+    else
+      hipLaunchKernelGGL(k_jacobi_diag_table<int32_t>, dim3(g1), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const int32_t*)A->rowptr, A->diag_off, vals, d, A->index_base);
+    MFEM_CHECK_LAUNCH();
+    return MFEM_OK;
+  }
   const int grid = mfem_grid_for(A->n * 8, MFEM_BLOCK, ctx->num_cus * 16);
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_jacobi_rows<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n,

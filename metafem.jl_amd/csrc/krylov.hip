@@ -646,13 +646,16 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const bool is_cg = o->method == MFEM_SOLVER_CG;
   const bool jac = o->precond != MFEM_PRECOND_NONE;
   const bool left = o->left_precond != MFEM_LEFT_NONE;
-  const bool need_copy = ((jac && !is_cg) || left) && !o->scale_in_place;
+  // Right Jacobi on a solver layout: the column scaling is applied while the layout copy is made (Mat_Div_Jacobi folded into the bind), so
+  // the scaled matrix exists only in that copy -- no scaled CSR copy, no scaling pass.  Not with a left preconditioner (it reads the
+  // scaled CSR values) and not with scale_in_place (the caller wants `vals` scaled, Pr_Jacobi! semantics).
+  bool fused_scale = jac && !is_cg && !left && !o->scale_in_place;
+  const bool need_copy_unfused = ((jac && !is_cg) || left) && !o->scale_in_place;
   // workspace: x, b (padded copies), d, dinv (CG) / left scaling dl, work vectors, optional matrix copy
   const size_t vec_bytes = (size_t)nv * sizeof(double);
   // slot-major copy of the working values for near-uniform rows (spmv_ell.hip), made once per solve after the scaling
   int rc_plan = mfem_ell_plan(ctx, A);
   if (rc_plan) return rc_plan;
-  const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
   const size_t ell_bytes = mfem_ell_vals_bytes(A);
   size_t sell_bytes = 0;
   if (!ell_bytes && A->ell_state != 1) {  // rows of uneven length: row-sorted sliced layout
@@ -660,6 +663,9 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (rc_plan) return rc_plan;
     sell_bytes = mfem_sell_vals_bytes(A);
   }
+  fused_scale = fused_scale && (ell_bytes || sell_bytes);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
+  const bool need_copy = need_copy_unfused && !fused_scale;
+  const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
   size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes + sell_bytes;
   int rc = mfem_ws_reserve(ctx, total);
   if (rc) return rc;
@@ -701,7 +707,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       rc = mfem_jacobi2_by_column(ctx, A, vals_src, V.d);
     } else if (is_cg && ell_bytes) {
       // CG does not scale the matrix: transpose first and read |diag| from the copy (n values instead of all nonzeros)
-      rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+      rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), nullptr);
       if (!rc && A->ell_vals) {
         ell_bound = true;
         rc = mfem_ell_diag(ctx, A, V.d);
@@ -723,8 +729,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
         rc = mfem_comm_halo(ctx, V.d);                                      // norm comes with them, mfem_jacobi2_by_column)
         if (rc) return rc;
       }
-      rc = mfem_mat_div_jacobi_from(ctx, A, vals_src, vals_work, V.d);
-      if (rc) return rc;
+      if (!fused_scale) {
+        rc = mfem_mat_div_jacobi_from(ctx, A, vals_src, vals_work, V.d);
+        if (rc) return rc;
+      }
     }
   }
 
@@ -745,13 +753,22 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   }
 
   // bind the slot-major copy: every mfem_spmv_launch(A, vals_work, ...) below runs the ELL kernel
+  // (fused_scale: vals_work is the caller's unscaled array and only names the bound values; every SpMV below runs on the scaled copy)
   if (ell_bytes && !ell_bound) {
-    rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+    rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
+    if (fused_scale && !A->ell_vals) {
+      mfem_set_error("solver layout could not be bound for the fused Jacobi scaling");
+      return MFEM_ERR_INVALID;
+    }
   }
   if (sell_bytes) {
-    rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+    rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
+    if (fused_scale && !A->sell_vals) {
+      mfem_set_error("sliced layout could not be bound for the fused Jacobi scaling");
+      return MFEM_ERR_INVALID;
+    }
   }
   int64_t n_global = n;
   if (ctx->comm) {

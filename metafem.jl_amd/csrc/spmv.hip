@@ -853,8 +853,10 @@ static void csr_drop_plans(mfem_csr_s* A) {
   A->symp_state = 0;
   if (A->rb_rows) hipFree(A->rb_rows);
   if (A->cw_elide) hipFree(A->cw_elide);
+  if (A->diag_off) hipFree(A->diag_off);
   A->rb_rows = nullptr;
   A->cw_elide = nullptr;
+  A->diag_off = nullptr;
   A->rb_state = 0;
   A->rb_ntiles = A->rb_elided = 0;
   A->cw_R = 0;
@@ -963,6 +965,7 @@ extern "C" int mfem_csr_destroy(mfem_csr A) {
   mfem_sell_free(A);
   if (A->rb_rows) hipFree(A->rb_rows);
   if (A->cw_elide) hipFree(A->cw_elide);
+  if (A->diag_off) hipFree(A->diag_off);
   if (A->owned_rowptr) hipFree(A->owned_rowptr);
   if (A->owned_colidx) hipFree(A->owned_colidx);
   delete A;

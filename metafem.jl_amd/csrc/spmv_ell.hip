@@ -90,7 +90,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_cols(int64_t n, int64_t npad
 // unit-stride lanes into the wave's LDS block, written out slot by slot with lane <-> row (both sides coalesced).
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals_lds(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
-                                                               const double* __restrict__ vals, int base, double* __restrict__ out) {
+                                                               const double* __restrict__ vals, int base, double* __restrict__ out,
+                                                               const int32_t* __restrict__ col, const double* __restrict__ dsc) {
+  // dsc != nullptr: the copy is the right-Jacobi-scaled matrix, entry / dsc[its column] (Mat_Div_Jacobi folded into this pass)
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   double* T = lds + (size_t)w * 64 * K;
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals_lds(int64_t n, int64_t 
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 64 * u;
         tv[u] = i < cnt ? vals[s0 + i] : 0.0;
+        if (dsc && i < cnt) tv[u] /= dsc[col[s0 + i] - base];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -288,7 +291,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
                                                            int base, const DiaOffsets* __restrict__ Op,
                                                            const int32_t* __restrict__ flags, double* __restrict__ out, SympGeom Gm,
-                                                           double* __restrict__ pv) {
+                                                           double* __restrict__ pv, const double* __restrict__ dsc) {
+  // dsc != nullptr: the copy is the right-Jacobi-scaled matrix, entry / dsc[its column] (Mat_Div_Jacobi folded into this pass; the
+  // columns are then read for every tile)
   const DiaOffsets& O = *Op;
   extern __shared__ double lds[];
   const int64_t slo = pv ? (int64_t)Gm.p0 * Gm.PL : 0, shi = pv ? (int64_t)Gm.p1 * Gm.PL : 0;  // swept rows
@@ -302,7 +307,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int half = LPR == 2 ? lane >> 5 : 0, rl = lane & (RT - 1);
   double* T = lds + (size_t)w * RT * K;
+  // columns are staged only for the Jacobi scaling pass (dsc); the placement below needs them for the few tiles that are not `full`
+  // (mesh boundary) and reads those from memory -- 8 instead of 12 bytes of LDS per staged entry, half as many more waves per CU
   int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * RT * K) + (size_t)w * RT * K;
+  const bool stage_cols = dsc != nullptr;
   const int64_t ntiles = npad >> SH;
   for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
     const int64_t r0 = tile << SH, r = r0 + rl;
@@ -327,21 +335,42 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 64 * u;
         tv[u] = i < cnt ? vals[s0 + i] : 0.0;
-        tc[u] = (i < cnt && !full) ? col[s0 + i] : 0;
+        tc[u] = (i < cnt && stage_cols) ? col[s0 + i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 64 * u;
         if (i < cnt) {
           T[i] = tv[u];
-          if (!full) Tc[i] = tc[u] - base;
+          if (stage_cols) Tc[i] = tc[u] - base;
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (dsc) {
+      // right Jacobi scaling of the staged tile, entry / dsc[column]: the gathers of 16 entries per lane are in flight together -- one more
+      // memory round trip per batch of 1024 entries (dividing inside the staging loop above made every batch of its loads wait twice)
+      __builtin_amdgcn_wave_barrier();
+      for (int i0 = lane; i0 < cnt; i0 += 64 * 16) {
+        double dd[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int i = i0 + 64 * u;
+          dd[u] = i < cnt ? dsc[Tc[i]] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int i = i0 + 64 * u;
+          if (i < cnt) T[i] /= dd[u];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
     const int off0 = (int)(lo - s0);
     const int dir = half ? -1 : 1;
+    auto colat = [&](int j) -> int64_t { return stage_cols ? (int64_t)Tc[off0 + j] : (int64_t)col[lo + j] - base; };
     if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
       int line = 0, pcol = 0;
@@ -361,7 +390,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         const int sl = half ? 26 - t : t;
         const bool act = half == 0 || t < 13;
         double v = 0.0;
-        if (act && j >= 0 && j < len && (full || (int64_t)Tc[off0 + j] - r == O.off[cls][sl])) {
+        if (act && j >= 0 && j < len && (full || colat(j) - r == O.off[cls][sl])) {
           v = T[off0 + j];
           j += dir;
         }
@@ -383,7 +412,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         int j = 0;
         for (int sl = 0; sl < Dh; ++sl) {
           double v = 0.0;
-          if (j < len && (full || (int64_t)Tc[off0 + j] - r == O.off[cls][sl])) {
+          if (j < len && (full || colat(j) - r == O.off[cls][sl])) {
             v = T[off0 + j];
             ++j;
           }
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         int j = len - 1;
         for (int sl = D - 1; sl >= Dh; --sl) {
           double v = 0.0;
-          if (j >= 0 && (full || (int64_t)Tc[off0 + j] - r == O.off[cls][sl])) {
+          if (j >= 0 && (full || colat(j) - r == O.off[cls][sl])) {
             v = T[off0 + j];
             --j;
           }
@@ -1368,7 +1397,9 @@ size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
 }
 
 // Transpose CSR-ordered values into `buf` and route subsequent mfem_spmv_launch calls with these `vals` to the ELL kernel.
-int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
+// dsc (optional): right Jacobi column scaling applied on the way (copy = vals[j] / dsc[col[j]]): the Krylov loop then runs on the scaled
+// matrix without a scaled CSR copy ever existing (solve_inner).  `vals` stays the identity of the bound values.
+int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
   A->ell_bound_mode = 0;
@@ -1378,11 +1409,12 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     const DiaOffsets* O = (const DiaOffsets*)A->dia_dev;
     // a lane per row while at least two waves of 64-row tiles fit 64 KB of staging (K <= 42: the 27-diagonal lattice); two lanes per row,
     // 32-row tiles, beyond (the 81 diagonals of three fields)
-    const int lpr = 12 * 64 * (size_t)A->ell_K * 2 > 64 * 1024 ? 2 : 1;
+    const size_t eb = dsc ? 12 : 8;  // 8 B value (+ 4 B column for the scaling pass) per staged entry (<= rt K per tile)
+    const int lpr = eb * 64 * (size_t)A->ell_K * 2 > 64 * 1024 ? 2 : 1;
     const int rt = 64 / lpr;
-    int wv = 4;
-    while (wv > 1 && 12 * rt * (size_t)A->ell_K * wv > 64 * 1024) wv >>= 1;
-    const size_t ldsb = 12 * rt * (size_t)A->ell_K * wv;  // 8 B value + 4 B column per staged entry (<= rt K per tile)
+    int wv = 2;  // two-wave workgroups: what fits a CU is then decided in steps of two waves (27 diagonals: 27.6 KB per workgroup, 5 per CU)
+    while (wv > 1 && eb * rt * (size_t)A->ell_K * wv > 64 * 1024) wv >>= 1;
+    const size_t ldsb = eb * rt * (size_t)A->ell_K * wv;
     const int64_t nt = A->ell_npad / rt;
     int g = (int)((nt + wv - 1) / wv);
     if (g > ctx->num_cus * 16) g = ctx->num_cus * 16;
@@ -1390,7 +1422,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
 #define DV_LAUNCH(RP, LPR_)                                                                                                        \
   hipLaunchKernelGGL((k_dia_vals<RP, LPR_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
-                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals)
+                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc)
       if (A->rowptr_bits == 64) {
         if (lpr == 2) DV_LAUNCH(int64_t, 2); else DV_LAUNCH(int64_t, 1);
       } else {
@@ -1462,10 +1494,10 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
   if (grid > ctx->num_cus * 16) grid = ctx->num_cus * 16;
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_ell_vals_lds<int64_t>, dim3(grid), dim3(64 * waves), lds, ctx->stream, A->n, A->ell_npad, A->ell_K,
-                       (const int64_t*)A->rowptr, vals, A->index_base, buf);
+                       (const int64_t*)A->rowptr, vals, A->index_base, buf, A->colidx, dsc);
   else
     hipLaunchKernelGGL(k_ell_vals_lds<int32_t>, dim3(grid), dim3(64 * waves), lds, ctx->stream, A->n, A->ell_npad, A->ell_K,
-                       (const int32_t*)A->rowptr, vals, A->index_base, buf);
+                       (const int32_t*)A->rowptr, vals, A->index_base, buf, A->colidx, dsc);
   MFEM_CHECK_LAUNCH();
   A->ell_vals = buf;
   A->ell_src = vals;
@@ -1749,7 +1781,7 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   if (bytes) {
     rc = mfem_ws_reserve(ctx, bytes);
     if (rc) return rc;
-    rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws);
+    rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
     if (rc) return rc;
   } else {
     rc = mfem_sell_plan(ctx, A);
@@ -1758,7 +1790,7 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     if (sb) {
       rc = mfem_ws_reserve(ctx, sb);
       if (rc) return rc;
-      rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws);
+      rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;
     }
   }

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_block_sizes(int64_t n, int6
 template <typename RP, typename T, bool COLS>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
                                                             const int32_t* __restrict__ rowid, const int64_t* __restrict__ ptr,
-                                                            const T* __restrict__ src, int base, T* __restrict__ out) {
+                                                            const T* __restrict__ src, int base, T* __restrict__ out,
+                                                            const int32_t* __restrict__ col, const double* __restrict__ dsc) {
+  // values only -- dsc != nullptr: entry / dsc[its column] (right Jacobi scaling folded into the copy)
   const int lane = threadIdx.x & 63, g = lane & 3;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -145,7 +147,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_fill(int64_t n, int64_t nbl
       if (COLS) pad = (T)r;
     }
     T* o = out + p0 + (rs & (SELL_B - 1));
-    for (int s = g; s < Kb; s += 4) o[(int64_t)s * SELL_B] = s < len ? (COLS ? (T)(src[lo + s] - base) : src[lo + s]) : pad;
+    if (!COLS && dsc) {
+      for (int s = g; s < Kb; s += 4) o[(int64_t)s * SELL_B] = s < len ? (T)((double)src[lo + s] / dsc[col[lo + s] - base]) : pad;
+    } else {
+      for (int s = g; s < Kb; s += 4) o[(int64_t)s * SELL_B] = s < len ? (COLS ? (T)(src[lo + s] - base) : src[lo + s]) : pad;
+    }
   }
 }
 
@@ -314,10 +320,10 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
     const int g2 = mfem_grid_for(8 * nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
     if (A->rowptr_bits == 64)
       hipLaunchKernelGGL((k_sell_fill<int64_t, int32_t, true>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, n, nblk,
-                         (const int64_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols);
+                         (const int64_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols, (const int32_t*)nullptr, (const double*)nullptr);
     else
       hipLaunchKernelGGL((k_sell_fill<int32_t, int32_t, true>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, n, nblk,
-                         (const int32_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols);
+                         (const int32_t*)A->rowptr, rowid, ptr, A->colidx, A->index_base, A->sell_cols, (const int32_t*)nullptr, (const double*)nullptr);
     if (hipGetLastError() != hipSuccess) {
       mfem_set_error("k_sell_fill launch failed");
       rc = MFEM_ERR_HIP;
@@ -366,17 +372,17 @@ size_t mfem_sell_vals_bytes(const mfem_csr_s* A) {
   return (A->sell_state == 1 && g_sell_enable && A->n >= g_layout_min_rows_cols) ? sizeof(double) * (size_t)A->sell_total : 0;
 }
 
-int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
+int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
   A->sell_vals = nullptr;
   A->sell_src = nullptr;
   if (A->sell_state != 1 || !g_sell_enable || !buf) return MFEM_OK;
   const int g2 = mfem_grid_for(8 * A->sell_nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL((k_sell_fill<int64_t, double, false>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk,
-                       (const int64_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf);
+                       (const int64_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf, A->colidx, dsc);
   else
     hipLaunchKernelGGL((k_sell_fill<int32_t, double, false>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk,
-                       (const int32_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf);
+                       (const int32_t*)A->rowptr, A->sell_rowid, A->sell_ptr, vals, A->index_base, buf, A->colidx, dsc);
   MFEM_CHECK_LAUNCH();
   A->sell_vals = buf;
   A->sell_src = vals;
