@@ -73,6 +73,74 @@ def pikachu():
     np.savez_compressed(os.path.join(HERE, "pikachu_tet10.npz"), vert=vert, conn=conn.astype(np.int32), xyz=pts, T=sc["T"])
 
 
+def line_samples():
+    """DATA from the reference's committed Paraview line samples (CSV): the columns its scripts plot.
+    thermal_conduction/MetaFEM_a.csv, MetaFEM_b.csv (3D_Script.jl:73-74): T along two vertical lines of the tet-10 result;
+    stress_concentration/{2D,3D}_MetaFEM_{x,y}.csv (3D_Script.jl:93-94): d1..d3 along the symmetry lines of the plate with a hole;
+    cylinder_flow/MetaFEM_y2.csv, MetaFEM_y3.csv (3D_MetaFEM_Script.jl:122-123): p, u1, u2, u3 along two lines through the channel --
+    the only reference-produced numbers of a run with Pl_func = Pl_Jacobi (:90), + the COMSOL mesh of that example."""
+    import csv
+
+    from oracle import readers
+
+    def read(path, cols):
+        rows = list(csv.DictReader(open(path)))
+        pts = np.array([[float(r[f"Points:{d}"]) for d in range(3)] for r in rows])
+        mask = np.array([int(float(r["vtkValidPointMask"])) for r in rows], dtype=np.int8)
+        vals = {c: np.array([float(r[c]) if r[c] != "nan" else np.nan for r in rows]) for c in cols}
+        return pts, mask, vals
+
+    out = {}
+    base = os.path.join(REF, "examples/thermal_conduction")
+    for tag in ("a", "b"):
+        pts, mask, v = read(os.path.join(base, f"MetaFEM_{tag}.csv"), ["T"])
+        out.update({f"thermal_{tag}_pts": pts, f"thermal_{tag}_mask": mask, f"thermal_{tag}_T": v["T"]})
+    base = os.path.join(REF, "examples/linear_elasticity/stress_concentration")
+    for dim in (2, 3):
+        for tag in ("x", "y"):
+            pts, mask, v = read(os.path.join(base, f"{dim}D_MetaFEM_{tag}.csv"), [f"d{i + 1}" for i in range(dim)])
+            out.update({f"stress{dim}d_{tag}_pts": pts, f"stress{dim}d_{tag}_mask": mask})
+            out.update({f"stress{dim}d_{tag}_d{i + 1}": v[f"d{i + 1}"] for i in range(dim)})
+    base = os.path.join(REF, "examples/incompressible_flow/cylinder_flow")
+    for tag in ("y2", "y3"):
+        pts, mask, v = read(os.path.join(base, f"MetaFEM_{tag}.csv"), ["p", "u1", "u2", "u3"])
+        out.update({f"cylinder_{tag}_pts": pts, f"cylinder_{tag}_mask": mask})
+        out.update({f"cylinder_{tag}_{c}": v[c] for c in ("p", "u1", "u2", "u3")})
+    np.savez_compressed(os.path.join(HERE, "line_samples.npz"), **out)
+    vert, conn = readers.read_mphtxt(os.path.join(base, "3D_COMSOL_Mesh.mphtxt"))
+    np.savez_compressed(os.path.join(HERE, "cylinder_mesh.npz"), vert=vert, conn=conn.astype(np.int32))
+
+
+def cylinder_oracle(precomputed=None):
+    """Oracle output for pin 9 (about 25 minutes of numpy: six Newton steps on 164 808 unknowns, not something the CPU suite can
+    repeat): oracle/cylinder.py runs examples/incompressible_flow/cylinder_flow/3D_MetaFEM_Script.jl with the script's own solver
+    (idrs!, s = 8, Pl_func = Pl_Jacobi) and the fields p, u1, u2, u3 are sampled at the points of the reference's MetaFEM_y2.csv /
+    MetaFEM_y3.csv (oracle/sampling.py).  Stored: the samples, the Newton history, the nodal solution (float32, for the GPU comparison)."""
+    from oracle import cylinder, reference_element as re_
+    from oracle.sampling import Sampler
+
+    zm = np.load(os.path.join(HERE, "cylinder_mesh.npz"))
+    zl = np.load(os.path.join(HERE, "line_samples.npz"))
+    if precomputed is None:
+        dom, hist = cylinder.run(zm["vert"], zm["conn"].astype(np.int64))
+        x, coords, cp_ids = dom.x, dom.mesh.coords, dom.mesh.cp_ids
+    else:  # (x, coords, cp_ids, hist) of an earlier run of the same function
+        x, coords, cp_ids, hist = precomputed
+    import types
+
+    disc = re_.initialize_classical_element(3, "SIMPLEX", 2, 1, 6, itp_type="Serendipity")
+    S = Sampler(types.SimpleNamespace(coords=coords, cp_ids=cp_ids, nel=cp_ids.shape[1]), disc)
+    n = coords.shape[0]
+    fields = {"p": x[:n], "u1": x[n:2 * n], "u2": x[2 * n:3 * n], "u3": x[3 * n:4 * n]}
+    out = {"newton_history": np.array(hist), "x_f32": x.astype(np.float32)}
+    for tag in ("y2", "y3"):
+        got, valid = S.sample(fields, zl[f"cylinder_{tag}_pts"], tol=1e-5)
+        out[f"{tag}_valid"] = valid
+        for k, v in got.items():
+            out[f"{tag}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "oracle_cylinder_lines.npz"), **out)
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -184,9 +252,12 @@ if __name__ == "__main__":
         cantilever()
         stress_concentration()
         pikachu()
+        line_samples()
     tables()
     thermal_hex8()
     elasticity_hex8()
     thermal_hex27()
     c_header()
+    if "--cylinder" in sys.argv:  # 25 minutes: only on request
+        cylinder_oracle()
     print("fixtures written to", HERE)

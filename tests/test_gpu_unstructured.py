@@ -23,6 +23,17 @@ def _wf(wf):
                       nonlinear_gradients=[G.GradTerm(g.dual_pos, g.dual_s, g.base_pos, g.base_s, g.fn, g.td_order) for g in wf.nonlinear_gradients])
 
 
+def _sampler(msh, shape, dim):
+    """oracle.sampling.Sampler over the PRODUCT's mesh arrays (same node order as the oracle's discretization: tests/test_product_tables.py)."""
+    import types
+
+    from oracle import reference_element as re_
+    from oracle.sampling import Sampler
+
+    disc = re_.initialize_classical_element(dim, shape, 2, 1, 5, itp_type="Serendipity")
+    return Sampler(types.SimpleNamespace(coords=np.asarray(msh.coords), cp_ids=np.asarray(msh.cp_ids), nel=msh.cp_ids.shape[1]), disc)
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_stress_concentration_on_gpu_reproduces_reference_vtk(mf, dim):
     import torch
@@ -63,6 +74,18 @@ def test_stress_concentration_on_gpu_reproduces_reference_vtk(mf, dim):
     n, scale = msh.ncp, np.abs(z["d2"]).max()
     for fld in range(dim):
         assert np.abs(got[fld * n:(fld + 1) * n][idx] - z[f"d{fld + 1}"]).max() < 1e-5 * scale
+    # the reference's committed line samples of this result ({2D,3D}_MetaFEM_{x,y}.csv, 3D_Script.jl:93-94), from the GPU field
+    zl = np.load(os.path.join(GOLD, "line_samples.npz"))
+    S = _sampler(msh, "CUBE", dim)
+    fields = {f"d{i + 1}": got[i * n:(i + 1) * n] for i in range(dim)}
+    for tag in ("x", "y"):
+        pts, mask = zl[f"stress{dim}d_{tag}_pts"], zl[f"stress{dim}d_{tag}_mask"].astype(bool)
+        smp, valid = S.sample(fields, pts[:, :dim], tol=1e-5)
+        inside = mask & valid
+        assert inside.sum() >= mask.sum() - 1
+        sc = max(np.nanmax(np.abs(zl[f"stress{dim}d_{tag}_d{i + 1}"][mask])) for i in range(dim))
+        for i in range(dim):
+            assert np.abs(smp[f"d{i + 1}"][inside] - zl[f"stress{dim}d_{tag}_d{i + 1}"][inside]).max() < 2e-4 * sc
 
 
 def test_tet10_thermal_on_gpu_reproduces_reference_vtk(mf):
@@ -94,6 +117,15 @@ def test_tet10_thermal_on_gpu_reproduces_reference_vtk(mf):
     d, idx = cKDTree(msh.coords * 100.0).query(z["xyz"])
     assert d.max() < 1e-4
     assert (np.abs(T[idx] - z["T"]) / z["T"]).max() < 1e-5
+    # the reference's committed line samples of this result (MetaFEM_a.csv, MetaFEM_b.csv, 3D_Script.jl:73-74), from the GPU field
+    zl = np.load(os.path.join(GOLD, "line_samples.npz"))
+    S = _sampler(msh, "SIMPLEX", 3)
+    for tag in ("a", "b"):
+        pts, mask = zl[f"thermal_{tag}_pts"], zl[f"thermal_{tag}_mask"].astype(bool)
+        smp, valid = S.sample({"T": T}, pts / 100.0, tol=1e-5)
+        inside = mask & valid
+        assert inside.sum() >= mask.sum() - 2
+        assert np.abs(smp["T"][inside] - zl[f"thermal_{tag}_T"][inside]).max() < 0.02
     # transient variant (3D_Script_Dynamics.jl): three backward-Euler steps heat the body monotonically towards that state
     gt = G.GenericDomain(mf.default_context(), space, msh.coords, msh.cp_ids, 1, _wf(problems.thermal_domain(3, 0.6, C=4.184e3)),
                          [(fac.element_ID, fac.element_eindex, _wf(problems.thermal_convection(25.0, T0)))], max_time_level=1)

@@ -1,4 +1,5 @@
 """The oracle's pin: the reference's own committed result for examples/thermal_conduction/2D_Script.jl."""
+import functools
 import os
 
 import numpy as np
@@ -135,16 +136,41 @@ def test_oracle_reproduces_reference_cantilever_vtk():
 
 
 # ---- pins 4-6: unstructured meshes from the reference's example folders (fixtures = their mesh files + committed results) ----
+@functools.lru_cache(maxsize=None)
+def _solved_stress(dim):
+    from oracle import stress_concentration as scn
+
+    z = np.load(os.path.join(GOLD, f"stress_concentration_{dim}d.npz"))
+    dom = scn.build(z["vert"], z["conn"].astype(np.int64))
+    if dim == 2:
+        dom.linear_solver = scn.lu
+    else:  # the script's own solver (3D_Script.jl: idrs!, s = 20)
+        dom.linear_solver = lambda d: solvers.iterative_solve(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue, d.converge_tol,
+                                                              Sv_func=solvers.idrs, maxiter=2000, max_pass=20, s=20)
+    hist = dom.update_one_step()
+    return dom, hist
+
+
+@functools.lru_cache(maxsize=None)
+def _solved_tet10_thermal():
+    from oracle import thermal_3d
+
+    z = np.load(os.path.join(GOLD, "pikachu_tet10.npz"))
+    dom = thermal_3d.build(z["vert"], z["conn"].astype(np.int64))
+    dom.linear_solver = thermal_3d.lu
+    hist = dom.update_one_step()
+    return dom, hist, dom.x.copy()
+
+
+
 def test_oracle_reproduces_stress_concentration_2d_vtk():
     """examples/linear_elasticity/stress_concentration/2D_Script.jl: Abaqus quad mesh (.inp) -> quad-8, component-wise
     penalty on the symmetry lines, sigl{2,2} n{2} traction; every constant as written in the script."""
     from oracle import stress_concentration as scn
 
     z = np.load(os.path.join(GOLD, "stress_concentration_2d.npz"))
-    dom = scn.build(z["vert"], z["conn"].astype(np.int64))
+    dom, hist = _solved_stress(2)
     assert dom.mesh.ncp == 1399 == z["d1"].size
-    dom.linear_solver = scn.lu
-    hist = dom.update_one_step()
     assert hist[-1] < dom.converge_tol
     d, idx = cKDTree(dom.mesh.coords).query(z["xyz"])
     assert d.max() < 1e-7
@@ -159,11 +185,8 @@ def test_oracle_reproduces_stress_concentration_3d_vtk():
     from oracle import stress_concentration as scn
 
     z = np.load(os.path.join(GOLD, "stress_concentration_3d.npz"))
-    dom = scn.build(z["vert"], z["conn"].astype(np.int64))
+    dom, hist = _solved_stress(3)
     assert dom.mesh.ncp == 15645 == z["d1"].size
-    dom.linear_solver = lambda d: solvers.iterative_solve(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue, d.converge_tol,
-                                                          Sv_func=solvers.idrs, maxiter=2000, max_pass=20, s=20)
-    hist = dom.update_one_step()
     assert hist[-1] < dom.converge_tol
     d, idx = cKDTree(dom.mesh.coords).query(z["xyz"])
     assert d.max() < 1e-7
@@ -179,11 +202,10 @@ def test_oracle_reproduces_tet10_thermal_vtk():
     from oracle import thermal_3d
 
     z = np.load(os.path.join(GOLD, "pikachu_tet10.npz"))
-    dom = thermal_3d.build(z["vert"], z["conn"].astype(np.int64))
+    dom, hist, T_solved = _solved_tet10_thermal()
     assert dom.mesh.ncp == 23703 == z["T"].size and dom.mesh.nel == 15334
-    dom.linear_solver = thermal_3d.lu
-    hist = dom.update_one_step()
     assert hist[-1] < dom.converge_tol
+    dom.x[:] = T_solved
     d, idx = cKDTree(dom.mesh.coords * 100.0).query(z["xyz"])  # write_VTK(...; scale = 100)
     assert d.max() < 1e-4
     assert (np.abs(dom.x[idx] - z["T"]) / z["T"]).max() < 1e-5
@@ -194,3 +216,80 @@ def test_oracle_reproduces_tet10_thermal_vtk():
     dom.update_x_star()
     dom.K_nonlinear_func()
     assert np.linalg.norm(dom.residue) / np.sqrt(dom.residue.size) < 1e-6  # the script's converge_tol
+
+
+# ---- pins 7-9: the reference's committed Paraview line samples (CSV), reproduced by sampling the oracle's fields --------------
+def _line(z, key):
+    return z[key + "_pts"], z[key + "_mask"].astype(bool)
+
+
+def test_oracle_reproduces_thermal_line_samples():
+    """examples/thermal_conduction/MetaFEM_a.csv, MetaFEM_b.csv (read at 3D_Script.jl:73-74): T along two vertical lines of the
+    tet-10 result, sampled in Paraview from the written VTK (coordinates x 100, 5 significant digits)."""
+    from oracle.sampling import Sampler
+
+    z = np.load(os.path.join(GOLD, "line_samples.npz"))
+    dom, _, T = _solved_tet10_thermal()
+    S = Sampler(dom.mesh, dom.disc)
+    for tag in ("a", "b"):
+        pts, mask = _line(z, f"thermal_{tag}")
+        got, valid = S.sample({"T": T}, pts / 100.0, tol=1e-5)  # write_VTK(...; scale = 100)
+        inside = mask & valid
+        assert inside.sum() >= mask.sum() - 2  # (a sample point on the boundary may fall either way)
+        assert np.abs(got["T"][inside] - z[f"thermal_{tag}_T"][inside]).max() < 0.02  # 5 digits of ~300 K = 0.005 K
+
+
+def test_oracle_reproduces_stress_concentration_line_samples():
+    """examples/linear_elasticity/stress_concentration/{2D,3D}_MetaFEM_{x,y}.csv (read at 3D_Script.jl:93-94): displacements
+    along the two symmetry lines of the plate with a hole (quad-8 / hex-20), 5 significant digits."""
+    from oracle.sampling import Sampler
+
+    z = np.load(os.path.join(GOLD, "line_samples.npz"))
+    for dim in (2, 3):
+        dom, _ = _solved_stress(dim)
+        S = Sampler(dom.mesh, dom.disc)
+        n = dom.mesh.ncp
+        fields = {f"d{i + 1}": dom.x[i * n:(i + 1) * n] for i in range(dim)}
+        for tag in ("x", "y"):
+            pts, mask = _line(z, f"stress{dim}d_{tag}")
+            got, valid = S.sample(fields, pts[:, :dim], tol=1e-5)
+            inside = mask & valid
+            assert inside.sum() >= mask.sum() - 1
+            scale = max(np.nanmax(np.abs(z[f"stress{dim}d_{tag}_d{i + 1}"][mask])) for i in range(dim))
+            for i in range(dim):
+                ref = z[f"stress{dim}d_{tag}_d{i + 1}"]
+                assert np.abs(got[f"d{i + 1}"][inside] - ref[inside]).max() < 2e-4 * scale, (dim, tag, i)
+
+
+def test_oracle_reproduces_cylinder_flow_line_samples():
+    """examples/incompressible_flow/cylinder_flow/MetaFEM_y2.csv, MetaFEM_y3.csv (read at 3D_MetaFEM_Script.jl:122-123): p, u1, u2, u3 along
+    two lines through the channel -- the reference's only committed numbers of a run with Pl_func = Pl_Jacobi (:90).  The oracle's run of
+    that script (oracle/cylinder.py; tet-10, 164 808 DOF, idrs!(s = 8) + Pl_Jacobi, every constant as written) takes minutes of numpy, so
+    its sampled lines are the committed fixture oracle_cylinder_lines.npz (make_golden.py::cylinder_oracle); here they are compared with
+    the reference's file, and the pieces the fixture was made with are exercised on a small case."""
+    zl = np.load(os.path.join(GOLD, "line_samples.npz"))
+    zo = np.load(os.path.join(GOLD, "oracle_cylinder_lines.npz"))
+    h = zo["newton_history"]
+    assert h[-1] < 1e-6 and len(h) <= 7 and np.all(h[1:] < 0.2 * h[:-1])  # the script's converge_tol within its max_iter = 6
+    for tag in ("y2", "y3"):
+        mask = zl[f"cylinder_{tag}_mask"].astype(bool)
+        inside = mask & zo[f"{tag}_valid"]
+        assert inside.sum() >= mask.sum() - 1
+        u_scale = np.abs(zl[f"cylinder_{tag}_u1"][mask]).max()
+        for k in ("p", "u1", "u2", "u3"):
+            ref = zl[f"cylinder_{tag}_{k}"]
+            scale = u_scale if k != "p" else np.abs(ref[mask]).max()
+            assert np.abs(zo[f"{tag}_{k}"][inside] - ref[inside]).max() < 1e-3 * scale, (tag, k)
+    # the generator's building blocks on a case the CPU suite can afford: the weak forms assemble on a coarse tetrahedral brick and
+    # one Newton step with the script's solver (idrs! + Pl_Jacobi) contracts
+    from oracle import cylinder
+
+    n = (3, 2, 2)
+    vert, cube = om.make_brick((0.5, 0.41, 0.41), n)
+    conn = om.simplex_split(cube, n)  # make_Brick(..., :SIMPLEX), 201_Helper_TM.jl:55-76
+    dom = cylinder.build(vert, conn, L=0.5, itg_order=6)
+    dom.linear_solver = cylinder.solver_of_the_script
+    dom.x[:] = 0.0
+    dom.dessemble_x(cylinder.INNER_INFOS)
+    hist = dom.update_one_step(max_iter=2)
+    assert hist[1] < 0.5 * hist[0]
