@@ -141,6 +141,22 @@ def cylinder_oracle(precomputed=None):
     np.savez_compressed(os.path.join(HERE, "oracle_cylinder_lines.npz"), **out)
 
 
+def neo_hookean_oracle(steps=3):
+    """Oracle output for the hyperelastic tensile test (examples/hyper_elasticity/static_Neo_Hookean.jl; oracle/hyperelastic.py): mean
+    elongation of the right face after the first `steps` load steps of each of the script's three material setups (LU solves, Newton to
+    the script's 1e-5).  About 12 s per load step."""
+    from oracle import hyperelastic as he
+
+    dom = he.build()
+    lu = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    out = {}
+    for s, (mu, lam, _, sig) in enumerate([(1e6, 1e6, 10, 4e5), (1e6, 2e8, 40, 1e5), (2e6, 2e8, 80, 1e5)]):  # :88
+        d1s, P1s, hists = he.run_setup(dom, mu, lam, steps, sig, linear_solver=lu)
+        out[f"d1s_{s}"], out[f"P1s_{s}"] = d1s, P1s
+        out[f"newton_last_{s}"] = np.array([h[-1] for h in hists])
+    np.savez_compressed(os.path.join(HERE, "oracle_neo_hookean.npz"), **out)
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -258,6 +274,7 @@ if __name__ == "__main__":
     elasticity_hex8()
     thermal_hex27()
     c_header()
+    neo_hookean_oracle()
     if "--cylinder" in sys.argv:  # 25 minutes: only on request
         cylinder_oracle()
     print("fixtures written to", HERE)

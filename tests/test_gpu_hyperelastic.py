@@ -1,0 +1,77 @@
+"""examples/hyper_elasticity/static_Neo_Hookean.jl on the GPU through the product's generic path: hex-20 bar (40 x 4 x 4), finite-strain
+Neo-Hookean weak form -Bilinear(F{i,j}, P{i,j}) with P = dW/dF (9 residual + 81 nonlinear-gradient terms per Newton iteration), penalty-fixed
+left face, nominal traction on the right face, the script's three material setups and 130 load steps with update_OneStep(max_iter = 7) and
+the script's solver bicgstabl_GS!(s = 4, maxiter = 3000, max_pass = 10) (:80).  Checked against the closed form the script itself plots
+(uniaxial_Neo_Hookean, :123) and, on the first load steps, against the oracle's run of the same script (committed fixture)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SETUPS = [(1e6, 1e6, 10, 4e5), (1e6, 2e8, 40, 1e5), (2e6, 2e8, 80, 1e5)]  # mu, lam, total steps, step load (:88)
+
+
+def test_neo_hookean_tensile_test_on_gpu(mf):
+    import torch
+    from metafem_jl_amd import element, generic as G, mesh as pm
+    from oracle import hyperelastic as he, mesh as om
+    from test_gpu_unstructured import _wf
+
+    L_box, e_number, LW = 1.0, 4, 10
+    size = (L_box * LW, L_box, L_box)
+    space = element.classical_space(3, "Serendipity", 2, 5)
+    vert, conn = om.make_brick(size, (e_number * LW, e_number, e_number))  # make_Brick is data here (tests/test_product_mesh.py covers the product's)
+    msh = pm.mesh_Classical(vert, conn, space)
+    fac = pm.get_BoundaryMesh(msh)
+    err = L_box / e_number * 0.01
+    c = fac.centroid
+    left, right = fac.select(np.abs(c[:, 0]) < err), fac.select(np.abs(c[:, 0] - size[0]) < err)
+    params = dict(mu=1e6, lam=1e6, tau=1e9)
+    gd = G.GenericDomain(mf.default_context(), space, msh.coords, msh.cp_ids, 3, _wf(he.domain_weakform(params)),
+                         [(left.element_ID, left.element_eindex, _wf(he.fixed_weakform(params))),
+                          (right.element_ID, right.element_eindex, _wf(he.load_weakform()))])
+    n = msh.ncp
+    assert n == 3665 and gd.A.n == 10995
+    gd.converge_tol = 1e-5  # :86
+    stats = []
+
+    def solver(g):  # :80
+        dx, st = mf.iterative_Solve(g.A, g.K_total, g.residue, g.converge_tol, Sv_func=mf.bicgstabl_GS_, maxiter=3000, max_pass=10, s=4)
+        stats.append(st)
+        return dx
+
+    gd.linear_solver = solver
+    right_cps = np.nonzero(np.abs(msh.coords[:, 0] - size[0]) < 0.25 * L_box / e_number)[0]  # :83-84
+    zo = np.load(os.path.join(GOLD, "oracle_neo_hookean.npz"))
+    worst = 0.0
+    full = os.environ.get("MFEM_FULL_TENSILE") == "1"  # all 130 load steps of the script (75 s); default: all 10 of the first setup (elongation
+    for s, (mu, lam, steps, sig) in enumerate(SETUPS):  # up to 1.9) and the first 10 of the two nearly incompressible ones
+        steps = steps if full else min(steps, 10)
+        params["mu"], params["lam"], params["tau"] = mu, lam, 1000 * max(lam, mu) / L_box  # :92-94
+        gd.x.zero_()
+        d1s = []
+        for i in range(1, steps + 1):
+            gd.controlpoints["Pl1"] = torch.full((n,), sig * i, dtype=torch.float64, device="cuda")
+            hist = gd.update_OneStep(max_iter=7)
+            assert hist[-1] < gd.converge_tol, (s, i, hist)  # 1e-5 on the normalised Newton residual (north_star: 1e-6-level for nonlinear residuals; the script's own tolerance)
+            d1 = float(gd.x[:n][torch.tensor(right_cps, device="cuda")].sum()) / (size[0] * right_cps.size)  # :108
+            d1s.append(d1)
+        d1s = np.array(d1s)
+        P1s = sig * np.arange(1, steps + 1)
+        # the closed form the script plots its points against (uniaxial stress state; the clamped end costs about a percent)
+        ana = he.uniaxial_neo_hookean(1.0 + d1s, lam, mu)
+        dev = np.abs(ana - P1s) / P1s
+        worst = max(worst, dev.max())
+        assert dev.max() < 0.02, (s, dev.max())
+        assert np.all(np.diff(d1s) > 0)
+        # the oracle's run of the same script on the first load steps (its LU solves; Newton to 1e-5 on both sides)
+        k = zo[f"d1s_{s}"].size
+        assert np.abs(d1s[:k] - zo[f"d1s_{s}"]).max() < 1e-6 * zo[f"d1s_{s}"].max(), (s, d1s[:k], zo[f"d1s_{s}"])
+    # like the reference, the linear solver reports and never fails (02_Preconditioner.jl:66-73): a solve that stops at max_pass above the
+    # tolerance still gives Newton a useful step; every Newton loop above reached 1e-5.  Most solves do converge:
+    nconv = sum(1 for st in stats if st.converged)
+    print(f"neo-hookean: {len(stats)} bicgstabl_GS! solves ({nconv} reached the tolerance, worst final residual "
+          f"{max(st.final_res for st in stats):.2e}), worst deviation from the closed form {worst:.3%}, final elongation {d1s[-1]:.3f}")
+    assert nconv >= 0.8 * len(stats)

@@ -293,3 +293,26 @@ def test_oracle_reproduces_cylinder_flow_line_samples():
     dom.dessemble_x(cylinder.INNER_INFOS)
     hist = dom.update_one_step(max_iter=2)
     assert hist[1] < 0.5 * hist[0]
+
+
+def test_oracle_reproduces_the_neo_hookean_closed_form():
+    """examples/hyper_elasticity/static_Neo_Hookean.jl: the script plots its load / elongation points against the closed form
+    uniaxial_Neo_Hookean (:123) -- a known answer the reference holds for a NONLINEAR problem (finite-strain weak form with P = dW/dF from
+    symbolic differentiation, load stepping, Newton with max_iter = 7) solved with bicgstabl_GS!(s = 4) (:80).  The committed fixture
+    (make_golden.py::neo_hookean_oracle) holds the oracle's first three load steps of each of the three material setups; here one load step is
+    recomputed, once with LU and once with the script's bicgstabl_GS!, and everything is compared with the closed form."""
+    from oracle import hyperelastic as he
+
+    zo = np.load(os.path.join(GOLD, "oracle_neo_hookean.npz"))
+    setups = [(1e6, 1e6, 4e5), (1e6, 2e8, 1e5), (2e6, 2e8, 1e5)]
+    for s, (mu, lam, sig) in enumerate(setups):
+        d1s, P1s = zo[f"d1s_{s}"], zo[f"P1s_{s}"]
+        assert np.all(zo[f"newton_last_{s}"] < 1e-5)  # the script's converge_tol
+        ana = he.uniaxial_neo_hookean(1.0 + d1s, lam, mu)
+        assert np.abs(ana - P1s).max() < 0.015 * P1s.max(), (s, ana, P1s)  # the clamped end costs about a percent of the uniaxial state
+    dom = he.build()
+    lu = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    d_lu, _, h_lu = he.run_setup(dom, 1e6, 1e6, 1, 4e5, linear_solver=lu)
+    assert h_lu[0][-1] < 1e-5 and abs(d_lu[0] - zo["d1s_0"][0]) < 1e-9
+    d_bi, _, h_bi = he.run_setup(dom, 1e6, 1e6, 1, 4e5)  # solver_of_the_script: bicgstabl_GS!, s = 4
+    assert h_bi[0][-1] < 1e-5 and abs(d_bi[0] - d_lu[0]) < 1e-6 * d_lu[0]
