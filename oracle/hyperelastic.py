@@ -18,21 +18,42 @@ from .fem import AssembleWeakform, GradTerm, ResTerm
 INNER_INFOS = [("d1", 0, 0), ("d2", 1, 0), ("d3", 2, 0)]
 
 
-def uniaxial_neo_hookean(l1, lam, mu):
+def uniaxial_neo_hookean(l1, lam, mu):  # (keyword order of the script: l1, lam, mu)
     """static_Neo_Hookean.jl:123 -- nominal stress of the uniaxial state at stretch l1."""
     return mu * l1 + ((lam * mu * (l1 - 1)) / (mu + lam * l1) - mu) / l1
 
 
-def _tensors():
+def uniaxial_mooney_rivlin(l1, C10, C01, lam):
+    """static_Mooney_Rivlin.jl:125-126 -- Jac(l1, ...) and the nominal stress mooney_Rivlin(l1, ...) of the uniaxial state."""
+    a = 2 * C10 + 2 * C01 * l1 ** 2 + lam * l1
+    Jac = l1 * (-a + np.sqrt(a ** 2 + 8 * C01 * (lam + 2 * C10 + 4 * C01))) / (4 * C01)
+    return 2 * C10 * l1 + 4 * C01 * Jac + (lam * (Jac - 1) - 2 * C10 - 4 * C01) / l1
+
+
+MODELS = {  # model -> names of its material GLOBAL_VARs, in the order of the lambdified arguments
+    "neo_hookean": ("mu", "lam"),
+    "mooney_rivlin": ("C10", "C01", "lam"),
+}
+
+
+def _tensors(model: str = "neo_hookean"):
     F = sp.Matrix(3, 3, lambda i, j: sp.Symbol(f"F{i}{j}", real=True))
-    mu, lam = sp.symbols("mu lam", positive=True)
+    mats = sp.symbols(" ".join(MODELS[model]), positive=True)
     J = F.det()
-    C = F.T * F
-    W = mu / 2 * (C.trace() - 3 - 2 * sp.log(J)) + lam / 2 * (J - 1) ** 2  # :49
+    if model == "neo_hookean":
+        mu, lam = mats
+        C = F.T * F
+        W = mu / 2 * (C.trace() - 3 - 2 * sp.log(J)) + lam / 2 * (J - 1) ** 2  # static_Neo_Hookean.jl:49
+    else:
+        C10, C01, lam = mats
+        B = F * F.T                                                            # static_Mooney_Rivlin.jl:48-52
+        I1 = B.trace()
+        I2 = (I1 ** 2 - (B * B).trace()) / 2
+        W = C10 * (I1 - 3 - 2 * sp.log(J)) + C01 * (I2 - 3 - 4 * sp.log(J)) + lam / 2 * (J - 1) ** 2
     Fs = [F[i, j] for i in range(3) for j in range(3)]
     P = [sp.diff(W, f) for f in Fs]
     A = [[sp.diff(p, f) for f in Fs] for p in P]
-    args = Fs + [mu, lam]
+    args = Fs + list(mats)
     mods = [{"log": _log}, "numpy"]  # the term functions are data shared with the GPU tests: they must accept torch tensors too
     fP = sp.lambdify(args, P, mods, cse=True)
     fA = sp.lambdify(args, [a for row in A for a in row], mods, cse=True)
@@ -48,12 +69,13 @@ def _log(x):
 _CACHE = {}
 
 
-def domain_weakform(params: dict) -> AssembleWeakform:
-    """-Bilinear(F{i,j}, P{i,j}): the dual word F{i,j} = delta{i,j} + d{i;j} varies as d{i;j}.  `params` (mu, lam) is read at call
-    time: GLOBAL_VARs of the script (physics.global_vars, :92-94)."""
-    if "t" not in _CACHE:
-        _CACHE["t"] = _tensors()
-    fP, fA = _CACHE["t"]
+def domain_weakform(params: dict, model: str = "neo_hookean") -> AssembleWeakform:
+    """-Bilinear(F{i,j}, P{i,j}): the dual word F{i,j} = delta{i,j} + d{i;j} varies as d{i;j}.  `params` (the model's material constants)
+    is read at call time: GLOBAL_VARs of the script (physics.global_vars, :92-94)."""
+    if model not in _CACHE:
+        _CACHE[model] = _tensors(model)
+    fP, fA = _CACHE[model]
+    mat_names = MODELS[model]
     wf = AssembleWeakform()
     wf.inner_vars = [(f"d{i + 1}__d{j}", i, 1 + j, 0) for i in range(3) for j in range(3)]
 
@@ -63,7 +85,7 @@ def domain_weakform(params: dict) -> AssembleWeakform:
             for j in range(3):
                 g = env[f"d{i + 1}__d{j}"]
                 out.append(g + 1.0 if i == j else g)
-        return out + [params["mu"], params["lam"]]
+        return out + [params[k] for k in mat_names]
 
     def evaluate(env):  # one evaluation of P and A per environment (the 90 term functions share it; cached IN the environment)
         m = env.get("__hyperelastic")
@@ -100,8 +122,8 @@ def load_weakform() -> AssembleWeakform:
     return wf
 
 
-def build(e_number: int = 4, LW_ratio: int = 10, L_box: float = 1.0):
-    """:7-78."""
+def build(e_number: int = 4, LW_ratio: int = 10, L_box: float = 1.0, model: str = "neo_hookean"):
+    """:7-78 (the two scripts differ in W and its constants only)."""
     size = (L_box * LW_ratio, L_box, L_box)
     disc = re_.initialize_classical_element(3, "CUBE", 2, 1, 5, itp_type="Serendipity")  # :69
     vert, conn = om.make_brick(size, (e_number * LW_ratio, e_number, e_number))
@@ -110,8 +132,8 @@ def build(e_number: int = 4, LW_ratio: int = 10, L_box: float = 1.0):
     err = L_box / e_number * 0.01
     c = fac.centroid
     left, right = np.abs(c[:, 0]) < err, np.abs(c[:, 0] - size[0]) < err
-    params = dict(mu=1e6, lam=1e6, tau=1e9, L=size[0])
-    dom = fem.FEMDomain(msh, disc, 3, domain_weakform(params), [(fac.select(left), fixed_weakform(params)), (fac.select(right), load_weakform())])
+    params = dict(mu=1e6, lam=1e6, C10=1e6, C01=1e6, tau=1e9, L=size[0])
+    dom = fem.FEMDomain(msh, disc, 3, domain_weakform(params, model), [(fac.select(left), fixed_weakform(params)), (fac.select(right), load_weakform())])
     dom.converge_tol = 1e-5  # :86
     dom.params = params
     dx = L_box / e_number
@@ -126,10 +148,14 @@ def solver_of_the_script(dom):
                                    Sv_func=solvers.bicgstabl_gs, maxiter=3000, max_pass=10, s=4)
 
 
-def run_setup(dom, mu: float, lam: float, total_steps: int, sigma_step: float, linear_solver=None, max_iter: int = 7):
-    """One entry of `setups` (:88-112): returns (elongations d1s, nominal stresses P1s, Newton histories)."""
+def run_setup(dom, mu: float, lam: float, total_steps: int, sigma_step: float, linear_solver=None, max_iter: int = 7, materials=None):
+    """One entry of `setups` (:88-112): returns (elongations d1s, nominal stresses P1s, Newton histories).  `materials` (dict) replaces
+    (mu, lam) for the Mooney-Rivlin script: C10, C01, lam."""
     P = dom.params
-    P["mu"], P["lam"], P["tau"] = mu, lam, 1000 * max(lam, mu) / 1.0  # :92-94 (L_box = 1)
+    if materials is None:
+        materials = dict(mu=mu, lam=lam)
+    P.update(materials)
+    P["tau"] = 1000 * max(materials.values()) / 1.0  # :92-94 / Mooney :100 (L_box = 1)
     dom.linear_solver = linear_solver or solver_of_the_script
     dom.x[:] = 0.0  # :96-99
     d1s, P1s, hists = [], [], []

@@ -157,6 +157,20 @@ def neo_hookean_oracle(steps=3):
     np.savez_compressed(os.path.join(HERE, "oracle_neo_hookean.npz"), **out)
 
 
+def mooney_rivlin_oracle(steps=3):
+    """The same for examples/hyper_elasticity/static_Mooney_Rivlin.jl (W of :48-52, setups of :94)."""
+    from oracle import hyperelastic as he
+
+    dom = he.build(model="mooney_rivlin")
+    lu = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
+    out = {}
+    for s, (C10, C01, lam, _, sig) in enumerate([(1e6, 1e6, 1e8, 30, 4e5), (1e6, 5e6, 1e8, 30, 5e5), (5e6, 1e6, 1e8, 40, 10e5)]):
+        d1s, P1s, hists = he.run_setup(dom, 0, 0, steps, sig, linear_solver=lu, materials=dict(C10=C10, C01=C01, lam=lam))
+        out[f"d1s_{s}"], out[f"P1s_{s}"] = d1s, P1s
+        out[f"newton_last_{s}"] = np.array([h[-1] for h in hists])
+    np.savez_compressed(os.path.join(HERE, "oracle_mooney_rivlin.npz"), **out)
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -275,6 +289,7 @@ if __name__ == "__main__":
     thermal_hex27()
     c_header()
     neo_hookean_oracle()
+    mooney_rivlin_oracle()
     if "--cylinder" in sys.argv:  # 25 minutes: only on request
         cylinder_oracle()
     print("fixtures written to", HERE)

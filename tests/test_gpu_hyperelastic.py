@@ -10,10 +10,17 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-SETUPS = [(1e6, 1e6, 10, 4e5), (1e6, 2e8, 40, 1e5), (2e6, 2e8, 80, 1e5)]  # mu, lam, total steps, step load (:88)
+# (material constants, total steps, step load): static_Neo_Hookean.jl:88 / static_Mooney_Rivlin.jl:94
+SETUPS = {
+    "neo_hookean": [(dict(mu=1e6, lam=1e6), 10, 4e5), (dict(mu=1e6, lam=2e8), 40, 1e5), (dict(mu=2e6, lam=2e8), 80, 1e5)],
+    "mooney_rivlin": [(dict(C10=1e6, C01=1e6, lam=1e8), 30, 4e5), (dict(C10=1e6, C01=5e6, lam=1e8), 30, 5e5), (dict(C10=5e6, C01=1e6, lam=1e8), 40, 10e5)],
+}
 
 
-def test_neo_hookean_tensile_test_on_gpu(mf):
+@pytest.mark.parametrize("model", ["neo_hookean", "mooney_rivlin"])
+def test_hyperelastic_tensile_test_on_gpu(mf, model):
+    """model = mooney_rivlin: static_Mooney_Rivlin.jl -- W = C10 (I1 - 3 - 2 ln J) + C01 (I2 - 3 - 4 ln J) + lam/2 (J - 1)^2 (:48-52), closed form
+    mooney_Rivlin(l1, ...) of :125-126, otherwise the same script."""
     import torch
     from metafem_jl_amd import element, generic as G, mesh as pm
     from oracle import hyperelastic as he, mesh as om
@@ -28,8 +35,8 @@ def test_neo_hookean_tensile_test_on_gpu(mf):
     err = L_box / e_number * 0.01
     c = fac.centroid
     left, right = fac.select(np.abs(c[:, 0]) < err), fac.select(np.abs(c[:, 0] - size[0]) < err)
-    params = dict(mu=1e6, lam=1e6, tau=1e9)
-    gd = G.GenericDomain(mf.default_context(), space, msh.coords, msh.cp_ids, 3, _wf(he.domain_weakform(params)),
+    params = dict(mu=1e6, lam=1e6, C10=1e6, C01=1e6, tau=1e9)
+    gd = G.GenericDomain(mf.default_context(), space, msh.coords, msh.cp_ids, 3, _wf(he.domain_weakform(params, model)),
                          [(left.element_ID, left.element_eindex, _wf(he.fixed_weakform(params))),
                           (right.element_ID, right.element_eindex, _wf(he.load_weakform()))])
     n = msh.ncp
@@ -44,12 +51,14 @@ def test_neo_hookean_tensile_test_on_gpu(mf):
 
     gd.linear_solver = solver
     right_cps = np.nonzero(np.abs(msh.coords[:, 0] - size[0]) < 0.25 * L_box / e_number)[0]  # :83-84
-    zo = np.load(os.path.join(GOLD, "oracle_neo_hookean.npz"))
+    zo = np.load(os.path.join(GOLD, f"oracle_{model}.npz"))
+    closed_form = he.uniaxial_neo_hookean if model == "neo_hookean" else he.uniaxial_mooney_rivlin
     worst = 0.0
     full = os.environ.get("MFEM_FULL_TENSILE") == "1"  # all 130 load steps of the script (75 s); default: all 10 of the first setup (elongation
-    for s, (mu, lam, steps, sig) in enumerate(SETUPS):  # up to 1.9) and the first 10 of the two nearly incompressible ones
-        steps = steps if full else min(steps, 10)
-        params["mu"], params["lam"], params["tau"] = mu, lam, 1000 * max(lam, mu) / L_box  # :92-94
+    for s, (mats, steps, sig) in enumerate(SETUPS[model]):  # up to 1.9) and the first 10 (6) of the nearly incompressible ones
+        steps = steps if full else min(steps, 10 if model == "neo_hookean" else 6)
+        params.update(mats)
+        params["tau"] = 1000 * max(mats.values()) / L_box  # :92-94
         gd.x.zero_()
         d1s = []
         for i in range(1, steps + 1):
@@ -61,7 +70,7 @@ def test_neo_hookean_tensile_test_on_gpu(mf):
         d1s = np.array(d1s)
         P1s = sig * np.arange(1, steps + 1)
         # the closed form the script plots its points against (uniaxial stress state; the clamped end costs about a percent)
-        ana = he.uniaxial_neo_hookean(1.0 + d1s, lam, mu)
+        ana = closed_form(1.0 + d1s, **mats)
         dev = np.abs(ana - P1s) / P1s
         worst = max(worst, dev.max())
         assert dev.max() < 0.02, (s, dev.max())
@@ -72,6 +81,6 @@ def test_neo_hookean_tensile_test_on_gpu(mf):
     # like the reference, the linear solver reports and never fails (02_Preconditioner.jl:66-73): a solve that stops at max_pass above the
     # tolerance still gives Newton a useful step; every Newton loop above reached 1e-5.  Most solves do converge:
     nconv = sum(1 for st in stats if st.converged)
-    print(f"neo-hookean: {len(stats)} bicgstabl_GS! solves ({nconv} reached the tolerance, worst final residual "
+    print(f"{model}: {len(stats)} bicgstabl_GS! solves ({nconv} reached the tolerance, worst final residual "
           f"{max(st.final_res for st in stats):.2e}), worst deviation from the closed form {worst:.3%}, final elongation {d1s[-1]:.3f}")
     assert nconv >= 0.8 * len(stats)

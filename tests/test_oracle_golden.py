@@ -310,6 +310,12 @@ def test_oracle_reproduces_the_neo_hookean_closed_form():
         assert np.all(zo[f"newton_last_{s}"] < 1e-5)  # the script's converge_tol
         ana = he.uniaxial_neo_hookean(1.0 + d1s, lam, mu)
         assert np.abs(ana - P1s).max() < 0.015 * P1s.max(), (s, ana, P1s)  # the clamped end costs about a percent of the uniaxial state
+    # the sister script static_Mooney_Rivlin.jl (W of :48-52, closed form mooney_Rivlin of :125-126): the committed oracle steps
+    zm = np.load(os.path.join(GOLD, "oracle_mooney_rivlin.npz"))
+    for s, mats in enumerate([dict(C10=1e6, C01=1e6, lam=1e8), dict(C10=1e6, C01=5e6, lam=1e8), dict(C10=5e6, C01=1e6, lam=1e8)]):
+        assert np.all(zm[f"newton_last_{s}"] < 1e-5)
+        ana = he.uniaxial_mooney_rivlin(1.0 + zm[f"d1s_{s}"], **mats)
+        assert np.abs(ana - zm[f"P1s_{s}"]).max() < 0.015 * zm[f"P1s_{s}"].max(), (s, ana)
     dom = he.build()
     lu = lambda d: solvers.solver_lu_cpu(d.pattern.rowptr, d.pattern.colidx, d.K_total, d.residue)
     d_lu, _, h_lu = he.run_setup(dom, 1e6, 1e6, 1, 4e5, linear_solver=lu)
