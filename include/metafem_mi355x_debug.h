@@ -34,7 +34,9 @@ int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
  * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128); bit 26 rows outside the swept planes
  * in a launch of their own; bit 27 the patch-major copy made from the slot-major copy in a second pass. */
 int mfem_debug_set_ell(int enable);
-/* mode 3: bit 0 on/off; bit 1 always read explicit columns; bits 8-13 sort rows within windows of 2^w rows (0 = whole
+/* mode 3: bit 0 on/off; bit 1 always read explicit columns; bit 2 every XCD walks a contiguous eighth of the blocks; bits 4-7 (x 8 = R)
+ * rows sorted inside lattice regions of R^3 points when the pattern carries a lattice hint (mfem_brick_pattern) -- both measured slower than
+ * the default at hex-27 128^3 (profiles/r03_sell_regions.txt), same results; bits 8-13 sort rows within windows of 2^w rows (0 = whole
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
 int mfem_debug_set_sell(int enable);
 /* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems

@@ -210,6 +210,11 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   A->rowptr_bits = 64;
   A->index_base = 0;
   A->ncols = (b->plo > 0 || b->phi < b->m[0]) ? xlen : n;
+  // hint for the solver layouts: the rows of one field are the nodes of a lattice with m[1] x m[2] points per plane (row = field * n_owned +
+  // (plane * m1 + j) * m2 + k) -- any use of it must stay correct for an arbitrary pattern (it only orders work)
+  A->lat_m1 = b->m[1];
+  A->lat_m2 = b->m[2];
+  A->lat_fields = n_fields;
   MFEM_CHECK_HIP(hipMalloc(&A->owned_rowptr, sizeof(int64_t) * (n + 1)));
   MFEM_CHECK_HIP(hipMalloc(&A->owned_colidx, sizeof(int32_t) * (nnz > 0 ? nnz : 1)));
   A->rowptr = A->owned_rowptr;

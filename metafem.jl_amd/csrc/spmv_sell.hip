@@ -26,21 +26,30 @@ static int g_sell_offsets = 1;  // blocks with one diagonal list skip their colu
 static int g_sell_window_log2 = 0;
 static int g_sell_unroll = 5;   // slots in flight per lane (bits 16-20 of mfem_debug_set_sell; 0 = default)
 static int g_sell_wg_per_cu = 8;
+static int g_sell_region = 0;   // edge of the lattice regions of the row sort (bits 4-7 of mfem_debug_set_sell x 8; 0 = global sort)
+static int g_sell_xcd = 0;      // bit 2: every XCD walks a contiguous eighth of the block list
 extern "C" int mfem_debug_set_sell(int enable) {  // bit 0: layout on/off; bit 1: always read explicit columns
   ++mfem_debug_epoch;
   g_sell_enable = enable & 1;
   g_sell_offsets = (enable & 2) ? 0 : 1;
+  g_sell_xcd = (enable & 4) ? 1 : 0;
+  g_sell_region = ((enable >> 4) & 15) * 8;
   g_sell_window_log2 = (enable >> 8) & 63;
   g_sell_unroll = ((enable >> 16) & 31) ? ((enable >> 16) & 31) : 5;
   g_sell_wg_per_cu = ((enable >> 24) & 31) ? ((enable >> 24) & 31) : 8;  // rows are sorted within windows of 2^w consecutive rows (0 = over the whole matrix)
   return MFEM_OK;
 }
 
+struct SellRegions {  // lattice regions of the row sort (R = 0: none)
+  int R;
+  int64_t n_nodes, PL, m2, nri, nrj, nrk;
+};
+
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                             int base, int maxlen, int wshift, int lenbits,
                                                             uint64_t* __restrict__ keys, int32_t* __restrict__ ids,
-                                                            int32_t* __restrict__ n_ghost_rows) {
+                                                            int32_t* __restrict__ n_ghost_rows, SellRegions G) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) {
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
@@ -56,7 +65,16 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* _
       }
     }
     // ghost-reading rows sort behind all others (bit 63): the leading blocks can run while the halo exchange is in flight
-    keys[r] = ((uint64_t)(ghost ? 1 : 0) << 63) | ((uint64_t)(r >> wshift) << (32 + lenbits)) |
+    // window of the sort: 2^wshift consecutive rows, or -- lattice hint -- a cube of R^3 lattice points: the rows of all lengths (node
+    // types) of one region are neighbours in the block list, so the x entries they share are fetched while they are still in the L2s
+    uint64_t win = (uint64_t)(r >> wshift);
+    if (G.R > 0) {
+      const int64_t node = r % G.n_nodes, f = r / G.n_nodes;
+      const int64_t pi = node / G.PL, rem = node - pi * G.PL;
+      const int64_t pj = rem / G.m2, pk = rem - pj * G.m2;
+      win = (uint64_t)(((f * G.nri + pi / G.R) * G.nrj + pj / G.R) * G.nrk + pk / G.R);
+    }
+    keys[r] = ((uint64_t)(ghost ? 1 : 0) << 63) | (win << (32 + lenbits)) |
               ((uint64_t)(uint32_t)(maxlen - (int32_t)(hi - lo)) << 32) | h;
     ids[r] = (int32_t)r;
     if (ghost) atomicAdd(n_ghost_rows, 1);
@@ -162,14 +180,22 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nbl
                                                             const double* __restrict__ vals, const double* __restrict__ x,
                                                             double* __restrict__ y, double alpha, double beta,
                                                             const double* __restrict__ dotw, double* __restrict__ partials,
-                                                            const int32_t* __restrict__ done_flag, int64_t b_lo, int64_t b_hi) {
+                                                            const int32_t* __restrict__ done_flag, int64_t b_lo, int64_t b_hi, int xcd) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t b = b_lo + wave; b < b_hi; b += nwaves) {  // [b_lo, b_hi): all blocks, or one part of a split (multi-rank) SpMV
+  // xcd != 0: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch) and walk one contiguous eighth of the blocks
+  int64_t b_first = b_lo + wave, b_stride = nwaves, b_end = b_hi;
+  if (xcd) {
+    const int64_t x = blockIdx.x & 7, wpw = blockDim.x >> 6, nb = b_hi - b_lo;
+    b_first = b_lo + nb * x / 8 + ((int64_t)(blockIdx.x >> 3) * wpw + (threadIdx.x >> 6));
+    b_end = b_lo + nb * (x + 1) / 8;
+    b_stride = (int64_t)(gridDim.x >> 3) * wpw;
+  }
+  for (int64_t b = b_first; b < b_end; b += b_stride) {  // [b_lo, b_hi): all blocks, or one part of a split (multi-rank) SpMV
     const int64_t p0 = ptr[b];
     const int Kb = (int)((ptr[b + 1] - p0) / SELL_B);
     // lane l owns the block's rows l and l + 64: the value loads of a slot are two unit-stride 512-byte runs, and the x
@@ -274,6 +300,8 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   int32_t n_ghost = 0;
   int32_t* d_ghost = ctx->d_flags + 9;
   const bool has_ghosts = A->ncols > A->n;
+  SellRegions G{};
+  uint64_t nwin = 1;
   const int grid = mfem_grid_for(n, MFEM_BLOCK, ctx->num_cus * 16);
   int lenbits = 1;
   while ((1 << lenbits) <= A->max_row_nnz && lenbits < 31) ++lenbits;
@@ -285,16 +313,29 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   SELL_CHECK(hipMalloc(&sizes, sizeof(int64_t) * (size_t)(nblk + 1)));
   SELL_CHECK(hipMalloc(&ptr, sizeof(int64_t) * (size_t)(nblk + 1)));
   SELL_CHECK(hipMemsetAsync(d_ghost, 0, sizeof(int32_t), ctx->stream));
+  if (g_sell_region > 0 && g_sell_window_log2 == 0 && A->lat_m1 > 0 && A->lat_m2 > 0 && A->lat_fields > 0 && n % A->lat_fields == 0 &&
+      (n / A->lat_fields) % ((int64_t)A->lat_m1 * A->lat_m2) == 0) {
+    G.R = g_sell_region;
+    G.n_nodes = n / A->lat_fields;
+    G.PL = (int64_t)A->lat_m1 * A->lat_m2;
+    G.m2 = A->lat_m2;
+    G.nri = (G.n_nodes / G.PL + G.R - 1) / G.R;
+    G.nrj = (A->lat_m1 + G.R - 1) / G.R;
+    G.nrk = (A->lat_m2 + G.R - 1) / G.R;
+    nwin = (uint64_t)A->lat_fields * G.nri * G.nrj * G.nrk;
+  }
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_sell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int64_t*)A->rowptr, A->colidx,
-                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost);
+                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost, G);
   else
     hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr, A->colidx,
-                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost);
+                       A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost, G);
   SELL_CHECK(hipMemcpyAsync(ctx->h_flags + 9, d_ghost, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   {
     int bits = 32 + lenbits;  // the low word is the signature of the diagonal list
-    if (wshift < 63)
+    if (G.R > 0) {
+      while (bits < 63 && ((nwin - 1) >> (bits - 32 - lenbits))) ++bits;                     // region index on top
+    } else if (wshift < 63)
       while (bits < 64 && ((uint64_t)(n - 1) >> wshift) >> (bits - 32 - lenbits)) ++bits;  // window index on top
     if (has_ghosts) bits = 64;  // ... and the ghost-reading rows behind everything else
     SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, ids, rowid, (int)n, 0, bits, ctx->stream));
@@ -315,7 +356,8 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   SELL_CHECK(hipStreamSynchronize(ctx->stream));
   n_ghost = ctx->h_flags[9];
   // (padding: up to one block of the longest rows at the tail; with ghost-reading rows sorted last, one more where they begin)
-  if ((double)total <= 1.15 * (double)A->nnz + (has_ghosts ? 256.0 : 128.0) * A->max_row_nnz) {
+  // (... and with lattice regions every region pads each of its row lengths to whole blocks: the regions are sized so that this stays small)
+  if ((double)total <= (G.R > 0 ? 1.25 : 1.15) * (double)A->nnz + (has_ghosts ? 256.0 : 128.0) * A->max_row_nnz) {
     SELL_CHECK(hipMalloc(&A->sell_cols, sizeof(int32_t) * (size_t)total));
     const int g2 = mfem_grid_for(8 * nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
     if (A->rowptr_bits == 64)
@@ -425,7 +467,7 @@ int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 #define SELL_LAUNCH(U)                                                                                                            \
   hipLaunchKernelGGL(k_spmv_sell<U>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk, A->sell_ptr, A->sell_rowid, \
                      g_sell_offsets ? A->sell_flags : nullptr, A->sell_off, A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw,   \
-                     partials, done_flag, b_lo, b_hi)
+                     partials, done_flag, b_lo, b_hi, (g_sell_xcd && (grid & 7) == 0) ? 1 : 0)
   switch (g_sell_unroll) {
     case 4: SELL_LAUNCH(4); break;
     case 8: SELL_LAUNCH(8); break;

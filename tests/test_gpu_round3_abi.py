@@ -134,3 +134,36 @@ def test_row_owner_assembly_refuses_collapsed_elements_and_the_host_falls_back(m
     dom3.K_linear_func()
     assert np.allclose(K_rows, dom3.K_linear.cpu().numpy(), rtol=1e-12, atol=1e-14)
     assert np.abs(K_rows).max() > 0
+
+
+@pytest.mark.parametrize("knob", [1 | (4 << 4), 1 | 4 | (2 << 4), 1 | 4])
+def test_sliced_layout_region_sort_and_xcd_walk_equal_the_csr_kernel(mf, knob):
+    """mfem_debug_set_sell bits 4-7 (rows sorted inside lattice regions of (8 x value)^3 points) and bit 2 (XCD-contiguous block walks): only the
+    order of the work changes; y equals the CSR kernel's on a hex-27 brick, also on a slab with ghost columns."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib, parallel as par
+
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    _lib.lib.mfem_debug_set_sell(knob)
+    try:
+        for slab in (None, (6, 14)):
+            b = mf.make_Brick((2.0, 1.0, 1.0), (10, 9, 8), 2, 5)
+            if slab:
+                b.set_slab(*slab)
+            A = b.pattern(1)
+            K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+            nloc = par.local_vector_length(slab[0], slab[1], b.m[1], b.m[2], 1, order=2) if slab else A.n
+            x = mf.FEM_rand(nloc, 3, 0) - 0.5
+            mode = C.c_int32()
+            _lib.check(_lib.lib.mfem_csr_solver_layout(b.ctx._h, A._h, C.byref(mode), None, None, None))
+            assert mode.value == 3
+            y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+            y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+            mf.mul_(y0, A, K, x)
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+            assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+    finally:
+        _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
