@@ -129,6 +129,50 @@ def load_traffic():
         return {}
 
 
+def collect_traffic_live(leg: str, timeout_s: int = 240):
+    """HBM-side bytes per launch of the priced kernels on `leg`, COLLECTED IN THIS RUN: two child runs of tools/pmc_leg.py under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes as MI355X_MICROARCH.md prescribes; the program
+    itself directly after `--`; children of this process, started with subprocess -- nothing here is exec-replaced), summarised by
+    tools/make_r03_traffic.py (gfx950 x2 FETCH correction, calibration on k_axpby in the same runs).  Returns (dict, None) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mfem_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for grp in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, f"{leg}_{grp}")
+            with open(d + ".log", "w") as log:
+                # its own process group: a pass that overruns is ended as a group (the profiler's launcher AND the program under it)
+                pr = subprocess.Popen([rp, "--kernel-trace", "--pmc", grp, "-d", d, "-o", "out", "--output-format", "csv", "--",
+                                       sys.executable, os.path.join(ROOT, "tools", "pmc_leg.py"), leg, "2"],
+                                      cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+                try:
+                    rc = pr.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    import signal
+
+                    os.killpg(pr.pid, signal.SIGKILL)  # exactly the group started above
+                    pr.wait()
+                    return None, f"rocprofv3 --pmc {grp} pass did not finish in {timeout_s} s"
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {grp} pass exited with {rc}"
+        out = os.path.join(tmp, "traffic.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_r03_traffic.py"), tmp, out, "this bench.py run"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        if r.returncode != 0 or not os.path.exists(out):
+            return None, "tools/make_r03_traffic.py failed"
+        return json.load(open(out)), None
+    except Exception as e:  # a missing counter, a timeout: the committed file stays the source
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +186,9 @@ def main():
     ap.add_argument("--secondary-n", type=int, default=256, help="c2 at N = 1: also run this mesh size (configs[1]) for a few steps (0 = skip)")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--hex27-n", type=int, default=128, help="c2 at N = 1: CSR-kernel roofline on the hex-27 matrix of this size (0 = skip)")
+    ap.add_argument("--live-traffic", type=int, default=1,
+                    help="N = 1, default sizes: collect the roofline objects' `traffic` in this run (two rocprofv3 --pmc child passes on the "
+                         "headline workload, ~40 s) instead of reading profiles/r03_traffic.json (0 = read the file)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.n <= 0:
@@ -449,6 +496,31 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # never lose the line over a side measurement
             out["roofline"]["csr_kernel_hex27"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.live_traffic and args.n == cfg["n"]:
+        # the counters of the headline workload's two priced kernels, observed in THIS run (the parent's GPU work is over and its
+        # memory released; the children set up the same matrix themselves)
+        leg = f"{args.config}_{args.n}"
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        live, why = collect_traffic_live(leg)
+        rf = out["roofline"]
+        for obj, key in ((rf, f"{main_res['kernel_key']}@{leg}"), (rf.get("csr_kernel"), f"csr_kernel@{leg}")):
+            if obj is None:
+                continue
+            ent = live.get(key) if live else None
+            if ent and ent.get("hbm_bytes_per_launch"):
+                tb = ent["hbm_bytes_per_launch"]
+                obj["traffic_committed_file"] = obj.get("traffic")
+                obj["traffic"] = tb
+                obj["traffic_over_algorithmic"] = tb / obj["algorithmic_bytes_per_launch"]
+                obj["frac_actual"] = tb / (obj["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                cal = ent.get("calibration") or {}
+                obj["traffic_source"] = (f"collected in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (two child passes of "
+                                         f"tools/pmc_leg.py {leg}; {ent.get('launches_measured')} launches; FETCH_SIZE x 2 per MI355X_MICROARCH.md; in-run "
+                                         f"calibration on k_axpby: read {cal.get('FETCH_SIZE_x2_bytes', 0) / max(cal.get('expected_read_bytes', 1), 1):.4f} x, "
+                                         f"written {cal.get('WRITE_SIZE_bytes', 0) / max(cal.get('expected_write_bytes', 1), 1):.4f} x of the known bytes)")
+            elif obj.get("traffic_source"):
+                obj["traffic_source"] += f"; live collection not available ({why or 'kernel missing in the counter output'})"
     if rank == 0:
         if world == 1 and args.config == "c2" and args.cpu_n > 0:
             cb = cpu_baseline(args.cpu_n, args.iters, args.cpu_repeats)

@@ -79,3 +79,14 @@ def test_c3_c4_legs_single_gpu(config, n, ndof):
     out = run_bench(["--config", config, "--n", str(n), "--iters", "40"] + SMALL)
     _common(out, 1)
     assert out["config"]["n_dof"] == ndof and "csr_kernel" in out["roofline"]
+
+
+def test_traffic_is_collected_in_the_run_at_a_config_size():
+    """At a config's own size bench.py observes the HBM counters itself: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) on the
+    workload's leg; `traffic_source` says so and the calibration kernel's known bytes are met.  (c3 at 128^3: the smallest such leg.)"""
+    out = run_bench(["--config", "c3", "--steps", "1", "--warmup", "0", "--iters", "40"], timeout=1200)
+    _common(out, 1)
+    for obj in (out["roofline"], out["roofline"]["csr_kernel"]):
+        assert obj["traffic"] and obj["traffic_source"].startswith("collected in this run"), obj.get("traffic_source")
+        assert 0.9 < obj["traffic_over_algorithmic"] < 1.4 and 0 < obj["frac_actual"] < 1
+        assert "read 1.000" in obj["traffic_source"] and "written 1.000" in obj["traffic_source"]
