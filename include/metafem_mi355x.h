@@ -157,7 +157,9 @@ typedef struct {
   int32_t fixed_iterations; /* !=0: ignore converge_tol, run exactly maxiter iterations in ONE pass (benchmark mode) */
   int32_t scale_in_place;   /* !=0: Pr_Jacobi! semantics -- `vals` is overwritten by the column-scaled matrix
                                (the reference scales its private gather K_total[K_val_ids], :35,118).
-                               ==0: the library scales a private copy (nnz*8 B of workspace). */
+                               ==0: `vals` is left untouched.  On the solver layouts the scaling happens while the layout copy is made
+                               (no scaled CSR copy exists); small systems on the CSR kernel and solves with a left preconditioner
+                               scale a private copy (nnz*8 B of workspace). */
   int32_t left_precond;     /* mfem_left_precond_kind (Pl_func).  The reference applies Pl to every mat-vec result inside
                                the Krylov body; here the rows of the working matrix and b are scaled once, which is the
                                same operator.  The restart wrapper follows :57-60 (true residual un-scaled, tol_factor).
