@@ -108,16 +108,17 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ell_vals_lds(int64_t n, int64_t 
     }
     const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
     const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= 64 K
-    for (int i0 = lane; i0 < cnt; i0 += 64 * 8) {
-      double tv[8];
+    constexpr int NB = 28;  // loads in flight per lane: a tile of 27-entry rows in ONE round trip (with 8 the kernel waited 79 % of its wave cycles)
+    for (int i0 = lane; i0 < cnt; i0 += 64 * NB) {
+      double tv[NB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int i = i0 + 64 * u;
         tv[u] = i < cnt ? vals[s0 + i] : 0.0;
         if (dsc && i < cnt) tv[u] /= dsc[col[s0 + i] - base];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int i = i0 + 64 * u;
         if (i < cnt) T[i] = tv[u];
       }
@@ -327,18 +328,21 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     // a tile of a regular block whose rows all have every diagonal of the class (cnt = RT D: away from the mesh boundary, nearly all
     // tiles): entry s of a row IS its slot s -- the columns are not needed, a third of the kernel's reads
     const bool full = cls >= 0 && cnt == RT * O.D[cls];
-    // staging: all loads of a lane are issued before the first LDS store (cnt <= RT K: a handful of batches of 8)
-    for (int i0 = lane; i0 < cnt; i0 += 64 * 8) {
-      double tv[8];
-      int32_t tc[8];
+    // staging: all loads of a lane are issued before the first LDS store.  28 in flight per lane: a 64-row tile of 27-entry rows (27 per lane) is
+    // ONE memory round trip, a 32-row tile of 81-entry rows two (SQ counters of the version with batches of 8: 79 % of the wave cycles waiting,
+    // ~10 waves per CU with 4 KB in flight each)
+    constexpr int NB = 28;
+    for (int i0 = lane; i0 < cnt; i0 += 64 * NB) {
+      double tv[NB];
+      int32_t tc[NB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int i = i0 + 64 * u;
         tv[u] = i < cnt ? vals[s0 + i] : 0.0;
         tc[u] = (i < cnt && stage_cols) ? col[s0 + i] : 0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int i = i0 + 64 * u;
         if (i < cnt) {
           T[i] = tv[u];
