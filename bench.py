@@ -230,6 +230,7 @@ def main():
     dev = f"cuda:{local_rank}"
     use_comm = world > 1 or os.environ.get("MFEM_BENCH_FORCE_COMM") == "1"  # the env var exercises the RCCL path at N = 1
     traffic_db = load_traffic()
+    state = {"gloo_group": None, "transport": None}  # set when the RCCL transport had to be replaced (run_workload)
 
     def barrier():
         if dist is not None:
@@ -294,11 +295,35 @@ def main():
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                comm = (parallel.HostSlabComm if host_comm else parallel.SlabComm)(ctx, brick, rank, world, n_fields=F)
-                if not host_comm and os.environ.get("MFEM_BENCH_SKIP_SELFTEST") != "1":
-                    # every RCCL call of the solver's schedule once, on a ring, before the timed region: a transport problem shows
-                    # up here with a message instead of as a hang inside the Krylov loop
-                    _lib.check(_lib.lib.mfem_debug_comm_selftest(ctx._h, order * m1 * m2, 2))
+                if host_comm:
+                    comm = parallel.HostSlabComm(ctx, brick, rank, world, n_fields=F)
+                else:
+                    ok, why = 1, ""
+                    try:
+                        comm = parallel.SlabComm(ctx, brick, rank, world, n_fields=F)
+                        if os.environ.get("MFEM_BENCH_SIMULATE_RCCL_FAILURE") == "1":  # test hook for the fallback below
+                            raise RuntimeError("simulated failure of the RCCL self-test")
+                        if os.environ.get("MFEM_BENCH_SKIP_SELFTEST") != "1":
+                            # every RCCL call of the solver's schedule once, on a ring, before the timed region: a transport problem
+                            # shows up here with a message instead of as a hang inside the Krylov loop
+                            _lib.check(_lib.lib.mfem_debug_comm_selftest(ctx._h, order * m1 * m2, 2))
+                    except Exception as e:  # the library's RCCL transport is unusable on this rank
+                        ok, why = 0, repr(e)
+                    if dist is not None:  # all ranks take the same transport
+                        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                        ok = int(flag.item())
+                    if not ok:
+                        # fall back to the host-callback transport (device -> pinned host -> gloo -> device): the same solver code path,
+                        # a slower exchange -- the run still produces its line, and says so
+                        print(f"bench.py rank {rank}: RCCL transport of the library not usable ({why or 'another rank failed'}); "
+                              f"falling back to the host-callback transport over gloo", file=sys.stderr)
+                        if comm is not None:
+                            comm.close()
+                        if state.get("gloo_group") is None and dist is not None:
+                            state["gloo_group"] = dist.new_group(backend="gloo")
+                        comm = parallel.HostSlabComm(ctx, brick, rank, world, n_fields=F, group=state.get("gloo_group"))
+                        state["transport"] = "host callbacks over gloo (fallback: the library's RCCL self-test failed)"
                 C.CDLL(None).fflush(None)
             finally:
                 os.dup2(saved, 1)
@@ -462,8 +487,9 @@ def main():
                 "baseline_config": {"c2": "the north_star target size (512^3 hex-8, 1 GPU); configs[1] (256^3) is `secondary_256`",
                                     "c3": "configs[2]", "c4": "configs[3]"}[args.config] if args.n == cfg["n"] else f"{args.config} at a non-default size",
                 "n_dof": r["n_global"], "nnz_per_gpu": r["nnz"], "krylov_steps_per_step": per_step_updates,
-                "parallelism": "single GPU" if world == 1 else f"slab decomposition x{world} (RCCL halo overlapped with the interior "
-                                                               f"rows + one all-reduce per reduction group)",
+                "parallelism": "single GPU" if world == 1 else f"slab decomposition x{world} ("
+                               + (state["transport"] or ("host callbacks over gloo, ranks sharing one GPU: functional run" if host_comm else "RCCL"))
+                               + " halo overlapped with the interior rows + one all-reduce per reduction group)",
                 "solve_ms_per_step": solve_ms_step,
                 # the two halves of the metric on their own (whole job, all ranks)
                 "assembly_ms_per_step": r["elapsed"] / r["steps"] * 1e3 - solve_ms_step,

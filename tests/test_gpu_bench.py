@@ -90,3 +90,11 @@ def test_traffic_is_collected_in_the_run_at_a_config_size():
         assert obj["traffic"] and obj["traffic_source"].startswith("collected in this run"), obj.get("traffic_source")
         assert 0.9 < obj["traffic_over_algorithmic"] < 1.4 and 0 < obj["frac_actual"] < 1
         assert "read 1.000" in obj["traffic_source"] and "written 1.000" in obj["traffic_source"]
+
+
+def test_falls_back_to_the_host_transport_when_the_rccl_self_test_fails():
+    """If the library's RCCL transport is not usable (here: simulated), every rank agrees on the host-callback transport and the run still
+    prints its line, saying which transport carried it."""
+    out = run_bench(["--gpus", "1", "--n", "40"] + SMALL, env={"MFEM_BENCH_FORCE_COMM": "1", "MFEM_BENCH_SIMULATE_RCCL_FAILURE": "1"})
+    _common(out, 1)
+    assert out["config"]["n_dof"] == 41 ** 3
