@@ -39,6 +39,10 @@ int mfem_debug_set_ell(int enable);
  * the default at hex-27 128^3 (profiles/r03_sell_regions.txt), same results; bits 8-13 sort rows within windows of 2^w rows (0 = whole
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
 int mfem_debug_set_sell(int enable);
+/* mode 4 (symmetric lattice tiles, hex-27): 0 = off (mode 3 serves those solves), 1 = on (default). */
+int mfem_debug_set_lat27(int enable);
+/* SpMVs mode 4 has served so far, process-wide */
+long long mfem_debug_lat27_spmv_count(void);
 /* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
  * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
 int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);

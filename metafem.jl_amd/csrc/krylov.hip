@@ -663,10 +663,18 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (rc_plan) return rc_plan;
     sell_bytes = mfem_sell_vals_bytes(A);
   }
+  // hex-27 lattice matrix, solver on the unscaled matrix, one rank: the symmetric lattice-tile layout if this solve's values are symmetric
+  // (decided by its bind; the sliced layout takes over in the same workspace otherwise)
+  size_t lat_bytes = 0;
+  if (sell_bytes && (is_cg || !jac) && !left && !ctx->comm) {
+    rc_plan = mfem_lat27_plan(ctx, A);
+    if (rc_plan) return rc_plan;
+    lat_bytes = mfem_lat27_bytes(A);
+  }
   fused_scale = fused_scale && (ell_bytes || sell_bytes);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
   const bool need_copy = need_copy_unfused && !fused_scale;
   const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
-  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes + sell_bytes;
+  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes + (lat_bytes > sell_bytes ? lat_bytes : sell_bytes);
   int rc = mfem_ws_reserve(ctx, total);
   if (rc) return rc;
   char* base = (char*)ctx->ws;
@@ -696,6 +704,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     ~EllGuard() {
       mfem_ell_unbind(A);
       mfem_sell_unbind(A);
+      mfem_lat27_unbind(A);
     }
   } ell_guard{A};
 
@@ -762,7 +771,11 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       return MFEM_ERR_INVALID;
     }
   }
-  if (sell_bytes) {
+  if (lat_bytes) {
+    rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+    if (rc) return rc;
+  }
+  if (sell_bytes && !mfem_lat27_bound(A, vals_work)) {
     rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
     if (fused_scale && !A->sell_vals) {

@@ -847,8 +847,10 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
 static void csr_drop_plans(mfem_csr_s* A) {
   mfem_ell_unbind(A);
   mfem_sell_unbind(A);
+  mfem_lat27_unbind(A);
   mfem_ell_free(A);
   mfem_sell_free(A);
+  A->lat27_state = 0;
   A->sym_state = 0;
   A->symp_state = 0;
   if (A->rb_rows) hipFree(A->rb_rows);
@@ -1088,6 +1090,8 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   {
     const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part);
     if (e != 0) return e < 0 ? e : MFEM_OK;
+    const int lt = mfem_spmv_lat27_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part.part);
+    if (lt != 0) return lt < 0 ? lt : MFEM_OK;
     // (the sliced layout splits by BLOCKS: its ghost-reading rows are sorted behind all others, whatever the zones say)
     const int sl = mfem_spmv_sell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part.part);
     if (sl != 0) return sl < 0 ? sl : MFEM_OK;

@@ -1707,6 +1707,11 @@ extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int6
   int64_t e = A->nnz;
   int sym = 0;
   if (mode == 1 || mode == 2) e = (int64_t)A->ell_K * A->ell_npad;
+  if (mode == 3) e = A->sell_total;
+  if (mode == 4) {
+    e = mfem_lat27_entries(A);
+    sym = 3;
+  }
   if (mode == 2 && symp_wanted(A)) {
     sym = 2;
     // the rows outside the swept planes read their K slots; the sweep reads symp_pairs value pairs
@@ -1740,6 +1745,7 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
     const double reg = A->sell_nblk > 0 ? (double)A->sell_regular_blocks / (double)A->sell_nblk : 0.0;
     b = A->sell_total * 8 + (int64_t)((1.0 - reg) * (double)A->sell_total) * 4 + A->n * 16 + A->n * 4;  // + the row permutation
   }
+  if (mode == 4) b = mfem_lat27_design_bytes(A);
   if (mode == 2) {
     b += (A->n > reg ? A->n - reg : 0) * (int64_t)slots * 4;  // rows in generic blocks read their columns
     if (sym == 2) {  // the sweep stages a (4 + 2) x (32 + 2) neighbourhood of x per step instead of reading each swept entry once
@@ -1764,9 +1770,14 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
     rc = mfem_sell_plan(ctx, A);
     if (rc) return rc;
     if (mfem_sell_vals_bytes(A)) m = 3;
+    if (m == 3 && !ctx->comm) {  // symmetric lattice-tile layout (spmv_lat27.hip): the structure allows it; each solve's values decide
+      rc = mfem_lat27_plan(ctx, A);
+      if (rc) return rc;
+      if (mfem_lat27_bytes(A)) m = 4;
+    }
   }
   if (mode) *mode = m;
-  if (slots) *slots = (m == 1 || m == 2) ? A->ell_K : m == 3 ? A->max_row_nnz : 0;
+  if (slots) *slots = (m == 1 || m == 2) ? A->ell_K : m >= 3 ? A->max_row_nnz : 0;
   if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
@@ -1791,15 +1802,24 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     rc = mfem_sell_plan(ctx, A);
     if (rc) return rc;
     const size_t sb = mfem_sell_vals_bytes(A);
-    if (sb) {
-      rc = mfem_ws_reserve(ctx, sb);
+    size_t lb = 0;
+    if (sb && !ctx->comm) {
+      rc = mfem_lat27_plan(ctx, A);
       if (rc) return rc;
-      rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+      lb = mfem_lat27_bytes(A);
+    }
+    if (sb) {
+      rc = mfem_ws_reserve(ctx, lb > sb ? lb : sb);
+      if (rc) return rc;
+      if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws);
+      if (rc) return rc;
+      if (!mfem_lat27_bound(A, vals)) rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;
     }
   }
   rc = mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr, nullptr);
   mfem_ell_unbind(A);
   mfem_sell_unbind(A);
+  mfem_lat27_unbind(A);
   return rc;
 }

@@ -1,0 +1,465 @@
+// Symmetric lattice-tile layout for the Krylov loop on the hex-27 (order-2 Lagrange, one field) lattice matrix: solver layout mode 4.
+// The caller-facing contract stays CSR (mul!, misc/04_GPU_Utils.jl:131; iterative_Solve!, solver/03_Iterative_Solvers.jl:31-49).
+//
+// Why: the row-sorted sliced layout (spmv_sell.hip) streams all 64 entries of an average hex-27 row and gathers x from global memory
+// (10 L1 accesses per value line, 1.33 x the design bytes from HBM: profiles/r03_sell_memory_path.txt).  A hex-27 stiffness matrix
+// that CG may be run on is symmetric, and its pattern is a lattice stencil whose reach depends on the parity of the node in each
+// direction (even = element boundary: offsets -2..2, odd = element interior: -1..1; 8 node types, 27..125 entries per row).
+//
+//   * layout (per solve, one pass over the CSR values): only the diagonal and the entries with column > row are stored -- 14..63 of a
+//     row's 27..125.  Rows are grouped in units of 4 x 4 x 8 lattice points = 16 rows of each of the 8 types; a wave owns a unit, four
+//     lanes share a row and take every fourth stored entry, so a unit is 68 wave-wide 16-byte-per-lane... (8 bytes per lane per step,
+//     two steps per 16-byte load) unit-stride steps: 34.8 KB instead of the 65.5 KB of its 8 192 entries.  No column stream: the column of
+//     a slot is the row's lattice position plus a per-type table entry.
+//   * SpMV, pass 1 (k_spmv_lat27): a workgroup owns a tile of 8 x 8 x 32 lattice points (16 units, 8 waves).  It stages x of the tile and
+//     of the (+2, +-2, +-2) neighbourhood its stored entries reach in LDS (4 320 cells), and accumulates y in a second LDS block of
+//     the same shape: for a stored entry a = A[r][c] the lane adds a x[c] to its register sum for row r and a x[r] to cell c
+//     (ds_add_f64) -- the mirrored entry A[c][r] is never read.  The whole y block -- own cells and neighbourhood -- leaves as one
+//     contiguous 34.6 KB run per tile.
+//   * pass 2 (k_lat27_gather): row r sums the up to 18 tiles whose block covers it, in a fixed order, applies alpha / beta and the fused
+//     dot product.  No global atomics; 2.1 cells per row written and read again (+ 12 % traffic).
+//   * eligibility is decided in two steps: the pattern must BE the lattice stencil (checked entry by entry once per pattern), and the values
+//     of this solve must be symmetric: the layout pass reads both A[r][c] and A[c][r] and the bind falls back to the sliced layout when
+//     max |A[r][c] - A[c][r]| > 1e-13 max |A[r][c]|.  Only taken when the solver runs on the unscaled matrix (CG, or no Jacobi scaling).
+//   * y differs from the CSR kernel's by round-off (other summation order), and the order in which the waves of a workgroup add into
+//     an LDS cell is not fixed: results are reproducible to ~1e-16 relative, not bitwise (mfem_debug_set_lat27(0) selects the sliced layout).
+#include "blas1.h"
+
+#define L27_TI 8
+#define L27_TJ 8
+#define L27_TK 32
+#define L27_SJ (L27_TJ + 4)
+#define L27_SK (L27_TK + 4)
+#define L27_CELLS ((L27_TI + 2) * L27_SJ * L27_SK)  // 4320
+#define L27_UNIT_D 4352                             // doubles per unit: 64 lanes x 68 steps
+#define L27_TAB 272                                 // table entries: 4 x (16 + 3 x 10 + 3 x 6 + 4)
+#define L27_PAD 127
+
+typedef double l_d2 __attribute__((ext_vector_type(2)));
+
+extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
+static int g_lat27_enable = 1;
+static long long g_lat27_count = 0;
+extern "C" long long mfem_debug_lat27_spmv_count(void) { return g_lat27_count; }  // SpMVs the layout has served (bench.py: which kernel ran)
+extern "C" int mfem_debug_set_lat27(int enable) {
+  ++mfem_debug_epoch;
+  g_lat27_enable = enable & 1;
+  return MFEM_OK;
+}
+
+struct Lat27Geom {
+  int m0, m1, m2;     // lattice points per direction (odd)
+  int nui, nuj, nuk;  // units of 4 x 4 x 8 points
+  int nti, ntj, ntk;  // tiles of 8 x 8 x 32 points
+  int64_t n;
+};
+
+// type t = 4 (i odd) + 2 (j odd) + (k odd); steps per lane K4, stored slots Kup, group base inside a unit (doubles), table base (entries)
+__constant__ int c_l27_Kup[8];
+__constant__ int16_t c_l27_off[L27_TAB];   // [tb[t] + q * K4 + it]: LDS cell offset of slot it * 4 + q (0 for padding)
+__constant__ int8_t c_l27_d[L27_TAB][4];   // same index: (di, dj, dk) of the slot; di = L27_PAD for padding
+static const int h_l27_K4[8] = {16, 10, 10, 6, 10, 6, 6, 4};
+static const int h_l27_gb[8] = {0, 1024, 1664, 2304, 2688, 3328, 3712, 4096};
+static const int h_l27_tb[8] = {0, 64, 104, 144, 168, 208, 232, 256};
+__constant__ int c_l27_K4[8];
+__constant__ int c_l27_gb[8];
+__constant__ int c_l27_tb[8];
+static bool g_l27_tables = false;
+
+static int lat27_upload_tables() {
+  if (g_l27_tables) return MFEM_OK;
+  int Kup[8];
+  int16_t off[L27_TAB];
+  int8_t d[L27_TAB][4];
+  memset(off, 0, sizeof(off));
+  for (int i = 0; i < L27_TAB; ++i) { d[i][0] = L27_PAD; d[i][1] = d[i][2] = d[i][3] = 0; }
+  for (int t = 0; t < 8; ++t) {
+    const int R[3] = {(t & 4) ? 1 : 2, (t & 2) ? 1 : 2, (t & 1) ? 1 : 2};
+    const int K4 = h_l27_K4[t];
+    int s = 0;
+    auto put = [&](int di, int dj, int dk) {
+      const int it = s / 4, q = s % 4, idx = h_l27_tb[t] + q * K4 + it;
+      off[idx] = (int16_t)((di * L27_SJ + dj) * L27_SK + dk);
+      d[idx][0] = (int8_t)di; d[idx][1] = (int8_t)dj; d[idx][2] = (int8_t)dk;
+      ++s;
+    };
+    put(0, 0, 0);  // slot 0: the diagonal
+    for (int di = 0; di <= R[0]; ++di)
+      for (int dj = -R[1]; dj <= R[1]; ++dj)
+        for (int dk = -R[2]; dk <= R[2]; ++dk)
+          if (di > 0 || dj > 0 || (dj == 0 && dk > 0)) put(di, dj, dk);
+    Kup[t] = s;
+    if (s > 4 * K4) return MFEM_ERR_INVALID;
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_l27_Kup), Kup, sizeof(Kup)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_off), off, sizeof(off)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_d), d, sizeof(d)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_K4), h_l27_K4, sizeof(h_l27_K4)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_gb), h_l27_gb, sizeof(h_l27_gb)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_tb), h_l27_tb, sizeof(h_l27_tb)) != hipSuccess) {
+    mfem_set_error("lattice-tile tables: hipMemcpyToSymbol failed");
+    return MFEM_ERR_HIP;
+  }
+  g_l27_tables = true;
+  return MFEM_OK;
+}
+
+// offsets a row at lattice coordinate g (of m points) has along one direction: [lo, lo + cnt)
+__device__ __forceinline__ void l27_range(int g, int m, int& lo, int& cnt) {
+  if (g & 1) {
+    lo = -1;
+    cnt = 3;
+  } else {
+    lo = g >= 2 ? -2 : -g;
+    const int hi = (m - 1 - g) >= 2 ? 2 : (m - 1 - g);
+    cnt = hi - lo + 1;
+  }
+}
+
+// 1 in *bad if some row is not the lattice stencil row: length = product of the per-direction ranges, columns in lexicographic order
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_l27_verify(Lat27Geom G, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                             int base, int32_t* __restrict__ bad) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t PL = (int64_t)G.m1 * G.m2;
+  int fail = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < G.n; r += stride) {
+    const int gi = (int)(r / PL);
+    const int64_t rem = r - gi * PL;
+    const int gj = (int)(rem / G.m2), gk = (int)(rem - (int64_t)gj * G.m2);
+    int li, ni, lj, nj, lk, nk;
+    l27_range(gi, G.m0, li, ni);
+    l27_range(gj, G.m1, lj, nj);
+    l27_range(gk, G.m2, lk, nk);
+    const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+    if (hi - lo != (int64_t)ni * nj * nk) {
+      fail = 1;
+      continue;
+    }
+    int64_t j = lo;
+    for (int a = 0; a < ni; ++a)
+      for (int b = 0; b < nj; ++b) {
+        const int64_t c0 = r + (int64_t)(li + a) * PL + (int64_t)(lj + b) * G.m2 + lk;
+        for (int c = 0; c < nk; ++c, ++j)
+          if ((int64_t)col[j] - base != c0 + c) fail = 1;
+      }
+  }
+  if (fail) bad[0] = 1;
+}
+
+// The layout pass: a wave per unit.  stats[0] = max |A[r][c] - A[c][r]|, stats[1] = max |A[r][c]| over the stored pairs (bit patterns of
+// non-negative doubles, which order like integers).
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* __restrict__ rowptr, int base,
+                                                           const double* __restrict__ vals, double* __restrict__ out,
+                                                           unsigned long long* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, q = lane & 3, rho = lane >> 2;
+  const int ra = rho >> 3, rb = (rho >> 2) & 1, rc = rho & 3;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
+  const int64_t PL = (int64_t)G.m1 * G.m2;
+  double amax = 0.0, dmax = 0.0;
+  for (int64_t u = wave; u < nunits; u += nwaves) {
+    const int uk = (int)(u % G.nuk);
+    const int64_t u2 = u / G.nuk;
+    const int uj = (int)(u2 % G.nuj), ui = (int)(u2 / G.nuj);
+    double* ou = out + u * L27_UNIT_D;
+    for (int t = 0; t < 8; ++t) {
+      const int gi = ui * 4 + ((t >> 2) & 1) + 2 * ra, gj = uj * 4 + ((t >> 1) & 1) + 2 * rb, gk = uk * 8 + (t & 1) + 2 * rc;
+      const bool valid = gi < G.m0 && gj < G.m1 && gk < G.m2;
+      const int64_t r = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+      int li = 0, ni = 1, lj = 0, nj = 1, lk = 0, nk = 1;
+      int64_t rp = 0;
+      if (valid) {
+        l27_range(gi, G.m0, li, ni);
+        l27_range(gj, G.m1, lj, nj);
+        l27_range(gk, G.m2, lk, nk);
+        rp = (int64_t)rowptr[r] - base;
+      }
+      const int K4 = c_l27_K4[t], tb = c_l27_tb[t] + q * K4;
+      double* og = ou + c_l27_gb[t] + lane * 2;
+      for (int it = 0; it < K4; it += 2) {
+        l_d2 pr;
+        pr.x = 0.0;
+        pr.y = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int di = c_l27_d[tb + it + h][0], dj = c_l27_d[tb + it + h][1], dk = c_l27_d[tb + it + h][2];
+          const int ci = gi + di, cj = gj + dj, ck = gk + dk;
+          if (valid && di != L27_PAD && ci < G.m0 && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {
+            const double v = vals[rp + ((int64_t)(di - li) * nj + (dj - lj)) * nk + (dk - lk)];
+            const int64_t c = r + (int64_t)di * PL + (int64_t)dj * G.m2 + dk;
+            int mi, qi, mj, qj, mk, qk;
+            l27_range(ci, G.m0, mi, qi);
+            l27_range(cj, G.m1, mj, qj);
+            l27_range(ck, G.m2, mk, qk);
+            const double w = vals[(int64_t)rowptr[c] - base + ((int64_t)(-di - mi) * qj + (-dj - mj)) * qk + (-dk - mk)];
+            double df = fabs(v - w);
+            if (!(df == df)) df = __builtin_huge_val();  // NaN (or inf - inf) somewhere: never symmetric (fmax would drop it)
+            amax = fmax(amax, fabs(v));
+            dmax = fmax(dmax, df);
+            if (h) pr.y = v; else pr.x = v;
+          }
+        }
+        *(l_d2*)(og + (int64_t)(it >> 1) * 128) = pr;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
+    dmax = fmax(dmax, __shfl_down(dmax, o, MFEM_WAVE));
+  }
+  if (lane == 0) {
+    atomicMax(stats + 0, (unsigned long long)__double_as_longlong(dmax));
+    atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
+  }
+}
+
+template <int K4>
+__device__ __forceinline__ void l27_group(const double* __restrict__ gv, const uint32_t* __restrict__ tq, int pos, int q,
+                                          const double* xs, double* ys) {
+  l_d2 v[K4 / 2];
+#pragma unroll
+  for (int u = 0; u < K4 / 2; ++u) v[u] = __builtin_nontemporal_load((const l_d2*)gv + u * 64);
+  uint32_t w[K4 / 2];
+#pragma unroll
+  for (int u = 0; u < K4 / 2; ++u) w[u] = tq[u];
+  const double xr = xs[pos];
+  double acc = 0.0;
+#pragma unroll
+  for (int it = 0; it < K4; ++it) {
+    const int o = (it & 1) ? ((int)w[it >> 1] >> 16) : (int)(int16_t)(w[it >> 1] & 0xffffu);
+    const double a = (it & 1) ? v[it >> 1].y : v[it >> 1].x;
+    acc += a * xs[pos + o];
+    double m = a * xr;
+    if (it == 0) m = q == 0 ? 0.0 : m;  // slot 0 is the diagonal: nothing to mirror
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + pos + o), m);
+  }
+  acc += __shfl_xor(acc, 1, MFEM_WAVE);
+  acc += __shfl_xor(acc, 2, MFEM_WAVE);
+  if (q == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + pos), acc);
+}
+
+// pass 1: one workgroup per tile.  dump[tile][cell] = what the tile's stored entries contribute to y on its own cells and on the
+// (+2, +-2, +-2) neighbourhood.
+__global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double* __restrict__ vals, const double* __restrict__ x,
+                                                       double* __restrict__ dump, const int32_t* __restrict__ done_flag) {
+  __shared__ double xs[L27_CELLS];
+  __shared__ double ys[L27_CELLS];
+  __shared__ uint32_t tabs[L27_TAB / 2];
+  if (done_flag && done_flag[0]) return;
+  // workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch): each XCD walks a contiguous eighth of the tiles, so the
+  // neighbourhoods that overlap are staged through one L2
+  const int ntiles = G.nti * G.ntj * G.ntk, chunk = (ntiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
+  const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < L27_TAB / 2; e += 512)
+    tabs[e] = (uint32_t)(uint16_t)c_l27_off[2 * e] | ((uint32_t)(uint16_t)c_l27_off[2 * e + 1] << 16);
+  const int i0 = ti * L27_TI, j0 = tj * L27_TJ - 2, k0 = tk * L27_TK - 2;
+  for (int e = tid; e < L27_CELLS; e += 512) {
+    const int li = e / (L27_SJ * L27_SK), r2 = e - li * (L27_SJ * L27_SK), lj = r2 / L27_SK, lk = r2 - lj * L27_SK;
+    const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+    double xv = 0.0;
+    if (gi < G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) xv = x[((int64_t)gi * G.m1 + gj) * G.m2 + gk];
+    xs[e] = xv;
+    ys[e] = 0.0;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6, q = lane & 3, rho = lane >> 2;
+  const int ra = rho >> 3, rb = (rho >> 2) & 1, rc = rho & 3;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const int uu = wv + 8 * h;  // unit inside the tile: (a, b, c) in 2 x 2 x 4
+    const int ua = uu >> 3, ub = (uu >> 2) & 1, uc = uu & 3;
+    const int ui = ti * 2 + ua, uj = tj * 2 + ub, uk = tk * 4 + uc;
+    if (ui >= G.nui || uj >= G.nuj || uk >= G.nuk) continue;
+    const double* uv = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * L27_UNIT_D + lane * 2;
+    // LDS cell of the lane's row of type (0, 0, 0); the other types are +1 in the odd directions
+    const int p0 = ((ua * 4 + 2 * ra) * L27_SJ + (ub * 4 + 2 * rb + 2)) * L27_SK + (uc * 8 + 2 * rc + 2);
+    const int PI = L27_SJ * L27_SK, PJ = L27_SK;
+    l27_group<16>(uv + 0, tabs + (0 + q * 16) / 2, p0, q, xs, ys);
+    l27_group<10>(uv + 1024, tabs + (64 + q * 10) / 2, p0 + 1, q, xs, ys);
+    l27_group<10>(uv + 1664, tabs + (104 + q * 10) / 2, p0 + PJ, q, xs, ys);
+    l27_group<6>(uv + 2304, tabs + (144 + q * 6) / 2, p0 + PJ + 1, q, xs, ys);
+    l27_group<10>(uv + 2688, tabs + (168 + q * 10) / 2, p0 + PI, q, xs, ys);
+    l27_group<6>(uv + 3328, tabs + (208 + q * 6) / 2, p0 + PI + 1, q, xs, ys);
+    l27_group<6>(uv + 3712, tabs + (232 + q * 6) / 2, p0 + PI + PJ, q, xs, ys);
+    l27_group<4>(uv + 4096, tabs + (256 + q * 4) / 2, p0 + PI + PJ + 1, q, xs, ys);
+  }
+  __syncthreads();
+  double* dt = dump + (int64_t)tile * L27_CELLS;
+  for (int e = tid; e < L27_CELLS; e += 512) dt[e] = ys[e];
+}
+
+// pass 2: y[r] = alpha * (sum over the tiles whose block covers r, fixed order) + beta * y[r]; fused dot with dotw
+__global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather(Lat27Geom G, const double* __restrict__ dump, double* __restrict__ y,
+                                                               double alpha, double beta, const double* __restrict__ dotw,
+                                                               double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+    for (int e = threadIdx.x; e < L27_TI * L27_TJ * L27_TK; e += MFEM_BLOCK) {
+      const int lk = e & (L27_TK - 1), lj = (e >> 5) & (L27_TJ - 1), li = e >> 8;
+      const int gi = ti * L27_TI + li, gj = tj * L27_TJ + lj, gk = tk * L27_TK + lk;
+      if (gi >= G.m0 || gj >= G.m1 || gk >= G.m2) continue;
+      double s = 0.0;
+      // covering tiles: (ti + a, tj + b, tk + c), a in {-1, 0}, b, c in {-1, 0, 1}: the row's cell in that tile's block must exist
+      for (int a = -1; a <= 0; ++a) {
+        if (a < 0 && (li >= 2 || ti == 0)) continue;
+        for (int b = -1; b <= 1; ++b) {
+          if ((b < 0 && (lj >= 2 || tj == 0)) || (b > 0 && (lj < L27_TJ - 2 || tj == G.ntj - 1))) continue;
+          for (int c = -1; c <= 1; ++c) {
+            if ((c < 0 && (lk >= 2 || tk == 0)) || (c > 0 && (lk < L27_TK - 2 || tk == G.ntk - 1))) continue;
+            const int64_t src = ((int64_t)(ti + a) * G.ntj + (tj + b)) * G.ntk + (tk + c);
+            const int cell = ((li - L27_TI * a) * L27_SJ + (lj - L27_TJ * b + 2)) * L27_SK + (lk - L27_TK * c + 2);
+            s += dump[src * L27_CELLS + cell];
+          }
+        }
+      }
+      const int64_t r = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+      double yv = alpha * s;
+      if (beta != 0.0) yv += beta * y[r];
+      y[r] = yv;
+      if (dotw) dot_acc += yv * dotw[r];
+    }
+  }
+  if (partials) {
+    const double bsum = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bsum;
+  }
+}
+
+static Lat27Geom lat27_geom(const mfem_csr_s* A) {
+  Lat27Geom G{};
+  G.m1 = A->lat_m1;
+  G.m2 = A->lat_m2;
+  G.n = A->n;
+  G.m0 = (int)(A->n / ((int64_t)A->lat_m1 * A->lat_m2));
+  G.nui = (G.m0 + 3) / 4;
+  G.nuj = (G.m1 + 3) / 4;
+  G.nuk = (G.m2 + 7) / 8;
+  G.nti = (G.m0 + L27_TI - 1) / L27_TI;
+  G.ntj = (G.m1 + L27_TJ - 1) / L27_TJ;
+  G.ntk = (G.m2 + L27_TK - 1) / L27_TK;
+  return G;
+}
+
+// lat27_state: 0 not inspected, -1 not the lattice stencil, 1 structure ok
+int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  if (A->lat27_state != 0) return MFEM_OK;
+  if (A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
+  A->lat27_state = -1;
+  if (A->lat_fields != 1 || A->lat_m1 < 3 || A->lat_m2 < 3 || !(A->lat_m1 & 1) || !(A->lat_m2 & 1)) return MFEM_OK;
+  if (A->ncols > A->n) return MFEM_OK;  // slab patterns (ghost columns) keep the sliced layout
+  const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2;
+  if (A->n % PL != 0) return MFEM_OK;
+  const int64_t m0 = A->n / PL;
+  if (m0 < 3 || !(m0 & 1) || m0 > (1 << 20) || A->max_row_nnz > 125) return MFEM_OK;
+  int rc = lat27_upload_tables();
+  if (rc) return rc;
+  const Lat27Geom G = lat27_geom(A);
+  if ((int64_t)G.nti * G.ntj * G.ntk >= ((int64_t)1 << 28)) return MFEM_OK;
+  int32_t* d_bad = ctx->d_flags + 12;
+  MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
+  const int grid = mfem_grid_for(A->n, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_l27_verify<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->colidx,
+                       A->index_base, d_bad);
+  else
+    hipLaunchKernelGGL(k_l27_verify<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->colidx,
+                       A->index_base, d_bad);
+  MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_flags[12] == 0) A->lat27_state = 1;
+  return MFEM_OK;
+}
+
+static size_t lat27_vals_doubles(const Lat27Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * L27_UNIT_D; }
+static size_t lat27_dump_doubles(const Lat27Geom& G) { return (size_t)G.nti * G.ntj * G.ntk * L27_CELLS; }
+
+// workspace of the layout: the stored entries, then the per-tile y blocks
+size_t mfem_lat27_bytes(const mfem_csr_s* A) {
+  if (A->lat27_state != 1 || !g_lat27_enable || A->n < g_layout_min_rows_cols) return 0;
+  const Lat27Geom G = lat27_geom(A);
+  return sizeof(double) * (lat27_vals_doubles(G) + lat27_dump_doubles(G));
+}
+
+// Makes the layout copy of `vals` in buf; binds it if the values are symmetric (else leaves the pattern unbound: the caller binds
+// the sliced layout instead).  One stream synchronisation (the symmetry verdict).
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
+  A->lat27_vals = nullptr;
+  A->lat27_src = nullptr;
+  if (A->lat27_state != 1 || !g_lat27_enable || !buf) return MFEM_OK;
+  const Lat27Geom G = lat27_geom(A);
+  unsigned long long* d_stats = (unsigned long long*)(ctx->d_flags + 12);
+  MFEM_CHECK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
+  const int grid = mfem_grid_for(nunits * 64, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_l27_fill<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->index_base,
+                       vals, buf, d_stats);
+  else
+    hipLaunchKernelGGL(k_l27_fill<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->index_base,
+                       vals, buf, d_stats);
+  MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double dmax, amax;
+  memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
+  memcpy(&amax, ctx->h_flags + 14, sizeof(double));
+  A->lat27_asym = amax > 0.0 ? dmax / amax : (dmax > 0.0 ? 1.0 : 0.0);
+  if (!(dmax <= 1e-13 * amax)) return MFEM_OK;  // not symmetric (or NaN): the sliced layout serves this solve
+  A->lat27_vals = buf;
+  A->lat27_dump = buf + lat27_vals_doubles(G);
+  A->lat27_src = vals;
+  return MFEM_OK;
+}
+
+bool mfem_lat27_bound(const mfem_csr_s* A, const double* vals) { return A->lat27_vals && vals == A->lat27_src; }
+
+void mfem_lat27_unbind(mfem_csr_s* A) {
+  A->lat27_vals = nullptr;
+  A->lat27_dump = nullptr;
+  A->lat27_src = nullptr;
+}
+
+// returns 1 if launched, 0 if another kernel should be used, <0 on error
+int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
+                           double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part) {
+  if (!A->lat27_vals || vals != A->lat27_src) return 0;
+  if (part != 0) {
+    mfem_set_error("lattice-tile layout bound on a split SpMV");
+    return MFEM_ERR_INVALID;
+  }
+  if (n_partials) *n_partials = 0;
+  const Lat27Geom G = lat27_geom(A);
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  const int chunk = (ntiles + 7) / 8;
+  hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dump, done_flag);
+  MFEM_CHECK_LAUNCH();
+  int cap = ctx->num_cus * 8;
+  if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+  const int grid = ntiles < cap ? ntiles : cap;
+  hipLaunchKernelGGL(k_lat27_gather, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials,
+                     done_flag);
+  MFEM_CHECK_LAUNCH();
+  if (n_partials && partials) *n_partials = grid;
+  ++g_lat27_count;
+  return 1;
+}
+
+// bytes one SpMV of the layout moves by design: the stored entries, x as the tiles stage it, the y blocks written and read again, y
+int64_t mfem_lat27_design_bytes(const mfem_csr_s* A) {
+  const Lat27Geom G = lat27_geom(A);
+  const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
+  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * 3 + A->n * 8;
+}
+int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_vals_doubles(lat27_geom(A)); }

@@ -259,7 +259,13 @@ def test_solver_layout_inspector(mf):
     b3 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
     assert layout(b3, b3.pattern(1))[0] == 3        # small brick: boundary rows would need > 10 % padding in a uniform layout
     b27 = mf.make_Brick((1.0, 1.0, 1.0), (4, 4, 4), 2, 5)
-    assert layout(b27, b27.pattern(1))[0] == 3      # 27 / 45 / 75 / 125 entries per row: row-sorted sliced ELL
+    assert layout(b27, b27.pattern(1))[0] == 4      # the hex-27 lattice stencil: symmetric lattice tiles (if the values of the solve are symmetric)
+    _lib.lib.mfem_debug_set_lat27(0)
+    try:
+        b27s = mf.make_Brick((1.0, 1.0, 1.0), (4, 4, 4), 2, 5)
+        assert layout(b27s, b27s.pattern(1))[0] == 3  # 27 / 45 / 75 / 125 entries per row: row-sorted sliced ELL
+    finally:
+        _lib.lib.mfem_debug_set_lat27(1)
     b2 = mf.make_Brick((1.0, 1.0, 1.0), (3, 3, 3))
     assert layout(b2, b2.pattern(1))[0] == 0        # 64 rows: less than one block, CSR tile kernel
     K = b1.assemble_thermal(A1, 0.6, 25.0, 293.15, 0x3F)

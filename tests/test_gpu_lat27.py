@@ -1,0 +1,123 @@
+"""Solver layout mode 4 (csrc/spmv_lat27.hip): the hex-27 lattice matrix stored as symmetric lattice tiles.  The caller's contract stays
+CSR (mul!, misc/04_GPU_Utils.jl:131; iterative_Solve!, solver/03_Iterative_Solvers.jl:31-49): every check is against the CSR kernel /
+the sliced layout on the same values.  Tolerances: 1e-13 relative for one SpMV (other summation order), 1e-9 for converged solutions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K_COND, H, TENV = 0.6, 25.0, 293.15
+
+
+def _mode(b, A):
+    from metafem_jl_amd import _lib
+
+    mode = C.c_int32()
+    _lib.check(_lib.lib.mfem_csr_solver_layout(b.ctx._h, A._h, C.byref(mode), None, None, None))
+    return mode.value
+
+
+@pytest.fixture()
+def small_layouts():
+    from metafem_jl_amd import _lib
+
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    yield _lib
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+    _lib.lib.mfem_debug_set_lat27(1)
+
+
+@pytest.mark.parametrize("dims", [(3, 3, 3), (4, 4, 4), (3, 4, 5), (9, 5, 17), (5, 16, 4), (17, 9, 12), (1, 40, 3), (20, 20, 20)])
+def test_spmv_equals_the_csr_kernel(mf, small_layouts, dims):
+    """Tiles and units cut by the lattice in every direction (lattice points 2 n + 1: never a multiple of the 8 x 8 x 32 tile), alpha / beta."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 0.7, 1.3), dims, 2, 5)
+    A = b.pattern(1)
+    if A.n < 128:
+        pytest.skip("less than one block: CSR kernel")
+    K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    assert _mode(b, A) == 4
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
+        y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+        c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
+        assert int(_lib.lib.mfem_debug_lat27_spmv_count()) == c0 + 1
+        want = alpha * y0 + beta * 7.0
+        assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+
+
+def test_values_that_are_not_symmetric_take_the_sliced_layout(mf, small_layouts):
+    """The layout pass measures max |A[r][c] - A[c][r]|: one perturbed entry (relative 1e-9) and the bind leaves the solve to mode 3; a perturbation
+    at round-off level (1e-15) keeps mode 4.  Either way y equals the CSR kernel's on the values given."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (6, 5, 7), 2, 5)
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    for eps, served in ((1e-9, 0), (1e-15, 1), (float("nan"), 0)):
+        K2 = K.clone()
+        pos = int(A.nnz // 2 + 1)  # an off-diagonal entry somewhere in the middle
+        K2[pos] = K2[pos] * (1.0 + eps) if eps == eps else float("nan")
+        y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        y1 = torch.zeros_like(y0)
+        mf.mul_(y0, A, K2, x)
+        c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K2.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+        assert int(_lib.lib.mfem_debug_lat27_spmv_count()) - c0 == served, eps
+        if eps == eps:
+            assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+        else:
+            assert bool(torch.isnan(y1).any())
+
+
+def test_solvers(mf, small_layouts):
+    """cg! runs on the layout (with and without Jacobi); bicgstabl_GS! only without the right Jacobi scaling (the scaled matrix A D^-1 is not
+    symmetric); every solution equals the sliced-layout solve."""
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (10, 9, 8), 2, 5)
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    cases = [
+        ("cg jacobi", dict(Sv_func=mf.cg_), True),
+        ("cg plain", dict(Sv_func=mf.cg_, Pr_func=mf.Identity), True),
+        ("bicgstab jacobi", dict(Sv_func=mf.bicgstabl_GS_, s=2), False),
+        ("bicgstab plain", dict(Sv_func=mf.bicgstabl_GS_, s=2, Pr_func=mf.Identity), True),
+        ("idrs jacobi", dict(Sv_func=mf.idrs_, s=4), False),
+    ]
+    for name, kw, expect in cases:
+        sol = {}
+        for lat in (1, 0):
+            _lib.lib.mfem_debug_set_lat27(lat)
+            c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+            x, st = mf.iterative_Solve(A, K, rhs, 1e-11, maxiter=3000, max_pass=4, **kw)
+            used = int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0
+            assert used == (expect and lat == 1), (name, lat)
+            assert st.converged, name
+            sol[lat] = x.cpu().numpy()
+        assert np.abs(sol[1] - sol[0]).max() <= 1e-9 * np.abs(sol[0]).max(), name
+
+
+def test_patterns_that_only_look_like_the_lattice_are_refused(mf, small_layouts):
+    """The lattice hint of mfem_brick_pattern only proposes the layout: hex-8 (order 1) and the 3-field pattern keep their layouts, and a
+    slab pattern with ghost columns keeps the sliced one."""
+    _lib = small_layouts
+    b8 = mf.make_Brick((1.0, 1.0, 1.0), (7, 7, 7))  # 8^3 points: even counts
+    assert _mode(b8, b8.pattern(1)) != 4
+    b27 = mf.make_Brick((1.0, 1.0, 1.0), (5, 4, 4), 2, 5)
+    assert _mode(b27, b27.pattern(3)) != 4
+    sb = mf.make_Brick((2.0, 1.0, 1.0), (10, 6, 6), 2, 5)
+    sb.set_slab(6, 14)
+    assert _mode(sb, sb.pattern(1)) == 3
+    # order-1 lattice with odd point counts (the hint alone cannot tell it from order 2): refused by the entry-by-entry check
+    b1 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
+    assert _mode(b1, b1.pattern(1)) != 4

@@ -147,6 +147,7 @@ def test_sliced_layout_region_sort_and_xcd_walk_equal_the_csr_kernel(mf, knob):
 
     _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
     _lib.lib.mfem_debug_set_sell(knob)
+    _lib.lib.mfem_debug_set_lat27(0)  # (the full brick would take the lattice-tile layout)
     try:
         for slab in (None, (6, 14)):
             b = mf.make_Brick((2.0, 1.0, 1.0), (10, 9, 8), 2, 5)
@@ -166,4 +167,5 @@ def test_sliced_layout_region_sort_and_xcd_walk_equal_the_csr_kernel(mf, knob):
             assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
     finally:
         _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_lat27(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
