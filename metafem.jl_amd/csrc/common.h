@@ -166,13 +166,14 @@ struct mfem_csr_s {
   // symmetric lattice-tile layout of the hex-27 lattice matrix (spmv_lat27.hip): lat27_state 0 = not inspected, -1 = no, 1 = the pattern is the stencil
   int lat27_state;
   const double* lat27_src;
+  const double* lat27_dsc;  // not owned: right Jacobi scaling applied to x while it is staged (nullptr: none)
   double* lat27_vals;       // not owned (solver workspace): the stored (diagonal + upper) entries, unit by unit
   double* lat27_dump;       // not owned (behind lat27_vals): one y block per tile
   double lat27_asym;        // max |A[r][c] - A[c][r]| / max |A[r][c]| seen by the last bind
 };
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
-int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf);  // binds only symmetric values
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);  // binds only symmetric values
 void mfem_lat27_unbind(mfem_csr_s* A);
 bool mfem_lat27_bound(const mfem_csr_s* A, const double* vals);
 int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,

@@ -663,10 +663,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (rc_plan) return rc_plan;
     sell_bytes = mfem_sell_vals_bytes(A);
   }
-  // hex-27 lattice matrix, solver on the unscaled matrix, one rank: the symmetric lattice-tile layout if this solve's values are symmetric
-  // (decided by its bind; the sliced layout takes over in the same workspace otherwise)
+  // hex-27 lattice matrix on one rank: the symmetric lattice-tile layout if this solve's values are symmetric (decided by its bind; the sliced
+  // layout takes over in the same workspace otherwise).  A right Jacobi scaling is applied to x there, not to the stored matrix.
   size_t lat_bytes = 0;
-  if (sell_bytes && (is_cg || !jac) && !left && !ctx->comm) {
+  if (sell_bytes && !left && !ctx->comm && (is_cg || !jac || fused_scale)) {
     rc_plan = mfem_lat27_plan(ctx, A);
     if (rc_plan) return rc_plan;
     lat_bytes = mfem_lat27_bytes(A);
@@ -772,7 +772,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     }
   }
   if (lat_bytes) {
-    rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes));
+    rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
   }
   if (sell_bytes && !mfem_lat27_bound(A, vals_work)) {

@@ -1811,7 +1811,7 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     if (sb) {
       rc = mfem_ws_reserve(ctx, lb > sb ? lb : sb);
       if (rc) return rc;
-      if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws);
+      if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;
       if (!mfem_lat27_bound(A, vals)) rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;

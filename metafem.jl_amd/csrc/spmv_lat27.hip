@@ -20,7 +20,8 @@
 //     dot product.  No global atomics; 2.1 cells per row written and read again (+ 12 % traffic).
 //   * eligibility is decided in two steps: the pattern must BE the lattice stencil (checked entry by entry once per pattern), and the values
 //     of this solve must be symmetric: the layout pass reads both A[r][c] and A[c][r] and the bind falls back to the sliced layout when
-//     max |A[r][c] - A[c][r]| > 1e-13 max |A[r][c]|.  Only taken when the solver runs on the unscaled matrix (CG, or no Jacobi scaling).
+//     max |A[r][c] - A[c][r]| > 1e-13 max |A[r][c]|.  A right Jacobi scaling (bicgstabl_GS!, idrs!, cgs2! work on A D^-1, which is not
+//     symmetric) is applied to x while it is staged: (A D^-1) x = A (x / d), so the stored matrix stays the symmetric A.
 //   * y differs from the CSR kernel's by round-off (other summation order), and the order in which the waves of a workgroup add into
 //     an LDS cell is not fixed: results are reproducible to ~1e-16 relative, not bitwise (mfem_debug_set_lat27(0) selects the sliced layout).
 #include "blas1.h"
@@ -31,6 +32,8 @@
 #define L27_SJ (L27_TJ + 4)
 #define L27_SK (L27_TK + 4)
 #define L27_CELLS ((L27_TI + 2) * L27_SJ * L27_SK)  // 4320
+#define L27_PI (L27_SJ * L27_SK + 8)                 // plane stride of the LDS blocks: 440 = 8 mod 16, so the 16 rows of a step (2 a PI + 2 b SK + 2 c) fall on 16 different bank pairs
+#define L27_LDS_CELLS ((L27_TI + 2) * L27_PI)
 #define L27_UNIT_D 4352                             // doubles per unit: 64 lanes x 68 steps
 #define L27_TAB 272                                 // table entries: 4 x (16 + 3 x 10 + 3 x 6 + 4)
 #define L27_PAD 127
@@ -41,6 +44,8 @@ extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
 static int g_lat27_enable = 1;
 static long long g_lat27_count = 0;
 extern "C" long long mfem_debug_lat27_spmv_count(void) { return g_lat27_count; }  // SpMVs the layout has served (bench.py: which kernel ran)
+// max |A[r][c] - A[c][r]| / max |A[r][c]| the layout pass of the last bind on this pattern measured (-1: no bind yet)
+extern "C" double mfem_debug_lat27_asymmetry(mfem_csr A) { return A ? A->lat27_asym : -1.0; }
 extern "C" int mfem_debug_set_lat27(int enable) {
   ++mfem_debug_epoch;
   g_lat27_enable = enable & 1;
@@ -79,7 +84,7 @@ static int lat27_upload_tables() {
     int s = 0;
     auto put = [&](int di, int dj, int dk) {
       const int it = s / 4, q = s % 4, idx = h_l27_tb[t] + q * K4 + it;
-      off[idx] = (int16_t)((di * L27_SJ + dj) * L27_SK + dk);
+      off[idx] = (int16_t)(di * L27_PI + dj * L27_SK + dk);
       d[idx][0] = (int8_t)di; d[idx][1] = (int8_t)dj; d[idx][2] = (int8_t)dk;
       ++s;
     };
@@ -217,37 +222,87 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
   }
 }
 
-template <int K4>
-__device__ __forceinline__ void l27_group(const double* __restrict__ gv, const uint32_t* __restrict__ tq, int pos, int q,
-                                          const double* xs, double* ys) {
-  l_d2 v[K4 / 2];
+// A unit's 68 steps run as 9 chunks (type 0 in two halves of 8 steps, then one chunk per type: 10, 10, 6, 10, 6, 6, 4 steps); the values of
+// chunk k + 1 are in flight while chunk k is worked through LDS (two register buffers that swap roles).
+template <int N>
+__device__ __forceinline__ void l27_load(l_d2 (&v)[5], const double* __restrict__ gv) {
 #pragma unroll
-  for (int u = 0; u < K4 / 2; ++u) v[u] = __builtin_nontemporal_load((const l_d2*)gv + u * 64);
-  uint32_t w[K4 / 2];
+  for (int u = 0; u < N / 2; ++u) v[u] = __builtin_nontemporal_load((const l_d2*)gv + u * 64);
+}
+
+template <int N, bool DIAG>
+__device__ __forceinline__ void l27_proc(const l_d2 (&v)[5], const uint32_t* __restrict__ tq, int pos, int q, double xr, const double* xs,
+                                         double* ys, double& acc) {
+  uint32_t w[N / 2];
 #pragma unroll
-  for (int u = 0; u < K4 / 2; ++u) w[u] = tq[u];
-  const double xr = xs[pos];
-  double acc = 0.0;
+  for (int u = 0; u < N / 2; ++u) w[u] = tq[u];
 #pragma unroll
-  for (int it = 0; it < K4; ++it) {
+  for (int it = 0; it < N; ++it) {
     const int o = (it & 1) ? ((int)w[it >> 1] >> 16) : (int)(int16_t)(w[it >> 1] & 0xffffu);
     const double a = (it & 1) ? v[it >> 1].y : v[it >> 1].x;
     acc += a * xs[pos + o];
     double m = a * xr;
-    if (it == 0) m = q == 0 ? 0.0 : m;  // slot 0 is the diagonal: nothing to mirror
+    if (DIAG && it == 0) m = q == 0 ? 0.0 : m;  // slot 0 is the diagonal: nothing to mirror
     __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + pos + o), m);
   }
+}
+
+__device__ __forceinline__ void l27_finish(int pos, int q, double acc, double* ys) {
   acc += __shfl_xor(acc, 1, MFEM_WAVE);
   acc += __shfl_xor(acc, 2, MFEM_WAVE);
   if (q == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + pos), acc);
 }
 
+
+// on entry A holds the unit's first chunk; on exit B holds the first chunk of the unit at uv_next (if any)
+__device__ __forceinline__ void l27_unit(l_d2 (&A)[5], l_d2 (&B)[5], const double* __restrict__ uv, const double* __restrict__ uv_next,
+                                         int p0, int q, const uint32_t* __restrict__ tabs, const double* xs, double* ys) {
+  const int PI = L27_PI, PJ = L27_SK;
+  double acc = 0.0, xr = xs[p0];
+  l27_load<8>(B, uv + 512);
+  l27_proc<8, true>(A, tabs + q * 8, p0, q, xr, xs, ys, acc);
+  l27_load<10>(A, uv + 1024);
+  l27_proc<8, false>(B, tabs + q * 8 + 4, p0, q, xr, xs, ys, acc);
+  l27_finish(p0, q, acc, ys);
+  l27_load<10>(B, uv + 1664);
+  acc = 0.0; xr = xs[p0 + 1];
+  l27_proc<10, true>(A, tabs + 32 + q * 5, p0 + 1, q, xr, xs, ys, acc);
+  l27_finish(p0 + 1, q, acc, ys);
+  l27_load<6>(A, uv + 2304);
+  acc = 0.0; xr = xs[p0 + PJ];
+  l27_proc<10, true>(B, tabs + 52 + q * 5, p0 + PJ, q, xr, xs, ys, acc);
+  l27_finish(p0 + PJ, q, acc, ys);
+  l27_load<10>(B, uv + 2688);
+  acc = 0.0; xr = xs[p0 + PJ + 1];
+  l27_proc<6, true>(A, tabs + 72 + q * 3, p0 + PJ + 1, q, xr, xs, ys, acc);
+  l27_finish(p0 + PJ + 1, q, acc, ys);
+  l27_load<6>(A, uv + 3328);
+  acc = 0.0; xr = xs[p0 + PI];
+  l27_proc<10, true>(B, tabs + 84 + q * 5, p0 + PI, q, xr, xs, ys, acc);
+  l27_finish(p0 + PI, q, acc, ys);
+  l27_load<6>(B, uv + 3712);
+  acc = 0.0; xr = xs[p0 + PI + 1];
+  l27_proc<6, true>(A, tabs + 104 + q * 3, p0 + PI + 1, q, xr, xs, ys, acc);
+  l27_finish(p0 + PI + 1, q, acc, ys);
+  l27_load<4>(A, uv + 4096);
+  acc = 0.0; xr = xs[p0 + PI + PJ];
+  l27_proc<6, true>(B, tabs + 116 + q * 3, p0 + PI + PJ, q, xr, xs, ys, acc);
+  l27_finish(p0 + PI + PJ, q, acc, ys);
+  if (uv_next) l27_load<8>(B, uv_next);
+  acc = 0.0; xr = xs[p0 + PI + PJ + 1];
+  l27_proc<4, true>(A, tabs + 128 + q * 2, p0 + PI + PJ + 1, q, xr, xs, ys, acc);
+  l27_finish(p0 + PI + PJ + 1, q, acc, ys);
+}
+
 // pass 1: one workgroup per tile.  dump[tile][cell] = what the tile's stored entries contribute to y on its own cells and on the
 // (+2, +-2, +-2) neighbourhood.
+// dsc != nullptr: the operator is A D^-1 (right Jacobi scaling, Mat_Div_Jacobi of 02_Preconditioner.jl:141-148): the stored matrix stays the
+// symmetric A and x is divided by d while it is staged.
 __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double* __restrict__ vals, const double* __restrict__ x,
-                                                       double* __restrict__ dump, const int32_t* __restrict__ done_flag) {
-  __shared__ double xs[L27_CELLS];
-  __shared__ double ys[L27_CELLS];
+                                                       const double* __restrict__ dsc, double* __restrict__ dump,
+                                                       const int32_t* __restrict__ done_flag) {
+  __shared__ double xs[L27_LDS_CELLS];
+  __shared__ double ys[L27_LDS_CELLS];
   __shared__ uint32_t tabs[L27_TAB / 2];
   if (done_flag && done_flag[0]) return;
   // workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch): each XCD walks a contiguous eighth of the tiles, so the
@@ -257,45 +312,47 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double
   if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
   const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6, q = lane & 3, rho = lane >> 2;
+  const int ra = rho >> 3, rb = (rho >> 2) & 1, rc = rho & 3;
+  // the wave's two units: (0, b, c) and (1, b, c) of the tile's 2 x 2 x 4; the second exists only if the first does
+  const int ub = (wv >> 2) & 1, uc = wv & 3;
+  const int ui = ti * 2, uj = tj * 2 + ub, uk = tk * 4 + uc;
+  const bool e0 = uj < G.nuj && uk < G.nuk, e1 = e0 && ui + 1 < G.nui;
+  const double* uv0 = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * L27_UNIT_D + lane * 2;
+  const double* uv1 = uv0 + (int64_t)G.nuj * G.nuk * L27_UNIT_D;
+  l_d2 A[5], B[5];
+  if (e0) l27_load<8>(A, uv0);  // in flight while x is staged
   for (int e = tid; e < L27_TAB / 2; e += 512)
     tabs[e] = (uint32_t)(uint16_t)c_l27_off[2 * e] | ((uint32_t)(uint16_t)c_l27_off[2 * e + 1] << 16);
   const int i0 = ti * L27_TI, j0 = tj * L27_TJ - 2, k0 = tk * L27_TK - 2;
-  for (int e = tid; e < L27_CELLS; e += 512) {
-    const int li = e / (L27_SJ * L27_SK), r2 = e - li * (L27_SJ * L27_SK), lj = r2 / L27_SK, lk = r2 - lj * L27_SK;
+  for (int e = tid; e < L27_LDS_CELLS; e += 512) {
+    const int li = e / L27_PI, r2 = e - li * L27_PI, lj = r2 / L27_SK, lk = r2 - lj * L27_SK;
     const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
     double xv = 0.0;
-    if (gi < G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) xv = x[((int64_t)gi * G.m1 + gj) * G.m2 + gk];
+    if (lj < L27_SJ && gi < G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
+      const int64_t r = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+      xv = dsc ? x[r] / dsc[r] : x[r];
+    }
     xs[e] = xv;
     ys[e] = 0.0;
   }
   __syncthreads();
-  const int lane = tid & 63, wv = tid >> 6, q = lane & 3, rho = lane >> 2;
-  const int ra = rho >> 3, rb = (rho >> 2) & 1, rc = rho & 3;
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    const int uu = wv + 8 * h;  // unit inside the tile: (a, b, c) in 2 x 2 x 4
-    const int ua = uu >> 3, ub = (uu >> 2) & 1, uc = uu & 3;
-    const int ui = ti * 2 + ua, uj = tj * 2 + ub, uk = tk * 4 + uc;
-    if (ui >= G.nui || uj >= G.nuj || uk >= G.nuk) continue;
-    const double* uv = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * L27_UNIT_D + lane * 2;
-    // LDS cell of the lane's row of type (0, 0, 0); the other types are +1 in the odd directions
-    const int p0 = ((ua * 4 + 2 * ra) * L27_SJ + (ub * 4 + 2 * rb + 2)) * L27_SK + (uc * 8 + 2 * rc + 2);
-    const int PI = L27_SJ * L27_SK, PJ = L27_SK;
-    l27_group<16>(uv + 0, tabs + (0 + q * 16) / 2, p0, q, xs, ys);
-    l27_group<10>(uv + 1024, tabs + (64 + q * 10) / 2, p0 + 1, q, xs, ys);
-    l27_group<10>(uv + 1664, tabs + (104 + q * 10) / 2, p0 + PJ, q, xs, ys);
-    l27_group<6>(uv + 2304, tabs + (144 + q * 6) / 2, p0 + PJ + 1, q, xs, ys);
-    l27_group<10>(uv + 2688, tabs + (168 + q * 10) / 2, p0 + PI, q, xs, ys);
-    l27_group<6>(uv + 3328, tabs + (208 + q * 6) / 2, p0 + PI + 1, q, xs, ys);
-    l27_group<6>(uv + 3712, tabs + (232 + q * 6) / 2, p0 + PI + PJ, q, xs, ys);
-    l27_group<4>(uv + 4096, tabs + (256 + q * 4) / 2, p0 + PI + PJ + 1, q, xs, ys);
+  if (e0) {
+    // LDS cell of the lane's row of type (0, 0, 0) in the first unit; the other types are +1 in the odd directions, the second unit 4 planes on
+    const int p0 = (2 * ra) * L27_PI + (ub * 4 + 2 * rb + 2) * L27_SK + (uc * 8 + 2 * rc + 2);
+    l27_unit(A, B, uv0, e1 ? uv1 : nullptr, p0, q, tabs, xs, ys);
+    if (e1) l27_unit(B, A, uv1, nullptr, p0 + 4 * L27_PI, q, tabs, xs, ys);
   }
   __syncthreads();
   double* dt = dump + (int64_t)tile * L27_CELLS;
-  for (int e = tid; e < L27_CELLS; e += 512) dt[e] = ys[e];
+  for (int e = tid; e < L27_CELLS; e += 512) {
+    const int li = e / (L27_SJ * L27_SK);
+    dt[e] = ys[e + 8 * li];
+  }
 }
 
-// pass 2: y[r] = alpha * (sum over the tiles whose block covers r, fixed order) + beta * y[r]; fused dot with dotw
+// pass 2: y[r] = alpha * (sum over the tiles whose block covers r, fixed order) + beta * y[r]; fused dot with dotw.  A thread owns a
+// (j, k) position of the tile and its 8 lattice planes: 8 independent loads per covering tile.
 __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather(Lat27Geom G, const double* __restrict__ dump, double* __restrict__ y,
                                                                double alpha, double beta, const double* __restrict__ dotw,
                                                                double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
@@ -303,31 +360,40 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather(Lat27Geom G, const 
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
   const int ntiles = G.nti * G.ntj * G.ntk;
+  const int lk = threadIdx.x & (L27_TK - 1), lj = threadIdx.x >> 5;
+  const int PC = L27_SJ * L27_SK;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
-    for (int e = threadIdx.x; e < L27_TI * L27_TJ * L27_TK; e += MFEM_BLOCK) {
-      const int lk = e & (L27_TK - 1), lj = (e >> 5) & (L27_TJ - 1), li = e >> 8;
-      const int gi = ti * L27_TI + li, gj = tj * L27_TJ + lj, gk = tk * L27_TK + lk;
-      if (gi >= G.m0 || gj >= G.m1 || gk >= G.m2) continue;
-      double s = 0.0;
-      // covering tiles: (ti + a, tj + b, tk + c), a in {-1, 0}, b, c in {-1, 0, 1}: the row's cell in that tile's block must exist
-      for (int a = -1; a <= 0; ++a) {
-        if (a < 0 && (li >= 2 || ti == 0)) continue;
-        for (int b = -1; b <= 1; ++b) {
-          if ((b < 0 && (lj >= 2 || tj == 0)) || (b > 0 && (lj < L27_TJ - 2 || tj == G.ntj - 1))) continue;
-          for (int c = -1; c <= 1; ++c) {
-            if ((c < 0 && (lk >= 2 || tk == 0)) || (c > 0 && (lk < L27_TK - 2 || tk == G.ntk - 1))) continue;
-            const int64_t src = ((int64_t)(ti + a) * G.ntj + (tj + b)) * G.ntk + (tk + c);
-            const int cell = ((li - L27_TI * a) * L27_SJ + (lj - L27_TJ * b + 2)) * L27_SK + (lk - L27_TK * c + 2);
-            s += dump[src * L27_CELLS + cell];
-          }
+    const int gj = tj * L27_TJ + lj, gk = tk * L27_TK + lk, gi0 = ti * L27_TI;
+    if (gj >= G.m1 || gk >= G.m2) continue;
+    double s[L27_TI];
+#pragma unroll
+    for (int u = 0; u < L27_TI; ++u) s[u] = 0.0;
+    // covering tiles (ti + a, tj + b, tk + c), a in {-1, 0}, b, c in {-1, 0, 1}, in this fixed order: the row's cell must exist in that tile's block
+    for (int b = -1; b <= 1; ++b) {
+      if ((b < 0 && (lj >= 2 || tj == 0)) || (b > 0 && (lj < L27_TJ - 2 || tj == G.ntj - 1))) continue;
+      for (int c = -1; c <= 1; ++c) {
+        if ((c < 0 && (lk >= 2 || tk == 0)) || (c > 0 && (lk < L27_TK - 2 || tk == G.ntk - 1))) continue;
+        const int cell = (lj - L27_TJ * b + 2) * L27_SK + (lk - L27_TK * c + 2);
+        if (ti > 0) {  // the tile below: its planes 8, 9 are this tile's 0, 1
+          const double* d = dump + (((int64_t)(ti - 1) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * L27_CELLS + cell;
+          s[0] += d[8 * PC];
+          s[1] += d[9 * PC];
         }
+        const double* d = dump + (((int64_t)ti * G.ntj + (tj + b)) * G.ntk + (tk + c)) * L27_CELLS + cell;
+#pragma unroll
+        for (int u = 0; u < L27_TI; ++u) s[u] += d[u * PC];
       }
-      const int64_t r = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
-      double yv = alpha * s;
-      if (beta != 0.0) yv += beta * y[r];
-      y[r] = yv;
-      if (dotw) dot_acc += yv * dotw[r];
+    }
+#pragma unroll
+    for (int u = 0; u < L27_TI; ++u) {
+      if (gi0 + u < G.m0) {
+        const int64_t r = ((int64_t)(gi0 + u) * G.m1 + gj) * G.m2 + gk;
+        double yv = alpha * s[u];
+        if (beta != 0.0) yv += beta * y[r];
+        y[r] = yv;
+        if (dotw) dot_acc += yv * dotw[r];
+      }
     }
   }
   if (partials) {
@@ -394,9 +460,10 @@ size_t mfem_lat27_bytes(const mfem_csr_s* A) {
 
 // Makes the layout copy of `vals` in buf; binds it if the values are symmetric (else leaves the pattern unbound: the caller binds
 // the sliced layout instead).  One stream synchronisation (the symmetry verdict).
-int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf) {
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
   A->lat27_vals = nullptr;
   A->lat27_src = nullptr;
+  A->lat27_dsc = nullptr;
   if (A->lat27_state != 1 || !g_lat27_enable || !buf) return MFEM_OK;
   const Lat27Geom G = lat27_geom(A);
   unsigned long long* d_stats = (unsigned long long*)(ctx->d_flags + 12);
@@ -420,6 +487,7 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
   A->lat27_vals = buf;
   A->lat27_dump = buf + lat27_vals_doubles(G);
   A->lat27_src = vals;
+  A->lat27_dsc = dsc;
   return MFEM_OK;
 }
 
@@ -429,6 +497,7 @@ void mfem_lat27_unbind(mfem_csr_s* A) {
   A->lat27_vals = nullptr;
   A->lat27_dump = nullptr;
   A->lat27_src = nullptr;
+  A->lat27_dsc = nullptr;
 }
 
 // returns 1 if launched, 0 if another kernel should be used, <0 on error
@@ -443,7 +512,7 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   const Lat27Geom G = lat27_geom(A);
   const int ntiles = G.nti * G.ntj * G.ntk;
   const int chunk = (ntiles + 7) / 8;
-  hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dump, done_flag);
+  hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag);
   MFEM_CHECK_LAUNCH();
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
@@ -460,6 +529,6 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
 int64_t mfem_lat27_design_bytes(const mfem_csr_s* A) {
   const Lat27Geom G = lat27_geom(A);
   const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
-  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * 3 + A->n * 8;
+  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_dsc ? 4 : 3) + A->n * 8;
 }
 int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_vals_doubles(lat27_geom(A)); }

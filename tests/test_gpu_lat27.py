@@ -80,8 +80,9 @@ def test_values_that_are_not_symmetric_take_the_sliced_layout(mf, small_layouts)
 
 
 def test_solvers(mf, small_layouts):
-    """cg! runs on the layout (with and without Jacobi); bicgstabl_GS! only without the right Jacobi scaling (the scaled matrix A D^-1 is not
-    symmetric); every solution equals the sliced-layout solve."""
+    """Every solver runs on the layout: cg! on A, the others on A D^-1 with the right Jacobi scaling applied to x while it is staged (the stored
+    matrix stays the symmetric A); not with scale_in_place (the caller's array then holds A D^-1, which is not symmetric) and not with a left
+    preconditioner.  Every solution equals the sliced-layout solve."""
     _lib = small_layouts
     b = mf.make_Brick((1.0, 1.0, 1.0), (10, 9, 8), 2, 5)
     A = b.pattern(1)
@@ -90,16 +91,20 @@ def test_solvers(mf, small_layouts):
     cases = [
         ("cg jacobi", dict(Sv_func=mf.cg_), True),
         ("cg plain", dict(Sv_func=mf.cg_, Pr_func=mf.Identity), True),
-        ("bicgstab jacobi", dict(Sv_func=mf.bicgstabl_GS_, s=2), False),
+        ("bicgstab jacobi", dict(Sv_func=mf.bicgstabl_GS_, s=2), True),
+        ("bicgstab colnorm", dict(Sv_func=mf.bicgstabl_GS_, s=2, Pr_func=mf.Pr_Jacobi_colnorm_), True),
+        ("bicgstab in place", dict(Sv_func=mf.bicgstabl_GS_, s=2, scale_in_place=True), False),
+        ("idrs left", dict(Sv_func=mf.idrs_, s=4, Pl_func=mf.Pl_Jacobi_), False),
+        ("cgs2 jacobi", dict(Sv_func=mf.cgs2_), True),
         ("bicgstab plain", dict(Sv_func=mf.bicgstabl_GS_, s=2, Pr_func=mf.Identity), True),
-        ("idrs jacobi", dict(Sv_func=mf.idrs_, s=4), False),
+        ("idrs jacobi", dict(Sv_func=mf.idrs_, s=4), True),
     ]
     for name, kw, expect in cases:
         sol = {}
         for lat in (1, 0):
             _lib.lib.mfem_debug_set_lat27(lat)
             c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
-            x, st = mf.iterative_Solve(A, K, rhs, 1e-11, maxiter=3000, max_pass=4, **kw)
+            x, st = mf.iterative_Solve(A, K.clone(), rhs, 1e-11, maxiter=3000, max_pass=4, **kw)
             used = int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0
             assert used == (expect and lat == 1), (name, lat)
             assert st.converged, name
