@@ -368,6 +368,7 @@ def main():
         tot, cnt = C.c_double(), C.c_int64()
         _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
         sym_count0 = int(_lib.lib.mfem_debug_sym_spmv_count())
+        lat_count0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
         barrier()
         t0 = time.perf_counter()
         solve_ms = 0.0
@@ -396,9 +397,17 @@ def main():
             csr_bytes = A.nnz * 12 + A.n * 16 + (A.n + 1) * 8
             mode, slots, npad, reg = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
             _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
+            lat_used = int(_lib.lib.mfem_debug_lat27_spmv_count()) > lat_count0
+            if mode.value == 4 and not lat_used:
+                # the structure allows the symmetric lattice tiles, but the values of these solves did not pass the symmetry measure: the sliced
+                # layout ran -- ask for its accounting
+                _lib.lib.mfem_debug_set_lat27(0)
+                _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
             ent, symf, byts = C.c_int64(), C.c_int32(), C.c_int64()
             _lib.check(_lib.lib.mfem_csr_solver_layout_entries(ctx._h, A._h, C.byref(ent), C.byref(symf)))
             _lib.check(_lib.lib.mfem_csr_solver_layout_bytes(ctx._h, A._h, C.byref(byts)))
+            if not lat_used:
+                _lib.lib.mfem_debug_set_lat27(1)
             sym_used = bool(symf.value) and int(_lib.lib.mfem_debug_sym_spmv_count()) > sym_count0
             plain_bytes = None
             spmv_bytes = byts.value
@@ -421,6 +430,12 @@ def main():
                     spmv_bytes = plain
             elif mode.value == 1:
                 kernel, kkey = "k_spmv_ell (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)", "k_spmv_ell"
+            elif mode.value == 4:
+                kernel, kkey = ("k_spmv_lat27 + k_lat27_gather (two launches per SpMV): symmetric lattice tiles of the hex-27 matrix, copy made once per "
+                                "solve; the values passed the per-solve symmetry measure (max |A[r][c] - A[c][r]| <= 1e-13 max |A[r][c]|), so only the "
+                                "diagonal and the entries with column > row are stored and read (14..63 of a row's 27..125); x and y of a tile of "
+                                "8 x 8 x 32 lattice points in LDS, mirrored products added there (ds_add_f64); the second launch sums the tiles' y blocks "
+                                "in a fixed order; y equals the CSR kernel's to round-off"), "k_spmv_lat27"
             elif mode.value == 3:
                 kernel, kkey = ("k_spmv_sell (rows sorted by length and diagonal-list signature, SELL-128 copy made once per solve; blocks "
                                 "whose rows share one diagonal list read no columns)"), "k_spmv_sell"
@@ -454,7 +469,11 @@ def main():
                         "+ x as the kernel stages it (patch sweep: overlapping patch neighbourhoods, 1.6 n entries) + y "
                         "(mfem_csr_solver_layout_bytes); the plain diagonal-slotted kernel reads "
                         "plain_diagonal_kernel_bytes_per_launch"}
-               if r["sym_used"] else {}),
+               if r["sym_used"] and r["kernel_key"] != "k_spmv_lat27" else {}),
+            **({"note": "algorithmic bytes = what this kernel pair moves by design (mfem_csr_solver_layout_bytes): 8 B per stored entry (diagonal + upper "
+                        "entries, padded to 68 wave steps per 128 rows, units cut by the lattice edge included) + x as the tiles stage it (4 320 cells per "
+                        "2 048 rows) + the tiles' y blocks written and read again + y"}
+               if r["kernel_key"] == "k_spmv_lat27" else {}),
             "csr_equivalent": {"bytes_per_launch": r["csr_bytes"], "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
                                "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
                                        "kernel would have to sustain to match this time"},
