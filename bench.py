@@ -369,6 +369,7 @@ def main():
         _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
         sym_count0 = int(_lib.lib.mfem_debug_sym_spmv_count())
         lat_count0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+        lat8_count0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
         barrier()
         t0 = time.perf_counter()
         solve_ms = 0.0
@@ -403,11 +404,17 @@ def main():
                 # layout ran -- ask for its accounting
                 _lib.lib.mfem_debug_set_lat27(0)
                 _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
+            lat8_used = int(_lib.lib.mfem_debug_lat8_spmv_count()) > lat8_count0
+            if mode.value == 5 and not lat8_used:  # (the same for the 3-field lattice tiles: the diagonal-slotted layout ran)
+                _lib.lib.mfem_debug_set_lat8(0)
+                _lib.check(_lib.lib.mfem_csr_solver_layout(ctx._h, A._h, C.byref(mode), C.byref(slots), C.byref(npad), C.byref(reg)))
             ent, symf, byts = C.c_int64(), C.c_int32(), C.c_int64()
             _lib.check(_lib.lib.mfem_csr_solver_layout_entries(ctx._h, A._h, C.byref(ent), C.byref(symf)))
             _lib.check(_lib.lib.mfem_csr_solver_layout_bytes(ctx._h, A._h, C.byref(byts)))
             if not lat_used:
                 _lib.lib.mfem_debug_set_lat27(1)
+            if not lat8_used:
+                _lib.lib.mfem_debug_set_lat8(1)
             sym_used = bool(symf.value) and int(_lib.lib.mfem_debug_sym_spmv_count()) > sym_count0
             plain_bytes = None
             spmv_bytes = byts.value
@@ -436,6 +443,13 @@ def main():
                                 "diagonal and the entries with column > row are stored and read (14..63 of a row's 27..125); x and y of a tile of "
                                 "8 x 8 x 32 lattice points in LDS, mirrored products added there (ds_add_f64); the second launch sums the tiles' y blocks "
                                 "in a fixed order; y equals the CSR kernel's to round-off"), "k_spmv_lat27"
+            elif mode.value == 5:
+                kernel, kkey = ("k_spmv_lat8 + k_lat8_gather (two launches per SpMV): symmetric lattice tiles of the 3-field 27-point matrix, copy made "
+                                "once per solve; the values passed the per-solve symmetry measure (max |a - a^T| <= 1e-13 max |a|), so per node only "
+                                "the 6 upper entries of its own 3 x 3 block and the blocks towards its 13 upper neighbours are stored and read (123 of "
+                                "243 values); lane = node, x and y of a tile of 8 x 8 x 16 nodes in LDS, mirrored products added there (ds_add_f64), "
+                                "the right Jacobi scaling applied to x while it is staged; the second launch sums the tiles' y blocks in a fixed "
+                                "order; y equals the CSR kernel's to round-off"), "k_spmv_lat8"
             elif mode.value == 3:
                 kernel, kkey = ("k_spmv_sell (rows sorted by length and diagonal-list signature, SELL-128 copy made once per solve; blocks "
                                 "whose rows share one diagonal list read no columns)"), "k_spmv_sell"
@@ -469,11 +483,15 @@ def main():
                         "+ x as the kernel stages it (patch sweep: overlapping patch neighbourhoods, 1.6 n entries) + y "
                         "(mfem_csr_solver_layout_bytes); the plain diagonal-slotted kernel reads "
                         "plain_diagonal_kernel_bytes_per_launch"}
-               if r["sym_used"] and r["kernel_key"] != "k_spmv_lat27" else {}),
+               if r["sym_used"] and r["kernel_key"] not in ("k_spmv_lat27", "k_spmv_lat8") else {}),
             **({"note": "algorithmic bytes = what this kernel pair moves by design (mfem_csr_solver_layout_bytes): 8 B per stored entry (diagonal + upper "
                         "entries, padded to 68 wave steps per 128 rows, units cut by the lattice edge included) + x as the tiles stage it (4 320 cells per "
                         "2 048 rows) + the tiles' y blocks written and read again + y"}
                if r["kernel_key"] == "k_spmv_lat27" else {}),
+            **({"note": "algorithmic bytes = what this kernel pair moves by design (mfem_csr_solver_layout_bytes): 8 B per stored entry (123 per node, "
+                        "padded to 124 wave steps per 64 nodes, units cut by the lattice edge included) + x and the Jacobi scaling as the tiles stage them "
+                        "(1 620 cells per field per 1 024 nodes) + the tiles' y blocks written and read again + y"}
+               if r["kernel_key"] == "k_spmv_lat8" else {}),
             "csr_equivalent": {"bytes_per_launch": r["csr_bytes"], "achieved": csr_equiv, "frac": csr_equiv / HBM_PEAK_GBS,
                                "note": "the same launch priced with SURVEY 8(d)'s CSR formula (12 B per nonzero): what a CSR "
                                        "kernel would have to sustain to match this time"},

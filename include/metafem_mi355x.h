@@ -105,7 +105,10 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
  *           8 x 8 x 32 lattice points staged in LDS, the mirrored products added there; a second pass sums the tiles' y blocks in a
  *           fixed order.  Taken per solve only if max |A[r][c] - A[c][r]| <= 1e-13 max |A[r][c]| (measured by the layout pass; mode 3
  *           serves the solve otherwise).  y agrees with the CSR kernel to round-off (other summation order), not bitwise, and not
- *           bitwise from run to run.
+ *           bitwise from run to run.  A right Jacobi scaling (A D^-1) is applied to x while it is staged; the stored matrix stays A.
+ *   mode 5  the same construction for the 3-field 27-point lattice matrix (hex-8 elasticity, field-major rows): lane = node, per node the 6
+ *           upper entries of its own 3 x 3 block and the blocks towards its 13 upper neighbours (123 of 243 values), tiles of 8 x 8 x 16 nodes;
+ *           mode 2 serves the solve if the values are not symmetric.
  * The copy is made once per solve from the caller's CSR-ordered values, like the reference's K_total[K_val_ids] gather
  * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks (mode 2). */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
@@ -119,7 +122,7 @@ int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t*
  * 257-point lines on.  entries = 8-byte matrix values one SpMV of the planned layout reads from memory, bytes (may be NULL) = all
  * bytes the planned kernel reads and writes per SpMV by design: those entries, 4-byte columns of rows in generic blocks, x as
  * often as the kernel stages / gathers it from memory by design (form 2: the patch neighbourhoods overlap, 1.6 n entries), y.
- * symmetric_sweep = 0 / 1 / 2 (assuming the values pass the check); 3 = mode 4. */
+ * symmetric_sweep = 0 / 1 / 2 (assuming the values pass the check); 3 = modes 4 and 5. */
 int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep);
 int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes);
 /* The same accounting for the CSR kernel behind mul! (mfem_spmv_csr: the caller's arrays, no copy): bytes one launch moves BY DESIGN =

@@ -45,6 +45,10 @@ int mfem_debug_set_lat27(int enable);
 long long mfem_debug_lat27_spmv_count(void);
 /* max |A[r][c] - A[c][r]| / max |A[r][c]| measured by the layout pass of the last mode-4 bind on this pattern (mode 4 is taken up to 1e-13) */
 double mfem_debug_lat27_asymmetry(mfem_csr A);
+/* mode 5 (symmetric lattice tiles, 3-field 27-point matrix): the same three entry points */
+int mfem_debug_set_lat8(int enable);
+long long mfem_debug_lat8_spmv_count(void);
+double mfem_debug_lat8_asymmetry(mfem_csr A);
 /* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
  * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
 int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);

@@ -147,6 +147,9 @@ SIGNATURES = {
     "mfem_debug_set_lat27": (c_int, [c_int]),
     "mfem_debug_lat27_spmv_count": (c_int64, []),
     "mfem_debug_lat27_asymmetry": (C.c_double, [c_void_p]),
+    "mfem_debug_set_lat8": (c_int, [c_int]),
+    "mfem_debug_lat8_spmv_count": (c_int64, []),
+    "mfem_debug_lat8_asymmetry": (C.c_double, [c_void_p]),
     "mfem_debug_set_vec_grid": (c_int, [c_int]),
     "mfem_debug_set_layout_min_rows": (c_int, [c_int64, c_int64]),
     "mfem_spmv_solver_layout": (c_int, [P, P, P, P, P, c_double, c_double]),

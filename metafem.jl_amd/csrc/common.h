@@ -170,7 +170,25 @@ struct mfem_csr_s {
   double* lat27_vals;       // not owned (solver workspace): the stored (diagonal + upper) entries, unit by unit
   double* lat27_dump;       // not owned (behind lat27_vals): one y block per tile
   double lat27_asym;        // max |A[r][c] - A[c][r]| / max |A[r][c]| seen by the last bind
+  int lat27_scaled;         // the last bind carried a right Jacobi scaling (accounting)
+  // the same for the 3-field 27-point lattice matrix (hex-8 elasticity; spmv_lat8.hip)
+  int lat8_state;
+  const double* lat8_src;
+  const double* lat8_dsc;
+  double* lat8_vals;
+  double* lat8_dump;
+  double lat8_asym;
+  int lat8_scaled;
 };
+int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A);
+size_t mfem_lat8_bytes(const mfem_csr_s* A);
+int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);  // binds only symmetric values
+void mfem_lat8_unbind(mfem_csr_s* A);
+bool mfem_lat8_bound(const mfem_csr_s* A, const double* vals);
+int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha, double beta,
+                          const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part);
+int64_t mfem_lat8_design_bytes(const mfem_csr_s* A);
+int64_t mfem_lat8_entries(const mfem_csr_s* A);
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
 int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);  // binds only symmetric values

@@ -671,10 +671,20 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (rc_plan) return rc_plan;
     lat_bytes = mfem_lat27_bytes(A);
   }
+  // the same for the 3-field 27-point lattice matrix (hex-8 elasticity), which would otherwise take the diagonal-slotted layout
+  size_t lat8_bytes = 0;
+  if ((ell_bytes || sell_bytes) && !left && !ctx->comm && (is_cg || !jac || fused_scale)) {
+    rc_plan = mfem_lat8_plan(ctx, A);
+    if (rc_plan) return rc_plan;
+    lat8_bytes = mfem_lat8_bytes(A);
+  }
   fused_scale = fused_scale && (ell_bytes || sell_bytes);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
   const bool need_copy = need_copy_unfused && !fused_scale;
   const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
-  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + ell_bytes + (lat_bytes > sell_bytes ? lat_bytes : sell_bytes);
+  size_t layout_bytes = ell_bytes > sell_bytes ? ell_bytes : sell_bytes;  // (one of the two is 0)
+  if (lat_bytes > layout_bytes) layout_bytes = lat_bytes;
+  if (lat8_bytes > layout_bytes) layout_bytes = lat8_bytes;
+  size_t total = vec_bytes * (4 + nwork) + csr_copy_bytes + layout_bytes;
   int rc = mfem_ws_reserve(ctx, total);
   if (rc) return rc;
   char* base = (char*)ctx->ws;
@@ -705,8 +715,17 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       mfem_ell_unbind(A);
       mfem_sell_unbind(A);
       mfem_lat27_unbind(A);
+      mfem_lat8_unbind(A);
     }
   } ell_guard{A};
+  // symmetric lattice tiles of the 3-field matrix: bound first (the Jacobi step below then takes |diag| from the CSR values); only the pointer of
+  // the column scaling is handed over here, the SpMVs read it after it has been filled
+  bool lat8_bound = false;
+  if (lat8_bytes) {
+    rc = mfem_lat8_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
+    if (rc) return rc;
+    lat8_bound = mfem_lat8_bound(A, vals_work);
+  }
 
   // Pr = Pr_func!(A)   (02_Preconditioner.jl:38, 103-120)
   V.dinv = nullptr;
@@ -714,7 +733,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   if (jac) {
     if (o->precond == MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !is_cg) {
       rc = mfem_jacobi2_by_column(ctx, A, vals_src, V.d);
-    } else if (is_cg && ell_bytes) {
+    } else if (is_cg && ell_bytes && !lat8_bound) {
       // CG does not scale the matrix: transpose first and read |diag| from the copy (n values instead of all nonzeros)
       rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), nullptr);
       if (!rc && A->ell_vals) {
@@ -763,7 +782,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
 
   // bind the slot-major copy: every mfem_spmv_launch(A, vals_work, ...) below runs the ELL kernel
   // (fused_scale: vals_work is the caller's unscaled array and only names the bound values; every SpMV below runs on the scaled copy)
-  if (ell_bytes && !ell_bound) {
+  if (ell_bytes && !ell_bound && !lat8_bound) {
     rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
     if (fused_scale && !A->ell_vals) {
@@ -775,7 +794,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
   }
-  if (sell_bytes && !mfem_lat27_bound(A, vals_work)) {
+  if (sell_bytes && !mfem_lat27_bound(A, vals_work) && !lat8_bound) {
     rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
     if (fused_scale && !A->sell_vals) {

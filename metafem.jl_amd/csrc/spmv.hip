@@ -848,6 +848,8 @@ static void csr_drop_plans(mfem_csr_s* A) {
   mfem_ell_unbind(A);
   mfem_sell_unbind(A);
   mfem_lat27_unbind(A);
+  mfem_lat8_unbind(A);
+  A->lat8_state = 0;
   mfem_ell_free(A);
   mfem_sell_free(A);
   A->lat27_state = 0;
@@ -1088,6 +1090,8 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   if (n_partials) *n_partials = 0;
   if (A->n == 0) return MFEM_OK;
   {
+    const int l8 = mfem_spmv_lat8_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part.part);
+    if (l8 != 0) return l8 < 0 ? l8 : MFEM_OK;
     const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part);
     if (e != 0) return e < 0 ? e : MFEM_OK;
     const int lt = mfem_spmv_lat27_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part.part);

@@ -1712,6 +1712,10 @@ extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int6
     e = mfem_lat27_entries(A);
     sym = 3;
   }
+  if (mode == 5) {
+    e = mfem_lat8_entries(A);
+    sym = 3;
+  }
   if (mode == 2 && symp_wanted(A)) {
     sym = 2;
     // the rows outside the swept planes read their K slots; the sweep reads symp_pairs value pairs
@@ -1746,6 +1750,7 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
     b = A->sell_total * 8 + (int64_t)((1.0 - reg) * (double)A->sell_total) * 4 + A->n * 16 + A->n * 4;  // + the row permutation
   }
   if (mode == 4) b = mfem_lat27_design_bytes(A);
+  if (mode == 5) b = mfem_lat8_design_bytes(A);
   if (mode == 2) {
     b += (A->n > reg ? A->n - reg : 0) * (int64_t)slots * 4;  // rows in generic blocks read their columns
     if (sym == 2) {  // the sweep stages a (4 + 2) x (32 + 2) neighbourhood of x per step instead of reading each swept entry once
@@ -1776,9 +1781,14 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
       if (mfem_lat27_bytes(A)) m = 4;
     }
   }
+  if (m != 0 && m != 4 && !ctx->comm) {  // symmetric lattice tiles of the 3-field 27-point matrix (spmv_lat8.hip): the structure allows it; each solve's values decide
+    rc = mfem_lat8_plan(ctx, A);
+    if (rc) return rc;
+    if (mfem_lat8_bytes(A)) m = 5;
+  }
   if (mode) *mode = m;
-  if (slots) *slots = (m == 1 || m == 2) ? A->ell_K : m >= 3 ? A->max_row_nnz : 0;
-  if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
+  if (slots) *slots = (m == 1 || m == 2 || m == 5) ? A->ell_K : m >= 3 ? A->max_row_nnz : 0;
+  if (padded_rows) *padded_rows = (m == 1 || m == 2 || m == 5) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
 }
@@ -1794,9 +1804,17 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   if (rc) return rc;
   const size_t bytes = mfem_ell_vals_bytes(A);
   if (bytes) {
-    rc = mfem_ws_reserve(ctx, bytes);
+    size_t l8 = 0;
+    if (!ctx->comm) {
+      rc = mfem_lat8_plan(ctx, A);
+      if (rc) return rc;
+      l8 = mfem_lat8_bytes(A);
+    }
+    rc = mfem_ws_reserve(ctx, l8 > bytes ? l8 : bytes);
     if (rc) return rc;
-    rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+    if (l8) rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+    if (rc) return rc;
+    if (!mfem_lat8_bound(A, vals)) rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
     if (rc) return rc;
   } else {
     rc = mfem_sell_plan(ctx, A);
@@ -1807,13 +1825,24 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
       rc = mfem_lat27_plan(ctx, A);
       if (rc) return rc;
       lb = mfem_lat27_bytes(A);
+      if (!lb) {
+        rc = mfem_lat8_plan(ctx, A);
+        if (rc) return rc;
+        const size_t l8 = mfem_lat8_bytes(A);
+        if (l8) {
+          rc = mfem_ws_reserve(ctx, l8 > sb ? l8 : sb);
+          if (rc) return rc;
+          rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+          if (rc) return rc;
+        }
+      }
     }
     if (sb) {
       rc = mfem_ws_reserve(ctx, lb > sb ? lb : sb);
       if (rc) return rc;
       if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;
-      if (!mfem_lat27_bound(A, vals)) rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+      if (!mfem_lat27_bound(A, vals) && !mfem_lat8_bound(A, vals)) rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;
     }
   }
@@ -1821,5 +1850,6 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   mfem_ell_unbind(A);
   mfem_sell_unbind(A);
   mfem_lat27_unbind(A);
+  mfem_lat8_unbind(A);
   return rc;
 }

@@ -488,6 +488,7 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
   A->lat27_dump = buf + lat27_vals_doubles(G);
   A->lat27_src = vals;
   A->lat27_dsc = dsc;
+  A->lat27_scaled = dsc ? 1 : 0;
   return MFEM_OK;
 }
 
@@ -529,6 +530,6 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
 int64_t mfem_lat27_design_bytes(const mfem_csr_s* A) {
   const Lat27Geom G = lat27_geom(A);
   const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
-  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_dsc ? 4 : 3) + A->n * 8;
+  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_scaled ? 4 : 3) + A->n * 8;
 }
 int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_vals_doubles(lat27_geom(A)); }

@@ -1,0 +1,465 @@
+// Symmetric lattice-tile layout for the Krylov loop on the 3-field 27-point lattice matrix (hex-8 elasticity, field-major rows
+// row = field * N + node: cantilever/3D_Script.jl's system): solver layout mode 5.  The caller-facing contract stays CSR (mul!,
+// misc/04_GPU_Utils.jl:131; iterative_Solve!, linear_solver/02_Preconditioner.jl:32-76).  Companion of spmv_lat27.hip (mode 4).
+//
+// The diagonal-slotted layout (mode 2) streams all 81 entries of a row.  The stiffness matrix is symmetric (the penalty and traction terms keep
+// it so; the right Jacobi scaling A D^-1 of bicgstabl_GS! / idrs! is applied to x while it is staged, so the stored matrix stays A), so per node
+// only the 6 upper entries of its own 3 x 3 block and the 3 x 3 blocks towards its 13 upper lattice neighbours are stored: 123 of 243 values.
+//
+//   * layout (per solve): a unit is 4 x 4 x 4 nodes = the 64 lanes of a wave, lane = node; its 123 steps (+ 1 padding step) are wave-uniform:
+//     step s is entry (f, node) -> (g, node + d) for every lane, so the column offsets are immediates and nothing is looked up.  A unit is
+//     124 x 512 B, unit-stride.
+//   * SpMV pass 1 (k_spmv_lat8): a workgroup owns a tile of 8 x 8 x 16 nodes (16 units, 8 waves), stages x of the tile and of the (+1, +-1, +-1)
+//     neighbourhood for the three fields in LDS (3 x 1 620 cells) and accumulates y in a second block of the same shape: for a stored entry
+//     a = A[(f, p)][(g, p')] the lane adds a x[g][p'] to its register sum of row (f, p) and a x[f][p] to cell (g, p') (ds_add_f64).  The y
+//     block leaves as one contiguous run per tile.
+//   * pass 2 (k_lat8_gather) sums the up to 18 tile blocks that cover a row in a fixed order, applies alpha / beta and the fused dot product.
+//   * the pattern must be the full stencil (checked entry by entry once), the values of a solve symmetric to 1e-13 of the largest entry
+//     (measured by the layout pass; the diagonal-slotted layout serves the solve otherwise).  Results equal the CSR kernel's to round-off, not
+//     bitwise, and not bitwise from run to run (order of the LDS adds of different waves).  mfem_debug_set_lat8(0) switches the layout off.
+#include "blas1.h"
+
+#define L8_F 3
+#define L8_TI 8
+#define L8_TJ 8
+#define L8_TK 16
+#define L8_SJ (L8_TJ + 2)
+#define L8_SK (L8_TK + 2)
+#define L8_PI (L8_SJ * L8_SK)            // 180
+#define L8_FC ((L8_TI + 1) * L8_PI)      // cells per field: 1620
+#define L8_STEPS 124                     // 42 + 41 + 40 stored steps + 1 padding step
+#define L8_UNIT_D (L8_STEPS * 64)
+
+typedef double m_d2 __attribute__((ext_vector_type(2)));
+
+extern int64_t g_layout_min_rows_dia;  // spmv_ell.hip
+static int g_lat8_enable = 1;
+static long long g_lat8_count = 0;
+extern "C" long long mfem_debug_lat8_spmv_count(void) { return g_lat8_count; }
+extern "C" double mfem_debug_lat8_asymmetry(mfem_csr A) { return A ? A->lat8_asym : -1.0; }
+extern "C" int mfem_debug_set_lat8(int enable) {
+  ++mfem_debug_epoch;
+  g_lat8_enable = enable & 1;
+  return MFEM_OK;
+}
+
+struct Lat8Geom {
+  int m0, m1, m2;     // nodes per direction
+  int nui, nuj, nuk;  // units of 4 x 4 x 4 nodes
+  int nti, ntj, ntk;  // tiles of 8 x 8 x 16 nodes
+  int64_t N;          // m0 * m1 * m2
+};
+
+// ---- the step list of a unit (compile-time) ---------------------------------------------------------------------------------
+// row field f: for g = 0..2: [the node's own block entry (f, g) if g >= f], then the 13 upper neighbours e = 1..13 (d = (0,0,1) .. (1,1,1))
+__host__ __device__ constexpr int l8_first(int f) { return f == 0 ? 0 : f == 1 ? 42 : 83; }
+__host__ __device__ constexpr int l8_row_field(int s) { return s < 42 ? 0 : s < 83 ? 1 : 2; }
+// (g, e) of step s; e = 0: the node itself
+__host__ __device__ constexpr int l8_g(int s) {
+  const int f = l8_row_field(s);
+  int t = s - l8_first(f);
+  for (int g = 0; g < 3; ++g) {
+    const int len = 13 + (g >= f ? 1 : 0);
+    if (t < len) return g;
+    t -= len;
+  }
+  return 0;
+}
+__host__ __device__ constexpr int l8_e(int s) {
+  const int f = l8_row_field(s);
+  int t = s - l8_first(f);
+  for (int g = 0; g < 3; ++g) {
+    const int own = g >= f ? 1 : 0;
+    const int len = 13 + own;
+    if (t < len) return own ? t : t + 1;
+    t -= len;
+  }
+  return 0;
+}
+__host__ __device__ constexpr int l8_di(int e) { return (e + 13) / 9 - 1; }
+__host__ __device__ constexpr int l8_dj(int e) { return ((e + 13) / 3) % 3 - 1; }
+__host__ __device__ constexpr int l8_dk(int e) { return (e + 13) % 3 - 1; }
+__host__ __device__ constexpr int l8_off(int e) { return l8_di(e) * L8_PI + l8_dj(e) * L8_SK + l8_dk(e); }
+
+// offsets a node at lattice coordinate g (of m) has along one direction: [lo, lo + cnt)
+__device__ __forceinline__ void l8_range(int g, int m, int& lo, int& cnt) {
+  lo = g > 0 ? -1 : 0;
+  cnt = (g < m - 1 ? 1 : 0) - lo + 1;
+}
+
+// 1 in *bad if some row is not the 3-field stencil row: 3 x (present neighbours), columns field-major then lexicographic
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, int base,
+                                                            int32_t* __restrict__ bad) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, PL = (int64_t)G.m1 * G.m2;
+  int fail = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < L8_F * G.N; r += stride) {
+    const int64_t p = r % G.N;
+    const int gi = (int)(p / PL);
+    const int64_t rem = p - gi * PL;
+    const int gj = (int)(rem / G.m2), gk = (int)(rem - (int64_t)gj * G.m2);
+    int li, ni, lj, nj, lk, nk;
+    l8_range(gi, G.m0, li, ni);
+    l8_range(gj, G.m1, lj, nj);
+    l8_range(gk, G.m2, lk, nk);
+    const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
+    if (hi - lo != (int64_t)L8_F * ni * nj * nk) {
+      fail = 1;
+      continue;
+    }
+    int64_t j = lo;
+    for (int g = 0; g < L8_F; ++g)
+      for (int a = 0; a < ni; ++a)
+        for (int b = 0; b < nj; ++b) {
+          const int64_t c0 = g * G.N + p + (int64_t)(li + a) * PL + (int64_t)(lj + b) * G.m2 + lk;
+          for (int c = 0; c < nk; ++c, ++j)
+            if ((int64_t)col[j] - base != c0 + c) fail = 1;
+        }
+  }
+  if (fail) bad[0] = 1;
+}
+
+// The layout pass: a wave per unit, lane = node.  stats[0] = max |a - a^T| over the stored pairs, stats[1] = max |a| (bit patterns).
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __restrict__ rowptr, int base, const double* __restrict__ vals,
+                                                          double* __restrict__ out, unsigned long long* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int la = lane >> 4, lb = (lane >> 2) & 3, lc = lane & 3;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk, PL = (int64_t)G.m1 * G.m2;
+  double amax = 0.0, dmax = 0.0;
+  for (int64_t u = wave; u < nunits; u += nwaves) {
+    const int uk = (int)(u % G.nuk);
+    const int64_t u2 = u / G.nuk;
+    const int uj = (int)(u2 % G.nuj), ui = (int)(u2 / G.nuj);
+    const int gi = ui * 4 + la, gj = uj * 4 + lb, gk = uk * 4 + lc;
+    const bool valid = gi < G.m0 && gj < G.m1 && gk < G.m2;
+    const int64_t p = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+    int li = 0, ni = 1, lj = 0, nj = 1, lk = 0, nk = 1;
+    if (valid) {
+      l8_range(gi, G.m0, li, ni);
+      l8_range(gj, G.m1, lj, nj);
+      l8_range(gk, G.m2, lk, nk);
+    }
+    const int cnt = ni * nj * nk;
+    double* ou = out + u * L8_UNIT_D + lane * 2;
+    int64_t rp[3] = {0, 0, 0};
+    if (valid)
+      for (int f = 0; f < 3; ++f) rp[f] = (int64_t)rowptr[f * G.N + p] - base;
+    for (int s = 0; s < L8_STEPS; s += 2) {
+      m_d2 pr;
+      pr.x = 0.0;
+      pr.y = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int st = s + h;
+        if (st >= 123 || !valid) continue;
+        const int f = l8_row_field(st), g = l8_g(st), e = l8_e(st);
+        const int di = l8_di(e), dj = l8_dj(e), dk = l8_dk(e);
+        const int ci = gi + di, cj = gj + dj, ck = gk + dk;
+        if (ci < G.m0 && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {
+          const double v = vals[rp[f] + (int64_t)g * cnt + ((di - li) * nj + (dj - lj)) * nk + (dk - lk)];
+          const int64_t pc = p + (int64_t)di * PL + (int64_t)dj * G.m2 + dk;
+          int mi, qi, mj, qj, mk, qk;
+          l8_range(ci, G.m0, mi, qi);
+          l8_range(cj, G.m1, mj, qj);
+          l8_range(ck, G.m2, mk, qk);
+          const double w = vals[(int64_t)rowptr[g * G.N + pc] - base + (int64_t)f * (qi * qj * qk) + ((-di - mi) * qj + (-dj - mj)) * qk + (-dk - mk)];
+          double df = fabs(v - w);
+          if (!(df == df)) df = __builtin_huge_val();
+          amax = fmax(amax, fabs(v));
+          dmax = fmax(dmax, df);
+          if (h) pr.y = v; else pr.x = v;
+        }
+      }
+      *(m_d2*)(ou + (int64_t)(s >> 1) * 128) = pr;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
+    dmax = fmax(dmax, __shfl_down(dmax, o, MFEM_WAVE));
+  }
+  if (lane == 0) {
+    atomicMax(stats + 0, (unsigned long long)__double_as_longlong(dmax));
+    atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
+  }
+}
+
+#define L8_LDS_ADD(ptr, val) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ptr), (val))
+
+template <int N>
+__device__ __forceinline__ void l8_load(m_d2 (&v)[4], const double* __restrict__ gv) {
+#pragma unroll
+  for (int u = 0; u < N / 2; ++u) v[u] = __builtin_nontemporal_load((const m_d2*)gv + u * 64);
+}
+
+// steps [S0 + I, S0 + N) of a unit from the register buffer v; x0..x2 = the lane's own x (3 fields), a0..a2 = its three row sums.  Everything about
+// a step is a compile-time constant (template recursion, not a loop: the row sums must stay in registers).
+template <int S0, int I, int N>
+__device__ __forceinline__ void l8_proc(const m_d2 (&v)[4], int pos, double x0, double x1, double x2, double& a0, double& a1, double& a2,
+                                        const double* xs, double* ys) {
+  if constexpr (I < N) {
+    constexpr int s = S0 + I;
+    if constexpr (s < 123) {
+      constexpr int f = l8_row_field(s), g = l8_g(s), e = l8_e(s);
+      constexpr int coff = g * L8_FC + l8_off(e);
+      const double a = (I & 1) ? v[I >> 1].y : v[I >> 1].x;
+      const double xr = f == 0 ? x0 : f == 1 ? x1 : x2;
+      double& acc = f == 0 ? a0 : f == 1 ? a1 : a2;
+      acc += a * xs[pos + coff];
+      if constexpr (!(e == 0 && g == f)) L8_LDS_ADD(ys + pos + coff, a * xr);  // (the diagonal entry has no mirror)
+      if constexpr (s == 41 || s == 82 || s == 122) L8_LDS_ADD(ys + pos + f * L8_FC, acc);
+    }
+    l8_proc<S0, I + 1, N>(v, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+  }
+}
+
+// chunk C (8 steps; the last one 4) from one buffer while chunk C + 1 -- or the first chunk of the next unit -- is loaded into the other
+template <int C>
+__device__ __forceinline__ void l8_run(m_d2 (&A)[4], m_d2 (&B)[4], const double* __restrict__ uv, const double* __restrict__ uv_next, int pos,
+                                       double x0, double x1, double x2, double& a0, double& a1, double& a2, const double* xs, double* ys) {
+  if constexpr (C < 15) {
+    l8_load<(C + 1 == 15) ? 4 : 8>((C & 1) ? A : B, uv + (C + 1) * 512);
+  } else {
+    if (uv_next) l8_load<8>(A, uv_next);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting the LDS reads of later chunks: 128 VGPRs and spills without)
+  l8_proc<C * 8, 0, (C == 15) ? 4 : 8>((C & 1) ? B : A, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));  // the row sums are due HERE (the compiler otherwise sinks the whole chain of multiply-adds to the
+  __builtin_amdgcn_sched_barrier(0);                 // flush at the end of the field and keeps every value and x it needs alive until then: spills)
+  if constexpr (C < 15) l8_run<C + 1>(A, B, uv, uv_next, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+}
+
+// pass 1: one workgroup per tile; dump[tile][field][cell]
+__global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* __restrict__ vals, const double* __restrict__ x,
+                                                      const double* __restrict__ dsc, double* __restrict__ dump,
+                                                      const int32_t* __restrict__ done_flag) {
+  __shared__ double xs[L8_F * L8_FC];
+  __shared__ double ys[L8_F * L8_FC];
+  if (done_flag && done_flag[0]) return;
+  const int ntiles = G.nti * G.ntj * G.ntk, chunk = (ntiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);  // every XCD walks a contiguous eighth of the tiles
+  if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
+  const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int la = lane >> 4, lb = (lane >> 2) & 3, lc = lane & 3;
+  // the wave's two units: (0, b, c) and (1, b, c) of the tile's 2 x 2 x 4
+  const int ub = wv >> 2, uc = wv & 3;
+  const int ui = ti * 2, uj = tj * 2 + ub, uk = tk * 4 + uc;
+  const bool e0 = uj < G.nuj && uk < G.nuk, e1 = e0 && ui + 1 < G.nui;
+  const double* uv0 = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * L8_UNIT_D + lane * 2;
+  m_d2 A[4], B[4];
+  if (e0) l8_load<8>(A, uv0);  // in flight while x is staged
+  const int i0 = ti * L8_TI, j0 = tj * L8_TJ - 1, k0 = tk * L8_TK - 1;
+  for (int e = tid; e < L8_F * L8_FC; e += 512) {
+    const int f = e / L8_FC, c = e - f * L8_FC;
+    const int li = c / L8_PI, r2 = c - li * L8_PI, lj = r2 / L8_SK, lk = r2 - lj * L8_SK;
+    const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+    double xv = 0.0;
+    if (gi < G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
+      const int64_t r = f * G.N + ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+      xv = dsc ? x[r] / dsc[r] : x[r];
+    }
+    xs[e] = xv;
+    ys[e] = 0.0;
+  }
+  __syncthreads();
+  if (e0) {
+    const int pos0 = la * L8_PI + (ub * 4 + lb + 1) * L8_SK + (uc * 4 + lc + 1);
+    const int nu = e1 ? 2 : 1;
+    const int64_t ustride = (int64_t)G.nuj * G.nuk * L8_UNIT_D;
+#pragma unroll 1
+    for (int h = 0; h < nu; ++h) {  // (16 chunks per unit: the two register buffers are back in their roles for the next unit)
+      const double* uv = uv0 + h * ustride;
+      const int pos = pos0 + h * 4 * L8_PI;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      l8_run<0>(A, B, uv, h + 1 < nu ? uv + ustride : nullptr, pos, xs[pos], xs[L8_FC + pos], xs[2 * L8_FC + pos], a0, a1, a2, xs, ys);
+    }
+  }
+  __syncthreads();
+  double* dt = dump + (int64_t)tile * (L8_F * L8_FC);
+  for (int e = tid; e < L8_F * L8_FC; e += 512) dt[e] = ys[e];
+}
+
+// pass 2: a thread owns a (j, k) position of the tile and four of its planes, for the three fields
+__global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const double* __restrict__ dump, double* __restrict__ y, double alpha,
+                                                              double beta, const double* __restrict__ dotw, double* __restrict__ partials,
+                                                              const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  const int lk = threadIdx.x & (L8_TK - 1), lj = (threadIdx.x >> 4) & (L8_TJ - 1), lh = threadIdx.x >> 7;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+    const int gj = tj * L8_TJ + lj, gk = tk * L8_TK + lk, gi0 = ti * L8_TI + 4 * lh;
+    if (gj >= G.m1 || gk >= G.m2) continue;
+    double s[L8_F][4];
+#pragma unroll
+    for (int f = 0; f < L8_F; ++f)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[f][u] = 0.0;
+    for (int b = -1; b <= 1; ++b) {
+      if ((b < 0 && (lj >= 1 || tj == 0)) || (b > 0 && (lj < L8_TJ - 1 || tj == G.ntj - 1))) continue;
+      for (int c = -1; c <= 1; ++c) {
+        if ((c < 0 && (lk >= 1 || tk == 0)) || (c > 0 && (lk < L8_TK - 1 || tk == G.ntk - 1))) continue;
+        const int cell = (lj - L8_TJ * b + 1) * L8_SK + (lk - L8_TK * c + 1);
+        if (ti > 0 && lh == 0) {  // the tile below: its plane 8 is this tile's plane 0
+          const double* d = dump + (((int64_t)(ti - 1) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (L8_F * L8_FC) + cell + 8 * L8_PI;
+#pragma unroll
+          for (int f = 0; f < L8_F; ++f) s[f][0] += d[f * L8_FC];
+        }
+        const double* d = dump + (((int64_t)ti * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (L8_F * L8_FC) + cell + 4 * lh * L8_PI;
+#pragma unroll
+        for (int f = 0; f < L8_F; ++f)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) s[f][u] += d[f * L8_FC + u * L8_PI];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < L8_F; ++f)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (gi0 + u < G.m0) {
+          const int64_t r = f * G.N + ((int64_t)(gi0 + u) * G.m1 + gj) * G.m2 + gk;
+          double yv = alpha * s[f][u];
+          if (beta != 0.0) yv += beta * y[r];
+          y[r] = yv;
+          if (dotw) dot_acc += yv * dotw[r];
+        }
+  }
+  if (partials) {
+    const double bsum = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bsum;
+  }
+}
+
+static Lat8Geom lat8_geom(const mfem_csr_s* A) {
+  Lat8Geom G{};
+  G.m1 = A->lat_m1;
+  G.m2 = A->lat_m2;
+  G.N = A->n / L8_F;
+  G.m0 = (int)(G.N / ((int64_t)A->lat_m1 * A->lat_m2));
+  G.nui = (G.m0 + 3) / 4;
+  G.nuj = (G.m1 + 3) / 4;
+  G.nuk = (G.m2 + 3) / 4;
+  G.nti = (G.m0 + L8_TI - 1) / L8_TI;
+  G.ntj = (G.m1 + L8_TJ - 1) / L8_TJ;
+  G.ntk = (G.m2 + L8_TK - 1) / L8_TK;
+  return G;
+}
+
+// lat8_state: 0 not inspected, -1 not the 3-field stencil, 1 structure ok
+int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  if (A->lat8_state != 0) return MFEM_OK;
+  if (A->n < g_layout_min_rows_dia) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
+  A->lat8_state = -1;
+  if (A->lat_fields != L8_F || A->lat_m1 < 2 || A->lat_m2 < 2 || A->n % L8_F != 0) return MFEM_OK;
+  if (A->ncols > A->n) return MFEM_OK;  // slab patterns (ghost columns) keep the diagonal-slotted layout
+  const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2, N = A->n / L8_F;
+  if (N % PL != 0) return MFEM_OK;
+  const int64_t m0 = N / PL;
+  if (m0 < 2 || m0 > (1 << 20) || A->max_row_nnz > 81) return MFEM_OK;
+  const Lat8Geom G = lat8_geom(A);
+  if ((int64_t)G.nti * G.ntj * G.ntk >= ((int64_t)1 << 28)) return MFEM_OK;
+  int32_t* d_bad = ctx->d_flags + 12;
+  MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
+  const int grid = mfem_grid_for(A->n, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_l8_verify<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->colidx, A->index_base,
+                       d_bad);
+  else
+    hipLaunchKernelGGL(k_l8_verify<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->colidx, A->index_base,
+                       d_bad);
+  MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_flags[12] == 0) A->lat8_state = 1;
+  return MFEM_OK;
+}
+
+static size_t lat8_vals_doubles(const Lat8Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * L8_UNIT_D; }
+static size_t lat8_dump_doubles(const Lat8Geom& G) { return (size_t)G.nti * G.ntj * G.ntk * L8_F * L8_FC; }
+
+size_t mfem_lat8_bytes(const mfem_csr_s* A) {
+  if (A->lat8_state != 1 || !g_lat8_enable || A->n < g_layout_min_rows_dia) return 0;
+  const Lat8Geom G = lat8_geom(A);
+  return sizeof(double) * (lat8_vals_doubles(G) + lat8_dump_doubles(G));
+}
+
+// Makes the layout copy of `vals` in buf and binds it if the values are symmetric (one stream synchronisation: the verdict).  dsc: right Jacobi
+// scaling the SpMV applies to x (nullptr: none); only the pointer is kept, it may be filled after the bind.
+int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
+  A->lat8_vals = nullptr;
+  A->lat8_src = nullptr;
+  A->lat8_dsc = nullptr;
+  if (A->lat8_state != 1 || !g_lat8_enable || !buf) return MFEM_OK;
+  const Lat8Geom G = lat8_geom(A);
+  unsigned long long* d_stats = (unsigned long long*)(ctx->d_flags + 12);
+  MFEM_CHECK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
+  const int grid = mfem_grid_for(nunits * 64, MFEM_BLOCK, ctx->num_cus * 16);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_l8_fill<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->index_base, vals, buf,
+                       d_stats);
+  else
+    hipLaunchKernelGGL(k_l8_fill<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->index_base, vals, buf,
+                       d_stats);
+  MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double dmax, amax;
+  memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
+  memcpy(&amax, ctx->h_flags + 14, sizeof(double));
+  A->lat8_asym = amax > 0.0 ? dmax / amax : (dmax > 0.0 ? 1.0 : 0.0);
+  if (!(dmax <= 1e-13 * amax)) return MFEM_OK;  // not symmetric (or NaN): the diagonal-slotted layout serves this solve
+  A->lat8_vals = buf;
+  A->lat8_dump = buf + lat8_vals_doubles(G);
+  A->lat8_src = vals;
+  A->lat8_dsc = dsc;
+  A->lat8_scaled = dsc ? 1 : 0;
+  return MFEM_OK;
+}
+
+bool mfem_lat8_bound(const mfem_csr_s* A, const double* vals) { return A->lat8_vals && vals == A->lat8_src; }
+
+void mfem_lat8_unbind(mfem_csr_s* A) {
+  A->lat8_vals = nullptr;
+  A->lat8_dump = nullptr;
+  A->lat8_src = nullptr;
+  A->lat8_dsc = nullptr;
+}
+
+// returns 1 if launched, 0 if another kernel should be used, <0 on error
+int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha, double beta,
+                          const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part) {
+  if (!A->lat8_vals || vals != A->lat8_src) return 0;
+  if (part != 0) {
+    mfem_set_error("lattice-tile layout bound on a split SpMV");
+    return MFEM_ERR_INVALID;
+  }
+  if (n_partials) *n_partials = 0;
+  const Lat8Geom G = lat8_geom(A);
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  const int chunk = (ntiles + 7) / 8;
+  hipLaunchKernelGGL(k_spmv_lat8, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag);
+  MFEM_CHECK_LAUNCH();
+  int cap = ctx->num_cus * 8;
+  if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
+  const int grid = ntiles < cap ? ntiles : cap;
+  hipLaunchKernelGGL(k_lat8_gather, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag);
+  MFEM_CHECK_LAUNCH();
+  if (n_partials && partials) *n_partials = grid;
+  ++g_lat8_count;
+  return 1;
+}
+
+// bytes one SpMV of the layout moves by design: the stored entries, x (and d) as the tiles stage it, the y blocks written and read again, y
+int64_t mfem_lat8_design_bytes(const mfem_csr_s* A) {
+  const Lat8Geom G = lat8_geom(A);
+  const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
+  return (int64_t)lat8_vals_doubles(G) * 8 + tiles * L8_F * L8_FC * 8 * (A->lat8_scaled ? 4 : 3) + A->n * 8;
+}
+int64_t mfem_lat8_entries(const mfem_csr_s* A) { return (int64_t)lat8_vals_doubles(lat8_geom(A)); }

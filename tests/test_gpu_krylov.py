@@ -255,7 +255,13 @@ def test_solver_layout_inspector(mf):
     A1 = b1.pattern(1)
     m, slots, npad, reg = layout(b1, A1)
     assert (m, slots) == (2, 27) and npad % 128 == 0 and npad >= A1.n and 0.5 * A1.n <= reg <= A1.n
-    assert layout(b1, b1.pattern(3))[:2] == (2, 81)  # field-major 3-field matrix: one diagonal list per row field
+    assert layout(b1, b1.pattern(3))[:2] == (5, 81)  # field-major 3-field 27-point matrix: symmetric lattice tiles (if the values of the solve are symmetric)
+    _lib.lib.mfem_debug_set_lat8(0)
+    try:
+        b1s = mf.make_Brick((1.0, 1.0, 1.0), (24, 24, 24))
+        assert layout(b1s, b1s.pattern(3))[:2] == (2, 81)  # ... else diagonal slots: one diagonal list per row field
+    finally:
+        _lib.lib.mfem_debug_set_lat8(1)
     b3 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
     assert layout(b3, b3.pattern(1))[0] == 3        # small brick: boundary rows would need > 10 % padding in a uniform layout
     b27 = mf.make_Brick((1.0, 1.0, 1.0), (4, 4, 4), 2, 5)

@@ -1,0 +1,122 @@
+"""Solver layout mode 5 (csrc/spmv_lat8.hip): the 3-field 27-point lattice matrix (hex-8 elasticity, cantilever/3D_Script.jl's system) stored as
+symmetric lattice tiles.  The caller's contract stays CSR (mul!, misc/04_GPU_Utils.jl:131; iterative_Solve!, 02_Preconditioner.jl:32-76): every check
+is against the CSR kernel / the diagonal-slotted or sliced layout on the same values.  Tolerances: 1e-13 relative for one SpMV (other summation
+order), 1e-8 for converged solutions (tolerance of the solves 1e-11)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LAM, MU, TAU = 0.5769230769230769, 0.38461538461538464, 1000.0
+
+
+def _mode(b, A):
+    from metafem_jl_amd import _lib
+
+    mode = C.c_int32()
+    _lib.check(_lib.lib.mfem_csr_solver_layout(b.ctx._h, A._h, C.byref(mode), None, None, None))
+    return mode.value
+
+
+@pytest.fixture()
+def small_layouts():
+    from metafem_jl_amd import _lib
+
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    yield _lib
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+    _lib.lib.mfem_debug_set_lat8(1)
+
+
+@pytest.mark.parametrize("dims", [(3, 3, 3), (4, 4, 4), (3, 4, 5), (9, 5, 17), (5, 16, 4), (17, 9, 12), (1, 40, 3), (20, 20, 20), (8, 8, 16), (7, 7, 15)])
+def test_spmv_equals_the_csr_kernel(mf, small_layouts, dims):
+    """Tiles (8 x 8 x 16 nodes) and units (4 x 4 x 4) cut by the lattice in every direction, exact fits included; alpha / beta."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 0.7, 1.3), dims, 1, 3)
+    A = b.pattern(3)
+    if A.n < 128:
+        pytest.skip("less than one block: CSR kernel")
+    K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    assert _mode(b, A) == 5
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
+        y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+        c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
+        assert int(_lib.lib.mfem_debug_lat8_spmv_count()) == c0 + 1
+        assert _lib.lib.mfem_debug_lat8_asymmetry(A._h) <= 1e-14
+        want = alpha * y0 + beta * 7.0
+        assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+
+
+def test_values_that_are_not_symmetric_take_the_other_layout(mf, small_layouts):
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (6, 5, 7), 1, 3)
+    A = b.pattern(3)
+    K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    for eps, served in ((1e-9, 0), (1e-15, 1), (float("nan"), 0)):
+        K2 = K.clone()
+        pos = int(A.nnz // 2 + 5)
+        K2[pos] = K2[pos] * (1.0 + eps) if eps == eps else float("nan")
+        y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        y1 = torch.zeros_like(y0)
+        mf.mul_(y0, A, K2, x)
+        c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K2.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+        assert int(_lib.lib.mfem_debug_lat8_spmv_count()) - c0 == served, eps
+        if eps == eps:
+            assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+        else:
+            assert bool(torch.isnan(y1).any())
+
+
+def test_solvers(mf, small_layouts):
+    """bicgstabl_GS! / idrs! / cgs2! with the right Jacobi scaling (applied to x while it is staged), cg!, and the cases that must not take the
+    layout (scale_in_place, a left preconditioner); every solution equals the solve on the other layouts."""
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (10, 9, 8), 1, 3)
+    A = b.pattern(3)
+    K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    cases = [
+        ("cg jacobi", dict(Sv_func=mf.cg_), True),
+        ("bicgstab jacobi", dict(Sv_func=mf.bicgstabl_GS_, s=2), True),
+        ("bicgstab colnorm", dict(Sv_func=mf.bicgstabl_GS_, s=2, Pr_func=mf.Pr_Jacobi_colnorm_), True),
+        ("bicgstab plain", dict(Sv_func=mf.bicgstabl_GS_, s=2, Pr_func=mf.Identity), True),
+        ("bicgstab in place", dict(Sv_func=mf.bicgstabl_GS_, s=2, scale_in_place=True), False),
+        ("idrs jacobi", dict(Sv_func=mf.idrs_, s=4), True),
+        ("idrs left", dict(Sv_func=mf.idrs_, s=4, Pl_func=mf.Pl_Jacobi_), False),
+        ("cgs2 jacobi", dict(Sv_func=mf.cgs2_), True),
+    ]
+    for name, kw, expect in cases:
+        sol = {}
+        for lat in (1, 0):
+            _lib.lib.mfem_debug_set_lat8(lat)
+            c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+            x, st = mf.iterative_Solve(A, K.clone(), rhs, 1e-11, maxiter=6000, max_pass=4, **kw)
+            used = int(_lib.lib.mfem_debug_lat8_spmv_count()) > c0
+            assert used == (expect and lat == 1), (name, lat)
+            assert st.converged, name
+            sol[lat] = x.cpu().numpy()
+        assert np.abs(sol[1] - sol[0]).max() <= 1e-8 * np.abs(sol[0]).max(), name
+
+
+def test_other_patterns_are_refused(mf, small_layouts):
+    """One field, two fields, hex-27 with three fields and slab patterns keep their layouts."""
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (7, 7, 7))
+    assert _mode(b, b.pattern(1)) != 5 and _mode(b, b.pattern(2)) != 5
+    b27 = mf.make_Brick((1.0, 1.0, 1.0), (5, 4, 4), 2, 5)
+    assert _mode(b27, b27.pattern(3)) != 5
+    sb = mf.make_Brick((2.0, 1.0, 1.0), (20, 6, 6))
+    sb.set_slab(6, 14)
+    assert _mode(sb, sb.pattern(3)) != 5
