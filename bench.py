@@ -439,13 +439,13 @@ def main():
                 kernel, kkey = "k_spmv_ell (SpMV on the slot-major copy of the CSR matrix made once per solve; f64 val / i32 col)", "k_spmv_ell"
             elif mode.value == 4:
                 kernel, kkey = ("k_spmv_lat27 + k_lat27_gather (two launches per SpMV): symmetric lattice tiles of the hex-27 matrix, copy made once per "
-                                "solve; the values passed the per-solve symmetry measure (max |A[r][c] - A[c][r]| <= 1e-13 max |A[r][c]|), so only the "
+                                "solve; the values passed the per-solve symmetry measure (probe product against the CSR kernel within 4e-13 max |A[r][c]|), so only the "
                                 "diagonal and the entries with column > row are stored and read (14..63 of a row's 27..125); x and y of a tile of "
                                 "8 x 8 x 32 lattice points in LDS, mirrored products added there (ds_add_f64); the second launch sums the tiles' y blocks "
                                 "in a fixed order; y equals the CSR kernel's to round-off"), "k_spmv_lat27"
             elif mode.value == 5:
                 kernel, kkey = ("k_spmv_lat8 + k_lat8_gather (two launches per SpMV): symmetric lattice tiles of the 3-field 27-point matrix, copy made "
-                                "once per solve; the values passed the per-solve symmetry measure (max |a - a^T| <= 1e-13 max |a|), so per node only "
+                                "once per solve; the values passed the per-solve symmetry measure (probe product against the CSR kernel within 4e-13 max |a|), so per node only "
                                 "the 6 upper entries of its own 3 x 3 block and the blocks towards its 13 upper neighbours are stored and read (123 of "
                                 "243 values); lane = node, x and y of a tile of 8 x 8 x 16 nodes in LDS, mirrored products added there (ds_add_f64), "
                                 "the right Jacobi scaling applied to x while it is staged; the second launch sums the tiles' y blocks in a fixed "

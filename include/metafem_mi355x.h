@@ -103,8 +103,9 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
  *           keeps the matrix unscaled (cg!, or no Jacobi scaling): symmetric lattice tiles -- only the diagonal and the entries with
  *           column > row are stored (14..63 of a row's 27..125), 16 rows of each of the 8 node types per wave, x and y of a tile of
  *           8 x 8 x 32 lattice points staged in LDS, the mirrored products added there; a second pass sums the tiles' y blocks in a
- *           fixed order.  Taken per solve only if max |A[r][c] - A[c][r]| <= 1e-13 max |A[r][c]| (measured by the layout pass; mode 3
- *           serves the solve otherwise).  y agrees with the CSR kernel to round-off (other summation order), not bitwise, and not
+ *           fixed order.  Taken per solve only if the values are symmetric: the bind compares one probe product of the layout with the CSR
+ *           kernel's (x in [0.75, 1.25): an entry pair that differs by delta shows up as >= 0.75 |delta|) and requires
+ *           max |difference| <= 4e-13 max |A[r][c]| (mode 3 serves the solve otherwise).  y agrees with the CSR kernel to round-off (other summation order), not bitwise, and not
  *           bitwise from run to run.  A right Jacobi scaling (A D^-1) is applied to x while it is staged; the stored matrix stays A.
  *   mode 5  the same construction for the 3-field 27-point lattice matrix (hex-8 elasticity, field-major rows): lane = node, per node the 6
  *           upper entries of its own 3 x 3 block and the blocks towards its 13 upper neighbours (123 of 243 values), tiles of 8 x 8 x 16 nodes;

@@ -43,7 +43,7 @@ int mfem_debug_set_sell(int enable);
 int mfem_debug_set_lat27(int enable);
 /* SpMVs mode 4 has served so far, process-wide */
 long long mfem_debug_lat27_spmv_count(void);
-/* max |A[r][c] - A[c][r]| / max |A[r][c]| measured by the layout pass of the last mode-4 bind on this pattern (mode 4 is taken up to 1e-13) */
+/* max |layout x - CSR x| / max |A[r][c]| of the probe product of the last mode-4 bind on this pattern (mode 4 is taken up to 4e-13) */
 double mfem_debug_lat27_asymmetry(mfem_csr A);
 /* mode 5 (symmetric lattice tiles, 3-field 27-point matrix): the same three entry points */
 int mfem_debug_set_lat8(int enable);

@@ -182,7 +182,7 @@ struct mfem_csr_s {
 };
 int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat8_bytes(const mfem_csr_s* A);
-int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);  // binds only symmetric values
+int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles
 void mfem_lat8_unbind(mfem_csr_s* A);
 bool mfem_lat8_bound(const mfem_csr_s* A, const double* vals);
 int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha, double beta,
@@ -191,7 +191,10 @@ int64_t mfem_lat8_design_bytes(const mfem_csr_s* A);
 int64_t mfem_lat8_entries(const mfem_csr_s* A);
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
-int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);  // binds only symmetric values
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles
+extern int mfem_probe_active;
+int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
+                   void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym);
 void mfem_lat27_unbind(mfem_csr_s* A);
 bool mfem_lat27_bound(const mfem_csr_s* A, const double* vals);
 int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,

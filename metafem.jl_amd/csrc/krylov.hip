@@ -722,8 +722,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // the column scaling is handed over here, the SpMVs read it after it has been filled
   bool lat8_bound = false;
   if (lat8_bytes) {
-    rc = mfem_lat8_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
+    // (the first three work vectors serve the bind's probe product and are cleared again)
+    rc = mfem_lat8_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr, V.w[0]);
     if (rc) return rc;
+    MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
     lat8_bound = mfem_lat8_bound(A, vals_work);
   }
 
@@ -791,8 +793,9 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     }
   }
   if (lat_bytes) {
-    rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
+    rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr, V.w[0]);
     if (rc) return rc;
+    MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
   }
   if (sell_bytes && !mfem_lat27_bound(A, vals_work) && !lat8_bound) {
     rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);

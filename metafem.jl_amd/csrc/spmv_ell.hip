@@ -1810,9 +1810,10 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
       if (rc) return rc;
       l8 = mfem_lat8_bytes(A);
     }
-    rc = mfem_ws_reserve(ctx, l8 > bytes ? l8 : bytes);
+    const size_t lay = ((l8 > bytes ? l8 : bytes) + 255) & ~(size_t)255;
+    rc = mfem_ws_reserve(ctx, lay + (l8 ? 3 * (size_t)A->n * sizeof(double) : 0));
     if (rc) return rc;
-    if (l8) rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+    if (l8) rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, (double*)((char*)ctx->ws + lay));
     if (rc) return rc;
     if (!mfem_lat8_bound(A, vals)) rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
     if (rc) return rc;
@@ -1830,17 +1831,19 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
         if (rc) return rc;
         const size_t l8 = mfem_lat8_bytes(A);
         if (l8) {
-          rc = mfem_ws_reserve(ctx, l8 > sb ? l8 : sb);
+          const size_t lay = ((l8 > sb ? l8 : sb) + 255) & ~(size_t)255;
+          rc = mfem_ws_reserve(ctx, lay + 3 * (size_t)A->n * sizeof(double));
           if (rc) return rc;
-          rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+          rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, (double*)((char*)ctx->ws + lay));
           if (rc) return rc;
         }
       }
     }
     if (sb) {
-      rc = mfem_ws_reserve(ctx, lb > sb ? lb : sb);
+      const size_t lay = ((lb > sb ? lb : sb) + 255) & ~(size_t)255;
+      if (!mfem_lat8_bound(A, vals)) rc = mfem_ws_reserve(ctx, lay + (lb ? 3 * (size_t)A->n * sizeof(double) : 0));
       if (rc) return rc;
-      if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+      if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr, (double*)((char*)ctx->ws + lay));
       if (rc) return rc;
       if (!mfem_lat27_bound(A, vals) && !mfem_lat8_bound(A, vals)) rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
       if (rc) return rc;

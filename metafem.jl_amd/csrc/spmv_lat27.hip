@@ -19,8 +19,8 @@
 //   * pass 2 (k_lat27_gather): row r sums the up to 18 tiles whose block covers it, in a fixed order, applies alpha / beta and the fused
 //     dot product.  No global atomics; 2.1 cells per row written and read again (+ 12 % traffic).
 //   * eligibility is decided in two steps: the pattern must BE the lattice stencil (checked entry by entry once per pattern), and the values
-//     of this solve must be symmetric: the layout pass reads both A[r][c] and A[c][r] and the bind falls back to the sliced layout when
-//     max |A[r][c] - A[c][r]| > 1e-13 max |A[r][c]|.  A right Jacobi scaling (bicgstabl_GS!, idrs!, cgs2! work on A D^-1, which is not
+//     of this solve must be symmetric: measured per bind with a probe product (mfem_sym_probe below: the layout against the CSR kernel on one
+//     vector); the sliced layout serves the solve when they differ by more than 4e-13 max |A[r][c]|.  A right Jacobi scaling (bicgstabl_GS!, idrs!, cgs2! work on A D^-1, which is not
 //     symmetric) is applied to x while it is staged: (A D^-1) x = A (x / d), so the stored matrix stays the symmetric A.
 //   * y differs from the CSR kernel's by round-off (other summation order), and the order in which the waves of a workgroup add into
 //     an LDS cell is not fixed: results are reproducible to ~1e-16 relative, not bitwise (mfem_debug_set_lat27(0) selects the sliced layout).
@@ -43,6 +43,7 @@ typedef double l_d2 __attribute__((ext_vector_type(2)));
 extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
 static int g_lat27_enable = 1;
 static long long g_lat27_count = 0;
+int mfem_probe_active = 0;  // set while mfem_sym_probe runs its two products: they are not SpMVs a solver asked for (the counters skip them)
 extern "C" long long mfem_debug_lat27_spmv_count(void) { return g_lat27_count; }  // SpMVs the layout has served (bench.py: which kernel ran)
 // max |A[r][c] - A[c][r]| / max |A[r][c]| the layout pass of the last bind on this pattern measured (-1: no bind yet)
 extern "C" double mfem_debug_lat27_asymmetry(mfem_csr A) { return A ? A->lat27_asym : -1.0; }
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_verify(Lat27Geom G, const RP
   if (fail) bad[0] = 1;
 }
 
-// The layout pass: a wave per unit.  stats[0] = max |A[r][c] - A[c][r]|, stats[1] = max |A[r][c]| over the stored pairs (bit patterns of
-// non-negative doubles, which order like integers).
+// The layout pass: a wave per unit.  stats[1] = max |A[r][c]| over the stored entries (bit pattern of a non-negative double, which orders like
+// an integer).
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* __restrict__ rowptr, int base,
                                                            const double* __restrict__ vals, double* __restrict__ out,
@@ -163,8 +164,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
-  const int64_t PL = (int64_t)G.m1 * G.m2;
-  double amax = 0.0, dmax = 0.0;
+  double amax = 0.0;
   for (int64_t u = wave; u < nunits; u += nwaves) {
     const int uk = (int)(u % G.nuk);
     const int64_t u2 = u / G.nuk;
@@ -194,16 +194,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
           const int ci = gi + di, cj = gj + dj, ck = gk + dk;
           if (valid && di != L27_PAD && ci < G.m0 && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {
             const double v = vals[rp + ((int64_t)(di - li) * nj + (dj - lj)) * nk + (dk - lk)];
-            const int64_t c = r + (int64_t)di * PL + (int64_t)dj * G.m2 + dk;
-            int mi, qi, mj, qj, mk, qk;
-            l27_range(ci, G.m0, mi, qi);
-            l27_range(cj, G.m1, mj, qj);
-            l27_range(ck, G.m2, mk, qk);
-            const double w = vals[(int64_t)rowptr[c] - base + ((int64_t)(-di - mi) * qj + (-dj - mj)) * qk + (-dk - mk)];
-            double df = fabs(v - w);
-            if (!(df == df)) df = __builtin_huge_val();  // NaN (or inf - inf) somewhere: never symmetric (fmax would drop it)
-            amax = fmax(amax, fabs(v));
-            dmax = fmax(dmax, df);
+            double av = fabs(v);
+            if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
+            amax = fmax(amax, av);
             if (h) pr.y = v; else pr.x = v;
           }
         }
@@ -212,14 +205,67 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
-    dmax = fmax(dmax, __shfl_down(dmax, o, MFEM_WAVE));
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
+  if (lane == 0) atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
+}
+
+// ---- the symmetry measure shared by the lattice-tile layouts (modes 4 and 5) ---------------------------------------------------------
+// The layout stores one triangle and mirrors it; whether that is the caller's matrix is measured with a probe product: x with entries in
+// [0.75, 1.25), y1 = (layout) x, y2 = (CSR kernel on the caller's values) x.  y1 - y2 = (L - U^T) x: an entry pair that differs by delta shows up
+// as >= 0.75 |delta| in its row (the other terms of that row are the other pairs' differences: no cancellation for a generic x).  The two products
+// round differently (<= a few 1e-15 max|a| for rows of up to 125 entries), so the layout is taken when max |y1 - y2| <= 4e-13 max |a|.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_probe_vector(int64_t n, double* __restrict__ x) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t z = (uint64_t)i + 0x9E3779B97F4A7C15ull;  // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    x[i] = 0.75 + 0.5 * (double)(z >> 11) * (1.0 / 9007199254740992.0);
   }
-  if (lane == 0) {
-    atomicMax(stats + 0, (unsigned long long)__double_as_longlong(dmax));
-    atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
+}
+__global__ __launch_bounds__(MFEM_BLOCK) void k_probe_diff(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                             unsigned long long* __restrict__ out) {
+  double d = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double e = fabs(a[i] - b[i]);
+    if (!(e == e)) e = __builtin_huge_val();
+    d = fmax(d, e);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_down(d, o, MFEM_WAVE));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
+}
+
+// scratch: 3 n doubles.  The layout must be bound for `vals` with no column scaling; unbind() must leave the pattern without any bound layout
+// (the second product then runs the CSR kernel).  *asym = max |y1 - y2| / amax.
+int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
+                   void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym) {
+  const int64_t n = A->n;
+  double *x = scratch, *y1 = scratch + n, *y2 = scratch + 2 * n;
+  unsigned long long* d_stat = (unsigned long long*)(ctx->d_flags + 12);
+  const int prof = ctx->prof_on;
+  ctx->prof_on = 0;  // (not SpMVs of the solve: bench.py's per-launch timing must not see them)
+  mfem_probe_active = 1;
+  MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(k_probe_vector, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, x);
+  int rc = mfem_spmv_launch(ctx, A, vals, x, y1, 1.0, 0.0, nullptr, nullptr, nullptr);
+  if (!rc) {
+    unbind(A);
+    rc = mfem_spmv_launch(ctx, A, vals, x, y2, 1.0, 0.0, nullptr, nullptr, nullptr);
+    rebind(A, cookie);
+  }
+  ctx->prof_on = prof;
+  mfem_probe_active = 0;
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_probe_diff, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, y1, y2, d_stat);
+  MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double dmax;
+  memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
+  const bool finite = amax < __builtin_huge_val();
+  *asym = (amax > 0.0 && finite) ? dmax / amax : ((dmax > 0.0 || !finite) ? 1.0 : 0.0);
+  return MFEM_OK;
 }
 
 // A unit's 68 steps run as 9 chunks (type 0 in two halves of 8 steps, then one chunk per type: 10, 10, 6, 10, 6, 6, 4 steps); the values of
@@ -458,13 +504,20 @@ size_t mfem_lat27_bytes(const mfem_csr_s* A) {
   return sizeof(double) * (lat27_vals_doubles(G) + lat27_dump_doubles(G));
 }
 
-// Makes the layout copy of `vals` in buf; binds it if the values are symmetric (else leaves the pattern unbound: the caller binds
-// the sliced layout instead).  One stream synchronisation (the symmetry verdict).
-int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
-  A->lat27_vals = nullptr;
-  A->lat27_src = nullptr;
-  A->lat27_dsc = nullptr;
-  if (A->lat27_state != 1 || !g_lat27_enable || !buf) return MFEM_OK;
+struct Lat27Bind { double *vals, *dump; const double* src; };
+static void lat27_probe_unbind(mfem_csr_s* A) { mfem_lat27_unbind(A); }
+static void lat27_probe_rebind(mfem_csr_s* A, void* c) {
+  const Lat27Bind* b = (const Lat27Bind*)c;
+  A->lat27_vals = b->vals;
+  A->lat27_dump = b->dump;
+  A->lat27_src = b->src;
+}
+
+// Makes the layout copy of `vals` in buf and binds it if the values are symmetric (mfem_sym_probe; else leaves the pattern unbound: the caller
+// binds the sliced layout instead).  scratch: 3 n doubles, left dirty.  Two stream synchronisations (max |a|, the verdict).
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch) {
+  mfem_lat27_unbind(A);
+  if (A->lat27_state != 1 || !g_lat27_enable || !buf || !scratch) return MFEM_OK;
   const Lat27Geom G = lat27_geom(A);
   unsigned long long* d_stats = (unsigned long long*)(ctx->d_flags + 12);
   MFEM_CHECK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -479,14 +532,17 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
   MFEM_CHECK_LAUNCH();
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  double dmax, amax;
-  memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
+  double amax;
   memcpy(&amax, ctx->h_flags + 14, sizeof(double));
-  A->lat27_asym = amax > 0.0 ? dmax / amax : (dmax > 0.0 ? 1.0 : 0.0);
-  if (!(dmax <= 1e-13 * amax)) return MFEM_OK;  // not symmetric (or NaN): the sliced layout serves this solve
-  A->lat27_vals = buf;
-  A->lat27_dump = buf + lat27_vals_doubles(G);
-  A->lat27_src = vals;
+  Lat27Bind B{buf, buf + lat27_vals_doubles(G), vals};
+  lat27_probe_rebind(A, &B);
+  double asym = 1.0;
+  int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat27_probe_unbind, lat27_probe_rebind, &B, &asym);
+  A->lat27_asym = asym;
+  if (rc || !(asym <= 4e-13)) {  // not symmetric (or NaN): the sliced layout serves this solve
+    mfem_lat27_unbind(A);
+    return rc;
+  }
   A->lat27_dsc = dsc;
   A->lat27_scaled = dsc ? 1 : 0;
   return MFEM_OK;
@@ -522,7 +578,7 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
                      done_flag);
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
-  ++g_lat27_count;
+  if (!mfem_probe_active) ++g_lat27_count;
   return 1;
 }
 

@@ -14,8 +14,8 @@
 //     a = A[(f, p)][(g, p')] the lane adds a x[g][p'] to its register sum of row (f, p) and a x[f][p] to cell (g, p') (ds_add_f64).  The y
 //     block leaves as one contiguous run per tile.
 //   * pass 2 (k_lat8_gather) sums the up to 18 tile blocks that cover a row in a fixed order, applies alpha / beta and the fused dot product.
-//   * the pattern must be the full stencil (checked entry by entry once), the values of a solve symmetric to 1e-13 of the largest entry
-//     (measured by the layout pass; the diagonal-slotted layout serves the solve otherwise).  Results equal the CSR kernel's to round-off, not
+//   * the pattern must be the full stencil (checked entry by entry once), the values of a solve symmetric (a probe product of the layout against
+//     the CSR kernel, mfem_sym_probe in spmv_lat27.hip, within 4e-13 of the largest entry; the diagonal-slotted layout serves the solve otherwise).  Results equal the CSR kernel's to round-off, not
 //     bitwise, and not bitwise from run to run (order of the LDS adds of different waves).  mfem_debug_set_lat8(0) switches the layout off.
 #include "blas1.h"
 
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* 
   if (fail) bad[0] = 1;
 }
 
-// The layout pass: a wave per unit, lane = node.  stats[0] = max |a - a^T| over the stored pairs, stats[1] = max |a| (bit patterns).
+// The layout pass: a wave per unit, lane = node.  stats[1] = max |a| over the stored entries (bit pattern).
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __restrict__ rowptr, int base, const double* __restrict__ vals,
                                                           double* __restrict__ out, unsigned long long* __restrict__ stats) {
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
   const int la = lane >> 4, lb = (lane >> 2) & 3, lc = lane & 3;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk, PL = (int64_t)G.m1 * G.m2;
-  double amax = 0.0, dmax = 0.0;
+  const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
+  double amax = 0.0;
   for (int64_t u = wave; u < nunits; u += nwaves) {
     const int uk = (int)(u % G.nuk);
     const int64_t u2 = u / G.nuk;
@@ -160,16 +160,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
         const int ci = gi + di, cj = gj + dj, ck = gk + dk;
         if (ci < G.m0 && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {
           const double v = vals[rp[f] + (int64_t)g * cnt + ((di - li) * nj + (dj - lj)) * nk + (dk - lk)];
-          const int64_t pc = p + (int64_t)di * PL + (int64_t)dj * G.m2 + dk;
-          int mi, qi, mj, qj, mk, qk;
-          l8_range(ci, G.m0, mi, qi);
-          l8_range(cj, G.m1, mj, qj);
-          l8_range(ck, G.m2, mk, qk);
-          const double w = vals[(int64_t)rowptr[g * G.N + pc] - base + (int64_t)f * (qi * qj * qk) + ((-di - mi) * qj + (-dj - mj)) * qk + (-dk - mk)];
-          double df = fabs(v - w);
-          if (!(df == df)) df = __builtin_huge_val();
-          amax = fmax(amax, fabs(v));
-          dmax = fmax(dmax, df);
+          double av = fabs(v);
+          if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
+          amax = fmax(amax, av);
           if (h) pr.y = v; else pr.x = v;
         }
       }
@@ -177,14 +170,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
-    dmax = fmax(dmax, __shfl_down(dmax, o, MFEM_WAVE));
-  }
-  if (lane == 0) {
-    atomicMax(stats + 0, (unsigned long long)__double_as_longlong(dmax));
-    atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
-  }
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
+  if (lane == 0) atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
 }
 
 #define L8_LDS_ADD(ptr, val) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ptr), (val))
@@ -389,13 +376,20 @@ size_t mfem_lat8_bytes(const mfem_csr_s* A) {
   return sizeof(double) * (lat8_vals_doubles(G) + lat8_dump_doubles(G));
 }
 
-// Makes the layout copy of `vals` in buf and binds it if the values are symmetric (one stream synchronisation: the verdict).  dsc: right Jacobi
-// scaling the SpMV applies to x (nullptr: none); only the pointer is kept, it may be filled after the bind.
-int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
-  A->lat8_vals = nullptr;
-  A->lat8_src = nullptr;
-  A->lat8_dsc = nullptr;
-  if (A->lat8_state != 1 || !g_lat8_enable || !buf) return MFEM_OK;
+struct Lat8Bind { double *vals, *dump; const double* src; };
+static void lat8_probe_unbind(mfem_csr_s* A) { mfem_lat8_unbind(A); }
+static void lat8_probe_rebind(mfem_csr_s* A, void* c) {
+  const Lat8Bind* b = (const Lat8Bind*)c;
+  A->lat8_vals = b->vals;
+  A->lat8_dump = b->dump;
+  A->lat8_src = b->src;
+}
+
+// Makes the layout copy of `vals` in buf and binds it if the values are symmetric (mfem_sym_probe, spmv_lat27.hip).  dsc: right Jacobi scaling the
+// SpMV applies to x (nullptr: none); only the pointer is kept, it may be filled after the bind.  scratch: 3 n doubles, left dirty.
+int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch) {
+  mfem_lat8_unbind(A);
+  if (A->lat8_state != 1 || !g_lat8_enable || !buf || !scratch) return MFEM_OK;
   const Lat8Geom G = lat8_geom(A);
   unsigned long long* d_stats = (unsigned long long*)(ctx->d_flags + 12);
   MFEM_CHECK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -410,14 +404,17 @@ int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   MFEM_CHECK_LAUNCH();
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  double dmax, amax;
-  memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
+  double amax;
   memcpy(&amax, ctx->h_flags + 14, sizeof(double));
-  A->lat8_asym = amax > 0.0 ? dmax / amax : (dmax > 0.0 ? 1.0 : 0.0);
-  if (!(dmax <= 1e-13 * amax)) return MFEM_OK;  // not symmetric (or NaN): the diagonal-slotted layout serves this solve
-  A->lat8_vals = buf;
-  A->lat8_dump = buf + lat8_vals_doubles(G);
-  A->lat8_src = vals;
+  Lat8Bind B{buf, buf + lat8_vals_doubles(G), vals};
+  lat8_probe_rebind(A, &B);
+  double asym = 1.0;
+  int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat8_probe_unbind, lat8_probe_rebind, &B, &asym);
+  A->lat8_asym = asym;
+  if (rc || !(asym <= 4e-13)) {  // not symmetric (or NaN): the diagonal-slotted layout serves this solve
+    mfem_lat8_unbind(A);
+    return rc;
+  }
   A->lat8_dsc = dsc;
   A->lat8_scaled = dsc ? 1 : 0;
   return MFEM_OK;
@@ -452,7 +449,7 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   hipLaunchKernelGGL(k_lat8_gather, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag);
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
-  ++g_lat8_count;
+  if (!mfem_probe_active) ++g_lat8_count;
   return 1;
 }
 
