@@ -171,6 +171,7 @@ struct mfem_csr_s {
   double* lat27_dump;       // not owned (behind lat27_vals): one y block per tile
   double lat27_asym;        // max |A[r][c] - A[c][r]| / max |A[r][c]| seen by the last bind
   int lat27_scaled;         // the last bind carried a right Jacobi scaling (accounting)
+  int lat_refused;          // a lattice-tile bind has refused values of this pattern once (not symmetric): solves plan the other layouts too from then on
   // the same for the 3-field 27-point lattice matrix (hex-8 elasticity; spmv_lat8.hip)
   int lat8_state;
   const double* lat8_src;

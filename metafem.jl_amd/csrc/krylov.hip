@@ -653,32 +653,36 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const bool need_copy_unfused = ((jac && !is_cg) || left) && !o->scale_in_place;
   // workspace: x, b (padded copies), d, dinv (CG) / left scaling dl, work vectors, optional matrix copy
   const size_t vec_bytes = (size_t)nv * sizeof(double);
-  // slot-major copy of the working values for near-uniform rows (spmv_ell.hip), made once per solve after the scaling
-  int rc_plan = mfem_ell_plan(ctx, A);
-  if (rc_plan) return rc_plan;
-  const size_t ell_bytes = mfem_ell_vals_bytes(A);
-  size_t sell_bytes = 0;
-  if (!ell_bytes && A->ell_state != 1) {  // rows of uneven length: row-sorted sliced layout
-    rc_plan = mfem_sell_plan(ctx, A);
-    if (rc_plan) return rc_plan;
-    sell_bytes = mfem_sell_vals_bytes(A);
-  }
-  // hex-27 lattice matrix on one rank: the symmetric lattice-tile layout if this solve's values are symmetric (decided by its bind; the sliced
-  // layout takes over in the same workspace otherwise).  A right Jacobi scaling is applied to x there, not to the stored matrix.
-  size_t lat_bytes = 0;
-  if (sell_bytes && !left && !ctx->comm && (is_cg || !jac || fused_scale)) {
+  // Symmetric lattice tiles first (spmv_lat27.hip: the hex-27 lattice matrix; spmv_lat8.hip: the 3-field 27-point matrix), one rank, solver on
+  // the unscaled or right-scaled matrix: taken if this solve's values are symmetric (decided by the bind).  A right Jacobi scaling is applied to x
+  // there, not to the stored matrix.  While a pattern's values have never been refused, the other layouts are not even planned (their inspections
+  // and column copies cost 20 - 40 ms and 2 - 4 GB at the BASELINE sizes); the first refusal plans them and this function starts over.
+  int rc_plan = MFEM_OK;
+  size_t lat_bytes = 0, lat8_bytes = 0;
+  if (!left && !ctx->comm && (is_cg || !jac || fused_scale)) {
     rc_plan = mfem_lat27_plan(ctx, A);
     if (rc_plan) return rc_plan;
     lat_bytes = mfem_lat27_bytes(A);
+    if (!lat_bytes) {
+      rc_plan = mfem_lat8_plan(ctx, A);
+      if (rc_plan) return rc_plan;
+      lat8_bytes = mfem_lat8_bytes(A);
+    }
   }
-  // the same for the 3-field 27-point lattice matrix (hex-8 elasticity), which would otherwise take the diagonal-slotted layout
-  size_t lat8_bytes = 0;
-  if ((ell_bytes || sell_bytes) && !left && !ctx->comm && (is_cg || !jac || fused_scale)) {
-    rc_plan = mfem_lat8_plan(ctx, A);
+  const bool lat_only = (lat_bytes || lat8_bytes) && !A->lat_refused;
+  // slot-major copy of the working values for near-uniform rows (spmv_ell.hip), made once per solve after the scaling
+  size_t ell_bytes = 0, sell_bytes = 0;
+  if (!lat_only) {
+    rc_plan = mfem_ell_plan(ctx, A);
     if (rc_plan) return rc_plan;
-    lat8_bytes = mfem_lat8_bytes(A);
+    ell_bytes = mfem_ell_vals_bytes(A);
+    if (!ell_bytes && A->ell_state != 1) {  // rows of uneven length: row-sorted sliced layout
+      rc_plan = mfem_sell_plan(ctx, A);
+      if (rc_plan) return rc_plan;
+      sell_bytes = mfem_sell_vals_bytes(A);
+    }
   }
-  fused_scale = fused_scale && (ell_bytes || sell_bytes);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
+  fused_scale = fused_scale && (ell_bytes || sell_bytes || lat_only);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
   const bool need_copy = need_copy_unfused && !fused_scale;
   const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
   size_t layout_bytes = ell_bytes > sell_bytes ? ell_bytes : sell_bytes;  // (one of the two is 0)
@@ -727,6 +731,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (rc) return rc;
     MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
     lat8_bound = mfem_lat8_bound(A, vals_work);
+    if (!lat8_bound && lat_only) {  // first refusal on this pattern: plan the other layouts and start over
+      A->lat_refused = 1;
+      return solve_inner(ctx, A, vals, b, x_out, o, stats);
+    }
   }
 
   // Pr = Pr_func!(A)   (02_Preconditioner.jl:38, 103-120)
@@ -796,6 +804,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr, V.w[0]);
     if (rc) return rc;
     MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
+    if (!mfem_lat27_bound(A, vals_work) && lat_only) {  // first refusal on this pattern: plan the other layouts and start over
+      A->lat_refused = 1;
+      return solve_inner(ctx, A, vals, b, x_out, o, stats);
+    }
   }
   if (sell_bytes && !mfem_lat27_bound(A, vals_work) && !lat8_bound) {
     rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);

@@ -850,6 +850,7 @@ static void csr_drop_plans(mfem_csr_s* A) {
   mfem_lat27_unbind(A);
   mfem_lat8_unbind(A);
   A->lat8_state = 0;
+  A->lat_refused = 0;
   mfem_ell_free(A);
   mfem_sell_free(A);
   A->lat27_state = 0;

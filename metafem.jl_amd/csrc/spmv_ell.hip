@@ -1763,32 +1763,35 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
 }
 
 // What the Krylov loop of the next mfem_solve will run on this pattern: 0 = CSR tile kernel, 1 = slot-major copy with explicit
-// columns, 2 = slot-major copy with diagonal-slotted regular blocks.  Plans the pattern if that has not happened yet.
+// columns, 2 = slot-major copy with diagonal-slotted regular blocks, 3 = row-sorted sliced layout, 4 / 5 = symmetric lattice tiles (one rank;
+// the values of each solve decide, modes 3 / 2 serve it otherwise).  Plans what it reports if that has not happened yet.
 extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
                                       int64_t* regular_rows) {
   MFEM_REQUIRE(ctx && A, "null handle");
-  int rc = mfem_ell_plan(ctx, A);
-  if (rc) return rc;
-  int m = 0;
-  if (mfem_ell_vals_bytes(A)) m = (A->dia_state == 1 && g_dia_enable) ? 2 : 1;
-  if (m == 0 && !(A->ell_state == 1 && g_ell_enable)) {
-    rc = mfem_sell_plan(ctx, A);
+  int rc = MFEM_OK, m = 0;
+  if (!ctx->comm) {  // the lattice-tile layouts are looked at first: where they apply, the others are planned only on demand (krylov.hip)
+    rc = mfem_lat27_plan(ctx, A);
     if (rc) return rc;
-    if (mfem_sell_vals_bytes(A)) m = 3;
-    if (m == 3 && !ctx->comm) {  // symmetric lattice-tile layout (spmv_lat27.hip): the structure allows it; each solve's values decide
-      rc = mfem_lat27_plan(ctx, A);
+    if (mfem_lat27_bytes(A)) m = 4;
+    if (m == 0) {
+      rc = mfem_lat8_plan(ctx, A);
       if (rc) return rc;
-      if (mfem_lat27_bytes(A)) m = 4;
+      if (mfem_lat8_bytes(A)) m = 5;
     }
   }
-  if (m != 0 && m != 4 && !ctx->comm) {  // symmetric lattice tiles of the 3-field 27-point matrix (spmv_lat8.hip): the structure allows it; each solve's values decide
-    rc = mfem_lat8_plan(ctx, A);
+  if (m == 0) {
+    rc = mfem_ell_plan(ctx, A);
     if (rc) return rc;
-    if (mfem_lat8_bytes(A)) m = 5;
+    if (mfem_ell_vals_bytes(A)) m = (A->dia_state == 1 && g_dia_enable) ? 2 : 1;
+    if (m == 0 && !(A->ell_state == 1 && g_ell_enable)) {
+      rc = mfem_sell_plan(ctx, A);
+      if (rc) return rc;
+      if (mfem_sell_vals_bytes(A)) m = 3;
+    }
   }
   if (mode) *mode = m;
-  if (slots) *slots = (m == 1 || m == 2 || m == 5) ? A->ell_K : m >= 3 ? A->max_row_nnz : 0;
-  if (padded_rows) *padded_rows = (m == 1 || m == 2 || m == 5) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
+  if (slots) *slots = (m == 1 || m == 2) ? A->ell_K : m >= 3 ? A->max_row_nnz : 0;
+  if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
 }
@@ -1800,53 +1803,47 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(A->n == 0 || (x && y && (A->nnz == 0 || vals)), "null vector");
   if (A->n == 0) return MFEM_OK;
-  int rc = mfem_ell_plan(ctx, A);
-  if (rc) return rc;
-  const size_t bytes = mfem_ell_vals_bytes(A);
-  if (bytes) {
-    size_t l8 = 0;
-    if (!ctx->comm) {
+  int rc = MFEM_OK;
+  bool bound = false;
+  if (!ctx->comm) {  // lattice tiles, if the structure allows them and these values are symmetric
+    rc = mfem_lat27_plan(ctx, A);
+    if (rc) return rc;
+    size_t lb = mfem_lat27_bytes(A);
+    const bool is27 = lb != 0;
+    if (!lb) {
       rc = mfem_lat8_plan(ctx, A);
       if (rc) return rc;
-      l8 = mfem_lat8_bytes(A);
+      lb = mfem_lat8_bytes(A);
     }
-    const size_t lay = ((l8 > bytes ? l8 : bytes) + 255) & ~(size_t)255;
-    rc = mfem_ws_reserve(ctx, lay + (l8 ? 3 * (size_t)A->n * sizeof(double) : 0));
-    if (rc) return rc;
-    if (l8) rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, (double*)((char*)ctx->ws + lay));
-    if (rc) return rc;
-    if (!mfem_lat8_bound(A, vals)) rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
-    if (rc) return rc;
-  } else {
-    rc = mfem_sell_plan(ctx, A);
-    if (rc) return rc;
-    const size_t sb = mfem_sell_vals_bytes(A);
-    size_t lb = 0;
-    if (sb && !ctx->comm) {
-      rc = mfem_lat27_plan(ctx, A);
+    if (lb) {
+      const size_t lay = (lb + 255) & ~(size_t)255;
+      rc = mfem_ws_reserve(ctx, lay + 3 * (size_t)A->n * sizeof(double));
       if (rc) return rc;
-      lb = mfem_lat27_bytes(A);
-      if (!lb) {
-        rc = mfem_lat8_plan(ctx, A);
+      double* scratch = (double*)((char*)ctx->ws + lay);
+      rc = is27 ? mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch) : mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch);
+      if (rc) return rc;
+      bound = mfem_lat27_bound(A, vals) || mfem_lat8_bound(A, vals);
+    }
+  }
+  if (!bound) {
+    rc = mfem_ell_plan(ctx, A);
+    if (rc) return rc;
+    const size_t bytes = mfem_ell_vals_bytes(A);
+    if (bytes) {
+      rc = mfem_ws_reserve(ctx, bytes);
+      if (rc) return rc;
+      rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+      if (rc) return rc;
+    } else {
+      rc = mfem_sell_plan(ctx, A);
+      if (rc) return rc;
+      const size_t sb = mfem_sell_vals_bytes(A);
+      if (sb) {
+        rc = mfem_ws_reserve(ctx, sb);
         if (rc) return rc;
-        const size_t l8 = mfem_lat8_bytes(A);
-        if (l8) {
-          const size_t lay = ((l8 > sb ? l8 : sb) + 255) & ~(size_t)255;
-          rc = mfem_ws_reserve(ctx, lay + 3 * (size_t)A->n * sizeof(double));
-          if (rc) return rc;
-          rc = mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, (double*)((char*)ctx->ws + lay));
-          if (rc) return rc;
-        }
+        rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+        if (rc) return rc;
       }
-    }
-    if (sb) {
-      const size_t lay = ((lb > sb ? lb : sb) + 255) & ~(size_t)255;
-      if (!mfem_lat8_bound(A, vals)) rc = mfem_ws_reserve(ctx, lay + (lb ? 3 * (size_t)A->n * sizeof(double) : 0));
-      if (rc) return rc;
-      if (lb) rc = mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr, (double*)((char*)ctx->ws + lay));
-      if (rc) return rc;
-      if (!mfem_lat27_bound(A, vals) && !mfem_lat8_bound(A, vals)) rc = mfem_sell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
-      if (rc) return rc;
     }
   }
   rc = mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr, nullptr);

@@ -112,6 +112,28 @@ def test_solvers(mf, small_layouts):
         assert np.abs(sol[1] - sol[0]).max() <= 1e-9 * np.abs(sol[0]).max(), name
 
 
+def test_a_solve_whose_values_are_refused_starts_over_on_the_other_layouts(mf, small_layouts):
+    """The sliced layout is planned only after the lattice tiles have refused values of the pattern once (mfem_solve then starts over); later
+    symmetric solves on the same pattern take the tiles again."""
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (8, 7, 6), 2, 5)
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    K2 = K.clone()
+    w = K[A.nnz // 2:A.nnz // 2 + 60].abs()
+    K2[int(A.nnz // 2 + int(w.argsort(descending=True)[1]))] *= 1.0 + 1e-6  # the second largest entry of a middle row: off-diagonal, not small
+    sols = []
+    for vals, expect in ((K, True), (K2, False), (K, True), (K2, False)):
+        c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+        x, st = mf.iterative_Solve(A, vals, rhs, 1e-11, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=3000, max_pass=4)
+        assert st.converged and (int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0) == expect
+        sols.append(x.cpu().numpy())
+    assert np.abs(sols[0] - sols[2]).max() <= 1e-9 * np.abs(sols[0]).max()
+    assert np.abs(sols[1] - sols[3]).max() <= 1e-9 * np.abs(sols[1]).max()
+    assert np.abs(sols[0] - sols[1]).max() <= 1e-3 * np.abs(sols[0]).max()   # (a 1e-6 perturbation of one entry)
+
+
 def test_patterns_that_only_look_like_the_lattice_are_refused(mf, small_layouts):
     """The lattice hint of mfem_brick_pattern only proposes the layout: hex-8 (order 1) and the 3-field pattern keep their layouts, and a
     slab pattern with ghost columns keeps the sliced one."""

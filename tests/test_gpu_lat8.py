@@ -110,6 +110,25 @@ def test_solvers(mf, small_layouts):
         assert np.abs(sol[1] - sol[0]).max() <= 1e-8 * np.abs(sol[0]).max(), name
 
 
+def test_a_solve_whose_values_are_refused_starts_over_on_the_other_layouts(mf, small_layouts):
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (9, 7, 6), 1, 3)
+    A = b.pattern(3)
+    K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    K2 = K.clone()
+    w = K[A.nnz // 2:A.nnz // 2 + 60].abs()
+    K2[int(A.nnz // 2 + int(w.argsort(descending=True)[1]))] *= 1.0 + 1e-6  # the second largest entry of a middle row: off-diagonal, not small
+    sols = []
+    for vals, expect in ((K, True), (K2, False), (K, True)):
+        c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+        x, st = mf.iterative_Solve(A, vals, rhs, 1e-11, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=6000, max_pass=4)
+        assert st.converged and (int(_lib.lib.mfem_debug_lat8_spmv_count()) > c0) == expect
+        sols.append(x.cpu().numpy())
+    assert np.abs(sols[0] - sols[2]).max() <= 1e-8 * np.abs(sols[0]).max()
+    assert np.abs(sols[0] - sols[1]).max() <= 1e-2 * np.abs(sols[0]).max()
+
+
 def test_other_patterns_are_refused(mf, small_layouts):
     """One field, two fields, hex-27 with three fields and slab patterns keep their layouts."""
     _lib = small_layouts
