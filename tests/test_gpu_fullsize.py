@@ -170,3 +170,87 @@ def test_c4_hex27_128_symmetry_and_constants(mf):
     T = torch.full((A.n,), TENV, dtype=torch.float64, device="cuda")
     R = brick.residual_thermal(T, K_COND, H, TENV, mf.ALL_FACES, s=s)
     assert abs(float(R.sum()) - SRC) <= 1e-9 * SRC
+
+
+def _layout_spmv(_lib, brick, A, K, x, count):
+    import torch
+
+    y = torch.empty(A.n, dtype=torch.float64, device="cuda")
+    c0 = int(count())
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+    assert int(count()) == c0 + 1, "the symmetric lattice-tile layout did not take these values"
+    return y
+
+
+def test_c3_lattice_tiles_at_full_size(mf):
+    """configs[2] through solver layout mode 5 (csrc/spmv_lat8.hip): rigid translations stay in the null space of the un-penalised operator, the
+    product equals the CSR kernel's to round-off, x . A z = z . A x, and a bicgstabl_GS! solve (right Jacobi: applied to x inside the layout)
+    reaches the same residual level as on the diagonal-slotted layout."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    E, nu = 1.0, 0.3
+    lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (128, 128, 128))
+    A = brick.pattern(3)
+    K0 = brick.assemble_elasticity(A, lam, mu, 0.0, 0)
+    count = _lib.lib.mfem_debug_lat8_spmv_count
+    nn = 129 ** 3
+    for f in range(3):
+        u = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        u[f * nn:(f + 1) * nn] = 1.0
+        y = _layout_spmv(_lib, brick, A, K0, u, count)
+        assert float(y.abs().max()) <= 1e-10 * float(K0.abs().max())
+    del K0
+    K = brick.assemble_elasticity(A, lam, mu, 1000.0, mf.FACE_BITS["x0"])
+    x, z = mf.FEM_rand(A.n, 5, 0) - 0.5, mf.FEM_rand(A.n, 5, 1) - 0.5
+    Ax, Az = _layout_spmv(_lib, brick, A, K, x, count), _layout_spmv(_lib, brick, A, K, z, count)
+    y0 = torch.empty_like(x)
+    mf.mul_(y0, A, K, x)
+    assert float((Ax - y0).abs().max()) <= 1e-13 * float(y0.abs().max())
+    assert abs(mf.dot(z, Ax) - mf.dot(x, Az)) <= 1e-10 * abs(mf.dot(z, Ax))
+    rhs = mf.FEM_rand(A.n, 7, 0) - 0.5
+    res = {}
+    for lat in (1, 0):
+        _lib.lib.mfem_debug_set_lat8(lat)
+        try:
+            dx, st = mf.iterative_Solve(A, K, rhs, 1e-8, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=6000, max_pass=4)
+        finally:
+            _lib.lib.mfem_debug_set_lat8(1)
+        assert st.converged == 1
+        r = torch.empty_like(rhs)
+        mf.mul_(r, A, K, dx)
+        res[lat] = float((r - rhs).norm() / rhs.norm())
+    assert res[1] <= 4.0 * max(res[0], 1e-12) and res[1] <= 1e-4, res
+
+
+def test_c4_lattice_tiles_at_full_size(mf):
+    """configs[3] through solver layout mode 4 (csrc/spmv_lat27.hip): K 1 sums to -h x area, the product equals the CSR kernel's to round-off,
+    x . A z = z . A x, and cg! reaches the same solution as on the sliced layout."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (128, 128, 128), 2, 5)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES)
+    count = _lib.lib.mfem_debug_lat27_spmv_count
+    one = torch.ones(A.n, dtype=torch.float64, device="cuda")
+    y = _layout_spmv(_lib, brick, A, K, one, count)
+    assert abs(float(y.sum()) + H * 6.0) <= 1e-8
+    x, z = mf.FEM_rand(A.n, 6, 0) - 0.5, mf.FEM_rand(A.n, 6, 1) - 0.5
+    Ax, Az = _layout_spmv(_lib, brick, A, K, x, count), _layout_spmv(_lib, brick, A, K, z, count)
+    y0 = torch.empty_like(x)
+    mf.mul_(y0, A, K, x)
+    assert float((Ax - y0).abs().max()) <= 1e-13 * float(y0.abs().max())
+    assert abs(mf.dot(z, Ax) - mf.dot(x, Az)) <= 1e-10 * abs(mf.dot(z, Ax))
+    rhs = mf.FEM_rand(A.n, 7, 0) - 0.5
+    sol = {}
+    for lat in (1, 0):
+        _lib.lib.mfem_debug_set_lat27(lat)
+        try:
+            dx, st = mf.iterative_Solve(A, K, rhs, 1e-10, Sv_func=mf.cg_, maxiter=4000, max_pass=2)
+        finally:
+            _lib.lib.mfem_debug_set_lat27(1)
+        assert st.converged == 1
+        sol[lat] = dx
+    assert float((sol[1] - sol[0]).abs().max()) <= 1e-9 * float(sol[0].abs().max())
