@@ -215,6 +215,9 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   A->lat_m1 = b->m[1];
   A->lat_m2 = b->m[2];
   A->lat_fields = n_fields;
+  A->lat_m0 = b->m[0];
+  A->lat_plo = b->plo;
+  A->lat_gw = b->p;
   MFEM_CHECK_HIP(hipMalloc(&A->owned_rowptr, sizeof(int64_t) * (n + 1)));
   MFEM_CHECK_HIP(hipMalloc(&A->owned_colidx, sizeof(int32_t) * (nnz > 0 ? nnz : 1)));
   A->rowptr = A->owned_rowptr;

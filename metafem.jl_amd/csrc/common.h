@@ -114,6 +114,7 @@ struct mfem_csr_s {
   uint8_t* cw_elide;        // owned: one flag per tile of cw_R rows of the fixed-row-count wave-tile kernel (k_spmv_csr_w): columns derivable from the tile's first row
   int cw_R;
   int32_t lat_m1, lat_m2, lat_fields;  // lattice hint of a structured pattern (0 = none): points per lattice plane = lat_m1 * lat_m2 (brick.hip)
+  int32_t lat_m0, lat_plo, lat_gw;     // ... planes of the whole lattice, first owned plane of a slab, ghost planes per side (0 = not given)
   uint16_t* diag_off;       // owned, [n], built on first use: offset of the diagonal entry inside its row (0xFFFF = none stored): |diag| is then an
                             // n-sized gather instead of a scan of all nonzeros (Jacobi_By_Diagonal of every solve)
   // owned storage (mfem_brick_pattern) -- freed in destroy

@@ -659,10 +659,12 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // and column copies cost 20 - 40 ms and 2 - 4 GB at the BASELINE sizes); the first refusal plans them and this function starts over.
   int rc_plan = MFEM_OK;
   size_t lat_bytes = 0, lat8_bytes = 0;
-  if (!left && !ctx->comm && (is_cg || !jac || fused_scale)) {
-    rc_plan = mfem_lat27_plan(ctx, A);
-    if (rc_plan) return rc_plan;
-    lat_bytes = mfem_lat27_bytes(A);
+  if (!left && (is_cg || !jac || fused_scale)) {
+    if (!ctx->comm) {  // (mode 4 on one rank only; mode 5 also on slabs)
+      rc_plan = mfem_lat27_plan(ctx, A);
+      if (rc_plan) return rc_plan;
+      lat_bytes = mfem_lat27_bytes(A);
+    }
     if (!lat_bytes) {
       rc_plan = mfem_lat8_plan(ctx, A);
       if (rc_plan) return rc_plan;

@@ -1044,6 +1044,15 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   ProfScope prof{ctx, -1};
   int rc = prof.begin();
   if (rc) return rc;
+  if (mfem_lat8_bound(A, vals)) {  // the lattice tiles do not split into interior / boundary rows: exchange, then one SpMV
+    rc = mfem_comm_halo_begin(ctx, x);
+    if (rc) return rc;
+    rc = mfem_comm_halo_end(ctx);
+    if (rc) return rc;
+    rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, kAllRows);
+    if (rc) return rc;
+    return prof.end();
+  }
   rc = mfem_comm_halo_begin(ctx, x);
   if (rc) return rc;
   // an error between begin and end must not leave the exchange "in flight": the communicator would refuse every later one

@@ -1769,15 +1769,16 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
                                       int64_t* regular_rows) {
   MFEM_REQUIRE(ctx && A, "null handle");
   int rc = MFEM_OK, m = 0;
-  if (!ctx->comm) {  // the lattice-tile layouts are looked at first: where they apply, the others are planned only on demand (krylov.hip)
+  // the lattice-tile layouts are looked at first: where they apply, the others are planned only on demand (krylov.hip)
+  if (!ctx->comm) {
     rc = mfem_lat27_plan(ctx, A);
     if (rc) return rc;
     if (mfem_lat27_bytes(A)) m = 4;
-    if (m == 0) {
-      rc = mfem_lat8_plan(ctx, A);
-      if (rc) return rc;
-      if (mfem_lat8_bytes(A)) m = 5;
-    }
+  }
+  if (m == 0) {
+    rc = mfem_lat8_plan(ctx, A);
+    if (rc) return rc;
+    if (mfem_lat8_bytes(A)) m = 5;
   }
   if (m == 0) {
     rc = mfem_ell_plan(ctx, A);
@@ -1805,10 +1806,13 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   if (A->n == 0) return MFEM_OK;
   int rc = MFEM_OK;
   bool bound = false;
-  if (!ctx->comm) {  // lattice tiles, if the structure allows them and these values are symmetric
-    rc = mfem_lat27_plan(ctx, A);
-    if (rc) return rc;
-    size_t lb = mfem_lat27_bytes(A);
+  {  // lattice tiles, if the structure allows them and these values are symmetric
+    size_t lb = 0;
+    if (!ctx->comm) {
+      rc = mfem_lat27_plan(ctx, A);
+      if (rc) return rc;
+      lb = mfem_lat27_bytes(A);
+    }
     const bool is27 = lb != 0;
     if (!lb) {
       rc = mfem_lat8_plan(ctx, A);
@@ -1817,7 +1821,7 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     }
     if (lb) {
       const size_t lay = (lb + 255) & ~(size_t)255;
-      rc = mfem_ws_reserve(ctx, lay + 3 * (size_t)A->n * sizeof(double));
+      rc = mfem_ws_reserve(ctx, lay + (2 * (size_t)A->n + (size_t)(A->ncols > A->n ? A->ncols : A->n)) * sizeof(double));
       if (rc) return rc;
       double* scratch = (double*)((char*)ctx->ws + lay);
       rc = is27 ? mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch) : mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch);

@@ -236,18 +236,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_probe_diff(int64_t n, const doub
   if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
 }
 
-// scratch: 3 n doubles.  The layout must be bound for `vals` with no column scaling; unbind() must leave the pattern without any bound layout
+// scratch: ncols + 2 n doubles (x carries the ghost entries of a slab pattern).  The layout must be bound for `vals` with no column scaling; unbind() must leave the pattern without any bound layout
 // (the second product then runs the CSR kernel).  *asym = max |y1 - y2| / amax.
 int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
                    void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym) {
-  const int64_t n = A->n;
-  double *x = scratch, *y1 = scratch + n, *y2 = scratch + 2 * n;
+  const int64_t n = A->n, nc = A->ncols > n ? A->ncols : n;
+  double *x = scratch, *y1 = scratch + nc, *y2 = y1 + n;
   unsigned long long* d_stat = (unsigned long long*)(ctx->d_flags + 12);
   const int prof = ctx->prof_on;
   ctx->prof_on = 0;  // (not SpMVs of the solve: bench.py's per-launch timing must not see them)
   mfem_probe_active = 1;
   MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(k_probe_vector, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, x);
+  hipLaunchKernelGGL(k_probe_vector, dim3(mfem_vec_grid(ctx, nc)), dim3(MFEM_BLOCK), 0, ctx->stream, nc, x);
   int rc = mfem_spmv_launch(ctx, A, vals, x, y1, 1.0, 0.0, nullptr, nullptr, nullptr);
   if (!rc) {
     unbind(A);

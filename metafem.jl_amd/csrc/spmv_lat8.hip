@@ -44,11 +44,22 @@ extern "C" int mfem_debug_set_lat8(int enable) {
 }
 
 struct Lat8Geom {
-  int m0, m1, m2;     // nodes per direction
+  int m0, m1, m2;     // OWNED nodes per direction (m0 = owned lattice planes of a slab)
   int nui, nuj, nuk;  // units of 4 x 4 x 4 nodes
   int nti, ntj, ntk;  // tiles of 8 x 8 x 16 nodes
-  int64_t N;          // m0 * m1 * m2
+  int64_t N;          // m0 * m1 * m2 owned nodes
+  // slab: the owned planes are [plo, plo + m0) of a lattice of mg planes; x carries, behind the 3 N owned entries, per field a low and a high
+  // block of gw ghost planes (brick_xindex); plo = 0, mg = m0 for a whole brick
+  int plo, mg, gw;
 };
+// local x index of field f at GLOBAL plane gi (owned or ghost), in-plane position ip
+__device__ __forceinline__ int64_t l8_xindex(const Lat8Geom& G, int f, int gi, int64_t ip) {
+  const int64_t PL = (int64_t)G.m1 * G.m2;
+  if (gi >= G.plo && gi < G.plo + G.m0) return f * G.N + (int64_t)(gi - G.plo) * PL + ip;
+  const int side = gi < G.plo ? 0 : 1;
+  const int off = side ? gi - (G.plo + G.m0) : gi - (G.plo - G.gw);
+  return (int64_t)L8_F * G.N + ((int64_t)(f * 2 + side) * G.gw + off) * PL + ip;
+}
 
 // ---- the step list of a unit (compile-time) ---------------------------------------------------------------------------------
 // row field f: for g = 0..2: [the node's own block entry (f, g) if g >= f], then the 13 upper neighbours e = 1..13 (d = (0,0,1) .. (1,1,1))
@@ -95,11 +106,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* 
   int fail = 0;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < L8_F * G.N; r += stride) {
     const int64_t p = r % G.N;
-    const int gi = (int)(p / PL);
-    const int64_t rem = p - gi * PL;
+    const int gi = (int)(p / PL) + G.plo;  // global plane
+    const int64_t rem = p % PL;
     const int gj = (int)(rem / G.m2), gk = (int)(rem - (int64_t)gj * G.m2);
     int li, ni, lj, nj, lk, nk;
-    l8_range(gi, G.m0, li, ni);
+    l8_range(gi, G.mg, li, ni);
     l8_range(gj, G.m1, lj, nj);
     l8_range(gk, G.m2, lk, nk);
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* 
     for (int g = 0; g < L8_F; ++g)
       for (int a = 0; a < ni; ++a)
         for (int b = 0; b < nj; ++b) {
-          const int64_t c0 = g * G.N + p + (int64_t)(li + a) * PL + (int64_t)(lj + b) * G.m2 + lk;
+          const int64_t c0 = l8_xindex(G, g, gi + li + a, (int64_t)(gj + lj + b) * G.m2 + gk + lk);
           for (int c = 0; c < nk; ++c, ++j)
             if ((int64_t)col[j] - base != c0 + c) fail = 1;
         }
@@ -133,12 +144,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
     const int uk = (int)(u % G.nuk);
     const int64_t u2 = u / G.nuk;
     const int uj = (int)(u2 % G.nuj), ui = (int)(u2 / G.nuj);
-    const int gi = ui * 4 + la, gj = uj * 4 + lb, gk = uk * 4 + lc;
-    const bool valid = gi < G.m0 && gj < G.m1 && gk < G.m2;
-    const int64_t p = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+    const int oi = ui * 4 + la, gj = uj * 4 + lb, gk = uk * 4 + lc;  // oi: owned plane
+    const int gi = oi + G.plo;
+    const bool valid = oi < G.m0 && gj < G.m1 && gk < G.m2;
+    const int64_t p = ((int64_t)oi * G.m1 + gj) * G.m2 + gk;
     int li = 0, ni = 1, lj = 0, nj = 1, lk = 0, nk = 1;
     if (valid) {
-      l8_range(gi, G.m0, li, ni);
+      l8_range(gi, G.mg, li, ni);
       l8_range(gj, G.m1, lj, nj);
       l8_range(gk, G.m2, lk, nk);
     }
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
         const int f = l8_row_field(st), g = l8_g(st), e = l8_e(st);
         const int di = l8_di(e), dj = l8_dj(e), dk = l8_dk(e);
         const int ci = gi + di, cj = gj + dj, ck = gk + dk;
-        if (ci < G.m0 && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {
+        if (ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (the neighbour may sit in a ghost plane: its x comes from the ghost block)
           const double v = vals[rp[f] + (int64_t)g * cnt + ((di - li) * nj + (dj - lj)) * nk + (dk - lk)];
           double av = fabs(v);
           if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
@@ -243,10 +255,10 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
   for (int e = tid; e < L8_F * L8_FC; e += 512) {
     const int f = e / L8_FC, c = e - f * L8_FC;
     const int li = c / L8_PI, r2 = c - li * L8_PI, lj = r2 / L8_SK, lk = r2 - lj * L8_SK;
-    const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+    const int gi = G.plo + i0 + li, gj = j0 + lj, gk = k0 + lk;  // global plane: the plane behind the last owned one is a ghost plane
     double xv = 0.0;
-    if (gi < G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
-      const int64_t r = f * G.N + ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+    if (gi < G.mg && gi <= G.plo + G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
+      const int64_t r = l8_xindex(G, f, gi, (int64_t)gj * G.m2 + gk);
       xv = dsc ? x[r] / dsc[r] : x[r];
     }
     xs[e] = xv;
@@ -271,9 +283,14 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
 }
 
 // pass 2: a thread owns a (j, k) position of the tile and four of its planes, for the three fields
+// Slab with a lower neighbour (G.plo > 0): the rows of the first owned plane also have entries towards the ghost plane below.  No stored entry mirrors
+// onto them (the rows that would belong to the neighbour rank), so they are taken from the caller's CSR values here: 27 products per row of that plane.
+template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const double* __restrict__ dump, double* __restrict__ y, double alpha,
                                                               double beta, const double* __restrict__ dotw, double* __restrict__ partials,
-                                                              const int32_t* __restrict__ done_flag) {
+                                                              const int32_t* __restrict__ done_flag, const RP* __restrict__ rowptr, int base,
+                                                              const double* __restrict__ csr_vals, const double* __restrict__ x,
+                                                              const double* __restrict__ dsc) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
@@ -305,6 +322,24 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
           for (int u = 0; u < 4; ++u) s[f][u] += d[f * L8_FC + u * L8_PI];
       }
     }
+    if (G.plo > 0 && ti == 0 && lh == 0) {  // the lower ghost plane (see above)
+      int l1, n1, l2, n2, l0, n0;
+      l8_range(G.plo, G.mg, l0, n0);
+      l8_range(gj, G.m1, l1, n1);
+      l8_range(gk, G.m2, l2, n2);
+      const int cnt = n0 * n1 * n2;
+      for (int f = 0; f < L8_F; ++f) {
+        const int64_t rp = (int64_t)rowptr[f * G.N + (int64_t)gj * G.m2 + gk] - base;
+        double acc = 0.0;
+        for (int g = 0; g < L8_F; ++g)
+          for (int b = 0; b < n1; ++b)
+            for (int c = 0; c < n2; ++c) {
+              const int64_t xi = l8_xindex(G, g, G.plo - 1, (int64_t)(gj + l1 + b) * G.m2 + gk + l2 + c);
+              acc += csr_vals[rp + (int64_t)g * cnt + b * n2 + c] * (dsc ? x[xi] / dsc[xi] : x[xi]);
+            }
+        s[f][0] += acc;
+      }
+    }
 #pragma unroll
     for (int f = 0; f < L8_F; ++f)
 #pragma unroll
@@ -329,6 +364,9 @@ static Lat8Geom lat8_geom(const mfem_csr_s* A) {
   G.m2 = A->lat_m2;
   G.N = A->n / L8_F;
   G.m0 = (int)(G.N / ((int64_t)A->lat_m1 * A->lat_m2));
+  G.plo = A->lat_plo;
+  G.mg = A->lat_m0 > 0 ? A->lat_m0 : G.m0;
+  G.gw = A->lat_gw > 0 ? A->lat_gw : 1;
   G.nui = (G.m0 + 3) / 4;
   G.nuj = (G.m1 + 3) / 4;
   G.nuk = (G.m2 + 3) / 4;
@@ -344,11 +382,15 @@ int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->n < g_layout_min_rows_dia) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
   A->lat8_state = -1;
   if (A->lat_fields != L8_F || A->lat_m1 < 2 || A->lat_m2 < 2 || A->n % L8_F != 0) return MFEM_OK;
-  if (A->ncols > A->n) return MFEM_OK;  // slab patterns (ghost columns) keep the diagonal-slotted layout
   const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2, N = A->n / L8_F;
   if (N % PL != 0) return MFEM_OK;
   const int64_t m0 = N / PL;
-  if (m0 < 2 || m0 > (1 << 20) || A->max_row_nnz > 81) return MFEM_OK;
+  if (m0 < 1 || m0 > (1 << 20) || A->max_row_nnz > 81) return MFEM_OK;
+  if (A->ncols > A->n) {  // slab pattern (ghost columns): the hint must say where the owned planes sit in the lattice and how the ghost blocks are laid out
+    if (A->lat_m0 < m0 || A->lat_gw != 1 || A->lat_plo < 0 || A->lat_plo + m0 > A->lat_m0 || A->ncols != A->n + 2 * L8_F * PL) return MFEM_OK;
+  } else if (A->lat_m0 > 0 && (A->lat_m0 != m0 || A->lat_plo != 0)) {
+    return MFEM_OK;
+  }
   const Lat8Geom G = lat8_geom(A);
   if ((int64_t)G.nti * G.ntj * G.ntk >= ((int64_t)1 << 28)) return MFEM_OK;
   int32_t* d_bad = ctx->d_flags + 12;
@@ -433,7 +475,7 @@ void mfem_lat8_unbind(mfem_csr_s* A) {
 int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha, double beta,
                           const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part) {
   if (!A->lat8_vals || vals != A->lat8_src) return 0;
-  if (part != 0) {
+  if (part != 0) {  // (mfem_spmv_halo does not split when a lattice-tile layout is bound)
     mfem_set_error("lattice-tile layout bound on a split SpMV");
     return MFEM_ERR_INVALID;
   }
@@ -446,7 +488,12 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;
-  hipLaunchKernelGGL(k_lat8_gather, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_lat8_gather<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag,
+                       (const int64_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);
+  else
+    hipLaunchKernelGGL(k_lat8_gather<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag,
+                       (const int32_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   if (!mfem_probe_active) ++g_lat8_count;
