@@ -659,12 +659,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // and column copies cost 20 - 40 ms and 2 - 4 GB at the BASELINE sizes); the first refusal plans them and this function starts over.
   int rc_plan = MFEM_OK;
   size_t lat_bytes = 0, lat8_bytes = 0;
-  if (!left && (is_cg || !jac || fused_scale)) {
-    if (!ctx->comm) {  // (mode 4 on one rank only; mode 5 also on slabs)
-      rc_plan = mfem_lat27_plan(ctx, A);
-      if (rc_plan) return rc_plan;
-      lat_bytes = mfem_lat27_bytes(A);
-    }
+  if (!left && (is_cg || !jac || fused_scale)) {  // (both also on slab patterns: the plans read the pattern's lattice hint)
+    rc_plan = mfem_lat27_plan(ctx, A);
+    if (rc_plan) return rc_plan;
+    lat_bytes = mfem_lat27_bytes(A);
     if (!lat_bytes) {
       rc_plan = mfem_lat8_plan(ctx, A);
       if (rc_plan) return rc_plan;
@@ -724,15 +722,17 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       mfem_lat8_unbind(A);
     }
   } ell_guard{A};
-  // symmetric lattice tiles of the 3-field matrix: bound first (the Jacobi step below then takes |diag| from the CSR values); only the pointer of
-  // the column scaling is handed over here, the SpMVs read it after it has been filled
+  // symmetric lattice tiles: bound first, before anything is communicated (a refusal starts this function over) -- the Jacobi step below then takes
+  // |diag| from the CSR values; only the pointer of the column scaling is handed over here, the SpMVs read it after it has been filled.
+  // (the first three work vectors serve the bind's probe product and are cleared again)
   bool lat8_bound = false;
-  if (lat8_bytes) {
-    // (the first three work vectors serve the bind's probe product and are cleared again)
-    rc = mfem_lat8_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr, V.w[0]);
+  if (lat_bytes || lat8_bytes) {
+    double* lay = (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes);
+    rc = lat_bytes ? mfem_lat27_bind(ctx, A, vals_work, lay, fused_scale ? V.d : nullptr, V.w[0])
+                   : mfem_lat8_bind(ctx, A, vals_work, lay, fused_scale ? V.d : nullptr, V.w[0]);
     if (rc) return rc;
     MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
-    lat8_bound = mfem_lat8_bound(A, vals_work);
+    lat8_bound = mfem_lat27_bound(A, vals_work) || mfem_lat8_bound(A, vals_work);  // (either of the two)
     if (!lat8_bound && lat_only) {  // first refusal on this pattern: plan the other layouts and start over
       A->lat_refused = 1;
       return solve_inner(ctx, A, vals, b, x_out, o, stats);
@@ -802,16 +802,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       return MFEM_ERR_INVALID;
     }
   }
-  if (lat_bytes) {
-    rc = mfem_lat27_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr, V.w[0]);
-    if (rc) return rc;
-    MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
-    if (!mfem_lat27_bound(A, vals_work) && lat_only) {  // first refusal on this pattern: plan the other layouts and start over
-      A->lat_refused = 1;
-      return solve_inner(ctx, A, vals, b, x_out, o, stats);
-    }
-  }
-  if (sell_bytes && !mfem_lat27_bound(A, vals_work) && !lat8_bound) {
+  if (sell_bytes && !lat8_bound) {
     rc = mfem_sell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), fused_scale ? V.d : nullptr);
     if (rc) return rc;
     if (fused_scale && !A->sell_vals) {

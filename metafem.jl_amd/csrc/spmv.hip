@@ -1044,7 +1044,7 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   ProfScope prof{ctx, -1};
   int rc = prof.begin();
   if (rc) return rc;
-  if (mfem_lat8_bound(A, vals)) {  // the lattice tiles do not split into interior / boundary rows: exchange, then one SpMV
+  if (mfem_lat8_bound(A, vals) || mfem_lat27_bound(A, vals)) {  // the lattice tiles do not split into interior / boundary rows: exchange, then one SpMV
     rc = mfem_comm_halo_begin(ctx, x);
     if (rc) return rc;
     rc = mfem_comm_halo_end(ctx);

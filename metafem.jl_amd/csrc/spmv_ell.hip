@@ -1770,11 +1770,9 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
   MFEM_REQUIRE(ctx && A, "null handle");
   int rc = MFEM_OK, m = 0;
   // the lattice-tile layouts are looked at first: where they apply, the others are planned only on demand (krylov.hip)
-  if (!ctx->comm) {
-    rc = mfem_lat27_plan(ctx, A);
-    if (rc) return rc;
-    if (mfem_lat27_bytes(A)) m = 4;
-  }
+  rc = mfem_lat27_plan(ctx, A);
+  if (rc) return rc;
+  if (mfem_lat27_bytes(A)) m = 4;
   if (m == 0) {
     rc = mfem_lat8_plan(ctx, A);
     if (rc) return rc;
@@ -1807,12 +1805,9 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   int rc = MFEM_OK;
   bool bound = false;
   {  // lattice tiles, if the structure allows them and these values are symmetric
-    size_t lb = 0;
-    if (!ctx->comm) {
-      rc = mfem_lat27_plan(ctx, A);
-      if (rc) return rc;
-      lb = mfem_lat27_bytes(A);
-    }
+    rc = mfem_lat27_plan(ctx, A);
+    if (rc) return rc;
+    size_t lb = mfem_lat27_bytes(A);
     const bool is27 = lb != 0;
     if (!lb) {
       rc = mfem_lat8_plan(ctx, A);

@@ -54,11 +54,22 @@ extern "C" int mfem_debug_set_lat27(int enable) {
 }
 
 struct Lat27Geom {
-  int m0, m1, m2;     // lattice points per direction (odd)
+  int m0, m1, m2;     // OWNED lattice points per direction (m0 = owned planes of a slab; m1, m2 odd)
   int nui, nuj, nuk;  // units of 4 x 4 x 8 points
   int nti, ntj, ntk;  // tiles of 8 x 8 x 32 points
-  int64_t n;
+  int64_t n;          // m0 * m1 * m2 owned rows
+  // slab: the owned planes are [plo, plo + m0) (plo even: slabs are cut on element boundaries) of a lattice of mg planes; x carries, behind the n
+  // owned entries, a low and a high block of gw = 2 ghost planes (brick_xindex); plo = 0, mg = m0 for a whole brick
+  int plo, mg, gw;
 };
+// local x index at GLOBAL plane gi (owned or ghost), in-plane position ip
+__device__ __forceinline__ int64_t l27_xindex(const Lat27Geom& G, int gi, int64_t ip) {
+  const int64_t PL = (int64_t)G.m1 * G.m2;
+  if (gi >= G.plo && gi < G.plo + G.m0) return (int64_t)(gi - G.plo) * PL + ip;
+  const int side = gi < G.plo ? 0 : 1;
+  const int off = side ? gi - (G.plo + G.m0) : gi - (G.plo - G.gw);
+  return G.n + ((int64_t)side * G.gw + off) * PL + ip;
+}
 
 // type t = 4 (i odd) + 2 (j odd) + (k odd); steps per lane K4, stored slots Kup, group base inside a unit (doubles), table base (entries)
 __constant__ int c_l27_Kup[8];
@@ -130,11 +141,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_verify(Lat27Geom G, const RP
   const int64_t PL = (int64_t)G.m1 * G.m2;
   int fail = 0;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < G.n; r += stride) {
-    const int gi = (int)(r / PL);
-    const int64_t rem = r - gi * PL;
+    const int gi = (int)(r / PL) + G.plo;  // global plane
+    const int64_t rem = r % PL;
     const int gj = (int)(rem / G.m2), gk = (int)(rem - (int64_t)gj * G.m2);
     int li, ni, lj, nj, lk, nk;
-    l27_range(gi, G.m0, li, ni);
+    l27_range(gi, G.mg, li, ni);
     l27_range(gj, G.m1, lj, nj);
     l27_range(gk, G.m2, lk, nk);
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_verify(Lat27Geom G, const RP
     int64_t j = lo;
     for (int a = 0; a < ni; ++a)
       for (int b = 0; b < nj; ++b) {
-        const int64_t c0 = r + (int64_t)(li + a) * PL + (int64_t)(lj + b) * G.m2 + lk;
+        const int64_t c0 = l27_xindex(G, gi + li + a, (int64_t)(gj + lj + b) * G.m2 + gk + lk);
         for (int c = 0; c < nk; ++c, ++j)
           if ((int64_t)col[j] - base != c0 + c) fail = 1;
       }
@@ -171,13 +182,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
     const int uj = (int)(u2 % G.nuj), ui = (int)(u2 / G.nuj);
     double* ou = out + u * L27_UNIT_D;
     for (int t = 0; t < 8; ++t) {
-      const int gi = ui * 4 + ((t >> 2) & 1) + 2 * ra, gj = uj * 4 + ((t >> 1) & 1) + 2 * rb, gk = uk * 8 + (t & 1) + 2 * rc;
-      const bool valid = gi < G.m0 && gj < G.m1 && gk < G.m2;
-      const int64_t r = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+      const int oi = ui * 4 + ((t >> 2) & 1) + 2 * ra, gj = uj * 4 + ((t >> 1) & 1) + 2 * rb, gk = uk * 8 + (t & 1) + 2 * rc;  // oi: owned plane
+      const int gi = oi + G.plo;
+      const bool valid = oi < G.m0 && gj < G.m1 && gk < G.m2;
+      const int64_t r = ((int64_t)oi * G.m1 + gj) * G.m2 + gk;
       int li = 0, ni = 1, lj = 0, nj = 1, lk = 0, nk = 1;
       int64_t rp = 0;
       if (valid) {
-        l27_range(gi, G.m0, li, ni);
+        l27_range(gi, G.mg, li, ni);
         l27_range(gj, G.m1, lj, nj);
         l27_range(gk, G.m2, lk, nk);
         rp = (int64_t)rowptr[r] - base;
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
         for (int h = 0; h < 2; ++h) {
           const int di = c_l27_d[tb + it + h][0], dj = c_l27_d[tb + it + h][1], dk = c_l27_d[tb + it + h][2];
           const int ci = gi + di, cj = gj + dj, ck = gk + dk;
-          if (valid && di != L27_PAD && ci < G.m0 && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {
+          if (valid && di != L27_PAD && ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (ci may be a ghost plane of a slab)
             const double v = vals[rp + ((int64_t)(di - li) * nj + (dj - lj)) * nk + (dk - lk)];
             double av = fabs(v);
             if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
@@ -373,10 +385,10 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double
   const int i0 = ti * L27_TI, j0 = tj * L27_TJ - 2, k0 = tk * L27_TK - 2;
   for (int e = tid; e < L27_LDS_CELLS; e += 512) {
     const int li = e / L27_PI, r2 = e - li * L27_PI, lj = r2 / L27_SK, lk = r2 - lj * L27_SK;
-    const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+    const int gi = G.plo + i0 + li, gj = j0 + lj, gk = k0 + lk;  // global plane: the two planes behind the last owned one are ghost planes
     double xv = 0.0;
-    if (lj < L27_SJ && gi < G.m0 && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
-      const int64_t r = ((int64_t)gi * G.m1 + gj) * G.m2 + gk;
+    if (lj < L27_SJ && gi < G.mg && gi < G.plo + G.m0 + G.gw && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
+      const int64_t r = l27_xindex(G, gi, (int64_t)gj * G.m2 + gk);
       xv = dsc ? x[r] / dsc[r] : x[r];
     }
     xs[e] = xv;
@@ -399,9 +411,14 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double
 
 // pass 2: y[r] = alpha * (sum over the tiles whose block covers r, fixed order) + beta * y[r]; fused dot with dotw.  A thread owns a
 // (j, k) position of the tile and its 8 lattice planes: 8 independent loads per covering tile.
+// Slab with a lower neighbour (G.plo > 0): the rows of the first owned plane (an even plane: reach 2) also have entries towards the two ghost planes
+// below.  No stored entry mirrors onto them (the rows that would belong to the neighbour rank), so they are taken from the caller's CSR values here.
+template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather(Lat27Geom G, const double* __restrict__ dump, double* __restrict__ y,
                                                                double alpha, double beta, const double* __restrict__ dotw,
-                                                               double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+                                                               double* __restrict__ partials, const int32_t* __restrict__ done_flag,
+                                                               const RP* __restrict__ rowptr, int base, const double* __restrict__ csr_vals,
+                                                               const double* __restrict__ x, const double* __restrict__ dsc) {
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
   double dot_acc = 0.0;
@@ -431,6 +448,20 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather(Lat27Geom G, const 
         for (int u = 0; u < L27_TI; ++u) s[u] += d[u * PC];
       }
     }
+    if (G.plo > 0 && ti == 0) {  // the lower ghost planes (see above): the first two of the row's five i-offsets
+      int l1, n1, l2, n2;
+      l27_range(gj, G.m1, l1, n1);
+      l27_range(gk, G.m2, l2, n2);
+      const int64_t rp = (int64_t)rowptr[(int64_t)gj * G.m2 + gk] - base;
+      double acc = 0.0;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < n1; ++b)
+          for (int c = 0; c < n2; ++c) {
+            const int64_t xi = l27_xindex(G, G.plo - 2 + a, (int64_t)(gj + l1 + b) * G.m2 + gk + l2 + c);
+            acc += csr_vals[rp + ((int64_t)a * n1 + b) * n2 + c] * (dsc ? x[xi] / dsc[xi] : x[xi]);
+          }
+      s[0] += acc;
+    }
 #pragma unroll
     for (int u = 0; u < L27_TI; ++u) {
       if (gi0 + u < G.m0) {
@@ -454,6 +485,9 @@ static Lat27Geom lat27_geom(const mfem_csr_s* A) {
   G.m2 = A->lat_m2;
   G.n = A->n;
   G.m0 = (int)(A->n / ((int64_t)A->lat_m1 * A->lat_m2));
+  G.plo = A->lat_plo;
+  G.mg = A->lat_m0 > 0 ? A->lat_m0 : G.m0;
+  G.gw = 2;
   G.nui = (G.m0 + 3) / 4;
   G.nuj = (G.m1 + 3) / 4;
   G.nuk = (G.m2 + 7) / 8;
@@ -469,11 +503,18 @@ int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
   A->lat27_state = -1;
   if (A->lat_fields != 1 || A->lat_m1 < 3 || A->lat_m2 < 3 || !(A->lat_m1 & 1) || !(A->lat_m2 & 1)) return MFEM_OK;
-  if (A->ncols > A->n) return MFEM_OK;  // slab patterns (ghost columns) keep the sliced layout
   const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2;
   if (A->n % PL != 0) return MFEM_OK;
   const int64_t m0 = A->n / PL;
-  if (m0 < 3 || !(m0 & 1) || m0 > (1 << 20) || A->max_row_nnz > 125) return MFEM_OK;
+  if (m0 < 1 || m0 > (1 << 20) || A->max_row_nnz > 125) return MFEM_OK;
+  if (A->ncols > A->n) {  // slab pattern (ghost columns): the hint must place the owned planes in the lattice (on element boundaries) and describe the ghost blocks
+    if (A->lat_m0 < 3 || !(A->lat_m0 & 1) || A->lat_gw != 2 || A->lat_plo < 0 || (A->lat_plo & 1) || A->lat_plo + m0 > A->lat_m0 ||
+        A->ncols != A->n + 4 * PL)
+      return MFEM_OK;
+  } else {
+    if (m0 < 3 || !(m0 & 1)) return MFEM_OK;
+    if (A->lat_m0 > 0 && (A->lat_m0 != m0 || A->lat_plo != 0)) return MFEM_OK;
+  }
   int rc = lat27_upload_tables();
   if (rc) return rc;
   const Lat27Geom G = lat27_geom(A);
@@ -574,8 +615,12 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;
-  hipLaunchKernelGGL(k_lat27_gather, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials,
-                     done_flag);
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_lat27_gather<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials,
+                       done_flag, (const int64_t*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc);
+  else
+    hipLaunchKernelGGL(k_lat27_gather<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials,
+                       done_flag, (const int32_t*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc);
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   if (!mfem_probe_active) ++g_lat27_count;

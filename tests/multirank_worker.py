@@ -154,6 +154,7 @@ def main():
     tol_classic = 1e-11 if F == 3 else 1e-12
     sym0 = int(_lib.lib.mfem_debug_sym_spmv_count())
     lat8_0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+    lat27_0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
     for overlap in (1, 0):
         _lib.lib.mfem_debug_set_halo_overlap(overlap)
         tag = "overlap" if overlap else "blocking"
@@ -175,6 +176,8 @@ def main():
         check("symmetric_sweep_kernel_ran", int(_lib.lib.mfem_debug_sym_spmv_count()) > sym0)
     if case == "elasticity_hex8":  # the slab solves ran on the symmetric lattice tiles (mode 5: ghost planes staged, lower-ghost terms from the CSR values)
         check("lattice_tiles_ran_on_the_slab", int(_lib.lib.mfem_debug_lat8_spmv_count()) > lat8_0)
+    if case == "thermal_hex27":  # (mode 4: two ghost planes per side)
+        check("lattice_tiles_ran_on_the_slab", int(_lib.lib.mfem_debug_lat27_spmv_count()) > lat27_0)
     for sv, name, s_par in ((mf.bicgstabl_GS_, "bicgstabl2", 2), (mf.idrs_, "idrs8", 8)):
         for pr, pname in ((mf.Pr_Jacobi_, "diag"), (mf.Pr_Jacobi_colnorm_, "colnorm")):
             xg, sg = gsolve(sv, s=s_par, Pr_func=pr)

@@ -134,17 +134,40 @@ def test_a_solve_whose_values_are_refused_starts_over_on_the_other_layouts(mf, s
     assert np.abs(sols[0] - sols[1]).max() <= 1e-3 * np.abs(sols[0]).max()   # (a 1e-6 perturbation of one entry)
 
 
+@pytest.mark.parametrize("lo,hi", [(0, 6), (6, 14), (14, 21), (8, 10), (2, 12)])
+def test_spmv_on_slabs_equals_the_csr_kernel(mf, small_layouts, lo, hi):
+    """Slabs of a 10 x 6 x 5 hex-27 brick (21 lattice planes; slabs start on element boundaries = even planes): x carries a low and a high block of
+    two ghost planes.  Entries towards the upper ghost planes are stored entries, those of the first owned plane towards the two lower ghost planes
+    come from the CSR values in the second pass."""
+    import torch
+    from metafem_jl_amd import parallel as par
+
+    _lib = small_layouts
+    n = (10, 6, 5)
+    sb = mf.make_Brick((2.0, 1.0, 1.0), n, 2, 5)
+    sb.set_slab(lo, hi)
+    A = sb.pattern(1)
+    K = sb.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    assert _mode(sb, A) == 4
+    nloc = par.local_vector_length(lo, hi, 2 * n[1] + 1, 2 * n[2] + 1, 1, order=2)
+    assert nloc == A.ncols
+    x = mf.FEM_rand(nloc, 3, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+    c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(sb.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+    assert int(_lib.lib.mfem_debug_lat27_spmv_count()) == c0 + 1
+    assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+
+
 def test_patterns_that_only_look_like_the_lattice_are_refused(mf, small_layouts):
-    """The lattice hint of mfem_brick_pattern only proposes the layout: hex-8 (order 1) and the 3-field pattern keep their layouts, and a
-    slab pattern with ghost columns keeps the sliced one."""
+    """The lattice hint of mfem_brick_pattern only proposes the layout: hex-8 (order 1) and the 3-field pattern keep their layouts."""
     _lib = small_layouts
     b8 = mf.make_Brick((1.0, 1.0, 1.0), (7, 7, 7))  # 8^3 points: even counts
     assert _mode(b8, b8.pattern(1)) != 4
     b27 = mf.make_Brick((1.0, 1.0, 1.0), (5, 4, 4), 2, 5)
     assert _mode(b27, b27.pattern(3)) != 4
-    sb = mf.make_Brick((2.0, 1.0, 1.0), (10, 6, 6), 2, 5)
-    sb.set_slab(6, 14)
-    assert _mode(sb, sb.pattern(1)) == 3
     # order-1 lattice with odd point counts (the hint alone cannot tell it from order 2): refused by the entry-by-entry check
     b1 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
     assert _mode(b1, b1.pattern(1)) != 4

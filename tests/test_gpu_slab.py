@@ -249,6 +249,7 @@ def test_solver_layout_spmv_on_hex27_slabs(mf, lo, hi):
     x = mf.FEM_rand(nloc, 3, 0) - 0.5
     mode = C.c_int32()
     _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    _lib.lib.mfem_debug_set_lat27(0)  # (slabs on element boundaries would take the lattice tiles: tests/test_gpu_lat27.py)
     try:
         _lib.check(_lib.lib.mfem_csr_solver_layout(sb.ctx._h, A._h, C.byref(mode), None, None, None))
         assert mode.value == 3
@@ -258,4 +259,5 @@ def test_solver_layout_spmv_on_hex27_slabs(mf, lo, hi):
         _lib.check(_lib.lib.mfem_spmv_solver_layout(sb.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
         assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
     finally:
+        _lib.lib.mfem_debug_set_lat27(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
