@@ -42,6 +42,14 @@ for _ in range(L):
 for _ in range(3):
     mf.axpby_(0.5, x, 0.25, y)  # calibration: 2 n doubles read, n written
 solve()
+# C3 / C4: the same solve once more on the layouts the lattice tiles replaced (modes 2 / 3), so that one pass prices both kernels
+from metafem_jl_amd import _lib
+if cfg in ("c3", "c4"):
+    _lib.lib.mfem_debug_set_lat27(0)
+    _lib.lib.mfem_debug_set_lat8(0)
+    solve()
+    _lib.lib.mfem_debug_set_lat27(1)
+    _lib.lib.mfem_debug_set_lat8(1)
 torch.cuda.synchronize()
 byts, cols = A.spmv_bytes()
 print("LEG", leg, "n", A.n, "nnz", A.nnz, "csr_design_bytes", byts, "cols_read", cols)
