@@ -131,6 +131,43 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* 
 }
 
 // The layout pass: a wave per unit, lane = node.  stats[1] = max |a| over the stored entries (bit pattern).
+// The steps of a unit are compile-time constants here too (template recursion): the entries of one row field are requested back to back (a lane's
+// three runs of 13 - 14 consecutive CSR entries: each cache line is touched while it is still in flight), then leave as 16-byte stores.
+struct L8Row {  // what a lane knows about its node
+  bool valid;
+  int gi, gj, gk, li, lj, lk, nj, nk, cnt;
+  int64_t rp[3];
+};
+template <int S, int SEND>
+__device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* v /* [SEND - S0] */, double& amax) {
+  if constexpr (S < SEND) {
+    double val = 0.0;
+    if constexpr (S < 123) {
+      constexpr int f = l8_row_field(S), g = l8_g(S), e = l8_e(S);
+      constexpr int di = l8_di(e), dj = l8_dj(e), dk = l8_dk(e);
+      const int ci = R.gi + di, cj = R.gj + dj, ck = R.gk + dk;
+      if (R.valid && ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (the neighbour may sit in a ghost plane: its x comes from the ghost block)
+        val = vals[R.rp[f] + (int64_t)g * R.cnt + ((di - R.li) * R.nj + (dj - R.lj)) * R.nk + (dk - R.lk)];
+        double av = fabs(val);
+        if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
+        amax = fmax(amax, av);
+      }
+    }
+    v[0] = val;
+    l8_fetch<S + 1, SEND>(R, G, vals, v + 1, amax);
+  }
+}
+// steps [S0, S0 + 2 NP) from v to their places: pair k at doubles ((S0 / 2 + k) * 64 + lane) * 2
+template <int S0, int NP>
+__device__ __forceinline__ void l8_put(double* __restrict__ ou, const double* v) {
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    m_d2 pr;
+    pr.x = v[2 * k];
+    pr.y = v[2 * k + 1];
+    *(m_d2*)(ou + (int64_t)(S0 / 2 + k) * 128) = pr;
+  }
+}
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __restrict__ rowptr, int base, const double* __restrict__ vals,
                                                           double* __restrict__ out, unsigned long long* __restrict__ stats) {
@@ -144,41 +181,43 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
     const int uk = (int)(u % G.nuk);
     const int64_t u2 = u / G.nuk;
     const int uj = (int)(u2 % G.nuj), ui = (int)(u2 / G.nuj);
-    const int oi = ui * 4 + la, gj = uj * 4 + lb, gk = uk * 4 + lc;  // oi: owned plane
-    const int gi = oi + G.plo;
-    const bool valid = oi < G.m0 && gj < G.m1 && gk < G.m2;
-    const int64_t p = ((int64_t)oi * G.m1 + gj) * G.m2 + gk;
-    int li = 0, ni = 1, lj = 0, nj = 1, lk = 0, nk = 1;
-    if (valid) {
-      l8_range(gi, G.mg, li, ni);
-      l8_range(gj, G.m1, lj, nj);
-      l8_range(gk, G.m2, lk, nk);
-    }
-    const int cnt = ni * nj * nk;
-    double* ou = out + u * L8_UNIT_D + lane * 2;
-    int64_t rp[3] = {0, 0, 0};
-    if (valid)
-      for (int f = 0; f < 3; ++f) rp[f] = (int64_t)rowptr[f * G.N + p] - base;
-    for (int s = 0; s < L8_STEPS; s += 2) {
-      m_d2 pr;
-      pr.x = 0.0;
-      pr.y = 0.0;
+    const int oi = ui * 4 + la;  // owned plane
+    L8Row R;
+    R.gi = oi + G.plo;
+    R.gj = uj * 4 + lb;
+    R.gk = uk * 4 + lc;
+    R.valid = oi < G.m0 && R.gj < G.m1 && R.gk < G.m2;
+    const int64_t p = ((int64_t)oi * G.m1 + R.gj) * G.m2 + R.gk;
+    int ni = 1;
+    R.li = R.lj = R.lk = 0;
+    R.nj = R.nk = 1;
+    R.rp[0] = R.rp[1] = R.rp[2] = 0;
+    if (R.valid) {
+      l8_range(R.gi, G.mg, R.li, ni);
+      l8_range(R.gj, G.m1, R.lj, R.nj);
+      l8_range(R.gk, G.m2, R.lk, R.nk);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int st = s + h;
-        if (st >= 123 || !valid) continue;
-        const int f = l8_row_field(st), g = l8_g(st), e = l8_e(st);
-        const int di = l8_di(e), dj = l8_dj(e), dk = l8_dk(e);
-        const int ci = gi + di, cj = gj + dj, ck = gk + dk;
-        if (ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (the neighbour may sit in a ghost plane: its x comes from the ghost block)
-          const double v = vals[rp[f] + (int64_t)g * cnt + ((di - li) * nj + (dj - lj)) * nk + (dk - lk)];
-          double av = fabs(v);
-          if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
-          amax = fmax(amax, av);
-          if (h) pr.y = v; else pr.x = v;
-        }
-      }
-      *(m_d2*)(ou + (int64_t)(s >> 1) * 128) = pr;
+      for (int f = 0; f < 3; ++f) R.rp[f] = (int64_t)rowptr[f * G.N + p] - base;
+    }
+    R.cnt = ni * R.nj * R.nk;
+    double* ou = out + u * L8_UNIT_D + lane * 2;
+    {  // row field 0: steps 0 .. 41
+      double v[42];
+      l8_fetch<0, 42>(R, G, vals, v, amax);
+      l8_put<0, 21>(ou, v);
+    }
+    double carry;
+    {  // row field 1: steps 42 .. 82 (the last one pairs with the first of field 2)
+      double v[41];
+      l8_fetch<42, 83>(R, G, vals, v, amax);
+      l8_put<42, 20>(ou, v);
+      carry = v[40];
+    }
+    {  // row field 2: steps 83 .. 122, and the padding step 123
+      double v[42];
+      v[0] = carry;
+      l8_fetch<83, 124>(R, G, vals, v + 1, amax);
+      l8_put<82, 21>(ou, v);
     }
   }
 #pragma unroll
