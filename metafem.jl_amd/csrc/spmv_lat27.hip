@@ -515,6 +515,12 @@ int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A) {
     if (m0 < 3 || !(m0 & 1)) return MFEM_OK;
     if (A->lat_m0 > 0 && (A->lat_m0 != m0 || A->lat_plo != 0)) return MFEM_OK;
   }
+  {  // cheap refusal before the entry-by-entry check: the longest row of the stencil is known from the lattice sizes (a hex-8 lattice with odd point
+     // counts carries the same hint: 27 against 125)
+    const int64_t mg = A->lat_m0 > 0 ? A->lat_m0 : m0;
+    auto w = [](int64_t m) { return m >= 5 ? 5 : 3; };
+    if (A->max_row_nnz != w(mg) * w(A->lat_m1) * w(A->lat_m2)) return MFEM_OK;
+  }
   int rc = lat27_upload_tables();
   if (rc) return rc;
   const Lat27Geom G = lat27_geom(A);

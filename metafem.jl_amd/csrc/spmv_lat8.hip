@@ -430,6 +430,11 @@ int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   } else if (A->lat_m0 > 0 && (A->lat_m0 != m0 || A->lat_plo != 0)) {
     return MFEM_OK;
   }
+  {  // cheap refusal before the entry-by-entry check: the longest row of the stencil is known from the lattice sizes
+    const int64_t mg = A->lat_m0 > 0 ? A->lat_m0 : m0;
+    auto w = [](int64_t m) { return m >= 3 ? 3 : (int)m; };
+    if (A->max_row_nnz != L8_F * w(mg) * w(A->lat_m1) * w(A->lat_m2)) return MFEM_OK;
+  }
   const Lat8Geom G = lat8_geom(A);
   if ((int64_t)G.nti * G.ntj * G.ntk >= ((int64_t)1 << 28)) return MFEM_OK;
   int32_t* d_bad = ctx->d_flags + 12;
