@@ -280,76 +280,54 @@ int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   return MFEM_OK;
 }
 
-// A unit's 68 steps run as 9 chunks (type 0 in two halves of 8 steps, then one chunk per type: 10, 10, 6, 10, 6, 6, 4 steps); the values of
-// chunk k + 1 are in flight while chunk k is worked through LDS (two register buffers that swap roles).
+// A unit's 68 steps run as 5 chunks of 16 / 10 / 10 / 16 / 16 steps (type 0; type 1; type 2; types 3 + 4; types 5 + 6 + 7: neighbours in the unit's
+// storage); the values of chunk k + 1 are in flight while chunk k is worked through LDS (two register buffers that swap roles; 9 smaller chunks left
+// 32 - 64 bytes per lane in flight, this keeps 80 - 128).
 template <int N>
-__device__ __forceinline__ void l27_load(l_d2 (&v)[5], const double* __restrict__ gv) {
+__device__ __forceinline__ void l27_load(l_d2 (&v)[8], const double* __restrict__ gv) {
 #pragma unroll
   for (int u = 0; u < N / 2; ++u) v[u] = __builtin_nontemporal_load((const l_d2*)gv + u * 64);
 }
 
-template <int N, bool DIAG>
-__device__ __forceinline__ void l27_proc(const l_d2 (&v)[5], const uint32_t* __restrict__ tq, int pos, int q, double xr, const double* xs,
-                                         double* ys, double& acc) {
+// N steps of one type from v[OFF ...] (OFF in 16-byte pairs)
+template <int N, int OFF>
+__device__ __forceinline__ void l27_proc(const l_d2 (&v)[8], const uint32_t* __restrict__ tq, int pos, int q, const double* xs, double* ys) {
   uint32_t w[N / 2];
 #pragma unroll
   for (int u = 0; u < N / 2; ++u) w[u] = tq[u];
+  const double xr = xs[pos];
+  double acc = 0.0;
 #pragma unroll
   for (int it = 0; it < N; ++it) {
     const int o = (it & 1) ? ((int)w[it >> 1] >> 16) : (int)(int16_t)(w[it >> 1] & 0xffffu);
-    const double a = (it & 1) ? v[it >> 1].y : v[it >> 1].x;
+    const double a = (it & 1) ? v[OFF + (it >> 1)].y : v[OFF + (it >> 1)].x;
     acc += a * xs[pos + o];
     double m = a * xr;
-    if (DIAG && it == 0) m = q == 0 ? 0.0 : m;  // slot 0 is the diagonal: nothing to mirror
+    if (it == 0) m = q == 0 ? 0.0 : m;  // slot 0 is the diagonal: nothing to mirror
     __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + pos + o), m);
   }
-}
-
-__device__ __forceinline__ void l27_finish(int pos, int q, double acc, double* ys) {
   acc += __shfl_xor(acc, 1, MFEM_WAVE);
   acc += __shfl_xor(acc, 2, MFEM_WAVE);
   if (q == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + pos), acc);
 }
 
-
 // on entry A holds the unit's first chunk; on exit B holds the first chunk of the unit at uv_next (if any)
-__device__ __forceinline__ void l27_unit(l_d2 (&A)[5], l_d2 (&B)[5], const double* __restrict__ uv, const double* __restrict__ uv_next,
+__device__ __forceinline__ void l27_unit(l_d2 (&A)[8], l_d2 (&B)[8], const double* __restrict__ uv, const double* __restrict__ uv_next,
                                          int p0, int q, const uint32_t* __restrict__ tabs, const double* xs, double* ys) {
   const int PI = L27_PI, PJ = L27_SK;
-  double acc = 0.0, xr = xs[p0];
-  l27_load<8>(B, uv + 512);
-  l27_proc<8, true>(A, tabs + q * 8, p0, q, xr, xs, ys, acc);
-  l27_load<10>(A, uv + 1024);
-  l27_proc<8, false>(B, tabs + q * 8 + 4, p0, q, xr, xs, ys, acc);
-  l27_finish(p0, q, acc, ys);
-  l27_load<10>(B, uv + 1664);
-  acc = 0.0; xr = xs[p0 + 1];
-  l27_proc<10, true>(A, tabs + 32 + q * 5, p0 + 1, q, xr, xs, ys, acc);
-  l27_finish(p0 + 1, q, acc, ys);
-  l27_load<6>(A, uv + 2304);
-  acc = 0.0; xr = xs[p0 + PJ];
-  l27_proc<10, true>(B, tabs + 52 + q * 5, p0 + PJ, q, xr, xs, ys, acc);
-  l27_finish(p0 + PJ, q, acc, ys);
-  l27_load<10>(B, uv + 2688);
-  acc = 0.0; xr = xs[p0 + PJ + 1];
-  l27_proc<6, true>(A, tabs + 72 + q * 3, p0 + PJ + 1, q, xr, xs, ys, acc);
-  l27_finish(p0 + PJ + 1, q, acc, ys);
-  l27_load<6>(A, uv + 3328);
-  acc = 0.0; xr = xs[p0 + PI];
-  l27_proc<10, true>(B, tabs + 84 + q * 5, p0 + PI, q, xr, xs, ys, acc);
-  l27_finish(p0 + PI, q, acc, ys);
-  l27_load<6>(B, uv + 3712);
-  acc = 0.0; xr = xs[p0 + PI + 1];
-  l27_proc<6, true>(A, tabs + 104 + q * 3, p0 + PI + 1, q, xr, xs, ys, acc);
-  l27_finish(p0 + PI + 1, q, acc, ys);
-  l27_load<4>(A, uv + 4096);
-  acc = 0.0; xr = xs[p0 + PI + PJ];
-  l27_proc<6, true>(B, tabs + 116 + q * 3, p0 + PI + PJ, q, xr, xs, ys, acc);
-  l27_finish(p0 + PI + PJ, q, acc, ys);
-  if (uv_next) l27_load<8>(B, uv_next);
-  acc = 0.0; xr = xs[p0 + PI + PJ + 1];
-  l27_proc<4, true>(A, tabs + 128 + q * 2, p0 + PI + PJ + 1, q, xr, xs, ys, acc);
-  l27_finish(p0 + PI + PJ + 1, q, acc, ys);
+  l27_load<10>(B, uv + 1024);
+  l27_proc<16, 0>(A, tabs + q * 8, p0, q, xs, ys);                     // type 0
+  l27_load<10>(A, uv + 1664);
+  l27_proc<10, 0>(B, tabs + 32 + q * 5, p0 + 1, q, xs, ys);            // type 1 (k odd)
+  l27_load<16>(B, uv + 2304);
+  l27_proc<10, 0>(A, tabs + 52 + q * 5, p0 + PJ, q, xs, ys);           // type 2 (j odd)
+  l27_load<16>(A, uv + 3328);
+  l27_proc<6, 0>(B, tabs + 72 + q * 3, p0 + PJ + 1, q, xs, ys);        // type 3
+  l27_proc<10, 3>(B, tabs + 84 + q * 5, p0 + PI, q, xs, ys);           // type 4 (i odd)
+  if (uv_next) l27_load<16>(B, uv_next);
+  l27_proc<6, 0>(A, tabs + 104 + q * 3, p0 + PI + 1, q, xs, ys);       // type 5
+  l27_proc<6, 3>(A, tabs + 116 + q * 3, p0 + PI + PJ, q, xs, ys);      // type 6
+  l27_proc<4, 6>(A, tabs + 128 + q * 2, p0 + PI + PJ + 1, q, xs, ys);  // type 7
 }
 
 // pass 1: one workgroup per tile.  dump[tile][cell] = what the tile's stored entries contribute to y on its own cells and on the
@@ -378,8 +356,8 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double
   const bool e0 = uj < G.nuj && uk < G.nuk, e1 = e0 && ui + 1 < G.nui;
   const double* uv0 = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * L27_UNIT_D + lane * 2;
   const double* uv1 = uv0 + (int64_t)G.nuj * G.nuk * L27_UNIT_D;
-  l_d2 A[5], B[5];
-  if (e0) l27_load<8>(A, uv0);  // in flight while x is staged
+  l_d2 A[8], B[8];
+  if (e0) l27_load<16>(A, uv0);  // in flight while x is staged
   for (int e = tid; e < L27_TAB / 2; e += 512)
     tabs[e] = (uint32_t)(uint16_t)c_l27_off[2 * e] | ((uint32_t)(uint16_t)c_l27_off[2 * e + 1] << 16);
   const int i0 = ti * L27_TI, j0 = tj * L27_TJ - 2, k0 = tk * L27_TK - 2;
