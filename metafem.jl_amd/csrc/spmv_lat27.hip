@@ -25,6 +25,7 @@
 //   * y differs from the CSR kernel's by round-off (other summation order), and the order in which the waves of a workgroup add into
 //     an LDS cell is not fixed: results are reproducible to ~1e-16 relative, not bitwise (mfem_debug_set_lat27(0) selects the sliced layout).
 #include "blas1.h"
+#include "spmv_lat_tables.h"
 
 #define L27_TI 8
 #define L27_TJ 8
@@ -35,8 +36,6 @@
 #define L27_PI (L27_SJ * L27_SK + 8)                 // plane stride of the LDS blocks: 440 = 8 mod 16, so the 16 rows of a step (2 a PI + 2 b SK + 2 c) fall on 16 different bank pairs
 #define L27_LDS_CELLS ((L27_TI + 2) * L27_PI)
 #define L27_UNIT_D 4352                             // doubles per unit: 64 lanes x 68 steps
-#define L27_TAB 272                                 // table entries: 4 x (16 + 3 x 10 + 3 x 6 + 4)
-#define L27_PAD 127
 
 typedef double l_d2 __attribute__((ext_vector_type(2)));
 
@@ -75,9 +74,6 @@ __device__ __forceinline__ int64_t l27_xindex(const Lat27Geom& G, int gi, int64_
 __constant__ int c_l27_Kup[8];
 __constant__ int16_t c_l27_off[L27_TAB];   // [tb[t] + q * K4 + it]: LDS cell offset of slot it * 4 + q (0 for padding)
 __constant__ int8_t c_l27_d[L27_TAB][4];   // same index: (di, dj, dk) of the slot; di = L27_PAD for padding
-static const int h_l27_K4[8] = {16, 10, 10, 6, 10, 6, 6, 4};
-static const int h_l27_gb[8] = {0, 1024, 1664, 2304, 2688, 3328, 3712, 4096};
-static const int h_l27_tb[8] = {0, 64, 104, 144, 168, 208, 232, 256};
 __constant__ int c_l27_K4[8];
 __constant__ int c_l27_gb[8];
 __constant__ int c_l27_tb[8];
@@ -88,32 +84,14 @@ static int lat27_upload_tables() {
   int Kup[8];
   int16_t off[L27_TAB];
   int8_t d[L27_TAB][4];
-  memset(off, 0, sizeof(off));
-  for (int i = 0; i < L27_TAB; ++i) { d[i][0] = L27_PAD; d[i][1] = d[i][2] = d[i][3] = 0; }
-  for (int t = 0; t < 8; ++t) {
-    const int R[3] = {(t & 4) ? 1 : 2, (t & 2) ? 1 : 2, (t & 1) ? 1 : 2};
-    const int K4 = h_l27_K4[t];
-    int s = 0;
-    auto put = [&](int di, int dj, int dk) {
-      const int it = s / 4, q = s % 4, idx = h_l27_tb[t] + q * K4 + it;
-      off[idx] = (int16_t)(di * L27_PI + dj * L27_SK + dk);
-      d[idx][0] = (int8_t)di; d[idx][1] = (int8_t)dj; d[idx][2] = (int8_t)dk;
-      ++s;
-    };
-    put(0, 0, 0);  // slot 0: the diagonal
-    for (int di = 0; di <= R[0]; ++di)
-      for (int dj = -R[1]; dj <= R[1]; ++dj)
-        for (int dk = -R[2]; dk <= R[2]; ++dk)
-          if (di > 0 || dj > 0 || (dj == 0 && dk > 0)) put(di, dj, dk);
-    Kup[t] = s;
-    if (s > 4 * K4) return MFEM_ERR_INVALID;
-  }
+  if (!l27_build_tables(d, Kup)) return MFEM_ERR_INVALID;  // (spmv_lat_tables.h)
+  for (int i = 0; i < L27_TAB; ++i) off[i] = d[i][0] == L27_PAD ? (int16_t)0 : (int16_t)(d[i][0] * L27_PI + d[i][1] * L27_SK + d[i][2]);
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_l27_Kup), Kup, sizeof(Kup)) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_l27_off), off, sizeof(off)) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_l27_d), d, sizeof(d)) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_K4), h_l27_K4, sizeof(h_l27_K4)) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_gb), h_l27_gb, sizeof(h_l27_gb)) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_tb), h_l27_tb, sizeof(h_l27_tb)) != hipSuccess) {
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_K4), l27_K4, sizeof(l27_K4)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_gb), l27_gb, sizeof(l27_gb)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_l27_tb), l27_tb, sizeof(l27_tb)) != hipSuccess) {
     mfem_set_error("lattice-tile tables: hipMemcpyToSymbol failed");
     return MFEM_ERR_HIP;
   }

@@ -18,6 +18,7 @@
 //     the CSR kernel, mfem_sym_probe in spmv_lat27.hip, within 4e-13 of the largest entry; the diagonal-slotted layout serves the solve otherwise).  Results equal the CSR kernel's to round-off, not
 //     bitwise, and not bitwise from run to run (order of the LDS adds of different waves).  mfem_debug_set_lat8(0) switches the layout off.
 #include "blas1.h"
+#include "spmv_lat_tables.h"
 
 #define L8_F 3
 #define L8_TI 8
@@ -27,7 +28,7 @@
 #define L8_SK (L8_TK + 2)
 #define L8_PI (L8_SJ * L8_SK)            // 180
 #define L8_FC ((L8_TI + 1) * L8_PI)      // cells per field: 1620
-#define L8_STEPS 124                     // 42 + 41 + 40 stored steps + 1 padding step
+// (L8_STEPS = 124: 42 + 41 + 40 stored steps + 1 padding step, spmv_lat_tables.h)
 #define L8_UNIT_D (L8_STEPS * 64)
 
 typedef double m_d2 __attribute__((ext_vector_type(2)));
@@ -61,35 +62,7 @@ __device__ __forceinline__ int64_t l8_xindex(const Lat8Geom& G, int f, int gi, i
   return (int64_t)L8_F * G.N + ((int64_t)(f * 2 + side) * G.gw + off) * PL + ip;
 }
 
-// ---- the step list of a unit (compile-time) ---------------------------------------------------------------------------------
-// row field f: for g = 0..2: [the node's own block entry (f, g) if g >= f], then the 13 upper neighbours e = 1..13 (d = (0,0,1) .. (1,1,1))
-__host__ __device__ constexpr int l8_first(int f) { return f == 0 ? 0 : f == 1 ? 42 : 83; }
-__host__ __device__ constexpr int l8_row_field(int s) { return s < 42 ? 0 : s < 83 ? 1 : 2; }
-// (g, e) of step s; e = 0: the node itself
-__host__ __device__ constexpr int l8_g(int s) {
-  const int f = l8_row_field(s);
-  int t = s - l8_first(f);
-  for (int g = 0; g < 3; ++g) {
-    const int len = 13 + (g >= f ? 1 : 0);
-    if (t < len) return g;
-    t -= len;
-  }
-  return 0;
-}
-__host__ __device__ constexpr int l8_e(int s) {
-  const int f = l8_row_field(s);
-  int t = s - l8_first(f);
-  for (int g = 0; g < 3; ++g) {
-    const int own = g >= f ? 1 : 0;
-    const int len = 13 + own;
-    if (t < len) return own ? t : t + 1;
-    t -= len;
-  }
-  return 0;
-}
-__host__ __device__ constexpr int l8_di(int e) { return (e + 13) / 9 - 1; }
-__host__ __device__ constexpr int l8_dj(int e) { return ((e + 13) / 3) % 3 - 1; }
-__host__ __device__ constexpr int l8_dk(int e) { return (e + 13) % 3 - 1; }
+// ---- the step list of a unit (compile-time): spmv_lat_tables.h
 __host__ __device__ constexpr int l8_off(int e) { return l8_di(e) * L8_PI + l8_dj(e) * L8_SK + l8_dk(e); }
 
 // offsets a node at lattice coordinate g (of m) has along one direction: [lo, lo + cnt)

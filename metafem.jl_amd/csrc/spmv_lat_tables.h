@@ -1,0 +1,76 @@
+// Step / slot tables of the symmetric lattice-tile layouts (spmv_lat27.hip: mode 4, spmv_lat8.hip: mode 5).  Host + device:
+// tools/host_check_lat.cpp replays a product with them on the CPU (tests/test_host_checks.py).
+#pragma once
+#ifndef __HIPCC__
+#define __host__
+#define __device__
+#endif
+#include <stdint.h>
+
+// ---- mode 5: 3 fields on the 27-point stencil, lane = node.  The 123 steps of a unit (+ 1 padding step), wave-uniform:
+// row field f: for g = 0..2: [the node's own block entry (f, g) if g >= f], then the 13 upper neighbours e = 1..13 (d = (0,0,1) .. (1,1,1))
+#define L8_STEPS 124
+__host__ __device__ constexpr int l8_first(int f) { return f == 0 ? 0 : f == 1 ? 42 : 83; }
+__host__ __device__ constexpr int l8_row_field(int s) { return s < 42 ? 0 : s < 83 ? 1 : 2; }
+// (g, e) of step s; e = 0: the node itself
+__host__ __device__ constexpr int l8_g(int s) {
+  const int f = l8_row_field(s);
+  int t = s - l8_first(f);
+  for (int g = 0; g < 3; ++g) {
+    const int len = 13 + (g >= f ? 1 : 0);
+    if (t < len) return g;
+    t -= len;
+  }
+  return 0;
+}
+__host__ __device__ constexpr int l8_e(int s) {
+  const int f = l8_row_field(s);
+  int t = s - l8_first(f);
+  for (int g = 0; g < 3; ++g) {
+    const int own = g >= f ? 1 : 0;
+    const int len = 13 + own;
+    if (t < len) return own ? t : t + 1;
+    t -= len;
+  }
+  return 0;
+}
+__host__ __device__ constexpr int l8_di(int e) { return (e + 13) / 9 - 1; }
+__host__ __device__ constexpr int l8_dj(int e) { return ((e + 13) / 3) % 3 - 1; }
+__host__ __device__ constexpr int l8_dk(int e) { return (e + 13) % 3 - 1; }
+
+// ---- mode 4: the hex-27 lattice, 8 node types t = 4 (i odd) + 2 (j odd) + (k odd), four lanes per row, slot s = 4 it + q of lane q at step it.
+// Slot 0 is the diagonal, then the offsets with (di, dj, dk) > 0 in lexicographic order; reach 2 in an even direction, 1 in an odd one.
+#define L27_TAB 272  // table entries: 4 x (16 + 3 x 10 + 3 x 6 + 4)
+#define L27_PAD 127
+static const int l27_K4[8] = {16, 10, 10, 6, 10, 6, 6, 4};             // steps per lane
+static const int l27_gb[8] = {0, 1024, 1664, 2304, 2688, 3328, 3712, 4096};  // group base inside a unit (doubles)
+static const int l27_tb[8] = {0, 64, 104, 144, 168, 208, 232, 256};    // table base (entries); entry of (t, q, it) at tb[t] + q * K4[t] + it
+// d[idx] = (di, dj, dk, 0) of the slot, di = L27_PAD for padding; Kup[t] = stored slots of type t.  Returns false if a type does not fit its steps.
+inline bool l27_build_tables(int8_t (*d)[4], int* Kup) {
+  for (int i = 0; i < L27_TAB; ++i) {
+    d[i][0] = L27_PAD;
+    d[i][1] = d[i][2] = d[i][3] = 0;
+  }
+  for (int t = 0; t < 8; ++t) {
+    const int R[3] = {(t & 4) ? 1 : 2, (t & 2) ? 1 : 2, (t & 1) ? 1 : 2};
+    const int K4 = l27_K4[t];
+    int s = 0;
+    auto put = [&](int di, int dj, int dk) {
+      if (s < 4 * K4) {
+        const int it = s / 4, q = s % 4, idx = l27_tb[t] + q * K4 + it;
+        d[idx][0] = (int8_t)di;
+        d[idx][1] = (int8_t)dj;
+        d[idx][2] = (int8_t)dk;
+      }
+      ++s;
+    };
+    put(0, 0, 0);  // slot 0: the diagonal
+    for (int di = 0; di <= R[0]; ++di)
+      for (int dj = -R[1]; dj <= R[1]; ++dj)
+        for (int dk = -R[2]; dk <= R[2]; ++dk)
+          if (di > 0 || dj > 0 || (dj == 0 && dk > 0)) put(di, dj, dk);
+    Kup[t] = s;
+    if (s > 4 * K4) return false;
+  }
+  return true;
+}

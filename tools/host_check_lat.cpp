@@ -1,0 +1,146 @@
+// CPU check of the step / slot tables of the symmetric lattice-tile layouts (csrc/spmv_lat_tables.h; tests/test_host_checks.py).
+// A random symmetric matrix with the lattice stencil is multiplied twice: entry by entry (every stored entry of the full stencil), and the way the
+// kernels do it -- only the slots the tables list, each used for row r (a x[c]) and, unless it is the diagonal, mirrored onto row c (a x[r]).
+// If the tables list every unordered pair exactly once, the two products agree to round-off on every lattice size.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "spmv_lat_tables.h"
+
+static double rnd() { return (double)rand() / RAND_MAX - 0.5; }
+
+// ---- mode 4: one field, reach 2 in an even direction and 1 in an odd one
+static int check27(int m0, int m1, int m2) {
+  int8_t d[L27_TAB][4];
+  int Kup[8];
+  if (!l27_build_tables(d, Kup)) return printf("table build failed\n"), 1;
+  const int want[8] = {63, 38, 38, 23, 38, 23, 23, 14};
+  for (int t = 0; t < 8; ++t)
+    if (Kup[t] != want[t]) return printf("type %d: %d stored slots, expected %d\n", t, Kup[t], want[t]), 1;
+  const long n = (long)m0 * m1 * m2;
+  auto id = [&](int i, int j, int k) { return ((long)i * m1 + j) * m2 + k; };
+  auto reach = [](int g) { return (g & 1) ? 1 : 2; };
+  std::map<std::pair<long, long>, double> A;  // symmetric values on the stencil pairs
+  for (int i = 0; i < m0; ++i)
+    for (int j = 0; j < m1; ++j)
+      for (int k = 0; k < m2; ++k)
+        for (int di = -reach(i); di <= reach(i); ++di)
+          for (int dj = -reach(j); dj <= reach(j); ++dj)
+            for (int dk = -reach(k); dk <= reach(k); ++dk) {
+              const int ci = i + di, cj = j + dj, ck = k + dk;
+              if (ci < 0 || ci >= m0 || cj < 0 || cj >= m1 || ck < 0 || ck >= m2) continue;
+              const long r = id(i, j, k), c = id(ci, cj, ck);
+              // (the stencil must be symmetric as a pattern: c reaches r as well)
+              if (std::abs(di) > reach(ci) || std::abs(dj) > reach(cj) || std::abs(dk) > reach(ck)) return printf("pattern not symmetric\n"), 1;
+              if (r <= c) A[{r, c}] = rnd();
+            }
+  std::vector<double> x(n), y0(n, 0.0), y1(n, 0.0);
+  for (auto& v : x) v = rnd();
+  for (auto& e : A) {
+    y0[e.first.first] += e.second * x[e.first.second];
+    if (e.first.first != e.first.second) y0[e.first.second] += e.second * x[e.first.first];
+  }
+  long used = 0;
+  for (int i = 0; i < m0; ++i)
+    for (int j = 0; j < m1; ++j)
+      for (int k = 0; k < m2; ++k) {
+        const int t = 4 * (i & 1) + 2 * (j & 1) + (k & 1), K4 = l27_K4[t];
+        const long r = id(i, j, k);
+        for (int q = 0; q < 4; ++q)
+          for (int it = 0; it < K4; ++it) {
+            const int8_t* o = d[l27_tb[t] + q * K4 + it];
+            if (o[0] == L27_PAD) continue;
+            const int ci = i + o[0], cj = j + o[1], ck = k + o[2];
+            if (ci >= m0 || cj < 0 || cj >= m1 || ck < 0 || ck >= m2) continue;  // outside the lattice: the kernels store 0 there
+            const long c = id(ci, cj, ck);
+            if (c < r) return printf("slot below the diagonal\n"), 1;
+            const auto f = A.find({r, c});
+            if (f == A.end()) return printf("slot off the stencil\n"), 1;
+            y1[r] += f->second * x[c];
+            if (!(it == 0 && q == 0)) y1[c] += f->second * x[r];
+            else if (c != r) return printf("slot 0 is not the diagonal\n"), 1;
+            ++used;
+          }
+      }
+  if (used != (long)A.size()) return printf("%ld slots used, %zu pairs\n", used, A.size()), 1;
+  double err = 0.0, scale = 0.0;
+  for (long r = 0; r < n; ++r) {
+    err = std::fmax(err, std::fabs(y0[r] - y1[r]));
+    scale = std::fmax(scale, std::fabs(y0[r]));
+  }
+  if (!(err <= 1e-13 * scale)) return printf("mode 4 on %d x %d x %d: error %.3e\n", m0, m1, m2, err / scale), 1;
+  return 0;
+}
+
+// ---- mode 5: three fields on the 27-point stencil, field-major
+static int check8(int m0, int m1, int m2) {
+  const long N = (long)m0 * m1 * m2, n = 3 * N;
+  auto id = [&](int f, int i, int j, int k) { return f * N + ((long)i * m1 + j) * m2 + k; };
+  std::map<std::pair<long, long>, double> A;
+  for (int f = 0; f < 3; ++f)
+    for (int i = 0; i < m0; ++i)
+      for (int j = 0; j < m1; ++j)
+        for (int k = 0; k < m2; ++k)
+          for (int g = 0; g < 3; ++g)
+            for (int di = -1; di <= 1; ++di)
+              for (int dj = -1; dj <= 1; ++dj)
+                for (int dk = -1; dk <= 1; ++dk) {
+                  const int ci = i + di, cj = j + dj, ck = k + dk;
+                  if (ci < 0 || ci >= m0 || cj < 0 || cj >= m1 || ck < 0 || ck >= m2) continue;
+                  const long r = id(f, i, j, k), c = id(g, ci, cj, ck);
+                  A[{r < c ? r : c, r < c ? c : r}] = 0.0;
+                }
+  for (auto& e : A) e.second = rnd();
+  std::vector<double> x(n), y0(n, 0.0), y1(n, 0.0);
+  for (auto& v : x) v = rnd();
+  for (auto& e : A) {
+    y0[e.first.first] += e.second * x[e.first.second];
+    if (e.first.first != e.first.second) y0[e.first.second] += e.second * x[e.first.first];
+  }
+  long used = 0;
+  int last[3] = {-1, -1, -1};
+  for (int s = 0; s < 123; ++s) {
+    const int f = l8_row_field(s);
+    if (s < l8_first(f) || l8_g(s) < 0 || l8_g(s) > 2 || l8_e(s) < 0 || l8_e(s) > 13) return printf("step %d malformed\n", s), 1;
+    last[f] = s;
+  }
+  if (last[0] != 41 || last[1] != 82 || last[2] != 122) return printf("field boundaries\n"), 1;
+  for (int i = 0; i < m0; ++i)
+    for (int j = 0; j < m1; ++j)
+      for (int k = 0; k < m2; ++k)
+        for (int s = 0; s < 123; ++s) {
+          const int f = l8_row_field(s), g = l8_g(s), e = l8_e(s);
+          const int ci = i + l8_di(e), cj = j + l8_dj(e), ck = k + l8_dk(e);
+          if (e == 0 && g < f) return printf("own-block slot below the diagonal\n"), 1;
+          if (ci >= m0 || cj < 0 || cj >= m1 || ck < 0 || ck >= m2) continue;
+          const long r = id(f, i, j, k), c = id(g, ci, cj, ck);
+          const auto it = A.find({r < c ? r : c, r < c ? c : r});
+          if (it == A.end()) return printf("step off the stencil\n"), 1;
+          y1[r] += it->second * x[c];
+          if (!(e == 0 && g == f)) y1[c] += it->second * x[r];
+          ++used;
+        }
+  if (used != (long)A.size()) return printf("%ld steps used, %zu pairs\n", used, A.size()), 1;
+  double err = 0.0, scale = 0.0;
+  for (long r = 0; r < n; ++r) {
+    err = std::fmax(err, std::fabs(y0[r] - y1[r]));
+    scale = std::fmax(scale, std::fabs(y0[r]));
+  }
+  if (!(err <= 1e-13 * scale)) return printf("mode 5 on %d x %d x %d: error %.3e\n", m0, m1, m2, err / scale), 1;
+  return 0;
+}
+
+int main() {
+  srand(12345);
+  const int s27[][3] = {{3, 3, 3}, {5, 3, 7}, {9, 5, 5}, {7, 11, 3}};
+  for (auto& s : s27)
+    if (check27(s[0], s[1], s[2])) return 1;
+  const int s8[][3] = {{1, 1, 1}, {2, 2, 2}, {3, 4, 5}, {6, 2, 7}, {1, 5, 4}};
+  for (auto& s : s8)
+    if (check8(s[0], s[1], s[2])) return 1;
+  printf("lattice-tile tables: every stencil pair listed exactly once, products agree\nOK\n");
+  return 0;
+}
