@@ -115,6 +115,7 @@ struct mfem_csr_s {
   int cw_R;
   int32_t lat_m1, lat_m2, lat_fields;  // lattice hint of a structured pattern (0 = none): points per lattice plane = lat_m1 * lat_m2 (brick.hip)
   int32_t lat_m0, lat_plo, lat_gw;     // ... planes of the whole lattice, first owned plane of a slab, ghost planes per side (0 = not given)
+  int32_t lat_inferred;                // the hint was read off row 0 of a caller-supplied pattern (mfem_lattice_from_first_row), not given by mfem_brick_pattern
   uint16_t* diag_off;       // owned, [n], built on first use: offset of the diagonal entry inside its row (0xFFFF = none stored): |diag| is then an
                             // n-sized gather instead of a scan of all nonzeros (Jacobi_By_Diagonal of every solve)
   // owned storage (mfem_brick_pattern) -- freed in destroy
@@ -191,6 +192,7 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
                           const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part);
 int64_t mfem_lat8_design_bytes(const mfem_csr_s* A);
 int64_t mfem_lat8_entries(const mfem_csr_s* A);
+int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A);  // proposes lat_* for a pattern without a hint (spmv_lat27.hip)
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
 int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles

@@ -851,6 +851,10 @@ static void csr_drop_plans(mfem_csr_s* A) {
   mfem_lat8_unbind(A);
   A->lat8_state = 0;
   A->lat_refused = 0;
+  if (A->lat_inferred) {  // (a hint read off the arrays goes with them)
+    A->lat_fields = A->lat_m0 = A->lat_m1 = A->lat_m2 = A->lat_plo = A->lat_gw = 0;
+    A->lat_inferred = 0;
+  }
   mfem_ell_free(A);
   mfem_sell_free(A);
   A->lat27_state = 0;

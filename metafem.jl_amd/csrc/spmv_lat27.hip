@@ -453,11 +453,74 @@ static Lat27Geom lat27_geom(const mfem_csr_s* A) {
   return G;
 }
 
+// A pattern without a lattice hint (lat_fields == 0, no ghost columns): propose one from the columns of row 0 -- the corner node of a lattice
+// numbered plane by plane, line by line -- for the two stencils the lattice-tile layouts know.  Only a proposal: the plans check every entry.
+//   hex-27, one field:      row 0 = 27 columns {a PL + b m2 + c : a, b, c in 0..2}  ->  m2 = col[3], PL = col[9]
+//   27-point, three fields: row 0 = 3 x 8 columns {g N + a PL + b m2 + c : a, b, c in 0..1}  ->  m2 = col[2], PL = col[4], N = col[8]
+// lat_fields = -1 afterwards if neither fits (so that the question is asked once per pattern).
+int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A) {
+  if (A->lat_fields != 0) return MFEM_OK;
+  A->lat_fields = -1;
+  A->lat_inferred = 1;
+  if (A->n < 8 || (A->ncols > A->n)) return MFEM_OK;
+  int64_t rp[2] = {0, 0};
+  if (A->rowptr_bits == 64) {
+    MFEM_CHECK_HIP(hipMemcpyAsync(rp, A->rowptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    int32_t r32[2];
+    MFEM_CHECK_HIP(hipMemcpyAsync(r32, A->rowptr, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    rp[0] = r32[0];
+    rp[1] = r32[1];
+  }
+  const int64_t len = rp[1] - rp[0];
+  if (len != 27 && len != 24) return MFEM_OK;
+  int32_t c[27];
+  MFEM_CHECK_HIP(hipMemcpyAsync(c, A->colidx + (rp[0] - A->index_base), (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < len; ++i) c[i] -= A->index_base;
+  if (c[0] != 0) return MFEM_OK;
+  if (len == 27) {
+    const int64_t m2 = c[3], PL = c[9];
+    if (m2 < 3 || PL < 3 * m2 || PL % m2 != 0 || A->n % PL != 0) return MFEM_OK;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        for (int k = 0; k < 3; ++k)
+          if (c[(a * 3 + b) * 3 + k] != a * PL + b * m2 + k) return MFEM_OK;
+    A->lat_fields = 1;
+    A->lat_m2 = (int32_t)m2;
+    A->lat_m1 = (int32_t)(PL / m2);
+    A->lat_m0 = (int32_t)(A->n / PL);
+    A->lat_plo = 0;
+    A->lat_gw = 2;
+  } else {
+    const int64_t m2 = c[2], PL = c[4], N = c[8];
+    if (m2 < 2 || PL < 2 * m2 || PL % m2 != 0 || N < 2 * PL || N % PL != 0 || A->n != 3 * N) return MFEM_OK;
+    for (int g = 0; g < 3; ++g)
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          for (int k = 0; k < 2; ++k)
+            if (c[g * 8 + (a * 2 + b) * 2 + k] != g * N + a * PL + b * m2 + k) return MFEM_OK;
+    A->lat_fields = 3;
+    A->lat_m2 = (int32_t)m2;
+    A->lat_m1 = (int32_t)(PL / m2);
+    A->lat_m0 = (int32_t)(N / PL);
+    A->lat_plo = 0;
+    A->lat_gw = 1;
+  }
+  return MFEM_OK;
+}
+
 // lat27_state: 0 not inspected, -1 not the lattice stencil, 1 structure ok
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->lat27_state != 0) return MFEM_OK;
   if (A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
   A->lat27_state = -1;
+  if (A->lat_fields == 0) {  // a caller-supplied pattern (mfem_csr_create: the reference's own K_J_ptr / K_J): read the lattice off row 0
+    int rc0 = mfem_lattice_from_first_row(ctx, A);
+    if (rc0) return rc0;
+  }
   if (A->lat_fields != 1 || A->lat_m1 < 3 || A->lat_m2 < 3 || !(A->lat_m1 & 1) || !(A->lat_m2 & 1)) return MFEM_OK;
   const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2;
   if (A->n % PL != 0) return MFEM_OK;

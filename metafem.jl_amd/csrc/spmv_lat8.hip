@@ -393,6 +393,10 @@ int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->lat8_state != 0) return MFEM_OK;
   if (A->n < g_layout_min_rows_dia) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
   A->lat8_state = -1;
+  if (A->lat_fields == 0) {  // a caller-supplied pattern: read the lattice off row 0 (spmv_lat27.hip)
+    int rc0 = mfem_lattice_from_first_row(ctx, A);
+    if (rc0) return rc0;
+  }
   if (A->lat_fields != L8_F || A->lat_m1 < 2 || A->lat_m2 < 2 || A->n % L8_F != 0) return MFEM_OK;
   const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2, N = A->n / L8_F;
   if (N % PL != 0) return MFEM_OK;

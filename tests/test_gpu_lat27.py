@@ -171,3 +171,30 @@ def test_patterns_that_only_look_like_the_lattice_are_refused(mf, small_layouts)
     # order-1 lattice with odd point counts (the hint alone cannot tell it from order 2): refused by the entry-by-entry check
     b1 = mf.make_Brick((1.0, 1.0, 1.0), (6, 6, 6))
     assert _mode(b1, b1.pattern(1)) != 4
+
+
+@pytest.mark.parametrize("rp_dtype,base", [("int32", 1), ("int64", 0)])
+def test_caller_supplied_csr_takes_the_lattice_tiles(mf, small_layouts, rp_dtype, base):
+    """The reference hands over its own K_J_ptr / K_J (1-based Int32, columns sorted; mfem_csr_create): no lattice hint comes with them.  The plan
+    reads the lattice off row 0, checks every entry, and the solve runs on the tiles; a pattern with one column moved does not."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (7, 5, 6), 2, 5)
+    A0 = b.pattern(1)
+    K = b.assemble_thermal(A0, K_COND, H, TENV, 0x3F)
+    rp = (A0.rowptr.clone() + base).to(getattr(torch, rp_dtype))
+    ci = (A0.colidx.clone() + base).to(torch.int32)
+    A = mf.FEM_SpMat_CSR(rp, ci, A0.n, base, ctx=b.ctx)
+    assert _mode(b, A) == 4
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+    x1, st = mf.iterative_Solve(A, K, rhs, 1e-11, Sv_func=mf.cg_, maxiter=3000, max_pass=2)
+    assert st.converged and int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0
+    x0, st0 = mf.iterative_Solve(A0, K, rhs, 1e-11, Sv_func=mf.cg_, maxiter=3000, max_pass=2)
+    assert float((x1 - x0).abs().max()) <= 1e-9 * float(x0.abs().max())
+    ci2 = ci.clone()
+    j = int(A0.nnz // 2)
+    ci2[j], ci2[j + 1] = ci[j + 1].item(), ci[j].item()  # two neighbouring columns of a middle row swapped: not the stencil order any more
+    A2 = mf.FEM_SpMat_CSR(rp, ci2, A0.n, base, ctx=b.ctx)
+    assert _mode(b, A2) != 4

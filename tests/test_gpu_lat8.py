@@ -163,3 +163,23 @@ def test_other_patterns_are_refused(mf, small_layouts):
     assert _mode(b, b.pattern(1)) != 5 and _mode(b, b.pattern(2)) != 5
     b27 = mf.make_Brick((1.0, 1.0, 1.0), (5, 4, 4), 2, 5)
     assert _mode(b27, b27.pattern(3)) != 5
+
+
+def test_caller_supplied_csr_takes_the_lattice_tiles(mf, small_layouts):
+    """1-based Int32 CSR of the 3-field matrix through mfem_csr_create (the reference's K_J_ptr / K_J): the lattice is read off row 0."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (9, 6, 7), 1, 3)
+    A0 = b.pattern(3)
+    K = b.assemble_elasticity(A0, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    rp = (A0.rowptr.clone() + 1).to(torch.int32)
+    ci = (A0.colidx.clone() + 1).to(torch.int32)
+    A = mf.FEM_SpMat_CSR(rp, ci, A0.n, 1, ctx=b.ctx)
+    assert _mode(b, A) == 5
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+    x1, st = mf.iterative_Solve(A, K, rhs, 1e-11, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=6000, max_pass=4)
+    assert st.converged and int(_lib.lib.mfem_debug_lat8_spmv_count()) > c0
+    x0, _ = mf.iterative_Solve(A0, K, rhs, 1e-11, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=6000, max_pass=4)
+    assert float((x1 - x0).abs().max()) <= 1e-8 * float(x0.abs().max())
