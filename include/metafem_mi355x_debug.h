@@ -49,7 +49,8 @@ double mfem_debug_lat27_asymmetry(mfem_csr A);
 int mfem_debug_set_lat8(int enable);
 long long mfem_debug_lat8_spmv_count(void);
 double mfem_debug_lat8_asymmetry(mfem_csr A);
-/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2, 1 000 000 for modes 1 and 3): smaller systems
+/* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2 -- and mode 5 --, 1 000 000 for modes 1 and 3; mode 4 from
+ * min(explicit_columns, 180 000) rows: profiles/r03_lat_tiles_thresholds.txt): smaller systems
  * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
 int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)

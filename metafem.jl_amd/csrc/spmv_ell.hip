@@ -30,10 +30,15 @@ __host__ __device__ __forceinline__ int64_t ell_base(int64_t r, int K) { return 
 // (tools/probe_ell.py, tools/probe_small_solve.py: crossover ~3e5 rows with diagonal slots, ~1e6 rows with explicit columns).
 int64_t g_layout_min_rows_dia = 262144;
 int64_t g_layout_min_rows_cols = 1000000;
+// hex-27 lattice tiles (spmv_lat27.hip): crossover against the CSR tile kernel + cycle graphs between 1.2e5 rows (41 / 45 us per CG iteration)
+// and 2.7e5 (70 / 54 us); at 9.1e5 rows 183 / 110 us (tools/probe_lat_threshold.py, profiles/r03_lat_tiles_thresholds.txt)
+#define LAT27_MIN_ROWS 180000
+int64_t g_layout_min_rows_lat27 = LAT27_MIN_ROWS;
 extern "C" int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns) {
   ++mfem_debug_epoch;
   g_layout_min_rows_dia = diagonal_slots;
   g_layout_min_rows_cols = explicit_columns;
+  g_layout_min_rows_lat27 = explicit_columns < LAT27_MIN_ROWS ? explicit_columns : LAT27_MIN_ROWS;
   return MFEM_OK;
 }
 

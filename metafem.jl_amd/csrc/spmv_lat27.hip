@@ -39,7 +39,7 @@
 
 typedef double l_d2 __attribute__((ext_vector_type(2)));
 
-extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
+extern int64_t g_layout_min_rows_lat27;  // spmv_ell.hip
 static int g_lat27_enable = 1;
 static long long g_lat27_count = 0;
 int mfem_probe_active = 0;  // set while mfem_sym_probe runs its two products: they are not SpMVs a solver asked for (the counters skip them)
@@ -515,7 +515,7 @@ int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A) {
 // lat27_state: 0 not inspected, -1 not the lattice stencil, 1 structure ok
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->lat27_state != 0) return MFEM_OK;
-  if (A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
+  if (A->n < g_layout_min_rows_lat27) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
   A->lat27_state = -1;
   if (A->lat_fields == 0) {  // a caller-supplied pattern (mfem_csr_create: the reference's own K_J_ptr / K_J): read the lattice off row 0
     int rc0 = mfem_lattice_from_first_row(ctx, A);
@@ -565,7 +565,7 @@ static size_t lat27_dump_doubles(const Lat27Geom& G) { return (size_t)G.nti * G.
 
 // workspace of the layout: the stored entries, then the per-tile y blocks
 size_t mfem_lat27_bytes(const mfem_csr_s* A) {
-  if (A->lat27_state != 1 || !g_lat27_enable || A->n < g_layout_min_rows_cols) return 0;
+  if (A->lat27_state != 1 || !g_lat27_enable || A->n < g_layout_min_rows_lat27) return 0;
   const Lat27Geom G = lat27_geom(A);
   return sizeof(double) * (lat27_vals_doubles(G) + lat27_dump_doubles(G));
 }
