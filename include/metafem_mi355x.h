@@ -107,9 +107,11 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
  *           kernel's (x in [0.75, 1.25): an entry pair that differs by delta shows up as >= 0.75 |delta|) and requires
  *           max |difference| <= 4e-13 max |A[r][c]| (mode 3 serves the solve otherwise).  y agrees with the CSR kernel to round-off (other summation order), not bitwise, and not
  *           bitwise from run to run.  A right Jacobi scaling (A D^-1) is applied to x while it is staged; the stored matrix stays A.
- *   mode 5  the same construction for the 3-field 27-point lattice matrix (hex-8 elasticity, field-major rows): lane = node, per node the 6
- *           upper entries of its own 3 x 3 block and the blocks towards its 13 upper neighbours (123 of 243 values), tiles of 8 x 8 x 16 nodes;
- *           mode 2 serves the solve if the values are not symmetric.
+ *   mode 5  the same construction for the F-field 27-point lattice matrix, F = 1..3 (hex-8; field-major rows; F = 3: elasticity): lane = node, per
+ *           node the upper entries of its own F x F block and the blocks towards its 13 upper neighbours (F = 3: 123 of 243 values; F = 1: 14
+ *           of 27), tiles of 8 x 8 x 16 nodes; mode 2 serves the solve if the values are not symmetric.  One field: only for the solvers that
+ *           work on A D^-1 (idrs!, bicgstabl_GS!, cgs2! with Pr_Jacobi!: the scaled copy mode 2 would make is not symmetric, so its mirrored
+ *           sweep cannot run); cg! keeps mode 2's bitwise patch sweep, and this query answers for cg!.
  * The copy is made once per solve from the caller's CSR-ordered values, like the reference's K_total[K_val_ids] gather
  * (02_Preconditioner.jl:35).  slots = padded row length, regular_rows = rows in diagonal-slotted blocks (mode 2). */
 int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,

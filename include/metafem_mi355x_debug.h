@@ -45,7 +45,8 @@ int mfem_debug_set_lat27(int enable);
 long long mfem_debug_lat27_spmv_count(void);
 /* max |layout x - CSR x| / max |A[r][c]| of the probe product of the last mode-4 bind on this pattern (mode 4 is taken up to 4e-13) */
 double mfem_debug_lat27_asymmetry(mfem_csr A);
-/* mode 5 (symmetric lattice tiles, 3-field 27-point matrix): the same three entry points */
+/* mode 5 (symmetric lattice tiles, F-field 27-point matrix): the same three entry points; bit 1 of `enable`: mfem_csr_solver_layout and
+ * mfem_spmv_solver_layout report / take mode 5 for ONE field too (they answer for cg!, which keeps mode 2 there) */
 int mfem_debug_set_lat8(int enable);
 long long mfem_debug_lat8_spmv_count(void);
 double mfem_debug_lat8_asymmetry(mfem_csr A);

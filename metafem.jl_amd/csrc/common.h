@@ -184,6 +184,7 @@ struct mfem_csr_s {
   int lat8_scaled;
 };
 int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A);
+bool mfem_lat8_for_method(const mfem_csr_s* A, bool is_cg);  // one-field matrices: only the solvers that work on A D^-1 (cg! keeps the bitwise patch sweep)
 size_t mfem_lat8_bytes(const mfem_csr_s* A);
 int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles
 void mfem_lat8_unbind(mfem_csr_s* A);

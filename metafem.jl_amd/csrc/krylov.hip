@@ -666,7 +666,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (!lat_bytes) {
       rc_plan = mfem_lat8_plan(ctx, A);
       if (rc_plan) return rc_plan;
-      lat8_bytes = mfem_lat8_bytes(A);
+      if (mfem_lat8_for_method(A, is_cg)) lat8_bytes = mfem_lat8_bytes(A);
     }
   }
   const bool lat_only = (lat_bytes || lat8_bytes) && !A->lat_refused;

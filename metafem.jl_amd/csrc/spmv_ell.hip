@@ -1781,7 +1781,7 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
   if (m == 0) {
     rc = mfem_lat8_plan(ctx, A);
     if (rc) return rc;
-    if (mfem_lat8_bytes(A)) m = 5;
+    if (mfem_lat8_bytes(A) && mfem_lat8_for_method(A, true)) m = 5;
   }
   if (m == 0) {
     rc = mfem_ell_plan(ctx, A);
@@ -1817,7 +1817,7 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     if (!lb) {
       rc = mfem_lat8_plan(ctx, A);
       if (rc) return rc;
-      lb = mfem_lat8_bytes(A);
+      if (mfem_lat8_for_method(A, true)) lb = mfem_lat8_bytes(A);
     }
     if (lb) {
       const size_t lay = (lb + 255) & ~(size_t)255;

@@ -456,7 +456,7 @@ static Lat27Geom lat27_geom(const mfem_csr_s* A) {
 // A pattern without a lattice hint (lat_fields == 0, no ghost columns): propose one from the columns of row 0 -- the corner node of a lattice
 // numbered plane by plane, line by line -- for the two stencils the lattice-tile layouts know.  Only a proposal: the plans check every entry.
 //   hex-27, one field:      row 0 = 27 columns {a PL + b m2 + c : a, b, c in 0..2}  ->  m2 = col[3], PL = col[9]
-//   27-point, three fields: row 0 = 3 x 8 columns {g N + a PL + b m2 + c : a, b, c in 0..1}  ->  m2 = col[2], PL = col[4], N = col[8]
+//   27-point, F = 1..3 fields: row 0 = F x 8 columns {g N + a PL + b m2 + c : a, b, c in 0..1}  ->  m2 = col[2], PL = col[4], N = col[8] (F > 1)
 // lat_fields = -1 afterwards if neither fits (so that the question is asked once per pattern).
 int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->lat_fields != 0) return MFEM_OK;
@@ -475,7 +475,7 @@ int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A) {
     rp[1] = r32[1];
   }
   const int64_t len = rp[1] - rp[0];
-  if (len != 27 && len != 24) return MFEM_OK;
+  if (len != 27 && len != 24 && len != 16 && len != 8) return MFEM_OK;
   int32_t c[27];
   MFEM_CHECK_HIP(hipMemcpyAsync(c, A->colidx + (rp[0] - A->index_base), (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -495,14 +495,16 @@ int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A) {
     A->lat_plo = 0;
     A->lat_gw = 2;
   } else {
-    const int64_t m2 = c[2], PL = c[4], N = c[8];
-    if (m2 < 2 || PL < 2 * m2 || PL % m2 != 0 || N < 2 * PL || N % PL != 0 || A->n != 3 * N) return MFEM_OK;
-    for (int g = 0; g < 3; ++g)
+    const int F = (int)(len / 8);
+    if (A->n % F != 0) return MFEM_OK;
+    const int64_t m2 = c[2], PL = c[4], N = F > 1 ? c[8] : A->n;
+    if (m2 < 2 || PL < 2 * m2 || PL % m2 != 0 || N < 2 * PL || N % PL != 0 || A->n != F * N) return MFEM_OK;
+    for (int g = 0; g < F; ++g)
       for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b)
           for (int k = 0; k < 2; ++k)
             if (c[g * 8 + (a * 2 + b) * 2 + k] != g * N + a * PL + b * m2 + k) return MFEM_OK;
-    A->lat_fields = 3;
+    A->lat_fields = F;
     A->lat_m2 = (int32_t)m2;
     A->lat_m1 = (int32_t)(PL / m2);
     A->lat_m0 = (int32_t)(N / PL);

@@ -1,5 +1,5 @@
-// Symmetric lattice-tile layout for the Krylov loop on the 3-field 27-point lattice matrix (hex-8 elasticity, field-major rows
-// row = field * N + node: cantilever/3D_Script.jl's system): solver layout mode 5.  The caller-facing contract stays CSR (mul!,
+// Symmetric lattice-tile layout for the Krylov loop on the F-field 27-point lattice matrix, F = 1..3 (hex-8; field-major rows
+// row = field * N + node; F = 3: linear elasticity, cantilever/3D_Script.jl's system): solver layout mode 5.  The caller-facing contract stays CSR (mul!,
 // misc/04_GPU_Utils.jl:131; iterative_Solve!, linear_solver/02_Preconditioner.jl:32-76).  Companion of spmv_lat27.hip (mode 4).
 //
 // The diagonal-slotted layout (mode 2) streams all 81 entries of a row.  The stiffness matrix is symmetric (the penalty and traction terms keep
@@ -20,7 +20,6 @@
 #include "blas1.h"
 #include "spmv_lat_tables.h"
 
-#define L8_F 3
 #define L8_TI 8
 #define L8_TJ 8
 #define L8_TK 16
@@ -28,30 +27,33 @@
 #define L8_SK (L8_TK + 2)
 #define L8_PI (L8_SJ * L8_SK)            // 180
 #define L8_FC ((L8_TI + 1) * L8_PI)      // cells per field: 1620
-// (L8_STEPS = 124: 42 + 41 + 40 stored steps + 1 padding step, spmv_lat_tables.h)
-#define L8_UNIT_D (L8_STEPS * 64)
 
 typedef double m_d2 __attribute__((ext_vector_type(2)));
 
 extern int64_t g_layout_min_rows_dia;  // spmv_ell.hip
 static int g_lat8_enable = 1;
+static int g_lat8_one_field_everywhere = 0;  // bit 1 of mfem_debug_set_lat8: the query / diagnostic SpMV entry also report and take mode 5 for ONE field
 static long long g_lat8_count = 0;
 extern "C" long long mfem_debug_lat8_spmv_count(void) { return g_lat8_count; }
 extern "C" double mfem_debug_lat8_asymmetry(mfem_csr A) { return A ? A->lat8_asym : -1.0; }
 extern "C" int mfem_debug_set_lat8(int enable) {
   ++mfem_debug_epoch;
   g_lat8_enable = enable & 1;
+  g_lat8_one_field_everywhere = (enable >> 1) & 1;
   return MFEM_OK;
 }
+// One field: cg! keeps the bitwise patch sweep of mode 2 (it moves the same bytes); the solvers that work on A D^-1 (idrs!, bicgstabl_GS!, cgs2!) cannot
+// use that sweep -- the scaled copy is not symmetric -- and take the tiles.  The layout query and the diagnostic SpMV entry answer for cg!.
+bool mfem_lat8_for_method(const mfem_csr_s* A, bool is_cg) { return A->lat_fields != 1 || !is_cg || g_lat8_one_field_everywhere; }
 
 struct Lat8Geom {
   int m0, m1, m2;     // OWNED nodes per direction (m0 = owned lattice planes of a slab)
   int nui, nuj, nuk;  // units of 4 x 4 x 4 nodes
   int nti, ntj, ntk;  // tiles of 8 x 8 x 16 nodes
   int64_t N;          // m0 * m1 * m2 owned nodes
-  // slab: the owned planes are [plo, plo + m0) of a lattice of mg planes; x carries, behind the 3 N owned entries, per field a low and a high
+  // slab: the owned planes are [plo, plo + m0) of a lattice of mg planes; x carries, behind the F N owned entries, per field a low and a high
   // block of gw ghost planes (brick_xindex); plo = 0, mg = m0 for a whole brick
-  int plo, mg, gw;
+  int plo, mg, gw, F;
 };
 // local x index of field f at GLOBAL plane gi (owned or ghost), in-plane position ip
 __device__ __forceinline__ int64_t l8_xindex(const Lat8Geom& G, int f, int gi, int64_t ip) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ int64_t l8_xindex(const Lat8Geom& G, int f, int gi, i
   if (gi >= G.plo && gi < G.plo + G.m0) return f * G.N + (int64_t)(gi - G.plo) * PL + ip;
   const int side = gi < G.plo ? 0 : 1;
   const int off = side ? gi - (G.plo + G.m0) : gi - (G.plo - G.gw);
-  return (int64_t)L8_F * G.N + ((int64_t)(f * 2 + side) * G.gw + off) * PL + ip;
+  return (int64_t)G.F * G.N + ((int64_t)(f * 2 + side) * G.gw + off) * PL + ip;
 }
 
 // ---- the step list of a unit (compile-time): spmv_lat_tables.h
@@ -71,13 +73,13 @@ __device__ __forceinline__ void l8_range(int g, int m, int& lo, int& cnt) {
   cnt = (g < m - 1 ? 1 : 0) - lo + 1;
 }
 
-// 1 in *bad if some row is not the 3-field stencil row: 3 x (present neighbours), columns field-major then lexicographic
+// 1 in *bad if some row is not the F-field stencil row: F x (present neighbours), columns field-major then lexicographic
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, int base,
                                                             int32_t* __restrict__ bad) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, PL = (int64_t)G.m1 * G.m2;
   int fail = 0;
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < L8_F * G.N; r += stride) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < G.F * G.N; r += stride) {
     const int64_t p = r % G.N;
     const int gi = (int)(p / PL) + G.plo;  // global plane
     const int64_t rem = p % PL;
@@ -87,12 +89,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* 
     l8_range(gj, G.m1, lj, nj);
     l8_range(gk, G.m2, lk, nk);
     const int64_t lo = (int64_t)rowptr[r] - base, hi = (int64_t)rowptr[r + 1] - base;
-    if (hi - lo != (int64_t)L8_F * ni * nj * nk) {
+    if (hi - lo != (int64_t)G.F * ni * nj * nk) {
       fail = 1;
       continue;
     }
     int64_t j = lo;
-    for (int g = 0; g < L8_F; ++g)
+    for (int g = 0; g < G.F; ++g)
       for (int a = 0; a < ni; ++a)
         for (int b = 0; b < nj; ++b) {
           const int64_t c0 = l8_xindex(G, g, gi + li + a, (int64_t)(gj + lj + b) * G.m2 + gk + lk);
@@ -105,18 +107,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_verify(Lat8Geom G, const RP* 
 
 // The layout pass: a wave per unit, lane = node.  stats[1] = max |a| over the stored entries (bit pattern).
 // The steps of a unit are compile-time constants here too (template recursion): the entries of one row field are requested back to back (a lane's
-// three runs of 13 - 14 consecutive CSR entries: each cache line is touched while it is still in flight), then leave as 16-byte stores.
+// F runs of 13 - 14 consecutive CSR entries: each cache line is touched while it is still in flight), then leave as 16-byte stores.
 struct L8Row {  // what a lane knows about its node
   bool valid;
   int gi, gj, gk, li, lj, lk, nj, nk, cnt;
   int64_t rp[3];
 };
-template <int S, int SEND>
-__device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* v /* [SEND - S0] */, double& amax) {
+template <int F, int S, int SEND>
+__device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* v, double& amax) {
   if constexpr (S < SEND) {
     double val = 0.0;
-    if constexpr (S < 123) {
-      constexpr int f = l8_row_field(S), g = l8_g(S), e = l8_e(S);
+    if constexpr (S < l8_nsteps(F)) {
+      constexpr int f = l8_row_field(F, S), g = l8_g(F, S), e = l8_e(F, S);
       constexpr int di = l8_di(e), dj = l8_dj(e), dk = l8_dk(e);
       const int ci = R.gi + di, cj = R.gj + dj, ck = R.gk + dk;
       if (R.valid && ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (the neighbour may sit in a ghost plane: its x comes from the ghost block)
@@ -127,7 +129,7 @@ __device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, cons
       }
     }
     v[0] = val;
-    l8_fetch<S + 1, SEND>(R, G, vals, v + 1, amax);
+    l8_fetch<F, S + 1, SEND>(R, G, vals, v + 1, amax);
   }
 }
 // steps [S0, S0 + 2 NP) from v to their places: pair k at doubles ((S0 / 2 + k) * 64 + lane) * 2
@@ -141,7 +143,25 @@ __device__ __forceinline__ void l8_put(double* __restrict__ ou, const double* v)
     *(m_d2*)(ou + (int64_t)(S0 / 2 + k) * 128) = pr;
   }
 }
-template <typename RP>
+// the steps of row field f: [first(f), first(f + 1)), the last field up to the padded end.  Pairs are (even, odd) steps: a field that starts on an
+// odd step takes the previous field's last value along (carry), one that ends on an even step (and is not the last) hands its last value on.
+template <int F, int f>
+__device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* __restrict__ ou, double& carry,
+                                              double& amax) {
+  if constexpr (f < F) {
+    constexpr int S0 = l8_first(F, f), S1 = (f == F - 1) ? l8_padded(F) : l8_first(F, f + 1);
+    constexpr int lead = S0 & 1;                 // one value carried in
+    constexpr int cnt = S1 - S0 + lead;          // values in v
+    constexpr int np = cnt / 2;                  // whole pairs
+    double v[cnt];
+    if constexpr (lead) v[0] = carry;
+    l8_fetch<F, S0, S1>(R, G, vals, v + lead, amax);
+    l8_put<S0 - lead, np>(ou, v);
+    if constexpr (cnt & 1) carry = v[cnt - 1];
+    l8_fill_field<F, f + 1>(R, G, vals, ou, carry, amax);
+  }
+}
+template <typename RP, int F>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __restrict__ rowptr, int base, const double* __restrict__ vals,
                                                           double* __restrict__ out, unsigned long long* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
@@ -170,28 +190,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
       l8_range(R.gj, G.m1, R.lj, R.nj);
       l8_range(R.gk, G.m2, R.lk, R.nk);
 #pragma unroll
-      for (int f = 0; f < 3; ++f) R.rp[f] = (int64_t)rowptr[f * G.N + p] - base;
+      for (int f = 0; f < F; ++f) R.rp[f] = (int64_t)rowptr[f * G.N + p] - base;
     }
     R.cnt = ni * R.nj * R.nk;
-    double* ou = out + u * L8_UNIT_D + lane * 2;
-    {  // row field 0: steps 0 .. 41
-      double v[42];
-      l8_fetch<0, 42>(R, G, vals, v, amax);
-      l8_put<0, 21>(ou, v);
-    }
-    double carry;
-    {  // row field 1: steps 42 .. 82 (the last one pairs with the first of field 2)
-      double v[41];
-      l8_fetch<42, 83>(R, G, vals, v, amax);
-      l8_put<42, 20>(ou, v);
-      carry = v[40];
-    }
-    {  // row field 2: steps 83 .. 122, and the padding step 123
-      double v[42];
-      v[0] = carry;
-      l8_fetch<83, 124>(R, G, vals, v + 1, amax);
-      l8_put<82, 21>(ou, v);
-    }
+    double carry = 0.0;
+    l8_fill_field<F, 0>(R, G, vals, out + u * (int64_t)(l8_padded(F) * 64) + lane * 2, carry, amax);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
@@ -206,49 +209,54 @@ __device__ __forceinline__ void l8_load(m_d2 (&v)[4], const double* __restrict__
   for (int u = 0; u < N / 2; ++u) v[u] = __builtin_nontemporal_load((const m_d2*)gv + u * 64);
 }
 
-// steps [S0 + I, S0 + N) of a unit from the register buffer v; x0..x2 = the lane's own x (3 fields), a0..a2 = its three row sums.  Everything about
+// steps [S0 + I, S0 + N) of a unit from the register buffer v; x0..x2 = the lane's own x (F fields), a0..a2 = its row sums.  Everything about
 // a step is a compile-time constant (template recursion, not a loop: the row sums must stay in registers).
-template <int S0, int I, int N>
+template <int F, int S0, int I, int N>
 __device__ __forceinline__ void l8_proc(const m_d2 (&v)[4], int pos, double x0, double x1, double x2, double& a0, double& a1, double& a2,
                                         const double* xs, double* ys) {
   if constexpr (I < N) {
     constexpr int s = S0 + I;
-    if constexpr (s < 123) {
-      constexpr int f = l8_row_field(s), g = l8_g(s), e = l8_e(s);
+    if constexpr (s < l8_nsteps(F)) {
+      constexpr int f = l8_row_field(F, s), g = l8_g(F, s), e = l8_e(F, s);
       constexpr int coff = g * L8_FC + l8_off(e);
       const double a = (I & 1) ? v[I >> 1].y : v[I >> 1].x;
       const double xr = f == 0 ? x0 : f == 1 ? x1 : x2;
       double& acc = f == 0 ? a0 : f == 1 ? a1 : a2;
       acc += a * xs[pos + coff];
       if constexpr (!(e == 0 && g == f)) L8_LDS_ADD(ys + pos + coff, a * xr);  // (the diagonal entry has no mirror)
-      if constexpr (s == 41 || s == 82 || s == 122) L8_LDS_ADD(ys + pos + f * L8_FC, acc);
+      if constexpr (s == l8_first(F, f + 1) - 1) L8_LDS_ADD(ys + pos + f * L8_FC, acc);  // the field's last step: its row sum is complete
     }
-    l8_proc<S0, I + 1, N>(v, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+    l8_proc<F, S0, I + 1, N>(v, pos, x0, x1, x2, a0, a1, a2, xs, ys);
   }
 }
 
-// chunk C (8 steps; the last one 4) from one buffer while chunk C + 1 -- or the first chunk of the next unit -- is loaded into the other
-template <int C>
+// chunk C (8 steps; the last one what is left) from one buffer while chunk C + 1 -- or the first chunk of the next unit -- is loaded into the other
+template <int F, int C>
 __device__ __forceinline__ void l8_run(m_d2 (&A)[4], m_d2 (&B)[4], const double* __restrict__ uv, const double* __restrict__ uv_next, int pos,
                                        double x0, double x1, double x2, double& a0, double& a1, double& a2, const double* xs, double* ys) {
-  if constexpr (C < 15) {
-    l8_load<(C + 1 == 15) ? 4 : 8>((C & 1) ? A : B, uv + (C + 1) * 512);
+  constexpr int NCH = (l8_padded(F) + 7) / 8, LAST = NCH - 1;
+  constexpr int nthis = (C == LAST) ? l8_padded(F) - 8 * LAST : 8;
+  if constexpr (C < LAST) {
+    constexpr int nnext = (C + 1 == LAST) ? l8_padded(F) - 8 * LAST : 8;
+    l8_load<nnext>((C & 1) ? A : B, uv + (C + 1) * 512);
   } else {
-    if (uv_next) l8_load<8>(A, uv_next);
+    if (uv_next) l8_load<(NCH == 1 ? l8_padded(F) : 8)>((C & 1) ? A : B, uv_next);
   }
   __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting the LDS reads of later chunks: 128 VGPRs and spills without)
-  l8_proc<C * 8, 0, (C == 15) ? 4 : 8>((C & 1) ? B : A, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+  l8_proc<F, C * 8, 0, nthis>((C & 1) ? B : A, pos, x0, x1, x2, a0, a1, a2, xs, ys);
   asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));  // the row sums are due HERE (the compiler otherwise sinks the whole chain of multiply-adds to the
   __builtin_amdgcn_sched_barrier(0);                 // flush at the end of the field and keeps every value and x it needs alive until then: spills)
-  if constexpr (C < 15) l8_run<C + 1>(A, B, uv, uv_next, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+  if constexpr (C < LAST) l8_run<F, C + 1>(A, B, uv, uv_next, pos, x0, x1, x2, a0, a1, a2, xs, ys);
 }
 
 // pass 1: one workgroup per tile; dump[tile][field][cell]
+template <int F>
 __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* __restrict__ vals, const double* __restrict__ x,
                                                       const double* __restrict__ dsc, double* __restrict__ dump,
                                                       const int32_t* __restrict__ done_flag) {
-  __shared__ double xs[L8_F * L8_FC];
-  __shared__ double ys[L8_F * L8_FC];
+  constexpr int UNIT_D = l8_padded(F) * 64, NCH = (l8_padded(F) + 7) / 8;
+  __shared__ double xs[F * L8_FC];
+  __shared__ double ys[F * L8_FC];
   if (done_flag && done_flag[0]) return;
   const int ntiles = G.nti * G.ntj * G.ntk, chunk = (ntiles + 7) >> 3;
   const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);  // every XCD walks a contiguous eighth of the tiles
@@ -260,11 +268,12 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
   const int ub = wv >> 2, uc = wv & 3;
   const int ui = ti * 2, uj = tj * 2 + ub, uk = tk * 4 + uc;
   const bool e0 = uj < G.nuj && uk < G.nuk, e1 = e0 && ui + 1 < G.nui;
-  const double* uv0 = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * L8_UNIT_D + lane * 2;
+  const double* uv0 = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * UNIT_D + lane * 2;
+  const int64_t ustride = (int64_t)G.nuj * G.nuk * UNIT_D;
   m_d2 A[4], B[4];
-  if (e0) l8_load<8>(A, uv0);  // in flight while x is staged
+  if (e0) l8_load<(NCH == 1 ? l8_padded(F) : 8)>(A, uv0);  // in flight while x is staged
   const int i0 = ti * L8_TI, j0 = tj * L8_TJ - 1, k0 = tk * L8_TK - 1;
-  for (int e = tid; e < L8_F * L8_FC; e += 512) {
+  for (int e = tid; e < F * L8_FC; e += 512) {
     const int f = e / L8_FC, c = e - f * L8_FC;
     const int li = c / L8_PI, r2 = c - li * L8_PI, lj = r2 / L8_SK, lk = r2 - lj * L8_SK;
     const int gi = G.plo + i0 + li, gj = j0 + lj, gk = k0 + lk;  // global plane: the plane behind the last owned one is a ghost plane
@@ -279,25 +288,38 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
   __syncthreads();
   if (e0) {
     const int pos0 = la * L8_PI + (ub * 4 + lb + 1) * L8_SK + (uc * 4 + lc + 1);
-    const int nu = e1 ? 2 : 1;
-    const int64_t ustride = (int64_t)G.nuj * G.nuk * L8_UNIT_D;
+    if constexpr (NCH % 2 == 0) {  // the two register buffers are back in their roles for the next unit
+      const int nu = e1 ? 2 : 1;
 #pragma unroll 1
-    for (int h = 0; h < nu; ++h) {  // (16 chunks per unit: the two register buffers are back in their roles for the next unit)
-      const double* uv = uv0 + h * ustride;
-      const int pos = pos0 + h * 4 * L8_PI;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      l8_run<0>(A, B, uv, h + 1 < nu ? uv + ustride : nullptr, pos, xs[pos], xs[L8_FC + pos], xs[2 * L8_FC + pos], a0, a1, a2, xs, ys);
+      for (int h = 0; h < nu; ++h) {
+        const double* uv = uv0 + h * ustride;
+        const int pos = pos0 + h * 4 * L8_PI;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        l8_run<F, 0>(A, B, uv, h + 1 < nu ? uv + ustride : nullptr, pos, xs[pos], xs[(F > 1 ? L8_FC : 0) + pos], xs[(F > 2 ? 2 * L8_FC : 0) + pos], a0, a1, a2,
+                     xs, ys);
+      }
+    } else {  // an odd number of chunks: the roles swap
+      {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        l8_run<F, 0>(A, B, uv0, e1 ? uv0 + ustride : nullptr, pos0, xs[pos0], xs[(F > 1 ? L8_FC : 0) + pos0], xs[(F > 2 ? 2 * L8_FC : 0) + pos0], a0, a1,
+                     a2, xs, ys);
+      }
+      if (e1) {
+        const int pos = pos0 + 4 * L8_PI;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        l8_run<F, 0>(B, A, uv0 + ustride, nullptr, pos, xs[pos], xs[(F > 1 ? L8_FC : 0) + pos], xs[(F > 2 ? 2 * L8_FC : 0) + pos], a0, a1, a2, xs, ys);
+      }
     }
   }
   __syncthreads();
-  double* dt = dump + (int64_t)tile * (L8_F * L8_FC);
-  for (int e = tid; e < L8_F * L8_FC; e += 512) dt[e] = ys[e];
+  double* dt = dump + (int64_t)tile * (F * L8_FC);
+  for (int e = tid; e < F * L8_FC; e += 512) dt[e] = ys[e];
 }
 
-// pass 2: a thread owns a (j, k) position of the tile and four of its planes, for the three fields
+// pass 2: a thread owns a (j, k) position of the tile and four of its planes, for the F fields
 // Slab with a lower neighbour (G.plo > 0): the rows of the first owned plane also have entries towards the ghost plane below.  No stored entry mirrors
-// onto them (the rows that would belong to the neighbour rank), so they are taken from the caller's CSR values here: 27 products per row of that plane.
-template <typename RP>
+// onto them (the rows that would belong to the neighbour rank), so they are taken from the caller's CSR values here: 9 F products per row of that plane.
+template <typename RP, int F>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const double* __restrict__ dump, double* __restrict__ y, double alpha,
                                                               double beta, const double* __restrict__ dotw, double* __restrict__ partials,
                                                               const int32_t* __restrict__ done_flag, const RP* __restrict__ rowptr, int base,
@@ -312,9 +334,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
     const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
     const int gj = tj * L8_TJ + lj, gk = tk * L8_TK + lk, gi0 = ti * L8_TI + 4 * lh;
     if (gj >= G.m1 || gk >= G.m2) continue;
-    double s[L8_F][4];
+    double s[F][4];
 #pragma unroll
-    for (int f = 0; f < L8_F; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
       for (int u = 0; u < 4; ++u) s[f][u] = 0.0;
     for (int b = -1; b <= 1; ++b) {
@@ -323,13 +345,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
         if ((c < 0 && (lk >= 1 || tk == 0)) || (c > 0 && (lk < L8_TK - 1 || tk == G.ntk - 1))) continue;
         const int cell = (lj - L8_TJ * b + 1) * L8_SK + (lk - L8_TK * c + 1);
         if (ti > 0 && lh == 0) {  // the tile below: its plane 8 is this tile's plane 0
-          const double* d = dump + (((int64_t)(ti - 1) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (L8_F * L8_FC) + cell + 8 * L8_PI;
+          const double* d = dump + (((int64_t)(ti - 1) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (F * L8_FC) + cell + 8 * L8_PI;
 #pragma unroll
-          for (int f = 0; f < L8_F; ++f) s[f][0] += d[f * L8_FC];
+          for (int f = 0; f < F; ++f) s[f][0] += d[f * L8_FC];
         }
-        const double* d = dump + (((int64_t)ti * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (L8_F * L8_FC) + cell + 4 * lh * L8_PI;
+        const double* d = dump + (((int64_t)ti * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (F * L8_FC) + cell + 4 * lh * L8_PI;
 #pragma unroll
-        for (int f = 0; f < L8_F; ++f)
+        for (int f = 0; f < F; ++f)
 #pragma unroll
           for (int u = 0; u < 4; ++u) s[f][u] += d[f * L8_FC + u * L8_PI];
       }
@@ -340,10 +362,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
       l8_range(gj, G.m1, l1, n1);
       l8_range(gk, G.m2, l2, n2);
       const int cnt = n0 * n1 * n2;
-      for (int f = 0; f < L8_F; ++f) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
         const int64_t rp = (int64_t)rowptr[f * G.N + (int64_t)gj * G.m2 + gk] - base;
         double acc = 0.0;
-        for (int g = 0; g < L8_F; ++g)
+        for (int g = 0; g < F; ++g)
           for (int b = 0; b < n1; ++b)
             for (int c = 0; c < n2; ++c) {
               const int64_t xi = l8_xindex(G, g, G.plo - 1, (int64_t)(gj + l1 + b) * G.m2 + gk + l2 + c);
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
       }
     }
 #pragma unroll
-    for (int f = 0; f < L8_F; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (gi0 + u < G.m0) {
@@ -372,9 +395,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
 
 static Lat8Geom lat8_geom(const mfem_csr_s* A) {
   Lat8Geom G{};
+  G.F = A->lat_fields;
   G.m1 = A->lat_m1;
   G.m2 = A->lat_m2;
-  G.N = A->n / L8_F;
+  G.N = A->n / G.F;
   G.m0 = (int)(G.N / ((int64_t)A->lat_m1 * A->lat_m2));
   G.plo = A->lat_plo;
   G.mg = A->lat_m0 > 0 ? A->lat_m0 : G.m0;
@@ -387,8 +411,9 @@ static Lat8Geom lat8_geom(const mfem_csr_s* A) {
   G.ntk = (G.m2 + L8_TK - 1) / L8_TK;
   return G;
 }
+static int lat8_unit_doubles(int F) { return (F == 1 ? l8_padded(1) : F == 2 ? l8_padded(2) : l8_padded(3)) * 64; }
 
-// lat8_state: 0 not inspected, -1 not the 3-field stencil, 1 structure ok
+// lat8_state: 0 not inspected, -1 not the F-field stencil, 1 structure ok
 int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->lat8_state != 0) return MFEM_OK;
   if (A->n < g_layout_min_rows_dia) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel
@@ -397,20 +422,21 @@ int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
     int rc0 = mfem_lattice_from_first_row(ctx, A);
     if (rc0) return rc0;
   }
-  if (A->lat_fields != L8_F || A->lat_m1 < 2 || A->lat_m2 < 2 || A->n % L8_F != 0) return MFEM_OK;
-  const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2, N = A->n / L8_F;
+  const int F = A->lat_fields;
+  if (F < 1 || F > 3 || A->lat_m1 < 2 || A->lat_m2 < 2 || A->n % F != 0) return MFEM_OK;
+  const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2, N = A->n / F;
   if (N % PL != 0) return MFEM_OK;
   const int64_t m0 = N / PL;
-  if (m0 < 1 || m0 > (1 << 20) || A->max_row_nnz > 81) return MFEM_OK;
+  if (m0 < 1 || m0 > (1 << 20) || A->max_row_nnz > 27 * F) return MFEM_OK;
   if (A->ncols > A->n) {  // slab pattern (ghost columns): the hint must say where the owned planes sit in the lattice and how the ghost blocks are laid out
-    if (A->lat_m0 < m0 || A->lat_gw != 1 || A->lat_plo < 0 || A->lat_plo + m0 > A->lat_m0 || A->ncols != A->n + 2 * L8_F * PL) return MFEM_OK;
+    if (A->lat_m0 < m0 || A->lat_gw != 1 || A->lat_plo < 0 || A->lat_plo + m0 > A->lat_m0 || A->ncols != A->n + 2 * F * PL) return MFEM_OK;
   } else if (A->lat_m0 > 0 && (A->lat_m0 != m0 || A->lat_plo != 0)) {
     return MFEM_OK;
   }
   {  // cheap refusal before the entry-by-entry check: the longest row of the stencil is known from the lattice sizes
     const int64_t mg = A->lat_m0 > 0 ? A->lat_m0 : m0;
     auto w = [](int64_t m) { return m >= 3 ? 3 : (int)m; };
-    if (A->max_row_nnz != L8_F * w(mg) * w(A->lat_m1) * w(A->lat_m2)) return MFEM_OK;
+    if (A->max_row_nnz != F * w(mg) * w(A->lat_m1) * w(A->lat_m2)) return MFEM_OK;
   }
   const Lat8Geom G = lat8_geom(A);
   if ((int64_t)G.nti * G.ntj * G.ntk >= ((int64_t)1 << 28)) return MFEM_OK;
@@ -430,8 +456,8 @@ int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   return MFEM_OK;
 }
 
-static size_t lat8_vals_doubles(const Lat8Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * L8_UNIT_D; }
-static size_t lat8_dump_doubles(const Lat8Geom& G) { return (size_t)G.nti * G.ntj * G.ntk * L8_F * L8_FC; }
+static size_t lat8_vals_doubles(const Lat8Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * lat8_unit_doubles(G.F); }
+static size_t lat8_dump_doubles(const Lat8Geom& G) { return (size_t)G.nti * G.ntj * G.ntk * G.F * L8_FC; }
 
 size_t mfem_lat8_bytes(const mfem_csr_s* A) {
   if (A->lat8_state != 1 || !g_lat8_enable || A->n < g_layout_min_rows_dia) return 0;
@@ -448,8 +474,15 @@ static void lat8_probe_rebind(mfem_csr_s* A, void* c) {
   A->lat8_src = b->src;
 }
 
+#define L8_DISPATCH_F(F_, CALL) \
+  do {                          \
+    if ((F_) == 1) { CALL(1); } \
+    else if ((F_) == 2) { CALL(2); } \
+    else { CALL(3); }           \
+  } while (0)
+
 // Makes the layout copy of `vals` in buf and binds it if the values are symmetric (mfem_sym_probe, spmv_lat27.hip).  dsc: right Jacobi scaling the
-// SpMV applies to x (nullptr: none); only the pointer is kept, it may be filled after the bind.  scratch: 3 n doubles, left dirty.
+// SpMV applies to x (nullptr: none); only the pointer is kept, it may be filled after the bind.  scratch: ncols + 2 n doubles, left dirty.
 int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch) {
   mfem_lat8_unbind(A);
   if (A->lat8_state != 1 || !g_lat8_enable || !buf || !scratch) return MFEM_OK;
@@ -458,12 +491,15 @@ int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   MFEM_CHECK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
   const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
   const int grid = mfem_grid_for(nunits * 64, MFEM_BLOCK, ctx->num_cus * 16);
-  if (A->rowptr_bits == 64)
-    hipLaunchKernelGGL(k_l8_fill<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->index_base, vals, buf,
-                       d_stats);
-  else
-    hipLaunchKernelGGL(k_l8_fill<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->index_base, vals, buf,
-                       d_stats);
+#define L8_FILL(FF)                                                                                                                             \
+  if (A->rowptr_bits == 64)                                                                                                                     \
+    hipLaunchKernelGGL((k_l8_fill<int64_t, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->index_base, vals, \
+                       buf, d_stats);                                                                                                           \
+  else                                                                                                                                          \
+    hipLaunchKernelGGL((k_l8_fill<int32_t, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->index_base, vals, \
+                       buf, d_stats)
+  L8_DISPATCH_F(G.F, L8_FILL);
+#undef L8_FILL
   MFEM_CHECK_LAUNCH();
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -474,7 +510,7 @@ int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   double asym = 1.0;
   int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat8_probe_unbind, lat8_probe_rebind, &B, &asym);
   A->lat8_asym = asym;
-  if (rc || !(asym <= 4e-13)) {  // not symmetric (or NaN): the diagonal-slotted layout serves this solve
+  if (rc || !(asym <= 4e-13)) {  // not symmetric (or NaN): the other layouts serve this solve
     mfem_lat8_unbind(A);
     return rc;
   }
@@ -504,17 +540,23 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   const Lat8Geom G = lat8_geom(A);
   const int ntiles = G.nti * G.ntj * G.ntk;
   const int chunk = (ntiles + 7) / 8;
-  hipLaunchKernelGGL(k_spmv_lat8, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag);
+#define L8_PASS1(FF) \
+  hipLaunchKernelGGL(k_spmv_lat8<FF>, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag)
+  L8_DISPATCH_F(G.F, L8_PASS1);
+#undef L8_PASS1
   MFEM_CHECK_LAUNCH();
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;
-  if (A->rowptr_bits == 64)
-    hipLaunchKernelGGL(k_lat8_gather<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag,
-                       (const int64_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);
-  else
-    hipLaunchKernelGGL(k_lat8_gather<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag,
-                       (const int32_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);
+#define L8_PASS2(FF)                                                                                                                                  \
+  if (A->rowptr_bits == 64)                                                                                                                           \
+    hipLaunchKernelGGL((k_lat8_gather<int64_t, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials,   \
+                       done_flag, (const int64_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);                                             \
+  else                                                                                                                                                \
+    hipLaunchKernelGGL((k_lat8_gather<int32_t, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials,   \
+                       done_flag, (const int32_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc)
+  L8_DISPATCH_F(G.F, L8_PASS2);
+#undef L8_PASS2
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   if (!mfem_probe_active) ++g_lat8_count;
@@ -525,6 +567,6 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 int64_t mfem_lat8_design_bytes(const mfem_csr_s* A) {
   const Lat8Geom G = lat8_geom(A);
   const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
-  return (int64_t)lat8_vals_doubles(G) * 8 + tiles * L8_F * L8_FC * 8 * (A->lat8_scaled ? 4 : 3) + A->n * 8;
+  return (int64_t)lat8_vals_doubles(G) * 8 + tiles * G.F * L8_FC * 8 * (A->lat8_scaled ? 4 : 3) + A->n * 8;
 }
 int64_t mfem_lat8_entries(const mfem_csr_s* A) { return (int64_t)lat8_vals_doubles(lat8_geom(A)); }

@@ -7,26 +7,32 @@
 #endif
 #include <stdint.h>
 
-// ---- mode 5: 3 fields on the 27-point stencil, lane = node.  The 123 steps of a unit (+ 1 padding step), wave-uniform:
-// row field f: for g = 0..2: [the node's own block entry (f, g) if g >= f], then the 13 upper neighbours e = 1..13 (d = (0,0,1) .. (1,1,1))
-#define L8_STEPS 124
-__host__ __device__ constexpr int l8_first(int f) { return f == 0 ? 0 : f == 1 ? 42 : 83; }
-__host__ __device__ constexpr int l8_row_field(int s) { return s < 42 ? 0 : s < 83 ? 1 : 2; }
+// ---- mode 5: F = 1..3 fields on the 27-point stencil (field-major rows), lane = node.  The steps of a unit, wave-uniform:
+// row field f: for g = 0..F-1: [the node's own block entry (f, g) if g >= f], then the 13 upper neighbours e = 1..13 (d = (0,0,1) .. (1,1,1))
+__host__ __device__ constexpr int l8_field_steps(int F, int f) { return 13 * F + (F - f); }
+__host__ __device__ constexpr int l8_first(int F, int f) { return f == 0 ? 0 : l8_first(F, f - 1) + l8_field_steps(F, f - 1); }
+__host__ __device__ constexpr int l8_nsteps(int F) { return l8_first(F, F); }           // 14, 55, 123
+__host__ __device__ constexpr int l8_padded(int F) { return (l8_nsteps(F) + 1) & ~1; }  // 14, 56, 124: steps leave in pairs (16-byte loads)
+__host__ __device__ constexpr int l8_row_field(int F, int s) {
+  int f = 0;
+  while (f + 1 < F && s >= l8_first(F, f + 1)) ++f;
+  return f;
+}
 // (g, e) of step s; e = 0: the node itself
-__host__ __device__ constexpr int l8_g(int s) {
-  const int f = l8_row_field(s);
-  int t = s - l8_first(f);
-  for (int g = 0; g < 3; ++g) {
+__host__ __device__ constexpr int l8_g(int F, int s) {
+  const int f = l8_row_field(F, s);
+  int t = s - l8_first(F, f);
+  for (int g = 0; g < F; ++g) {
     const int len = 13 + (g >= f ? 1 : 0);
     if (t < len) return g;
     t -= len;
   }
   return 0;
 }
-__host__ __device__ constexpr int l8_e(int s) {
-  const int f = l8_row_field(s);
-  int t = s - l8_first(f);
-  for (int g = 0; g < 3; ++g) {
+__host__ __device__ constexpr int l8_e(int F, int s) {
+  const int f = l8_row_field(F, s);
+  int t = s - l8_first(F, f);
+  for (int g = 0; g < F; ++g) {
     const int own = g >= f ? 1 : 0;
     const int len = 13 + own;
     if (t < len) return own ? t : t + 1;

@@ -75,16 +75,16 @@ static int check27(int m0, int m1, int m2) {
   return 0;
 }
 
-// ---- mode 5: three fields on the 27-point stencil, field-major
-static int check8(int m0, int m1, int m2) {
-  const long N = (long)m0 * m1 * m2, n = 3 * N;
+// ---- mode 5: F fields on the 27-point stencil, field-major
+static int check8(int F, int m0, int m1, int m2) {
+  const long N = (long)m0 * m1 * m2, n = F * N;
   auto id = [&](int f, int i, int j, int k) { return f * N + ((long)i * m1 + j) * m2 + k; };
   std::map<std::pair<long, long>, double> A;
-  for (int f = 0; f < 3; ++f)
+  for (int f = 0; f < F; ++f)
     for (int i = 0; i < m0; ++i)
       for (int j = 0; j < m1; ++j)
         for (int k = 0; k < m2; ++k)
-          for (int g = 0; g < 3; ++g)
+          for (int g = 0; g < F; ++g)
             for (int di = -1; di <= 1; ++di)
               for (int dj = -1; dj <= 1; ++dj)
                 for (int dk = -1; dk <= 1; ++dk) {
@@ -101,18 +101,18 @@ static int check8(int m0, int m1, int m2) {
     if (e.first.first != e.first.second) y0[e.first.second] += e.second * x[e.first.first];
   }
   long used = 0;
-  int last[3] = {-1, -1, -1};
-  for (int s = 0; s < 123; ++s) {
-    const int f = l8_row_field(s);
-    if (s < l8_first(f) || l8_g(s) < 0 || l8_g(s) > 2 || l8_e(s) < 0 || l8_e(s) > 13) return printf("step %d malformed\n", s), 1;
-    last[f] = s;
+  const int NS = l8_nsteps(F);
+  if (NS != 13 * F * F + F * (F + 1) / 2 || l8_padded(F) != ((NS + 1) & ~1)) return printf("step count\n"), 1;
+  for (int s = 0; s < NS; ++s) {
+    const int f = l8_row_field(F, s);
+    if (f < 0 || f >= F || s < l8_first(F, f) || s >= l8_first(F, f + 1) || l8_g(F, s) < 0 || l8_g(F, s) >= F || l8_e(F, s) < 0 || l8_e(F, s) > 13)
+      return printf("step %d malformed\n", s), 1;
   }
-  if (last[0] != 41 || last[1] != 82 || last[2] != 122) return printf("field boundaries\n"), 1;
   for (int i = 0; i < m0; ++i)
     for (int j = 0; j < m1; ++j)
       for (int k = 0; k < m2; ++k)
-        for (int s = 0; s < 123; ++s) {
-          const int f = l8_row_field(s), g = l8_g(s), e = l8_e(s);
+        for (int s = 0; s < NS; ++s) {
+          const int f = l8_row_field(F, s), g = l8_g(F, s), e = l8_e(F, s);
           const int ci = i + l8_di(e), cj = j + l8_dj(e), ck = k + l8_dk(e);
           if (e == 0 && g < f) return printf("own-block slot below the diagonal\n"), 1;
           if (ci >= m0 || cj < 0 || cj >= m1 || ck < 0 || ck >= m2) continue;
@@ -129,7 +129,7 @@ static int check8(int m0, int m1, int m2) {
     err = std::fmax(err, std::fabs(y0[r] - y1[r]));
     scale = std::fmax(scale, std::fabs(y0[r]));
   }
-  if (!(err <= 1e-13 * scale)) return printf("mode 5 on %d x %d x %d: error %.3e\n", m0, m1, m2, err / scale), 1;
+  if (!(err <= 1e-13 * scale)) return printf("mode 5, %d fields, on %d x %d x %d: error %.3e\n", F, m0, m1, m2, err / scale), 1;
   return 0;
 }
 
@@ -139,8 +139,9 @@ int main() {
   for (auto& s : s27)
     if (check27(s[0], s[1], s[2])) return 1;
   const int s8[][3] = {{1, 1, 1}, {2, 2, 2}, {3, 4, 5}, {6, 2, 7}, {1, 5, 4}};
-  for (auto& s : s8)
-    if (check8(s[0], s[1], s[2])) return 1;
+  for (int F = 1; F <= 3; ++F)
+    for (auto& s : s8)
+      if (check8(F, s[0], s[1], s[2])) return 1;
   printf("lattice-tile tables: every stencil pair listed exactly once, products agree\nOK\n");
   return 0;
 }
