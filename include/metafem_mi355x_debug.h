@@ -58,6 +58,9 @@ int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_colu
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
  * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */
 int mfem_debug_set_graphs(int on, int64_t max_n);
+/* idrs!: 1 = the literal bi-orthogonalisation loop of 04_IDRs.jl:62-66 (k dependent dot products and 2 k vector updates per inner step) instead of
+ * the merged form (one multi-dot pass, the alphas by forward substitution with M, one vector kernel): the same numbers in exact arithmetic. */
+int mfem_debug_set_idrs(int literal_orthogonalisation);
 /* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
 int mfem_debug_set_vec_grid(int workgroups_per_cu);
 /* Multi-rank SpMV: 1 (default) the halo exchange runs on a second stream beside the rows that read no ghost column and the

@@ -592,3 +592,30 @@ def test_patch_sweep_on_a_caller_supplied_symmetric_lattice_matrix(mf, rp_dtype,
         assert np.abs(x2.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
     finally:
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("s", [1, 4, 8, 11])
+def test_idrs_merged_biorthogonalisation_equals_the_literal_loop(mf, s):
+    """idrs! (04_IDRs.jl:62-73): the merged form of the bi-orthogonalisation (one multi-dot pass, alphas by forward substitution with M, one vector
+    kernel; default) against the literal loop (mfem_debug_set_idrs(1)): the first cycles agree to round-off, the converged solutions to the solver
+    tolerance; s = 11 needs two chunks of dot products."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick = mf.make_Brick((1.0, 2.0, 1.5), (9, 7, 11))
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    b = mf.FEM_rand(A.n, 11, 0) - 0.5
+    out = {}
+    try:
+        for literal in (0, 1):
+            _lib.lib.mfem_debug_set_idrs(literal)
+            x1, _ = mf.iterative_Solve(A, K, b, 1e-300, Sv_func=mf.idrs_, s=s, maxiter=2 * (s + 1), max_pass=1, fixed_iterations=True)
+            x2, st = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=mf.idrs_, s=s, maxiter=3000, max_pass=4)
+            assert st.converged == 1
+            out[literal] = (x1.clone(), x2.clone(), st.iterations)
+    finally:
+        _lib.lib.mfem_debug_set_idrs(0)
+    assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-11 * float(out[1][0].abs().max())
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-8 * float(out[1][1].abs().max())
+    assert abs(out[0][2] - out[1][2]) <= max(4, out[1][2] // 10)
