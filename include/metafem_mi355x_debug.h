@@ -61,6 +61,9 @@ int mfem_debug_set_graphs(int on, int64_t max_n);
 /* idrs!: 1 = the literal bi-orthogonalisation loop of 04_IDRs.jl:62-66 (k dependent dot products and 2 k vector updates per inner step) instead of
  * the merged form (one multi-dot pass, the alphas by forward substitution with M, one vector kernel): the same numbers in exact arithmetic. */
 int mfem_debug_set_idrs(int literal_orthogonalisation);
+/* bicgstabl_GS!: 1 = the literal operation sequence of 03_BiCGstabl.jl:41-94 (one pass over the vectors per dot product and per update) instead of the
+ * fused form (dot products produced by the SpMVs, the minimal-residual part on the Gram matrix of R[0..l], the updates of a sweep in one kernel). */
+int mfem_debug_set_bicgstabl(int literal_sequence);
 /* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
 int mfem_debug_set_vec_grid(int workgroups_per_cu);
 /* Multi-rank SpMV: 1 (default) the halo exchange runs on a second stream beside the rows that read no ghost column and the

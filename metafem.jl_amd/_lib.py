@@ -145,6 +145,7 @@ SIGNATURES = {
     "mfem_debug_set_hex8_thermal": (c_int, [c_int]),
     "mfem_debug_set_sell": (c_int, [c_int]),
     "mfem_debug_set_idrs": (c_int, [c_int]),
+    "mfem_debug_set_bicgstabl": (c_int, [c_int]),
     "mfem_debug_set_lat27": (c_int, [c_int]),
     "mfem_debug_lat27_spmv_count": (c_int64, []),
     "mfem_debug_lat27_asymmetry": (C.c_double, [c_void_p]),

@@ -619,3 +619,30 @@ def test_idrs_merged_biorthogonalisation_equals_the_literal_loop(mf, s):
     assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-11 * float(out[1][0].abs().max())
     assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-8 * float(out[1][1].abs().max())
     assert abs(out[0][2] - out[1][2]) <= max(4, out[1][2] // 10)
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_bicgstabl_fused_form_equals_the_literal_sequence(mf, l):
+    """bicgstabl_GS! (03_BiCGstabl.jl:41-94): the fused form (dot products produced by the SpMVs, the minimal-residual part on the Gram matrix of
+    R[0..l], the updates of a sweep in one kernel; default) against the literal operation sequence (mfem_debug_set_bicgstabl(1)): the first sweeps
+    agree to round-off, the converged solutions to the solver tolerance.  (l > 2 keeps the literal sequence: the Gram-matrix form of the modified
+    Gram-Schmidt loop squares the condition of R[1..l] -- measured 1e-8 instead of 1e-11 at l = 6.)"""
+    from metafem_jl_amd import _lib
+
+    brick = mf.make_Brick((1.0, 2.0, 1.5), (9, 7, 11))
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    b = mf.FEM_rand(A.n, 11, 0) - 0.5
+    out = {}
+    try:
+        for literal in (0, 1):
+            _lib.lib.mfem_debug_set_bicgstabl(literal)
+            x1, _ = mf.iterative_Solve(A, K, b, 1e-300, Sv_func=mf.bicgstabl_GS_, s=l, maxiter=3 * l, max_pass=1, fixed_iterations=True)
+            x2, st = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=mf.bicgstabl_GS_, s=l, maxiter=3000, max_pass=4)
+            assert st.converged == 1
+            out[literal] = (x1.clone(), x2.clone(), st.iterations)
+    finally:
+        _lib.lib.mfem_debug_set_bicgstabl(0)
+    assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-11 * float(out[1][0].abs().max())
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-8 * float(out[1][1].abs().max())
+    assert abs(out[0][2] - out[1][2]) <= max(2 * l, out[1][2] // 10)
