@@ -20,6 +20,7 @@ __constant__ double c_w[BRICK_MAX_Q];
 __constant__ double c_N[BRICK_MAX_Q][8];
 __constant__ double c_dN[BRICK_MAX_Q][8][3];
 // face tables: 2-D Gauss on [0,1]^2, bilinear face basis [q][c], c = c1 + 2*c2 (first tangential coord fastest)
+__constant__ double c_xi[BRICK_MAX_Q][6];  // xi0, xi1, xi2, xi1 xi2, xi0 xi2, xi0 xi1 at Gauss point q (trilinear-map form of the Jacobian)
 __constant__ double c_fw[BRICK_MAX_NG * BRICK_MAX_NG];
 __constant__ double c_fN[BRICK_MAX_NG * BRICK_MAX_NG][4];
 __constant__ double c_fdN[BRICK_MAX_NG * BRICK_MAX_NG][4][2];
@@ -36,14 +37,14 @@ static const double GW[4][4] = {{2.0, 0, 0, 0},
 
 int mfem_hex8_upload_tables(int ng) {
   if (g_tables_ng == ng) return MFEM_OK;
-  double w[BRICK_MAX_Q], N[BRICK_MAX_Q][8], dN[BRICK_MAX_Q][8][3];
+  double w[BRICK_MAX_Q], N[BRICK_MAX_Q][8], dN[BRICK_MAX_Q][8][3], xiq[BRICK_MAX_Q][6];
   double fw[16], fN[16][4], fdN[16][4][2];
   double gp[4], gw[4];
   for (int i = 0; i < ng; ++i) {
     gp[i] = GP[ng - 1][i] / 2.0 + 0.5;  // shift_gauss_point  103_Integrations.jl:1
     gw[i] = GW[ng - 1][i] / 2.0;        // shift_gauss_weight :2
   }
-  memset(w, 0, sizeof(w)); memset(N, 0, sizeof(N)); memset(dN, 0, sizeof(dN));
+  memset(w, 0, sizeof(w)); memset(N, 0, sizeof(N)); memset(dN, 0, sizeof(dN)); memset(xiq, 0, sizeof(xiq));
   memset(fw, 0, sizeof(fw)); memset(fN, 0, sizeof(fN)); memset(fdN, 0, sizeof(fdN));
   for (int qz = 0; qz < ng; ++qz)
     for (int qy = 0; qy < ng; ++qy)
@@ -51,6 +52,8 @@ int mfem_hex8_upload_tables(int ng) {
         const int q = qx + ng * (qy + ng * qz);
         const double xi[3] = {gp[qx], gp[qy], gp[qz]};
         w[q] = gw[qx] * gw[qy] * gw[qz];
+        xiq[q][0] = xi[0]; xiq[q][1] = xi[1]; xiq[q][2] = xi[2];
+        xiq[q][3] = xi[1] * xi[2]; xiq[q][4] = xi[0] * xi[2]; xiq[q][5] = xi[0] * xi[1];
         for (int b = 0; b < 8; ++b) {
           double f[3], df[3];
           for (int d = 0; d < 3; ++d) {
@@ -80,6 +83,7 @@ int mfem_hex8_upload_tables(int ng) {
   MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_w), w, sizeof(w)));
   MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_N), N, sizeof(N)));
   MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_dN), dN, sizeof(dN)));
+  MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_xi), xiq, sizeof(xiq)));
   MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fw), fw, sizeof(fw)));
   MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fN), fN, sizeof(fN)));
   MFEM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fdN), fdN, sizeof(fdN)));
@@ -131,6 +135,53 @@ __device__ __forceinline__ void hex8_load_coords(const BrickView& B, int I, int 
   }
 }
 
+// The same geometry from the element's trilinear map x(xi) = X_0 + sum_{b > 0} C[b - 1] prod_{d in b} xi_d (C: differences of the nodal
+// coordinates along the set bits of b, one butterfly per element): a column of J is 3 multiply-adds instead of the 8 of the table form.
+__device__ __forceinline__ void hex8_trilinear(const double (&X)[8][3], double (&C)[7][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double v[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) v[b] = X[b][i];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (b & (1 << d)) v[b] -= v[b ^ (1 << d)];
+#pragma unroll
+    for (int b = 1; b < 8; ++b) C[b - 1][i] = v[b];
+  }
+}
+__device__ __forceinline__ double hex8_geom_trilinear(const double (&C)[7][3], int q, double (&g)[8][3]) {
+  const double x0 = c_xi[q][0], x1 = c_xi[q][1], x2 = c_xi[q][2], x12 = c_xi[q][3], x02 = c_xi[q][4], x01 = c_xi[q][5];
+  double J[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    J[i][0] = C[0][i] + x1 * C[2][i] + x2 * C[4][i] + x12 * C[6][i];
+    J[i][1] = C[1][i] + x0 * C[2][i] + x2 * C[5][i] + x02 * C[6][i];
+    J[i][2] = C[3][i] + x0 * C[4][i] + x1 * C[5][i] + x01 * C[6][i];
+  }
+  const double det = J[0][0] * J[1][1] * J[2][2] - J[0][0] * J[1][2] * J[2][1] - J[0][1] * J[1][0] * J[2][2] +
+                     J[0][1] * J[1][2] * J[2][0] + J[0][2] * J[1][0] * J[2][1] - J[0][2] * J[1][1] * J[2][0];
+  const double id = 1.0 / det;
+  double I[3][3];
+  I[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id;
+  I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+  I[0][2] = (J[0][1] * J[1][2] - J[1][1] * J[0][2]) * id;
+  I[1][0] = (J[1][2] * J[2][0] - J[2][2] * J[1][0]) * id;
+  I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+  I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+  I[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id;
+  I[2][1] = (J[0][1] * J[2][0] - J[2][1] * J[0][0]) * id;
+  I[2][2] = (J[0][0] * J[1][1] - J[1][0] * J[0][1]) * id;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      g[b][s] = c_dN[q][b][0] * I[0][s] + c_dN[q][b][1] * I[1][s] + c_dN[q][b][2] * I[2][s];
+  return c_w[q] * det;
+}
+
 // Face quadrature on the brick face with normal dim nd (0,1,2) -- tangential dims follow the reference
 // (103_Integrations.jl:37): nd=0 -> (1,2), nd=1 -> (2,0), nd=2 -> (0,1).  Xf[c][3] are the 4 face nodes,
 // c = c1 + 2*c2.  Returns w^s = w_q * |t1 x t2| (4_Update_Integrator.jl:71,210-226); `nrm` (optional) is
@@ -167,6 +218,14 @@ __device__ __forceinline__ int face_bit(int nd, int high) {
 }
 
 __device__ __forceinline__ void node_ijk(const BrickView& B, int64_t node, int& i, int& j, int& k) {
+  if (B.n_owned < ((int64_t)1 << 31)) {  // (uniform) two 32-bit divisions: ~60 instructions against ~300 for the 64-bit pair
+    const uint32_t nd = (uint32_t)node, pl = (uint32_t)B.plane_len, m2 = (uint32_t)B.m2;
+    const uint32_t ip = nd / pl, rem = nd - ip * pl, jj = rem / m2;
+    i = (int)ip + B.plo;
+    j = (int)jj;
+    k = (int)(rem - jj * m2);
+    return;
+  }
   i = (int)(node / B.plane_len) + B.plo;
   const int64_t rem = node % B.plane_len;
   j = (int)(rem / B.m2);
@@ -842,14 +901,44 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, d
 // identical) and leave as contiguous runs, every CSR value written exactly once -- no memset, no atomics, no colours.
 #define EL2_NODES 32
 #define EL2_ROW 244  // 3 fields x 81 slots, padded
+// G[b][s][t] = sum_q w det d_sN_a d_tN_b for the row node a = AH + 1 - ex of the thread's element
+template <int AH>
+__device__ __forceinline__ void el2_integrate(const double (&C)[7][3], int nq, int ex, double (&G)[8][3][3]) {
+  double A[8][3][3];  // the loop's own accumulators, handed over once after the loop (accumulating into G itself makes the register allocator
+                      // rotate the 72 sums through ~140 copies per pass)
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) A[b][s][t] = 0.0;
+  for (int q = 0; q < nq; ++q) {
+    double g[8][3];
+    const double wd = hex8_geom_trilinear(C, q, g);
+    double ga[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) ga[s] = wd * (ex ? g[AH][s] : g[AH + 1][s]);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) A[b][s][t] += ga[s] * g[b][t];
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) G[b][s][t] = A[b][s][t];
+}
 __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_elasticity_matrix_lds(BrickView B, double lam, double mu, double tau,
-                                                                        uint32_t penalty, int64_t T, double* __restrict__ vals) {
+                                                                        uint32_t penalty, int64_t T, double* __restrict__ vals, int abl) {
   __shared__ double rows[EL2_NODES * EL2_ROW];
   __shared__ int64_t s_pre[EL2_NODES];
   __shared__ int32_t s_cn[EL2_NODES];
-  // lane <-> control point, half-wave <-> adjacent element: the 32 threads of an accumulation phase (one element slot e) are one half of
-  // a wave -- full LDS instructions instead of 8 scattered lanes in each of the four waves -- and neighbouring lanes load neighbouring
-  // elements' coordinates
+  // lane <-> control point, half-wave <-> adjacent element (two elements that differ in dimension 0 per wave): neighbouring lanes load
+  // neighbouring elements' coordinates, and the row node of a thread inside its element is known per wave up to one bit
   const int tid = threadIdx.x, nl = tid & (EL2_NODES - 1), e = tid / EL2_NODES;
   const int64_t node = (int64_t)blockIdx.x * EL2_NODES + nl;
   const bool live = node < B.n_owned;
@@ -872,74 +961,61 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   const int I = i - 1 + ex, J = j - 1 + ey, K = k - 1 + ez;
   const bool valid = live && I >= 0 && I < B.ne0 && J >= 0 && J < B.ne1 && K >= 0 && K < B.ne2;
   double G[8][3][3];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) G[b][s][t] = 0.0;
   if (valid) {
-    const int a = (1 - ex) + 2 * (1 - ey) + 4 * (1 - ez);
-    double X[8][3];
-    hex8_load_coords(B, I, J, K, X);
-#pragma unroll
-    for (int b = 0; b < 8; ++b)
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) G[b][s][t] = 0.0;
-    const int nq = B.ng * B.ng * B.ng;
-    for (int q = 0; q < nq; ++q) {
-      double g[8][3];
-      const double wd = hex8_geom(X, q, g);
-      double ga[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const bool me = (b == a);
-        ga[0] = me ? g[b][0] : ga[0];
-        ga[1] = me ? g[b][1] : ga[1];
-        ga[2] = me ? g[b][2] : ga[2];
-      }
-#pragma unroll
-      for (int b = 0; b < 8; ++b)
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) G[b][s][t] += wd * ga[s] * g[b][t];
+    double C[7][3];
+    {
+      double X[8][3];
+      hex8_load_coords(B, I, J, K, X);
+      hex8_trilinear(X, C);
+    }
+    // the row node a = (1 - ex) + 2 (1 - ey) + 4 (1 - ez) of this thread in its element: (ey, ez) is the wave's, ex the half-wave's -- the
+    // loop is instantiated per wave with the node pair as a constant, so its gradient is one select instead of a search through all eight
+    const int nq = (abl & 4) ? 0 : B.ng * B.ng * B.ng;
+    switch (e >> 1) {
+      case 0: el2_integrate<6>(C, nq, ex, G); break;
+      case 1: el2_integrate<4>(C, nq, ex, G); break;
+      case 2: el2_integrate<2>(C, nq, ex, G); break;
+      default: el2_integrate<0>(C, nq, ex, G); break;
     }
   }
   __syncthreads();
   double* R = rows + nl * EL2_ROW;  // [field fi][block fk * cn + slot]
-  for (int ph = 0; ph < 8; ++ph) {
-    if (valid && e == ph) {
-      // the entries of NB neighbours are read together and written together: one LDS round trip per batch instead of a chain
-      // of dependent read-modify-writes (the compiler cannot reorder them itself: dynamic indices).  Same order of additions
-      // per entry as before: distinct neighbours hit distinct entries.
-      constexpr int NB = 2;
+  // Accumulation without conflicts: in step b EVERY thread adds its element's block towards the element's node b.  The eight threads of a
+  // control point sit in eight different elements (offsets e), so in one step they touch the eight different neighbours e + b -- all 256
+  // threads work in every step, and a barrier orders the steps (an entry's contributions arrive by decreasing e: a fixed order, the same
+  // for the two mirrored entries of a pair of control points).
+  if (!(abl & 1)) {
+    const int slot0 = ((I - li) * cj + (J - lj)) * ck + (K - lk);
 #pragma unroll
-      for (int b0 = 0; b0 < 8; b0 += NB) {
-        double cur[NB][3][3];
-        int slot[NB];
+    for (int b = 0; b < 8; ++b) {
+      if (valid) {
+        const int slot = slot0 + ((b & 1) * cj + ((b >> 1) & 1)) * ck + (b >> 2);
+        double cur[3][3];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int b = b0 + u;
-          const int ni = I + (b & 1), nj = J + ((b >> 1) & 1), nk = K + (b >> 2);
-          slot[u] = ((ni - li) * cj + (nj - lj)) * ck + (nk - lk);
+        for (int fi = 0; fi < 3; ++fi)
 #pragma unroll
-          for (int fi = 0; fi < 3; ++fi)
+          for (int fk = 0; fk < 3; ++fk) cur[fi][fk] = R[fi * 81 + fk * cn + slot];
+        const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
 #pragma unroll
-            for (int fk = 0; fk < 3; ++fk) cur[u][fi][fk] = R[fi * 81 + fk * cn + slot[u]];
-        }
+        for (int fi = 0; fi < 3; ++fi)
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int b = b0 + u;
-          const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
-#pragma unroll
-          for (int fi = 0; fi < 3; ++fi)
-#pragma unroll
-            for (int fk = 0; fk < 3; ++fk) {
-              double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
-              if (fi == fk) v += mu * tr;
-              R[fi * 81 + fk * cn + slot[u]] = cur[u][fi][fk] - v;
-            }
-        }
+          for (int fk = 0; fk < 3; ++fk) {
+            double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
+            if (fi == fk) v += mu * tr;
+            R[fi * 81 + fk * cn + slot] = cur[fi][fk] - v;
+          }
       }
+      // steps b and b + 1 (b even) meet only in neighbours e + b == e' + b + 1, i.e. between the two threads of a control point whose
+      // elements differ in dimension 0 alone: the two halves of ONE wave, whose LDS instructions execute in program order -- no barrier
+      if (b & 1) __syncthreads();
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
   }
   if (live && e == 0 && tau != 0.0 && penalty != 0u) {
     visit_boundary_faces(B, i, j, k, penalty, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
@@ -961,11 +1037,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
     });
   }
   __syncthreads();
-  // write-out: row (f, node) = 3 cn contiguous values at f * 3 T + 3 pre(node)
-  for (int idx = tid; idx < EL2_NODES * 243; idx += MFEM_BLOCK) {
-    const int n2 = idx / 243, rem = idx - n2 * 243, f = rem / 81, o = rem - f * 81;
-    const int c3 = 3 * s_cn[n2];
-    if (o < c3) vals[(int64_t)f * 3 * T + 3 * s_pre[n2] + o] = rows[n2 * EL2_ROW + f * 81 + o];
+  // write-out: row (f, node) = 3 cn contiguous values at f * 3 T + 3 pre(node); a half-wave per row, three steps of 32 values
+  {
+    const int grp = tid >> 5, l32 = tid & 31;
+    for (int p = grp; p < ((abl & 2) ? 0 : EL2_NODES * 3); p += MFEM_BLOCK / 32) {
+      const int n2 = (p * 171) >> 9, f = p - 3 * n2;  // p / 3 for p < 96
+      const int c3 = 3 * s_cn[n2];
+      double* dst = vals + (int64_t)f * 3 * T + 3 * s_pre[n2];
+      const double* src = rows + n2 * EL2_ROW + f * 81;
+#pragma unroll
+      for (int o = l32; o < 81; o += 32)
+        if (o < c3) dst[o] = src[o];
+    }
   }
 }
 
@@ -1242,7 +1325,7 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
 static int g_elasticity_variant = 0;  // bit 0: the matrix row-owner kernel with in-place global accumulation; bit 1: the residual kernel that integrates per adjacent control point (both kept for comparison)
 extern "C" int mfem_debug_set_elasticity(int variant) {
   ++mfem_debug_epoch;
-  g_elasticity_variant = variant & 3;
+  g_elasticity_variant = variant & 0x1f;  // bits 2-4: timing-only ablations of the matrix kernel (no phases / no write-out / no integration)
   return MFEM_OK;
 }
 
@@ -1258,7 +1341,7 @@ extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mf
   if (!(g_elasticity_variant & 1)) {  // one thread per (control point, element), rows accumulated in LDS, written once
     const int grid = (int)((m->n_owned + EL2_NODES - 1) / EL2_NODES);
     hipLaunchKernelGGL(k_elasticity_matrix_lds, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->lambda, p->mu, p->tau,
-                       p->penalty_faces, T, vals);
+                       p->penalty_faces, T, vals, g_elasticity_variant >> 2);
     MFEM_CHECK_LAUNCH();
     return MFEM_OK;
   }

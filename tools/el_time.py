@@ -23,3 +23,7 @@ print("residual per-point ms", t(f))
 _lib.lib.mfem_debug_set_elasticity(0)
 K = torch.empty(A.nnz, dtype=torch.float64, device="cuda")
 print("matrix ms", t(lambda: b.assemble_elasticity(A, lam, mu, 1000.0, mf.FACE_BITS["x0"], out=K)))
+for bits, what in ((4, "no accumulation phases"), (8, "no write-out"), (16, "no integration"), (12, "no phases, no write-out"), (28, "nothing but loads")):
+    _lib.lib.mfem_debug_set_elasticity(bits)
+    print("matrix ms,", what, t(lambda: b.assemble_elasticity(A, lam, mu, 1000.0, mf.FACE_BITS["x0"], out=K)))
+_lib.lib.mfem_debug_set_elasticity(0)
