@@ -900,7 +900,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, d
 // in LDS in eight ordered phases (element 0 .. 7: the same summation order as the row-owner kernel, so the results are bitwise
 // identical) and leave as contiguous runs, every CSR value written exactly once -- no memset, no atomics, no colours.
 #define EL2_NODES 32
-#define EL2_ROW 244  // 3 fields x 81 slots, padded
+#define EL2_ROW 243  // 3 fields x 81 slots; an ODD number of doubles: the lanes of a step (one control point each) then spread over all banks (244: 1.94 -> 2.04 ms)
 // G[b][s][t] = sum_q w det d_sN_a d_tN_b for the row node a = AH + 1 - ex of the thread's element
 template <int AH>
 __device__ __forceinline__ void el2_integrate(const double (&C)[7][3], int nq, int ex, double (&G)[8][3][3]) {
@@ -1047,7 +1047,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
       const double* src = rows + n2 * EL2_ROW + f * 81;
 #pragma unroll
       for (int o = l32; o < 81; o += 32)
-        if (o < c3) dst[o] = src[o];
+        if (o < c3) {
+          __builtin_nontemporal_store(src[o], dst + o);  // (K is not read again by this kernel: 1.94 -> 1.79 ms)
+        }
     }
   }
 }
