@@ -75,9 +75,10 @@ int mfem_debug_set_halo_overlap(int on);
  * 16 GiB scratch budget). */
 int mfem_debug_set_hex27(int two_pass);
 /* hex-8 elasticity kernels.  Bit 0: matrix -- 0 (default) thread per (control point, element) with the rows accumulated in LDS and
- * written once; 1 the earlier row-owner kernel accumulating in global memory (same values bitwise).  Bit 1: residual -- 0 (default) the
- * plane-sweep kernel with one sum-factorised integration per element (2-point Gauss rule); 1 the kernel that integrates an
- * element once per adjacent control point (table form; equal to round-off). */
+ * written once; 1 the earlier row-owner kernel accumulating in global memory (equal to round-off: other summation order, table form of
+ * the Jacobian).  Bit 1: residual -- 0 (default) the plane-sweep kernel with one sum-factorised integration per element (2-point Gauss
+ * rule); 1 the kernel that integrates an element once per adjacent control point (table form; equal to round-off).  Bits 2-4: TIMING-ONLY
+ * ablations of the default matrix kernel (wrong values): no accumulation steps / no write-out / no integration (tools/el_time.py). */
 int mfem_debug_set_elasticity(int variant);
 /* hex-8 thermal matrix / residual kernels: 0 (default) the plane-sweep kernels with sum-factorised element integration
  * (2- and 3-point Gauss rules; other rules always use the tile kernels); 1 the 4 x 4 x 8 tile kernels with the table form. */

@@ -897,8 +897,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, d
 // Same operator, one thread per (control point, adjacent element): a workgroup owns 32 consecutive control points, its
 // 256 threads integrate the 8 adjacent elements of each of them concurrently (the row-owner kernel above walks them one after
 // the other and read-modify-writes global memory 576 times per thread).  The three rows of a control point are accumulated
-// in LDS in eight ordered phases (element 0 .. 7: the same summation order as the row-owner kernel, so the results are bitwise
-// identical) and leave as contiguous runs, every CSR value written exactly once -- no memset, no atomics, no colours.
+// in LDS in eight conflict-free steps (see below; fixed summation order: a second assembly gives the same bits, the row-owner kernel's
+// order is the reverse, equal to round-off) and leave as contiguous runs, every CSR value written exactly once -- no memset, no atomics,
+// no colours.  128^3: 1.80 ms (profiles/r03_elasticity_matrix_steps.txt).
 #define EL2_NODES 32
 #define EL2_ROW 243  // 3 fields x 81 slots; an ODD number of doubles: the lanes of a step (one control point each) then spread over all banks (244: 1.94 -> 2.04 ms)
 // G[b][s][t] = sum_q w det d_sN_a d_tN_b for the row node a = AH + 1 - ex of the thread's element

@@ -31,7 +31,8 @@ def _oracle(x, n, distort=False, itg=3):
     return od
 
 
-@pytest.mark.parametrize("n,distort,itg", [((1, 1, 1), False, 3), ((3, 2, 2), False, 3), ((4, 3, 5), True, 3), ((3, 3, 2), True, 5)])
+@pytest.mark.parametrize("n,distort,itg", [((1, 1, 1), False, 3), ((3, 2, 2), False, 3), ((4, 3, 5), True, 3), ((3, 3, 2), True, 5),
+                                           ((5, 6, 7), True, 3)])  # (336 control points: blocks of 32 that wrap lines and planes)
 def test_elasticity_pattern_matrix_residual(mf, n, distort, itg):
     import torch
 
@@ -49,6 +50,8 @@ def test_elasticity_pattern_matrix_residual(mf, n, distort, itg):
     assert np.array_equal(A.colidx.cpu().numpy(), od.pattern.colidx)
     K = brick.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"]).cpu().numpy()
     assert np.max(np.abs(K - od.K_linear)) <= 2e-13 * np.max(np.abs(od.K_linear))
+    # fixed order of the accumulation steps, no atomics: a second assembly gives the same bits
+    assert np.array_equal(K, brick.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"]).cpu().numpy())
     R = brick.residual_elasticity(torch.tensor(od.x_star, device="cuda"), LAM, MU, TAU, mf.FACE_BITS["x0"],
                                   mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.0)).cpu().numpy()
     assert np.max(np.abs(R - od.residue)) <= 1e-12 * np.max(np.abs(od.residue))
