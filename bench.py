@@ -102,8 +102,34 @@ def self_launch(n_ranks: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's stdout is drained by a thread while all ranks are watched: a rank that dies early (no such device, import error) would leave
+    # the others waiting in the rendezvous for ever -- they are ended (these exact processes) and the failure is reported
+    import threading
+    import time
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            time.sleep(5.0)  # (let the others notice by themselves first)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=30)
+    out0 = chunks[0] if chunks else b""
+    rcs = [p.wait() for p in procs]
+    if failed:
+        print("bench.py: a rank exited with an error; the remaining ranks were ended", file=sys.stderr)
     # stdout carries the JSON line only (RCCL / gloo banners that reached rank 0's stdout go to stderr)
     lines = out0.decode(errors="replace").splitlines()
     json_lines = [ln for ln in lines if ln.startswith("{") and ln.rstrip().endswith("}")]

@@ -98,3 +98,21 @@ def test_falls_back_to_the_host_transport_when_the_rccl_self_test_fails():
     out = run_bench(["--gpus", "1", "--n", "40"] + SMALL, env={"MFEM_BENCH_FORCE_COMM": "1", "MFEM_BENCH_SIMULATE_RCCL_FAILURE": "1"})
     _common(out, 1)
     assert out["config"]["n_dof"] == 41 ** 3
+
+
+def test_self_launch_ends_the_other_ranks_when_one_dies():
+    """`python bench.py --gpus 2` on a box with ONE GPU and without the host-transport switch: rank 1 has no device and exits with an
+    error; the launcher must end rank 0 (which would wait in the rendezvous for ever) and report the failure instead of hanging."""
+    import time
+
+    import torch
+
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.pop("MFEM_BENCH_HOST_COMM", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "24"] + SMALL, capture_output=True, text=True,
+                       timeout=300, env=e, cwd=ROOT)
+    assert r.returncode != 0 and "ranks failed" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 200
