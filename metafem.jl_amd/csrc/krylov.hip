@@ -663,10 +663,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     rc_plan = mfem_lat27_plan(ctx, A);
     if (rc_plan) return rc_plan;
     lat_bytes = mfem_lat27_bytes(A);
-    if (!lat_bytes) {
+    if (!lat_bytes && mfem_lat8_for_method(A, is_cg)) {  // (asked first: the plan's entry-by-entry check of the pattern costs 27 ms at 512^3)
       rc_plan = mfem_lat8_plan(ctx, A);
       if (rc_plan) return rc_plan;
-      if (mfem_lat8_for_method(A, is_cg)) lat8_bytes = mfem_lat8_bytes(A);
+      if (mfem_lat8_for_method(A, is_cg)) lat8_bytes = mfem_lat8_bytes(A);  // (again: the plan may have inferred the number of fields)
     }
   }
   const bool lat_only = (lat_bytes || lat8_bytes) && !A->lat_refused;
