@@ -18,6 +18,8 @@ struct KrylovVecs {
   double* b;
   double* d;           // Jacobi vector (right preconditioner) or |diag| (CG)
   const double* dinv;  // CG only
+  const double* cg_s = nullptr;  // scaled CG (cg_variant 4): S = sqrt|diag|, its extremes (the solver iterates on S^-1 A S^-1)
+  double cg_smax = 1.0, cg_smin = 1.0;
   double* w[3 * MFEM_MAX_S + 8];
   int nwork;
 };

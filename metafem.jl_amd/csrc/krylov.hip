@@ -24,6 +24,25 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_fill(int64_t n, double v, double
 }
 
 // y = 1 / x  (only the first n entries; the pad stays 0)
+// d <- sqrt(d) ; out[0] = max, out[1] = min over the new d (bit patterns of non-negative doubles; out[1] starts at +inf)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sqrt_max(int64_t n, double* __restrict__ d, unsigned long long* __restrict__ out) {
+  double m = 0.0, lo = __builtin_huge_val();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = sqrt(d[i]);
+    d[i] = v;
+    m = fmax(m, v == v ? v : __builtin_huge_val());
+    lo = fmin(lo, v == v ? v : 0.0);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmax(m, __shfl_down(m, o, MFEM_WAVE));
+    lo = fmin(lo, __shfl_down(lo, o, MFEM_WAVE));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    atomicMin(out + 1, (unsigned long long)__double_as_longlong(lo));
+  }
+}
 __global__ __launch_bounds__(MFEM_BLOCK) void k_recip(int64_t n, const double* __restrict__ x, double* __restrict__ y) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = 1.0 / x[i];
@@ -115,6 +134,11 @@ struct CgArgs {
   int64_t n_owned;  // entries in front of the ghost entries / padding (zrec: dinv counts as 0 behind them, whatever the array holds there)
   int32_t zrec;     // the `r` array carries z = r .* dinv (cg_variant 3): k_cg_pupdate then reads neither r nor dinv -- 9 vector
                     // streams per iteration instead of 10; r.z and r.r come from r = z ./ dinv in k_cg_update
+  // scaled CG (cg_variant 4; sw = nullptr otherwise): the iteration runs on r^ = S^-1 r, the stop test wants |r|.  Far from convergence the
+  // kernels store the bound smax^2 |r^|^2 >= |r|^2 (no extra stream, the test cannot fire wrongly); once that bound is within gate2 of the
+  // tolerance they read S and store |S r^|^2 = |r|^2 itself -- the same stopping rule as the classic recurrence.
+  const d2_t* sw;
+  double smax2, gate2;
 };
 
 // z = r .* dinv ; p = z ; partials: [0,G) r.z  [G,2G) r.r
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init(CgArgs a, d2_t* __restri
   const double s1 = block_reduce_sum(rr, red);
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = s0;
-    partials[gridDim.x + blockIdx.x] = s1;
+    partials[gridDim.x + blockIdx.x] = a.sw ? s1 * a.smax2 : s1;
   }
 }
 
@@ -174,6 +198,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
   if (flags[F_DONE]) return;
   const double pap = np > 0 ? reduce_partials_bcast(pap_partials, np, red) : S[S_PAP];
   const double alpha = S[S_RZ0 + cur] / pap;
+  const bool exact = a.sw && S[S_RR] * a.n_inv <= a.gate2;  // (S[RR]: what the previous iteration stored; uniform over the grid)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double rz = 0.0, rr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
@@ -193,13 +218,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
       z = dinv ? rv * dinv[i] : rv;
     }
     rz += rv.x * z.x + rv.y * z.y;
-    rr += rv.x * rv.x + rv.y * rv.y;
+    if (exact) {
+      const d2_t t = a.sw[i] * rv;
+      rr += t.x * t.x + t.y * t.y;
+    } else {
+      rr += rv.x * rv.x + rv.y * rv.y;
+    }
   }
   const double s0 = block_reduce_sum(rz, red);
   const double s1 = block_reduce_sum(rr, red);
   if (threadIdx.x == 0) {
     partials2[blockIdx.x] = s0;
-    partials2[gridDim.x + blockIdx.x] = s1;
+    partials2[gridDim.x + blockIdx.x] = (a.sw && !exact) ? s1 * a.smax2 : s1;
   }
 }
 
@@ -272,8 +302,14 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   a.tol = tol;
   a.maxiter = o->maxiter;
   a.fixed = o->fixed_iterations;
-  a.zrec = (o->cg_variant == 3 || (o->cg_variant == 0 && mfem_comm_world(ctx) <= 1)) ? 1 : 0;
+  a.zrec = (dinv && (o->cg_variant == 3 || (o->cg_variant == 0 && mfem_comm_world(ctx) <= 1))) ? 1 : 0;
   a.n_owned = V.n;
+  a.sw = (const d2_t*)V.cg_s;
+  a.smax2 = V.cg_smax * V.cg_smax;
+  {
+    const double ratio = V.cg_smin > 0.0 ? V.cg_smax / V.cg_smin : __builtin_huge_val();
+    a.gate2 = 16.0 * tol * tol * ratio * ratio;
+  }
   double* part1 = ctx->d_partials;                          // SpMV p.Ap partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;       // 2 x G
   int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
@@ -298,6 +334,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations); key = mfem_hash(key, a.zrec);
+  key = mfem_hash(key, V.cg_s); key = mfem_hash(key, a.smax2); key = mfem_hash(key, a.gate2);
   int it = 0;
   // flag banks: iteration `it` reads bank it & 1 (k_cg_init_fin fills bank 0) and leaves the next state in the other one
   for (;;) {
@@ -629,7 +666,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const int64_t n = A->n;
   if (n == 0) return MFEM_OK;
   const int s_param = o->l_or_s > 0 ? o->l_or_s : (o->method == MFEM_SOLVER_IDRS ? 4 : 2);
-  MFEM_REQUIRE(o->cg_variant >= 0 && o->cg_variant <= 3, "cg_variant must be 0 (auto), 1 (classic), 2 (single reduction) or 3 (classic, preconditioned residual carried)");
+  MFEM_REQUIRE(o->cg_variant >= 0 && o->cg_variant <= 4, "cg_variant must be 0 (auto), 1 (classic), 2 (single reduction), 3 (classic, preconditioned residual carried) or 4 (plain CG on the symmetrically scaled matrix)");
   // one reduction group per CG iteration where a reduction costs an all-reduce; the classic recurrence otherwise
   const bool cg_single = o->method == MFEM_SOLVER_CG && (o->cg_variant == 2 || (o->cg_variant == 0 && mfem_comm_world(ctx) > 1));
   MFEM_REQUIRE(s_param <= MFEM_MAX_S, "l_or_s too large");
@@ -742,7 +779,41 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // Pr = Pr_func!(A)   (02_Preconditioner.jl:38, 103-120)
   V.dinv = nullptr;
   bool ell_bound = false;
-  if (jac) {
+  // cg_variant 4: plain CG on S^-1 A S^-1, S = sqrt|diag A| -- the Jacobi-preconditioned iteration in the variables S x, without the stream of
+  // 1 / d in its vector kernels (8 instead of 9 per iteration).  The scaling is folded into the layout copy; taken where the symmetric patch
+  // sweep (mode 2) serves the pattern and these values pass its check, one rank; otherwise the classic recurrence below runs.
+  bool cg_scaled = false;
+  double s_max = 1.0;
+  if (jac && is_cg && (o->cg_variant == 4 || o->cg_variant == 0) && o->precond != MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !left && !ctx->comm && ell_bytes &&
+      !lat8_bound && mfem_symp_wanted(A)) {
+    rc = mfem_fill(ctx, n, 1.0, V.d);
+    if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
+    if (rc) return rc;
+    unsigned long long* d_stat = (unsigned long long*)(ctx->d_flags + 12);  // [12,13]: max, [14,15]: min
+    MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
+    MFEM_CHECK_HIP(hipMemsetAsync(d_stat + 1, 0x7f, sizeof(unsigned long long), ctx->stream));  // (0x7f7f...: a huge finite double)
+    hipLaunchKernelGGL(k_sqrt_max, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.d, d_stat);
+    MFEM_CHECK_LAUNCH();
+    rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), nullptr, V.d);  // (synchronises: the check's verdict)
+    if (rc) return rc;
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    double s_min = 0.0;
+    memcpy(&s_max, ctx->h_flags + 12, sizeof(double));
+    memcpy(&s_min, ctx->h_flags + 14, sizeof(double));
+    if (A->ell_vals && A->symp_bound && s_min > 0.0 && s_max < __builtin_huge_val()) {
+      cg_scaled = true;
+      ell_bound = true;
+      V.cg_s = V.d;
+      V.cg_smax = s_max;
+      V.cg_smin = s_min;
+      hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.b, V.d, V.b);  // b^ = S^-1 b
+      MFEM_CHECK_LAUNCH();
+    } else {
+      mfem_ell_unbind(A);  // (not symmetric after all: the classic recurrence on an unscaled copy)
+    }
+  }
+  if (jac && !cg_scaled) {
     if (o->precond == MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !is_cg) {
       rc = mfem_jacobi2_by_column(ctx, A, vals_src, V.d);
     } else if (is_cg && ell_bytes && !lat8_bound) {
@@ -836,7 +907,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
 
   int pass = 1, total_iters = 0, spmvs = 0;
   double res = res0;
-  double tol_factor = 1.0;  // only a left preconditioner moves it (:57-59)
+  double tol_factor = 1.0;  // only a left preconditioner moves it (:57-59); the scaled CG's kernels test the true residual themselves
   for (;;) {
     int it = 0;
     switch (o->method) {
@@ -866,10 +937,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     rc = mfem_read_scalars(ctx, S_RR, 1);
     if (rc) return rc;
     res = sqrt(ctx->h_scalars[S_RR] * n_inv);
-    if (left) {
-      // w0 holds the row-scaled residual Pl(r): res above is the preconditioned one; the true one is ||D_l w0|| (:57-59)
+    if (left || cg_scaled) {
+      // w0 holds the row-scaled residual Pl(r) (scaled CG: S^-1 r): res above is the preconditioned one; the true one is ||D_l w0|| (:57-59)
       const double pres = res;
-      hipLaunchKernelGGL(k_mul, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.w[0], dl, V.w[0]);
+      hipLaunchKernelGGL(k_mul, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.w[0], cg_scaled ? V.d : dl, V.w[0]);
       MFEM_CHECK_LAUNCH();
       rc = mfem_dot_device(ctx, n, V.w[0], V.w[0], ctx->d_scalars + S_RR);
       if (rc) return rc;
@@ -880,13 +951,13 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       rc = mfem_read_scalars(ctx, S_RR, 1);
       if (rc) return rc;
       res = sqrt(ctx->h_scalars[S_RR] * n_inv);
-      tol_factor = res > 0.0 ? fmin(pres / res, 1.0) : 1.0;
+      if (left) tol_factor = res > 0.0 ? fmin(pres / res, 1.0) : 1.0;
     }
     if (o->fixed_iterations || res < o->converge_tol || pass >= o->max_pass) break;
     ++pass;
   }
   // return Pr(x) = x ./ d  (:75, 93-96)
-  if (jac && !is_cg) {
+  if ((jac && !is_cg) || cg_scaled) {  // (scaled CG: x = S^-1 x^)
     hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.x, V.d, x_out);
     MFEM_CHECK_LAUNCH();
   } else {

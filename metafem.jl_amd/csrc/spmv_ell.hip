@@ -299,7 +299,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
                                                            int base, const DiaOffsets* __restrict__ Op,
                                                            const int32_t* __restrict__ flags, double* __restrict__ out, SympGeom Gm,
-                                                           double* __restrict__ pv, const double* __restrict__ dsc) {
+                                                           double* __restrict__ pv, const double* __restrict__ dsc,
+                                                           const double* __restrict__ ssym) {
+  // ssym != nullptr: the copy is S^-1 A S^-1, entry / (ssym[row] * ssym[column]) with the PRODUCT formed first -- a mirrored pair then
+  // divides by the same number, so a bitwise symmetric matrix stays bitwise symmetric (the scaled CG, cg_variant 4)
   // dsc != nullptr: the copy is the right-Jacobi-scaled matrix, entry / dsc[its column] (Mat_Div_Jacobi folded into this pass; the
   // columns are then read for every tile)
   const DiaOffsets& O = *Op;
@@ -381,6 +384,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     }
     const int off0 = (int)(lo - s0);
     const int dir = half ? -1 : 1;
+    const double sr = (ssym && r < n) ? ssym[r] : 1.0;
+    auto sym_scaled = [&](double a, int64_t c) -> double { return ssym ? a / (sr * ssym[c]) : a; };
     auto colat = [&](int j) -> int64_t { return stage_cols ? (int64_t)Tc[off0 + j] : (int64_t)col[lo + j] - base; };
     if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         const bool act = half == 0 || t < 13;
         double v = 0.0;
         if (act && j >= 0 && j < len && (full || colat(j) - r == O.off[cls][sl])) {
-          v = T[off0 + j];
+          v = sym_scaled(T[off0 + j], r + O.off[cls][sl]);
           j += dir;
         }
         if (!act) continue;
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         for (int sl = 0; sl < Dh; ++sl) {
           double v = 0.0;
           if (j < len && (full || colat(j) - r == O.off[cls][sl])) {
-            v = T[off0 + j];
+            v = sym_scaled(T[off0 + j], r + O.off[cls][sl]);
             ++j;
           }
           DIA_ST(out + ell_base(r, K) + sl * ELL_B, v);
@@ -434,14 +439,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         for (int sl = D - 1; sl >= Dh; --sl) {
           double v = 0.0;
           if (j >= 0 && (full || colat(j) - r == O.off[cls][sl])) {
-            v = T[off0 + j];
+            v = sym_scaled(T[off0 + j], r + O.off[cls][sl]);
             --j;
           }
           DIA_ST(out + ell_base(r, K) + sl * ELL_B, v);
         }
       }
     } else {                 // generic block: slot s = s-th entry, columns come from ell_cols
-      for (int sl = half; sl < K; sl += LPR) out[ell_base(r, K) + sl * ELL_B] = sl < len ? T[off0 + sl] : 0.0;
+      for (int sl = half; sl < K; sl += LPR) out[ell_base(r, K) + sl * ELL_B] = sl < len ? sym_scaled(T[off0 + sl], colat(sl)) : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1344,6 +1349,7 @@ static bool symp_wanted(const mfem_csr_s* A) {
   return (int64_t)(A->symp_p1 - A->symp_p0) * A->symp_PL >= 24000000 || A->symp_m2 > 256;
 }
 static int symp_nseg(const mfem_context_s* ctx, const mfem_csr_s* A);
+bool mfem_symp_wanted(const mfem_csr_s* A) { return symp_wanted(A); }
 static SympGeom symp_geom(const mfem_context_s* ctx, const mfem_csr_s* A) {
   SympGeom G;
   G.PL = A->symp_PL;
@@ -1410,7 +1416,7 @@ size_t mfem_ell_vals_bytes(const mfem_csr_s* A) {
 // Transpose CSR-ordered values into `buf` and route subsequent mfem_spmv_launch calls with these `vals` to the ELL kernel.
 // dsc (optional): right Jacobi column scaling applied on the way (copy = vals[j] / dsc[col[j]]): the Krylov loop then runs on the scaled
 // matrix without a scaled CSR copy ever existing (solve_inner).  `vals` stays the identity of the bound values.
-int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc) {
+int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, const double* ssym) {
   A->ell_vals = nullptr;
   A->ell_src = nullptr;
   A->ell_bound_mode = 0;
@@ -1433,7 +1439,7 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
 #define DV_LAUNCH(RP, LPR_)                                                                                                        \
   hipLaunchKernelGGL((k_dia_vals<RP, LPR_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
-                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc)
+                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc, ssym)
       if (A->rowptr_bits == 64) {
         if (lpr == 2) DV_LAUNCH(int64_t, 2); else DV_LAUNCH(int64_t, 1);
       } else {
@@ -1838,7 +1844,7 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
     if (bytes) {
       rc = mfem_ws_reserve(ctx, bytes);
       if (rc) return rc;
-      rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr);
+      rc = mfem_ell_bind(ctx, A, vals, (double*)ctx->ws, nullptr, nullptr);
       if (rc) return rc;
     } else {
       rc = mfem_sell_plan(ctx, A);

@@ -474,6 +474,48 @@ def test_cg_with_symmetric_sweep_matches_plain_kernel(mf):
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
 
 
+def test_scaled_cg_matches_the_jacobi_recurrence(mf):
+    """cg_variant 4: plain CG on S^-1 A S^-1 (S = sqrt|diag|, folded into the sweep layout's copy with the product s_r s_c formed first, so the
+    mirrored sweep still applies) -- the Jacobi-preconditioned iteration without the 1 / d stream.  On a matrix whose diagonal varies by three
+    orders of magnitude: the sweep kernel runs, the solution equals the classic recurrence's to 1e-9 and the TRUE residual meets the tolerance;
+    with unsymmetric values the variant falls back to the classic recurrence on the plain kernel."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick, A, K = _sym_brick(mf)
+    n = A.n
+    # symmetric rescaling of the thermal matrix: K' = T K T with T = diag(t), t in [1, 30] -- stays bitwise symmetric (t_r * t_c formed first)
+    t = 1.0 + 29.0 * mf.FEM_rand(n, 3, 0)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (A.rowptr[1:] - A.rowptr[:-1]).long())
+    cols = A.colidx.long() - int(getattr(A, "index_base", 0))
+    Kt = K * (t[rows] * t[cols])
+    b = mf.FEM_rand(n, 11, 0) - 0.5
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        c0 = _lib.lib.mfem_debug_sym_spmv_count()
+        x3, st3 = mf.iterative_Solve(A, Kt, b, 1e-10, Sv_func=mf.cg_, maxiter=4000, max_pass=3, cg_variant=3)
+        c1 = _lib.lib.mfem_debug_sym_spmv_count()
+        x4, st4 = mf.iterative_Solve(A, Kt, b, 1e-10, Sv_func=mf.cg_, maxiter=4000, max_pass=3, cg_variant=4)
+        c2 = _lib.lib.mfem_debug_sym_spmv_count()
+        assert st3.converged == 1 and st4.converged == 1 and c1 > c0 and c2 > c1
+        assert float((x3 - x4).abs().max()) <= 1e-9 * float(x3.abs().max())
+        r = b.clone()
+        mf.mul_(r, A, Kt, x4, -1.0, 1.0)
+        assert float(r.norm()) / n ** 0.5 <= 1e-10
+        assert abs(st4.final_res - float(r.norm()) / n ** 0.5) <= 1e-3 * st4.final_res + 1e-14  # the reported residual is the true one
+        assert abs(st4.iterations - st3.iterations) <= 2  # (the same stopping rule: the kernels switch to the true residual norm near the tolerance)
+        # unsymmetric values: the classic recurrence on the plain kernel
+        rp = A.rowptr.cpu().numpy()
+        row = 7 * 4096 + 21 * 64 + 33
+        Ku = Kt.clone()
+        Ku[int(rp[row]) + 20] *= 1.0 + 1e-3
+        xa, sta = mf.iterative_Solve(A, Ku, b, 1e-30, Sv_func=mf.cg_, maxiter=30, max_pass=1, fixed_iterations=True, cg_variant=4)
+        xb, stb = mf.iterative_Solve(A, Ku, b, 1e-30, Sv_func=mf.cg_, maxiter=30, max_pass=1, fixed_iterations=True, cg_variant=1)
+        assert float((xa - xb).abs().max()) <= 1e-11 * float(xb.abs().max())
+    finally:
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
 def test_cg_graph_cache_follows_the_symmetry_of_the_values(mf):
     """Same buffers, first symmetric then unsymmetric values: the cached CG cycle graph of the sweep kernel must not be replayed
     on the unsymmetric matrix (the graph key carries the outcome of the per-solve symmetry check)."""
@@ -587,9 +629,18 @@ def test_patch_sweep_on_a_caller_supplied_symmetric_lattice_matrix(mf, rp_dtype,
         K2 = K.clone()
         K2[k] = torch.nextafter(K2[k], torch.tensor(float("inf"), dtype=torch.float64, device="cuda"))
         before = _lib.lib.mfem_debug_sym_spmv_count()
-        x2, st2 = mf.iterative_Solve(A, K2, torch.tensor(b, device="cuda"), tol, Sv_func=mf.cg_, maxiter=500, max_pass=3)
+        x2, st2 = mf.iterative_Solve(A, K2, torch.tensor(b, device="cuda"), tol, Sv_func=mf.cg_, maxiter=500, max_pass=3, cg_variant=3)
         assert st2.converged == 1 and _lib.lib.mfem_debug_sym_spmv_count() == before
         assert np.abs(x2.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+        # the default on this layout is the scaled CG (cg_variant 4): its check sees the SCALED copy a / (s_r s_c), where a difference of one ulp
+        # can vanish in the rounding of the division (the iteration then runs on a matrix that IS symmetric); eight ulps cannot
+        K3 = K.clone()
+        for _ in range(8):
+            K3[k] = torch.nextafter(K3[k], torch.tensor(float("inf"), dtype=torch.float64, device="cuda"))
+        before = _lib.lib.mfem_debug_sym_spmv_count()
+        x3, st3 = mf.iterative_Solve(A, K3, torch.tensor(b, device="cuda"), tol, Sv_func=mf.cg_, maxiter=500, max_pass=3)
+        assert st3.converged == 1 and _lib.lib.mfem_debug_sym_spmv_count() == before
+        assert np.abs(x3.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
     finally:
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
 
