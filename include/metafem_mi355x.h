@@ -184,7 +184,14 @@ typedef struct {
                                3: the classic recurrence carrying z = M^-1 r instead of r (z -= alpha M^-1 A p; r = M z only inside the
                                kernel that needs r.z and r.r): the p update then reads neither r nor M^-1 -- 9 vector streams per
                                iteration instead of 10; same iterates in exact arithmetic, round-off-level differences.
-                               0 = auto: 2 when a communicator with more than one rank is attached, else 3. */
+                               4: plain CG on S^-1 A S^-1, S = sqrt|diag A| -- the Jacobi-preconditioned iteration in the variables
+                               S x, 8 vector streams per iteration (no M^-1 stream).  The scaling is folded into the solver layout's
+                               copy as a / (s_r s_c) with the product formed first (a bitwise symmetric matrix stays so; an asymmetry
+                               of one ulp can vanish in that rounding -- the iteration then runs on a symmetric matrix); the kernels
+                               stop on the TRUE residual norm (they read S once the bound smax |S^-1 r| comes near the tolerance).
+                               Taken where the mirrored patch sweep (mode 2) serves the pattern and these values pass its check, one
+                               rank, Jacobi by the diagonal; otherwise 3 runs.
+                               0 = auto: 2 when a communicator with more than one rank is attached, else 4 where it applies, else 3. */
 } mfem_solve_options;
 
 typedef struct {

@@ -241,7 +241,8 @@ def iterative_Solve(A: FEM_SpMat_CSR, K_vals: torch.Tensor, residue: torch.Tenso
     """iterative_Solve!(globalfield; Sv_func!, Pr_func!, Pl_func, max_pass, maxiter, s) (02_Preconditioner.jl:32-76).
     Pl_func: Identity, Pl_Jacobi_ (:155-168) or Pl_Jacobi_rownorm_ (normalized_by_row = true).
     cg_variant (cg_ only): 0 auto, 1 classic recurrence, 2 single reduction group per iteration (Chronopoulos-Gear), 3 classic
-    recurrence carrying the preconditioned residual (one vector stream less per iteration; auto on one rank).
+    recurrence carrying the preconditioned residual (one vector stream less per iteration), 4 plain CG on the symmetrically Jacobi-scaled
+    matrix (one stream less again; on the mirrored-sweep layout, one rank: the auto choice there, else 3).
 
     Returns (delta_x, stats); delta_x is a NEW device vector like the reference's return value.
     """
