@@ -189,8 +189,8 @@ typedef struct {
                                copy as a / (s_r s_c) with the product formed first (a bitwise symmetric matrix stays so; an asymmetry
                                of one ulp can vanish in that rounding -- the iteration then runs on a symmetric matrix); the kernels
                                stop on the TRUE residual norm (they read S once the bound smax |S^-1 r| comes near the tolerance).
-                               Taken where the mirrored patch sweep (mode 2) serves the pattern and these values pass its check, one
-                               rank, Jacobi by the diagonal; otherwise 3 runs.
+                               Taken on the diagonal-slotted solver layout (mode 2, mirrored or plain kernels), one rank, Jacobi by the
+                               diagonal, a positive finite diagonal; otherwise 3 runs.
                                0 = auto: 2 when a communicator with more than one rank is attached, else 4 where it applies, else 3. */
 } mfem_solve_options;
 

@@ -217,6 +217,7 @@ bool mfem_sell_bound(const mfem_csr_s* A, const double* vals);  // the sliced la
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_ell_vals_bytes(const mfem_csr_s* A);
 int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, const double* ssym = nullptr);
+bool mfem_dia_layout_planned(const mfem_csr_s* A);  // mfem_ell_bind would make the diagonal-slotted copy (mode 2)
 bool mfem_symp_wanted(const mfem_csr_s* A);  // the symmetric patch sweep (mode 2) would be tried for this pattern
 void mfem_ell_unbind(mfem_csr_s* A);
 int mfem_ell_diag(mfem_context_s* ctx, mfem_csr_s* A, double* d);

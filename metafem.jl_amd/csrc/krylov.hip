@@ -780,12 +780,12 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   V.dinv = nullptr;
   bool ell_bound = false;
   // cg_variant 4: plain CG on S^-1 A S^-1, S = sqrt|diag A| -- the Jacobi-preconditioned iteration in the variables S x, without the stream of
-  // 1 / d in its vector kernels (8 instead of 9 per iteration).  The scaling is folded into the layout copy; taken where the symmetric patch
-  // sweep (mode 2) serves the pattern and these values pass its check, one rank; otherwise the classic recurrence below runs.
+  // 1 / d in its vector kernels (8 instead of 9 per iteration).  The scaling is folded into the diagonal-slotted layout copy (mode 2: plain or
+  // mirrored kernels alike -- a bitwise symmetric matrix stays one), one rank; otherwise the classic recurrence below runs.
   bool cg_scaled = false;
   double s_max = 1.0;
   if (jac && is_cg && (o->cg_variant == 4 || o->cg_variant == 0) && o->precond != MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !left && !ctx->comm && ell_bytes &&
-      !lat8_bound && mfem_symp_wanted(A)) {
+      !lat8_bound && mfem_dia_layout_planned(A)) {
     rc = mfem_fill(ctx, n, 1.0, V.d);
     if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
     if (rc) return rc;
@@ -801,7 +801,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     double s_min = 0.0;
     memcpy(&s_max, ctx->h_flags + 12, sizeof(double));
     memcpy(&s_min, ctx->h_flags + 14, sizeof(double));
-    if (A->ell_vals && A->symp_bound && s_min > 0.0 && s_max < __builtin_huge_val()) {
+    if (A->ell_vals && A->ell_bound_mode == 2 && s_min > 0.0 && s_max < __builtin_huge_val()) {
       cg_scaled = true;
       ell_bound = true;
       V.cg_s = V.d;
@@ -810,7 +810,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.b, V.d, V.b);  // b^ = S^-1 b
       MFEM_CHECK_LAUNCH();
     } else {
-      mfem_ell_unbind(A);  // (not symmetric after all: the classic recurrence on an unscaled copy)
+      mfem_ell_unbind(A);  // (no diagonal-slotted copy after all, or a zero / non-finite diagonal: the classic recurrence on an unscaled copy)
     }
   }
   if (jac && !cg_scaled) {

@@ -1350,6 +1350,7 @@ static bool symp_wanted(const mfem_csr_s* A) {
 }
 static int symp_nseg(const mfem_context_s* ctx, const mfem_csr_s* A);
 bool mfem_symp_wanted(const mfem_csr_s* A) { return symp_wanted(A); }
+bool mfem_dia_layout_planned(const mfem_csr_s* A) { return A->ell_state == 1 && g_ell_enable && A->dia_state == 1 && g_dia_enable; }
 static SympGeom symp_geom(const mfem_context_s* ctx, const mfem_csr_s* A) {
   SympGeom G;
   G.PL = A->symp_PL;
