@@ -189,9 +189,12 @@ typedef struct {
                                copy as a / (s_r s_c) with the product formed first (a bitwise symmetric matrix stays so; an asymmetry
                                of one ulp can vanish in that rounding -- the iteration then runs on a symmetric matrix); the kernels
                                stop on the TRUE residual norm (they read S once the bound smax |S^-1 r| comes near the tolerance).
-                               Taken on the diagonal-slotted solver layout (mode 2, mirrored or plain kernels), one rank, Jacobi by the
-                               diagonal, a positive finite diagonal; otherwise 3 runs.
-                               0 = auto: 2 when a communicator with more than one rank is attached, else 4 where it applies, else 3. */
+                               Taken on the diagonal-slotted solver layout (mode 2, mirrored or plain kernels), Jacobi by the diagonal,
+                               a positive finite diagonal on every rank (ghost columns are divided by their owners' S); otherwise 3
+                               runs.  With more than one rank and cg_variant 0 the single-reduction form runs on the scaled system
+                               (9 vector streams instead of 10: its u IS r).
+                               0 = auto: the single-reduction form when a communicator with more than one rank is attached, the
+                               two-reduction form otherwise -- each on the scaled system where that applies. */
 } mfem_solve_options;
 
 typedef struct {

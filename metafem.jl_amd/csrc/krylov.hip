@@ -430,7 +430,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_init(CgArgs a, const d2_t* 
   const double s1 = block_reduce_sum(rr, red);
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = s0;
-    partials[gridDim.x + blockIdx.x] = s1;
+    partials[gridDim.x + blockIdx.x] = a.sw ? s1 * a.smax2 : s1;  // (scaled CG: the bound, see CgArgs)
   }
 }
 
@@ -483,6 +483,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_update(CgArgs a, const d2_t
   if (flags[F_DONE]) return;
   const double alpha = S[S_CG_ALPHA], beta = S[S_CG_BETA];
   const bool first = beta == 0.0;  // p and s hold nothing yet (or leftovers of an earlier pass)
+  const bool exact = a.sw && S[S_RR] * a.n_inv <= a.gate2;  // scaled CG: |r| itself instead of its bound (a rank's own gate: the sum over
+                                                            // ranks of bounds and exact parts is still a bound)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double ru = 0.0, rr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
@@ -500,6 +502,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_update(CgArgs a, const d2_t
       z = uv - alpha * (sn * dv);
       rv.x = dv.x != 0.0 ? z.x * recip_nr(dv.x) : 0.0;
       rv.y = dv.y != 0.0 ? z.y * recip_nr(dv.y) : 0.0;
+    } else if (a.zrec) {  // no preconditioner (scaled CG, Identity): u IS r -- 9 vector streams, r neither read nor written
+      z = uv - alpha * sn;
+      rv = z;
+      if (2 * i >= a.n_owned) rv.x = 0.0;  // (ghost entries and padding take no part in the sums)
+      if (2 * i + 1 >= a.n_owned) rv.y = 0.0;
     } else {
       rv = r[i] - alpha * sn;
       r[i] = rv;
@@ -510,13 +517,19 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_update(CgArgs a, const d2_t
     // r is 0 by the mask above, but 0 * NaN is NaN -- keep them out of the sums explicitly
     if (2 * i < a.n_owned) ru += rv.x * z.x;
     if (2 * i + 1 < a.n_owned) ru += rv.y * z.y;
-    rr += rv.x * rv.x + rv.y * rv.y;
+    if (exact) {
+      const d2_t sc = a.sw[i];
+      if (2 * i < a.n_owned) rr += (sc.x * rv.x) * (sc.x * rv.x);
+      if (2 * i + 1 < a.n_owned) rr += (sc.y * rv.y) * (sc.y * rv.y);
+    } else {
+      rr += rv.x * rv.x + rv.y * rv.y;
+    }
   }
   const double s0 = block_reduce_sum(ru, red);
   const double s1 = block_reduce_sum(rr, red);
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = s0;
-    partials[gridDim.x + blockIdx.x] = s1;
+    partials[gridDim.x + blockIdx.x] = (a.sw && !exact) ? s1 * a.smax2 : s1;
   }
 }
 
@@ -533,8 +546,14 @@ static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   a.tol = tol;
   a.maxiter = o->maxiter;
   a.fixed = o->fixed_iterations;
-  a.zrec = 1;  // 10 vector streams in k_cgcg_update instead of 12
+  a.zrec = 1;  // 10 vector streams in k_cgcg_update instead of 12 (9 without a preconditioner: u is r)
   a.n_owned = V.n;
+  a.sw = (const d2_t*)V.cg_s;
+  a.smax2 = V.cg_smax * V.cg_smax;
+  {
+    const double ratio = V.cg_smin > 0.0 ? V.cg_smax / V.cg_smin : __builtin_huge_val();
+    a.gate2 = 16.0 * tol * tol * ratio * ratio;
+  }
   double* part1 = ctx->d_partials;                      // SpMV w.u partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;   // 2 x G: r.u, r.r
   double* T = S + S_TMP0;
@@ -570,6 +589,7 @@ static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations);
+  key = mfem_hash(key, V.cg_s); key = mfem_hash(key, a.smax2); key = mfem_hash(key, a.gate2);
   auto iteration = [&]() -> int {
     hipLaunchKernelGGL(k_cgcg_update, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (const d2_t*)w, (const d2_t*)dinv, (d2_t*)u,
                        (d2_t*)p, (d2_t*)sv, (d2_t*)V.x, (d2_t*)r, S, F, part2);
@@ -784,7 +804,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // mirrored kernels alike -- a bitwise symmetric matrix stays one), one rank; otherwise the classic recurrence below runs.
   bool cg_scaled = false;
   double s_max = 1.0;
-  if (jac && is_cg && (o->cg_variant == 4 || o->cg_variant == 0) && o->precond != MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !left && !ctx->comm && ell_bytes &&
+  if (jac && is_cg && (o->cg_variant == 4 || o->cg_variant == 0) && o->precond != MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !left && ell_bytes &&
       !lat8_bound && mfem_dia_layout_planned(A)) {
     rc = mfem_fill(ctx, n, 1.0, V.d);
     if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals_work, V.d, 0);
@@ -794,6 +814,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     MFEM_CHECK_HIP(hipMemsetAsync(d_stat + 1, 0x7f, sizeof(unsigned long long), ctx->stream));  // (0x7f7f...: a huge finite double)
     hipLaunchKernelGGL(k_sqrt_max, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.d, d_stat);
     MFEM_CHECK_LAUNCH();
+    if (ctx->comm) {  // the ghost columns are divided by their owners' S
+      rc = mfem_comm_halo(ctx, V.d);
+      if (rc) return rc;
+    }
     rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), nullptr, V.d);  // (synchronises: the check's verdict)
     if (rc) return rc;
     MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -801,7 +825,17 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     double s_min = 0.0;
     memcpy(&s_max, ctx->h_flags + 12, sizeof(double));
     memcpy(&s_min, ctx->h_flags + 14, sizeof(double));
-    if (A->ell_vals && A->ell_bound_mode == 2 && s_min > 0.0 && s_max < __builtin_huge_val()) {
+    bool ok = A->ell_vals && A->ell_bound_mode == 2 && s_min > 0.0 && s_max < __builtin_huge_val();
+    if (ctx->comm) {  // every rank iterates on the same system: scaled only if all of them can
+      ctx->h_scalars[S_TMP0] = ok ? 1.0 : 0.0;
+      MFEM_CHECK_HIP(hipMemcpyAsync(ctx->d_scalars + S_TMP0, ctx->h_scalars + S_TMP0, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      rc = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
+      if (rc) return rc;
+      rc = mfem_read_scalars(ctx, S_TMP0, 1);
+      if (rc) return rc;
+      ok = (int)(ctx->h_scalars[S_TMP0] + 0.5) == mfem_comm_world(ctx);
+    }
+    if (ok) {
       cg_scaled = true;
       ell_bound = true;
       V.cg_s = V.d;

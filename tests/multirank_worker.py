@@ -171,6 +171,9 @@ def main():
         x2, s2 = lsolve(mf.cg_)  # auto: single-reduction form with world > 1
         check(f"cg_single_reduction_{tag}", s2.converged == 1 and abs(s2.iterations - sg.iterations) <= 2 and relerr(x2, xg) <= 1e-10,
               iters=(s2.iterations, sg.iterations), rel_err=relerr(x2, xg))
+        x4, s4 = lsolve(mf.cg_, cg_variant=4)  # plain CG on S^-1 A S^-1 in the classic two-reduction form (on the mode-2 layout: the scaling of the
+        check(f"cg_scaled_classic_form_{tag}",  # ghost columns by their owners' S; elsewhere variant 3 runs), world ranks
+              s4.converged == 1 and abs(s4.iterations - sg.iterations) <= 2 and relerr(x4, xg) <= 1e-10, iters=(s4.iterations, sg.iterations), rel_err=relerr(x4, xg))
         xg2, sg2 = gsolve(mf.cg_, cg_variant=2)  # the single-reduction form on one rank
         check(f"cg_single_reduction_one_rank_{tag}", sg2.converged == 1 and relerr(owned_t(xg2, owned, dev), xg) <= 1e-10,
               iters=(sg2.iterations, sg.iterations))
