@@ -24,12 +24,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_fill(int64_t n, double v, double
 }
 
 // y = 1 / x  (only the first n entries; the pad stays 0)
-// d <- sqrt(d) ; out[0] = max, out[1] = min over the new d (bit patterns of non-negative doubles; out[1] starts at +inf)
-__global__ __launch_bounds__(MFEM_BLOCK) void k_sqrt_max(int64_t n, double* __restrict__ d, unsigned long long* __restrict__ out) {
+// d <- sqrt(d), t <- 1 / sqrt(d) ; out[0] = max, out[1] = min over the new d (bit patterns of non-negative doubles; out[1] starts huge)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sqrt_max(int64_t n, double* __restrict__ d, double* __restrict__ t, unsigned long long* __restrict__ out) {
   double m = 0.0, lo = __builtin_huge_val();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const double v = sqrt(d[i]);
     d[i] = v;
+    t[i] = 1.0 / v;
     m = fmax(m, v == v ? v : __builtin_huge_val());
     lo = fmin(lo, v == v ? v : 0.0);
   }
@@ -804,8 +805,8 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // mirrored kernels alike -- a bitwise symmetric matrix stays one), one rank; otherwise the classic recurrence below runs.
   bool cg_scaled = false;
   double s_max = 1.0;
-  // (auto: not for passes of fewer than 64 iterations -- the scaled copy costs ~1.5 ms more per solve at 256^3 than the plain one, an iteration
-  // saves 0.026 ms there)
+  // (auto: not for passes of fewer than 64 iterations -- the scaled copy and its S vectors cost 1.2 ms more per solve at 256^3 than the plain
+  // path, an iteration saves 0.026 ms there: tools/cg_per_solve.py)
   if (jac && is_cg && (o->cg_variant == 4 || (o->cg_variant == 0 && o->maxiter >= 64)) && o->precond != MFEM_PRECOND_JACOBI_RIGHT_COLNORM && !left &&
       ell_bytes && !lat8_bound && mfem_dia_layout_planned(A)) {
     rc = mfem_fill(ctx, n, 1.0, V.d);
@@ -814,13 +815,13 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     unsigned long long* d_stat = (unsigned long long*)(ctx->d_flags + 12);  // [12,13]: max, [14,15]: min
     MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
     MFEM_CHECK_HIP(hipMemsetAsync(d_stat + 1, 0x7f, sizeof(unsigned long long), ctx->stream));  // (0x7f7f...: a huge finite double)
-    hipLaunchKernelGGL(k_sqrt_max, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.d, d_stat);
+    hipLaunchKernelGGL(k_sqrt_max, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.d, dinv_buf, d_stat);  // S and 1 / S
     MFEM_CHECK_LAUNCH();
-    if (ctx->comm) {  // the ghost columns are divided by their owners' S
-      rc = mfem_comm_halo(ctx, V.d);
+    if (ctx->comm) {  // the ghost columns are scaled by their owners' 1 / S
+      rc = mfem_comm_halo(ctx, dinv_buf);
       if (rc) return rc;
     }
-    rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), nullptr, V.d);  // (synchronises: the check's verdict)
+    rc = mfem_ell_bind(ctx, A, vals_work, (double*)(base + vec_bytes * (4 + nwork) + csr_copy_bytes), nullptr, dinv_buf);  // (synchronises: the check's verdict)
     if (rc) return rc;
     MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -843,7 +844,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       V.cg_s = V.d;
       V.cg_smax = s_max;
       V.cg_smin = s_min;
-      hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.b, V.d, V.b);  // b^ = S^-1 b
+      hipLaunchKernelGGL(k_mul, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.b, dinv_buf, V.b);  // b^ = S^-1 b
       MFEM_CHECK_LAUNCH();
     } else {
       mfem_ell_unbind(A);  // (no diagonal-slotted copy after all, or a zero / non-finite diagonal: the classic recurrence on an unscaled copy)
@@ -993,7 +994,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     ++pass;
   }
   // return Pr(x) = x ./ d  (:75, 93-96)
-  if ((jac && !is_cg) || cg_scaled) {  // (scaled CG: x = S^-1 x^)
+  if (cg_scaled) {  // x = S^-1 x^
+    hipLaunchKernelGGL(k_mul, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.x, dinv_buf, x_out);
+    MFEM_CHECK_LAUNCH();
+  } else if (jac && !is_cg) {
     hipLaunchKernelGGL(k_div, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, V.x, V.d, x_out);
     MFEM_CHECK_LAUNCH();
   } else {

@@ -301,8 +301,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
                                                            const int32_t* __restrict__ flags, double* __restrict__ out, SympGeom Gm,
                                                            double* __restrict__ pv, const double* __restrict__ dsc,
                                                            const double* __restrict__ ssym) {
-  // ssym != nullptr: the copy is S^-1 A S^-1, entry / (ssym[row] * ssym[column]) with the PRODUCT formed first -- a mirrored pair then
-  // divides by the same number, so a bitwise symmetric matrix stays bitwise symmetric (the scaled CG, cg_variant 4)
+  // ssym != nullptr: the copy is S^-1 A S^-1 with ssym = 1 / S, entry * (ssym[row] * ssym[column]) with the PRODUCT of the two factors formed
+  // first -- a mirrored pair is then multiplied by the same number, so a bitwise symmetric matrix stays bitwise symmetric (the scaled CG,
+  // cg_variant 4).  (Multiplying by reciprocals, not dividing: 27 divisions per row cost more than the rest of the placement.)
   // dsc != nullptr: the copy is the right-Jacobi-scaled matrix, entry / dsc[its column] (Mat_Div_Jacobi folded into this pass; the
   // columns are then read for every tile)
   const DiaOffsets& O = *Op;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     const int off0 = (int)(lo - s0);
     const int dir = half ? -1 : 1;
     const double sr = (ssym && r < n) ? ssym[r] : 1.0;
-    auto sym_scaled = [&](double a, int64_t c) -> double { return ssym ? a / (sr * ssym[c]) : a; };
+    auto sym_scaled = [&](double a, int64_t c) -> double { return ssym ? a * (sr * ssym[c]) : a; };
     auto colat = [&](int j) -> int64_t { return stage_cols ? (int64_t)Tc[off0 + j] : (int64_t)col[lo + j] - base; };
     if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
