@@ -186,7 +186,7 @@ typedef struct {
                                iteration instead of 10; same iterates in exact arithmetic, round-off-level differences.
                                4: plain CG on S^-1 A S^-1, S = sqrt|diag A| -- the Jacobi-preconditioned iteration in the variables
                                S x, 8 vector streams per iteration (no M^-1 stream).  The scaling is folded into the solver layout's
-                               copy as a / (s_r s_c) with the product formed first (a bitwise symmetric matrix stays so; an asymmetry
+                               copy as a * (t_r t_c), t = 1 / S, with the product t_r t_c formed first (a bitwise symmetric matrix stays so; an asymmetry
                                of one ulp can vanish in that rounding -- the iteration then runs on a symmetric matrix); the kernels
                                stop on the TRUE residual norm (they read S once the bound smax |S^-1 r| comes near the tolerance).
                                Taken on the diagonal-slotted solver layout (mode 2, mirrored or plain kernels), Jacobi by the diagonal,

@@ -475,7 +475,7 @@ def test_cg_with_symmetric_sweep_matches_plain_kernel(mf):
 
 
 def test_scaled_cg_matches_the_jacobi_recurrence(mf):
-    """cg_variant 4: plain CG on S^-1 A S^-1 (S = sqrt|diag|, folded into the sweep layout's copy with the product s_r s_c formed first, so the
+    """cg_variant 4: plain CG on S^-1 A S^-1 (S = sqrt|diag|, folded into the layout copy as a * (t_r t_c), t = 1 / S, the product of the factors formed first, so the
     mirrored sweep still applies) -- the Jacobi-preconditioned iteration without the 1 / d stream.  On a matrix whose diagonal varies by three
     orders of magnitude: the sweep kernel runs, the solution equals the classic recurrence's to 1e-9 and the TRUE residual meets the tolerance;
     with unsymmetric values the variant falls back to the classic recurrence on the plain kernel."""
@@ -632,8 +632,8 @@ def test_patch_sweep_on_a_caller_supplied_symmetric_lattice_matrix(mf, rp_dtype,
         x2, st2 = mf.iterative_Solve(A, K2, torch.tensor(b, device="cuda"), tol, Sv_func=mf.cg_, maxiter=500, max_pass=3, cg_variant=3)
         assert st2.converged == 1 and _lib.lib.mfem_debug_sym_spmv_count() == before
         assert np.abs(x2.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
-        # the default on this layout is the scaled CG (cg_variant 4): its check sees the SCALED copy a / (s_r s_c), where a difference of one ulp
-        # can vanish in the rounding of the division (the iteration then runs on a matrix that IS symmetric); eight ulps cannot
+        # the default on this layout is the scaled CG (cg_variant 4): its check sees the SCALED copy a * (t_r t_c), where a difference of one ulp
+        # can vanish in the rounding of the product (the iteration then runs on a matrix that IS symmetric); eight ulps cannot
         K3 = K.clone()
         for _ in range(8):
             K3[k] = torch.nextafter(K3[k], torch.tensor(float("inf"), dtype=torch.float64, device="cuda"))
