@@ -292,9 +292,11 @@ struct SympGeom {
 // With pv != nullptr the rows of the swept lattice planes [Gm.p0, Gm.p1) go straight to the patch-major copy of the patch sweep (layout:
 // k_spmv_symp) -- their 27 slots, the edge block entries they own, and the diagonal alone to the slot-major copy (k_ell_diag reads it
 // there) -- instead of through the slot-major copy and a second pass (k_symp_bind): 1.97 + 1.85 ms -> one pass at 256^3.
-template <typename RP, int LPR>  // LPR = lanes per row: 1 (64 rows per wave tile) or 2 (32 rows)
 // the copies are written as full coalesced streams and not read again by this kernel: nontemporal stores (per-solve work of C2 3.65 -> 3.3 ms)
 #define DIA_ST(p, v) __builtin_nontemporal_store((v), (p))
+// LPR = lanes per row: 1 (64 rows per wave tile) or 2 (32 rows); SYM: the symmetrically scaled copy -- its own instantiation, so that the plain
+// copy's code is what it was (2.4 ms at 256^3; 2.7 with the test for the scaling in it)
+template <typename RP, int LPR, bool SYM>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
                                                            int base, const DiaOffsets* __restrict__ Op,
@@ -385,8 +387,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     }
     const int off0 = (int)(lo - s0);
     const int dir = half ? -1 : 1;
-    const double sr = (ssym && r < n) ? ssym[r] : 1.0;
-    auto sym_scaled = [&](double a, int64_t c) -> double { return ssym ? a * (sr * ssym[c]) : a; };
+    double sr = 1.0;
+    if constexpr (SYM) sr = r < n ? ssym[r] : 1.0;
+    auto sym_scaled = [&](double a, int64_t c) -> double {
+      if constexpr (SYM) return a * (sr * ssym[c]);
+      else return a;
+    };
     auto colat = [&](int j) -> int64_t { return stage_cols ? (int64_t)Tc[off0 + j] : (int64_t)col[lo + j] - base; };
     if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
@@ -1439,14 +1445,16 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     if (g > ctx->num_cus * 16) g = ctx->num_cus * 16;
     // the slot-major copy; with the patch sweep wanted (and not the two-pass knob) the swept planes go straight to the patch-major copy
     auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
-#define DV_LAUNCH(RP, LPR_)                                                                                                        \
-  hipLaunchKernelGGL((k_dia_vals<RP, LPR_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
+#define DV_LAUNCH_(RP, LPR_, SYM_)                                                                                                  \
+  hipLaunchKernelGGL((k_dia_vals<RP, LPR_, SYM_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
                      A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc, ssym)
+#define DV_LAUNCH(RP, LPR_) do { if (ssym) DV_LAUNCH_(RP, LPR_, true); else DV_LAUNCH_(RP, LPR_, false); } while (0)
       if (A->rowptr_bits == 64) {
         if (lpr == 2) DV_LAUNCH(int64_t, 2); else DV_LAUNCH(int64_t, 1);
       } else {
         if (lpr == 2) DV_LAUNCH(int32_t, 2); else DV_LAUNCH(int32_t, 1);
       }
+#undef DV_LAUNCH_
 #undef DV_LAUNCH
       MFEM_CHECK_LAUNCH();
       return MFEM_OK;
