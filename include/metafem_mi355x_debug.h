@@ -94,6 +94,11 @@ int mfem_prof_spmv_read(mfem_context ctx, double* total_ms /* [host] */, int64_t
  * well (self send / receive).  MFEM_OK when every received entry and the reduced scalars are right. */
 int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds);
 
+/* Placement experiment: the solver workspace's base becomes align_up(hipMalloc's pointer, align) + offset (0, 0: off).  tools/placement_probe.py;
+ * mfem_debug_ws_address returns the base in use. */
+int mfem_debug_set_ws_placement(long long align, long long offset);
+unsigned long long mfem_debug_ws_address(mfem_context ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,6 +182,8 @@ SIGNATURES = {
     "mfem_csr_replan": (c_int, [P, P]),
     "mfem_csr_spmv_bytes": (c_int, [P, P, C.POINTER(c_int64), C.POINTER(c_int64)]),
     "mfem_debug_comm_selftest": (c_int, [P, c_int64, c_int32]),
+    "mfem_debug_set_ws_placement": (c_int, [C.c_longlong, C.c_longlong]),
+    "mfem_debug_ws_address": (C.c_ulonglong, [P]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

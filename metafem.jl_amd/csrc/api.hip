@@ -48,7 +48,7 @@ static void context_release(mfem_context_s* ctx) {
   if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
   if (ctx->d_flags) hipFree(ctx->d_flags);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
-  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->ws_raw) hipFree(ctx->ws_raw);
   if (ctx->prof_ev) {
     for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i)
       if (ctx->prof_ev[i]) hipEventDestroy(ctx->prof_ev[i]);
@@ -171,13 +171,23 @@ void mfem_graphs_invalidate(mfem_context_s* ctx) {
     }
 }
 
+static size_t g_ws_align = 0, g_ws_offset = 0;  // placement experiment (mfem_debug_set_ws_placement): base = align_up(raw, align) + offset
+extern "C" int mfem_debug_set_ws_placement(long long align, long long offset) {
+  g_ws_align = align > 0 ? (size_t)align : 0;
+  g_ws_offset = offset > 0 ? (size_t)offset : 0;
+  return MFEM_OK;
+}
+extern "C" unsigned long long mfem_debug_ws_address(mfem_context ctx) { return ctx ? (unsigned long long)(uintptr_t)ctx->ws : 0ull; }
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return MFEM_OK;
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->ws) MFEM_CHECK_HIP(hipFree(ctx->ws));
-  ctx->ws = nullptr;
+  if (ctx->ws_raw) MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
+  ctx->ws = ctx->ws_raw = nullptr;
   ctx->ws_bytes = 0;
-  MFEM_CHECK_HIP(hipMalloc(&ctx->ws, bytes));
+  MFEM_CHECK_HIP(hipMalloc(&ctx->ws_raw, bytes + g_ws_align + g_ws_offset));
+  uintptr_t p = (uintptr_t)ctx->ws_raw;
+  if (g_ws_align) p = (p + g_ws_align - 1) / g_ws_align * g_ws_align;
+  ctx->ws = (void*)(p + g_ws_offset);
   ctx->ws_bytes = bytes;
   return MFEM_OK;
 }

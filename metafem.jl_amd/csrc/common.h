@@ -66,7 +66,8 @@ struct mfem_context_s {
   int32_t* d_flags;     // [16] device flags (done, iteration count, ...)
   int32_t* h_flags;     // pinned
   // generic workspace (grown on demand, never shrunk)
-  void* ws;
+  void* ws;        // (ws_raw + the placement offset, see mfem_ws_reserve)
+  void* ws_raw;    // what hipMalloc returned
   size_t ws_bytes;
   // optional user shadow vectors
   const double* shadow;
