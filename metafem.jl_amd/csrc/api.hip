@@ -49,6 +49,7 @@ static void context_release(mfem_context_s* ctx) {
   if (ctx->d_flags) hipFree(ctx->d_flags);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->ws_raw) hipFree(ctx->ws_raw);
+  if (ctx->ws_alt_raw) hipFree(ctx->ws_alt_raw);
   if (ctx->prof_ev) {
     for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i)
       if (ctx->prof_ev[i]) hipEventDestroy(ctx->prof_ev[i]);
@@ -178,11 +179,63 @@ extern "C" int mfem_debug_set_ws_placement(long long align, long long offset) {
   return MFEM_OK;
 }
 extern "C" unsigned long long mfem_debug_ws_address(mfem_context ctx) { return ctx ? (unsigned long long)(uintptr_t)ctx->ws : 0ull; }
+// Next candidate for the workspace (same size, same placement rule).  First call (no alternative held): the current one moves to ws_alt*.  Later
+// calls: the current one is freed (the alternative stays) -- at most two are alive.  ws_try counts the candidates allocated after the first; it is
+// unchanged when memory did not allow another one.
+int mfem_ws_next_candidate(mfem_context_s* ctx) {
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  const size_t need = ctx->ws_bytes + g_ws_align + g_ws_offset;
+  if (ctx->ws_alt_raw) {  // drop the current candidate first
+    MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
+    ctx->ws = ctx->ws_raw = nullptr;
+  }
+  size_t freeb = 0, totalb = 0;
+  void* raw = nullptr;
+  bool ok = hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb >= need + ((size_t)4 << 30);
+  if (ok && hipMalloc(&raw, need) != hipSuccess) ok = false;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (!ctx->ws_raw) {  // the current one is gone: back to the alternative
+      ctx->ws = ctx->ws_alt;
+      ctx->ws_raw = ctx->ws_alt_raw;
+      ctx->ws_alt = ctx->ws_alt_raw = nullptr;
+    }
+    return MFEM_OK;
+  }
+  if (ctx->ws_raw) {
+    ctx->ws_alt = ctx->ws;
+    ctx->ws_alt_raw = ctx->ws_raw;
+  }
+  ctx->ws_raw = raw;
+  uintptr_t p = (uintptr_t)raw;
+  if (g_ws_align) p = (p + g_ws_align - 1) / g_ws_align * g_ws_align;
+  ctx->ws = (void*)(p + g_ws_offset);
+  ctx->ws_try += 1;
+  return MFEM_OK;
+}
+// end of the trial: keep_current = false goes back to the first allocation
+int mfem_ws_decide(mfem_context_s* ctx, bool keep_current) {
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws_alt_raw) {
+    if (keep_current) {
+      MFEM_CHECK_HIP(hipFree(ctx->ws_alt_raw));
+    } else {
+      MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
+      ctx->ws = ctx->ws_alt;
+      ctx->ws_raw = ctx->ws_alt_raw;
+    }
+  }
+  ctx->ws_alt = ctx->ws_alt_raw = nullptr;
+  ctx->ws_try = 99;  // decided
+  return MFEM_OK;
+}
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return MFEM_OK;
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->ws_raw) MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
-  ctx->ws = ctx->ws_raw = nullptr;
+  if (ctx->ws_alt_raw) MFEM_CHECK_HIP(hipFree(ctx->ws_alt_raw));
+  ctx->ws = ctx->ws_raw = ctx->ws_alt = ctx->ws_alt_raw = nullptr;
+  ctx->ws_try = 0;  // (a new allocation: undecided again)
   ctx->ws_bytes = 0;
   MFEM_CHECK_HIP(hipMalloc(&ctx->ws_raw, bytes + g_ws_align + g_ws_offset));
   uintptr_t p = (uintptr_t)ctx->ws_raw;

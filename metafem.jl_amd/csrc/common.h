@@ -69,6 +69,14 @@ struct mfem_context_s {
   void* ws;        // (ws_raw + the placement offset, see mfem_ws_reserve)
   void* ws_raw;    // what hipMalloc returned
   size_t ws_bytes;
+  // placement of a large workspace (krylov.hip, solve_inner): the solver SpMV runs at one of two speeds depending on the physical memory an
+  // allocation received (profiles/r03_placement_probe.txt); the first big solve on a workspace times it, tries ONE second allocation and keeps
+  // the faster.  ws_try: candidates allocated after the first (the best so far kept in ws_alt*); 99: decided.
+  int ws_try;
+  void* ws_alt;
+  void* ws_alt_raw;
+  float ws_try_ms;
+  float ws_log[4];  // the candidates' times (ms for two SpMVs), in the order tried; [3]: which one was kept (0-based)
   // optional user shadow vectors
   const double* shadow;
   int32_t shadow_count;
@@ -228,6 +236,8 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
                          const SpmvPart& part);
 
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes);
+int mfem_ws_next_candidate(mfem_context_s* ctx);
+int mfem_ws_decide(mfem_context_s* ctx, bool keep_current);
 uint64_t mfem_next_csr_serial();
 bool mfem_context_alive(mfem_context_s* ctx);       // false once mfem_context_destroy has run (api.hip)
 void mfem_graphs_invalidate(mfem_context_s* ctx);  // drops every cached cycle graph of the context (api.hip)

@@ -634,6 +634,16 @@ extern "C" int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+static int g_ws_trial = 1;           // timed choice between two allocations of a large workspace (mfem_debug_set_ws_trial)
+extern "C" int mfem_debug_set_ws_trial(int on) {
+  g_ws_trial = on ? 1 : 0;
+  return MFEM_OK;
+}
+extern "C" int mfem_debug_ws_trial_log(mfem_context ctx, double* out4) {  // times of the candidates tried (ms for two SpMVs; 0: not tried)
+  MFEM_REQUIRE(ctx && out4, "null argument");
+  for (int i = 0; i < 4; ++i) out4[i] = ctx->ws_log[i];
+  return MFEM_OK;
+}
 static int g_graphs = 1;             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
 static int64_t g_graph_max_n = 4000000;  // above this size kernels are long enough that launch latency is hidden anyway
 extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) {
@@ -930,6 +940,66 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     n_global = (int64_t)(ctx->h_scalars[S_TMP0] + 0.5);
   }
   const double n_inv = 1.0 / (double)n_global;
+
+  // Placement of a large workspace (one rank; >= 8 GB: where the effect was seen): the SpMV on the bound layout runs at one of two speeds that
+  // follow the PHYSICAL memory the allocation received (profiles/r03_placement_probe.txt: 4.0 or 4.5 ms at 512^3, alternating between
+  // allocations).  The first solve on a workspace times two SpMVs, tries up to two more allocations (if memory allows; at most two alive) the
+  // same way and keeps the fastest -- this function starts over on each candidate, like after a refused layout.  ~0.1 s once per workspace at 512^3.
+  if (g_ws_trial && !ctx->comm && ctx->ws_try < 99 && total >= ((size_t)8 << 30) && !o->scale_in_place && layout_bytes > 0) {
+    float ms = 0.f;
+    {
+      const int prof = ctx->prof_on;
+      ctx->prof_on = 0;
+      mfem_probe_active = 1;
+      hipEvent_t e0, e1;
+      MFEM_CHECK_HIP(hipEventCreate(&e0));
+      MFEM_CHECK_HIP(hipEventCreate(&e1));
+      rc = mfem_spmv_launch(ctx, A, vals_work, V.w[0], V.w[1], 1.0, 0.0, nullptr, nullptr, nullptr);  // (warm: tables, code)
+      MFEM_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+      for (int k = 0; k < 2 && !rc; ++k) rc = mfem_spmv_launch(ctx, A, vals_work, V.w[0], V.w[1], 1.0, 0.0, nullptr, nullptr, nullptr);
+      MFEM_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+      MFEM_CHECK_HIP(hipEventSynchronize(e1));
+      MFEM_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      ctx->prof_on = prof;
+      mfem_probe_active = 0;
+      if (rc) return rc;
+      MFEM_CHECK_HIP(hipMemsetAsync(V.w[1], 0, vec_bytes, ctx->stream));  // (A * 0: zero anyway; the work vectors start clear)
+    }
+    // The two speeds are 11 % apart: a candidate 5 % faster than another has found the fast kind.  Two alike (both fast, or both slow): one more
+    // candidate is tried (the current one freed first -- a new allocation does not come back to memory just freed, the probe's alternation).
+    const int tried = ctx->ws_try;
+    bool restart = false;
+    if (tried >= 0 && tried < 3) ctx->ws_log[tried] = ms;
+    if (tried == 0) {
+      ctx->ws_try_ms = ms;
+      rc = mfem_ws_next_candidate(ctx);  // (the first stays alive as the alternative)
+      if (rc) return rc;
+      if (ctx->ws_try == 1) restart = true;
+      else ctx->ws_try = 99;  // no memory for a second one: the first stays
+    } else if (ms < 0.95f * ctx->ws_try_ms) {
+      rc = mfem_ws_decide(ctx, true);   // the current one is the fast kind
+    } else if (ctx->ws_try_ms < 0.95f * ms) {
+      rc = mfem_ws_decide(ctx, false);  // the alternative was: back to it
+      restart = true;
+    } else if (tried < 2) {
+      if (ms < ctx->ws_try_ms) {  // alike: the better of the two becomes the alternative, the other is replaced
+        void* t = ctx->ws; ctx->ws = ctx->ws_alt; ctx->ws_alt = t;
+        t = ctx->ws_raw; ctx->ws_raw = ctx->ws_alt_raw; ctx->ws_alt_raw = t;
+        ctx->ws_try_ms = ms;
+      }
+      rc = mfem_ws_next_candidate(ctx);
+      if (rc) return rc;
+      if (ctx->ws_try == tried) rc = mfem_ws_decide(ctx, true);  // (no memory: what is left stays)
+      restart = true;
+    } else {
+      rc = mfem_ws_decide(ctx, ms <= ctx->ws_try_ms);
+      restart = !(ms <= ctx->ws_try_ms);
+    }
+    if (rc) return rc;
+    if (restart) return solve_inner(ctx, A, vals, b, x_out, o, stats);  // (the guard above unbinds the layouts of the workspace left behind)
+  }
 
   // initial residual for the report: b itself since x0 = 0 (:42-45)
   rc = mfem_dot_device(ctx, n, b, b, ctx->d_scalars + S_TMP0);

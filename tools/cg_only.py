@@ -13,3 +13,8 @@ for var in variants:
     for _ in range(2):
         _, st = mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=its, max_pass=1, fixed_iterations=True, cg_variant=var)
         print(st.solve_ms / its, "ms/it", "cg_variant", var, "solve_ms", st.solve_ms)
+import ctypes as C
+from metafem_jl_amd import _lib
+log = (C.c_double * 4)()
+_lib.lib.mfem_debug_ws_trial_log(mf.default_context()._h, log)
+print("workspace candidates tried (ms for two SpMVs):", [round(v, 3) for v in log[:3]])
