@@ -944,7 +944,8 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // Placement of a large workspace (one rank; >= 8 GB: where the effect was seen): the SpMV on the bound layout runs at one of two speeds that
   // follow the PHYSICAL memory the allocation received (profiles/r03_placement_probe.txt: 4.0 or 4.5 ms at 512^3, alternating between
   // allocations).  The first solve on a workspace times two SpMVs, tries up to two more allocations (if memory allows; at most two alive) the
-  // same way and keeps the fastest -- this function starts over on each candidate, like after a refused layout.  ~0.1 s once per workspace at 512^3.
+  // same way and keeps the fastest -- this function starts over on each candidate, like after a refused layout.  Once per workspace; the
+  // allocations themselves are what it costs (about 7 s at 512^3: hipMalloc / hipFree of 45 GB, twice).
   if (g_ws_trial && !ctx->comm && ctx->ws_try < 99 && total >= ((size_t)8 << 30) && !o->scale_in_place && layout_bytes > 0) {
     float ms = 0.f;
     {
