@@ -100,7 +100,8 @@ int mfem_debug_set_ws_placement(long long align, long long offset);
 unsigned long long mfem_debug_ws_address(mfem_context ctx);
 /* 1 (default): the first solve on a workspace of 8 GB or more (one rank) times the solver SpMV, tries one second allocation of the workspace
  * the same way and keeps the faster (the speed follows the physical memory an allocation received: 7 % of every later iteration at 512^3).
- * Paid once per workspace: about 7 s at 512^3 (hipMalloc / hipFree of 45 GB, twice).  0: off. */
+ * Paid once per workspace: 5 - 7 s at 512^3 (a second hipMalloc of 45 GB takes 2 s, a hipFree about as long; environment variable
+ * MFEM_WS_TRIAL_VERBOSE=1 prints the steps' times to stderr).  0: off. */
 int mfem_debug_set_ws_trial(int on);
 /* out4[0..2]: the times (ms for two SpMVs) of the workspace candidates tried by that choice, in order; 0 = not tried. */
 int mfem_debug_ws_trial_log(mfem_context ctx, double* out4);

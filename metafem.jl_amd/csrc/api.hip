@@ -182,17 +182,26 @@ extern "C" unsigned long long mfem_debug_ws_address(mfem_context ctx) { return c
 // Next candidate for the workspace (same size, same placement rule).  First call (no alternative held): the current one moves to ws_alt*.  Later
 // calls: the current one is freed (the alternative stays) -- at most two are alive.  ws_try counts the candidates allocated after the first; it is
 // unchanged when memory did not allow another one.
+#include <chrono>
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int mfem_ws_next_candidate(mfem_context_s* ctx) {
+  const bool verbose = getenv("MFEM_WS_TRIAL_VERBOSE") != nullptr;
+  double t0 = now_ms();
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (verbose) fprintf(stderr, "ws trial: sync %.1f ms\n", now_ms() - t0);
   const size_t need = ctx->ws_bytes + g_ws_align + g_ws_offset;
   if (ctx->ws_alt_raw) {  // drop the current candidate first
+    t0 = now_ms();
     MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
+    if (verbose) fprintf(stderr, "ws trial: hipFree %.1f ms\n", now_ms() - t0);
     ctx->ws = ctx->ws_raw = nullptr;
   }
   size_t freeb = 0, totalb = 0;
   void* raw = nullptr;
   bool ok = hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb >= need + ((size_t)4 << 30);
+  t0 = now_ms();
   if (ok && hipMalloc(&raw, need) != hipSuccess) ok = false;
+  if (verbose) fprintf(stderr, "ws trial: hipMalloc %.1f ms\n", now_ms() - t0);
   if (!ok) {
     (void)hipGetLastError();
     if (!ctx->ws_raw) {  // the current one is gone: back to the alternative
