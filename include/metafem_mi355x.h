@@ -37,8 +37,14 @@ typedef enum {
   MFEM_ERR_HIP = -2,       /* a HIP runtime call failed */
   MFEM_ERR_UNSUPPORTED = -3,
   MFEM_ERR_NOT_CONVERGED = -4, /* never returned by mfem_solve (reference semantics: it reports, not fails) */
-  MFEM_ERR_COMM = -5
+  MFEM_ERR_COMM = -5,
+  MFEM_ERR_ALLOC = -6,     /* host memory exhausted inside the library (std::bad_alloc caught at the boundary) */
+  MFEM_ERR_INTERNAL = -7   /* any other C++ exception caught at the boundary (mfem_last_error() carries its what()) */
 } mfem_status;
+/* Error convention of every entry point that returns int: MFEM_OK or a negative mfem_status, with mfem_last_error() (thread-local text) set.
+ * NOTHING is thrown or aborted across this boundary: each entry point is a function-try-block whose handler maps std::bad_alloc to
+ * MFEM_ERR_ALLOC and anything else to MFEM_ERR_INTERNAL (csrc/common.h: MFEM_API_CATCH), so a host that calls through ccall / ctypes / cgo
+ * never sees a C++ exception unwind into its frames.  After a non-zero return the handles passed in stay valid and destroyable. */
 
 typedef struct mfem_context_s* mfem_context;
 typedef struct mfem_csr_s* mfem_csr;       /* CSR pattern + SpMV plan (no values) */
@@ -206,6 +212,27 @@ typedef struct {
   int32_t converged;
   int32_t spmv_count;
 } mfem_solve_stats;
+
+/* What a solve does to the matrix it is handed -- read before relying on bit patterns:
+ *  - mfem_solve copies `vals` once per call into a SOLVER LAYOUT chosen from the pattern and its size (mfem_csr_solver_layout reports the mode);
+ *    the Krylov loop's SpMVs read that copy, `vals` itself is never modified (scale_in_place apart).
+ *  - Modes 0-3 (CSR kernel, slot-major / diagonal-slotted copy incl. its mirrored sweep, sliced layout) are BITWISE REPRODUCIBLE run to run: a
+ *    fixed summation order, no floating-point atomics.  The mirrored sweep of mode 2 is taken only after a per-solve BITWISE symmetry check of
+ *    the values and returns bit for bit what the plain kernel returns.
+ *  - Modes 4 and 5 (symmetric lattice tiles; the default for the hex-27 one-field and the hex-8 three-field lattice matrices from 1.8e5 rows
+ *    on, one rank or slabs) are NOT bitwise reproducible: mirrored products are added into an LDS block with ds_add_f64, whose order across
+ *    the waves of a workgroup is not fixed.  Results repeat to ~1e-16 relative and equal the CSR kernel's to round-off (<= 1e-13 relative,
+ *    asserted in tests/test_gpu_lat27.py / test_gpu_lat8.py).  mfem_debug_set_lat27(0) / mfem_debug_set_lat8(0) select the reproducible
+ *    modes 3 / 2 instead.
+ *  - SYMMETRY GATE of modes 4 / 5: they store one triangle, so every bind measures whether THESE values are symmetric -- one probe product
+ *    (entries of magnitude in [0.75, 1.25), random signs) through the layout against the CSR kernel on the caller's values; the layout is taken
+ *    when max over rows r of |difference|_r <= 4e-13 |a_rr| (rows without a stored non-zero diagonal: 4e-13 max|a|).  Consequence: an
+ *    asymmetry BELOW that level (about 2 000 ulp of the row's diagonal) is not detected and the solve then runs on the symmetrised matrix
+ *    (upper triangle mirrored); anything above it sends the solve to modes 3 / 2 on the caller's exact values.  The residual the solve
+ *    reports is computed with the layout that ran.  mfem_debug_lat27_asymmetry / mfem_debug_lat8_asymmetry return the last measure.
+ * Threading: one context per host thread; handles are not shared between threads while a call is in flight.  Quadrature / lattice tables live
+ * in __constant__ memory per PROCESS (uploads are serialised): assemblies with different Gauss orders must not run concurrently from
+ * different host threads.  The mfem_debug_* knobs are process-wide atomics, to be changed only while no call is in flight. */
 
 /* delta_x = iterative_Solve!(globalfield; Sv_func!, Pr_func!, max_pass, maxiter, s)
  * (linear_solver/02_Preconditioner.jl:32-76).  b = residue, x_out = the returned vector

@@ -106,6 +106,11 @@ int mfem_debug_set_ws_trial(int on);
 /* out4[0..2]: the times (ms for two SpMVs) of the workspace candidates tried by that choice, in order; 0 = not tried. */
 int mfem_debug_ws_trial_log(mfem_context ctx, double* out4);
 
+/* Fault injection for the error convention (metafem_mi355x.h: nothing is thrown across the boundary): the nth host allocation the library
+ * probes from now on (handle structs, planning vectors) throws std::bad_alloc once; the entry point that hits it returns MFEM_ERR_ALLOC with
+ * mfem_last_error() set and leaves every handle valid.  0 disarms.  tests/test_gpu_round4_abi.py. */
+int mfem_debug_fail_host_alloc(int nth);
+
 #ifdef __cplusplus
 }
 #endif

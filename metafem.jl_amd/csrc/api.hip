@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <atomic>
 
+#include <exception>
 #include <mutex>
+#include <new>
 #include <set>
 
 #include "common.h"
@@ -24,7 +26,38 @@ void mfem_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int mfem_debug_epoch = 0;
+int mfem_api_exception(const char* entry) noexcept {
+  try {
+    throw;  // the exception the entry point's handler caught
+  } catch (const std::bad_alloc&) {
+    mfem_set_error("%s: host memory exhausted (std::bad_alloc)", entry);
+    return MFEM_ERR_ALLOC;
+  } catch (const std::exception& e) {
+    mfem_set_error("%s: internal error: %s", entry, e.what());
+    return MFEM_ERR_INTERNAL;
+  } catch (...) {
+    mfem_set_error("%s: internal error (unknown C++ exception)", entry);
+    return MFEM_ERR_INTERNAL;
+  }
+}
+
+// countdown to an injected host allocation failure: 0 = off, k = the k-th probed allocation from now throws (once)
+static std::atomic<int> g_fail_host_alloc{0};
+extern "C" int mfem_debug_fail_host_alloc(int nth) {
+  g_fail_host_alloc.store(nth > 0 ? nth : 0);
+  return MFEM_OK;
+}
+void mfem_host_alloc_probe() {
+  int v = g_fail_host_alloc.load();
+  while (v > 0) {
+    if (g_fail_host_alloc.compare_exchange_weak(v, v - 1)) {
+      if (v == 1) throw std::bad_alloc();
+      return;
+    }
+  }
+}
+
+std::atomic<int> mfem_debug_epoch{0};
 
 extern "C" int mfem_abi_version(void) { return MFEM_ABI_VERSION; }
 extern "C" const char* mfem_last_error(void) { return g_err; }
@@ -63,7 +96,7 @@ static void context_release(mfem_context_s* ctx) {
   if (ctx->graph_stream) hipStreamDestroy(ctx->graph_stream);
 }
 
-extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) {
+extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) try {
   MFEM_REQUIRE(out != nullptr, "out is null");
   int ndev = 0;
   MFEM_CHECK_HIP(hipGetDeviceCount(&ndev));
@@ -75,6 +108,7 @@ extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) 
     mfem_set_error("libmetafem_mi355x is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
     return MFEM_ERR_UNSUPPORTED;
   }
+  mfem_host_alloc_probe();
   mfem_context_s* c = new mfem_context_s();
   memset(c, 0, sizeof(*c));
   c->device = device;
@@ -92,21 +126,21 @@ extern "C" int mfem_context_create(int device, void* stream, mfem_context* out) 
   }
   *out = c;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_context_create")
 
-extern "C" int mfem_context_set_stream(mfem_context ctx, void* stream) {
+extern "C" int mfem_context_set_stream(mfem_context ctx, void* stream) try {
   MFEM_REQUIRE(ctx != nullptr, "ctx is null");
   ctx->stream = (hipStream_t)stream;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_context_set_stream")
 
-extern "C" int mfem_context_sync(mfem_context ctx) {
+extern "C" int mfem_context_sync(mfem_context ctx) try {
   MFEM_REQUIRE(ctx != nullptr, "ctx is null");
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_context_sync")
 
-extern "C" int mfem_context_destroy(mfem_context ctx) {
+extern "C" int mfem_context_destroy(mfem_context ctx) try {
   if (!ctx) return MFEM_OK;
   {
     std::lock_guard<std::mutex> lk(g_ctx_mutex);
@@ -116,7 +150,7 @@ extern "C" int mfem_context_destroy(mfem_context ctx) {
   context_release(ctx);
   delete ctx;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_context_destroy")
 
 int mfem_prof_flush(mfem_context_s* ctx) {
   if (ctx->prof_used == 0) return MFEM_OK;
@@ -131,7 +165,7 @@ int mfem_prof_flush(mfem_context_s* ctx) {
   return MFEM_OK;
 }
 
-extern "C" int mfem_prof_spmv_enable(mfem_context ctx, int on) {
+extern "C" int mfem_prof_spmv_enable(mfem_context ctx, int on) try {
   MFEM_REQUIRE(ctx, "null ctx");
   if (on && !ctx->prof_ev) {
     ctx->prof_ev = new hipEvent_t[2 * MFEM_PROF_PAIRS]();
@@ -143,9 +177,9 @@ extern "C" int mfem_prof_spmv_enable(mfem_context ctx, int on) {
   }
   ctx->prof_on = on ? 1 : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_prof_spmv_enable")
 
-extern "C" int mfem_prof_spmv_read(mfem_context ctx, double* total_ms, int64_t* launches, int reset) {
+extern "C" int mfem_prof_spmv_read(mfem_context ctx, double* total_ms, int64_t* launches, int reset) try {
   MFEM_REQUIRE(ctx && total_ms && launches, "null argument");
   int rc = mfem_prof_flush(ctx);
   if (rc) return rc;
@@ -156,7 +190,7 @@ extern "C" int mfem_prof_spmv_read(mfem_context ctx, double* total_ms, int64_t* 
     ctx->prof_count = 0;
   }
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_prof_spmv_read")
 
 uint64_t mfem_next_csr_serial() {
   static std::atomic<uint64_t> next{1};
@@ -172,12 +206,12 @@ void mfem_graphs_invalidate(mfem_context_s* ctx) {
     }
 }
 
-static size_t g_ws_align = 0, g_ws_offset = 0;  // placement experiment (mfem_debug_set_ws_placement): base = align_up(raw, align) + offset
-extern "C" int mfem_debug_set_ws_placement(long long align, long long offset) {
+static std::atomic<size_t> g_ws_align{0}, g_ws_offset{0};  // placement experiment (mfem_debug_set_ws_placement): base = align_up(raw, align) + offset
+extern "C" int mfem_debug_set_ws_placement(long long align, long long offset) try {
   g_ws_align = align > 0 ? (size_t)align : 0;
   g_ws_offset = offset > 0 ? (size_t)offset : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_ws_placement")
 extern "C" unsigned long long mfem_debug_ws_address(mfem_context ctx) { return ctx ? (unsigned long long)(uintptr_t)ctx->ws : 0ull; }
 // Next candidate for the workspace (same size, same placement rule).  First call (no alternative held): the current one moves to ws_alt*.  Later
 // calls: the current one is freed (the alternative stays) -- at most two are alive.  ws_try counts the candidates allocated after the first; it is

@@ -32,7 +32,7 @@ struct Hex27Tables {        // device-global, filled once per ng
   double fw[16];
 };
 static Hex27Tables* g_tab = nullptr;
-static int g_tab_ng = 0;
+static std::atomic<int> g_tab_ng{0};
 
 static const double GP27[4][4] = {{0.0, 0, 0, 0},
                                   {-0.57735026918962576451, 0.57735026918962576451, 0, 0},
@@ -53,7 +53,10 @@ static void lag2(double x, double* L, double* dL) {  // nodes 0, 1/2, 1 (102_Int
 }
 
 static int hex27_upload_tables(int ng) {
+  static std::mutex mu;  // uploads from two host threads must not interleave (the tables themselves are process-wide: see the threading note in include/metafem_mi355x.h)
+  std::lock_guard<std::mutex> lk(mu);
   if (g_tab && g_tab_ng == ng) return MFEM_OK;
+  mfem_host_alloc_probe();
   Hex27Tables* h = new Hex27Tables();
   memset(h, 0, sizeof(*h));
   double gp[4], gw[4];
@@ -735,15 +738,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // 0 (default): colour-partitioned RMW scatter; 1: Ke -> element-major scratch (MFMA kernel, no colours, no RMW) +
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
-static int g_hex27_two_pass = 1;
-static int g_hex27_chunk_planes = 0;  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
-static size_t g_hex27_scratch_budget = (size_t)16 << 30;
-extern "C" int mfem_debug_set_hex27(int two_pass) {
+static std::atomic<int> g_hex27_two_pass{1};
+static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
+static std::atomic<size_t> g_hex27_scratch_budget{(size_t)16 << 30};
+extern "C" int mfem_debug_set_hex27(int two_pass) try {
   ++mfem_debug_epoch;
   g_hex27_two_pass = (two_pass & 3) == 0 ? 1 : (two_pass & 3);  // 0 / 1 two-pass (default), 2 FP64 atomics, 3 colour scatter
   g_hex27_chunk_planes = (two_pass >> 16) & 255;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_hex27")
 
 // mode: 0 residual, 1 matrix with colour scatter / atomics (row descriptors per wave), 2 matrix -> scratch
 static size_t hex27_lds_bytes(int ng, int mode) {

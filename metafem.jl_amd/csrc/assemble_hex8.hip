@@ -24,7 +24,7 @@ __constant__ double c_xi[BRICK_MAX_Q][6];  // xi0, xi1, xi2, xi1 xi2, xi0 xi2, x
 __constant__ double c_fw[BRICK_MAX_NG * BRICK_MAX_NG];
 __constant__ double c_fN[BRICK_MAX_NG * BRICK_MAX_NG][4];
 __constant__ double c_fdN[BRICK_MAX_NG * BRICK_MAX_NG][4][2];
-static int g_tables_ng = 0;
+static std::atomic<int> g_tables_ng{0};
 
 static const double GP[4][4] = {{0.0, 0, 0, 0},
                                 {-0.57735026918962576451, 0.57735026918962576451, 0, 0},
@@ -36,6 +36,8 @@ static const double GW[4][4] = {{2.0, 0, 0, 0},
                                 {0.34785484513745385737, 0.65214515486254614263, 0.65214515486254614263, 0.34785484513745385737}};
 
 int mfem_hex8_upload_tables(int ng) {
+  static std::mutex mu;  // uploads from two host threads must not interleave (the tables themselves are process-wide: see the threading note in include/metafem_mi355x.h)
+  std::lock_guard<std::mutex> lk(mu);
   if (g_tables_ng == ng) return MFEM_OK;
   double w[BRICK_MAX_Q], N[BRICK_MAX_Q][8], dN[BRICK_MAX_Q][8][3], xiq[BRICK_MAX_Q][6];
   double fw[16], fN[16][4], fdN[16][4][2];
@@ -784,12 +786,12 @@ static dim3 boundary_grid(const mfem_brick_s* m) {  // boundary_point(): one thr
   const int64_t cnt = boundary_count(m->plo, m->phi, m->ne[0], m->plane_len, m->m[1], m->m[2]);
   return dim3((unsigned)((cnt + MFEM_BLOCK - 1) / MFEM_BLOCK > 0 ? (cnt + MFEM_BLOCK - 1) / MFEM_BLOCK : 1));
 }
-static int g_thermal_variant = 0;  // 1: the 4 x 4 x 8 tile kernels for every Gauss order (kept: 1- and 4-point rules use them)
-extern "C" int mfem_debug_set_hex8_thermal(int variant) {
+static std::atomic<int> g_thermal_variant{0};  // 1: the 4 x 4 x 8 tile kernels for every Gauss order (kept: 1- and 4-point rules use them)
+extern "C" int mfem_debug_set_hex8_thermal(int variant) try {
   ++mfem_debug_epoch;
   g_thermal_variant = variant ? 1 : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_hex8_thermal")
 // planes per sweep segment: 32, shorter when the (j, k) tiles alone cannot fill the chip
 static int sweep_planes(const mfem_brick_s* m, int64_t* grid) {
   const int64_t ntj = (m->m[1] + SW_N - 1) / SW_N, ntk = (m->m[2] + SW_N - 1) / SW_N;
@@ -1269,7 +1271,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
                                 const double* s, double* residue);
 
 extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
-                                           double* vals) {
+                                           double* vals) try {
   MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
   MFEM_REQUIRE(A->n == m->n_owned, "pattern was not built for 1 field on this brick");
   if (m->p == 2) return mfem_hex27_assemble_thermal(ctx, m, A, p, vals);  // FP64 MFMA Ke = B^T D B path
@@ -1293,10 +1295,10 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
     MFEM_CHECK_LAUNCH();
   }
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_assemble_thermal")
 
 extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const mfem_thermal_params* p,
-                                           const double* x_star, const double* s, double* residue) {
+                                           const double* x_star, const double* s, double* residue) try {
   MFEM_REQUIRE(ctx && m && p && x_star && residue, "null argument");
   if (m->p == 2) return mfem_hex27_residual_thermal(ctx, m, p, x_star, s, residue);
   int rc = mfem_hex8_upload_tables(m->ng);
@@ -1323,17 +1325,17 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
   }
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_residual_thermal")
 
-static int g_elasticity_variant = 0;  // bit 0: the matrix row-owner kernel with in-place global accumulation; bit 1: the residual kernel that integrates per adjacent control point (both kept for comparison)
-extern "C" int mfem_debug_set_elasticity(int variant) {
+static std::atomic<int> g_elasticity_variant{0};  // bit 0: the matrix row-owner kernel with in-place global accumulation; bit 1: the residual kernel that integrates per adjacent control point (both kept for comparison)
+extern "C" int mfem_debug_set_elasticity(int variant) try {
   ++mfem_debug_epoch;
   g_elasticity_variant = variant & 0x1f;  // bits 2-4: timing-only ablations of the matrix kernel (no phases / no write-out / no integration)
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_elasticity")
 
 extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_elasticity_params* p,
-                                              double* vals) {
+                                              double* vals) try {
   MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
   MFEM_REQUIRE(m->p == 1, "fused elasticity assembly is implemented for hex-8 (itp_order 1)");
   MFEM_REQUIRE(A->n == 3 * m->n_owned, "pattern was not built for 3 fields on this brick");
@@ -1354,10 +1356,10 @@ extern "C" int mfem_brick_assemble_elasticity(mfem_context ctx, mfem_brick m, mf
                      p->penalty_faces, T, vals);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_assemble_elasticity")
 
 extern "C" int mfem_brick_residual_elasticity(mfem_context ctx, mfem_brick m, const mfem_elasticity_params* p,
-                                              const double* x_star, double* residue) {
+                                              const double* x_star, double* residue) try {
   MFEM_REQUIRE(ctx && m && p && x_star && residue, "null argument");
   MFEM_REQUIRE(m->p == 1, "fused elasticity residual is implemented for hex-8 (itp_order 1)");
   int rc = mfem_hex8_upload_tables(m->ng);
@@ -1383,4 +1385,4 @@ extern "C" int mfem_brick_residual_elasticity(mfem_context ctx, mfem_brick m, co
                      x_star, residue);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_residual_elasticity")

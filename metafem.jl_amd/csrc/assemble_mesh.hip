@@ -284,7 +284,7 @@ extern "C" int mfem_mesh_assemble_elements(mfem_context ctx, int32_t dim, int32_
                                            const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
                                            const mfem_const_term* terms, const int32_t* sparse_IDs_by_el,
                                            int64_t slot_block_stride, double* K_val, const int32_t* elIDs, int64_t n_items,
-                                           int32_t n_colours, const int64_t* colour_offsets) {
+                                           int32_t n_colours, const int64_t* colour_offsets) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   MFEM_REQUIRE(itg > 0 && itp > 0 && nel >= 0 && ncp > 0 && n_items >= 0 && n_items <= nel, "bad sizes");
@@ -298,7 +298,7 @@ extern "C" int mfem_mesh_assemble_elements(mfem_context ctx, int32_t dim, int32_
   if (rc) return rc;
   MeshItems V{itg, itp, ncp, ref_itp_vals, 0, itg_weight, 0, nullptr, 0, coords, controlpoint_IDs, nullptr, nullptr, elIDs, index_base};
   return ma_launch(ctx, dim, V, T, sparse_IDs_by_el, slot_block_stride, K_val, n_items, n_colours, colour_offsets);
-}
+} MFEM_API_CATCH("mfem_mesh_assemble_elements")
 
 // ---- row-owner form of the scatter -----------------------------------------------------------------------------------
 // Scattering an element matrix entry by entry is what the assembly of a large mesh spends its time on (hex-20 elasticity:
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_row_ranks(int itp, int64_t 
 
 extern "C" int mfem_mesh_row_ranks(mfem_context ctx, int32_t itp, int64_t nel, int64_t ncp, int32_t n_fields, mfem_csr A,
                                    const int64_t* adj_ptr, const int32_t* adj, const int32_t* controlpoint_IDs,
-                                   int32_t index_base, uint16_t* ranks) {
+                                   int32_t index_base, uint16_t* ranks) try {
   MFEM_REQUIRE(ctx && A && adj_ptr && adj && controlpoint_IDs && ranks, "null argument");
   MFEM_REQUIRE(itp > 0 && nel >= 0 && ncp > 0 && n_fields >= 1 && n_fields <= 4, "bad sizes");
   MFEM_REQUIRE(A->n == (int64_t)n_fields * ncp, "pattern rows != n_fields * ncp");
@@ -379,7 +379,7 @@ extern "C" int mfem_mesh_row_ranks(mfem_context ctx, int32_t itp, int64_t nel, i
     return MFEM_ERR_UNSUPPORTED;
   }
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_mesh_row_ranks")
 
 template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_gather(int itp, int64_t ncp, GatherBlocks B, const RP* __restrict__ rowptr,
@@ -447,7 +447,7 @@ extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, i
                                                 const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
                                                 const mfem_const_term* terms, int32_t n_fields, mfem_csr A,
                                                 const int64_t* adj_ptr, const int32_t* adj, const uint16_t* ranks,
-                                                double* K_val) {
+                                                double* K_val) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   MFEM_REQUIRE(itg > 0 && itp > 0 && nel >= 0 && ncp > 0, "bad sizes");
@@ -499,7 +499,7 @@ extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, i
                        A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_mesh_assemble_elements_rows")
 
 extern "C" int mfem_mesh_assemble_facets(mfem_context ctx, int32_t dim, int32_t itg_b, int32_t itp, int32_t n_face_ids,
                                          int64_t n_facets, int64_t ncp, const double* bdy_ref_itp_vals,
@@ -508,7 +508,7 @@ extern "C" int mfem_mesh_assemble_facets(mfem_context ctx, int32_t dim, int32_t 
                                          const int32_t* element_eindex, int32_t index_base, int32_t n_terms,
                                          const mfem_const_term* terms, const int32_t* sparse_IDs_by_el,
                                          int64_t slot_block_stride, double* K_val, const int32_t* facetIDs, int64_t n_items,
-                                         int32_t n_colours, const int64_t* colour_offsets) {
+                                         int32_t n_colours, const int64_t* colour_offsets) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   MFEM_REQUIRE(itg_b > 0 && itp > 0 && n_face_ids > 0 && n_facets >= 0 && ncp > 0 && n_items >= 0 && n_items <= n_facets, "bad sizes");
@@ -525,4 +525,4 @@ extern "C" int mfem_mesh_assemble_facets(mfem_context ctx, int32_t dim, int32_t 
   MeshItems V{itg_b, itp, ncp, bdy_ref_itp_vals, rs, bdy_itg_weights, (int64_t)itg_b, bdy_tangent_directions, ts, coords,
               controlpoint_IDs, element_ID, element_eindex, facetIDs, index_base};
   return ma_launch(ctx, dim, V, T, sparse_IDs_by_el, slot_block_stride, K_val, n_items, n_colours, colour_offsets);
-}
+} MFEM_API_CATCH("mfem_mesh_assemble_facets")

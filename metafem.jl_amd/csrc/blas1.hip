@@ -88,12 +88,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_rand(int64_t n, uint64_t seed, u
 
 // 3 workgroups per CU: CG iteration at 256^3 1.057 ms vs 1.078 ms with 8 (fewer partial sums for the consumer kernels to
 // re-reduce, longer unit-stride runs per workgroup); 1: 1.138, 2: 1.059, 4: 1.062, 5: 1.074, 16: 1.095 (tools/probe_vecgrid.py)
-static int g_vec_grid_mult = 3;
-extern "C" int mfem_debug_set_vec_grid(int workgroups_per_cu) {
+static std::atomic<int> g_vec_grid_mult{3};
+extern "C" int mfem_debug_set_vec_grid(int workgroups_per_cu) try {
   ++mfem_debug_epoch;
   if (workgroups_per_cu > 0) g_vec_grid_mult = workgroups_per_cu;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_vec_grid")
 
 int mfem_vec_grid(mfem_context_s* ctx, int64_t n) {
   // 16 B per lane; persistent grid of at most g_vec_grid_mult workgroups per CU
@@ -117,7 +117,7 @@ int mfem_dot_device(mfem_context_s* ctx, int64_t n, const double* x, const doubl
   return MFEM_OK;
 }
 
-extern "C" int mfem_axpby(mfem_context ctx, int64_t n, double a, const double* x, double b, double* y) {
+extern "C" int mfem_axpby(mfem_context ctx, int64_t n, double a, const double* x, double b, double* y) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(n >= 0, "negative n");
   if (n == 0) return MFEM_OK;
@@ -125,9 +125,9 @@ extern "C" int mfem_axpby(mfem_context ctx, int64_t n, double a, const double* x
   hipLaunchKernelGGL(k_axpby, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, a, x, b, y);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_axpby")
 
-extern "C" int mfem_dot(mfem_context ctx, int64_t n, const double* x, const double* y, double* out) {
+extern "C" int mfem_dot(mfem_context ctx, int64_t n, const double* x, const double* y, double* out) try {
   MFEM_REQUIRE(ctx && out, "null argument");
   MFEM_REQUIRE(n >= 0, "negative n");
   if (n == 0) {
@@ -142,17 +142,17 @@ extern "C" int mfem_dot(mfem_context ctx, int64_t n, const double* x, const doub
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   *out = ctx->h_scalars[MFEM_NSCALARS - 1];
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_dot")
 
-extern "C" int mfem_nrm2(mfem_context ctx, int64_t n, const double* x, double* out) {
+extern "C" int mfem_nrm2(mfem_context ctx, int64_t n, const double* x, double* out) try {
   double d = 0.0;
   int rc = mfem_dot(ctx, n, x, x, &d);
   if (rc) return rc;
   *out = sqrt(d);
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_nrm2")
 
-extern "C" int mfem_rand(mfem_context ctx, int64_t n, uint64_t seed, uint32_t stream_id, double* x) {
+extern "C" int mfem_rand(mfem_context ctx, int64_t n, uint64_t seed, uint32_t stream_id, double* x) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(n >= 0, "negative n");
   if (n == 0) return MFEM_OK;
@@ -160,4 +160,4 @@ extern "C" int mfem_rand(mfem_context ctx, int64_t n, uint64_t seed, uint32_t st
   hipLaunchKernelGGL(k_rand, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, seed, stream_id, x);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_rand")

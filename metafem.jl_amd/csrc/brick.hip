@@ -47,6 +47,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_brick_coords(BrickView B, double
 
 static int upload_dim_tables(mfem_brick_s* b, int d) {
   const int m = b->m[d], p = b->p;
+  mfem_host_alloc_probe();
   std::vector<int32_t> lo(m), c(m);
   std::vector<int64_t> P(m + 1);
   int64_t acc = 0;
@@ -93,13 +94,14 @@ static int brick_alloc_coords(mfem_brick_s* b) {
 }
 
 extern "C" int mfem_brick_create(mfem_context ctx, int32_t nx, int32_t ny, int32_t nz, double lx, double ly, double lz,
-                                 int32_t itp_order, int32_t itg_order, mfem_brick* out) {
+                                 int32_t itp_order, int32_t itg_order, mfem_brick* out) try {
   MFEM_REQUIRE(ctx && out, "null argument");
   MFEM_REQUIRE(nx > 0 && ny > 0 && nz > 0, "element counts must be positive");
   MFEM_REQUIRE(itp_order == 1 || itp_order == 2, "Lagrange cube order must be 1 or 2 (reference 3_InitializeMesh.jl:132-135)");
   MFEM_REQUIRE(itg_order >= 0 && itg_order <= 7, "itg_order out of range (Gauss tables exist for 1..4 points)");
   const int64_t m0 = (int64_t)itp_order * nx + 1, m1 = (int64_t)itp_order * ny + 1, m2 = (int64_t)itp_order * nz + 1;
   MFEM_REQUIRE(m0 * m1 * m2 < ((int64_t)1 << 31), "control-point ids must fit int32 (FEM_Int)");
+  mfem_host_alloc_probe();
   mfem_brick_s* b = new mfem_brick_s();
   memset(b, 0, sizeof(*b));
   b->ctx = ctx;
@@ -114,7 +116,12 @@ extern "C" int mfem_brick_create(mfem_context ctx, int32_t nx, int32_t ny, int32
   b->plo = 0; b->phi = b->m[0]; b->clo = 0; b->chi = b->m[0];
   b->n_owned = m0 * b->plane_len;
   int rc = MFEM_OK;
-  for (int d = 0; d < 3 && rc == MFEM_OK; ++d) rc = upload_dim_tables(b, d);
+  try {
+    for (int d = 0; d < 3 && rc == MFEM_OK; ++d) rc = upload_dim_tables(b, d);
+  } catch (...) {  // (host vectors of the tables: nothing half-built is left behind; the entry point's handler reports it)
+    mfem_brick_destroy(b);
+    throw;
+  }
   if (rc == MFEM_OK) rc = brick_alloc_coords(b);
   if (rc != MFEM_OK) {
     mfem_brick_destroy(b);
@@ -122,9 +129,9 @@ extern "C" int mfem_brick_create(mfem_context ctx, int32_t nx, int32_t ny, int32
   }
   *out = b;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_create")
 
-extern "C" int mfem_brick_destroy(mfem_brick b) {
+extern "C" int mfem_brick_destroy(mfem_brick b) try {
   if (!b) return MFEM_OK;
   for (int d = 0; d < 3; ++d) {
     if (b->coords[d]) hipFree(b->coords[d]);
@@ -134,13 +141,13 @@ extern "C" int mfem_brick_destroy(mfem_brick b) {
   }
   delete b;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_destroy")
 
 extern "C" int64_t mfem_brick_num_controlpoints(mfem_brick b) { return b ? (int64_t)b->m[0] * b->plane_len : -1; }
 extern "C" int64_t mfem_brick_num_elements(mfem_brick b) { return b ? (int64_t)b->ne[0] * b->ne[1] * b->ne[2] : -1; }
 extern "C" double* mfem_brick_coords(mfem_brick b, int32_t d) { return (b && d >= 0 && d < 3) ? b->coords[d] : nullptr; }
 
-extern "C" int mfem_brick_set_slab(mfem_brick b, int32_t plane_lo, int32_t plane_hi) {
+extern "C" int mfem_brick_set_slab(mfem_brick b, int32_t plane_lo, int32_t plane_hi) try {
   MFEM_REQUIRE(b, "null brick");
   MFEM_REQUIRE(plane_lo >= 0 && plane_hi <= b->m[0] && plane_lo < plane_hi, "bad plane range");
   const int gw = b->p;  // ghost planes per side
@@ -158,7 +165,7 @@ extern "C" int mfem_brick_set_slab(mfem_brick b, int32_t plane_lo, int32_t plane
   MFEM_CHECK_HIP(hipMemcpy(&pplo, b->d_P[0] + plane_lo, sizeof(int64_t), hipMemcpyDeviceToHost));
   b->Pplo = pplo;
   return brick_alloc_coords(b);
-}
+} MFEM_API_CATCH("mfem_brick_set_slab")
 
 // ---- pattern ---------------------------------------------------------------------------------
 // rows: f*n_owned + node ; row (f,node) holds F blocks of c(node) entries, block g lists the coupled
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_brick_pattern(BrickView B, int64
 
 int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A);
 
-extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fields, mfem_csr* out) {
+extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fields, mfem_csr* out) try {
   MFEM_REQUIRE(ctx && b && out, "null argument");
   MFEM_REQUIRE(n_fields >= 1 && n_fields <= 8, "n_fields out of range");
   int64_t Pphi = 0;
@@ -202,6 +209,7 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   const int64_t nnz = (int64_t)n_fields * n_fields * T;
   const int64_t xlen = n + (int64_t)2 * n_fields * b->p * b->plane_len;
   MFEM_REQUIRE(xlen < ((int64_t)1 << 31), "local column ids must fit int32");
+  mfem_host_alloc_probe();
   mfem_csr_s* A = new mfem_csr_s();
   memset(A, 0, sizeof(*A));
   A->ctx = ctx;
@@ -233,4 +241,4 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   }
   *out = A;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_brick_pattern")

@@ -63,16 +63,17 @@ struct mfem_comm_s {
     }                                                                               \
   } while (0)
 
-extern "C" int mfem_comm_unique_id(void* out128) {
+extern "C" int mfem_comm_unique_id(void* out128) try {
   MFEM_REQUIRE(out128, "null buffer");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
   MFEM_CHECK_NCCL(ncclGetUniqueId(&id));
   memcpy(out128, &id, sizeof(id));
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_comm_unique_id")
 
 static mfem_comm_s* comm_new(int backend, int rank, int world) {
+  mfem_host_alloc_probe();
   mfem_comm_s* c = new mfem_comm_s();
   memset(c, 0, sizeof(*c));
   c->backend = backend;
@@ -81,7 +82,7 @@ static mfem_comm_s* comm_new(int backend, int rank, int world) {
   return c;
 }
 
-extern "C" int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out) {
+extern "C" int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, const void* unique_id128, mfem_comm* out) try {
   MFEM_REQUIRE(ctx && unique_id128 && out, "null argument");
   MFEM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
   MFEM_CHECK_HIP(hipSetDevice(ctx->device));
@@ -108,10 +109,10 @@ extern "C" int mfem_comm_create(mfem_context ctx, int32_t rank, int32_t world, c
   }
   *out = c;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_comm_create")
 
 extern "C" int mfem_comm_create_host(mfem_context ctx, int32_t rank, int32_t world, const mfem_comm_host_ops* ops,
-                                     mfem_comm* out) {
+                                     mfem_comm* out) try {
   MFEM_REQUIRE(ctx && ops && out, "null argument");
   MFEM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
   MFEM_REQUIRE(ops->allreduce_sum && ops->neighbour_exchange, "both callbacks are required");
@@ -119,9 +120,9 @@ extern "C" int mfem_comm_create_host(mfem_context ctx, int32_t rank, int32_t wor
   c->host = *ops;
   *out = c;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_comm_create_host")
 
-extern "C" int mfem_comm_destroy(mfem_comm c) {
+extern "C" int mfem_comm_destroy(mfem_comm c) try {
   if (!c) return MFEM_OK;
   if (c->backend == 0) {
     if (c->halo_stream) hipStreamSynchronize(c->halo_stream);
@@ -134,10 +135,10 @@ extern "C" int mfem_comm_destroy(mfem_comm c) {
   if (c->d_stage) hipFree(c->d_stage);
   delete c;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_comm_destroy")
 
 extern "C" int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_owned_nodes, int64_t plane_len,
-                                     int32_t n_fields) {
+                                     int32_t n_fields) try {
   MFEM_REQUIRE(ctx, "null ctx");
   if (!c) {
     ctx->comm = nullptr;
@@ -151,7 +152,7 @@ extern "C" int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_ow
   ctx->halo_plane_len = plane_len;
   ctx->halo_fields = n_fields;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_context_set_comm")
 
 int mfem_comm_world(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->world : 1; }
 int mfem_comm_rank(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
@@ -377,23 +378,23 @@ int mfem_comm_halo_reduce(mfem_context_s* ctx, double* x) {
   return MFEM_OK;
 }
 
-extern "C" int mfem_allreduce_sum(mfem_context ctx, double* dev_scalars, int32_t count) {
+extern "C" int mfem_allreduce_sum(mfem_context ctx, double* dev_scalars, int32_t count) try {
   MFEM_REQUIRE(ctx && dev_scalars && count >= 0, "bad argument");
   MFEM_REQUIRE(ctx->comm, "no communicator attached (mfem_context_set_comm)");
   return mfem_comm_allreduce(ctx, dev_scalars, count);
-}
+} MFEM_API_CATCH("mfem_allreduce_sum")
 
-extern "C" int mfem_halo_exchange(mfem_context ctx, double* x_local) {
+extern "C" int mfem_halo_exchange(mfem_context ctx, double* x_local) try {
   MFEM_REQUIRE(ctx && x_local, "bad argument");
   MFEM_REQUIRE(ctx->comm, "no communicator attached (mfem_context_set_comm)");
   return mfem_comm_halo(ctx, x_local);
-}
+} MFEM_API_CATCH("mfem_halo_exchange")
 
-extern "C" int mfem_halo_reduce(mfem_context ctx, double* x_local) {
+extern "C" int mfem_halo_reduce(mfem_context ctx, double* x_local) try {
   MFEM_REQUIRE(ctx && x_local, "bad argument");
   MFEM_REQUIRE(ctx->comm, "no communicator attached (mfem_context_set_comm)");
   return mfem_comm_halo_reduce(ctx, x_local);
-}
+} MFEM_API_CATCH("mfem_halo_reduce")
 
 // ---- diagnostic: the RCCL choreography of one overlapped SpMV + reduction group, on a ring ------------------------------------
 // What the solver issues per iteration with the RCCL transport -- grouped ncclSend / ncclRecv on the high-priority halo stream fenced
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_ring_check(int64_t n, double bas
     if (r[i] != base + (double)i) atomicAdd(bad, 1);
 }
 
-extern "C" int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds) {
+extern "C" int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds) try {
   MFEM_REQUIRE(ctx && count > 0 && rounds > 0, "bad argument");
   mfem_comm_s* c = ctx->comm;
   MFEM_REQUIRE(c && c->backend == 0, "needs an attached RCCL communicator (mfem_comm_create + mfem_context_set_comm)");
@@ -476,4 +477,4 @@ extern "C" int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t
   hipFree(snd);
   hipFree(rcv);
   return rc;
-}
+} MFEM_API_CATCH("mfem_debug_comm_selftest")

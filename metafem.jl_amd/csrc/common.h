@@ -1,6 +1,8 @@
 // Shared internals of libmetafem_mi355x.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -14,6 +16,14 @@
 #define MFEM_NSCALARS 4096       // device-resident Krylov scalars (doubles)  // upper bound on per-launch partial sums of a fused reduction
 
 void mfem_set_error(const char* fmt, ...);
+
+// Every `extern "C" int` entry point is a function-try-block closed by this handler: no C++ exception leaves the library (include/metafem_mi355x.h,
+// error convention).  mfem_api_exception (api.hip) rethrows the exception in flight, maps it to a status and sets mfem_last_error().
+int mfem_api_exception(const char* entry) noexcept;
+#define MFEM_API_CATCH(entry) catch (...) { return mfem_api_exception(entry); }
+// Called in front of the library's host allocations (new / std::vector): throws std::bad_alloc when mfem_debug_fail_host_alloc armed it -- the
+// test hook that shows the handler above at work (tests/test_gpu_round4_abi.py).
+void mfem_host_alloc_probe();
 
 #define MFEM_CHECK_HIP(expr)                                                                  \
   do {                                                                                        \
@@ -100,6 +110,7 @@ struct mfem_context_s {
   hipStream_t graph_stream;
   hipEvent_t graph_ev;
   int graph_active;   // set by mfem_solve for the duration of a solve when cycles may be captured
+  int probe_active;   // set while a measuring product runs on this context (symmetry probe, placement trial): not an SpMV a solver asked for -- the usage counters skip it
 };
 #define MFEM_PROF_PAIRS 1024
 int mfem_prof_flush(mfem_context_s* ctx);
@@ -206,7 +217,6 @@ int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A);  // propose
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
 int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles
-extern int mfem_probe_active;
 int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
                    void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym);
 void mfem_lat27_unbind(mfem_csr_s* A);
@@ -241,7 +251,7 @@ int mfem_ws_decide(mfem_context_s* ctx, bool keep_current);
 uint64_t mfem_next_csr_serial();
 bool mfem_context_alive(mfem_context_s* ctx);       // false once mfem_context_destroy has run (api.hip)
 void mfem_graphs_invalidate(mfem_context_s* ctx);  // drops every cached cycle graph of the context (api.hip)
-extern int mfem_debug_epoch;  // bumped by every mfem_debug_set_*: part of the cycle-graph cache key (api.hip)
+extern std::atomic<int> mfem_debug_epoch;  // bumped by every mfem_debug_set_*: part of the cycle-graph cache key (api.hip)
 
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ double wave_reduce_sum(double v) {

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_update_geometry(
 extern "C" int mfem_update_basic_elements(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
                                           const double* ref_itp_vals, const double* itg_weight, const double* coords,
                                           const int32_t* controlpoint_IDs, int32_t index_base, double* integral_vals,
-                                          double* integral_weights) {
+                                          double* integral_weights) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   MFEM_REQUIRE(itg > 0 && itp > 0 && nel >= 0 && ncp > 0, "bad sizes");
@@ -130,14 +130,14 @@ extern "C" int mfem_update_basic_elements(mfem_context ctx, int32_t dim, int32_t
                        (double*)nullptr);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_update_basic_elements")
 
 extern "C" int mfem_update_basic_boundary(mfem_context ctx, int32_t dim, int32_t itg_b, int32_t itp, int32_t n_face_ids,
                                           int64_t n_facets, int64_t ncp, const double* bdy_ref_itp_vals,
                                           const double* bdy_itg_weights, const double* bdy_tangent_directions,
                                           const double* coords, const int32_t* controlpoint_IDs, const int32_t* element_ID,
                                           const int32_t* element_eindex, int32_t index_base, double* integral_vals,
-                                          double* integral_weights, double* normal_directions) {
+                                          double* integral_weights, double* normal_directions) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   MFEM_REQUIRE(itg_b > 0 && itp > 0 && n_face_ids > 0 && n_facets >= 0 && ncp > 0, "bad sizes");
@@ -159,4 +159,4 @@ extern "C" int mfem_update_basic_boundary(mfem_context ctx, int32_t dim, int32_t
                        normal_directions);
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_update_basic_boundary")

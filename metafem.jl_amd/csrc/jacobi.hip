@@ -176,19 +176,19 @@ int mfem_jacobi_diag_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* va
   return MFEM_OK;
 }
 
-extern "C" int mfem_jacobi_by_diagonal(mfem_context ctx, mfem_csr A, const double* vals, double* d) {
+extern "C" int mfem_jacobi_by_diagonal(mfem_context ctx, mfem_csr A, const double* vals, double* d) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(A->n == 0 || (vals && d), "null array");
   return mfem_jacobi_diag_launch(ctx, A, vals, d, 0);
-}
+} MFEM_API_CATCH("mfem_jacobi_by_diagonal")
 
-extern "C" int mfem_jacobi_by_row(mfem_context ctx, mfem_csr A, const double* vals, double* d) {
+extern "C" int mfem_jacobi_by_row(mfem_context ctx, mfem_csr A, const double* vals, double* d) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(A->n == 0 || (vals && d), "null array");
   return mfem_jacobi_diag_launch(ctx, A, vals, d, 1);
-}
+} MFEM_API_CATCH("mfem_jacobi_by_row")
 
-extern "C" int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double* vals, double* d) {
+extern "C" int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double* vals, double* d) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   if (A->n == 0) return MFEM_OK;
   MFEM_REQUIRE(vals && d, "null array");
@@ -210,7 +210,7 @@ extern "C" int mfem_jacobi2_by_column(mfem_context ctx, mfem_csr A, const double
   MFEM_CHECK_LAUNCH();
   if (slab) return mfem_comm_halo(ctx, d);  // ghost entries = the owners' d
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_jacobi2_by_column")
 
 int mfem_mat_div_jacobi_from(mfem_context_s* ctx, mfem_csr_s* A, const double* src, double* vals, const double* d) {
   if (A->nnz == 0) return MFEM_OK;
@@ -220,9 +220,9 @@ int mfem_mat_div_jacobi_from(mfem_context_s* ctx, mfem_csr_s* A, const double* s
   return MFEM_OK;
 }
 
-extern "C" int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double* d) {
+extern "C" int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double* d) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   if (A->nnz == 0) return MFEM_OK;
   MFEM_REQUIRE(vals && d, "null array");
   return mfem_mat_div_jacobi_from(ctx, A, vals, vals, d);
-}
+} MFEM_API_CATCH("mfem_mat_div_jacobi")

@@ -60,7 +60,10 @@ inline uint64_t mfem_csr_graph_key(uint64_t key, const mfem_csr_s* A) {
   key = mfem_hash(key, A->n); key = mfem_hash(key, A->nnz); key = mfem_hash(key, A->max_row_nnz);
   key = mfem_hash(key, A->index_base); key = mfem_hash(key, A->ell_vals);
   key = mfem_hash(key, A->ell_bound_mode + 16 * A->sym_bound + 32 * A->symp_bound); key = mfem_hash(key, A->sell_vals); key = mfem_hash(key, A->lat27_vals); key = mfem_hash(key, A->lat8_vals); key = mfem_hash(key, A->symp_vals);
-  key = mfem_hash(key, mfem_debug_epoch);
+  // the column scaling the lattice-tile kernels apply to x is a kernel argument too: a solve with right Jacobi (dsc = the solve's d) and one without
+  // (dsc = null) on the same pattern, values and workspace must not share a captured cycle
+  key = mfem_hash(key, A->lat27_dsc); key = mfem_hash(key, A->lat8_dsc);
+  key = mfem_hash(key, mfem_debug_epoch.load());
   return key;
 }
 

@@ -624,40 +624,40 @@ static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* val
 // ------------------------------------------------------------------------------------------
 // iterative_Solve! wrapper
 // ------------------------------------------------------------------------------------------
-extern "C" int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int32_t count) {
+extern "C" int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int32_t count) try {
   MFEM_REQUIRE(ctx, "null ctx");
   MFEM_REQUIRE(count >= 0, "negative count");
   ctx->shadow = shadow;
   ctx->shadow_count = shadow ? count : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_solve_set_shadow")
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int g_ws_trial = 1;           // timed choice between two allocations of a large workspace (mfem_debug_set_ws_trial)
-extern "C" int mfem_debug_set_ws_trial(int on) {
+static std::atomic<int> g_ws_trial{1};           // timed choice between two allocations of a large workspace (mfem_debug_set_ws_trial)
+extern "C" int mfem_debug_set_ws_trial(int on) try {
   g_ws_trial = on ? 1 : 0;
   return MFEM_OK;
-}
-extern "C" int mfem_debug_ws_trial_log(mfem_context ctx, double* out4) {  // times of the candidates tried (ms for two SpMVs; 0: not tried)
+} MFEM_API_CATCH("mfem_debug_set_ws_trial")
+extern "C" int mfem_debug_ws_trial_log(mfem_context ctx, double* out4) try {  // times of the candidates tried (ms for two SpMVs; 0: not tried)
   MFEM_REQUIRE(ctx && out4, "null argument");
   for (int i = 0; i < 4; ++i) out4[i] = ctx->ws_log[i];
   return MFEM_OK;
-}
-static int g_graphs = 1;             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
-static int64_t g_graph_max_n = 4000000;  // above this size kernels are long enough that launch latency is hidden anyway
-extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) {
+} MFEM_API_CATCH("mfem_debug_ws_trial_log")
+static std::atomic<int> g_graphs{1};             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
+static std::atomic<int64_t> g_graph_max_n{4000000};  // above this size kernels are long enough that launch latency is hidden anyway
+extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) try {
   ++mfem_debug_epoch;
   g_graphs = on ? 1 : 0;
   if (max_n > 0) g_graph_max_n = max_n;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_graphs")
 
 static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
                        const mfem_solve_options* o, mfem_solve_stats* stats);
 
 extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
-                          const mfem_solve_options* o, mfem_solve_stats* stats) {
+                          const mfem_solve_options* o, mfem_solve_stats* stats) try {
   MFEM_REQUIRE(ctx && A && o, "null argument");
   // Cycle graphs: not with a communicator (RCCL calls inside the cycle), not while per-launch SpMV timing is on (event
   // records inside the cycle), not in benchmark mode on large systems.  The legacy null stream cannot be captured: the
@@ -683,7 +683,7 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
     ctx->stream = user;
   }
   return rc;
-}
+} MFEM_API_CATCH("mfem_solve")
 
 static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
                        const mfem_solve_options* o, mfem_solve_stats* stats) {
@@ -752,6 +752,10 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   }
   fused_scale = fused_scale && (ell_bytes || sell_bytes || lat_only);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
   const bool need_copy = need_copy_unfused && !fused_scale;
+  // The lattice tiles take the caller's UNSCALED values (a right scaling goes to x).  When the scaling could not be folded into a layout after all
+  // (tiles planned but refused once, no other layout at this size) the working values are a scaled copy in the workspace that is filled only
+  // further down: nothing may be bound from it here -- the tiles are out for this solve.
+  if (need_copy && jac && !is_cg) lat_bytes = lat8_bytes = 0;
   const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
   size_t layout_bytes = ell_bytes > sell_bytes ? ell_bytes : sell_bytes;  // (one of the two is 0)
   if (lat_bytes > layout_bytes) layout_bytes = lat_bytes;
@@ -951,7 +955,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     {
       const int prof = ctx->prof_on;
       ctx->prof_on = 0;
-      mfem_probe_active = 1;
+      ctx->probe_active = 1;
       hipEvent_t e0, e1;
       MFEM_CHECK_HIP(hipEventCreate(&e0));
       MFEM_CHECK_HIP(hipEventCreate(&e1));
@@ -964,7 +968,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
       ctx->prof_on = prof;
-      mfem_probe_active = 0;
+      ctx->probe_active = 0;
       if (rc) return rc;
       MFEM_CHECK_HIP(hipMemsetAsync(V.w[1], 0, vec_bytes, ctx->stream));  // (A * 0: zero anyway; the work vectors start clear)
     }

@@ -112,12 +112,12 @@ __global__ void kb_sweep_end(FoldArg fa, BlArgs a, double* __restrict__ S, int32
 }
 
 // ---- fused form ------------------------------------------------------------------------------------------------------------------------
-static int g_bicgstabl_literal = 0;
-extern "C" int mfem_debug_set_bicgstabl(int literal_sequence) {
+static std::atomic<int> g_bicgstabl_literal{0};
+extern "C" int mfem_debug_set_bicgstabl(int literal_sequence) try {
   ++mfem_debug_epoch;
   g_bicgstabl_literal = literal_sequence ? 1 : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_bicgstabl")
 enum {
   B_Z = B_DOT + KK_MAX_DOTS,              // Gram matrix Z[p + (BL_MAXL + 1) * q] = R[p]' R[q], 0 <= p <= q <= l
   B_AX = B_Z + (BL_MAXL + 1) * (BL_MAXL + 1),  // x  += sum_k ax[k] R[k], k = 0..l

@@ -132,12 +132,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList
   }
 }
 
-static int g_idrs_literal = 0;
-extern "C" int mfem_debug_set_idrs(int literal_orthogonalisation) {
+static std::atomic<int> g_idrs_literal{0};
+extern "C" int mfem_debug_set_idrs(int literal_orthogonalisation) try {
   ++mfem_debug_epoch;
   g_idrs_literal = literal_orthogonalisation ? 1 : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_idrs")
 
 // merged bi-orthogonalisation, scalar part: d = P' g (I_D) -> alpha[0..k) (I_AL), column k of M from row k on, beta = f_k / M_kk   (:62-73)
 __global__ void ki_ortho(FoldArg fa, int dst, int m, int k, int s, int last, double* __restrict__ S, const int32_t* __restrict__ F) {

@@ -125,7 +125,7 @@ static int group_for(int m) {
 
 extern "C" int mfem_op_var(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t sd, int64_t cpID_shift,
                            const int32_t* el_g_cpIDs, const double* x, double* target, const int32_t* itg_hostIDs,
-                           const int32_t* elIDs, int64_t n_threads) {
+                           const int32_t* elIDs, int64_t n_threads) try {
   MFEM_REQUIRE(ctx, "null ctx");
   int rc = check_layout(L);
   if (rc) return rc;
@@ -142,11 +142,11 @@ extern "C" int mfem_op_var(mfem_context ctx, const mfem_op_layout* L, const doub
 #undef LAUNCH_VAR
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_op_var")
 
 extern "C" int mfem_op_res(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t dual_sd, const double* vals,
                            int64_t cpID_shift, const int32_t* el_g_cpIDs, double* residue, const int32_t* itg_hostIDs,
-                           const int32_t* elIDs, int64_t n_threads) {
+                           const int32_t* elIDs, int64_t n_threads) try {
   MFEM_REQUIRE(ctx, "null ctx");
   int rc = check_layout(L);
   if (rc) return rc;
@@ -167,11 +167,11 @@ extern "C" int mfem_op_res(mfem_context ctx, const mfem_op_layout* L, const doub
     MFEM_CHECK_LAUNCH();
     return MFEM_OK;
   });
-}
+} MFEM_API_CATCH("mfem_op_res")
 
 extern "C" int mfem_op_kval(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t dual_sd, int32_t base_sd,
                             const double* vals, const int32_t* sparse_IDs_by_el, int64_t sparse_ID_shift, double* K_val,
-                            const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+                            const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) try {
   MFEM_REQUIRE(ctx, "null ctx");
   int rc = check_layout(L);
   if (rc) return rc;
@@ -193,7 +193,7 @@ extern "C" int mfem_op_kval(mfem_context ctx, const mfem_op_layout* L, const dou
     MFEM_CHECK_LAUNCH();
     return MFEM_OK;
   });
-}
+} MFEM_API_CATCH("mfem_op_kval")
 
 
 // =====================================================================================================
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_op_var_batch(OpView V, VarTerms 
 extern "C" int mfem_op_kval_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
                                   const mfem_kval_term* terms, const double* vals, const int32_t* sparse_IDs_by_el,
                                   int64_t slot_block_stride, int64_t sparse_ID_shift_unit, double* K_val,
-                                  const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+                                  const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) try {
   MFEM_REQUIRE(ctx, "null ctx");
   int rc = check_layout(L);
   if (rc) return rc;
@@ -347,11 +347,11 @@ extern "C" int mfem_op_kval_batch(mfem_context ctx, const mfem_op_layout* L, con
     MFEM_CHECK_LAUNCH();
     return MFEM_OK;
   });
-}
+} MFEM_API_CATCH("mfem_op_kval_batch")
 
 extern "C" int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
                                  const mfem_res_term* terms, const double* vals, const int32_t* el_g_cpIDs, double* residue,
-                                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+                                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) try {
   MFEM_REQUIRE(ctx, "null ctx");
   int rc = check_layout(L);
   if (rc) return rc;
@@ -380,11 +380,11 @@ extern "C" int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, cons
     MFEM_CHECK_LAUNCH();
     return MFEM_OK;
   });
-}
+} MFEM_API_CATCH("mfem_op_res_batch")
 
 extern "C" int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
                                  const mfem_var_term* terms, const int32_t* el_g_cpIDs, double* targets,
-                                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) {
+                                 const int32_t* itg_hostIDs, const int32_t* elIDs, int64_t n_threads) try {
   MFEM_REQUIRE(ctx, "null ctx");
   int rc = check_layout(L);
   if (rc) return rc;
@@ -408,4 +408,4 @@ extern "C" int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, cons
 #undef LAUNCH_VARB
   MFEM_CHECK_LAUNCH();
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_op_var_batch")

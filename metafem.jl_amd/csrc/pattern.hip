@@ -81,7 +81,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_slots(int itp, int64_t nel, int6
 }
 
 extern "C" int mfem_pattern_build(mfem_context ctx, int32_t itp, int64_t nel, int64_t ncp, const int32_t* controlpoint_IDs,
-                                  int32_t index_base, int32_t n_fields, mfem_csr* out, int32_t* sparse_IDs_by_el) {
+                                  int32_t index_base, int32_t n_fields, mfem_csr* out, int32_t* sparse_IDs_by_el) try {
   MFEM_REQUIRE(ctx && controlpoint_IDs && out, "null argument");
   MFEM_REQUIRE(itp > 0 && nel > 0 && ncp > 0, "sizes must be positive");
   MFEM_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
@@ -123,6 +123,7 @@ extern "C" int mfem_pattern_build(mfem_context ctx, int32_t itp, int64_t nel, in
     PB_CHECK(hipStreamSynchronize(ctx->stream));
     const int F = n_fields;
     const int64_t n = (int64_t)F * ncp, nnz = (int64_t)F * F * U;
+    mfem_host_alloc_probe();
     A = new mfem_csr_s();
     memset(A, 0, sizeof(*A));
     A->ctx = ctx;
@@ -163,4 +164,4 @@ done:
   *out = A;
   return MFEM_OK;
 #undef PB_CHECK
-}
+} MFEM_API_CATCH("mfem_pattern_build")

@@ -719,12 +719,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_wave_per_row(
 // ---- host side ----------------------------------------------------------------------------
 // Defaults from the 256^3 hex-8 sweep on MI355X (profiles/r01_spmv_sweep.txt): the round-robin tile map
 // beat the XCD-contiguous one by ~4 %, and issuing the whole tile's loads up front (x8) beat x4 by ~6 %.
-static int g_spmv_xcd_aware = 0;
-static int g_rb_elide = 1;  // row-block kernel: tiles whose rows repeat the column offsets of their first two rows read only those columns; bit 25 turns the inspection off (set before the pattern is created)
-static int g_rb_xcd = 1;  // row-block kernel: an XCD walks a contiguous eighth of the tiles (hex-27 128^3: 2.89 against 3.01 ms with round-robin tiles); bit 26 turns it off
-static int g_spmv_tile2688 = 1;  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
-static int g_spmv_grid_mult = 8;  // workgroups per CU of the persistent grid
-static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
+static std::atomic<int> g_spmv_xcd_aware{0};
+static std::atomic<int> g_rb_elide{1};  // row-block kernel: tiles whose rows repeat the column offsets of their first two rows read only those columns; bit 25 turns the inspection off (set before the pattern is created)
+static std::atomic<int> g_rb_xcd{1};  // row-block kernel: an XCD walks a contiguous eighth of the tiles (hex-27 128^3: 2.89 against 3.01 ms with round-robin tiles); bit 26 turns it off
+static std::atomic<int> g_spmv_tile2688{1};  // bit 27 of mfem_debug_set_spmv's first argument turns the 2688-entry wave tile off
+static std::atomic<int> g_spmv_grid_mult{8};  // workgroups per CU of the persistent grid
+static std::atomic<int> g_spmv_grid_mult_set{0};  // the caller chose it (mfem_debug_set_spmv): also applies to the wave-private kernel, which otherwise sizes its grid from what is resident
 // Kernel variant (bits 16-18 of mfem_debug_set_spmv's first argument):
 //   0 library default: 7 where tiles of a fixed row count fill their LDS block, 3 otherwise
 //   1 product tile, CAP 4032, a nonzero PAIR per lane and load (16-byte / 8-byte loads), 8 pairs in flight, 256 threads
@@ -734,9 +734,9 @@ static int g_spmv_grid_mult_set = 0;  // the caller chose it (mfem_debug_set_spm
 //     where they do not apply (split SpMV, unaligned arrays, fewer than 16 entries per row)
 //   4 row-transposing workgroup tile, CAP 4032, 256 threads
 //   6 wave-private row-transposing tiles (1792 / 2048 entries per wave), 2 waves per workgroup   7 (and 5) the same, 1 wave
-static int g_spmv_variant = 0;
+static std::atomic<int> g_spmv_variant{0};
 
-extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning hook for bench/profiling
+extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) try {  // tuning hook for bench/profiling
   ++mfem_debug_epoch;
   g_spmv_xcd_aware = xcd_aware & 0xFFFF;   // tiles per XCD run (0 = plain round-robin)
   g_spmv_variant = (xcd_aware >> 16) & 7;
@@ -746,7 +746,7 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) {  // tuning ho
   g_spmv_grid_mult_set = grid_mult > 0;
   g_spmv_grid_mult = grid_mult > 0 ? grid_mult : 8;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_spmv")
 
 // Measured on the hex-27 128^3 matrix (capacity, gathers in flight, workgroups per CU): (2048, 16, 6) 2.99 ms, (1792, 16, 7) 2.86,
 // (1536, 16, 8) 2.62, (1536, 20, 8) 3.02, (1280, 16, 8) 2.82, (1024, 12, 12) 4.47 -- two waves on every SIMD, the largest tile that allows it
@@ -872,13 +872,14 @@ static void csr_drop_plans(mfem_csr_s* A) {
 }
 
 extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const void* rowptr, int rowptr_bits,
-                               const int32_t* colidx, int index_base, mfem_csr* out) {
+                               const int32_t* colidx, int index_base, mfem_csr* out) try {
   MFEM_REQUIRE(ctx && out, "null argument");
   MFEM_REQUIRE(n >= 0 && nnz >= 0, "negative size");
   MFEM_REQUIRE(rowptr_bits == 32 || rowptr_bits == 64, "rowptr_bits must be 32 or 64");
   MFEM_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
   MFEM_REQUIRE(n == 0 || (rowptr && (nnz == 0 || colidx)), "null pattern arrays");
   MFEM_REQUIRE(rowptr_bits == 64 || nnz < ((int64_t)1 << 31), "nnz >= 2^31 needs 64-bit rowptr");
+  mfem_host_alloc_probe();
   mfem_csr_s* A = new mfem_csr_s();
   memset(A, 0, sizeof(*A));
   A->ctx = ctx;
@@ -896,17 +897,17 @@ extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const v
   }
   *out = A;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_csr_create")
 
 // The handle caches what it learnt from the borrowed rowptr / colidx (longest row, row blocks, which tiles repeat one column-offset
 // list, the solver layouts).  A caller that has rewritten those arrays in place (same n, same nnz) re-runs the inspection here.
-extern "C" int mfem_csr_replan(mfem_context ctx, mfem_csr A) {
+extern "C" int mfem_csr_replan(mfem_context ctx, mfem_csr A) try {
   MFEM_REQUIRE(ctx && A, "null argument");
   MFEM_REQUIRE(A->ctx == ctx, "the pattern belongs to another context");
   mfem_graphs_invalidate(ctx);
   csr_drop_plans(A);
   return mfem_csr_plan(ctx, A);
-}
+} MFEM_API_CATCH("mfem_csr_replan")
 
 // Column entries (4 bytes each) one launch of the default CSR kernel reads by design: all of them in a tile whose rows do not repeat one
 // offset list, the leading 128 / 256 staged entries (the first row / the first two rows) in a tile that does.
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_csr_cols_read(int64_t n, int64_t
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
 }
 
-extern "C" int mfem_csr_spmv_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes, int64_t* column_entries_read) {
+extern "C" int mfem_csr_spmv_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes, int64_t* column_entries_read) try {
   MFEM_REQUIRE(ctx && A && bytes, "null argument");
   int64_t cols = A->nnz, table = 0;
   const bool rb = A->rb_state == 1 && A->rb_rows, cw = !rb && A->cw_R > 0 && A->cw_elide;
@@ -964,9 +965,9 @@ extern "C" int mfem_csr_spmv_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes,
   // values once, the columns the kernel reads, x once (gathers of one entry by several rows are cache hits by design), y once, row pointers once
   *bytes = A->nnz * 8 + cols * 4 + A->n * 16 + (A->n + 1) * (A->rowptr_bits / 8) + table;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_csr_spmv_bytes")
 
-extern "C" int mfem_csr_destroy(mfem_csr A) {
+extern "C" int mfem_csr_destroy(mfem_csr A) try {
   if (!A) return MFEM_OK;
   // a cached cycle graph holds this pattern's arrays in its kernel arguments
   if (A->ctx && mfem_context_alive(A->ctx)) mfem_graphs_invalidate(A->ctx);
@@ -979,7 +980,7 @@ extern "C" int mfem_csr_destroy(mfem_csr A) {
   if (A->owned_colidx) hipFree(A->owned_colidx);
   delete A;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_csr_destroy")
 
 extern "C" const int64_t* mfem_csr_rowptr64(mfem_csr A) {
   return (A && A->rowptr_bits == 64) ? (const int64_t*)A->rowptr : nullptr;
@@ -1035,12 +1036,12 @@ int mfem_spmv_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, con
 // run beside it, the few planes of rows that do run after it has arrived (one extra small launch).  The row-sorted sliced layout
 // splits by blocks instead of zones: its ghost-reading rows are sorted behind all others when the pattern is planned.  Without a
 // communicator this is mfem_spmv_launch.
-static int g_halo_overlap = 1;
-extern "C" int mfem_debug_set_halo_overlap(int on) {
+static std::atomic<int> g_halo_overlap{1};
+extern "C" int mfem_debug_set_halo_overlap(int on) try {
   ++mfem_debug_epoch;
   g_halo_overlap = on ? 1 : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_halo_overlap")
 
 int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* x, double* y, double alpha, double beta,
                    const double* dotw, double* partials, int* n_partials, const int32_t* done_flag) {
@@ -1123,7 +1124,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   if (variant == 3 && A->rb_state == 1 && part.part == 0 && ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0) &&
       (A->ncols > 0 ? A->ncols : A->n) < ((int64_t)1 << 29)) {
     // tiles cut by nonzeros (rows of uneven length); the grid is what is resident
-    int grid = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult : RB_WG_PER_CU);
+    int grid = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult.load() : RB_WG_PER_CU);
     if (grid > MFEM_MAX_PARTIALS) grid = MFEM_MAX_PARTIALS;
     if ((int64_t)grid > A->rb_ntiles) grid = (int)A->rb_ntiles;
     if (A->rowptr_bits == 64)
@@ -1158,7 +1159,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
       // persistent grid = what is resident at once (LDS-limited; other counts leave a ragged last round: 8 per CU measured
       // 1.43 ms against 1.06 ms with 7 or 14 at 256^3)
       const int resident = (huge ? 4 : big ? 6 : 7) / waves;  // the 2688-entry tile keeps 42 gathers + the next tile in registers: one wave per SIMD
-      int capw = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult : resident);
+      int capw = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult.load() : resident);
       if (capw > MFEM_MAX_PARTIALS) capw = MFEM_MAX_PARTIALS;
       if (part.part != 0 && capw > MFEM_MAX_PARTIALS / 2) capw = MFEM_MAX_PARTIALS / 2;
       if (part.part == 2) {
@@ -1212,7 +1213,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
     cap &= ~7;  // multiple of 8 so blockIdx % 8 is a stable XCD label along the grid-stride loop
     if (cap < 8) cap = 8;
     int grid = (int)(ntiles < cap ? ((ntiles + 7) & ~(int64_t)7) : cap);
-    int xcd = (ntiles >= 64) ? g_spmv_xcd_aware : 0;
+    int xcd = (ntiles >= 64) ? g_spmv_xcd_aware.load() : 0;
     const int xch = xcd & 0xFFFF;
     const int64_t span = (int64_t)8 * (xch > 0 ? xch : 1);
     const int64_t ntiles_padded = xch ? (ntiles + span - 1) / span * span : ntiles;
@@ -1251,8 +1252,8 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
 }
 
 extern "C" int mfem_spmv_csr(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y,
-                             double alpha, double beta) {
+                             double alpha, double beta) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(A->n == 0 || (x && y && (A->nnz == 0 || vals)), "null vector");
   return mfem_spmv_launch(ctx, A, vals, x, y, alpha, beta, nullptr, nullptr, nullptr, nullptr);
-}
+} MFEM_API_CATCH("mfem_spmv_csr")

@@ -28,37 +28,37 @@ __host__ __device__ __forceinline__ int64_t ell_base(int64_t r, int K) { return 
 // Size thresholds: below them the Krylov loop is launch-bound and the CSR tile kernel, which spreads the nonzeros of few rows
 // over many lanes, is as fast or faster than a lane-per-row layout whose slots are walked one dependent batch after the other
 // (tools/probe_ell.py, tools/probe_small_solve.py: crossover ~3e5 rows with diagonal slots, ~1e6 rows with explicit columns).
-int64_t g_layout_min_rows_dia = 262144;
-int64_t g_layout_min_rows_cols = 1000000;
+std::atomic<int64_t> g_layout_min_rows_dia{262144};
+std::atomic<int64_t> g_layout_min_rows_cols{1000000};
 // hex-27 lattice tiles (spmv_lat27.hip): crossover against the CSR tile kernel + cycle graphs between 1.2e5 rows (41 / 45 us per CG iteration)
 // and 2.7e5 (70 / 54 us); at 9.1e5 rows 183 / 110 us (tools/probe_lat_threshold.py, profiles/r03_lat_tiles_thresholds.txt)
 #define LAT27_MIN_ROWS 180000
-int64_t g_layout_min_rows_lat27 = LAT27_MIN_ROWS;
-extern "C" int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns) {
+std::atomic<int64_t> g_layout_min_rows_lat27{LAT27_MIN_ROWS};
+extern "C" int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns) try {
   ++mfem_debug_epoch;
   g_layout_min_rows_dia = diagonal_slots;
   g_layout_min_rows_cols = explicit_columns;
   g_layout_min_rows_lat27 = explicit_columns < LAT27_MIN_ROWS ? explicit_columns : LAT27_MIN_ROWS;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_layout_min_rows")
 
-static int g_ell_enable = 1;
-static int g_dia_enable = 1;
+static std::atomic<int> g_ell_enable{1};
+static std::atomic<int> g_dia_enable{1};
 // 0 (default): 2 rows x 3 diagonals, sharing the x loads of a run of three consecutive offsets when the diagonals come in such
 // runs; 8: 2 rows x3 without that sharing; 1: 2 rows x2, 3: 2 rows x9, 4: 4 rows x1, 5: 4 rows x3, 6: 2 rows x1
-static int g_dia_variant = 0;
-static int g_dia_block = MFEM_BLOCK;  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
-static int g_dia_sym = 1;      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernels off
-static int g_symp_direct = 1;  // bit 27: 0 = patch-major copy made from the slot-major copy in a second pass (k_symp_bind) instead of by k_dia_vals
-static int g_symp_tail = 1;    // bit 26: 0 = the rows outside the swept planes in a launch of their own (as in a split SpMV)
-static int g_dia_symp = 1;     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
-static int g_dia_xcd = 0;      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
+static std::atomic<int> g_dia_variant{0};
+static std::atomic<int> g_dia_block{MFEM_BLOCK};  // threads per workgroup of the default diagonal-slotted kernel (tuning: 256 / 512 / 1024)
+static std::atomic<int> g_dia_sym{1};      // bit 22 of mfem_debug_set_ell turns the symmetric sweep kernels off
+static std::atomic<int> g_symp_direct{1};  // bit 27: 0 = patch-major copy made from the slot-major copy in a second pass (k_symp_bind) instead of by k_dia_vals
+static std::atomic<int> g_symp_tail{1};    // bit 26: 0 = the rows outside the swept planes in a launch of their own (as in a split SpMV)
+static std::atomic<int> g_dia_symp{1};     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
+static std::atomic<int> g_dia_xcd{0};      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
 // workgroup counts that are not fully resident (10, 12 per CU) lose 15 %.
-static int g_ell_variant = 6;
-static int g_ell_grid_mult = 6;
-extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: kernel variant; bits 8-15: workgroups per CU
+static std::atomic<int> g_ell_variant{6};
+static std::atomic<int> g_ell_grid_mult{6};
+extern "C" int mfem_debug_set_ell(int enable) try {  // bit 0: enable; bits 4-7: kernel variant; bits 8-15: workgroups per CU
   ++mfem_debug_epoch;
   g_ell_enable = enable & 1;
   g_dia_enable = (enable & 2) ? 0 : 1;   // bit 1: keep explicit columns even when the matrix is diagonal-structured
@@ -72,7 +72,7 @@ extern "C" int mfem_debug_set_ell(int enable) {  // bit 0: enable; bits 4-7: ker
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_ell")
 
 // cols[s][r] (0-based) for s < K; pad: the row index itself
 template <typename RP>
@@ -1170,6 +1170,7 @@ int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
       const int64_t w0 = centre > 1024 ? centre - 1024 : 0;
       const int64_t wn = (A->n - w0) < 2048 ? (A->n - w0) : 2048;  // rows in the window
       if (wn <= 0) continue;
+      mfem_host_alloc_probe();
       std::vector<int64_t> win((size_t)wn + 1);
       if (A->rowptr_bits == 64) {
         MFEM_CHECK_HIP(hipMemcpyAsync(win.data(), (const char*)A->rowptr + w0 * 8, (size_t)(wn + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1338,7 +1339,7 @@ static int sym27_grid(const mfem_context_s* ctx, const mfem_csr_s* A, int64_t* n
   if (nsteps_out) *nsteps_out = nsteps;
   return A->sym_S * nseg;
 }
-static int64_t g_sym_launches = 0;
+static std::atomic<int64_t> g_sym_launches{0};
 // the sweep kernel needs ~2 workgroups per CU of >= 8 steps each to beat the plain kernel: chunk ranges below ~2700 chunks (1.4 M rows) stay on the
 // plain kernel (mfem_debug_set_layout_min_rows(0, ...) lifts the limit for the parity tests)
 static bool sym27_wanted(const mfem_csr_s* A) {
@@ -1722,7 +1723,7 @@ int mfem_spmv_ell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
 // Matrix entries (8-byte values) one SpMV of the planned solver layout reads from memory: K * padded rows for the slot-major
 // layouts, less what the symmetric sweep kernel takes from LDS when the bound values are symmetric (*symmetric_sweep = 1 if the
 // structure allows that kernel; whether it runs is decided per solve by the bitwise symmetry check of the values).
-extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep) {
+extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int64_t* entries, int32_t* symmetric_sweep) try {
   MFEM_REQUIRE(ctx && A, "null argument");
   int32_t mode = 0;
   int rc = mfem_csr_solver_layout(ctx, A, &mode, nullptr, nullptr, nullptr);
@@ -1753,11 +1754,11 @@ extern "C" int mfem_csr_solver_layout_entries(mfem_context ctx, mfem_csr A, int6
   if (entries) *entries = e;
   if (symmetric_sweep) *symmetric_sweep = sym;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_csr_solver_layout_entries")
 
 // Bytes one SpMV of the planned solver layout moves by design (bench.py's roofline numerator): matrix entries, 4-byte columns where the
 // kernel reads them, x as often as the kernel fetches it from memory by design, y once.
-extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes) {
+extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_t* bytes) try {
   MFEM_REQUIRE(ctx && A && bytes, "null argument");
   int32_t mode = 0, slots = 0, sym = 0;
   int64_t npad = 0, reg = 0, ent = 0;
@@ -1783,13 +1784,13 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
   }
   *bytes = b;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_csr_solver_layout_bytes")
 
 // What the Krylov loop of the next mfem_solve will run on this pattern: 0 = CSR tile kernel, 1 = slot-major copy with explicit
 // columns, 2 = slot-major copy with diagonal-slotted regular blocks, 3 = row-sorted sliced layout, 4 / 5 = symmetric lattice tiles (one rank;
 // the values of each solve decide, modes 3 / 2 serve it otherwise).  Plans what it reports if that has not happened yet.
 extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mode, int32_t* slots, int64_t* padded_rows,
-                                      int64_t* regular_rows) {
+                                      int64_t* regular_rows) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   int rc = MFEM_OK, m = 0;
   // the lattice-tile layouts are looked at first: where they apply, the others are planned only on demand (krylov.hip)
@@ -1816,12 +1817,12 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
   if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_csr_solver_layout")
 
 // y = alpha A x + beta y through the layout mfem_solve would use for this pattern (the one-off conversion of `vals` included):
 // a test / diagnostic entry point -- production SpMVs of caller-supplied values go through mfem_spmv_csr.
 extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const double* vals, const double* x, double* y, double alpha,
-                                       double beta) {
+                                       double beta) try {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(A->n == 0 || (x && y && (A->nnz == 0 || vals)), "null vector");
   if (A->n == 0) return MFEM_OK;
@@ -1874,4 +1875,4 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
   mfem_lat27_unbind(A);
   mfem_lat8_unbind(A);
   return rc;
-}
+} MFEM_API_CATCH("mfem_spmv_solver_layout")

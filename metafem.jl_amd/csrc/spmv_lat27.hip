@@ -20,7 +20,7 @@
 //     dot product.  No global atomics; 2.1 cells per row written and read again (+ 12 % traffic).
 //   * eligibility is decided in two steps: the pattern must BE the lattice stencil (checked entry by entry once per pattern), and the values
 //     of this solve must be symmetric: measured per bind with a probe product (mfem_sym_probe below: the layout against the CSR kernel on one
-//     vector); the sliced layout serves the solve when they differ by more than 4e-13 max |A[r][c]|.  A right Jacobi scaling (bicgstabl_GS!, idrs!, cgs2! work on A D^-1, which is not
+//     vector); the sliced layout serves the solve when a row of the two products differs by more than 4e-13 of that row's diagonal entry.  A right Jacobi scaling (bicgstabl_GS!, idrs!, cgs2! work on A D^-1, which is not
 //     symmetric) is applied to x while it is staged: (A D^-1) x = A (x / d), so the stored matrix stays the symmetric A.
 //   * y differs from the CSR kernel's by round-off (other summation order), and the order in which the waves of a workgroup add into
 //     an LDS cell is not fixed: results are reproducible to ~1e-16 relative, not bitwise (mfem_debug_set_lat27(0) selects the sliced layout).
@@ -39,18 +39,17 @@
 
 typedef double l_d2 __attribute__((ext_vector_type(2)));
 
-extern int64_t g_layout_min_rows_lat27;  // spmv_ell.hip
-static int g_lat27_enable = 1;
-static long long g_lat27_count = 0;
-int mfem_probe_active = 0;  // set while mfem_sym_probe runs its two products: they are not SpMVs a solver asked for (the counters skip them)
+extern std::atomic<int64_t> g_layout_min_rows_lat27;  // spmv_ell.hip
+static std::atomic<int> g_lat27_enable{1};
+static std::atomic<long long> g_lat27_count{0};
 extern "C" long long mfem_debug_lat27_spmv_count(void) { return g_lat27_count; }  // SpMVs the layout has served (bench.py: which kernel ran)
 // max |A[r][c] - A[c][r]| / max |A[r][c]| the layout pass of the last bind on this pattern measured (-1: no bind yet)
 extern "C" double mfem_debug_lat27_asymmetry(mfem_csr A) { return A ? A->lat27_asym : -1.0; }
-extern "C" int mfem_debug_set_lat27(int enable) {
+extern "C" int mfem_debug_set_lat27(int enable) try {
   ++mfem_debug_epoch;
   g_lat27_enable = enable & 1;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_lat27")
 
 struct Lat27Geom {
   int m0, m1, m2;     // OWNED lattice points per direction (m0 = owned planes of a slab; m1, m2 odd)
@@ -77,9 +76,11 @@ __constant__ int8_t c_l27_d[L27_TAB][4];   // same index: (di, dj, dk) of the sl
 __constant__ int c_l27_K4[8];
 __constant__ int c_l27_gb[8];
 __constant__ int c_l27_tb[8];
-static bool g_l27_tables = false;
+static std::atomic<bool> g_l27_tables{false};
 
 static int lat27_upload_tables() {
+  static std::mutex mu;  // uploads from two host threads must not interleave (the tables themselves are process-wide: see the threading note in include/metafem_mi355x.h)
+  std::lock_guard<std::mutex> lk(mu);
   if (g_l27_tables) return MFEM_OK;
   int Kup[8];
   int16_t off[L27_TAB];
@@ -200,24 +201,29 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l27_fill(Lat27Geom G, const RP* 
 }
 
 // ---- the symmetry measure shared by the lattice-tile layouts (modes 4 and 5) ---------------------------------------------------------
-// The layout stores one triangle and mirrors it; whether that is the caller's matrix is measured with a probe product: x with entries in
-// [0.75, 1.25), y1 = (layout) x, y2 = (CSR kernel on the caller's values) x.  y1 - y2 = (L - U^T) x: an entry pair that differs by delta shows up
-// as >= 0.75 |delta| in its row (the other terms of that row are the other pairs' differences: no cancellation for a generic x).  The two products
-// round differently (<= a few 1e-15 max|a| for rows of up to 125 entries), so the layout is taken when max |y1 - y2| <= 4e-13 max |a|.
+// The layout stores one triangle and mirrors it; whether that is the caller's matrix is measured with a probe product: x with entries of magnitude
+// in [0.75, 1.25) and a random SIGN each (zero mean: a skew part with zero row sums -- convection-like terms -- is not attenuated the way a
+// nearly constant probe would), y1 = (layout) x, y2 = (CSR kernel on the caller's values) x.  y1 - y2 = (L - U^T) x: an entry pair that differs by
+// delta shows up as >= 0.75 |delta| in its row (the other terms of that row are the other pairs' differences: no cancellation for a generic x).
+// The two products round differently (a few 1e-15 of the row's entries for rows of up to 125 entries), so the layout is taken when
+//     max over rows r of |y1 - y2|_r / |a_rr|  <=  4e-13
+// -- the difference is weighed PER ROW by that row's diagonal entry (badly scaled matrices: a penalty or Robin row of 1e5 no longer hides an
+// asymmetric pair in a row of 1e-3); rows without a stored non-zero diagonal are weighed by the global max |a|.
 __global__ __launch_bounds__(MFEM_BLOCK) void k_probe_vector(int64_t n, double* __restrict__ x) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint64_t z = (uint64_t)i + 0x9E3779B97F4A7C15ull;  // splitmix64
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    x[i] = 0.75 + 0.5 * (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    const double mag = 0.75 + 0.5 * (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    x[i] = (z & 1ull) ? mag : -mag;
   }
 }
 __global__ __launch_bounds__(MFEM_BLOCK) void k_probe_diff(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
-                                                             unsigned long long* __restrict__ out) {
+                                                             const double* __restrict__ scale, unsigned long long* __restrict__ out) {
   double d = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double e = fabs(a[i] - b[i]);
+    double e = fabs(a[i] - b[i]) / scale[i];  // (scale > 0: |diagonal| or the preset max |a|)
     if (!(e == e)) e = __builtin_huge_val();
     d = fmax(d, e);
   }
@@ -227,16 +233,16 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_probe_diff(int64_t n, const doub
 }
 
 // scratch: ncols + 2 n doubles (x carries the ghost entries of a slab pattern).  The layout must be bound for `vals` with no column scaling; unbind() must leave the pattern without any bound layout
-// (the second product then runs the CSR kernel).  *asym = max |y1 - y2| / amax.
+// (the second product then runs the CSR kernel).  *asym = max over rows of |y1 - y2|_r / |a_rr| (rows without a non-zero diagonal: / amax).
 int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
                    void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym) {
   const int64_t n = A->n, nc = A->ncols > n ? A->ncols : n;
   double *x = scratch, *y1 = scratch + nc, *y2 = y1 + n;
   unsigned long long* d_stat = (unsigned long long*)(ctx->d_flags + 12);
+  MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
   const int prof = ctx->prof_on;
   ctx->prof_on = 0;  // (not SpMVs of the solve: bench.py's per-launch timing must not see them)
-  mfem_probe_active = 1;
-  MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
+  ctx->probe_active = 1;
   hipLaunchKernelGGL(k_probe_vector, dim3(mfem_vec_grid(ctx, nc)), dim3(MFEM_BLOCK), 0, ctx->stream, nc, x);
   int rc = mfem_spmv_launch(ctx, A, vals, x, y1, 1.0, 0.0, nullptr, nullptr, nullptr);
   if (!rc) {
@@ -245,16 +251,25 @@ int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
     rebind(A, cookie);
   }
   ctx->prof_on = prof;
-  mfem_probe_active = 0;
+  ctx->probe_active = 0;
   if (rc) return rc;
-  hipLaunchKernelGGL(k_probe_diff, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, y1, y2, d_stat);
+  const bool finite = amax < __builtin_huge_val() && amax == amax;
+  if (!(amax > 0.0) || !finite) {  // an all-zero matrix is symmetric; a non-finite one is not taken
+    *asym = finite ? 0.0 : 1.0;
+    return MFEM_OK;
+  }
+  // the rows' weights into x (the probe vector has served): |a_rr|, preset max |a| where no non-zero diagonal is stored
+  int mfem_fill(mfem_context_s* ctx, int64_t n, double v, double* x);  // (krylov.hip)
+  rc = mfem_fill(ctx, n, amax, x);
+  if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals, x, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_probe_diff, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, y1, y2, x, d_stat);
   MFEM_CHECK_LAUNCH();
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   double dmax;
   memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
-  const bool finite = amax < __builtin_huge_val();
-  *asym = (amax > 0.0 && finite) ? dmax / amax : ((dmax > 0.0 || !finite) ? 1.0 : 0.0);
+  *asym = dmax;  // already relative: max_r |y1 - y2|_r / |a_rr|
   return MFEM_OK;
 }
 
@@ -650,7 +665,7 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
                        done_flag, (const int32_t*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc);
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
-  if (!mfem_probe_active) ++g_lat27_count;
+  if (!ctx->probe_active) ++g_lat27_count;
   return 1;
 }
 

@@ -30,18 +30,18 @@
 
 typedef double m_d2 __attribute__((ext_vector_type(2)));
 
-extern int64_t g_layout_min_rows_dia;  // spmv_ell.hip
-static int g_lat8_enable = 1;
-static int g_lat8_one_field_everywhere = 0;  // bit 1 of mfem_debug_set_lat8: the query / diagnostic SpMV entry also report and take mode 5 for ONE field
-static long long g_lat8_count = 0;
+extern std::atomic<int64_t> g_layout_min_rows_dia;  // spmv_ell.hip
+static std::atomic<int> g_lat8_enable{1};
+static std::atomic<int> g_lat8_one_field_everywhere{0};  // bit 1 of mfem_debug_set_lat8: the query / diagnostic SpMV entry also report and take mode 5 for ONE field
+static std::atomic<long long> g_lat8_count{0};
 extern "C" long long mfem_debug_lat8_spmv_count(void) { return g_lat8_count; }
 extern "C" double mfem_debug_lat8_asymmetry(mfem_csr A) { return A ? A->lat8_asym : -1.0; }
-extern "C" int mfem_debug_set_lat8(int enable) {
+extern "C" int mfem_debug_set_lat8(int enable) try {
   ++mfem_debug_epoch;
   g_lat8_enable = enable & 1;
   g_lat8_one_field_everywhere = (enable >> 1) & 1;
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_lat8")
 // One field: cg! keeps the bitwise patch sweep of mode 2 (it moves the same bytes); the solvers that work on A D^-1 (idrs!, bicgstabl_GS!, cgs2!) cannot
 // use that sweep -- the scaled copy is not symmetric -- and take the tiles.  The layout query and the diagnostic SpMV entry answer for cg!.
 bool mfem_lat8_for_method(const mfem_csr_s* A, bool is_cg) { return A->lat_fields != 1 || !is_cg || g_lat8_one_field_everywhere; }
@@ -559,7 +559,7 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 #undef L8_PASS2
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
-  if (!mfem_probe_active) ++g_lat8_count;
+  if (!ctx->probe_active) ++g_lat8_count;
   return 1;
 }
 

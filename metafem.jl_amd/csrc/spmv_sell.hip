@@ -20,15 +20,15 @@
 typedef double s_d2 __attribute__((ext_vector_type(2)));
 typedef int s_i2 __attribute__((ext_vector_type(2)));
 
-extern int64_t g_layout_min_rows_cols;  // spmv_ell.hip
-static int g_sell_enable = 1;
-static int g_sell_offsets = 1;  // blocks with one diagonal list skip their column stream
-static int g_sell_window_log2 = 0;
-static int g_sell_unroll = 5;   // slots in flight per lane (bits 16-20 of mfem_debug_set_sell; 0 = default)
-static int g_sell_wg_per_cu = 8;
-static int g_sell_region = 0;   // edge of the lattice regions of the row sort (bits 4-7 of mfem_debug_set_sell x 8; 0 = global sort)
-static int g_sell_xcd = 0;      // bit 2: every XCD walks a contiguous eighth of the block list
-extern "C" int mfem_debug_set_sell(int enable) {  // bit 0: layout on/off; bit 1: always read explicit columns
+extern std::atomic<int64_t> g_layout_min_rows_cols;  // spmv_ell.hip
+static std::atomic<int> g_sell_enable{1};
+static std::atomic<int> g_sell_offsets{1};  // blocks with one diagonal list skip their column stream
+static std::atomic<int> g_sell_window_log2{0};
+static std::atomic<int> g_sell_unroll{5};   // slots in flight per lane (bits 16-20 of mfem_debug_set_sell; 0 = default)
+static std::atomic<int> g_sell_wg_per_cu{8};
+static std::atomic<int> g_sell_region{0};   // edge of the lattice regions of the row sort (bits 4-7 of mfem_debug_set_sell x 8; 0 = global sort)
+static std::atomic<int> g_sell_xcd{0};      // bit 2: every XCD walks a contiguous eighth of the block list
+extern "C" int mfem_debug_set_sell(int enable) try {  // bit 0: layout on/off; bit 1: always read explicit columns
   ++mfem_debug_epoch;
   g_sell_enable = enable & 1;
   g_sell_offsets = (enable & 2) ? 0 : 1;
@@ -38,7 +38,7 @@ extern "C" int mfem_debug_set_sell(int enable) {  // bit 0: layout on/off; bit 1
   g_sell_unroll = ((enable >> 16) & 31) ? ((enable >> 16) & 31) : 5;
   g_sell_wg_per_cu = ((enable >> 24) & 31) ? ((enable >> 24) & 31) : 8;  // rows are sorted within windows of 2^w consecutive rows (0 = over the whole matrix)
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_set_sell")
 
 struct SellRegions {  // lattice regions of the row sort (R = 0: none)
   int R;
@@ -305,7 +305,7 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   const int grid = mfem_grid_for(n, MFEM_BLOCK, ctx->num_cus * 16);
   int lenbits = 1;
   while ((1 << lenbits) <= A->max_row_nnz && lenbits < 31) ++lenbits;
-  const int wshift = g_sell_window_log2 > 0 ? g_sell_window_log2 : 63;
+  const int wshift = g_sell_window_log2 > 0 ? g_sell_window_log2.load() : 63;
   SELL_CHECK(hipMalloc(&keys, sizeof(uint64_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&ids, sizeof(int32_t) * (size_t)n));
   SELL_CHECK(hipMalloc(&keys2, sizeof(uint64_t) * (size_t)n));

@@ -50,7 +50,7 @@ def test_spmv_equals_the_csr_kernel(mf, small_layouts, dims):
         c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
         _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
         assert int(_lib.lib.mfem_debug_lat8_spmv_count()) == c0 + 1
-        assert _lib.lib.mfem_debug_lat8_asymmetry(A._h) <= 1e-14
+        assert _lib.lib.mfem_debug_lat8_asymmetry(A._h) <= 1e-13  # per-row measure |y_layout - y_csr|_r / |a_rr| of the bind's probe (gate: 4e-13)
         want = alpha * y0 + beta * 7.0
         assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
 
