@@ -13,8 +13,13 @@ solver:
     BASELINE.json (256^3) runs in the same invocation as the `secondary_256` object.
 --config c3: configs[2], linear elasticity hex-8 (3 DOF per node), 128^3 per GPU, BiCGStab(2) (bicgstabl_GS!).
 --config c4: configs[3], thermal conduction on quadratic hex-27 (FP64-MFMA Ke), 128^3 per GPU, Jacobi-PCG.
-N > 1 (every config): weak scaling -- every rank owns an `--n`-element-thick slab of an (n N) x n x n mesh (slab decomposition
+N > 1 (every config), `--scaling weak` (default): every rank owns an `--n`-element-thick slab of an (n N) x n x n mesh (slab decomposition
 along i, `order` ghost node planes per neighbour exchanged over RCCL beside the interior rows, one all-reduce per reduction group).
+`--scaling strong`: THE n^3 mesh of the config (512^3 / 128^3 / 128^3) is cut into N slabs along i -- the north_star's "the mesh is
+domain-decomposed across the 8 GPUs"; the line then says "scaling": "strong".
+At N = 1 the default invocation also runs configs[1] (256^3: `secondary_256`), configs[2] (`secondary_c3`) and configs[3] (`secondary_c4`, with the
+FP64-MFMA roofline of the hex-27 Ke kernels as `roofline_hex27_ke`) for a few timed steps each, so one driver line carries all four configs.
+Every timed solve's residual is checked: the run FAILS if the last timed solve did not reduce ||r|| (`initial_res` / `final_res` are printed).
 
 Prints ONE JSON line on rank 0.
 """
@@ -145,6 +150,9 @@ def self_launch(n_ranks: int) -> int:
     return 0
 
 
+TRAFFIC_FILE = "profiles/r03_traffic.json"
+
+
 def load_traffic():
     """profiles/r03_traffic.json: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950 x2
     FETCH correction, calibrated in the same run) of THIS tree's kernels, keyed by '<kernel key>@<workload key>'.  Collected by
@@ -212,6 +220,14 @@ def main():
     ap.add_argument("--secondary-n", type=int, default=256, help="c2 at N = 1: also run this mesh size (configs[1]) for a few steps (0 = skip)")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--hex27-n", type=int, default=128, help="c2 at N = 1: CSR-kernel roofline on the hex-27 matrix of this size (0 = skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = an --n thick slab per rank of an (n N) x n x n mesh; strong = the config's n^3 mesh cut into N slabs")
+    ap.add_argument("--secondary-configs", type=int, default=1,
+                    help="c2 at N = 1, default size: also run configs[2] (c3) and configs[3] (c4) for --secondary-steps timed steps each and the hex-27 "
+                         "Ke MFMA roofline (0 = skip)")
+    ap.add_argument("--ws-trial", type=int, default=1,
+                    help="1 (default here): opt in to the library's workspace placement trial (mfem_debug_set_ws_trial; OFF by default in the library "
+                         "since round 4) -- the line says so in config.workspace_placement_trial and prints the first step's wall time; 0 = as the library ships")
     ap.add_argument("--live-traffic", type=int, default=1,
                     help="N = 1, default sizes: collect the roofline objects' `traffic` in this run (two rocprofv3 --pmc child passes on the "
                          "headline workload, ~40 s) instead of reading profiles/r03_traffic.json (0 = read the file)")
@@ -305,11 +321,54 @@ def main():
                 "frac_actual": (gbs(traffic) / HBM_PEAK_GBS) if traffic else None,
                 "n": A.n, "nnz": A.nnz}
 
-    def run_workload(N, steps, warmup, want_csr):
-        """One workload of the selected config on an (N * world) x N x N mesh, `steps` timed steps."""
+    def hex27_ke_roofline(n27, repeats=5):
+        """north_star: 'MFMA used only for the dense per-element Ke = B^T D B contraction on high-order hex elements ... evidenced by MFMA
+        utilisation (hex-27 Ke) against gfx950 peak'.  The element kernels of the hex-27 matrix assembly (pass 1: geometry + 63 FP64 MFMAs per
+        element into a scratch of element matrices; pass 2: row-owner gather into CSR; no boundary faces) timed live with events on the stream they
+        are launched on (the context runs on torch's current stream), priced with SURVEY 8(d)'s USEFUL flops: 2 * 27 * 27 * 81 = 118 098 per element.
+        The MFMA-pipe busy fraction of pass 1 comes from the committed counter file (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128 SIMDs per XCD))."""
+        PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 matrix (MFMA) peak, dense
+        b27 = mf.Brick((1.0, 1.0, 1.0), (n27,) * 3, 2, 5, ctx=ctx)
+        A27 = b27.pattern(1)
+        K27 = torch.empty(A27.nnz, dtype=torch.float64, device=dev)
+        b27.assemble_thermal(A27, K_COND, 0.0, TENV, 0, out=K27)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(repeats):
+            b27.assemble_thermal(A27, K_COND, 0.0, TENV, 0, out=K27)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / repeats
+        nel = n27 ** 3
+        flops = 118098.0 * nel
+        busy = None
+        src = None
+        for key in ("hex27_counters_MFMA@c4_%d" % n27,):
+            ent = traffic_db.get(key, {}).get("per_kernel", {})
+            for kname, cs in ent.items():
+                if "k_hex27<true" in kname and cs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("mean"):
+                    busy = cs["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cs["GRBM_GUI_ACTIVE"]["mean"] * 128.0)
+                    src = (f"{TRAFFIC_FILE}['{key}']['{kname}']: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128) of the pass-1 kernel, "
+                           f"rocprofv3 --pmc pass of tools/run_pmc_r03.sh (tree {traffic_db[key].get('tree', '?')}), not collected in this run")
+        del b27, A27, K27
+        torch.cuda.empty_cache()
+        return {"kernel": "k_hex27<true, true> (pass 1: sum-factorised geometry + Ke = B^T D B on __builtin_amdgcn_mfma_f64_16x16x4f64, element matrices to "
+                          "scratch) + k_hex27_gather_lds (pass 2: row-owner gather into sorted CSR); one matrix assembly without boundary faces",
+                "matrix": f"hex-27 thermal {n27}^3 ({nel} elements)", "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_TFLOPS,
+                "useful_flop_per_assembly": flops, "avg_assembly_ms": ms, "assemblies_timed": repeats,
+                "achieved": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / PEAK_TFLOPS,
+                "mfma_pipe_busy_in_pass1": busy, "mfma_pipe_busy_source": src,
+                "note": "useful flops only (SURVEY 8(d)): the B build and the zero-padding of the 27 x 81 operands to MFMA tiles are not counted"}
+
+    strong = args.scaling == "strong" and world > 1
+
+    def run_workload(cfg, ckey, N, steps, warmup, want_csr):
+        """One workload of config `ckey`, `steps` timed steps: weak scaling = an (N * world) x N x N mesh (an N-thick slab per rank), strong scaling =
+        the N^3 mesh cut into `world` slabs along i."""
         order, F = cfg["order"], cfg["fields"]
-        nx_global = N * world
-        brick = mf.Brick((float(world), 1.0, 1.0), (nx_global, N, N), order, cfg["itg"], ctx=ctx)
+        nx_global = N if strong else N * world
+        brick = mf.Brick((1.0 if strong else float(world), 1.0, 1.0), (nx_global, N, N), order, cfg["itg"], ctx=ctx)
         m0, m1, m2 = brick.m
         comm = None
         if use_comm:
@@ -388,9 +447,17 @@ def main():
             assemble()
             return solve()
 
-        for _ in range(warmup):
+        t_first = time.perf_counter()
+        for w in range(warmup):
             step()
+            if w == 0:
+                torch.cuda.synchronize()
+                t_first = time.perf_counter() - t_first  # the first step: one-off plans, tables, workspace allocation (and the placement trial if opted in)
         _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 1))
+        if comm is not None:
+            _lib.check(_lib.lib.mfem_prof_comm_enable(ctx._h, 1))
+            hw, hn, aw, an = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+            _lib.check(_lib.lib.mfem_prof_comm_read(ctx._h, C.byref(hw), C.byref(hn), C.byref(aw), C.byref(an), 1))
         tot, cnt = C.c_double(), C.c_int64()
         _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
         sym_count0 = int(_lib.lib.mfem_debug_sym_spmv_count())
@@ -400,6 +467,7 @@ def main():
         t0 = time.perf_counter()
         solve_ms = 0.0
         iters_done = spmvs_done = 0
+        st = None
         for _ in range(steps):
             st = step()
             solve_ms += st.solve_ms
@@ -409,6 +477,22 @@ def main():
         elapsed = time.perf_counter() - t0
         _lib.check(_lib.lib.mfem_prof_spmv_read(ctx._h, C.byref(tot), C.byref(cnt), 1))
         _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 0))
+        comm_exposed = None
+        if comm is not None:
+            # communication this rank's solver stream was exposed to during the timed steps (mfem_prof_comm_*), every rank's numbers on rank 0
+            _lib.check(_lib.lib.mfem_prof_comm_read(ctx._h, C.byref(hw), C.byref(hn), C.byref(aw), C.byref(an), 1))
+            _lib.check(_lib.lib.mfem_prof_comm_enable(ctx._h, 0))
+            mine = torch.tensor([hw.value, float(hn.value), aw.value, float(an.value), solve_ms], dtype=torch.float64,
+                                device="cpu" if (host_comm or state.get("gloo_group") is not None) else dev)
+            if dist is not None:
+                allr = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine, group=state.get("gloo_group") if mine.device.type == "cpu" and not host_comm else None)
+            else:
+                allr = [mine]
+            comm_exposed = [{"rank": i, "halo_wait_ms_per_step": float(v[0]) / steps, "halo_waits_per_step": float(v[1]) / steps,
+                             "allreduce_ms_per_step": float(v[2]) / steps, "allreduces_per_step": float(v[3]) / steps,
+                             "solve_ms_per_step": float(v[4]) / steps,
+                             "exposed_fraction_of_solve": (float(v[0]) + float(v[2])) / max(float(v[4]), 1e-12)} for i, v in enumerate(allr)]
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_comm else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,7 +501,10 @@ def main():
         updates = iters_done if cfg["solver"] == "cg" else spmvs_done
         res = {"N": N, "nx_global": nx_global, "n_global": n_global, "nnz": A.nnz, "n_local": A.n, "elapsed": elapsed,
                "steps": steps, "solve_ms": solve_ms, "iters_done": iters_done, "spmvs_done": spmvs_done, "updates": updates,
-               "spmv_ms": tot.value / max(cnt.value, 1), "spmv_launches": int(cnt.value)}
+               "spmv_ms": tot.value / max(cnt.value, 1), "spmv_launches": int(cnt.value),
+               # the LAST timed solve, as the library reports it (true residual ||b - A x|| / sqrt(n) recomputed after the pass, 02_Preconditioner.jl:53-55)
+               "initial_res": st.initial_res if st else None, "final_res": st.final_res if st else None,
+               "first_step_s": t_first if warmup > 0 else None, "comm_exposed": comm_exposed, "cfg": cfg, "ckey": ckey}
         if rank == 0:
             if cfg["solver"] == "cg":
                 assert iters_done == args.iters * steps, (iters_done, args.iters, steps)
@@ -485,7 +572,7 @@ def main():
             res.update(kernel=kernel, kernel_key=kkey, spmv_bytes=spmv_bytes, csr_bytes=csr_bytes, mode=mode.value, sym_used=sym_used,
                        plain_bytes=plain_bytes)
             if want_csr and world == 1:
-                res["csr_kernel"] = csr_kernel_roofline(A, K, f"{args.config}_{N}")
+                res["csr_kernel"] = csr_kernel_roofline(A, K, f"{ckey}_{N}")
         if comm is not None:
             comm.close()
         del brick, A, K, x_star, s, R
@@ -523,7 +610,29 @@ def main():
                                        "kernel would have to sustain to match this time"},
         }
 
-    main_res = run_workload(args.n, args.steps, args.warmup, want_csr=True)
+    if args.ws_trial:
+        _lib.check(_lib.lib.mfem_debug_set_ws_trial(1))
+    main_res = run_workload(cfg, args.config, args.n, args.steps, args.warmup, want_csr=True)
+
+    def check_residual(r, what):
+        """bench.py checks what it times: the last timed solve must have reduced the residual (and produced finite numbers)."""
+        ir, fr = r["initial_res"], r["final_res"]
+        # CG reduces the energy norm monotonically and, over 200 iterations, the residual too: final < initial is required.  bicgstabl_GS! is not
+        # monotone -- over the first sweeps of a small problem ||r|| may sit above ||r0|| -- so short / small legs only have to stay finite and within
+        # 100 x ||r0||; at the config's own size and iteration count (c3: 50 sweeps at 128^3) the strict rule holds for it as well
+        strict = r["cfg"]["solver"] == "cg" or (r["N"] == r["cfg"]["n"] and args.iters >= 200)
+        ok = ir is not None and fr is not None and fr == fr and ir == ir and fr < float("inf") and (fr < ir if strict else fr < 100.0 * ir)
+        if not ok:
+            raise SystemExit(f"bench.py: {what}: the last timed solve did not reduce the residual (initial {ir}, final {fr}) -- the run is invalid")
+
+    def secondary_object(t, title, wkey, baseline_config):
+        tv = t["n_global"] * t["updates"] / t["elapsed"]
+        sms = t["solve_ms"] / t["steps"]
+        return {"workload": title, "baseline_config": baseline_config, "value": tv, "unit": "DOF-updates/s", "n_dof": t["n_global"], "nnz": t["nnz"],
+                "steps": t["steps"], "ms_per_step": t["elapsed"] / t["steps"] * 1e3, "solve_ms_per_step": sms,
+                "assembly_ms_per_step": t["elapsed"] / t["steps"] * 1e3 - sms, "krylov_steps_per_step": t["updates"] / t["steps"],
+                "initial_res": t["initial_res"], "final_res": t["final_res"],
+                "roofline": solver_roofline(t, wkey), "csr_kernel": t.get("csr_kernel")}
 
     if rank == 0:
         r = main_res
@@ -539,12 +648,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{cfg['title']}, {r['nx_global']}x{args.n}x{args.n} structured mesh (make_Brick): fused assembly (K + R) + "
+                "workload": f"{cfg['title']}, {r['nx_global']}x{args.n}x{args.n} structured mesh (make_Brick)"
+                            + (f" cut into {world} slabs along i (strong scaling)" if strong else "") + ": fused assembly (K + R) + "
                             + (f"{args.iters} Jacobi-CG iterations per step" if cfg["solver"] == "cg" else
                                f"{max(args.iters // 4, 1)} BiCGStab(2) sweeps (bicgstabl_GS!, right Jacobi) = {per_step_updates:.0f} SpMV-equivalent steps per step"),
                 "baseline_config": {"c2": "the north_star target size (512^3 hex-8, 1 GPU); configs[1] (256^3) is `secondary_256`",
@@ -558,22 +668,43 @@ def main():
                 "assembly_ms_per_step": r["elapsed"] / r["steps"] * 1e3 - solve_ms_step,
                 "assembly_dof_per_s": r["n_global"] / max(r["elapsed"] / r["steps"] - solve_ms_step * 1e-3, 1e-12),
                 "solve_dof_updates_per_s": r["n_global"] * per_step_updates / (solve_ms_step * 1e-3),
+                # the last timed solve (true residuals, ||.||_2 / sqrt(n)): the run fails unless final < initial
+                "initial_res": r["initial_res"], "final_res": r["final_res"],
+                "first_step_s": r["first_step_s"],
+                "workspace_placement_trial": ("on (--ws-trial 1: the first solve times the SpMV on up to three allocations of the workspace and keeps the "
+                                              "fastest; its cost is inside first_step_s, outside the timed region)" if args.ws_trial else
+                                              "off (library default since round 4)"),
             },
             "roofline": solver_roofline(r, f"{args.config}_{args.n}"),
         }
+        if r["comm_exposed"] is not None:
+            # what the solver stream of every rank waited for (hip-event pairs around the wait for the halo stream and around each all-reduce)
+            out["comm_exposed"] = r["comm_exposed"]
+        check_residual(r, f"{args.config} {args.n}^3")
         if "csr_kernel" in r:
             # the north_star's own number: the CSR kernel behind mul! on this matrix, measured in this run
             out["roofline"]["csr_kernel"] = r["csr_kernel"]
     if world == 1 and args.config == "c2" and args.secondary_n > 0 and args.secondary_n != args.n:
         # configs[1] of BASELINE.json (256^3 hex-8; also the matrix the round-1 / round-2 lines were quoted on)
-        t = run_workload(args.secondary_n, args.secondary_steps, 1, want_csr=True)
-        tv = t["n_global"] * t["updates"] / t["elapsed"]
-        out[f"secondary_{args.secondary_n}"] = {
-            "workload": f"{cfg['title']}, {args.secondary_n}^3 (BASELINE.json configs[1]), {t['steps']} timed steps after 1 warm-up, same step as above",
-            "value": tv, "unit": "DOF-updates/s", "n_dof": t["n_global"], "nnz": t["nnz"], "ms_per_step": t["elapsed"] / t["steps"] * 1e3,
-            "roofline": solver_roofline(t, f"c2_{args.secondary_n}"),
-            "csr_kernel": t.get("csr_kernel"),
-        }
+        t = run_workload(cfg, "c2", args.secondary_n, args.secondary_steps, 1, want_csr=True)
+        check_residual(t, f"c2 {args.secondary_n}^3")
+        out[f"secondary_{args.secondary_n}"] = secondary_object(
+            t, f"{cfg['title']}, {args.secondary_n}^3, {t['steps']} timed steps after 1 warm-up, same step as above", f"c2_{args.secondary_n}",
+            "configs[1]")
+    if world == 1 and args.config == "c2" and args.secondary_configs and args.n == cfg["n"]:
+        # configs[2] and configs[3] of BASELINE.json in the same invocation (what `--config c3` / `--config c4` run, fewer steps): the driver's one
+        # line then carries all four configs
+        for ck in ("c3", "c4"):
+            c = CONFIGS[ck]
+            t = run_workload(c, ck, c["n"], args.secondary_steps, 1, want_csr=True)
+            check_residual(t, f"{ck} {c['n']}^3")
+            per = t["updates"] / t["steps"]
+            out[f"secondary_{ck}"] = secondary_object(
+                t, f"{c['title']}, {c['n']}^3, {t['steps']} timed steps after 1 warm-up: fused assembly (K + R) + "
+                   + (f"{args.iters} Jacobi-CG iterations" if c["solver"] == "cg" else f"{per:.0f} SpMV-equivalent steps of bicgstabl_GS! (s = 2, right Jacobi)")
+                   + " per step", f"{ck}_{c['n']}", {"c3": "configs[2]", "c4": "configs[3]"}[ck])
+            out[f"secondary_{ck}"]["metric"] = c["metric"]
+        out["roofline_hex27_ke"] = hex27_ke_roofline(CONFIGS["c4"]["n"])
     if rank == 0 and world == 1 and args.config == "c2" and args.hex27_n > 0:
         # the CSR kernel on the other matrix shape of the configs: hex-27 (27..125 entries per row), configs[3]'s size
         try:

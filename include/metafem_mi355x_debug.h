@@ -87,6 +87,14 @@ int mfem_debug_set_hex8_thermal(int variant);
  * read: total device ms and launch count since the last reset. */
 int mfem_prof_spmv_enable(mfem_context ctx, int on);
 int mfem_prof_spmv_read(mfem_context ctx, double* total_ms /* [host] */, int64_t* launches /* [host] */, int reset);
+/* Communication the solver's stream is EXPOSED to, per rank (communicator attached to ctx; zeros without one): halo_wait = time the context stream
+ * spent waiting for the halo exchange after the interior rows were done (RCCL: hip-event pair around the wait for the halo stream -- ~0 when the
+ * exchange finished beside the interior rows; host callbacks: the whole staged exchange), allreduce = the all-reduces of the reduction groups
+ * (event pair around ncclAllReduce on the context stream: includes waiting for the slowest rank).  Off by default; the events cost a few
+ * microseconds per operation, and captured cycle graphs are not used with a communicator anyway. */
+int mfem_prof_comm_enable(mfem_context ctx, int on);
+int mfem_prof_comm_read(mfem_context ctx, double* halo_wait_ms /* [host] */, int64_t* halo_waits /* [host] */, double* allreduce_ms /* [host] */,
+                        int64_t* allreduces /* [host] */, int reset);
 /* RCCL transport check on the communicator attached to ctx (mfem_comm_create, not the host-callback one): `rounds` times the call
  * sequence one overlapped SpMV + reduction group issues -- grouped ncclSend / ncclRecv of `count` doubles on the halo stream fenced
  * by events, a kernel on the context stream beside it, the stream wait, ncclAllReduce of 3 scalars on the context stream with the
@@ -98,11 +106,14 @@ int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds);
  * mfem_debug_ws_address returns the base in use. */
 int mfem_debug_set_ws_placement(long long align, long long offset);
 unsigned long long mfem_debug_ws_address(mfem_context ctx);
-/* 1 (default): the first solve on a workspace of 8 GB or more (one rank) times the solver SpMV, tries one second allocation of the workspace
- * the same way and keeps the faster (the speed follows the physical memory an allocation received: 7 % of every later iteration at 512^3).
- * Paid once per workspace: 5 - 7 s at 512^3 (a second hipMalloc of 45 GB takes 2 s, a hipFree about as long; environment variable
- * MFEM_WS_TRIAL_VERBOSE=1 prints the steps' times to stderr).  0: off. */
+/* Workspace placement trial, OFF by default (round 4: a drop-in mfem_solve must not hide seconds of allocation work).  1: the first solve on a
+ * workspace of 8 GB or more times the solver SpMV, tries up to two more allocations of the workspace the same way (at most two alive: PEAK MEMORY
+ * = TWICE THE WORKSPACE, 90 GB at 512^3) and keeps the fastest -- the speed follows the physical memory an allocation received (7 % of every later
+ * iteration at 512^3, profiles/r04_placement_counters.txt).  Paid once per workspace: 5 - 7 s at 512^3 (a hipMalloc of 45 GB takes 2 s, a hipFree
+ * about as long; MFEM_WS_TRIAL_VERBOSE=1 prints the steps' times to stderr).  Rank-local: with a communicator attached every rank runs its own
+ * trial (the candidates' timing uses no collective).  bench.py opts in with --ws-trial 1 and says so in its line. */
 int mfem_debug_set_ws_trial(int on);
+
 /* out4[0..2]: the times (ms for two SpMVs) of the workspace candidates tried by that choice, in order; 0 = not tried. */
 int mfem_debug_ws_trial_log(mfem_context ctx, double* out4);
 

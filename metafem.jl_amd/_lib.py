@@ -114,6 +114,8 @@ SIGNATURES = {
     "mfem_debug_set_hex27": (c_int, [c_int]),
     "mfem_prof_spmv_enable": (c_int, [P, c_int]),
     "mfem_prof_spmv_read": (c_int, [P, C.POINTER(c_double), C.POINTER(c_int64), c_int]),
+    "mfem_prof_comm_enable": (c_int, [P, c_int]),
+    "mfem_prof_comm_read": (c_int, [P, C.POINTER(c_double), C.POINTER(c_int64), C.POINTER(c_double), C.POINTER(c_int64), c_int]),
     "mfem_solve": (c_int, [P, P, P, P, P, C.POINTER(SolveOptions), C.POINTER(SolveStats)]),
     "mfem_solve_set_shadow": (c_int, [P, P, c_int32]),
     "mfem_brick_create": (c_int, [P, c_int32, c_int32, c_int32, c_double, c_double, c_double, c_int32, c_int32,

@@ -62,6 +62,7 @@ std::atomic<int> mfem_debug_epoch{0};
 extern "C" int mfem_abi_version(void) { return MFEM_ABI_VERSION; }
 extern "C" const char* mfem_last_error(void) { return g_err; }
 
+int mfem_ws_release(void* raw);  // (defined with the workspace allocator below)
 static int context_allocate(mfem_context_s* c) {
   MFEM_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(double) * MFEM_MAX_PARTIALS * 8));
   MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * MFEM_NSCALARS));
@@ -81,8 +82,8 @@ static void context_release(mfem_context_s* ctx) {
   if (ctx->h_scalars) hipHostFree(ctx->h_scalars);
   if (ctx->d_flags) hipFree(ctx->d_flags);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
-  if (ctx->ws_raw) hipFree(ctx->ws_raw);
-  if (ctx->ws_alt_raw) hipFree(ctx->ws_alt_raw);
+  (void)mfem_ws_release(ctx->ws_raw);
+  (void)mfem_ws_release(ctx->ws_alt_raw);
   if (ctx->prof_ev) {
     for (int i = 0; i < 2 * MFEM_PROF_PAIRS; ++i)
       if (ctx->prof_ev[i]) hipEventDestroy(ctx->prof_ev[i]);
@@ -212,6 +213,19 @@ extern "C" int mfem_debug_set_ws_placement(long long align, long long offset) tr
   g_ws_offset = offset > 0 ? (size_t)offset : 0;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_ws_placement")
+// (Round 4 tried the virtual-memory API for the workspace -- hipMemAddressReserve + hipMemCreate / hipMemMap in one, 1 GiB or 2 MiB physical chunks:
+// the same two SpMV speeds, and one run faulted on a re-mapped range; profiles/r04_placement_counters.txt.  hipMalloc stays.)
+static int ws_alloc(mfem_context_s* ctx, void** raw, size_t bytes) {
+  (void)ctx;
+  *raw = nullptr;
+  MFEM_CHECK_HIP(hipMalloc(raw, bytes));
+  return MFEM_OK;
+}
+static int ws_free(void* raw) {
+  if (raw) MFEM_CHECK_HIP(hipFree(raw));
+  return MFEM_OK;
+}
+int mfem_ws_release(void* raw) { return ws_free(raw); }
 extern "C" unsigned long long mfem_debug_ws_address(mfem_context ctx) { return ctx ? (unsigned long long)(uintptr_t)ctx->ws : 0ull; }
 // Next candidate for the workspace (same size, same placement rule).  First call (no alternative held): the current one moves to ws_alt*.  Later
 // calls: the current one is freed (the alternative stays) -- at most two are alive.  ws_try counts the candidates allocated after the first; it is
@@ -226,16 +240,19 @@ int mfem_ws_next_candidate(mfem_context_s* ctx) {
   const size_t need = ctx->ws_bytes + g_ws_align + g_ws_offset;
   if (ctx->ws_alt_raw) {  // drop the current candidate first
     t0 = now_ms();
-    MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
-    if (verbose) fprintf(stderr, "ws trial: hipFree %.1f ms\n", now_ms() - t0);
+    {
+      int rcf = ws_free(ctx->ws_raw);
+      if (rcf) return rcf;
+    }
+    if (verbose) fprintf(stderr, "ws trial: free %.1f ms\n", now_ms() - t0);
     ctx->ws = ctx->ws_raw = nullptr;
   }
   size_t freeb = 0, totalb = 0;
   void* raw = nullptr;
   bool ok = hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb >= need + ((size_t)4 << 30);
   t0 = now_ms();
-  if (ok && hipMalloc(&raw, need) != hipSuccess) ok = false;
-  if (verbose) fprintf(stderr, "ws trial: hipMalloc %.1f ms\n", now_ms() - t0);
+  if (ok && ws_alloc(ctx, &raw, need) != MFEM_OK) ok = false;
+  if (verbose) fprintf(stderr, "ws trial: alloc %.1f ms\n", now_ms() - t0);
   if (!ok) {
     (void)hipGetLastError();
     if (!ctx->ws_raw) {  // the current one is gone: back to the alternative
@@ -261,9 +278,11 @@ int mfem_ws_decide(mfem_context_s* ctx, bool keep_current) {
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->ws_alt_raw) {
     if (keep_current) {
-      MFEM_CHECK_HIP(hipFree(ctx->ws_alt_raw));
+      int rcf = ws_free(ctx->ws_alt_raw);
+      if (rcf) return rcf;
     } else {
-      MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
+      int rcf = ws_free(ctx->ws_raw);
+      if (rcf) return rcf;
       ctx->ws = ctx->ws_alt;
       ctx->ws_raw = ctx->ws_alt_raw;
     }
@@ -275,12 +294,14 @@ int mfem_ws_decide(mfem_context_s* ctx, bool keep_current) {
 int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return MFEM_OK;
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->ws_raw) MFEM_CHECK_HIP(hipFree(ctx->ws_raw));
-  if (ctx->ws_alt_raw) MFEM_CHECK_HIP(hipFree(ctx->ws_alt_raw));
+  int rcf = ws_free(ctx->ws_raw);
+  if (!rcf) rcf = ws_free(ctx->ws_alt_raw);
   ctx->ws = ctx->ws_raw = ctx->ws_alt = ctx->ws_alt_raw = nullptr;
+  if (rcf) return rcf;
   ctx->ws_try = 0;  // (a new allocation: undecided again)
   ctx->ws_bytes = 0;
-  MFEM_CHECK_HIP(hipMalloc(&ctx->ws_raw, bytes + g_ws_align + g_ws_offset));
+  rcf = ws_alloc(ctx, &ctx->ws_raw, bytes + g_ws_align + g_ws_offset);
+  if (rcf) return rcf;
   uintptr_t p = (uintptr_t)ctx->ws_raw;
   if (g_ws_align) p = (p + g_ws_align - 1) / g_ws_align * g_ws_align;
   ctx->ws = (void*)(p + g_ws_offset);

@@ -31,7 +31,103 @@ struct mfem_comm_s {
   double* d_stage;              // device staging of the reverse exchange [from_lo | from_hi], each d_block doubles
   size_t d_block;
   double* pending_x;            // begin() issued for this vector, end() not yet
+  // Optional timing of the communication the solver's stream is EXPOSED to (mfem_prof_comm_enable / _read; bench.py prints it per rank): kind 0 = the
+  // wait for the halo exchange (RCCL: event pair on the context stream around the wait for the halo stream -- zero-length when the exchange
+  // finished beside the interior rows; host callbacks: host clock around staging + callback), kind 1 = one all-reduce of a reduction group (event
+  // pair around ncclAllReduce: includes waiting for the slowest rank; host callbacks: host clock).
+  int prof_on;
+  hipEvent_t* pev;              // [2 * COMM_PROF_PAIRS]
+  unsigned char* pkind;         // [COMM_PROF_PAIRS]
+  int pused;
+  double p_ms[2];
+  int64_t p_n[2];
 };
+#define COMM_PROF_PAIRS 2048
+
+static int comm_prof_flush(mfem_comm_s* c) {
+  if (!c->pused) return MFEM_OK;
+  MFEM_CHECK_HIP(hipEventSynchronize(c->pev[2 * c->pused - 1]));
+  for (int k = 0; k < c->pused; ++k) {
+    float ms = 0.f;
+    MFEM_CHECK_HIP(hipEventElapsedTime(&ms, c->pev[2 * k], c->pev[2 * k + 1]));
+    c->p_ms[c->pkind[k]] += ms;
+    c->p_n[c->pkind[k]] += 1;
+  }
+  c->pused = 0;
+  return MFEM_OK;
+}
+// event bracket on the context stream (RCCL backend); k = -1: not timed
+static int comm_prof_begin(mfem_context_s* ctx, mfem_comm_s* c, int kind, int* k) {
+  *k = -1;
+  if (!c->prof_on || !c->pev) return MFEM_OK;
+  if (c->pused == COMM_PROF_PAIRS) {
+    int rc = comm_prof_flush(c);
+    if (rc) return rc;
+  }
+  *k = c->pused;
+  c->pkind[*k] = (unsigned char)kind;
+  MFEM_CHECK_HIP(hipEventRecord(c->pev[2 * *k], ctx->stream));
+  return MFEM_OK;
+}
+static int comm_prof_end(mfem_context_s* ctx, mfem_comm_s* c, int k) {
+  if (k < 0) return MFEM_OK;
+  MFEM_CHECK_HIP(hipEventRecord(c->pev[2 * k + 1], ctx->stream));
+  c->pused = k + 1;
+  return MFEM_OK;
+}
+#include <chrono>
+static double comm_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct CommHostTimer {  // host-callback backend: wall time of the staged operation (its stream synchronisations included)
+  mfem_comm_s* c;
+  int kind;
+  int count;  // 1: this bracket completes one operation (the begin half of an exchange adds time only)
+  double t0;
+  CommHostTimer(mfem_comm_s* c_, int kind_, int count_ = 1) : c(c_), kind(kind_), count(count_), t0(c_->prof_on ? comm_now_ms() : 0.0) {}
+  ~CommHostTimer() {
+    if (c->prof_on) {
+      c->p_ms[kind] += comm_now_ms() - t0;
+      c->p_n[kind] += count;
+    }
+  }
+};
+
+extern "C" int mfem_prof_comm_enable(mfem_context ctx, int on) try {
+  MFEM_REQUIRE(ctx, "null ctx");
+  mfem_comm_s* c = ctx->comm;
+  if (!c) return MFEM_OK;  // nothing to time on one rank
+  if (on && c->backend == 0 && !c->pev) {
+    mfem_host_alloc_probe();
+    c->pev = new hipEvent_t[2 * COMM_PROF_PAIRS]();
+    c->pkind = new unsigned char[COMM_PROF_PAIRS]();
+    for (int i = 0; i < 2 * COMM_PROF_PAIRS; ++i) MFEM_CHECK_HIP(hipEventCreate(&c->pev[i]));
+  }
+  if (!on && c->backend == 0) {
+    int rc = comm_prof_flush(c);
+    if (rc) return rc;
+  }
+  c->prof_on = on ? 1 : 0;
+  return MFEM_OK;
+} MFEM_API_CATCH("mfem_prof_comm_enable")
+
+extern "C" int mfem_prof_comm_read(mfem_context ctx, double* halo_wait_ms, int64_t* halo_waits, double* allreduce_ms, int64_t* allreduces,
+                                   int reset) try {
+  MFEM_REQUIRE(ctx && halo_wait_ms && halo_waits && allreduce_ms && allreduces, "null argument");
+  *halo_wait_ms = *allreduce_ms = 0.0;
+  *halo_waits = *allreduces = 0;
+  mfem_comm_s* c = ctx->comm;
+  if (!c) return MFEM_OK;
+  if (c->backend == 0) {
+    int rc = comm_prof_flush(c);
+    if (rc) return rc;
+  }
+  *halo_wait_ms = c->p_ms[0]; *halo_waits = c->p_n[0];
+  *allreduce_ms = c->p_ms[1]; *allreduces = c->p_n[1];
+  if (reset) {
+    c->p_ms[0] = c->p_ms[1] = 0.0;
+    c->p_n[0] = c->p_n[1] = 0;
+  }
+  return MFEM_OK;
+} MFEM_API_CATCH("mfem_prof_comm_read")
 
 #define MFEM_CHECK_NCCL(expr)                                                              \
   do {                                                                                     \
@@ -133,6 +229,12 @@ extern "C" int mfem_comm_destroy(mfem_comm c) try {
   }
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->d_stage) hipFree(c->d_stage);
+  if (c->pev) {
+    for (int i = 0; i < 2 * COMM_PROF_PAIRS; ++i)
+      if (c->pev[i]) hipEventDestroy(c->pev[i]);
+    delete[] c->pev;
+    delete[] c->pkind;
+  }
   delete c;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_comm_destroy")
@@ -183,10 +285,14 @@ int mfem_comm_allreduce(mfem_context_s* ctx, double* dev, int count) {
   if (!c || count <= 0) return MFEM_OK;
   MFEM_COMM_ALIVE(c);
   if (c->backend == 0) {
+    int k = -1;
+    int rc = comm_prof_begin(ctx, c, 1, &k);
+    if (rc) return rc;
     MFEM_CHECK_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, c->comm, ctx->stream));
-    return MFEM_OK;
+    return comm_prof_end(ctx, c, k);
   }
   // host-staged: the scalars visit the host (one stream sync per reduction group)
+  CommHostTimer timer(c, 1);
   int rc = stage_reserve(ctx, c, (size_t)(count > 64 ? count : 64), false);
   if (rc) return rc;
   MFEM_CHECK_HIP(hipMemcpyAsync(c->h_stage, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
@@ -251,6 +357,7 @@ int mfem_comm_halo_begin(mfem_context_s* ctx, double* x) {
     c->pending_x = x;
     return MFEM_OK;
   }
+  CommHostTimer timer(c, 0, 0);  // (host callbacks: nothing overlaps, the whole exchange is exposed)
   const size_t blk = (size_t)F * (size_t)PL;
   int rc = stage_reserve(ctx, c, blk > 64 ? blk : 64, false);
   if (rc) return rc;
@@ -287,9 +394,13 @@ int mfem_comm_halo_end(mfem_context_s* ctx) {
   double* x = c->pending_x;
   c->pending_x = nullptr;
   if (c->backend == 0) {
+    int k = -1;
+    int rc = comm_prof_begin(ctx, c, 0, &k);
+    if (rc) return rc;
     MFEM_CHECK_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
-    return MFEM_OK;
+    return comm_prof_end(ctx, c, k);
   }
+  CommHostTimer timer(c, 0);
   const int64_t PL = ctx->halo_plane_len, NO = c->n_owned_nodes;
   const int F = ctx->halo_fields;
   double* ghost = x + (int64_t)F * NO;

@@ -214,6 +214,14 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 int64_t mfem_lat8_design_bytes(const mfem_csr_s* A);
 int64_t mfem_lat8_entries(const mfem_csr_s* A);
 int mfem_lattice_from_first_row(mfem_context_s* ctx, mfem_csr_s* A);  // proposes lat_* for a pattern without a hint (spmv_lat27.hip)
+// First i-layer of lattice tiles (8 planes each, `gw` planes of upward reach) that stages a ghost plane of the upper neighbour: the layers below it
+// are the interior part of a slab's split SpMV.  m0 = owned planes; without an upper neighbour every layer is interior.
+static inline int mfem_lat_first_ghost_layer(int m0, int gw, int nti, bool has_upper) {
+  if (!has_upper) return nti;
+  int t = m0 - 7 - gw;  // a layer's staged planes end at 8 ti + 7 + gw
+  t = t <= 0 ? 0 : (t + 7) / 8;
+  return t < nti ? t : nti;
+}
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
 int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles

@@ -634,7 +634,7 @@ extern "C" int mfem_solve_set_shadow(mfem_context ctx, const double* shadow, int
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static std::atomic<int> g_ws_trial{1};           // timed choice between two allocations of a large workspace (mfem_debug_set_ws_trial)
+static std::atomic<int> g_ws_trial{0};           // timed choice between allocations of a large workspace: OPT-IN since round 4 (mfem_debug_set_ws_trial)
 extern "C" int mfem_debug_set_ws_trial(int on) try {
   g_ws_trial = on ? 1 : 0;
   return MFEM_OK;
@@ -654,7 +654,7 @@ extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) try {
 } MFEM_API_CATCH("mfem_debug_set_graphs")
 
 static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
-                       const mfem_solve_options* o, mfem_solve_stats* stats);
+                       const mfem_solve_options* o, mfem_solve_stats* stats, bool allow_lat = true);
 
 extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
                           const mfem_solve_options* o, mfem_solve_stats* stats) try {
@@ -685,8 +685,9 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
   return rc;
 } MFEM_API_CATCH("mfem_solve")
 
+// allow_lat = false: the start-over after the symmetric lattice tiles have refused this solve's values (they are not tried again in this call)
 static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
-                       const mfem_solve_options* o, mfem_solve_stats* stats) {
+                       const mfem_solve_options* o, mfem_solve_stats* stats, bool allow_lat) {
   MFEM_REQUIRE(A->n == 0 || (vals && b && x_out), "null array");
   MFEM_REQUIRE(o->maxiter >= 0 && o->max_pass >= 1, "maxiter >= 0 and max_pass >= 1 required");
   MFEM_REQUIRE(o->method >= MFEM_SOLVER_CG && o->method <= MFEM_SOLVER_CGS2, "unknown method");
@@ -727,7 +728,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // and column copies cost 20 - 40 ms and 2 - 4 GB at the BASELINE sizes); the first refusal plans them and this function starts over.
   int rc_plan = MFEM_OK;
   size_t lat_bytes = 0, lat8_bytes = 0;
-  if (!left && (is_cg || !jac || fused_scale)) {  // (both also on slab patterns: the plans read the pattern's lattice hint)
+  if (allow_lat && !left && (is_cg || !jac || fused_scale)) {  // (both also on slab patterns: the plans read the pattern's lattice hint)
     rc_plan = mfem_lat27_plan(ctx, A);
     if (rc_plan) return rc_plan;
     lat_bytes = mfem_lat27_bytes(A);
@@ -750,11 +751,13 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       sell_bytes = mfem_sell_vals_bytes(A);
     }
   }
-  fused_scale = fused_scale && (ell_bytes || sell_bytes || lat_only);  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy)
+  // (the CSR kernel of small systems reads the caller's array: it needs the scaled copy.  Planned tiles keep the scaling fused -- they take the caller's
+  // UNSCALED values and apply a right scaling to x; should they refuse the values with no other layout to carry the fused scaling, the solve starts
+  // over without them, below)
+  fused_scale = fused_scale && (ell_bytes || sell_bytes || lat_bytes || lat8_bytes);
   const bool need_copy = need_copy_unfused && !fused_scale;
-  // The lattice tiles take the caller's UNSCALED values (a right scaling goes to x).  When the scaling could not be folded into a layout after all
-  // (tiles planned but refused once, no other layout at this size) the working values are a scaled copy in the workspace that is filled only
-  // further down: nothing may be bound from it here -- the tiles are out for this solve.
+  // The tiles are never bound from a scaled working copy (it lives in the workspace and is filled only further down); cannot happen with the rule
+  // above, kept as the invariant's guard
   if (need_copy && jac && !is_cg) lat_bytes = lat8_bytes = 0;
   const size_t csr_copy_bytes = need_copy ? align_up((size_t)A->nnz * sizeof(double), 256) : 0;
   size_t layout_bytes = ell_bytes > sell_bytes ? ell_bytes : sell_bytes;  // (one of the two is 0)
@@ -805,9 +808,11 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     if (rc) return rc;
     MFEM_CHECK_HIP(hipMemsetAsync(V.w[0], 0, vec_bytes * 3, ctx->stream));
     lat8_bound = mfem_lat27_bound(A, vals_work) || mfem_lat8_bound(A, vals_work);  // (either of the two)
-    if (!lat8_bound && lat_only) {  // first refusal on this pattern: plan the other layouts and start over
+    if (!lat8_bound && (lat_only || (fused_scale && !ell_bytes && !sell_bytes))) {
+      // refused: no other layout was planned beside the tiles (first refusal on this pattern), or none exists at this size to carry the fused
+      // scaling -- start over without the tiles (the other layouts get planned; a scaled copy is made where the CSR kernel serves)
       A->lat_refused = 1;
-      return solve_inner(ctx, A, vals, b, x_out, o, stats);
+      return solve_inner(ctx, A, vals, b, x_out, o, stats, false);
     }
   }
 
@@ -950,7 +955,28 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   // allocations).  The first solve on a workspace times two SpMVs, tries up to two more allocations (if memory allows; at most two alive) the
   // same way and keeps the fastest -- this function starts over on each candidate, like after a refused layout.  Once per workspace; the
   // allocations themselves are what it costs (about 7 s at 512^3: hipMalloc / hipFree of 45 GB, twice).
-  if (g_ws_trial && !ctx->comm && ctx->ws_try < 99 && total >= ((size_t)8 << 30) && !o->scale_in_place && layout_bytes > 0) {
+  // With a communicator (round 4: the same choice at N > 1 as at N = 1) the trial is rank-local -- its timing uses no collective -- but the START
+  // OVER is agreed: this function holds collectives above, so all ranks repeat it together while any rank still has a candidate to try (two
+  // 1-scalar all-reduces per solve while the knob is on, none otherwise).
+  const bool in_trial = g_ws_trial && ctx->ws_try < 99 && total >= ((size_t)8 << 30) && !o->scale_in_place && layout_bytes > 0;
+  bool any_trial = in_trial;
+  auto agree = [&](bool mine, bool* any) -> int {  // logical OR over the ranks
+    if (!ctx->comm) { *any = mine; return MFEM_OK; }
+    ctx->h_scalars[S_TMP0] = mine ? 1.0 : 0.0;
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->d_scalars + S_TMP0, ctx->h_scalars + S_TMP0, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rca = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
+    if (!rca) rca = mfem_read_scalars(ctx, S_TMP0, 1);
+    if (rca) return rca;
+    *any = ctx->h_scalars[S_TMP0] > 0.5;
+    return MFEM_OK;
+  };
+  if (g_ws_trial && ctx->comm) {
+    rc = agree(in_trial, &any_trial);
+    if (rc) return rc;
+  }
+  if (any_trial) {
+    bool restart = false;
+    if (in_trial) {
     float ms = 0.f;
     {
       const int prof = ctx->prof_on;
@@ -975,7 +1001,6 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
     // The two speeds are 11 % apart: a candidate 5 % faster than another has found the fast kind.  Two alike (both fast, or both slow): one more
     // candidate is tried (the current one freed first -- a new allocation does not come back to memory just freed, the probe's alternation).
     const int tried = ctx->ws_try;
-    bool restart = false;
     if (tried >= 0 && tried < 3) ctx->ws_log[tried] = ms;
     if (tried == 0) {
       ctx->ws_try_ms = ms;
@@ -1003,7 +1028,12 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       restart = !(ms <= ctx->ws_try_ms);
     }
     if (rc) return rc;
-    if (restart) return solve_inner(ctx, A, vals, b, x_out, o, stats);  // (the guard above unbinds the layouts of the workspace left behind)
+    }  // in_trial
+    if (ctx->comm) {
+      rc = agree(restart, &restart);
+      if (rc) return rc;
+    }
+    if (restart) return solve_inner(ctx, A, vals, b, x_out, o, stats, allow_lat);  // (the guard above unbinds the layouts of the workspace left behind)
   }
 
   // initial residual for the report: b itself since x0 = 0 (:42-45)

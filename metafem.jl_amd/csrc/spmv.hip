@@ -1049,12 +1049,25 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   ProfScope prof{ctx, -1};
   int rc = prof.begin();
   if (rc) return rc;
-  if (mfem_lat8_bound(A, vals) || mfem_lat27_bound(A, vals)) {  // the lattice tiles do not split into interior / boundary rows: exchange, then one SpMV
+  if (mfem_lat8_bound(A, vals) || mfem_lat27_bound(A, vals)) {
+    // lattice tiles split by i-LAYERS of tiles, not by row zones: the layers that stage no ghost plane run beside the exchange (part 1), the top
+    // layers and the gather pass -- which reads the lower ghost planes for the first owned rows -- after it (part 2)
     rc = mfem_comm_halo_begin(ctx, x);
     if (rc) return rc;
+    SpmvPart P;
+    memset(&P, 0, sizeof(P));
+    if (g_halo_overlap) {
+      P.part = 1;
+      rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, P);
+      if (rc) {
+        mfem_comm_halo_end(ctx);
+        return rc;
+      }
+      P.part = 2;
+    }
     rc = mfem_comm_halo_end(ctx);
     if (rc) return rc;
-    rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, kAllRows);
+    rc = spmv_launch_inner(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, P);
     if (rc) return rc;
     return prof.end();
   }

@@ -329,16 +329,18 @@ __device__ __forceinline__ void l27_unit(l_d2 (&A)[8], l_d2 (&B)[8], const doubl
 // symmetric A and x is divided by d while it is staged.
 __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double* __restrict__ vals, const double* __restrict__ x,
                                                        const double* __restrict__ dsc, double* __restrict__ dump,
-                                                       const int32_t* __restrict__ done_flag) {
+                                                       const int32_t* __restrict__ done_flag, int tile0, int tcount) {
   __shared__ double xs[L27_LDS_CELLS];
   __shared__ double ys[L27_LDS_CELLS];
   __shared__ uint32_t tabs[L27_TAB / 2];
   if (done_flag && done_flag[0]) return;
   // workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch): each XCD walks a contiguous eighth of the tiles, so the
   // neighbourhoods that overlap are staged through one L2
-  const int ntiles = G.nti * G.ntj * G.ntk, chunk = (ntiles + 7) >> 3;
-  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
+  // (this launch covers the tiles [tile0, tile0 + tcount) of the i-major tile list: all of them, or the interior / boundary part of a slab's SpMV)
+  const int chunk = (tcount + 7) >> 3;
+  const int tsub = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= chunk || tsub >= tcount) return;
+  const int tile = tile0 + tsub;
   const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6, q = lane & 3, rho = lane >> 2;
@@ -644,16 +646,22 @@ void mfem_lat27_unbind(mfem_csr_s* A) {
 int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,
                            double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part) {
   if (!A->lat27_vals || vals != A->lat27_src) return 0;
-  if (part != 0) {
-    mfem_set_error("lattice-tile layout bound on a split SpMV");
-    return MFEM_ERR_INVALID;
-  }
   if (n_partials) *n_partials = 0;
   const Lat27Geom G = lat27_geom(A);
   const int ntiles = G.nti * G.ntj * G.ntk;
-  const int chunk = (ntiles + 7) / 8;
-  hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag);
-  MFEM_CHECK_LAUNCH();
+  // Split SpMV of a slab (mfem_spmv_halo): part 1 = the tiles that stage no ghost plane of the upper neighbour (the i-layers below
+  // mfem_lat_first_ghost_layer: a contiguous prefix of the i-major tile list), launched beside the halo exchange; part 2 = the remaining layers and
+  // the gather pass (which reads the lower ghost planes for the first owned rows), launched after it.  part 0 = everything.
+  const int tb = mfem_lat_first_ghost_layer(G.m0, G.gw, G.nti, G.plo + G.m0 < G.mg) * G.ntj * G.ntk;
+  const int tile0 = part == 2 ? tb : 0;
+  const int tcount = part == 1 ? tb : ntiles - tile0;
+  const int chunk = (tcount + 7) / 8;
+  if (tcount > 0) {
+    hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag,
+                       tile0, tcount);
+    MFEM_CHECK_LAUNCH();
+  }
+  if (part == 1) return 1;  // (the gather pass belongs to part 2)
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;

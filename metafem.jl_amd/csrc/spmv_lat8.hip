@@ -253,14 +253,16 @@ __device__ __forceinline__ void l8_run(m_d2 (&A)[4], m_d2 (&B)[4], const double*
 template <int F>
 __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* __restrict__ vals, const double* __restrict__ x,
                                                       const double* __restrict__ dsc, double* __restrict__ dump,
-                                                      const int32_t* __restrict__ done_flag) {
+                                                      const int32_t* __restrict__ done_flag, int tile0, int tcount) {
   constexpr int UNIT_D = l8_padded(F) * 64, NCH = (l8_padded(F) + 7) / 8;
   __shared__ double xs[F * L8_FC];
   __shared__ double ys[F * L8_FC];
   if (done_flag && done_flag[0]) return;
-  const int ntiles = G.nti * G.ntj * G.ntk, chunk = (ntiles + 7) >> 3;
-  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);  // every XCD walks a contiguous eighth of the tiles
-  if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
+  // (this launch covers the tiles [tile0, tile0 + tcount) of the i-major tile list: all of them, or the interior / boundary part of a slab's SpMV)
+  const int chunk = (tcount + 7) >> 3;
+  const int tsub = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);  // every XCD walks a contiguous eighth of the tiles
+  if ((int)(blockIdx.x >> 3) >= chunk || tsub >= tcount) return;
+  const int tile = tile0 + tsub;
   const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int la = lane >> 4, lb = (lane >> 2) & 3, lc = lane & 3;
@@ -532,19 +534,23 @@ void mfem_lat8_unbind(mfem_csr_s* A) {
 int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha, double beta,
                           const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part) {
   if (!A->lat8_vals || vals != A->lat8_src) return 0;
-  if (part != 0) {  // (mfem_spmv_halo does not split when a lattice-tile layout is bound)
-    mfem_set_error("lattice-tile layout bound on a split SpMV");
-    return MFEM_ERR_INVALID;
-  }
   if (n_partials) *n_partials = 0;
   const Lat8Geom G = lat8_geom(A);
   const int ntiles = G.nti * G.ntj * G.ntk;
-  const int chunk = (ntiles + 7) / 8;
-#define L8_PASS1(FF) \
-  hipLaunchKernelGGL(k_spmv_lat8<FF>, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag)
-  L8_DISPATCH_F(G.F, L8_PASS1);
+  // split SpMV of a slab: see mfem_spmv_lat27_launch -- part 1 = the i-layers of tiles that stage no ghost plane, part 2 = the rest + the gather pass
+  const int tb = mfem_lat_first_ghost_layer(G.m0, G.gw, G.nti, G.plo + G.m0 < G.mg) * G.ntj * G.ntk;
+  const int tile0 = part == 2 ? tb : 0;
+  const int tcount = part == 1 ? tb : ntiles - tile0;
+  const int chunk = (tcount + 7) / 8;
+#define L8_PASS1(FF)                                                                                                                              \
+  hipLaunchKernelGGL(k_spmv_lat8<FF>, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag, tile0, \
+                     tcount)
+  if (tcount > 0) {
+    L8_DISPATCH_F(G.F, L8_PASS1);
+    MFEM_CHECK_LAUNCH();
+  }
 #undef L8_PASS1
-  MFEM_CHECK_LAUNCH();
+  if (part == 1) return 1;  // (the gather pass belongs to part 2)
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;
