@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--secondary-configs", type=int, default=1,
                     help="c2 at N = 1, default size: also run configs[2] (c3) and configs[3] (c4) for --secondary-steps timed steps each and the hex-27 "
                          "Ke MFMA roofline (0 = skip)")
+    ap.add_argument("--secondary-config-n", type=int, default=0,
+                    help="elements per side of the c3 / c4 legs and of the hex-27 Ke roofline of the default line (0 = the configs' own 128; a smaller "
+                         "value makes the legs run at any --n: functional checks of the line's schema)")
     ap.add_argument("--ws-trial", type=int, default=1,
                     help="1 (default here): opt in to the library's workspace placement trial (mfem_debug_set_ws_trial; OFF by default in the library "
                          "since round 4) -- the line says so in config.workspace_placement_trial and prints the first step's wall time; 0 = as the library ships")
@@ -691,11 +694,13 @@ def main():
         out[f"secondary_{args.secondary_n}"] = secondary_object(
             t, f"{cfg['title']}, {args.secondary_n}^3, {t['steps']} timed steps after 1 warm-up, same step as above", f"c2_{args.secondary_n}",
             "configs[1]")
-    if world == 1 and args.config == "c2" and args.secondary_configs and args.n == cfg["n"]:
+    if world == 1 and args.config == "c2" and args.secondary_configs and (args.n == cfg["n"] or args.secondary_config_n > 0):
         # configs[2] and configs[3] of BASELINE.json in the same invocation (what `--config c3` / `--config c4` run, fewer steps): the driver's one
         # line then carries all four configs
         for ck in ("c3", "c4"):
-            c = CONFIGS[ck]
+            c = dict(CONFIGS[ck])
+            if args.secondary_config_n > 0:
+                c["n"] = args.secondary_config_n
             t = run_workload(c, ck, c["n"], args.secondary_steps, 1, want_csr=True)
             check_residual(t, f"{ck} {c['n']}^3")
             per = t["updates"] / t["steps"]
@@ -704,7 +709,7 @@ def main():
                    + (f"{args.iters} Jacobi-CG iterations" if c["solver"] == "cg" else f"{per:.0f} SpMV-equivalent steps of bicgstabl_GS! (s = 2, right Jacobi)")
                    + " per step", f"{ck}_{c['n']}", {"c3": "configs[2]", "c4": "configs[3]"}[ck])
             out[f"secondary_{ck}"]["metric"] = c["metric"]
-        out["roofline_hex27_ke"] = hex27_ke_roofline(CONFIGS["c4"]["n"])
+        out["roofline_hex27_ke"] = hex27_ke_roofline(args.secondary_config_n or CONFIGS["c4"]["n"])
     if rank == 0 and world == 1 and args.config == "c2" and args.hex27_n > 0:
         # the CSR kernel on the other matrix shape of the configs: hex-27 (27..125 entries per row), configs[3]'s size
         try:

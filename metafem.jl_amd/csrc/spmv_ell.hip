@@ -52,6 +52,7 @@ static std::atomic<int> g_dia_sym{1};      // bit 22 of mfem_debug_set_ell turns
 static std::atomic<int> g_symp_direct{1};  // bit 27: 0 = patch-major copy made from the slot-major copy in a second pass (k_symp_bind) instead of by k_dia_vals
 static std::atomic<int> g_symp_tail{1};    // bit 26: 0 = the rows outside the swept planes in a launch of their own (as in a split SpMV)
 static std::atomic<int> g_dia_symp{1};     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
+static std::atomic<int> g_dia_pipe{1};     // bit 28: 0 = the layout copy (k_dia_vals) without its software pipeline
 static std::atomic<int> g_dia_xcd{0};      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
@@ -68,6 +69,7 @@ extern "C" int mfem_debug_set_ell(int enable) try {  // bit 0: enable; bits 4-7:
   g_dia_symp = ((enable >> 23) & 1) ? 0 : 1;
   g_symp_tail = ((enable >> 26) & 1) ? 0 : 1;
   g_symp_direct = ((enable >> 27) & 1) ? 0 : 1;
+  g_dia_pipe = ((enable >> 28) & 1) ? 0 : 1;
   g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
@@ -296,7 +298,7 @@ struct SympGeom {
 #define DIA_ST(p, v) __builtin_nontemporal_store((v), (p))
 // LPR = lanes per row: 1 (64 rows per wave tile) or 2 (32 rows); SYM: the symmetrically scaled copy -- its own instantiation, so that the plain
 // copy's code is what it was (2.4 ms at 256^3; 2.7 with the test for the scaling in it)
-template <typename RP, int LPR, bool SYM>
+template <typename RP, int LPR, bool SYM, bool PIPE>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad, int K, const RP* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, const double* __restrict__ vals,
                                                            int base, const DiaOffsets* __restrict__ Op,
@@ -324,9 +326,37 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
   // columns are staged only for the Jacobi scaling pass (dsc); the placement below needs them for the few tiles that are not `full`
   // (mesh boundary) and reads those from memory -- 8 instead of 12 bytes of LDS per staged entry, half as many more waves per CU
   int32_t* Tc = reinterpret_cast<int32_t*>(lds + (size_t)nw * RT * K) + (size_t)w * RT * K;
-  const bool stage_cols = dsc != nullptr;
+  const bool stage_cols = !PIPE && dsc != nullptr;
   const int64_t ntiles = npad >> SH;
-  for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+  constexpr int NB = 28;
+  // Software pipeline (round 4; a lane per row, rows of at most NB entries, no scaling pass -- the 27-diagonal lattice copies of C2): the NEXT tile's
+  // values are loaded into registers before the current tile is placed, so a wave keeps one tile of loads in flight while it reads LDS and issues
+  // its 27 scattered stores -- each wave had one memory round trip per tile with nothing else outstanding (10 waves per CU).
+  constexpr bool pipe = PIPE;  // (chosen at the launch: LPR == 1, no scaling pass, K <= NB)
+  const int64_t tstride = (int64_t)gridDim.x * nw;
+  double tvn[NB];
+  int64_t s0n = 0;
+  int cntn = 0;
+  auto tile_span = [&](int64_t t, int64_t& s0_, int& cnt_) {
+    const int64_t q0 = t << SH, qend = (q0 + RT < n) ? q0 + RT : n;
+    s0_ = q0 < n ? (int64_t)rowptr[q0] - base : 0;
+    cnt_ = q0 < n ? (int)((int64_t)rowptr[qend] - base - s0_) : 0;
+  };
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int i = lane + 64 * u;
+      tvn[u] = i < cntn ? __builtin_nontemporal_load(vals + s0n + i) : 0.0;
+    }
+  };
+  if (pipe) {
+    const int64_t t0 = (int64_t)blockIdx.x * nw + w;
+    if (t0 < ntiles) {
+      tile_span(t0, s0n, cntn);
+      prefetch();
+    }
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += tstride) {
     const int64_t r0 = tile << SH, r = r0 + rl;
     const int64_t rend = (r0 + RT < n) ? r0 + RT : n;
     int64_t lo = 0;
@@ -335,16 +365,36 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
       lo = (int64_t)rowptr[r] - base;
       len = (int)((int64_t)rowptr[r + 1] - base - lo);
     }
-    const int64_t s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
-    const int cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;  // <= RT D
+    int64_t s0;
+    int cnt;  // <= RT D
+    int64_t s0_next = 0;
+    int cnt_next = 0;
+    if (pipe) {
+      s0 = s0n;
+      cnt = cntn;
+      if (tile + tstride < ntiles) tile_span(tile + tstride, s0_next, cnt_next);  // (these row pointers arrive beside the values in flight)
+    } else {
+      s0 = r0 < n ? (int64_t)rowptr[r0] - base : 0;
+      cnt = r0 < n ? (int)((int64_t)rowptr[rend] - base - s0) : 0;
+    }
     const int cls = __builtin_amdgcn_readfirstlane(flags[tile >> (7 - SH)]) - 1;
     // a tile of a regular block whose rows all have every diagonal of the class (cnt = RT D: away from the mesh boundary, nearly all
     // tiles): entry s of a row IS its slot s -- the columns are not needed, a third of the kernel's reads
     const bool full = cls >= 0 && cnt == RT * O.D[cls];
+    if (pipe) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = lane + 64 * u;
+        if (i < cnt) T[i] = tvn[u];
+      }
+      s0n = s0_next;
+      cntn = cnt_next;
+      if (tile + tstride < ntiles) prefetch();  // in flight until the next trip's LDS stores
+    }
     // staging: all loads of a lane are issued before the first LDS store.  28 in flight per lane: a 64-row tile of 27-entry rows (27 per lane) is
     // ONE memory round trip, a 32-row tile of 81-entry rows two (SQ counters of the version with batches of 8: 79 % of the wave cycles waiting,
     // ~10 waves per CU with 4 KB in flight each)
-    constexpr int NB = 28;
+    if constexpr (!PIPE)
     for (int i0 = lane; i0 < cnt; i0 += 64 * NB) {
       double tv[NB];
       int32_t tc[NB];
@@ -365,7 +415,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (dsc) {
+    if (!PIPE && dsc) {
       // right Jacobi scaling of the staged tile, entry / dsc[column]: the gathers of 16 entries per lane are in flight together -- one more
       // memory round trip per batch of 1024 entries (dividing inside the staging loop above made every batch of its loads wait twice)
       __builtin_amdgcn_wave_barrier();
@@ -1446,14 +1496,16 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     if (g > ctx->num_cus * 16) g = ctx->num_cus * 16;
     // the slot-major copy; with the patch sweep wanted (and not the two-pass knob) the swept planes go straight to the patch-major copy
     auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
-#define DV_LAUNCH_(RP, LPR_, SYM_)                                                                                                  \
-  hipLaunchKernelGGL((k_dia_vals<RP, LPR_, SYM_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
+#define DV_LAUNCH_(RP, LPR_, SYM_, PIPE_)                                                                                                  \
+  hipLaunchKernelGGL((k_dia_vals<RP, LPR_, SYM_, PIPE_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
                      A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc, ssym)
-#define DV_LAUNCH(RP, LPR_) do { if (ssym) DV_LAUNCH_(RP, LPR_, true); else DV_LAUNCH_(RP, LPR_, false); } while (0)
+#define DV_LAUNCH(RP, LPR_, PIPE_) do { if (ssym) DV_LAUNCH_(RP, LPR_, true, PIPE_); else DV_LAUNCH_(RP, LPR_, false, PIPE_); } while (0)
+      // (the software-pipelined staging: a lane per row, rows of at most 28 entries, no scaling pass; bit 28 of mfem_debug_set_ell turns it off)
+      const bool pipe = lpr == 1 && !dsc && A->ell_K <= 28 && g_dia_pipe;
       if (A->rowptr_bits == 64) {
-        if (lpr == 2) DV_LAUNCH(int64_t, 2); else DV_LAUNCH(int64_t, 1);
+        if (lpr == 2) DV_LAUNCH(int64_t, 2, false); else if (pipe) DV_LAUNCH(int64_t, 1, true); else DV_LAUNCH(int64_t, 1, false);
       } else {
-        if (lpr == 2) DV_LAUNCH(int32_t, 2); else DV_LAUNCH(int32_t, 1);
+        if (lpr == 2) DV_LAUNCH(int32_t, 2, false); else if (pipe) DV_LAUNCH(int32_t, 1, true); else DV_LAUNCH(int32_t, 1, false);
       }
 #undef DV_LAUNCH_
 #undef DV_LAUNCH

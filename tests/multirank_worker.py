@@ -7,6 +7,7 @@ single-rank solve of the global problem, which the rank computes itself on a sec
 
 usage: multirank_worker.py <case> <world> <rank> <port>
 """
+import ctypes as C
 import json
 import os
 import sys
@@ -33,13 +34,21 @@ def main():
     import torch
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # MFEM_WORKER_TRANSPORT=rccl: one GPU per rank and the library's RCCL transport (mfem_comm_create) -- needs `world` GPUs; default: all
+    # ranks on cuda:0 through the host-callback communicator
+    rccl = os.environ.get("MFEM_WORKER_TRANSPORT") == "rccl"
+    devid = rank if rccl else 0
+    if rccl:
+        torch.cuda.set_device(devid)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=torch.device(f"cuda:{devid}"))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     import metafem_jl_amd as mf
     from metafem_jl_amd import _lib, parallel as par
 
     n, order, itg, F = CASES[case]
     x_len = (2.0, 1.0, 1.0)
-    dev = "cuda:0"
+    dev = f"cuda:{devid}"
     force_layouts = case != "thermal_hex8_small"
     if force_layouts:
         _lib.lib.mfem_debug_set_layout_min_rows(0, 0)  # solver layouts (diagonal slots / symmetric sweep / sliced) on these small systems
@@ -52,7 +61,7 @@ def main():
         ok = ok and bool(cond)
 
     # ---- global problem on its own context (no communicator): the single-rank reference ------------------------------
-    gctx = mf.Context(0)
+    gctx = mf.Context(devid)
     gb = mf.Brick(x_len, n, order, itg, ctx=gctx)
     gA = gb.pattern(F)
     m0, m1, m2 = gb.m
@@ -75,7 +84,7 @@ def main():
         return mf.iterative_Solve(gA, gK, gR, 1e-11, Sv_func=sv, maxiter=4000, max_pass=3, shadow=sh, **kw)
 
     # ---- this rank's slab -----------------------------------------------------------------------------------------------
-    ctx = mf.Context(0)
+    ctx = mf.Context(devid)
     sb = mf.Brick(x_len, n, order, itg, ctx=ctx)
     lo, hi = par.slab_planes(m0, world, rank, order)
     sb.set_slab(lo, hi)
@@ -83,7 +92,7 @@ def main():
     n_owned = (hi - lo) * pl
     nloc = par.local_vector_length(lo, hi, m1, m2, F, order)
     assert A.n == F * n_owned and A.ncols == (nloc if world > 1 and (lo > 0 or hi < m0) else A.n), (A.n, A.ncols, nloc)
-    comm = par.HostSlabComm(ctx, sb, rank, world, n_fields=F, poison=True)
+    comm = par.SlabComm(ctx, sb, rank, world, n_fields=F) if rccl else par.HostSlabComm(ctx, sb, rank, world, n_fields=F, poison=True)
     if F == 1:
         K = sb.assemble_thermal(A, K_COND, H, TENV, 0x3F)
         s_loc = torch.full((nloc,), SRC, dtype=torch.float64, device=dev)
@@ -193,7 +202,16 @@ def main():
             check(f"{name}_{pname}", s1.converged == 1 and sg.converged == 1 and relerr(x1, xg) <= 1e-8 and
                   abs(s1.iterations - sg.iterations) <= max(4, sg.iterations // 10),
                   iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
-    check("callbacks_ran", comm.calls["exchange"] > 10 and comm.calls["allreduce"] > 10, **comm.calls)
+    if rccl:
+        hw, hn, aw, an = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+        _lib.check(_lib.lib.mfem_prof_comm_enable(ctx._h, 1))
+        lsolve(mf.cg_)
+        _lib.check(_lib.lib.mfem_prof_comm_read(ctx._h, C.byref(hw), C.byref(hn), C.byref(aw), C.byref(an), 1))
+        _lib.check(_lib.lib.mfem_prof_comm_enable(ctx._h, 0))
+        check("rccl_exposed_communication_is_timed", hn.value > 10 and an.value > 10 and hw.value >= 0.0 and aw.value > 0.0,
+              halo_waits=int(hn.value), halo_wait_ms=hw.value, allreduces=int(an.value), allreduce_ms=aw.value)
+    else:
+        check("callbacks_ran", comm.calls["exchange"] > 10 and comm.calls["allreduce"] > 10, **comm.calls)
     comm.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -24,16 +24,19 @@ def run_bench(args, env=None, timeout=900):
     return json.loads(lines[0])
 
 
-def _common(out, n_gpus, steps=1):
+def _common(out, n_gpus, steps=1, scaling="weak"):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in out, k
-    assert out["n_gpus"] == n_gpus and out["steps"] == steps and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["n_gpus"] == n_gpus and out["steps"] == steps and out["value"] > 0 and out["scaling"] == scaling
     assert out["dtype"] == "f64" and out["vs_baseline"] is None and "workload" in out["config"]
     rf = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert 0 < rf["frac"] < 1.0
+    # bench.py checks what it times: the residuals of the last timed solve are in the line (and the run fails when the solve did not reduce them)
+    c = out["config"]
+    assert c["initial_res"] > 0 and c["final_res"] >= 0 and c["final_res"] == c["final_res"] and "workspace_placement_trial" in c
 
 
 def test_single_gpu_line_has_every_object():
@@ -41,13 +44,15 @@ def test_single_gpu_line_has_every_object():
                      "--cpu-repeats", "1", "--iters", "30"])
     _common(out, 1, steps=2)
     assert out["config"]["n_dof"] == 41 ** 3 and out["config"]["krylov_steps_per_step"] == 30
+    assert out["config"]["final_res"] < out["config"]["initial_res"] and out["config"]["first_step_s"] > 0
+    assert out["config"]["workspace_placement_trial"].startswith("on")  # bench.py opts in explicitly (the library's default is off)
     ck = out["roofline"]["csr_kernel"]
     # (41-point lattice lines: no 64-row tile sits inside one line, so nothing is elided here; + the tile table)
     assert ck["column_entries_read"] <= ck["nnz"] and ck["algorithmic_bytes_per_launch"] <= 1.001 * ck["csr_equivalent"]["bytes_per_launch"]
     assert "frac_actual" in ck and "traffic_over_algorithmic" in ck
     assert "csr_kernel_hex27" in out["roofline"] and "error" not in out["roofline"]["csr_kernel_hex27"]
     sec = out["secondary_24"]
-    assert sec["n_dof"] == 25 ** 3 and sec["value"] > 0 and 0 < sec["roofline"]["frac"] < 1
+    assert sec["n_dof"] == 25 ** 3 and sec["value"] > 0 and 0 < sec["roofline"]["frac"] < 1 and sec["final_res"] < sec["initial_res"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert out["vs_cpu_baseline"]["main_workload"] > 0
@@ -58,12 +63,43 @@ def test_two_ranks_on_one_gpu_through_the_host_transport():
     _common(out, 2)
     assert out["config"]["n_dof"] == 97 * 49 * 49 and "slab decomposition x2" in out["config"]["parallelism"]
     assert out["cpu_baseline"] is None
+    # the communication each rank's solver stream was exposed to, per rank (host transport: the whole staged exchange is exposed)
+    ce = out["comm_exposed"]
+    assert [c["rank"] for c in ce] == [0, 1]
+    for c in ce:
+        assert c["halo_waits_per_step"] >= 200 and c["allreduces_per_step"] >= 200 and c["halo_wait_ms_per_step"] > 0 and c["allreduce_ms_per_step"] > 0
+        assert 0 < c["exposed_fraction_of_solve"] < 1.5
 
 
-def test_rccl_world1_through_the_whole_bench_path():
-    out = run_bench(["--gpus", "1", "--n", "48"] + SMALL, env={"MFEM_BENCH_FORCE_COMM": "1"})
+def test_strong_scaling_cuts_the_one_gpu_mesh_into_slabs():
+    """--scaling strong: THE n^3 mesh is cut into N slabs (north_star: 'the mesh is domain-decomposed across the 8 GPUs'), the line says
+    "strong" and the DOF count is the one-GPU mesh's; same for the vector and the hex-27 configs (slabs of an order-2 lattice start on element
+    boundaries)."""
+    out = run_bench(["--gpus", "2", "--n", "48", "--scaling", "strong"] + SMALL, env={"MFEM_BENCH_HOST_COMM": "1"})
+    _common(out, 2, scaling="strong")
+    assert out["config"]["n_dof"] == 49 ** 3 and "cut into 2 slabs" in out["config"]["workload"]
+    assert out["config"]["final_res"] < out["config"]["initial_res"]
+    for config, n, iters, ndof in (("c3", 16, 40, 3 * 17 ** 3), ("c4", 8, 20, 17 ** 3)):
+        out = run_bench(["--config", config, "--gpus", "2", "--n", str(n), "--iters", str(iters), "--scaling", "strong"] + SMALL,
+                        env={"MFEM_BENCH_HOST_COMM": "1"})
+        _common(out, 2, scaling="strong")
+        assert out["config"]["n_dof"] == ndof
+
+
+def test_default_line_carries_all_four_configs():
+    """The default invocation (c2, N = 1) also runs configs[2] and configs[3] and the FP64-MFMA roofline of the hex-27 Ke kernels, so the driver's
+    one line carries all four configs; here at reduced sizes (--secondary-config-n)."""
+    out = run_bench(["--n", "32", "--steps", "1", "--warmup", "1", "--secondary-n", "0", "--hex27-n", "0", "--cpu-n", "0", "--iters", "40",
+                     "--secondary-config-n", "12", "--secondary-steps", "2"])
     _common(out, 1)
-    assert out["config"]["n_dof"] == 49 ** 3
+    for key, ndof, metric in (("secondary_c3", 3 * 13 ** 3, "elasticity"), ("secondary_c4", 25 ** 3, "hex-27")):
+        t = out[key]
+        assert t["n_dof"] == ndof and t["value"] > 0 and t["steps"] == 2 and metric in t["metric"]
+        assert 0 < t["roofline"]["frac"] < 1 and t["csr_kernel"]["frac"] > 0
+        assert t["final_res"] == t["final_res"] and t["initial_res"] > 0
+    ke = out["roofline_hex27_ke"]
+    assert ke["bound"] == "mfma" and ke["peak"] == 78.6 and ke["useful_flop_per_assembly"] == 118098.0 * 12 ** 3
+    assert ke["achieved"] > 0 and 0 < ke["frac"] < 1 and abs(ke["frac"] - ke["achieved"] / ke["peak"]) < 1e-12
 
 
 @pytest.mark.parametrize("config,n,iters,ndof", [("c3", 16, 40, 3 * 33 * 17 * 17), ("c4", 8, 20, 33 * 17 * 17)])

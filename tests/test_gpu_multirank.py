@@ -30,14 +30,14 @@ def _free_port():
     return p
 
 
-def run_ranks(case, world, timeout=900):
+def run_ranks(case, world, timeout=900, transport=None):
     """Start the ranks as fresh processes; their output goes to temporary FILES (a rank that fills a 64 KB pipe while rank 0 waits
     for it in a collective would hang the test until its timeout), one deadline for the whole group."""
     import tempfile
     import time
 
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **({"MFEM_WORKER_TRANSPORT": transport} if transport else {}))
     logs = [tempfile.TemporaryFile() for _ in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), case, str(world), str(r), str(port)],
                               stdout=logs[r], stderr=subprocess.STDOUT, env=env) for r in range(world)]
@@ -83,3 +83,42 @@ def test_multirank_solve_equals_single_rank(case, world):
         assert need in names, need
     if case == "thermal_hex8":
         assert "symmetric_sweep_kernel_ran" in names
+
+
+def _n_gpus():
+    import torch
+
+    return torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="the RCCL transport needs one GPU per rank: runs the first time the suite meets a box with >= 2 GPUs")
+@pytest.mark.parametrize("case", ["thermal_hex8", "elasticity_hex8", "thermal_hex27"])
+def test_two_ranks_over_real_rccl_equal_the_single_rank_solve(case):
+    """The library's RCCL transport with MORE THAN ONE rank (ncclSend / ncclRecv of the halo planes on the halo stream beside the interior rows, one
+    ncclAllReduce per reduction group): every check of the host-transport runs above -- ghost planes bitwise, Jacobi vectors, every solver against
+    the single-rank solve of the global problem -- plus the exposed-communication timers.  One GPU per rank."""
+    reports = run_ranks(case, 2, transport="rccl")
+    names = set(reports[0]["checks"])
+    for need in ("halo_ghost_planes_bitwise", "cg_classic_overlap", "cg_single_reduction_overlap", "bicgstabl2_diag", "idrs8_diag",
+                 "rccl_exposed_communication_is_timed"):
+        assert need in names, need
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs 2 GPUs")
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_gpus_over_rccl(scaling):
+    """bench.py --gpus 2 --n 64 on two GPUs over RCCL (self-launched child processes), weak and strong scaling: the line carries the per-rank
+    exposed communication and the residual check of the timed solve passed (bench.py exits non-zero otherwise)."""
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n", "64", "--steps", "2", "--warmup", "1", "--cpu-n", "0",
+                        "--scaling", scaling], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and "RCCL" in out["config"]["parallelism"]
+    assert out["config"]["n_dof"] == (129 if scaling == "weak" else 65) * 65 * 65
+    assert out["config"]["final_res"] < out["config"]["initial_res"]
+    ce = out["comm_exposed"]
+    assert len(ce) == 2 and all(c["allreduces_per_step"] > 0 and c["halo_waits_per_step"] > 0 for c in ce)
