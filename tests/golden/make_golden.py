@@ -171,6 +171,22 @@ def mooney_rivlin_oracle(steps=3):
     np.savez_compressed(os.path.join(HERE, "oracle_mooney_rivlin.npz"), **out)
 
 
+def j2_plasticity_oracle():
+    """Oracle output for examples/hypo_elastic_plasticity/J2Plasticity.jl (oracle/plasticity.py): the mean elongation of the right face after
+    every load of the script's three load histories / hardening setups (pseudo-time relaxation to max |d1_t| < 1e-4 per load, LU solves, Newton
+    with max_iter = 3 to the script's 1e-3), the pseudo-time steps each load took, and the script's own d1_analytical (:226-228) beside them --
+    numbers, not source.  About 2.5 minutes."""
+    from oracle import plasticity as pl
+
+    dom = pl.build()
+    out = {}
+    for g in range(3):
+        d1, cnt = pl.run_group(dom, pl.S_TEST_GROUPS[g], pl.EB_GROUPS[g], pl.EP_GROUPS[g], linear_solver=pl.lu)
+        out[f"d1_{g}"], out[f"steps_{g}"] = d1, np.array(cnt)
+        out[f"s_tests_{g}"], out[f"d1_analytical_{g}"] = np.array(pl.S_TEST_GROUPS[g], dtype=float), pl.D1_ANALYTICAL[g]
+    np.savez_compressed(os.path.join(HERE, "oracle_j2_plasticity.npz"), **out)
+
+
 def tables():
     out = {}
     for name, args in {"quad8": (2, "CUBE", 2, 1, 5, "Serendipity"), "hex8": (3, "CUBE", 1, 1, 3, "Lagrange"),
@@ -290,6 +306,7 @@ if __name__ == "__main__":
     c_header()
     neo_hookean_oracle()
     mooney_rivlin_oracle()
+    j2_plasticity_oracle()
     if "--cylinder" in sys.argv:  # 25 minutes: only on request
         cylinder_oracle()
     print("fixtures written to", HERE)

@@ -1,0 +1,81 @@
+"""examples/hypo_elastic_plasticity/J2Plasticity.jl on the GPU through the product's generic path: hex-20 bar (10 x 4 x 4), TWO time levels
+(viscous damping + inertia: Bilinear(d{i}, rho (c d{i;t} + d{i;t,t})), :59; dissipative generalised-alpha, dt = 1), the plastic strain as an
+INTEGRATION_POINT_VAR fed by a user function in the coefficient stage (strain_updater, :52-55: a radial-return update with isotropic / kinematic
+hardening kept in state arrays at the integration points), pseudo-time relaxation of every load until max |d1_t| < 1e-4 (:276-288),
+update_OneStep(max_iter = 3) and the script's solver bicgstabl_GS!(s = 8, maxiter = 2000, max_pass = 20) (:218) -- the l > 2 literal sequence.
+Checked against the numbers the script itself holds (d1_analytical, :226-228) and against the oracle's run of the same script (fixture)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_j2_plasticity_on_gpu(mf):
+    import torch
+    from metafem_jl_amd import element, generic as G, mesh as pm
+    from oracle import mesh as om, plasticity as pl
+    from test_gpu_unstructured import _wf
+
+    L_box, e_number, LW = 1.0, 4, 10
+    size = (L_box * LW, L_box, L_box)
+    space = element.classical_space(3, "Serendipity", 2, 5)
+    vert, conn = om.make_brick(size, (int(e_number * LW / 4), e_number, e_number))  # (data here; tests/test_product_mesh.py covers the product's make_Brick)
+    msh = pm.mesh_Classical(vert, conn, space)
+    fac = pm.get_BoundaryMesh(msh)
+    err = L_box / e_number * 0.01
+    c = fac.centroid
+    left, right = fac.select(np.abs(c[:, 0]) < err), fac.select(np.abs(c[:, 0] - size[0]) < err)
+    params = dict(rho=1e3, c=2.0, lam=0.0, mu=pl.EY / 2, tau=1000 * pl.EY / L_box ** 2)
+    nel = msh.cp_ids.shape[1]
+    # the state arrays live where the coefficient stage works: [elements, integration points] tensors on the device
+    state = pl.MaterialState(lambda: torch.zeros((nel, 27), dtype=torch.float64, device="cuda"), 100.0, params["lam"], params["mu"], 0.0, pl.EY / 2, 1.0)
+    gd = G.GenericDomain(mf.default_context(), space, msh.coords, msh.cp_ids, 3, _wf(pl.domain_weakform(params, lambda env: state)),
+                         [(left.element_ID, left.element_eindex, _wf(pl.fixed_weakform(params))),
+                          (right.element_ID, right.element_eindex, _wf(pl.load_weakform()))],
+                         max_time_level=2, element_colours="auto")
+    n = msh.ncp
+    N = 3 * n
+    assert n == 965 and gd.A.n == N and gd.x.numel() == 3 * N
+    gd.converge_tol = 1e-3  # :219
+    gd.dt = 1.0             # :244
+    stats = []
+
+    def solver(g):  # :218
+        dx, st = mf.iterative_Solve(g.A, g.K_total, g.residue, g.converge_tol, Sv_func=mf.bicgstabl_GS_, maxiter=2000, max_pass=20, s=8)
+        stats.append(st)
+        return dx
+
+    gd.linear_solver = solver
+    right_cps = torch.tensor(np.nonzero(np.abs(msh.coords[:, 0] - size[0]) < 0.25 * L_box / e_number)[0], device="cuda")  # :241
+    z = np.load(os.path.join(GOLD, "oracle_j2_plasticity.npz"))
+    full = os.environ.get("MFEM_FULL_PLASTICITY") == "1"  # all 49 loads of the script; default: the whole first history (isotropic hardening, 17 loads:
+    worst = 0.0                                            # elastic, plastic, unloading, reverse yielding) and the first 9 loads of the other two
+    for g in range(3):
+        loads = pl.S_TEST_GROUPS[g] if (full or g == 0) else pl.S_TEST_GROUPS[g][:9]
+        gd.x.zero_()
+        gd.t = 0.0
+        state.reset(pl.EB_GROUPS[g], pl.EP_GROUPS[g])
+        d1s = []
+        for s in loads:
+            gd.controlpoints["sl1"] = torch.full((n,), float(s), dtype=torch.float64, device="cuda")
+            for counter in range(1, 200):
+                hist = gd.update_OneStep(max_iter=3)
+                state.update_states()
+                if float(gd.x[N:N + n].abs().max()) < 1e-4:  # max |d1_t| (:282)
+                    break
+            assert counter < 60, (g, s, counter)
+            d1s.append(float(gd.x[:n][right_cps].sum()) / right_cps.numel())  # :286
+        d1s = np.array(d1s)
+        k = d1s.size
+        dev = np.abs(d1s - pl.D1_ANALYTICAL[g][:k])
+        worst = max(worst, dev.max())
+        assert dev.max() < 0.7e-3, (g, d1s, pl.D1_ANALYTICAL[g][:k])  # the script's own numbers: plot-level (0.7e-3 of a 52e-3 range)
+        # the oracle's run of the same script (LU solves there, bicgstabl_GS!(s = 8) here; Newton to 1e-3, pseudo-time to 1e-4 on both sides)
+        assert np.abs(d1s - z[f"d1_{g}"][:k]).max() < 5e-5, (g, d1s, z[f"d1_{g}"][:k])
+    assert state.yielded_calls > 0
+    nconv = sum(1 for st in stats if st.converged)
+    print(f"J2 plasticity: {len(stats)} bicgstabl_GS!(s = 8) solves ({nconv} reached the tolerance), worst deviation from d1_analytical {worst:.2e}")
+    assert nconv >= 0.9 * len(stats)

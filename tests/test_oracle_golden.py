@@ -322,3 +322,31 @@ def test_oracle_reproduces_the_neo_hookean_closed_form():
     assert h_lu[0][-1] < 1e-5 and abs(d_lu[0] - zo["d1s_0"][0]) < 1e-9
     d_bi, _, h_bi = he.run_setup(dom, 1e6, 1e6, 1, 4e5)  # solver_of_the_script: bicgstabl_GS!, s = 4
     assert h_bi[0][-1] < 1e-5 and abs(d_bi[0] - d_lu[0]) < 1e-6 * d_lu[0]
+
+
+def test_oracle_reproduces_the_j2_plasticity_answers_of_the_script():
+    """examples/hypo_elastic_plasticity/J2Plasticity.jl holds its own answer: d1_analytical (:226-228), the elongation of a 1-D elastic-plastic bar
+    under three load histories with isotropic, mixed and kinematic hardening.  It is the only reference-held check of max_time_level = 2 (d{i;t},
+    d{i;t,t}: :59), of an INTEGRATION_POINT_VAR fed by a user function in the coefficient stage (strain_updater: :52-55) and of bicgstabl_GS!(s = 8)
+    (:218).  The committed fixture (make_golden.py::j2_plasticity_oracle) holds the oracle's run of all 49 loads; here the first loads of the first
+    history are recomputed -- with LU and with the script's solver -- and everything is compared with the script's numbers: plot-level agreement
+    (the script shows them in one figure), 0.7e-3 of a 52e-3 range."""
+    from oracle import plasticity as pl
+
+    z = np.load(os.path.join(GOLD, "oracle_j2_plasticity.npz"))
+    for g in range(3):
+        assert np.array_equal(z[f"d1_analytical_{g}"], pl.D1_ANALYTICAL[g]) and np.array_equal(z[f"s_tests_{g}"], np.array(pl.S_TEST_GROUPS[g], dtype=float))
+        dev = np.abs(z[f"d1_{g}"] - pl.D1_ANALYTICAL[g])
+        assert dev.max() < 0.7e-3, (g, dev)
+        assert z[f"steps_{g}"].max() < 40  # every load relaxed to max |d1_t| < 1e-4 (none hit the cap)
+    # the elastic range is exact up to the clamped end (0.7 %), the first plastic loads follow the hardening slope E Ep / (E + Ep)
+    assert np.abs(z["d1_0"][:2] / pl.D1_ANALYTICAL[0][:2] - 1).max() < 0.01
+    dom = pl.build()
+    assert dom.max_time_level == 2 and dom.x.size == 3 * dom.basicfield_size
+    d_lu, c_lu = pl.run_group(dom, pl.S_TEST_GROUPS[0][:4], pl.EB_GROUPS[0], pl.EP_GROUPS[0], linear_solver=pl.lu)
+    assert np.abs(d_lu - z["d1_0"][:4]).max() < 1e-12 and c_lu == list(z["steps_0"][:4])
+    assert dom.state.yielded_calls > 0  # the return mapping was active in the fourth load (120 > Y = 100)
+    d_bi, c_bi = pl.run_group(dom, pl.S_TEST_GROUPS[0][:2], pl.EB_GROUPS[0], pl.EP_GROUPS[0])  # solver_of_the_script: bicgstabl_GS!, s = 8
+    # Newton and the linear solve stop at 1e-3 (normalised residual), the pseudo-time loop at max |d1_t| < 1e-4 with dt = 1: two solvers agree to
+    # that level only -- 7e-6 here, 0.1 % of the elongation
+    assert np.abs(d_bi - d_lu[:2]).max() < 5e-5
