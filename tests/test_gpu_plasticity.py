@@ -43,8 +43,10 @@ def test_j2_plasticity_on_gpu(mf):
     gd.dt = 1.0             # :244
     stats = []
 
+    lin_tol = [None]  # None: the script's setting (the solver stops at globalfield.converge_tol = 1e-3)
+
     def solver(g):  # :218
-        dx, st = mf.iterative_Solve(g.A, g.K_total, g.residue, g.converge_tol, Sv_func=mf.bicgstabl_GS_, maxiter=2000, max_pass=20, s=8)
+        dx, st = mf.iterative_Solve(g.A, g.K_total, g.residue, lin_tol[0] or g.converge_tol, Sv_func=mf.bicgstabl_GS_, maxiter=2000, max_pass=20, s=8)
         stats.append(st)
         return dx
 
@@ -53,8 +55,15 @@ def test_j2_plasticity_on_gpu(mf):
     z = np.load(os.path.join(GOLD, "oracle_j2_plasticity.npz"))
     full = os.environ.get("MFEM_FULL_PLASTICITY") == "1"  # all 49 loads of the script; default: the whole first history (isotropic hardening, 17 loads:
     worst = 0.0                                            # elastic, plastic, unloading, reverse yielding) and the first 9 loads of the other two
-    for g in range(3):
-        loads = pl.S_TEST_GROUPS[g] if (full or g == 0) else pl.S_TEST_GROUPS[g][:9]
+    # Pass "parity": the first six loads of the first history (elastic, then plastic at 120 and 140) with the linear solves driven to 1e-10 -- the
+    # oracle's fixture was made with LU solves, so only then do both sides take the same Newton steps: <= 1e-7 of the elongation.  Pass "script":
+    # every load with the script's own tolerances (linear solve to 1e-3): against the script's numbers, and against the fixture at the level those
+    # tolerances leave (the plastic history accumulates what each load's loose solves leave behind: 1e-4 after 17 loads).
+    for g in (-1, 0, 1, 2):
+        if g < 0:
+            g, loads, lin_tol[0] = 0, pl.S_TEST_GROUPS[0][:6], 1e-10
+        else:
+            loads, lin_tol[0] = (pl.S_TEST_GROUPS[g] if (full or g == 0) else pl.S_TEST_GROUPS[g][:9]), None
         gd.x.zero_()
         gd.t = 0.0
         state.reset(pl.EB_GROUPS[g], pl.EP_GROUPS[g])
@@ -74,7 +83,7 @@ def test_j2_plasticity_on_gpu(mf):
         worst = max(worst, dev.max())
         assert dev.max() < 0.7e-3, (g, d1s, pl.D1_ANALYTICAL[g][:k])  # the script's own numbers: plot-level (0.7e-3 of a 52e-3 range)
         # the oracle's run of the same script (LU solves there, bicgstabl_GS!(s = 8) here; Newton to 1e-3, pseudo-time to 1e-4 on both sides)
-        assert np.abs(d1s - z[f"d1_{g}"][:k]).max() < 5e-5, (g, d1s, z[f"d1_{g}"][:k])
+        assert np.abs(d1s - z[f"d1_{g}"][:k]).max() < (1e-7 * np.abs(z[f"d1_{g}"][:k]).max() if lin_tol[0] else 3e-4), (g, lin_tol[0], d1s, z[f"d1_{g}"][:k])
     assert state.yielded_calls > 0
     nconv = sum(1 for st in stats if st.converged)
     print(f"J2 plasticity: {len(stats)} bicgstabl_GS!(s = 8) solves ({nconv} reached the tolerance), worst deviation from d1_analytical {worst:.2e}")
