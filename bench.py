@@ -438,13 +438,13 @@ def main():
         if cfg["solver"] == "cg":
             def solve():
                 return mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, Pr_func=mf.Pr_Jacobi_, maxiter=args.iters, max_pass=1,
-                                          fixed_iterations=True)[1]
+                                          fixed_iterations=True)
         else:
             # bicgstabl_GS! with s = 2 (03_BiCGstabl.jl:18-96): one sweep = 4 SpMVs and advances the solver's `iter` by s = 2
             # (:93), so maxiter = iters / 2 gives `--iters` SpMV-equivalent steps per solve
             def solve():
                 return mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.bicgstabl_GS_, Pr_func=mf.Pr_Jacobi_, maxiter=max(args.iters // 2, 2),
-                                          max_pass=1, s=2, fixed_iterations=True)[1]
+                                          max_pass=1, s=2, fixed_iterations=True)
 
         def step():
             assemble()
@@ -470,9 +470,9 @@ def main():
         t0 = time.perf_counter()
         solve_ms = 0.0
         iters_done = spmvs_done = 0
-        st = None
+        st = dx_last = None
         for _ in range(steps):
-            st = step()
+            dx_last, st = step()
             solve_ms += st.solve_ms
             iters_done += st.iterations
             spmvs_done += st.spmv_count
@@ -508,6 +508,15 @@ def main():
                # the LAST timed solve, as the library reports it (true residual ||b - A x|| / sqrt(n) recomputed after the pass, 02_Preconditioner.jl:53-55)
                "initial_res": st.initial_res if st else None, "final_res": st.final_res if st else None,
                "first_step_s": t_first if warmup > 0 else None, "comm_exposed": comm_exposed, "cfg": cfg, "ckey": ckey}
+        if world == 1 and not use_comm and dx_last is not None:
+            # ... and recomputed OUTSIDE the solver, after the timed region: ||R - K dx|| / sqrt(n) with mul! = the CSR kernel on the caller's arrays
+            # (another kernel, another copy of the matrix than the solver layout the Krylov loop ran on)
+            rr = torch.empty_like(R)
+            mf.mul_(rr, A, K, dx_last)
+            rr.sub_(R)
+            res["final_res_recomputed"] = mf.normalized_norm(rr, ctx=ctx)
+            del rr
+        del dx_last
         if rank == 0:
             if cfg["solver"] == "cg":
                 assert iters_done == args.iters * steps, (iters_done, args.iters, steps)
@@ -621,12 +630,17 @@ def main():
         """bench.py checks what it times: the last timed solve must have reduced the residual (and produced finite numbers)."""
         ir, fr = r["initial_res"], r["final_res"]
         # CG reduces the energy norm monotonically and, over 200 iterations, the residual too: final < initial is required.  bicgstabl_GS! is not
-        # monotone -- over the first sweeps of a small problem ||r|| may sit above ||r0|| -- so short / small legs only have to stay finite and within
-        # 100 x ||r0||; at the config's own size and iteration count (c3: 50 sweeps at 128^3) the strict rule holds for it as well
-        strict = r["cfg"]["solver"] == "cg" or (r["N"] == r["cfg"]["n"] and args.iters >= 200)
+        # monotone -- on the penalty-constrained elasticity operator of c3 ||r|| hovers around ||r0|| for the first hundreds of steps (3.1e-6 -> 2.7e-6
+        # or 3.3e-6 after 200 steps at 128^3, run to run: mode 5 is not bitwise reproducible) -- so its legs have to stay finite and within 100 x ||r0||.
+        # Independent of convergence, the residual the solver reports must be the one recomputed outside it with the CSR kernel (one rank).
+        strict = r["cfg"]["solver"] == "cg"
         ok = ir is not None and fr is not None and fr == fr and ir == ir and fr < float("inf") and (fr < ir if strict else fr < 100.0 * ir)
         if not ok:
             raise SystemExit(f"bench.py: {what}: the last timed solve did not reduce the residual (initial {ir}, final {fr}) -- the run is invalid")
+        rc = r.get("final_res_recomputed")
+        if rc is not None and not (abs(rc - fr) <= 1e-5 * max(fr, rc) + 1e-9 * ir):  # (two kernels, two summation orders: round-off of K dx against a small residual)
+            raise SystemExit(f"bench.py: {what}: the solver reports a final residual of {fr}, the CSR kernel on the caller's matrix gives {rc} for the "
+                             f"solution it returned -- the run is invalid")
 
     def secondary_object(t, title, wkey, baseline_config):
         tv = t["n_global"] * t["updates"] / t["elapsed"]
@@ -634,7 +648,7 @@ def main():
         return {"workload": title, "baseline_config": baseline_config, "value": tv, "unit": "DOF-updates/s", "n_dof": t["n_global"], "nnz": t["nnz"],
                 "steps": t["steps"], "ms_per_step": t["elapsed"] / t["steps"] * 1e3, "solve_ms_per_step": sms,
                 "assembly_ms_per_step": t["elapsed"] / t["steps"] * 1e3 - sms, "krylov_steps_per_step": t["updates"] / t["steps"],
-                "initial_res": t["initial_res"], "final_res": t["final_res"],
+                "initial_res": t["initial_res"], "final_res": t["final_res"], "final_res_recomputed": t.get("final_res_recomputed"),
                 "roofline": solver_roofline(t, wkey), "csr_kernel": t.get("csr_kernel")}
 
     if rank == 0:
@@ -673,6 +687,8 @@ def main():
                 "solve_dof_updates_per_s": r["n_global"] * per_step_updates / (solve_ms_step * 1e-3),
                 # the last timed solve (true residuals, ||.||_2 / sqrt(n)): the run fails unless final < initial
                 "initial_res": r["initial_res"], "final_res": r["final_res"],
+                # the same residual recomputed after the timed region with mul! (the CSR kernel on the caller's arrays): must agree to 1e-5 relative
+                "final_res_recomputed": r.get("final_res_recomputed"),
                 "first_step_s": r["first_step_s"],
                 "workspace_placement_trial": ("on (--ws-trial 1: the first solve times the SpMV on up to three allocations of the workspace and keeps the "
                                               "fastest; its cost is inside first_step_s, outside the timed region)" if args.ws_trial else

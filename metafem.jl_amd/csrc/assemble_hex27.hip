@@ -132,6 +132,7 @@ __host__ __device__ inline int h27_max(int a, int b) { return a > b ? a : b; }
 // workgroup-shared decode table of the sum-factorised stages (int32 words)
 #define H27_NDEC (H27_N1 + H27_N2 + H27_N3 + (NI == 3 ? 0 : H27_NA + H27_NB))
 #define H27_WAVES 8                  // waves per workgroup (they share the reference tables in LDS)
+#define H27_NQP(nq) (((nq) + 3) & ~3)  // Gauss points padded to whole k-groups of the MFMA loop
 #define H27_THREADS (64 * H27_WAVES)
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {  // l wave-uniform
@@ -149,6 +150,7 @@ struct Hex27Args {
   BrickView B;
   const Hex27Tables* tab;
   double kcond;
+  int affine_fast;   // matrix: elements whose 27 nodes are an affine image of the reference nodes (to round-off) take the constant-Jacobian shortcut
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
   int nq, ng;
   int e_lo, e_cnt, ring;  // element planes [e_lo, e_lo + e_cnt) of dimension 0 this launch covers; scratch variant: plane I kept in ring slot I % ring
@@ -208,8 +210,9 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   extern __shared__ double lds[];
   constexpr int NI = MATRIX ? 3 : 5;
   // workgroup-shared reference tables
-  double* s_dN = lds;                           // [nq][3][27]   (matrix only: MFMA operands)
-  double* s_w = s_dN + (MATRIX ? A.nq * 81 : 0); // [nq]
+  double* s_dN = lds;                           // [nqp + 1][3][27] (matrix only: MFMA operands; nqp = nq rounded up to the 4 Gauss points of a k-group,
+                                                //  rows nq .. nqp zero: the k-rows past the last Gauss point and the columns past node 26 read zeros)
+  double* s_w = s_dN + (MATRIX ? (H27_NQP(A.nq) + 1) * 81 : 0); // [nq]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nq = A.nq, ng = A.ng;
   double* s_tab1 = s_w + ((A.nq + 1) & ~1);     // [2][ng][4]
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   double* wave_base = s_tab1 + 8 * ng + (h27_pad(H27_NDEC) >> 1);
   const int n1 = H27_N1, n2 = H27_N2, n3 = H27_N3;
   if (MATRIX)
-    for (int i = tid; i < nq * 81; i += H27_THREADS) s_dN[i] = (&A.tab->dN[0][0][0])[i];
+    for (int i = tid; i < (H27_NQP(nq) + 1) * 81; i += H27_THREADS) s_dN[i] = i < nq * 81 ? (&A.tab->dN[0][0][0])[i] : 0.0;
   for (int i = tid; i < nq; i += H27_THREADS) s_w[i] = A.tab->w[i];
   for (int i = tid; i < 8 * ng; i += H27_THREADS) s_tab1[i] = A.tab->tab1[i / (4 * ng)][(i >> 2) % ng][i & 3];
   // decode words of the three sum-factorisation stages: low half = offset of the first of the 3 operands (stride NI),
@@ -259,6 +262,8 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     }
   }
   double* W = wave_base + (size_t)wv * W_SIZE(MATRIX && !SCRATCH);
+  if (MATRIX)  // G rows of the padding Gauss points nq .. nqp - 1: multiplied by the table's zero rows, so they only have to be finite -- cleared once
+    for (int t = lane; t < 9 * (H27_NQP(nq) - nq); t += 64) W[W_J + 9 * nq + t] = 0.0;  // (later writes to this space are stage-2 sums: finite)
   __syncthreads();
   const BrickView& B = A.B;
   int64_t* rowbase = reinterpret_cast<int64_t*>(W + W_INFO);
@@ -326,6 +331,50 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     if (have) walk.get(I, J, K);
     if (have) cur = fetch_nodes(I, J, K);
     __builtin_amdgcn_wave_barrier();
+    // ---- 2'. AFFINE elements (round 4).  The counters say pass 1 is bound by the ONE pipe FP64 VALU and FP64 MFMA share (MFMA busy 53 % + FP64 /
+    //      integer VALU 33 % of the SIMD cycles: profiles/r04_hex27_wave_counters.txt), and ~45 % of an element's 560 VALU instructions are the
+    //      sum-factorised Jacobian, its adjugate and det at 27 Gauss points.  When the element's 27 nodes are an affine image of the reference
+    //      nodes -- every element of make_Brick until a caller moves coordinates (mfem_brick_coords) -- J is one matrix: G_q = w_q G0 with
+    //      G0 = -k adj(J) adj(J)^T / det, 6 numbers computed once.  The test is made per element on the coordinates themselves (lane a against
+    //      x(0) + a0 e0 / 2 + a1 e1 / 2 + a2 e2 / 2 with the edge vectors e_m = x(corner m) - x(0)), to 16 ulp of the coordinates' magnitude:
+    //      what J's own cancellation error is made of.  Anything else takes the general path below; both give G to round-off of each other.
+    bool affine = false;
+    if (MATRIX && A.affine_fast) {
+      const double x0 = W[W_X + 0], y0 = W[W_X + 1], z0 = W[W_X + 2];
+      const double ex0 = W[W_X + NI * 2 + 0] - x0, ey0 = W[W_X + NI * 2 + 1] - y0, ez0 = W[W_X + NI * 2 + 2] - z0;     // node (2,0,0): d x / d xi0
+      const double ex1 = W[W_X + NI * 6 + 0] - x0, ey1 = W[W_X + NI * 6 + 1] - y0, ez1 = W[W_X + NI * 6 + 2] - z0;     // node (0,2,0): d x / d xi1
+      const double ex2 = W[W_X + NI * 18 + 0] - x0, ey2 = W[W_X + NI * 18 + 1] - y0, ez2 = W[W_X + NI * 18 + 2] - z0;  // node (0,0,2): d x / d xi2
+      bool mine = true;
+      if (lane < 27) {
+        const double a0 = 0.5 * (lane % 3), a1 = 0.5 * ((lane / 3) % 3), a2 = 0.5 * (lane / 9);
+        const double px = x0 + a0 * ex0 + a1 * ex1 + a2 * ex2, py = y0 + a0 * ey0 + a1 * ey1 + a2 * ey2, pz = z0 + a0 * ez0 + a1 * ez1 + a2 * ez2;
+        const double mx = W[W_X + NI * lane + 0], my = W[W_X + NI * lane + 1], mz = W[W_X + NI * lane + 2];
+        const double tol = 3.6e-15;  // 16 ulp of the largest coordinate magnitude the element spans, per component
+        mine = fabs(mx - px) <= tol * (fabs(x0) + fabs(ex0) + fabs(ex1) + fabs(ex2)) &&
+               fabs(my - py) <= tol * (fabs(y0) + fabs(ey0) + fabs(ey1) + fabs(ey2)) &&
+               fabs(mz - pz) <= tol * (fabs(z0) + fabs(ez0) + fabs(ez1) + fabs(ez2));
+      }
+      affine = __all(mine);
+      if (affine) {
+        // J[i][m] = e_m[i]; adjugate rows c_m (as in 2b), G0 = -k / det * C C^T
+        const double j00 = ex0, j01 = ex1, j02 = ex2, j10 = ey0, j11 = ey1, j12 = ey2, j20 = ez0, j21 = ez1, j22 = ez2;
+        const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+        const double c00 = j11 * j22 - j12 * j21, c01 = j02 * j21 - j01 * j22, c02 = j01 * j12 - j11 * j02;
+        const double c10 = j12 * j20 - j22 * j10, c11 = j00 * j22 - j02 * j20, c12 = j02 * j10 - j00 * j12;
+        const double c20 = j10 * j21 - j11 * j20, c21 = j01 * j20 - j21 * j00, c22 = j00 * j11 - j10 * j01;
+        const double sc0 = -A.kcond / det;
+        const double g0 = sc0 * (c00 * c00 + c01 * c01 + c02 * c02), g1 = sc0 * (c00 * c10 + c01 * c11 + c02 * c12),
+                     g2 = sc0 * (c00 * c20 + c01 * c21 + c02 * c22), g3 = sc0 * (c10 * c10 + c11 * c11 + c12 * c12),
+                     g4 = sc0 * (c10 * c20 + c11 * c21 + c12 * c22), g5 = sc0 * (c20 * c20 + c21 * c21 + c22 * c22);
+        __builtin_amdgcn_wave_barrier();  // (the reads of W_X above are done: W_J overlays it)
+        for (int q = lane; q < nq; q += 64) {
+          double* Jm = W + W_J + q * 9;
+          const double wq = s_w[q];
+          Jm[0] = wq * g0; Jm[1] = wq * g1; Jm[2] = wq * g2; Jm[3] = wq * g3; Jm[4] = wq * g4; Jm[5] = wq * g5;
+        }
+      }
+    }
+    if (!affine) {
     // ---- 2a. J[q][i][m] = sum_a dN[q][a][m] X[a][i], sum-factorised over the tensor-product basis
     //      (dN[q][a][0] = D(q0,a0) L(q1,a1) L(q2,a2), ...): three stages of 3-term sums through the wave's LDS block,
     //      ~2000 multiply-adds per element instead of 6561 -- FP64 VALU work runs on the same pipe as the FP64 MFMAs
@@ -385,6 +434,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       Jm[8] = (j00 * j11 - j10 * j01) * id;
       W[W_D + q] = s_w[q] * det;
     }
+    }  // !affine
     __builtin_amdgcn_wave_barrier();
     if (MATRIX) {
       // ---- 3. Ke = B^T D B on the matrix cores.  MFMA fragments are formed on the fly:
@@ -397,29 +447,18 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       // sum_m dN[q][a][m] G_q[m][n] (3 FMAs).  The order of the 3 nq rows along k is free: k-steps 3 g + n (n = 0..2) carry
       // the rows (q = 4 g + kl, n), so a lane keeps one Gauss point for three steps and reads its six table entries and the
       // six entries of G once per group (12 LDS words per group; the first version read 30).
-      const int ngroups = (nq + 3) >> 2;
+      // Branch-free k-groups (round 4): the k-rows past the last Gauss point read zero rows of the table (and the finite filler behind G), the
+      // lanes whose second column block lies past node 26 read the table's zero row with stride 0 -- no per-group zeroing of 24 registers, no
+      // exec-mask regions between the LDS reads and the MFMAs.
+      const int ngroups = H27_NQP(nq) >> 2;
+      const double* dn0 = s_dN + kl * 81 + c;
+      const double* dn1 = hi_ok ? dn0 + 16 : s_dN + H27_NQP(nq) * 81;
+      const int st1 = hi_ok ? 4 * 81 : 0;
+      const double* Gq = W + W_J + kl * 9;
       for (int g = 0; g < ngroups; ++g) {
-        const int q = 4 * g + kl;
-        double d0[3] = {0.0, 0.0, 0.0}, d1[3] = {0.0, 0.0, 0.0};
-        double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        if (q < nq) {
-          const double* dn = s_dN + q * 81 + c;
-          d0[0] = dn[0];
-          d0[1] = dn[27];
-          d0[2] = dn[54];
-          if (hi_ok) {
-            d1[0] = dn[16];
-            d1[1] = dn[43];
-            d1[2] = dn[70];
-          }
-          const double* Gq = W + W_J + q * 9;
-          G[0][0] = Gq[0];
-          G[0][1] = G[1][0] = Gq[1];
-          G[0][2] = G[2][0] = Gq[2];
-          G[1][1] = Gq[3];
-          G[1][2] = G[2][1] = Gq[4];
-          G[2][2] = Gq[5];
-        }
+        const double d0[3] = {dn0[0], dn0[27], dn0[54]};
+        const double d1[3] = {dn1[0], dn1[27], dn1[54]};
+        const double G[3][3] = {{Gq[0], Gq[1], Gq[2]}, {Gq[1], Gq[3], Gq[4]}, {Gq[2], Gq[4], Gq[5]}};
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
           const double a0 = d0[0] * G[0][n] + d0[1] * G[1][n] + d0[2] * G[2][n];
@@ -428,6 +467,9 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
           C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d1[n], C01, 0, 0, 0);
           C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d1[n], C11, 0, 0, 0);
         }
+        dn0 += 4 * 81;
+        dn1 += st1;
+        Gq += 36;
       }
       if (SCRATCH) {
         // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
@@ -739,19 +781,21 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
 static std::atomic<int> g_hex27_two_pass{1};
+static std::atomic<int> g_hex27_affine{1};  // bit 8 of mfem_debug_set_hex27 turns the affine-element shortcut of the matrix kernel off (every element then takes the general path)
 static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
 static std::atomic<size_t> g_hex27_scratch_budget{(size_t)16 << 30};
 extern "C" int mfem_debug_set_hex27(int two_pass) try {
   ++mfem_debug_epoch;
   g_hex27_two_pass = (two_pass & 3) == 0 ? 1 : (two_pass & 3);  // 0 / 1 two-pass (default), 2 FP64 atomics, 3 colour scatter
   g_hex27_chunk_planes = (two_pass >> 16) & 255;
+  g_hex27_affine = ((two_pass >> 8) & 1) ? 0 : 1;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex27")
 
 // mode: 0 residual, 1 matrix with colour scatter / atomics (row descriptors per wave), 2 matrix -> scratch
 static size_t hex27_lds_bytes(int ng, int mode) {
   const int nq = ng * ng * ng, NI = mode == 0 ? 5 : 3;
-  return sizeof(double) * ((size_t)(mode == 0 ? 0 : nq * 81) + ((nq + 1) & ~1) + 8 * ng + (h27_pad(H27_NDEC) >> 1) +
+  return sizeof(double) * ((size_t)(mode == 0 ? 0 : (H27_NQP(nq) + 1) * 81) + ((nq + 1) & ~1) + 8 * ng + (h27_pad(H27_NDEC) >> 1) +
                            H27_WAVES * (size_t)(W_SIZE(mode == 1)));
 }
 
@@ -819,7 +863,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   if (g_hex27_two_pass == 2) {
     MFEM_CHECK_HIP(hipMemsetAsync(vals, 0, sizeof(double) * (size_t)Acsr->nnz, ctx->stream));
     const int64_t nel = (int64_t)m->ne[0] * m->ne[1] * m->ne[2];
-    Hex27Args A{B, g_tab, p->k, -2, nq, m->ng, 0, m->ne[0], 1};
+    Hex27Args A{B, g_tab, p->k, g_hex27_affine, -2, nq, m->ng, 0, m->ne[0], 1};
     int64_t grid = (nel + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;
@@ -846,7 +890,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     const int64_t plane_rows = B.plane_len;
     for (int a = elo; a < ehi; a += P) {
       const int b = a + P < ehi ? a + P : ehi;
-      Hex27Args A{B, g_tab, p->k, -1, nq, m->ng, a, b - a, ring};
+      Hex27Args A{B, g_tab, p->k, g_hex27_affine, -1, nq, m->ng, a, b - a, ring};
       int64_t grid = ((b - a) * plane_el + H27_WAVES - 1) / H27_WAVES;
       const int64_t cap = (int64_t)ctx->num_cus * 2;
       if (grid > cap) grid = cap;
@@ -866,7 +910,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
   for (int colour = 0; colour < 8; ++colour) {
     const int64_t ne = hex27_colour_count(m, colour, elo, ehi);
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1};
+    Hex27Args A{B, g_tab, p->k, g_hex27_affine, colour, nq, m->ng, elo, ehi - elo, 1};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;  // 2 workgroups (16 waves) per CU, persistent over the colour's elements
     if (grid > cap) grid = cap;
@@ -890,7 +934,7 @@ int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem
   for (int colour = 0; colour < 8; ++colour) {
     const int64_t ne = hex27_colour_count(m, colour, elo, ehi);
     if (ne <= 0) continue;
-    Hex27Args A{B, g_tab, p->k, colour, nq, m->ng, elo, ehi - elo, 1};
+    Hex27Args A{B, g_tab, p->k, g_hex27_affine, colour, nq, m->ng, elo, ehi - elo, 1};
     int64_t grid = (ne + H27_WAVES - 1) / H27_WAVES;
     const int64_t cap = (int64_t)ctx->num_cus * 2;
     if (grid > cap) grid = cap;

@@ -86,3 +86,49 @@ def test_hex27_matrix_is_symmetric(mf, variant):
     K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F).cpu().numpy()
     M = sp.csr_matrix((K, A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=(A.n, A.n))
     assert abs(M - M.T).max() <= 1e-13 * abs(M).max()
+
+
+@pytest.mark.parametrize("case", ["uniform", "sheared", "half_distorted", "offset_origin"])
+def test_hex27_affine_element_shortcut(mf, case):
+    """Round 4: elements whose 27 nodes are an affine image of the reference nodes take a constant-Jacobian shortcut in the MFMA kernel (G_q = w_q G0).
+    Against the oracle (<= 1e-12) and against the general path (bit 8 of mfem_debug_set_hex27, <= 1e-13) on: the uniform brick; a SHEARED brick (affine,
+    J full, not symmetric); a brick whose x > 0.5 half is distorted (both paths inside one launch); a brick far from the origin (the affine test is
+    made to 16 ulp of the coordinates' magnitude, where mid-node coordinates differ from the corner average by round-off)."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    x, n = (1.0, 1.5, 0.75), (4, 3, 5)
+    disc = re_.initialize_classical_element(3, "CUBE", 2, 1, 5)
+    msh = om.lattice_mesh(x, n, disc)
+    c = msh.coords.copy()
+    if case == "sheared":
+        M = np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]])
+        c = c @ M.T + np.array([0.3, -0.2, 0.1])
+    elif case == "half_distorted":
+        bump = 0.02 * np.stack([np.sin(3 * c[:, 1]) * np.cos(c[:, 2]), np.sin(2 * c[:, 0] + c[:, 2]), c[:, 0] * c[:, 1]], axis=1)
+        c = c + bump * (c[:, :1] > 0.5)
+    elif case == "offset_origin":
+        c = c + np.array([1000.0, -333.0, 77.7])
+    msh.coords = c
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, K_COND), [])
+    od.controlpoints["s"] = np.zeros(msh.ncp)
+    od.update_time()
+    od.K_linear_func()
+    brick = mf.make_Brick(x, n, 2, 5)
+    for d in range(3):
+        brick.coords_view(d).copy_(torch.tensor(c[:, d], device="cuda"))
+    A = brick.pattern(1)
+    Ks = {}
+    try:
+        for knob in (0, 1 << 8):
+            _lib.lib.mfem_debug_set_hex27(knob)
+            Ks[knob] = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+    finally:
+        _lib.lib.mfem_debug_set_hex27(0)
+    scale = np.abs(od.K_linear).max()
+    # (far from the origin both paths -- and the oracle -- compute J from differences of coordinates of magnitude 1e3: 1e-16 x 1e3 / h per entry)
+    tol = 1e-12 if case != "offset_origin" else 1e-9
+    assert np.abs(Ks[0] - od.K_linear).max() <= tol * scale
+    assert np.abs(Ks[1 << 8] - od.K_linear).max() <= tol * scale
+    assert np.abs(Ks[0] - Ks[1 << 8]).max() <= 0.1 * tol * scale
