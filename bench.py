@@ -150,15 +150,15 @@ def self_launch(n_ranks: int) -> int:
     return 0
 
 
-TRAFFIC_FILE = "profiles/r03_traffic.json"
+TRAFFIC_FILE = "profiles/r04_traffic.json"
 
 
 def load_traffic():
-    """profiles/r03_traffic.json: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950 x2
+    """profiles/r04_traffic.json: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950 x2
     FETCH correction, calibrated in the same run) of THIS tree's kernels, keyed by '<kernel key>@<workload key>'.  Collected by
     tools/run_pmc_r03.sh, not in this run (the line says so in `traffic_source`)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        return json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
     except Exception:
         return {}
 
@@ -233,7 +233,7 @@ def main():
                          "since round 4) -- the line says so in config.workspace_placement_trial and prints the first step's wall time; 0 = as the library ships")
     ap.add_argument("--live-traffic", type=int, default=1,
                     help="N = 1, default sizes: collect the roofline objects' `traffic` in this run (two rocprofv3 --pmc child passes on the "
-                         "headline workload, ~40 s) instead of reading profiles/r03_traffic.json (0 = read the file)")
+                         "headline workload, ~40 s) instead of reading profiles/r04_traffic.json (0 = read the file)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.n <= 0:
@@ -286,7 +286,7 @@ def main():
         t = traffic_db.get(key)
         if not t:
             return None, None
-        return t.get("hbm_bytes_per_launch"), (f"profiles/r03_traffic.json['{key}']: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+        return t.get("hbm_bytes_per_launch"), (f"profiles/r04_traffic.json['{key}']: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                                f"kernel on this workload (tree {t.get('tree', '?')}; gfx950 x2 FETCH_SIZE correction, calibrated "
                                                f"in the same run), not collected in this run")
 
@@ -295,7 +295,7 @@ def main():
         launches.  `achieved` / `frac` price the launch with the bytes the kernel moves BY DESIGN (mfem_csr_spmv_bytes: values, the
         columns it reads -- tiles whose rows repeat one column-offset list read only their first rows' columns --, x, y, row pointers);
         `csr_equivalent` with SURVEY 8(d)'s formula (12 B per nonzero), the north_star's 'CSR SpMV % of HBM roofline' of a kernel
-        without that inspection; `frac_actual` with the PMC-measured traffic of profiles/r03_traffic.json."""
+        without that inspection; `frac_actual` with the PMC-measured traffic of profiles/r04_traffic.json."""
         x = mf.FEM_rand(A.ncols, 0x5EED, 0, ctx=ctx)
         y = torch.empty(A.n, dtype=torch.float64, device=dev)
         for _ in range(3):

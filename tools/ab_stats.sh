@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cp $R/metafem.jl_amd/libmetafem_mi355x.so /tmp/lib_keep.so
+trap 'cp /tmp/lib_keep.so $R/metafem.jl_amd/libmetafem_mi355x.so' EXIT  # restored on every way out
 for f in $R/$2/lib*.so; do
   cp "$f" $R/metafem.jl_amd/libmetafem_mi355x.so
   n=$(basename $f .so)
