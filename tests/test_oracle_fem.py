@@ -207,3 +207,28 @@ def test_transient_conduction_mode_decays_at_the_backward_euler_rate():
         dom.update_one_step()
         amp /= 1.0 + dt * lam
         assert np.allclose(dom.x[:msh.ncp], amp * mode, atol=1e-10)
+
+
+def test_thermoelastic_example_reaches_the_textbook_thermal_bending():
+    """examples/thermal_elasticity/themal_hypo_elasticity.jl (oracle/thermoelastic.py): four coupled fields, one time level, thermal strain in the dual
+    and the base word of the elasticity form, convection to a nodal environment temperature.  The reference holds no numbers for it; the steady state
+    is the stress-free thermal bending of a beam: linear temperature 200 -> 100 across the height, tip deflection alpha g l^2 / 2 = 0.25, mean elongation
+    alpha T_mean l = 0.075.  Coarse mesh (5 x 2 x 2 hex-20), the script's stopping rule."""
+    from oracle import thermoelastic as te
+
+    dom = te.build(e_number=2)
+    assert dom.n_fields == 4 and dom.max_time_level == 1 and (3, 0) in dom.pattern.blocks and (0, 3) in dom.pattern.blocks  # the coupling blocks
+    log, hists = te.run(dom)
+    assert len(log) < 120 and log[-1][0] < 1e-4 and log[-1][2] < 1e-2   # :125
+    assert all(h[-1] < 1e-6 for h in hists)                              # every step's Newton loop reached the script's tolerance (the form is linear: 2 evaluations)
+    n, c = dom.mesh.ncp, dom.mesh.coords
+    tip = np.abs(c[:, 0] - 10.0) < 1e-9
+    assert abs(dom.x[n:2 * n][tip].mean() - 0.25) < 2e-3 and abs(dom.x[:n][tip].mean() - 0.075) < 1e-3
+    mid = np.abs(c[:, 0] - 5.0) < 0.3
+    T = dom.x[3 * n:4 * n]
+    assert abs(T[mid & (np.abs(c[:, 1]) < 1e-9)].mean() - 200.0) < 0.2 and abs(T[mid & (np.abs(c[:, 1] - 1.0) < 1e-9)].mean() - 100.0) < 0.2
+    # K is not symmetric (the T row couples to grad d through -alpha sigma_mm, the d rows to T through the thermal strain: same constant, but the
+    # viscous / capacity terms and the penalty sit on different blocks) -- the script's solver is bicgstabl_GS!(s = 8): one step with it
+    dom2 = te.build(e_number=2)
+    log2, _ = te.run(dom2, linear_solver=te.solver_of_the_script, max_steps=2, stop=False)
+    assert np.abs(log2 - log[:2]).max() < 1e-6 * np.abs(log[:2]).max()
