@@ -226,15 +226,25 @@ extern "C" int mfem_brick_pattern(mfem_context ctx, mfem_brick b, int32_t n_fiel
   A->lat_m0 = b->m[0];
   A->lat_plo = b->plo;
   A->lat_gw = b->p;
-  MFEM_CHECK_HIP(hipMalloc(&A->owned_rowptr, sizeof(int64_t) * (n + 1)));
-  MFEM_CHECK_HIP(hipMalloc(&A->owned_colidx, sizeof(int32_t) * (nnz > 0 ? nnz : 1)));
-  A->rowptr = A->owned_rowptr;
-  A->colidx = (const int32_t*)A->owned_colidx;
-  BrickView B = mfem_brick_view(b, n_fields);
-  hipLaunchKernelGGL(k_brick_pattern, dim3(mfem_grid_for(b->n_owned, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK), 0,
-                     ctx->stream, B, T, (int64_t*)A->owned_rowptr, (int32_t*)A->owned_colidx);
-  MFEM_CHECK_LAUNCH();
-  int rc = mfem_csr_plan(ctx, A);
+  // (from here on every way out releases the half-built handle: a failed 14 GB hipMalloc at 512^3 must not leak the row pointers)
+  auto build = [&]() -> int {
+    MFEM_CHECK_HIP(hipMalloc(&A->owned_rowptr, sizeof(int64_t) * (n + 1)));
+    MFEM_CHECK_HIP(hipMalloc(&A->owned_colidx, sizeof(int32_t) * (nnz > 0 ? nnz : 1)));
+    A->rowptr = A->owned_rowptr;
+    A->colidx = (const int32_t*)A->owned_colidx;
+    BrickView B = mfem_brick_view(b, n_fields);
+    hipLaunchKernelGGL(k_brick_pattern, dim3(mfem_grid_for(b->n_owned, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK), 0,
+                       ctx->stream, B, T, (int64_t*)A->owned_rowptr, (int32_t*)A->owned_colidx);
+    MFEM_CHECK_LAUNCH();
+    return mfem_csr_plan(ctx, A);
+  };
+  int rc = MFEM_OK;
+  try {
+    rc = build();
+  } catch (...) {
+    mfem_csr_destroy(A);
+    throw;
+  }
   if (rc != MFEM_OK) {
     mfem_csr_destroy(A);
     return rc;

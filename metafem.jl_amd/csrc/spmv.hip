@@ -889,7 +889,14 @@ extern "C" int mfem_csr_create(mfem_context ctx, int64_t n, int64_t nnz, const v
   A->rowptr_bits = rowptr_bits;
   A->colidx = colidx;
   A->index_base = index_base;
-  int rc = mfem_csr_plan(ctx, A);
+  int rc = MFEM_OK;
+  try {
+    rc = mfem_csr_plan(ctx, A);
+  } catch (...) {  // (a host allocation of the inspection failed: nothing half-planned is left behind; the entry point's handler reports it)
+    csr_drop_plans(A);
+    delete A;
+    throw;
+  }
   if (rc != MFEM_OK) {
     csr_drop_plans(A);  // whatever the failed plan step left behind (row blocks, elision flags)
     delete A;
