@@ -295,7 +295,13 @@ struct SympGeom {
 // k_spmv_symp) -- their 27 slots, the edge block entries they own, and the diagonal alone to the slot-major copy (k_ell_diag reads it
 // there) -- instead of through the slot-major copy and a second pass (k_symp_bind): 1.97 + 1.85 ms -> one pass at 256^3.
 // the copies are written as full coalesced streams and not read again by this kernel: nontemporal stores (per-solve work of C2 3.65 -> 3.3 ms)
+#if defined(DV_ABL) && DV_ABL == 1   // timing-only ablation builds (tools/ab_libs.sh; never in the product library): 1 = no stores (one per lane and tile
+#define DIA_ST(p, v) do { if ((v) == 1.2345e300) __builtin_nontemporal_store((v), (p)); } while (0)  // keeps the loads alive), 3 = plain instead of nontemporal stores
+#elif defined(DV_ABL) && DV_ABL == 3
+#define DIA_ST(p, v) (*(p) = (v))
+#else
 #define DIA_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 // LPR = lanes per row: 1 (64 rows per wave tile) or 2 (32 rows); SYM: the symmetrically scaled copy -- its own instantiation, so that the plain
 // copy's code is what it was (2.4 ms at 256^3; 2.7 with the test for the scaling in it)
 template <typename RP, int LPR, bool SYM, bool PIPE>
@@ -346,7 +352,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int i = lane + 64 * u;
+#if defined(DV_ABL) && DV_ABL == 2   // (ablation: no value loads)
+      tvn[u] = (double)i;
+#else
       tvn[u] = i < cntn ? __builtin_nontemporal_load(vals + s0n + i) : 0.0;
+#endif
     }
   };
   if (pipe) {
