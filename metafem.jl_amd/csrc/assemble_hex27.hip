@@ -339,7 +339,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     //      x(0) + a0 e0 / 2 + a1 e1 / 2 + a2 e2 / 2 with the edge vectors e_m = x(corner m) - x(0)), to 16 ulp of the coordinates' magnitude:
     //      what J's own cancellation error is made of.  Anything else takes the general path below; both give G to round-off of each other.
     bool affine = false;
-    if (MATRIX && A.affine_fast) {
+    if (A.affine_fast) {
       const double x0 = W[W_X + 0], y0 = W[W_X + 1], z0 = W[W_X + 2];
       const double ex0 = W[W_X + NI * 2 + 0] - x0, ey0 = W[W_X + NI * 2 + 1] - y0, ez0 = W[W_X + NI * 2 + 2] - z0;     // node (2,0,0): d x / d xi0
       const double ex1 = W[W_X + NI * 6 + 0] - x0, ey1 = W[W_X + NI * 6 + 1] - y0, ez1 = W[W_X + NI * 6 + 2] - z0;     // node (0,2,0): d x / d xi1
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
                fabs(mz - pz) <= tol * (fabs(z0) + fabs(ez0) + fabs(ez1) + fabs(ez2));
       }
       affine = __all(mine);
-      if (affine) {
+      if (affine && MATRIX) {
         // J[i][m] = e_m[i]; adjugate rows c_m (as in 2b), G0 = -k / det * C C^T
         const double j00 = ex0, j01 = ex1, j02 = ex2, j10 = ey0, j11 = ey1, j12 = ey2, j20 = ez0, j21 = ez1, j22 = ez2;
         const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
@@ -371,6 +371,44 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
           double* Jm = W + W_J + q * 9;
           const double wq = s_w[q];
           Jm[0] = wq * g0; Jm[1] = wq * g1; Jm[2] = wq * g2; Jm[3] = wq * g3; Jm[4] = wq * g4; Jm[5] = wq * g5;
+        }
+      }
+      if (affine && !MATRIX) {
+        // Residual on an affine element: only T and s (components 3, 4 of the 5 interleaved ones) go through the three sum-factorised stages -- the
+        // same decode words, walked over the compact index u -> t = (u / 2) NI + 3 + (u & 1): 2 + 3 + 2 trips of 64 lanes instead of 5 + 7 + 6 --, and the
+        // inverse Jacobian is one matrix, written to every Gauss point's row for the flux stage below (the general path computes 27 of them).
+        const double j00 = ex0, j01 = ex1, j02 = ex2, j10 = ey0, j11 = ey1, j12 = ey2, j20 = ez0, j21 = ez1, j22 = ez2;
+        const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+        const double id = 1.0 / det;
+        const double i0 = (j11 * j22 - j12 * j21) * id, i1 = (j02 * j21 - j01 * j22) * id, i2 = (j01 * j12 - j11 * j02) * id;
+        const double i3 = (j12 * j20 - j22 * j10) * id, i4 = (j00 * j22 - j02 * j20) * id, i5 = (j02 * j10 - j00 * j12) * id;
+        const double i6 = (j10 * j21 - j11 * j20) * id, i7 = (j01 * j20 - j21 * j00) * id, i8 = (j00 * j11 - j10 * j01) * id;
+        for (int u = lane; u < 2 * (n1 / NI); u += 64) {
+          const int t = (u >> 1) * NI + 3 + (u & 1);
+          const int d = s_dec[t];
+          const double* x = W + W_X + (d & 0xffff);
+          const double* tb = s_tab1 + (d >> 16);
+          W[W_T1 + t] = tb[0] * x[0] + tb[1] * x[NI] + tb[2] * x[2 * NI];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int u = lane; u < 2 * (n2 / NI); u += 64) {
+          const int t = (u >> 1) * NI + 3 + (u & 1);
+          const int d = s_dec[n1 + t];
+          const double* x = W + W_T1 + (d & 0xffff);
+          const double* tb = s_tab1 + (d >> 16);
+          W[W_T2 + t] = tb[0] * x[0] + tb[1] * x[NI] + tb[2] * x[2 * NI];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 9 * nq + lane; t < n3; t += 64) {  // grad_xi T and s at the Gauss points (the J entries in front of them are not needed)
+          const int d = s_dec[n1 + n2 + t];
+          const double* x = W + W_T2 + (d & 0xffff);
+          const double* tb = s_tab1 + (d >> 16);
+          W[W_J + t] = tb[0] * x[0] + tb[1] * x[NI] + tb[2] * x[2 * NI];
+        }
+        for (int q = lane; q < nq; q += 64) {  // (rows 0 .. 9 nq of this space: X and T1 are dead, the outputs above sit behind them)
+          double* Jm = W + W_J + q * 9;
+          Jm[0] = i0; Jm[1] = i1; Jm[2] = i2; Jm[3] = i3; Jm[4] = i4; Jm[5] = i5; Jm[6] = i6; Jm[7] = i7; Jm[8] = i8;
+          W[W_D + q] = s_w[q] * det;
         }
       }
     }

@@ -119,13 +119,23 @@ def test_hex27_affine_element_shortcut(mf, case):
     for d in range(3):
         brick.coords_view(d).copy_(torch.tensor(c[:, d], device="cuda"))
     A = brick.pattern(1)
-    Ks = {}
+    rng = np.random.default_rng(4)
+    od.controlpoints["s"] = 100.0 * rng.standard_normal(msh.ncp)
+    od.x_star[:] = 300.0 + 10.0 * rng.standard_normal(od.basicfield_size)
+    od.K_nonlinear_func()
+    xs, ss = torch.tensor(od.x_star, device="cuda"), torch.tensor(od.controlpoints["s"], device="cuda")
+    Ks, Rs = {}, {}
     try:
         for knob in (0, 1 << 8):
             _lib.lib.mfem_debug_set_hex27(knob)
             Ks[knob] = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+            Rs[knob] = brick.residual_thermal(xs, K_COND, 0.0, TENV, 0, s=ss).cpu().numpy()  # the matrix-free residual takes the shortcut too
     finally:
         _lib.lib.mfem_debug_set_hex27(0)
+    rscale = np.abs(od.residue).max()
+    rtol = 1e-11 if case != "offset_origin" else 1e-8
+    assert np.abs(Rs[0] - od.residue).max() <= rtol * rscale and np.abs(Rs[1 << 8] - od.residue).max() <= rtol * rscale
+    assert np.abs(Rs[0] - Rs[1 << 8]).max() <= 0.1 * rtol * rscale
     scale = np.abs(od.K_linear).max()
     # (far from the origin both paths -- and the oracle -- compute J from differences of coordinates of magnitude 1e3: 1e-16 x 1e3 / h per entry)
     tol = 1e-12 if case != "offset_origin" else 1e-9

@@ -24,6 +24,20 @@ for knob, tag in ((0, "affine shortcut"), (1 << 8, "general path"), (0, "affine 
     _lib.lib.mfem_debug_set_hex27(knob)
     ms = timed()
     print(f"N {N} uniform brick, {tag:16s}: {ms:.3f} ms per assembly = {118098.0 * N ** 3 / (ms * 1e-3) / 1e12:.2f} TFLOP/s useful = {118098.0 * N ** 3 / (ms * 1e-3) / 78.6e12:.3f} of the FP64 matrix peak", flush=True)
+xs = mf.FEM_rand(A.n, 1, 0); R = torch.empty_like(xs)
+def timed_res():
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(5):
+            brick.residual_thermal(xs, 0.6, 0.0, 293.15, 0, s=xs, out=R)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 5)
+    return best
+for knob, tag in ((0, "affine shortcut"), (1 << 8, "general path"), (0, "affine shortcut"), (1 << 8, "general path")):
+    _lib.lib.mfem_debug_set_hex27(knob)
+    print(f"N {N} uniform brick, residual, {tag:16s}: {timed_res():.3f} ms", flush=True)
 _lib.lib.mfem_debug_set_hex27(0)
 x0 = brick.coords_view(0); x1 = brick.coords_view(1); x2 = brick.coords_view(2)
 x0.add_(0.001 * torch.sin(3 * x1) * torch.cos(x2))
