@@ -127,3 +127,43 @@ def test_matrix_kernel_equals_the_row_owner_kernel(mf):
     scale = float(K_row.abs().max())
     assert scale > 0 and float((K - K_row).abs().max()) <= 2e-13 * scale
     assert torch.equal(K, brick.assemble_elasticity(A, LAM, MU, TAU, faces))
+
+
+@pytest.mark.parametrize("case", ["uniform", "sheared", "half_distorted"])
+def test_affine_element_shortcut_of_the_matrix_kernel(mf, case):
+    """Round 4: on an affine element (parallelepiped: the mixed coefficients of its trilinear map vanish to 16 ulp of the coordinates' magnitude) the matrix
+    kernel takes G = det Jinv^T M Jinv from the quadrature's reference integrals instead of integrating at 8 Gauss points.  Against the oracle (2e-13) and
+    against the general path (bit 5 of mfem_debug_set_elasticity) on the uniform brick, a sheared brick (affine, full J) and a brick distorted only where
+    x > 1.5 (both paths inside one launch, inside one wave)."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    x, n = (3.0, 1.0, 1.0), (6, 3, 4)
+    disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
+    msh = om.lattice_mesh(x, n, disc)
+    c = msh.coords.copy()
+    if case == "sheared":
+        c = c @ np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]]).T + np.array([0.3, -0.2, 0.1])
+    elif case == "half_distorted":
+        c = c + 0.03 * np.stack([np.sin(2 * c[:, 1]), np.cos(2 * c[:, 2]) - 1, c[:, 0] * c[:, 1] / x[0]], axis=1) * (c[:, :1] > 1.5)
+    msh.coords = c
+    od = fem.FEMDomain(msh, disc, 3, problems.elasticity_domain(3, LAM, MU), [])
+    od.update_time()
+    od.K_linear_func()
+    brick = mf.make_Brick(x, n, 1, 3)
+    for d in range(3):
+        brick.coords_view(d).copy_(torch.tensor(c[:, d], device="cuda"))
+    A = brick.pattern(3)
+    Ks = {}
+    try:
+        for knob in (0, 1 << 5):
+            _lib.lib.mfem_debug_set_elasticity(knob)
+            Ks[knob] = brick.assemble_elasticity(A, LAM, MU, 0.0, 0).cpu().numpy()
+    finally:
+        _lib.lib.mfem_debug_set_elasticity(0)
+    scale = np.abs(od.K_linear).max()
+    assert np.abs(Ks[0] - od.K_linear).max() <= 2e-13 * scale and np.abs(Ks[1 << 5] - od.K_linear).max() <= 2e-13 * scale
+    assert np.abs(Ks[0] - Ks[1 << 5]).max() <= 1e-13 * scale
+    if case != "half_distorted":
+        assert not np.array_equal(Ks[0], Ks[1 << 5])  # (the two paths round differently: the knob does select another code path)
