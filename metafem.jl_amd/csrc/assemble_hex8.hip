@@ -606,7 +606,7 @@ __device__ __forceinline__ void sweep_load_coords(const BrickView& B, int ip, in
 template <int NG>
 __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_residual_sweep(BrickView B, int L, double kcond, const double* __restrict__ x,
                                                                          const double* __restrict__ src,
-                                                                         double* __restrict__ res) {
+                                                                         double* __restrict__ res, int affine_fast) {
   __shared__ double Fe[SW_THREADS * 9];
   const int tid = threadIdx.x, ek = tid % SW_E, ej = tid / SW_E;
   const SweepTile T = sweep_tile(B, L);
@@ -655,7 +655,8 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         Tn[1][c] = Tq[c]; Sn[1][c] = Sq[c];
       }
       double fe[2][4];
-      sf_thermal_fe<NG>(X, Tn, Sn, has_src, kcond, fe);
+      if (affine_fast && sf_is_affine(X)) sf_thermal_fe<NG, true>(X, Tn, Sn, has_src, kcond, fe);  // (one adjugate for a parallelepiped: see k_thermal_matrix_sweep)
+      else sf_thermal_fe<NG, false>(X, Tn, Sn, has_src, kcond, fe);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         Fe[tid * 9 + 2 * c] = fe[0][c];
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
 }
 
 template <int NG>
-__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals) {
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals, int stage_rows) {
   __shared__ double Ke[SW_THREADS * SW_KSTRIDE];
   const int tid = threadIdx.x, ek = tid % SW_E, ej = tid / SW_E;
   const SweepTile T = sweep_tile(B, L);
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
     ck = B.c2[k];
   }
   const bool jk_inner = nd_ok && j > 0 && j < B.ne1 && k > 0 && k < B.ne2;  // all nine in-plane neighbours exist
+  const bool staged = (stage_rows & 1) != 0;  // (kernel argument, uniform: the per-thread write-out is kept behind bit 1 of mfem_debug_set_hex8_thermal)
   double Xn[3][4];
   auto request = [&](int ip) {
 #pragma unroll
@@ -735,36 +737,57 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         X[0][1][c] = Xn[0][c]; X[1][1][c] = Xn[1][c]; X[2][1][c] = Xn[2][c];
       }
       double k36[36];
-      sf_thermal_ke<NG>(X, kcond, k36);
+      // affine elements (bit 1 of the kernel's flag word): one adjugate instead of NG^3 -- the FP64 work is what this kernel's time follows (a table of
+      // reference integrals, ke = sum_t g0[t] K6[t], was measured too: 216 constant loads per element made the kernel 1.7x SLOWER)
+      if ((stage_rows & 2) && sf_is_affine(X)) sf_thermal_ke<NG, true>(X, kcond, k36);
+      else sf_thermal_ke<NG, false>(X, kcond, k36);
 #pragma unroll
       for (int t = 0; t < 36; ++t) Ke[tid * SW_KSTRIDE + t] = k36[t];
       if (I < Ilast) request(I + 2);
     }
     __syncthreads();
-    if (nd_ok) {
-      // now[bx * 9 + dj * 3 + dk]: entries of this plane's point towards node plane I + bx; up[...]: entries of the point above it
-      // (node plane I + 1) towards node plane I + bx
-      double now[18], up[18];
+    // now[bx * 9 + dj * 3 + dk]: entries of this plane's point towards node plane I + bx; up[...]: entries of the point above it
+    // (node plane I + 1) towards node plane I + bx
+    double now[18], up[18];
 #pragma unroll
-      for (int t = 0; t < 18; ++t) now[t] = up[t] = 0.0;
-      if (plane) {
+    for (int t = 0; t < 18; ++t) now[t] = up[t] = 0.0;
+    if (nd_ok && plane) {
 #pragma unroll
-        for (int ez = 0; ez < 2; ++ez)
+      for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
-          for (int ey = 0; ey < 2; ++ey) {
-            const int Jn = j - 1 + ey, Kn = k - 1 + ez;
-            if (Jn < 0 || Jn >= B.ne1 || Kn < 0 || Kn >= B.ne2) continue;
-            const double* ke = Ke + ((ej + ey) * SW_E + ek + ez) * SW_KSTRIDE;
-            const int a0 = 2 * (1 - ey) + 4 * (1 - ez);
+        for (int ey = 0; ey < 2; ++ey) {
+          const int Jn = j - 1 + ey, Kn = k - 1 + ez;
+          if (Jn < 0 || Jn >= B.ne1 || Kn < 0 || Kn >= B.ne2) continue;
+          const double* ke = Ke + ((ej + ey) * SW_E + ek + ez) * SW_KSTRIDE;
+          const int a0 = 2 * (1 - ey) + 4 * (1 - ez);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-              const int slot = (b & 1) * 9 + (ey + ((b >> 1) & 1)) * 3 + ez + (b >> 2);
-              now[slot] += ke[sym36(a0, b)];
-              up[slot] += ke[sym36(a0 + 1, b)];
-            }
+          for (int b = 0; b < 8; ++b) {
+            const int slot = (b & 1) * 9 + (ey + ((b >> 1) & 1)) * 3 + ez + (b >> 2);
+            now[slot] += ke[sym36(a0, b)];
+            up[slot] += ke[sym36(a0 + 1, b)];
           }
+        }
+    }
+    // Write-out.  A point away from the lattice boundary has its full 27-entry row, one contiguous run in (di, dj, dk) order -- and the rows of the
+    // points of one tile line are contiguous in CSR too.  Writing row[t] per thread puts 64 lanes 216 bytes apart: 27 x 64 eight-byte requests per
+    // wave and plane, and at 4.6e8 requests per assembly (256^3) the L2's request rate, not its bytes, set the kernel's time (round 4).  The rows now go
+    // through LDS (the element matrices of this plane are dead once every point has gathered them) and leave as contiguous streams: a wave per tile line.
+    // (Every barrier below is reached by ALL threads of the workgroup: `staged` is a kernel argument, nothing here sits inside a per-thread branch.)
+    const bool full_row = nd_ok && jk_inner && I > 0 && I < B.ne0 && I >= T.i0;
+    if (staged) {
+      __syncthreads();  // every point has gathered from Ke
+      if (full_row) {
+        double* st = Ke + tid * 27;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          st[t] = carry[t];
+          st[9 + t] = carry[9 + t] + now[t];
+          st[18 + t] = now[9 + t];
+        }
       }
-      if (I >= T.i0) {
+    }
+    if (nd_ok) {
+      if (I >= T.i0 && !(staged && full_row)) {
         double* row = vals + brick_prefix(B, I, j, k);
         if (jk_inner && I > 0 && I < B.ne0) {  // the full 27-entry row is one contiguous run in (di, dj, dk) order
 #pragma unroll
@@ -792,6 +815,20 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
 #pragma unroll
       for (int t = 0; t < 18; ++t) carry[t] = up[t];
     }
+    if (staged) {
+      __syncthreads();  // the staged rows are complete
+      if (I >= T.i0 && I > 0 && I < B.ne0) {
+        const int k0 = max(T.tk0, 1), k1 = min(min(T.tk0 + SW_N, B.ne2), B.m2);  // points of a tile line with a full row: k in [k0, k1)
+        const int cnt = (k1 - k0) * 27;
+        for (int line = tid >> 6; line < SW_N; line += SW_THREADS / 64) {
+          const int jl = T.tj0 + line;
+          if (jl < 1 || jl >= B.ne1 || jl >= B.m1 || cnt <= 0) continue;
+          double* dst = vals + brick_prefix(B, I, jl, k0);
+          const double* src = Ke + (line * SW_E + (k0 - T.tk0)) * 27;
+          for (int o = tid & 63; o < cnt; o += 64) __builtin_nontemporal_store(src[o], dst + o);
+        }
+      }
+    }
     __syncthreads();
   }
 }
@@ -801,9 +838,11 @@ static dim3 boundary_grid(const mfem_brick_s* m) {  // boundary_point(): one thr
   return dim3((unsigned)((cnt + MFEM_BLOCK - 1) / MFEM_BLOCK > 0 ? (cnt + MFEM_BLOCK - 1) / MFEM_BLOCK : 1));
 }
 static std::atomic<int> g_thermal_variant{0};  // 1: the 4 x 4 x 8 tile kernels for every Gauss order (kept: 1- and 4-point rules use them)
+static std::atomic<int> g_thermal_stage_rows{3};  // the matrix sweep kernel's flag word: bit 0 rows staged through LDS (off: bit 1 of mfem_debug_set_hex8_thermal), bit 1 the affine-element shortcut (off: bit 2)
 extern "C" int mfem_debug_set_hex8_thermal(int variant) try {
   ++mfem_debug_epoch;
-  g_thermal_variant = variant ? 1 : 0;
+  g_thermal_variant = (variant & 1) ? 1 : 0;
+  g_thermal_stage_rows = ((variant & 2) ? 0 : 1) | ((variant & 4) ? 0 : 2);
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex8_thermal")
 // planes per sweep segment: 32, shorter when the (j, k) tiles alone cannot fill the chip
@@ -1361,9 +1400,9 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
     int64_t grid;
     const int L = sweep_planes(m, &grid);
     if (m->ng == 2)
-      hipLaunchKernelGGL(k_thermal_matrix_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals);
+      hipLaunchKernelGGL(k_thermal_matrix_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals, g_thermal_stage_rows.load());
     else
-      hipLaunchKernelGGL(k_thermal_matrix_sweep<3>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals);
+      hipLaunchKernelGGL(k_thermal_matrix_sweep<3>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals, g_thermal_stage_rows.load());
   } else {
     const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
     hipLaunchKernelGGL(k_thermal_matrix, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, vals);
@@ -1388,10 +1427,10 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
     const int L = sweep_planes(m, &grid);
     if (m->ng == 2)
       hipLaunchKernelGGL(k_thermal_residual_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, x_star, s,
-                         residue);
+                         residue, (g_thermal_stage_rows.load() >> 1) & 1);
     else
       hipLaunchKernelGGL(k_thermal_residual_sweep<3>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, x_star, s,
-                         residue);
+                         residue, (g_thermal_stage_rows.load() >> 1) & 1);
     if (p->h != 0.0 && p->robin_faces != 0u) {
       MFEM_CHECK_LAUNCH();
       hipLaunchKernelGGL(k_thermal_residual_robin, boundary_grid(m), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->h, p->Tenv, p->robin_faces,

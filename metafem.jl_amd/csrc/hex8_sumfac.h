@@ -252,7 +252,7 @@ SF_HD double sf_adjugate(const SfCols<NG>& C, int qx, int qy, int qz, double (&R
 
 // ---- thermal residual of one element (3D_Script.jl:30-31, domain part):
 //   fe[a] = sum_q w det ( -k grad N_a . grad T + N_a s )
-template <int NG>
+template <int NG, bool AFFINE = false>  // AFFINE: see sf_thermal_ke (one adjugate for the element)
 SF_HD void sf_thermal_fe(const double (&X)[3][2][4], const double (&T)[2][4], const double (&Sn)[2][4], bool has_src, double kcond,
                          double (&fe)[2][4]) {
   SfCols<NG> C;
@@ -261,6 +261,9 @@ SF_HD void sf_thermal_fe(const double (&X)[3][2][4], const double (&T)[2][4], co
   sf_ref_grads<NG>(T, t0, t1, t2);
   double F[3][NG][NG][NG], S[NG][NG][NG];
   if (has_src) sf_ref_interp<NG>(Sn, S);
+  double R0[3][3];
+  double det0 = 1.0;
+  if (AFFINE) det0 = sf_adjugate<NG>(C, 0, 0, 0, R0);
 #pragma unroll
   for (int qx = 0; qx < NG; ++qx)
 #pragma unroll
@@ -268,7 +271,15 @@ SF_HD void sf_thermal_fe(const double (&X)[3][2][4], const double (&T)[2][4], co
 #pragma unroll
       for (int qz = 0; qz < NG; ++qz) {
         double R[3][3];
-        const double det = sf_adjugate<NG>(C, qx, qy, qz, R);
+        double det = det0;
+        if (AFFINE) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) R[m][n] = R0[m][n];
+        } else {
+          det = sf_adjugate<NG>(C, qx, qy, qz, R);
+        }
         const double w = sf_w<NG>(qx) * sf_w<NG>(qy) * sf_w<NG>(qz);
         const double g0 = t0[qy][qz], g1 = t1[qx][qz], g2 = t2[qx][qy];
         double v[3];
@@ -344,16 +355,36 @@ SF_HD void sf_elasticity_fe(const double (&X)[3][2][4], const double (&U)[3][2][
   }
 }
 
+// All eight nodes of X[i][bx][c] (c = by + 2 bz) on the affine image of the reference cube, to 16 ulp of the coordinates' magnitude (what the Jacobian's own
+// cancellation error is made of): every element of make_Brick until a caller moves coordinates.
+SF_HD bool sf_is_affine(const double (&X)[3][2][4]) {
+  bool ok = true;
+  for (int i = 0; i < 3; ++i) {
+    const double x0 = X[i][0][0];
+    const double e0 = X[i][1][0] - x0, e1 = X[i][0][1] - x0, e2 = X[i][0][2] - x0;
+    const double a0 = e0 < 0 ? -e0 : e0, a1 = e1 < 0 ? -e1 : e1, a2 = e2 < 0 ? -e2 : e2, ax = x0 < 0 ? -x0 : x0;
+    const double tol = 3.6e-15 * (ax + a0 + a1 + a2);
+    const double d1 = X[i][1][1] - (x0 + e0 + e1), d2 = X[i][1][2] - (x0 + e0 + e2), d3 = X[i][0][3] - (x0 + e1 + e2), d4 = X[i][1][3] - (x0 + e0 + e1 + e2);
+    ok = ok && (d1 < 0 ? -d1 : d1) <= tol && (d2 < 0 ? -d2 : d2) <= tol && (d3 < 0 ? -d3 : d3) <= tol && (d4 < 0 ? -d4 : d4) <= tol;
+  }
+  return ok;
+}
+
 // ---- thermal element matrix, the 36 unique entries of the symmetric 8 x 8 Ke = sum_q w det (-k) grad N_a . grad N_b.
 // Node a = ax + 2 ay + 4 az (tensor order, x fastest = c_dN's order); packing ke36[sym36(a, b)] of assemble_hex8.hip.
 SF_HD constexpr int sf_sym36(int a, int b) {
   return a <= b ? a * 8 - (a * (a - 1)) / 2 + (b - a) : b * 8 - (b * (b - 1)) / 2 + (a - b);
 }
-template <int NG>
+// AFFINE = true (round 4): the caller has found the element to be a parallelepiped (sf_is_affine below) -- the adjugate and det are those of ONE Gauss point
+// (they are the same at all of them up to round-off), 1 instead of NG^3 evaluations; everything else is the same code.
+template <int NG, bool AFFINE = false>
 SF_HD void sf_thermal_ke(const double (&X)[3][2][4], double kcond, double (&ke)[36]) {
   SfCols<NG> C;
   sf_columns<NG>(X, C);
   double G[6][NG][NG][NG];  // 00 01 02 11 12 22
+  double R0[3][3];
+  double det0 = 1.0;
+  if (AFFINE) det0 = sf_adjugate<NG>(C, 0, 0, 0, R0);
 #pragma unroll
   for (int qx = 0; qx < NG; ++qx)
 #pragma unroll
@@ -361,7 +392,15 @@ SF_HD void sf_thermal_ke(const double (&X)[3][2][4], double kcond, double (&ke)[
 #pragma unroll
       for (int qz = 0; qz < NG; ++qz) {
         double R[3][3];
-        const double det = sf_adjugate<NG>(C, qx, qy, qz, R);
+        double det = det0;
+        if (AFFINE) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) R[m][n] = R0[m][n];
+        } else {
+          det = sf_adjugate<NG>(C, qx, qy, qz, R);
+        }
         const double sc = (-kcond * (sf_w<NG>(qx) * sf_w<NG>(qy) * sf_w<NG>(qz))) / det;
         int t = 0;
 #pragma unroll

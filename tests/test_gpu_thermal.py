@@ -160,3 +160,61 @@ def test_sweep_kernels_equal_tile_kernels_and_keep_K_bitwise_symmetric(mf, n, it
     M = sp.csr_matrix((out[0][0], A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=(A.n, A.n))
     D = (M - M.T).tocoo()
     assert D.nnz == 0 or np.max(np.abs(D.data)) == 0.0
+
+
+@pytest.mark.parametrize("case", ["uniform", "sheared", "half_distorted"])
+@pytest.mark.parametrize("itg", [3, 5])
+def test_affine_element_shortcut_of_the_matrix_sweep(mf, case, itg):
+    """Round 4: on an affine element (all eight nodes on the affine image of the reference cube to 16 ulp of the coordinates' magnitude) the sweep kernel takes
+    Ke = sum_t g0[t] K6[t] -- one adjugate and the quadrature's reference integrals -- instead of the sum-factorised integration.  Against the oracle and
+    against the general path (bit 2 of mfem_debug_set_hex8_thermal), with the rows staged through LDS and written per thread (bit 1): uniform brick,
+    sheared brick (affine, full J), brick distorted where x > 0.5 (both paths inside one workgroup)."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    x, n = (1.0, 2.0, 0.5), (20, 17, 19)  # more than one 15 x 15 tile in j and k, tiles cut by the lattice
+    od = _oracle_domain(x, n, itg_order=itg, faces=[])
+    c = od.mesh.coords.copy()
+    if case == "sheared":
+        c = c @ np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]]).T + np.array([0.3, -0.2, 0.1])
+    elif case == "half_distorted":
+        c = np.where(c[:, :1] > 0.5, _distort(c), c)
+    od = _oracle_domain(x, n, itg_order=itg, distort=lambda _c: c, faces=[])
+    od.update_time()
+    od.K_linear_func()
+    brick = mf.make_Brick(x, n, 1, itg)
+    for d in range(3):
+        brick.coords_view(d).copy_(torch.tensor(c[:, d], device="cuda"))
+    A = brick.pattern(1)
+    rng = np.random.default_rng(4)
+    od.controlpoints["s"] = 100.0 * rng.standard_normal(od.mesh.ncp)
+    od.x_star[:] = 300.0 + 10.0 * rng.standard_normal(od.basicfield_size)
+    od.K_nonlinear_func()
+    xs, ss = torch.tensor(od.x_star, device="cuda"), torch.tensor(od.controlpoints["s"], device="cuda")
+    Ks, Rs = {}, {}
+    try:
+        for knob in (0, 4, 2, 6):
+            _lib.lib.mfem_debug_set_hex8_thermal(knob)
+            Ks[knob] = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+            Rs[knob] = brick.residual_thermal(xs, K_COND, 0.0, TENV, 0, s=ss).cpu().numpy()  # the matrix-free residual sweep takes the shortcut too
+    finally:
+        _lib.lib.mfem_debug_set_hex8_thermal(0)
+    rscale = np.abs(od.residue).max()
+    for knob, R in Rs.items():
+        assert np.abs(R - od.residue).max() <= 1e-12 * rscale, knob
+    assert np.abs(Rs[0] - Rs[4]).max() <= 1e-13 * rscale
+    scale = np.abs(od.K_linear).max()
+    for knob, K in Ks.items():
+        assert np.abs(K - od.K_linear).max() <= 2e-13 * scale, knob
+    assert np.array_equal(Ks[0], Ks[2]) and np.array_equal(Ks[4], Ks[6])  # the write-out does not touch the values
+    assert np.abs(Ks[0] - Ks[4]).max() <= 1e-13 * scale
+    if case != "half_distorted":
+        assert not np.array_equal(Ks[0], Ks[4])  # (another code path: other rounding)
+    M = sp_csr(Ks[0], A)
+    assert abs(M - M.T).max() <= 1e-13 * scale  # symmetric to round-off on either path
+
+
+def sp_csr(K, A):
+    import scipy.sparse as sp
+
+    return sp.csr_matrix((K, A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=(A.n, A.n))
