@@ -228,8 +228,9 @@ typedef struct {
  *    (entries of magnitude in [0.75, 1.25), random signs) through the layout against the CSR kernel on the caller's values; the layout is taken
  *    when max over rows r of |difference|_r <= 4e-13 |a_rr| (rows without a stored non-zero diagonal: 4e-13 max|a|).  Consequence: an
  *    asymmetry BELOW that level (about 2 000 ulp of the row's diagonal) is not detected and the solve then runs on the symmetrised matrix
- *    (upper triangle mirrored); anything above it sends the solve to modes 3 / 2 on the caller's exact values.  The residual the solve
- *    reports is computed with the layout that ran.  mfem_debug_lat27_asymmetry / mfem_debug_lat8_asymmetry return the last measure.
+ *    (upper triangle mirrored); anything above it sends the solve to modes 3 / 2 on the caller's exact values.  The residual a solve on
+ *    ONE rank reports (stats.final_res, and with it `converged`) is recomputed at the end with the CSR kernel on the caller's own values (one extra
+ *    SpMV per solve; not in fixed_iterations mode) -- it cannot hide a substitution.  mfem_debug_lat27_asymmetry / mfem_debug_lat8_asymmetry return the last measure.
  * Threading: one context per host thread; handles are not shared between threads while a call is in flight.  Quadrature / lattice tables live
  * in __constant__ memory per PROCESS (uploads are serialised): assemblies with different Gauss orders must not run concurrently from
  * different host threads.  The mfem_debug_* knobs are process-wide atomics, to be changed only while no call is in flight. */

@@ -172,3 +172,36 @@ def test_symmetry_gate_weighs_the_probe_per_row(mf):
         assert served(K3) == 0
     finally:
         lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("order,fields", [(1, 3), (2, 1)])
+def test_residual_reported_by_a_lattice_tile_solve_comes_from_the_callers_csr_values(mf, order, fields):
+    """modes 4 / 5 run the Krylov loop on a half-stored copy that passed a symmetry gate; the residual the caller is told (and `converged`) is
+    recomputed at the end with the CSR kernel on the caller's own values -- here: equal to ||b - A x|| / sqrt(n) from mul!, for values with an asymmetry
+    just BELOW the gate (the loop then ran on the symmetrised matrix) as for symmetric ones."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    lib = _lib.lib
+    lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        b = mf.make_Brick((1.0, 1.0, 1.0), (9, 8, 7), order, 5 if order == 2 else 3)
+        A = b.pattern(fields)
+        K = b.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES) if fields == 1 else b.assemble_elasticity(A, LAM, MU, 1000.0, mf.FACE_BITS["x0"])
+        count = lib.mfem_debug_lat27_spmv_count if order == 2 else lib.mfem_debug_lat8_spmv_count
+        rhs = mf.FEM_rand(A.n, 7, 0) - 0.5
+        r = torch.empty_like(rhs)
+        for eps in (0.0, 1e-13):
+            K2 = K.clone()
+            if eps:
+                row = A.n // 2
+                lo = int(A.rowptr[row])
+                K2[lo] += eps * float(K2[lo:int(A.rowptr[row + 1])].abs().max())  # first entry of a middle row: an off-diagonal one
+            c0 = int(count())
+            x, st = mf.iterative_Solve(A, K2, rhs, 1e-9, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=4000, max_pass=4)
+            assert int(count()) > c0 and st.converged == 1  # the tiles served the solve
+            mf.mul_(r, A, K2, x)
+            true_res = mf.normalized_norm(r - rhs)
+            assert st.final_res == pytest.approx(true_res, rel=1e-6, abs=1e-16)
+    finally:
+        lib.mfem_debug_set_layout_min_rows(262144, 1000000)
