@@ -199,7 +199,8 @@ typedef struct {
                                a positive finite diagonal on every rank (ghost columns are divided by their owners' S); otherwise 3
                                runs.  With more than one rank and cg_variant 0 the single-reduction form runs on the scaled system
                                (9 vector streams instead of 10: its u IS r).
-                               0 = auto: the single-reduction form when a communicator with more than one rank is attached, the
+                               0 = auto: the single-reduction form when a communicator with more than one rank is attached AND the system has
+                               fewer than 2e7 rows per rank (above that the vector stream it adds costs more than the all-reduce it saves), the
                                two-reduction form otherwise -- each on the scaled system where that applies. */
 } mfem_solve_options;
 

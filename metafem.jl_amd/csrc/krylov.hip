@@ -644,6 +644,11 @@ extern "C" int mfem_debug_ws_trial_log(mfem_context ctx, double* out4) try {  //
   for (int i = 0; i < 4; ++i) out4[i] = ctx->ws_log[i];
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_ws_trial_log")
+static std::atomic<int64_t> g_cg_single_max_rows{20000000};  // rows per rank below which the auto choice with a communicator is the single-reduction CG (mfem_debug_set_cg_single_max_rows)
+extern "C" int mfem_debug_set_cg_single_max_rows(int64_t rows) {
+  g_cg_single_max_rows = rows;
+  return MFEM_OK;
+}
 static std::atomic<int> g_graphs{1};             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
 static std::atomic<int64_t> g_graph_max_n{4000000};  // above this size kernels are long enough that launch latency is hidden anyway
 extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) try {
@@ -699,8 +704,24 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   if (n == 0) return MFEM_OK;
   const int s_param = o->l_or_s > 0 ? o->l_or_s : (o->method == MFEM_SOLVER_IDRS ? 4 : 2);
   MFEM_REQUIRE(o->cg_variant >= 0 && o->cg_variant <= 4, "cg_variant must be 0 (auto), 1 (classic), 2 (single reduction), 3 (classic, preconditioned residual carried) or 4 (plain CG on the symmetrically scaled matrix)");
-  // one reduction group per CG iteration where a reduction costs an all-reduce; the classic recurrence otherwise
-  const bool cg_single = o->method == MFEM_SOLVER_CG && (o->cg_variant == 2 || (o->cg_variant == 0 && mfem_comm_world(ctx) > 1));
+  // rows of the whole system (one all-reduce per solve with a communicator: every rank must take the same decisions below)
+  int64_t n_global = n;
+  if (ctx->comm) {
+    ctx->h_scalars[S_TMP0] = (double)n;
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->d_scalars + S_TMP0, ctx->h_scalars + S_TMP0, sizeof(double), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    int rcg = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
+    if (!rcg) rcg = mfem_read_scalars(ctx, S_TMP0, 1);
+    if (rcg) return rcg;
+    n_global = (int64_t)(ctx->h_scalars[S_TMP0] + 0.5);
+  }
+  // One reduction group per CG iteration where a reduction costs an all-reduce -- as long as the all-reduce it saves (~30 us on a node) is worth more than
+  // the vector stream the single-reduction form adds (9 against 8: n * 8 B at ~5.3 TB/s).  Break-even near 2e7 rows per rank (round 4: design figures,
+  // no multi-GPU box): above it -- 512^3 per rank: 0.2 ms of stream against 0.03 ms of all-reduce per iteration -- the classic recurrence runs with a
+  // communicator too.  Decided on n_global / world: the same on every rank.
+  const int world_ranks = mfem_comm_world(ctx);
+  const bool cg_single = o->method == MFEM_SOLVER_CG &&
+                         (o->cg_variant == 2 || (o->cg_variant == 0 && world_ranks > 1 && n_global / world_ranks < g_cg_single_max_rows));
   MFEM_REQUIRE(s_param <= MFEM_MAX_S, "l_or_s too large");
   // x may carry ghost entries behind the owned rows (slab decomposition)
   const int64_t ghosts = ctx->comm ? 2 * ctx->halo_plane_len * ctx->halo_fields : 0;
@@ -936,17 +957,6 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
       mfem_set_error("sliced layout could not be bound for the fused Jacobi scaling");
       return MFEM_ERR_INVALID;
     }
-  }
-  int64_t n_global = n;
-  if (ctx->comm) {
-    ctx->h_scalars[S_TMP0] = (double)n;
-    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->d_scalars + S_TMP0, ctx->h_scalars + S_TMP0, sizeof(double), hipMemcpyHostToDevice,
-                                  ctx->stream));
-    rc = mfem_comm_allreduce(ctx, ctx->d_scalars + S_TMP0, 1);
-    if (rc) return rc;
-    rc = mfem_read_scalars(ctx, S_TMP0, 1);
-    if (rc) return rc;
-    n_global = (int64_t)(ctx->h_scalars[S_TMP0] + 0.5);
   }
   const double n_inv = 1.0 / (double)n_global;
 

@@ -187,6 +187,14 @@ def main():
         check(f"cg_single_reduction_one_rank_{tag}", sg2.converged == 1 and relerr(owned_t(xg2, owned, dev), xg) <= 1e-10,
               iters=(sg2.iterations, sg.iterations))
     _lib.lib.mfem_debug_set_halo_overlap(1)
+    # the auto choice of the CG form is size-dependent with a communicator (single reduction below 2e7 rows per rank, the classic recurrence -- one
+    # vector stream less, one all-reduce more -- above): force the large-system branch on this small problem
+    _lib.lib.mfem_debug_set_cg_single_max_rows(0)
+    xg, sg = gsolve(mf.cg_, cg_variant=1)
+    xa, sa = lsolve(mf.cg_)
+    _lib.lib.mfem_debug_set_cg_single_max_rows(20000000)
+    check("cg_auto_takes_the_classic_recurrence_on_large_systems", sa.converged == 1 and abs(sa.iterations - sg.iterations) <= 2 and relerr(xa, xg) <= 1e-10,
+          iters=(sa.iterations, sg.iterations), rel_err=relerr(xa, xg))
     if case == "thermal_hex8":
         check("symmetric_sweep_kernel_ran", int(_lib.lib.mfem_debug_sym_spmv_count()) > sym0)
     if case == "elasticity_hex8":  # the slab solves ran on the symmetric lattice tiles (mode 5: ghost planes staged, lower-ghost terms from the CSR values)
