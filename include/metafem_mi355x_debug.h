@@ -113,6 +113,9 @@ unsigned long long mfem_debug_ws_address(mfem_context ctx);
  * about as long; MFEM_WS_TRIAL_VERBOSE=1 prints the steps' times to stderr).  Rank-local: with a communicator attached every rank runs its own
  * trial (the candidates' timing uses no collective).  bench.py opts in with --ws-trial 1 and says so in its line. */
 int mfem_debug_set_ws_trial(int on);
+/* 1 (default): the two vector kernels of the classic CG recurrences use streaming (nontemporal) loads, and from 4e7 rows on streaming stores too
+ * (csrc/krylov.hip: cg_ld / cg_st); 0: plain accesses.  Same values either way. */
+int mfem_debug_set_cg_streaming(int on);
 /* cg_variant 0 (auto) with a communicator of more than one rank: the single-reduction CG (one all-reduce, 9 vector streams per iteration) below this many
  * rows per rank (n_global / world; default 2e7), the classic recurrence (two all-reduces, 8 streams) from there on -- at 512^3 per rank a vector stream
  * costs 0.2 ms, an all-reduce ~0.03 ms.  Set 0 for always-classic, a huge value for always-single. */

@@ -187,6 +187,7 @@ SIGNATURES = {
     "mfem_debug_set_ws_placement": (c_int, [C.c_longlong, C.c_longlong]),
     "mfem_debug_ws_address": (C.c_ulonglong, [P]),
     "mfem_debug_set_ws_trial": (c_int, [c_int]),
+    "mfem_debug_set_cg_streaming": (c_int, [c_int]),
     "mfem_debug_set_cg_single_max_rows": (c_int, [c_int64]),
     "mfem_debug_fail_host_alloc": (c_int, [c_int]),
     "mfem_debug_ws_trial_log": (c_int, [P, C.POINTER(C.c_double)]),

@@ -126,6 +126,28 @@ int mfem_read_flags(mfem_context_s* ctx) {
 // Jacobi-preconditioned CG (added solver; M = |diag K|).  Three kernels per iteration:
 //   SpMV (+ p.Ap partials) | x,r update (+ r.z, r.r partials) | p update (+ scalar bookkeeping)
 // ------------------------------------------------------------------------------------------
+// Streaming hints of the two CG vector kernels (round 4; tools/ab_libs.sh with tools/cg_per_solve.py on one box): NT = 2, nontemporal LOADS, is worth
+// 4.7 % of a CG iteration at 256^3 (0.758 -> 0.723 ms: the vectors of one iteration are within reach of the 256 MB Infinity Cache, plain stores keep p
+// there for the SpMV that reads it next); NT = 1, nontemporal loads AND stores, 1 - 2 % at 512^3 (5.58 -> 5.45-5.54 ms; NT = 2 there: + 0.6 %).  Chosen by
+// the vector length at the launch (cg_nt_mode); 0 = plain accesses (bit 0 of mfem_debug_set_cg_streaming off).
+template <int NT>
+__device__ __forceinline__ d2_t cg_ld(const d2_t* p, int64_t i) {
+  if constexpr (NT >= 1) return __builtin_nontemporal_load(p + i);
+  else return p[i];
+}
+template <int NT>
+__device__ __forceinline__ void cg_st(d2_t* p, int64_t i, d2_t v) {
+  if constexpr (NT == 1) __builtin_nontemporal_store(v, p + i);
+  else p[i] = v;
+}
+#define CG_LD(p, i) cg_ld<NT>((p), (i))
+#define CG_ST(p, i, v) cg_st<NT>((p), (i), (v))
+static std::atomic<int> g_cg_streaming{1};
+extern "C" int mfem_debug_set_cg_streaming(int on) {
+  ++mfem_debug_epoch;
+  g_cg_streaming = on ? 1 : 0;
+  return MFEM_OK;
+}
 struct CgArgs {
   int64_t n2;       // padded length / 2
   double n_inv;     // 1 / global n (for normalized_norm)
@@ -189,6 +211,7 @@ __device__ __forceinline__ double recip_nr(double d) {
 }
 
 // alpha = rz / p.Ap ; x += alpha p ; r -= alpha Ap ; partials2: [0,G) r.z  [G,2G) r.r   (z = r .* dinv)
+template <int NT>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, const double* __restrict__ pap_partials,
                                                             int np, const d2_t* __restrict__ Ap,
                                                             const d2_t* __restrict__ dinv,
@@ -203,7 +226,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double rz = 0.0, rr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
-    const d2_t av = Ap[i];  // x += alpha p happens in k_cg_pupdate, which reads p anyway (one vector stream less per iteration)
+    const d2_t av = CG_LD(Ap, i);  // x += alpha p happens in k_cg_pupdate, which reads p anyway (one vector stream less per iteration)
     d2_t rv, z;
     if (a.zrec && dinv) {  // the array holds z: z -= alpha dinv .* Ap ; r = z ./ dinv for the two dot products only
       d2_t dv = dinv[i];
@@ -214,8 +237,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
       rv.x = dv.x != 0.0 ? z.x * recip_nr(dv.x) : 0.0;
       rv.y = dv.y != 0.0 ? z.y * recip_nr(dv.y) : 0.0;
     } else {
-      rv = r[i] - alpha * av;
-      r[i] = rv;
+      rv = CG_LD(r, i) - alpha * av;
+      CG_ST(r, i, rv);
       z = dinv ? rv * dinv[i] : rv;
     }
     rz += rv.x * z.x + rv.y * z.y;
@@ -236,6 +259,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_update(CgArgs a, int cur, con
 
 // x += alpha p (the alpha of k_cg_update, recomputed from the same partials) ; beta = rz_new / rz_old ; p = z + beta p ;
 // workgroup 0 also advances the scalar state.  x gets this iteration's update even when the iteration turns out to be the last.
+template <int NT>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, const double* __restrict__ pap_partials, int np1,
                                                              const double* __restrict__ partials2, int np,
                                                              const d2_t* __restrict__ r, const d2_t* __restrict__ dinv,
@@ -265,10 +289,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_pupdate(CgArgs a, int cur, co
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (!done) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
-      const d2_t rv = r[i], pv = p[i];
-      x[i] = x[i] + alpha * pv;
+      const d2_t rv = CG_LD(r, i), pv = CG_LD(p, i);
+      CG_ST(x, i, CG_LD(x, i) + alpha * pv);
       const d2_t z = (dinv && !a.zrec) ? rv * dinv[i] : rv;
-      p[i] = z + beta * pv;
+      CG_ST(p, i, z + beta * pv);
     }
   } else {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) x[i] = x[i] + alpha * p[i];
@@ -331,6 +355,7 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   }
   MFEM_CHECK_LAUNCH();
   const int check = o->check_every > 0 ? o->check_every : 32;
+  const int nt = !g_cg_streaming ? 0 : (nv >= 40000000 ? 1 : 2);  // (see cg_ld / cg_st: loads only while a vector is within reach of the Infinity Cache)
   uint64_t key = mfem_hash(MFEM_HASH_SEED, (int)MFEM_SOLVER_CG);
   key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]); key = mfem_hash(key, V.x);
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
@@ -363,8 +388,10 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         if (rc) return rc;
         np1 = 0;
       }
-      hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1,
-                         (const d2_t*)Ap, (const d2_t*)dinv, (d2_t*)r, S, F, part2);
+#define CG_UPDATE(NT_) hipLaunchKernelGGL(k_cg_update<NT_>, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, \
+                                          (const d2_t*)Ap, (const d2_t*)dinv, (d2_t*)r, S, F, part2)
+      if (nt == 1) CG_UPDATE(1); else if (nt == 2) CG_UPDATE(2); else CG_UPDATE(0);
+#undef CG_UPDATE
       MFEM_CHECK_LAUNCH();
       if (ctx->comm) {
         rc = mfem_fold_list(ctx, FoldList{{part2, part2 + G}, {G, G}, 2}, S + S_TMP0, F);
@@ -373,8 +400,10 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         if (rc) return rc;
         np2 = 0;
       }
-      hipLaunchKernelGGL(k_cg_pupdate, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, part2, np2, (const d2_t*)r,
-                         (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F, Fn);
+#define CG_PUPDATE(NT_) hipLaunchKernelGGL(k_cg_pupdate<NT_>, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, np1, part2, np2, (const d2_t*)r, \
+                                           (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F, Fn)
+      if (nt == 1) CG_PUPDATE(1); else if (nt == 2) CG_PUPDATE(2); else CG_PUPDATE(0);
+#undef CG_PUPDATE
       MFEM_CHECK_LAUNCH();
       return MFEM_OK;
     };

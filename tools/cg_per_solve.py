@@ -4,6 +4,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metafem_jl_amd as mf
+from metafem_jl_amd import _lib
+_lib.lib.mfem_debug_set_ws_trial(1)  # (512^3: compare on the same kind of backing memory)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3, 4]
 brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N))
