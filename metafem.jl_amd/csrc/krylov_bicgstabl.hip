@@ -138,7 +138,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void kb_ulist(int64_t n2, VecList L, co
   const double beta = S[B_BETA];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride)
-    for (int t = 0; t < L.m; ++t) L.a[t][i] = L.b[t][i] - beta * L.a[t][i];
+    for (int t = 0; t < L.m; ++t) L.a[t][i] = KB_LD(L.b[t], i) - beta * KB_LD(L.a[t], i);
 }
 // R[i] -= alpha U[i+1], i < m ; x += alpha U[0]   (:55-61)
 __global__ __launch_bounds__(MFEM_BLOCK) void kb_rlist(int64_t n2, VecList L, const d2_t* __restrict__ U0, d2_t* __restrict__ x,
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void kb_rlist(int64_t n2, VecList L, co
   const double alpha = S[B_ALPHA];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
-    for (int t = 0; t < L.m; ++t) L.a[t][i] = L.a[t][i] - alpha * L.b[t][i];
-    x[i] = x[i] + alpha * U0[i];
+    for (int t = 0; t < L.m; ++t) L.a[t][i] = KB_LD(L.a[t], i) - alpha * KB_LD(L.b[t], i);
+    x[i] = KB_LD(x, i) + alpha * KB_LD(U0, i);
   }
 }
 // the MR part on the Gram matrix (:64-80) and the combined coefficients of the updates (:82-91)
@@ -230,18 +230,18 @@ __global__ __launch_bounds__(MFEM_BLOCK) void kb_final(int64_t n2, int64_t n_own
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double a_rr = 0.0, a_sr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
-    d2_t r0 = R0[i], u0 = U0[i];
-    d2_t xv = x[i] + ax[0] * r0;
+    d2_t r0 = KB_LD(R0, i), u0 = KB_LD(U0, i);
+    d2_t xv = KB_LD(x, i) + ax[0] * r0;
     for (int k = 1; k <= L.l; ++k) {
-      const d2_t rk = L.R[k][i];
+      const d2_t rk = KB_LD(L.R[k], i);
       xv += ax[k] * rk;
       r0 -= ar[k] * rk;
-      u0 -= au[k] * L.U[k][i];
+      u0 -= au[k] * KB_LD(L.U[k], i);
     }
     x[i] = xv;
     R0[i] = r0;
     U0[i] = u0;
-    const d2_t sh = shadow[i];
+    const d2_t sh = KB_LD(shadow, i);
     if (2 * i < n_owned) { a_rr += r0.x * r0.x; a_sr += sh.x * r0.x; }
     if (2 * i + 1 < n_owned) { a_rr += r0.y * r0.y; a_sr += sh.y * r0.y; }
   }

@@ -121,13 +121,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList
   const double omega = S[I_OMEGA];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
-    d2_t v = c[0] * L.G[0][i];
-    d2_t q = c[0] * L.U[0][i];
+    d2_t v = c[0] * KB_LD(L.G[0], i);
+    d2_t q = c[0] * KB_LD(L.U[0], i);
     for (int t = 1; t < L.m; ++t) {
-      v += c[t] * L.G[t][i];
-      q += c[t] * L.U[t][i];
+      v += c[t] * KB_LD(L.G[t], i);
+      q += c[t] * KB_LD(L.U[t], i);
     }
-    v = r[i] - v;
+    v = KB_LD(r, i) - v;
     Uk[i] = q + omega * v;
   }
 }
@@ -171,15 +171,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_update(int64_t n2, int64_t n_ow
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double acc = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
-    d2_t g = Gk[i], u = Uk[i];
+    d2_t g = KB_LD(Gk, i), u = KB_LD(Uk, i);
     for (int t = 0; t < L.m; ++t) {
-      g -= al[t] * L.G[t][i];
-      u -= al[t] * L.U[t][i];
+      g -= al[t] * KB_LD(L.G[t], i);
+      u -= al[t] * KB_LD(L.U[t], i);
     }
     Gk[i] = g;
     Uk[i] = u;
-    x[i] = x[i] + beta * u;
-    const d2_t rn = r[i] - beta * g;
+    x[i] = KB_LD(x, i) + beta * u;
+    const d2_t rn = KB_LD(r, i) - beta * g;
     r[i] = rn;
     if (2 * i < n_owned) acc += rn.x * rn.x;
     if (2 * i + 1 < n_owned) acc += rn.y * rn.y;
