@@ -518,12 +518,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cgcg_update(CgArgs a, const d2_t
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double ru = 0.0, rr = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n2; i += stride) {
-    const d2_t uv = u[i], wv = w[i];
-    const d2_t pv = first ? uv : uv + beta * p[i];
-    const d2_t sn = first ? wv : wv + beta * sv[i];
+    // (streaming loads: every vector is read once per iteration here -- see cg_ld)
+    const d2_t uv = __builtin_nontemporal_load(u + i), wv = __builtin_nontemporal_load(w + i);
+    const d2_t pv = first ? uv : uv + beta * __builtin_nontemporal_load(p + i);
+    const d2_t sn = first ? wv : wv + beta * __builtin_nontemporal_load(sv + i);
     p[i] = pv;
     sv[i] = sn;
-    x[i] = x[i] + alpha * pv;
+    x[i] = __builtin_nontemporal_load(x + i) + alpha * pv;
     d2_t rv, z;
     if (a.zrec && dinv) {  // u carries the recurrence (u -= alpha dinv .* s); r = u ./ dinv for the dot products only: r is neither read nor written
       d2_t dv = dinv[i];
