@@ -53,6 +53,7 @@ static std::atomic<int> g_symp_direct{1};  // bit 27: 0 = patch-major copy made 
 static std::atomic<int> g_symp_tail{1};    // bit 26: 0 = the rows outside the swept planes in a launch of their own (as in a split SpMV)
 static std::atomic<int> g_dia_symp{1};     // bit 23: the workgroup-tile sweep (k_spmv_sym27) instead of the wave-private patch sweep (k_spmv_symp)
 static std::atomic<int> g_dia_pipe{1};     // bit 28: 0 = the layout copy (k_dia_vals) without its software pipeline
+static std::atomic<int> g_dia_fast{1};     // bit 29: 0 = the layout copy without its fast path for full swept tiles (then pipelined as in bit 28)
 static std::atomic<int> g_dia_xcd{0};      // 1: each XCD walks a contiguous eighth of the rows (needs a grid that is a multiple of 8)
 // kernel variant (rows per lane x slots per batch, see the switch in mfem_spmv_ell_launch) and persistent workgroups per CU.
 // Measured inside CG at 256^3 (profiles/r01_spmv_sweep.txt): 2 rows x 1 slot, 6 or 8 workgroups per CU is the fastest;
@@ -70,6 +71,7 @@ extern "C" int mfem_debug_set_ell(int enable) try {  // bit 0: enable; bits 4-7:
   g_symp_tail = ((enable >> 26) & 1) ? 0 : 1;
   g_symp_direct = ((enable >> 27) & 1) ? 0 : 1;
   g_dia_pipe = ((enable >> 28) & 1) ? 0 : 1;
+  g_dia_fast = ((enable >> 29) & 1) ? 0 : 1;
   g_dia_block = ((enable >> 24) & 3) == 1 ? 512 : ((enable >> 24) & 3) == 2 ? 1024 : ((enable >> 24) & 3) == 3 ? 128 : MFEM_BLOCK;  // bit 20: XCD-contiguous chunks
   g_ell_variant = (enable >> 4) & 15;
   if ((enable >> 8) & 255) g_ell_grid_mult = (enable >> 8) & 255;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
                                                            int base, const DiaOffsets* __restrict__ Op,
                                                            const int32_t* __restrict__ flags, double* __restrict__ out, SympGeom Gm,
                                                            double* __restrict__ pv, const double* __restrict__ dsc,
-                                                           const double* __restrict__ ssym) {
+                                                           const double* __restrict__ ssym, int fast) {
   // ssym != nullptr: the copy is S^-1 A S^-1 with ssym = 1 / S, entry * (ssym[row] * ssym[column]) with the PRODUCT of the two factors formed
   // first -- a mirrored pair is then multiplied by the same number, so a bitwise symmetric matrix stays bitwise symmetric (the scaled CG,
   // cg_variant 4).  (Multiplying by reciprocals, not dividing: 27 divisions per row cost more than the rest of the placement.)
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
   // bytes of staging per wave: two waves per CU on 81-entry rows (4.0 ms per bind at C3 against 3.4 ms with two lanes); on 27-entry
   // rows six waves per CU are enough and the lane per row is faster (2.4 against 2.7 ms at 256^3).
   constexpr int RT = 64 / LPR, SH = LPR == 2 ? 5 : 6;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;  // (w: wave-uniform, known to the compiler)
   const int half = LPR == 2 ? lane >> 5 : 0, rl = lane & (RT - 1);
   double* T = lds + (size_t)w * RT * K;
   // columns are staged only for the Jacobi scaling pass (dsc); the placement below needs them for the few tiles that are not `full`
@@ -368,6 +370,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
   }
   for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += tstride) {
     const int64_t r0 = tile << SH, r = r0 + rl;
+    // fast != 0: the swept rows are filled by k_symp_fill (below) -- this launch visits only the tiles that hold other rows and leaves the swept rows of
+    // those tiles alone
+    if (fast && r0 >= slo && r0 + RT <= shi) continue;
     const int64_t rend = (r0 + RT < n) ? r0 + RT : n;
     int64_t lo = 0;
     int len = 0;
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
     auto colat = [&](int j) -> int64_t { return stage_cols ? (int64_t)Tc[off0 + j] : (int64_t)col[lo + j] - base; };
     if (cls >= 0 && r0 < shi && r0 + RT > slo) {  // a tile with swept rows (all of them in regular blocks of the 27-diagonal lattice class)
       const bool sw = r >= slo && r < shi;
+      if (fast && sw) len = 0;  // (k_symp_fill's row: nothing is stored for it below)
       int line = 0, pcol = 0;
       int64_t mainoff = 0, lowoff = 0, edgeoff = 0;
       if (sw) {
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
         if (!act) continue;
         if (!sw) {
           DIA_ST(out + ell_base(r, K) + sl * ELL_B, v);
-        } else {
+        } else if (!fast) {
           DIA_ST(pv + (sl < 13 ? lowoff + sl * SP_ROWS : mainoff + (sl - 13) * SP_ROWS), v);
           if (sl == 13) out[ell_base(r, K) + 13 * ELL_B] = v;  // the diagonal (offset 0 is the 14th of the 27 lattice offsets)
           if (half == 0 && t < 13) {                           // the edge block entry the row owns for this lower slot, if any
@@ -516,6 +522,162 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
       for (int sl = half; sl < K; sl += LPR) out[ell_base(r, K) + sl * ELL_B] = sl < len ? sym_scaled(T[off0 + sl], colat(sl)) : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// The swept rows of the patch-major copy: a workgroup of two waves per patch step (plane, strip of SP_L lines, patch column), a wave per pair of lattice lines,
+// lane = line * SP_W + column -- 64 rows whose CSR values are two contiguous runs (one per line: 6.9 KB when all 32 rows have their 27 entries).  Every slot store of
+// a wave is ONE aligned 512-byte piece of the copy and the two halves of each 1 KB slot are written by the same workgroup; the step's edge block (318 entries owned by
+// rows of both waves) is gathered in LDS and written as one contiguous piece.  (k_dia_vals' tiles of 64 consecutive rows drift against the patch columns -- a
+// 513-point line is 16 patches + 1 point -- and wrote two or three unaligned pieces per slot and the edge entries one by one; tools/copy_probe.hip, 512^3, all stores:
+// 14.8 ms in that shape, 10.7 ms in this one; a plain aligned copy of the same bytes 9.4 ms.)  Two memory round trips per full tile -- the four row pointers of the
+// runs (scalar loads), then the 27 values + the 27 factors of the symmetric scaling per lane, all issued before the first wait; tiles with short rows (lattice edge)
+// or missing lines / columns take the general path: per-lane row pointers, masked staging, the short rows' columns decoded into slots (offset = di PL + dj m2 + dk,
+// guaranteed by the class test in mfem_ell_plan) and every row expanded to its 27 slots in LDS.
+template <typename RP, bool SYM>
+__global__ __launch_bounds__(128) void k_symp_fill(int64_t n, int K, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    const double* __restrict__ vals, int base, const DiaOffsets* __restrict__ Op, int cls,
+                                                    double* __restrict__ out, SympGeom Gm, double* __restrict__ pv, const double* __restrict__ ssym) {
+  const DiaOffsets& O = *Op;
+  extern __shared__ double lds[];
+  constexpr int RUN = SP_W * 27;  // entries of a full 32-row run
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (launched with two waves per workgroup)
+  double* T = lds + (size_t)w * (2 * RUN);
+  double* E = lds + 2 * (2 * RUN);  // the step's edge block (SP_EPAD entries; zero between steps: entries of rows outside the lattice and the padding stay 0)
+  const int spNP = Gm.NS * Gm.NPk;
+  const int64_t spT = (int64_t)spNP * (Gm.p1 - Gm.p0);
+  const int h = lane >> 5, c = lane & (SP_W - 1);
+  const int32_t PL = (int32_t)Gm.PL, m2 = Gm.m2;
+  auto uni64 = [](int64_t x) -> int64_t {  // (the same value in every lane: into scalar registers, so that what depends on it stays scalar)
+    const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)x), xh = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)xh << 32) | xl);
+  };
+  for (int i = threadIdx.x; i < SP_EPAD; i += 128) E[i] = 0.0;
+  __syncthreads();
+  for (int64_t step = blockIdx.x; step < spT; step += gridDim.x) {  // (every barrier below is reached by both waves: the trip count is the workgroup's)
+    const int kp = (int)(step % Gm.NPk);
+    const int64_t q = step / Gm.NPk;
+    const int strip = (int)(q % Gm.NS), pl = (int)(q / Gm.NS);
+    const int jj0 = strip * SP_L + 2 * w, kk0 = kp * SP_W;
+    const int ncol = m2 - kk0 < SP_W ? m2 - kk0 : SP_W, nlines = Gm.m1 - jj0 < 2 ? (Gm.m1 - jj0 < 1 ? 0 : 1) : 2;  // (the last strip may end before this wave's lines)
+    const int64_t rb = (int64_t)(Gm.p0 + pl) * Gm.PL + (int64_t)jj0 * m2 + kk0;  // lane 0's row
+    const int64_t rB = nlines == 2 ? rb + m2 : rb;                              // lane 32's row (no second line: the first again, nothing of it is used)
+    int64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (nlines > 0) {
+      a0 = uni64((int64_t)rowptr[rb]) - base, a1 = uni64((int64_t)rowptr[rb + ncol]) - base;
+      b0 = uni64((int64_t)rowptr[rB]) - base, b1 = uni64((int64_t)rowptr[rB + ncol]) - base;
+    }
+    const bool full = ncol == SP_W && nlines == 2 && a1 - a0 == RUN && b1 - b0 == RUN;
+    const bool valid = c < ncol && h < nlines;
+    const int64_t r = rb + (int64_t)h * m2 + c;
+    const int line = 2 * w + h;
+    double* const pm = pv + step * SP_MAIN + line * SP_W + c;
+    double* const plo = pv + spT * SP_MAIN + step * SP_LOW + line * SP_W + c;
+    double* const pe = pv + step * SP_MAIN + 14 * SP_ROWS;
+    const double* Tr = T + lane * 27;
+    double sc[27];
+    double srow = 1.0;
+    uint32_t present = 0x7FFFFFFu;
+    if (full) {
+      double tv[27];
+      const double* vA = vals + a0 + lane;
+      const double* vB = vals + b0 + lane - RUN;
+      const double* v13 = h ? vB : vA;  // entries 832 .. 895 of the tile: the first run ends at 864
+#pragma unroll
+      for (int u = 0; u < 27; ++u) tv[u] = __builtin_nontemporal_load((u < 13 ? vA : u == 13 ? v13 : vB) + 64 * u);
+      if constexpr (SYM) {
+        srow = ssym[r];
+#pragma unroll
+        for (int u = 0; u < 27; ++u) sc[u] = ssym[r + O.off[cls][u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 27; ++u) T[lane + 64 * u] = tv[u];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      int64_t lo = 0;
+      int len = 0;
+      if (valid) {
+        lo = (int64_t)rowptr[r] - base;
+        len = (int)((int64_t)rowptr[r + 1] - base - lo);
+      }
+      const int cntA = (int)(a1 - a0), cntB = nlines == 2 ? (int)(b1 - b0) : 0;  // <= RUN each (regular blocks: at most 27 entries per row)
+      {
+        double ta[14], tb[14];
+#pragma unroll
+        for (int u = 0; u < 14; ++u) {
+          const int i = lane + 64 * u;
+          ta[u] = i < cntA ? __builtin_nontemporal_load(vals + a0 + i) : 0.0;
+          tb[u] = i < cntB ? __builtin_nontemporal_load(vals + b0 + i) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 14; ++u) {
+          const int i = lane + 64 * u;
+          if (i < cntA) T[i] = ta[u];
+          if (i < cntB) T[RUN + i] = tb[u];
+        }
+      }
+      // the columns of the short rows (their entries are decoded into slots below; a row of 27 entries has entry s in slot s)
+      int32_t cj[27];
+      const bool shortrow = valid && len < 27;
+#pragma unroll
+      for (int j = 0; j < 27; ++j) cj[j] = (shortrow && j < len) ? col[lo + j] - base : 0;
+      __builtin_amdgcn_wave_barrier();
+      const int off0 = h * RUN + (int)(lo - (h ? b0 : a0));
+      double ev[27];
+#pragma unroll
+      for (int j = 0; j < 27; ++j) ev[j] = j < len ? T[off0 + j] : 0.0;
+      __builtin_amdgcn_wave_barrier();  // every lane holds its entries: the staging area may now be overwritten by the expanded rows
+      present = 0;
+      if (shortrow) {
+#pragma unroll
+        for (int sl = 0; sl < 27; ++sl) T[lane * 27 + sl] = 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 27; ++j) {
+        if (j < len) {
+          int sl = j;
+          if (shortrow) {
+            const int32_t d = cj[j] - (int32_t)r;
+            const int di = (2 * d > PL) - (2 * d < -PL);
+            const int32_t d1 = d - di * PL;
+            const int dj = (2 * d1 > m2) - (2 * d1 < -m2);
+            sl = 9 * (di + 1) + 3 * (dj + 1) + (d1 - dj * m2 + 1);
+          }
+          T[lane * 27 + sl] = ev[j];
+          present |= 1u << sl;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (SYM) {
+        srow = valid ? ssym[r] : 1.0;
+#pragma unroll
+        for (int u = 0; u < 27; ++u) sc[u] = valid ? ssym[r + O.off[cls][u]] : 1.0;
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int sl = 0; sl < 27; ++sl) {
+        double v = 0.0;
+        if (present >> sl & 1u) {
+          v = Tr[sl];
+          if constexpr (SYM) v = v * (srow * sc[sl]);  // (the product of the two factors first: a mirrored pair is multiplied by the same number)
+        }
+        if (sl < 13) {
+          DIA_ST(plo + sl * SP_ROWS, v);
+          const int e = sp_edge_of(sl, line, c);
+          if (e >= 0) E[e] = v;
+        } else {
+          DIA_ST(pm + (sl - 13) * SP_ROWS, v);
+          if (sl == 13) DIA_ST(out + ell_base(r, K) + 13 * ELL_B, v);  // the diagonal also to the slot-major copy (k_ell_diag reads it there)
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SP_EPAD; i += 128) {
+      DIA_ST(pe + i, E[i]);
+      E[i] = 0.0;
+    }
+    __syncthreads();
   }
 }
 
@@ -1508,10 +1670,13 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
     auto dia_vals = [&](const SympGeom& G, double* pvals) -> int {
 #define DV_LAUNCH_(RP, LPR_, SYM_, PIPE_)                                                                                                  \
   hipLaunchKernelGGL((k_dia_vals<RP, LPR_, SYM_, PIPE_>), dim3(g), dim3(64 * wv), ldsb, ctx->stream, A->n, A->ell_npad, A->ell_K, (const RP*)A->rowptr, \
-                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc, ssym)
+                     A->colidx, vals, A->index_base, O, A->dia_flags, buf, G, pvals, dsc, ssym, fast ? 1 : 0)
 #define DV_LAUNCH(RP, LPR_, PIPE_) do { if (ssym) DV_LAUNCH_(RP, LPR_, true, PIPE_); else DV_LAUNCH_(RP, LPR_, false, PIPE_); } while (0)
       // (the software-pipelined staging: a lane per row, rows of at most 28 entries, no scaling pass; bit 28 of mfem_debug_set_ell turns it off)
-      const bool pipe = lpr == 1 && !dsc && A->ell_K <= 28 && g_dia_pipe;
+      // the swept rows by k_symp_fill (patch-aligned tiles): a patch-major copy to fill, no column scaling pass, 32-bit row arithmetic, lattice lines and
+      // planes long enough for its column decoding
+      const bool fast = lpr == 1 && !dsc && pvals && A->n < ((int64_t)1 << 31) && G.PL < ((int64_t)1 << 30) && G.m1 >= 3 && G.m2 >= 3 && g_dia_fast;
+      const bool pipe = lpr == 1 && !dsc && A->ell_K <= 28 && g_dia_pipe && !fast;
       if (A->rowptr_bits == 64) {
         if (lpr == 2) DV_LAUNCH(int64_t, 2, false); else if (pipe) DV_LAUNCH(int64_t, 1, true); else DV_LAUNCH(int64_t, 1, false);
       } else {
@@ -1520,6 +1685,19 @@ int mfem_ell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double
 #undef DV_LAUNCH_
 #undef DV_LAUNCH
       MFEM_CHECK_LAUNCH();
+      if (fast) {
+        const int64_t ft = (int64_t)(G.p1 - G.p0) * G.NS * G.NPk;  // patch steps, one workgroup of two waves each
+        int gf = (int)(ft < (int64_t)ctx->num_cus * 20 ? ft : (int64_t)ctx->num_cus * 20);  // (5 workgroups are resident per CU: four rounds)
+        if (gf < 1) gf = 1;
+        const size_t lf = sizeof(double) * (2 * (2 * SP_W * 27) + SP_EPAD);
+#define SF_LAUNCH(RP, SYM_)                                                                                                                   \
+  hipLaunchKernelGGL((k_symp_fill<RP, SYM_>), dim3(gf), dim3(128), lf, ctx->stream, A->n, A->ell_K, (const RP*)A->rowptr, A->colidx, vals, A->index_base, O, \
+                     A->sym_cls, buf, G, pvals, ssym)
+        if (A->rowptr_bits == 64) { if (ssym) SF_LAUNCH(int64_t, true); else SF_LAUNCH(int64_t, false); }
+        else { if (ssym) SF_LAUNCH(int32_t, true); else SF_LAUNCH(int32_t, false); }
+#undef SF_LAUNCH
+        MFEM_CHECK_LAUNCH();
+      }
       return MFEM_OK;
     };
     const bool sweep = symp_wanted(A), direct = sweep && g_symp_direct && (g_dia_variant == 0 || g_dia_variant == 7);  // (the other variants read all rows from the slot-major copy)

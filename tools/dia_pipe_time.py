@@ -1,4 +1,5 @@
-"""Per-solve work of CG (layout copy k_dia_vals + checks) with and without the software pipeline of the copy (bit 28 of mfem_debug_set_ell), at N^3:
+"""Per-solve work of CG (layout copy k_dia_vals + checks) with the copy's fast path for full swept tiles (default), without it (bit 29 of mfem_debug_set_ell:
+the software-pipelined general path) and without either (bits 28 + 29), at N^3:
 two fixed-iteration solves (16 and 116 iterations), best of 3 -> per-solve work = t16 - 16 * per-iteration.  usage: dia_pipe_time.py N [N ...]"""
 import os, sys
 import torch
@@ -18,13 +19,13 @@ for N in [int(a) for a in sys.argv[1:]] or [256]:
         return t, x
     for var in (3, 4):
         xs = {}
-        for knob, tag in ((0, "pipelined"), (1 << 28, "plain"), (0, "pipelined"), (1 << 28, "plain")):
+        for knob, tag in ((0, "fast"), (1 << 29, "pipelined"), (3 << 28, "plain"), (0, "fast"), (1 << 29, "pipelined")):
             _lib.lib.mfem_debug_set_ell(1 | knob)
             (t0, x), (t1, _) = best(16, var), best(116, var)
             per = (t1 - t0) / 100
             xs.setdefault(tag, x)
             print(f"N {N} cg_variant {var} copy {tag:9s}: per iteration {per:.4f} ms, per-solve work {t0 - 16 * per:.3f} ms", flush=True)
         _lib.lib.mfem_debug_set_ell(1)
-        print(f"N {N} cg_variant {var}: solutions bitwise equal: {bool(torch.equal(xs['pipelined'], xs['plain']))}", flush=True)
+        print(f"N {N} cg_variant {var}: solutions bitwise equal: {bool(torch.equal(xs['fast'], xs['plain']) and torch.equal(xs['fast'], xs['pipelined']))}", flush=True)
     del brick, A, K, b
     torch.cuda.empty_cache()
