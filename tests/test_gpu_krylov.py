@@ -697,3 +697,43 @@ def test_bicgstabl_fused_form_equals_the_literal_sequence(mf, l):
     assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-11 * float(out[1][0].abs().max())
     assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-8 * float(out[1][1].abs().max())
     assert abs(out[0][2] - out[1][2]) <= max(2 * l, out[1][2] // 10)
+
+
+@pytest.mark.parametrize("elems", [(20, 12, 96), (20, 14, 63), (40, 30, 24), (40, 13, 40), (40, 17, 33)])
+def test_patch_aligned_fill_is_bitwise_the_row_tile_copy(mf, elems):
+    """The per-solve patch-major copy of the swept rows is made by k_symp_fill (a workgroup per patch step: aligned slot pieces, the edge block through LDS,
+    short rows decoded from their columns); k_dia_vals' row tiles (bit 29 of mfem_debug_set_ell) and the two-pass bind (bit 27) must give the same copy:
+    the sweep's y bit for bit, and the scaled CG (cg_variant 4: the S^-1 A S^-1 copy) the same iterates -- on lattices whose lines are odd, shorter than a
+    patch, one point longer than whole patches, and whose last strip has 1, 2 or 3 lines (lattice = elements + 1 per direction)."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick = mf.make_Brick((1.0, 0.7, 1.3), elems)
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    x = mf.FEM_rand(A.n, 5, 0) - 0.5
+    b = torch.ones(A.n, dtype=torch.float64, device="cuda")
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        ent, sym = C.c_int64(), C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout_entries(brick.ctx._h, A._h, C.byref(ent), C.byref(sym)))
+        assert sym.value == 2  # (the patch sweep is what runs)
+        ys, xs = [], []
+        for knob in (0, 1 << 29, 3 << 28, 1 << 27):
+            _lib.lib.mfem_debug_set_ell(1 | knob)
+            y = torch.full((A.n,), 3.0, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+            ys.append(y)
+            xx, st = mf.iterative_Solve(A, K, b, 1e-30, Sv_func=mf.cg_, maxiter=12, max_pass=1, fixed_iterations=True, cg_variant=4)
+            xs.append(xx)
+        assert all(torch.equal(ys[0], yy) for yy in ys[1:])
+        assert all(torch.equal(xs[0], xx) for xx in xs[1:])
+        yc = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+        _lib.lib.mfem_debug_set_ell(0)
+        mf.mul_(yc, A, K, x)  # CSR kernel
+        assert float((yc - ys[0]).abs().max()) <= 1e-13 * float(yc.abs().max())
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
