@@ -26,6 +26,8 @@ struct Hex27Tables {        // device-global, filled once per ng
   double N[H27_MAXQ][27];
   double w[H27_MAXQ];
   double tab1[2][4][4];       // 1-D Lagrange-2 values (k = 0) and derivatives (k = 1) at the ng Gauss points: [k][q][a], rows padded to 4
+  double T1[4][3][4];         // affine elements: 1-D integrals over the ng Gauss points, [X][a][b] (rows padded to 4): X = 0: sum w l'_a l'_b, 1: sum w l_a l_b,
+                              // 2: sum w l'_a l_b, 3: sum w l_a l'_b -- the reference integrals of Ke are products of three of them (tensor-product basis and quadrature)
   // face tables: 2-D Lagrange-2 on [0,1]^2 at ng x ng Gauss points, c = c1 + 3*c2
   double fN[16][9];
   double fdN[16][9][2];
@@ -95,6 +97,19 @@ static int hex27_upload_tables(int ng) {
         h->fdN[q][c][0] = d1[c1] * L2[c2];
         h->fdN[q][c][1] = L1[c1] * d2[c2];
       }
+    }
+  for (int a = 0; a < 3; ++a)  // 1-D integrals of the affine-element path, with THIS quadrature (what the general path sums on an element with a constant Jacobian)
+    for (int b2 = 0; b2 < 3; ++b2) {
+      double dd = 0.0, mm = 0.0, cc = 0.0, ct = 0.0;
+      for (int q = 0; q < ng; ++q) {
+        const double* L = h->tab1[0][q];
+        const double* dL = h->tab1[1][q];
+        dd += gw[q] * dL[a] * dL[b2];
+        mm += gw[q] * L[a] * L[b2];
+        cc += gw[q] * dL[a] * L[b2];
+        ct += gw[q] * L[a] * dL[b2];
+      }
+      h->T1[0][a][b2] = dd; h->T1[1][a][b2] = mm; h->T1[2][a][b2] = cc; h->T1[3][a][b2] = ct;
     }
   if (!g_tab) MFEM_CHECK_HIP(hipMalloc(&g_tab, sizeof(Hex27Tables)));
   MFEM_CHECK_HIP(hipMemcpy(g_tab, h, sizeof(Hex27Tables), hipMemcpyHostToDevice));
@@ -731,6 +746,187 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather_lds(BrickView B, co
   }
 }
 
+// ---- Affine meshes (round 4): the matrix without Ke ever being stored.  On an element whose 27 nodes are an affine image of the reference nodes the Jacobian is
+// one matrix and Ke = sum_t G0_t S_t -- six numbers per element (G0 = -k adj(J) adj(J)^T / det, as in k_hex27's affine branch) times six 27 x 27 reference
+// integrals (products of the 1-D integrals Hex27Tables::T1, summed with the same quadrature).  When EVERY element of the launch is affine (each make_Brick mesh until a caller moves coordinates;
+// tested per assembly on the coordinates themselves, k_hex27_affine_g0), the row-owner gather below computes each (row, element) run from G0 and the table instead of
+// reading it from the element-major scratch: no pass 1, no 12.2 GB scratch written and read back (128^3: 10.5 -> 3 ms for the matrix).  Any non-affine element sends
+// the whole assembly through the two-pass MFMA path above.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_affine_g0(BrickView B, double kcond, int elo, int ecnt, double* __restrict__ g,
+                                                                int32_t* __restrict__ nonaffine) {
+  const int64_t nel = (int64_t)ecnt * B.ne1 * B.ne2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nel) return;
+  const int K = (int)(idx % B.ne2), J = (int)((idx / B.ne2) % B.ne1), I = elo + (int)(idx / ((int64_t)B.ne1 * B.ne2));
+  auto node = [&](int a, double& x, double& y, double& z) {
+    const int64_t c = brick_cindex(B, 2 * I + a % 3, 2 * J + (a / 3) % 3, 2 * K + a / 9);
+    x = B.X0[c]; y = B.X1[c]; z = B.X2[c];
+  };
+  double x0, y0, z0, ex0, ey0, ez0, ex1, ey1, ez1, ex2, ey2, ez2;
+  node(0, x0, y0, z0);
+  node(2, ex0, ey0, ez0);
+  node(6, ex1, ey1, ez1);
+  node(18, ex2, ey2, ez2);
+  ex0 -= x0; ey0 -= y0; ez0 -= z0; ex1 -= x0; ey1 -= y0; ez1 -= z0; ex2 -= x0; ey2 -= y0; ez2 -= z0;
+  const double tol = 3.6e-15;  // (the test of k_hex27: 16 ulp of the coordinates' magnitude, per component)
+  const double tx = tol * (fabs(x0) + fabs(ex0) + fabs(ex1) + fabs(ex2)), ty = tol * (fabs(y0) + fabs(ey0) + fabs(ey1) + fabs(ey2)),
+               tz = tol * (fabs(z0) + fabs(ez0) + fabs(ez1) + fabs(ez2));
+  bool affine = true;
+  for (int a = 0; a < 27; ++a) {
+    double mx, my, mz;
+    node(a, mx, my, mz);
+    const double a0 = 0.5 * (a % 3), a1 = 0.5 * ((a / 3) % 3), a2 = 0.5 * (a / 9);
+    const double px = x0 + a0 * ex0 + a1 * ex1 + a2 * ex2, py = y0 + a0 * ey0 + a1 * ey1 + a2 * ey2, pz = z0 + a0 * ez0 + a1 * ez1 + a2 * ez2;
+    affine = affine && fabs(mx - px) <= tx && fabs(my - py) <= ty && fabs(mz - pz) <= tz;
+  }
+  double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0;
+  if (affine) {
+    const double j00 = ex0, j01 = ex1, j02 = ex2, j10 = ey0, j11 = ey1, j12 = ey2, j20 = ez0, j21 = ez1, j22 = ez2;
+    const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+    const double c00 = j11 * j22 - j12 * j21, c01 = j02 * j21 - j01 * j22, c02 = j01 * j12 - j11 * j02;
+    const double c10 = j12 * j20 - j22 * j10, c11 = j00 * j22 - j02 * j20, c12 = j02 * j10 - j00 * j12;
+    const double c20 = j10 * j21 - j11 * j20, c21 = j01 * j20 - j21 * j00, c22 = j00 * j11 - j10 * j01;
+    const double sc0 = -kcond / det;
+    g0 = sc0 * (c00 * c00 + c01 * c01 + c02 * c02); g1 = sc0 * (c00 * c10 + c01 * c11 + c02 * c12);
+    g2 = sc0 * (c00 * c20 + c01 * c21 + c02 * c22); g3 = sc0 * (c10 * c10 + c11 * c11 + c12 * c12);
+    g4 = sc0 * (c10 * c20 + c11 * c21 + c12 * c22); g5 = sc0 * (c20 * c20 + c21 * c21 + c22 * c22);
+  } else {
+    atomicAdd(nonaffine, 1);
+  }
+  double* ge = g + idx * 6;
+  ge[0] = g0; ge[1] = g1; ge[2] = g2; ge[3] = g3; ge[4] = g4; ge[5] = g5;
+}
+
+// The row-owner gather of k_hex27_gather_lds with the runs computed in place.  A wave owns 8 consecutive control points per trip; thread (row, e) takes the row's
+// e-th candidate element (3.4 of 8 exist on average) and computes ITS 27-entry run Ke_e[la][0..26] from registers: G0 (6 numbers) and the twelve
+// 3-entry rows of the 1-D integrals that belong to its local node la = (a0, a1, a2) -- the reference integrals factor per direction,
+//   Ke[la][lb] = M2 P + D2 Q + Ct2 R + C2 T,  P = g0 D0 M1 + g1 (C0 Ct1 + Ct0 C1) + g3 M0 D1,  Q = g5 M0 M1,  R = g2 C0 M1 + g4 C1 M0,  T = g2 Ct0 M1 + g4 Ct1 M0
+// (X_d = the 1-D integral X at (a_d, b_d); D = l'l', M = ll, C = l'l, Ct = ll') -- and adds it into the row's box in LDS (ds_add_f64: the threads of one instruction hold
+// different (row, element) pairs and the same local node b, i.e. different entries).  36 LDS reads + 27 additions per run; a first version with one lane per entry
+// and the 27 x 27 x 6 table in LDS (12 reads per entry) was bound by LDS bandwidth at 6.5 ms (128^3).  The additions into one entry come in program order: the
+// result is reproducible (and differs from the two-pass path's in the last bits: another summation order).
+#define D27_WAVES 8
+#define D27_NODES (8 * D27_WAVES)
+#define D27_THREADS (64 * D27_WAVES)
+#define D27_TAB 1024  // lattice planes + lines + points whose row-box tables (lo, c, P per direction) are kept in LDS (16 bytes each); beyond: read from memory
+#define D27_LDS_BYTES (sizeof(double) * (48 + D27_NODES * G27_ROW + D27_TAB) + sizeof(int32_t) * (2 * D27_TAB))
+__global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, const Hex27Tables* __restrict__ tab, const double* __restrict__ g,
+                                                              double* __restrict__ vals, int64_t row_lo, int64_t row_hi, int elo) {
+  extern __shared__ double lds[];
+  double* sT = lds;                          // [4][3][4]
+  double* rows = sT + 48;                    // [D27_NODES][G27_ROW]
+  int64_t* t_P = reinterpret_cast<int64_t*>(rows + D27_NODES * G27_ROW);  // [D27_TAB]: P0 | P1 | P2
+  int32_t* t_lo = reinterpret_cast<int32_t*>(t_P + D27_TAB);              // [D27_TAB]: lo0 | lo1 | lo2
+  int32_t* t_c = t_lo + D27_TAB;             // [D27_TAB]: c0 | c1 | c2
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 48) sT[tid] = (&tab->T1[0][0][0])[tid];
+  // the row-box tables: phase A below looks a control point's box up per direction (a chain of dependent loads when they come from memory)
+  const bool tabs = B.m0 + B.m1 + B.m2 <= D27_TAB;
+  const int32_t *lo0 = B.lo0, *lo1 = B.lo1, *lo2 = B.lo2, *c0 = B.c0, *c1p = B.c1, *c2p = B.c2;
+  const int64_t *P0 = B.P0, *P1 = B.P1, *P2 = B.P2;
+  if (tabs) {
+    for (int i = tid; i < B.m0; i += D27_THREADS) { t_lo[i] = B.lo0[i]; t_c[i] = B.c0[i]; t_P[i] = B.P0[i]; }
+    for (int i = tid; i < B.m1; i += D27_THREADS) { t_lo[B.m0 + i] = B.lo1[i]; t_c[B.m0 + i] = B.c1[i]; t_P[B.m0 + i] = B.P1[i]; }
+    for (int i = tid; i < B.m2; i += D27_THREADS) { t_lo[B.m0 + B.m1 + i] = B.lo2[i]; t_c[B.m0 + B.m1 + i] = B.c2[i]; t_P[B.m0 + B.m1 + i] = B.P2[i]; }
+    lo0 = t_lo; lo1 = t_lo + B.m0; lo2 = t_lo + B.m0 + B.m1;
+    c0 = t_c; c1p = t_c + B.m0; c2p = t_c + B.m0 + B.m1;
+    P0 = t_P; P1 = t_P + B.m0; P2 = t_P + B.m0 + B.m1;
+  }
+  __syncthreads();  // (the only workgroup barrier: from here on the waves never exchange data)
+  const int64_t nblk = (row_hi - row_lo + D27_NODES - 1) / D27_NODES;
+  // Phase A of a block, per thread (row nl = tid / 8, candidate element e = tid % 8): the row's box, the element, its G0 -- in registers
+  struct PairPre {
+    int64_t pre;
+    int32_t len, c1, c2, la, b0;
+    bool valid;
+    double g[6];
+  };
+  auto phase_a = [&](int64_t blk) -> PairPre {
+    PairPre P{0, 0, 1, 1, 0, 0, false, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+    const int nl = tid >> 3, e = tid & 7;
+    const int64_t row = row_lo + blk * D27_NODES + nl;
+    if (row >= row_hi) return P;
+    const uint32_t r32 = (uint32_t)row, pl = (uint32_t)B.plane_len, m2 = (uint32_t)B.m2;  // control-point ids fit int32
+    const uint32_t q0 = r32 / pl, rem = r32 - q0 * pl, q1 = rem / m2;
+    const int gg[3] = {(int)q0 + B.plo, (int)q1, (int)(rem - q1 * m2)};
+    const int l0 = lo0[gg[0]], l1 = lo1[gg[1]], l2 = lo2[gg[2]];
+    P.c1 = c1p[gg[1]];
+    P.c2 = c2p[gg[2]];
+    const int cc0 = c0[gg[0]];
+    P.pre = (P0[gg[0]] - B.Pplo) * B.S1 * B.S2 + (int64_t)cc0 * (P1[gg[1]] * B.S2 + (int64_t)P.c1 * P2[gg[2]]);  // (brick_prefix)
+    P.len = cc0 * P.c1 * P.c2;
+    const int ed[3] = {e & 1, (e >> 1) & 1, e >> 2};
+    const int ne[3] = {B.ne0, B.ne1, B.ne2};
+    int E[3];
+    bool valid = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (gg[d] & 1) {
+        E[d] = (gg[d] - 1) >> 1;
+        valid = valid && ed[d] == 0;
+      } else {
+        E[d] = (gg[d] >> 1) - 1 + ed[d];
+      }
+      valid = valid && E[d] >= 0 && E[d] < ne[d];
+    }
+    P.valid = valid;
+    P.la = valid ? (gg[0] - 2 * E[0]) + 3 * (gg[1] - 2 * E[1]) + 9 * (gg[2] - 2 * E[2]) : 0;
+    P.b0 = nl * G27_ROW + ((2 * E[0] - l0) * P.c1 + (2 * E[1] - l1)) * P.c2 + (2 * E[2] - l2);  // the element's first node in the row's box
+    if (valid) {
+      const double* ge = g + (((int64_t)(E[0] - elo) * ne[1] + E[1]) * ne[2] + E[2]) * 6;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) P.g[t] = ge[t];
+    }
+    return P;
+  };
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    for (int t = lane; t < 8 * G27_ROW; t += 64) rows[wv * 8 * G27_ROW + t] = 0.0;
+    const PairPre cur = phase_a(blk);  // (its loads wait behind the other waves' arithmetic: two workgroups of eight waves per CU)
+    __builtin_amdgcn_wave_barrier();
+    if (cur.valid) {
+      const int a0 = cur.la % 3, a1 = (cur.la / 3) % 3, a2 = cur.la / 9;
+      double X0[4][3], X2[4][3];  // [D, M, C, Ct][b]
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          X0[x][b] = sT[(x * 3 + a0) * 4 + b];
+          X2[x][b] = sT[(x * 3 + a2) * 4 + b];
+        }
+      const double g0 = cur.g[0], g1 = cur.g[1], g2 = cur.g[2], g3 = cur.g[3], g4 = cur.g[4], g5 = cur.g[5];
+#pragma unroll
+      for (int b1 = 0; b1 < 3; ++b1) {
+        const double D1 = sT[(0 * 3 + a1) * 4 + b1], M1 = sT[(1 * 3 + a1) * 4 + b1], C1 = sT[(2 * 3 + a1) * 4 + b1], Ct1 = sT[(3 * 3 + a1) * 4 + b1];
+#pragma unroll
+        for (int b0 = 0; b0 < 3; ++b0) {
+          const double D0 = X0[0][b0], M0 = X0[1][b0], C0 = X0[2][b0], Ct0 = X0[3][b0];
+          const double Pq = g0 * (D0 * M1) + g1 * (C0 * Ct1 + Ct0 * C1) + g3 * (M0 * D1);
+          const double Qq = g5 * (M0 * M1);
+          const double Rq = g2 * (C0 * M1) + g4 * (C1 * M0);
+          const double Tq = g2 * (Ct0 * M1) + g4 * (Ct1 * M0);
+          double* rp = rows + cur.b0 + (b0 * cur.c1 + b1) * cur.c2;
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) {
+            const double v = X2[1][b2] * Pq + X2[0][b2] * Qq + X2[3][b2] * Rq + X2[2][b2] * Tq;
+            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(rp + b2), v);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // (row r's length and first entry sit in lane 8 r: scalars, no LDS round trip)
+      const int len = __builtin_amdgcn_readlane(cur.len, 8 * r);
+      const uint32_t plo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)cur.pre, 8 * r), phi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)cur.pre >> 32), 8 * r);
+      double* dst = vals + (int64_t)(((uint64_t)phi << 32) | plo);
+      const double* src = rows + (wv * 8 + r) * G27_ROW;
+      if (lane < len) __builtin_nontemporal_store(src[lane], dst + lane);
+      if (lane + 64 < len) __builtin_nontemporal_store(src[lane + 64], dst + lane + 64);  // (at most 125 entries per row)
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- Robin faces (hex-27): one thread per (boundary face element, face node a) = one row of the 9 x 9 face matrix;
 // 9 face nodes, ng x ng Gauss points.  colour = parity of the face element in its two tangential directions; the two
 // opposite faces of a direction share no node and go into the same launch (side = -1): 4 launches per direction.
@@ -819,6 +1015,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
 static std::atomic<int> g_hex27_two_pass{1};
+static std::atomic<int> g_hex27_direct{1};  // bit 9 of mfem_debug_set_hex27 turns the scratch-free assembly of all-affine meshes off (two-pass MFMA path then)
 static std::atomic<int> g_hex27_affine{1};  // bit 8 of mfem_debug_set_hex27 turns the affine-element shortcut of the matrix kernel off (every element then takes the general path)
 static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
 static std::atomic<size_t> g_hex27_scratch_budget{(size_t)16 << 30};
@@ -827,6 +1024,7 @@ extern "C" int mfem_debug_set_hex27(int two_pass) try {
   g_hex27_two_pass = (two_pass & 3) == 0 ? 1 : (two_pass & 3);  // 0 / 1 two-pass (default), 2 FP64 atomics, 3 colour scatter
   g_hex27_chunk_planes = (two_pass >> 16) & 255;
   g_hex27_affine = ((two_pass >> 8) & 1) ? 0 : 1;
+  g_hex27_direct = ((two_pass >> 9) & 1) ? 0 : 1;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex27")
 
@@ -908,6 +1106,29 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     hipLaunchKernelGGL(k_hex27<true>, dim3((int)grid), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, vals);
     MFEM_CHECK_LAUNCH();
     return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
+  }
+  if (g_hex27_two_pass == 1 && g_hex27_direct && g_hex27_affine && m->n_owned < ((int64_t)1 << 31)) {
+    // all elements affine?  G0 of every element + a count of the ones that are not (one 4-byte read-back per assembly: the coordinates belong to the caller,
+    // mfem_brick_coords, and may have changed since the last call)
+    const int64_t nel = (int64_t)(ehi - elo) * m->ne[1] * m->ne[2];
+    rc = mfem_ws_reserve(ctx, sizeof(double) * 6 * (size_t)nel);
+    if (rc) return rc;
+    int32_t* d_cnt = ctx->d_flags + 14;
+    MFEM_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_hex27_affine_g0, dim3((unsigned)((nel + MFEM_BLOCK - 1) / MFEM_BLOCK)), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, elo, ehi - elo,
+                       (double*)ctx->ws, d_cnt);
+    MFEM_CHECK_LAUNCH();
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 14, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_flags[14] == 0) {
+      MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)D27_LDS_BYTES));
+      const int64_t nblk = (m->n_owned + D27_NODES - 1) / D27_NODES;
+      const int grid = (int)(nblk < (int64_t)ctx->num_cus * 2 ? nblk : (int64_t)ctx->num_cus * 2);  // two 8-wave workgroups per CU (78 KB of LDS each), persistent
+      hipLaunchKernelGGL(k_hex27_direct, dim3(grid), dim3(D27_THREADS), D27_LDS_BYTES, ctx->stream, B, (const Hex27Tables*)g_tab, (const double*)ctx->ws, vals,
+                         (int64_t)0, m->n_owned, elo);
+      MFEM_CHECK_LAUNCH();
+      return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
+    }
   }
   if (g_hex27_two_pass == 1) {
     // pass 1: every element's Ke on the matrix cores -> element-major scratch; pass 2: row-owner gather -> CSR.

@@ -368,11 +368,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_dia_vals(int64_t n, int64_t npad
       prefetch();
     }
   }
-  for (int64_t tile = (int64_t)blockIdx.x * nw + w; tile < ntiles; tile += tstride) {
+  // fast != 0: the swept rows are filled by k_symp_fill (below) -- this launch visits only the tiles that hold other rows (the tiles [sk0, sk1) lie inside the
+  // swept range and are stepped over) and leaves the swept rows of the tiles it visits alone
+  const int64_t sk0 = fast ? (slo + RT - 1) >> SH : 0, sk1 = fast ? (shi >> SH > sk0 ? shi >> SH : sk0) : 0;
+  for (int64_t tix = (int64_t)blockIdx.x * nw + w; tix < ntiles - (sk1 - sk0); tix += tstride) {
+    const int64_t tile = tix < sk0 ? tix : tix + (sk1 - sk0);
     const int64_t r0 = tile << SH, r = r0 + rl;
-    // fast != 0: the swept rows are filled by k_symp_fill (below) -- this launch visits only the tiles that hold other rows and leaves the swept rows of
-    // those tiles alone
-    if (fast && r0 >= slo && r0 + RT <= shi) continue;
     const int64_t rend = (r0 + RT < n) ? r0 + RT : n;
     int64_t lo = 0;
     int len = 0;
