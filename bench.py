@@ -334,15 +334,32 @@ def main():
         b27 = mf.Brick((1.0, 1.0, 1.0), (n27,) * 3, 2, 5, ctx=ctx)
         A27 = b27.pattern(1)
         K27 = torch.empty(A27.nnz, dtype=torch.float64, device=dev)
-        b27.assemble_thermal(A27, K_COND, 0.0, TENV, 0, out=K27)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(repeats):
+
+        def timed_assembly():
             b27.assemble_thermal(A27, K_COND, 0.0, TENV, 0, out=K27)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / repeats
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(repeats):
+                b27.assemble_thermal(A27, K_COND, 0.0, TENV, 0, out=K27)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / repeats
+
+        # The make_Brick mesh is affine element by element, and the library then assembles without ever storing Ke (k_hex27_direct: round 4).  The MFMA
+        # figure below is the GENERAL path's -- what a mesh with one curved element takes -- forced here on the same mesh (bit 9 of mfem_debug_set_hex27),
+        # the default path's time is reported beside it against the bytes it must write.
+        ms_direct = timed_assembly()
+        Kd = K27.clone()
+        _lib.lib.mfem_debug_set_hex27(1 << 9)
+        try:
+            ms = timed_assembly()
+        finally:
+            _lib.lib.mfem_debug_set_hex27(0)
+        agree = float((K27 - Kd).abs().max() / K27.abs().max())
+        assert agree <= 1e-13, f"hex-27: the scratch-free assembly and the two-pass MFMA assembly differ by {agree:.2e} of max |K|"
+        nnz27, n27_rows = int(A27.nnz), int(A27.n)
+        del Kd
         nel = n27 ** 3
         flops = 118098.0 * nel
         busy = None
@@ -362,7 +379,18 @@ def main():
                 "useful_flop_per_assembly": flops, "avg_assembly_ms": ms, "assemblies_timed": repeats,
                 "achieved": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / PEAK_TFLOPS,
                 "mfma_pipe_busy_in_pass1": busy, "mfma_pipe_busy_source": src,
-                "note": "useful flops only (SURVEY 8(d)): the B build and the zero-padding of the 27 x 81 operands to MFMA tiles are not counted"}
+                "note": "useful flops only (SURVEY 8(d)): the B build and the zero-padding of the 27 x 81 operands to MFMA tiles are not counted; "
+                        "measured with the scratch-free path of all-affine meshes turned off (this mesh would take it: `affine_mesh_assembly`)",
+                "affine_mesh_assembly": {
+                    "kernel": "k_hex27_affine_g0 (per element: affine test on the 27 nodes + G0 = -k adj(J) adj(J)^T / det) + k_hex27_direct (row-owner gather, "
+                              "each (row, element) run computed from G0 and the 1-D reference integrals in registers, rows accumulated in LDS): the default "
+                              "when every element is affine; Ke is never stored",
+                    "avg_assembly_ms": ms_direct, "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                    "algorithmic_bytes_per_assembly": 8 * nnz27 + 2 * 48 * nel + 3 * 8 * n27_rows,
+                    "achieved": (8 * nnz27 + 2 * 48 * nel + 3 * 8 * n27_rows) / (ms_direct * 1e-3) / 1e9,
+                    "frac": (8 * nnz27 + 2 * 48 * nel + 3 * 8 * n27_rows) / (ms_direct * 1e-3) / 1e9 / 8000.0,
+                    "max_rel_difference_to_the_mfma_path": agree,
+                    "note": "algorithmic bytes = the CSR values written once + G0 written and read + the coordinates read"}}
 
     strong = args.scaling == "strong" and world > 1
 

@@ -72,8 +72,12 @@ int mfem_debug_set_halo_overlap(int on);
 /* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
  * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
  * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
- * 16 GiB scratch budget). */
+ * 16 GiB scratch budget).  Bit 8: the constant-Jacobian shortcut of affine elements off (every element takes the general path).
+ * Bit 9: the scratch-free assembly of meshes whose elements are ALL affine off (such a mesh then takes the two-pass MFMA path;
+ * by default its matrix is built by a row-owner gather from per-element G0 and the reference integrals, Ke never stored). */
 int mfem_debug_set_hex27(int two_pass);
+/* number of hex-27 matrix assemblies that took the scratch-free path so far (process-wide) */
+int64_t mfem_debug_hex27_direct_count(void);
 /* hex-8 elasticity kernels.  Bit 0: matrix -- 0 (default) thread per (control point, element) with the rows accumulated in LDS and
  * written once; 1 the earlier row-owner kernel accumulating in global memory (equal to round-off: other summation order, table form of
  * the Jacobian).  Bit 1: residual -- 0 (default) the plane-sweep kernel with one sum-factorised integration per element (2-point Gauss

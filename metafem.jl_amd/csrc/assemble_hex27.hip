@@ -1015,6 +1015,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_faces(Face27Args A, const 
 // row-owner gather.  Measured at 128^3 (profiles/r01_hex27_mfma_counters.txt): scatter 19.7-22.9 ms; two-pass 30.9 ms
 // (MFMA pass 11.8 ms + gather 17.4 ms, the gather being bound by its per-slot index arithmetic).
 static std::atomic<int> g_hex27_two_pass{1};
+static std::atomic<long long> g_hex27_direct_count{0};  // assemblies that took the scratch-free path (tests)
+extern "C" int64_t mfem_debug_hex27_direct_count(void) { return g_hex27_direct_count; }
 static std::atomic<int> g_hex27_direct{1};  // bit 9 of mfem_debug_set_hex27 turns the scratch-free assembly of all-affine meshes off (two-pass MFMA path then)
 static std::atomic<int> g_hex27_affine{1};  // bit 8 of mfem_debug_set_hex27 turns the affine-element shortcut of the matrix kernel off (every element then takes the general path)
 static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
@@ -1127,6 +1129,7 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
       hipLaunchKernelGGL(k_hex27_direct, dim3(grid), dim3(D27_THREADS), D27_LDS_BYTES, ctx->stream, B, (const Hex27Tables*)g_tab, (const double*)ctx->ws, vals,
                          (int64_t)0, m->n_owned, elo);
       MFEM_CHECK_LAUNCH();
+      ++g_hex27_direct_count;
       return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
     }
   }

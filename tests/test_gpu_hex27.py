@@ -126,9 +126,15 @@ def test_hex27_affine_element_shortcut(mf, case):
     xs, ss = torch.tensor(od.x_star, device="cuda"), torch.tensor(od.controlpoints["s"], device="cuda")
     Ks, Rs = {}, {}
     try:
-        for knob in (0, 1 << 8):
+        for knob in (0, 1 << 8, 1 << 9):
             _lib.lib.mfem_debug_set_hex27(knob)
+            before = _lib.lib.mfem_debug_hex27_direct_count()
             Ks[knob] = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+            # a mesh whose elements are ALL affine is assembled without Ke being stored (round 4: per-element G0 + the 1-D reference integrals); one
+            # distorted element sends the whole mesh through the two-pass MFMA path
+            assert (_lib.lib.mfem_debug_hex27_direct_count() > before) == (knob == 0 and case != "half_distorted")
+            if knob == 1 << 9:
+                continue
             Rs[knob] = brick.residual_thermal(xs, K_COND, 0.0, TENV, 0, s=ss).cpu().numpy()  # the matrix-free residual takes the shortcut too
     finally:
         _lib.lib.mfem_debug_set_hex27(0)
@@ -142,3 +148,4 @@ def test_hex27_affine_element_shortcut(mf, case):
     assert np.abs(Ks[0] - od.K_linear).max() <= tol * scale
     assert np.abs(Ks[1 << 8] - od.K_linear).max() <= tol * scale
     assert np.abs(Ks[0] - Ks[1 << 8]).max() <= 0.1 * tol * scale
+    assert np.abs(Ks[1 << 9] - od.K_linear).max() <= tol * scale and np.abs(Ks[0] - Ks[1 << 9]).max() <= 0.1 * tol * scale
