@@ -22,12 +22,16 @@ struct KrylovVecs {
   double cg_smax = 1.0, cg_smin = 1.0;
   double* w[3 * MFEM_MAX_S + 8];
   int nwork;
+  bool x_zero = false;  // x is still the zero vector a solve starts from (x0 = 0, 02_Preconditioner.jl:45): the first pass's r = b - A x is b itself
 };
 
 int mfem_fill(mfem_context_s* ctx, int64_t n, double v, double* x);
 int mfem_sum_partials(mfem_context_s* ctx, const double* partials, int np, double* d_out);
 int mfem_true_residual(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* b, const double* x,
                        double* r, int64_t nv, double* d_rr);
+// r = b - A x at the start of a pass; the SpMV is skipped while V.x_zero holds (r = b, r.r summed in the order the SpMV path sums it: the same bits).
+// *spmv_out is advanced only when a product ran.
+int mfem_pass_residual(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const KrylovVecs& V, double* r, double* d_rr, int* spmv_out);
 int mfem_read_scalars(mfem_context_s* ctx, int first, int count);
 int mfem_read_flags(mfem_context_s* ctx);
 int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, KrylovVecs& V,

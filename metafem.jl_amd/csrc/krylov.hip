@@ -109,6 +109,39 @@ int mfem_true_residual(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, c
   return MFEM_OK;
 }
 
+// r = b, partial sums of b.b: k_resid_finish without its read of r (the SpMV of a zero vector leaves +-0 there: r + b = b)
+__global__ __launch_bounds__(MFEM_BLOCK) void k_resid_from_b(int64_t n, const d2_t* __restrict__ b, d2_t* __restrict__ r, double* __restrict__ partials) {
+  __shared__ double red[MFEM_BLOCK / MFEM_WAVE];
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const d2_t v = b[i];
+    r[i] = v;
+    acc += v.x * v.x + v.y * v.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double v = reinterpret_cast<const double*>(b)[n - 1];
+    reinterpret_cast<double*>(r)[n - 1] = v;
+    acc += v * v;
+  }
+  const double s = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+int mfem_pass_residual(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const KrylovVecs& V, double* r, double* d_rr, int* spmv_out) {
+  if (!V.x_zero) {
+    ++*spmv_out;
+    return mfem_true_residual(ctx, A, vals, V.b, V.x, r, V.nv, d_rr);
+  }
+  const int grid = mfem_vec_grid(ctx, A->n);
+  hipLaunchKernelGGL(k_resid_from_b, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, (const d2_t*)V.b, (d2_t*)r, ctx->d_partials);
+  MFEM_CHECK_LAUNCH();
+  int rc = mfem_sum_partials(ctx, ctx->d_partials, grid, d_rr);
+  if (rc) return rc;
+  if (ctx->comm) return mfem_comm_allreduce(ctx, d_rr, 1);
+  return MFEM_OK;
+}
+
 int mfem_read_scalars(mfem_context_s* ctx, int first, int count) {
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + first, ctx->d_scalars + first, sizeof(double) * count,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -337,9 +370,8 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   }
   double* part1 = ctx->d_partials;                          // SpMV p.Ap partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;       // 2 x G
-  int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
+  int rc = mfem_pass_residual(ctx, A, vals, V, r, S + S_RR, spmv_out);
   if (rc) return rc;
-  ++*spmv_out;
   const int G = mfem_vec_grid(ctx, nv);
   hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, (d2_t*)r, (const d2_t*)dinv, (d2_t*)p,
                      part2);
@@ -588,9 +620,8 @@ static int cgcg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   double* part1 = ctx->d_partials;                      // SpMV w.u partials
   double* part2 = ctx->d_partials + MFEM_MAX_PARTIALS;   // 2 x G: r.u, r.r
   double* T = S + S_TMP0;
-  int rc = mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR);
+  int rc = mfem_pass_residual(ctx, A, vals, V, r, S + S_RR, spmv_out);
   if (rc) return rc;
-  ++*spmv_out;
   const int G = mfem_vec_grid(ctx, nv);
   // the scalar step after an SpMV: fold (+ all-reduce) gamma', r.r, delta' and advance alpha / beta / the stop flags
   auto scalars = [&](int np1, int init) -> int {
@@ -1088,6 +1119,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
   const double res0 = sqrt(ctx->h_scalars[S_TMP0] * n_inv);
 
   int pass = 1, total_iters = 0, spmvs = 0;
+  V.x_zero = true;  // (the workspace was cleared above; nothing has written x since)
   double res = res0;
   double tol_factor = 1.0;  // only a left preconditioner moves it (:57-59); the scaled CG's kernels test the true residual themselves
   for (;;) {
@@ -1111,6 +1143,7 @@ static int solve_inner(mfem_context ctx, mfem_csr A, double* vals, const double*
         rc = MFEM_ERR_INVALID;
     }
     if (rc) return rc;
+    V.x_zero = false;
     total_iters += it;
     // true residual between passes (:53-55)
     rc = mfem_true_residual(ctx, A, vals_work, V.b, V.x, V.w[0], nv, ctx->d_scalars + S_RR);

@@ -292,8 +292,7 @@ int mfem_bicgstabl_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, 
   BlArgs a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations, l};
 
   // r = b - A x ; Pl(r) (identity)   (:19-21)
-  RC(mfem_true_residual(ctx, A, vals, V.b, V.x, R[0], nv, S + S_RR));
-  ++*spmv_out;
+  RC(mfem_pass_residual(ctx, A, vals, V, R[0], S + S_RR, spmv_out));
   K1(kb_init, a, S, F);
   // r_shadow = FEM_rand (:37); U, R[2..] = FEM_buffer (zeros)
   if (ctx->shadow && ctx->shadow_count >= 1) {

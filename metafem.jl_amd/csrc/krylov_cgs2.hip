@@ -103,8 +103,7 @@ int mfem_cgs2_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   double *r = V.w[0], *r0 = V.w[1], *s0 = V.w[2], *u = V.w[3], *w = V.w[4], *s = V.w[5], *v = V.w[6], *t = V.w[7], *c = V.w[8];
   KK k{ctx, nv, V.n, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
   C2Args a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations};
-  RC(mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR));
-  ++*spmv_out;
+  RC(mfem_pass_residual(ctx, A, vals, V, r, S + S_RR, spmv_out));
   K1(kc_init, a, S, F);
   MFEM_CHECK_HIP(hipMemcpyAsync(r0, r, sizeof(double) * nv, hipMemcpyDeviceToDevice, ctx->stream));  // r0 = copy(r)
   if (ctx->shadow && ctx->shadow_count >= 1)

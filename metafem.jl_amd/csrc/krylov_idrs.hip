@@ -218,8 +218,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   KK k{ctx, nv, V.n, mfem_vec_grid(ctx, nv), S, F, ctx->stream};
   IdArgs a{1.0 / (double)n_global, tol, o->maxiter, o->fixed_iterations, s};
 
-  RC(mfem_true_residual(ctx, A, vals, V.b, V.x, r, nv, S + S_RR));  // :27-29
-  ++*spmv_out;
+  RC(mfem_pass_residual(ctx, A, vals, V, r, S + S_RR, spmv_out));  // :27-29
   K1(ki_init, a, S, F);
   for (int i = 0; i < s; ++i) {  // P = FEM_rand (:35)
     if (ctx->shadow && ctx->shadow_count >= s)
