@@ -211,7 +211,7 @@ typedef struct {
   double initial_res;
   double solve_ms;         /* device time, hip events on the context stream */
   int32_t converged;
-  int32_t spmv_count;
+  int32_t spmv_count;      /* matrix-vector products that ran (the first pass starts from r = b: x0 = 0, no product) */
 } mfem_solve_stats;
 
 /* What a solve does to the matrix it is handed -- read before relying on bit patterns:
