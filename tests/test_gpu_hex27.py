@@ -149,3 +149,24 @@ def test_hex27_affine_element_shortcut(mf, case):
     assert np.abs(Ks[1 << 8] - od.K_linear).max() <= tol * scale
     assert np.abs(Ks[0] - Ks[1 << 8]).max() <= 0.1 * tol * scale
     assert np.abs(Ks[1 << 9] - od.K_linear).max() <= tol * scale and np.abs(Ks[0] - Ks[1 << 9]).max() <= 0.1 * tol * scale
+
+
+def test_hex27_scratch_free_path_on_a_long_lattice(mf):
+    """k_hex27_direct keeps the row-box tables (lo, c, P per direction) in LDS up to 1024 lattice planes + lines + points and reads them from memory beyond: a
+    brick of 520 x 3 x 2 elements (1041 + 7 + 5 lattice coordinates) takes the second way.  Against the two-pass MFMA path (bit 9 of mfem_debug_set_hex27)."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick = mf.make_Brick((26.0, 0.3, 0.2), (520, 3, 2), 2, 5)
+    A = brick.pattern(1)
+    try:
+        before = _lib.lib.mfem_debug_hex27_direct_count()
+        Kd = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+        assert _lib.lib.mfem_debug_hex27_direct_count() == before + 1
+        _lib.lib.mfem_debug_set_hex27(1 << 9)
+        Kt = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+        assert _lib.lib.mfem_debug_hex27_direct_count() == before + 1
+    finally:
+        _lib.lib.mfem_debug_set_hex27(0)
+    assert float((Kd - Kt).abs().max()) <= 1e-13 * float(Kt.abs().max())
+    assert bool(torch.isfinite(Kd).all())
