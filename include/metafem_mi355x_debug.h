@@ -40,14 +40,14 @@ int mfem_debug_set_ell(int enable);
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
 int mfem_debug_set_sell(int enable);
 /* mode 4 (symmetric lattice tiles, hex-27): 0 = off (mode 3 serves those solves), 1 = on (default). */
-int mfem_debug_set_lat27(int enable);
+int mfem_debug_set_lat27(int enable);  /* bit 1: pass 2 (the gather of the tiles' y blocks) by the kernel that walks the covering blocks one memory round trip at a time (same y bit for bit) */
 /* SpMVs mode 4 has served so far, process-wide */
 long long mfem_debug_lat27_spmv_count(void);
 /* max |layout x - CSR x| / max |A[r][c]| of the probe product of the last mode-4 bind on this pattern (mode 4 is taken up to 4e-13) */
 double mfem_debug_lat27_asymmetry(mfem_csr A);
 /* mode 5 (symmetric lattice tiles, F-field 27-point matrix): the same three entry points; bit 1 of `enable`: mfem_csr_solver_layout and
  * mfem_spmv_solver_layout report / take mode 5 for ONE field too (they answer for cg!, which keeps mode 2 there) */
-int mfem_debug_set_lat8(int enable);
+int mfem_debug_set_lat8(int enable);  /* bit 2: pass 2 by the staged gather (all loads of a tile in flight at once, sums in the same order; measured slower on these tiles, off by default) */
 long long mfem_debug_lat8_spmv_count(void);
 double mfem_debug_lat8_asymmetry(mfem_csr A);
 /* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2 -- and mode 5 --, 1 000 000 for modes 1 and 3; mode 4 from

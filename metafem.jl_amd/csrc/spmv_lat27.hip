@@ -41,6 +41,7 @@ typedef double l_d2 __attribute__((ext_vector_type(2)));
 
 extern std::atomic<int64_t> g_layout_min_rows_lat27;  // spmv_ell.hip
 static std::atomic<int> g_lat27_enable{1};
+static std::atomic<int> g_lat27_gather_staged{1};  // bit 1 of mfem_debug_set_lat27: 0 = pass 2 by k_lat27_gather (masked blocks, a round trip per covering block)
 static std::atomic<long long> g_lat27_count{0};
 extern "C" long long mfem_debug_lat27_spmv_count(void) { return g_lat27_count; }  // SpMVs the layout has served (bench.py: which kernel ran)
 // max |A[r][c] - A[c][r]| / max |A[r][c]| the layout pass of the last bind on this pattern measured (-1: no bind yet)
@@ -48,6 +49,7 @@ extern "C" double mfem_debug_lat27_asymmetry(mfem_csr A) { return A ? A->lat27_a
 extern "C" int mfem_debug_set_lat27(int enable) try {
   ++mfem_debug_epoch;
   g_lat27_enable = enable & 1;
+  g_lat27_gather_staged = ((enable >> 1) & 1) ? 0 : 1;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_lat27")
 
@@ -452,6 +454,114 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather(Lat27Geom G, const 
   }
 }
 
+// pass 2, staged (round 4): the same sums in the same order, but every global load of a tile is in flight at once.  The kernel above walks the up to 18
+// covering blocks of a row in masked code blocks, one memory round trip each (every wave holds lanes on the tile's k rim, so every wave takes at least
+// three, the waves on the j rim nine: 3.1 TB/s).  Here the workgroup first copies the 4 320 (row, covering block) values of its tile -- the extended box
+// (8 + 2 planes) x (8 + 2 + 2 lines) x (32 + 2 + 2 columns): own cells, the cells the tile below / beside / diagonal to it holds for these rows -- into
+// LDS, 17 independent loads per thread, and the row owners then add them from LDS in the order of the kernel above (bitwise the same y).
+// Measured (tools/gather_ab.py, C4): 1 % off a 200-iteration solve -- the round trips were not what bounds pass 2 (a 0.18 ms kernel of 0.56 GB).
+#define L27_EJ (L27_TJ + 4)
+#define L27_EK (L27_TK + 4)
+#define L27_ECELLS ((L27_TI + 2) * L27_EJ * L27_EK)  // 4320
+#define L27_EU ((L27_ECELLS + MFEM_BLOCK - 1) / MFEM_BLOCK)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather_st(Lat27Geom G, const double* __restrict__ dump, double* __restrict__ y,
+                                                                  double alpha, double beta, const double* __restrict__ dotw,
+                                                                  double* __restrict__ partials, const int32_t* __restrict__ done_flag,
+                                                                  const RP* __restrict__ rowptr, int base, const double* __restrict__ csr_vals,
+                                                                  const double* __restrict__ x, const double* __restrict__ dsc) {
+  __shared__ double E[L27_ECELLS];
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  const int lk = threadIdx.x & (L27_TK - 1), lj = threadIdx.x >> 5;
+  const int PC = L27_SJ * L27_SK;
+  // extended line / column e -> (neighbour offset, line or column of this tile): 0 .. T - 1 own; T, T + 1: the block below / before holds rows 0, 1;
+  // T + 2, T + 3: the block after holds rows T - 2, T - 1
+  auto ext = [](int e, int T, int& off, int& l) {
+    if (e < T) { off = 0; l = e; }
+    else if (e < T + 2) { off = -1; l = e - T; }
+    else { off = 1; l = e - 4; }
+  };
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // (the trip count is the workgroup's: every barrier below is reached by all threads)
+    const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+    double t[L27_EU];
+#pragma unroll
+    for (int u = 0; u < L27_EU; ++u) {
+      const int e = threadIdx.x + u * MFEM_BLOCK;
+      t[u] = 0.0;
+      if (e < L27_ECELLS) {
+        const int ei = e / (L27_EJ * L27_EK), r2 = e - ei * (L27_EJ * L27_EK), ej = r2 / L27_EK, ek = r2 - ej * L27_EK;
+        int b, c, sj, sk;
+        ext(ej, L27_TJ, b, sj);
+        ext(ek, L27_TK, c, sk);
+        const int a = ei < L27_TI ? 0 : -1;  // (planes 8, 9 of the block below are this tile's planes 0, 1: the block's plane index is ei either way)
+        const bool ok = (a == 0 || ti > 0) && (b == 0 || (b < 0 ? tj > 0 : tj < G.ntj - 1)) && (c == 0 || (c < 0 ? tk > 0 : tk < G.ntk - 1));
+        if (ok)
+          t[u] = __builtin_nontemporal_load(dump + (((int64_t)(ti + a) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * L27_CELLS + ei * PC +
+                                            (sj - L27_TJ * b + 2) * L27_SK + (sk - L27_TK * c + 2));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < L27_EU; ++u) {
+      const int e = threadIdx.x + u * MFEM_BLOCK;
+      if (e < L27_ECELLS) E[e] = t[u];
+    }
+    __syncthreads();
+    const int gj = tj * L27_TJ + lj, gk = tk * L27_TK + lk, gi0 = ti * L27_TI;
+    if (gj < G.m1 && gk < G.m2) {
+      double s[L27_TI];
+#pragma unroll
+      for (int u = 0; u < L27_TI; ++u) s[u] = 0.0;
+      for (int b = -1; b <= 1; ++b) {
+        if ((b < 0 && (lj >= 2 || tj == 0)) || (b > 0 && (lj < L27_TJ - 2 || tj == G.ntj - 1))) continue;
+        const int ej = b == 0 ? lj : b < 0 ? L27_TJ + lj : lj + 4;
+        for (int c = -1; c <= 1; ++c) {
+          if ((c < 0 && (lk >= 2 || tk == 0)) || (c > 0 && (lk < L27_TK - 2 || tk == G.ntk - 1))) continue;
+          const int ek = c == 0 ? lk : c < 0 ? L27_TK + lk : lk + 4;
+          const double* d = E + ej * L27_EK + ek;
+          if (ti > 0) {
+            s[0] += d[8 * (L27_EJ * L27_EK)];
+            s[1] += d[9 * (L27_EJ * L27_EK)];
+          }
+#pragma unroll
+          for (int u = 0; u < L27_TI; ++u) s[u] += d[u * (L27_EJ * L27_EK)];
+        }
+      }
+      if (G.plo > 0 && ti == 0) {  // the lower ghost planes (see k_lat27_gather): the first two of the row's five i-offsets
+        int l1, n1, l2, n2;
+        l27_range(gj, G.m1, l1, n1);
+        l27_range(gk, G.m2, l2, n2);
+        const int64_t rp = (int64_t)rowptr[(int64_t)gj * G.m2 + gk] - base;
+        double acc = 0.0;
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < n1; ++b)
+            for (int c = 0; c < n2; ++c) {
+              const int64_t xi = l27_xindex(G, G.plo - 2 + a, (int64_t)(gj + l1 + b) * G.m2 + gk + l2 + c);
+              acc += csr_vals[rp + ((int64_t)a * n1 + b) * n2 + c] * (dsc ? x[xi] / dsc[xi] : x[xi]);
+            }
+        s[0] += acc;
+      }
+#pragma unroll
+      for (int u = 0; u < L27_TI; ++u) {
+        if (gi0 + u < G.m0) {
+          const int64_t r = ((int64_t)(gi0 + u) * G.m1 + gj) * G.m2 + gk;
+          double yv = alpha * s[u];
+          if (beta != 0.0) yv += beta * y[r];
+          y[r] = yv;
+          if (dotw) dot_acc += yv * dotw[r];
+        }
+      }
+    }
+    __syncthreads();  // the staged values are consumed: the next tile's may land
+  }
+  if (partials) {
+    const double bsum = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bsum;
+  }
+}
+
 static Lat27Geom lat27_geom(const mfem_csr_s* A) {
   Lat27Geom G{};
   G.m1 = A->lat_m1;
@@ -665,12 +775,15 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;
-  if (A->rowptr_bits == 64)
-    hipLaunchKernelGGL(k_lat27_gather<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials,
-                       done_flag, (const int64_t*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc);
-  else
-    hipLaunchKernelGGL(k_lat27_gather<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials,
-                       done_flag, (const int32_t*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc);
+#define L27_GATHER(KERNEL, RP)                                                                                                              \
+  hipLaunchKernelGGL(KERNEL<RP>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials, done_flag, \
+                     (const RP*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc)
+  if (g_lat27_gather_staged) {
+    if (A->rowptr_bits == 64) L27_GATHER(k_lat27_gather_st, int64_t); else L27_GATHER(k_lat27_gather_st, int32_t);
+  } else {
+    if (A->rowptr_bits == 64) L27_GATHER(k_lat27_gather, int64_t); else L27_GATHER(k_lat27_gather, int32_t);
+  }
+#undef L27_GATHER
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   if (!ctx->probe_active) ++g_lat27_count;

@@ -32,6 +32,7 @@ typedef double m_d2 __attribute__((ext_vector_type(2)));
 
 extern std::atomic<int64_t> g_layout_min_rows_dia;  // spmv_ell.hip
 static std::atomic<int> g_lat8_enable{1};
+static std::atomic<int> g_lat8_gather_staged{0};  // bit 2 of mfem_debug_set_lat8: 1 = pass 2 by k_lat8_gather_st (measured on C3, tools/gather_ab.py: 1.6 % SLOWER per solve than k_lat8_gather -- its two barriers and the LDS round trip cost more than the round trips it saves on these small tiles; the hex-27 tiles gain 1 %)
 static std::atomic<int> g_lat8_one_field_everywhere{0};  // bit 1 of mfem_debug_set_lat8: the query / diagnostic SpMV entry also report and take mode 5 for ONE field
 static std::atomic<long long> g_lat8_count{0};
 extern "C" long long mfem_debug_lat8_spmv_count(void) { return g_lat8_count; }
@@ -40,6 +41,7 @@ extern "C" int mfem_debug_set_lat8(int enable) try {
   ++mfem_debug_epoch;
   g_lat8_enable = enable & 1;
   g_lat8_one_field_everywhere = (enable >> 1) & 1;
+  g_lat8_gather_staged = (enable >> 2) & 1;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_lat8")
 // One field: cg! keeps the bitwise patch sweep of mode 2 (it moves the same bytes); the solvers that work on A D^-1 (idrs!, bicgstabl_GS!, cgs2!) cannot
@@ -395,6 +397,119 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather(Lat8Geom G, const do
   }
 }
 
+// pass 2, staged (round 4; see k_lat27_gather_st; NOT the default here, see g_lat8_gather_staged): the F x 1 620 (row, covering block) values of a tile -- the extended box (8 + 1 planes) x (8 + 1 + 1 lines)
+// x (16 + 1 + 1 columns) per field -- are copied to LDS with all loads in flight at once (19 per thread for three fields), the row owners then add them in the
+// order of k_lat8_gather (bitwise the same y).
+#define L8_EJ (L8_TJ + 2)
+#define L8_EK (L8_TK + 2)
+#define L8_EF ((L8_TI + 1) * L8_EJ * L8_EK)  // 1620 per field
+template <typename RP, int F>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_lat8_gather_st(Lat8Geom G, const double* __restrict__ dump, double* __restrict__ y, double alpha,
+                                                                 double beta, const double* __restrict__ dotw, double* __restrict__ partials,
+                                                                 const int32_t* __restrict__ done_flag, const RP* __restrict__ rowptr, int base,
+                                                                 const double* __restrict__ csr_vals, const double* __restrict__ x,
+                                                                 const double* __restrict__ dsc) {
+  constexpr int EC = F * L8_EF, EU = (EC + MFEM_BLOCK - 1) / MFEM_BLOCK;
+  __shared__ double E[EC];
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  const int lk = threadIdx.x & (L8_TK - 1), lj = (threadIdx.x >> 4) & (L8_TJ - 1), lh = threadIdx.x >> 7;
+  // extended line / column e -> (neighbour offset, line or column of this tile): 0 .. T - 1 own; T: the block before holds row 0; T + 1: the block after holds row T - 1
+  auto ext = [](int e, int T, int& off, int& l) {
+    if (e < T) { off = 0; l = e; }
+    else if (e == T) { off = -1; l = 0; }
+    else { off = 1; l = T - 1; }
+  };
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // (the trip count is the workgroup's: every barrier below is reached by all threads)
+    const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+    double t[EU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int e = threadIdx.x + u * MFEM_BLOCK;
+      t[u] = 0.0;
+      if (e < EC) {
+        const int f = e / L8_EF, r1 = e - f * L8_EF, ei = r1 / (L8_EJ * L8_EK), r2 = r1 - ei * (L8_EJ * L8_EK), ej = r2 / L8_EK, ek = r2 - ej * L8_EK;
+        int b, c, sj, sk;
+        ext(ej, L8_TJ, b, sj);
+        ext(ek, L8_TK, c, sk);
+        const int a = ei < L8_TI ? 0 : -1;  // (plane 8 of the block below is this tile's plane 0: the block's plane index is ei either way)
+        const bool ok = (a == 0 || ti > 0) && (b == 0 || (b < 0 ? tj > 0 : tj < G.ntj - 1)) && (c == 0 || (c < 0 ? tk > 0 : tk < G.ntk - 1));
+        if (ok)
+          t[u] = __builtin_nontemporal_load(dump + (((int64_t)(ti + a) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * (F * L8_FC) + f * L8_FC + ei * L8_PI +
+                                            (sj - L8_TJ * b + 1) * L8_SK + (sk - L8_TK * c + 1));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int e = threadIdx.x + u * MFEM_BLOCK;
+      if (e < EC) E[e] = t[u];
+    }
+    __syncthreads();
+    const int gj = tj * L8_TJ + lj, gk = tk * L8_TK + lk, gi0 = ti * L8_TI + 4 * lh;
+    if (gj < G.m1 && gk < G.m2) {
+      double s[F][4];
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[f][u] = 0.0;
+      for (int b = -1; b <= 1; ++b) {
+        if ((b < 0 && (lj >= 1 || tj == 0)) || (b > 0 && (lj < L8_TJ - 1 || tj == G.ntj - 1))) continue;
+        const int ej = b == 0 ? lj : b < 0 ? L8_TJ : L8_TJ + 1;
+        for (int c = -1; c <= 1; ++c) {
+          if ((c < 0 && (lk >= 1 || tk == 0)) || (c > 0 && (lk < L8_TK - 1 || tk == G.ntk - 1))) continue;
+          const int ek = c == 0 ? lk : c < 0 ? L8_TK : L8_TK + 1;
+          const double* d = E + ej * L8_EK + ek;
+          if (ti > 0 && lh == 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) s[f][0] += d[f * L8_EF + 8 * (L8_EJ * L8_EK)];
+          }
+#pragma unroll
+          for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[f][u] += d[f * L8_EF + (4 * lh + u) * (L8_EJ * L8_EK)];
+        }
+      }
+      if (G.plo > 0 && ti == 0 && lh == 0) {  // the lower ghost plane (see k_lat8_gather)
+        int l1, n1, l2, n2, l0, n0;
+        l8_range(G.plo, G.mg, l0, n0);
+        l8_range(gj, G.m1, l1, n1);
+        l8_range(gk, G.m2, l2, n2);
+        const int cnt = n0 * n1 * n2;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const int64_t rp = (int64_t)rowptr[f * G.N + (int64_t)gj * G.m2 + gk] - base;
+          double acc = 0.0;
+          for (int g = 0; g < F; ++g)
+            for (int b = 0; b < n1; ++b)
+              for (int c = 0; c < n2; ++c) {
+                const int64_t xi = l8_xindex(G, g, G.plo - 1, (int64_t)(gj + l1 + b) * G.m2 + gk + l2 + c);
+                acc += csr_vals[rp + (int64_t)g * cnt + b * n2 + c] * (dsc ? x[xi] / dsc[xi] : x[xi]);
+              }
+          s[f][0] += acc;
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (gi0 + u < G.m0) {
+            const int64_t r = f * G.N + ((int64_t)(gi0 + u) * G.m1 + gj) * G.m2 + gk;
+            double yv = alpha * s[f][u];
+            if (beta != 0.0) yv += beta * y[r];
+            y[r] = yv;
+            if (dotw) dot_acc += yv * dotw[r];
+          }
+    }
+    __syncthreads();  // the staged values are consumed: the next tile's may land
+  }
+  if (partials) {
+    const double bsum = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bsum;
+  }
+}
+
 static Lat8Geom lat8_geom(const mfem_csr_s* A) {
   Lat8Geom G{};
   G.F = A->lat_fields;
@@ -554,15 +669,18 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   int cap = ctx->num_cus * 8;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
   const int grid = ntiles < cap ? ntiles : cap;
-#define L8_PASS2(FF)                                                                                                                                  \
-  if (A->rowptr_bits == 64)                                                                                                                           \
-    hipLaunchKernelGGL((k_lat8_gather<int64_t, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials,   \
-                       done_flag, (const int64_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);                                             \
-  else                                                                                                                                                \
-    hipLaunchKernelGGL((k_lat8_gather<int32_t, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials,   \
-                       done_flag, (const int32_t*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc)
+#define L8_GATHER(KERNEL, RP, FF)                                                                                                             \
+  hipLaunchKernelGGL((KERNEL<RP, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag, \
+                     (const RP*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc)
+#define L8_PASS2(FF)                                                                                                             \
+  if (g_lat8_gather_staged) {                                                                                                   \
+    if (A->rowptr_bits == 64) L8_GATHER(k_lat8_gather_st, int64_t, FF); else L8_GATHER(k_lat8_gather_st, int32_t, FF);          \
+  } else {                                                                                                                      \
+    if (A->rowptr_bits == 64) L8_GATHER(k_lat8_gather, int64_t, FF); else L8_GATHER(k_lat8_gather, int32_t, FF);                \
+  }
   L8_DISPATCH_F(G.F, L8_PASS2);
 #undef L8_PASS2
+#undef L8_GATHER
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
   if (!ctx->probe_active) ++g_lat8_count;

@@ -44,13 +44,16 @@ def test_spmv_equals_the_csr_kernel(mf, small_layouts, dims):
     x = mf.FEM_rand(A.n, 3, 0) - 0.5
     y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
     mf.mul_(y0, A, K, x)
-    for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
-        y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
-        c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
-        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
-        assert int(_lib.lib.mfem_debug_lat27_spmv_count()) == c0 + 1
-        want = alpha * y0 + beta * 7.0
-        assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+    # pass 2 by the staged gather (default: all loads of a tile in flight at once) and by the kernel that walks the covering blocks (bit 1): the same sums
+    for knob in (1, 1 | 2):
+        _lib.lib.mfem_debug_set_lat27(knob)
+        for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
+            y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+            c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
+            assert int(_lib.lib.mfem_debug_lat27_spmv_count()) == c0 + 1
+            want = alpha * y0 + beta * 7.0
+            assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
 
 
 def test_values_that_are_not_symmetric_take_the_sliced_layout(mf, small_layouts):

@@ -45,14 +45,17 @@ def test_spmv_equals_the_csr_kernel(mf, small_layouts, dims):
     x = mf.FEM_rand(A.n, 3, 0) - 0.5
     y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
     mf.mul_(y0, A, K, x)
-    for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
-        y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
-        c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
-        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
-        assert int(_lib.lib.mfem_debug_lat8_spmv_count()) == c0 + 1
-        assert _lib.lib.mfem_debug_lat8_asymmetry(A._h) <= 1e-13  # per-row measure |y_layout - y_csr|_r / |a_rr| of the bind's probe (gate: 4e-13)
-        want = alpha * y0 + beta * 7.0
-        assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+    # pass 2 by the kernel that walks the covering blocks (default) and by the staged gather (bit 2: all loads of a tile in flight at once): the same sums
+    for knob in (1, 1 | 4):
+        _lib.lib.mfem_debug_set_lat8(knob)
+        for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
+            y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+            c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
+            assert int(_lib.lib.mfem_debug_lat8_spmv_count()) == c0 + 1
+            assert _lib.lib.mfem_debug_lat8_asymmetry(A._h) <= 1e-13  # per-row measure |y_layout - y_csr|_r / |a_rr| of the bind's probe (gate: 4e-13)
+            want = alpha * y0 + beta * 7.0
+            assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
 
 
 def test_values_that_are_not_symmetric_take_the_other_layout(mf, small_layouts):
