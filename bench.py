@@ -596,6 +596,14 @@ def main():
                                 "diagonal and the entries with column > row are stored and read (14..63 of a row's 27..125); x and y of a tile of "
                                 "8 x 8 x 32 lattice points in LDS, mirrored products added there (ds_add_f64); the second launch sums the tiles' y blocks "
                                 "in a fixed order; y equals the CSR kernel's to round-off"), "k_spmv_lat27"
+                if cfg["solver"] == "cg" and world == 1 and lat_used and _lib.lib.mfem_debug_lat27_cg_fused():
+                    # one rank: the CG iteration runs pass 2 inside its residual update (k_lat27_gather_cg); the SpMV launch the library times is pass 1
+                    kernel, kkey = ("k_spmv_lat27 (pass 1 of the SpMV; pass 2 -- the sums over the tiles' y blocks -- runs inside the CG residual update, "
+                                    "k_lat27_gather_cg, and p . A p comes from pass 1: A p is never stored): symmetric lattice tiles of the hex-27 matrix, copy made "
+                                    "once per solve; the values passed the per-solve symmetry measure (probe product against the CSR kernel within 4e-13 max |A[r][c]|), "
+                                    "so only the diagonal and the entries with column > row are stored and read (14..63 of a row's 27..125); x and y of a tile of "
+                                    "8 x 8 x 32 lattice points in LDS, mirrored products added there (ds_add_f64)"), "k_spmv_lat27_pass1"
+                    spmv_bytes = int(_lib.lib.mfem_debug_lat27_pass1_bytes(A._h))
             elif mode.value == 5:
                 kernel, kkey = ("k_spmv_lat8 + k_lat8_gather (two launches per SpMV): symmetric lattice tiles of the 3-field 27-point matrix, copy made "
                                 "once per solve; the values passed the per-solve symmetry measure (probe product against the CSR kernel within 4e-13 max |a|), so per node only "
@@ -636,11 +644,15 @@ def main():
                         "+ x as the kernel stages it (patch sweep: overlapping patch neighbourhoods, 1.6 n entries) + y "
                         "(mfem_csr_solver_layout_bytes); the plain diagonal-slotted kernel reads "
                         "plain_diagonal_kernel_bytes_per_launch"}
-               if r["sym_used"] and r["kernel_key"] not in ("k_spmv_lat27", "k_spmv_lat8") else {}),
+               if r["sym_used"] and r["kernel_key"] not in ("k_spmv_lat27", "k_spmv_lat27_pass1", "k_spmv_lat8") else {}),
             **({"note": "algorithmic bytes = what this kernel pair moves by design (mfem_csr_solver_layout_bytes): 8 B per stored entry (diagonal + upper "
                         "entries, padded to 68 wave steps per 128 rows, units cut by the lattice edge included) + x as the tiles stage it (4 320 cells per "
                         "2 048 rows) + the tiles' y blocks written and read again + y"}
                if r["kernel_key"] == "k_spmv_lat27" else {}),
+            **({"note": "algorithmic bytes = what pass 1 moves by design (mfem_debug_lat27_pass1_bytes): 8 B per stored entry (diagonal + upper entries, padded "
+                        "to 68 wave steps per 128 rows, units cut by the lattice edge included) + x as the tiles stage it (4 320 cells per 2 048 rows) + the "
+                        "tiles' y blocks written; reading them back is part of the residual update kernel's bytes"}
+               if r["kernel_key"] == "k_spmv_lat27_pass1" else {}),
             **({"note": "algorithmic bytes = what this kernel pair moves by design (mfem_csr_solver_layout_bytes): 8 B per stored entry (123 per node, "
                         "padded to 124 wave steps per 64 nodes, units cut by the lattice edge included) + x and the Jacobi scaling as the tiles stage them "
                         "(1 620 cells per field per 1 024 nodes) + the tiles' y blocks written and read again + y"}

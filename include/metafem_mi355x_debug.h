@@ -41,6 +41,11 @@ int mfem_debug_set_ell(int enable);
 int mfem_debug_set_sell(int enable);
 /* mode 4 (symmetric lattice tiles, hex-27): 0 = off (mode 3 serves those solves), 1 = on (default). */
 int mfem_debug_set_lat27(int enable);  /* bit 1: pass 2 (the gather of the tiles' y blocks) by the kernel that walks the covering blocks one memory round trip at a time (same y bit for bit) */
+/* bit 2 of mfem_debug_set_lat27: CG iterations on the tiles as SpMV (pass 1 + pass 2) + residual update; by default, on one rank, pass 2 runs INSIDE the residual
+ * update (k_lat27_gather_cg: A p is never stored, p . A p comes from pass 1) -- the same iterates to round-off.  mfem_debug_lat27_cg_fused: that switch;
+ * mfem_debug_lat27_pass1_bytes: what pass 1 alone moves by design (the SpMV launch bench.py times in that mode). */
+int mfem_debug_lat27_cg_fused(void);
+int64_t mfem_debug_lat27_pass1_bytes(mfem_csr A);
 /* SpMVs mode 4 has served so far, process-wide */
 long long mfem_debug_lat27_spmv_count(void);
 /* max |layout x - CSR x| / max |A[r][c]| of the probe product of the last mode-4 bind on this pattern (mode 4 is taken up to 4e-13) */

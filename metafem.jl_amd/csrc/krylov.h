@@ -12,6 +12,32 @@ enum {
 // device flags (ctx->d_flags)
 enum { F_DONE = 0, F_ITER = 1, F_AUX = 2 };
 
+// 1 / d to ~1 ulp for a normal, non-zero d: v_rcp_f64 (about 24 good bits) + two Newton steps -- 5 instructions where the IEEE
+// division sequence takes ~14.  Used where r = z / dinv only feeds the dot products of the z-carrying recurrences.
+__device__ __forceinline__ double mfem_recip_nr(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+
+// what the fused pass 2 + residual update of the lattice tiles (spmv_lat27.hip: k_lat27_gather_cg) needs of a CG iteration: the fields of CgArgs that k_cg_update reads,
+// the iteration's scalar bank, the vectors.  S[S_PAP] must hold p . A p (folded from mfem_lat27_dot_partials) when the kernel runs.
+struct LatCgUpdate {
+  int32_t zrec, cur;
+  const double* sw;
+  double smax2, gate2, n_inv;
+  const double* dinv;
+  double* r;
+  const double* S;
+  const int32_t* flags;
+  double* partials2;  // [0, grid) r.z, [grid, 2 grid) r.r
+};
+bool mfem_lat27_cg_fused(const mfem_context_s* ctx, const mfem_csr_s* A, const double* vals);
+const double* mfem_lat27_dot_partials(const mfem_csr_s* A, int* np);
+int mfem_lat27_gather_cg_update(mfem_context_s* ctx, mfem_csr_s* A, const LatCgUpdate& U, int grid);
+
 struct KrylovVecs {
   int64_t n, nv;
   double* x;

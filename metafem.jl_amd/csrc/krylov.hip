@@ -233,15 +233,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_cg_init_fin(CgArgs a, const doub
   }
 }
 
-// 1 / d to ~1 ulp for a normal, non-zero d: v_rcp_f64 (about 24 good bits) + two Newton steps -- 5 instructions where the IEEE
-// division sequence takes ~14.  Used where r = z / dinv only feeds the dot products of the z-carrying recurrences.
-__device__ __forceinline__ double recip_nr(double d) {
-  double y = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-d, y, 1.0);
-  return fma(y, e, y);
-}
+__device__ __forceinline__ double recip_nr(double d) { return mfem_recip_nr(d); }  // (krylov.h)
 
 // alpha = rz / p.Ap ; x += alpha p ; r -= alpha Ap ; partials2: [0,G) r.z  [G,2G) r.r   (z = r .* dinv)
 template <int NT>
@@ -393,6 +385,8 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
   key = mfem_hash(key, dinv); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations); key = mfem_hash(key, a.zrec);
   key = mfem_hash(key, V.cg_s); key = mfem_hash(key, a.smax2); key = mfem_hash(key, a.gate2);
+  const bool lat_fused = mfem_lat27_cg_fused(ctx, A, vals);  // (lattice tiles of the hex-27 matrix, one rank: pass 2 inside the residual update)
+  key = mfem_hash(key, (int)lat_fused);
   int it = 0;
   // flag banks: iteration `it` reads bank it & 1 (k_cg_init_fin fills bank 0) and leaves the next state in the other one
   for (;;) {
@@ -410,6 +404,26 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
       int np1 = 0;
       // with a communicator: the exchange of p's boundary planes runs beside the rows that need no ghost entry, and every
       // reduction group is one fold kernel + one all-reduce
+      if (lat_fused) {
+        // lattice tiles, one rank: pass 1 (its blocks stay in the dump, p . A p comes as one partial per tile), the fold of the partials, then pass 2 and
+        // the residual update in one kernel (spmv_lat27.hip: k_lat27_gather_cg) -- A p itself is never stored
+        int rc = mfem_spmv_halo(ctx, A, vals, p, nullptr, 1.0, 0.0, p, part1, &np1, F);
+        if (rc) return rc;
+        int npt = 0;
+        const double* tp = mfem_lat27_dot_partials(A, &npt);
+        rc = mfem_fold_list(ctx, FoldList{{tp}, {npt}, 1}, S + S_PAP, F);
+        if (rc) return rc;
+        np1 = 0;
+        const LatCgUpdate U{a.zrec, cur, (const double*)a.sw, a.smax2, a.gate2, a.n_inv, dinv, r, S, F, part2};
+        rc = mfem_lat27_gather_cg_update(ctx, A, U, G);
+        if (rc) return rc;
+#define CG_PUPDATE_F(NT_) hipLaunchKernelGGL(k_cg_pupdate<NT_>, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, 0, part2, G, (const d2_t*)r, \
+                                             (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F, Fn)
+        if (nt == 1) CG_PUPDATE_F(1); else if (nt == 2) CG_PUPDATE_F(2); else CG_PUPDATE_F(0);
+#undef CG_PUPDATE_F
+        MFEM_CHECK_LAUNCH();
+        return MFEM_OK;
+      }
       int rc = mfem_spmv_halo(ctx, A, vals, p, Ap, 1.0, 0.0, p, part1, &np1, F);
       if (rc) return rc;
       int np2 = G;

@@ -26,6 +26,7 @@
 //     an LDS cell is not fixed: results are reproducible to ~1e-16 relative, not bitwise (mfem_debug_set_lat27(0) selects the sliced layout).
 #include "blas1.h"
 #include "spmv_lat_tables.h"
+#include "krylov.h"  // scalar / flag slots of the Krylov loop (the fused CG update below)
 
 #define L27_TI 8
 #define L27_TJ 8
@@ -41,6 +42,7 @@ typedef double l_d2 __attribute__((ext_vector_type(2)));
 
 extern std::atomic<int64_t> g_layout_min_rows_lat27;  // spmv_ell.hip
 static std::atomic<int> g_lat27_enable{1};
+static std::atomic<int> g_lat27_cg_fused{1};  // bit 2 of mfem_debug_set_lat27: 0 = CG iterations as SpMV (pass 1 + pass 2) + k_cg_update instead of pass 1 + k_lat27_gather_cg
 static std::atomic<int> g_lat27_gather_staged{1};  // bit 1 of mfem_debug_set_lat27: 0 = pass 2 by k_lat27_gather (masked blocks, a round trip per covering block)
 static std::atomic<long long> g_lat27_count{0};
 extern "C" long long mfem_debug_lat27_spmv_count(void) { return g_lat27_count; }  // SpMVs the layout has served (bench.py: which kernel ran)
@@ -50,6 +52,7 @@ extern "C" int mfem_debug_set_lat27(int enable) try {
   ++mfem_debug_epoch;
   g_lat27_enable = enable & 1;
   g_lat27_gather_staged = ((enable >> 1) & 1) ? 0 : 1;
+  g_lat27_cg_fused = ((enable >> 2) & 1) ? 0 : 1;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_lat27")
 
@@ -329,12 +332,15 @@ __device__ __forceinline__ void l27_unit(l_d2 (&A)[8], l_d2 (&B)[8], const doubl
 // (+2, +-2, +-2) neighbourhood.
 // dsc != nullptr: the operator is A D^-1 (right Jacobi scaling, Mat_Div_Jacobi of 02_Preconditioner.jl:141-148): the stored matrix stays the
 // symmetric A and x is divided by d while it is staged.
+// dotp != nullptr (the fused CG iteration, no column scaling): dotp[tile] = sum over the tile's block of x(cell) * y-contribution(cell); summed over the tiles that is
+// x . A x -- every contribution to y[r] sits in exactly one cell of one block, beside the x[r] the tile staged -- so the dot product of a CG iteration needs no pass 2.
 __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double* __restrict__ vals, const double* __restrict__ x,
                                                        const double* __restrict__ dsc, double* __restrict__ dump,
-                                                       const int32_t* __restrict__ done_flag, int tile0, int tcount) {
+                                                       const int32_t* __restrict__ done_flag, int tile0, int tcount, double* __restrict__ dotp) {
   __shared__ double xs[L27_LDS_CELLS];
   __shared__ double ys[L27_LDS_CELLS];
   __shared__ uint32_t tabs[L27_TAB / 2];
+  __shared__ double dred[8];
   if (done_flag && done_flag[0]) return;
   // workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch): each XCD walks a contiguous eighth of the tiles, so the
   // neighbourhoods that overlap are staged through one L2
@@ -378,9 +384,16 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double
   }
   __syncthreads();
   double* dt = dump + (int64_t)tile * L27_CELLS;
+  double dacc = 0.0;
   for (int e = tid; e < L27_CELLS; e += 512) {
     const int li = e / (L27_SJ * L27_SK);
-    dt[e] = ys[e + 8 * li];
+    const double yv = ys[e + 8 * li];
+    dt[e] = yv;
+    dacc += yv * xs[e + 8 * li];
+  }
+  if (dotp) {  // (kernel argument: every thread of the workgroup takes the same way)
+    const double d = block_reduce_sum(dacc, dred);
+    if (tid == 0) dotp[tile] = d;
   }
 }
 
@@ -562,6 +575,106 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather_st(Lat27Geom G, con
   }
 }
 
+// The fused CG iteration on the lattice tiles (one rank): pass 2 and the residual update of Jacobi-CG in one kernel.  q = A p is needed twice in a CG iteration --
+// in p . q, which pass 1 now delivers (k_spmv_lat27: dotp), and in r -= alpha q -- so the sums over the covering blocks are formed here, used and never stored:
+// no y written and read back, no separate gather launch (3 of the iteration's vector streams and one launch less).  Staging and summation order are
+// k_lat27_gather_st's; the update arithmetic is k_cg_update's (krylov.hip), operation for operation.
+__global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather_cg(Lat27Geom G, const double* __restrict__ dump, LatCgUpdate U) {
+  __shared__ double E[L27_ECELLS];
+  __shared__ double red[4];
+  if (U.flags[F_DONE]) return;
+  const double alpha = U.S[S_RZ0 + U.cur] / U.S[S_PAP];
+  const bool exact = U.sw && U.S[S_RR] * U.n_inv <= U.gate2;
+  double rz = 0.0, rr = 0.0;
+  const int ntiles = G.nti * G.ntj * G.ntk;
+  const int lk = threadIdx.x & (L27_TK - 1), lj = threadIdx.x >> 5;
+  const int PC = L27_SJ * L27_SK;
+  auto ext = [](int e, int T, int& off, int& l) {
+    if (e < T) { off = 0; l = e; }
+    else if (e < T + 2) { off = -1; l = e - T; }
+    else { off = 1; l = e - 4; }
+  };
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // (the trip count is the workgroup's: every barrier below is reached by all threads)
+    const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+    double t[L27_EU];
+#pragma unroll
+    for (int u = 0; u < L27_EU; ++u) {
+      const int e = threadIdx.x + u * MFEM_BLOCK;
+      t[u] = 0.0;
+      if (e < L27_ECELLS) {
+        const int ei = e / (L27_EJ * L27_EK), r2 = e - ei * (L27_EJ * L27_EK), ej = r2 / L27_EK, ek = r2 - ej * L27_EK;
+        int b, c, sj, sk;
+        ext(ej, L27_TJ, b, sj);
+        ext(ek, L27_TK, c, sk);
+        const int a = ei < L27_TI ? 0 : -1;
+        const bool ok = (a == 0 || ti > 0) && (b == 0 || (b < 0 ? tj > 0 : tj < G.ntj - 1)) && (c == 0 || (c < 0 ? tk > 0 : tk < G.ntk - 1));
+        if (ok)
+          t[u] = __builtin_nontemporal_load(dump + (((int64_t)(ti + a) * G.ntj + (tj + b)) * G.ntk + (tk + c)) * L27_CELLS + ei * PC +
+                                            (sj - L27_TJ * b + 2) * L27_SK + (sk - L27_TK * c + 2));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < L27_EU; ++u) {
+      const int e = threadIdx.x + u * MFEM_BLOCK;
+      if (e < L27_ECELLS) E[e] = t[u];
+    }
+    __syncthreads();
+    const int gj = tj * L27_TJ + lj, gk = tk * L27_TK + lk, gi0 = ti * L27_TI;
+    if (gj < G.m1 && gk < G.m2) {
+      double s[L27_TI];
+#pragma unroll
+      for (int u = 0; u < L27_TI; ++u) s[u] = 0.0;
+      for (int b = -1; b <= 1; ++b) {
+        if ((b < 0 && (lj >= 2 || tj == 0)) || (b > 0 && (lj < L27_TJ - 2 || tj == G.ntj - 1))) continue;
+        const int ej = b == 0 ? lj : b < 0 ? L27_TJ + lj : lj + 4;
+        for (int c = -1; c <= 1; ++c) {
+          if ((c < 0 && (lk >= 2 || tk == 0)) || (c > 0 && (lk < L27_TK - 2 || tk == G.ntk - 1))) continue;
+          const int ek = c == 0 ? lk : c < 0 ? L27_TK + lk : lk + 4;
+          const double* d = E + ej * L27_EK + ek;
+          if (ti > 0) {
+            s[0] += d[8 * (L27_EJ * L27_EK)];
+            s[1] += d[9 * (L27_EJ * L27_EK)];
+          }
+#pragma unroll
+          for (int u = 0; u < L27_TI; ++u) s[u] += d[u * (L27_EJ * L27_EK)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < L27_TI; ++u) {
+        if (gi0 + u < G.m0) {
+          const int64_t i = ((int64_t)(gi0 + u) * G.m1 + gj) * G.m2 + gk;
+          const double av = s[u];  // (A p)[i]
+          double rv, z;
+          if (U.zrec && U.dinv) {  // the array holds z: z -= alpha dinv .* Ap ; r = z ./ dinv for the two dot products only
+            const double dv = U.dinv[i];
+            z = U.r[i] - alpha * (av * dv);
+            U.r[i] = z;
+            rv = dv != 0.0 ? z * mfem_recip_nr(dv) : 0.0;
+          } else {
+            rv = U.r[i] - alpha * av;
+            U.r[i] = rv;
+            z = U.dinv ? rv * U.dinv[i] : rv;
+          }
+          rz += rv * z;
+          if (exact) {
+            const double tt = U.sw[i] * rv;
+            rr += tt * tt;
+          } else {
+            rr += rv * rv;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the staged values are consumed: the next tile's may land
+  }
+  const double s0 = block_reduce_sum(rz, red);
+  const double s1 = block_reduce_sum(rr, red);
+  if (threadIdx.x == 0) {
+    U.partials2[blockIdx.x] = s0;
+    U.partials2[gridDim.x + blockIdx.x] = (U.sw && !exact) ? s1 * U.smax2 : s1;
+  }
+}
+
 static Lat27Geom lat27_geom(const mfem_csr_s* A) {
   Lat27Geom G{};
   G.m1 = A->lat_m1;
@@ -696,7 +809,7 @@ static size_t lat27_dump_doubles(const Lat27Geom& G) { return (size_t)G.nti * G.
 size_t mfem_lat27_bytes(const mfem_csr_s* A) {
   if (A->lat27_state != 1 || !g_lat27_enable || A->n < g_layout_min_rows_lat27) return 0;
   const Lat27Geom G = lat27_geom(A);
-  return sizeof(double) * (lat27_vals_doubles(G) + lat27_dump_doubles(G));
+  return sizeof(double) * (lat27_vals_doubles(G) + lat27_dump_doubles(G) + (size_t)G.nti * G.ntj * G.ntk);  // (+ one dot-product partial per tile: the fused CG iteration)
 }
 
 struct Lat27Bind { double *vals, *dump; const double* src; };
@@ -766,9 +879,22 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
   const int tile0 = part == 2 ? tb : 0;
   const int tcount = part == 1 ? tb : ntiles - tile0;
   const int chunk = (tcount + 7) / 8;
+  if (!y) {
+    // the fused CG iteration (mfem_lat27_cg_fused): pass 1 alone, the tiles' blocks stay in the dump for mfem_lat27_gather_cg_update, x . A x comes out
+    // as one partial per tile behind the dump
+    MFEM_REQUIRE(part == 0 && dotw == x && alpha == 1.0 && beta == 0.0 && !A->lat27_dsc, "lattice tiles: pass 1 alone serves only the fused CG iteration");
+    double* dotp = A->lat27_dump + lat27_dump_doubles(G);
+    hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, (const double*)nullptr, A->lat27_dump, done_flag, 0, ntiles,
+                       dotp);
+    MFEM_CHECK_LAUNCH();
+    (void)partials;  // (the caller reads the partials where mfem_lat27_dot_partials says)
+    if (n_partials) *n_partials = ntiles;
+    if (!ctx->probe_active) ++g_lat27_count;
+    return 1;
+  }
   if (tcount > 0) {
     hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag,
-                       tile0, tcount);
+                       tile0, tcount, (double*)nullptr);
     MFEM_CHECK_LAUNCH();
   }
   if (part == 1) return 1;  // (the gather pass belongs to part 2)
@@ -797,3 +923,26 @@ int64_t mfem_lat27_design_bytes(const mfem_csr_s* A) {
   return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_scaled ? 4 : 3) + A->n * 8;
 }
 int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_vals_doubles(lat27_geom(A)); }
+
+// ---- the fused CG iteration (krylov.hip, cg_solve_pass): pass 1 alone (mfem_spmv_halo with y = nullptr), the dot-product partials, pass 2 + residual update
+bool mfem_lat27_cg_fused(const mfem_context_s* ctx, const mfem_csr_s* A, const double* vals) {
+  return g_lat27_cg_fused && mfem_lat27_bound(A, vals) && !A->lat27_dsc && !ctx->comm;
+}
+const double* mfem_lat27_dot_partials(const mfem_csr_s* A, int* np) {
+  const Lat27Geom G = lat27_geom(A);
+  *np = G.nti * G.ntj * G.ntk;
+  return A->lat27_dump + lat27_dump_doubles(G);
+}
+int mfem_lat27_gather_cg_update(mfem_context_s* ctx, mfem_csr_s* A, const LatCgUpdate& U, int grid) {
+  const Lat27Geom G = lat27_geom(A);
+  hipLaunchKernelGGL(k_lat27_gather_cg, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const double*)A->lat27_dump, U);
+  MFEM_CHECK_LAUNCH();
+  return MFEM_OK;
+}
+// (accounting for bench.py) is the fused CG iteration on, and what pass 1 alone moves by design: the stored entries, x as the tiles stage it, the y blocks written
+extern "C" int mfem_debug_lat27_cg_fused(void) { return g_lat27_cg_fused; }
+extern "C" int64_t mfem_debug_lat27_pass1_bytes(mfem_csr A) {
+  if (!A || A->lat27_state != 1) return -1;
+  const Lat27Geom G = lat27_geom(A);
+  return (int64_t)lat27_vals_doubles(G) * 8 + (int64_t)G.nti * G.ntj * G.ntk * L27_CELLS * 8 * 2;
+}

@@ -115,6 +115,30 @@ def test_solvers(mf, small_layouts):
         assert np.abs(sol[1] - sol[0]).max() <= 1e-9 * np.abs(sol[0]).max(), name
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+def test_fused_cg_iteration_equals_spmv_plus_update(mf, small_layouts, variant):
+    """One rank, CG on the lattice tiles: pass 2 runs inside the residual update (k_lat27_gather_cg: A p is never stored, p . A p comes from pass 1).
+    Bit 2 of mfem_debug_set_lat27 restores SpMV (pass 1 + pass 2) + k_cg_update: the same iterates to round-off for every recurrence (classic,
+    z-carrying, scaled), with and without the Jacobi preconditioner, after a fixed number of iterations and at convergence."""
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 0.8, 1.2), (9, 10, 17), 2, 5)   # tiles cut by the lattice in every direction, two tile layers in i
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    for kw in (dict(), dict(Pr_func=mf.Identity)):
+        for fixed in (True, False):
+            sol = {}
+            for knob in (1, 1 | 4):
+                _lib.lib.mfem_debug_set_lat27(knob)
+                c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+                x, st = mf.iterative_Solve(A, K, rhs, 1e-30 if fixed else 1e-11, Sv_func=mf.cg_, maxiter=25 if fixed else 3000, max_pass=1 if fixed else 4,
+                                           fixed_iterations=fixed, cg_variant=variant, **kw)
+                assert int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0
+                assert fixed or st.converged
+                sol[knob] = x.cpu().numpy()
+            assert np.abs(sol[1] - sol[1 | 4]).max() <= 1e-11 * np.abs(sol[1 | 4]).max(), (variant, kw, fixed)
+
+
 def test_a_solve_whose_values_are_refused_starts_over_on_the_other_layouts(mf, small_layouts):
     """The sliced layout is planned only after the lattice tiles have refused values of the pattern once (mfem_solve then starts over); later
     symmetric solves on the same pattern take the tiles again."""

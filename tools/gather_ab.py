@@ -31,8 +31,13 @@ K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
 s = torch.full((A.n,), 1600.0, dtype=torch.float64, device="cuda")
 R = b.residual_thermal(torch.zeros(A.n, dtype=torch.float64, device="cuda"), 0.6, 25.0, 293.15, 0x3F, s=s)
 c4 = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, maxiter=200, max_pass=1, fixed_iterations=True)[1].solve_ms
+xs = {}
 for rnd in range(2):
-    for knob, tag in ((1, "staged"), (1 | 2, "walking")):
+    for knob, tag in ((1, "fused CG iteration (pass 2 inside the residual update)"), (1 | 4, "staged pass 2"), (1 | 4 | 2, "walking pass 2")):
         _lib.lib.mfem_debug_set_lat27(knob)
-        print(f"C4 pass 2 {tag:8s}: solve {best(c4):.2f} ms", flush=True)
+        print(f"C4 {tag:56s}: solve {best(c4):.2f} ms", flush=True)
+        xs[tag] = mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.cg_, maxiter=200, max_pass=1, fixed_iterations=True)[0]
 _lib.lib.mfem_debug_set_lat27(1)
+ks = list(xs)
+for k in ks[1:]:
+    print(f"C4 x after 200 iterations, {ks[0][:5]} against {k[:7]}: max |dx| / max |x| = {float((xs[ks[0]] - xs[k]).abs().max() / xs[k].abs().max()):.2e}", flush=True)
