@@ -23,7 +23,7 @@ __device__ __forceinline__ double mfem_recip_nr(double d) {
 }
 
 // what the fused pass 2 + residual update of the lattice tiles (spmv_lat27.hip: k_lat27_gather_cg) needs of a CG iteration: the fields of CgArgs that k_cg_update reads,
-// the iteration's scalar bank, the vectors.  S[S_PAP] must hold p . A p (folded from mfem_lat27_dot_partials) when the kernel runs.
+// the iteration's scalar bank, the vectors, and p . A p as the partials pass 1 left (mfem_lat27_dot_partials).
 struct LatCgUpdate {
   int32_t zrec, cur;
   const double* sw;
@@ -33,6 +33,8 @@ struct LatCgUpdate {
   const double* S;
   const int32_t* flags;
   double* partials2;  // [0, grid) r.z, [grid, 2 grid) r.r
+  const double* pap_partials;  // p . A p: np partials (mfem_lat27_dot_partials), or np = 0 and the sum in S[S_PAP]
+  int32_t np;
 };
 bool mfem_lat27_cg_fused(const mfem_context_s* ctx, const mfem_csr_s* A, const double* vals);
 const double* mfem_lat27_dot_partials(const mfem_csr_s* A, int* np);

@@ -410,14 +410,11 @@ static int cg_solve_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals,
         int rc = mfem_spmv_halo(ctx, A, vals, p, nullptr, 1.0, 0.0, p, part1, &np1, F);
         if (rc) return rc;
         int npt = 0;
-        const double* tp = mfem_lat27_dot_partials(A, &npt);
-        rc = mfem_fold_list(ctx, FoldList{{tp}, {npt}, 1}, S + S_PAP, F);
-        if (rc) return rc;
-        np1 = 0;
-        const LatCgUpdate U{a.zrec, cur, (const double*)a.sw, a.smax2, a.gate2, a.n_inv, dinv, r, S, F, part2};
+        const double* tp = mfem_lat27_dot_partials(A, &npt);  // (one per tile; both kernels below fold them themselves, like the partials of any other SpMV)
+        const LatCgUpdate U{a.zrec, cur, (const double*)a.sw, a.smax2, a.gate2, a.n_inv, dinv, r, S, F, part2, tp, npt};
         rc = mfem_lat27_gather_cg_update(ctx, A, U, G);
         if (rc) return rc;
-#define CG_PUPDATE_F(NT_) hipLaunchKernelGGL(k_cg_pupdate<NT_>, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, part1, 0, part2, G, (const d2_t*)r, \
+#define CG_PUPDATE_F(NT_) hipLaunchKernelGGL(k_cg_pupdate<NT_>, dim3(G), dim3(MFEM_BLOCK), 0, ctx->stream, a, cur, tp, npt, part2, G, (const d2_t*)r, \
                                              (const d2_t*)dinv, (d2_t*)p, (d2_t*)V.x, S, F, Fn)
         if (nt == 1) CG_PUPDATE_F(1); else if (nt == 2) CG_PUPDATE_F(2); else CG_PUPDATE_F(0);
 #undef CG_PUPDATE_F

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_lat27_gather_cg(Lat27Geom G, con
   __shared__ double E[L27_ECELLS];
   __shared__ double red[4];
   if (U.flags[F_DONE]) return;
-  const double alpha = U.S[S_RZ0 + U.cur] / U.S[S_PAP];
+  const double pap = U.np > 0 ? reduce_partials_bcast(U.pap_partials, U.np, red) : U.S[S_PAP];  // (as k_cg_update / k_cg_pupdate: every workgroup folds the partials itself)
+  const double alpha = U.S[S_RZ0 + U.cur] / pap;
   const bool exact = U.sw && U.S[S_RR] * U.n_inv <= U.gate2;
   double rz = 0.0, rr = 0.0;
   const int ntiles = G.nti * G.ntj * G.ntk;
