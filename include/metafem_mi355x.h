@@ -109,7 +109,8 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
  *           keeps the matrix unscaled (cg!, or no Jacobi scaling): symmetric lattice tiles -- only the diagonal and the entries with
  *           column > row are stored (14..63 of a row's 27..125), 16 rows of each of the 8 node types per wave, x and y of a tile of
  *           8 x 8 x 32 lattice points staged in LDS, the mirrored products added there; a second pass sums the tiles' y blocks in a
- *           fixed order.  Taken per solve only if the values are symmetric: the bind compares one probe product of the layout with the CSR
+ *           fixed order (for cg! on one rank that pass runs inside the residual update of the iteration and p . A p comes from the first pass: A p
+ *           is never stored; same iterates to round-off).  Taken per solve only if the values are symmetric: the bind compares one probe product of the layout with the CSR
  *           kernel's (x in [0.75, 1.25): an entry pair that differs by delta shows up as >= 0.75 |delta|) and requires
  *           max |difference| <= 4e-13 max |A[r][c]| (mode 3 serves the solve otherwise).  y agrees with the CSR kernel to round-off (other summation order), not bitwise, and not
  *           bitwise from run to run.  A right Jacobi scaling (A D^-1) is applied to x while it is staged; the stored matrix stays A.
