@@ -44,6 +44,16 @@ for _ in range(3):
 solve()
 # C3 / C4: the same solve once more on the layouts the lattice tiles replaced (modes 2 / 3), so that one pass prices both kernels
 from metafem_jl_amd import _lib
+if cfg == "c4":
+    # the two-pass MFMA assembly (what a mesh with a non-affine element takes: this mesh is assembled without it, k_hex27_direct) and the CG iteration as
+    # SpMV pass 1 + pass 2 + update (this solve fused pass 2 into the update), so that the counters of those kernels exist too
+    _lib.lib.mfem_debug_set_hex27(1 << 9)
+    for _ in range(2):
+        b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F, out=K)
+    _lib.lib.mfem_debug_set_hex27(0)
+    _lib.lib.mfem_debug_set_lat27(1 | 4)
+    solve()
+    _lib.lib.mfem_debug_set_lat27(1)
 if cfg in ("c3", "c4"):
     _lib.lib.mfem_debug_set_lat27(0)
     _lib.lib.mfem_debug_set_lat8(0)
