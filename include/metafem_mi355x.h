@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MFEM_ABI_VERSION 4
+#define MFEM_ABI_VERSION 5
 
 typedef enum {
   MFEM_OK = 0,
@@ -296,15 +296,23 @@ typedef struct {
   double h;            /* h*Bilinear(T, Tenv - T) on robin_faces     :31 */
   double Tenv;
   uint32_t robin_faces;
+  /* ABI 5: weakly imposed (Nitsche-type) Dirichlet faces, the reference's own way of fixing a temperature --
+   *   h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i}) on fixed_faces     thermal_conduction/2D_Script.jl:58
+   * with k the conductivity above.  The second term couples a face node's row to ALL nodes of the host element and has no mirrored
+   * counterpart: K is NONSYMMETRIC wherever fixed_faces != 0 (cg! is then not applicable; idrs! / bicgstabl_GS! as in the script). */
+  uint32_t fixed_faces;
+  double h_penalty;
+  double Tw;
 } mfem_thermal_params;
 
 /* K_linear_func for the thermal weak form: vals (CSR order of mfem_brick_pattern(.., 1, ..)) =
- *   sum_el sum_q w (-k) dN_a.dN_b + sum_facets sum_q w^s (-h) N_a N_b.   Overwrites vals. */
+ *   sum_el sum_q w (-k) dN_a.dN_b + sum_robin sum_q w^s (-h) N_a N_b + sum_fixed sum_q w^s N_a (-h_penalty N_b + k n.grad N_b).
+ * Overwrites vals. */
 int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
                                 double* vals);
 /* K_nonlinear_func (residual part) for the same form, evaluated matrix-free at x_star:
- *   residue[a] = sum_q w(-k dN_a.dT + N_a s) + sum_q w^s N_a h (Tenv - T).   s = nodal source
- * (CONTROLPOINT_VAR `s`, may be NULL = 0).  Overwrites residue. */
+ *   residue[a] = sum_q w(-k dN_a.dT + N_a s) + sum_robin w^s N_a h (Tenv - T) + sum_fixed w^s N_a (h_penalty (Tw - T) + k n.grad T).
+ * s = nodal source (CONTROLPOINT_VAR `s`, may be NULL = 0).  Overwrites residue. */
 int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const mfem_thermal_params* p,
                                 const double* x_star, const double* s, double* residue);
 

@@ -369,17 +369,22 @@ class Brick:
         return A
 
     def assemble_thermal(self, A: FEM_SpMat_CSR, k: float, h: float = 0.0, Tenv: float = 0.0,
-                         robin_faces: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         robin_faces: int = 0, out: Optional[torch.Tensor] = None, *, fixed_faces: int = 0,
+                         h_penalty: float = 0.0, Tw: float = 0.0) -> torch.Tensor:
+        """K_linear_func of -k*Bilinear(T{;i},T{;i}) + h*Bilinear(T, Tenv - T) on robin_faces
+        (examples/thermal_conduction/3D_Script.jl:30-31) + the weakly imposed Dirichlet faces
+        h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i}) on fixed_faces (2D_Script.jl:58; K is nonsymmetric then)."""
         vals = out if out is not None else torch.empty(A.nnz, dtype=torch.float64, device=f"cuda:{self.ctx.device}")
-        p = ThermalParams(k, h, Tenv, robin_faces)
+        p = ThermalParams(k, h, Tenv, robin_faces, fixed_faces, h_penalty, Tw)
         check(lib.mfem_brick_assemble_thermal(self.ctx._h, self._h, A._h, C.byref(p), _ptr(vals)))
         return vals
 
     def residual_thermal(self, x_star: torch.Tensor, k: float, h: float = 0.0, Tenv: float = 0.0, robin_faces: int = 0,
-                         s: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         s: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, *, fixed_faces: int = 0,
+                         h_penalty: float = 0.0, Tw: float = 0.0) -> torch.Tensor:
         _need(x_star, torch.float64, "x_star", self.n_owned)
         res = out if out is not None else torch.empty(self.n_owned, dtype=torch.float64, device=x_star.device)
-        p = ThermalParams(k, h, Tenv, robin_faces)
+        p = ThermalParams(k, h, Tenv, robin_faces, fixed_faces, h_penalty, Tw)
         check(lib.mfem_brick_residual_thermal(self.ctx._h, self._h, C.byref(p), _ptr(x_star), _ptr(s), _ptr(res)))
         return res
 
@@ -444,8 +449,11 @@ class ThermalDomain:
     on a structured brick: the two generated closures are the fused HIP kernels, update_OneStep is the
     reference's Newton driver (04_Time_Domain.jl:59-80)."""
 
-    def __init__(self, brick: Brick, k: float, h: float, Tenv: float, robin_faces: int = ALL_FACES):
+    def __init__(self, brick: Brick, k: float, h: float, Tenv: float, robin_faces: int = ALL_FACES, *, fixed_faces: int = 0,
+                 h_penalty: float = 0.0, Tw: float = 0.0):
         self.brick, self.k, self.h, self.Tenv, self.robin_faces = brick, k, h, Tenv, robin_faces
+        # weakly imposed Dirichlet faces (fix_boundary of examples/thermal_conduction/2D_Script.jl:58)
+        self.fixed = dict(fixed_faces=fixed_faces, h_penalty=h_penalty, Tw=Tw)
         dev = f"cuda:{brick.ctx.device}"
         self.A = brick.pattern(1)  # assemble_Global_Variables! -> assemble_SparseID!
         n = self.A.n
@@ -463,10 +471,10 @@ class ThermalDomain:
         self.history = []
 
     def K_linear_func(self):
-        self.brick.assemble_thermal(self.A, self.k, self.h, self.Tenv, self.robin_faces, out=self.K_linear)
+        self.brick.assemble_thermal(self.A, self.k, self.h, self.Tenv, self.robin_faces, out=self.K_linear, **self.fixed)
 
     def K_nonlinear_func(self):
-        self.brick.residual_thermal(self.x_star, self.k, self.h, self.Tenv, self.robin_faces, s=self.s, out=self.residue)
+        self.brick.residual_thermal(self.x_star, self.k, self.h, self.Tenv, self.robin_faces, s=self.s, out=self.residue, **self.fixed)
 
     def update_OneStep(self, max_iter: int = 4):
         self.dx.zero_()  # initialize_dx! with max_time_level = 0

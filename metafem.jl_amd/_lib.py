@@ -46,7 +46,8 @@ class SolveStats(C.Structure):
 
 
 class ThermalParams(C.Structure):
-    _fields_ = [("k", c_double), ("h", c_double), ("Tenv", c_double), ("robin_faces", c_uint32)]
+    _fields_ = [("k", c_double), ("h", c_double), ("Tenv", c_double), ("robin_faces", c_uint32), ("fixed_faces", c_uint32),
+                ("h_penalty", c_double), ("Tw", c_double)]
 
 
 class ElasticityParams(C.Structure):

@@ -1387,12 +1387,16 @@ int mfem_hex8_upload_tables(int ng);
 int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s* A, const mfem_thermal_params* p, double* vals);
 int mfem_hex27_residual_thermal(mfem_context_s* ctx, mfem_brick_s* m, const mfem_thermal_params* p, const double* x_star,
                                 const double* s, double* residue);
+int mfem_brick_nitsche_faces(mfem_context_s* ctx, mfem_brick_s* m, bool matrix, const mfem_thermal_params* p, const double* xstar, double* out);
 
 extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_csr A, const mfem_thermal_params* p,
                                            double* vals) try {
   MFEM_REQUIRE(ctx && m && A && p && vals, "null argument");
   MFEM_REQUIRE(A->n == m->n_owned, "pattern was not built for 1 field on this brick");
-  if (m->p == 2) return mfem_hex27_assemble_thermal(ctx, m, A, p, vals);  // FP64 MFMA Ke = B^T D B path
+  if (m->p == 2) {  // FP64 MFMA Ke = B^T D B path
+    const int rc27 = mfem_hex27_assemble_thermal(ctx, m, A, p, vals);
+    return rc27 ? rc27 : mfem_brick_nitsche_faces(ctx, m, true, p, nullptr, vals);
+  }
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
@@ -1412,13 +1416,16 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
     hipLaunchKernelGGL(k_thermal_matrix_robin, boundary_grid(m), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->h, p->robin_faces, vals);
     MFEM_CHECK_LAUNCH();
   }
-  return MFEM_OK;
+  return mfem_brick_nitsche_faces(ctx, m, true, p, nullptr, vals);
 } MFEM_API_CATCH("mfem_brick_assemble_thermal")
 
 extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const mfem_thermal_params* p,
                                            const double* x_star, const double* s, double* residue) try {
   MFEM_REQUIRE(ctx && m && p && x_star && residue, "null argument");
-  if (m->p == 2) return mfem_hex27_residual_thermal(ctx, m, p, x_star, s, residue);
+  if (m->p == 2) {
+    const int rc27 = mfem_hex27_residual_thermal(ctx, m, p, x_star, s, residue);
+    return rc27 ? rc27 : mfem_brick_nitsche_faces(ctx, m, false, p, x_star, residue);
+  }
   int rc = mfem_hex8_upload_tables(m->ng);
   if (rc) return rc;
   BrickView B = mfem_brick_view(m, 1);
@@ -1442,7 +1449,7 @@ extern "C" int mfem_brick_residual_thermal(mfem_context ctx, mfem_brick m, const
                        p->Tenv, p->robin_faces, x_star, s, residue);
   }
   MFEM_CHECK_LAUNCH();
-  return MFEM_OK;
+  return mfem_brick_nitsche_faces(ctx, m, false, p, x_star, residue);
 } MFEM_API_CATCH("mfem_brick_residual_thermal")
 
 static std::atomic<int> g_elasticity_variant{0};  // bit 0: the matrix row-owner kernel with in-place global accumulation; bit 1: the residual kernel that integrates per adjacent control point (both kept for comparison)
