@@ -138,6 +138,16 @@ int mfem_debug_ws_trial_log(mfem_context ctx, double* out4);
  * mfem_last_error() set and leaves every handle valid.  0 disarms.  tests/test_gpu_round4_abi.py. */
 int mfem_debug_fail_host_alloc(int nth);
 
+/* A = S + N (round 5, csrc/spmv_rem.hip): a symmetric lattice-tile bind (modes 4 / 5) whose values fail the symmetry gate in at most n / 8 rows keeps
+ * the tiles and carries the mirrored entries' differences N[r][c] = A[r][c] - A[c][r] of those rows as a small CSR applied after the tiles' gather pass
+ * (Nitsche / SUPG faces: the reference's nonsymmetric K).  Bit 0 (default 1): on; 0 -- such values send the solve to the layouts that read every entry, as
+ * before.  Bit 1 (default 0): the diagnostic product mfem_spmv_solver_layout, which answers for cg!, takes a remainder too (tests).
+ * mfem_debug_remainder_info: rows / entries of the remainder the CURRENT or last bind on this pattern carries (0 / 0: none), and the asymmetry the
+ * probe measured on the tiles alone; mfem_debug_rem_spmv_count: products that applied one (process-wide). */
+int mfem_debug_set_remainder(int enable);
+int mfem_debug_remainder_info(mfem_csr A, int64_t* rows /* [host] */, int64_t* entries /* [host] */, double* asym_before /* [host] */);
+long long mfem_debug_rem_spmv_count(void);
+
 #ifdef __cplusplus
 }
 #endif

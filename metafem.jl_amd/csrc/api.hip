@@ -43,10 +43,10 @@ int mfem_api_exception(const char* entry) noexcept {
 
 // countdown to an injected host allocation failure: 0 = off, k = the k-th probed allocation from now throws (once)
 static std::atomic<int> g_fail_host_alloc{0};
-extern "C" int mfem_debug_fail_host_alloc(int nth) {
+extern "C" int mfem_debug_fail_host_alloc(int nth) try {
   g_fail_host_alloc.store(nth > 0 ? nth : 0);
   return MFEM_OK;
-}
+} MFEM_API_CATCH("mfem_debug_fail_host_alloc")
 void mfem_host_alloc_probe() {
   int v = g_fail_host_alloc.load();
   while (v > 0) {
@@ -297,9 +297,9 @@ int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {
   int rcf = ws_free(ctx->ws_raw);
   if (!rcf) rcf = ws_free(ctx->ws_alt_raw);
   ctx->ws = ctx->ws_raw = ctx->ws_alt = ctx->ws_alt_raw = nullptr;
-  if (rcf) return rcf;
   ctx->ws_try = 0;  // (a new allocation: undecided again)
-  ctx->ws_bytes = 0;
+  ctx->ws_bytes = 0;  // (BEFORE the early return: a failed free must not leave a size behind that lets a later, smaller request succeed on a null workspace)
+  if (rcf) return rcf;
   rcf = ws_alloc(ctx, &ctx->ws_raw, bytes + g_ws_align + g_ws_offset);
   if (rcf) return rcf;
   uintptr_t p = (uintptr_t)ctx->ws_raw;

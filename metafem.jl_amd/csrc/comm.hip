@@ -97,9 +97,20 @@ extern "C" int mfem_prof_comm_enable(mfem_context ctx, int on) try {
   if (!c) return MFEM_OK;  // nothing to time on one rank
   if (on && c->backend == 0 && !c->pev) {
     mfem_host_alloc_probe();
-    c->pev = new hipEvent_t[2 * COMM_PROF_PAIRS]();
-    c->pkind = new unsigned char[COMM_PROF_PAIRS]();
-    for (int i = 0; i < 2 * COMM_PROF_PAIRS; ++i) MFEM_CHECK_HIP(hipEventCreate(&c->pev[i]));
+    hipEvent_t* ev = new hipEvent_t[2 * COMM_PROF_PAIRS]();
+    unsigned char* kd = new unsigned char[COMM_PROF_PAIRS]();
+    for (int i = 0; i < 2 * COMM_PROF_PAIRS; ++i) {
+      const hipError_t e = hipEventCreate(&ev[i]);
+      if (e != hipSuccess) {  // nothing half-made stays behind: the timers of the all-reduce / halo path would record on null events
+        for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
+        delete[] ev;
+        delete[] kd;
+        mfem_set_error("mfem_prof_comm_enable: hipEventCreate -> %s", hipGetErrorString(e));
+        return MFEM_ERR_HIP;
+      }
+    }
+    c->pev = ev;
+    c->pkind = kd;
   }
   if (!on && c->backend == 0) {
     int rc = comm_prof_flush(c);

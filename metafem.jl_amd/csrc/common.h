@@ -112,6 +112,7 @@ struct mfem_context_s {
   hipStream_t graph_stream;
   hipEvent_t graph_ev;
   int graph_active;   // set by mfem_solve for the duration of a solve when cycles may be captured
+  int force_csr;      // set while a product must run the CSR kernel on the caller's arrays whatever layout is bound (the residual a tile solve reports, krylov.hip)
   int probe_active;   // set while a measuring product runs on this context (symmetry probe, placement trial): not an SpMV a solver asked for -- the usage counters skip it
 };
 #define MFEM_PROF_PAIRS 1024
@@ -204,11 +205,33 @@ struct mfem_csr_s {
   double* lat8_dump;
   double lat8_asym;
   int lat8_scaled;
+  // A = S + N (spmv_rem.hip): the sparse skew remainder a lattice-tile bind carries when the values are nonsymmetric in a few rows only (Nitsche / SUPG
+  // faces): owned device storage, grown on demand and kept between solves; rem_active: the CURRENT bind applies it after the tiles' gather pass
+  int rem_active;
+  int64_t rem_nrows, rem_nent, rem_cap_rows, rem_cap_ent;
+  int32_t* rem_rows;   // [rem_nrows] the rows of N
+  int64_t* rem_ptr;    // [rem_nrows] first entry of each
+  int32_t* rem_len;    // [rem_nrows] entries of each
+  int32_t* rem_col;    // [rem_nent] 0-based columns
+  double* rem_val;     // [rem_nent] A[r][c] - A[c][r]
+  unsigned long long* rem_cnt;  // device counters of the build
+  double rem_asym_before;       // what the probe measured on the tiles alone (the asymmetry the remainder repairs)
+  int64_t rem_last_rows, rem_last_ent;  // what the last ACCEPTED remainder of the last probe held (0: none) -- survives the unbind at the end of a solve (tests, bench.py)
 };
+bool mfem_rem_enabled();
+bool mfem_rem_diag();
+void mfem_rem_clear(mfem_csr_s* A);
+void mfem_rem_free(mfem_csr_s* A);
+int mfem_rem_build(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, int n_fields, const double* y1, const double* y2, const double* scale,
+                   double gate, bool* built);
+int mfem_rem_apply(mfem_context_s* ctx, mfem_csr_s* A, const double* x, const double* dsc, double* y, double alpha, const double* dotw,
+                   double* partials, int* n_partials, const int32_t* done_flag);
+int64_t mfem_rem_design_bytes(const mfem_csr_s* A);
 int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A);
 bool mfem_lat8_for_method(const mfem_csr_s* A, bool is_cg);  // one-field matrices: only the solvers that work on A D^-1 (cg! keeps the bitwise patch sweep)
 size_t mfem_lat8_bytes(const mfem_csr_s* A);
-int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles
+// binds symmetric values, or -- allow_rem -- values whose asymmetry a sparse remainder (spmv_rem.hip) repairs; scratch: 3 n doubles
+int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch, bool allow_rem = false);
 void mfem_lat8_unbind(mfem_csr_s* A);
 bool mfem_lat8_bound(const mfem_csr_s* A, const double* vals);
 int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha, double beta,
@@ -226,9 +249,11 @@ static inline int mfem_lat_first_ghost_layer(int m0, int gw, int nti, bool has_u
 }
 int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_lat27_bytes(const mfem_csr_s* A);
-int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch);  // binds only symmetric values; scratch: 3 n doubles
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch, bool allow_rem = false);
+// rem_fields > 0: rows above the gate may be repaired by a remainder built for that many fields (then *asym is the measure of tiles + remainder and
+// A->rem_active is set); 0: symmetric values only
 int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
-                   void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym);
+                   void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym, int rem_fields = 0);
 void mfem_lat27_unbind(mfem_csr_s* A);
 bool mfem_lat27_bound(const mfem_csr_s* A, const double* vals);
 int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, const double* x, double* y, double alpha,

@@ -95,6 +95,9 @@ inline uint64_t mfem_csr_graph_key(uint64_t key, const mfem_csr_s* A) {
   // the column scaling the lattice-tile kernels apply to x is a kernel argument too: a solve with right Jacobi (dsc = the solve's d) and one without
   // (dsc = null) on the same pattern, values and workspace must not share a captured cycle
   key = mfem_hash(key, A->lat27_dsc); key = mfem_hash(key, A->lat8_dsc);
+  // ... and so are the arrays of the skew remainder a tile bind may carry (spmv_rem.hip)
+  key = mfem_hash(key, A->rem_active);
+  if (A->rem_active) { key = mfem_hash(key, A->rem_nrows); key = mfem_hash(key, A->rem_rows); key = mfem_hash(key, A->rem_col); key = mfem_hash(key, A->rem_val); }
   key = mfem_hash(key, mfem_debug_epoch.load());
   return key;
 }

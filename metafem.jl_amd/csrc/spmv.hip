@@ -857,6 +857,7 @@ static void csr_drop_plans(mfem_csr_s* A) {
   }
   mfem_ell_free(A);
   mfem_sell_free(A);
+  mfem_rem_free(A);
   A->lat27_state = 0;
   A->sym_state = 0;
   A->symp_state = 0;
@@ -980,6 +981,7 @@ extern "C" int mfem_csr_destroy(mfem_csr A) try {
   if (A->ctx && mfem_context_alive(A->ctx)) mfem_graphs_invalidate(A->ctx);
   mfem_ell_free(A);
   mfem_sell_free(A);
+  mfem_rem_free(A);
   if (A->rb_rows) hipFree(A->rb_rows);
   if (A->cw_elide) hipFree(A->cw_elide);
   if (A->diag_off) hipFree(A->diag_off);
@@ -1124,7 +1126,7 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
                              const int32_t* done_flag, const SpmvPart& part) {
   if (n_partials) *n_partials = 0;
   if (A->n == 0) return MFEM_OK;
-  {
+  if (!ctx->force_csr) {
     const int l8 = mfem_spmv_lat8_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part.part);
     if (l8 != 0) return l8 < 0 ? l8 : MFEM_OK;
     const int e = mfem_spmv_ell_launch(ctx, A, vals, x, y, alpha, beta, dotw, partials, n_partials, done_flag, part);

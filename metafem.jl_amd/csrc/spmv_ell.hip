@@ -1362,7 +1362,26 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_dia_outside(int64_t n, int6
 }
 
 // Decide eligibility and build the column table (once per pattern).  A->max_row_nnz must be known (mfem_csr_plan).
+static int ell_plan_body(mfem_context_s* ctx, mfem_csr_s* A);
 int mfem_ell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  // The inspection allocates on the host (std::vector, mfem_host_alloc_probe) after it has begun to record its verdict: an exception on the way
+  // must leave the pattern UNPLANNED -- the next solve inspects again -- not half-planned on the slower path for good.  Same for an error return.
+  if (A->ell_state != 0) return MFEM_OK;
+  struct Undo {
+    mfem_csr_s* A;
+    bool armed;
+    ~Undo() {
+      if (!armed) return;
+      mfem_ell_free(A);  // (also resets ell_state / dia_state to "not inspected")
+      A->sym_state = 0;
+      A->symp_state = 0;
+    }
+  } undo{A, true};
+  const int rc = ell_plan_body(ctx, A);
+  if (!rc) undo.armed = false;
+  return rc;
+}
+static int ell_plan_body(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->ell_state != 0) return MFEM_OK;
   if (A->n < g_layout_min_rows_dia && A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes: CSR tile kernel
   A->ell_state = -1;
@@ -2084,7 +2103,8 @@ extern "C" int mfem_spmv_solver_layout(mfem_context ctx, mfem_csr A, const doubl
       rc = mfem_ws_reserve(ctx, lay + (2 * (size_t)A->n + (size_t)(A->ncols > A->n ? A->ncols : A->n)) * sizeof(double));
       if (rc) return rc;
       double* scratch = (double*)((char*)ctx->ws + lay);
-      rc = is27 ? mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch) : mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch);
+      rc = is27 ? mfem_lat27_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch, mfem_rem_diag())
+                : mfem_lat8_bind(ctx, A, vals, (double*)ctx->ws, nullptr, scratch, mfem_rem_diag());
       if (rc) return rc;
       bound = mfem_lat27_bound(A, vals) || mfem_lat8_bound(A, vals);
     }

@@ -240,7 +240,10 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_probe_diff(int64_t n, const doub
 // scratch: ncols + 2 n doubles (x carries the ghost entries of a slab pattern).  The layout must be bound for `vals` with no column scaling; unbind() must leave the pattern without any bound layout
 // (the second product then runs the CSR kernel).  *asym = max over rows of |y1 - y2|_r / |a_rr| (rows without a non-zero diagonal: / amax).
 int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* scratch, double amax, void (*unbind)(mfem_csr_s*),
-                   void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym) {
+                   void (*rebind)(mfem_csr_s*, void*), void* cookie, double* asym, int rem_fields) {
+  A->rem_active = 0;
+  A->rem_asym_before = 0.0;
+  A->rem_last_rows = A->rem_last_ent = 0;
   const int64_t n = A->n, nc = A->ncols > n ? A->ncols : n;
   double *x = scratch, *y1 = scratch + nc, *y2 = y1 + n;
   unsigned long long* d_stat = (unsigned long long*)(ctx->d_flags + 12);
@@ -275,6 +278,34 @@ int mfem_sym_probe(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   double dmax;
   memcpy(&dmax, ctx->h_flags + 12, sizeof(double));
   *asym = dmax;  // already relative: max_r |y1 - y2|_r / |a_rr|
+  A->rem_asym_before = dmax;
+  if (dmax <= 4e-13 || rem_fields <= 0 || !(dmax < __builtin_huge_val())) return MFEM_OK;
+  // A = S + N (spmv_rem.hip): the rows above the gate get a remainder N[r][c] = A[r][c] - A[c][r] on their mirrored entries; accepted when the SAME
+  // probe passes on S + N.  (x holds the rows' weights now, y1 / y2 the two products.)
+  bool built = false;
+  rc = mfem_rem_build(ctx, A, vals, rem_fields, y1, y2, x, 4e-13, &built);
+  if (rc || !built) return rc;
+  hipLaunchKernelGGL(k_probe_vector, dim3(mfem_vec_grid(ctx, nc)), dim3(MFEM_BLOCK), 0, ctx->stream, nc, x);  // the probe vector again (the weights took its place)
+  MFEM_CHECK_LAUNCH();
+  ctx->probe_active = 1;
+  rc = mfem_rem_apply(ctx, A, x, nullptr, y1, 1.0, nullptr, nullptr, nullptr, nullptr);
+  ctx->probe_active = 0;
+  if (!rc) rc = mfem_fill(ctx, n, amax, x);
+  if (!rc) rc = mfem_jacobi_diag_launch(ctx, A, vals, x, 0);
+  if (rc) return rc;
+  MFEM_CHECK_HIP(hipMemsetAsync(d_stat, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(k_probe_diff, dim3(mfem_vec_grid(ctx, n)), dim3(MFEM_BLOCK), 0, ctx->stream, n, y1, y2, x, d_stat);
+  MFEM_CHECK_LAUNCH();
+  MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stat, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double dmax2;
+  memcpy(&dmax2, ctx->h_flags + 12, sizeof(double));
+  if (dmax2 <= 4e-13) {
+    *asym = dmax2;
+    A->rem_active = 1;
+    A->rem_last_rows = A->rem_nrows;
+    A->rem_last_ent = A->rem_nent;
+  }
   return MFEM_OK;
 }
 
@@ -824,7 +855,7 @@ static void lat27_probe_rebind(mfem_csr_s* A, void* c) {
 
 // Makes the layout copy of `vals` in buf and binds it if the values are symmetric (mfem_sym_probe; else leaves the pattern unbound: the caller
 // binds the sliced layout instead).  scratch: 3 n doubles, left dirty.  Two stream synchronisations (max |a|, the verdict).
-int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch) {
+int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch, bool allow_rem) {
   mfem_lat27_unbind(A);
   if (A->lat27_state != 1 || !g_lat27_enable || !buf || !scratch) return MFEM_OK;
   const Lat27Geom G = lat27_geom(A);
@@ -846,7 +877,7 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
   Lat27Bind B{buf, buf + lat27_vals_doubles(G), vals};
   lat27_probe_rebind(A, &B);
   double asym = 1.0;
-  int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat27_probe_unbind, lat27_probe_rebind, &B, &asym);
+  int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat27_probe_unbind, lat27_probe_rebind, &B, &asym, allow_rem ? 1 : 0);
   A->lat27_asym = asym;
   if (rc || !(asym <= 4e-13)) {  // not symmetric (or NaN): the sliced layout serves this solve
     mfem_lat27_unbind(A);
@@ -860,6 +891,7 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
 bool mfem_lat27_bound(const mfem_csr_s* A, const double* vals) { return A->lat27_vals && vals == A->lat27_src; }
 
 void mfem_lat27_unbind(mfem_csr_s* A) {
+  if (A->lat27_vals) A->rem_active = 0;  // (the remainder belongs to the bind)
   A->lat27_vals = nullptr;
   A->lat27_dump = nullptr;
   A->lat27_src = nullptr;
@@ -913,6 +945,10 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
 #undef L27_GATHER
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
+  if (A->rem_active) {  // A = S + N: the skew remainder of the few nonsymmetric rows (spmv_rem.hip)
+    const int rcr = mfem_rem_apply(ctx, A, x, A->lat27_dsc, y, alpha, dotw, partials, n_partials, done_flag);
+    if (rcr) return rcr;
+  }
   if (!ctx->probe_active) ++g_lat27_count;
   return 1;
 }
@@ -921,13 +957,13 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
 int64_t mfem_lat27_design_bytes(const mfem_csr_s* A) {
   const Lat27Geom G = lat27_geom(A);
   const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
-  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_scaled ? 4 : 3) + A->n * 8;
+  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_scaled ? 4 : 3) + A->n * 8 + mfem_rem_design_bytes(A);
 }
 int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_vals_doubles(lat27_geom(A)); }
 
 // ---- the fused CG iteration (krylov.hip, cg_solve_pass): pass 1 alone (mfem_spmv_halo with y = nullptr), the dot-product partials, pass 2 + residual update
 bool mfem_lat27_cg_fused(const mfem_context_s* ctx, const mfem_csr_s* A, const double* vals) {
-  return g_lat27_cg_fused && mfem_lat27_bound(A, vals) && !A->lat27_dsc && !ctx->comm;
+  return g_lat27_cg_fused && mfem_lat27_bound(A, vals) && !A->lat27_dsc && !ctx->comm && !A->rem_active;
 }
 const double* mfem_lat27_dot_partials(const mfem_csr_s* A, int* np) {
   const Lat27Geom G = lat27_geom(A);

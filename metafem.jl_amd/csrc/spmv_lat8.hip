@@ -600,7 +600,7 @@ static void lat8_probe_rebind(mfem_csr_s* A, void* c) {
 
 // Makes the layout copy of `vals` in buf and binds it if the values are symmetric (mfem_sym_probe, spmv_lat27.hip).  dsc: right Jacobi scaling the
 // SpMV applies to x (nullptr: none); only the pointer is kept, it may be filled after the bind.  scratch: ncols + 2 n doubles, left dirty.
-int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch) {
+int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc, double* scratch, bool allow_rem) {
   mfem_lat8_unbind(A);
   if (A->lat8_state != 1 || !g_lat8_enable || !buf || !scratch) return MFEM_OK;
   const Lat8Geom G = lat8_geom(A);
@@ -625,7 +625,7 @@ int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   Lat8Bind B{buf, buf + lat8_vals_doubles(G), vals};
   lat8_probe_rebind(A, &B);
   double asym = 1.0;
-  int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat8_probe_unbind, lat8_probe_rebind, &B, &asym);
+  int rc = mfem_sym_probe(ctx, A, vals, scratch, amax, lat8_probe_unbind, lat8_probe_rebind, &B, &asym, allow_rem ? G.F : 0);
   A->lat8_asym = asym;
   if (rc || !(asym <= 4e-13)) {  // not symmetric (or NaN): the other layouts serve this solve
     mfem_lat8_unbind(A);
@@ -639,6 +639,7 @@ int mfem_lat8_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
 bool mfem_lat8_bound(const mfem_csr_s* A, const double* vals) { return A->lat8_vals && vals == A->lat8_src; }
 
 void mfem_lat8_unbind(mfem_csr_s* A) {
+  if (A->lat8_vals) A->rem_active = 0;  // (the remainder belongs to the bind)
   A->lat8_vals = nullptr;
   A->lat8_dump = nullptr;
   A->lat8_src = nullptr;
@@ -683,6 +684,10 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 #undef L8_GATHER
   MFEM_CHECK_LAUNCH();
   if (n_partials && partials) *n_partials = grid;
+  if (A->rem_active) {  // A = S + N: the skew remainder of the few nonsymmetric rows (spmv_rem.hip)
+    const int rcr = mfem_rem_apply(ctx, A, x, A->lat8_dsc, y, alpha, dotw, partials, n_partials, done_flag);
+    if (rcr) return rcr;
+  }
   if (!ctx->probe_active) ++g_lat8_count;
   return 1;
 }
@@ -691,6 +696,6 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
 int64_t mfem_lat8_design_bytes(const mfem_csr_s* A) {
   const Lat8Geom G = lat8_geom(A);
   const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
-  return (int64_t)lat8_vals_doubles(G) * 8 + tiles * G.F * L8_FC * 8 * (A->lat8_scaled ? 4 : 3) + A->n * 8;
+  return (int64_t)lat8_vals_doubles(G) * 8 + tiles * G.F * L8_FC * 8 * (A->lat8_scaled ? 4 : 3) + A->n * 8 + mfem_rem_design_bytes(A);
 }
 int64_t mfem_lat8_entries(const mfem_csr_s* A) { return (int64_t)lat8_vals_doubles(lat8_geom(A)); }

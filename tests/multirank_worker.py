@@ -26,7 +26,15 @@ CASES = {
     "thermal_hex8_small": ((11, 5, 4), 1, 3, 1),  # CSR tile kernel (default thresholds), uneven slabs
     "elasticity_hex8": ((12, 6, 5), 1, 3, 3),
     "thermal_hex27": ((8, 4, 3), 2, 5, 1),
+    # round 5: the reference's NONSYMMETRIC matrices on slabs -- Nitsche faces on x = 0 (asymmetric rows in rank 0's slab only: its tiles carry a remainder,
+    # the other ranks' do not) ...
+    "nitsche_hex8": ((40, 6, 5), 1, 3, 1),
+    "nitsche_hex27": ((20, 4, 3), 2, 5, 1),
+    # ... and an elasticity matrix whose rows in the first lattice planes are ALL perturbed: rank 0's tiles REFUSE the values (too many rows for a
+    # remainder) and its solve starts over on another layout while the other ranks keep theirs -- the start-over must issue no collective
+    "asym_one_slab_hex8": ((24, 6, 5), 1, 3, 3),
 }
+H_PEN, TW = 1000.0, 1173.15
 
 
 def main():
@@ -67,14 +75,34 @@ def main():
     m0, m1, m2 = gb.m
     pl = m1 * m2
     ncp = m0 * pl
+    nonsym = case.startswith("nitsche") or case.startswith("asym")
+    fix = dict(fixed_faces=mf.FACE_BITS["x0"], h_penalty=H_PEN, Tw=TW) if case.startswith("nitsche") else {}
+    robin = 0x3F & ~mf.FACE_BITS["x0"] if case.startswith("nitsche") else 0x3F
+
+    def perturb(K_, rowptr_, first_global_plane, n_rows_per_field):
+        """asym_one_slab: every entry of the rows in global lattice planes 0..3 scaled by 1 + 1e-3 u(global row, position in row) -- the same numbers
+        on the global matrix and on the slab that owns those planes (rows of a slab keep the global order of their entries)."""
+        if not case.startswith("asym"):
+            return K_
+        rp = rowptr_.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(rp.numel() - 1, device=dev), rp[1:] - rp[:-1])
+        posn = torch.arange(K_.numel(), device=dev) - rp[rows]
+        node = rows % n_rows_per_field
+        fld = rows // n_rows_per_field
+        gplane = node // pl + first_global_plane
+        gnode = node + first_global_plane * pl
+        u = (((fld * ncp + gnode) * 131 + posn * 7919) % 1000).to(torch.float64) / 1000.0
+        return torch.where(gplane < 4, K_ * (1.0 + 1e-3 * u), K_)
+
     if F == 1:
-        gK = gb.assemble_thermal(gA, K_COND, H, TENV, 0x3F)
+        gK = gb.assemble_thermal(gA, K_COND, H, TENV, robin, **fix)
         gs = torch.full((gA.n,), SRC, dtype=torch.float64, device=dev)
-        gR = gb.residual_thermal(torch.zeros(gA.n, dtype=torch.float64, device=dev), K_COND, H, TENV, 0x3F, s=gs)
+        gR = gb.residual_thermal(torch.zeros(gA.n, dtype=torch.float64, device=dev), K_COND, H, TENV, robin, s=gs, **fix)
     else:
         gK = gb.assemble_elasticity(gA, LAM, MU, TAU, mf.FACE_BITS["x0"])
         gR = gb.residual_elasticity(torch.zeros(gA.n, dtype=torch.float64, device=dev), LAM, MU, TAU, mf.FACE_BITS["x0"],
                                     mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.3))
+    gK = perturb(gK, gA.rowptr, 0, ncp)
     g_d = mf.jacobi_by_diagonal(gA, gK).cpu().numpy()
     g_dc = mf.jacobi2_by_column(gA, gK).cpu().numpy()
     g_shadow = mf.FEM_rand(8 * gA.n, 0x5EED, 7, ctx=gctx)  # shadow vectors of BiCGStab / IDR(8): the SAME global vectors on every layout
@@ -94,13 +122,15 @@ def main():
     assert A.n == F * n_owned and A.ncols == (nloc if world > 1 and (lo > 0 or hi < m0) else A.n), (A.n, A.ncols, nloc)
     comm = par.SlabComm(ctx, sb, rank, world, n_fields=F) if rccl else par.HostSlabComm(ctx, sb, rank, world, n_fields=F, poison=True)
     if F == 1:
-        K = sb.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+        K = sb.assemble_thermal(A, K_COND, H, TENV, robin, **fix)
         s_loc = torch.full((nloc,), SRC, dtype=torch.float64, device=dev)
-        R = sb.residual_thermal(torch.zeros(nloc, dtype=torch.float64, device=dev), K_COND, H, TENV, 0x3F, s=s_loc)
+        R = sb.residual_thermal(torch.zeros(nloc, dtype=torch.float64, device=dev), K_COND, H, TENV, robin, s=s_loc, **fix)
     else:
         K = sb.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
         R = sb.residual_elasticity(torch.zeros(nloc, dtype=torch.float64, device=dev), LAM, MU, TAU, mf.FACE_BITS["x0"],
                                    mf.FACE_BITS["y1"], (0.0, 1.0, 0.0, 0.0, 0.0, 0.3))
+
+    K = perturb(K, A.rowptr, lo, n_owned)
 
     def owned(gvec):  # the entries of a global field-major vector this rank owns, in local order
         gvec = np.asarray(gvec)
@@ -156,6 +186,36 @@ def main():
         xg_o = owned(xg_.cpu().numpy())
         scale = np.abs(xg_.cpu().numpy()).max()
         return float(np.abs(xl_.cpu().numpy() - xg_o).max() / scale)
+
+    if nonsym:
+        # ---- the reference's solvers on a nonsymmetric matrix (cg! does not apply) -----------------------------------------
+        lat8_0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+        lat27_0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+        rem_0 = int(_lib.lib.mfem_debug_rem_spmv_count())
+        for overlap in (1, 0):
+            _lib.lib.mfem_debug_set_halo_overlap(overlap)
+            tag = "overlap" if overlap else "blocking"
+            for sv, name, s_par in ((mf.bicgstabl_GS_, "bicgstabl2", 2), (mf.idrs_, "idrs8", 8)):
+                xg, sg = gsolve(sv, s=s_par, Pr_func=mf.Pr_Jacobi_)
+                x1, s1 = lsolve(sv, s=s_par, Pr_func=mf.Pr_Jacobi_)
+                check(f"{name}_diag_{tag}", s1.converged == 1 and sg.converged == 1 and relerr(x1, xg) <= 1e-8 and
+                      abs(s1.iterations - sg.iterations) <= max(4, sg.iterations // 10), iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
+        _lib.lib.mfem_debug_set_halo_overlap(1)
+        tiles = (int(_lib.lib.mfem_debug_lat8_spmv_count()) - lat8_0) + (int(_lib.lib.mfem_debug_lat27_spmv_count()) - lat27_0)
+        rem = int(_lib.lib.mfem_debug_rem_spmv_count()) - rem_0
+        if case.startswith("nitsche"):
+            # every rank ran its slab on the tiles (the global single-rank solves count too); only processes that hold the x = 0 planes applied a remainder
+            check("tiles_served_the_nonsymmetric_solves", tiles > 0, tiles=tiles)
+            check("remainder_applied", rem > 0, remainder_products=rem)
+        else:
+            # rank 0's slab refused (its first planes are perturbed in every row); the start-over ran without a hang -- that this line is reached is the test
+            check("solves_completed_with_a_rank_local_refusal", True, tiles=tiles, remainder_products=rem)
+        check("callbacks_ran", rccl or (comm.calls["exchange"] > 10 and comm.calls["allreduce"] > 10))
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        print("MULTIRANK_REPORT " + json.dumps(report), flush=True)
+        sys.exit(0 if ok else 1)
 
     # classic CG runs the same recurrence on every layout; what differs between 1 and `world` ranks is the order in which the
     # partial sums of the dot products are added.  1e-12 of max|x| for the thermal operators; the penalty-constrained

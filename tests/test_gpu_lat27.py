@@ -27,6 +27,7 @@ def small_layouts():
     yield _lib
     _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
     _lib.lib.mfem_debug_set_lat27(1)
+    _lib.lib.mfem_debug_set_remainder(1)
 
 
 @pytest.mark.parametrize("dims", [(3, 3, 3), (4, 4, 4), (3, 4, 5), (9, 5, 17), (5, 16, 4), (17, 9, 12), (1, 40, 3), (20, 20, 20)])
@@ -143,6 +144,7 @@ def test_a_solve_whose_values_are_refused_starts_over_on_the_other_layouts(mf, s
     """The sliced layout is planned only after the lattice tiles have refused values of the pattern once (mfem_solve then starts over); later
     symmetric solves on the same pattern take the tiles again."""
     _lib = small_layouts
+    _lib.lib.mfem_debug_set_remainder(0)  # (round 5: a single asymmetric entry would be repaired by a remainder and keep the tiles -- tests/test_gpu_remainder.py; this test is about the refusal path)
     b = mf.make_Brick((1.0, 1.0, 1.0), (8, 7, 6), 2, 5)
     A = b.pattern(1)
     K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)

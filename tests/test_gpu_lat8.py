@@ -28,6 +28,7 @@ def small_layouts():
     yield _lib
     _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
     _lib.lib.mfem_debug_set_lat8(1)
+    _lib.lib.mfem_debug_set_remainder(1)
 
 
 @pytest.mark.parametrize("dims", [(3, 3, 3), (4, 4, 4), (3, 4, 5), (9, 5, 17), (5, 16, 4), (17, 9, 12), (1, 40, 3), (20, 20, 20), (8, 8, 16), (7, 7, 15)])
@@ -115,6 +116,7 @@ def test_solvers(mf, small_layouts):
 
 def test_a_solve_whose_values_are_refused_starts_over_on_the_other_layouts(mf, small_layouts):
     _lib = small_layouts
+    _lib.lib.mfem_debug_set_remainder(0)  # (round 5: a single asymmetric entry would be repaired by a remainder and keep the tiles -- tests/test_gpu_remainder.py; this test is about the refusal path)
     b = mf.make_Brick((1.0, 1.0, 1.0), (9, 7, 6), 1, 3)
     A = b.pattern(3)
     K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])

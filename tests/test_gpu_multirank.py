@@ -85,6 +85,19 @@ def test_multirank_solve_equals_single_rank(case, world):
         assert "symmetric_sweep_kernel_ran" in names
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["nitsche_hex8", "nitsche_hex27", "asym_one_slab_hex8"])
+def test_multirank_nonsymmetric_solves(case, world):
+    """Round 5: the reference's nonsymmetric matrices on slabs.  nitsche_*: Nitsche face on x = 0 -- rank 0's lattice tiles carry a skew remainder
+    (spmv_rem.hip), the others none; bicgstabl_GS!(2) / idrs!(8) with Pr_Jacobi! equal the single-rank solve of the global problem (<= 1e-8, same
+    shadow vectors).  asym_one_slab: rank 0's tiles REFUSE its values while the other ranks keep theirs -- the rank-local start-over of mfem_solve
+    issues no collective (it used to repeat the n_global all-reduce and pair it with the other ranks' next collective)."""
+    reports = run_ranks(case, world)
+    names = set(reports[0]["checks"])
+    for need in ("bicgstabl2_diag_overlap", "idrs8_diag_overlap", "bicgstabl2_diag_blocking", "idrs8_diag_blocking"):
+        assert need in names, need
+
+
 def _n_gpus():
     import torch
 

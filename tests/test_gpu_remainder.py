@@ -1,0 +1,253 @@
+"""A = S + N (csrc/spmv_rem.hip): the symmetric lattice-tile layouts (solver layout modes 4 / 5) on the reference's own NONSYMMETRIC matrices.
+
+The reference fixes a temperature weakly -- h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i}), examples/thermal_conduction/2D_Script.jl:58 --
+which makes K nonsymmetric in the rows next to that face; its solvers are idrs! / bicgstabl_GS! with Pr_Jacobi! (02_Preconditioner.jl:32-76).  Round 4 sent
+every such solve to the layouts that read all entries; now the tiles keep serving it and the mirrored entries' differences of the few affected rows are
+applied as a small CSR behind them.  Every check is against the CSR kernel behind mul! (misc/04_GPU_Utils.jl:131) or the solve without the remainder:
+1e-13 relative for one product, 1e-12 for iterates after a fixed number of steps on the same shadow vectors, 1e-8 for converged solutions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K_COND, H, TENV = 0.6, 25.0, 293.15
+H_PEN, TW = 1000.0, 1173.15
+LAM, MU, TAU = 0.5769230769230769, 0.38461538461538464, 1000.0
+
+
+@pytest.fixture()
+def small_layouts():
+    from metafem_jl_amd import _lib
+
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    _lib.lib.mfem_debug_set_remainder(3)   # on, and the diagnostic product (which answers for cg!) takes it too
+    _lib.lib.mfem_debug_set_lat8(3)        # ... as it takes the one-field tiles
+    yield _lib
+    _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+    _lib.lib.mfem_debug_set_remainder(1)
+    _lib.lib.mfem_debug_set_lat8(1)
+    _lib.lib.mfem_debug_set_lat27(1)
+
+
+def _info(_lib, A):
+    rows, ent, asym = C.c_int64(), C.c_int64(), C.c_double()
+    _lib.check(_lib.lib.mfem_debug_remainder_info(A._h, C.byref(rows), C.byref(ent), C.byref(asym)))
+    return rows.value, ent.value, asym.value
+
+
+def _distort(brick):
+    import torch
+
+    c = [brick.coords_view(d).clone() for d in range(3)]
+    brick.coords_view(0).add_(0.03 * torch.sin(3 * c[1]) * torch.cos(2 * c[2]))
+    brick.coords_view(1).add_(0.02 * torch.sin(2 * c[0] + c[2]))
+    brick.coords_view(2).add_(0.025 * c[0] * c[1])
+
+
+def _nitsche_matrix(mf, order, dims, fixed, distorted=False, slab=None):
+    b = mf.make_Brick((1.0, 0.7, 1.3), dims, order, 3 if order == 1 else 5)
+    if slab:
+        b.set_slab(*slab)
+    if distorted:
+        _distort(b)
+    A = b.pattern(1)
+    robin = 0x3F & ~fixed
+    K = b.assemble_thermal(A, K_COND, H, TENV, robin, fixed_faces=fixed, h_penalty=H_PEN, Tw=TW)
+    return b, A, K
+
+
+X0, X1 = 1 << 4, 1 << 2   # reference local face ids 5 (x = 0) and 3 (x = L)
+
+
+# (the remainder is taken for at most n / 8 rows: these bricks are long in x so that the one or two lattice planes next to a fixed x face stay below that)
+@pytest.mark.parametrize("order,dims,fixed,distorted", [
+    (1, (40, 5, 9), X0, False), (1, (40, 5, 9), X0 | X1, True), (1, (33, 7, 15), X0, True), (1, (33, 7, 15), X0 | X1, False),
+    (1, (24, 8, 16), X1, True), (2, (12, 2, 3), X0, False), (2, (12, 2, 3), X1, True), (2, (16, 3, 2), X0 | X1, False), (2, (16, 3, 2), X0, True)])
+def test_product_of_tiles_plus_remainder_equals_the_csr_kernel(mf, small_layouts, order, dims, fixed, distorted):
+    import torch
+
+    _lib = small_layouts
+    b, A, K = _nitsche_matrix(mf, order, dims, fixed, distorted)
+    count = _lib.lib.mfem_debug_lat8_spmv_count if order == 1 else _lib.lib.mfem_debug_lat27_spmv_count
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    for alpha, beta in ((1.0, 0.0), (-2.5, 0.75)):
+        y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+        c0, r0 = int(count()), int(_lib.lib.mfem_debug_rem_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), alpha, beta))
+        assert int(count()) == c0 + 1, "the tiles did not serve the nonsymmetric values"
+        assert int(_lib.lib.mfem_debug_rem_spmv_count()) == r0 + 1
+        rows, ent, asym = _info(_lib, A)
+        assert 0 < rows <= A.n // 8 and ent >= rows and asym > 4e-13
+        want = alpha * y0 + beta * 7.0
+        assert float((want - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+    # the rows of N sit next to the fixed faces only: with x = 0 fixed on an undistorted brick exactly the second lattice plane(s)
+    if fixed == X0 and not distorted:
+        m = b.m
+        assert rows == order * m[1] * m[2]
+
+
+def test_without_the_remainder_the_same_values_are_refused(mf, small_layouts):
+    import torch
+
+    _lib = small_layouts
+    b, A, K = _nitsche_matrix(mf, 1, (40, 5, 9), X0)
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    y = torch.empty_like(x)
+    _lib.lib.mfem_debug_set_remainder(0)
+    c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+    assert int(_lib.lib.mfem_debug_lat8_spmv_count()) == c0
+    y0 = torch.empty_like(x)
+    mf.mul_(y0, A, K, x)
+    assert float((y - y0).abs().max()) <= 1e-13 * float(y0.abs().max())
+
+
+def test_three_fields_with_scattered_asymmetric_rows(mf, small_layouts):
+    """Elasticity (F = 3: the mirrored triangle is decided per NODE, then per field) with 1 % of the rows perturbed in one entry each, upper and lower
+    entries alike; then every second row: more than n / 8, the tiles refuse as before."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 1.0, 1.0), (12, 11, 10))
+    A = b.pattern(3)
+    K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    rp = A.rowptr.to(torch.int64)
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    for every, served in ((97, 1), (2, 0)):  # (many couplings of the uniform-grid operator are exact zeros: a perturbed zero stays zero)
+        rows = torch.arange(3, A.n, every, device="cuda")
+        pos = rp[rows] + (rows * 7) % (rp[rows + 1] - rp[rows])
+        K2 = K.clone()
+        K2[pos] *= 1.0 + 1e-4
+        mf.mul_(y0, A, K2, x)
+        c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K2.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+        assert int(_lib.lib.mfem_debug_lat8_spmv_count()) - c0 == served
+        assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+        if served:
+            nrows, ent, asym = _info(_lib, A)
+            assert 0 < nrows <= 2 * rows.numel() and asym > 1e-9
+
+
+@pytest.mark.parametrize("order,lo,hi", [(1, 0, 14), (1, 14, 28), (1, 28, 41), (2, 0, 18), (2, 18, 30), (2, 30, 41)])
+def test_slabs(mf, small_layouts, order, lo, hi):
+    """Slab patterns ([owned | ghost] columns) of a brick with Nitsche faces on x = 0 and x = L: the first and the last slab hold asymmetric rows, the
+    middle one none; ghost columns are never mirrored (the tiles read them from the stored triangle or the caller's CSR values), so the remainder is
+    rank-local."""
+    import torch
+    from metafem_jl_amd import parallel as par
+
+    _lib = small_layouts
+    n = (40, 9, 6) if order == 1 else (20, 6, 5)
+    fixed = X0 | X1
+    b, A, K = _nitsche_matrix(mf, order, n, fixed, distorted=False, slab=(lo, hi))
+    nloc = par.local_vector_length(lo, hi, order * n[1] + 1, order * n[2] + 1, 1, order=order)
+    assert nloc == A.ncols
+    x = mf.FEM_rand(nloc, 3, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    y1 = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+    count = _lib.lib.mfem_debug_lat8_spmv_count if order == 1 else _lib.lib.mfem_debug_lat27_spmv_count
+    c0 = int(count())
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y1.data_ptr(), 1.0, 0.0))
+    assert int(count()) == c0 + 1
+    assert (_info(_lib, A)[0] > 0) == (lo == 0 or hi == order * n[0] + 1)
+    assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())
+
+
+@pytest.mark.parametrize("order,dims", [(1, (24, 9, 10)), (2, (14, 3, 3))])
+def test_reference_solvers_keep_the_tiles_on_the_nitsche_matrix(mf, small_layouts, order, dims):
+    """idrs!(s = 8) -- the reference default (src/MetaFEM.jl:36-37) --, bicgstabl_GS!(2) and cgs2! with Pr_Jacobi! on the nonsymmetric K: the tiles + remainder
+    serve the solve (the right Jacobi scaling is applied to x for both parts); iterates after 6 fixed steps equal those of the solve on the layouts
+    that read every entry to 1e-12 (same shadow vectors), converged solutions to 1e-8; cg! is not offered the remainder."""
+    _lib = small_layouts
+    b, A, K = _nitsche_matrix(mf, order, dims, X0, distorted=True)
+    count = _lib.lib.mfem_debug_lat8_spmv_count if order == 1 else _lib.lib.mfem_debug_lat27_spmv_count
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    shadow = mf.FEM_rand(8 * A.n, 0x5EED, 7)
+    for name, kw, nsh in (("idrs8", dict(Sv_func=mf.idrs_, s=8), 8), ("bicgstabl2", dict(Sv_func=mf.bicgstabl_GS_, s=2), 1),
+                          ("cgs2", dict(Sv_func=mf.cgs2_), 1)):
+        fixed_x, conv_x = {}, {}
+        for rem in (1, 0):
+            _lib.lib.mfem_debug_set_remainder(rem)
+            c0, r0 = int(count()), int(_lib.lib.mfem_debug_rem_spmv_count())
+            x, st = mf.iterative_Solve(A, K, rhs, 1e-300, maxiter=6, max_pass=1, fixed_iterations=True, shadow=shadow[:nsh * A.n], **kw)
+            fixed_x[rem] = x
+            x, st = mf.iterative_Solve(A, K, rhs, 1e-11, maxiter=3000, max_pass=4, **kw)
+            assert st.converged == 1, (name, rem)
+            conv_x[rem] = x
+            assert (int(count()) > c0) == bool(rem), (name, rem)
+            assert (int(_lib.lib.mfem_debug_rem_spmv_count()) > r0) == bool(rem), (name, rem)
+        assert float((fixed_x[1] - fixed_x[0]).abs().max()) <= 1e-12 * float(fixed_x[0].abs().max()), name
+        assert float((conv_x[1] - conv_x[0]).abs().max()) <= 1e-8 * float(conv_x[0].abs().max()), name
+    _lib.lib.mfem_debug_set_remainder(1)
+    c0 = int(count())
+    mf.iterative_Solve(A, K, rhs, 1e-300, Sv_func=mf.cg_, maxiter=5, max_pass=1, fixed_iterations=True)
+    assert int(count()) == c0  # cg! on a nonsymmetric matrix is the caller's mistake: it keeps the reproducible layouts, as before
+
+
+def test_residual_reported_comes_from_the_callers_values_and_can_force_another_pass(mf, small_layouts):
+    """The residual that ends the passes is the CSR kernel's on the caller's values: with the tiles + remainder serving the solve the reported
+    final_res equals ||b - A x|| / sqrt(n) from mul!."""
+    import torch
+
+    _lib = small_layouts
+    _lib.lib.mfem_debug_set_remainder(1)
+    b, A, K = _nitsche_matrix(mf, 1, (12, 9, 10), X0)
+    rhs = mf.FEM_rand(A.n, 7, 0) - 0.5
+    r = torch.empty_like(rhs)
+    x, st = mf.iterative_Solve(A, K, rhs, 1e-9, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=4000, max_pass=4)
+    assert st.converged == 1
+    mf.mul_(r, A, K, x)
+    assert st.final_res == pytest.approx(mf.normalized_norm(r - rhs), rel=1e-6, abs=1e-16)
+
+
+def test_refusal_is_not_sticky(mf, small_layouts):
+    """after values the tiles had to REFUSE (too many asymmetric rows) later solves on the same handle -- symmetric values, or values a
+    remainder repairs -- are served by the tiles again; only the planning of the other layouts is remembered."""
+    import torch
+
+    _lib = small_layouts
+    _lib.lib.mfem_debug_set_remainder(1)
+    b, A, K = _nitsche_matrix(mf, 1, (12, 9, 10), X0)
+    Ksym = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    Kbad = K.clone()
+    Kbad[torch.arange(1, A.nnz, 7, device="cuda")] *= 1.0 + 1e-3   # every row touched: far more than n / 8
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    served = []
+    for vals in (Kbad, Ksym, K, Kbad, K):
+        c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+        x, st = mf.iterative_Solve(A, vals, rhs, 1e-10, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=3000, max_pass=4)
+        assert st.converged == 1
+        r = torch.empty_like(rhs)
+        mf.mul_(r, A, vals, x)
+        assert mf.normalized_norm(r - rhs) <= 2e-10
+        served.append(int(_lib.lib.mfem_debug_lat8_spmv_count()) > c0)
+    assert served == [False, True, True, False, True]
+
+
+def test_cycle_graphs_do_not_mix_solves_with_and_without_a_remainder(mf, small_layouts):
+    """The captured cycle of a small solve bakes the remainder's arrays into its kernel arguments: a symmetric solve and a Nitsche solve on the same
+    pattern, values buffer and workspace must each replay their own graph."""
+    import torch
+
+    _lib = small_layouts
+    _lib.lib.mfem_debug_set_remainder(1)
+    b, A, K = _nitsche_matrix(mf, 1, (12, 9, 10), X0)
+    Ksym = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    buf = torch.empty_like(K)
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    ref = {}
+    for name, vals in (("nitsche", K), ("sym", Ksym)):
+        _lib.lib.mfem_debug_set_graphs(0, 0)
+        ref[name] = mf.iterative_Solve(A, vals.clone(), rhs, 1e-11, Sv_func=mf.idrs_, s=4, maxiter=3000, max_pass=4)[0]
+    _lib.lib.mfem_debug_set_graphs(1, 0)
+    for name, vals in (("nitsche", K), ("sym", Ksym), ("nitsche", K), ("sym", Ksym)):
+        buf.copy_(vals)
+        x, st = mf.iterative_Solve(A, buf, rhs, 1e-11, Sv_func=mf.idrs_, s=4, maxiter=3000, max_pass=4)
+        assert st.converged == 1
+        assert float((x - ref[name]).abs().max()) <= 1e-8 * float(ref[name].abs().max()), name

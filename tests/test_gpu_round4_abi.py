@@ -8,6 +8,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _remainder_back_on():
+    """(tests that switch the skew remainder of the lattice tiles off must not leak that into later tests)"""
+    yield
+    from metafem_jl_amd import _lib
+
+    _lib.lib.mfem_debug_set_remainder(1)
+
 K_COND, H, TENV = 0.6, 25.0, 293.15
 LAM, MU = 0.5769230769230769, 0.38461538461538464
 MFEM_ERR_ALLOC = -6
@@ -102,6 +111,7 @@ def test_refused_lattice_tiles_with_no_other_layout_do_not_bind_the_unfilled_sca
     import torch
     from metafem_jl_amd import _lib
 
+    _lib.lib.mfem_debug_set_remainder(0)  # (round 5: these scattered asymmetries touch ~6 % of the rows -- a remainder would repair them and keep the tiles; the refusal path is what is under test)
     b = mf.make_Brick((1.0, 1.0, 1.0), (32, 32, 32), 2, 5)
     A = b.pattern(1)
     assert 180000 <= A.n < 1000000
@@ -127,6 +137,14 @@ def test_refused_lattice_tiles_with_no_other_layout_do_not_bind_the_unfilled_sca
     assert st.converged == 1 and int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0
     mf.mul_(r, A, K, x)
     assert mf.normalized_norm(r - rhs) <= 2e-10
+    # round 5: with the remainder on, the same nonsymmetric values keep the tiles at DEFAULT thresholds and give the same solution
+    _lib.lib.mfem_debug_set_remainder(1)
+    c1, r1 = int(_lib.lib.mfem_debug_lat27_spmv_count()), int(_lib.lib.mfem_debug_rem_spmv_count())
+    x, st = mf.iterative_Solve(A, K2, rhs, 1e-10, Sv_func=mf.bicgstabl_GS_, s=2, Pr_func=mf.Pr_Jacobi_, maxiter=4000, max_pass=4)
+    assert st.converged == 1 and int(_lib.lib.mfem_debug_lat27_spmv_count()) > c1 and int(_lib.lib.mfem_debug_rem_spmv_count()) > r1
+    mf.mul_(r, A, K2, x)
+    assert mf.normalized_norm(r - rhs) <= 2e-10
+    assert float((x - sols[0]).abs().max()) <= 1e-7 * float(sols[0].abs().max())
 
 
 def test_symmetry_gate_weighs_the_probe_per_row(mf):
