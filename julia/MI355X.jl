@@ -21,7 +21,7 @@ import LinearAlgebra
 
 # ---- library handle and error convention ---------------------------------------------------------------------------------
 const lib = get(ENV, "METAFEM_MI355X_LIB", joinpath(@__DIR__, "..", "metafem.jl_amd", "libmetafem_mi355x.so"))
-const ABI_VERSION = 4    # == MFEM_ABI_VERSION
+const ABI_VERSION = 5    # == MFEM_ABI_VERSION
 
 struct MFEMError <: Exception
     rc::Cint
@@ -81,11 +81,14 @@ struct SolveStats                         # == mfem_solve_stats
     spmv_count::Int32
 end
 
-struct ThermalParams                      # == mfem_thermal_params
+Base.@kwdef struct ThermalParams          # == mfem_thermal_params
     k::Float64
-    h::Float64
-    Tenv::Float64
-    robin_faces::UInt32
+    h::Float64 = 0.0
+    Tenv::Float64 = 0.0
+    robin_faces::UInt32 = 0x00
+    fixed_faces::UInt32 = 0x00            # ABI 5: h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i}) (thermal_conduction/2D_Script.jl:58)
+    h_penalty::Float64 = 0.0
+    Tw::Float64 = 0.0
 end
 
 struct ElasticityParams                   # == mfem_elasticity_params
@@ -194,7 +197,7 @@ end
 
 # ---- S1: the linear-solver seam --------------------------------------------------------------------------------------------
 const SOLVER_ID = Dict(:cg! => 0, :bicgstabl_GS! => 1, :idrs! => 2, :cgs2! => 3)
-const PR_ID = Dict(:Identity => 0, :Pr_Jacobi! => 1)
+const PR_ID = Dict(:Identity => 0, :Pr_Jacobi! => 1)      # (install! passes nameof(Pr_func!))
 const PL_ID = Dict(:Identity => 0, :Pl_Jacobi => 1)      # cylinder_flow/3D_MetaFEM_Script.jl:90 passes Pl_func = Pl_Jacobi
 
 """
@@ -388,5 +391,55 @@ set_slab!(b::Brick, plane_lo::Integer, plane_hi::Integer) =
 #     FEM_convert(::Type{ROC_DeviceArray}, src::AbstractArray{T, N}) where {T, N} = ROCArray{T, N}(src)
 # The solver `@eval` loops (02_Preconditioner.jl:30-31, 03_BiCGstabl.jl:16) then specialise for it; iterative_Solve! above replaces
 # their bodies for this array type.
+
+# ---- install!: the seams above as METHODS of MetaFEM's own functions, so that a script written for the reference runs as it is -------------------------
+"""
+    MI355X.install!(MetaFEM)
+
+Adds, inside the MetaFEM module, the ROCArray methods of the four seams (SURVEY.md section 8b) and makes ROCArray the default array type -- after it
+`fem_domain.linear_solver = x -> iterative_Solve!(x; Sv_func! = idrs!, maxiter = 2000, max_pass = 10, s = 8)` (every example script's line) lands in
+`mfem_solve`, and the generated updaters' `_Var_Basic` / `_Kval_Basic` / `_Res_Basic` calls (05_CodeGenerator.jl:9-10,33-34,77-78,112-113,138-139) in
+`mfem_op_*`.  julia/examples/thermal_3D.jl is the whole recipe: two lines, then `include` of the reference's own script.
+
+  S0  misc/04_GPU_Utils.jl:1-38        DEFAULT_ARRAYINFO._type, FEM_ArrayTypes, FEM_zeros / FEM_ones / FEM_rand / FEM_buffer / FEM_convert
+  S1  misc/04_GPU_Utils.jl:120,131     FEM_SpMat_CSR, mul!;  linear_solver/02_Preconditioner.jl:30-76  iterative_Solve!(::GlobalField{ROCArray})
+  S3  solver/06_FEM_Kernel.jl:1,28,65  the three operators on ROCArray arguments
+The solver selectors arrive as the reference's FUNCTIONS (`idrs!`, `Pr_Jacobi!`, `Pl_Jacobi`); they are mapped to the enum by name.
+
+Still Julia-side work for a maintainer (not bound here because their table layouts are MetaFEM-internal): update_BasicElements_{2,3}D /
+update_BasicBoundary_{2,3}D (mesh/unstructured_mesh/4_Update_Integrator.jl:2-75) -> mfem_update_basic_elements / _boundary, and assemble_SparseID!
+(solver/03_GlobalAssembly.jl:77-140) -> mfem_pattern_build; INTEGRATION.md shows both calls.
+"""
+function install!(MetaFEM::Module)
+    me = @__MODULE__
+    @eval MetaFEM begin
+        const ROC_DeviceArray{T, N} = $(AMDGPU.ROCArray){T, N}
+        DEFAULT_ARRAYINFO._type = ROC_DeviceArray
+        FEM_zeros(::Type{ROC_DeviceArray}, ::Type{T}, dims::Number...) where {T} = $(AMDGPU).zeros(T, dims...)
+        FEM_ones(::Type{ROC_DeviceArray}, ::Type{T}, dims::Number...) where {T} = $(AMDGPU).ones(T, dims...)
+        FEM_rand(::Type{ROC_DeviceArray}, ::Type{T}, dims::Number...) where {T} = $me.FEM_rand!($(AMDGPU.ROCArray){T}(undef, dims...))
+        FEM_buffer(::Type{ROC_DeviceArray}, ::Type{T}, dims::Number...) where {T} = $(AMDGPU).zeros(T, dims...)
+        FEM_convert(::Type{ROC_DeviceArray}, src::$(AMDGPU.ROCArray)) = src
+        FEM_convert(::Type{ROC_DeviceArray}, src::AbstractArray{T, N}) where {T, N} = $(AMDGPU.ROCArray){T, N}(src)
+        FEM_SpMat_CSR(J_ptr::$(AMDGPU.ROCArray), Js::$(AMDGPU.ROCArray), Ks::$(AMDGPU.ROCArray), dim::Tuple) = $me.FEM_SpMat_CSR(J_ptr, Js, Ks, dim)
+        mul!(b::$(AMDGPU.ROCArray){Float64, 1}, A::$me.SpMat_CSR, x::$(AMDGPU.ROCArray){Float64, 1}, alpha::Number = 1., beta::Number = 0.) =
+            $me.mul!(b, A, x, alpha, beta)
+        function iterative_Solve!(globalfield::GlobalField{ROC_DeviceArray}; Sv_func!::Function = idrs!, Pr_func!::Function = Pr_Jacobi!,
+                                  Pl_func::Function = Identity, max_pass = 4, maxiter = 2000, s = 0, kwargs...)
+            $me.iterative_Solve!(globalfield; Sv_func! = nameof(Sv_func!), Pr_func! = nameof(Pr_func!), Pl_func = nameof(Pl_func), max_pass = max_pass,
+                                 maxiter = maxiter, s = s)
+        end
+        _Var_Basic(itp_vals::$(AMDGPU.ROCArray), sd_IDs, cpID_shift, el_g_cpIDs::$(AMDGPU.ROCArray), x_star::$(AMDGPU.ROCArray),
+                   target::$(AMDGPU.ROCArray), itg_hostIDs::$(AMDGPU.ROCArray), elIDs::$(AMDGPU.ROCArray)) =
+            $me._Var_Basic(itp_vals, sd_IDs, cpID_shift, el_g_cpIDs, x_star, target, itg_hostIDs, elIDs)
+        _Kval_Basic(itp_vals::$(AMDGPU.ROCArray), dual_sd_IDs, base_sd_IDs, vals::$(AMDGPU.ROCArray), sparse_IDs_by_el::$(AMDGPU.ROCArray),
+                    sparse_ID_shift, K_val::$(AMDGPU.ROCArray), itg_hostIDs::$(AMDGPU.ROCArray), elIDs::$(AMDGPU.ROCArray)) =
+            $me._Kval_Basic(itp_vals, dual_sd_IDs, base_sd_IDs, vals, sparse_IDs_by_el, sparse_ID_shift, K_val, itg_hostIDs, elIDs)
+        _Res_Basic(itp_vals::$(AMDGPU.ROCArray), dual_sd_IDs, vals::$(AMDGPU.ROCArray), cpID_shift, el_g_cpIDs::$(AMDGPU.ROCArray),
+                   residue::$(AMDGPU.ROCArray), itg_hostIDs::$(AMDGPU.ROCArray), elIDs::$(AMDGPU.ROCArray)) =
+            $me._Res_Basic(itp_vals, dual_sd_IDs, vals, cpID_shift, el_g_cpIDs, residue, itg_hostIDs, elIDs)
+    end
+    return nothing
+end
 
 end # module
