@@ -257,7 +257,7 @@ int mfem_rem_apply(mfem_context_s* ctx, mfem_csr_s* A, const double* x, const do
   return MFEM_OK;
 }
 // bytes one application moves by design (accounting: bench.py adds them to the tiles' bytes)
-int64_t mfem_rem_design_bytes(const mfem_csr_s* A) {
-  if (!A->rem_active) return 0;
-  return A->rem_nent * (8 + 4 + 8) + A->rem_nrows * (4 + 8 + 4 + 16);
+int64_t mfem_rem_design_bytes(const mfem_csr_s* A) {  // (of the last accepted remainder: the query comes after the solve has unbound its layout)
+  if (!A->rem_last_rows) return 0;
+  return A->rem_last_ent * (8 + 4 + 8) + A->rem_last_rows * (4 + 8 + 4 + 16);  // value, column, gathered x per entry; row id, pointer, length, y read + written per row
 }

@@ -97,6 +97,18 @@ def test_default_line_carries_all_four_configs():
         assert t["n_dof"] == ndof and t["value"] > 0 and t["steps"] == 2 and metric in t["metric"]
         assert 0 < t["roofline"]["frac"] < 1 and t["csr_kernel"]["frac"] > 0
         assert t["final_res"] == t["final_res"] and t["initial_res"] > 0
+    # round 5: the c3 leg also says what solving that system TO A TOLERANCE costs with the reference's solvers and with cg! ...
+    ttt = out["secondary_c3"]["time_to_tol"]
+    for name in ("bicgstabl_GS!(2)", "idrs!(8)", "cg!"):
+        assert ttt[name]["iterations"] > 0 and ttt[name]["ms"] > 0 and ttt[name]["converged"] is True and ttt[name]["final_res_over_initial"] <= 1e-8
+    # ... and the line carries the reference's own solver / boundary-condition path: idrs!(8) on configs[1], the Nitsche-Dirichlet NONSYMMETRIC K on
+    # configs[1] and configs[3] under bicgstabl_GS!(2) (reduced sizes here)
+    for key, ndof in (("ref_idrs8_256", 13 ** 3), ("nitsche_c2_256", 13 ** 3), ("nitsche_c4_128", 25 ** 3)):
+        t = out[key]
+        assert t["n_dof"] == ndof and t["value"] > 0 and t["steps"] == 2 and 0 < t["roofline"]["frac"] < 1
+        assert t["initial_res"] > 0 and t["final_res"] < 2.0 * t["initial_res"]
+        assert abs(t["final_res_recomputed"] - t["final_res"]) <= 1e-5 * t["final_res"] + 1e-9 * t["initial_res"]
+    assert out["nitsche_c2_256"]["csr_kernel"]["frac"] > 0
     ke = out["roofline_hex27_ke"]
     assert ke["bound"] == "mfma" and ke["peak"] == 78.6 and ke["useful_flop_per_assembly"] == 118098.0 * 12 ** 3
     assert ke["achieved"] > 0 and 0 < ke["frac"] < 1 and abs(ke["frac"] - ke["achieved"] / ke["peak"]) < 1e-12

@@ -1,7 +1,7 @@
 """One workload for the rocprofv3 --pmc passes of round 3 (tools/run_pmc_r03.sh): build the matrix of a BASELINE config, run its
 assembly kernels, a few launches of the CSR kernel behind mul!, one short solve on the solver layout and a calibration kernel of
 known bytes (mfem_axpby: 2 vectors read, 1 written).
-usage: pmc_leg.py c2_256 | c2_512 | c3_128 | c4_128 [launches]"""
+usage: pmc_leg.py c2_256 | c2_512 | c3_128 | c4_128 | ref_idrs8_256 | nitsche_c2_256 | nitsche_c4_128 [launches]"""
 import sys
 
 import torch
@@ -11,10 +11,25 @@ import metafem_jl_amd as mf
 
 leg = sys.argv[1]
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-cfg, N = leg.split("_")
+# round 5: the reference's own solver / boundary-condition legs of bench.py (REF_LEGS): ref_idrs8_256, nitsche_c2_256, nitsche_c4_128
+REF = {"ref_idrs8": ("c2", "idrs8", False), "nitsche_c2": ("c2", "bicgstabl2", True), "nitsche_c4": ("c4", "bicgstabl2", True)}
+cfg, N = leg.rsplit("_", 1)
 N = int(N)
 lam, mu = 0.5769230769230769, 0.38461538461538464
-if cfg == "c2":
+if cfg in REF:
+    base, solver, nitsche = REF[cfg]
+    b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 1 if base == "c2" else 2, 3 if base == "c2" else 5)
+    A = b.pattern(1)
+    fixed = mf.FACE_BITS["x0"] if nitsche else 0
+    fix = dict(fixed_faces=fixed, h_penalty=1000.0 if fixed else 0.0, Tw=1173.15 if fixed else 0.0)
+    K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F & ~fixed, **fix)
+    s = torch.full((A.n,), 1600.0, dtype=torch.float64, device="cuda")
+    R = b.residual_thermal(torch.zeros(A.n, dtype=torch.float64, device="cuda"), 0.6, 25.0, 293.15, 0x3F & ~fixed, s=s, **fix)
+    if solver == "idrs8":
+        solve = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.idrs_, maxiter=27, max_pass=1, s=8, fixed_iterations=True)
+    else:
+        solve = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.bicgstabl_GS_, maxiter=12, max_pass=1, s=2, fixed_iterations=True)
+elif cfg == "c2":
     b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 1, 3)
     A = b.pattern(1)
     K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
@@ -54,6 +69,15 @@ if cfg == "c4":
     _lib.lib.mfem_debug_set_lat27(1 | 4)
     solve()
     _lib.lib.mfem_debug_set_lat27(1)
+if cfg in REF:
+    # the same solve without the skew remainder (a nonsymmetric K then takes the layouts that read every entry: round 4's path) and without the tiles
+    _lib.lib.mfem_debug_set_remainder(0)
+    _lib.lib.mfem_debug_set_lat27(0)
+    _lib.lib.mfem_debug_set_lat8(0)
+    solve()
+    _lib.lib.mfem_debug_set_remainder(1)
+    _lib.lib.mfem_debug_set_lat27(1)
+    _lib.lib.mfem_debug_set_lat8(1)
 if cfg in ("c3", "c4"):
     _lib.lib.mfem_debug_set_lat27(0)
     _lib.lib.mfem_debug_set_lat8(0)
