@@ -43,15 +43,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 H_PEN, TW = 1000.0, 1173.15                       # examples/thermal_conduction/2D_Script.jl:46-47: h_penalty, Tw of the weakly imposed Dirichlet face
 
 # The reference's OWN solver / boundary-condition path at scale (round 5): legs of the default line, a few timed steps each.
-#   ref_idrs8_256    configs[1]'s mesh and form solved the way every example script does: idrs!(s = 8) -- the default Sv_func!, src/MetaFEM.jl:36-37,
+# (in the line: `ref_idrs8_256`, `nitsche_c2_256`, `nitsche_c4_128`; alone: --config ref_idrs8 | nitsche_c2 | nitsche_c4)
+#   ref_idrs8        configs[1]'s mesh and form solved the way every example script does: idrs!(s = 8) -- the default Sv_func!, src/MetaFEM.jl:36-37,
 #                    linear_solver/04_IDRs.jl:26-95 -- with Pr_Jacobi! (02_Preconditioner.jl:32-76)
-#   nitsche_c2_256   the same mesh with the temperature FIXED on x = 0 the reference's way: h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i})
+#   nitsche_c2       the same mesh with the temperature FIXED on x = 0 the reference's way: h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i})
 #                    (thermal_conduction/2D_Script.jl:58) -- K is NONSYMMETRIC; convection on the other five faces; bicgstabl_GS!(2)
-#   nitsche_c4_128   configs[3]'s mesh (hex-27) with the same face, bicgstabl_GS!(2)
+#   nitsche_c4       configs[3]'s mesh (hex-27) with the same face, bicgstabl_GS!(2)
 REF_LEGS = {
-    "ref_idrs8_256": dict(base="c2", n=256, solver="idrs8", nitsche=False),
-    "nitsche_c2_256": dict(base="c2", n=256, solver="bicgstabl2", nitsche=True),
-    "nitsche_c4_128": dict(base="c4", n=128, solver="bicgstabl2", nitsche=True),
+    "ref_idrs8": dict(base="c2", n=256, solver="idrs8", nitsche=False),
+    "nitsche_c2": dict(base="c2", n=256, solver="bicgstabl2", nitsche=True),
+    "nitsche_c4": dict(base="c4", n=128, solver="bicgstabl2", nitsche=True),
 }
 SOLVER_TEXT = {"cg": "Jacobi-CG iterations", "bicgstabl2": "SpMV-equivalent steps of bicgstabl_GS! (s = 2, right Jacobi)",
                "idrs8": "SpMV-equivalent steps of idrs! (s = 8, right Jacobi)"}
@@ -228,7 +229,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + sorted(REF_LEGS), default="c2")
     ap.add_argument("--n", type=int, default=0, help="elements per side of the per-GPU mesh (0 = the config's size: 512 / 128 / 128)")
     ap.add_argument("--iters", type=int, default=200, help="Krylov iterations per step (BiCGStab(2): SpMV-equivalent steps)")
     ap.add_argument("--cpu-n", type=int, default=192, help="elements per side of the CPU-baseline sample (0 = skip)")
@@ -250,6 +251,9 @@ def main():
     ap.add_argument("--time-to-tol", type=int, default=1,
                     help="c3 legs: after the fixed-count steps, solve the same system to ||r|| / sqrt(n) <= 1e-8 ||r0|| with bicgstabl_GS!(2), idrs!(8) and cg! "
                          "and report iterations / ms / converged (0 = skip)")
+    ap.add_argument("--remainder", type=int, default=1,
+                    help="0: switch the skew remainder of the lattice tiles off (mfem_debug_set_remainder): a nonsymmetric K then takes the layouts that read "
+                         "every entry, as until round 4 -- the A/B of profiles/r05_nitsche_ab.txt")
     ap.add_argument("--ws-trial", type=int, default=1,
                     help="1 (default here): opt in to the library's workspace placement trial (mfem_debug_set_ws_trial; OFF by default in the library "
                          "since round 4) -- the line says so in config.workspace_placement_trial and prints the first step's wall time; 0 = as the library ships")
@@ -257,7 +261,13 @@ def main():
                     help="N = 1, default sizes: collect the roofline objects' `traffic` in this run (two rocprofv3 --pmc child passes on the "
                          "headline workload, ~40 s) instead of reading profiles/r05_traffic.json (0 = read the file)")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    if args.config in REF_LEGS:  # one of the reference-solver legs alone (profiles: tools/run_profiles_r05.sh)
+        leg = REF_LEGS[args.config]
+        cfg = dict(CONFIGS[leg["base"]], solver=leg["solver"], nitsche=leg["nitsche"], n=leg["n"],
+                   metric=f"DOF-updates/sec (assembly + {SOLVER_TEXT[leg['solver']]}) on " + CONFIGS[leg["base"]]["title"]
+                          + (" with a Nitsche-Dirichlet face (nonsymmetric K)" if leg["nitsche"] else ""))
+    else:
+        cfg = CONFIGS[args.config]
     if args.n <= 0:
         args.n = cfg["n"]
 
@@ -724,7 +734,9 @@ def main():
 
     if args.ws_trial:
         _lib.check(_lib.lib.mfem_debug_set_ws_trial(1))
-    main_res = run_workload(cfg, args.config, args.n, args.steps, args.warmup, want_csr=True)
+    if not args.remainder:
+        _lib.check(_lib.lib.mfem_debug_set_remainder(0))
+    main_res = run_workload(cfg, REF_LEGS[args.config]["base"] if args.config in REF_LEGS else args.config, args.n, args.steps, args.warmup, want_csr=True)
 
     def check_residual(r, what):
         """bench.py checks what it times: the last timed solve must have reduced the residual (and produced finite numbers)."""
@@ -777,9 +789,12 @@ def main():
                 "workload": f"{cfg['title']}, {r['nx_global']}x{args.n}x{args.n} structured mesh (make_Brick)"
                             + (f" cut into {world} slabs along i (strong scaling)" if strong else "") + ": fused assembly (K + R) + "
                             + (f"{args.iters} Jacobi-CG iterations per step" if cfg["solver"] == "cg" else
-                               f"{max(args.iters // 4, 1)} BiCGStab(2) sweeps (bicgstabl_GS!, right Jacobi) = {per_step_updates:.0f} SpMV-equivalent steps per step"),
+                               f"{per_step_updates:.0f} {SOLVER_TEXT[cfg['solver']]} per step")
+                            + (", temperature fixed on x = 0 by the reference's Nitsche form (2D_Script.jl:58: nonsymmetric K)" if cfg.get("nitsche") else ""),
                 "baseline_config": {"c2": "the north_star target size (512^3 hex-8, 1 GPU); configs[1] (256^3) is `secondary_256`",
-                                    "c3": "configs[2]", "c4": "configs[3]"}[args.config] if args.n == cfg["n"] else f"{args.config} at a non-default size",
+                                    "c3": "configs[2]", "c4": "configs[3]", "ref_idrs8": "configs[1] solved with the reference's default solver",
+                                    "nitsche_c2": "configs[1] mesh and form, Dirichlet face added", "nitsche_c4": "configs[3] mesh and form, Dirichlet face added"
+                                    }[args.config] if args.n == cfg["n"] else f"{args.config} at a non-default size",
                 "n_dof": r["n_global"], "nnz_per_gpu": r["nnz"], "krylov_steps_per_step": per_step_updates,
                 "parallelism": "single GPU" if world == 1 else f"slab decomposition x{world} ("
                                + (state["transport"] or ("host callbacks over gloo, ranks sharing one GPU: functional run" if host_comm else "RCCL"))
@@ -804,6 +819,8 @@ def main():
             # what the solver stream of every rank waited for (hip-event pairs around the wait for the halo stream and around each all-reduce)
             out["comm_exposed"] = r["comm_exposed"]
         check_residual(r, f"{args.config} {args.n}^3")
+        if r.get("remainder"):
+            out["remainder"] = r["remainder"]
         if "csr_kernel" in r:
             # the north_star's own number: the CSR kernel behind mul! on this matrix, measured in this run
             out["roofline"]["csr_kernel"] = r["csr_kernel"]
@@ -837,12 +854,13 @@ def main():
             c = dict(CONFIGS[leg["base"]], solver=leg["solver"], nitsche=leg["nitsche"], n=args.secondary_config_n or leg["n"])
             t = run_workload(c, leg["base"], c["n"], args.secondary_steps, 1, want_csr=leg["nitsche"])
             check_residual(t, f"{lk} {c['n']}^3")
+            lk = f"{lk}_{leg['n']}"  # (the key names the leg at its own size: ref_idrs8_256, nitsche_c2_256, nitsche_c4_128)
             per = t["updates"] / t["steps"]
             obj = secondary_object(
                 t, f"{c['title']}, {c['n']}^3" + (", temperature fixed on x = 0 by the reference's Nitsche form (h_penalty*Bilinear(T, Tw - T) + k*Bilinear(T, n{i}*T{;i}), "
                                                    "2D_Script.jl:58: NONSYMMETRIC K), convection on the other faces" if leg["nitsche"] else "")
                    + f", {t['steps']} timed steps after 1 warm-up: fused assembly (K + R) + {per:.0f} {SOLVER_TEXT[leg['solver']]} per step",
-                f"{lk}", {"c2": "configs[1]", "c4": "configs[3]"}[leg["base"]] + (" mesh and form, Dirichlet face added" if leg["nitsche"] else " solved with the reference's default solver"))
+                f"{lk[:lk.rfind('_')]}_{c['n']}", {"c2": "configs[1]", "c4": "configs[3]"}[leg["base"]] + (" mesh and form, Dirichlet face added" if leg["nitsche"] else " solved with the reference's default solver"))
             obj["metric"] = f"DOF-updates/sec (assembly + {SOLVER_TEXT[leg['solver']]})"
             out[lk] = obj
     if rank == 0 and world == 1 and args.config == "c2" and args.hex27_n > 0:

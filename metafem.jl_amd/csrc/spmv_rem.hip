@@ -14,6 +14,7 @@
 // on every row -- the acceptance test is the same as for symmetric values, only the operator it is applied to is S + N.
 // Everything here is generic in the pattern: the mirrored entry of (r, c) is found by searching row c of the caller's CSR for column r.
 #include "blas1.h"
+#include <hipcub/hipcub.hpp>
 
 #define MFEM_REM_MAX_FRACTION 8  // a remainder of more than n / 8 rows is not taken
 
@@ -169,8 +170,8 @@ void mfem_rem_free(mfem_csr_s* A) {
 
 static int rem_apply_grid(const mfem_context_s* ctx, int64_t nrows) {
   int64_t g = (nrows + MFEM_BLOCK / 16 - 1) / (MFEM_BLOCK / 16);
-  int cap = ctx->num_cus * 2;
-  if (cap > 512) cap = 512;
+  int cap = ctx->num_cus * 4;  // (its partial sums follow the gather pass's in one array of MFEM_MAX_PARTIALS: the gather takes at most half)
+  if (cap > MFEM_MAX_PARTIALS / 4) cap = MFEM_MAX_PARTIALS / 4;
   if (g > cap) g = cap;
   return g < 1 ? 1 : (int)g;
 }
@@ -207,6 +208,23 @@ int mfem_rem_build(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, int n
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   const int64_t nrows = (int64_t)h[0];
   if (nrows == 0 || nrows > n / MFEM_REM_MAX_FRACTION) return MFEM_OK;
+  {
+    // the flagged rows in ASCENDING order (the flag pass appends them in the order its atomics land): the application then writes y and gathers x with
+    // neighbouring groups on neighbouring lines, and the layout is the same from run to run.  Sorted into rem_len's storage (same size), copied back.
+    size_t tb = 0;
+    int32_t* alt = A->rem_len;
+    MFEM_CHECK_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (const int32_t*)A->rem_rows, alt, (int)nrows, 0, 32, ctx->stream));
+    void* tmp = nullptr;
+    MFEM_CHECK_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    hipError_t es = hipcub::DeviceRadixSort::SortKeys(tmp, tb, (const int32_t*)A->rem_rows, alt, (int)nrows, 0, 32, ctx->stream);
+    if (es == hipSuccess) es = hipMemcpyAsync(A->rem_rows, alt, sizeof(int32_t) * (size_t)nrows, hipMemcpyDeviceToDevice, ctx->stream);
+    if (es == hipSuccess) es = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (es != hipSuccess) {
+      mfem_set_error("remainder: sorting the rows -> %s", hipGetErrorString(es));
+      return MFEM_ERR_HIP;
+    }
+  }
   const int grid = mfem_grid_for(nrows * 64, MFEM_BLOCK, ctx->num_cus * 16);
 #define REM_ROWS(RP, FILL_)                                                                                                                         \
   hipLaunchKernelGGL((k_rem_rows<RP, FILL_>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, N, (const RP*)A->rowptr, A->colidx, A->index_base, vals, \

@@ -122,7 +122,7 @@ def test_c3_c4_legs_with_two_ranks(config, n, iters, ndof):
     assert out["config"]["krylov_steps_per_step"] >= iters * 0.9
 
 
-@pytest.mark.parametrize("config,n,ndof", [("c3", 24, 3 * 25 ** 3), ("c4", 12, 25 ** 3)])
+@pytest.mark.parametrize("config,n,ndof", [("c3", 24, 3 * 25 ** 3), ("c4", 12, 25 ** 3), ("nitsche_c2", 24, 25 ** 3), ("ref_idrs8", 24, 25 ** 3)])
 def test_c3_c4_legs_single_gpu(config, n, ndof):
     out = run_bench(["--config", config, "--n", str(n), "--iters", "40"] + SMALL)
     _common(out, 1)

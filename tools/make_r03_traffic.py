@@ -70,9 +70,11 @@ for leg in legs:
         _, w = kb(W, k, "WRITE_SIZE")
         per_kernel[k.split("(")[0][:90]] = {"launches": nl, "fetch_bytes_x2": f * 1024 * 2, "write_bytes": w * 1024, "hbm_bytes": f * 2048 + w * 1024}
     for key, subs in KEYS:
-        ks = [k for k in set(F) | set(W) if any(s in k for s in subs)]
+        ks = [k for k in set(F) | set(W) if any(s in k for s in subs if s != "k_rem_apply")]
         if not ks:
             continue
+        if "k_rem_apply" in subs:  # the skew remainder rides with whichever tile kernel of the leg it follows
+            ks += [k for k in set(F) | set(W) if "k_rem_apply" in k]
         main_launches = max(kb(F, k, "FETCH_SIZE")[0] for k in ks)
         # a "launch" = the main kernel + its companion launch (rows outside the swept planes), each at its own mean
         fetch = sum(kb(F, k, "FETCH_SIZE")[1] for k in ks) * 1024 * 2

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 5, on the GPU box: everything profiles/r05_* is made from.
+# Round 5, on the GPU box: everything profiles/r05_* is made from (the BASELINE configs + the reference's own solver / boundary-condition legs of bench.py: REF_LEGS).
 #   1. HBM traffic of the priced kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, + the hex-27 MFMA / SQ passes) -> gpurun_out/r05_traffic.json
 #   2. rocprofv3 --kernel-trace --stats of one bench leg per config (512^3 alone, 256^3 alone, c3, c4) -> gpurun_out/prof_r05/<leg>_kernel_stats.csv
 #   3. the bench lines: default invocation (driver's command), --config c3, --config c4
 # Counter passes only with --kernel-trace; the program itself directly after `--`.   usage: bash tools/run_profiles_r05.sh [pmc|stats|lines ...]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-what=${@:-"pmc stats lines"}
+what=${@:-"pmc stats ab lines"}
 mkdir -p $R/gpurun_out/pmc_r05 $R/gpurun_out/prof_r05
 if echo "$what" | grep -q pmc; then
   for leg in c2_256 c2_512 c3_128 c4_128 ref_idrs8_256 nitsche_c2_256 nitsche_c4_128; do
@@ -22,13 +22,28 @@ if echo "$what" | grep -q pmc; then
 fi
 if echo "$what" | grep -q stats; then
   i=0
-  for leg in "c2_512:--config c2 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c2_256:--config c2 --n 256 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c3_128:--config c3" "c4_128:--config c4"; do
+  for leg in "c2_512:--config c2 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c2_256:--config c2 --n 256 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c3_128:--config c3" "c4_128:--config c4" "ref_idrs8_256:--config ref_idrs8" "nitsche_c2_256:--config nitsche_c2" "nitsche_c4_128:--config nitsche_c4"; do
     name=${leg%%:*}; args=${leg#*:}
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05/$name -o bench --output-format csv -- python3 $R/bench.py $args --steps 3 --warmup 1 --live-traffic 0 --cpu-n 0 > $R/gpurun_out/prof_r05/${name}_under_rocprof.json 2> $R/gpurun_out/prof_r05/${name}.err || { echo "stats $name failed"; tail -3 $R/gpurun_out/prof_r05/${name}.err; exit 1; }
     cp $R/gpurun_out/prof_r05/$name/bench_kernel_stats.csv $R/gpurun_out/prof_r05/${name}_kernel_stats.csv
     rm -f $R/gpurun_out/prof_r05/$name/bench_kernel_trace.csv
     echo "done stats $name"
   done
+fi
+if echo "$what" | grep -q ab; then
+  # A/B of the nonsymmetric legs: tiles + skew remainder (default) against the layouts that read every entry (--remainder 0: what ran until round 4),
+  # and the symmetric form of the same mesh under the same solver for reference
+  : > $R/gpurun_out/r05_nitsche_ab.txt
+  for leg in "nitsche_c2 --remainder 1" "nitsche_c2 --remainder 0" "nitsche_c4 --remainder 1" "nitsche_c4 --remainder 0"; do
+    timeout -k 10 200 python3 $R/bench.py --config $leg --steps 5 --warmup 1 --live-traffic 0 --cpu-n 0 > $R/gpurun_out/ab_tmp.json 2> $R/gpurun_out/ab_tmp.err || { echo "ab $leg failed"; tail -3 $R/gpurun_out/ab_tmp.err; exit 1; }
+    python3 - "$leg" $R/gpurun_out/ab_tmp.json >> $R/gpurun_out/r05_nitsche_ab.txt <<'PYEOF'
+import json, sys
+d = json.load(open(sys.argv[2])); r = d["roofline"]
+print(f"--config {sys.argv[1]:28s} value {d['value']:.4e} DOF-updates/s  ms/step {d['ms_per_step']:8.2f}  solver SpMV {r['avg_launch_ms']:.4f} ms  "
+      f"design bytes {r['algorithmic_bytes_per_launch']:.4e}  frac {r['frac']:.3f}  remainder rows {(d.get('remainder') or {}).get('rows')}  kernel: {r['kernel'][:60]}")
+PYEOF
+  done
+  cat $R/gpurun_out/r05_nitsche_ab.txt
 fi
 if echo "$what" | grep -q lines; then
   timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/r05_bench_n1.json 2> $R/gpurun_out/r05_bench_n1.err || { echo "default line failed"; tail -3 $R/gpurun_out/r05_bench_n1.err; exit 1; }
