@@ -79,8 +79,13 @@ int mfem_debug_set_halo_overlap(int on);
  * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
  * 16 GiB scratch budget).  Bit 8: the constant-Jacobian shortcut of affine elements off (every element takes the general path).
  * Bit 9: the scratch-free assembly of meshes whose elements are ALL affine off (such a mesh then takes the two-pass MFMA path;
- * by default its matrix is built by a row-owner gather from per-element G0 and the reference integrals, Ke never stored). */
+ * by default its matrix is built by a row-owner gather from per-element G0 and the reference integrals, Ke never stored).
+ * Bit 10 (round 5): the PER-ELEMENT choice off -- a mesh with at least one non-affine element then takes the two-pass path whole (round 4's behaviour;
+ * by default its affine elements are computed in place and only the others go through pass 1, into a scratch that holds only them).  Bits 24-30:
+ * percentage of non-affine elements up to which the per-element choice is taken (0 = the default 80; beyond it the two-pass path is faster). */
 int mfem_debug_set_hex27(int two_pass);
+/* number of hex-27 matrix assemblies that took the per-element choice with at least one stored (non-affine) element (process-wide) */
+int64_t mfem_debug_hex27_mixed_count(void);
 /* number of hex-27 matrix assemblies that took the scratch-free path so far (process-wide) */
 int64_t mfem_debug_hex27_direct_count(void);
 /* hex-8 elasticity kernels.  Bit 0: matrix -- 0 (default) thread per (control point, element) with the rows accumulated in LDS and

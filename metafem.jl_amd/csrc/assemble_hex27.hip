@@ -169,6 +169,10 @@ struct Hex27Args {
   int colour;        // 0..7: (I&1) | (J&1)<<1 | (K&1)<<2
   int nq, ng;
   int e_lo, e_cnt, ring;  // element planes [e_lo, e_lo + e_cnt) of dimension 0 this launch covers; scratch variant: plane I kept in ring slot I % ring
+  // mixed meshes (round 5): pass 1 over a LIST of elements only -- elist[k] = index (I - e_lo, J, K) of the k-th non-affine element inside the planes
+  // above, its Ke goes to scratch slot k; nullptr: every element of the planes
+  const int32_t* elist;
+  int64_t ecount;
 };
 
 // Walk of one wave over its elements: the elements of a launch form an n0 x n1 x n2 grid (one colour's sub-lattice, or the
@@ -316,8 +320,17 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   int I = 0, J = 0, K = 0;
   ElemWalk walk;
   walk.init(B, A.colour, A.e_lo, A.e_cnt, (int64_t)blockIdx.x * H27_WAVES + wv, nwaves);
-  bool have = walk.have();  // wave-uniform
-  if (have) walk.get(I, J, K);
+  // list mode (mixed meshes): the wave walks the entries lk, lk + nwaves, ... of the element list instead of the launch's grid
+  int64_t lk = (int64_t)blockIdx.x * H27_WAVES + wv, lk_cur = 0;
+  auto list_get = [&](int64_t k, int& I_, int& J_, int& K_) {
+    const uint32_t id = (uint32_t)A.elist[k], n2 = (uint32_t)B.ne2, n12 = (uint32_t)B.ne1 * n2;
+    const uint32_t i = id / n12, rem = id - i * n12, j = rem / n2;
+    I_ = A.e_lo + (int)i; J_ = (int)j; K_ = (int)(rem - j * n2);
+  };
+  bool have = A.elist ? lk < A.ecount : walk.have();  // wave-uniform
+  if (have) {
+    if (A.elist) list_get(lk, I, J, K); else walk.get(I, J, K);
+  }
   NodePre cur = have ? fetch_nodes(I, J, K) : NodePre{0.0, 0.0, 0.0, 0, 0, 0};
   while (have) {
     // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
@@ -341,9 +354,16 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     }
     // next element of this wave: issue its node loads now
     const int Ic = I, Jc = J, Kc = K;
-    walk.advance();
-    have = walk.have();
-    if (have) walk.get(I, J, K);
+    lk_cur = lk;
+    if (A.elist) {
+      lk += nwaves;
+      have = lk < A.ecount;
+      if (have) list_get(lk, I, J, K);
+    } else {
+      walk.advance();
+      have = walk.have();
+      if (have) walk.get(I, J, K);
+    }
     if (have) cur = fetch_nodes(I, J, K);
     __builtin_amdgcn_wave_barrier();
     // ---- 2'. AFFINE elements (round 4).  The counters say pass 1 is bound by the ONE pipe FP64 VALU and FP64 MFMA share (MFMA busy 53 % + FP64 /
@@ -527,7 +547,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       if (SCRATCH) {
         // ---- 4'. two-pass assembly: Ke goes to the element-major scratch [e][a][b] (written once, no RMW); the
         //      row-owner gather kernel below turns it into CSR rows.
-        double* ke = out + (((int64_t)(Ic % A.ring) * B.ne1 + Jc) * B.ne2 + Kc) * 729;
+        double* ke = A.elist ? out + lk_cur * 729 : out + (((int64_t)(Ic % A.ring) * B.ne1 + Jc) * B.ne2 + Kc) * 729;
         const int rc_hi = scratch_row(16 + c > 26 ? 26 : 16 + c);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -752,8 +772,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_gather_lds(BrickView B, co
 // tested per assembly on the coordinates themselves, k_hex27_affine_g0), the row-owner gather below computes each (row, element) run from G0 and the table instead of
 // reading it from the element-major scratch: no pass 1, no 12.2 GB scratch written and read back (128^3: 10.5 -> 3 ms for the matrix).  Any non-affine element sends
 // the whole assembly through the two-pass MFMA path above.
+// slot (optional): per element -1 (affine) or its place k in the compact scratch of the non-affine elements' Ke; elist[k] = the element's index
+// (the places are handed out by an atomic counter: which element gets which place varies from run to run, what is stored there does not)
 __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_affine_g0(BrickView B, double kcond, int elo, int ecnt, double* __restrict__ g,
-                                                                int32_t* __restrict__ nonaffine) {
+                                                                int32_t* __restrict__ nonaffine, int32_t* __restrict__ slot,
+                                                                int32_t* __restrict__ elist) {
   const int64_t nel = (int64_t)ecnt * B.ne1 * B.ne2;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nel) return;
@@ -790,8 +813,13 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_affine_g0(BrickView B, dou
     g0 = sc0 * (c00 * c00 + c01 * c01 + c02 * c02); g1 = sc0 * (c00 * c10 + c01 * c11 + c02 * c12);
     g2 = sc0 * (c00 * c20 + c01 * c21 + c02 * c22); g3 = sc0 * (c10 * c10 + c11 * c11 + c12 * c12);
     g4 = sc0 * (c10 * c20 + c11 * c21 + c12 * c22); g5 = sc0 * (c20 * c20 + c21 * c21 + c22 * c22);
+    if (slot) slot[idx] = -1;
   } else {
-    atomicAdd(nonaffine, 1);
+    const int k = atomicAdd(nonaffine, 1);
+    if (slot) {
+      slot[idx] = k;
+      elist[k] = (int32_t)idx;
+    }
   }
   double* ge = g + idx * 6;
   ge[0] = g0; ge[1] = g1; ge[2] = g2; ge[3] = g3; ge[4] = g4; ge[5] = g5;
@@ -810,8 +838,14 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_hex27_affine_g0(BrickView B, dou
 #define D27_THREADS (64 * D27_WAVES)
 #define D27_TAB 1024  // lattice planes + lines + points whose row-box tables (lo, c, P per direction) are kept in LDS (16 bytes each); beyond: read from memory
 #define D27_LDS_BYTES (sizeof(double) * (48 + D27_NODES * G27_ROW + D27_TAB) + sizeof(int32_t) * (2 * D27_TAB))
+// Mixed meshes (round 5): slot_of != nullptr -- element idx is affine where slot_of[idx] < 0 (computed in place, as above) and otherwise has its Ke in the
+// compact scratch `ke` at slot_of[idx] (pass 1 ran for those elements only, k_hex27<true, true> in list mode): their runs Ke[la][0..26] are streamed in by the
+// half-waves exactly as in k_hex27_gather_lds (one contiguous 216-byte read per run) after the wave's in-place runs have been added.  One distorted element no
+// longer sends the whole mesh through the two-pass path: the assembly costs what its affine part costs plus pass 1 + the streamed runs of the rest.
+#define D27_FLIGHT 8
 __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, const Hex27Tables* __restrict__ tab, const double* __restrict__ g,
-                                                              double* __restrict__ vals, int64_t row_lo, int64_t row_hi, int elo) {
+                                                              double* __restrict__ vals, int64_t row_lo, int64_t row_hi, int elo,
+                                                              const int32_t* __restrict__ slot_of, const double* __restrict__ ke) {
   extern __shared__ double lds[];
   double* sT = lds;                          // [4][3][4]
   double* rows = sT + 48;                    // [D27_NODES][G27_ROW]
@@ -840,9 +874,10 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
     int32_t len, c1, c2, la, b0;
     bool valid;
     double g[6];
+    int32_t slot;  // >= 0: the element's place in the compact scratch (non-affine), < 0: computed in place
   };
   auto phase_a = [&](int64_t blk) -> PairPre {
-    PairPre P{0, 0, 1, 1, 0, 0, false, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+    PairPre P{0, 0, 1, 1, 0, 0, false, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, -1};
     const int nl = tid >> 3, e = tid & 7;
     const int64_t row = row_lo + blk * D27_NODES + nl;
     if (row >= row_hi) return P;
@@ -873,9 +908,11 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
     P.la = valid ? (gg[0] - 2 * E[0]) + 3 * (gg[1] - 2 * E[1]) + 9 * (gg[2] - 2 * E[2]) : 0;
     P.b0 = nl * G27_ROW + ((2 * E[0] - l0) * P.c1 + (2 * E[1] - l1)) * P.c2 + (2 * E[2] - l2);  // the element's first node in the row's box
     if (valid) {
-      const double* ge = g + (((int64_t)(E[0] - elo) * ne[1] + E[1]) * ne[2] + E[2]) * 6;
+      const int64_t eidx = ((int64_t)(E[0] - elo) * ne[1] + E[1]) * ne[2] + E[2];
+      const double* ge = g + eidx * 6;
 #pragma unroll
       for (int t = 0; t < 6; ++t) P.g[t] = ge[t];
+      if (slot_of) P.slot = slot_of[eidx];
     }
     return P;
   };
@@ -883,7 +920,7 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
     for (int t = lane; t < 8 * G27_ROW; t += 64) rows[wv * 8 * G27_ROW + t] = 0.0;
     const PairPre cur = phase_a(blk);  // (its loads wait behind the other waves' arithmetic: two workgroups of eight waves per CU)
     __builtin_amdgcn_wave_barrier();
-    if (cur.valid) {
+    if (cur.valid && cur.slot < 0) {
       const int a0 = cur.la % 3, a1 = (cur.la / 3) % 3, a2 = cur.la / 9;
       double X0[4][3], X2[4][3];  // [D, M, C, Ct][b]
 #pragma unroll
@@ -911,6 +948,39 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
             __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(rp + b2), v);
           }
         }
+      }
+    }
+    const uint64_t stored = slot_of ? __ballot(cur.valid && cur.slot >= 0) : 0ull;  // (wave-uniform) pairs whose run sits in the scratch
+    if (stored) {
+      // a half-wave streams the runs of its 4 rows in, element order e = 0..7 per row: lane lb < 27 loads entry lb of a run and adds it at the slot of local
+      // node lb in the row's box; what a lane needs about pair p sits in lane p's registers (the pair's own phase A): fetched with wave shuffles
+      __builtin_amdgcn_wave_barrier();
+      const int lb = lane & 31, hb = lane & 32;
+      const bool active = lb < 27;
+      const int bx = lb % 3, by = (lb / 3) % 3, bz = lb / 9;
+      const int64_t my_src = ((int64_t)(cur.slot >= 0 ? cur.slot : 0) * 27 + scratch_row(cur.la)) * 27;
+      const int my_lo = (int)(uint32_t)(uint64_t)my_src, my_hi = (int)(uint32_t)((uint64_t)my_src >> 32);
+      uint32_t todo = hb ? (uint32_t)(stored >> 32) : (uint32_t)stored;
+      while (__any(todo != 0u)) {  // (both half-waves take part in every shuffle)
+        double v[D27_FLIGHT];
+        int sl[D27_FLIGHT];
+#pragma unroll
+        for (int j = 0; j < D27_FLIGHT; ++j) {
+          const bool has = todo != 0u;
+          const int p = hb + (has ? __builtin_ctz(todo) : 0);
+          if (has) todo &= todo - 1u;
+          const uint32_t slo = (uint32_t)__shfl(my_lo, p, MFEM_WAVE), shi = (uint32_t)__shfl(my_hi, p, MFEM_WAVE);
+          const int pb0 = __shfl(cur.b0, p, MFEM_WAVE), pc1 = __shfl(cur.c1, p, MFEM_WAVE), pc2 = __shfl(cur.c2, p, MFEM_WAVE);
+          sl[j] = -1;
+          v[j] = 0.0;
+          if (has && active) {
+            v[j] = __builtin_nontemporal_load(ke + (int64_t)(((uint64_t)shi << 32) | slo) + lb);
+            sl[j] = pb0 + (bx * pc1 + by) * pc2 + bz;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < D27_FLIGHT; ++j)
+          if (sl[j] >= 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(rows + sl[j]), v[j]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1019,6 +1089,10 @@ static std::atomic<long long> g_hex27_direct_count{0};  // assemblies that took 
 extern "C" int64_t mfem_debug_hex27_direct_count(void) { return g_hex27_direct_count; }
 static std::atomic<int> g_hex27_direct{1};  // bit 9 of mfem_debug_set_hex27 turns the scratch-free assembly of all-affine meshes off (two-pass MFMA path then)
 static std::atomic<int> g_hex27_affine{1};  // bit 8 of mfem_debug_set_hex27 turns the affine-element shortcut of the matrix kernel off (every element then takes the general path)
+static std::atomic<int> g_hex27_mixed{1};       // bit 10 of mfem_debug_set_hex27 turns the per-element choice off: a mesh with a non-affine element then takes the two-pass path whole (round 4's behaviour)
+static std::atomic<int> g_hex27_mixed_max{80};  // bits 24-30: percentage of non-affine elements up to which the per-element choice is taken (0 = the default 80: profiles/r05_hex27_mixed.txt -- at 75 % the choice takes 11.2 ms against 11.9 for the two-pass path, at 100 % 13.1 against 12.2)
+static std::atomic<long long> g_hex27_mixed_count{0};  // assemblies that took it with at least one stored element (tests)
+extern "C" int64_t mfem_debug_hex27_mixed_count(void) { return g_hex27_mixed_count; }
 static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
 static std::atomic<size_t> g_hex27_scratch_budget{(size_t)16 << 30};
 extern "C" int mfem_debug_set_hex27(int two_pass) try {
@@ -1027,6 +1101,8 @@ extern "C" int mfem_debug_set_hex27(int two_pass) try {
   g_hex27_chunk_planes = (two_pass >> 16) & 255;
   g_hex27_affine = ((two_pass >> 8) & 1) ? 0 : 1;
   g_hex27_direct = ((two_pass >> 9) & 1) ? 0 : 1;
+  g_hex27_mixed = ((two_pass >> 10) & 1) ? 0 : 1;
+  g_hex27_mixed_max = ((two_pass >> 24) & 127) ? ((two_pass >> 24) & 127) : 80;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex27")
 
@@ -1113,23 +1189,51 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     // all elements affine?  G0 of every element + a count of the ones that are not (one 4-byte read-back per assembly: the coordinates belong to the caller,
     // mfem_brick_coords, and may have changed since the last call)
     const int64_t nel = (int64_t)(ehi - elo) * m->ne[1] * m->ne[2];
-    rc = mfem_ws_reserve(ctx, sizeof(double) * 6 * (size_t)nel);
+    // workspace: G0 [6 nel] | slot [nel] | elist [nel] (int32) -- the compact scratch of the non-affine elements follows once their number is known
+    const size_t g_bytes = sizeof(double) * 6 * (size_t)nel, map_bytes = (sizeof(int32_t) * (size_t)nel + 255) & ~(size_t)255;
+    rc = mfem_ws_reserve(ctx, g_bytes + 2 * map_bytes);
     if (rc) return rc;
     int32_t* d_cnt = ctx->d_flags + 14;
     MFEM_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_hex27_affine_g0, dim3((unsigned)((nel + MFEM_BLOCK - 1) / MFEM_BLOCK)), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, elo, ehi - elo,
-                       (double*)ctx->ws, d_cnt);
+                       (double*)ctx->ws, d_cnt, (int32_t*)((char*)ctx->ws + g_bytes), (int32_t*)((char*)ctx->ws + g_bytes + map_bytes));
     MFEM_CHECK_LAUNCH();
     MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 14, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_flags[14] == 0) {
+    const int64_t n_stored = ctx->h_flags[14];
+    // Per-element choice (round 5; until then ONE distorted element sent the whole mesh through the two-pass path: a 2.6x cliff).  Affine elements are
+    // computed in place by the row-owner gather, the others go through pass 1 into a scratch that holds ONLY them and are streamed in by the same gather.
+    // Beyond g_hex27_mixed_max (80 % of the elements by default) the plain two-pass path is the faster one (its gather streams every run with no
+    // arithmetic beside it); a scratch beyond the budget goes there too (it rings over element planes).
+    const size_t stored_bytes = sizeof(double) * 729 * (size_t)n_stored;
+    if (n_stored == 0 || (g_hex27_mixed && n_stored * 100 <= nel * (int64_t)g_hex27_mixed_max && stored_bytes <= g_hex27_scratch_budget)) {
+      const size_t head = (g_bytes + 2 * map_bytes + 255) & ~(size_t)255;
+      if (n_stored) {
+        // (growing the workspace moves it: the tables just made are small -- made again after the move instead of copied)
+        if (ctx->ws_bytes < head + stored_bytes) {
+          rc = mfem_ws_reserve(ctx, head + stored_bytes);
+          if (rc) return rc;
+          MFEM_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+          hipLaunchKernelGGL(k_hex27_affine_g0, dim3((unsigned)((nel + MFEM_BLOCK - 1) / MFEM_BLOCK)), dim3(MFEM_BLOCK), 0, ctx->stream, B, p->k, elo,
+                             ehi - elo, (double*)ctx->ws, d_cnt, (int32_t*)((char*)ctx->ws + g_bytes), (int32_t*)((char*)ctx->ws + g_bytes + map_bytes));
+          MFEM_CHECK_LAUNCH();
+        }
+        MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Hex27Args A{B, g_tab, p->k, 0, -1, nq, m->ng, elo, ehi - elo, 1, (const int32_t*)((char*)ctx->ws + g_bytes + map_bytes), n_stored};
+        int64_t grid1 = (n_stored + H27_WAVES - 1) / H27_WAVES;
+        if (grid1 > (int64_t)ctx->num_cus * 2) grid1 = (int64_t)ctx->num_cus * 2;
+        hipLaunchKernelGGL((k_hex27<true, true>), dim3((int)grid1), dim3(H27_THREADS), lds, ctx->stream, A, nullptr, nullptr, (double*)((char*)ctx->ws + head));
+        MFEM_CHECK_LAUNCH();
+        ++g_hex27_mixed_count;
+      }
       MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)D27_LDS_BYTES));
       const int64_t nblk = (m->n_owned + D27_NODES - 1) / D27_NODES;
       const int grid = (int)(nblk < (int64_t)ctx->num_cus * 2 ? nblk : (int64_t)ctx->num_cus * 2);  // two 8-wave workgroups per CU (78 KB of LDS each), persistent
       hipLaunchKernelGGL(k_hex27_direct, dim3(grid), dim3(D27_THREADS), D27_LDS_BYTES, ctx->stream, B, (const Hex27Tables*)g_tab, (const double*)ctx->ws, vals,
-                         (int64_t)0, m->n_owned, elo);
+                         (int64_t)0, m->n_owned, elo, n_stored ? (const int32_t*)((char*)ctx->ws + g_bytes) : (const int32_t*)nullptr,
+                         (const double*)((char*)ctx->ws + head));
       MFEM_CHECK_LAUNCH();
-      ++g_hex27_direct_count;
+      if (!n_stored) ++g_hex27_direct_count;
       return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
     }
   }

@@ -170,3 +170,104 @@ def test_hex27_scratch_free_path_on_a_long_lattice(mf):
         _lib.lib.mfem_debug_set_hex27(0)
     assert float((Kd - Kt).abs().max()) <= 1e-13 * float(Kt.abs().max())
     assert bool(torch.isfinite(Kd).all())
+
+
+def _centre_nodes(n):
+    """lattice ids of the elements' centre nodes (odd, odd, odd): a node that belongs to ONE element -- moving it makes exactly that element non-affine"""
+    m = [2 * v + 1 for v in n]
+    I, J, K = np.meshgrid(np.arange(n[0]), np.arange(n[1]), np.arange(n[2]), indexing="ij")
+    return (((2 * I + 1) * m[1] + (2 * J + 1)) * m[2] + (2 * K + 1)).ravel()
+
+
+@pytest.mark.parametrize("percent", [1, 30, 75, 100])
+def test_hex27_per_element_choice_on_mixed_meshes(mf, percent):
+    """Round 5: no all-or-nothing switch.  A mesh with `percent` % of its elements distorted (their centre node moved: exactly those
+    elements become non-affine) is assembled with the affine elements computed in place and the others through pass 1 into a scratch that holds only them
+    (k_hex27<true, true> in list mode + the streamed runs of k_hex27_direct).  Against the oracle <= 1e-12, against the two-pass MFMA path <= 1e-13; which path
+    ran is asserted (up to 80 % stored elements the per-element choice, beyond it the plain two-pass path -- or the choice when forced, bits 24-30)."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import fem, mesh as om, problems, reference_element as re_
+
+    x, n = (1.0, 1.5, 0.75), (5, 4, 5)
+    disc = re_.initialize_classical_element(3, "CUBE", 2, 1, 5)
+    msh = om.lattice_mesh(x, n, disc)
+    cn = _centre_nodes(n)
+    rng = np.random.default_rng(percent)
+    pick = cn if percent == 100 else rng.choice(cn, size=max(1, (len(cn) * percent) // 100), replace=False)
+    msh.coords[pick] += 0.03 * rng.standard_normal((len(pick), 3)) * np.array(x) / np.array(n)
+    od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, K_COND), [])
+    od.controlpoints["s"] = np.zeros(msh.ncp)
+    od.update_time()
+    od.K_linear_func()
+    brick = mf.make_Brick(x, n, 2, 5)
+    for d in range(3):
+        brick.coords_view(d).copy_(torch.tensor(msh.coords[:, d], device="cuda"))
+    A = brick.pattern(1)
+    lib = _lib.lib
+    scale = np.abs(od.K_linear).max()
+    try:
+        m0, d0 = lib.mfem_debug_hex27_mixed_count(), lib.mfem_debug_hex27_direct_count()
+        K = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+        assert lib.mfem_debug_hex27_direct_count() == d0                            # not the all-affine path ...
+        assert (lib.mfem_debug_hex27_mixed_count() > m0) == (percent <= 80)        # ... the per-element choice up to 80 % of the elements
+        lib.mfem_debug_set_hex27(1 << 10)                                           # the choice off: the two-pass path whole (round 4)
+        m1 = lib.mfem_debug_hex27_mixed_count()
+        K2 = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+        assert lib.mfem_debug_hex27_mixed_count() == m1
+        lib.mfem_debug_set_hex27(100 << 24)                                         # forced for any fraction
+        Kf = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+        assert lib.mfem_debug_hex27_mixed_count() > m1
+    finally:
+        lib.mfem_debug_set_hex27(0)
+    for got in (K, K2, Kf):
+        assert np.abs(got - od.K_linear).max() <= 1e-12 * scale
+    assert np.abs(K - K2).max() <= 1e-13 * scale and np.abs(Kf - K2).max() <= 1e-13 * scale
+    # with faces and a second assembly on the same workspace (the tables of the first call are reused in place)
+    Ka = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    Kb = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    assert float((Ka - Kb).abs().max()) == 0.0
+
+
+def test_hex27_assembly_time_is_monotone_in_the_distorted_fraction(mf):
+    """... and costs what its parts cost: at 48^3 elements the assembly with 0 / 1 / 25 / 50 % distorted elements takes increasing time, 1 % within 1.35x
+    of the all-affine mesh (round 4: 2.6x -- the whole mesh took the two-pass path), and never more than the two-pass path forced on the same mesh."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    n = (48, 48, 48)
+    brick = mf.make_Brick((1.0, 1.0, 1.0), n, 2, 5)
+    A = brick.pattern(1)
+    K = torch.empty(A.nnz, dtype=torch.float64, device="cuda")
+    base = [brick.coords_view(d).clone() for d in range(3)]
+    cn = torch.tensor(_centre_nodes(n), device="cuda")
+    perm = cn[torch.randperm(cn.numel(), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))]
+
+    def timed(reps=5):
+        brick.assemble_thermal(A, K_COND, 0.0, TENV, 0, out=K)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            brick.assemble_thermal(A, K_COND, 0.0, TENV, 0, out=K)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t = {}
+    for pct in (0, 1, 25, 50):
+        for d in range(3):
+            brick.coords_view(d).copy_(base[d])
+        k = (cn.numel() * pct) // 100
+        if k:
+            brick.coords_view(0)[perm[:k]] += 0.003
+        t[pct] = timed()
+    try:
+        _lib.lib.mfem_debug_set_hex27(1 << 10)
+        t["two_pass"] = timed()
+    finally:
+        _lib.lib.mfem_debug_set_hex27(0)
+    print("hex-27 48^3 assembly ms by distorted fraction:", {k: round(v, 3) for k, v in t.items()})
+    assert t[0] <= 1.10 * t[1] and t[1] <= 1.10 * t[25] and t[25] <= 1.10 * t[50]
+    assert t[1] <= 1.35 * t[0]
+    assert t[50] <= 1.10 * t["two_pass"]
