@@ -440,3 +440,116 @@ def test_t512_cg_converges_and_recurrences_agree(mf, t512):
     dx3, st3 = _cg(mf, A, K, R0, tol, 8000, max_pass=2, cg_variant=3)
     assert st3.converged == 1
     assert float((dx3 - dx).abs().max()) <= 1e-10 * float(dx.abs().max())
+
+
+# ---- round 5: the reference's own solver / boundary-condition path at the BASELINE sizes (bench.py: ref_idrs8_256, nitsche_c2_256, nitsche_c4_128) ----------
+H_PEN, TW = 1000.0, 1173.15  # examples/thermal_conduction/2D_Script.jl:46-47
+
+
+def _nitsche(mf, order, n):
+    import torch
+
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (n, n, n), order, 3 if order == 1 else 5)
+    A = brick.pattern(1)
+    x0 = mf.FACE_BITS["x0"]
+    kw = dict(fixed_faces=x0, h_penalty=H_PEN, Tw=TW)
+    K = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES & ~x0, **kw)
+    s = torch.full((A.n,), SRC, dtype=torch.float64, device="cuda")
+    return brick, A, K, s, kw, mf.ALL_FACES & ~x0
+
+
+@pytest.mark.parametrize("order,n", [(1, 256), (2, 128)])
+def test_nitsche_operator_properties_at_full_size(mf, order, n):
+    """The thermal form with the temperature fixed on x = 0 the reference's way (2D_Script.jl:58) at configs[1] / configs[3] size: the residual is affine in
+    T with the assembled K as its gradient (matrix-free face kernel against the assembled one); K applied to a constant leaves only the boundary terms
+    (-h * area of the five convective faces - h_penalty * area of the fixed one: the normal-derivative term annihilates constants); K is NOT symmetric,
+    and the asymmetry sits in the rows of the first lattice planes only; T = Tw, Tenv = Tw, s = 0 is the exact solution (zero residual)."""
+    import torch
+
+    brick, A, K, s, kw, robin = _nitsche(mf, order, n)
+    m = order * n + 1
+    assert A.n == m ** 3
+    rng = mf.FEM_rand(A.n, 21, 0)
+    T = 300.0 + 20.0 * (rng - 0.5)
+    R0 = brick.residual_thermal(torch.zeros_like(T), K_COND, H, TENV, robin, s=s, **kw)
+    R = brick.residual_thermal(T, K_COND, H, TENV, robin, s=s, **kw)
+    KT = torch.empty_like(T)
+    mf.mul_(KT, A, K, T)
+    assert float((R - (KT + R0)).abs().max()) <= 1e-9 * float(R.abs().max())
+    one = torch.ones_like(T)
+    y = torch.empty_like(T)
+    mf.mul_(y, A, K, one)
+    assert abs(float(y.sum()) + H * 5.0 + H_PEN * 1.0) <= 1e-7 * H_PEN
+    yi = y.view(m, m, m)[1:-1, 1:-1, 1:-1]
+    assert float(yi.abs().max()) <= 1e-9 * float(K.abs().max())
+    # nonsymmetric: x.A y != y.A x, and (A - A^T) x vanishes away from the fixed face
+    xv, yv = mf.FEM_rand(A.n, 11, 0) - 0.5, mf.FEM_rand(A.n, 11, 1) - 0.5
+    Ax, Ay = torch.empty_like(T), torch.empty_like(T)
+    mf.mul_(Ax, A, K, xv)
+    mf.mul_(Ay, A, K, yv)
+    assert abs(mf.dot(xv, Ay) - mf.dot(yv, Ax)) > 1e-8 * abs(mf.dot(xv, Ay))
+    far = slice(order + 1, None)
+    xv2 = xv.clone().view(m, m, m)
+    yv2 = yv.clone().view(m, m, m)
+    xv2[:order + 1] = 0.0
+    yv2[:order + 1] = 0.0   # vectors supported away from the face see a symmetric operator
+    mf.mul_(Ax, A, K, xv2.view(-1))
+    mf.mul_(Ay, A, K, yv2.view(-1))
+    a, b = mf.dot(xv2.view(-1), Ay), mf.dot(yv2.view(-1), Ax)
+    assert abs(a - b) <= 1e-11 * abs(a)
+    # exact solution of the homogeneous case
+    Tw = torch.full_like(T, TW)
+    Rz = brick.residual_thermal(Tw, K_COND, H, TW, robin, s=None, **kw)
+    assert float(Rz.abs().max()) <= 1e-9 * H_PEN * TW / (order * n) ** 2
+
+
+@pytest.mark.parametrize("order,n,mode", [(1, 256, 5), (2, 128, 4)])
+def test_nitsche_tiles_plus_remainder_at_full_size(mf, order, n, mode):
+    """A = S + N at configs[1] / configs[3] size, DEFAULT thresholds: bicgstabl_GS!(2) / idrs!(8) with Pr_Jacobi! on the nonsymmetric K run on the symmetric
+    lattice tiles + the skew remainder (rows = the lattice planes next to the fixed face: `order` planes of m^2 points); the residual the solver reports
+    equals ||b - A x|| / sqrt(n) from mul! (the CSR kernel on the caller's values); the solve without the remainder (the layouts that read every
+    entry) reaches the same solution; iterates after 8 fixed steps agree to 1e-12 with the same shadow vector."""
+    import ctypes as C
+
+    import torch
+    from metafem_jl_amd import _lib
+
+    lib = _lib.lib
+    brick, A, K, s, kw, robin = _nitsche(mf, order, n)
+    m = order * n + 1
+    R0 = brick.residual_thermal(torch.zeros(A.n, dtype=torch.float64, device="cuda"), K_COND, H, TENV, robin, s=s, **kw)
+    count = lib.mfem_debug_lat8_spmv_count if order == 1 else lib.mfem_debug_lat27_spmv_count
+    shadow = mf.FEM_rand(A.n, 0x5EED, 7)
+    r = torch.empty_like(R0)
+    sols, fixed = {}, {}
+    try:
+        for rem in (1, 0):
+            lib.mfem_debug_set_remainder(rem)
+            c0, r0 = int(count()), int(lib.mfem_debug_rem_spmv_count())
+            fixed[rem], _ = mf.iterative_Solve(A, K, R0, 1e-300, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=8, max_pass=1, fixed_iterations=True, shadow=shadow)
+            tol = 1e-9 * mf.normalized_norm(R0)
+            x, st = mf.iterative_Solve(A, K, R0, tol, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=4000, max_pass=4)
+            assert st.converged == 1 and st.final_res < tol
+            assert (int(count()) > c0) == bool(rem) and (int(lib.mfem_debug_rem_spmv_count()) > r0) == bool(rem)
+            mf.mul_(r, A, K, x)
+            assert st.final_res == pytest.approx(mf.normalized_norm(r - R0), rel=1e-6)
+            sols[rem] = x
+            if rem:
+                rows, ent, asym = C.c_int64(), C.c_int64(), C.c_double()
+                _lib.check(lib.mfem_debug_remainder_info(A._h, C.byref(rows), C.byref(ent), C.byref(asym)))
+                assert rows.value == order * m * m and asym.value > 4e-13
+    finally:
+        lib.mfem_debug_set_remainder(1)
+    assert float((fixed[1] - fixed[0]).abs().max()) <= 1e-12 * float(fixed[0].abs().max())
+    # (two solves stopped at a RESIDUAL of 1e-9 ||R0||: their solutions differ by that times the conditioning of a 256^3 Laplacian)
+    assert float((sols[1] - sols[0]).abs().max()) <= 1e-5 * float(sols[0].abs().max())
+    # the reference's default solver on the same system
+    x, st = mf.iterative_Solve(A, K, R0, 1e-9 * mf.normalized_norm(R0), Sv_func=mf.idrs_, s=8, maxiter=4000, max_pass=4)
+    assert st.converged == 1
+    assert float((x - sols[1]).abs().max()) <= 1e-5 * float(sols[1].abs().max())
+    # Newton round trip: T = -delta solves the (linear) problem; the fixed face sits at Tw to the penalty's accuracy
+    T = -sols[1]
+    R1 = brick.residual_thermal(T, K_COND, H, TENV, robin, s=s, **kw)
+    assert mf.normalized_norm(R1) <= 1e-8 * mf.normalized_norm(R0)
+    face = T.view(m, m, m)[0]
+    assert float((face - TW).abs().max()) < 0.05 * TW
