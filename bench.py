@@ -251,6 +251,10 @@ def main():
     ap.add_argument("--time-to-tol", type=int, default=1,
                     help="c3 legs: after the fixed-count steps, solve the same system to ||r|| / sqrt(n) <= 1e-8 ||r0|| with bicgstabl_GS!(2), idrs!(8) and cg! "
                          "and report iterations / ms / converged (0 = skip)")
+    ap.add_argument("--strong-leg", type=int, default=1,
+                    help="N > 1 with --scaling weak (the driver's command): also time THE config's n^3 mesh cut into N slabs for --secondary-steps steps and "
+                         "report it as `strong_scaling` (value, ms/step, exposed communication) -- one SCALE run then answers the north_star's '>= 6x at 8 GPUs' "
+                         "for the weak AND the strong reading (0 = skip)")
     ap.add_argument("--remainder", type=int, default=1,
                     help="0: switch the skew remainder of the lattice tiles off (mfem_debug_set_remainder): a nonsymmetric K then takes the layouts that read "
                          "every entry, as until round 4 -- the A/B of profiles/r05_nitsche_ab.txt")
@@ -426,7 +430,7 @@ def main():
 
     strong = args.scaling == "strong" and world > 1
 
-    def run_workload(cfg, ckey, N, steps, warmup, want_csr):
+    def run_workload(cfg, ckey, N, steps, warmup, want_csr, strong=strong):
         """One workload of config `ckey`, `steps` timed steps: weak scaling = an (N * world) x N x N mesh (an N-thick slab per rank), strong scaling =
         the N^3 mesh cut into `world` slabs along i."""
         order, F = cfg["order"], cfg["fields"]
@@ -824,6 +828,20 @@ def main():
         if "csr_kernel" in r:
             # the north_star's own number: the CSR kernel behind mul! on this matrix, measured in this run
             out["roofline"]["csr_kernel"] = r["csr_kernel"]
+    strong_res = None
+    if world > 1 and not strong and args.strong_leg:
+        # the same config as ONE mesh of its own size cut into `world` slabs (what --scaling strong times), a few steps: every rank takes part
+        strong_res = run_workload(cfg, REF_LEGS[args.config]["base"] if args.config in REF_LEGS else args.config, args.n, args.secondary_steps, 1,
+                                  want_csr=False, strong=True)
+        if rank == 0:
+            check_residual(strong_res, f"{args.config} {args.n}^3 strong")
+            t = strong_res
+            out["strong_scaling"] = {
+                "workload": f"{cfg['title']}, THE {args.n}^3 mesh cut into {world} slabs along i, {t['steps']} timed steps after 1 warm-up, same step as above",
+                "scaling": "strong", "value": t["n_global"] * t["updates"] / t["elapsed"], "unit": "DOF-updates/s", "n_dof": t["n_global"],
+                "ms_per_step": t["elapsed"] / t["steps"] * 1e3, "solve_ms_per_step": t["solve_ms"] / t["steps"],
+                "initial_res": t["initial_res"], "final_res": t["final_res"], "comm_exposed": t["comm_exposed"],
+                "note": "speed-up over one GPU = this value / the N = 1 line's value on the same mesh (the driver computes it from its own runs)"}
     if world == 1 and args.config == "c2" and args.secondary_n > 0 and args.secondary_n != args.n:
         # configs[1] of BASELINE.json (256^3 hex-8; also the matrix the round-1 / round-2 lines were quoted on)
         t = run_workload(cfg, "c2", args.secondary_n, args.secondary_steps, 1, want_csr=True)

@@ -257,6 +257,23 @@ def main():
     _lib.lib.mfem_debug_set_cg_single_max_rows(20000000)
     check("cg_auto_takes_the_classic_recurrence_on_large_systems", sa.converged == 1 and abs(sa.iterations - sg.iterations) <= 2 and relerr(xa, xg) <= 1e-10,
           iters=(sa.iterations, sg.iterations), rel_err=relerr(xa, xg))
+    if not rccl:
+        # ---- the communication SCHEDULE of one iteration (design budget), counted on the host transport's callbacks: fixed-count
+        #      solves of 10 and 60 iterations differ by 50 iterations' worth of calls -- one halo exchange per SpMV and ONE all-reduce per CG iteration in
+        #      the single-reduction form (two in the classic recurrence); bicgstabl_GS!(2): 4 SpMVs and at most 10 reduction groups per sweep (= 2 iterations)
+        def calls_per_iteration(sv, iters_unit=1, **kw):
+            c = {}
+            for nit in (10, 60):
+                e0, a0 = comm.calls["exchange"], comm.calls["allreduce"]
+                mf.iterative_Solve(A, K, R, 1e-300, Sv_func=sv, maxiter=nit, max_pass=1, fixed_iterations=True, shadow=shadow_loc.get(sv), **kw)
+                c[nit] = (comm.calls["exchange"] - e0, comm.calls["allreduce"] - a0)
+            return (c[60][0] - c[10][0]) / (50.0 / iters_unit), (c[60][1] - c[10][1]) / (50.0 / iters_unit)
+        ex, ar = calls_per_iteration(mf.cg_)
+        check("schedule_cg_single_reduction_1_halo_1_allreduce_per_iteration", ex == 1.0 and ar == 1.0, exchanges=ex, allreduces=ar)
+        ex, ar = calls_per_iteration(mf.cg_, cg_variant=1)
+        check("schedule_cg_classic_1_halo_2_allreduces_per_iteration", ex == 1.0 and ar == 2.0, exchanges=ex, allreduces=ar)
+        ex, ar = calls_per_iteration(mf.bicgstabl_GS_, iters_unit=2, s=2)
+        check("schedule_bicgstabl2_4_halos_at_most_10_allreduces_per_sweep", ex == 4.0 and 1.0 <= ar <= 10.0, exchanges=ex, allreduces=ar)
     if case == "thermal_hex8":
         check("symmetric_sweep_kernel_ran", int(_lib.lib.mfem_debug_sym_spmv_count()) > sym0)
     if case == "elasticity_hex8":  # the slab solves ran on the symmetric lattice tiles (mode 5: ghost planes staged, lower-ghost terms from the CSR values)

@@ -63,6 +63,10 @@ def test_two_ranks_on_one_gpu_through_the_host_transport():
     _common(out, 2)
     assert out["config"]["n_dof"] == 97 * 49 * 49 and "slab decomposition x2" in out["config"]["parallelism"]
     assert out["cpu_baseline"] is None
+    # round 5: the weak line also carries the STRONG reading (the config's own mesh cut into N slabs), so one scaling run answers both
+    ss = out["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["n_dof"] == 49 ** 3 and ss["value"] > 0 and ss["final_res"] < ss["initial_res"]
+    assert [c["rank"] for c in ss["comm_exposed"]] == [0, 1]
     # the communication each rank's solver stream was exposed to, per rank (host transport: the whole staged exchange is exposed)
     ce = out["comm_exposed"]
     assert [c["rank"] for c in ce] == [0, 1]
