@@ -524,11 +524,28 @@ def main():
             return solve()
 
         t_first = time.perf_counter()
+        first_split = None
         for w in range(warmup):
-            step()
             if w == 0:
+                # the first step, split: assembly (tables, first launches) | the first solve = one-off plans of the solver layouts +
+                # workspace allocation (+ the placement trial if opted in) + the solve itself
+                assemble()
                 torch.cuda.synchronize()
-                t_first = time.perf_counter() - t_first  # the first step: one-off plans, tables, workspace allocation (and the placement trial if opted in)
+                t_asm1 = time.perf_counter() - t_first
+                solve()
+                torch.cuda.synchronize()
+                t_first = time.perf_counter() - t_first
+                first_split = {"assembly_s": t_asm1, "solve_s": t_first - t_asm1}
+            else:
+                t_w = time.perf_counter()
+                _, st_w = step()
+                torch.cuda.synchronize()
+                if first_split is not None and "steady_step_s" not in first_split:
+                    first_split["steady_step_s"] = time.perf_counter() - t_w
+                    first_split["steady_solve_s"] = st_w.solve_ms * 1e-3
+                    first_split["one_off_s"] = max(first_split["solve_s"] - st_w.solve_ms * 1e-3, 0.0)
+                    first_split["note"] = ("one_off_s = first solve - a steady solve: pattern inspection and layout plans (once per pattern), workspace "
+                                           "allocation, and the placement trial's extra allocations and timed products when --ws-trial 1")
         _lib.check(_lib.lib.mfem_prof_spmv_enable(ctx._h, 1))
         if comm is not None:
             _lib.check(_lib.lib.mfem_prof_comm_enable(ctx._h, 1))
@@ -581,7 +598,7 @@ def main():
                "spmv_ms": tot.value / max(cnt.value, 1), "spmv_launches": int(cnt.value),
                # the LAST timed solve, as the library reports it (true residual ||b - A x|| / sqrt(n) recomputed after the pass, 02_Preconditioner.jl:53-55)
                "initial_res": st.initial_res if st else None, "final_res": st.final_res if st else None,
-               "first_step_s": t_first if warmup > 0 else None, "comm_exposed": comm_exposed, "cfg": cfg, "ckey": ckey}
+               "first_step_s": t_first if warmup > 0 else None, "first_step_split": first_split, "comm_exposed": comm_exposed, "cfg": cfg, "ckey": ckey}
         # A = S + N (csrc/spmv_rem.hip): did the timed solves run on symmetric lattice tiles + the sparse skew remainder of a nonsymmetric K, and how big was it
         rr_, re_, ra_ = C.c_int64(), C.c_int64(), C.c_double()
         _lib.check(_lib.lib.mfem_debug_remainder_info(A._h, C.byref(rr_), C.byref(re_), C.byref(ra_)))
@@ -812,7 +829,7 @@ def main():
                 "initial_res": r["initial_res"], "final_res": r["final_res"],
                 # the same residual recomputed after the timed region with mul! (the CSR kernel on the caller's arrays): must agree to 1e-5 relative
                 "final_res_recomputed": r.get("final_res_recomputed"),
-                "first_step_s": r["first_step_s"],
+                "first_step_s": r["first_step_s"], "first_step_split": r.get("first_step_split"),
                 "workspace_placement_trial": ("on (--ws-trial 1: the first solve times the SpMV on up to three allocations of the workspace and keeps the "
                                               "fastest; its cost is inside first_step_s, outside the timed region)" if args.ws_trial else
                                               "off (library default since round 4)"),

@@ -237,7 +237,19 @@ typedef struct {
  * in __constant__ memory per PROCESS (uploads are serialised): assemblies with different Gauss orders must not run concurrently from
  * different host threads.  The mfem_debug_* knobs are process-wide atomics, to be changed only while no call is in flight. */
 
-/* delta_x = iterative_Solve!(globalfield; Sv_func!, Pr_func!, max_pass, maxiter, s)
+/* Speed of a large solve depends on the ALLOCATION its workspace received, by up to ~10 %: at 512^3 (45 GB of workspace) the Krylov loop's SpMV runs at
+ * 3.9 - 4.05 ms or at 4.3 - 4.5 ms depending on the physical memory behind the workspace (address-translation reach: UTCL2 misses 1.1 - 1.3e5 against 2.0e5
+ * per launch with identical requests and bytes, profiles/r04_placement_counters.txt); which kind a hipMalloc returns is outside the library's control (the
+ * virtual-memory API with 2 MiB / 1 GiB chunks showed the same spread).  The library does NOT hunt for the fast kind by default -- that costs seconds of
+ * allocation work and twice the workspace (mfem_debug_set_ws_trial, opt-in; bench.py opts in and says so) -- so a caller sees either speed, about evenly.
+ * Results are identical.
+ * A nonsymmetric K (round 5): the symmetric lattice tiles of modes 4 / 5 keep serving idrs! / bicgstabl_GS! / cgs2! solves whose values fail the symmetry gate in
+ * at most n / 8 rows -- the reference's Nitsche / SUPG boundary terms -- by carrying the mirrored entries' differences of those rows as a small CSR applied
+ * behind the tiles (A = S + N, csrc/spmv_rem.hip); the acceptance test is the same probe, applied to S + N.  cg! is never offered that.
+ * Between passes: when the tiles' copy says a pass has converged, the residual that ENDS the passes is recomputed with the CSR kernel on the
+ * caller's own values (one rank; with a communicator the tiles' residual decides, and stats.final_res is the tiles').
+ *
+ * delta_x = iterative_Solve!(globalfield; Sv_func!, Pr_func!, max_pass, maxiter, s)
  * (linear_solver/02_Preconditioner.jl:32-76).  b = residue, x_out = the returned vector
  * (caller-allocated, length n; x0 = 0 as in :45).  K_val_ids is the identity in this backend. */
 int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const double* b, double* x_out,
