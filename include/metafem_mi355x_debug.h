@@ -143,6 +143,12 @@ int mfem_debug_ws_trial_log(mfem_context ctx, double* out4);
  * mfem_last_error() set and leaves every handle valid.  0 disarms.  tests/test_gpu_round4_abi.py. */
 int mfem_debug_fail_host_alloc(int nth);
 
+/* CSR kernel behind mul! on rows of near-uniform length (k_spmv_csr_w), a round-5 experiment, OFF by default: on = 1 makes the workgroups of an XCD walk an eighth of
+ * every lattice plane through all planes (one-field lattice patterns whose two planes of x exceed `min_bytes`; < 0 keeps the threshold, default 3 MiB) instead of
+ * sharing one front with the other XCDs, so that an L2 holds the x window it re-reads.  Measured: 8.34 against 8.23 ms at 512^3, 1.113 against 1.092 at 256^3
+ * (profiles/r05_csr_strips.txt) -- the kernel's time does not follow the re-read x (Infinity-Cache hits).  Same tiles, same sums: bitwise the same y. */
+int mfem_debug_set_csr_strips(int on, int64_t min_bytes);
+
 /* A = S + N (round 5, csrc/spmv_rem.hip): a symmetric lattice-tile bind (modes 4 / 5) whose values fail the symmetry gate in at most n / 8 rows keeps
  * the tiles and carries the mirrored entries' differences N[r][c] = A[r][c] - A[c][r] of those rows as a small CSR applied after the tiles' gather pass
  * (Nitsche / SUPG faces: the reference's nonsymmetric K).  Bit 0 (default 1): on; 0 -- such values send the solve to the layouts that read every entry, as

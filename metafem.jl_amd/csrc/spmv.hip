@@ -298,6 +298,15 @@ __global__ __launch_bounds__(BLK) void k_spmv_csr_t(
   }
 }
 
+static std::atomic<int> g_csr_w_strips{0};                       // mfem_debug_set_csr_strips -- OFF: measured, no gain (profiles/r05_csr_strips.txt)
+static std::atomic<int64_t> g_csr_w_strip_min_bytes{3 << 20};  // two lattice planes of x beyond this many bytes -> XCD strips
+extern "C" int mfem_debug_set_csr_strips(int on, int64_t min_bytes) try {
+  ++mfem_debug_epoch;
+  g_csr_w_strips = on ? 1 : 0;
+  if (min_bytes >= 0) g_csr_w_strip_min_bytes = min_bytes;
+  return MFEM_OK;
+} MFEM_API_CATCH("mfem_debug_set_csr_strips")
+
 // Wave-private row-transposing tiles.  What bounds the two kernels above is the texture addresser: a 64-lane gather costs
 // ~17 cycles when the lanes read consecutive entries of x and ~100 cycles in CSR order with a nonzero pair per lane (42 distinct
 // cache lines per instruction; tools/ta_probe.hip), i.e. ~1.2 ms of addresser time per SpMV at 256^3.  Here a WAVE owns a run
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int R, int tpr_log2, int64_t ntiles, const double* __restrict__ dotw,
-    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part, const uint8_t* __restrict__ elide) {
+    double* __restrict__ partials, const int32_t* __restrict__ done_flag, SpmvPart part, const uint8_t* __restrict__ elide, int64_t strip_tp) {
   constexpr int LU = (CAPW / 2 + 63) / 64;  // (16 B + 8 B) loads per lane that cover a full tile
   static_assert(CAPW % 128 == 0, "the staging loop stores whole 128-entry groups");
   // NG = gathers a lane issues up front (rows of up to NG * tpr entries have none left over)
@@ -332,13 +341,32 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   // gathers were in flight), the row-pointer pair of the tile after that is requested one step earlier still.
   d2_t pv[LU];
   i2_t pc[LU];
-  int64_t t_cur = (int64_t)blockIdx.x * WAVES + w;
-  // skip tiles that belong to the other part of a split SpMV (wave-uniform)
-  auto next_tile = [&](int64_t t) -> int64_t {
-    while (t < ntiles && spmv_part_skip(part, t * R, (t * R + R < n) ? t * R + R : n)) t += tstride;
-    return t;
+  // Which tile a wave takes next.  Default: tiles round-robin over the grid -- all XCDs move along ONE front through the matrix, and a line of x is held by
+  // an L2 from its first use (as the upper neighbour plane of a row) to its last (lower neighbour plane): two lattice planes of x, 1 MB at 256^3 but 4.2 MB at
+  // 512^3 -- more than the 4 MB L2 of an XCD, so x came in three times (counter traffic 1.12x the design bytes, round 4).
+  // strip_tp > 0 (round 5, an experiment kept behind mfem_debug_set_csr_strips, OFF by default: 8.34 against 8.23 ms at 512^3 -- the re-read x comes from the
+  // Infinity Cache and is not what the kernel's time follows): tiles per lattice plane, rounded up.  The workgroups of XCD c (blockIdx % 8:
+  // round-robin dispatch) then take, in every plane, the tiles [tp c / 8, tp (c + 1) / 8) -- an eighth of the plane swept through all planes, whose x window
+  // (3 planes x 1 / 8 plane + two lines) stays in that XCD's L2.  Same tiles, same sums, another order of the walk: bitwise the same y.
+  const int64_t xc = blockIdx.x & 7;
+  const int64_t sb = strip_tp > 0 ? strip_tp * xc / 8 : 0, sx = strip_tp > 0 ? strip_tp * (xc + 1) / 8 - sb : 1;
+  const int64_t qstride = strip_tp > 0 ? (int64_t)(gridDim.x >> 3) * WAVES : tstride;
+  int64_t q_cur = strip_tp > 0 ? (int64_t)(blockIdx.x >> 3) * WAVES + w : (int64_t)blockIdx.x * WAVES + w;
+  auto tile_at = [&](int64_t q) -> int64_t {  // tile of walk position q; >= ntiles: past the end (and so is every later position)
+    if (strip_tp <= 0) return q;
+    const int64_t p = q / sx, t = p * strip_tp + sb + (q - p * sx);
+    return p * strip_tp >= ntiles ? ntiles : (t < ntiles ? t : -1);  // -1: this position holds no tile (the last, partial plane), later ones may
   };
-  t_cur = next_tile(t_cur);
+  // skip positions without a tile and tiles that belong to the other part of a split SpMV (wave-uniform)
+  auto next_tile = [&](int64_t& q) -> int64_t {
+    for (;;) {
+      const int64_t t = tile_at(q);
+      if (t >= ntiles) return ntiles;
+      if (t >= 0 && !spmv_part_skip(part, t * R, (t * R + R < n) ? t * R + R : n)) return t;
+      q += qstride;
+    }
+  };
+  int64_t t_cur = next_tile(q_cur);
   int64_t sa_cur = 0;
   int cnt_cur = 0, lo_cur = 0, hi_cur = 0;
   auto uniform64 = [](int64_t v) -> int64_t {  // the value is the same in every lane: keep it in scalar registers
@@ -400,7 +428,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     }
     // ---- ... then the request for the next tile: it returns behind the gathers (loads return in order), so the row sums
     //      below do not wait for it, and it is in flight while they run
-    const int64_t t_next = next_tile(t_cur + tstride);
+    q_cur += qstride;
+    const int64_t t_next = next_tile(q_cur);
     int64_t sa_n = 0;
     int cnt_n = 0, lo_n = 0, hi_n = 0, el_n = 0;
     // (the LDS block is still being read below: the next tile stays in registers until the top of the loop)
@@ -1191,10 +1220,16 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
         if (want < capw) capw = (int)want;
       }
       const int gridw = (int)((ntw + waves - 1) / waves < capw ? (ntw + waves - 1) / waves : capw);
+      // XCD strips (see the kernel): a one-field lattice pattern whose two planes of x outgrow an XCD's L2 (4 MB) -- 512^3, not 256^3
+      int64_t strip_tp = 0;
+      if (g_csr_w_strips && part.part == 0 && (gridw & 7) == 0 && A->lat_fields == 1 && A->lat_m1 > 0 && A->lat_m2 > 0 && A->ncols <= A->n) {
+        const int64_t PL = (int64_t)A->lat_m1 * A->lat_m2;
+        if (PL * 16 > g_csr_w_strip_min_bytes && A->n >= 4 * PL) strip_tp = (PL + Rw - 1) / Rw;
+      }
 #define LAUNCH_W(RP, CAPW, WV, NG)                                                                               \
   hipLaunchKernelGGL((k_spmv_csr_w<RP, CAPW, WV, NG>), dim3(gridw), dim3(64 * WV), 0, ctx->stream, A->n, A->nnz, \
                      (const RP*)A->rowptr, A->colidx, vals, x, y, alpha, beta, base, Rw, tl, ntw, dotw, partials, \
-                     done_flag, part, (A->cw_elide && A->cw_R == Rw) ? A->cw_elide : nullptr)
+                     done_flag, part, (A->cw_elide && A->cw_R == Rw) ? A->cw_elide : nullptr, strip_tp)
 #define LAUNCH_WV(RP)                                   \
   do {                                                  \
     if (huge && waves == 2) LAUNCH_W(RP, 2688, 2, 42);  \
