@@ -255,6 +255,7 @@ def main():
                     help="N > 1 with --scaling weak (the driver's command): also time THE config's n^3 mesh cut into N slabs for --secondary-steps steps and "
                          "report it as `strong_scaling` (value, ms/step, exposed communication) -- one SCALE run then answers the north_star's '>= 6x at 8 GPUs' "
                          "for the weak AND the strong reading (0 = skip)")
+    ap.add_argument("--strong-leg-timeout", type=float, default=240.0, help="seconds after which the strong-scaling leg is given up (the weak line is printed without it)")
     ap.add_argument("--remainder", type=int, default=1,
                     help="0: switch the skew remainder of the lattice tiles off (mfem_debug_set_remainder): a nonsymmetric K then takes the layouts that read "
                          "every entry, as until round 4 -- the A/B of profiles/r05_nitsche_ab.txt")
@@ -769,7 +770,9 @@ def main():
         strict = r["cfg"]["solver"] == "cg"
         # (round 5: 2 x ||r0|| instead of 100 x -- a solve that DIVERGES is not a measurement; whether the same system converges in a sane number of steps is
         # the `time_to_tol` object of the c3 legs)
-        ok = ir is not None and fr is not None and fr == fr and ir == ir and fr < float("inf") and (fr < ir if strict else fr < 2.0 * ir)
+        # (shorter fixed counts than the default 200 -- the functional runs of the test-suite -- sit inside BiCGStab's initial hump: 40 steps leave 2.3 x ||r0|| on c3)
+        loose = 2.0 if args.iters >= 200 else 10.0
+        ok = ir is not None and fr is not None and fr == fr and ir == ir and fr < float("inf") and (fr < ir if strict else fr < loose * ir)
         if not ok:
             raise SystemExit(f"bench.py: {what}: the last timed solve did not reduce the residual (initial {ir}, final {fr}) -- the run is invalid")
         rc = r.get("final_res_recomputed")
@@ -847,11 +850,39 @@ def main():
             out["roofline"]["csr_kernel"] = r["csr_kernel"]
     strong_res = None
     if world > 1 and not strong and args.strong_leg:
-        # the same config as ONE mesh of its own size cut into `world` slabs (what --scaling strong times), a few steps: every rank takes part
-        strong_res = run_workload(cfg, REF_LEGS[args.config]["base"] if args.config in REF_LEGS else args.config, args.n, args.secondary_steps, 1,
-                                  want_csr=False, strong=True)
-        if rank == 0:
-            check_residual(strong_res, f"{args.config} {args.n}^3 strong")
+        # the same config as ONE mesh of its own size cut into `world` slabs (what --scaling strong times), a few steps: every rank takes part.
+        # The weak measurement above is what the driver asked for and is COMPLETE at this point: a watchdog on every rank makes sure a problem in this extra
+        # leg (it builds a second communicator) can only cost the extra object, never the line -- past the deadline rank 0 prints the line it has and
+        # all ranks leave.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["strong_scaling"] = {"error": f"the strong-scaling leg did not finish within {args.strong_leg_timeout} s; the line above is the complete weak measurement"}
+                out["cpu_baseline"] = None
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.strong_leg_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            strong_res = run_workload(cfg, REF_LEGS[args.config]["base"] if args.config in REF_LEGS else args.config, args.n, args.secondary_steps, 1,
+                                      want_csr=False, strong=True)
+        except Exception as e:  # (an error on one rank usually shows on all of them: every rank reports and the line still goes out)
+            strong_res = None
+            if rank == 0:
+                out["strong_scaling"] = {"error": repr(e)}
+        finally:
+            watchdog.cancel()
+        if rank == 0 and strong_res is not None:
+            try:
+                check_residual(strong_res, f"{args.config} {args.n}^3 strong")
+            except SystemExit as e:  # (the extra leg must not take the line down)
+                out["strong_scaling"] = {"error": str(e)}
+                strong_res = None
+        if rank == 0 and strong_res is not None:
             t = strong_res
             out["strong_scaling"] = {
                 "workload": f"{cfg['title']}, THE {args.n}^3 mesh cut into {world} slabs along i, {t['steps']} timed steps after 1 warm-up, same step as above",
