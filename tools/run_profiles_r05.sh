@@ -22,7 +22,7 @@ if echo "$what" | grep -q pmc; then
 fi
 if echo "$what" | grep -q stats; then
   i=0
-  for leg in "c2_512:--config c2 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c2_256:--config c2 --n 256 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c3_128:--config c3" "c4_128:--config c4" "ref_idrs8_256:--config ref_idrs8" "nitsche_c2_256:--config nitsche_c2" "nitsche_c4_128:--config nitsche_c4"; do
+  for leg in "c2_512:--config c2 --secondary-n 0 --secondary-configs 0 --ref-legs 0 --hex27-n 0" "c2_256:--config c2 --n 256 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c3_128:--config c3" "c4_128:--config c4" "ref_idrs8_256:--config ref_idrs8" "nitsche_c2_256:--config nitsche_c2" "nitsche_c4_128:--config nitsche_c4"; do
     name=${leg%%:*}; args=${leg#*:}
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05/$name -o bench --output-format csv -- python3 $R/bench.py $args --steps 3 --warmup 1 --live-traffic 0 --cpu-n 0 > $R/gpurun_out/prof_r05/${name}_under_rocprof.json 2> $R/gpurun_out/prof_r05/${name}.err || { echo "stats $name failed"; tail -3 $R/gpurun_out/prof_r05/${name}.err; exit 1; }
     cp $R/gpurun_out/prof_r05/$name/bench_kernel_stats.csv $R/gpurun_out/prof_r05/${name}_kernel_stats.csv
