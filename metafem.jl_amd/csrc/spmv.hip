@@ -471,8 +471,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
 // in LDS next to its val / col streams.  Same software pipeline as above (next tile's streams requested behind the first chunk of
 // gathers); the tile's row range is requested one tile earlier still.
 #define RB_ROWS 128  // row pointers staged per tile (tiles with more rows -- runs of very short rows -- read the rest from memory)
+#ifndef RB_WAVES_PER_EU
+#define RB_WAVES_PER_EU 2
+#endif
 template <typename RP, int CAPW, int NG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_spmv_csr_rb(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RB_WAVES_PER_EU))) void k_spmv_csr_rb(
     int64_t n, int64_t nnz, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
     const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double alpha,
     double beta, int base, int64_t ntiles, const int32_t* __restrict__ rs, const double* __restrict__ dotw,
@@ -779,9 +782,16 @@ extern "C" int mfem_debug_set_spmv(int xcd_aware, int grid_mult) try {  // tunin
 
 // Measured on the hex-27 128^3 matrix (capacity, gathers in flight, workgroups per CU): (2048, 16, 6) 2.99 ms, (1792, 16, 7) 2.86,
 // (1536, 16, 8) 2.62, (1536, 20, 8) 3.02, (1280, 16, 8) 2.82, (1024, 12, 12) 4.47 -- two waves on every SIMD, the largest tile that allows it
+// (overridable with -D for the sweep of tools/rb_sweep.sh: profiles/r05_csr_rb_sweep.txt)
+#ifndef RB_CAP
 #define RB_CAP 1536  // entries per tile of the row-block kernel (19.5 KB of LDS: eight one-wave workgroups per CU)
+#endif
+#ifndef RB_NG
 #define RB_NG 16    // gathers a lane has in flight
+#endif
+#ifndef RB_WG_PER_CU
 #define RB_WG_PER_CU 8
+#endif
 // do wave tiles of a fixed row count fill their LDS block (>= 0.65)?  (rows of near-uniform length: k_spmv_csr_w)
 static bool csr_w_fills(const mfem_csr_s* A) {
   if (!(A->max_row_nnz > 0 && A->max_row_nnz <= 2048 - 2) || A->n == 0) return false;
