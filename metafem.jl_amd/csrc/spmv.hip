@@ -1185,7 +1185,18 @@ static int spmv_launch_inner(mfem_context_s* ctx, mfem_csr_s* A, const double* v
   if (variant == 3 && A->rb_state == 1 && part.part == 0 && ((((uintptr_t)vals) & 15) == 0) && ((((uintptr_t)A->colidx) & 7) == 0) &&
       (A->ncols > 0 ? A->ncols : A->n) < ((int64_t)1 << 29)) {
     // tiles cut by nonzeros (rows of uneven length); the grid is what is resident
-    int grid = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult.load() : RB_WG_PER_CU);
+    // (persistent grid = what is resident at once: one workgroup more per CU than fits runs as a second round and doubles the time -- the runtime says how
+    // many of these one-wave workgroups a CU holds, RB_WG_PER_CU is the upper bound)
+    static std::atomic<int> rb_resident[2] = {{0}, {0}};
+    std::atomic<int>& res = rb_resident[A->rowptr_bits == 64 ? 1 : 0];
+    if (res == 0) {
+      int occ = 0;
+      const hipError_t eo = A->rowptr_bits == 64
+          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k_spmv_csr_rb<int64_t, RB_CAP, RB_NG>), 64, 0)
+          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k_spmv_csr_rb<int32_t, RB_CAP, RB_NG>), 64, 0);
+      res = (eo == hipSuccess && occ >= 1 && occ <= RB_WG_PER_CU) ? occ : RB_WG_PER_CU;
+    }
+    int grid = ctx->num_cus * (g_spmv_grid_mult_set ? g_spmv_grid_mult.load() : res.load());
     if (grid > MFEM_MAX_PARTIALS) grid = MFEM_MAX_PARTIALS;
     if ((int64_t)grid > A->rb_ntiles) grid = (int)A->rb_ntiles;
     if (A->rowptr_bits == 64)

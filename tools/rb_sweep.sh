@@ -12,9 +12,9 @@ build() {  # name, flags
   echo "built $1"
 }
 build cap1536_ng16_wg8_eu2 ""
-build cap1024_ng16_wg12_eu3 "-DRB_CAP=1024 -DRB_WG_PER_CU=12 -DRB_WAVES_PER_EU=3"
-build cap768_ng16_wg16_eu4 "-DRB_CAP=768 -DRB_WG_PER_CU=16 -DRB_WAVES_PER_EU=4"
 build cap1024_ng8_wg12_eu3 "-DRB_CAP=1024 -DRB_NG=8 -DRB_WG_PER_CU=12 -DRB_WAVES_PER_EU=3"
-build cap1536_ng24_wg8_eu2 "-DRB_NG=24"
-build cap2048_ng16_wg6_eu2 "-DRB_CAP=2048 -DRB_WG_PER_CU=6"
-build cap1280_ng16_wg9_eu3 "-DRB_CAP=1280 -DRB_WG_PER_CU=9 -DRB_WAVES_PER_EU=3"
+build cap1024_ng12_wg12_eu3 "-DRB_CAP=1024 -DRB_NG=12 -DRB_WG_PER_CU=12 -DRB_WAVES_PER_EU=3"
+build cap1280_ng8_wg12_eu3 "-DRB_CAP=1280 -DRB_NG=8 -DRB_WG_PER_CU=12 -DRB_WAVES_PER_EU=3"
+build cap768_ng8_wg16_eu4 "-DRB_CAP=768 -DRB_NG=8 -DRB_WG_PER_CU=16 -DRB_WAVES_PER_EU=4"
+build cap1536_ng12_wg8_eu2 "-DRB_NG=12"
+build cap1792_ng16_wg8_eu2 "-DRB_CAP=1792"
