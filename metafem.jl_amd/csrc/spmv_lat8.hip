@@ -115,23 +115,31 @@ struct L8Row {  // what a lane knows about its node
   int gi, gj, gk, li, lj, lk, nj, nk, cnt;
   int64_t rp[3];
 };
+// Round 5: the fill reads the caller's CSR values through LDS.  A lane's entries sit in its own row, 216 F bytes from the next lane's: read straight from memory every
+// load instruction touched 64 different lines (3.4 ms for the 5.5 GB of the 256^3 one-field copy = 1.6 TB/s: round 4's weakest per-solve pass).  The rows of four
+// k-consecutive nodes are ONE contiguous piece of the CSR value array, so the wave copies the four pieces of an i-layer of its unit (row field f) into LDS with unit-stride
+// loads and the 16 lanes of that layer pick their entries there; four layers per field.  `src` = the lane's row in the staged copy (valid in the lane's own phase).
 template <int F, int S, int SEND>
-__device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* v, double& amax) {
+__device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, const double* src, bool active, double* v, double& amax) {
   if constexpr (S < SEND) {
-    double val = 0.0;
     if constexpr (S < l8_nsteps(F)) {
-      constexpr int f = l8_row_field(F, S), g = l8_g(F, S), e = l8_e(F, S);
+      constexpr int g = l8_g(F, S), e = l8_e(F, S);
       constexpr int di = l8_di(e), dj = l8_dj(e), dk = l8_dk(e);
       const int ci = R.gi + di, cj = R.gj + dj, ck = R.gk + dk;
-      if (R.valid && ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (the neighbour may sit in a ghost plane: its x comes from the ghost block)
-        val = vals[R.rp[f] + (int64_t)g * R.cnt + ((di - R.li) * R.nj + (dj - R.lj)) * R.nk + (dk - R.lk)];
-        double av = fabs(val);
-        if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
-        amax = fmax(amax, av);
+      if (active) {
+        double val = 0.0;
+        if (R.valid && ci < G.mg && cj >= 0 && cj < G.m1 && ck >= 0 && ck < G.m2) {  // (the neighbour may sit in a ghost plane: its x comes from the ghost block)
+          val = src[g * R.cnt + ((di - R.li) * R.nj + (dj - R.lj)) * R.nk + (dk - R.lk)];
+          double av = fabs(val);
+          if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
+          amax = fmax(amax, av);
+        }
+        v[0] = val;
       }
+    } else {
+      if (active) v[0] = 0.0;  // (the padding step)
     }
-    v[0] = val;
-    l8_fetch<F, S + 1, SEND>(R, G, vals, v + 1, amax);
+    l8_fetch<F, S + 1, SEND>(R, G, src, active, v + 1, amax);
   }
 }
 // steps [S0, S0 + 2 NP) from v to their places: pair k at doubles ((S0 / 2 + k) * 64 + lane) * 2
@@ -145,28 +153,75 @@ __device__ __forceinline__ void l8_put(double* __restrict__ ou, const double* v)
     *(m_d2*)(ou + (int64_t)(S0 / 2 + k) * 128) = pr;
   }
 }
+#define L8_SEG (4 * 27)  // entries of the four rows of a staged piece, per field of columns
 // the steps of row field f: [first(f), first(f + 1)), the last field up to the padded end.  Pairs are (even, odd) steps: a field that starts on an
 // odd step takes the previous field's last value along (carry), one that ends on an even step (and is not the last) hands its last value on.
 template <int F, int f>
-__device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* __restrict__ ou, double& carry,
-                                              double& amax) {
+__device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* stage, double* __restrict__ ou,
+                                              double& carry, double& amax) {
   if constexpr (f < F) {
     constexpr int S0 = l8_first(F, f), S1 = (f == F - 1) ? l8_padded(F) : l8_first(F, f + 1);
     constexpr int lead = S0 & 1;                 // one value carried in
     constexpr int cnt = S1 - S0 + lead;          // values in v
     constexpr int np = cnt / 2;                  // whole pairs
+    constexpr int SEGCAP = F * L8_SEG + 4;       // doubles per staged piece (+ padding: the four pieces start on different banks)
     double v[cnt];
     if constexpr (lead) v[0] = carry;
-    l8_fetch<F, S0, S1>(R, G, vals, v + lead, amax);
+    const int lane = threadIdx.x & 63;
+    // the piece a lane's row belongs to: rows of the four lanes (la, lb, 0..3); its start = the first lane's row, its end = the end of the last valid row
+    const int64_t rowlen = R.valid ? (int64_t)F * R.cnt : 0;
+    const int64_t rstart = R.valid ? R.rp[f] : ((int64_t)1 << 62), rend = R.valid ? R.rp[f] + rowlen : 0;
+    int64_t ps = rstart, pe = rend;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      const int64_t os = __shfl_xor(ps, o, MFEM_WAVE), oe = __shfl_xor(pe, o, MFEM_WAVE);
+      ps = os < ps ? os : ps;
+      pe = oe > pe ? oe : pe;
+    }
+    const int plen = pe > ps ? (int)(pe - ps) : 0;  // (0: no valid row in the piece)
+    const int lb = (lane >> 2) & 3;
+    const double* src = stage + lb * SEGCAP + (R.valid ? (int)(rstart - ps) : 0);
+#pragma unroll 1
+    for (int la = 0; la < 4; ++la) {
+      // the four pieces of layer la: start / length are those of lanes 16 la + 4 lb (wave-uniform through readlane)
+      double t[4][(F * L8_SEG + 63) / 64];
+      int len[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int sl = 16 * la + 4 * b;
+        const uint32_t lo32 = __builtin_amdgcn_readlane((uint32_t)(uint64_t)ps, sl), hi32 = __builtin_amdgcn_readlane((uint32_t)((uint64_t)ps >> 32), sl);
+        const int64_t st = (int64_t)(((uint64_t)hi32 << 32) | lo32);
+        len[b] = __builtin_amdgcn_readlane(plen, sl);
+#pragma unroll
+        for (int u = 0; u < (F * L8_SEG + 63) / 64; ++u) {
+          const int i = lane + 64 * u;
+          t[b][u] = i < len[b] ? __builtin_nontemporal_load(vals + st + i) : 0.0;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // (the previous layer's reads of the staged copy are done)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int u = 0; u < (F * L8_SEG + 63) / 64; ++u) {
+          const int i = lane + 64 * u;
+          if (i < len[b]) stage[b * SEGCAP + i] = t[b][u];
+        }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      l8_fetch<F, S0, S1>(R, G, src, (lane >> 4) == la, v + lead, amax);
+    }
     l8_put<S0 - lead, np>(ou, v);
     if constexpr (cnt & 1) carry = v[cnt - 1];
-    l8_fill_field<F, f + 1>(R, G, vals, ou, carry, amax);
+    l8_fill_field<F, f + 1>(R, G, vals, stage, ou, carry, amax);
   }
 }
 template <typename RP, int F>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __restrict__ rowptr, int base, const double* __restrict__ vals,
                                                           double* __restrict__ out, unsigned long long* __restrict__ stats) {
+  __shared__ double stage_all[MFEM_BLOCK / 64][4 * (F * L8_SEG + 4)];
   const int lane = threadIdx.x & 63;
+  double* stage = stage_all[threadIdx.x >> 6];
   const int la = lane >> 4, lb = (lane >> 2) & 3, lc = lane & 3;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -196,7 +251,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
     }
     R.cnt = ni * R.nj * R.nk;
     double carry = 0.0;
-    l8_fill_field<F, 0>(R, G, vals, out + u * (int64_t)(l8_padded(F) * 64) + lane * 2, carry, amax);
+    l8_fill_field<F, 0>(R, G, vals, stage, out + u * (int64_t)(l8_padded(F) * 64) + lane * 2, carry, amax);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
