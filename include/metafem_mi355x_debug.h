@@ -82,8 +82,12 @@ int mfem_debug_set_halo_overlap(int on);
  * by default its matrix is built by a row-owner gather from per-element G0 and the reference integrals, Ke never stored).
  * Bit 10 (round 5): the PER-ELEMENT choice off -- a mesh with at least one non-affine element then takes the two-pass path whole (round 4's behaviour;
  * by default its affine elements are computed in place and only the others go through pass 1, into a scratch that holds only them).  Bits 24-30:
- * percentage of non-affine elements up to which the per-element choice is taken (0 = the default 80; beyond it the two-pass path is faster). */
+ * percentage of non-affine elements up to which the per-element choice is taken (0 = the default 80; beyond it the two-pass path is faster).
+ * Bit 11 (round 5): the row-owner kernel of GENERAL elements off (k_hex27_rows_gq: rows computed in place from per-element G_q by sum factorisation, no Ke
+ * stored anywhere; taken by default from bits 2-7 percent of non-affine elements on -- 0 = the default 10 -- when the mesh has three Gauss points per direction). */
 int mfem_debug_set_hex27(int two_pass);
+/* number of hex-27 matrix assemblies that took the row-owner kernel of general elements (process-wide) */
+int64_t mfem_debug_hex27_rows_count(void);
 /* number of hex-27 matrix assemblies that took the per-element choice with at least one stored (non-affine) element (process-wide) */
 int64_t mfem_debug_hex27_mixed_count(void);
 /* number of hex-27 matrix assemblies that took the scratch-free path so far (process-wide) */

@@ -997,6 +997,347 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
   }
 }
 
+// ---- General (non-affine) elements without Ke ever being stored (round 5).  The two-pass path costs 12 ms at 128^3: 129 kflop per element on the matrix cores
+// plus a 21.9 GB round trip of element matrices.  Here a row's owner computes the run Ke_e[la][0..26] of each adjacent element e itself, from the element's
+// G_q (6 numbers per Gauss point: k_hex27_gq_lane stores them, 1296 bytes per element instead of 5832) by sum factorisation over the tensor-product
+// basis: with h[q][n] = sum_m dN[q][la][m] G_q[m][n],
+//   Ke[la][b] = sum_q0 ( D(q0,b0) WB0 + L(q0,b0) WB1 ),  WB0 = sum_q1 L(q1,b1) VA0,  WB1 = sum_q1 ( D(q1,b1) VA1 + L(q1,b1) VA2 ),
+//   VA0 = sum_q2 h0 L(q2,b2),  VA1 = sum_q2 h1 L(q2,b2),  VA2 = sum_q2 h2 D(q2,b2)
+// -- about 1000 FMAs per run, all in the registers of ONE lane (the b-side tables are compile-time constants: ng = 3), 27 k FMAs per element against 65 k MFMA-
+// equivalent FMAs + the operand FMAs of the two-pass path, and no scratch round trip.
+// Work decomposition: a workgroup takes a tile of 4 x 4 x 4 control points starting on an even lattice point.  Per direction the tile has 6 (node, element) slots
+// -- node 0 (even: elements 2T - 1 and 2T), node 1 (element 2T), node 2 (2T and 2T + 1), node 3 (2T + 1) -- so its (row, element) pairs are exactly 6 x 6 x 6 = 216
+// jobs on 3 x 3 x 3 elements, whose G_q (35 KB) the workgroup stages in LDS once (2.25 - 3.4 x redundancy against 27 x without staging).  Wave (h0, h1) owns the
+// nodes {2 h0, 2 h0 + 1} x {2 h1, 2 h1 + 1} x {0..3}: 3 x 3 x 6 = 54 jobs on 54 of its 64 lanes, and every job of a row sits in the same wave -- the 27 additions of a
+// job into the row's box in LDS come in program order (plain read - add - write in batches, see below), lanes of one instruction never meet in an entry (same
+// local node b of different elements): the result is reproducible.  The wave's 16 rows leave as contiguous streams.  The next tile's G_q is requested while this one's rows leave.
+namespace r27 {
+__host__ __device__ constexpr double gp(int q) { return (q == 0 ? -0.77459666924148337704 : q == 1 ? 0.0 : 0.77459666924148337704) / 2.0 + 0.5; }  // (hex27_upload_tables)
+__host__ __device__ constexpr double L(int q, int b) {  // lag2 at Gauss point q
+  return b == 0 ? 2.0 * (gp(q) - 0.5) * (gp(q) - 1.0) : b == 1 ? -4.0 * gp(q) * (gp(q) - 1.0) : 2.0 * gp(q) * (gp(q) - 0.5);
+}
+__host__ __device__ constexpr double D(int q, int b) { return b == 0 ? 4.0 * gp(q) - 3.0 : b == 1 ? -8.0 * gp(q) + 4.0 : 4.0 * gp(q) - 1.0; }
+// the row box of a lattice point of an order-2 brick in one direction (what upload_dim_tables of brick.hip tabulates as lo / c / P): first coupled
+// point, their number, and the number of box entries of all points in front of it -- closed forms, so that no table load (a memory round trip per tile and
+// wave) sits in front of the arithmetic
+__device__ __forceinline__ int lo(int g) { return (g & 1) ? g - 1 : (g >= 2 ? g - 2 : 0); }
+__device__ __forceinline__ int cnt(int g, int m) { return ((g & 1) ? g + 1 : (g + 2 > m - 1 ? m - 1 : g + 2)) - lo(g) + 1; }
+__device__ __forceinline__ int pre(int g) { return g == 0 ? 0 : 3 + 3 * (g >> 1) + 5 * ((g - 1) >> 1); }
+}  // namespace r27
+// G_q = -k w_q det J_q^-1 J_q^-T of every element (6 numbers per Gauss point, 1296 bytes per element) -> gq[e][q0][q1][q2][6].  ONE LANE per element: the
+// sum-factorised Jacobian runs in the lane's registers (contract a0 for this q0: 54 numbers; a1 for this q1: 27; a2 per Gauss point) straight from the
+// coordinate arrays -- ~3900 FP64 instructions per element with every lane busy, no LDS traffic, no decode tables (the wave-per-element stages of k_hex27 took
+// 2.4 ms for this at 128^3; this kernel: see profiles/r05_hex27_rows.txt).  The 18 numbers of a (q0, q1) pair leave through a small LDS transpose so that the
+// stores are runs of 144 bytes per element instead of one 8-byte store per lane 1296 bytes apart.
+__global__ __launch_bounds__(256) void k_hex27_gq_lane(BrickView B, const Hex27Tables* __restrict__ tab, double kcond, int elo, int ecnt,
+                                                        double* __restrict__ gq) {
+  __shared__ double stage[4][64 * 19];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t nel = (int64_t)ecnt * B.ne1 * B.ne2;
+  const int64_t e_wave = (int64_t)blockIdx.x * 256 + wv * 64;  // first element of this wave
+  if (e_wave >= nel) return;
+  const int64_t idx = e_wave + lane < nel ? e_wave + lane : nel - 1;  // (lanes past the end repeat the last element and store nothing)
+  const int K = (int)(idx % B.ne2), J = (int)((idx / B.ne2) % B.ne1), I = elo + (int)(idx / ((int64_t)B.ne1 * B.ne2));
+  const int64_t c000 = brick_cindex(B, 2 * I, 2 * J, 2 * K);
+  double Lt[3][3], Dt[3][3];  // [q][a] (wave-uniform: scalar registers)
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      Lt[q][a] = tab->tab1[0][q][a];
+      Dt[q][a] = tab->tab1[1][q][a];
+    }
+  double* st = stage[wv];
+#pragma unroll 1
+  for (int q0 = 0; q0 < 3; ++q0) {
+    const double l0 = Lt[q0][0], l1 = Lt[q0][1], l2 = Lt[q0][2], d0 = Dt[q0][0], d1 = Dt[q0][1], d2 = Dt[q0][2];
+    double TL[9][3], TD[9][3];  // [a1 + 3 a2][i]: values / xi0-derivatives at q0
+#pragma unroll
+    for (int a12 = 0; a12 < 9; ++a12) {
+      const int64_t c = c000 + (int64_t)(a12 % 3) * B.m2 + (a12 / 3);
+      const double* Xs[3] = {B.X0, B.X1, B.X2};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double x0 = Xs[i][c], x1 = Xs[i][c + B.plane_len], x2 = Xs[i][c + 2 * B.plane_len];
+        TL[a12][i] = l0 * x0 + l1 * x1 + l2 * x2;
+        TD[a12][i] = d0 * x0 + d1 * x1 + d2 * x2;
+      }
+    }
+#pragma unroll 1
+    for (int q1 = 0; q1 < 3; ++q1) {
+      const double m0 = Lt[q1][0], m1 = Lt[q1][1], m2 = Lt[q1][2], e0 = Dt[q1][0], e1 = Dt[q1][1], e2 = Dt[q1][2];
+      double LL[3][3], LD[3][3], DL[3][3];  // [a2][i]
+#pragma unroll
+      for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          LL[a2][i] = m0 * TL[3 * a2][i] + m1 * TL[3 * a2 + 1][i] + m2 * TL[3 * a2 + 2][i];
+          LD[a2][i] = e0 * TL[3 * a2][i] + e1 * TL[3 * a2 + 1][i] + e2 * TL[3 * a2 + 2][i];
+          DL[a2][i] = m0 * TD[3 * a2][i] + m1 * TD[3 * a2 + 1][i] + m2 * TD[3 * a2 + 2][i];
+        }
+#pragma unroll
+      for (int q2 = 0; q2 < 3; ++q2) {
+        double Jm[3][3];  // [i][m] = d x_i / d xi_m
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          Jm[i][0] = Lt[q2][0] * DL[0][i] + Lt[q2][1] * DL[1][i] + Lt[q2][2] * DL[2][i];
+          Jm[i][1] = Lt[q2][0] * LD[0][i] + Lt[q2][1] * LD[1][i] + Lt[q2][2] * LD[2][i];
+          Jm[i][2] = Dt[q2][0] * LL[0][i] + Dt[q2][1] * LL[1][i] + Dt[q2][2] * LL[2][i];
+        }
+        const double j00 = Jm[0][0], j01 = Jm[0][1], j02 = Jm[0][2], j10 = Jm[1][0], j11 = Jm[1][1], j12 = Jm[1][2], j20 = Jm[2][0], j21 = Jm[2][1],
+                     j22 = Jm[2][2];
+        const double det = j00 * j11 * j22 - j00 * j12 * j21 - j01 * j10 * j22 + j01 * j12 * j20 + j02 * j10 * j21 - j02 * j11 * j20;
+        const double c00 = j11 * j22 - j12 * j21, c01 = j02 * j21 - j01 * j22, c02 = j01 * j12 - j11 * j02;
+        const double c10 = j12 * j20 - j22 * j10, c11 = j00 * j22 - j02 * j20, c12 = j02 * j10 - j00 * j12;
+        const double c20 = j10 * j21 - j11 * j20, c21 = j01 * j20 - j21 * j00, c22 = j00 * j11 - j10 * j01;
+        const double sc = -kcond * tab->w[q0 + 3 * q1 + 9 * q2] / det;  // (as step 2b of k_hex27)
+        double* o = st + lane * 19 + 6 * q2;
+        o[0] = sc * (c00 * c00 + c01 * c01 + c02 * c02);
+        o[1] = sc * (c00 * c10 + c01 * c11 + c02 * c12);
+        o[2] = sc * (c00 * c20 + c01 * c21 + c02 * c22);
+        o[3] = sc * (c10 * c10 + c11 * c11 + c12 * c12);
+        o[4] = sc * (c10 * c20 + c11 * c21 + c12 * c22);
+        o[5] = sc * (c20 * c20 + c21 * c21 + c22 * c22);
+      }
+      __builtin_amdgcn_wave_barrier();
+      double* dst = gq + e_wave * 162 + (q0 * 9 + q1 * 3) * 6;
+#pragma unroll
+      for (int sidx = 0; sidx < 18; ++sidx) {
+        const int flat = sidx * 64 + lane, e = flat / 18, j = flat - e * 18;
+        if (e_wave + e < nel) dst[(int64_t)e * 162 + j] = st[e * 19 + j];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// b-side table rows of a Gauss point for the stages whose point index is a loop counter: L(q, 0..2), D(q, 0..2) (read into scalar registers)
+__constant__ double c_r27_LD[3][8] = {{r27::L(0, 0), r27::L(0, 1), r27::L(0, 2), r27::D(0, 0), r27::D(0, 1), r27::D(0, 2), 0.0, 0.0},
+                                       {r27::L(1, 0), r27::L(1, 1), r27::L(1, 2), r27::D(1, 0), r27::D(1, 1), r27::D(1, 2), 0.0, 0.0},
+                                       {r27::L(2, 0), r27::L(2, 1), r27::L(2, 2), r27::D(2, 0), r27::D(2, 1), r27::D(2, 2), 0.0, 0.0}};
+#define R27_THREADS 256
+#define R27_GD (27 * 162)   // doubles of G_q per tile
+#define R27_BUF (R27_GD + 2)  // one LDS buffer: the tile's G_q, later its 64 row boxes ((5 + 3 + 5 + 3)^3 = 4096 doubles)
+#define R27_LDS_BYTES (sizeof(double) * (2 * R27_BUF + 32))
+__global__ __launch_bounds__(R27_THREADS, 2) void k_hex27_rows_gq(BrickView B, const Hex27Tables* __restrict__ tab, const double* __restrict__ gq,
+                                                                   double* __restrict__ vals, int elo, int ecnt, int T0lo, int nT0, int nT1, int nT2, int ablate) {
+  extern __shared__ double lds[];
+  // two buffers: G_q of this tile (read by the arithmetic; afterwards the same space holds the tile's row boxes) | G_q of the next tile, arriving
+  // straight from memory (global_load_lds: no registers in between) while this tile's arithmetic runs
+  double* sT = lds + 2 * R27_BUF;  // tab1: [2][4][4]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), h0 = wv & 1, h1 = wv >> 1;  // (wv in a scalar register: what depends on it alone is scalar arithmetic)
+  if (tid < 32) sT[tid] = (&tab->tab1[0][0][0])[tid];
+  // ---- this lane's job inside any tile
+  const bool job = lane < 54;
+  const int s2 = lane % 6, s1 = 3 * h1 + (lane / 6) % 3, s0 = 3 * h0 + (job ? lane / 18 : 0);
+  auto slot_t = [](int sl) { return (0xE90 >> (2 * sl)) & 3; };   // node of the slot: 0 0 1 2 2 3
+  auto slot_le = [](int sl) { return (0xA54 >> (2 * sl)) & 3; };  // its element, counted from 2T - 1: 0 1 1 1 2 2
+  auto slot_a = [](int sl) { return (0x492 >> (2 * sl)) & 3; };   // the node's local index in that element: 2 0 1 2 0 1
+  const int t0 = slot_t(s0), t1 = slot_t(s1), t2 = slot_t(s2);
+  const int le0 = slot_le(s0), le1 = slot_le(s1), le2 = slot_le(s2);
+  const int a0 = slot_a(s0), a1 = slot_a(s1), a2 = slot_a(s2);
+  // interior layout of the tile's row boxes per direction: counts 5 3 5 3, offsets 0 5 8 13 (as arithmetic: a table indexed per lane is a load from memory)
+  auto CI = [](int tt) { return 5 - 2 * (tt & 1); };
+  auto PX = [](int tt) { return 5 * ((tt + 1) >> 1) + 3 * (tt >> 1); };
+  const int gjob_off = ((le0 * 3 + le1) * 3 + le2) * 162;
+  const int ntiles = nT0 * nT1 * nT2;  // (the host keeps it below 2^31)
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  auto tile_of = [&](int t, int& T0, int& T1, int& T2) {
+    const uint32_t ut = (uint32_t)t, q = ut / (uint32_t)nT2;
+    T2 = (int)(ut - q * (uint32_t)nT2);
+    const uint32_t q1 = q / (uint32_t)nT1;
+    T1 = (int)(q - q1 * (uint32_t)nT1);
+    T0 = T0lo + (int)q1;
+  };
+  // G_q of the tile's 27 elements: the 3 elements of an (l0, l1) column are one contiguous run of 486 doubles = 243 pieces of 16 bytes -- thread tid < 243
+  // moves piece tid of each of the 9 columns (column base and validity are wave-uniform; the piece's element along the run is tid / 81).  A wave's 64 pieces
+  // land as one 1 KB block (what global_load_lds writes: LDS base + 16 x lane).
+  const int l2_of_piece = tid / 81;
+  const int64_t sE1 = (int64_t)B.ne2 * 162, sE0 = sE1 * B.ne1;  // doubles between element columns
+  auto request = [&](int T0, int T1, int T2, double* buf) {
+    const int E2 = 2 * T2 - 1 + l2_of_piece;
+    const bool ok2 = tid < 243 && E2 >= 0 && E2 < B.ne2 && !(ablate & 4);
+    const double* base = gq + ((int64_t)(2 * T0 - 1 - elo) * sE0 + (int64_t)(2 * T1 - 1) * sE1 + (int64_t)(2 * T2 - 1) * 162) + 2 * tid;
+    double* dst = buf + 128 * wv;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int E0 = 2 * T0 - 1 + c / 3, E1 = 2 * T1 - 1 + c % 3;
+      if (ok2 && E0 >= elo && E0 < elo + ecnt && E1 >= 0 && E1 < B.ne1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (c / 3) * sE0 + (c % 3) * sE1),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 486), 16, 0, 0);
+    }
+  };
+  // Vector memory operations of a wave complete in the order they were issued (one counter for loads and stores on this chip), so "at most as many
+  // outstanding as row stores were issued behind the G_q loads" means the loads have landed -- without waiting for the stores to reach memory, which
+  // __syncthreads() does (its s_waitcnt vmcnt(0) cost 1.5 ms of a 5.8 ms kernel: a memory round trip per tile).  The count is wave-uniform: a branch per value.
+  auto wait_loads_behind = [](int nstores) {
+#define R27_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (nstores) {
+      R27_W(0) R27_W(1) R27_W(2) R27_W(3) R27_W(4) R27_W(5) R27_W(6) R27_W(7) R27_W(8) R27_W(9) R27_W(10) R27_W(11) R27_W(12) R27_W(13) R27_W(14) R27_W(15)
+      R27_W(16) R27_W(17) R27_W(18) R27_W(19) R27_W(20) R27_W(21) R27_W(22) R27_W(23) R27_W(24) R27_W(25) R27_W(26) R27_W(27) R27_W(28)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef R27_W
+  };
+  // Tile order: workgroups with equal blockIdx % 8 share an XCD (round-robin dispatch) and its L2; each XCD walks ONE contiguous eighth of the tiles, its
+  // workgroups side by side -- the tiles in flight on an XCD are neighbours along k and the previous lattice line is still in its L2, so most of the 3.4-fold
+  // re-reading of G_q (a tile needs 27 elements for the 8 it owns) is served there instead of from memory (grids that are no multiple of 8: plain stride)
+  const bool xcd = (gridDim.x & 7) == 0;
+  const int tstride = xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int tend = xcd ? (int)(((int64_t)ntiles * ((blockIdx.x & 7) + 1)) >> 3) : ntiles;
+  int t = xcd ? (int)(((int64_t)ntiles * (blockIdx.x & 7)) >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int cur = 0, nstores = 0;
+  int T0 = 0, T1 = 0, T2 = 0, N0 = 0, N1 = 0, N2 = 0;  // this tile / the next one of this workgroup
+  if (t < tend) {
+    tile_of(t, N0, N1, N2);
+    request(N0, N1, N2, lds);
+  }
+  for (; t < tend; t += tstride, cur ^= 1) {
+    double* sG = lds + (cur ? R27_BUF : 0);
+    double* rows = sG;  // (after the arithmetic)
+    wait_loads_behind(__builtin_amdgcn_readfirstlane(nstores));  // this wave's share of the tile's G_q has landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... everybody's; and every wave is done with the other buffer (the previous tile's rows: read before its stores were issued)
+    T0 = N0; T1 = N1; T2 = N2;
+    if (t + tstride < tend) {
+      tile_of(t + tstride, N0, N1, N2);
+      request(N0, N1, N2, lds + (cur ? 0 : R27_BUF));
+    }
+    // ---- the job
+    const int g0 = 4 * T0 + t0, g1 = 4 * T1 + t1, g2 = 4 * T2 + t2;
+    const int E0 = 2 * T0 - 1 + le0, E1 = 2 * T1 - 1 + le1, E2 = 2 * T2 - 1 + le2;
+    const bool valid = job && g0 >= B.plo && g0 < B.phi && g1 < B.m1 && g2 < B.m2 && E0 >= elo && E0 < elo + ecnt && E0 < B.ne0 && E1 >= 0 && E1 < B.ne1 &&
+                       E2 >= 0 && E2 < B.ne2 && !(ablate & 1);
+    double o[27];
+#pragma unroll
+    for (int b = 0; b < 27; ++b) o[b] = 0.0;
+    if (valid) {
+      // 1-D values / derivatives of the row's own local node at the Gauss points: sT[q * 4 + a_d], sT[16 + q * 4 + a_d] -- read where they are used.
+      // The loops over q0 and q1 are REAL loops (their b-side table rows come from constant memory into scalar registers): fully unrolled, the compiler moves
+      // all 81 G_q reads of the job to the top of one 1200-instruction block and spills the accumulators (484 bytes of scratch per lane); a body of three Gauss
+      // points keeps 63 accumulators + 18 G entries + temporaries in registers.
+      const double* gjob = sG + gjob_off;
+      const double* Ta0 = sT + a0;
+      const double* Ta1 = sT + a1;
+      const double* Ta2 = sT + a2;
+      const double La2[3] = {Ta2[0], Ta2[4], Ta2[8]}, Da2[3] = {Ta2[16], Ta2[20], Ta2[24]};
+      // the 9 (q0, q1) pairs in a real loop, two per trip: the 18 G entries and the four table values of the NEXT pair are requested before this pair's
+      // arithmetic, into the other of two register sets (A / B: no copies)
+      double WB0[9], WB1[9];  // [b1 + 3 b2]
+      d2v gA[9], gB[9];
+      double tA[4], tB[4];  // La0, Da0, La1, Da1 of the pair
+      auto fetch = [&](int it, d2v (&gg)[9], double (&tt)[4]) {
+        const int n0 = it / 3, n1 = it - 3 * n0;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) gg[u] = *reinterpret_cast<const d2v*>(gjob + 18 * it + 2 * u);
+        tt[0] = Ta0[n0 * 4]; tt[1] = Ta0[16 + n0 * 4]; tt[2] = Ta1[n1 * 4]; tt[3] = Ta1[16 + n1 * 4];
+      };
+      auto pair = [&](int it, const d2v (&gc)[9], const double (&tc)[4]) {
+        const int q0 = it / 3, q1 = it - 3 * q0;
+        if (q1 == 0) {
+#pragma unroll
+          for (int b = 0; b < 9; ++b) WB0[b] = WB1[b] = 0.0;
+        }
+        const double p01 = tc[1] * tc[2], p10 = tc[0] * tc[3], p00 = tc[0] * tc[2];
+        double VA0[3] = {0.0, 0.0, 0.0}, VA1[3] = {0.0, 0.0, 0.0}, VA2[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q2 = 0; q2 < 3; ++q2) {
+          const d2v g01 = gc[3 * q2], g23 = gc[3 * q2 + 1], g45 = gc[3 * q2 + 2];
+          const double u0 = p01 * La2[q2], u1 = p10 * La2[q2], u2 = p00 * Da2[q2];
+          const double hh0 = __builtin_fma(u2, g23.x, __builtin_fma(u1, g01.y, u0 * g01.x));
+          const double hh1 = __builtin_fma(u2, g45.x, __builtin_fma(u1, g23.y, u0 * g01.y));
+          const double hh2 = __builtin_fma(u2, g45.y, __builtin_fma(u1, g45.x, u0 * g23.x));
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) {
+            VA0[b2] = __builtin_fma(hh0, r27::L(q2, b2), VA0[b2]);
+            VA1[b2] = __builtin_fma(hh1, r27::L(q2, b2), VA1[b2]);
+            VA2[b2] = __builtin_fma(hh2, r27::D(q2, b2), VA2[b2]);
+          }
+        }
+        const double cL[3] = {c_r27_LD[q1][0], c_r27_LD[q1][1], c_r27_LD[q1][2]}, cD[3] = {c_r27_LD[q1][3], c_r27_LD[q1][4], c_r27_LD[q1][5]};
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2)
+#pragma unroll
+          for (int b1 = 0; b1 < 3; ++b1) {
+            WB0[b1 + 3 * b2] = __builtin_fma(cL[b1], VA0[b2], WB0[b1 + 3 * b2]);
+            WB1[b1 + 3 * b2] = __builtin_fma(cL[b1], VA2[b2], __builtin_fma(cD[b1], VA1[b2], WB1[b1 + 3 * b2]));
+          }
+        if (q1 == 2) {
+          const double eL[3] = {c_r27_LD[q0][0], c_r27_LD[q0][1], c_r27_LD[q0][2]}, eD[3] = {c_r27_LD[q0][3], c_r27_LD[q0][4], c_r27_LD[q0][5]};
+#pragma unroll
+          for (int b12 = 0; b12 < 9; ++b12)
+#pragma unroll
+            for (int b0 = 0; b0 < 3; ++b0) o[b0 + 3 * b12] = __builtin_fma(eL[b0], WB1[b12], __builtin_fma(eD[b0], WB0[b12], o[b0 + 3 * b12]));
+        }
+      };
+      fetch(0, gA, tA);
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        fetch(2 * k + 1, gB, tB);
+        pair(2 * k, gA, tA);
+        fetch(2 * k + 2, gA, tA);
+        pair(2 * k + 1, gB, tB);
+      }
+      pair(8, gA, tA);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read its G_q: the buffer becomes the tile's row boxes (the next tile's loads stay in flight)
+    // the wave's rows: four lattice lines (t0, t1) of up to four points each.  The rows of a line follow one another in the CSR values, and so they do in LDS
+    // (a row's box starts where the previous one of its line ends: cc0 cc1 x the entries of the line's points in front of it) -- a line is zeroed, and later
+    // leaves, as ONE stream of cc0 cc1 (entries along the line) doubles; all of it wave-uniform arithmetic
+    const int p2lo = r27::pre(4 * T2);
+    const int p2hi = (4 * T2 + 4 < B.m2 ? r27::pre(4 * T2 + 4) : r27::pre(B.m2 - 1) + r27::cnt(B.m2 - 1, B.m2)) - p2lo;  // entries along the line of the tile's points
+    int line_len[4], line_base[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int z0 = 2 * h0 + (rg >> 1), z1 = 2 * h1 + (rg & 1), q0 = 4 * T0 + z0, q1 = 4 * T1 + z1;
+      line_base[rg] = PX(z0) * 256 + CI(z0) * PX(z1) * 16;
+      line_len[rg] = (q0 >= B.plo && q0 < B.phi && q1 < B.m1) ? r27::cnt(q0, B.m0) * r27::cnt(q1, B.m1) * p2hi : 0;
+      for (int i = lane; i < line_len[rg]; i += 64) rows[line_base[rg] + i] = 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid && !(ablate & 2)) {
+      // Into the row's box with plain read - add - write (ds_add_f64 costs ~2.4 cycles per LANE on this chip: 150 cycles per instruction, the whole kernel's time
+      // when the 27 additions of a job are atomics).  Safe because every job of a row sits in THIS wave and the wave's LDS operations execute in order: the
+      // lanes of one instruction hold the same local node b of different (row, element) pairs -- different entries --, and two entries b, b' of different
+      // jobs coincide only where b_d = 2 meets b'_d = 0 in some direction.  The 27 entries go in 8 batches by the set of directions with b_d = 2 (8 + 3 x 4 +
+      // 3 x 2 + 1): no two entries of one batch can meet, so a batch is all its reads, then the additions, then all its writes.
+      const int c1 = r27::cnt(g1, B.m1), c2 = r27::cnt(g2, B.m2), c12 = c1 * c2;
+      const int row_off = PX(t0) * 256 + CI(t0) * PX(t1) * 16 + r27::cnt(g0, B.m0) * c1 * (r27::pre(g2) - p2lo);  // the row's box: behind those of its line's points in front of it
+      double* rp = rows + row_off + ((2 * E0 - r27::lo(g0)) * c1 + (2 * E1 - r27::lo(g1))) * c2 + (2 * E2 - r27::lo(g2));  // the element's first node in the row's box
+#pragma unroll
+      for (int M = 0; M < 8; ++M) {
+        double curv[8];
+        int n = 0;
+#pragma unroll
+        for (int b = 0; b < 27; ++b) {
+          const int b0 = b % 3, b1 = (b / 3) % 3, b2 = b / 9;
+          if (((b0 == 2) | ((b1 == 2) << 1) | ((b2 == 2) << 2)) == M) curv[n++] = rp[b0 * c12 + b1 * c2 + b2];
+        }
+        n = 0;
+#pragma unroll
+        for (int b = 0; b < 27; ++b) {
+          const int b0 = b % 3, b1 = (b / 3) % 3, b2 = b / 9;
+          if (((b0 == 2) | ((b1 == 2) << 1) | ((b2 == 2) << 2)) == M) rp[b0 * c12 + b1 * c2 + b2] = curv[n++] + o[b];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- the wave's four lines leave
+    nstores = 0;
+    if (!(ablate & 8)) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        nstores += (line_len[rg] + 63) >> 6;
+        const int z0 = 2 * h0 + (rg >> 1), z1 = 2 * h1 + (rg & 1), q0 = 4 * T0 + z0, q1 = 4 * T1 + z1;
+        const int cc0 = r27::cnt(q0, B.m0), cc1 = r27::cnt(q1, B.m1);
+        double* dst = vals + ((int64_t)r27::pre(q0) - B.Pplo) * B.S1 * B.S2 + (int64_t)cc0 * ((int64_t)r27::pre(q1) * B.S2 + (int64_t)cc1 * p2lo);  // (brick_prefix of the line's first point)
+        const double* src = rows + line_base[rg];
+        for (int i = lane; i < line_len[rg]; i += 64) __builtin_nontemporal_store(src[i], dst + i);
+      }
+    }
+  }
+}
+
 // ---- Robin faces (hex-27): one thread per (boundary face element, face node a) = one row of the 9 x 9 face matrix;
 // 9 face nodes, ng x ng Gauss points.  colour = parity of the face element in its two tangential directions; the two
 // opposite faces of a direction share no node and go into the same launch (side = -1): 4 launches per direction.
@@ -1093,6 +1434,12 @@ static std::atomic<int> g_hex27_mixed{1};       // bit 10 of mfem_debug_set_hex2
 static std::atomic<int> g_hex27_mixed_max{80};  // bits 24-30: percentage of non-affine elements up to which the per-element choice is taken (0 = the default 80: profiles/r05_hex27_mixed.txt -- at 75 % the choice takes 11.2 ms against 11.9 for the two-pass path, at 100 % 13.1 against 12.2)
 static std::atomic<long long> g_hex27_mixed_count{0};  // assemblies that took it with at least one stored element (tests)
 extern "C" int64_t mfem_debug_hex27_mixed_count(void) { return g_hex27_mixed_count; }
+static std::atomic<int> g_hex27_rows{1};        // bit 11 of mfem_debug_set_hex27 turns the row-owner kernel of general elements (k_hex27_rows_gq) off
+static std::atomic<int> g_hex27_rows_min{0};    // bits 2-7: percentage of non-affine elements FROM which it is taken (0 = the default, R27_MIN_PERCENT; below: the per-element choice)
+static std::atomic<int> g_hex27_rows_ablate{0};  // bits 12-15: TIMING-ONLY ablations of k_hex27_rows_gq (wrong values): 1 no arithmetic, 2 no LDS additions, 4 no G_q loads, 8 no row stores
+static std::atomic<long long> g_hex27_rows_count{0};  // assemblies that took it (tests)
+extern "C" int64_t mfem_debug_hex27_rows_count(void) { return g_hex27_rows_count; }
+#define R27_MIN_PERCENT 10
 static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
 static std::atomic<size_t> g_hex27_scratch_budget{(size_t)16 << 30};
 extern "C" int mfem_debug_set_hex27(int two_pass) try {
@@ -1102,6 +1449,9 @@ extern "C" int mfem_debug_set_hex27(int two_pass) try {
   g_hex27_affine = ((two_pass >> 8) & 1) ? 0 : 1;
   g_hex27_direct = ((two_pass >> 9) & 1) ? 0 : 1;
   g_hex27_mixed = ((two_pass >> 10) & 1) ? 0 : 1;
+  g_hex27_rows = ((two_pass >> 11) & 1) ? 0 : 1;
+  g_hex27_rows_min = (two_pass >> 2) & 63;
+  g_hex27_rows_ablate = (two_pass >> 12) & 15;
   g_hex27_mixed_max = ((two_pass >> 24) & 127) ? ((two_pass >> 24) & 127) : 80;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex27")
@@ -1205,6 +1555,26 @@ int mfem_hex27_assemble_thermal(mfem_context_s* ctx, mfem_brick_s* m, mfem_csr_s
     // computed in place by the row-owner gather, the others go through pass 1 into a scratch that holds ONLY them and are streamed in by the same gather.
     // Beyond g_hex27_mixed_max (80 % of the elements by default) the plain two-pass path is the faster one (its gather streams every run with no
     // arithmetic beside it); a scratch beyond the budget goes there too (it rings over element planes).
+    // Mostly general elements (round 5): G_q of every element (1296 bytes each) -> the row owners compute their runs from it, no Ke anywhere
+    // (k_hex27_rows_gq; three Gauss points per direction -- its b-side tables are compile-time constants).
+    const size_t gq_bytes = sizeof(double) * 6 * (size_t)nq * (size_t)nel;
+    if (g_hex27_rows && m->ng == 3 && n_stored * 100 >= nel * (int64_t)(g_hex27_rows_min ? (int)g_hex27_rows_min : R27_MIN_PERCENT) && n_stored > 0 &&
+        gq_bytes <= g_hex27_scratch_budget && g_hex27_chunk_planes == 0) {
+      rc = mfem_ws_reserve(ctx, gq_bytes);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_hex27_gq_lane, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, B, (const Hex27Tables*)g_tab, p->k, elo, ehi - elo,
+                         (double*)ctx->ws);
+      MFEM_CHECK_LAUNCH();
+      MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hex27_rows_gq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)R27_LDS_BYTES));
+      const int T0lo = m->plo / 4, nT0 = (m->phi - 1) / 4 - T0lo + 1, nT1 = (m->m[1] + 3) / 4, nT2 = (m->m[2] + 3) / 4;
+      const int64_t ntiles = (int64_t)nT0 * nT1 * nT2;
+      const int gridr = (int)(ntiles < (int64_t)ctx->num_cus * 2 ? ntiles : (int64_t)ctx->num_cus * 2);  // two 4-wave workgroups per CU (67 KB of LDS each), persistent
+      hipLaunchKernelGGL(k_hex27_rows_gq, dim3(gridr), dim3(R27_THREADS), R27_LDS_BYTES, ctx->stream, B, (const Hex27Tables*)g_tab, (const double*)ctx->ws, vals, elo,
+                         ehi - elo, T0lo, nT0, nT1, nT2, (int)g_hex27_rows_ablate);
+      MFEM_CHECK_LAUNCH();
+      ++g_hex27_rows_count;
+      return hex27_launch_faces(ctx, m, true, p->h, p->Tenv, p->robin_faces, nullptr, vals);
+    }
     const size_t stored_bytes = sizeof(double) * 729 * (size_t)n_stored;
     if (n_stored == 0 || (g_hex27_mixed && n_stored * 100 <= nel * (int64_t)g_hex27_mixed_max && stored_bytes <= g_hex27_scratch_budget)) {
       const size_t head = (g_bytes + 2 * map_bytes + 255) & ~(size_t)255;

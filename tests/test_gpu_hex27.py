@@ -27,10 +27,12 @@ def _oracle(x, n, itg=5, distort=False, faces=None):
     return od
 
 
-@pytest.fixture(params=[0, 1 | (1 << 16), 1 | (3 << 16), 2, 3],
-                ids=["two_pass_gather", "two_pass_ring_1_plane", "two_pass_ring_3_planes", "fp64_atomics", "colour_scatter"])
+@pytest.fixture(params=[0, 1 << 11, 1 | (1 << 16), 1 | (3 << 16), 2, 3],
+                ids=["default", "two_pass_gather", "two_pass_ring_1_plane", "two_pass_ring_3_planes", "fp64_atomics", "colour_scatter"])
 def variant(request):
-    """All matrix-assembly variants: MFMA Ke -> scratch ring + LDS row-building gather (default), FP64 atomics, colour-partitioned RMW scatter."""
+    """All matrix-assembly variants: the default choice (all-affine meshes: rows from G0; distorted meshes with 3 Gauss points per direction: rows from G_q,
+    k_hex27_rows_gq), MFMA Ke -> scratch ring + LDS row-building gather (bit 11: the row-owner kernel of general elements off), FP64 atomics,
+    colour-partitioned RMW scatter."""
     from metafem_jl_amd import _lib
 
     _lib.lib.mfem_debug_set_hex27(request.param)
@@ -184,7 +186,8 @@ def test_hex27_per_element_choice_on_mixed_meshes(mf, percent):
     """Round 5: no all-or-nothing switch.  A mesh with `percent` % of its elements distorted (their centre node moved: exactly those
     elements become non-affine) is assembled with the affine elements computed in place and the others through pass 1 into a scratch that holds only them
     (k_hex27<true, true> in list mode + the streamed runs of k_hex27_direct).  Against the oracle <= 1e-12, against the two-pass MFMA path <= 1e-13; which path
-    ran is asserted (up to 80 % stored elements the per-element choice, beyond it the plain two-pass path -- or the choice when forced, bits 24-30)."""
+    ran is asserted: below 10 % stored elements the per-element choice, from 10 % on the row-owner kernel of general elements (k_hex27_rows_gq: rows from
+    per-element G_q, no Ke stored); with that kernel off (bit 11) the choice up to 80 %, beyond it the plain two-pass path -- or the choice when forced, bits 24-30."""
     import torch
     from metafem_jl_amd import _lib
     from oracle import fem, mesh as om, problems, reference_element as re_
@@ -207,22 +210,32 @@ def test_hex27_per_element_choice_on_mixed_meshes(mf, percent):
     lib = _lib.lib
     scale = np.abs(od.K_linear).max()
     try:
-        m0, d0 = lib.mfem_debug_hex27_mixed_count(), lib.mfem_debug_hex27_direct_count()
+        m0, d0, r0 = lib.mfem_debug_hex27_mixed_count(), lib.mfem_debug_hex27_direct_count(), lib.mfem_debug_hex27_rows_count()
         K = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
         assert lib.mfem_debug_hex27_direct_count() == d0                            # not the all-affine path ...
-        assert (lib.mfem_debug_hex27_mixed_count() > m0) == (percent <= 80)        # ... the per-element choice up to 80 % of the elements
-        lib.mfem_debug_set_hex27(1 << 10)                                           # the choice off: the two-pass path whole (round 4)
+        assert (lib.mfem_debug_hex27_mixed_count() > m0) == (percent < 10)         # ... the per-element choice below 10 % of the elements,
+        assert (lib.mfem_debug_hex27_rows_count() > r0) == (percent >= 10)          # from there on the row-owner kernel of general elements
+        lib.mfem_debug_set_hex27(1 << 11)                                           # that kernel off: the per-element choice up to 80 %, the two-pass path beyond
+        m2 = lib.mfem_debug_hex27_mixed_count()
+        K1 = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+        assert (lib.mfem_debug_hex27_mixed_count() > m2) == (percent <= 80) and lib.mfem_debug_hex27_rows_count() == r0 + (percent >= 10)
+        lib.mfem_debug_set_hex27((1 << 10) | (1 << 11))                             # the choice off too: the two-pass path whole (round 4)
         m1 = lib.mfem_debug_hex27_mixed_count()
         K2 = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
         assert lib.mfem_debug_hex27_mixed_count() == m1
-        lib.mfem_debug_set_hex27(100 << 24)                                         # forced for any fraction
+        lib.mfem_debug_set_hex27((100 << 24) | (1 << 11))                           # forced for any fraction
         Kf = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
         assert lib.mfem_debug_hex27_mixed_count() > m1
+        lib.mfem_debug_set_hex27(1 << 2)                                            # the row-owner kernel from 1 % on
+        r1 = lib.mfem_debug_hex27_rows_count()
+        Kr = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
+        assert lib.mfem_debug_hex27_rows_count() == r1 + 1
     finally:
         lib.mfem_debug_set_hex27(0)
-    for got in (K, K2, Kf):
+    for got in (K, K1, K2, Kf, Kr):
         assert np.abs(got - od.K_linear).max() <= 1e-12 * scale
-    assert np.abs(K - K2).max() <= 1e-13 * scale and np.abs(Kf - K2).max() <= 1e-13 * scale
+    assert np.abs(K1 - K2).max() <= 1e-13 * scale and np.abs(Kf - K2).max() <= 1e-13 * scale
+    assert np.abs(K - K2).max() <= 2e-13 * scale and np.abs(Kr - K2).max() <= 2e-13 * scale  # (rows from G_q: another summation order than the MFMA tiles)
     # with faces and a second assembly on the same workspace (the tables of the first call are reused in place)
     Ka = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
     Kb = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
@@ -263,7 +276,7 @@ def test_hex27_assembly_time_is_monotone_in_the_distorted_fraction(mf):
             brick.coords_view(0)[perm[:k]] += 0.003
         t[pct] = timed()
     try:
-        _lib.lib.mfem_debug_set_hex27(1 << 10)
+        _lib.lib.mfem_debug_set_hex27((1 << 10) | (1 << 11))
         t["two_pass"] = timed()
     finally:
         _lib.lib.mfem_debug_set_hex27(0)
@@ -272,3 +285,54 @@ def test_hex27_assembly_time_is_monotone_in_the_distorted_fraction(mf):
     assert t[0] <= 1.25 * t[1] and t[1] <= 1.25 * t[25] and t[25] <= 1.25 * t[50]
     assert t[1] <= 1.6 * t[0]
     assert t[50] <= 1.15 * t["two_pass"]
+
+
+@pytest.mark.parametrize("n,x,itg", [((1, 1, 1), (1.0, 1.0, 1.0), 5), ((2, 3, 2), (1.0, 1.5, 0.75), 5), ((5, 4, 7), (1.0, 1.5, 0.75), 5), ((9, 2, 3), (2.0, 0.5, 0.75), 4),
+                                     ((4, 4, 4), (1.0, 1.0, 1.0), 5)])
+def test_hex27_rows_from_gq_on_distorted_meshes(mf, n, x, itg):
+    """Round 5: the row-owner kernel of general elements (k_hex27_rows_gq -- G_q of every element stored, 1296 bytes each; every (row, element) run computed
+    in place by sum factorisation; no Ke, no scatter).  Fully distorted meshes whose sizes leave partial 4 x 4 x 4 tiles in every direction, with all six Robin
+    faces: against the oracle <= 1e-12, against the two-pass MFMA path <= 2e-13, twice bitwise the same (the additions into a row come in program order), and
+    the matrix stays symmetric to round-off.  A mesh with four Gauss points per direction does not take it (its tables are compile-time constants for three)."""
+    import scipy.sparse as sp
+    from metafem_jl_amd import _lib
+
+    import torch
+
+    od = _oracle(x, n, itg, True)
+    brick = mf.make_Brick(x, n, 2, itg)
+    for d in range(3):
+        brick.coords_view(d).copy_(torch.tensor(od.mesh.coords[:, d], device="cuda"))
+    A = brick.pattern(1)
+    lib = _lib.lib
+    r0 = lib.mfem_debug_hex27_rows_count()
+    K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    assert lib.mfem_debug_hex27_rows_count() == r0 + 1
+    Kagain = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    assert float((K - Kagain).abs().max()) == 0.0
+    try:
+        lib.mfem_debug_set_hex27(1 << 11)
+        Kt = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+        assert lib.mfem_debug_hex27_rows_count() == r0 + 2
+    finally:
+        lib.mfem_debug_set_hex27(0)
+    scale = np.abs(od.K_linear).max()
+    assert np.abs(K.cpu().numpy() - od.K_linear).max() <= 1e-12 * scale
+    assert float((K - Kt).abs().max()) <= 2e-13 * scale
+    M = sp.csr_matrix((K.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=(A.n, A.n))
+    assert abs(M - M.T).max() <= 1e-13 * scale
+
+
+def test_hex27_rows_from_gq_needs_three_gauss_points(mf):
+    import torch
+    from metafem_jl_amd import _lib
+
+    od = _oracle((1.0, 1.5, 0.75), (2, 1, 2), 7, True)
+    brick = mf.make_Brick((1.0, 1.5, 0.75), (2, 1, 2), 2, 7)
+    for d in range(3):
+        brick.coords_view(d).copy_(torch.tensor(od.mesh.coords[:, d], device="cuda"))
+    A = brick.pattern(1)
+    r0 = _lib.lib.mfem_debug_hex27_rows_count()
+    K = brick.assemble_thermal(A, K_COND, H, TENV, 0x3F).cpu().numpy()
+    assert _lib.lib.mfem_debug_hex27_rows_count() == r0
+    assert np.abs(K - od.K_linear).max() <= 1e-12 * np.abs(od.K_linear).max()

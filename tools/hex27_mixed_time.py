@@ -1,5 +1,6 @@
 """hex-27 matrix assembly time against the fraction of non-affine elements (round 5: per-element choice between the in-place computation of affine elements
-and pass 1 + streamed runs for the others), 128^3 by default: default policy, the choice forced for every fraction, the two-pass path forced.
+and pass 1 + streamed runs for the others; rows of general elements computed in place from G_q), 128^3 by default: default policy, the row-owner kernel
+of general elements forced, the per-element choice forced for every fraction, the two-pass path forced.
 usage: hex27_mixed_time.py [n]   -> profiles/r05_hex27_mixed.txt"""
 import sys
 
@@ -35,7 +36,7 @@ def timed(reps=5):
 
 
 print(f"hex-27 {N}^3 thermal matrix assembly (no faces), ms per assembly; distorted = elements whose centre node is moved")
-print(f"{'distorted %':>12s} {'default policy':>16s} {'choice forced':>16s} {'two-pass forced':>16s}")
+print(f"{'distorted %':>12s} {'default policy':>16s} {'rows from G_q':>16s} {'choice forced':>16s} {'two-pass forced':>16s}")
 for pct in (0, 1, 5, 10, 25, 50, 75, 100):
     for d in range(3):
         brick.coords_view(d).copy_(base[d])
@@ -43,8 +44,9 @@ for pct in (0, 1, 5, 10, 25, 50, 75, 100):
     if k:
         brick.coords_view(0)[perm[:k]] += 0.3 / N * 0.05
     row = []
-    for knob in (0, 100 << 24, 1 << 10):
+    # default | the row-owner kernel of general elements from 1 % on (bits 2-7) | it off, the per-element choice for every fraction | both off: two-pass
+    for knob in (0, 1 << 2, (100 << 24) | (1 << 11), (1 << 10) | (1 << 11)):
         _lib.lib.mfem_debug_set_hex27(knob)
         row.append(timed())
     _lib.lib.mfem_debug_set_hex27(0)
-    print(f"{pct:12d} {row[0]:16.3f} {row[1]:16.3f} {row[2]:16.3f}", flush=True)
+    print(f"{pct:12d} {row[0]:16.3f} {row[1]:16.3f} {row[2]:16.3f} {row[3]:16.3f}", flush=True)
