@@ -397,6 +397,24 @@ def main():
         assert agree <= 1e-13, f"hex-27: the scratch-free assembly and the two-pass MFMA assembly differ by {agree:.2e} of max |K|"
         nnz27, n27_rows = int(A27.nnz), int(A27.n)
         del Kd
+        # ... and a mesh of GENERAL elements (the centre node of every element moved): round 5's row-owner kernel computes the rows from per-element G_q
+        # (k_hex27_gq_lane + k_hex27_rows_gq, Ke never stored); the two-pass MFMA path on the same coordinates beside it (bit 11 turns the row-owner kernel off)
+        m27 = 2 * n27 + 1
+        odd = torch.arange(1, m27, 2, device=dev)
+        centre = ((odd[:, None, None] * m27 + odd[None, :, None]) * m27 + odd[None, None, :]).reshape(-1)
+        b27.coords_view(0)[centre] += 0.015 / n27
+        rows_before = int(_lib.lib.mfem_debug_hex27_rows_count())
+        ms_rows = timed_assembly()
+        rows_ran = int(_lib.lib.mfem_debug_hex27_rows_count()) > rows_before
+        Kd = K27.clone()
+        _lib.lib.mfem_debug_set_hex27(1 << 11)
+        try:
+            ms_two_pass_general = timed_assembly()
+        finally:
+            _lib.lib.mfem_debug_set_hex27(0)
+        agree_general = float((K27 - Kd).abs().max() / K27.abs().max())
+        assert rows_ran and agree_general <= 2e-13, f"hex-27 general elements: rows from G_q against the two-pass MFMA path: {agree_general:.2e} of max |K| (ran: {rows_ran})"
+        del Kd
         nel = n27 ** 3
         flops = 118098.0 * nel
         busy = None
@@ -427,7 +445,19 @@ def main():
                     "achieved": (8 * nnz27 + 2 * 48 * nel + 3 * 8 * n27_rows) / (ms_direct * 1e-3) / 1e9,
                     "frac": (8 * nnz27 + 2 * 48 * nel + 3 * 8 * n27_rows) / (ms_direct * 1e-3) / 1e9 / 8000.0,
                     "max_rel_difference_to_the_mfma_path": agree,
-                    "note": "algorithmic bytes = the CSR values written once + G0 written and read + the coordinates read"}}
+                    "note": "algorithmic bytes = the CSR values written once + G0 written and read + the coordinates read"},
+                "general_mesh_assembly": {
+                    "kernel": "k_hex27_affine_g0 (affine test) + k_hex27_gq_lane (G_q = -k w det J^-1 J^-T at the 27 Gauss points, one lane per element) + k_hex27_rows_gq "
+                              "(row owners compute every (row, element) run from G_q by sum factorisation in registers, rows accumulated in LDS without atomics): the "
+                              "default from 30 % non-affine elements on (three Gauss points per direction); Ke is never stored",
+                    "mesh": "the same mesh with the centre node of EVERY element moved (all elements non-affine)",
+                    "avg_assembly_ms": ms_rows, "two_pass_mfma_path_same_mesh_ms": ms_two_pass_general,
+                    "useful_flop_per_assembly": flops, "achieved_on_useful_flops_tflops": flops / (ms_rows * 1e-3) / 1e12,
+                    "frac_of_fp64_peak_on_useful_flops": flops / (ms_rows * 1e-3) / 1e12 / PEAK_TFLOPS,
+                    "executed_flop_per_assembly": 2.0 * 1053 * 27 * nel,
+                    "max_rel_difference_to_the_mfma_path": agree_general,
+                    "note": "useful flops = the 118 098 per element of Ke = B^T D B (the yardstick of the MFMA path); the kernel itself executes 2 x 1053 FMAs per "
+                            "(row, element) run; counters and the development steps: profiles/r05_hex27_rows.txt"}}
 
     strong = args.scaling == "strong" and world > 1
 

@@ -84,7 +84,8 @@ int mfem_debug_set_halo_overlap(int on);
  * by default its affine elements are computed in place and only the others go through pass 1, into a scratch that holds only them).  Bits 24-30:
  * percentage of non-affine elements up to which the per-element choice is taken (0 = the default 80; beyond it the two-pass path is faster).
  * Bit 11 (round 5): the row-owner kernel of GENERAL elements off (k_hex27_rows_gq: rows computed in place from per-element G_q by sum factorisation, no Ke
- * stored anywhere; taken by default from bits 2-7 percent of non-affine elements on -- 0 = the default 10 -- when the mesh has three Gauss points per direction). */
+ * stored anywhere; taken by default from bits 2-7 percent of non-affine elements on -- 0 = the default 30 -- when the mesh has three Gauss points per direction).
+ * Bits 12-14: TIMING-ONLY ablations of that kernel (wrong values; tools/hex27_rows_ablate.py). */
 int mfem_debug_set_hex27(int two_pass);
 /* number of hex-27 matrix assemblies that took the row-owner kernel of general elements (process-wide) */
 int64_t mfem_debug_hex27_rows_count(void);

@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(R27_THREADS, 2) void k_hex27_rows_gq(BrickView B, c
     __builtin_amdgcn_wave_barrier();
     // ---- the wave's four lines leave
     nstores = 0;
-    if (!(ablate & 8)) {
+    {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         nstores += (line_len[rg] + 63) >> 6;
@@ -1436,10 +1436,10 @@ static std::atomic<long long> g_hex27_mixed_count{0};  // assemblies that took i
 extern "C" int64_t mfem_debug_hex27_mixed_count(void) { return g_hex27_mixed_count; }
 static std::atomic<int> g_hex27_rows{1};        // bit 11 of mfem_debug_set_hex27 turns the row-owner kernel of general elements (k_hex27_rows_gq) off
 static std::atomic<int> g_hex27_rows_min{0};    // bits 2-7: percentage of non-affine elements FROM which it is taken (0 = the default, R27_MIN_PERCENT; below: the per-element choice)
-static std::atomic<int> g_hex27_rows_ablate{0};  // bits 12-15: TIMING-ONLY ablations of k_hex27_rows_gq (wrong values): 1 no arithmetic, 2 no LDS additions, 4 no G_q loads, 8 no row stores
+static std::atomic<int> g_hex27_rows_ablate{0};  // bits 12-14: TIMING-ONLY ablations of k_hex27_rows_gq (wrong values): 1 no arithmetic, 2 no LDS additions, 4 no G_q loads
 static std::atomic<long long> g_hex27_rows_count{0};  // assemblies that took it (tests)
 extern "C" int64_t mfem_debug_hex27_rows_count(void) { return g_hex27_rows_count; }
-#define R27_MIN_PERCENT 10
+#define R27_MIN_PERCENT 30
 static std::atomic<int> g_hex27_chunk_planes{0};  // bits 16-23 of mfem_debug_set_hex27: element planes per scratch chunk (0 = from the budget)
 static std::atomic<size_t> g_hex27_scratch_budget{(size_t)16 << 30};
 extern "C" int mfem_debug_set_hex27(int two_pass) try {
@@ -1451,7 +1451,7 @@ extern "C" int mfem_debug_set_hex27(int two_pass) try {
   g_hex27_mixed = ((two_pass >> 10) & 1) ? 0 : 1;
   g_hex27_rows = ((two_pass >> 11) & 1) ? 0 : 1;
   g_hex27_rows_min = (two_pass >> 2) & 63;
-  g_hex27_rows_ablate = (two_pass >> 12) & 15;
+  g_hex27_rows_ablate = (two_pass >> 12) & 7;
   g_hex27_mixed_max = ((two_pass >> 24) & 127) ? ((two_pass >> 24) & 127) : 80;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex27")

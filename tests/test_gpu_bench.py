@@ -116,6 +116,10 @@ def test_default_line_carries_all_four_configs():
     ke = out["roofline_hex27_ke"]
     assert ke["bound"] == "mfma" and ke["peak"] == 78.6 and ke["useful_flop_per_assembly"] == 118098.0 * 12 ** 3
     assert ke["achieved"] > 0 and 0 < ke["frac"] < 1 and abs(ke["frac"] - ke["achieved"] / ke["peak"]) < 1e-12
+    # round 5: the same mesh with every element distorted, assembled by the row-owner kernel of general elements (the line fails unless it ran and agrees
+    # with the two-pass MFMA path to 2e-13)
+    gm = ke["general_mesh_assembly"]
+    assert gm["avg_assembly_ms"] > 0 and gm["two_pass_mfma_path_same_mesh_ms"] > 0 and gm["max_rel_difference_to_the_mfma_path"] <= 2e-13
 
 
 @pytest.mark.parametrize("config,n,iters,ndof", [("c3", 16, 40, 3 * 33 * 17 * 17), ("c4", 8, 20, 33 * 17 * 17)])

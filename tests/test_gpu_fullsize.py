@@ -172,6 +172,45 @@ def test_c4_hex27_128_symmetry_and_constants(mf):
     assert abs(float(R.sum()) - SRC) <= 1e-9 * SRC
 
 
+def test_c4_hex27_128_distorted_rows_from_gq_against_the_two_pass_path(mf):
+    """Round 5: the C4 mesh with EVERY element distorted (its centre node moved) -- the row-owner kernel of general elements (274 625 tiles of 4 x 4 x 4 lattice
+    points, G_q of the next tile arriving in LDS behind a count of outstanding stores) against the two-pass MFMA path on the same coordinates: the 1.08e9 values
+    agree to 2e-13 of the largest, K 1 = -h x (area of the faces) to round-off (the partition of unity survives the distortion), and twice the same bits."""
+    import numpy as np
+    import torch
+    from metafem_jl_amd import _lib
+
+    N = 128
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 2, 5)
+    A = brick.pattern(1)
+    m = 2 * N + 1
+    odd = torch.arange(1, m, 2, device="cuda")
+    cn = ((odd[:, None, None] * m + odd[None, :, None]) * m + odd[None, None, :]).reshape(-1)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for d in range(3):
+        brick.coords_view(d)[cn] += (0.05 / N) * (torch.rand(cn.numel(), device="cuda", dtype=torch.float64, generator=g) - 0.5)
+    lib = _lib.lib
+    r0 = lib.mfem_debug_hex27_rows_count()
+    K = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES)
+    assert lib.mfem_debug_hex27_rows_count() == r0 + 1
+    K2 = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES)
+    assert torch.equal(K, K2)
+    del K2
+    one = torch.ones(A.n, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(one)
+    mf.mul_(y, A, K, one)
+    assert abs(float(y.sum()) + H * 6.0) <= 1e-8
+    try:
+        lib.mfem_debug_set_hex27(1 << 11)
+        Kt = brick.assemble_thermal(A, K_COND, H, TENV, mf.ALL_FACES)
+        assert lib.mfem_debug_hex27_rows_count() == r0 + 2
+    finally:
+        lib.mfem_debug_set_hex27(0)
+    scale = float(Kt.abs().max())
+    Kt -= K
+    assert float(Kt.abs().max()) <= 2e-13 * scale
+
+
 def _layout_spmv(_lib, brick, A, K, x, count):
     import torch
 

@@ -186,7 +186,7 @@ def test_hex27_per_element_choice_on_mixed_meshes(mf, percent):
     """Round 5: no all-or-nothing switch.  A mesh with `percent` % of its elements distorted (their centre node moved: exactly those
     elements become non-affine) is assembled with the affine elements computed in place and the others through pass 1 into a scratch that holds only them
     (k_hex27<true, true> in list mode + the streamed runs of k_hex27_direct).  Against the oracle <= 1e-12, against the two-pass MFMA path <= 1e-13; which path
-    ran is asserted: below 10 % stored elements the per-element choice, from 10 % on the row-owner kernel of general elements (k_hex27_rows_gq: rows from
+    ran is asserted: below 30 % stored elements the per-element choice, from 30 % on the row-owner kernel of general elements (k_hex27_rows_gq: rows from
     per-element G_q, no Ke stored); with that kernel off (bit 11) the choice up to 80 %, beyond it the plain two-pass path -- or the choice when forced, bits 24-30."""
     import torch
     from metafem_jl_amd import _lib
@@ -213,12 +213,12 @@ def test_hex27_per_element_choice_on_mixed_meshes(mf, percent):
         m0, d0, r0 = lib.mfem_debug_hex27_mixed_count(), lib.mfem_debug_hex27_direct_count(), lib.mfem_debug_hex27_rows_count()
         K = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
         assert lib.mfem_debug_hex27_direct_count() == d0                            # not the all-affine path ...
-        assert (lib.mfem_debug_hex27_mixed_count() > m0) == (percent < 10)         # ... the per-element choice below 10 % of the elements,
-        assert (lib.mfem_debug_hex27_rows_count() > r0) == (percent >= 10)          # from there on the row-owner kernel of general elements
+        assert (lib.mfem_debug_hex27_mixed_count() > m0) == (percent < 30)         # ... the per-element choice below 30 % of the elements,
+        assert (lib.mfem_debug_hex27_rows_count() > r0) == (percent >= 30)          # from there on the row-owner kernel of general elements
         lib.mfem_debug_set_hex27(1 << 11)                                           # that kernel off: the per-element choice up to 80 %, the two-pass path beyond
         m2 = lib.mfem_debug_hex27_mixed_count()
         K1 = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()
-        assert (lib.mfem_debug_hex27_mixed_count() > m2) == (percent <= 80) and lib.mfem_debug_hex27_rows_count() == r0 + (percent >= 10)
+        assert (lib.mfem_debug_hex27_mixed_count() > m2) == (percent <= 80) and lib.mfem_debug_hex27_rows_count() == r0 + (percent >= 30)
         lib.mfem_debug_set_hex27((1 << 10) | (1 << 11))                             # the choice off too: the two-pass path whole (round 4)
         m1 = lib.mfem_debug_hex27_mixed_count()
         K2 = brick.assemble_thermal(A, K_COND, 0.0, TENV, 0).cpu().numpy()

@@ -215,6 +215,46 @@ def test_hex27_slab_rows_equal_global_rows(mf, n, lo, hi, itg, chunk):
         _lib.lib.mfem_debug_set_hex27(0)
 
 
+@pytest.mark.parametrize("n,lo,hi", [((6, 3, 5), 0, 4), ((6, 3, 5), 4, 8), ((6, 3, 5), 8, 13), ((5, 2, 2), 2, 6), ((7, 3, 3), 6, 10)])
+@pytest.mark.parametrize("knob,name", [(0, "rows_from_gq"), (1 << 11, "two_pass"), ((1 << 11) | (100 << 24), "per_element_choice")])
+def test_hex27_distorted_slab_rows_equal_global_rows(mf, n, lo, hi, knob, name):
+    """Round 5: DISTORTED order-2 meshes on slabs -- every assembly path of general elements (rows from per-element G_q: tiles of 4 x 4 x 4 lattice points that
+    start in front of the slab's first plane and end behind its last one; the two-pass MFMA path; the per-element choice) gives a slab the rows the global
+    assembly gives, bitwise (same kernels, same summation order per row), and which path ran is asserted."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    x = (2.0, 1.0, 1.5)
+    m1, m2 = 2 * n[1] + 1, 2 * n[2] + 1
+    pl = m1 * m2
+    lib = _lib.lib
+    lib.mfem_debug_set_hex27(knob)
+    try:
+        gb = mf.make_Brick(x, n, 2, 5)
+        c = [gb.coords_view(d).clone() for d in range(3)]
+        bump = [0.02 * torch.sin(3 * c[1]) * torch.cos(c[2]), 0.02 * torch.sin(2 * c[0] + c[2]), 0.02 * c[0] * c[1]]
+        for d in range(3):
+            gb.coords_view(d).copy_(c[d] + bump[d])
+        gA = gb.pattern(1)
+        r_before = lib.mfem_debug_hex27_rows_count()
+        gK = gb.assemble_thermal(gA, K_COND, H, TENV, 0x3F)
+        assert (lib.mfem_debug_hex27_rows_count() > r_before) == (knob == 0)
+        grp = gA.rowptr.cpu().numpy()
+        sb = mf.make_Brick(x, n, 2, 5)
+        sb.set_slab(lo, hi)
+        clo, chi = max(lo - 2, 0), min(hi + 2, 2 * n[0] + 1)
+        for d in range(3):
+            sb.coords_view(d).copy_((c[d] + bump[d])[clo * pl:chi * pl])
+        sA = sb.pattern(1)
+        r_before = lib.mfem_debug_hex27_rows_count()
+        sK = sb.assemble_thermal(sA, K_COND, H, TENV, 0x3F)
+        assert (lib.mfem_debug_hex27_rows_count() > r_before) == (knob == 0)
+        r0, r1 = lo * pl, hi * pl
+        assert torch.equal(sK, gK[int(grp[r0]):int(grp[r1])])
+    finally:
+        lib.mfem_debug_set_hex27(0)
+
+
 def test_hex27_slab_needs_element_boundaries(mf):
     sb = mf.make_Brick((1.0, 1.0, 1.0), (4, 2, 2), 2, 5)
     with pytest.raises(Exception):
