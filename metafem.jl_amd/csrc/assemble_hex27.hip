@@ -298,10 +298,13 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
     int64_t rb;
     int32_t s1, c2;
   };
+  // (every lane loads -- lanes 27 .. 63 repeat node 26 -- and the wave fetches on every step, the last one repeating its element: behind a condition the
+  // loaded registers meet zeros / their old values in a phi, and the copies that resolves into wait for the loads at once -- the prefetch would hide nothing)
   auto fetch_nodes = [&](int I, int J, int K) -> NodePre {
     NodePre n{0.0, 0.0, 0.0, 0, 0, 0};
-    if (lane < 27) {
-      const int gi = 2 * I + lane % 3, gj = 2 * J + (lane / 3) % 3, gk = 2 * K + lane / 9;
+    {
+      const int ln = lane < 27 ? lane : 26;
+      const int gi = 2 * I + ln % 3, gj = 2 * J + (ln / 3) % 3, gk = 2 * K + ln / 9;
       const int64_t c = brick_cindex(B, gi, gj, gk);
       n.x0 = B.X0[c];
       n.x1 = B.X1[c];
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
   if (have) {
     if (A.elist) list_get(lk, I, J, K); else walk.get(I, J, K);
   }
-  NodePre cur = have ? fetch_nodes(I, J, K) : NodePre{0.0, 0.0, 0.0, 0, 0, 0};
+  NodePre cur = fetch_nodes(have ? I : A.e_lo, have ? J : 0, have ? K : 0);  // (a wave without an element loads the first one of the launch's planes: inside the slab's coordinates)
   while (have) {
     // ---- 1. nodes: coordinates + row descriptors (matrix) / nodal values (residual)
     if (lane < 27) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(H27_THREADS, 4) void k_hex27(Hex27Args A, const dou
       have = walk.have();
       if (have) walk.get(I, J, K);
     }
-    if (have) cur = fetch_nodes(I, J, K);
+    cur = fetch_nodes(I, J, K);  // (I, J, K keep the last element when the walk is over)
     __builtin_amdgcn_wave_barrier();
     // ---- 2'. AFFINE elements (round 4).  The counters say pass 1 is bound by the ONE pipe FP64 VALU and FP64 MFMA share (MFMA busy 53 % + FP64 /
     //      integer VALU 33 % of the SIMD cycles: profiles/r04_hex27_wave_counters.txt), and ~45 % of an element's 560 VALU instructions are the

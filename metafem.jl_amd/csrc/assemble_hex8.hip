@@ -620,21 +620,23 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   double Xn[3][4], Tq[4], Sq[4];  // the plane requested last (consumed at the top of the next step)
 #pragma unroll
   for (int c = 0; c < 4; ++c) Sq[c] = 0.0;
+  const int Jc = min(max(J, 0), B.ne1 - 1), Kc = min(max(K, 0), B.ne2 - 1);  // (threads without an element column load what a neighbour loads)
+  // (every thread requests on every step, from clamped positions: behind a condition the requested registers meet their old values in a phi, and the copies that resolves into wait for the loads AT ONCE -- the prefetch then costs a memory round trip per plane instead of hiding one: round 5, found in the ISA)
   auto request = [&](int ip) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+      const int64_t ci = brick_cindex(B, ip, Jc + (c & 1), Kc + (c >> 1));
       Xn[0][c] = B.X0[ci];
       Xn[1][c] = B.X1[ci];
       Xn[2][c] = B.X2[ci];
-      const int64_t xi = brick_xindex(B, 0, ip, J + (c & 1), K + (c >> 1));
+      const int64_t xi = brick_xindex(B, 0, ip, Jc + (c & 1), Kc + (c >> 1));
       Tq[c] = x[xi];
       if (has_src) Sq[c] = src[xi];
     }
   };
   double X[3][2][4], Tn[2][4], Sn[2][4];
   const int Ifirst = max(T.i0 - 1, 0), Ilast = min(T.i1 - 1, B.ne0 - 1);  // element planes of this segment
-  if (el_ok) {
+  {
     request(Ifirst);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -662,9 +664,9 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         Fe[tid * 9 + 2 * c] = fe[0][c];
         Fe[tid * 9 + 2 * c + 1] = fe[1][c];
       }
-      if (I < Ilast) request(I + 2);  // in flight during phase B and the two barriers
     }
-    __syncthreads();
+    request(min(max(I + 2, Ifirst), Ilast + 1));  // in flight during the rest of this plane's step: gather, write-out, barriers (mfem_lds_barrier does not wait for it)
+    mfem_lds_barrier();
     if (nd_ok) {
       double lo = 0.0, up = 0.0;
       if (plane) {
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
       if (I >= T.i0) res[(int64_t)(I - B.plo) * B.plane_len + (int64_t)j * B.m2 + k] = carry + lo;
       carry = up;
     }
-    __syncthreads();
+    mfem_lds_barrier();
   }
 }
 
@@ -706,10 +708,12 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   const bool jk_inner = nd_ok && j > 0 && j < B.ne1 && k > 0 && k < B.ne2;  // all nine in-plane neighbours exist
   const bool staged = (stage_rows & 1) != 0;  // (kernel argument, uniform: the per-thread write-out is kept behind bit 1 of mfem_debug_set_hex8_thermal)
   double Xn[3][4];
+  const int Jc = min(max(J, 0), B.ne1 - 1), Kc = min(max(K, 0), B.ne2 - 1);  // (threads without an element column load what a neighbour loads)
+  // (every thread requests on every step, from clamped positions: behind a condition the requested registers meet their old values in a phi, and the copies that resolves into wait for the loads AT ONCE -- the prefetch then costs a memory round trip per plane instead of hiding one: round 5, found in the ISA)
   auto request = [&](int ip) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+      const int64_t ci = brick_cindex(B, ip, Jc + (c & 1), Kc + (c >> 1));
       Xn[0][c] = B.X0[ci];
       Xn[1][c] = B.X1[ci];
       Xn[2][c] = B.X2[ci];
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   };
   double X[3][2][4];
   const int Ifirst = max(T.i0 - 1, 0), Ilast = min(T.i1 - 1, B.ne0 - 1);
-  if (el_ok) {
+  {
     request(Ifirst);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -743,9 +747,9 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
       else sf_thermal_ke<NG, false>(X, kcond, k36);
 #pragma unroll
       for (int t = 0; t < 36; ++t) Ke[tid * SW_KSTRIDE + t] = k36[t];
-      if (I < Ilast) request(I + 2);
     }
-    __syncthreads();
+    request(min(max(I + 2, Ifirst), Ilast + 1));  // in flight during the rest of this plane's step: gather, write-out, barriers (mfem_lds_barrier does not wait for it)
+    mfem_lds_barrier();
     // now[bx * 9 + dj * 3 + dk]: entries of this plane's point towards node plane I + bx; up[...]: entries of the point above it
     // (node plane I + 1) towards node plane I + bx
     double now[18], up[18];
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
     // (Every barrier below is reached by ALL threads of the workgroup: `staged` is a kernel argument, nothing here sits inside a per-thread branch.)
     const bool full_row = nd_ok && jk_inner && I > 0 && I < B.ne0 && I >= T.i0;
     if (staged) {
-      __syncthreads();  // every point has gathered from Ke
+      mfem_lds_barrier();  // every point has gathered from Ke
       if (full_row) {
         double* st = Ke + tid * 27;
 #pragma unroll
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
       for (int t = 0; t < 18; ++t) carry[t] = up[t];
     }
     if (staged) {
-      __syncthreads();  // the staged rows are complete
+      mfem_lds_barrier();  // the staged rows are complete
       if (I >= T.i0 && I > 0 && I < B.ne0) {
         const int k0 = max(T.tk0, 1), k1 = min(min(T.tk0 + SW_N, B.ne2), B.m2);  // points of a tile line with a full row: k in [k0, k1)
         const int cnt = (k1 - k0) * 27;
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         }
       }
     }
-    __syncthreads();
+    mfem_lds_barrier();
   }
 }
 
@@ -1295,20 +1299,22 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   const int j = T.tj0 + ej, k = T.tk0 + ek;          // phase B: this thread's control point column
   const bool nd_ok = ej < SW_N && ek < SW_N && j < B.m1 && k < B.m2;
   double Xn[3][4], Un[3][4];  // the plane requested last (consumed at the top of the next step)
+  const int Jc = min(max(J, 0), B.ne1 - 1), Kc = min(max(K, 0), B.ne2 - 1);  // (threads without an element column load what a neighbour loads)
+  // (every thread requests on every step, from clamped positions: behind a condition the requested registers meet their old values in a phi, and the copies that resolves into wait for the loads AT ONCE -- the prefetch then costs a memory round trip per plane instead of hiding one: round 5, found in the ISA)
   auto request = [&](int ip) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int64_t ci = brick_cindex(B, ip, J + (c & 1), K + (c >> 1));
+      const int64_t ci = brick_cindex(B, ip, Jc + (c & 1), Kc + (c >> 1));
       Xn[0][c] = B.X0[ci];
       Xn[1][c] = B.X1[ci];
       Xn[2][c] = B.X2[ci];
 #pragma unroll
-      for (int f = 0; f < 3; ++f) Un[f][c] = x[brick_xindex(B, f, ip, J + (c & 1), K + (c >> 1))];
+      for (int f = 0; f < 3; ++f) Un[f][c] = x[brick_xindex(B, f, ip, Jc + (c & 1), Kc + (c >> 1))];
     }
   };
   double X[3][2][4], U[3][2][4];
   const int Ifirst = max(T.i0 - 1, 0), Ilast = min(T.i1 - 1, B.ne0 - 1);  // element planes of this segment
-  if (el_ok) {
+  {
     request(Ifirst);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -1341,9 +1347,9 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
           Fe[tid * ESW_STRIDE + f * 8 + 2 * c] = fe[f][0][c];
           Fe[tid * ESW_STRIDE + f * 8 + 2 * c + 1] = fe[f][1][c];
         }
-      if (I < Ilast) request(I + 2);  // in flight during phase B and the two barriers
     }
-    __syncthreads();
+    request(min(max(I + 2, Ifirst), Ilast + 1));  // in flight during the rest of this plane's step: gather, write-out, barriers (mfem_lds_barrier does not wait for it)
+    mfem_lds_barrier();
     if (nd_ok) {
       double lo[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 0.0, 0.0};
       if (plane) {
@@ -1367,7 +1373,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         carry[f] = up[f];
       }
     }
-    __syncthreads();
+    mfem_lds_barrier();
   }
 }
 

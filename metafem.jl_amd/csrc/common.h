@@ -296,6 +296,13 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
 }
 
 // Block-wide sum for blockDim.x == MFEM_BLOCK (4 waves). Result valid in thread 0.
+// Workgroup barrier for data the waves exchange through LDS ONLY.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: it also waits until every
+// global load of the wave has returned and every global STORE has reached memory -- in a kernel that requests the next plane's data early, or streams its
+// results out with stores, that is a memory round trip per barrier (round 5: found in k_hex27_rows_gq with the counters, then in the plane sweeps).  Here only
+// the LDS counter is drained; global loads into registers are waited for where the registers are used (the compiler's own s_waitcnt), stores never.
+// NOT for barriers that order global-memory accesses between the waves of a workgroup.
+__device__ __forceinline__ void mfem_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 4 doubles */) {
   v = wave_reduce_sum(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
