@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   __shared__ __attribute__((aligned(16))) int32_t sc_all[WAVES][CAPW + 4];
   __shared__ double red[4];
   if (done_flag && done_flag[0]) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (scalar: the tile index and what is loaded with it then are, too)
   double* sv = sv_all[w];
   int32_t* sc = sc_all[w];
   const int tpr = 1 << tpr_log2;
@@ -337,6 +337,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   const int64_t tstride = (int64_t)gridDim.x * WAVES;
   // x as a buffer resource (byte offsets are 32-bit: the host side uses this kernel only while 8 * columns < 4 GiB)
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0xFFFFFFFF, 0x00020000);
+  // Round 5 -- the pipeline below only works when the NUMBER of loads between a load and its first use is the same on every path: the compiler's
+  // s_waitcnt vmcnt(N) for "the gathers have returned" counts the loads issued behind them, and where paths with different counts meet (a request behind
+  // `if (t_next < ntiles)`, a column stream behind `if (!el)`, a gather behind `if (j < hi)`) it must assume the smallest -- vmcnt(0), i.e. the row sums waited
+  // for the next tile's streams as well, and a value read back with readfirstlane right behind its load (row pointers, the elision flag) waited for every
+  // gather in front of it.  Now: tile-level scalars come through scalar loads (the tile index is wave-uniform), every vector load is issued on every path --
+  // a column stream that is not needed aims past the end of its bounds-checked buffer (returns zero, moves no data), a lane without an entry gathers x[0].
   // Software pipeline per wave: the tile after the current one sits in registers (requested while the current tile's
   // gathers were in flight), the row-pointer pair of the tile after that is requested one step earlier still.
   d2_t pv[LU];
@@ -375,26 +381,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
   };
   // elide[t] != 0: every row of tile t repeats the column offsets of the tile's first row (inspected once per pattern, k_csr_w_elide): only
   // that row's columns are read (the first 128 staged entries hold them)
-  auto request = [&](int64_t t, int64_t& sa, int& cnt, int& lo, int& hi, int& el) {  // issue the loads of tile t into pv / pc
+  auto request = [&](int64_t tq, int64_t& sa, int& cnt, int& lo, int& hi, int& el) {  // issue the loads of tile t into pv / pc
+    const int64_t t = uniform64(tq);  // (wave-uniform: the loads below that depend on it alone are scalar loads)
     const int64_t r0 = t * R, r1 = (r0 + R < n) ? r0 + R : n;
-    const int64_t s = uniform64((int64_t)rowptr[r0] - base), e = uniform64((int64_t)rowptr[r1] - base);
+    const int64_t s = (int64_t)rowptr[r0] - base, e = (int64_t)rowptr[r1] - base;
     sa = s & ~(int64_t)1;
     cnt = (int)(e - sa);
-    el = elide ? __builtin_amdgcn_readfirstlane((int)elide[t]) : 0;
-    const int64_t r = r0 + rsel;
-    lo = hi = 0;
-    if (r < r1) {
-      lo = (int)((int64_t)rowptr[r] - base - sa);
-      hi = (int)((int64_t)rowptr[r + 1] - base - sa);
-    }
+    el = elide ? (int)elide[t] : 0;
+    const int64_t r = r0 + rsel, rr = r < r1 ? r : r1 - 1;  // (a lane group behind the tile's last row reads that row's pointers and keeps an empty range)
+    const int lo_r = (int)((int64_t)rowptr[rr] - base - sa), hi_r = (int)((int64_t)rowptr[rr + 1] - base - sa);
+    lo = r < r1 ? lo_r : 0;
+    hi = r < r1 ? hi_r : 0;
     // the tile's two streams as bounds-checked buffers (base in scalar registers, one offset register per lane, entries past
-    // the tile's end read as zero): no per-load address pairs, no masks
+    // the tile's end read as zero): no per-load address pairs, no masks.  A tile whose rows repeat their first row's column offsets (el) reads 128 columns:
+    // its column buffer ends there, the loads behind it return zeros without touching memory
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(vals + sa), 0, cnt * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(col + sa), 0, cnt * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(col + sa), 0, (el && cnt > 128 ? 128 : cnt) * 4, 0x00020000);
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       pv[u] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(vr, lane * 16, u * 1024, 2));
-      if (!el || u == 0) pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
+      pc[u] = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(cr, lane * 8, u * 512, 2));
     }
   };
   int el_cur = 0;
@@ -422,9 +428,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       const int j = j0 + u * tpr;
-      xx[u] = 0.0;
-      // buffer form of the load: one 32-bit offset register per gather instead of a 64-bit address pair (28 gathers in flight)
-      if (j < hi) xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, (colof(j) - base) * 8, 0, 0));
+      // buffer form of the load: one 32-bit offset register per gather instead of a 64-bit address pair (28 gathers in flight); a lane whose row has no
+      // entry j reads x[first column of the vector] instead (the product is dropped below) -- every lane issues every gather
+      const int off = j < hi ? (colof(j) - base) * 8 : 0;
+      xx[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xres, off, 0, 0));
     }
     // ---- ... then the request for the next tile: it returns behind the gathers (loads return in order), so the row sums
     //      below do not wait for it, and it is in flight while they run
@@ -432,13 +439,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(CAPW
     const int64_t t_next = next_tile(q_cur);
     int64_t sa_n = 0;
     int cnt_n = 0, lo_n = 0, hi_n = 0, el_n = 0;
-    // (the LDS block is still being read below: the next tile stays in registers until the top of the loop)
-    if (t_next < ntiles) request(t_next, sa_n, cnt_n, lo_n, hi_n, el_n);
+    // (the LDS block is still being read below: the next tile stays in registers until the top of the loop; behind the last tile the current one is
+    // requested once more -- its registers are never used)
+    request(t_next < ntiles ? t_next : t_cur, sa_n, cnt_n, lo_n, hi_n, el_n);
     double sum = 0.0;
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       const int j = j0 + u * tpr;
-      sum += (j < hi ? sv[j] : 0.0) * xx[u];
+      sum += j < hi ? sv[j] * xx[u] : 0.0;
     }
     for (int j = j0 + NG * tpr; j < hi; j += tpr) sum += sv[j] * x[colof(j) - base];  // rows longer than NG * tpr entries
     for (int off = tpr >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, MFEM_WAVE);
