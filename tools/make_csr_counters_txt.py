@@ -41,5 +41,8 @@ Late in round 5 the ISA of k_spmv_csr_w showed why its software pipeline did not
 smallest count -- vmcnt(0): the row sums waited for the next tile's streams too.  With every load issued on every path (scalar loads for tile-level values, a bounded column
 buffer for elided tiles, inactive lanes gathering x[0]) the waits count down (vmcnt(57) ... vmcnt(30)) as intended: mul! 8.1-8.5 -> 7.9-8.1 ms at 512^3, 1.03-1.04 -> 1.02 ms at 256^3
 -- the kernel is bound by the loaded memory latency at eight waves per CU (~10 us per tile and wave), not by the order of its waits.  The same change in k_spmv_csr_rb was
-measured and not kept: its chunks of 16 gathers are mostly empty on short rows, issuing all of them cost 12 %; with the gathers left conditional nothing changed.""")
+measured and not kept: its chunks of 16 gathers are mostly empty on short rows, issuing all of them cost 12 %; with the gathers left conditional nothing changed.
+Two tiles in flight per wave in k_spmv_csr_w (a second register set for the tile after next: 43 KB per wave under way instead of 21.5; 256 VGPRs + 120 bytes of scratch) was
+measured too: 1.29 ms at 256^3 and 9.8 ms at 512^3 against 1.02 / 7.9 -- more requests in flight only lengthen the queues: at 5.0 TB/s of counter traffic the kernel sits at
+80 % of what a streaming kernel reaches on this chip (6.3 TB/s), and the rest of its requests are the gathers' L2 traffic.  Not kept.""")
 open(f"{R}/profiles/r05_csr_counters.txt", "w").write("\n".join(out) + "\n")
