@@ -98,6 +98,9 @@ struct CombineList {
 // U_k = sum_t c[t] U[k+t] + omega * (r - sum_t c[t] G[k+t])      (:49-58)
 // The coefficients c = LowerTriangular(M[k:s, k:s]) \ f[k:s] (:47; a host solve in the reference) are computed by every
 // workgroup for itself from a shared-memory copy of the m x m block (m <= 32: a few hundred flops) -- no separate 1-thread kernel.
+// M = L.m as a template constant (1 .. 8; round 5): the 2 M + 1 loads of an index are issued before the first product (the run-time loop waited for each
+// pair before the next was requested); M = 0: the run-time form (s > 8).  Same arithmetic in the same order.
+template <int M>
 __global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList L, int k, const d2_t* __restrict__ r, d2_t* Uk,
                                                           const double* __restrict__ S, const int32_t* __restrict__ F) {
   __shared__ double c[IS_MAXS];
@@ -121,14 +124,33 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList
   const double omega = S[I_OMEGA];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
-    d2_t v = c[0] * KB_LD(L.G[0], i);
-    d2_t q = c[0] * KB_LD(L.U[0], i);
-    for (int t = 1; t < L.m; ++t) {
-      v += c[t] * KB_LD(L.G[t], i);
-      q += c[t] * KB_LD(L.U[t], i);
+    if constexpr (M > 0) {
+      d2_t g[M], u[M];
+#pragma unroll
+      for (int t = 0; t < M; ++t) {
+        g[t] = KB_LD(L.G[t], i);
+        u[t] = KB_LD(L.U[t], i);
+      }
+      const d2_t rv = KB_LD(r, i);
+      d2_t v = c[0] * g[0];
+      d2_t q = c[0] * u[0];
+#pragma unroll
+      for (int t = 1; t < M; ++t) {
+        v += c[t] * g[t];
+        q += c[t] * u[t];
+      }
+      v = rv - v;
+      Uk[i] = q + omega * v;
+    } else {
+      d2_t v = c[0] * KB_LD(L.G[0], i);
+      d2_t q = c[0] * KB_LD(L.U[0], i);
+      for (int t = 1; t < L.m; ++t) {
+        v += c[t] * KB_LD(L.G[t], i);
+        q += c[t] * KB_LD(L.U[t], i);
+      }
+      v = KB_LD(r, i) - v;
+      Uk[i] = q + omega * v;
     }
-    v = KB_LD(r, i) - v;
-    Uk[i] = q + omega * v;
   }
 }
 
@@ -159,6 +181,7 @@ __global__ void ki_ortho(FoldArg fa, int dst, int m, int k, int s, int last, dou
   S[I_BETA] = S[I_F + k] / S[I_M + k + IS_MAXS * k];
 }
 // ... vector part: g -= sum alpha_t g_t ; u -= sum alpha_t u_t ; x += beta u ; r -= beta g ; partial sums of r'r over the owned entries
+template <int M>  // (M = L.m for 0 .. 8 -- all loads of an index up front, see ki_combine --, -1: the run-time form)
 __global__ __launch_bounds__(MFEM_BLOCK) void ki_update(int64_t n2, int64_t n_owned, CombineList L, d2_t* __restrict__ Gk, d2_t* __restrict__ Uk,
                                                          d2_t* __restrict__ x, d2_t* __restrict__ r, const double* __restrict__ S,
                                                          const int32_t* __restrict__ F, double* __restrict__ partials) {
@@ -172,14 +195,33 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_update(int64_t n2, int64_t n_ow
   double acc = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
     d2_t g = KB_LD(Gk, i), u = KB_LD(Uk, i);
-    for (int t = 0; t < L.m; ++t) {
-      g -= al[t] * KB_LD(L.G[t], i);
-      u -= al[t] * KB_LD(L.U[t], i);
+    d2_t xv, rv;
+    if constexpr (M >= 0) {
+      d2_t gt[M > 0 ? M : 1], ut[M > 0 ? M : 1];
+#pragma unroll
+      for (int t = 0; t < M; ++t) {
+        gt[t] = KB_LD(L.G[t], i);
+        ut[t] = KB_LD(L.U[t], i);
+      }
+      xv = KB_LD(x, i);
+      rv = KB_LD(r, i);
+#pragma unroll
+      for (int t = 0; t < M; ++t) {
+        g -= al[t] * gt[t];
+        u -= al[t] * ut[t];
+      }
+    } else {
+      for (int t = 0; t < L.m; ++t) {
+        g -= al[t] * KB_LD(L.G[t], i);
+        u -= al[t] * KB_LD(L.U[t], i);
+      }
+      xv = KB_LD(x, i);
+      rv = KB_LD(r, i);
     }
     Gk[i] = g;
     Uk[i] = u;
-    x[i] = KB_LD(x, i) + beta * u;
-    const d2_t rn = KB_LD(r, i) - beta * g;
+    x[i] = xv + beta * u;
+    const d2_t rn = rv - beta * g;
     r[i] = rn;
     if (2 * i < n_owned) acc += rn.x * rn.x;
     if (2 * i + 1 < n_owned) acc += rn.y * rn.y;
@@ -259,7 +301,12 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
         C.G[t] = (const d2_t*)G[kk + t];
         C.U[t] = (const d2_t*)U[kk + t];
       }
-      hipLaunchKernelGGL(ki_combine, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, kk, (const d2_t*)r, (d2_t*)U[kk], S, F);
+#define KI_COMBINE(M_) case M_: hipLaunchKernelGGL(ki_combine<M_>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, kk, (const d2_t*)r, (d2_t*)U[kk], S, F); break;
+      switch (C.m) {
+        KI_COMBINE(1) KI_COMBINE(2) KI_COMBINE(3) KI_COMBINE(4) KI_COMBINE(5) KI_COMBINE(6) KI_COMBINE(7) KI_COMBINE(8)
+        default: hipLaunchKernelGGL(ki_combine<0>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, kk, (const d2_t*)r, (d2_t*)U[kk], S, F); break;
+      }
+#undef KI_COMBINE
       MFEM_CHECK_LAUNCH();
       RC(k.spmv(A, vals, U[kk], G[kk], spmv_cnt));  // :59
       if (g_idrs_literal) {
@@ -304,8 +351,12 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
           Q.U[t] = (const d2_t*)U[t];
         }
         double* part = ctx->d_partials;
-        hipLaunchKernelGGL(ki_update, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, V.n, Q, (d2_t*)G[kk], (d2_t*)U[kk], (d2_t*)V.x, (d2_t*)r, S, F,
-                           part);
+#define KI_UPDATE(M_) case M_: hipLaunchKernelGGL(ki_update<M_>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, V.n, Q, (d2_t*)G[kk], (d2_t*)U[kk], (d2_t*)V.x, (d2_t*)r, S, F, part); break;
+        switch (Q.m) {
+          KI_UPDATE(0) KI_UPDATE(1) KI_UPDATE(2) KI_UPDATE(3) KI_UPDATE(4) KI_UPDATE(5) KI_UPDATE(6) KI_UPDATE(7) KI_UPDATE(8)
+          default: hipLaunchKernelGGL(ki_update<-1>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, V.n, Q, (d2_t*)G[kk], (d2_t*)U[kk], (d2_t*)V.x, (d2_t*)r, S, F, part); break;
+        }
+#undef KI_UPDATE
         MFEM_CHECK_LAUNCH();
         FoldArg fe{part, k.G, 1, I_DOT};
         if (ctx->comm) {  // (fold + all-reduce here, like KK::dots_partials)

@@ -73,6 +73,10 @@ struct DotList {
 // partials[k*G + blockIdx] = partial of x_k . y_k  for k < m   (one pass over memory per distinct vector read).
 // Only the first n entries count: behind them a slab vector carries ghost entries (copies of the neighbours' values, which
 // their owners sum) and every vector carries padding.
+// M = number of dot products when it is a template constant (1 .. 8; round 5): all 2 M (M + 1 with SAMEY: every y_k is the same vector, as in P' g) loads of
+// an index are issued before the first product -- behind the run-time test `k < L.m` each pair of loads sat in its own branch and was waited for there, one
+// memory round trip after the other.  M = 0: the run-time form.  Same products, same order of the sums: bitwise the same partials.
+template <int M, bool SAMEY>
 static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n, DotList L, double* __restrict__ partials,
                                                                    const int32_t* __restrict__ flags) {
   __shared__ double red[4];
@@ -82,13 +86,31 @@ static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n, Dot
   double acc[KK_MAX_DOTS];
 #pragma unroll
   for (int k = 0; k < KK_MAX_DOTS; ++k) acc[k] = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+  if constexpr (M > 0) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+      d2_t a[M], b[M];
 #pragma unroll
-    for (int k = 0; k < KK_MAX_DOTS; ++k)
-      if (k < L.m) {
-        const d2_t a = KB_LD(L.x[k], i), b = KB_LD(L.y[k], i);
-        acc[k] += a.x * b.x + a.y * b.y;
+      for (int k = 0; k < M; ++k) a[k] = KB_LD(L.x[k], i);
+      if constexpr (SAMEY) {
+        b[0] = KB_LD(L.y[0], i);
+#pragma unroll
+        for (int k = 1; k < M; ++k) b[k] = b[0];
+      } else {
+#pragma unroll
+        for (int k = 0; k < M; ++k) b[k] = KB_LD(L.y[k], i);
       }
+#pragma unroll
+      for (int k = 0; k < M; ++k) acc[k] += a[k].x * b[k].x + a[k].y * b[k].y;
+    }
+  } else {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+#pragma unroll
+      for (int k = 0; k < KK_MAX_DOTS; ++k)
+        if (k < L.m) {
+          const d2_t a = KB_LD(L.x[k], i), b = KB_LD(L.y[k], i);
+          acc[k] += a.x * b.x + a.y * b.y;
+        }
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd n: the last entry shares its 16 bytes with the first ghost / pad entry
 #pragma unroll
@@ -101,6 +123,20 @@ static __global__ __launch_bounds__(MFEM_BLOCK) void kk_multi_dot(int64_t n, Dot
       const double s = block_reduce_sum(acc[k], red);
       if (threadIdx.x == 0) partials[(int64_t)k * gridDim.x + blockIdx.x] = s;
     }
+}
+static inline void kk_multi_dot_launch(int G, hipStream_t st, int64_t n, const DotList& L, double* part, const int32_t* F) {
+  bool same = true;
+  for (int k = 1; k < L.m; ++k) same = same && L.y[k] == L.y[0];
+#define KK_MD(M_)                                                                                                                   \
+  case M_:                                                                                                                          \
+    if (same) hipLaunchKernelGGL((kk_multi_dot<M_, true>), dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F);                        \
+    else hipLaunchKernelGGL((kk_multi_dot<M_, false>), dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F);                            \
+    break;
+  switch (L.m) {
+    KK_MD(1) KK_MD(2) KK_MD(3) KK_MD(4) KK_MD(5) KK_MD(6) KK_MD(7) KK_MD(8)
+    default: hipLaunchKernelGGL((kk_multi_dot<0, false>), dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F); break;
+  }
+#undef KK_MD
 }
 
 // Single workgroup: S[out + k] = sum(partials[k*G .. (k+1)*G)) for k < m
@@ -158,7 +194,7 @@ struct KK {
   // S[out + k] = x_k . y_k (all-reduced over ranks when a communicator is attached)
   int dots(const DotList& L, int out) const {
     double* part = ctx->d_partials;
-    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F);
+    kk_multi_dot_launch(G, st, n, L, part, F);
     MFEM_CHECK_LAUNCH();
     hipLaunchKernelGGL(kk_fold, dim3(1), dim3(MFEM_BLOCK), 0, st, part, G, L.m, out, S, F);
     MFEM_CHECK_LAUNCH();
@@ -169,7 +205,7 @@ struct KK {
   // communicator the fold + all-reduce happen here and the descriptor is empty.
   int dots_partials(const DotList& L, int out, FoldArg* fa) const {
     double* part = ctx->d_partials;
-    hipLaunchKernelGGL(kk_multi_dot, dim3(G), dim3(MFEM_BLOCK), 0, st, n, L, part, F);
+    kk_multi_dot_launch(G, st, n, L, part, F);
     MFEM_CHECK_LAUNCH();
     *fa = FoldArg{part, G, L.m, out};
     if (ctx->comm) {
