@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -318,6 +319,21 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 
   return r;
 }
 
+// Workgroups of `kernel` a CU holds at once (registers, LDS, waves), from the runtime, cached per kernel; `fallback` when the query fails.  A PERSISTENT grid must
+// be a multiple of what is resident: one workgroup more per CU than fits runs as a second round while the others idle (round 5: k_lat8_gather<F = 1> at 75
+// VGPRs holds 6 workgroups per CU and was launched with 8 -- two rounds for the work of 1.33).
+static inline int mfem_resident_per_cu(const void* kernel, int block_threads, size_t dyn_lds, int fallback) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(kernel);
+  if (it != cache.end()) return it->second;
+  int occ = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, dyn_lds);
+  const int v = (e == hipSuccess && occ >= 1) ? occ : fallback;
+  cache[kernel] = v;
+  return v;
+}
 static inline int mfem_grid_for(int64_t work_items, int per_block, int cap) {
   int64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;

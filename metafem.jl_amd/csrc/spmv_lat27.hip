@@ -931,12 +931,16 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
     MFEM_CHECK_LAUNCH();
   }
   if (part == 1) return 1;  // (the gather pass belongs to part 2)
-  int cap = ctx->num_cus * 8;
-  if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
-  const int grid = ntiles < cap ? ntiles : cap;
+  // persistent grid = what is resident (mfem_resident_per_cu; the staged gather holds 3 workgroups per CU at 145 VGPRs, the plain one 6: both were launched with 8)
+  int grid = 1;
 #define L27_GATHER(KERNEL, RP)                                                                                                              \
-  hipLaunchKernelGGL(KERNEL<RP>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials, done_flag, \
-                     (const RP*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc)
+  do {                                                                                                                                      \
+    int cap = ctx->num_cus * mfem_resident_per_cu(reinterpret_cast<const void*>(&KERNEL<RP>), MFEM_BLOCK, 0, 3);                            \
+    if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;                                                                                   \
+    grid = ntiles < cap ? ntiles : cap;                                                                                                     \
+    hipLaunchKernelGGL(KERNEL<RP>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat27_dump, y, alpha, beta, dotw, partials, done_flag, \
+                       (const RP*)A->rowptr, A->index_base, A->lat27_src, x, A->lat27_dsc);                                                 \
+  } while (0)
   if (g_lat27_gather_staged) {
     if (A->rowptr_bits == 64) L27_GATHER(k_lat27_gather_st, int64_t); else L27_GATHER(k_lat27_gather_st, int32_t);
   } else {

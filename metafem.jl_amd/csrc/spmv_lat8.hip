@@ -722,12 +722,17 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   }
 #undef L8_PASS1
   if (part == 1) return 1;  // (the gather pass belongs to part 2)
-  int cap = ctx->num_cus * 8;
-  if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;
-  const int grid = ntiles < cap ? ntiles : cap;
+  // persistent grid = what is resident (mfem_resident_per_cu): the F = 1 kernel holds 6 workgroups per CU, F = 2 five, F = 3 four -- launched with 8 per CU
+  // (until round 5) the one- and two-field gathers ran two rounds for the work of 1.33 / 1.6
+  int grid = 1;
 #define L8_GATHER(KERNEL, RP, FF)                                                                                                             \
-  hipLaunchKernelGGL((KERNEL<RP, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag, \
-                     (const RP*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc)
+  do {                                                                                                                                        \
+    int cap = ctx->num_cus * mfem_resident_per_cu(reinterpret_cast<const void*>(&KERNEL<RP, FF>), MFEM_BLOCK, 0, 4);                          \
+    if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;                                                                                     \
+    grid = ntiles < cap ? ntiles : cap;                                                                                                       \
+    hipLaunchKernelGGL((KERNEL<RP, FF>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, A->lat8_dump, y, alpha, beta, dotw, partials, done_flag, \
+                       (const RP*)A->rowptr, A->index_base, A->lat8_src, x, A->lat8_dsc);                                                     \
+  } while (0)
 #define L8_PASS2(FF)                                                                                                             \
   if (g_lat8_gather_staged) {                                                                                                   \
     if (A->rowptr_bits == 64) L8_GATHER(k_lat8_gather_st, int64_t, FF); else L8_GATHER(k_lat8_gather_st, int32_t, FF);          \

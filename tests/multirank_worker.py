@@ -201,7 +201,8 @@ def main():
                 # (idrs! on a nonsymmetric matrix is sensitive to the summation order of its dot products: the iteration counts of `world` ranks and of one
                 # rank differ by up to ~20 % here while the solutions agree to 1e-9)
                 check(f"{name}_diag_{tag}", s1.converged == 1 and sg.converged == 1 and relerr(x1, xg) <= 1e-8 and
-                      abs(s1.iterations - sg.iterations) <= max(6, sg.iterations // 3), iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
+                      abs(s1.iterations - sg.iterations) <= max(6, sg.iterations // 3), iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg),
+                      converged=(int(s1.converged), int(sg.converged)), passes=(int(s1.passes), int(sg.passes)), final_res=(float(s1.final_res), float(sg.final_res)))
         _lib.lib.mfem_debug_set_halo_overlap(1)
         tiles = (int(_lib.lib.mfem_debug_lat8_spmv_count()) - lat8_0) + (int(_lib.lib.mfem_debug_lat27_spmv_count()) - lat27_0)
         rem = int(_lib.lib.mfem_debug_rem_spmv_count()) - rem_0
