@@ -1,4 +1,4 @@
-"""A few hex-27 matrix assemblies of a fully distorted N^3 mesh through the row-owner kernel of general elements (k_hex27<true,true,true> + k_hex27_rows_gq), for
+"""A few hex-27 matrix assemblies of a fully distorted N^3 mesh through the row-owner kernel of general elements (k_hex27_gq_lane + k_hex27_rows_gq), for
 rocprofv3 --kernel-trace --stats / --pmc.  usage: hex27_rows_once.py [N] [reps] [knob]"""
 import sys
 
