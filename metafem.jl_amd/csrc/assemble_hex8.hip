@@ -688,6 +688,14 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   }
 }
 
+// brick_prefix of an order-1 lattice from closed forms (what upload_dim_tables of brick.hip tabulates: a point couples to itself and its neighbours -- 2 at the two
+// ends of a direction, 3 in between -- so the entries of the points in front of point g are 3 g - 1 from the second point on): the write-out below asked the
+// tables per tile line and plane, five dependent loads from memory in front of the stores of every wave (round 5: the same finding as PX[] in k_hex27_rows_gq)
+__device__ __forceinline__ int sw1_cnt(int g, int m) { return (g > 0 ? 1 : 0) + 1 + (g < m - 1 ? 1 : 0); }
+__device__ __forceinline__ int64_t sw1_pre(int g) { return g > 0 ? 3 * (int64_t)g - 1 : 0; }
+__device__ __forceinline__ int64_t sw1_prefix(const BrickView& B, int i, int j, int k) {
+  return (sw1_pre(i) - B.Pplo) * B.S1 * B.S2 + (int64_t)sw1_cnt(i, B.m0) * (sw1_pre(j) * B.S2 + (int64_t)sw1_cnt(j, B.m1) * sw1_pre(k));
+}
 template <int NG>
 __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals, int stage_rows) {
   __shared__ double Ke[SW_THREADS * SW_KSTRIDE];
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         for (int line = tid >> 6; line < SW_N; line += SW_THREADS / 64) {
           const int jl = T.tj0 + line;
           if (jl < 1 || jl >= B.ne1 || jl >= B.m1 || cnt <= 0) continue;
-          double* dst = vals + brick_prefix(B, I, jl, k0);
+          double* dst = vals + sw1_prefix(B, I, jl, k0);
           const double* src = Ke + (line * SW_E + (k0 - T.tk0)) * 27;
           for (int o = tid & 63; o < cnt; o += 64) __builtin_nontemporal_store(src[o], dst + o);
         }
@@ -1060,11 +1068,11 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   int i = 0, j = 0, k = 0, li = 0, lj = 0, lk = 0, cj = 1, ck = 1, cn = 0;
   if (live) {
     node_ijk(B, node, i, j, k);
-    li = B.lo0[i]; lj = B.lo1[j]; lk = B.lo2[k];
-    cj = B.c1[j]; ck = B.c2[k];
-    cn = B.c0[i] * cj * ck;
+    li = i > 0 ? i - 1 : 0; lj = j > 0 ? j - 1 : 0; lk = k > 0 ? k - 1 : 0;  // (closed forms of the order-1 row boxes instead of table loads: sw1_prefix above)
+    cj = sw1_cnt(j, B.m1); ck = sw1_cnt(k, B.m2);
+    cn = sw1_cnt(i, B.m0) * cj * ck;
     if (e == 0) {
-      s_pre[nl] = brick_prefix(B, i, j, k);
+      s_pre[nl] = sw1_prefix(B, i, j, k);
       s_cn[nl] = cn;
     }
   } else if (e == 0) {
