@@ -418,15 +418,23 @@ __device__ __forceinline__ bool boundary_point(const BrickView& B, int& i, int& 
   return true;
 }
 
+// brick_prefix of an order-1 lattice from closed forms (what upload_dim_tables of brick.hip tabulates: a point couples to itself and its neighbours -- 2 at the two
+// ends of a direction, 3 in between -- so the entries of the points in front of point g are 3 g - 1 from the second point on): the write-out below asked the
+// tables per tile line and plane, five dependent loads from memory in front of the stores of every wave (round 5: the same finding as PX[] in k_hex27_rows_gq)
+__device__ __forceinline__ int sw1_cnt(int g, int m) { return (g > 0 ? 1 : 0) + 1 + (g < m - 1 ? 1 : 0); }
+__device__ __forceinline__ int64_t sw1_pre(int g) { return g > 0 ? 3 * (int64_t)g - 1 : 0; }
+__device__ __forceinline__ int64_t sw1_prefix(const BrickView& B, int i, int j, int k) {
+  return (sw1_pre(i) - B.Pplo) * B.S1 * B.S2 + (int64_t)sw1_cnt(i, B.m0) * (sw1_pre(j) * B.S2 + (int64_t)sw1_cnt(j, B.m1) * sw1_pre(k));
+}
 // Robin faces: h*Bilinear(T, Tenv - T) contributes -h N_a N_b (3D_Script.jl:31).  One thread per BOUNDARY control point, which
 // read-modify-writes its OWN row (row owner => race-free), after the matrix kernel.
 __global__ __launch_bounds__(MFEM_BLOCK) void k_thermal_matrix_robin(BrickView B, double h, uint32_t robin,
                                                                        double* __restrict__ vals) {
   int i, j, k;
   if (!boundary_point(B, i, j, k)) return;
-  const int li = B.lo0[i], lj = B.lo1[j], lk = B.lo2[k];
-  const int cj = B.c1[j], ck = B.c2[k];
-  double* row = vals + brick_prefix(B, i, j, k);
+  const int li = i > 0 ? i - 1 : 0, lj = j > 0 ? j - 1 : 0, lk = k > 0 ? k - 1 : 0;  // (the row box from closed forms: no table loads in front of the face loads)
+  const int cj = sw1_cnt(j, B.m1), ck = sw1_cnt(k, B.m2);
+  double* row = vals + sw1_prefix(B, i, j, k);
   visit_boundary_faces(B, i, j, k, robin, [&](int nd, int side, int ca, const int (&fn)[4][3], const double (&Xf)[4][3]) {
     double mab[4] = {0.0, 0.0, 0.0, 0.0};
     for (int q = 0; q < B.ng * B.ng; ++q) {
@@ -688,14 +696,6 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   }
 }
 
-// brick_prefix of an order-1 lattice from closed forms (what upload_dim_tables of brick.hip tabulates: a point couples to itself and its neighbours -- 2 at the two
-// ends of a direction, 3 in between -- so the entries of the points in front of point g are 3 g - 1 from the second point on): the write-out below asked the
-// tables per tile line and plane, five dependent loads from memory in front of the stores of every wave (round 5: the same finding as PX[] in k_hex27_rows_gq)
-__device__ __forceinline__ int sw1_cnt(int g, int m) { return (g > 0 ? 1 : 0) + 1 + (g < m - 1 ? 1 : 0); }
-__device__ __forceinline__ int64_t sw1_pre(int g) { return g > 0 ? 3 * (int64_t)g - 1 : 0; }
-__device__ __forceinline__ int64_t sw1_prefix(const BrickView& B, int i, int j, int k) {
-  return (sw1_pre(i) - B.Pplo) * B.S1 * B.S2 + (int64_t)sw1_cnt(i, B.m0) * (sw1_pre(j) * B.S2 + (int64_t)sw1_cnt(j, B.m1) * sw1_pre(k));
-}
 template <int NG>
 __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals, int stage_rows) {
   __shared__ double Ke[SW_THREADS * SW_KSTRIDE];
