@@ -161,6 +161,9 @@ int mfem_debug_set_csr_strips(int on, int64_t min_bytes);
  * mfem_debug_remainder_info: rows / entries of the remainder the CURRENT or last bind on this pattern carries (0 / 0: none), and the asymmetry the
  * probe measured on the tiles alone; mfem_debug_rem_spmv_count: products that applied one (process-wide). */
 int mfem_debug_set_remainder(int enable);
+/* TEST HOOK: the residual a single-rank tile solve recomputes from the caller's CSR values before it ends the passes is multiplied by `scale`
+ * (default 1; <= 0 resets): lets a test put the tiles' residual and the caller's on the two sides of the tolerance */
+int mfem_debug_set_recheck_scale(double scale);
 int mfem_debug_remainder_info(mfem_csr A, int64_t* rows /* [host] */, int64_t* entries /* [host] */, double* asym_before /* [host] */);
 long long mfem_debug_rem_spmv_count(void);
 

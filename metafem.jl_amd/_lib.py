@@ -198,6 +198,7 @@ SIGNATURES = {
     "mfem_debug_fail_host_alloc": (c_int, [c_int]),
     "mfem_debug_ws_trial_log": (c_int, [P, C.POINTER(C.c_double)]),
     "mfem_debug_set_remainder": (c_int, [c_int]),
+    "mfem_debug_set_recheck_scale": (c_int, [c_double]),
     "mfem_debug_set_csr_strips": (c_int, [c_int, c_int64]),
     "mfem_debug_remainder_info": (c_int, [P, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "mfem_debug_rem_spmv_count": (C.c_longlong, []),
