@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
 // jobs on 3 x 3 x 3 elements, whose G_q (35 KB) the workgroup stages in LDS once (2.25 - 3.4 x redundancy against 27 x without staging).  Wave (h0, h1) owns the
 // nodes {2 h0, 2 h0 + 1} x {2 h1, 2 h1 + 1} x {0..3}: 3 x 3 x 6 = 54 jobs on 54 of its 64 lanes, and every job of a row sits in the same wave -- the 27 additions of a
 // job into the row's box in LDS come in program order (plain read - add - write in batches, see below), lanes of one instruction never meet in an entry (same
-// local node b of different elements): the result is reproducible.  The wave's 16 rows leave as contiguous streams.  The next tile's G_q is requested while this one's rows leave.
+// local node b of different elements): the result is reproducible.  The wave's 16 rows leave as four contiguous streams (one per lattice line).  The next tile's G_q
+// arrives in a second LDS buffer (global_load_lds) during this tile's arithmetic; the buffer the arithmetic has finished with becomes the tile's row boxes.
 namespace r27 {
 __host__ __device__ constexpr double gp(int q) { return (q == 0 ? -0.77459666924148337704 : q == 1 ? 0.0 : 0.77459666924148337704) / 2.0 + 0.5; }  // (hex27_upload_tables)
 __host__ __device__ constexpr double L(int q, int b) {  // lag2 at Gauss point q
