@@ -87,6 +87,8 @@ int mfem_debug_set_halo_overlap(int on);
  * stored anywhere; taken by default from bits 2-7 percent of non-affine elements on -- 0 = the default 30 -- when the mesh has three Gauss points per direction).
  * Bits 12-14: TIMING-ONLY ablations of that kernel (wrong values; tools/hex27_rows_ablate.py). */
 int mfem_debug_set_hex27(int two_pass);
+/* number of mfem_mesh_assemble_elements_rows calls that ran the row-owner form (process-wide) */
+int64_t mfem_debug_mesh_rows_count(void);
 /* number of hex-27 matrix assemblies that took the row-owner kernel of general elements (process-wide) */
 int64_t mfem_debug_hex27_rows_count(void);
 /* number of hex-27 matrix assemblies that took the per-element choice with at least one stored (non-affine) element (process-wide) */

@@ -309,6 +309,10 @@ extern "C" int mfem_mesh_assemble_elements(mfem_context ctx, int32_t dim, int32_
 // fb * ncp + node(el, b) (binary search in the staged list) -- distinct positions within a step, steps in sequence: no
 // atomics, a fixed summation order (bitwise reproducible), every K entry read and written once, contiguously.
 #define MG_MAXROW 2048
+static std::atomic<long long> g_mesh_rows_count{0};  // assemblies that took the row-owner form (tests, bench.py)
+extern "C" int64_t mfem_debug_mesh_rows_count(void) { return g_mesh_rows_count; }
+// element-matrix scratch the row-owner form may take from the context workspace (288 GB of HBM: hex-20 elasticity at 128^3 needs 60 GB)
+static const size_t MG_SCRATCH_BUDGET = (size_t)96 << 30;
 struct GatherBlocks {
   int nf;          // fields
   int nb;          // blocks in the scratch (runs of the term list)
@@ -476,8 +480,8 @@ extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, i
     ++B.nb;
   }
   const size_t bytes = sizeof(double) * (size_t)nel * itp * B.nb * itp;
-  if (bytes > ((size_t)16 << 30)) {
-    mfem_set_error("element-matrix scratch of %zu bytes exceeds the 16 GiB budget; use mfem_mesh_assemble_elements", bytes);
+  if (bytes > MG_SCRATCH_BUDGET) {
+    mfem_set_error("element-matrix scratch of %zu bytes exceeds the 96 GiB budget; use mfem_mesh_assemble_elements", bytes);
     return MFEM_ERR_UNSUPPORTED;
   }
   rc = mfem_ws_reserve(ctx, bytes);
@@ -498,6 +502,7 @@ extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, i
     hipLaunchKernelGGL(k_mesh_gather<int32_t>, dim3(grid), dim3(64 * waves), ldsb, ctx->stream, itp, ncp, B, (const int32_t*)A->rowptr,
                        A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow);
   MFEM_CHECK_LAUNCH();
+  ++g_mesh_rows_count;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_mesh_assemble_elements_rows")
 

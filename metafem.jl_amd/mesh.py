@@ -132,6 +132,25 @@ def make_Brick(x, n, shape: str = "CUBE"):
     return coors, conn
 
 
+def _unique_rows(K: np.ndarray, return_counts: bool = False):
+    """np.unique(K, axis=0, return_index=True, return_inverse=True[, return_counts]) for integer rows >= -1: the rows are packed into ONE int64 key
+    (mixed radix, first column most significant: the same lexicographic order) when the radix product fits -- 10-20x faster than the
+    structured-dtype sort numpy uses for axis = 0 on the multi-million-row keys of a 96^3 mesh; otherwise numpy's own path."""
+    K = np.asarray(K)
+    lo = int(K.min()) if K.size else 0
+    radix = [int(K[:, c].max()) - lo + 1 for c in range(K.shape[1])] if K.size else []
+    total = 1
+    for r in radix:
+        total *= r
+    if K.size == 0 or lo < -1 or total >= 2 ** 62:
+        return np.unique(K, axis=0, return_index=True, return_inverse=True, return_counts=return_counts)
+    key = np.zeros(K.shape[0], dtype=np.int64)
+    for c, r in enumerate(radix):
+        key = key * r + (K[:, c] - lo)
+    out = np.unique(key, return_index=True, return_inverse=True, return_counts=return_counts)
+    return (K[out[1]],) + tuple(out[1:])
+
+
 # ---- control points --------------------------------------------------------------------------------------------------
 @dataclass
 class ClassicalMesh:
@@ -211,7 +230,7 @@ def mesh_Classical(vert: np.ndarray, conn: np.ndarray, space: ClassicalSpace) ->
             pos.append(w[0] * vert[:, g0].T + w[1] * vert[:, g1].T)
             owner.append(a)
         K = np.concatenate(keys)
-        uniq, first, inv = np.unique(K, axis=0, return_index=True, return_inverse=True)
+        uniq, first, inv = _unique_rows(K)
         inv = inv.reshape(-1)
         blocks.append(np.concatenate(pos)[first])
         for k, a in enumerate(owner):
@@ -234,7 +253,7 @@ def mesh_Classical(vert: np.ndarray, conn: np.ndarray, space: ClassicalSpace) ->
             pos.append(sum(wi * vert[:, conn[s]].T for wi, s in zip(w, slots)))
             owner.append(a)
         K = np.concatenate(keys)
-        uniq, first, inv = np.unique(K, axis=0, return_index=True, return_inverse=True)
+        uniq, first, inv = _unique_rows(K)
         inv = inv.reshape(-1)
         blocks.append(np.concatenate(pos)[first])
         for k, a in enumerate(owner):
@@ -282,7 +301,7 @@ def get_BoundaryMesh(mesh: ClassicalMesh) -> Facets:
     faces = _face_slots(mesh.dim, mesh.shape)
     fids = sorted(faces)
     K = np.concatenate([np.sort(conn[faces[f]], axis=0).T for f in fids])
-    uniq, inv, cnt = np.unique(K, axis=0, return_inverse=True, return_counts=True)
+    uniq, _, inv, cnt = _unique_rows(K, return_counts=True)
     single = cnt[inv.reshape(-1)] == 1
     el = np.tile(np.arange(nel), len(fids))[single]
     fi = np.repeat(np.array(fids), nel)[single]

@@ -15,13 +15,34 @@ SMALL = ["--steps", "1", "--warmup", "0", "--secondary-n", "0", "--cpu-n", "0", 
 
 
 def run_bench(args, env=None, timeout=900):
+    """-> the FULL result object (the side file the line names); the stdout line itself is checked here for every invocation: ONE line, strict JSON,
+    under 8 KB, contract keys + roofline + cpu_baseline (what the driver parses -- round 5's 32 KB line was not)."""
+    import tempfile
+
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=e,
-                       cwd=ROOT)
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert r.returncode == 0, f"rc={r.returncode}\n--- stdout ---\n{r.stdout[-2000:]}\n--- stderr ---\n{r.stderr[-4000:]}"
-    assert len(lines) == 1, f"stdout must carry ONE JSON line, got {len(lines)}:\n{r.stdout[-2000:]}"
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        side = os.path.join(tmp, "full.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-out", side] + args, capture_output=True, text=True, timeout=timeout,
+                           env=e, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert r.returncode == 0, f"rc={r.returncode}\n--- stdout ---\n{r.stdout[-2000:]}\n--- stderr ---\n{r.stderr[-4000:]}"
+        assert len(lines) == 1, f"stdout must carry ONE JSON line, got {len(lines)}:\n{r.stdout[-2000:]}"
+        assert len(lines[0].encode()) < 8192, len(lines[0])
+
+        def no_constants(c):
+            raise ValueError(c)
+        line = json.loads(lines[0], parse_constant=no_constants)
+        full = json.load(open(side))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["full"] == side and abs(line["value"] / full["value"] - 1) < 1e-4
+    assert 0 < line["roofline"]["frac"] < 1 and abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4 and len(line["roofline"]["kernel"]) <= 100
+    for k in ("workload", "n_dof", "nnz", "solve_ms_per_step", "assembly_ms_per_step", "initial_res", "final_res"):
+        assert k in line["config"], k
+    assert "errors" not in full, full["errors"]
+    full["_line"] = line
+    return full
 
 
 def _common(out, n_gpus, steps=1, scaling="weak"):
@@ -56,6 +77,13 @@ def test_single_gpu_line_has_every_object():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert out["vs_cpu_baseline"]["main_workload"] > 0
+    # the driver's line: cpu_baseline as numbers + a sample of at most 120 characters, one small object per leg
+    line = out["_line"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == cb["cores"] and len(line["cpu_baseline"]["sample"]) <= 120
+    assert set(line["secondary_24"]) >= {"value", "ms_per_step", "spmv_ms", "frac", "frac_actual", "csr_frac"}
+    assert line["roofline"]["csr_kernel"]["ms"] > 0
+    nl = out["newton_like"]
+    assert nl["iterations"] == 20 and nl["ms_per_step"] > 0 and nl["solve_ms"] > 0 and line["newton_like"]["per_solve_ms"] == pytest.approx(nl["per_solve_ms"], rel=1e-3)
 
 
 def test_two_ranks_on_one_gpu_through_the_host_transport():

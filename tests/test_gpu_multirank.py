@@ -129,7 +129,9 @@ def test_bench_two_gpus_over_rccl(scaling):
                         "--scaling", scaling], capture_output=True, text=True, timeout=600, cwd=root,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert line["comm_exposed"]["exposed_fraction_of_solve"] >= 0  # (the line carries the worst rank; the side file every rank)
+    out = json.load(open(os.path.join(root, line["full"])))
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and "RCCL" in out["config"]["parallelism"]
     assert out["config"]["n_dof"] == (129 if scaling == "weak" else 65) * 65 * 65
     assert out["config"]["final_res"] < out["config"]["initial_res"]

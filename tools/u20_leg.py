@@ -1,0 +1,21 @@
+"""The unstructured hex-20 legs of bench.py alone (for rocprofv3 --kernel-trace --stats and A/B runs).  usage: u20_leg.py [n = 96] [fields = 1,3] [steps = 3] [iters = 200]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import bench_legs as L  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+fields = [int(f) for f in (sys.argv[2] if len(sys.argv) > 2 else "1,3").split(",")]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+args = bench.parse_args(["--iters", str(iters)])
+B = L.Bench(args)
+for f in fields:
+    o = B.unstructured_leg(n, f, steps)
+    o["roofline"].pop("kernel_note", None)
+    o["csr_kernel"].pop("kernel_note", None)
+    print(json.dumps({k: v for k, v in o.items() if k != "workload"}, default=str), flush=True)
