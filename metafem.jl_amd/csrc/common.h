@@ -187,6 +187,7 @@ struct mfem_csr_s {
   int32_t* sell_flags;      // owned, [nblk]: 1 = all 128 rows share one diagonal list
   int32_t* sell_off;        // owned, [sell_total / 128]: that list, at ptr[b] / 128
   int32_t sell_regular_blocks;
+  int32_t sell_sig_sorted;      // 1: the diagonal-list signature took part in the row sort (lattice patterns); 0: mesh order within a length (unstructured)
   const double* sell_src;
   double* sell_vals;        // not owned (solver workspace), [sell_total]
   // symmetric lattice-tile layout of the hex-27 lattice matrix (spmv_lat27.hip): lat27_state 0 = not inspected, -1 = no, 1 = the pattern is the stencil

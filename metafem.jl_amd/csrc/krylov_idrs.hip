@@ -62,7 +62,7 @@ __global__ void ki_alpha(FoldArg fa, int i, double* __restrict__ S, const int32_
   S[I_ALPHA] = S[I_DOT] / S[I_M + i + IS_MAXS * i];
 }
 // stop test after the inner step, then f[k+1:] -= beta*M[k+1:,k]; iter += 1   (:79-81); S[I_DOT] = r.r
-__global__ void ki_step_end(FoldArg fa, IdArgs a, int k, double* __restrict__ S, int32_t* __restrict__ F) {
+__global__ void ki_step_end(FoldArg fa, IdArgs a, int k, double* __restrict__ S, int32_t* __restrict__ F, int f_done = 0) {
   if (F[F_DONE]) return;
   kk_fold_dev(fa, S);
   if (threadIdx.x != 0) return;
@@ -72,7 +72,7 @@ __global__ void ki_step_end(FoldArg fa, IdArgs a, int k, double* __restrict__ S,
     F[F_DONE] = 1;
     return;
   }
-  if (k >= 0) {
+  if (k >= 0 && !f_done) {
     const double beta = S[I_BETA];
     for (int i = k + 1; i < a.s; ++i) S[I_F + i] -= beta * S[I_M + i + IS_MAXS * k];
   }
@@ -155,14 +155,20 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_combine(int64_t n2, CombineList
 }
 
 static std::atomic<int> g_idrs_literal{0};
-extern "C" int mfem_debug_set_idrs(int literal_orthogonalisation) try {
+static std::atomic<int> g_idrs_uniform{0};   // bit 1: P = U(0,1) vectors from mfem_rand, streamed (the default until round 5)
+static std::atomic<int> g_idrs_unfused{0};   // bit 2: ki_update and ki_combine as separate kernels (round 5's sequence)
+extern "C" int mfem_debug_set_idrs(int bits) try {
   ++mfem_debug_epoch;
-  g_idrs_literal = literal_orthogonalisation ? 1 : 0;
+  g_idrs_literal = (bits & 1) ? 1 : 0;
+  g_idrs_uniform = (bits & 2) ? 1 : 0;
+  g_idrs_unfused = (bits & 4) ? 1 : 0;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_idrs")
 
 // merged bi-orthogonalisation, scalar part: d = P' g (I_D) -> alpha[0..k) (I_AL), column k of M from row k on, beta = f_k / M_kk   (:62-73)
-__global__ void ki_ortho(FoldArg fa, int dst, int m, int k, int s, int last, double* __restrict__ S, const int32_t* __restrict__ F) {
+// f_update != 0 (fused update + combine, round 6): f[k+1:] -= beta M[k+1:, k] happens HERE -- the next step's c is formed by the kernel that applies this
+// step's alphas, before ki_step_end runs (which then leaves f alone).  If the stop test of this step ends the solve, f is not used again.
+__global__ void ki_ortho(FoldArg fa, int dst, int m, int k, int s, int last, int f_update, double* __restrict__ S, const int32_t* __restrict__ F) {
   if (F[F_DONE]) return;
   kk_fold_dev(fa, S);
   if (threadIdx.x != 0) return;
@@ -178,7 +184,10 @@ __global__ void ki_ortho(FoldArg fa, int dst, int m, int k, int s, int last, dou
     for (int t = 0; t < k; ++t) v -= S[I_AL + t] * S[I_M + i + IS_MAXS * t];
     S[I_M + i + IS_MAXS * k] = v;
   }
-  S[I_BETA] = S[I_F + k] / S[I_M + k + IS_MAXS * k];
+  const double beta = S[I_F + k] / S[I_M + k + IS_MAXS * k];
+  S[I_BETA] = beta;
+  if (f_update)
+    for (int i = k + 1; i < s; ++i) S[I_F + i] -= beta * S[I_M + i + IS_MAXS * k];
 }
 // ... vector part: g -= sum alpha_t g_t ; u -= sum alpha_t u_t ; x += beta u ; r -= beta g ; partial sums of r'r over the owned entries
 template <int M>  // (M = L.m for 0 .. 8 -- all loads of an index up front, see ki_combine --, -1: the run-time form)
@@ -230,6 +239,103 @@ __global__ __launch_bounds__(MFEM_BLOCK) void ki_update(int64_t n2, int64_t n_ow
   if (threadIdx.x == 0) partials[blockIdx.x] = b;
 }
 
+// ki_update(k) and ki_combine(k + 1) in ONE pass (round 6): r' = r - beta g is used where it is formed, U_(k+1) leaves with it -- one stream (r) and one
+// launch less per inner step.  L lists the T = s - 1 other vector pairs: first the K = k new ones (alphas), then the s - k - 1 old ones of step k + 1's
+// combination (c = LowerTriangular(M[k+1:s, k+1:s]) \ f[k+1:s], f already updated by ki_ortho).  T is a template constant for s <= 8 (every load of an
+// index issued up front, on every path), -1 = the run-time form.  Same products and sums in the same order as the two kernels: bitwise the same vectors.
+template <int T>
+__global__ __launch_bounds__(MFEM_BLOCK) void ki_update_combine(int64_t n2, int64_t n_owned, CombineList L, int K, int kn, d2_t* __restrict__ Gk,
+                                                                 d2_t* __restrict__ Uk, d2_t* __restrict__ x, d2_t* __restrict__ r, d2_t* Un,
+                                                                 const double* __restrict__ S, const int32_t* __restrict__ F, double* __restrict__ partials) {
+  __shared__ double al[IS_MAXS];
+  __shared__ double c[IS_MAXS];
+  __shared__ double Ms[IS_MAXS * IS_MAXS];
+  __shared__ double fs[IS_MAXS];
+  __shared__ double red[4];
+  if (F[F_DONE]) return;
+  const int m = L.m - K;  // terms of the next combination (= s - kn)
+  if (threadIdx.x < K) al[threadIdx.x] = S[I_AL + threadIdx.x];
+  for (int t = threadIdx.x; t < m * m; t += blockDim.x) {
+    const int i = t % m, j = t / m;
+    Ms[i + IS_MAXS * j] = S[I_M + (kn + i) + IS_MAXS * (kn + j)];
+  }
+  if (threadIdx.x < m) fs[threadIdx.x] = S[I_F + kn + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 0; i < m; ++i) {
+      double v = fs[i];
+      for (int j = 0; j < i; ++j) v -= Ms[i + IS_MAXS * j] * c[j];
+      c[i] = v / Ms[i + IS_MAXS * i];
+    }
+  __syncthreads();
+  const double beta = S[I_BETA], omega = S[I_OMEGA];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+    d2_t g = KB_LD(Gk, i), u = KB_LD(Uk, i);
+    d2_t v, q;
+    if constexpr (T >= 0) {
+      d2_t gt[T > 0 ? T : 1], ut[T > 0 ? T : 1];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        gt[t] = KB_LD(L.G[t], i);
+        ut[t] = KB_LD(L.U[t], i);
+      }
+      const d2_t xv = KB_LD(x, i), rv = KB_LD(r, i);
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (t < K) {
+          g -= al[t] * gt[t];
+          u -= al[t] * ut[t];
+        }
+      Gk[i] = g;
+      Uk[i] = u;
+      x[i] = xv + beta * u;
+      const d2_t rn = rv - beta * g;
+      r[i] = rn;
+      if (2 * i < n_owned) acc += rn.x * rn.x;
+      if (2 * i + 1 < n_owned) acc += rn.y * rn.y;
+      if (m > 0) {
+        v = 0.0;  // (0 + c0 g0 = c0 g0: the sums of ki_combine)
+        q = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          if (t >= K) {
+            v += c[t - K] * gt[t];
+            q += c[t - K] * ut[t];
+          }
+        v = rn - v;
+        Un[i] = q + omega * v;
+      }
+    } else {
+      for (int t = 0; t < K; ++t) {
+        g -= al[t] * KB_LD(L.G[t], i);
+        u -= al[t] * KB_LD(L.U[t], i);
+      }
+      const d2_t xv = KB_LD(x, i), rv = KB_LD(r, i);
+      Gk[i] = g;
+      Uk[i] = u;
+      x[i] = xv + beta * u;
+      const d2_t rn = rv - beta * g;
+      r[i] = rn;
+      if (2 * i < n_owned) acc += rn.x * rn.x;
+      if (2 * i + 1 < n_owned) acc += rn.y * rn.y;
+      if (m > 0) {
+        v = c[0] * KB_LD(L.G[K], i);
+        q = c[0] * KB_LD(L.U[K], i);
+        for (int t = 1; t < m; ++t) {
+          v += c[t] * KB_LD(L.G[K + t], i);
+          q += c[t] * KB_LD(L.U[K + t], i);
+        }
+        v = rn - v;
+        Un[i] = q + omega * v;
+      }
+    }
+  }
+  const double b = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = b;
+}
+
 #define RC(x)            \
   do {                   \
     int _rc = (x);       \
@@ -262,11 +368,20 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
 
   RC(mfem_pass_residual(ctx, A, vals, V, r, S + S_RR, spmv_out));  // :27-29
   K1(ki_init, a, S, F);
-  for (int i = 0; i < s; ++i) {  // P = FEM_rand (:35)
-    if (ctx->shadow && ctx->shadow_count >= s)
+  // P (:35: FEM_rand, unseeded in the reference): the caller's shadow vectors if given; otherwise (round 6) the +-1 vectors of the seed's sign words, which are
+  // never stored -- P' g reads g only (kk_sign_dots) -- unless the literal loop wants them as vectors; mfem_debug_set_idrs(2): U(0,1) vectors, streamed
+  const bool user_shadow = ctx->shadow && ctx->shadow_count >= s;
+  const bool signs = !user_shadow && !g_idrs_uniform && !g_idrs_literal;
+  const bool fused = !g_idrs_literal && !g_idrs_unfused;
+  for (int i = 0; i < s; ++i) {
+    if (user_shadow)
       MFEM_CHECK_HIP(hipMemcpyAsync(P[i], ctx->shadow + (int64_t)i * V.n, sizeof(double) * V.n, hipMemcpyDeviceToDevice, ctx->stream));
-    else
+    else if (g_idrs_uniform)
       RC(mfem_rand(ctx, V.n, o->seed, (uint32_t)i, P[i]));
+    else if (!signs) {
+      hipLaunchKernelGGL(kk_sign_vector, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, V.n, o->seed, i, P[i]);
+      MFEM_CHECK_LAUNCH();
+    }
     MFEM_CHECK_HIP(hipMemsetAsync(U[i], 0, sizeof(double) * nv, ctx->stream));
     MFEM_CHECK_HIP(hipMemsetAsync(G[i], 0, sizeof(double) * nv, ctx->stream));
   }
@@ -279,6 +394,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
   key = mfem_hash(key, s); key = mfem_csr_graph_key(key, A); key = mfem_hash(key, vals); key = mfem_hash(key, V.w[0]);
   key = mfem_hash(key, V.x); key = mfem_hash(key, nv); key = mfem_hash(key, tol); key = mfem_hash(key, n_global);
   key = mfem_hash(key, o->maxiter); key = mfem_hash(key, o->fixed_iterations); key = mfem_hash(key, g_idrs_literal);
+  key = mfem_hash(key, (int)signs); key = mfem_hash(key, (int)fused); key = mfem_hash(key, o->seed);
   int dummy_spmv = 0;
   // one IDR cycle = s steps in G_j + the step into G_j+1: s + 1 SpMVs, constant kernel arguments
   auto cycle = [&](int* spmv_cnt) -> int {
@@ -286,12 +402,16 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
     for (int i0 = 0; i0 < s; i0 += KK_MAX_DOTS) {
       DotList L;
       L.m = (s - i0) < KK_MAX_DOTS ? (s - i0) : KK_MAX_DOTS;
-      for (int t = 0; t < L.m; ++t) {
-        L.x[t] = (const d2_t*)P[i0 + t];
-        L.y[t] = (const d2_t*)r;
-      }
       FoldArg fa;
-      RC(k.dots_partials(L, I_DOT, &fa));
+      if (signs) {
+        RC(k.sign_dots_partials(o->seed, i0, L.m, r, I_DOT, &fa));
+      } else {
+        for (int t = 0; t < L.m; ++t) {
+          L.x[t] = (const d2_t*)P[i0 + t];
+          L.y[t] = (const d2_t*)r;
+        }
+        RC(k.dots_partials(L, I_DOT, &fa));
+      }
       K1F(ki_store, fa, I_F + i0, L.m, -1, S, F);
     }
     for (int kk = 0; kk < s; ++kk) {
@@ -301,6 +421,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
         C.G[t] = (const d2_t*)G[kk + t];
         C.U[t] = (const d2_t*)U[kk + t];
       }
+      if (!fused || kk == 0) {  // (fused form: U_kk came out of the previous step's ki_update_combine)
 #define KI_COMBINE(M_) case M_: hipLaunchKernelGGL(ki_combine<M_>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, C, kk, (const d2_t*)r, (d2_t*)U[kk], S, F); break;
       switch (C.m) {
         KI_COMBINE(1) KI_COMBINE(2) KI_COMBINE(3) KI_COMBINE(4) KI_COMBINE(5) KI_COMBINE(6) KI_COMBINE(7) KI_COMBINE(8)
@@ -308,6 +429,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
       }
 #undef KI_COMBINE
       MFEM_CHECK_LAUNCH();
+      }
       RC(k.spmv(A, vals, U[kk], G[kk], spmv_cnt));  // :59
       if (g_idrs_literal) {
         for (int i = 0; i < kk; ++i) {                 // bi-orthogonalise (:62-66)
@@ -336,21 +458,46 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
         for (int i0 = 0; i0 < s; i0 += KK_MAX_DOTS) {
           DotList L;
           L.m = (s - i0) < KK_MAX_DOTS ? (s - i0) : KK_MAX_DOTS;
-          for (int t = 0; t < L.m; ++t) {
-            L.x[t] = (const d2_t*)P[i0 + t];
-            L.y[t] = (const d2_t*)G[kk];
-          }
           FoldArg fa;
-          RC(k.dots_partials(L, I_DOT, &fa));
-          K1F(ki_ortho, fa, I_D + i0, L.m, kk, s, (i0 + KK_MAX_DOTS >= s) ? 1 : 0, S, F);
+          if (signs) {
+            RC(k.sign_dots_partials(o->seed, i0, L.m, G[kk], I_DOT, &fa));
+          } else {
+            for (int t = 0; t < L.m; ++t) {
+              L.x[t] = (const d2_t*)P[i0 + t];
+              L.y[t] = (const d2_t*)G[kk];
+            }
+            RC(k.dots_partials(L, I_DOT, &fa));
+          }
+          K1F(ki_ortho, fa, I_D + i0, L.m, kk, s, (i0 + KK_MAX_DOTS >= s) ? 1 : 0, fused ? 1 : 0, S, F);
         }
+        double* part = ctx->d_partials;
+        if (fused) {
+          // this step's alphas and x / r update + the next step's combination in one pass: the s - 1 other pairs, new ones first
+          CombineList Q;
+          Q.m = s - 1;
+          for (int t = 0; t < kk; ++t) {
+            Q.G[t] = (const d2_t*)G[t];
+            Q.U[t] = (const d2_t*)U[t];
+          }
+          for (int t = kk + 1; t < s; ++t) {
+            Q.G[t - 1] = (const d2_t*)G[t];
+            Q.U[t - 1] = (const d2_t*)U[t];
+          }
+          d2_t* Un = (d2_t*)U[kk + 1 < s ? kk + 1 : kk];  // (not written at the last step: no terms)
+#define KI_UC(T_) case T_: hipLaunchKernelGGL(ki_update_combine<T_>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, V.n, Q, kk, kk + 1, (d2_t*)G[kk], (d2_t*)U[kk], (d2_t*)V.x, (d2_t*)r, Un, S, F, part); break;
+          switch (Q.m) {
+            KI_UC(0) KI_UC(1) KI_UC(2) KI_UC(3) KI_UC(4) KI_UC(5) KI_UC(6) KI_UC(7)
+            default: hipLaunchKernelGGL(ki_update_combine<-1>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, V.n, Q, kk, kk + 1, (d2_t*)G[kk], (d2_t*)U[kk], (d2_t*)V.x, (d2_t*)r, Un, S, F, part); break;
+          }
+#undef KI_UC
+          MFEM_CHECK_LAUNCH();
+        } else {
         CombineList Q;
         Q.m = kk;
         for (int t = 0; t < kk; ++t) {
           Q.G[t] = (const d2_t*)G[t];
           Q.U[t] = (const d2_t*)U[t];
         }
-        double* part = ctx->d_partials;
 #define KI_UPDATE(M_) case M_: hipLaunchKernelGGL(ki_update<M_>, dim3(k.G), dim3(MFEM_BLOCK), 0, ctx->stream, nv / 2, V.n, Q, (d2_t*)G[kk], (d2_t*)U[kk], (d2_t*)V.x, (d2_t*)r, S, F, part); break;
         switch (Q.m) {
           KI_UPDATE(0) KI_UPDATE(1) KI_UPDATE(2) KI_UPDATE(3) KI_UPDATE(4) KI_UPDATE(5) KI_UPDATE(6) KI_UPDATE(7) KI_UPDATE(8)
@@ -358,6 +505,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
         }
 #undef KI_UPDATE
         MFEM_CHECK_LAUNCH();
+        }
         FoldArg fe{part, k.G, 1, I_DOT};
         if (ctx->comm) {  // (fold + all-reduce here, like KK::dots_partials)
           hipLaunchKernelGGL(kk_fold, dim3(1), dim3(MFEM_BLOCK), 0, ctx->stream, part, k.G, 1, I_DOT, S, F);
@@ -365,7 +513,7 @@ int mfem_idrs_pass(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, Krylo
           fe.m = 0;
           RC(mfem_comm_allreduce(ctx, S + I_DOT, 1));
         }
-        K1F(ki_step_end, fe, a, kk, S, F);
+        K1F(ki_step_end, fe, a, kk, S, F, fused ? 1 : 0);
       }
     }
     // r in G_j+1  (:85-93)

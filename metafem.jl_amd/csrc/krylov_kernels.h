@@ -3,6 +3,7 @@
 // even length and 16-byte aligned (see mfem_solve), so every kernel streams d2 (16 B / lane).
 #pragma once
 #include "krylov.h"
+#include "rng.h"
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -139,6 +140,49 @@ static inline void kk_multi_dot_launch(int G, hipStream_t st, int64_t n, const D
 #undef KK_MD
 }
 
+// partials[k*G + blockIdx] = partial of P_(k0+k) . y for k < M, P_k = the +-1 vector of bit k of mfem_sign_word(seed, row) (rng.h): ONE stream (y) for M dot
+// products.  A product with +-1 is a sign flip: y's sign bit is XORed with the complement of the word's bit.
+template <int M>
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_sign_dots(int64_t n, uint64_t seed, int k0, const d2_t* __restrict__ y, double* __restrict__ partials,
+                                                                   const int32_t* __restrict__ flags) {
+  __shared__ double red[4];
+  if (flags[F_DONE]) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n2 = n >> 1;
+  double acc[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) acc[k] = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const d2_t v = KB_LD(y, i);
+    const uint64_t w0 = ~mfem_sign_word(seed, 2 * (uint64_t)i) >> k0, w1 = ~mfem_sign_word(seed, 2 * (uint64_t)i + 1) >> k0;
+    const uint64_t b0 = (uint64_t)__double_as_longlong(v.x), b1 = (uint64_t)__double_as_longlong(v.y);
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+      acc[k] += __longlong_as_double((long long)(b0 ^ (((w0 >> k) & 1ull) << 63))) + __longlong_as_double((long long)(b1 ^ (((w1 >> k) & 1ull) << 63)));
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd n: the last entry shares its 16 bytes with the first ghost / pad entry
+    const uint64_t w0 = ~mfem_sign_word(seed, (uint64_t)(n - 1)) >> k0;
+    const uint64_t b0 = (uint64_t)__double_as_longlong(y[n2].x);
+#pragma unroll
+    for (int k = 0; k < M; ++k) acc[k] += __longlong_as_double((long long)(b0 ^ (((w0 >> k) & 1ull) << 63)));
+  }
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    const double s = block_reduce_sum(acc[k], red);
+    if (threadIdx.x == 0) partials[(int64_t)k * gridDim.x + blockIdx.x] = s;
+  }
+}
+static inline void kk_sign_dots_launch(int G, hipStream_t st, int64_t n, uint64_t seed, int k0, int m, const double* y, double* part, const int32_t* F) {
+#define KK_SD(M_) case M_: hipLaunchKernelGGL((kk_sign_dots<M_>), dim3(G), dim3(MFEM_BLOCK), 0, st, n, seed, k0, (const d2_t*)y, part, F); break;
+  switch (m) { KK_SD(1) KK_SD(2) KK_SD(3) KK_SD(4) KK_SD(5) KK_SD(6) KK_SD(7) default: KK_SD(8) }
+#undef KK_SD
+}
+// x[i] = +-1 by bit k of the sign word: the explicit form of P_k (tests, the literal orthogonalisation loop)
+static __global__ __launch_bounds__(MFEM_BLOCK) void kk_sign_vector(int64_t n, uint64_t seed, int k, double* __restrict__ x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) x[i] = ((mfem_sign_word(seed, (uint64_t)i) >> k) & 1ull) ? 1.0 : -1.0;
+}
+
 // Single workgroup: S[out + k] = sum(partials[k*G .. (k+1)*G)) for k < m
 static __global__ __launch_bounds__(MFEM_BLOCK) void kk_fold(const double* __restrict__ partials, int G, int m, int out,
                                                               double* __restrict__ S, const int32_t* __restrict__ flags) {
@@ -213,6 +257,20 @@ struct KK {
       MFEM_CHECK_LAUNCH();
       fa->m = 0;
       return mfem_comm_allreduce(ctx, S + out, L.m);
+    }
+    return MFEM_OK;
+  }
+  // the m (<= 8) dot products P_(k0 ..)' y with the +-1 shadow vectors of `seed`: y is the only stream
+  int sign_dots_partials(uint64_t seed, int k0, int m, const double* y, int out, FoldArg* fa) const {
+    double* part = ctx->d_partials;
+    kk_sign_dots_launch(G, st, n, seed, k0, m, y, part, F);
+    MFEM_CHECK_LAUNCH();
+    *fa = FoldArg{part, G, m, out};
+    if (ctx->comm) {
+      hipLaunchKernelGGL(kk_fold, dim3(1), dim3(MFEM_BLOCK), 0, st, part, G, m, out, S, F);
+      MFEM_CHECK_LAUNCH();
+      fa->m = 0;
+      return mfem_comm_allreduce(ctx, S + out, m);
     }
     return MFEM_OK;
   }

@@ -142,31 +142,26 @@ __device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, cons
     l8_fetch<F, S + 1, SEND>(R, G, src, active, v + 1, amax);
   }
 }
-// steps [S0, S0 + 2 NP) from v to their places: pair k at doubles ((S0 / 2 + k) * 64 + lane) * 2
-template <int S0, int NP>
+// steps [S0, S0 + N) from v to their places in the unit: step s at position l8_order(F).pos[s] (phase-major, spmv_lat_tables.h), 8 bytes per lane
+template <int F, int S0, int I, int N>
 __device__ __forceinline__ void l8_put(double* __restrict__ ou, const double* v) {
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    m_d2 pr;
-    pr.x = v[2 * k];
-    pr.y = v[2 * k + 1];
-    *(m_d2*)(ou + (int64_t)(S0 / 2 + k) * 128) = pr;
+  if constexpr (I < N) {
+    constexpr L8Order O = l8_order(F);
+    ou[(int64_t)O.pos[S0 + I] * 64] = v[I];
+    l8_put<F, S0, I + 1, N>(ou, v);
   }
 }
 #define L8_SEG (4 * 27)  // entries of the four rows of a staged piece, per field of columns
-// the steps of row field f: [first(f), first(f + 1)), the last field up to the padded end.  Pairs are (even, odd) steps: a field that starts on an
-// odd step takes the previous field's last value along (carry), one that ends on an even step (and is not the last) hands its last value on.
+// the steps of row field f: [first(f), first(f + 1))
 template <int F, int f>
 __device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* stage, double* __restrict__ ou,
-                                              double& carry, double& amax) {
+                                              double& amax) {
   if constexpr (f < F) {
-    constexpr int S0 = l8_first(F, f), S1 = (f == F - 1) ? l8_padded(F) : l8_first(F, f + 1);
-    constexpr int lead = S0 & 1;                 // one value carried in
-    constexpr int cnt = S1 - S0 + lead;          // values in v
-    constexpr int np = cnt / 2;                  // whole pairs
+    constexpr int S0 = l8_first(F, f), S1 = l8_first(F, f + 1);
+    constexpr int lead = 0;
+    constexpr int cnt = S1 - S0;                 // values in v
     constexpr int SEGCAP = F * L8_SEG + 4;       // doubles per staged piece (+ padding: the four pieces start on different banks)
     double v[cnt];
-    if constexpr (lead) v[0] = carry;
     const int lane = threadIdx.x & 63;
     // the piece a lane's row belongs to: rows of the four lanes (la, lb, 0..3); its start = the first lane's row, its end = the end of the last valid row
     const int64_t rowlen = R.valid ? (int64_t)F * R.cnt : 0;
@@ -211,9 +206,9 @@ __device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G,
       __builtin_amdgcn_wave_barrier();
       l8_fetch<F, S0, S1>(R, G, src, (lane >> 4) == la, v + lead, amax);
     }
-    l8_put<S0 - lead, np>(ou, v);
-    if constexpr (cnt & 1) carry = v[cnt - 1];
-    l8_fill_field<F, f + 1>(R, G, vals, stage, ou, carry, amax);
+    l8_put<F, S0, 0, cnt>(ou, v);
+    if constexpr (f == F - 1 && l8_padded(F) > l8_nsteps(F)) ou[(int64_t)l8_nsteps(F) * 64] = 0.0;  // (the padding step)
+    l8_fill_field<F, f + 1>(R, G, vals, stage, ou, amax);
   }
 }
 template <typename RP, int F>
@@ -250,8 +245,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
       for (int f = 0; f < F; ++f) R.rp[f] = (int64_t)rowptr[f * G.N + p] - base;
     }
     R.cnt = ni * R.nj * R.nk;
-    double carry = 0.0;
-    l8_fill_field<F, 0>(R, G, vals, stage, out + u * (int64_t)(l8_padded(F) * 64) + lane * 2, carry, amax);
+    l8_fill_field<F, 0>(R, G, vals, stage, out + u * (int64_t)(l8_padded(F) * 64) + lane, amax);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
@@ -260,50 +254,59 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
 
 #define L8_LDS_ADD(ptr, val) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ptr), (val))
 
-template <int N>
-__device__ __forceinline__ void l8_load(m_d2 (&v)[4], const double* __restrict__ gv) {
+// ---- pass 1, deterministic (round 6; the order tables: spmv_lat_tables.h).  The two units of a wave are ONE stream of 2 x nsteps steps, phase-major (a
+// phase = the (dj, dk) of the steps' offset; inside a phase unit 0's steps, then unit 1's), worked through in chunks of 8 steps from two register buffers
+// that swap roles: the values of chunk k + 1 are in flight while chunk k goes through LDS, barriers or not.  Between two phases the workgroup meets at an
+// LDS-only barrier (mfem_lds_barrier: the loads in flight stay in flight).  Inside a phase a cell receives mirrored products from ONE wave -- the one that
+// owns the node column (j - dj, k - dk) --, in that wave's program order, so every LDS sum, and with it y, has ONE order: bitwise the same from run to run.
+// Until round 5 the waves added concurrently (ds_add_f64 across waves: ~1e-16 relative, not bitwise -- and IDR(8) / BiCGStab(2) iteration counts on C3
+// swung by 30 % from that round-off alone).
+template <int F, int V0, int N>
+__device__ __forceinline__ void l8_load(double (&v)[8], const double* const (&ub)[2]) {
+  constexpr L8Stream T = l8_stream(F);
 #pragma unroll
-  for (int u = 0; u < N / 2; ++u) v[u] = __builtin_nontemporal_load((const m_d2*)gv + u * 64);
+  for (int i = 0; i < N; ++i) v[i] = __builtin_nontemporal_load(ub[T.unit[V0 + i]] + (int64_t)T.pos[V0 + i] * 64);
 }
 
-// steps [S0 + I, S0 + N) of a unit from the register buffer v; x0..x2 = the lane's own x (F fields), a0..a2 = its row sums.  Everything about
-// a step is a compile-time constant (template recursion, not a loop: the row sums must stay in registers).
-template <int F, int S0, int I, int N>
-__device__ __forceinline__ void l8_proc(const m_d2 (&v)[4], int pos, double x0, double x1, double x2, double& a0, double& a1, double& a2,
+// steps [V0 + I, V0 + N) of the stream from the register buffer v; xo[h][f] = the lane's own x of unit h, acc[h][f] = its row sums.  Everything about a
+// step is a compile-time constant (template recursion, not a loop: the row sums must stay in registers).
+template <int F, int V0, int I, int N>
+__device__ __forceinline__ void l8_proc(const double (&v)[8], const int (&pos)[2], const bool (&act)[2], const double (&xo)[2][3], double (&acc)[2][3],
                                         const double* xs, double* ys) {
   if constexpr (I < N) {
-    constexpr int s = S0 + I;
-    if constexpr (s < l8_nsteps(F)) {
-      constexpr int f = l8_row_field(F, s), g = l8_g(F, s), e = l8_e(F, s);
-      constexpr int coff = g * L8_FC + l8_off(e);
-      const double a = (I & 1) ? v[I >> 1].y : v[I >> 1].x;
-      const double xr = f == 0 ? x0 : f == 1 ? x1 : x2;
-      double& acc = f == 0 ? a0 : f == 1 ? a1 : a2;
-      acc += a * xs[pos + coff];
-      if constexpr (!(e == 0 && g == f)) L8_LDS_ADD(ys + pos + coff, a * xr);  // (the diagonal entry has no mirror)
-      if constexpr (s == l8_first(F, f + 1) - 1) L8_LDS_ADD(ys + pos + f * L8_FC, acc);  // the field's last step: its row sum is complete
+    constexpr L8Stream T = l8_stream(F);
+    constexpr L8Order O = l8_order(F);
+    constexpr int vv = V0 + I, h = T.unit[vv], s = O.step[T.pos[vv]];
+    constexpr int f = l8_row_field(F, s), g = l8_g(F, s), e = l8_e(F, s);
+    constexpr int coff = g * L8_FC + l8_off(e);
+    if constexpr (vv > 0 && T.phase[vv] != T.phase[vv > 0 ? vv - 1 : 0]) mfem_lds_barrier();  // every wave of the workgroup passes here, whatever it owns
+    if (act[h]) {  // (wave-uniform)
+      const double a = v[I];
+      acc[h][f] += a * xs[pos[h] + coff];
+      if constexpr (!(e == 0 && g == f)) L8_LDS_ADD(ys + pos[h] + coff, a * xo[h][f]);  // (the diagonal entry has no mirror)
     }
-    l8_proc<F, S0, I + 1, N>(v, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+    l8_proc<F, V0, I + 1, N>(v, pos, act, xo, acc, xs, ys);
   }
 }
 
-// chunk C (8 steps; the last one what is left) from one buffer while chunk C + 1 -- or the first chunk of the next unit -- is loaded into the other
+// chunk C (8 steps; the last one what is left) from one buffer while chunk C + 1 is loaded into the other
 template <int F, int C>
-__device__ __forceinline__ void l8_run(m_d2 (&A)[4], m_d2 (&B)[4], const double* __restrict__ uv, const double* __restrict__ uv_next, int pos,
-                                       double x0, double x1, double x2, double& a0, double& a1, double& a2, const double* xs, double* ys) {
-  constexpr int NCH = (l8_padded(F) + 7) / 8, LAST = NCH - 1;
-  constexpr int nthis = (C == LAST) ? l8_padded(F) - 8 * LAST : 8;
+__device__ __forceinline__ void l8_run(double (&A)[8], double (&B)[8], const double* const (&ub)[2], const int (&pos)[2], const bool (&act)[2],
+                                       const double (&xo)[2][3], double (&acc)[2][3], const double* xs, double* ys) {
+  constexpr int NV = 2 * l8_nsteps(F), NCH = (NV + 7) / 8, LAST = NCH - 1;
+  constexpr int nthis = (C == LAST) ? NV - 8 * LAST : 8;
   if constexpr (C < LAST) {
-    constexpr int nnext = (C + 1 == LAST) ? l8_padded(F) - 8 * LAST : 8;
-    l8_load<nnext>((C & 1) ? A : B, uv + (C + 1) * 512);
-  } else {
-    if (uv_next) l8_load<(NCH == 1 ? l8_padded(F) : 8)>((C & 1) ? A : B, uv_next);
+    constexpr int nnext = (C + 1 == LAST) ? NV - 8 * LAST : 8;
+    l8_load<F, (C + 1) * 8, nnext>((C & 1) ? A : B, ub);
   }
-  __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting the LDS reads of later chunks: 128 VGPRs and spills without)
-  l8_proc<F, C * 8, 0, nthis>((C & 1) ? B : A, pos, x0, x1, x2, a0, a1, a2, xs, ys);
-  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));  // the row sums are due HERE (the compiler otherwise sinks the whole chain of multiply-adds to the
-  __builtin_amdgcn_sched_barrier(0);                 // flush at the end of the field and keeps every value and x it needs alive until then: spills)
-  if constexpr (C < LAST) l8_run<F, C + 1>(A, B, uv, uv_next, pos, x0, x1, x2, a0, a1, a2, xs, ys);
+  __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting the LDS reads of later chunks: spills without)
+  l8_proc<F, C * 8, 0, nthis>((C & 1) ? B : A, pos, act, xo, acc, xs, ys);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int f = 0; f < F; ++f) asm volatile("" : "+v"(acc[h][f]));  // the row sums are due HERE (the compiler otherwise sinks the whole chain of
+  __builtin_amdgcn_sched_barrier(0);                                   // multiply-adds to the end and keeps every value and x it needs alive until then)
+  if constexpr (C < LAST) l8_run<F, C + 1>(A, B, ub, pos, act, xo, acc, xs, ys);
 }
 
 // pass 1: one workgroup per tile; dump[tile][field][cell]
@@ -311,26 +314,27 @@ template <int F>
 __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* __restrict__ vals, const double* __restrict__ x,
                                                       const double* __restrict__ dsc, double* __restrict__ dump,
                                                       const int32_t* __restrict__ done_flag, int tile0, int tcount) {
-  constexpr int UNIT_D = l8_padded(F) * 64, NCH = (l8_padded(F) + 7) / 8;
+  constexpr int UNIT_D = l8_padded(F) * 64, NV = 2 * l8_nsteps(F);
   __shared__ double xs[F * L8_FC];
   __shared__ double ys[F * L8_FC];
   if (done_flag && done_flag[0]) return;
   // (this launch covers the tiles [tile0, tile0 + tcount) of the i-major tile list: all of them, or the interior / boundary part of a slab's SpMV)
   const int chunk = (tcount + 7) >> 3;
   const int tsub = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);  // every XCD walks a contiguous eighth of the tiles
-  if ((int)(blockIdx.x >> 3) >= chunk || tsub >= tcount) return;
+  if ((int)(blockIdx.x >> 3) >= chunk || tsub >= tcount) return;           // (the whole workgroup leaves: no barrier is left waiting)
   const int tile = tile0 + tsub;
   const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int la = lane >> 4, lb = (lane >> 2) & 3, lc = lane & 3;
   // the wave's two units: (0, b, c) and (1, b, c) of the tile's 2 x 2 x 4
-  const int ub = wv >> 2, uc = wv & 3;
-  const int ui = ti * 2, uj = tj * 2 + ub, uk = tk * 4 + uc;
-  const bool e0 = uj < G.nuj && uk < G.nuk, e1 = e0 && ui + 1 < G.nui;
-  const double* uv0 = vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * UNIT_D + lane * 2;
-  const int64_t ustride = (int64_t)G.nuj * G.nuk * UNIT_D;
-  m_d2 A[4], B[4];
-  if (e0) l8_load<(NCH == 1 ? l8_padded(F) : 8)>(A, uv0);  // in flight while x is staged
+  const int ub_ = wv >> 2, uc = wv & 3;
+  const int ui = ti * 2, uj = tj * 2 + ub_, uk = tk * 4 + uc;
+  const bool act[2] = {uj < G.nuj && uk < G.nuk, uj < G.nuj && uk < G.nuk && ui + 1 < G.nui};
+  // a unit that does not exist (lattice edge) is read from a place that does -- every load on every path -- and not worked on
+  const double* u0 = act[0] ? vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * UNIT_D + lane : vals + lane;
+  const double* const ub[2] = {u0, act[1] ? u0 + (int64_t)G.nuj * G.nuk * UNIT_D : u0};
+  double A[8], B[8];
+  l8_load<F, 0, (NV < 8 ? NV : 8)>(A, ub);  // in flight while x is staged
   const int i0 = ti * L8_TI, j0 = tj * L8_TJ - 1, k0 = tk * L8_TK - 1;
   for (int e = tid; e < F * L8_FC; e += 512) {
     const int f = e / L8_FC, c = e - f * L8_FC;
@@ -345,30 +349,25 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
     ys[e] = 0.0;
   }
   __syncthreads();
-  if (e0) {
-    const int pos0 = la * L8_PI + (ub * 4 + lb + 1) * L8_SK + (uc * 4 + lc + 1);
-    if constexpr (NCH % 2 == 0) {  // the two register buffers are back in their roles for the next unit
-      const int nu = e1 ? 2 : 1;
-#pragma unroll 1
-      for (int h = 0; h < nu; ++h) {
-        const double* uv = uv0 + h * ustride;
-        const int pos = pos0 + h * 4 * L8_PI;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        l8_run<F, 0>(A, B, uv, h + 1 < nu ? uv + ustride : nullptr, pos, xs[pos], xs[(F > 1 ? L8_FC : 0) + pos], xs[(F > 2 ? 2 * L8_FC : 0) + pos], a0, a1, a2,
-                     xs, ys);
+  {
+    const int p0 = la * L8_PI + (ub_ * 4 + lb + 1) * L8_SK + (uc * 4 + lc + 1);
+    const int pos[2] = {p0, p0 + 4 * L8_PI};
+    double xo[2][3], acc[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        xo[h][f] = f < F ? xs[f * L8_FC + pos[h]] : 0.0;
+        acc[h][f] = 0.0;
       }
-    } else {  // an odd number of chunks: the roles swap
-      {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        l8_run<F, 0>(A, B, uv0, e1 ? uv0 + ustride : nullptr, pos0, xs[pos0], xs[(F > 1 ? L8_FC : 0) + pos0], xs[(F > 2 ? 2 * L8_FC : 0) + pos0], a0, a1,
-                     a2, xs, ys);
+    l8_run<F, 0>(A, B, ub, pos, act, xo, acc, xs, ys);
+    // the row sums: still phase 8 (own cells; the other adds into them in this phase come from this wave)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (act[h]) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) L8_LDS_ADD(ys + pos[h] + f * L8_FC, acc[h][f]);
       }
-      if (e1) {
-        const int pos = pos0 + 4 * L8_PI;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        l8_run<F, 0>(B, A, uv0 + ustride, nullptr, pos, xs[pos], xs[(F > 1 ? L8_FC : 0) + pos], xs[(F > 2 ? 2 * L8_FC : 0) + pos], a0, a1, a2, xs, ys);
-      }
-    }
   }
   __syncthreads();
   double* dt = dump + (int64_t)tile * (F * L8_FC);

@@ -44,6 +44,55 @@ __host__ __device__ constexpr int l8_di(int e) { return (e + 13) / 9 - 1; }
 __host__ __device__ constexpr int l8_dj(int e) { return ((e + 13) / 3) % 3 - 1; }
 __host__ __device__ constexpr int l8_dk(int e) { return (e + 13) % 3 - 1; }
 
+// ---- mode 5, deterministic order (round 6).  The mirrored product of a step goes to the LDS cell of the neighbour at (di, dj, dk); two WAVES of a workgroup
+// add into one cell only across the (j, k) edges of their 4 x 4 columns of nodes.  Steps are therefore stored and run PHASE-MAJOR, a phase = one (dj, dk):
+// within a phase every cell receives products from ONE node column -- one wave -- in that wave's program order; workgroup barriers separate the phases,
+// so the order of the additions into a cell is fixed: y is bitwise reproducible.  Phases 0-7: (dj, dk) != (0, 0) in lexicographic order, phase 8:
+// (0, 0) -- the node's own block entries and the (1, 0, 0) neighbour --, which also takes the row sums.
+#define L8_NPHASE 9
+__host__ __device__ constexpr int l8_phase_of(int e) {
+  const int c = (l8_dj(e) + 1) * 3 + (l8_dk(e) + 1);  // 4 = (0, 0)
+  return c < 4 ? c : c == 4 ? 8 : c - 1;
+}
+struct L8Order {
+  int pos[128];     // position (in steps of 64 lanes x 8 bytes) of original step s inside a unit
+  int step[128];    // ... and back
+  int first[L8_NPHASE + 1];  // first position of a phase
+};
+__host__ __device__ constexpr L8Order l8_order(int F) {
+  L8Order o{};
+  int p = 0;
+  for (int ph = 0; ph < L8_NPHASE; ++ph) {
+    o.first[ph] = p;
+    for (int s = 0; s < l8_nsteps(F); ++s)
+      if (l8_phase_of(l8_e(F, s)) == ph) {
+        o.pos[s] = p;
+        o.step[p] = s;
+        ++p;
+      }
+  }
+  o.first[L8_NPHASE] = p;
+  return o;
+}
+// the two units of a wave as ONE stream of 2 * nsteps steps, phase-major, inside a phase unit 0's steps, then unit 1's: v -> (phase, unit, position)
+struct L8Stream {
+  int phase[256], unit[256], pos[256];
+};
+__host__ __device__ constexpr L8Stream l8_stream(int F) {
+  const L8Order o = l8_order(F);
+  L8Stream t{};
+  int v = 0;
+  for (int ph = 0; ph < L8_NPHASE; ++ph)
+    for (int h = 0; h < 2; ++h)
+      for (int p = o.first[ph]; p < o.first[ph + 1]; ++p) {
+        t.phase[v] = ph;
+        t.unit[v] = h;
+        t.pos[v] = p;
+        ++v;
+      }
+  return t;
+}
+
 // ---- mode 4: the hex-27 lattice, 8 node types t = 4 (i odd) + 2 (j odd) + (k odd), four lanes per row, slot s = 4 it + q of lane q at step it.
 // Slot 0 is the diagonal, then the offsets with (di, dj, dk) > 0 in lexicographic order; reach 2 in an even direction, 1 in an odd one.
 #define L27_TAB 272  // table entries: 4 x (16 + 3 x 10 + 3 x 6 + 4)

@@ -81,6 +81,27 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_sell_keys(int64_t n, const RP* _
   }
 }
 
+// Do the diagonal-list signatures repeat?  On a lattice a row shares its list with its first or second neighbour (hex-8: every interior row; hex-27: the
+// node types alternate with period 2); on an unstructured pattern practically never.  The signature is the LOW word of the sort key: where it does not
+// repeat it must not take part in the sort -- rows of one length would be shuffled by a hash and the x gathers of a 128-row block, local in mesh order,
+// would come from all over the vector (round 6: the hex-20 meshes of every shipped example ran this layout at 0.18 of HBM, 3 x slower than the CSR kernel).
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_sig_repeats(int64_t n, const uint64_t* __restrict__ keys, unsigned long long* __restrict__ count) {
+  __shared__ double red_unused[1];
+  (void)red_unused;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long c = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r + 2 < n; r += stride) {
+    const uint32_t h = (uint32_t)keys[r];
+    c += (h == (uint32_t)keys[r + 1] || h == (uint32_t)keys[r + 2]) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+__global__ __launch_bounds__(MFEM_BLOCK) void k_sell_clear_sig(int64_t n, uint64_t* __restrict__ keys) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += stride) keys[r] &= 0xFFFFFFFF00000000ull;
+}
+
 // flags[b] = 1 and off[ptr[b] / 128 + s] = the common diagonal list when all 128 rows of block b have the list of its first row
 template <typename RP>
 __global__ __launch_bounds__(SELL_B) void k_sell_block_flags(int64_t n, int64_t nblk, const RP* __restrict__ rowptr,
@@ -331,6 +352,21 @@ int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
     hipLaunchKernelGGL(k_sell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, (const int32_t*)A->rowptr, A->colidx,
                        A->index_base, A->max_row_nnz, wshift, lenbits, keys, ids, d_ghost, G);
   SELL_CHECK(hipMemcpyAsync(ctx->h_flags + 9, d_ghost, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  {
+    // signatures that do not repeat (unstructured patterns) stay out of the sort: rows of one length keep their mesh order
+    unsigned long long* d_rep = (unsigned long long*)(void*)sizes;  // (zeroed below before its own use)
+    unsigned long long h_rep = 0;
+    SELL_CHECK(hipMemsetAsync(d_rep, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_sell_sig_repeats, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, keys, d_rep);
+    SELL_CHECK(hipMemcpyAsync(&h_rep, d_rep, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    SELL_CHECK(hipStreamSynchronize(ctx->stream));
+    if ((int64_t)h_rep < n / 8) {
+      hipLaunchKernelGGL(k_sell_clear_sig, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, n, keys);
+      A->sell_sig_sorted = 0;
+    } else {
+      A->sell_sig_sorted = 1;
+    }
+  }
   {
     int bits = 32 + lenbits;  // the low word is the signature of the diagonal list
     if (G.R > 0) {

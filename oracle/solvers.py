@@ -43,6 +43,20 @@ def fem_rand(seed: int, stream: int, n: int) -> np.ndarray:
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
+def fem_sign(seed: int, k: int, n: int) -> np.ndarray:
+    """+-1 doubles: bit k of the sign word of row i (csrc/rng.h::mfem_sign_word, bit for bit).  The shadow vectors P of idrs! are arbitrary random
+    vectors in the reference (04_IDRs.jl:35: FEM_rand, unseeded); the product generates them as signs so that P' g needs no stored P (round 6), and this
+    restatement draws the same ones so that iterates can be compared step by step."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+             + np.uint64(0xD1B54A32D192ED03) * np.uint64(0x5149 + 1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return np.where((z >> np.uint64(k)) & np.uint64(1), 1.0, -1.0)
+
+
 def normalized_norm(x: np.ndarray) -> float:
     """04_Time_Domain.jl:51."""
     return float(np.linalg.norm(x) / math.sqrt(x.size))
@@ -176,8 +190,9 @@ def modify_omega(v1, v2):
     return omega * angle / rho if rho < angle else omega
 
 
-def idrs(x, A, b, r, *, Pl=Identity(), tol, maxiter, s=4, seed=0x5EED, shadow=None, **_):
-    """idrs! (04_IDRs.jl:26-95)."""
+def idrs(x, A, b, r, *, Pl=Identity(), tol, maxiter, s=4, seed=0x5EED, shadow=None, shadow_kind="sign", **_):
+    """idrs! (04_IDRs.jl:26-95).  P (:35, `FEM_rand`, unseeded): `shadow` if given, else seeded +-1 vectors (fem_sign; shadow_kind = "uniform": U[0,1)
+    vectors from fem_rand, the reference's distribution)."""
     mul(r, A, x, -1.0)
     r += b
     Pl(r)
@@ -186,7 +201,7 @@ def idrs(x, A, b, r, *, Pl=Identity(), tol, maxiter, s=4, seed=0x5EED, shadow=No
     it = 1
     n = b.size
     Ar = np.zeros(n)
-    P = [fem_rand(seed, k, n) for k in range(s)] if shadow is None else shadow
+    P = shadow if shadow is not None else [fem_sign(seed, k, n) if shadow_kind == "sign" else fem_rand(seed, k, n) for k in range(s)]
     U = [np.zeros(n) for _ in range(s)]
     G = [np.zeros(n) for _ in range(s)]
     Q, V = np.zeros(n), np.zeros(n)

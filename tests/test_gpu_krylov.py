@@ -672,6 +672,53 @@ def test_idrs_merged_biorthogonalisation_equals_the_literal_loop(mf, s):
     assert abs(out[0][2] - out[1][2]) <= max(4, out[1][2] // 10)
 
 
+@pytest.mark.parametrize("s", [1, 4, 8, 11, 20])
+def test_idrs_sign_shadow_vectors_and_fused_update(mf, s):
+    """Round 6: idrs! (04_IDRs.jl:26-95) no longer streams its shadow vectors.  P (:35, an unseeded rand in the reference) is the +-1 vector family of the
+    seed's sign words; P' g reads g only (kk_sign_dots), and the update of step k runs in one pass with the combination of step k + 1
+    (ki_update_combine).  Checked: (a) the generated signs ARE the oracle's fem_sign vectors -- the same solve with those vectors handed in as explicit
+    shadow vectors (the streamed multi-dot path) gives the same iterates; (b) the fused pass equals the two kernels (mfem_debug_set_idrs(4)) to
+    round-off; (c) U(0,1) vectors (mfem_debug_set_idrs(2), the default until round 5) still converge to the same solution; s = 11 / 20: two / three chunks
+    of dot products and the run-time form of the kernels; odd n."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import solvers
+
+    brick = mf.make_Brick((1.0, 2.0, 1.5), (9, 7, 11))  # 10 * 8 * 12 = 960 rows ... + an odd-length case below
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    b = mf.FEM_rand(A.n, 11, 0) - 0.5
+    seed = 0xC0FFEE
+    P = torch.tensor(np.concatenate([solvers.fem_sign(seed, k, A.n) for k in range(s)]), device="cuda")
+    fixed = dict(Sv_func=mf.idrs_, s=s, maxiter=2 * (s + 1) + 3, max_pass=1, fixed_iterations=True, seed=seed)
+    x_sign, _ = mf.iterative_Solve(A, K, b, 1e-300, **fixed)
+    x_expl, _ = mf.iterative_Solve(A, K, b, 1e-300, shadow=P, **fixed)
+    scale = float(x_expl.abs().max())
+    assert float((x_sign - x_expl).abs().max()) <= 1e-11 * scale  # (a): other summation order of the dot products only
+    conv = dict(Sv_func=mf.idrs_, s=s, maxiter=3000, max_pass=4, seed=seed)
+    x_ref, st_ref = mf.iterative_Solve(A, K, b, 1e-11, **conv)
+    assert st_ref.converged == 1
+    try:
+        _lib.lib.mfem_debug_set_idrs(4)
+        x_unfused, _ = mf.iterative_Solve(A, K, b, 1e-300, **fixed)
+        assert float((x_unfused - x_sign).abs().max()) <= 1e-12 * scale  # (b): the same products and sums (contracted differently by the compiler)
+        _lib.lib.mfem_debug_set_idrs(2)
+        x_uni, st_uni = mf.iterative_Solve(A, K, b, 1e-11, **conv)
+        assert st_uni.converged == 1 and float((x_uni - x_ref).abs().max()) <= 1e-8 * float(x_ref.abs().max())  # (c)
+    finally:
+        _lib.lib.mfem_debug_set_idrs(0)
+    # odd n (the last entry shares its 16 bytes with padding): 7 * 9 * 11 = 693 rows
+    brick = mf.make_Brick((1.0, 1.0, 1.0), (6, 8, 10))
+    A = brick.pattern(1)
+    K = brick.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+    assert A.n % 2 == 1
+    b = mf.FEM_rand(A.n, 12, 0) - 0.5
+    P = torch.tensor(np.concatenate([solvers.fem_sign(seed, k, A.n) for k in range(s)]), device="cuda")
+    x_sign, _ = mf.iterative_Solve(A, K, b, 1e-300, **fixed)
+    x_expl, _ = mf.iterative_Solve(A, K, b, 1e-300, shadow=P, **fixed)
+    assert float((x_sign - x_expl).abs().max()) <= 1e-11 * float(x_expl.abs().max())
+
+
 @pytest.mark.parametrize("l", [1, 2])
 def test_bicgstabl_fused_form_equals_the_literal_sequence(mf, l):
     """bicgstabl_GS! (03_BiCGstabl.jl:41-94): the fused form (dot products produced by the SpMVs, the minimal-residual part on the Gram matrix of

@@ -246,3 +246,42 @@ def test_caller_supplied_csr_takes_the_lattice_tiles(mf, small_layouts):
     assert st.converged and int(_lib.lib.mfem_debug_lat8_spmv_count()) > c0
     x0, _ = mf.iterative_Solve(A0, K, rhs, 1e-11, Sv_func=mf.bicgstabl_GS_, s=2, maxiter=6000, max_pass=4)
     assert float((x1 - x0).abs().max()) <= 1e-8 * float(x0.abs().max())
+
+
+@pytest.mark.parametrize("fields,dims", [(3, (20, 20, 20)), (3, (9, 5, 17)), (1, (33, 31, 29)), (1, (8, 8, 16))])
+def test_tiles_are_bitwise_reproducible(mf, small_layouts, fields, dims):
+    """Round 6: pass 1 of the tiles runs its steps phase-major -- a phase = the (dj, dk) of the steps' offset, barriers between
+    phases -- so every LDS cell receives its mirrored products from ONE wave per phase in program order: y is bitwise the same from run to run (until
+    round 5 the waves of a workgroup added concurrently: ~1e-16 relative).  20 products of the layout are identical bit for bit, and so are two solves
+    (iterates AND iteration counts) with the reference's two solvers, which run on A D^-1 through these tiles."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 0.7, 1.3), dims, 1, 3)
+    A = b.pattern(fields)
+    if fields == 1:
+        K = b.assemble_thermal(A, 0.6, 25.0, 293.15, 0x3F)
+        _lib.lib.mfem_debug_set_lat8(3)  # (one field: the layout query / diagnostic product answer for cg! unless asked)
+    else:
+        K = b.assemble_elasticity(A, LAM, MU, TAU, mf.FACE_BITS["x0"])
+    assert _mode(b, A) == 5
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    ys = []
+    for _ in range(20):
+        y = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+        ys.append(y)
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    assert float((y0 - ys[0]).abs().max()) <= 1e-13 * float(y0.abs().max())
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    for kw in (dict(Sv_func=mf.idrs_, s=8), dict(Sv_func=mf.bicgstabl_GS_, s=2)):
+        runs = []
+        for _ in range(3):
+            c0 = int(_lib.lib.mfem_debug_lat8_spmv_count())
+            xs, st = mf.iterative_Solve(A, K, rhs, 1e-10, maxiter=3000, max_pass=4, **kw)
+            assert st.converged == 1 and int(_lib.lib.mfem_debug_lat8_spmv_count()) > c0
+            runs.append((xs.clone(), st.iterations, st.spmv_count, st.final_res))
+        for r in runs[1:]:
+            assert torch.equal(r[0], runs[0][0]) and r[1:] == runs[0][1:]

@@ -108,6 +108,28 @@ static int check8(int F, int m0, int m1, int m2) {
     if (f < 0 || f >= F || s < l8_first(F, f) || s >= l8_first(F, f + 1) || l8_g(F, s) < 0 || l8_g(F, s) >= F || l8_e(F, s) < 0 || l8_e(F, s) > 13)
       return printf("step %d malformed\n", s), 1;
   }
+  // the phase-major order of round 6 (l8_order / l8_stream): a permutation of the steps, phases = the (dj, dk) of the offset, (0, 0) last; the stream of a
+  // wave's two units visits every (unit, position) once, phase-major, unit 0 before unit 1 inside a phase
+  {
+    const L8Order O = l8_order(F);
+    const L8Stream T = l8_stream(F);
+    std::vector<int> seen(NS, 0);
+    if (O.first[0] != 0 || O.first[L8_NPHASE] != NS) return printf("phase table\n"), 1;
+    for (int ph = 0; ph < L8_NPHASE; ++ph)
+      for (int p = O.first[ph]; p < O.first[ph + 1]; ++p) {
+        const int s = O.step[p], e = l8_e(F, s);
+        if (s < 0 || s >= NS || O.pos[s] != p || seen[s]++) return printf("order is not a permutation\n"), 1;
+        if (l8_phase_of(e) != ph || ((l8_dj(e) == 0 && l8_dk(e) == 0) != (ph == L8_NPHASE - 1))) return printf("step in the wrong phase\n"), 1;
+        if (p > O.first[ph] && l8_dj(l8_e(F, O.step[p - 1])) * 3 + l8_dk(l8_e(F, O.step[p - 1])) != l8_dj(e) * 3 + l8_dk(e)) return printf("phase mixes offsets\n"), 1;
+      }
+    std::vector<int> visits(2 * NS, 0);
+    for (int v = 0; v < 2 * NS; ++v) {
+      if (T.unit[v] < 0 || T.unit[v] > 1 || T.pos[v] < 0 || T.pos[v] >= NS) return printf("stream entry\n"), 1;
+      if (T.pos[v] < O.first[T.phase[v]] || T.pos[v] >= O.first[T.phase[v] + 1]) return printf("stream phase\n"), 1;
+      if (v > 0 && (T.phase[v] < T.phase[v - 1] || (T.phase[v] == T.phase[v - 1] && T.unit[v] < T.unit[v - 1]))) return printf("stream order\n"), 1;
+      if (visits[T.unit[v] * NS + T.pos[v]]++) return printf("stream visits twice\n"), 1;
+    }
+  }
   for (int i = 0; i < m0; ++i)
     for (int j = 0; j < m1; ++j)
       for (int k = 0; k < m2; ++k)

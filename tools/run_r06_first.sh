@@ -2,8 +2,8 @@
 # round 6, first GPU call: the bench tests (line schema), the default line, the u20 legs under rocprofv3 --stats
 R=$(pwd); mkdir -p gpurun_out; cd /tmp; export TMPDIR=/tmp
 cd $R
-timeout -k 10 420 python tools/u20_leg.py 48 1,3 2 40 > gpurun_out/u20_small.log 2>&1 || { echo "u20 small failed"; tail -20 gpurun_out/u20_small.log; exit 1; }
-tail -2 gpurun_out/u20_small.log | cut -c1-600
+true
+true
 timeout -k 10 600 python -m pytest tests/test_gpu_bench.py -x -q -k "single_gpu_line or default_line or two_ranks_on_one" > gpurun_out/bench_tests.log 2>&1 || { echo "bench tests failed"; tail -40 gpurun_out/bench_tests.log; exit 1; }
 tail -3 gpurun_out/bench_tests.log
 cd /tmp
