@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "metafem_mi355x is written for gfx950 (MI355X) only: counted s_waitcnt vmcnt(k) pipelines assume loads and stores share one in-order counter, global_load_lds_dwordx4 and v_mfma_f64 are used directly -- build with --offload-arch=gfx950"
+#endif
 #include "../../include/metafem_mi355x.h"
 #include "../../include/metafem_mi355x_debug.h"
 
@@ -217,6 +220,8 @@ struct mfem_csr_s {
   int32_t* rem_col;    // [rem_nent] 0-based columns
   double* rem_val;     // [rem_nent] A[r][c] - A[c][r]
   unsigned long long* rem_cnt;  // device counters of the build
+  void* rem_sort_tmp;           // owned: radix-sort scratch of the build, grown on demand (a nonsymmetric K rebuilds the remainder at every solve)
+  size_t rem_sort_bytes;
   double rem_asym_before;       // what the probe measured on the tiles alone (the asymmetry the remainder repairs)
   int64_t rem_last_rows, rem_last_ent;  // what the last ACCEPTED remainder of the last probe held (0: none) -- survives the unbind at the end of a solve (tests, bench.py)
 };

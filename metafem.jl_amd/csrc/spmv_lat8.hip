@@ -142,20 +142,25 @@ __device__ __forceinline__ void l8_fetch(const L8Row& R, const Lat8Geom& G, cons
     l8_fetch<F, S + 1, SEND>(R, G, src, active, v + 1, amax);
   }
 }
-// steps [S0, S0 + N) from v to their places in the unit: step s at position l8_order(F).pos[s] (phase-major, spmv_lat_tables.h), 8 bytes per lane
+// steps [S0, S0 + N) from v to their places: the two i-stacked units of a wave of pass 1 are stored as ONE stream of 2 x nsteps steps (l8_stream: phase-major,
+// unit 0 before unit 1 inside a phase) -- the wave reads its 2 x 63 KB front to back --, a pair of stream steps per lane side by side (16-byte loads):
+// step v of lane l at doubles ((v / 2) * 64 + l) * 2 + (v & 1).  ou = the pair's base + 2 * lane, h = which unit of the pair this is.
 template <int F, int S0, int I, int N>
-__device__ __forceinline__ void l8_put(double* __restrict__ ou, const double* v) {
+__device__ __forceinline__ void l8_put(double* __restrict__ ou, int h, const double* v) {
   if constexpr (I < N) {
     constexpr L8Order O = l8_order(F);
-    ou[(int64_t)O.pos[S0 + I] * 64] = v[I];
-    l8_put<F, S0, I + 1, N>(ou, v);
+    constexpr L8Stream T = l8_stream(F);
+    constexpr int v0 = T.at[0][O.pos[S0 + I]], v1 = T.at[1][O.pos[S0 + I]];
+    const int vv = h ? v1 : v0;
+    ou[(int64_t)(vv >> 1) * 128 + (vv & 1)] = v[I];
+    l8_put<F, S0, I + 1, N>(ou, h, v);
   }
 }
 #define L8_SEG (4 * 27)  // entries of the four rows of a staged piece, per field of columns
 // the steps of row field f: [first(f), first(f + 1))
 template <int F, int f>
 __device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G, const double* __restrict__ vals, double* stage, double* __restrict__ ou,
-                                              double& amax) {
+                                              int h, double& amax) {
   if constexpr (f < F) {
     constexpr int S0 = l8_first(F, f), S1 = l8_first(F, f + 1);
     constexpr int lead = 0;
@@ -206,9 +211,8 @@ __device__ __forceinline__ void l8_fill_field(const L8Row& R, const Lat8Geom& G,
       __builtin_amdgcn_wave_barrier();
       l8_fetch<F, S0, S1>(R, G, src, (lane >> 4) == la, v + lead, amax);
     }
-    l8_put<F, S0, 0, cnt>(ou, v);
-    if constexpr (f == F - 1 && l8_padded(F) > l8_nsteps(F)) ou[(int64_t)l8_nsteps(F) * 64] = 0.0;  // (the padding step)
-    l8_fill_field<F, f + 1>(R, G, vals, stage, ou, amax);
+    l8_put<F, S0, 0, cnt>(ou, h, v);
+    l8_fill_field<F, f + 1>(R, G, vals, stage, ou, h, amax);
   }
 }
 template <typename RP, int F>
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
       for (int f = 0; f < F; ++f) R.rp[f] = (int64_t)rowptr[f * G.N + p] - base;
     }
     R.cnt = ni * R.nj * R.nk;
-    l8_fill_field<F, 0>(R, G, vals, stage, out + u * (int64_t)(l8_padded(F) * 64) + lane, amax);
+    const int64_t pair = ((int64_t)(ui >> 1) * G.nuj + uj) * G.nuk + uk;
+    l8_fill_field<F, 0>(R, G, vals, stage, out + pair * (int64_t)(2 * l8_nsteps(F) * 64) + lane * 2, ui & 1, amax);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
@@ -261,17 +266,21 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_l8_fill(Lat8Geom G, const RP* __
 // owns the node column (j - dj, k - dk) --, in that wave's program order, so every LDS sum, and with it y, has ONE order: bitwise the same from run to run.
 // Until round 5 the waves added concurrently (ds_add_f64 across waves: ~1e-16 relative, not bitwise -- and IDR(8) / BiCGStab(2) iteration counts on C3
 // swung by 30 % from that round-off alone).
-template <int F, int V0, int N>
-__device__ __forceinline__ void l8_load(double (&v)[8], const double* const (&ub)[2]) {
-  constexpr L8Stream T = l8_stream(F);
+template <int F, int CH, int V0, int N>
+__device__ __forceinline__ void l8_load(double (&v)[CH], const double* __restrict__ sb) {
+  static_assert(V0 % 2 == 0 && N % 2 == 0 && CH % 2 == 0, "stream steps leave in pairs");
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = __builtin_nontemporal_load(ub[T.unit[V0 + i]] + (int64_t)T.pos[V0 + i] * 64);
+  for (int i = 0; i < N; i += 2) {
+    const m_d2 pr = __builtin_nontemporal_load((const m_d2*)sb + (int64_t)((V0 + i) >> 1) * 64);
+    v[i] = pr.x;
+    v[i + 1] = pr.y;
+  }
 }
 
 // steps [V0 + I, V0 + N) of the stream from the register buffer v; xo[h][f] = the lane's own x of unit h, acc[h][f] = its row sums.  Everything about a
 // step is a compile-time constant (template recursion, not a loop: the row sums must stay in registers).
-template <int F, int V0, int I, int N>
-__device__ __forceinline__ void l8_proc(const double (&v)[8], const int (&pos)[2], const bool (&act)[2], const double (&xo)[2][3], double (&acc)[2][3],
+template <int F, int CH, int V0, int I, int N>
+__device__ __forceinline__ void l8_proc(const double (&v)[CH], const int (&pos)[2], const bool (&act)[2], const double (&xo)[2][3], double (&acc)[2][3],
                                         const double* xs, double* ys) {
   if constexpr (I < N) {
     constexpr L8Stream T = l8_stream(F);
@@ -279,42 +288,44 @@ __device__ __forceinline__ void l8_proc(const double (&v)[8], const int (&pos)[2
     constexpr int vv = V0 + I, h = T.unit[vv], s = O.step[T.pos[vv]];
     constexpr int f = l8_row_field(F, s), g = l8_g(F, s), e = l8_e(F, s);
     constexpr int coff = g * L8_FC + l8_off(e);
+    // (measured, profiles/r06_lat8_deterministic.txt: neither the eight barriers nor the wave-uniform branches cost time -- what did was reading the two
+    //  units as two interleaved far-apart runs of 8-byte loads: +8 % on C3; stored as ONE stream per wave, 16 bytes per lane, the kernel is back at round 5's time)
     if constexpr (vv > 0 && T.phase[vv] != T.phase[vv > 0 ? vv - 1 : 0]) mfem_lds_barrier();  // every wave of the workgroup passes here, whatever it owns
     if (act[h]) {  // (wave-uniform)
       const double a = v[I];
       acc[h][f] += a * xs[pos[h] + coff];
       if constexpr (!(e == 0 && g == f)) L8_LDS_ADD(ys + pos[h] + coff, a * xo[h][f]);  // (the diagonal entry has no mirror)
     }
-    l8_proc<F, V0, I + 1, N>(v, pos, act, xo, acc, xs, ys);
+    l8_proc<F, CH, V0, I + 1, N>(v, pos, act, xo, acc, xs, ys);
   }
 }
 
-// chunk C (8 steps; the last one what is left) from one buffer while chunk C + 1 is loaded into the other
-template <int F, int C>
-__device__ __forceinline__ void l8_run(double (&A)[8], double (&B)[8], const double* const (&ub)[2], const int (&pos)[2], const bool (&act)[2],
+// chunk C (CH steps; the last one what is left) from one buffer while chunk C + 1 is loaded into the other
+template <int F, int CH, int C>
+__device__ __forceinline__ void l8_run(double (&A)[CH], double (&B)[CH], const double* __restrict__ ub, const int (&pos)[2], const bool (&act)[2],
                                        const double (&xo)[2][3], double (&acc)[2][3], const double* xs, double* ys) {
-  constexpr int NV = 2 * l8_nsteps(F), NCH = (NV + 7) / 8, LAST = NCH - 1;
-  constexpr int nthis = (C == LAST) ? NV - 8 * LAST : 8;
+  constexpr int NV = 2 * l8_nsteps(F), NCH = (NV + CH - 1) / CH, LAST = NCH - 1;
+  constexpr int nthis = (C == LAST) ? NV - CH * LAST : CH;
   if constexpr (C < LAST) {
-    constexpr int nnext = (C + 1 == LAST) ? NV - 8 * LAST : 8;
-    l8_load<F, (C + 1) * 8, nnext>((C & 1) ? A : B, ub);
+    constexpr int nnext = (C + 1 == LAST) ? NV - CH * LAST : CH;
+    l8_load<F, CH, (C + 1) * CH, nnext>((C & 1) ? A : B, ub);
   }
   __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting the LDS reads of later chunks: spills without)
-  l8_proc<F, C * 8, 0, nthis>((C & 1) ? B : A, pos, act, xo, acc, xs, ys);
+  l8_proc<F, CH, C * CH, 0, nthis>((C & 1) ? B : A, pos, act, xo, acc, xs, ys);
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int f = 0; f < F; ++f) asm volatile("" : "+v"(acc[h][f]));  // the row sums are due HERE (the compiler otherwise sinks the whole chain of
   __builtin_amdgcn_sched_barrier(0);                                   // multiply-adds to the end and keeps every value and x it needs alive until then)
-  if constexpr (C < LAST) l8_run<F, C + 1>(A, B, ub, pos, act, xo, acc, xs, ys);
+  if constexpr (C < LAST) l8_run<F, CH, C + 1>(A, B, ub, pos, act, xo, acc, xs, ys);
 }
 
 // pass 1: one workgroup per tile; dump[tile][field][cell]
-template <int F>
+template <int F, int CH>
 __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* __restrict__ vals, const double* __restrict__ x,
                                                       const double* __restrict__ dsc, double* __restrict__ dump,
                                                       const int32_t* __restrict__ done_flag, int tile0, int tcount) {
-  constexpr int UNIT_D = l8_padded(F) * 64, NV = 2 * l8_nsteps(F);
+  constexpr int NV = 2 * l8_nsteps(F), PAIR_D = NV * 64;
   __shared__ double xs[F * L8_FC];
   __shared__ double ys[F * L8_FC];
   if (done_flag && done_flag[0]) return;
@@ -330,11 +341,11 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
   const int ub_ = wv >> 2, uc = wv & 3;
   const int ui = ti * 2, uj = tj * 2 + ub_, uk = tk * 4 + uc;
   const bool act[2] = {uj < G.nuj && uk < G.nuk, uj < G.nuj && uk < G.nuk && ui + 1 < G.nui};
-  // a unit that does not exist (lattice edge) is read from a place that does -- every load on every path -- and not worked on
-  const double* u0 = act[0] ? vals + (((int64_t)ui * G.nuj + uj) * G.nuk + uk) * UNIT_D + lane : vals + lane;
-  const double* const ub[2] = {u0, act[1] ? u0 + (int64_t)G.nuj * G.nuk * UNIT_D : u0};
-  double A[8], B[8];
-  l8_load<F, 0, (NV < 8 ? NV : 8)>(A, ub);  // in flight while x is staged
+  // a pair that does not exist (lattice edge) is read from a place that does -- every load on every path -- and not worked on; the second unit of a
+  // pair cut by the lattice has its (unwritten) place in the stream: read, not worked on
+  const double* ub = vals + (act[0] ? (((int64_t)ti * G.nuj + uj) * G.nuk + uk) * PAIR_D : 0) + lane * 2;
+  double A[CH], B[CH];
+  l8_load<F, CH, 0, (NV < CH ? NV : CH)>(A, ub);  // in flight while x is staged
   const int i0 = ti * L8_TI, j0 = tj * L8_TJ - 1, k0 = tk * L8_TK - 1;
   for (int e = tid; e < F * L8_FC; e += 512) {
     const int f = e / L8_FC, c = e - f * L8_FC;
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat8(Lat8Geom G, const double* 
         xo[h][f] = f < F ? xs[f * L8_FC + pos[h]] : 0.0;
         acc[h][f] = 0.0;
       }
-    l8_run<F, 0>(A, B, ub, pos, act, xo, acc, xs, ys);
+    l8_run<F, CH, 0>(A, B, ub, pos, act, xo, acc, xs, ys);
     // the row sums: still phase 8 (own cells; the other adds into them in this phase come from this wave)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -582,7 +593,8 @@ static Lat8Geom lat8_geom(const mfem_csr_s* A) {
   G.ntk = (G.m2 + L8_TK - 1) / L8_TK;
   return G;
 }
-static int lat8_unit_doubles(int F) { return (F == 1 ? l8_padded(1) : F == 2 ? l8_padded(2) : l8_padded(3)) * 64; }
+// doubles of one stored pair of i-stacked units (the stream of a wave of pass 1: 2 x nsteps steps of 64 lanes)
+static int lat8_pair_doubles(int F) { return 2 * (F == 1 ? l8_nsteps(1) : F == 2 ? l8_nsteps(2) : l8_nsteps(3)) * 64; }
 
 // lat8_state: 0 not inspected, -1 not the F-field stencil, 1 structure ok
 int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
@@ -627,7 +639,7 @@ int mfem_lat8_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   return MFEM_OK;
 }
 
-static size_t lat8_vals_doubles(const Lat8Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * lat8_unit_doubles(G.F); }
+static size_t lat8_vals_doubles(const Lat8Geom& G) { return (size_t)((G.nui + 1) / 2) * G.nuj * G.nuk * lat8_pair_doubles(G.F); }
 static size_t lat8_dump_doubles(const Lat8Geom& G) { return (size_t)G.nti * G.ntj * G.ntk * G.F * L8_FC; }
 
 size_t mfem_lat8_bytes(const mfem_csr_s* A) {
@@ -712,9 +724,10 @@ int mfem_spmv_lat8_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   const int tile0 = part == 2 ? tb : 0;
   const int tcount = part == 1 ? tb : ntiles - tile0;
   const int chunk = (tcount + 7) / 8;
-#define L8_PASS1(FF)                                                                                                                              \
-  hipLaunchKernelGGL(k_spmv_lat8<FF>, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag, tile0, \
+#define L8_PASS1_CH(FF, CH_)                                                                                                                         \
+  hipLaunchKernelGGL((k_spmv_lat8<FF, CH_>), dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat8_vals, x, A->lat8_dsc, A->lat8_dump, done_flag, tile0, \
                      tcount)
+#define L8_PASS1(FF) L8_PASS1_CH(FF, 8)  // (12 and 16 steps per buffer were measured: the same time to 0.3 %)
   if (tcount > 0) {
     L8_DISPATCH_F(G.F, L8_PASS1);
     MFEM_CHECK_LAUNCH();

@@ -77,6 +77,7 @@ __host__ __device__ constexpr L8Order l8_order(int F) {
 // the two units of a wave as ONE stream of 2 * nsteps steps, phase-major, inside a phase unit 0's steps, then unit 1's: v -> (phase, unit, position)
 struct L8Stream {
   int phase[256], unit[256], pos[256];
+  int at[2][128];  // ... and back: stream index of (unit, position)
 };
 __host__ __device__ constexpr L8Stream l8_stream(int F) {
   const L8Order o = l8_order(F);
@@ -88,6 +89,7 @@ __host__ __device__ constexpr L8Stream l8_stream(int F) {
         t.phase[v] = ph;
         t.unit[v] = h;
         t.pos[v] = p;
+        t.at[h][p] = v;
         ++v;
       }
   return t;

@@ -163,6 +163,9 @@ void mfem_rem_free(mfem_csr_s* A) {
   if (A->rem_col) hipFree(A->rem_col);
   if (A->rem_val) hipFree(A->rem_val);
   if (A->rem_cnt) hipFree(A->rem_cnt);
+  if (A->rem_sort_tmp) hipFree(A->rem_sort_tmp);
+  A->rem_sort_tmp = nullptr;
+  A->rem_sort_bytes = 0;
   A->rem_rows = nullptr; A->rem_ptr = nullptr; A->rem_len = nullptr; A->rem_col = nullptr; A->rem_val = nullptr; A->rem_cnt = nullptr;
   A->rem_cap_rows = A->rem_cap_ent = 0;
   A->rem_active = 0;
@@ -214,12 +217,15 @@ int mfem_rem_build(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, int n
     size_t tb = 0;
     int32_t* alt = A->rem_len;
     MFEM_CHECK_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (const int32_t*)A->rem_rows, alt, (int)nrows, 0, 32, ctx->stream));
-    void* tmp = nullptr;
-    MFEM_CHECK_HIP(hipMalloc(&tmp, tb ? tb : 16));
-    hipError_t es = hipcub::DeviceRadixSort::SortKeys(tmp, tb, (const int32_t*)A->rem_rows, alt, (int)nrows, 0, 32, ctx->stream);
+    if (tb > A->rem_sort_bytes) {  // kept with the pattern (a hipMalloc / hipFree and a stream synchronisation per solve before)
+      if (A->rem_sort_tmp) (void)hipFree(A->rem_sort_tmp);
+      A->rem_sort_tmp = nullptr;
+      A->rem_sort_bytes = 0;
+      MFEM_CHECK_HIP(hipMalloc(&A->rem_sort_tmp, tb));
+      A->rem_sort_bytes = tb;
+    }
+    hipError_t es = hipcub::DeviceRadixSort::SortKeys(A->rem_sort_tmp, tb, (const int32_t*)A->rem_rows, alt, (int)nrows, 0, 32, ctx->stream);
     if (es == hipSuccess) es = hipMemcpyAsync(A->rem_rows, alt, sizeof(int32_t) * (size_t)nrows, hipMemcpyDeviceToDevice, ctx->stream);
-    if (es == hipSuccess) es = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
     if (es != hipSuccess) {
       mfem_set_error("remainder: sorting the rows -> %s", hipGetErrorString(es));
       return MFEM_ERR_HIP;
