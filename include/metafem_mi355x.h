@@ -173,7 +173,7 @@ typedef struct {
   int32_t max_pass;      /* restart passes, iterative_Solve! default 4 */
   int32_t check_every;   /* host polls the device convergence flag every this many iterations (>=1) */
   double converge_tol;   /* ABSOLUTE on ||r||_2/sqrt(n): globalfield.converge_tol (F10) */
-  uint64_t seed;         /* shadow-vector seed (reference is unseeded, F9) */
+  uint64_t seed;         /* shadow-vector seed (reference is unseeded, F9).  bicgstabl_GS! / cgs2!: mfem_rand(seed, stream) vectors; idrs! (round 6): the +-1 vectors of the seed's sign words (csrc/rng.h; oracle: fem_sign), never stored */
   int32_t fixed_iterations; /* !=0: ignore converge_tol, run exactly maxiter iterations in ONE pass (benchmark mode) */
   int32_t scale_in_place;   /* !=0: Pr_Jacobi! semantics -- `vals` is overwritten by the column-scaled matrix
                                (the reference scales its private gather K_total[K_val_ids], :35,118).
@@ -221,11 +221,13 @@ typedef struct {
  *  - Modes 0-3 (CSR kernel, slot-major / diagonal-slotted copy incl. its mirrored sweep, sliced layout) are BITWISE REPRODUCIBLE run to run: a
  *    fixed summation order, no floating-point atomics.  The mirrored sweep of mode 2 is taken only after a per-solve BITWISE symmetry check of
  *    the values and returns bit for bit what the plain kernel returns.
- *  - Modes 4 and 5 (symmetric lattice tiles; the default for the hex-27 one-field and the hex-8 three-field lattice matrices from 1.8e5 rows
- *    on, one rank or slabs) are NOT bitwise reproducible: mirrored products are added into an LDS block with ds_add_f64, whose order across
- *    the waves of a workgroup is not fixed.  Results repeat to ~1e-16 relative and equal the CSR kernel's to round-off (<= 1e-13 relative,
- *    asserted in tests/test_gpu_lat27.py / test_gpu_lat8.py).  mfem_debug_set_lat27(0) / mfem_debug_set_lat8(0) select the reproducible
- *    modes 3 / 2 instead.
+ *  - Mode 5 (symmetric lattice tiles of the hex-8 lattice matrices, 1-3 fields; the default for idrs! / bicgstabl_GS! / cgs2! from 2.6e5 rows on, one
+ *    rank or slabs) is BITWISE REPRODUCIBLE since round 6: pass 1 runs its steps phase-major with workgroup barriers between the phases, so every LDS
+ *    cell receives its mirrored products from one wave per phase in program order (tests/test_gpu_lat8.py::test_tiles_are_bitwise_reproducible: 20
+ *    products and repeated idrs!(8) / bicgstabl_GS!(2) solves identical bit for bit).  Its y equals the CSR kernel's to round-off (<= 1e-13 relative).
+ *  - Mode 4 (the tiles of the hex-27 one-field lattice matrix, from 1.8e5 rows on) is NOT bitwise reproducible: four lanes share a row and take every
+ *    fourth stored entry, the waves of a workgroup add mirrored products into one LDS block with ds_add_f64 in no fixed order.  Results repeat to
+ *    ~1e-16 relative and equal the CSR kernel's to round-off (tests/test_gpu_lat27.py).  mfem_debug_set_lat27(0) selects the reproducible mode 3.
  *  - SYMMETRY GATE of modes 4 / 5: they store one triangle, so every bind measures whether THESE values are symmetric -- one probe product
  *    (entries of magnitude in [0.75, 1.25), random signs) through the layout against the CSR kernel on the caller's values; the layout is taken
  *    when max over rows r of |difference|_r <= 4e-13 |a_rr| (rows without a stored non-zero diagonal: 4e-13 max|a|).  Consequence: an

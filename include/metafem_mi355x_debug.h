@@ -61,11 +61,17 @@ double mfem_debug_lat8_asymmetry(mfem_csr A);
 int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
- * the plain launch sequence.  on = 0 disables; max_n > 0 changes the size limit. */
+ * the plain launch sequence.  bit 0 of `on`: 0 disables; max_n > 0 changes the size limit.  bit 1 (round 6; also MFEM_GRAPH_COMM=1 in the
+ * environment): cycles are captured WITH an RCCL communicator attached too (ncclAllReduce on the context stream, the halo exchange's fork / join of
+ * the halo stream) -- off by default: RCCL with more than one rank has not executed on this pool; a capture that fails falls back to direct launches. */
 int mfem_debug_set_graphs(int on, int64_t max_n);
+/* cycles captured with a communicator attached so far (process-wide) */
+int mfem_debug_graph_comm_count(void);
 /* idrs!: 1 = the literal bi-orthogonalisation loop of 04_IDRs.jl:62-66 (k dependent dot products and 2 k vector updates per inner step) instead of
- * the merged form (one multi-dot pass, the alphas by forward substitution with M, one vector kernel): the same numbers in exact arithmetic. */
-int mfem_debug_set_idrs(int literal_orthogonalisation);
+ * the merged form (one multi-dot pass, the alphas by forward substitution with M, one vector kernel): the same numbers in exact arithmetic.
+ * Round 6 -- bits: 1 = the literal loop (above); 2 = shadow vectors as U(0,1) vectors from mfem_rand, streamed (the default until round 5; now P is the
+ * +-1 family of the seed's sign words and P' g reads g only); 4 = update of step k and combination of step k + 1 as two kernels (fused by default). */
+int mfem_debug_set_idrs(int bits);
 /* bicgstabl_GS!: 1 = the literal operation sequence of 03_BiCGstabl.jl:41-94 (one pass over the vectors per dot product and per update) instead of the
  * fused form (dot products produced by the SpMVs, the minimal-residual part on the Gram matrix of R[0..l], the updates of a sweep in one kernel). */
 int mfem_debug_set_bicgstabl(int literal_sequence);

@@ -117,6 +117,7 @@ SIGNATURES = {
     "mfem_debug_hex27_mixed_count": (c_int64, []),
     "mfem_debug_hex27_rows_count": (c_int64, []),
     "mfem_debug_mesh_rows_count": (c_int64, []),
+    "mfem_debug_graph_comm_count": (c_int, []),
     "mfem_debug_lat27_cg_fused": (c_int, []),
     "mfem_debug_lat27_pass1_bytes": (c_int64, [P]),
     "mfem_prof_spmv_enable": (c_int, [P, c_int]),

@@ -24,6 +24,7 @@ int mfem_comm_halo_end(mfem_context_s* ctx);
 int mfem_comm_halo_reduce(mfem_context_s* ctx, double* x_local);
 int mfem_comm_world(const mfem_context_s* ctx);
 int mfem_comm_rank(const mfem_context_s* ctx);
+bool mfem_comm_capturable(const mfem_context_s* ctx);
 int64_t mfem_comm_owned_nodes(const mfem_context_s* ctx);
 // SpMV with the halo exchange of x overlapped with the rows that need no ghost entry (spmv.hip)
 int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* x, double* y, double alpha, double beta,

@@ -268,6 +268,9 @@ extern "C" int mfem_context_set_comm(mfem_context ctx, mfem_comm c, int64_t n_ow
 } MFEM_API_CATCH("mfem_context_set_comm")
 
 int mfem_comm_world(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->world : 1; }
+// Can the communication of a Krylov cycle be recorded into a hipGraph?  RCCL calls on the context stream and the fork / join of the halo stream through
+// events are capturable; the host-callback transport synchronises the stream and calls the host, the exposed-communication timers read events: neither is.
+bool mfem_comm_capturable(const mfem_context_s* ctx) { return ctx->comm && ctx->comm->backend == 0 && !ctx->comm->prof_on && !ctx->comm->failed; }
 int mfem_comm_rank(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 int64_t mfem_comm_owned_nodes(const mfem_context_s* ctx) { return ctx->comm ? ctx->comm->n_owned_nodes : 0; }
 

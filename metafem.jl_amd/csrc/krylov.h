@@ -102,6 +102,8 @@ inline uint64_t mfem_csr_graph_key(uint64_t key, const mfem_csr_s* A) {
   return key;
 }
 
+extern std::atomic<int> mfem_graph_comm_broken;
+extern std::atomic<long long> mfem_graph_comm_captures;
 template <class Body>
 inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
   if (!ctx->graph_active) return body();
@@ -120,11 +122,22 @@ inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
   const int rc = body();
   hipGraph_t g = nullptr;
   const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  // With a communicator (MFEM_GRAPH_COMM=1) a cycle holds RCCL calls: if recording them does not work here, nothing has been launched yet -- the cycle
+  // runs as direct launches, now and for the rest of the process.  (Without a communicator a failed capture is an error, as before.)
+  auto comm_fallback = [&](const char* what, hipError_t err) -> int {
+    (void)hipGetLastError();
+    mfem_graph_comm_broken = 1;
+    ctx->graph_active = 0;
+    fprintf(stderr, "metafem_mi355x: %s failed with a communicator attached (%s): cycles run as direct launches from now on\n", what, hipGetErrorString(err));
+    return body();
+  };
   if (rc) {
     if (g) hipGraphDestroy(g);
+    if (ctx->comm && e != hipSuccess) return comm_fallback("capturing a Krylov cycle", e);
     return rc;
   }
   if (e != hipSuccess || !g) {
+    if (ctx->comm) return comm_fallback("hipStreamEndCapture", e);
     mfem_set_error("hipStreamEndCapture: %s", hipGetErrorString(e));
     return MFEM_ERR_HIP;
   }
@@ -132,9 +145,11 @@ inline int mfem_cycle_run(mfem_context_s* ctx, uint64_t key, Body body) {
   const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
   if (ei != hipSuccess) {
+    if (ctx->comm) return comm_fallback("hipGraphInstantiate", ei);
     mfem_set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
     return MFEM_ERR_HIP;
   }
+  if (ctx->comm) ++mfem_graph_comm_captures;
   ctx->graph_exec[slot] = exec;
   ctx->graph_key[slot] = key;
   MFEM_CHECK_HIP(hipGraphLaunch(exec, ctx->stream));

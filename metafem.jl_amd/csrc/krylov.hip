@@ -721,11 +721,30 @@ extern "C" int mfem_debug_set_cg_single_max_rows(int64_t rows) try {
   g_cg_single_max_rows = rows;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_cg_single_max_rows")
+std::atomic<int> mfem_graph_comm_broken{0};    // a capture with RCCL calls failed once: never tried again in this process
+std::atomic<long long> mfem_graph_comm_captures{0};  // cycles captured with a communicator attached (tests)
 static std::atomic<int> g_graphs{1};             // hipGraph replay of solver cycles (mfem_debug_set_graphs)
 static std::atomic<int64_t> g_graph_max_n{4000000};  // above this size kernels are long enough that launch latency is hidden anyway
+// Cycle graphs WITH a communicator (round 6): off unless asked for -- MFEM_GRAPH_COMM=1 in the environment or bit 1 of
+// mfem_debug_set_graphs -- because RCCL with more than one rank has never executed on this pool (no >= 2-GPU box): the un-captured sequence stays the
+// reference, tests/test_gpu_multirank.py (armed, skipif < 2 GPUs) compares the two.  What is captured: ncclAllReduce on the context stream, and the halo
+// exchange's fork (event on the context stream -> halo stream: grouped ncclSend / ncclRecv) and join (event back); a capture that fails falls back to
+// the direct launches for the rest of the process (mfem_cycle_run).
+static std::atomic<int> g_graph_comm{-1};  // -1: ask the environment on first use
+static bool graph_comm_wanted() {
+  int v = g_graph_comm;
+  if (v < 0) {
+    const char* e = getenv("MFEM_GRAPH_COMM");
+    v = (e && e[0] == '1') ? 1 : 0;
+    g_graph_comm = v;
+  }
+  return v == 1;
+}
+extern "C" int mfem_debug_graph_comm_count(void) { return (int)mfem_graph_comm_captures; }
 extern "C" int mfem_debug_set_graphs(int on, int64_t max_n) try {
   ++mfem_debug_epoch;
-  g_graphs = on ? 1 : 0;
+  g_graphs = (on & 1) ? 1 : 0;
+  g_graph_comm = (on & 2) ? 1 : 0;
   if (max_n > 0) g_graph_max_n = max_n;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_graphs")
@@ -748,7 +767,8 @@ extern "C" int mfem_solve(mfem_context ctx, mfem_csr A, double* vals, const doub
   // Cycle graphs: not with a communicator (RCCL calls inside the cycle), not while per-launch SpMV timing is on (event
   // records inside the cycle), not in benchmark mode on large systems.  The legacy null stream cannot be captured: the
   // solve then runs on a private stream, ordered after / before the caller's stream work through events.
-  const bool graphs = g_graphs && !ctx->comm && !ctx->prof_on && A->n > 0 && A->n <= g_graph_max_n;
+  const bool graphs = g_graphs && (!ctx->comm || (graph_comm_wanted() && !mfem_graph_comm_broken && mfem_comm_capturable(ctx))) && !ctx->prof_on && A->n > 0 &&
+                      A->n <= g_graph_max_n;
   if (!graphs) return solve_inner(ctx, A, vals, b, x_out, o, stats);
   hipStream_t user = ctx->stream;
   if (user == nullptr) {

@@ -291,6 +291,19 @@ def main():
                   abs(s1.iterations - sg.iterations) <= max(4, sg.iterations // 10),
                   iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
     if rccl:
+        # hipGraph replay of the Krylov cycles WITH the communicator's calls recorded (round 6: mfem_debug_set_graphs bit 1 / MFEM_GRAPH_COMM=1): the un-captured
+        # sequence above is the reference -- same iterates, same iteration counts
+        _lib.lib.mfem_debug_set_graphs(3, 0)
+        g0 = int(_lib.lib.mfem_debug_graph_comm_count())
+        for sv, name, kw in ((mf.cg_, "cg", dict(cg_variant=1)), (mf.cg_, "cg_single", dict()), (mf.bicgstabl_GS_, "bicgstabl2", dict(s=2)), (mf.idrs_, "idrs8", dict(s=8))):
+            _lib.lib.mfem_debug_set_graphs(1, 0)
+            x0_, s0_ = lsolve(sv, **kw)
+            _lib.lib.mfem_debug_set_graphs(3, 0)
+            x1_, s1_ = lsolve(sv, **kw)
+            check(f"graph_with_rccl_{name}", s1_.converged == 1 and s1_.iterations == s0_.iterations and relerr(x1_, x0_) <= 1e-12,
+                  iters=(s1_.iterations, s0_.iterations), rel_err=relerr(x1_, x0_))
+        check("graph_with_rccl_cycles_were_captured", int(_lib.lib.mfem_debug_graph_comm_count()) > g0, captured=int(_lib.lib.mfem_debug_graph_comm_count()) - g0)
+        _lib.lib.mfem_debug_set_graphs(1, 0)
         hw, hn, aw, an = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
         _lib.check(_lib.lib.mfem_prof_comm_enable(ctx._h, 1))
         lsolve(mf.cg_)

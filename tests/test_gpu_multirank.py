@@ -113,7 +113,7 @@ def test_two_ranks_over_real_rccl_equal_the_single_rank_solve(case):
     reports = run_ranks(case, 2, transport="rccl")
     names = set(reports[0]["checks"])
     for need in ("halo_ghost_planes_bitwise", "cg_classic_overlap", "cg_single_reduction_overlap", "bicgstabl2_diag", "idrs8_diag",
-                 "rccl_exposed_communication_is_timed"):
+                 "rccl_exposed_communication_is_timed", "graph_with_rccl_cg", "graph_with_rccl_idrs8", "graph_with_rccl_cycles_were_captured"):
         assert need in names, need
 
 

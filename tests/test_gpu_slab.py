@@ -125,6 +125,21 @@ def test_rccl_world1_solve_equals_plain_solve(mf, order):
         x, st = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=mf.cg_, maxiter=500, max_pass=2)
         assert st.iterations == st0.iterations
         assert torch.equal(x, ref)
+        # round 6: the Krylov cycles as hipGraphs WITH the communicator's calls recorded (mfem_debug_set_graphs bit 1 / MFEM_GRAPH_COMM=1; one rank: the
+        # all-reduces -- the exchange has no neighbour): the same iterates and iteration counts as the direct launches, and cycles were captured
+        from metafem_jl_amd import _lib
+
+        g0 = int(_lib.lib.mfem_debug_graph_comm_count())
+        try:
+            for sv, kw in ((mf.cg_, dict()), (mf.cg_, dict(cg_variant=1)), (mf.bicgstabl_GS_, dict(s=2)), (mf.idrs_, dict(s=8))):
+                _lib.lib.mfem_debug_set_graphs(1, 0)
+                x0, s0 = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=sv, maxiter=500, max_pass=3, **kw)
+                _lib.lib.mfem_debug_set_graphs(3, 0)
+                x1, s1 = mf.iterative_Solve(A, K, b, 1e-11, Sv_func=sv, maxiter=500, max_pass=3, **kw)
+                assert s1.converged == 1 and s1.iterations == s0.iterations and torch.equal(x0, x1)
+            assert int(_lib.lib.mfem_debug_graph_comm_count()) > g0
+        finally:
+            _lib.lib.mfem_debug_set_graphs(1, 0)
     finally:
         comm.close()
 
