@@ -22,25 +22,32 @@ extern "C" {
 
 /* launches of the symmetric-sweep SpMV kernels (mfem_csr_solver_layout_entries) so far, process-wide */
 int64_t mfem_debug_sym_spmv_count(void);
+/* binds of the patch sweep whose symmetry verdict came from the fingerprint the fill pass sums (round 6) instead of the separate check pass (process-wide) */
+long long mfem_debug_symp_fingerprint_count(void);
+/* THE tuning knobs: one entry point (round 6; until round 5 one function per knob).  Process-wide state read at launch time: set only while no call is
+ * in flight on any context; every call bumps the epoch that is part of the cycle-graph cache key.  No knob changes results beyond round-off.  Keys and
+ * the meaning of (a, b) are documented where the knobs are described below (lines marked `^ key "..."`); an unknown key returns MFEM_ERR_INVALID. */
+int mfem_debug_set(const char* key, int64_t a, int64_t b);
+
 /* CSR kernels behind mul!: tiles per XCD run (0 = dispatcher round-robin) | variant << 16 (0 default, 1 product tile, 3 wave tiles cut by
  * nonzeros -- set before the pattern is created --, 4 workgroup-wide transposing tile, 6 / 7 wave tiles of a fixed row count) | bit 27:
  * without the 2688-entry wave tile (rows of 64..83 entries then share 1792-entry tiles 16 at a time) | bit 26: row-block tiles round-robin
  * over the XCDs instead of a contiguous eighth each | bit 25: no column-offset inspection of the row-block tiles (before the pattern is
  * created), persistent workgroups per CU. */
-int mfem_debug_set_spmv(int xcd_aware, int grid_mult);
+/* ^ key "spmv": mfem_debug_set("spmv", a, b) with (int xcd_aware, int grid_mult) = (a[, b]) */
 /* modes 1/2: bit 0 on/off; bit 1 never use diagonal slots; bits 4-7 / 16-19 kernel variants; bits 8-15 workgroups per CU;
  * bit 20 XCD-contiguous row chunks; bit 22 symmetric sweep kernels off; bit 23 the workgroup-tile sweep (k_spmv_sym27) instead of
  * the wave-private patch sweep (k_spmv_symp);
  * bits 24-25 workgroup size of the diagonal-slotted kernel (0: 256, 1: 512, 2: 1024, 3: 128); bit 26 rows outside the swept planes
  * in a launch of their own; bit 27 the patch-major copy made from the slot-major copy in a second pass. */
-int mfem_debug_set_ell(int enable);
+/* ^ key "ell": mfem_debug_set("ell", a, b) with (int enable) = (a[, b]) */
 /* mode 3: bit 0 on/off; bit 1 always read explicit columns; bit 2 every XCD walks a contiguous eighth of the blocks; bits 4-7 (x 8 = R)
  * rows sorted inside lattice regions of R^3 points when the pattern carries a lattice hint (mfem_brick_pattern) -- both measured slower than
  * the default at hex-27 128^3 (profiles/r03_sell_regions.txt), same results; bits 8-13 sort rows within windows of 2^w rows (0 = whole
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
-int mfem_debug_set_sell(int enable);
+/* ^ key "sell": mfem_debug_set("sell", a, b) with (int enable) = (a[, b]) */
 /* mode 4 (symmetric lattice tiles, hex-27): 0 = off (mode 3 serves those solves), 1 = on (default). */
-int mfem_debug_set_lat27(int enable);  /* bit 1: pass 2 (the gather of the tiles' y blocks) by the kernel that walks the covering blocks one memory round trip at a time (same y bit for bit) */
+/* ^ key "lat27": mfem_debug_set("lat27", a, b) with (int enable) = (a[, b]) */  /* bit 1: pass 2 (the gather of the tiles' y blocks) by the kernel that walks the covering blocks one memory round trip at a time (same y bit for bit) */
 /* bit 2 of mfem_debug_set_lat27: CG iterations on the tiles as SpMV (pass 1 + pass 2) + residual update; by default, on one rank, pass 2 runs INSIDE the residual
  * update (k_lat27_gather_cg: A p is never stored, p . A p comes from pass 1) -- the same iterates to round-off.  mfem_debug_lat27_cg_fused: that switch;
  * mfem_debug_lat27_pass1_bytes: what pass 1 alone moves by design (the SpMV launch bench.py times in that mode). */
@@ -52,34 +59,34 @@ long long mfem_debug_lat27_spmv_count(void);
 double mfem_debug_lat27_asymmetry(mfem_csr A);
 /* mode 5 (symmetric lattice tiles, F-field 27-point matrix): the same three entry points; bit 1 of `enable`: mfem_csr_solver_layout and
  * mfem_spmv_solver_layout report / take mode 5 for ONE field too (they answer for cg!, which keeps mode 2 there) */
-int mfem_debug_set_lat8(int enable);  /* bit 2: pass 2 by the staged gather (all loads of a tile in flight at once, sums in the same order; measured slower on these tiles, off by default) */
+/* ^ key "lat8": mfem_debug_set("lat8", a, b) with (int enable) = (a[, b]) */  /* bit 2: pass 2 by the staged gather (all loads of a tile in flight at once, sums in the same order; measured slower on these tiles, off by default) */
 long long mfem_debug_lat8_spmv_count(void);
 double mfem_debug_lat8_asymmetry(mfem_csr A);
 /* Modes 1-3 are used from these row counts on (defaults 262 144 for mode 2 -- and mode 5 --, 1 000 000 for modes 1 and 3; mode 4 from
  * min(explicit_columns, 180 000) rows: profiles/r03_lat_tiles_thresholds.txt): smaller systems
  * are launch-bound and stay on the CSR tile kernel.  The parity tests set both to 0. */
-int mfem_debug_set_layout_min_rows(int64_t diagonal_slots, int64_t explicit_columns);
+/* ^ key "layout_min_rows": mfem_debug_set("layout_min_rows", a, b) with (int64_t diagonal_slots, int64_t explicit_columns) = (a[, b]) */
 /* hipGraph replay of solver cycles inside mfem_solve (default on for n <= 4 000 000 without a communicator): an IDR(s)
  * cycle, a BiCGStab(l) sweep, a CGS2 step or a CG iteration pair is captured once and replayed; results are identical to
  * the plain launch sequence.  bit 0 of `on`: 0 disables; max_n > 0 changes the size limit.  bit 1 (round 6; also MFEM_GRAPH_COMM=1 in the
  * environment): cycles are captured WITH an RCCL communicator attached too (ncclAllReduce on the context stream, the halo exchange's fork / join of
  * the halo stream) -- off by default: RCCL with more than one rank has not executed on this pool; a capture that fails falls back to direct launches. */
-int mfem_debug_set_graphs(int on, int64_t max_n);
+/* ^ key "graphs": mfem_debug_set("graphs", a, b) with (int on, int64_t max_n) = (a[, b]) */
 /* cycles captured with a communicator attached so far (process-wide) */
 int mfem_debug_graph_comm_count(void);
 /* idrs!: 1 = the literal bi-orthogonalisation loop of 04_IDRs.jl:62-66 (k dependent dot products and 2 k vector updates per inner step) instead of
  * the merged form (one multi-dot pass, the alphas by forward substitution with M, one vector kernel): the same numbers in exact arithmetic.
  * Round 6 -- bits: 1 = the literal loop (above); 2 = shadow vectors as U(0,1) vectors from mfem_rand, streamed (the default until round 5; now P is the
  * +-1 family of the seed's sign words and P' g reads g only); 4 = update of step k and combination of step k + 1 as two kernels (fused by default). */
-int mfem_debug_set_idrs(int bits);
+/* ^ key "idrs": mfem_debug_set("idrs", a, b) with (int bits) = (a[, b]) */
 /* bicgstabl_GS!: 1 = the literal operation sequence of 03_BiCGstabl.jl:41-94 (one pass over the vectors per dot product and per update) instead of the
  * fused form (dot products produced by the SpMVs, the minimal-residual part on the Gram matrix of R[0..l], the updates of a sweep in one kernel). */
-int mfem_debug_set_bicgstabl(int literal_sequence);
+/* ^ key "bicgstabl": mfem_debug_set("bicgstabl", a, b) with (int literal_sequence) = (a[, b]) */
 /* persistent workgroups per CU of the streaming vector kernels (axpy family, fused CG updates, dots); default 3. */
-int mfem_debug_set_vec_grid(int workgroups_per_cu);
+/* ^ key "vec_grid": mfem_debug_set("vec_grid", a, b) with (int workgroups_per_cu) = (a[, b]) */
 /* Multi-rank SpMV: 1 (default) the halo exchange runs on a second stream beside the rows that read no ghost column and the
  * boundary rows follow in a second launch; 0 the exchange completes before a single launch (same results bitwise). */
-int mfem_debug_set_halo_overlap(int on);
+/* ^ key "halo_overlap": mfem_debug_set("halo_overlap", a, b) with (int on) = (a[, b]) */
 /* hex-27 matrix assembly: bits 0-1: 0 / 1 (default) two-pass -- MFMA Ke -> element-major scratch (a ring of element
  * planes) + LDS row-building gather; 2 FP64 atomics in one launch; 3 colour-partitioned read-modify-write scatter straight
  * from the MFMA accumulators (8 launches).  Bits 16-23: element planes per scratch chunk (0 = whole mesh if it fits the
@@ -92,7 +99,7 @@ int mfem_debug_set_halo_overlap(int on);
  * Bit 11 (round 5): the row-owner kernel of GENERAL elements off (k_hex27_rows_gq: rows computed in place from per-element G_q by sum factorisation, no Ke
  * stored anywhere; taken by default from bits 2-7 percent of non-affine elements on -- 0 = the default 30 -- when the mesh has three Gauss points per direction).
  * Bits 12-14: TIMING-ONLY ablations of that kernel (wrong values; tools/hex27_rows_ablate.py). */
-int mfem_debug_set_hex27(int two_pass);
+/* ^ key "hex27": mfem_debug_set("hex27", a, b) with (int two_pass) = (a[, b]) */
 /* number of mfem_mesh_assemble_elements_rows calls that ran the row-owner form (process-wide) */
 int64_t mfem_debug_mesh_rows_count(void);
 /* number of hex-27 matrix assemblies that took the row-owner kernel of general elements (process-wide) */
@@ -106,10 +113,10 @@ int64_t mfem_debug_hex27_direct_count(void);
  * the Jacobian).  Bit 1: residual -- 0 (default) the plane-sweep kernel with one sum-factorised integration per element (2-point Gauss
  * rule); 1 the kernel that integrates an element once per adjacent control point (table form; equal to round-off).  Bits 2-4: TIMING-ONLY
  * ablations of the default matrix kernel (wrong values): no accumulation steps / no write-out / no integration (tools/el_time.py). */
-int mfem_debug_set_elasticity(int variant);
+/* ^ key "elasticity": mfem_debug_set("elasticity", a, b) with (int variant) = (a[, b]) */
 /* hex-8 thermal matrix / residual kernels: 0 (default) the plane-sweep kernels with sum-factorised element integration
  * (2- and 3-point Gauss rules; other rules always use the tile kernels); 1 the 4 x 4 x 8 tile kernels with the table form. */
-int mfem_debug_set_hex8_thermal(int variant);
+/* ^ key "hex8_thermal": mfem_debug_set("hex8_thermal", a, b) with (int variant) = (a[, b]) */
 /* Per-launch timing of the solver's SpMV kernel with hip events on the context stream (bench.py's roofline).
  * read: total device ms and launch count since the last reset. */
 int mfem_prof_spmv_enable(mfem_context ctx, int on);
@@ -131,7 +138,7 @@ int mfem_debug_comm_selftest(mfem_context ctx, int64_t count, int32_t rounds);
 
 /* Placement experiment: the solver workspace's base becomes align_up(hipMalloc's pointer, align) + offset (0, 0: off).  tools/placement_probe.py;
  * mfem_debug_ws_address returns the base in use. */
-int mfem_debug_set_ws_placement(long long align, long long offset);
+/* ^ key "ws_placement": mfem_debug_set("ws_placement", a, b) with (long long align, long long offset) = (a[, b]) */
 unsigned long long mfem_debug_ws_address(mfem_context ctx);
 /* Workspace placement trial, OFF by default (round 4: a drop-in mfem_solve must not hide seconds of allocation work).  1: the first solve on a
  * workspace of 8 GB or more times the solver SpMV, tries up to two more allocations of the workspace the same way (at most two alive: PEAK MEMORY
@@ -139,14 +146,14 @@ unsigned long long mfem_debug_ws_address(mfem_context ctx);
  * iteration at 512^3, profiles/r04_placement_counters.txt).  Paid once per workspace: 5 - 7 s at 512^3 (a hipMalloc of 45 GB takes 2 s, a hipFree
  * about as long; MFEM_WS_TRIAL_VERBOSE=1 prints the steps' times to stderr).  Rank-local: with a communicator attached every rank runs its own
  * trial (the candidates' timing uses no collective).  bench.py opts in with --ws-trial 1 and says so in its line. */
-int mfem_debug_set_ws_trial(int on);
+/* ^ key "ws_trial": mfem_debug_set("ws_trial", a, b) with (int on) = (a[, b]) */
 /* 1 (default): the two vector kernels of the classic CG recurrences use streaming (nontemporal) loads, and from 4e7 rows on streaming stores too
  * (csrc/krylov.hip: cg_ld / cg_st); 0: plain accesses.  Same values either way. */
-int mfem_debug_set_cg_streaming(int on);
+/* ^ key "cg_streaming": mfem_debug_set("cg_streaming", a, b) with (int on) = (a[, b]) */
 /* cg_variant 0 (auto) with a communicator of more than one rank: the single-reduction CG (one all-reduce, 9 vector streams per iteration) below this many
  * rows per rank (n_global / world; default 2e7), the classic recurrence (two all-reduces, 8 streams) from there on -- at 512^3 per rank a vector stream
  * costs 0.2 ms, an all-reduce ~0.03 ms.  Set 0 for always-classic, a huge value for always-single. */
-int mfem_debug_set_cg_single_max_rows(int64_t rows);
+/* ^ key "cg_single_max_rows": mfem_debug_set("cg_single_max_rows", a, b) with (int64_t rows) = (a[, b]) */
 
 /* out4[0..2]: the times (ms for two SpMVs) of the workspace candidates tried by that choice, in order; 0 = not tried. */
 int mfem_debug_ws_trial_log(mfem_context ctx, double* out4);
@@ -160,7 +167,7 @@ int mfem_debug_fail_host_alloc(int nth);
  * every lattice plane through all planes (one-field lattice patterns whose two planes of x exceed `min_bytes`; < 0 keeps the threshold, default 3 MiB) instead of
  * sharing one front with the other XCDs, so that an L2 holds the x window it re-reads.  Measured: 8.34 against 8.23 ms at 512^3, 1.113 against 1.092 at 256^3
  * (profiles/r05_csr_strips.txt) -- the kernel's time does not follow the re-read x (Infinity-Cache hits).  Same tiles, same sums: bitwise the same y. */
-int mfem_debug_set_csr_strips(int on, int64_t min_bytes);
+/* ^ key "csr_strips": mfem_debug_set("csr_strips", a, b) with (int on, int64_t min_bytes) = (a[, b]) */
 
 /* A = S + N (round 5, csrc/spmv_rem.hip): a symmetric lattice-tile bind (modes 4 / 5) whose values fail the symmetry gate in at most n / 8 rows keeps
  * the tiles and carries the mirrored entries' differences N[r][c] = A[r][c] - A[c][r] of those rows as a small CSR applied after the tiles' gather pass
@@ -168,10 +175,10 @@ int mfem_debug_set_csr_strips(int on, int64_t min_bytes);
  * before.  Bit 1 (default 0): the diagnostic product mfem_spmv_solver_layout, which answers for cg!, takes a remainder too (tests).
  * mfem_debug_remainder_info: rows / entries of the remainder the CURRENT or last bind on this pattern carries (0 / 0: none), and the asymmetry the
  * probe measured on the tiles alone; mfem_debug_rem_spmv_count: products that applied one (process-wide). */
-int mfem_debug_set_remainder(int enable);
+/* ^ key "remainder": mfem_debug_set("remainder", a, b) with (int enable) = (a[, b]) */
 /* TEST HOOK: the residual a single-rank tile solve recomputes from the caller's CSR values before it ends the passes is multiplied by `scale`
  * (default 1; <= 0 resets): lets a test put the tiles' residual and the caller's on the two sides of the tolerance */
-int mfem_debug_set_recheck_scale(double scale);
+/* ^ key "recheck_scale_ppm": mfem_debug_set("recheck_scale_ppm", a, b) with (a = scale in millionths) = (a[, b]) */
 int mfem_debug_remainder_info(mfem_csr A, int64_t* rows /* [host] */, int64_t* entries /* [host] */, double* asym_before /* [host] */);
 long long mfem_debug_rem_spmv_count(void);
 

@@ -27,7 +27,27 @@ def _load():
     return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 
 
-lib = _load()
+class _Lib:
+    """The loaded library.  The 21 tuning knobs are ONE C entry point since round 6 -- mfem_debug_set(key, a, b), include/metafem_mi355x_debug.h --;
+    `lib.mfem_debug_set_<key>(a[, b])` stays available here as a spelling of it (tests, tools and bench.py were written against one function per knob)."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        if name.startswith("mfem_debug_set_"):
+            key = name[len("mfem_debug_set_"):]
+            cdll = self._cdll
+
+            def knob(a=0, b=0, _key=key):
+                if _key == "recheck_scale":
+                    return cdll.mfem_debug_set(b"recheck_scale_ppm", int(round(float(a) * 1e6)), 0)
+                return cdll.mfem_debug_set(_key.encode(), int(a), int(b))
+            return knob
+        return getattr(self._cdll, name)
+
+
+lib = _Lib(_load())
 
 c_void_p, c_int, c_int32, c_int64, c_double, c_uint64, c_uint32 = (
     C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_double, C.c_uint64, C.c_uint32)
@@ -111,12 +131,12 @@ SIGNATURES = {
     "mfem_jacobi2_by_column": (c_int, [P, P, P, P]),
     "mfem_jacobi_by_row": (c_int, [P, P, P, P]),
     "mfem_mat_div_jacobi": (c_int, [P, P, P, P]),
-    "mfem_debug_set_spmv": (c_int, [c_int, c_int]),
-    "mfem_debug_set_hex27": (c_int, [c_int]),
     "mfem_debug_hex27_direct_count": (c_int64, []),
     "mfem_debug_hex27_mixed_count": (c_int64, []),
     "mfem_debug_hex27_rows_count": (c_int64, []),
     "mfem_debug_mesh_rows_count": (c_int64, []),
+    "mfem_debug_symp_fingerprint_count": (C.c_longlong, []),
+    "mfem_debug_set": (c_int, [C.c_char_p, c_int64, c_int64]),
     "mfem_debug_graph_comm_count": (c_int, []),
     "mfem_debug_lat27_cg_fused": (c_int, []),
     "mfem_debug_lat27_pass1_bytes": (c_int64, [P]),
@@ -149,21 +169,10 @@ SIGNATURES = {
     "mfem_op_var": (c_int, [P, C.POINTER(OpLayout), P, c_int32, c_int64, P, P, P, P, P, c_int64]),
     "mfem_op_kval": (c_int, [P, C.POINTER(OpLayout), P, c_int32, c_int32, P, P, c_int64, P, P, P, c_int64]),
     "mfem_op_res": (c_int, [P, C.POINTER(OpLayout), P, c_int32, P, c_int64, P, P, P, P, c_int64]),
-    "mfem_debug_set_graphs": (c_int, [c_int, c_int64]),
-    "mfem_debug_set_ell": (c_int, [c_int]),
-    "mfem_debug_set_elasticity": (c_int, [c_int]),
-    "mfem_debug_set_hex8_thermal": (c_int, [c_int]),
-    "mfem_debug_set_sell": (c_int, [c_int]),
-    "mfem_debug_set_idrs": (c_int, [c_int]),
-    "mfem_debug_set_bicgstabl": (c_int, [c_int]),
-    "mfem_debug_set_lat27": (c_int, [c_int]),
     "mfem_debug_lat27_spmv_count": (c_int64, []),
     "mfem_debug_lat27_asymmetry": (C.c_double, [c_void_p]),
-    "mfem_debug_set_lat8": (c_int, [c_int]),
     "mfem_debug_lat8_spmv_count": (c_int64, []),
     "mfem_debug_lat8_asymmetry": (C.c_double, [c_void_p]),
-    "mfem_debug_set_vec_grid": (c_int, [c_int]),
-    "mfem_debug_set_layout_min_rows": (c_int, [c_int64, c_int64]),
     "mfem_spmv_solver_layout": (c_int, [P, P, P, P, P, c_double, c_double]),
     "mfem_csr_solver_layout": (c_int, [P, P, C.POINTER(c_int32), C.POINTER(c_int32), C.POINTER(c_int64), C.POINTER(c_int64)]),
     "mfem_csr_solver_layout_entries": (c_int, [P, P, C.POINTER(c_int64), C.POINTER(c_int32)]),
@@ -188,20 +197,12 @@ SIGNATURES = {
     "mfem_halo_reduce": (c_int, [P, P]),
     "mfem_comm_create_host": (c_int, [P, c_int32, c_int32, C.POINTER(CommHostOps), C.POINTER(P)]),
     "mfem_csr_ncols": (c_int64, [P]),
-    "mfem_debug_set_halo_overlap": (c_int, [c_int]),
     "mfem_csr_replan": (c_int, [P, P]),
     "mfem_csr_spmv_bytes": (c_int, [P, P, C.POINTER(c_int64), C.POINTER(c_int64)]),
     "mfem_debug_comm_selftest": (c_int, [P, c_int64, c_int32]),
-    "mfem_debug_set_ws_placement": (c_int, [C.c_longlong, C.c_longlong]),
     "mfem_debug_ws_address": (C.c_ulonglong, [P]),
-    "mfem_debug_set_ws_trial": (c_int, [c_int]),
-    "mfem_debug_set_cg_streaming": (c_int, [c_int]),
-    "mfem_debug_set_cg_single_max_rows": (c_int, [c_int64]),
     "mfem_debug_fail_host_alloc": (c_int, [c_int]),
     "mfem_debug_ws_trial_log": (c_int, [P, C.POINTER(C.c_double)]),
-    "mfem_debug_set_remainder": (c_int, [c_int]),
-    "mfem_debug_set_recheck_scale": (c_int, [c_double]),
-    "mfem_debug_set_csr_strips": (c_int, [c_int, c_int64]),
     "mfem_debug_remainder_info": (c_int, [P, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "mfem_debug_rem_spmv_count": (C.c_longlong, []),
 }

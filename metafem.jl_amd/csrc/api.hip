@@ -8,6 +8,7 @@
 #include <set>
 
 #include "common.h"
+#include <string>
 
 // contexts that exist: a pattern handle destroyed after its context (host-language finalisers run in any order) must not touch it
 static std::mutex g_ctx_mutex;
@@ -67,10 +68,10 @@ static int context_allocate(mfem_context_s* c) {
   MFEM_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(double) * MFEM_MAX_PARTIALS * 8));
   MFEM_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(double) * MFEM_NSCALARS));
   MFEM_CHECK_HIP(hipHostMalloc(&c->h_scalars, sizeof(double) * MFEM_NSCALARS));
-  MFEM_CHECK_HIP(hipMalloc(&c->d_flags, sizeof(int32_t) * 16));
-  MFEM_CHECK_HIP(hipHostMalloc(&c->h_flags, sizeof(int32_t) * 16));
+  MFEM_CHECK_HIP(hipMalloc(&c->d_flags, sizeof(int32_t) * 24));
+  MFEM_CHECK_HIP(hipHostMalloc(&c->h_flags, sizeof(int32_t) * 24));
   MFEM_CHECK_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * MFEM_NSCALARS, c->stream));
-  MFEM_CHECK_HIP(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 16, c->stream));
+  MFEM_CHECK_HIP(hipMemsetAsync(c->d_flags, 0, sizeof(int32_t) * 24, c->stream));
   MFEM_CHECK_HIP(hipEventCreate(&c->ev0));
   MFEM_CHECK_HIP(hipEventCreate(&c->ev1));
   return MFEM_OK;
@@ -308,3 +309,56 @@ int mfem_ws_reserve(mfem_context_s* ctx, size_t bytes) {
   ctx->ws_bytes = bytes;
   return MFEM_OK;
 }
+
+// ---- the ONE entry point of the tuning knobs (round 6: 22 mfem_debug_set_* prototypes left include/metafem_mi355x_debug.h; the functions stay in the
+// library, undeclared, and are reached through this table -- keys and the meaning of (a, b): the header)
+extern "C" {
+int mfem_debug_set_spmv(int, int);
+int mfem_debug_set_ell(int);
+int mfem_debug_set_sell(int);
+int mfem_debug_set_lat27(int);
+int mfem_debug_set_lat8(int);
+int mfem_debug_set_layout_min_rows(int64_t, int64_t);
+int mfem_debug_set_graphs(int, int64_t);
+int mfem_debug_set_idrs(int);
+int mfem_debug_set_bicgstabl(int);
+int mfem_debug_set_vec_grid(int);
+int mfem_debug_set_halo_overlap(int);
+int mfem_debug_set_hex27(int);
+int mfem_debug_set_elasticity(int);
+int mfem_debug_set_hex8_thermal(int);
+int mfem_debug_set_ws_placement(long long, long long);
+int mfem_debug_set_ws_trial(int);
+int mfem_debug_set_cg_streaming(int);
+int mfem_debug_set_cg_single_max_rows(int64_t);
+int mfem_debug_set_csr_strips(int, int64_t);
+int mfem_debug_set_remainder(int);
+int mfem_debug_set_recheck_scale(double);
+}
+extern "C" int mfem_debug_set(const char* key, int64_t a, int64_t b) try {
+  MFEM_REQUIRE(key, "null key");
+  const std::string k(key);
+  if (k == "spmv") return mfem_debug_set_spmv((int)a, (int)b);
+  if (k == "ell") return mfem_debug_set_ell((int)a);
+  if (k == "sell") return mfem_debug_set_sell((int)a);
+  if (k == "lat27") return mfem_debug_set_lat27((int)a);
+  if (k == "lat8") return mfem_debug_set_lat8((int)a);
+  if (k == "layout_min_rows") return mfem_debug_set_layout_min_rows(a, b);
+  if (k == "graphs") return mfem_debug_set_graphs((int)a, b);
+  if (k == "idrs") return mfem_debug_set_idrs((int)a);
+  if (k == "bicgstabl") return mfem_debug_set_bicgstabl((int)a);
+  if (k == "vec_grid") return mfem_debug_set_vec_grid((int)a);
+  if (k == "halo_overlap") return mfem_debug_set_halo_overlap((int)a);
+  if (k == "hex27") return mfem_debug_set_hex27((int)a);
+  if (k == "elasticity") return mfem_debug_set_elasticity((int)a);
+  if (k == "hex8_thermal") return mfem_debug_set_hex8_thermal((int)a);
+  if (k == "ws_placement") return mfem_debug_set_ws_placement((long long)a, (long long)b);
+  if (k == "ws_trial") return mfem_debug_set_ws_trial((int)a);
+  if (k == "cg_streaming") return mfem_debug_set_cg_streaming((int)a);
+  if (k == "cg_single_max_rows") return mfem_debug_set_cg_single_max_rows(a);
+  if (k == "csr_strips") return mfem_debug_set_csr_strips((int)a, b);
+  if (k == "remainder") return mfem_debug_set_remainder((int)a);
+  if (k == "recheck_scale_ppm") return mfem_debug_set_recheck_scale((double)a * 1e-6);
+  mfem_set_error("mfem_debug_set: unknown key '%s'", key);
+  return MFEM_ERR_INVALID;
+} MFEM_API_CATCH("mfem_debug_set")

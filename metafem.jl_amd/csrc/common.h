@@ -77,7 +77,7 @@ struct mfem_context_s {
   double* d_partials;   // [MFEM_MAX_PARTIALS * 8]
   double* d_scalars;    // [256] device-resident Krylov scalars
   double* h_scalars;    // pinned, [256]
-  int32_t* d_flags;     // [16] device flags: 0-7 the Krylov loop's two banks (done, iteration count, ...); 9 mirrored-sweep check; 10 ring self-test; 11 mesh
+  int32_t* d_flags;     // [24] device flags (16-17: the symmetry fingerprint of k_symp_fill, 64 bits): 0-7 the Krylov loop's two banks (done, iteration count, ...); 9 mirrored-sweep check; 10 ring self-test; 11 mesh
                         // assembly; 12-15 one-shot statistics, each user clears the slots it reads before its launch and synchronises after it (layout binds:
                         // 12-13 max |a| / symmetry measure, krylov.hip: 12-15 extremes of S, assemble_hex27.hip: 14 count of non-affine elements)
   int32_t* h_flags;     // pinned

@@ -424,6 +424,49 @@ def test_symmetric_sweep_is_refused_for_unsymmetric_values(mf):
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
 
 
+def test_fill_fingerprint_gives_the_check_passes_verdict(mf):
+    """Round 6: whether the swept rows of a solve's copy are bitwise symmetric is decided by a fingerprint the fill pass sums while it
+    writes them -- sign(c - r) x hash(pair) x bits(value), 64-bit wrap-around arithmetic: symmetric pairs cancel exactly in any order -- instead of a
+    separate pass over the copy (k_spmv_symp<1>, a quarter of the per-solve work; bit 30 of the "ell" knob restores it).  Same verdicts: symmetric values,
+    one ulp off in an interior pair, one ulp off next to the lattice edge, a NaN."""
+    import torch
+    from metafem_jl_amd import _lib
+
+    brick, A, K = _sym_brick(mf)
+    x = mf.FEM_rand(A.n, 7, 0) - 0.5
+    rp = A.rowptr.cpu().numpy()
+    inf = torch.tensor(float("inf"), dtype=torch.float64, device="cuda")
+    cases = {"symmetric": K}
+    for name, row, slot in (("interior pair", 9 * 4096 + 31 * 64 + 17, 20), ("upper entry", 15 * 4096 + 5 * 64 + 40, 25), ("lower entry", 18 * 4096 + 40 * 64 + 3, 2),
+                            ("next to the edge", 2 * 4096 + 1 * 64 + 1, 14)):
+        K2 = K.clone()
+        k = int(rp[row]) + slot
+        K2[k] = torch.nextafter(K2[k], inf)
+        cases[name] = K2
+    K2 = K.clone()
+    K2[int(rp[17 * 4096 + 17 * 64 + 17]) + 5] = float("nan")
+    cases["nan"] = K2
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        verdicts = {}
+        for bit30 in (0, 1):
+            _lib.lib.mfem_debug_set_ell(1 | (bit30 << 30))
+            f0 = int(_lib.lib.mfem_debug_symp_fingerprint_count())
+            for name, Kc in cases.items():
+                before = _lib.lib.mfem_debug_sym_spmv_count()
+                y = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+                _lib.check(_lib.lib.mfem_spmv_solver_layout(brick.ctx._h, A._h, Kc.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+                verdicts[(bit30, name)] = _lib.lib.mfem_debug_sym_spmv_count() > before
+            assert (int(_lib.lib.mfem_debug_symp_fingerprint_count()) > f0) == (bit30 == 0)
+        for name in cases:
+            assert verdicts[(0, name)] == (name == "symmetric"), (name, verdicts)  # the fingerprint looks at EVERY pair among the swept rows
+            assert verdicts[(1, name)] or not verdicts[(0, name)], (name, verdicts)  # ... the check pass at the pairs the sweep mirrors: never stricter
+        assert verdicts[(1, "symmetric")] and not verdicts[(1, "interior pair")]
+    finally:
+        _lib.lib.mfem_debug_set_ell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
 @pytest.mark.parametrize("n", [(9, 7, 11), (24, 20, 18)])
 def test_cg_carrying_the_preconditioned_residual_matches_the_classic_recurrence(mf, n):
     """cg_variant 3 (the one-rank default) carries z = M^-1 r instead of r -- one vector stream less per iteration; same iterates

@@ -1,0 +1,159 @@
+"""The unstructured serendipity hex-20 legs of bench.py (`u20_thermal_96`, `u20_elasticity_96`): what a user of
+mesh_Classical(...; itp_type = :Serendipity, itp_order = 2) + idrs!(s = 8) gets (examples/thermal_conduction/3D_Script.jl:39,49,
+examples/linear_elasticity/cantilever/3D_Script.jl:75,88).  The mesh is a brick handed over as UNSTRUCTURED connectivity: control points numbered by
+mesh_Classical, element order shuffled in blocks.  Small: K and R against the oracle's term-by-term assembly on the same arrays (oracle/fem.py restates
+05_CodeGenerator.jl:52-154 + 06_FEM_Kernel.jl), idrs!(8) against spsolve.  Full size (96^3, 884 736 elements): size-independent properties --
+symmetry as a bilinear form, K 1 = the boundary integral, rigid-body modes in the null space of the elasticity operator, the solver layout's product
+equal to mul!'s, which kernels ran."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bench
+    import bench_legs as L
+
+    return L.Bench(bench.parse_args([]))
+
+
+def _to_oracle_wf(wf):
+    """The term lists of metafem.jl_amd/physics.py are plain data + arithmetic closures: the oracle's FEMDomain (oracle/fem.py) evaluates them on numpy
+    arrays as they are."""
+    return wf
+
+
+@pytest.mark.parametrize("fields", [1, 3])
+def test_small_mesh_against_the_oracle(mf, B, fields):
+    """4^3 elements in shuffled blocks of 8: K_linear_func (mfem_mesh_assemble_elements_rows + _facets on the pattern of mfem_pattern_build) and
+    K_nonlinear_func (S3 operators) against the oracle's assembly of the SAME mesh arrays and weak forms; one Newton step with idrs!(8) against LU."""
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import generic as G, physics
+    from oracle import fem, mesh as om, reference_element as re_, solvers
+
+    B._umesh_key = None
+    space, msh, fac = B.unstructured_mesh(4, block=8)
+    disc = re_.initialize_classical_element(3, "CUBE", 2, 1, 5, itp_type="Serendipity")
+    # the oracle on the PRODUCT's arrays (its own mesh_Classical may number the edge nodes in another order: irrelevant here)
+    omesh = om.ClassicalMesh(3, np.asarray(msh.coords), np.asarray(msh.cp_ids), np.asarray(msh.vert_conn), msh.n_vertices)
+    ofac = om.boundary_facets(omesh)
+    assert np.array_equal(ofac.element_ID, fac.element_ID) and np.array_equal(ofac.element_eindex, fac.element_eindex)
+    if fields == 1:
+        wf = physics.thermal_domain(3, L.K_COND)
+        bnd = [(fac, physics.thermal_convection(L.H, L.TENV))]
+        obnd = [(ofac, _to_oracle_wf(bnd[0][1]))]
+    else:
+        wf = physics.elasticity_domain(3, L.LAM, L.MU)
+        c, oc = fac.centroid, ofac.centroid
+        bnd = [(fac.select(np.abs(c[:, 0]) < 1e-9), physics.penalty([0, 1, 2], L.TAU)), (fac.select(np.abs(c[:, 1] - 1.0) < 1e-9), physics.traction(3, "sl", rows=[1]))]
+        obnd = [(ofac.select(np.abs(oc[:, 0]) < 1e-9), _to_oracle_wf(bnd[0][1])), (ofac.select(np.abs(oc[:, 1] - 1.0) < 1e-9), _to_oracle_wf(bnd[1][1]))]
+    gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, fields, wf, [(f.element_ID, f.element_eindex, w) for f, w in bnd])
+    od = fem.FEMDomain(omesh, disc, fields, _to_oracle_wf(wf), obnd)
+    ext = {"s": np.full(msh.ncp, L.SRC)} if fields == 1 else {f"sl{v}": np.full(msh.ncp, 1.0 if v == 2 else 0.0) for v in (2, 4, 6)}
+    for k, v in ext.items():
+        gd.controlpoints[k] = torch.tensor(v, device="cuda")
+        od.controlpoints[k] = v
+    gd.K_linear_func()
+    gd.K_nonlinear_func()
+    od.update_time(); od.K_linear_func(); od.update_x_star(); od.K_nonlinear_func()
+    Kg, Ko = gd.K_total.cpu().numpy(), od.K_total
+    assert np.abs(Kg - Ko).max() <= 1e-12 * np.abs(Ko).max()
+    Rg, Ro = gd.residue.cpu().numpy(), od.residue
+    assert np.abs(Rg - Ro).max() <= 1e-11 * np.abs(Ro).max()
+    dx, st = mf.iterative_Solve(gd.A, gd.K_total, gd.residue, 1e-10 * solvers.normalized_norm(Ro), Sv_func=mf.idrs_, Pr_func=mf.Pr_Jacobi_, maxiter=3000, max_pass=10, s=8)
+    ref = solvers.solver_lu_cpu(od.pattern.rowptr, od.pattern.colidx, Ko, Ro)
+    assert st.converged == 1 and np.abs(dx.cpu().numpy() - ref).max() <= 1e-7 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("fields", [1, 3])
+def test_full_size_properties(mf, B, fields):
+    """96^3 hex-20 elements (3.6 M control points; 1.9e9 nonzeros with three fields), unstructured: properties that hold at any size."""
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import _lib, generic as G, physics
+
+    n = 96
+    space, msh, fac = B.unstructured_mesh(n)
+    ncp = msh.ncp
+    if fields == 1:
+        gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, L.K_COND),
+                             [(fac.element_ID, fac.element_eindex, physics.thermal_convection(L.H, L.TENV))])
+    else:  # the operator alone: its null space is the six rigid-body modes
+        gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 3, physics.elasticity_domain(3, L.LAM, L.MU), [])
+    rows0 = int(_lib.lib.mfem_debug_mesh_rows_count())
+    gd.K_linear_func()
+    assert int(_lib.lib.mfem_debug_mesh_rows_count()) > rows0  # the row-owner form ran (scratch within its budget)
+    A, K = gd.A, gd.K_linear
+    N = fields * ncp
+    assert A.n == N
+    f64 = dict(dtype=torch.float64, device="cuda")
+    kmax = float(K.abs().max())
+    y = torch.empty(N, **f64)
+    if fields == 1:
+        # K 1 = -h * (boundary integral of the shape functions): its sum is -h * area, interior rows vanish (the gradients of a constant)
+        mf.mul_(y, A, K, torch.ones(N, **f64))
+        assert abs(float(y.sum()) + L.H * 6.0) <= 1e-9 * L.H * 6.0
+        c = torch.tensor(msh.coords, device="cuda")
+        interior = ((c > 1.5 / n) & (c < 1.0 - 1.5 / n)).all(dim=1)
+        assert float(y[interior].abs().max()) <= 1e-11 * kmax
+        # K x = -k * (Laplace form) - h * (boundary mass): for x = x_1 (linear field, exactly represented) the interior rows vanish too
+        mf.mul_(y, A, K, c[:, 0].contiguous())
+        assert float(y[interior].abs().max()) <= 1e-11 * kmax
+    else:
+        c = torch.tensor(msh.coords, device="cuda")
+        zero = torch.zeros(ncp, **f64)
+        modes = [torch.cat([torch.ones(ncp, **f64) if d == k else zero for d in range(3)]) for k in range(3)]
+        modes += [torch.cat([zero, -c[:, 2], c[:, 1]]), torch.cat([c[:, 2], zero, -c[:, 0]]), torch.cat([-c[:, 1], c[:, 0], zero])]
+        for m in modes:
+            mf.mul_(y, A, K, m.contiguous())
+            assert float(y.abs().max()) <= 1e-10 * kmax
+    # symmetric as a bilinear form: u . K v = v . K u
+    u, v = mf.FEM_rand(N, 1, 0) - 0.5, mf.FEM_rand(N, 2, 0) - 0.5
+    Kv, Ku = torch.empty(N, **f64), torch.empty(N, **f64)
+    mf.mul_(Kv, A, K, v)
+    mf.mul_(Ku, A, K, u)
+    a, b = float(u @ Kv), float(v @ Ku)
+    assert abs(a - b) <= 1e-10 * (float(u.abs() @ Kv.abs()) + 1e-300)
+    # the layout the Krylov loop runs on (mode 3: rows sorted by length IN MESH ORDER -- round 6 --, SELL-128) gives mul!'s product
+    mode = C.c_int32()
+    _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
+    assert mode.value == 3
+    yl = torch.empty(N, **f64)
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), v.data_ptr(), yl.data_ptr(), 1.0, 0.0))
+    assert float((yl - Kv).abs().max()) <= 1e-13 * float(Kv.abs().max())
+    del gd
+    torch.cuda.empty_cache()
+
+
+def test_unstructured_patterns_keep_mesh_order_in_the_sliced_layout(mf, B):
+    """Round 6: the row sort of the sliced layout (csrc/spmv_sell.hip) used the hash of a row's diagonal list as its low key -- on a lattice that groups
+    the rows of one node type, on an unstructured pattern it SHUFFLES the rows of one length, and the x gathers of a 128-row block come from all over the
+    vector (the hex-20 meshes of every shipped example: 0.18 of HBM, 3 x slower than the CSR kernel).  Signatures that do not repeat stay out of the key:
+    the layout's product must then be at least as fast as mul! on the same matrix."""
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import generic as G, physics
+
+    space, msh, fac = B.unstructured_mesh(48)
+    gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, L.K_COND),
+                         [(fac.element_ID, fac.element_eindex, physics.thermal_convection(L.H, L.TENV))])
+    gd.K_linear_func()
+    gd.controlpoints["s"] = torch.full((msh.ncp,), L.SRC, dtype=torch.float64, device="cuda")
+    gd.K_nonlinear_func()
+    read = B.spmv_timer()
+    mf.iterative_Solve(gd.A, gd.K_total, gd.residue, 1e-300, Sv_func=mf.idrs_, Pr_func=mf.Pr_Jacobi_, maxiter=200, max_pass=1, s=8, fixed_iterations=True)
+    layout_ms, n_l = read()
+    csr = B.csr_kernel_roofline(gd.A, gd.K_total, "u20_1_48")
+    assert n_l >= 200 and layout_ms <= 1.15 * csr["avg_launch_ms"], (layout_ms, csr["avg_launch_ms"])
