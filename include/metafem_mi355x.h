@@ -97,7 +97,7 @@ int mfem_mat_div_jacobi(mfem_context ctx, mfem_csr A, double* vals, const double
 
 /* ---- solver layouts (inspector-executor; internal to mfem_solve, the caller's contract stays CSR) ------------------
  * Layout the Krylov loop of mfem_solve uses for this pattern (inspector result, computed on first use):
- *   mode 0  the CSR tile kernel (small systems -- see mfem_debug_set_layout_min_rows -- and matrices with < 128 rows)
+ *   mode 0  the CSR tile kernel (small systems -- see mfem_debug_set("layout_min_rows", ...) -- and matrices with < 128 rows)
  *   mode 1  slot-major padded copy of the working values + explicit columns (rows of near-uniform length)
  *   mode 2  as 1, and 128-row blocks whose entries all sit on a common list of <= 96 diagonals store their values by
  *           diagonal and do not read columns at all (any lattice stencil; up to 4 lists, e.g. one per row field of a
@@ -227,7 +227,7 @@ typedef struct {
  *    products and repeated idrs!(8) / bicgstabl_GS!(2) solves identical bit for bit).  Its y equals the CSR kernel's to round-off (<= 1e-13 relative).
  *  - Mode 4 (the tiles of the hex-27 one-field lattice matrix, from 1.8e5 rows on) is NOT bitwise reproducible: four lanes share a row and take every
  *    fourth stored entry, the waves of a workgroup add mirrored products into one LDS block with ds_add_f64 in no fixed order.  Results repeat to
- *    ~1e-16 relative and equal the CSR kernel's to round-off (tests/test_gpu_lat27.py).  mfem_debug_set_lat27(0) selects the reproducible mode 3.
+ *    ~1e-16 relative and equal the CSR kernel's to round-off (tests/test_gpu_lat27.py).  mfem_debug_set("lat27", 0, 0) selects the reproducible mode 3.
  *  - SYMMETRY GATE of modes 4 / 5: they store one triangle, so every bind measures whether THESE values are symmetric -- one probe product
  *    (entries of magnitude in [0.75, 1.25), random signs) through the layout against the CSR kernel on the caller's values; the layout is taken
  *    when max over rows r of |difference|_r <= 4e-13 |a_rr| (rows without a stored non-zero diagonal: 4e-13 max|a|).  Consequence: an
@@ -243,7 +243,7 @@ typedef struct {
  * 3.9 - 4.05 ms or at 4.3 - 4.5 ms depending on the physical memory behind the workspace (address-translation reach: UTCL2 misses 1.1 - 1.3e5 against 2.0e5
  * per launch with identical requests and bytes, profiles/r04_placement_counters.txt); which kind a hipMalloc returns is outside the library's control (the
  * virtual-memory API with 2 MiB / 1 GiB chunks showed the same spread).  The library does NOT hunt for the fast kind by default -- that costs seconds of
- * allocation work and twice the workspace (mfem_debug_set_ws_trial, opt-in; bench.py opts in and says so) -- so a caller sees either speed, about evenly.
+ * allocation work and twice the workspace (mfem_debug_set("ws_trial", 1, 0), opt-in; bench.py opts in and says so) -- so a caller sees either speed, about evenly.
  * Results are identical.
  * A nonsymmetric K (round 5): the symmetric lattice tiles of modes 4 / 5 keep serving idrs! / bicgstabl_GS! / cgs2! solves whose values fail the symmetry gate in
  * at most n / 8 rows -- the reference's Nitsche / SUPG boundary terms -- by carrying the mirrored entries' differences of those rows as a small CSR applied

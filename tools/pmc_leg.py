@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 2)[0] if "/" in __file__ else "..")
 import metafem_jl_amd as mf
 
 leg = sys.argv[1]
@@ -16,7 +16,32 @@ REF = {"ref_idrs8": ("c2", "idrs8", False), "nitsche_c2": ("c2", "bicgstabl2", T
 cfg, N = leg.rsplit("_", 1)
 N = int(N)
 lam, mu = 0.5769230769230769, 0.38461538461538464
-if cfg in REF:
+if cfg in ("u20_1", "u20_3"):
+    # round 6: the unstructured hex-20 legs of bench.py (u20_thermal_96 / u20_elasticity_96): the same mesh and domain as bench_legs.Bench.unstructured_leg
+    import bench
+    import bench_legs as BL
+    from metafem_jl_amd import generic as G, physics
+    import numpy as np
+
+    F = int(cfg[-1])
+    Bn = BL.Bench(bench.parse_args([]))
+    space, msh, fac = Bn.unstructured_mesh(N)
+    if F == 1:
+        gd = G.GenericDomain(Bn.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, 0.6), [(fac.element_ID, fac.element_eindex, physics.thermal_convection(25.0, 293.15))])
+        gd.controlpoints["s"] = torch.full((msh.ncp,), 1600.0, dtype=torch.float64, device="cuda")
+    else:
+        c = fac.centroid
+        wall, top = fac.select(np.abs(c[:, 0]) < 1e-9), fac.select(np.abs(c[:, 1] - 1.0) < 1e-9)
+        gd = G.GenericDomain(Bn.ctx, space, msh.coords, msh.cp_ids, 3, physics.elasticity_domain(3, lam, mu),
+                             [(wall.element_ID, wall.element_eindex, physics.penalty([0, 1, 2], 1000.0)), (top.element_ID, top.element_eindex, physics.traction(3, "sl", rows=[1]))])
+        for v in (2, 4, 6):
+            gd.controlpoints[f"sl{v}"] = torch.full((msh.ncp,), 1.0 if v == 2 else 0.0, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        gd.K_linear_func()
+        gd.K_nonlinear_func()
+    A, K, R = gd.A, gd.K_total, gd.residue
+    solve = lambda: mf.iterative_Solve(A, K, R, 1e-300, Sv_func=mf.idrs_, Pr_func=mf.Pr_Jacobi_, maxiter=27, max_pass=1, s=8, fixed_iterations=True)
+elif cfg in REF:
     base, solver, nitsche = REF[cfg]
     b = mf.make_Brick((1.0, 1.0, 1.0), (N, N, N), 1 if base == "c2" else 2, 3 if base == "c2" else 5)
     A = b.pattern(1)
