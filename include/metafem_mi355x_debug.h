@@ -45,6 +45,7 @@ int mfem_debug_set(const char* key, int64_t a, int64_t b);
  * rows sorted inside lattice regions of R^3 points when the pattern carries a lattice hint (mfem_brick_pattern) -- both measured slower than
  * the default at hex-27 128^3 (profiles/r03_sell_regions.txt), same results; bits 8-13 sort rows within windows of 2^w rows (0 = whole
  * matrix); bits 16-20 slots in flight per lane (4, 5 = default, 8, 9, 10, 15); bits 24-28 workgroups per CU (default 8). */
+/* (round 6) bit 3 of "sell": field-periodic blocks of a field-major multi-field matrix read their whole column stream again (A/B) */
 /* ^ key "sell": mfem_debug_set("sell", a, b) with (int enable) = (a[, b]) */
 /* mode 4 (symmetric lattice tiles, hex-27): 0 = off (mode 3 serves those solves), 1 = on (default). */
 /* ^ key "lat27": mfem_debug_set("lat27", a, b) with (int enable) = (a[, b]) */  /* bit 1: pass 2 (the gather of the tiles' y blocks) by the kernel that walks the covering blocks one memory round trip at a time (same y bit for bit) */
@@ -102,6 +103,9 @@ int mfem_debug_graph_comm_count(void);
 /* ^ key "hex27": mfem_debug_set("hex27", a, b) with (int two_pass) = (a[, b]) */
 /* number of mfem_mesh_assemble_elements_rows calls that ran the row-owner form (process-wide) */
 int64_t mfem_debug_mesh_rows_count(void);
+/* 128-row blocks of the sliced layout (mode 3) that are field-periodic -- col[f P + t] = col[t] + f shift: one column slot per node is read for the F
+ * column fields -- (-1: null handle; 0: none / not planned) */
+int64_t mfem_debug_sell_periodic_blocks(mfem_csr A);
 /* number of hex-27 matrix assemblies that took the row-owner kernel of general elements (process-wide) */
 int64_t mfem_debug_hex27_rows_count(void);
 /* number of hex-27 matrix assemblies that took the per-element choice with at least one stored (non-affine) element (process-wide) */

@@ -190,6 +190,11 @@ struct mfem_csr_s {
   int32_t* sell_flags;      // owned, [nblk]: 1 = all 128 rows share one diagonal list
   int32_t* sell_off;        // owned, [sell_total / 128]: that list, at ptr[b] / 128
   int32_t sell_regular_blocks;
+  // field-periodic blocks (round 6): a field-major multi-field matrix repeats the node list of a row once per column field, shifted by the rows of a field;
+  // a block whose 128 rows have one length K = F * P and columns col[f * P + t] = col[t] + f * shift reads the first P slots' columns only
+  int32_t sell_fields;          // F (0: none found)
+  int64_t sell_shift;           // column shift between two fields
+  int32_t sell_periodic_blocks;
   int32_t sell_sig_sorted;      // 1: the diagonal-list signature took part in the row sort (lattice patterns); 0: mesh order within a length (unstructured)
   const double* sell_src;
   double* sell_vals;        // not owned (solver workspace), [sell_total]

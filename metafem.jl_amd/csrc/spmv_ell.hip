@@ -2075,7 +2075,10 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
   if (mode == 1) b = ent * 12 + A->n * 16;
   if (mode == 3) {  // sliced layout: padded slots; blocks whose 128 rows share one diagonal list read it instead of their column stream
     const double reg = A->sell_nblk > 0 ? (double)A->sell_regular_blocks / (double)A->sell_nblk : 0.0;
-    b = A->sell_total * 8 + (int64_t)((1.0 - reg) * (double)A->sell_total) * 4 + A->n * 16 + A->n * 4;  // + the row permutation
+    // field-periodic blocks (round 6) read one column slot per node and F values: 1 / F of their column stream
+    const double per = (A->sell_nblk > 0 && A->sell_fields > 1) ? (double)A->sell_periodic_blocks / (double)A->sell_nblk : 0.0;
+    const double colfrac = (1.0 - reg - per) + (A->sell_fields > 1 ? per / (double)A->sell_fields : 0.0);
+    b = A->sell_total * 8 + (int64_t)(colfrac * (double)A->sell_total) * 4 + A->n * 16 + A->n * 4;  // + the row permutation
   }
   if (mode == 4) b = mfem_lat27_design_bytes(A);
   if (mode == 5) b = mfem_lat8_design_bytes(A);

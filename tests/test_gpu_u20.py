@@ -129,6 +129,8 @@ def test_full_size_properties(mf, B, fields):
     mode = C.c_int32()
     _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
     assert mode.value == 3
+    if fields == 3:  # the node list repeats per column field: nearly every block reads a third of its column stream
+        assert int(_lib.lib.mfem_debug_sell_periodic_blocks(A._h)) >= 0.9 * (N // 128)
     yl = torch.empty(N, **f64)
     _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), v.data_ptr(), yl.data_ptr(), 1.0, 0.0))
     assert float((yl - Kv).abs().max()) <= 1e-13 * float(Kv.abs().max())
@@ -157,3 +159,49 @@ def test_unstructured_patterns_keep_mesh_order_in_the_sliced_layout(mf, B):
     layout_ms, n_l = read()
     csr = B.csr_kernel_roofline(gd.A, gd.K_total, "u20_1_48")
     assert n_l >= 200 and layout_ms <= 1.15 * csr["avg_launch_ms"], (layout_ms, csr["avg_launch_ms"])
+
+
+@pytest.mark.parametrize("n,fields", [(6, 3), (10, 3)])
+def test_field_periodic_blocks_of_the_sliced_layout(mf, B, n, fields):
+    """Round 6: a field-major multi-field matrix lists, in row (g, i), the nodes coupled to i once per column field -- col[f P + t] = col[t] + f * (rows per
+    field).  Full 128-row blocks of the sliced layout with that form (flag 2, found by k_sell_block_periodic) read ONE column slot per node for the F fields:
+    a third of the column stream of a three-field matrix.  The product equals mul!'s to round-off and the one with the whole column stream (bit 3 of the
+    "sell" knob); it is the same from run to run bit for bit; a one-field matrix has no such blocks."""
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import _lib, generic as G, physics
+
+    B._umesh_key = None
+    space, msh, fac = B.unstructured_mesh(n, block=16)
+    wf = physics.elasticity_domain(3, L.LAM, L.MU)
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, fields, wf, [])
+        gd.K_linear_func()
+        A, K = gd.A, gd.K_linear
+        x = mf.FEM_rand(A.n, 3, 0) - 0.5
+        mode = C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
+        assert mode.value == 3
+        nper = int(_lib.lib.mfem_debug_sell_periodic_blocks(A._h))
+        assert nper >= (A.n // 128) // 2, nper  # (the blocks where the row length changes and the last one are not)
+        y0 = torch.empty(A.n, dtype=torch.float64, device="cuda")
+        mf.mul_(y0, A, K, x)
+        ys = []
+        for knob in (1, 1, 1 | 8):
+            _lib.lib.mfem_debug_set_sell(knob)
+            y = torch.empty(A.n, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+        for y in ys:
+            assert float((y - y0).abs().max()) <= 1e-13 * float(y0.abs().max())
+        # one field: nothing periodic
+        g1 = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, L.K_COND), [])
+        g1.K_linear_func()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, g1.A._h, C.byref(mode), None, None, None))
+        assert int(_lib.lib.mfem_debug_sell_periodic_blocks(g1.A._h)) == 0
+    finally:
+        _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)

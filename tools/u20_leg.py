@@ -13,6 +13,9 @@ fields = [int(f) for f in (sys.argv[2] if len(sys.argv) > 2 else "1,3").split(",
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 args = bench.parse_args(["--iters", str(iters)])
+if os.environ.get("MFEM_SELL_KNOB"):  # A/B: bit 3 = field-periodic blocks read their whole column stream
+    from metafem_jl_amd import _lib
+    _lib.lib.mfem_debug_set_sell(1 | int(os.environ["MFEM_SELL_KNOB"]))
 B = L.Bench(args)
 for f in fields:
     o = B.unstructured_leg(n, f, steps)
