@@ -225,9 +225,10 @@ typedef struct {
  *    rank or slabs) is BITWISE REPRODUCIBLE since round 6: pass 1 runs its steps phase-major with workgroup barriers between the phases, so every LDS
  *    cell receives its mirrored products from one wave per phase in program order (tests/test_gpu_lat8.py::test_tiles_are_bitwise_reproducible: 20
  *    products and repeated idrs!(8) / bicgstabl_GS!(2) solves identical bit for bit).  Its y equals the CSR kernel's to round-off (<= 1e-13 relative).
- *  - Mode 4 (the tiles of the hex-27 one-field lattice matrix, from 1.8e5 rows on) is NOT bitwise reproducible: four lanes share a row and take every
- *    fourth stored entry, the waves of a workgroup add mirrored products into one LDS block with ds_add_f64 in no fixed order.  Results repeat to
- *    ~1e-16 relative and equal the CSR kernel's to round-off (tests/test_gpu_lat27.py).  mfem_debug_set("lat27", 0, 0) selects the reproducible mode 3.
+ *  - Mode 4 (the tiles of the hex-27 one-field lattice matrix, from 1.8e5 rows on) is BITWISE REPRODUCIBLE since round 6 as well: pass 1 runs lane = row
+ *    (a wave owns the rows of four node types in a cube of 8^3 lattice points, the two waves of a cube split the types by the parity of their (j, k)
+ *    column), steps phase-major with barriers (tests/test_gpu_lat27.py::test_tiles_are_bitwise_reproducible).  The four-lanes-per-row kernel of rounds
+ *    3-5 (ds_add_f64 across waves: ~1e-16 relative, not bitwise) is still selectable: mfem_debug_set("lat27", 1 | 8, 0).
  *  - SYMMETRY GATE of modes 4 / 5: they store one triangle, so every bind measures whether THESE values are symmetric -- one probe product
  *    (entries of magnitude in [0.75, 1.25), random signs) through the layout against the CSR kernel on the caller's values; the layout is taken
  *    when max over rows r of |difference|_r <= 4e-13 |a_rr| (rows without a stored non-zero diagonal: 4e-13 max|a|).  Consequence: an

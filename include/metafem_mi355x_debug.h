@@ -48,6 +48,7 @@ int mfem_debug_set(const char* key, int64_t a, int64_t b);
 /* (round 6) bit 3 of "sell": field-periodic blocks of a field-major multi-field matrix read their whole column stream again (A/B) */
 /* ^ key "sell": mfem_debug_set("sell", a, b) with (int enable) = (a[, b]) */
 /* mode 4 (symmetric lattice tiles, hex-27): 0 = off (mode 3 serves those solves), 1 = on (default). */
+/* (round 6) bit 3 of "lat27": pass 1 by the four-lanes-per-row kernel of rounds 3-5 (not bitwise reproducible) instead of the deterministic lane = row form */
 /* ^ key "lat27": mfem_debug_set("lat27", a, b) with (int enable) = (a[, b]) */  /* bit 1: pass 2 (the gather of the tiles' y blocks) by the kernel that walks the covering blocks one memory round trip at a time (same y bit for bit) */
 /* bit 2 of mfem_debug_set_lat27: CG iterations on the tiles as SpMV (pass 1 + pass 2) + residual update; by default, on one rank, pass 2 runs INSIDE the residual
  * update (k_lat27_gather_cg: A p is never stored, p . A p comes from pass 1) -- the same iterates to round-off.  mfem_debug_lat27_cg_fused: that switch;

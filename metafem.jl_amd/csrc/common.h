@@ -192,6 +192,7 @@ struct mfem_csr_s {
   int32_t sell_regular_blocks;
   // field-periodic blocks (round 6): a field-major multi-field matrix repeats the node list of a row once per column field, shifted by the rows of a field;
   // a block whose 128 rows have one length K = F * P and columns col[f * P + t] = col[t] + f * shift reads the first P slots' columns only
+  int32_t lat27_det;            // the bound copy of the hex-27 tiles is in the deterministic (lane = row, phase-major) form
   int32_t sell_fields;          // F (0: none found)
   int64_t sell_shift;           // column shift between two fields
   int32_t sell_periodic_blocks;

@@ -42,6 +42,7 @@ typedef double l_d2 __attribute__((ext_vector_type(2)));
 
 extern std::atomic<int64_t> g_layout_min_rows_lat27;  // spmv_ell.hip
 static std::atomic<int> g_lat27_enable{1};
+static std::atomic<int> g_lat27_det{1};  // bit 3 of mfem_debug_set_lat27: 0 = pass 1 by the four-lanes-per-row kernel (not bitwise reproducible), 1 (default) = lane = row, phase-major
 static std::atomic<int> g_lat27_cg_fused{1};  // bit 2 of mfem_debug_set_lat27: 0 = CG iterations as SpMV (pass 1 + pass 2) + k_cg_update instead of pass 1 + k_lat27_gather_cg
 static std::atomic<int> g_lat27_gather_staged{1};  // bit 1 of mfem_debug_set_lat27: 0 = pass 2 by k_lat27_gather (masked blocks, a round trip per covering block)
 static std::atomic<long long> g_lat27_count{0};
@@ -53,6 +54,7 @@ extern "C" int mfem_debug_set_lat27(int enable) try {
   g_lat27_enable = enable & 1;
   g_lat27_gather_staged = ((enable >> 1) & 1) ? 0 : 1;
   g_lat27_cg_fused = ((enable >> 2) & 1) ? 0 : 1;
+  g_lat27_det = ((enable >> 3) & 1) ? 0 : 1;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_lat27")
 
@@ -426,6 +428,248 @@ __global__ __launch_bounds__(512, 4) void k_spmv_lat27(Lat27Geom G, const double
     const double d = block_reduce_sum(dacc, dred);
     if (tid == 0) dotp[tile] = d;
   }
+}
+
+
+// =====================================================================================================================================================
+// Deterministic form of pass 1 (round 6; tables and the argument: spmv_lat_tables.h, "mode 4, deterministic order").  LANE = ROW: a wave owns the rows of
+// four node types in a cube of 8 x 8 x 8 lattice points, the two waves of a cube split the types by the parity of their (j, k) column, a tile of
+// 8 x 8 x 32 points = 4 cubes = 8 waves as before.  Every stored slot is one wave-wide step with a compile-time offset; the steps run phase-major -- a phase =
+// the (dj, dk) of the offset -- with LDS-only barriers between phases, so every cell of the tile's y block receives its mirrored products from one wave
+// per phase in program order: y is bitwise the same from run to run.  A cube's 260 steps are stored as its two waves' streams (138 + 122 steps of 64
+// lanes), a pair of steps per lane side by side: each wave reads its 70 / 62 KB front to back with 16-byte loads.  bit 3 of the "lat27" knob selects
+// the four-lanes-per-row kernel above (ds_add_f64 across waves: ~1e-16, not bitwise) for the A/B.
+#define L27D_CUBE_D (L27D_CUBE_STEPS * 64)  // doubles per cube
+__host__ __device__ constexpr int l27d_coff(int di, int dj, int dk) { return di * L27_PI + dj * L27_SK + dk; }
+__host__ __device__ constexpr int l27d_toff(int t) { return ((t >> 2) & 1) * L27_PI + ((t >> 1) & 1) * L27_SK + (t & 1); }
+
+template <int PG, int V0, int N>
+__device__ __forceinline__ void l27d_load(double (&v)[8], const double* __restrict__ sb) {
+  static_assert(V0 % 2 == 0 && N % 2 == 0, "stream steps leave in pairs");
+#pragma unroll
+  for (int i = 0; i < N; i += 2) {
+    const l_d2 pr = __builtin_nontemporal_load((const l_d2*)sb + (int64_t)((V0 + i) >> 1) * 64);
+    v[i] = pr.x;
+    v[i + 1] = pr.y;
+  }
+}
+// the barriers of `n` phase changes (a phase without a step of this wave's types still has its barrier: both waves of a cube, and all cubes, meet 24 times)
+template <int n>
+__device__ __forceinline__ void l27d_barriers() {
+  if constexpr (n > 0) {
+    mfem_lds_barrier();
+    l27d_barriers<n - 1>();
+  }
+}
+template <int PG, int V0, int I, int N>
+__device__ __forceinline__ void l27d_proc(const double (&v)[8], int p0, bool act, const double (&xo)[4], double (&acc)[4], const double* xs, double* ys) {
+  if constexpr (I < N) {
+    constexpr L27DStream S = l27d_stream(PG);
+    constexpr int vv = V0 + I, q = S.q[vv], t = l27d_type(PG, q);
+    constexpr int coff = l27d_toff(t) + l27d_coff(S.di[vv], S.dj[vv], S.dk[vv]);
+    l27d_barriers<(vv == 0 ? S.phase[0] : S.phase[vv] - S.phase[vv > 0 ? vv - 1 : 0])>();
+    if (act) {  // (wave-uniform)
+      const double a = v[I];
+      acc[q] += a * xs[p0 + coff];
+      if constexpr (!(S.di[vv] == 0 && S.dj[vv] == 0 && S.dk[vv] == 0))
+        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + p0 + coff), a * xo[q]);  // (the diagonal has no mirror)
+    }
+    l27d_proc<PG, V0, I + 1, N>(v, p0, act, xo, acc, xs, ys);
+  }
+}
+template <int PG, int C>
+__device__ __forceinline__ void l27d_run(double (&A)[8], double (&B)[8], const double* __restrict__ sb, int p0, bool act, const double (&xo)[4],
+                                         double (&acc)[4], const double* xs, double* ys) {
+  constexpr int NV = l27d_stream(PG).n, NCH = (NV + 7) / 8, LAST = NCH - 1;
+  constexpr int nthis = (C == LAST) ? NV - 8 * LAST : 8;
+  if constexpr (C < LAST) {
+    constexpr int nnext = (C + 1 == LAST) ? NV - 8 * LAST : 8;
+    l27d_load<PG, (C + 1) * 8, nnext>((C & 1) ? A : B, sb);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  l27d_proc<PG, C * 8, 0, nthis>((C & 1) ? B : A, p0, act, xo, acc, xs, ys);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[q]));
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (C < LAST) l27d_run<PG, C + 1>(A, B, sb, p0, act, xo, acc, xs, ys);
+}
+template <int PG>
+__device__ __forceinline__ void l27d_wave(const double* __restrict__ sb, int p0, bool act, const double* xs, double* ys) {
+  constexpr L27DStream S = l27d_stream(PG);
+  double A[8], B[8];
+  l27d_load<PG, 0, 8>(A, sb);
+  double xo[4], acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xo[q] = xs[p0 + l27d_toff(l27d_type(PG, q))];
+    acc[q] = 0.0;
+  }
+  l27d_run<PG, 0>(A, B, sb, p0, act, xo, acc, xs, ys);
+  l27d_barriers<L27D_NPHASE - 1 - S.phase[S.n - 1]>();  // (none: the last phase holds the diagonal of every type)
+  if (act) {  // the row sums: still the last phase (own cells; the other adds into them in this phase come from this wave)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ys + p0 + l27d_toff(l27d_type(PG, q))), acc[q]);
+  }
+}
+
+// pass 1, deterministic: same tile, same dump, same arguments as k_spmv_lat27
+__global__ __launch_bounds__(512, 4) void k_spmv_lat27d(Lat27Geom G, const double* __restrict__ vals, const double* __restrict__ x,
+                                                        const double* __restrict__ dsc, double* __restrict__ dump,
+                                                        const int32_t* __restrict__ done_flag, int tile0, int tcount, double* __restrict__ dotp) {
+  __shared__ double xs[L27_LDS_CELLS];
+  __shared__ double ys[L27_LDS_CELLS];
+  __shared__ double dred[8];
+  if (done_flag && done_flag[0]) return;
+  const int chunk = (tcount + 7) >> 3;
+  const int tsub = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= chunk || tsub >= tcount) return;  // (the whole workgroup leaves)
+  const int tile = tile0 + tsub;
+  const int tk = tile % G.ntk, t2 = tile / G.ntk, tj = t2 % G.ntj, ti = t2 / G.ntj;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int cu = wv >> 1, pg = wv & 1;
+  const int nck = (G.m2 + 7) >> 3, ncj = G.ntj;  // cubes per direction (a tile is one cube in i and j, four in k)
+  const int ck = tk * 4 + cu;
+  const bool act = ck < nck;
+  // a cube that does not exist (lattice edge in k) is read from a place that does and not worked on
+  const double* sb = vals + (act ? (((int64_t)ti * ncj + tj) * nck + ck) * (int64_t)L27D_CUBE_D : 0) + (pg ? (int64_t)l27d_stream(0).n * 64 : 0) + lane * 2;
+  const int i0 = ti * L27_TI, j0 = tj * L27_TJ - 2, k0 = tk * L27_TK - 2;
+  for (int e = tid; e < L27_LDS_CELLS; e += 512) {
+    const int li = e / L27_PI, r2 = e - li * L27_PI, lj = r2 / L27_SK, lk = r2 - lj * L27_SK;
+    const int gi = G.plo + i0 + li, gj = j0 + lj, gk = k0 + lk;
+    double xv = 0.0;
+    if (lj < L27_SJ && gi < G.mg && gi < G.plo + G.m0 + G.gw && gj >= 0 && gj < G.m1 && gk >= 0 && gk < G.m2) {
+      const int64_t r = l27_xindex(G, gi, (int64_t)gj * G.m2 + gk);
+      xv = dsc ? x[r] / dsc[r] : x[r];
+    }
+    xs[e] = xv;
+    ys[e] = 0.0;
+  }
+  __syncthreads();
+  {
+    const int a = lane >> 4, b = (lane >> 2) & 3, c = lane & 3;
+    const int p0 = (2 * a) * L27_PI + (2 * b + 2) * L27_SK + (cu * 8 + 2 * c + 2);  // the lane's row of type (0, 0, 0)
+    if (pg == 0) l27d_wave<0>(sb, p0, act, xs, ys);
+    else l27d_wave<1>(sb, p0, act, xs, ys);
+  }
+  __syncthreads();
+  double* dt = dump + (int64_t)tile * L27_CELLS;
+  double dacc = 0.0;
+  for (int e = tid; e < L27_CELLS; e += 512) {
+    const int li = e / (L27_SJ * L27_SK);
+    const double yv = ys[e + 8 * li];
+    dt[e] = yv;
+    dacc += yv * xs[e + 8 * li];
+  }
+  if (dotp) {
+    const double d = block_reduce_sum(dacc, dred);
+    if (tid == 0) dotp[tile] = d;
+  }
+}
+
+// the layout pass of the deterministic form: a wave per (cube, parity group), lane = row.  A lane walks the UPPER HALF of its CSR row front to back (the
+// stored slots of a type in lexicographic order = ascending columns: each 128-byte line of the row is used up by 16 consecutive loads of the lane while it
+// sits in the L1) and drops every value at its place in the phase-major stream (8-byte stores; the two halves of a 16-byte pair come from two steps).  A
+// first version read in STREAM order -- 64 rows per instruction, each row touched again and again over 60 steps: 11.6 ms per bind of the 128^3 matrix
+// against 2.65 ms of the four-lanes-per-row fill.
+__constant__ uint8_t c_l27d_lex[2][4][64][4];  // [pg][q][e]: (di, dj + 2, dk + 2, stream step v) of the e-th stored slot of the wave's q-th type, lexicographic
+__constant__ int c_l27d_kup[2][4];
+static std::atomic<bool> g_l27d_tables{false};
+static int lat27d_upload_tables() {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (g_l27d_tables) return MFEM_OK;
+  static uint8_t h[2][4][64][4];
+  int kup[2][4];
+  memset(h, 0, sizeof(h));
+  for (int pg = 0; pg < 2; ++pg) {
+    const L27DStream S = l27d_stream(pg);
+    for (int q = 0; q < 4; ++q) {
+      const int t = l27d_type(pg, q);
+      const int R0 = (t & 4) ? 1 : 2, R1 = (t & 2) ? 1 : 2, R2 = (t & 1) ? 1 : 2;
+      int e = 0;
+      for (int di = 0; di <= R0; ++di)
+        for (int dj = -R1; dj <= R1; ++dj)
+          for (int dk = -R2; dk <= R2; ++dk) {
+            if (!(di > 0 || dj > 0 || (dj == 0 && dk >= 0))) continue;  // (the diagonal first: (0, 0, 0) is the smallest stored offset)
+            int v = -1;
+            for (int u = 0; u < S.n; ++u)
+              if (S.q[u] == q && S.di[u] == di && S.dj[u] == dj && S.dk[u] == dk) v = u;
+            if (v < 0 || e >= 64) {
+              mfem_set_error("lattice-tile tables (deterministic form): a stored slot has no stream step");
+              return MFEM_ERR_INTERNAL;
+            }
+            h[pg][q][e][0] = (uint8_t)di;
+            h[pg][q][e][1] = (uint8_t)(dj + 2);
+            h[pg][q][e][2] = (uint8_t)(dk + 2);
+            h[pg][q][e][3] = (uint8_t)v;
+            ++e;
+          }
+      kup[pg][q] = e;
+    }
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_l27d_lex), h, sizeof(h)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_l27d_kup), kup, sizeof(kup)) != hipSuccess) {
+    mfem_set_error("lattice-tile tables (deterministic form): hipMemcpyToSymbol failed");
+    return MFEM_ERR_HIP;
+  }
+  g_l27d_tables = true;
+  return MFEM_OK;
+}
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_l27d_fill(Lat27Geom G, const RP* __restrict__ rowptr, int base, const double* __restrict__ vals,
+                                                            double* __restrict__ out, unsigned long long* __restrict__ stats) {
+  // a wave per (cube, node type): the type's 64 rows 16 at a time, FOUR LANES PER ROW reading four consecutive entries of the row's upper half (16 rows x
+  // 32 bytes per load instruction: the lines in flight fit the L1 -- with a lane per row, 64 rows per instruction, the fill took 11.6 ms for the 128^3
+  // matrix, 4.4 x the four-lanes-per-row fill of the other form); every value goes to its place in the phase-major stream of its row's lane
+  const int lane = threadIdx.x & 63, qd = lane & 3, rho = lane >> 2;
+  const int b = rho >> 2, c = rho & 3;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nci = G.nti, ncj = G.ntj, nck = (G.m2 + 7) >> 3;
+  const int64_t nwork = 8 * (int64_t)nci * ncj * nck;
+  const int n0 = l27d_stream(0).n;
+  double amax = 0.0;
+  for (int64_t u = wave; u < nwork; u += nwaves) {
+    const int t = (int)(u & 7);
+    const int64_t cube = u >> 3;
+    const int ck = (int)(cube % nck);
+    const int64_t c2 = cube / nck;
+    const int cj = (int)(c2 % ncj), ci = (int)(c2 / ncj);
+    const int pg = (((t >> 1) & 1) + (t & 1)) & 1;
+    const int q = pg ? (t == 1 ? 0 : t == 5 ? 1 : t == 2 ? 2 : 3) : (t == 0 ? 0 : t == 4 ? 1 : t == 3 ? 2 : 3);  // (l27d_type backwards)
+    double* os = out + cube * (int64_t)L27D_CUBE_D + (pg ? (int64_t)n0 * 64 : 0);
+    const int kup = c_l27d_kup[pg][q];
+    for (int a = 0; a < 4; ++a) {
+      const int oi = ci * 8 + 2 * a + ((t >> 2) & 1), gj = cj * 8 + 2 * b + ((t >> 1) & 1), gk = ck * 8 + 2 * c + (t & 1);
+      const int gi = oi + G.plo;
+      const bool valid = oi < G.m0 && gj < G.m1 && gk < G.m2;
+      int li = 0, ni = 1, lj = 0, nj = 1, lk = 0, nk = 1;
+      int64_t rp = 0;
+      if (valid) {
+        l27_range(gi, G.mg, li, ni);
+        l27_range(gj, G.m1, lj, nj);
+        l27_range(gk, G.m2, lk, nk);
+        rp = (int64_t)rowptr[((int64_t)oi * G.m1 + gj) * G.m2 + gk] - base;
+      }
+      double* orow = os + (a * 16 + rho) * 2;  // the row's lane in the stream
+      for (int e = qd; e < kup; e += 4) {
+        const int di = c_l27d_lex[pg][q][e][0], dj = (int)c_l27d_lex[pg][q][e][1] - 2, dk = (int)c_l27d_lex[pg][q][e][2] - 2, v = c_l27d_lex[pg][q][e][3];
+        const int ci2 = gi + di, cj2 = gj + dj, ck2 = gk + dk;
+        double val = 0.0;
+        if (valid && ci2 < G.mg && cj2 >= 0 && cj2 < G.m1 && ck2 >= 0 && ck2 < G.m2) {  // (ci2 may be a ghost plane of a slab)
+          val = vals[rp + ((int64_t)(di - li) * nj + (dj - lj)) * nk + (dk - lk)];
+          double av = fabs(val);
+          if (!(av == av)) av = __builtin_huge_val();  // NaN: fmax would drop it
+          amax = fmax(amax, av);
+        }
+        orow[(int64_t)(v >> 1) * 128 + (v & 1)] = val;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, MFEM_WAVE));
+  if (lane == 0) atomicMax(stats + 1, (unsigned long long)__double_as_longlong(amax));
 }
 
 // pass 2: y[r] = alpha * (sum over the tiles whose block covers r, fixed order) + beta * y[r]; fused dot with dotw.  A thread owns a
@@ -834,7 +1078,11 @@ int mfem_lat27_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   return MFEM_OK;
 }
 
-static size_t lat27_vals_doubles(const Lat27Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * L27_UNIT_D; }
+static size_t lat27d_vals_doubles(const Lat27Geom& G) { return (size_t)G.nti * G.ntj * ((G.m2 + 7) / 8) * L27D_CUBE_D; }
+static size_t lat27q_vals_doubles(const Lat27Geom& G) { return (size_t)G.nui * G.nuj * G.nuk * L27_UNIT_D; }
+// (the workspace is sized for whichever form needs more: the knob may change between the plan and a bind)
+static size_t lat27_vals_doubles(const Lat27Geom& G) { const size_t a = lat27d_vals_doubles(G), b = lat27q_vals_doubles(G); return a > b ? a : b; }
+static size_t lat27_read_doubles(const Lat27Geom& G) { return g_lat27_det ? lat27d_vals_doubles(G) : lat27q_vals_doubles(G); }  // what pass 1 streams
 static size_t lat27_dump_doubles(const Lat27Geom& G) { return (size_t)G.nti * G.ntj * G.ntk * L27_CELLS; }
 
 // workspace of the layout: the stored entries, then the per-tile y blocks
@@ -861,6 +1109,17 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
   const Lat27Geom G = lat27_geom(A);
   unsigned long long* d_stats = (unsigned long long*)(ctx->d_flags + 12);
   MFEM_CHECK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  A->lat27_det = g_lat27_det ? 1 : 0;  // (the form THIS copy is made in: the launches follow the copy, not the knob)
+  if (A->lat27_det) {
+    const int rt = lat27d_upload_tables();
+    if (rt) return rt;
+    const int64_t nwork = 8 * (int64_t)G.nti * G.ntj * ((G.m2 + 7) / 8);  // a wave per (cube, node type)
+    const int grid = mfem_grid_for(nwork * 64, MFEM_BLOCK, ctx->num_cus * 16);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_l27d_fill<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int64_t*)A->rowptr, A->index_base, vals, buf, d_stats);
+    else
+      hipLaunchKernelGGL(k_l27d_fill<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->index_base, vals, buf, d_stats);
+  } else {
   const int64_t nunits = (int64_t)G.nui * G.nuj * G.nuk;
   const int grid = mfem_grid_for(nunits * 64, MFEM_BLOCK, ctx->num_cus * 16);
   if (A->rowptr_bits == 64)
@@ -869,6 +1128,7 @@ int mfem_lat27_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doub
   else
     hipLaunchKernelGGL(k_l27_fill<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, G, (const int32_t*)A->rowptr, A->index_base,
                        vals, buf, d_stats);
+  }
   MFEM_CHECK_LAUNCH();
   MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 12, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -917,8 +1177,12 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
     // as one partial per tile behind the dump
     MFEM_REQUIRE(part == 0 && dotw == x && alpha == 1.0 && beta == 0.0 && !A->lat27_dsc, "lattice tiles: pass 1 alone serves only the fused CG iteration");
     double* dotp = A->lat27_dump + lat27_dump_doubles(G);
-    hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, (const double*)nullptr, A->lat27_dump, done_flag, 0, ntiles,
-                       dotp);
+    if (A->lat27_det)
+      hipLaunchKernelGGL(k_spmv_lat27d, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, (const double*)nullptr, A->lat27_dump, done_flag, 0,
+                         ntiles, dotp);
+    else
+      hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, (const double*)nullptr, A->lat27_dump, done_flag, 0,
+                         ntiles, dotp);
     MFEM_CHECK_LAUNCH();
     (void)partials;  // (the caller reads the partials where mfem_lat27_dot_partials says)
     if (n_partials) *n_partials = ntiles;
@@ -926,8 +1190,12 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
     return 1;
   }
   if (tcount > 0) {
-    hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag,
-                       tile0, tcount, (double*)nullptr);
+    if (A->lat27_det)
+      hipLaunchKernelGGL(k_spmv_lat27d, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag, tile0, tcount,
+                         (double*)nullptr);
+    else
+      hipLaunchKernelGGL(k_spmv_lat27, dim3(8 * chunk), dim3(512), 0, ctx->stream, G, A->lat27_vals, x, A->lat27_dsc, A->lat27_dump, done_flag, tile0, tcount,
+                         (double*)nullptr);
     MFEM_CHECK_LAUNCH();
   }
   if (part == 1) return 1;  // (the gather pass belongs to part 2)
@@ -961,9 +1229,9 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
 int64_t mfem_lat27_design_bytes(const mfem_csr_s* A) {
   const Lat27Geom G = lat27_geom(A);
   const int64_t tiles = (int64_t)G.nti * G.ntj * G.ntk;
-  return (int64_t)lat27_vals_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_scaled ? 4 : 3) + A->n * 8 + mfem_rem_design_bytes(A);
+  return (int64_t)lat27_read_doubles(G) * 8 + tiles * L27_CELLS * 8 * (A->lat27_scaled ? 4 : 3) + A->n * 8 + mfem_rem_design_bytes(A);
 }
-int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_vals_doubles(lat27_geom(A)); }
+int64_t mfem_lat27_entries(const mfem_csr_s* A) { return (int64_t)lat27_read_doubles(lat27_geom(A)); }
 
 // ---- the fused CG iteration (krylov.hip, cg_solve_pass): pass 1 alone (mfem_spmv_halo with y = nullptr), the dot-product partials, pass 2 + residual update
 bool mfem_lat27_cg_fused(const mfem_context_s* ctx, const mfem_csr_s* A, const double* vals) {
@@ -985,5 +1253,5 @@ extern "C" int mfem_debug_lat27_cg_fused(void) { return g_lat27_cg_fused; }
 extern "C" int64_t mfem_debug_lat27_pass1_bytes(mfem_csr A) {
   if (!A || A->lat27_state != 1) return -1;
   const Lat27Geom G = lat27_geom(A);
-  return (int64_t)lat27_vals_doubles(G) * 8 + (int64_t)G.nti * G.ntj * G.ntk * L27_CELLS * 8 * 2;
+  return (int64_t)lat27_read_doubles(G) * 8 + (int64_t)G.nti * G.ntj * G.ntk * L27_CELLS * 8 * 2;
 }

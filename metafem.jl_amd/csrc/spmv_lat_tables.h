@@ -131,3 +131,48 @@ inline bool l27_build_tables(int8_t (*d)[4], int* Kup) {
   }
   return true;
 }
+
+// ---- mode 4, deterministic order (round 6): LANE = ROW.  A wave owns the rows of FOUR node types in a cube of 8 x 8 x 8 lattice points -- 4 x 4 x 4 = 64
+// rows per type, lane = (a, b, c), row = (2 a + pi, 2 b + pj, 2 c + pk) --, the two waves of a cube split the types by the parity of their (j, k) column:
+// pg = (pj + pk) & 1, so a lattice column belongs to ONE wave.  Every stored slot of a type is one wave-wide step with a compile-time offset (no padding
+// steps: 63 + 38 + 23 + 14 = 138 and 38 + 23 + 38 + 23 = 122 steps for 256 rows each, 32.5 entries per row against 34 with four lanes per row).  Steps run
+// phase-major (phases: below; the one of (0, 0) last, with the row sums), workgroup barriers between phases: inside a phase a cell receives products
+// from columns of ONE wave, in program order.
+// Offsets that differ by 2 in dj alone share a phase: their source columns (j - dj, k - dk) have the same k -- the same cube -- and the same parity of
+// j + k -- the same wave.  So a phase = (dk, parity of dj): 10 phases, 9 barriers per tile; the phase of (0, 0) -- (dk = 0, dj even) -- is the last.
+#define L27D_NPHASE 10
+#define L27D_MAXS 140
+__host__ __device__ constexpr int l27d_phase_of(int dj, int dk) {
+  const int c = (dk + 2) * 2 + (dj & 1);  // 4 = (dk = 0, dj even)
+  return c < 4 ? c : c == 4 ? 9 : c - 1;
+}
+__host__ __device__ constexpr int l27d_type(int pg, int q) { return pg == 0 ? (q == 0 ? 0 : q == 1 ? 4 : q == 2 ? 3 : 7) : (q == 0 ? 1 : q == 1 ? 5 : q == 2 ? 2 : 6); }
+struct L27DStream {
+  int n;                  // steps
+  int q[L27D_MAXS];       // which of the wave's four types
+  int di[L27D_MAXS], dj[L27D_MAXS], dk[L27D_MAXS];
+  int phase[L27D_MAXS];
+};
+__host__ __device__ constexpr L27DStream l27d_stream(int pg) {
+  L27DStream S{};
+  int v = 0;
+  for (int ph = 0; ph < L27D_NPHASE; ++ph)
+    for (int q = 0; q < 4; ++q) {
+      const int t = l27d_type(pg, q);
+      const int R0 = (t & 4) ? 1 : 2, R1 = (t & 2) ? 1 : 2, R2 = (t & 1) ? 1 : 2;
+      if (ph == L27D_NPHASE - 1) {  // the diagonal: slot 0
+        S.q[v] = q; S.di[v] = 0; S.dj[v] = 0; S.dk[v] = 0; S.phase[v] = ph;
+        ++v;
+      }
+      for (int di = 0; di <= R0; ++di)
+        for (int dj = -R1; dj <= R1; ++dj)
+          for (int dk = -R2; dk <= R2; ++dk)
+            if ((di > 0 || dj > 0 || (dj == 0 && dk > 0)) && l27d_phase_of(dj, dk) == ph) {
+              S.q[v] = q; S.di[v] = di; S.dj[v] = dj; S.dk[v] = dk; S.phase[v] = ph;
+              ++v;
+            }
+    }
+  S.n = v;
+  return S;
+}
+#define L27D_CUBE_STEPS 260  // 138 + 122

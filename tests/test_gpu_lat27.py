@@ -227,3 +227,45 @@ def test_caller_supplied_csr_takes_the_lattice_tiles(mf, small_layouts, rp_dtype
     ci2[j], ci2[j + 1] = ci[j + 1].item(), ci[j].item()  # two neighbouring columns of a middle row swapped: not the stencil order any more
     A2 = mf.FEM_SpMat_CSR(rp, ci2, A0.n, base, ctx=b.ctx)
     assert _mode(b, A2) != 4
+
+
+@pytest.mark.parametrize("dims", [(9, 5, 17), (20, 20, 20), (4, 4, 40)])
+def test_tiles_are_bitwise_reproducible(mf, small_layouts, dims):
+    """Round 6: pass 1 of the hex-27 tiles in its deterministic form -- lane = row, the two waves of a cube split the node types by the
+    parity of their (j, k) column, steps phase-major by the (dj, dk) of their offset with barriers between the phases -- gives a y that is the same bit for
+    bit from run to run (20 products), equals the CSR kernel's to round-off and the four-lanes-per-row kernel's (bit 3 of the "lat27" knob: ds_add_f64
+    across waves, ~1e-16) to round-off; CG, idrs!(8) and bicgstabl_GS!(2) solves repeat bit for bit, iteration counts included."""
+    import torch
+
+    _lib = small_layouts
+    b = mf.make_Brick((1.0, 0.7, 1.3), dims, 2, 5)
+    A = b.pattern(1)
+    K = b.assemble_thermal(A, K_COND, H, TENV, 0x3F)
+    assert _mode(b, A) == 4
+    x = mf.FEM_rand(A.n, 3, 0) - 0.5
+    y0 = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    mf.mul_(y0, A, K, x)
+    ys = []
+    for _ in range(20):
+        y = torch.full((A.n,), 7.0, dtype=torch.float64, device="cuda")
+        c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+        assert int(_lib.lib.mfem_debug_lat27_spmv_count()) == c0 + 1
+        ys.append(y)
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    assert float((y0 - ys[0]).abs().max()) <= 1e-13 * float(y0.abs().max())
+    _lib.lib.mfem_debug_set_lat27(1 | 8)
+    yq = torch.zeros(A.n, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib.mfem_spmv_solver_layout(b.ctx._h, A._h, K.data_ptr(), x.data_ptr(), yq.data_ptr(), 1.0, 0.0))
+    assert float((yq - ys[0]).abs().max()) <= 1e-13 * float(y0.abs().max())
+    _lib.lib.mfem_debug_set_lat27(1)
+    rhs = mf.FEM_rand(A.n, 5, 0) - 0.5
+    for kw in (dict(Sv_func=mf.cg_), dict(Sv_func=mf.idrs_, s=8), dict(Sv_func=mf.bicgstabl_GS_, s=2)):
+        runs = []
+        for _ in range(3):
+            c0 = int(_lib.lib.mfem_debug_lat27_spmv_count())
+            xs, st = mf.iterative_Solve(A, K, rhs, 1e-10, maxiter=3000, max_pass=4, **kw)
+            assert st.converged == 1 and int(_lib.lib.mfem_debug_lat27_spmv_count()) > c0
+            runs.append((xs.clone(), st.iterations, st.spmv_count, st.final_res))
+        for r in runs[1:]:
+            assert torch.equal(r[0], runs[0][0]) and r[1:] == runs[0][1:]

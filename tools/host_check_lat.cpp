@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string.h>
 #include <vector>
 
 #include "spmv_lat_tables.h"
@@ -20,6 +21,34 @@ static int check27(int m0, int m1, int m2) {
   const int want[8] = {63, 38, 38, 23, 38, 23, 23, 14};
   for (int t = 0; t < 8; ++t)
     if (Kup[t] != want[t]) return printf("type %d: %d stored slots, expected %d\n", t, Kup[t], want[t]), 1;
+  // the deterministic form (round 6, l27d_stream): the two parity groups' streams hold every stored slot of every type exactly once, phase-major, a phase
+  // = one (dj, dk), (0, 0) last; a (j, k) column belongs to one parity group
+  {
+    int seen[8][3][5][5];
+    memset(seen, 0, sizeof(seen));
+    int per_type[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int pg = 0; pg < 2; ++pg) {
+      const L27DStream S = l27d_stream(pg);
+      if (S.n != (pg ? 122 : 138) || (S.n & 1)) return printf("stream %d has %d steps\n", pg, S.n), 1;
+      for (int v = 0; v < S.n; ++v) {
+        const int t = l27d_type(pg, S.q[v]);
+        if ((((t >> 1) & 1) + (t & 1)) % 2 != pg) return printf("type %d in the wrong parity group\n", t), 1;
+        const int R[3] = {(t & 4) ? 1 : 2, (t & 2) ? 1 : 2, (t & 1) ? 1 : 2};
+        const int di = S.di[v], dj = S.dj[v], dk = S.dk[v];
+        if (di < 0 || di > R[0] || dj < -R[1] || dj > R[1] || dk < -R[2] || dk > R[2]) return printf("offset out of reach\n"), 1;
+        if (!(di > 0 || dj > 0 || (dj == 0 && dk >= 0))) return printf("lower entry stored\n"), 1;
+        if (S.phase[v] != l27d_phase_of(dj, dk) || (v > 0 && S.phase[v] < S.phase[v - 1])) return printf("phase order\n"), 1;
+        if (dj == 0 && dk == 0 && S.phase[v] != L27D_NPHASE - 1) return printf("(0, 0) is not in the last phase\n"), 1;
+        // two steps of one phase have the same dk and dj of the same parity: their source columns lie in one cube and have one parity of j + k -- one wave
+        for (int u = 0; u < v; ++u)
+          if (S.phase[u] == S.phase[v] && (S.dk[u] != dk || ((S.dj[u] - dj) & 1))) return printf("phase mixes waves\n"), 1;
+        if (seen[t][di][dj + 2][dk + 2]++) return printf("slot twice\n"), 1;
+        ++per_type[t];
+      }
+    }
+    for (int t = 0; t < 8; ++t)
+      if (per_type[t] != want[t]) return printf("type %d: %d steps in the streams, %d stored slots\n", t, per_type[t], want[t]), 1;
+  }
   const long n = (long)m0 * m1 * m2;
   auto id = [&](int i, int j, int k) { return ((long)i * m1 + j) * m2 + k; };
   auto reach = [](int g) { return (g & 1) ? 1 : 2; };
