@@ -205,3 +205,45 @@ def test_field_periodic_blocks_of_the_sliced_layout(mf, B, n, fields):
     finally:
         _lib.lib.mfem_debug_set_sell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("F", [2, 4, 6])
+def test_field_periodic_blocks_two_four_six_fields(mf, B, F):
+    """The field-periodic form of the sliced layout for other field counts (the cylinder-flow example has four: p, u1, u2, u3): a field-major F-field
+    matrix built as kron(ones(F, F), P1) on the pattern P1 of a one-field hex-20 mesh, random values.  F = 6 is served as three periods of two node lists."""
+    import scipy.sparse as sp
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import _lib, generic as G, physics
+
+    B._umesh_key = None
+    space, msh, fac = B.unstructured_mesh(7, block=16)
+    g1 = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, L.K_COND), [])
+    rp = g1.A.rowptr.cpu().numpy().astype(np.int64) - g1.A.index_base
+    ci = g1.A.colidx.cpu().numpy().astype(np.int64) - g1.A.index_base
+    n1 = g1.A.n
+    P1 = sp.csr_matrix((np.ones(ci.size), ci, rp), shape=(n1, n1))
+    M = sp.kron(sp.csr_matrix(np.ones((F, F))), P1, format="csr")
+    M.sort_indices()
+    rng = np.random.default_rng(F)
+    M.data = rng.standard_normal(M.nnz)
+    n = F * n1
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        A = mf.FEM_SpMat_CSR(torch.tensor(M.indptr, dtype=torch.int64, device="cuda"), torch.tensor(M.indices, dtype=torch.int32, device="cuda"), n, index_base=0, ctx=B.ctx)
+        K = torch.tensor(M.data, device="cuda")
+        mode = C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
+        assert mode.value == 3
+        assert int(_lib.lib.mfem_debug_sell_periodic_blocks(A._h)) >= (n // 128) // 2
+        x = mf.FEM_rand(n, 3, 0) - 0.5
+        want = torch.tensor(M @ x.cpu().numpy(), device="cuda")
+        for knob in (1, 1 | 8):
+            _lib.lib.mfem_debug_set_sell(knob)
+            y = torch.empty(n, dtype=torch.float64, device="cuda")
+            _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+            assert float((y - want).abs().max()) <= 1e-13 * float(want.abs().max())
+    finally:
+        _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
