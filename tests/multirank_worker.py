@@ -290,6 +290,13 @@ def main():
             check(f"{name}_{pname}", s1.converged == 1 and sg.converged == 1 and relerr(x1, xg) <= 1e-8 and
                   abs(s1.iterations - sg.iterations) <= max(4, sg.iterations // 10),
                   iters=(s1.iterations, sg.iterations), rel_err=relerr(x1, xg))
+    # round 6: idrs! with its DEFAULT shadow vectors -- the +-1 family of the seed's sign words, generated per rank from the local row index, never stored;
+    # P' g is a rank-local sign-dot + the all-reduce -- converges on the slabs to the single-rank solution (other shadow vectors than the global solve's:
+    # the converged solutions agree, not the iterates)
+    xg_, sg_ = gsolve(mf.idrs_, s=8, Pr_func=mf.Pr_Jacobi_)
+    xd_, sd_ = mf.iterative_Solve(A, K, R, 1e-11, Sv_func=mf.idrs_, maxiter=4000, max_pass=3, s=8, Pr_func=mf.Pr_Jacobi_)
+    check("idrs8_generated_sign_shadows_on_slabs", sd_.converged == 1 and relerr(xd_, xg_) <= 1e-7 and sd_.iterations <= 2 * sg_.iterations + 20,
+          iters=(sd_.iterations, sg_.iterations), rel_err=relerr(xd_, xg_))
     if rccl:
         # hipGraph replay of the Krylov cycles WITH the communicator's calls recorded (round 6: mfem_debug_set_graphs bit 1 / MFEM_GRAPH_COMM=1): the un-captured
         # sequence above is the reference -- same iterates, same iteration counts

@@ -79,7 +79,7 @@ def test_multirank_solve_equals_single_rank(case, world):
     names = set(reports[0]["checks"])
     for need in ("halo_ghost_planes_bitwise", "jacobi_diag_with_halo_bitwise", "jacobi_colnorm_is_global", "cg_classic_overlap",
                  "cg_classic_blocking", "cg_single_reduction_overlap", "bicgstabl2_diag", "bicgstabl2_colnorm", "idrs8_diag",
-                 "idrs8_colnorm", "callbacks_ran"):
+                 "idrs8_colnorm", "idrs8_generated_sign_shadows_on_slabs", "callbacks_ran"):
         assert need in names, need
     if case == "thermal_hex8":
         assert "symmetric_sweep_kernel_ran" in names
