@@ -69,26 +69,33 @@ __device__ __forceinline__ double ma_inv(const double (&J)[3][3], double (&I)[3]
 // OUT: 0 = add into K through the slot table (plain read-modify-write: colour batches), 1 = the same with FP64 atomics,
 //      2 = write the element matrix to an element-major scratch  S[((el * itp + a) * nb + k) * itp + b]  (k = index of the
 //          term run / sparse block): unit-stride stores, read back row by row by k_mesh_gather.
-template <int DIM, int S0, int NS, int OUT>
+// STAGE (round 6, elements of the row-owner form): PERSISTENT workgroups -- the elements' shared reference table (hex-20, 27 Gauss points: 17 KB) is copied to
+// LDS once per workgroup and every wave then walks its share of the elements.  With a wave per element and the table read from the L2 an element took
+// 38 us of a wave's time at 96^3 (three dependent phases of L2 round trips: 20 x 3 table reads per lane for the Jacobian alone); staging it per ELEMENT had
+// been measured slower in round 2 (1.25 against 0.91 ms at 32^3) -- the copy has to be amortised over many elements.
+template <int DIM, int S0, int NS, int OUT, bool STAGE = false>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, ConstTerms T, const int32_t* __restrict__ slots,
                                                                 int64_t block_stride, double* __restrict__ K, int64_t t0,
                                                                 int64_t t1, int nb) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int itg = V.itg, itp = V.itp;
-  // (staging the elements' shared reference table in LDS once per workgroup was measured slower: 1.25 ms against 0.91 ms for
-  // hex-20 elasticity 32^3 -- the table is L2-resident and the extra 17 KB cost a resident workgroup's worth of overlap)
   const size_t per_wave = (size_t)itg * itp * NS + (size_t)itg * (1 + DIM * DIM) + (size_t)itp * DIM;
-  double* Tt = lds + (size_t)w * per_wave;  // [itg][itp][NS]
+  const size_t ref_doubles = STAGE ? (size_t)itg * itp * (1 + DIM) : 0;
+  double* Rs = lds;                                          // [1 + DIM][itp][itg]: the reference table (STAGE)
+  double* Tt = lds + ref_doubles + (size_t)w * per_wave;     // [itg][itp][NS]
   double* wd = Tt + (size_t)itg * itp * NS;     // [itg]
   double* Ji = wd + itg;                        // [itg][DIM*DIM]  J^-1
   double* X = Ji + (size_t)itg * DIM * DIM;     // [itp][DIM]
-  const int64_t t = t0 + (int64_t)blockIdx.x * nw + w;
-  if (t >= t1) return;  // wave-uniform; no workgroup barrier below
+  if (STAGE) {
+    for (int i = threadIdx.x; i < (int)ref_doubles; i += blockDim.x) Rs[i] = V.ref[i];
+    __syncthreads();  // (the only workgroup barrier: every wave reaches it)
+  }
+  for (int64_t t = t0 + (int64_t)blockIdx.x * nw + w; t < t1; t += (int64_t)gridDim.x * nw) {  // (one trip unless STAGE: the grid covers the items)
   const int64_t h = V.order ? (int64_t)V.order[t] - V.base : t;
   const int64_t el = V.host_el ? (int64_t)V.host_el[h] - V.base : h;
   const int f = V.eindex ? V.eindex[h] - V.base : 0;
-  const double* R = V.ref + (int64_t)f * V.ref_stride;
+  const double* R = STAGE ? Rs : V.ref + (int64_t)f * V.ref_stride;
   const int32_t* cpe = V.cp + (int64_t)itp * el;
   for (int i = lane; i < itp * DIM; i += 64) {
     const int a = i / DIM, d = i - a * DIM;
@@ -163,6 +170,68 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   __builtin_amdgcn_wave_barrier();
   // ---- node pairs over the lanes
   const int npair = itp * itp;
+  if (OUT == 2 && itp >= 16) {
+    // Row-owner (scratch) form on elements of 16+ nodes (hex-20, hex-27): a lane takes FOUR dual nodes a for one base node b.  The pair loop is bound by
+    // LDS bandwidth -- 7 reads per pair and Gauss point with a pair per lane (w, 3 + 3 table entries; hex-20: 677 KB per element) --; with the b side and
+    // the weight shared by four pairs it is 4 reads per pair.  b runs fastest over the lanes: unit-stride stores into the element-major scratch.
+    constexpr int TA = 4;
+    const int ng = (itp + TA - 1) / TA;
+    for (int w_ = lane; w_ < ng * itp; w_ += 64) {
+      const int ag = w_ / itp, b = w_ - ag * itp, a0 = ag * TA;
+      double M[TA][NS * NS];
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int s = 0; s < NS * NS; ++s) M[i][s] = 0.0;
+      {
+        const double* tb = Tt + b * NS;
+        const double* ta[TA];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) ta[i] = Tt + (a0 + i < itp ? a0 + i : itp - 1) * NS;  // (a group cut by the element: its last node again, not stored)
+        const int qs = itp * NS;
+#pragma unroll 3
+        for (int q = 0; q < itg; ++q) {
+          const double wq_ = wd[q];
+          double vb[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) vb[s] = tb[q * qs + s] * wq_;
+#pragma unroll
+          for (int i = 0; i < TA; ++i) {
+            double va[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) va[s] = ta[i][q * qs + s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+              for (int u = 0; u < NS; ++u) M[i][s * NS + u] += va[s] * vb[u];
+          }
+        }
+      }
+      int i = 0, krun = 0;
+      while (i < T.n) {  // runs of terms with the same sparse block: one value per run and pair
+        const int block = T.block[i];
+        double sum[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) sum[t] = 0.0;
+        for (; i < T.n && T.block[i] == block; ++i) {
+          const int sel = (T.ds[i] - S0) * NS + (T.bs[i] - S0);  // wave-uniform: a scalar branch, not a select chain
+          const double cf = T.coef[i];
+          switch (sel) {
+#define MA_CASE(c) case c: if (c < NS * NS) { _Pragma("unroll") for (int t = 0; t < TA; ++t) sum[t] += cf * M[t][c < NS * NS ? c : 0]; } break;
+            MA_CASE(0) MA_CASE(1) MA_CASE(2) MA_CASE(3) MA_CASE(4) MA_CASE(5) MA_CASE(6) MA_CASE(7)
+            MA_CASE(8) MA_CASE(9) MA_CASE(10) MA_CASE(11) MA_CASE(12) MA_CASE(13) MA_CASE(14) MA_CASE(15)
+#undef MA_CASE
+            default: break;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+          if (a0 + t < itp) K[(((int64_t)el * itp + (a0 + t)) * nb + krun) * itp + b] = sum[t];
+        ++krun;
+      }
+    }
+    continue;
+  }
   for (int p = lane; p < npair; p += 64) {
     // slot table order: a fastest; scratch order: b fastest (the lanes' stores are unit-stride)
     const int a = OUT == 2 ? p / itp : p % itp, b = OUT == 2 ? p % itp : p / itp;
@@ -213,6 +282,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
       ++krun;
     }
   }
+  }  // items of this wave
 }
 
 static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const ConstTerms& T, const int32_t* slots,
@@ -228,10 +298,13 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
   const int mode = smax == 0 ? 2 : smin >= 1 ? 1 : 0;  // values only | gradients only | everything
   const int NS = mode == 2 ? 1 : mode == 1 ? dim : 1 + dim;
   const size_t per_wave = sizeof(double) * ((size_t)V.itg * V.itp * NS + (size_t)V.itg * (1 + dim * dim) + (size_t)V.itp * dim);
-  const size_t shared_ref = 0;
+  // the row-owner form on elements with a table worth staging (16+ nodes): persistent workgroups, the reference table in LDS (k_mesh_assemble: STAGE)
+  const bool stage = scratch_blocks > 0 && !V.eindex && !V.order && V.itp >= 16 && n_colours == 0;
+  const size_t shared_ref = stage ? sizeof(double) * (size_t)V.itg * V.itp * (1 + dim) : 0;
   int waves = 4;
-  while (waves > 1 && shared_ref + per_wave * waves > 64 * 1024) waves >>= 1;
-  MFEM_REQUIRE(shared_ref + per_wave * waves <= 64 * 1024, "element table too large for the fused mesh assembly (about 2 * itg * itp * (1 + dim) doubles must fit 64 KB)");
+  const size_t lds_cap = stage ? 96 * 1024 : 64 * 1024;  // (a workgroup may take up to 160 KB on gfx950; two staged workgroups per CU at hex-20)
+  while (waves > 1 && shared_ref + per_wave * waves > lds_cap) waves >>= 1;
+  MFEM_REQUIRE(shared_ref + per_wave * waves <= lds_cap, "element table too large for the fused mesh assembly (about 2 * itg * itp * (1 + dim) doubles must fit 64 KB)");
   const size_t ldsb = shared_ref + per_wave * waves;
   const bool atomic = n_colours == 0;
   const int out_mode = scratch_blocks > 0 ? 2 : atomic ? 1 : 0;
@@ -239,10 +312,24 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
   for (int c = 0; c < nbatch; ++c) {
     const int64_t a = atomic ? 0 : colour_offsets[c], b = atomic ? n_items : colour_offsets[c + 1];
     if (b <= a) continue;
-    const int grid = (int)((b - a + waves - 1) / waves);
-#define MA_LAUNCH(D, S0, NSS, AT)                                                                                      \
-  hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, AT>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots, \
-                     block_stride, K, a, b, scratch_blocks)
+    int grid = (int)((b - a + waves - 1) / waves);
+    if (stage) {  // persistent: what is resident (LDS-bound: 160 KB per CU)
+      const int per_cu = (int)(160 * 1024 / (ldsb > 0 ? ldsb : 1));
+      const int cap = ctx->num_cus * (per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu);
+      if (grid > cap) grid = cap;
+    }
+#define MA_LAUNCH(D, S0, NSS, AT)                                                                                             \
+  do {                                                                                                                        \
+    if (stage && AT == 2) {                                                                                                   \
+      if (ldsb > 64 * 1024)                                                                                                   \
+        MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_assemble<D, S0, NSS, 2, true>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));                         \
+      hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, 2, true>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots, \
+                         block_stride, K, a, b, scratch_blocks);                                                             \
+    } else                                                                                                                    \
+      hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, AT>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots,     \
+                         block_stride, K, a, b, scratch_blocks);                                                             \
+  } while (0)
 #define MA_MODE(D, AT)                                  \
   do {                                                  \
     if (mode == 2) MA_LAUNCH(D, 0, 1, AT);              \
