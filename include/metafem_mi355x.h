@@ -462,6 +462,14 @@ int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, int32_t itg,
                                      const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
                                      const mfem_const_term* terms, int32_t n_fields, mfem_csr A, const int64_t* adj_ptr,
                                      const int32_t* adj, const uint16_t* ranks, double* K_val);
+/* The same, K_val OVERWRITTEN: every entry of every row of the pattern receives the sum of its element contributions (zero where none) -- K_val need
+ * not be initialised.  What K_linear_func does first (05_CodeGenerator.jl:282: K_linear starts from zero): the memset of K and the read of the zeros
+ * are 2 x 8 bytes per nonzero that the accumulating form pays (hex-20 elasticity at 96^3: 30 GB of 70).  nel must be > 0. */
+int mfem_mesh_assemble_elements_rows_set(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                         const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                         const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                         const mfem_const_term* terms, int32_t n_fields, mfem_csr A, const int64_t* adj_ptr,
+                                         const int32_t* adj, const uint16_t* ranks, double* K_val);
 /* ranks [nel * itp * itp] (device, once per pattern): for adjacency entry j = (node i <- element el, local a) and local node
  * b, the position of node(el, b) among the control points coupled to i -- the column offset inside every field segment of a
  * row of node i (the role the reference's sparse_IDs_by_el plays for its scatter, read unit-stride by the row-owner pass).

@@ -184,6 +184,9 @@ int mfem_debug_fail_host_alloc(int nth);
 /* TEST HOOK: the residual a single-rank tile solve recomputes from the caller's CSR values before it ends the passes is multiplied by `scale`
  * (default 1; <= 0 resets): lets a test put the tiles' residual and the caller's on the two sides of the tolerance */
 /* ^ key "recheck_scale_ppm": mfem_debug_set("recheck_scale_ppm", a, b) with (a = scale in millionths) = (a[, b]) */
+/* The gather of mfem_mesh_assemble_elements_rows runs by NODE when a node's blocks x element nodes fit a wave (round 6: the rows of a node's fields share one
+ * adjacency walk, several nodes per wave); 1 = by row, as in round 5 (A/B and the bitwise comparison in tests/test_gpu_unstructured.py). */
+/* ^ key "mesh_gather_rows": mfem_debug_set("mesh_gather_rows", a, b) with (int by_row) = (a[, b]) */
 int mfem_debug_remainder_info(mfem_csr A, int64_t* rows /* [host] */, int64_t* entries /* [host] */, double* asym_before /* [host] */);
 long long mfem_debug_rem_spmv_count(void);
 

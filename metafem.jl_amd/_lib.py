@@ -186,6 +186,8 @@ SIGNATURES = {
                                             C.POINTER(ConstTerm), P, c_int64, P, P, c_int64, c_int32, C.POINTER(c_int64)]),
     "mfem_mesh_assemble_elements_rows": (c_int, [P, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, c_int32, c_int32,
                                                  C.POINTER(ConstTerm), c_int32, P, P, P, P, P]),
+    "mfem_mesh_assemble_elements_rows_set": (c_int, [P, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, c_int32, c_int32,
+                                                 C.POINTER(ConstTerm), c_int32, P, P, P, P, P]),
     "mfem_mesh_row_ranks": (c_int, [P, c_int32, c_int64, c_int64, c_int32, P, P, P, P, c_int32, P]),
     "mfem_mesh_assemble_facets": (c_int, [P, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, P, P, P, P, P, P, P, c_int32,
                                           c_int32, C.POINTER(ConstTerm), P, c_int64, P, P, c_int64, c_int32, C.POINTER(c_int64)]),

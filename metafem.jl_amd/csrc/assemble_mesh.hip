@@ -396,7 +396,8 @@ extern "C" int mfem_mesh_assemble_elements(mfem_context ctx, int32_t dim, int32_
 // fb * ncp + node(el, b) (binary search in the staged list) -- distinct positions within a step, steps in sequence: no
 // atomics, a fixed summation order (bitwise reproducible), every K entry read and written once, contiguously.
 #define MG_MAXROW 2048
-static std::atomic<long long> g_mesh_rows_count{0};  // assemblies that took the row-owner form (tests, bench.py)
+static std::atomic<long long> g_mesh_rows_count{0};
+int g_mesh_gather_rows = 0;  // mfem_debug_set("mesh_gather_rows"): 1 = the gather by row of round 5 (A/B, tests)  // assemblies that took the row-owner form (tests, bench.py)
 extern "C" int64_t mfem_debug_mesh_rows_count(void) { return g_mesh_rows_count; }
 // element-matrix scratch the row-owner form may take from the context workspace (288 GB of HBM: hex-20 elasticity at 128^3 needs 60 GB)
 static const size_t MG_SCRATCH_BUDGET = (size_t)96 << 30;
@@ -476,7 +477,7 @@ template <typename RP>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_gather(int itp, int64_t ncp, GatherBlocks B, const RP* __restrict__ rowptr,
                                                               int cbase, const int64_t* __restrict__ adj_ptr,
                                                               const int32_t* __restrict__ adj, const uint16_t* __restrict__ ranks,
-                                                              const double* __restrict__ S, double* __restrict__ K, int maxrow) {
+                                                              const double* __restrict__ S, double* __restrict__ K, int maxrow, int set) {
   extern __shared__ double gl[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   double* vals = gl + (size_t)w * maxrow;
@@ -528,17 +529,113 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_gather(int itp, int64_t ncp
         }
       }
     }
-    for (int t = lane; t < len; t += 64) K[lo + t] += vals[t];
+    if (set) for (int t = lane; t < len; t += 64) K[lo + t] = vals[t];
+    else for (int t = lane; t < len; t += 64) K[lo + t] += vals[t];
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
-                                                const double* ref_itp_vals, const double* itg_weight, const double* coords,
-                                                const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
-                                                const mfem_const_term* terms, int32_t n_fields, mfem_csr A,
-                                                const int64_t* adj_ptr, const int32_t* adj, const uint16_t* ranks,
-                                                double* K_val) try {
+// Round 6: the gather by NODE for blocks x nodes <= 64 (hex-20 with up to three fields, hex-8 with up to four).  The rows of a node's NF fields share the
+// adjacency list and the ranks: one pointer chase (adj_ptr -> adj -> scratch) per node instead of one per row, all NF x 8 scratch loads of a lane in flight
+// together; and a wave takes G = 64 / (blocks x nodes) nodes side by side (three for one field on hex-20, where a row's 20 lanes left 44 idle).  The
+// additions into a row keep the order of k_mesh_gather (adjacency entries in sequence): the same bits.
+#ifndef MGN_TB
+#define MGN_TB 4
+#endif
+template <typename RP, int NF>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_gather_nodes(int itp, int64_t ncp, GatherBlocks B, const RP* __restrict__ rowptr,
+                                                                    int cbase, const int64_t* __restrict__ adj_ptr,
+                                                                    const int32_t* __restrict__ adj, const uint16_t* __restrict__ ranks,
+                                                                    const double* __restrict__ S, double* __restrict__ K, int maxrow, int work, int G, int set) {
+  extern __shared__ double gl[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double* wave_vals = gl + (size_t)w * G * NF * maxrow;  // [G][NF][maxrow]
+  for (int t = lane; t < G * NF * maxrow; t += 64) wave_vals[t] = 0.0;
+  const int g = lane / work, u = lane - g * work;
+  const int kk = u / itp, b = u - kk * itp;
+  double* vals = wave_vals + (size_t)(g < G ? g : 0) * NF * maxrow;
+  bool lane_on[NF];
+  int kidx[NF], fbase[NF];
+#pragma unroll
+  for (int fd = 0; fd < NF; ++fd) {
+    lane_on[fd] = g < G && kk < B.cnt[fd];
+    kidx[fd] = lane_on[fd] ? B.k[fd][kk] : 0;
+    fbase[fd] = lane_on[fd] ? B.fb[fd][kk] : 0;
+  }
+  // adjacency entries per batch: NF x TB scratch loads of a lane in flight (registers -> resident waves: this kernel lives on the number of pointer chases in flight)
+  constexpr int TB = MGN_TB;
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t node0 = ((int64_t)blockIdx.x * nw + w) * G; node0 < ncp; node0 += (int64_t)gridDim.x * nw * G) {
+    const int64_t node = node0 + g;
+    const bool live = g < G && node < ncp;
+    int64_t lo[NF];
+    int len[NF];
+#pragma unroll
+    for (int fd = 0; fd < NF; ++fd) {
+      lo[fd] = live ? (int64_t)rowptr[(int64_t)fd * ncp + node] - cbase : 0;
+      len[fd] = live ? (int)((int64_t)rowptr[(int64_t)fd * ncp + node + 1] - cbase - lo[fd]) : 0;
+    }
+    const int64_t j0 = live ? adj_ptr[node] : 0, j1 = live ? adj_ptr[node + 1] : 0;
+    for (int64_t jb = j0; __any(jb < j1); jb += TB) {
+      const int nj = (int)(j1 - jb < 0 ? 0 : j1 - jb < TB ? j1 - jb : TB);
+      double v[NF][TB];
+      int rk[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        rk[t] = 0;
+#pragma unroll
+        for (int fd = 0; fd < NF; ++fd) v[fd][t] = 0.0;
+        if (t < nj) {
+          const int32_t ea = adj[jb + t];
+          const int64_t el = ea / itp;
+          const int a = ea - (int)el * itp;
+          const int64_t srow = ((int64_t)el * itp + a) * B.nb;
+#pragma unroll
+          for (int fd = 0; fd < NF; ++fd)
+            if (lane_on[fd]) v[fd][t] = S[(srow + kidx[fd]) * itp + b];
+          rk[t] = ranks[(jb + t) * itp + b];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        if (t < nj) {  // within a step the lanes of a node hit distinct positions, the steps run in sequence
+#pragma unroll
+          for (int fd = 0; fd < NF; ++fd)
+            if (lane_on[fd]) vals[fd * maxrow + fbase[fd] * (len[fd] / NF) + rk[t]] += v[fd][t];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the rows leave as whole waves
+    for (int gg = 0; gg < G; ++gg) {
+      if (node0 + gg >= ncp) break;
+#pragma unroll
+      for (int fd = 0; fd < NF; ++fd) {
+        const int64_t rlo = __shfl(lo[fd], gg * work);
+        const int rlen = __shfl(len[fd], gg * work);
+        double* rv = wave_vals + ((size_t)gg * NF + fd) * maxrow;
+        if (set) {  // (the rows are the first thing K receives: nothing to read)
+          for (int t = lane; t < rlen; t += 64) {
+            K[rlo + t] = rv[t];
+            rv[t] = 0.0;
+          }
+        } else {
+          for (int t = lane; t < rlen; t += 64) {
+            K[rlo + t] += rv[t];
+            rv[t] = 0.0;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static int mesh_rows(mfem_context_s* ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp, const double* ref_itp_vals,
+                     const double* itg_weight, const double* coords, const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                     const mfem_const_term* terms, int32_t n_fields, mfem_csr_s* A, const int64_t* adj_ptr, const int32_t* adj,
+                     const uint16_t* ranks, double* K_val, int overwrite) {
   MFEM_REQUIRE(ctx && A, "null handle");
   MFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   MFEM_REQUIRE(itg > 0 && itp > 0 && nel >= 0 && ncp > 0, "bad sizes");
@@ -580,18 +677,64 @@ extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, i
   const int64_t nrows = (int64_t)n_fields * ncp;
   const int maxrow = (A->max_row_nnz + 15) & ~15;
   const int waves = 4;
+  int work = 0;
+  for (int fd = 0; fd < n_fields; ++fd) work = B.cnt[fd] * itp > work ? B.cnt[fd] * itp : work;
+  int G = work > 0 && work <= 64 ? 64 / work : 0;
+  auto lds_nodes = [&](int g) { return sizeof(double) * (size_t)maxrow * waves * g * n_fields; };
+  while (G > 1 && lds_nodes(G) > 32 * 1024) --G;  // (long rows: fewer nodes side by side)
+  if (G > 0 && lds_nodes(G) <= 64 * 1024 && !g_mesh_gather_rows) {  // by node (k_mesh_gather_nodes)
+    const size_t ldsn = lds_nodes(G);
+    const int gridn = mfem_grid_for((ncp + G - 1) / G, waves, ctx->num_cus * 16);
+#define MG_NODES(RP, NF)                                                                                                                    \
+  hipLaunchKernelGGL((k_mesh_gather_nodes<RP, NF>), dim3(gridn), dim3(64 * waves), ldsn, ctx->stream, itp, ncp, B, (const RP*)A->rowptr, \
+                     A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow, work, G, overwrite)
+#define MG_FIELDS(RP)                                \
+  do {                                               \
+    if (n_fields == 1) MG_NODES(RP, 1);              \
+    else if (n_fields == 2) MG_NODES(RP, 2);         \
+    else if (n_fields == 3) MG_NODES(RP, 3);         \
+    else MG_NODES(RP, 4);                            \
+  } while (0)
+    if (A->rowptr_bits == 64) MG_FIELDS(int64_t); else MG_FIELDS(int32_t);
+#undef MG_FIELDS
+#undef MG_NODES
+    MFEM_CHECK_LAUNCH();
+    ++g_mesh_rows_count;
+    return MFEM_OK;
+  }
   const size_t ldsb = sizeof(double) * (size_t)maxrow * waves;
   const int grid = mfem_grid_for(nrows, waves, ctx->num_cus * 32);
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL(k_mesh_gather<int64_t>, dim3(grid), dim3(64 * waves), ldsb, ctx->stream, itp, ncp, B, (const int64_t*)A->rowptr,
-                       A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow);
+                       A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow, overwrite);
   else
     hipLaunchKernelGGL(k_mesh_gather<int32_t>, dim3(grid), dim3(64 * waves), ldsb, ctx->stream, itp, ncp, B, (const int32_t*)A->rowptr,
-                       A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow);
+                       A->index_base, adj_ptr, adj, ranks, S, K_val, maxrow, overwrite);
   MFEM_CHECK_LAUNCH();
   ++g_mesh_rows_count;
   return MFEM_OK;
+}
+
+extern "C" int mfem_mesh_assemble_elements_rows(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                                const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                                const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                                const mfem_const_term* terms, int32_t n_fields, mfem_csr A,
+                                                const int64_t* adj_ptr, const int32_t* adj, const uint16_t* ranks,
+                                                double* K_val) try {
+  return mesh_rows(ctx, dim, itg, itp, nel, ncp, ref_itp_vals, itg_weight, coords, controlpoint_IDs, index_base, n_terms, terms, n_fields, A, adj_ptr,
+                   adj, ranks, K_val, 0);
 } MFEM_API_CATCH("mfem_mesh_assemble_elements_rows")
+
+extern "C" int mfem_mesh_assemble_elements_rows_set(mfem_context ctx, int32_t dim, int32_t itg, int32_t itp, int64_t nel, int64_t ncp,
+                                                    const double* ref_itp_vals, const double* itg_weight, const double* coords,
+                                                    const int32_t* controlpoint_IDs, int32_t index_base, int32_t n_terms,
+                                                    const mfem_const_term* terms, int32_t n_fields, mfem_csr A,
+                                                    const int64_t* adj_ptr, const int32_t* adj, const uint16_t* ranks,
+                                                    double* K_val) try {
+  MFEM_REQUIRE(nel > 0, "the overwriting form needs elements (an empty mesh leaves K_val untouched)");
+  return mesh_rows(ctx, dim, itg, itp, nel, ncp, ref_itp_vals, itg_weight, coords, controlpoint_IDs, index_base, n_terms, terms, n_fields, A, adj_ptr,
+                   adj, ranks, K_val, 1);
+} MFEM_API_CATCH("mfem_mesh_assemble_elements_rows_set")
 
 extern "C" int mfem_mesh_assemble_facets(mfem_context ctx, int32_t dim, int32_t itg_b, int32_t itp, int32_t n_face_ids,
                                          int64_t n_facets, int64_t ncp, const double* bdy_ref_itp_vals,

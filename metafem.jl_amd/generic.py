@@ -341,15 +341,20 @@ class GenericDomain:
             arr = (_lib.ConstTerm * len(chunk))(*[_lib.ConstTerm(t.dual_s, t.base_s, t.dual_pos * self.n_fields + t.base_pos, 0,
                                                                  c * self.K_params[t.td_order]) for t, c in chunk])
             if g.facet_el is None and self.row_owner and self._row_ranks() is not None:
-                rc = lib.mfem_mesh_assemble_elements_rows(self.ctx._h, self.dim, self.space.itg, self.itp, self.nel, self.ncp,
+                fresh = getattr(self, "_K_fresh", False) and K is self.K_linear and self.nel > 0
+                fn = lib.mfem_mesh_assemble_elements_rows_set if fresh else lib.mfem_mesh_assemble_elements_rows
+                rc = fn(self.ctx._h, self.dim, self.space.itg, self.itp, self.nel, self.ncp,
                                                           self._ref.data_ptr(), self._itgw.data_ptr(), self.coords.data_ptr(),
                                                           self.cp.data_ptr(), 1, len(chunk), arr, self.n_fields, self.A._h,
                                                           self._adj_ptr.data_ptr(), self._adj.data_ptr(), self._row_ranks().data_ptr(),
                                                           K.data_ptr())
                 if rc == 0:
+                    if fresh:
+                        self._K_fresh = False
                     continue
                 if rc != -3:  # MFEM_ERR_UNSUPPORTED (row too long / scratch too large) falls back to the scatter form
                     check(rc)
+            self._K_started(K)
             if g.facet_el is None:
                 check(lib.mfem_mesh_assemble_elements(self.ctx._h, self.dim, self.space.itg, self.itp, self.nel, self.ncp,
                                                       self._ref.data_ptr(), self._itgw.data_ptr(), self.coords.data_ptr(),
@@ -365,7 +370,9 @@ class GenericDomain:
 
     # -- generated updater bodies -------------------------------------------------------------------
     def K_linear_func(self):
-        self.K_linear.zero_()
+        # K_linear starts from zero (05_CodeGenerator.jl:282).  When the first thing it receives is the row-owner element assembly, that launch WRITES
+        # every row instead (mfem_mesh_assemble_elements_rows_set): no memset, no read of the zeros.
+        self._K_fresh = True
         for wf, g in self._parts():
             if not wf.linear_gradients:
                 continue
@@ -378,6 +385,7 @@ class GenericDomain:
                     self._assemble_const(g, cterms, self.K_linear)
                 if not terms:
                     continue
+            self._K_started(self.K_linear)
             env: dict = {}
             self._externals(wf, g, env)
             w = self._w(g)
@@ -386,6 +394,13 @@ class GenericDomain:
                 continue
             for t in terms:
                 self._kval(g, t, self._vals(t.fn, env, w, self.K_params[t.td_order]), self.K_linear)
+        self._K_started(self.K_linear)
+
+    def _K_started(self, K: torch.Tensor):
+        """Zero K unless something has been put into it since K_linear_func began."""
+        if getattr(self, "_K_fresh", False):
+            K.zero_()
+            self._K_fresh = False
 
     def K_nonlinear_func(self):
         self.residue.zero_()

@@ -401,8 +401,19 @@ def test_fused_mesh_assembly_equals_the_operator_path(mf, case, coloured):
         gd.update_Time()
         gd.K_linear_func()
         doms.append(gd.K_linear.cpu().numpy())
+        if len(doms) == 1:
+            gd_rows = gd
     a, b = doms[0], doms[-1]
     assert np.abs(b).max() > 0
     assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
     if rows and case != "cavity":  # fixed summation order (the facet terms of these cases hit disjoint entries per launch... or are coloured)
-        pass
+        # the gather by node (round 6: several nodes per wave, a node's field rows together) against the gather by row
+        from metafem_jl_amd import _lib
+
+        _lib.lib.mfem_debug_set_mesh_gather_rows(1)
+        try:
+            gd_rows.K_linear_func()
+            by_row = gd_rows.K_linear.cpu().numpy()
+        finally:
+            _lib.lib.mfem_debug_set_mesh_gather_rows(0)
+        assert np.abs(by_row - doms[0]).max() <= 1e-14 * np.abs(doms[0]).max()  # (the facets add with atomics: bitwise is tests/test_gpu_u20.py, elements alone)

@@ -75,6 +75,38 @@ def test_small_mesh_against_the_oracle(mf, B, fields):
     assert st.converged == 1 and np.abs(dx.cpu().numpy() - ref).max() <= 1e-7 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("fields", [1, 2, 3])
+def test_gather_by_node_adds_in_the_order_of_the_gather_by_row(mf, B, fields):
+    """Elements alone (no facet launches: those add with atomics), 6^3 hex-20 in shuffled blocks: the row-owner assembly twice and once with the round-5
+    gather (one wave per row) -- the same bits (k_mesh_gather_nodes: three nodes per wave with one field, a node's field rows together with more)."""
+    import bench_legs as L
+    from metafem_jl_amd import _lib, generic as G, physics
+
+    B._umesh_key = None
+    space, msh, fac = B.unstructured_mesh(6, block=8)
+    if fields == 1:
+        wf = physics.thermal_domain(3, L.K_COND)
+    elif fields == 3:
+        wf = physics.elasticity_domain(3, L.LAM, L.MU)
+    else:
+        wf = physics.elasticity_domain(2, L.LAM, L.MU)  # two fields coupled through d/dx, d/dy on the 3-D mesh
+    gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, fields, wf, [])
+    rows0 = int(_lib.lib.mfem_debug_mesh_rows_count())
+    gd.K_linear_func()
+    assert int(_lib.lib.mfem_debug_mesh_rows_count()) > rows0
+    a = gd.K_linear.cpu().numpy().copy()
+    gd.K_linear_func()
+    assert np.array_equal(a, gd.K_linear.cpu().numpy())
+    _lib.lib.mfem_debug_set_mesh_gather_rows(1)
+    try:
+        gd.K_linear_func()
+        by_row = gd.K_linear.cpu().numpy()
+    finally:
+        _lib.lib.mfem_debug_set_mesh_gather_rows(0)
+    assert np.abs(a).max() > 0 and np.array_equal(a, by_row)
+    B._umesh_key = None
+
+
 @pytest.mark.parametrize("fields", [1, 3])
 def test_full_size_properties(mf, B, fields):
     """96^3 hex-20 elements (3.6 M control points; 1.9e9 nonzeros with three fields), unstructured: properties that hold at any size."""
