@@ -187,6 +187,9 @@ int mfem_debug_fail_host_alloc(int nth);
 /* The gather of mfem_mesh_assemble_elements_rows runs by NODE when a node's blocks x element nodes fit a wave (round 6: the rows of a node's fields share one
  * adjacency walk, several nodes per wave); 1 = by row, as in round 5 (A/B and the bitwise comparison in tests/test_gpu_unstructured.py). */
 /* ^ key "mesh_gather_rows": mfem_debug_set("mesh_gather_rows", a, b) with (int by_row) = (a[, b]) */
+/* TIMING ONLY (wrong results): phases of k_mesh_assemble left out -- 1 the pair products, 2 the stores of the row-owner form, 4 the geometry, 8 the
+ * physical table, 16 the coordinate gather (tools/u20_assembly_ab.py). */
+/* ^ key "mesh_abl": mfem_debug_set("mesh_abl", a, b) with (int bits) = (a[, b]) */
 int mfem_debug_remainder_info(mfem_csr A, int64_t* rows /* [host] */, int64_t* entries /* [host] */, double* asym_before /* [host] */);
 long long mfem_debug_rem_spmv_count(void);
 

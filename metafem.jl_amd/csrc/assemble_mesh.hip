@@ -40,6 +40,8 @@ struct MeshItems {
   int base;
 };
 
+int g_mesh_abl = 0;  // mfem_debug_set("mesh_abl"): ablation of k_mesh_assemble phases (tools/u20_assembly_ab.py): 1 no pair products, 2 no stores, 4 no geometry, 8 no table, 16 no coordinate gather
+
 template <int DIM>
 __device__ __forceinline__ double ma_inv(const double (&J)[3][3], double (&I)[3][3]) {
   if (DIM == 2) {
@@ -73,22 +75,40 @@ __device__ __forceinline__ double ma_inv(const double (&J)[3][3], double (&I)[3]
 // LDS once per workgroup and every wave then walks its share of the elements.  With a wave per element and the table read from the L2 an element took
 // 38 us of a wave's time at 96^3 (three dependent phases of L2 round trips: 20 x 3 table reads per lane for the Jacobian alone); staging it per ELEMENT had
 // been measured slower in round 2 (1.25 against 0.91 ms at 32^3) -- the copy has to be amortised over many elements.
-template <int DIM, int S0, int NS, int OUT, bool STAGE = false>
+//   The pair products of the STAGE form: a lane takes 4 dual x 2 base nodes (hex-20: 50 lanes, ONE round; 19 LDS reads per Gauss point for 8 pairs where the
+//   4 x 1 form of the first version read 16 for 4), and the terms are applied as a dense coefficient matrix per sparse block, built once per workgroup in
+//   LDS (the term list in the kernel arguments cost three dependent scalar loads and a branch per term and pair group: 4.8 of 15.3 ms on hex-20
+//   elasticity, 21 terms).  DIAGT: every term pairs a word with itself (thermal: grad . grad) -- 3 products per pair and Gauss point instead of 9.
+template <int DIM, int S0, int NS, int OUT, bool STAGE = false, bool DIAGT = false>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, ConstTerms T, const int32_t* __restrict__ slots,
                                                                 int64_t block_stride, double* __restrict__ K, int64_t t0,
-                                                                int64_t t1, int nb) {
+                                                                int64_t t1, int nb, int abl) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int itg = V.itg, itp = V.itp;
   const size_t per_wave = (size_t)itg * itp * NS + (size_t)itg * (1 + DIM * DIM) + (size_t)itp * DIM;
   const size_t ref_doubles = STAGE ? (size_t)itg * itp * (1 + DIM) : 0;
+  constexpr int NM = DIAGT ? NS : NS * NS;  // products kept per pair
+  const size_t coef_doubles = STAGE ? (size_t)nb * NM : 0;
   double* Rs = lds;                                          // [1 + DIM][itp][itg]: the reference table (STAGE)
-  double* Tt = lds + ref_doubles + (size_t)w * per_wave;     // [itg][itp][NS]
+  double* Cs = lds + ref_doubles;                            // [nb][NM]: block k = sum_c Cs[k][c] M[c] (STAGE)
+  double* Tt = lds + ref_doubles + coef_doubles + (size_t)w * per_wave;     // [itg][itp][NS]
   double* wd = Tt + (size_t)itg * itp * NS;     // [itg]
   double* Ji = wd + itg;                        // [itg][DIM*DIM]  J^-1
   double* X = Ji + (size_t)itg * DIM * DIM;     // [itp][DIM]
   if (STAGE) {
     for (int i = threadIdx.x; i < (int)ref_doubles; i += blockDim.x) Rs[i] = V.ref[i];
+    for (int c = threadIdx.x; c < (int)coef_doubles; c += blockDim.x) {  // terms in list order: a fixed sum
+      const int k = c / NM, m = c - k * NM;
+      double sum = 0.0;
+      int run = -1;
+      for (int i = 0; i < T.n; ++i) {
+        if (i == 0 || T.block[i] != T.block[i - 1]) ++run;
+        const int sel = DIAGT ? T.ds[i] - S0 : (T.ds[i] - S0) * NS + (T.bs[i] - S0);
+        if (run == k && sel == m) sum += T.coef[i];
+      }
+      Cs[c] = sum;
+    }
     __syncthreads();  // (the only workgroup barrier: every wave reaches it)
   }
   for (int64_t t = t0 + (int64_t)blockIdx.x * nw + w; t < t1; t += (int64_t)gridDim.x * nw) {  // (one trip unless STAGE: the grid covers the items)
@@ -97,7 +117,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   const int f = V.eindex ? V.eindex[h] - V.base : 0;
   const double* R = STAGE ? Rs : V.ref + (int64_t)f * V.ref_stride;
   const int32_t* cpe = V.cp + (int64_t)itp * el;
-  for (int i = lane; i < itp * DIM; i += 64) {
+  for (int i = lane; i < ((abl & 16) ? 0 : itp * DIM); i += 64) {
     const int a = i / DIM, d = i - a * DIM;
     X[i] = V.coords[((int64_t)cpe[a] - V.base) + (int64_t)d * V.ncp];
   }
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   // ---- geometry per Gauss point (lane <-> q)
-  for (int q = lane; q < itg; q += 64) {
+  for (int q = lane; q < ((abl & 4) ? 0 : itg); q += 64) {
     double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int a = 0; a < itp; ++a) {
 #pragma unroll
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   // ---- physical table T[q][a][s - S0]  (lane <-> (q, a))
-  for (int i = lane; i < itg * itp; i += 64) {
+  for (int i = lane; i < ((abl & 8) ? 0 : itg * itp); i += 64) {
     const int q = i % itg, a = i / itg;
     double* o = Tt + ((size_t)q * itp + a) * NS;
     if (S0 == 0) o[0] = R[q + itg * a];
@@ -170,6 +190,74 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   __builtin_amdgcn_wave_barrier();
   // ---- node pairs over the lanes
   const int npair = itp * itp;
+  if (STAGE) {
+    constexpr int TA = 4, TB = 2;
+    const int ng = (itp + TA - 1) / TA, nbp = (itp + TB - 1) / TB;
+    for (int w_ = lane; w_ < ng * nbp; w_ += 64) {
+      const int ag = w_ / nbp, bp = w_ - ag * nbp, a0 = ag * TA, b0 = bp * TB;
+      double M[TA][TB][NM];
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+          for (int c = 0; c < NM; ++c) M[i][j][c] = 0.0;
+      {
+        const double* ta[TA];
+        const double* tb[TB];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) ta[i] = Tt + (a0 + i < itp ? a0 + i : itp - 1) * NS;  // (a group cut by the element: its last node again, not stored)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) tb[j] = Tt + (b0 + j < itp ? b0 + j : itp - 1) * NS;
+        const int qs = itp * NS;
+        const int nq = (abl & 1) ? 0 : itg;
+#pragma unroll 3
+        for (int q = 0; q < nq; ++q) {
+          const double wq_ = wd[q];
+          double vb[TB][NS];
+#pragma unroll
+          for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) vb[j][s] = tb[j][q * qs + s] * wq_;
+#pragma unroll
+          for (int i = 0; i < TA; ++i) {
+            double va[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) va[s] = ta[i][q * qs + s];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+              if (DIAGT) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) M[i][j][s] += va[s] * vb[j][s];
+              } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                  for (int u = 0; u < NS; ++u) M[i][j][s * NS + u] += va[s] * vb[j][u];
+              }
+            }
+          }
+        }
+      }
+      for (int k = 0; k < nb; ++k) {
+        double ck[NM];
+#pragma unroll
+        for (int c = 0; c < NM; ++c) ck[c] = Cs[k * NM + c];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+          double* dst = K + (((int64_t)el * itp + (a0 + i)) * nb + k) * itp + b0;
+#pragma unroll
+          for (int j = 0; j < TB; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int c = 0; c < NM; ++c) sum += ck[c] * M[i][j][c];
+            if (a0 + i < itp && b0 + j < itp && !(abl & 2)) dst[j] = sum;
+          }
+        }
+      }
+    }
+    continue;
+  }
   if (OUT == 2 && itp >= 16) {
     // Row-owner (scratch) form on elements of 16+ nodes (hex-20, hex-27): a lane takes FOUR dual nodes a for one base node b.  The pair loop is bound by
     // LDS bandwidth -- 7 reads per pair and Gauss point with a pair per lane (w, 3 + 3 table entries; hex-20: 677 KB per element) --; with the b side and
@@ -189,8 +277,9 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
 #pragma unroll
         for (int i = 0; i < TA; ++i) ta[i] = Tt + (a0 + i < itp ? a0 + i : itp - 1) * NS;  // (a group cut by the element: its last node again, not stored)
         const int qs = itp * NS;
+        const int nq = (abl & 1) ? 0 : itg;
 #pragma unroll 3
-        for (int q = 0; q < itg; ++q) {
+        for (int q = 0; q < nq; ++q) {
           const double wq_ = wd[q];
           double vb[NS];
 #pragma unroll
@@ -226,7 +315,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
         }
 #pragma unroll
         for (int t = 0; t < TA; ++t)
-          if (a0 + t < itp) K[(((int64_t)el * itp + (a0 + t)) * nb + krun) * itp + b] = sum[t];
+          if (a0 + t < itp && !(abl & 2)) K[(((int64_t)el * itp + (a0 + t)) * nb + krun) * itp + b] = sum[t];
         ++krun;
       }
     }
@@ -300,7 +389,9 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
   const size_t per_wave = sizeof(double) * ((size_t)V.itg * V.itp * NS + (size_t)V.itg * (1 + dim * dim) + (size_t)V.itp * dim);
   // the row-owner form on elements with a table worth staging (16+ nodes): persistent workgroups, the reference table in LDS (k_mesh_assemble: STAGE)
   const bool stage = scratch_blocks > 0 && !V.eindex && !V.order && V.itp >= 16 && n_colours == 0;
-  const size_t shared_ref = stage ? sizeof(double) * (size_t)V.itg * V.itp * (1 + dim) : 0;
+  bool diag = true;  // every term pairs a word with itself
+  for (int i = 0; i < T.n; ++i) diag = diag && T.ds[i] == T.bs[i];
+  const size_t shared_ref = stage ? sizeof(double) * ((size_t)V.itg * V.itp * (1 + dim) + (size_t)scratch_blocks * (diag ? NS : NS * NS)) : 0;
   int waves = 4;
   const size_t lds_cap = stage ? 96 * 1024 : 64 * 1024;  // (a workgroup may take up to 160 KB on gfx950; two staged workgroups per CU at hex-20)
   while (waves > 1 && shared_ref + per_wave * waves > lds_cap) waves >>= 1;
@@ -320,15 +411,21 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
     }
 #define MA_LAUNCH(D, S0, NSS, AT)                                                                                             \
   do {                                                                                                                        \
-    if (stage && AT == 2) {                                                                                                   \
+    if (stage && AT == 2 && diag) {                                                                                           \
+      if (ldsb > 64 * 1024)                                                                                                   \
+        MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_assemble<D, S0, NSS, 2, true, true>),       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));                         \
+      hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, 2, true, true>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, \
+                         slots, block_stride, K, a, b, scratch_blocks, g_mesh_abl);                                          \
+    } else if (stage && AT == 2) {                                                                                            \
       if (ldsb > 64 * 1024)                                                                                                   \
         MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_assemble<D, S0, NSS, 2, true>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));                         \
       hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, 2, true>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots, \
-                         block_stride, K, a, b, scratch_blocks);                                                             \
+                         block_stride, K, a, b, scratch_blocks, g_mesh_abl);                                                             \
     } else                                                                                                                    \
       hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, AT>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots,     \
-                         block_stride, K, a, b, scratch_blocks);                                                             \
+                         block_stride, K, a, b, scratch_blocks, g_mesh_abl);                                                             \
   } while (0)
 #define MA_MODE(D, AT)                                  \
   do {                                                  \
