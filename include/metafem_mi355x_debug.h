@@ -184,6 +184,13 @@ int mfem_debug_fail_host_alloc(int nth);
 /* TEST HOOK: the residual a single-rank tile solve recomputes from the caller's CSR values before it ends the passes is multiplied by `scale`
  * (default 1; <= 0 resets): lets a test put the tiles' residual and the caller's on the two sides of the tolerance */
 /* ^ key "recheck_scale_ppm": mfem_debug_set("recheck_scale_ppm", a, b) with (a = scale in millionths) = (a[, b]) */
+/* Node-blocked sliced layout (round 6, csrc/spmv_sell.hip "BSELL"): mode 3 on a field-major F-field matrix (F = 2, 3, 4) whose F rows of a node share
+ * the node's coupling list -- a lane owns a node: one column index and F gathers of x per F x F values.  Taken for patterns without a lattice hint and
+ * without ghost columns.  0 = off (the row-sorted form, as before; read when the pattern's layout is planned).
+ * mfem_debug_bsell_fields: F of the pattern's planned layout (0: row-sorted form, -1: null handle); mfem_debug_bsell_spmv_count: products so far. */
+/* ^ key "bsell": mfem_debug_set("bsell", a, b) with (int on) = (a[, b]) */
+int mfem_debug_bsell_fields(mfem_csr A);
+long long mfem_debug_bsell_spmv_count(void);
 /* The gather of mfem_mesh_assemble_elements_rows runs by NODE when a node's blocks x element nodes fit a wave (round 6: the rows of a node's fields share one
  * adjacency walk, several nodes per wave); 1 = by row, as in round 5 (A/B and the bitwise comparison in tests/test_gpu_unstructured.py). */
 /* ^ key "mesh_gather_rows": mfem_debug_set("mesh_gather_rows", a, b) with (int by_row) = (a[, b]) */

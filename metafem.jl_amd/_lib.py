@@ -135,6 +135,8 @@ SIGNATURES = {
     "mfem_debug_hex27_mixed_count": (c_int64, []),
     "mfem_debug_hex27_rows_count": (c_int64, []),
     "mfem_debug_mesh_rows_count": (c_int64, []),
+    "mfem_debug_bsell_fields": (c_int, [P]),
+    "mfem_debug_bsell_spmv_count": (c_int64, []),
     "mfem_debug_sell_periodic_blocks": (c_int64, [P]),
     "mfem_debug_symp_fingerprint_count": (C.c_longlong, []),
     "mfem_debug_set": (c_int, [C.c_char_p, c_int64, c_int64]),

@@ -197,6 +197,11 @@ struct mfem_csr_s {
   int64_t sell_shift;           // column shift between two fields
   int32_t sell_periodic_blocks;
   int32_t sell_sig_sorted;      // 1: the diagonal-list signature took part in the row sort (lattice patterns); 0: mesh order within a length (unstructured)
+  // node-blocked form (round 6, "BSELL"): a field-major F-field matrix whose F rows of a node share the node's coupling list (every FEM pattern of
+  // mfem_pattern_build) -- a lane owns a NODE: per coupled node one column index, F gathers of x and F x F values.  bsell_F > 0: the sliced arrays are
+  // sell_rowid = sorted position -> node, sell_ptr = [node blocks + 1] in node slots x 64, sell_cols = node-level columns, sell_total = value entries
+  int32_t bsell_F;
+  int64_t bsell_ncp, bsell_slots;
   const double* sell_src;
   double* sell_vals;        // not owned (solver workspace), [sell_total]
   // symmetric lattice-tile layout of the hex-27 lattice matrix (spmv_lat27.hip): lat27_state 0 = not inspected, -1 = no, 1 = the pattern is the stencil

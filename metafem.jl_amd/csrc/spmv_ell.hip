@@ -2079,6 +2079,7 @@ extern "C" int mfem_csr_solver_layout_bytes(mfem_context ctx, mfem_csr A, int64_
     const double per = (A->sell_nblk > 0 && A->sell_fields > 1) ? (double)A->sell_periodic_blocks / (double)A->sell_nblk : 0.0;
     const double colfrac = (1.0 - reg - per) + (A->sell_fields > 1 ? per / (double)A->sell_fields : 0.0);
     b = A->sell_total * 8 + (int64_t)(colfrac * (double)A->sell_total) * 4 + A->n * 16 + A->n * 4;  // + the row permutation
+    if (A->bsell_F > 0) b = A->sell_total * 8 + A->bsell_slots * 4 + A->n * 16 + A->bsell_ncp * 4;  // node-blocked: one column per F x F values
   }
   if (mode == 4) b = mfem_lat27_design_bytes(A);
   if (mode == 5) b = mfem_lat8_design_bytes(A);
@@ -2121,7 +2122,7 @@ extern "C" int mfem_csr_solver_layout(mfem_context ctx, mfem_csr A, int32_t* mod
   }
   if (mode) *mode = m;
   if (slots) *slots = (m == 1 || m == 2) ? A->ell_K : m >= 3 ? A->max_row_nnz : 0;
-  if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? A->sell_nblk * 128 : 0;
+  if (padded_rows) *padded_rows = (m == 1 || m == 2) ? A->ell_npad : m == 3 ? (A->bsell_F > 0 ? A->sell_nblk * 64 * A->bsell_F : A->sell_nblk * 128) : 0;
   if (regular_rows) *regular_rows = m == 2 ? (int64_t)A->dia_regular_blocks * 128 : 0;
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_csr_solver_layout")

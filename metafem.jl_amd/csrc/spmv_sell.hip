@@ -301,6 +301,201 @@ __device__ __forceinline__ void sell_periodic_block(int Kb, int64_t shift, const
   }
 }
 
+// =====================================================================================================================================================
+// Node-blocked sliced layout ("BSELL", round 6) for field-major multi-field matrices on unstructured meshes: unknown (f, i) = f * ncp + i, and the rows
+// (0, i) .. (F - 1, i) of node i all list the nodes coupled to i, once per column field (what mfem_pattern_build makes for n_fields fields; checked entry
+// by entry by k_bsell_check).  The row-sorted layout above gives every ROW a lane: per value it reads a third of a column index (field-periodic blocks)
+// and gathers one x entry -- on hex-20 elasticity 96^3 the product moved 21.2 GB for 17.7 by design (x gathers that miss the L2s) at the HBM copy rate.
+// Here a lane owns a NODE: per coupled node ONE column index, F gathers of x and F x F values for the node's F row sums -- a ninth of the column stream,
+// a third of the gathers.  Nodes are stably sorted by their number of coupled nodes; a block is 64 nodes; slot t of a block holds, for each of its nodes,
+// the F x F values towards the node's t-th coupled node as F * F unit-stride runs of 64 doubles.
+// =====================================================================================================================================================
+static std::atomic<int> g_bsell_enable{1};  // bit 9 of mfem_debug_set_sell's word... (own key: mfem_debug_set("bsell", on))
+static std::atomic<long long> g_bsell_spmv_count{0};
+extern "C" int mfem_debug_set_bsell(int on) {
+  ++mfem_debug_epoch;
+  g_bsell_enable = on ? 1 : 0;
+  return MFEM_OK;
+}
+extern "C" long long mfem_debug_bsell_spmv_count(void) { return g_bsell_spmv_count; }
+extern "C" int mfem_debug_bsell_fields(mfem_csr A) { return A ? A->bsell_F : -1; }
+
+// bad[0] != 0: some node's rows do not have the node-blocked form
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_check(int64_t ncp, int F, const RP* __restrict__ rowptr, const int32_t* __restrict__ col, int base,
+                                                              int32_t* __restrict__ bad) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ncp; i += stride) {
+    const int64_t lo0 = (int64_t)rowptr[i] - base;
+    const int len = (int)((int64_t)rowptr[i + 1] - base - lo0);
+    bool ok = len % F == 0;
+    const int L = len / F;
+    for (int t = 0; ok && t < L; ++t) {
+      const int64_t c = (int64_t)col[lo0 + t] - base;
+      ok = c >= 0 && c < ncp;
+    }
+    for (int f = 0; ok && f < F; ++f) {
+      const int64_t lo = (int64_t)rowptr[(int64_t)f * ncp + i] - base;
+      ok = (int)((int64_t)rowptr[(int64_t)f * ncp + i + 1] - base - lo) == len;
+      for (int g = 0; ok && g < F; ++g)
+        for (int t = 0; ok && t < L; ++t) ok = (int64_t)col[lo + (int64_t)g * L + t] == (int64_t)col[lo0 + t] + (int64_t)g * ncp;
+    }
+    if (!ok) *bad = 1;
+  }
+}
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_keys(int64_t ncp, int F, int maxL, const RP* __restrict__ rowptr, uint32_t* __restrict__ keys,
+                                                             int32_t* __restrict__ ids) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ncp; i += stride) {
+    keys[i] = (uint32_t)(maxL - (int)(((int64_t)rowptr[i + 1] - (int64_t)rowptr[i]) / F));
+    ids[i] = (int32_t)i;
+  }
+}
+// node slots x 64 of every block (its first node is its longest)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_block_sizes(int64_t nblk, int F, const RP* __restrict__ rowptr, const int32_t* __restrict__ nodeid,
+                                                                    int64_t* __restrict__ sizes) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblk; b += stride) {
+    const int64_t i = nodeid[b * 64];
+    sizes[b] = ((int64_t)rowptr[i + 1] - (int64_t)rowptr[i]) / F * 64;
+  }
+}
+// node-level columns, 0-based (padding: the node itself, with zero values)
+template <typename RP>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_cols(int64_t ncp, int64_t nblk, int F, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                             int base, const int32_t* __restrict__ nodeid, const int64_t* __restrict__ ptr,
+                                                             int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < nblk; b += nwaves) {
+    const int64_t p0 = ptr[b];
+    const int Kb = (int)((ptr[b + 1] - p0) / 64);
+    const int64_t ns = b * 64 + lane;
+    int64_t lo = 0, i = 0;
+    int L = 0;
+    if (ns < ncp) {
+      i = nodeid[ns];
+      lo = (int64_t)rowptr[i] - base;
+      L = (int)(((int64_t)rowptr[i + 1] - base - lo) / F);
+    }
+    for (int t = 0; t < Kb; ++t) out[p0 + (int64_t)t * 64 + lane] = t < L ? col[lo + t] - base : (int32_t)i;
+  }
+}
+// values into the node-blocked layout (once per solve).  A lane quad per CSR row, 16 consecutive sorted nodes of one row field per wave pass: the quad
+// reads 32 contiguous bytes of its row per step, the 16 rows' stores of one slot are 128 contiguous bytes.  dsc != nullptr: entry / dsc[its column].
+template <typename RP, int F>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_fill(int64_t ncp, int64_t nblk, const RP* __restrict__ rowptr, const int32_t* __restrict__ nodeid,
+                                                             const int64_t* __restrict__ ptr, const double* __restrict__ src, int base,
+                                                             double* __restrict__ out, const int32_t* __restrict__ col, const double* __restrict__ dsc) {
+  const int lane = threadIdx.x & 63, g4 = lane & 3, q = lane >> 2;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p = wave; p < nblk * F * 4; p += nwaves) {
+    const int64_t b = p / (F * 4);
+    const int rem = (int)(p - b * (F * 4)), f = rem >> 2, sub = rem & 3;
+    const int64_t p0 = ptr[b];
+    const int Kb = (int)((ptr[b + 1] - p0) / 64);
+    const int nl = sub * 16 + q;  // the node's lane in the product kernel
+    const int64_t ns = b * 64 + nl;
+    int64_t lo = 0;
+    int L = 0;
+    if (ns < ncp) {
+      const int64_t i = nodeid[ns];
+      lo = (int64_t)rowptr[(int64_t)f * ncp + i] - base;
+      L = (int)(((int64_t)rowptr[(int64_t)f * ncp + i + 1] - base - lo) / F);
+    }
+    double* o = out + p0 * (F * F) + (int64_t)(f * F) * 64 + nl;
+#pragma unroll
+    for (int g = 0; g < F; ++g) {
+      const double* sg = src + lo + (int64_t)g * L;
+      const int32_t* cg = col + lo + (int64_t)g * L;
+      double* og = o + (int64_t)g * 64;
+      int t = g4;
+      for (; t + 12 < Kb; t += 16) {  // four loads of a lane in flight before the first store
+        double t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int tu = t + 4 * u;
+          t4[u] = tu < L ? (dsc ? sg[tu] / dsc[cg[tu] - base] : sg[tu]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) og[(int64_t)(t + 4 * u) * (64 * F * F)] = t4[u];
+      }
+      for (; t < Kb; t += 4) og[(int64_t)t * (64 * F * F)] = t < L ? (dsc ? sg[t] / dsc[cg[t] - base] : sg[t]) : 0.0;
+    }
+  }
+}
+
+// y = alpha A x + beta y: a wave per block of 64 nodes, a lane per node, U node slots (their F x F values, column and F x entries) in flight
+template <int F, int U>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_bsell(int64_t ncp, int64_t nblk, const int64_t* __restrict__ ptr, const int32_t* __restrict__ nodeid,
+                                                             const int32_t* __restrict__ cols, const double* __restrict__ vals, const double* __restrict__ x,
+                                                             double* __restrict__ y, double alpha, double beta, const double* __restrict__ dotw,
+                                                             double* __restrict__ partials, const int32_t* __restrict__ done_flag) {
+  __shared__ double red[4];
+  if (done_flag && done_flag[0]) return;
+  double dot_acc = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  constexpr int64_t SS = 64 * F * F;  // doubles per node slot of a block
+  for (int64_t b = wave; b < nblk; b += nwaves) {
+    const int64_t p0 = ptr[b];
+    const int Kb = (int)((ptr[b + 1] - p0) / 64);
+    const double* v = vals + p0 * (F * F) + lane;
+    const int32_t* c = cols + p0 + lane;
+    const int64_t ns = b * 64 + lane;
+    const int64_t node = ns < ncp ? nodeid[ns] : 0;
+    double acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.0;
+    int t = 0;
+    for (; t + U <= Kb; t += U) {
+      int32_t cu[U];
+      double vv[U][F * F], xx[U][F];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cu[u] = __builtin_nontemporal_load(c + (int64_t)(t + u) * 64);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int m = 0; m < F * F; ++m) vv[u][m] = __builtin_nontemporal_load(v + (int64_t)(t + u) * SS + m * 64);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int g = 0; g < F; ++g) xx[u][g] = x[(int64_t)cu[u] + (int64_t)g * ncp];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+          for (int g = 0; g < F; ++g) acc[f] += vv[u][f * F + g] * xx[u][g];
+    }
+    for (; t < Kb; ++t) {
+      const int64_t cc = c[(int64_t)t * 64];
+#pragma unroll
+      for (int g = 0; g < F; ++g) {
+        const double xg = x[cc + (int64_t)g * ncp];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] += __builtin_nontemporal_load(v + (int64_t)t * SS + (f * F + g) * 64) * xg;
+      }
+    }
+    if (ns < ncp) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const int64_t r = (int64_t)f * ncp + node;
+        double yv = alpha * acc[f];
+        if (beta != 0.0) yv += beta * y[r];
+        y[r] = yv;
+        if (dotw) dot_acc += yv * dotw[r];
+      }
+    }
+  }
+  if (partials) {
+    const double bsum = block_reduce_sum(dot_acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bsum;
+  }
+}
+
 template <int SELL_U>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nblk, const int64_t* __restrict__ ptr,
                                                             const int32_t* __restrict__ rowid, const int32_t* __restrict__ flags,
@@ -423,13 +618,125 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_spmv_sell(int64_t n, int64_t nbl
     }                                                                                       \
   } while (0)
 
+// Plans the node-blocked layout if the pattern has its form (F = 4, 3, 2 tried in that order).  A->bsell_F > 0 afterwards: taken.
+static int bsell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
+  A->bsell_F = 0;
+  if (!g_bsell_enable || A->ncols > A->n || A->lat_fields > 0) return MFEM_OK;  // (slab patterns with ghost columns and lattice patterns keep the row-sorted form)
+  int rc = MFEM_OK;
+  const int cand[3] = {4, 3, 2};  // the largest that fits (four fields also read as two super-fields of two, with four times the column indices)
+  int32_t* d_bad = ctx->d_flags + 9;
+  int F = 0;
+  for (int ci = 0; ci < 3 && F == 0; ++ci) {
+    const int f = cand[ci];
+    if (A->n % f != 0 || A->max_row_nnz % f != 0 || A->n / f < 64) continue;
+    const int64_t ncp = A->n / f;
+    MFEM_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
+    const int grid = mfem_grid_for(ncp, MFEM_BLOCK, ctx->num_cus * 16);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_bsell_check<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, ncp, f, (const int64_t*)A->rowptr, A->colidx, A->index_base, d_bad);
+    else
+      hipLaunchKernelGGL(k_bsell_check<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, ncp, f, (const int32_t*)A->rowptr, A->colidx, A->index_base, d_bad);
+    MFEM_CHECK_LAUNCH();
+    MFEM_CHECK_HIP(hipMemcpyAsync(ctx->h_flags + 9, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_flags[9] == 0) F = f;
+  }
+  if (F == 0) return MFEM_OK;
+  const int64_t ncp = A->n / F, nblk = (ncp + 63) / 64;
+  const int maxL = A->max_row_nnz / F;
+  uint32_t *keys = nullptr, *keys2 = nullptr;
+  int32_t *ids = nullptr, *nodeid = nullptr, *cols = nullptr;
+  int64_t *sizes = nullptr, *ptr = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0, tb2 = 0;
+  int64_t slots = 0;
+  const int grid = mfem_grid_for(ncp, MFEM_BLOCK, ctx->num_cus * 16);
+  int bits = 1;
+  while ((1 << bits) <= maxL && bits < 31) ++bits;
+  SELL_CHECK(hipMalloc(&keys, sizeof(uint32_t) * (size_t)ncp));
+  SELL_CHECK(hipMalloc(&keys2, sizeof(uint32_t) * (size_t)ncp));
+  SELL_CHECK(hipMalloc(&ids, sizeof(int32_t) * (size_t)ncp));
+  SELL_CHECK(hipMalloc(&nodeid, sizeof(int32_t) * (size_t)ncp));
+  SELL_CHECK(hipMalloc(&sizes, sizeof(int64_t) * (size_t)(nblk + 1)));
+  SELL_CHECK(hipMalloc(&ptr, sizeof(int64_t) * (size_t)(nblk + 1)));
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_bsell_keys<int64_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, ncp, F, maxL, (const int64_t*)A->rowptr, keys, ids);
+  else
+    hipLaunchKernelGGL(k_bsell_keys<int32_t>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, ncp, F, maxL, (const int32_t*)A->rowptr, keys, ids);
+  SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, ids, nodeid, (int)ncp, 0, bits, ctx->stream));
+  SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, sizes, ptr, (int)(nblk + 1), ctx->stream));
+  if (tb2 > tb) tb = tb2;
+  SELL_CHECK(hipMalloc(&tmp, tb));
+  SELL_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, ids, nodeid, (int)ncp, 0, bits, ctx->stream));  // stable: nodes of one length keep their mesh order
+  SELL_CHECK(hipMemsetAsync(sizes, 0, sizeof(int64_t) * (size_t)(nblk + 1), ctx->stream));
+  if (A->rowptr_bits == 64)
+    hipLaunchKernelGGL(k_bsell_block_sizes<int64_t>, dim3(mfem_grid_for(nblk, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK), 0, ctx->stream, nblk, F,
+                       (const int64_t*)A->rowptr, nodeid, sizes);
+  else
+    hipLaunchKernelGGL(k_bsell_block_sizes<int32_t>, dim3(mfem_grid_for(nblk, MFEM_BLOCK, ctx->num_cus * 16)), dim3(MFEM_BLOCK), 0, ctx->stream, nblk, F,
+                       (const int32_t*)A->rowptr, nodeid, sizes);
+  SELL_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sizes, ptr, (int)(nblk + 1), ctx->stream));
+  SELL_CHECK(hipMemcpyAsync(&slots, ptr + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  SELL_CHECK(hipStreamSynchronize(ctx->stream));
+  if ((double)slots * F * F <= 1.15 * (double)A->nnz + 128.0 * A->max_row_nnz * F) {
+    SELL_CHECK(hipMalloc(&cols, sizeof(int32_t) * (size_t)(slots > 0 ? slots : 1)));
+    const int g2 = mfem_grid_for(nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
+    if (A->rowptr_bits == 64)
+      hipLaunchKernelGGL(k_bsell_cols<int64_t>, dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, ncp, nblk, F, (const int64_t*)A->rowptr, A->colidx, A->index_base,
+                         nodeid, ptr, cols);
+    else
+      hipLaunchKernelGGL(k_bsell_cols<int32_t>, dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, ncp, nblk, F, (const int32_t*)A->rowptr, A->colidx, A->index_base,
+                         nodeid, ptr, cols);
+    if (hipGetLastError() != hipSuccess) {
+      mfem_set_error("k_bsell_cols launch failed");
+      rc = MFEM_ERR_HIP;
+      goto done;
+    }
+    A->sell_rowid = nodeid;
+    A->sell_ptr = ptr;
+    A->sell_cols = cols;
+    A->sell_flags = nullptr;
+    A->sell_off = nullptr;
+    A->sell_total = slots * F * F;
+    A->sell_nblk = nblk;
+    A->sell_nb_int = nblk;
+    A->sell_regular_blocks = 0;
+    A->sell_fields = F;
+    A->sell_shift = ncp;
+    A->sell_periodic_blocks = (int32_t)nblk;
+    A->sell_sig_sorted = 0;
+    A->bsell_F = F;
+    A->bsell_ncp = ncp;
+    A->bsell_slots = slots;
+    nodeid = nullptr;
+    ptr = nullptr;
+    cols = nullptr;
+  }
+done:
+  if (keys) hipFree(keys);
+  if (keys2) hipFree(keys2);
+  if (ids) hipFree(ids);
+  if (nodeid) hipFree(nodeid);
+  if (sizes) hipFree(sizes);
+  if (ptr) hipFree(ptr);
+  if (cols) hipFree(cols);
+  if (tmp) hipFree(tmp);
+  return rc;
+}
+
+
 // sell_state: 0 not planned, -1 not eligible, 1 ready
 int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   if (A->sell_state != 0) return MFEM_OK;
   if (A->n < g_layout_min_rows_cols) return MFEM_OK;  // launch-bound sizes stay on the CSR tile kernel: do not even sort
   A->sell_state = -1;
   if (A->n < SELL_B || A->nnz < 1 || A->max_row_nnz < 1 || A->n >= ((int64_t)1 << 31)) return MFEM_OK;
-  int rc = MFEM_OK;
+  int rc = bsell_plan(ctx, A);  // the node-blocked form first: a multi-field matrix on an unstructured mesh
+  if (rc) return rc;
+  if (A->bsell_F > 0) {
+    A->sell_state = 1;
+    return MFEM_OK;
+  }
   const int64_t n = A->n, nblk = (n + SELL_B - 1) / SELL_B;
   uint64_t *keys = nullptr, *keys2 = nullptr;
   int32_t *ids = nullptr, *rowid = nullptr;
@@ -600,6 +907,25 @@ int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   A->sell_vals = nullptr;
   A->sell_src = nullptr;
   if (A->sell_state != 1 || !g_sell_enable || !buf) return MFEM_OK;
+  if (A->bsell_F > 0) {
+    const int gb = mfem_grid_for(A->sell_nblk * A->bsell_F * 4 * 64, MFEM_BLOCK, ctx->num_cus * 16);
+#define BSELL_FILL(RP, F)                                                                                                                      \
+  hipLaunchKernelGGL((k_bsell_fill<RP, F>), dim3(gb), dim3(MFEM_BLOCK), 0, ctx->stream, A->bsell_ncp, A->sell_nblk, (const RP*)A->rowptr,    \
+                     A->sell_rowid, A->sell_ptr, vals, A->index_base, buf, A->colidx, dsc)
+#define BSELL_FILL_F(RP)                          \
+  do {                                            \
+    if (A->bsell_F == 3) BSELL_FILL(RP, 3);       \
+    else if (A->bsell_F == 2) BSELL_FILL(RP, 2);  \
+    else BSELL_FILL(RP, 4);                       \
+  } while (0)
+    if (A->rowptr_bits == 64) BSELL_FILL_F(int64_t); else BSELL_FILL_F(int32_t);
+#undef BSELL_FILL_F
+#undef BSELL_FILL
+    MFEM_CHECK_LAUNCH();
+    A->sell_vals = buf;
+    A->sell_src = vals;
+    return MFEM_OK;
+  }
   const int g2 = mfem_grid_for(8 * A->sell_nblk * 64, MFEM_BLOCK, ctx->num_cus * 16);
   if (A->rowptr_bits == 64)
     hipLaunchKernelGGL((k_sell_fill<int64_t, double, false>), dim3(g2), dim3(MFEM_BLOCK), 0, ctx->stream, A->n, A->sell_nblk,
@@ -632,6 +958,7 @@ void mfem_sell_free(mfem_csr_s* A) {
   A->sell_rowid = nullptr;
   A->sell_ptr = nullptr;
   A->sell_state = 0;
+  A->bsell_F = 0;
 }
 
 // returns 1 if launched, 0 if another kernel should be used, <0 on error
@@ -641,6 +968,28 @@ int mfem_spmv_sell_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* vals
   // part 1: the leading blocks, whose rows read no ghost column; part 2: the rest (mfem_spmv_halo)
   const int64_t b_lo = part == 2 ? A->sell_nb_int : 0, b_hi = part == 1 ? A->sell_nb_int : A->sell_nblk;
   if (n_partials) *n_partials = 0;
+  if (A->bsell_F > 0) {  // node-blocked form (no ghost columns: never split)
+    if (part == 2) return 1;
+    int capb = ctx->num_cus * g_sell_wg_per_cu;
+    if (capb > MFEM_MAX_PARTIALS) capb = MFEM_MAX_PARTIALS;
+    const int gridb = mfem_grid_for(A->sell_nblk * 64, MFEM_BLOCK, capb);
+#define BSELL_LAUNCH(F, U)                                                                                                                    \
+  hipLaunchKernelGGL((k_spmv_bsell<F, U>), dim3(gridb), dim3(MFEM_BLOCK), 0, ctx->stream, A->bsell_ncp, A->sell_nblk, A->sell_ptr, A->sell_rowid, \
+                     A->sell_cols, A->sell_vals, x, y, alpha, beta, dotw, partials, done_flag)
+    const int bu = g_sell_per_u;  // (A/B: node slots in flight)
+    if (A->bsell_F == 3) {  // (hex-20 elasticity 96^3, one box: 1 node slot in flight 2.98 ms, 2: 2.89, 3: 2.80)
+      if (bu == 1) BSELL_LAUNCH(3, 2);
+      else if (bu == 2) BSELL_LAUNCH(3, 4);
+      else if (bu == 3) BSELL_LAUNCH(3, 1);
+      else BSELL_LAUNCH(3, 3);
+    } else if (A->bsell_F == 2) BSELL_LAUNCH(2, 4);
+    else BSELL_LAUNCH(4, 2);
+#undef BSELL_LAUNCH
+    MFEM_CHECK_LAUNCH();
+    ++g_bsell_spmv_count;
+    if (n_partials && partials) *n_partials = gridb;
+    return 1;
+  }
   if (b_hi <= b_lo) return 1;
   int cap = ctx->num_cus * g_sell_wg_per_cu;
   if (cap > MFEM_MAX_PARTIALS) cap = MFEM_MAX_PARTIALS;

@@ -161,8 +161,8 @@ def test_full_size_properties(mf, B, fields):
     mode = C.c_int32()
     _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
     assert mode.value == 3
-    if fields == 3:  # the node list repeats per column field: nearly every block reads a third of its column stream
-        assert int(_lib.lib.mfem_debug_sell_periodic_blocks(A._h)) >= 0.9 * (N // 128)
+    if fields == 3:  # the three rows of a node share the node's coupling list: the node-blocked form (one column index per 3 x 3 values)
+        assert int(_lib.lib.mfem_debug_bsell_fields(A._h)) == 3
     yl = torch.empty(N, **f64)
     _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), v.data_ptr(), yl.data_ptr(), 1.0, 0.0))
     assert float((yl - Kv).abs().max()) <= 1e-13 * float(Kv.abs().max())
@@ -214,8 +214,9 @@ def test_field_periodic_blocks_of_the_sliced_layout(mf, B, n, fields):
         A, K = gd.A, gd.K_linear
         x = mf.FEM_rand(A.n, 3, 0) - 0.5
         mode = C.c_int32()
+        _lib.lib.mfem_debug_set_bsell(0)  # (the row-sorted form: the node-blocked one is test_node_blocked_layout)
         _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
-        assert mode.value == 3
+        assert mode.value == 3 and int(_lib.lib.mfem_debug_bsell_fields(A._h)) == 0
         nper = int(_lib.lib.mfem_debug_sell_periodic_blocks(A._h))
         assert nper >= (A.n // 128) // 2, nper  # (the blocks where the row length changes and the last one are not)
         y0 = torch.empty(A.n, dtype=torch.float64, device="cuda")
@@ -236,6 +237,7 @@ def test_field_periodic_blocks_of_the_sliced_layout(mf, B, n, fields):
         assert int(_lib.lib.mfem_debug_sell_periodic_blocks(g1.A._h)) == 0
     finally:
         _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_bsell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
 
 
@@ -266,8 +268,9 @@ def test_field_periodic_blocks_two_four_six_fields(mf, B, F):
         A = mf.FEM_SpMat_CSR(torch.tensor(M.indptr, dtype=torch.int64, device="cuda"), torch.tensor(M.indices, dtype=torch.int32, device="cuda"), n, index_base=0, ctx=B.ctx)
         K = torch.tensor(M.data, device="cuda")
         mode = C.c_int32()
+        _lib.lib.mfem_debug_set_bsell(0)
         _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
-        assert mode.value == 3
+        assert mode.value == 3 and int(_lib.lib.mfem_debug_bsell_fields(A._h)) == 0
         assert int(_lib.lib.mfem_debug_sell_periodic_blocks(A._h)) >= (n // 128) // 2
         x = mf.FEM_rand(n, 3, 0) - 0.5
         want = torch.tensor(M @ x.cpu().numpy(), device="cuda")
@@ -278,4 +281,72 @@ def test_field_periodic_blocks_two_four_six_fields(mf, B, F):
             assert float((y - want).abs().max()) <= 1e-13 * float(want.abs().max())
     finally:
         _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_bsell(1)
+        _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("F", [2, 3, 4, 6])
+def test_node_blocked_layout(mf, B, F):
+    """Mode 3 on a field-major multi-field matrix of an unstructured mesh takes the node-blocked form (csrc/spmv_sell.hip "BSELL": a lane owns a node, one
+    column index and F gathers of x per F x F values): kron(ones(F, F), P1) on the pattern P1 of a one-field hex-20 mesh with random values, against scipy;
+    y = alpha A x + beta y; and the same values through a Jacobi-preconditioned idrs!(8) solve (the layout copy with the column scaling folded in) against
+    the row-sorted form.  F = 6 is served as three super-fields of two."""
+    import scipy.sparse as sp
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import _lib, generic as G, physics
+
+    B._umesh_key = None
+    space, msh, fac = B.unstructured_mesh(7, block=16)
+    g1 = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, L.K_COND), [])
+    rp = g1.A.rowptr.cpu().numpy().astype(np.int64) - g1.A.index_base
+    ci = g1.A.colidx.cpu().numpy().astype(np.int64) - g1.A.index_base
+    n1 = g1.A.n
+    P1 = sp.csr_matrix((np.ones(ci.size), ci, rp), shape=(n1, n1))
+    M = sp.kron(sp.csr_matrix(np.ones((F, F))), P1, format="csr")
+    M.sort_indices()
+    rng = np.random.default_rng(10 + F)
+    M.data = rng.standard_normal(M.nnz)
+    M = (M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 1.0)).tocsr()  # diagonally dominant: the solve below converges
+    M.sort_indices()
+    n = F * n1
+    _lib.lib.mfem_debug_set_layout_min_rows(0, 0)
+    try:
+        def pattern():
+            return mf.FEM_SpMat_CSR(torch.tensor(M.indptr, dtype=torch.int64, device="cuda"), torch.tensor(M.indices, dtype=torch.int32, device="cuda"), n, index_base=0, ctx=B.ctx)
+
+        A = pattern()
+        K = torch.tensor(M.data, device="cuda")
+        mode = C.c_int32()
+        _lib.check(_lib.lib.mfem_csr_solver_layout(B.ctx._h, A._h, C.byref(mode), None, None, None))
+        assert mode.value == 3
+        assert int(_lib.lib.mfem_debug_bsell_fields(A._h)) == {2: 2, 3: 3, 4: 4, 6: 3}[F]
+        x = mf.FEM_rand(n, 3, 0) - 0.5
+        xs = x.cpu().numpy()
+        c0 = int(_lib.lib.mfem_debug_bsell_spmv_count())
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y.data_ptr(), 1.0, 0.0))
+        want = M @ xs
+        assert int(_lib.lib.mfem_debug_bsell_spmv_count()) > c0
+        assert np.abs(y.cpu().numpy() - want).max() <= 1e-13 * np.abs(want).max()
+        y2 = y.clone()
+        _lib.check(_lib.lib.mfem_spmv_solver_layout(B.ctx._h, A._h, K.data_ptr(), x.data_ptr(), y2.data_ptr(), -0.5, 2.0))
+        want2 = -0.5 * want + 2.0 * y.cpu().numpy()
+        assert np.abs(y2.cpu().numpy() - want2).max() <= 1e-13 * np.abs(want2).max()
+        # a solve (right Jacobi: the layout copy divides by the column's diagonal entry) on both forms
+        b = torch.tensor(M @ np.ones(n), device="cuda")
+        sols = []
+        for on in (1, 0):
+            _lib.lib.mfem_debug_set_bsell(on)
+            Ab = pattern()
+            dx, st = mf.iterative_Solve(Ab, K, b, 1e-11, Sv_func=mf.idrs_, Pr_func=mf.Pr_Jacobi_, maxiter=500, max_pass=4, s=8)
+            assert st.converged == 1
+            assert int(_lib.lib.mfem_debug_bsell_fields(Ab._h)) == (int(_lib.lib.mfem_debug_bsell_fields(A._h)) if on else 0)
+            sols.append(dx.cpu().numpy())
+        for sol in sols:
+            assert np.abs(sol - 1.0).max() <= 1e-8
+    finally:
+        _lib.lib.mfem_debug_set_sell(1)
+        _lib.lib.mfem_debug_set_bsell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)

@@ -16,6 +16,9 @@ args = bench.parse_args(["--iters", str(iters)])
 if os.environ.get("MFEM_SELL_KNOB"):  # A/B: bit 3 = field-periodic blocks read their whole column stream
     from metafem_jl_amd import _lib
     _lib.lib.mfem_debug_set_sell(1 | int(os.environ["MFEM_SELL_KNOB"]))
+if os.environ.get("MFEM_BSELL"):  # A/B: 0 = the row-sorted sliced layout instead of the node-blocked one
+    from metafem_jl_amd import _lib
+    _lib.lib.mfem_debug_set_bsell(int(os.environ["MFEM_BSELL"]))
 B = L.Bench(args)
 for f in fields:
     o = B.unstructured_leg(n, f, steps)
