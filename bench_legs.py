@@ -613,7 +613,7 @@ class Bench:
         elif mode.value == 5:
             kkey = "k_spmv_lat8"
         elif mode.value == 3:
-            kkey = "k_spmv_sell"
+            kkey = "k_spmv_bsell" if int(_lib.lib.mfem_debug_bsell_fields(A._h)) > 0 else "k_spmv_sell"
         else:
             kkey = "csr_kernel"
             spmv_bytes = A.spmv_bytes()[0]

@@ -33,6 +33,8 @@ KERNEL_NOTES = {
                    "8 x 8 x 16 nodes in LDS, the right Jacobi scaling applied to x while it is staged; the second launch sums the tiles' y blocks in a fixed order",
     "k_spmv_sell": "k_spmv_sell: rows sorted by length and diagonal-list signature, SELL-128 copy made once per solve; blocks whose rows share one diagonal "
                    "list read no columns",
+    "k_spmv_bsell": "k_spmv_bsell<F>: node-blocked sliced layout of a field-major F-field matrix (nodes sorted by their number of coupled nodes, 64 per block, "
+                    "copy made once per solve): a lane owns a node -- one column index and F gathers of x per F x F values",
     "csr_kernel": "mfem_spmv_csr (mul!): k_spmv_csr_w (rows of up to 64 entries, uniform length) / k_spmv_csr_rb (wide or uneven rows) on the caller's CSR "
                   "arrays (i64 rowptr / i32 col / f64 val), no copy",
     "remainder": "+ k_rem_apply (A = S + N: the values are NONSYMMETRIC in a few rows -- the Nitsche face --; the tiles apply the mirrored upper triangle S, a "

@@ -39,12 +39,13 @@ KEYS = [  # (kernel key of bench.py, substrings of the kernels one "launch" cons
     ("k_spmv_dia", ["k_spmv_dia<"]),
     ("k_spmv_ell", ["k_spmv_ell<"]),
     ("k_spmv_sell", ["k_spmv_sell"]),
+    ("k_spmv_bsell", ["k_spmv_bsell"]),
     ("k_spmv_lat27", ["k_spmv_lat27(", "k_spmv_lat27d(", "k_lat27_gather<", "k_lat27_gather_st<", "k_rem_apply"]),  # (+ the skew remainder of a nonsymmetric K, where one is carried)
     ("k_spmv_lat27_pass1", ["k_spmv_lat27(", "k_spmv_lat27d("]),  # the fused CG iteration times pass 1 alone (pass 2 runs inside the residual update: k_lat27_gather_cg)
     ("k_spmv_lat8", ["k_spmv_lat8<", "k_lat8_gather<", "k_lat8_gather_st<", "k_rem_apply"]),  # one SpMV = the tile pass + the pass that sums the tiles' y blocks (+ the remainder)
 ]
 ASSEMBLY = ["k_brick_nitsche", "k_rem_", "k_probe", "k_thermal_matrix", "k_thermal_residual", "k_elasticity_matrix", "k_elasticity_residual", "k_elast", "k_hex27", "k_dia_vals", "k_ell_vals",
-            "k_sell_vals", "k_sell_fill", "k_l27_fill", "k_l27d_fill", "k_l8_fill", "k_symp_bind", "k_jacobi", "k_ell_diag", "k_sell_diag", "k_mat_div"]
+            "k_sell_vals", "k_sell_fill", "k_bsell_fill", "k_l27_fill", "k_l27d_fill", "k_l8_fill", "k_symp_bind", "k_jacobi", "k_ell_diag", "k_sell_diag", "k_mat_div"]
 out = {}
 legs = sorted({os.path.basename(p)[:-len("_FETCH_SIZE")] for p in glob.glob(os.path.join(src, "*_FETCH_SIZE"))})
 for leg in legs:
