@@ -344,11 +344,20 @@ end
 """
 Unstructured meshes (read_Mesh / mesh_Classical): every constant-coefficient `K_linear` term of an integration domain in one call
 (row-owner form).  `terms`: word 0 = value, 1 + j = d/dx_j; block = sparse_mapping[(dual_pos, base_pos)]; coef includes K_params.
-`adj_ptr`, `adj`, `ranks`: built once per assemble_Global_Variables! (see `row_ranks!`).  K_linear is ACCUMULATED into.
+`adj_ptr`, `adj`, `ranks`: built once per assemble_Global_Variables! (see `row_ranks!`).  K_linear is ACCUMULATED into; `overwrite = true`
+(the element domain is the first thing K_linear receives after `K_linear .= 0`, 05_CodeGenerator.jl:282) writes every row instead: no memset needed.
 """
 function assemble_const_terms!(K_linear, dim, itg, itp, nel, ncp, ref_itp_vals, itg_weight, coords, controlpoint_IDs,
-                               terms::Vector{ConstTerm}, n_fields, A::CSRPattern, adj_ptr, adj, ranks)
+                               terms::Vector{ConstTerm}, n_fields, A::CSRPattern, adj_ptr, adj, ranks; overwrite::Bool = false)
     sort!(terms, by = t -> t.block)
+    if overwrite && nel > 0
+        check(ccall((:mfem_mesh_assemble_elements_rows_set, lib), Cint,
+                    (Ptr{Cvoid}, Int32, Int32, Int32, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32,
+                     Ptr{ConstTerm}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    ctx(), dim, itg, itp, nel, ncp, dptr(ref_itp_vals), dptr(itg_weight), dptr(coords), dptr(controlpoint_IDs), 1,
+                    length(terms), terms, n_fields, A.h, dptr(adj_ptr), dptr(adj), dptr(ranks), dptr(K_linear)))
+        return
+    end
     check(ccall((:mfem_mesh_assemble_elements_rows, lib), Cint,
                 (Ptr{Cvoid}, Int32, Int32, Int32, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32,
                  Ptr{ConstTerm}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
