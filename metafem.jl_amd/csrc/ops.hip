@@ -12,6 +12,8 @@
 // reference's FP64 atomics are used.
 #include "common.h"
 
+int g_op_wave_forms = 1;  // mfem_debug_set("op_wave_forms"): 0 = the sub-wave forms of the batched var / res operators on every element (A/B, tests)
+
 struct OpView {
   int itg, itp, n_sd, base;
   const double* N;  // [itg, itp, n_sd, n_host]
@@ -310,6 +312,167 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_op_var_batch(OpView V, VarTerms 
   }
 }
 
+// ---- wave-per-item forms of the two batched operators for elements of 16..64 nodes (round 6) ------------------------------------------
+// The sub-wave forms above give a lane a node (res) or a Gauss point (var) and let it walk its own 216-byte run of the table: 20 lanes of an element pull
+// 20 different sectors per load, and every term re-reads its slab -- hex-20 96^3: 12.0 ms per residual of four terms (1.3 TB/s), 9.3 ms for the nine
+// inner variables of elasticity.  Here a PERSISTENT wave owns an item: the slabs the terms use are copied to LDS once with unit-stride lanes (each slab
+// read once per item however many terms use it), the terms' (slab, shift) sit in lanes and are broadcast with readlane (no scalar loads per term), and
+// the short loop dimension is split over the 64 / itp (res: 3 for hex-20) or 64 / itg (var: 2) lane groups, partial sums joined with one shuffle each.
+struct SlabUse {
+  int lo, n;  // the slabs lo .. lo + n - 1 (first to last one a term uses: contiguous in an item's table) are copied
+};
+typedef double op_d2 __attribute__((ext_vector_type(2)));
+// `count` doubles from global memory to LDS, 8 loads of a lane in flight (a plain copy loop of unknown trip count compiles to load - wait - store per
+// trip: 27 round trips per hex-20 item); 16-byte loads when both sides allow
+__device__ __forceinline__ void op_stage(double* __restrict__ dst, const double* __restrict__ src, int count, int lane) {
+  if ((count & 1) == 0 && ((uintptr_t)src & 15) == 0) {
+    const op_d2* s2 = (const op_d2*)src;
+    op_d2* d2 = (op_d2*)dst;
+    const int c2 = count >> 1;
+    for (int b = 0; b < c2; b += 512) {
+      op_d2 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b + u * 64 + lane;
+        r[u] = i < c2 ? __builtin_nontemporal_load(s2 + i) : op_d2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b + u * 64 + lane;
+        if (i < c2) d2[i] = r[u];
+      }
+    }
+  } else {
+    for (int b = 0; b < count; b += 512) {
+      double r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b + u * 64 + lane;
+        r[u] = i < count ? src[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b + u * 64 + lane;
+        if (i < count) dst[i] = r[u];
+      }
+    }
+  }
+}
+
+template <bool ATOMIC>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_op_res_batch_wave(OpView V, ResTerms T, SlabUse U, const double* __restrict__ vals, int64_t term_stride,
+                                                                    const int32_t* __restrict__ cp, double* __restrict__ residue,
+                                                                    const int32_t* __restrict__ host_ids, const int32_t* __restrict__ el_ids,
+                                                                    int64_t t0, int64_t t1) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tab = V.itg * V.itp;
+  const size_t per_wave = (size_t)U.n * tab + (size_t)T.n * V.itg;
+  double* S = sm + (size_t)w * per_wave;  // [slab][a][q]
+  double* Vq = S + (size_t)U.n * tab;     // [term][q]
+  // the terms: lane i holds term i
+  int my_slot = 0;
+  long long my_shift = 0;
+  if (lane < T.n) {
+    my_slot = T.t[lane].dual_sd - U.lo;
+    my_shift = T.t[lane].cpID_shift;
+  }
+  const int H = 64 / V.itp, h = lane / V.itp, a = lane - h * V.itp;
+  const int qc = (V.itg + H - 1) / H, q0 = h * qc, q1 = h < H ? (q0 + qc < V.itg ? q0 + qc : V.itg) : q0;
+  for (int64_t t = t0 + (int64_t)blockIdx.x * nw + w; t < t1; t += (int64_t)gridDim.x * nw) {
+    const int64_t el = (int64_t)el_ids[t] - V.base, host = (int64_t)host_ids[t] - V.base;
+    op_stage(S, slab(V, U.lo, host), U.n * tab, lane);
+    for (int b = 0; b < T.n * V.itg; b += 256) {  // (four loads of a lane in flight)
+      double r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b + u * 64 + lane;
+        const int term = i / V.itg, q = i - term * V.itg;
+        r[u] = i < T.n * V.itg ? vals[term * term_stride + q + (int64_t)V.itg * t] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b + u * 64 + lane;
+        if (i < T.n * V.itg) Vq[i] = r[u];
+      }
+    }
+    const int64_t node = h == 0 ? (int64_t)cp[a + (int64_t)V.itp * el] - V.base : 0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    int i = 0;
+    while (i < T.n) {
+      const long long shift = __shfl(my_shift, i);
+      double acc = 0.0;
+      for (; i < T.n && __shfl(my_shift, i) == shift; ++i) {
+        const double* Ns = S + (size_t)__shfl(my_slot, i) * tab + V.itg * a;
+        const double* v = Vq + i * V.itg;
+        for (int q = q0; q < q1; ++q) acc += Ns[q] * v[q];
+      }
+      double tot = acc;
+      for (int o = 1; o < H; ++o) tot += __shfl(acc, lane + o * V.itp);  // (lanes of group 0 collect; the others' sums are not used)
+      if (h == 0) {
+        double* dst = residue + node + shift;
+        if (ATOMIC) atomicAdd(dst, tot); else *dst += tot;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the next item's copy overwrites S
+  }
+}
+
+__global__ __launch_bounds__(MFEM_BLOCK) void k_op_var_batch_wave(OpView V, VarTerms T, SlabUse U, const int32_t* __restrict__ cp,
+                                                                    double* __restrict__ targets, int64_t term_stride,
+                                                                    const int32_t* __restrict__ host_ids, const int32_t* __restrict__ el_ids, int64_t n) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tab = V.itg * V.itp;
+  const size_t per_wave = (size_t)U.n * tab + (size_t)T.n * V.itp;
+  double* S = sm + (size_t)w * per_wave;  // [slab][a][q]
+  double* Xa = S + (size_t)U.n * tab;     // [term][a]: the nodal values of the term's source vector
+  int my_slot = 0;
+  long long my_x = 0;  // lane i: the source vector of term i, shifted to the term's field (fetched by the gathering lanes with a lane permute)
+  if (lane < T.n) {
+    my_slot = T.t[lane].sd - U.lo;
+    my_x = (long long)(T.t[lane].x + T.t[lane].cpID_shift - V.base);
+  }
+  const int H = 64 / V.itg, h = lane / V.itg, q = lane - h * V.itg;
+  const int ac = (V.itp + H - 1) / H, a0 = h * ac, a1 = h < H ? (a0 + ac < V.itp ? a0 + ac : V.itp) : a0;
+  for (int64_t t = (int64_t)blockIdx.x * nw + w; t < n; t += (int64_t)gridDim.x * nw) {
+    const int64_t el = (int64_t)el_ids[t] - V.base, host = (int64_t)host_ids[t] - V.base;
+    const int32_t* cpe = cp + (int64_t)V.itp * el;
+    op_stage(S, slab(V, U.lo, host), U.n * tab, lane);
+    for (int b = 0; b < T.n * V.itp; b += 256) {  // (every lane takes part in the permutes; four gathers of a lane in flight)
+      double r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b + u * 64 + lane;
+        const bool on = i < T.n * V.itp;
+        const int term = on ? i / V.itp : 0, a = on ? i - term * V.itp : 0;
+        const double* xs = (const double*)__shfl(my_x, term);
+        r[u] = on ? xs[cpe[a]] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b + u * 64 + lane;
+        if (i < T.n * V.itp) Xa[i] = r[u];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < T.n; ++i) {
+      const double* Ns = S + (size_t)__shfl(my_slot, i) * tab + q;
+      const double* xa = Xa + i * V.itp;
+      double acc = 0.0;
+      for (int a = a0; a < a1; ++a) acc += Ns[V.itg * a] * xa[a];
+      double tot = acc;
+      for (int o = 1; o < H; ++o) tot += __shfl(acc, lane + o * V.itg);
+      if (h == 0) targets[i * term_stride + q + (int64_t)V.itg * t] = tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 extern "C" int mfem_op_kval_batch(mfem_context ctx, const mfem_op_layout* L, const double* itp_vals, int32_t n_terms,
                                   const mfem_kval_term* terms, const double* vals, const int32_t* sparse_IDs_by_el,
                                   int64_t slot_block_stride, int64_t sparse_ID_shift_unit, double* K_val,
@@ -370,6 +533,35 @@ extern "C" int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, cons
   const int per_block = MFEM_BLOCK / G;
   const int64_t term_stride = (int64_t)L->itg * n_threads;
   const bool atomic = L->n_colours == 0;
+  {  // elements of 16..64 nodes: a persistent wave per item, the slabs in LDS (k_op_res_batch_wave)
+    int sd_lo = terms[0].dual_sd, sd_hi = terms[0].dual_sd;
+    for (int i = 1; i < n_terms; ++i) {
+      sd_lo = terms[i].dual_sd < sd_lo ? terms[i].dual_sd : sd_lo;
+      sd_hi = terms[i].dual_sd > sd_hi ? terms[i].dual_sd : sd_hi;
+    }
+    const SlabUse U{sd_lo, sd_hi - sd_lo + 1};
+    const size_t per_wave = sizeof(double) * ((size_t)U.n * L->itg * L->itp + (size_t)n_terms * L->itg);
+    if (g_op_wave_forms && L->itp >= 16 && L->itp <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= 256) {
+      const size_t ldsb = per_wave * 4;
+      const int per_cu = (int)(160 * 1024 / ldsb);
+      return for_each_batch(L, n_threads, [&](int64_t a, int64_t b) -> int {
+        int grid = (int)((b - a + 3) / 4);
+        const int cap = ctx->num_cus * (per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu);
+        if (grid > cap) grid = cap;
+        if (atomic) {
+          if (ldsb > 64 * 1024) MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_op_res_batch_wave<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+          hipLaunchKernelGGL(k_op_res_batch_wave<true>, dim3(grid), dim3(MFEM_BLOCK), ldsb, ctx->stream, V, T, U, vals, term_stride, el_g_cpIDs, residue,
+                             itg_hostIDs, elIDs, a, b);
+        } else {
+          if (ldsb > 64 * 1024) MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_op_res_batch_wave<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+          hipLaunchKernelGGL(k_op_res_batch_wave<false>, dim3(grid), dim3(MFEM_BLOCK), ldsb, ctx->stream, V, T, U, vals, term_stride, el_g_cpIDs, residue,
+                             itg_hostIDs, elIDs, a, b);
+        }
+        MFEM_CHECK_LAUNCH();
+        return MFEM_OK;
+      });
+    }
+  }
   return for_each_batch(L, n_threads, [&](int64_t a, int64_t b) -> int {
     const int grid = (int)((b - a + per_block - 1) / per_block);
 #define LAUNCH_RESB(GG, AT) hipLaunchKernelGGL((k_op_res_batch<GG, AT>), dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, V, T, vals, \
@@ -400,8 +592,29 @@ extern "C" int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, cons
   OpView V{L->itg, L->itp, L->n_sd, L->index_base, itp_vals};
   const int G = group_for(L->itg);
   const int per_block = MFEM_BLOCK / G;
-  const int grid = (int)((n_threads + per_block - 1) / per_block);
   const int64_t term_stride = (int64_t)L->itg * n_threads;
+  {  // elements of 16+ nodes with up to 64 Gauss points: a persistent wave per item, the slabs in LDS (k_op_var_batch_wave)
+    int sd_lo = terms[0].sd, sd_hi = terms[0].sd;
+    for (int i = 1; i < n_terms; ++i) {
+      sd_lo = terms[i].sd < sd_lo ? terms[i].sd : sd_lo;
+      sd_hi = terms[i].sd > sd_hi ? terms[i].sd : sd_hi;
+    }
+    const SlabUse U{sd_lo, sd_hi - sd_lo + 1};
+    const size_t per_wave = sizeof(double) * ((size_t)U.n * L->itg * L->itp + (size_t)n_terms * L->itp);
+    if (g_op_wave_forms && L->itp >= 16 && L->itg <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= 256) {
+      const size_t ldsb = per_wave * 4;
+      const int per_cu = (int)(160 * 1024 / ldsb);
+      int gridw = (int)((n_threads + 3) / 4);
+      const int cap = ctx->num_cus * (per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu);
+      if (gridw > cap) gridw = cap;
+      if (ldsb > 64 * 1024) MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_op_var_batch_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      hipLaunchKernelGGL(k_op_var_batch_wave, dim3(gridw), dim3(MFEM_BLOCK), ldsb, ctx->stream, V, T, U, el_g_cpIDs, targets, term_stride, itg_hostIDs, elIDs,
+                         n_threads);
+      MFEM_CHECK_LAUNCH();
+      return MFEM_OK;
+    }
+  }
+  const int grid = (int)((n_threads + per_block - 1) / per_block);
 #define LAUNCH_VARB(GG) hipLaunchKernelGGL(k_op_var_batch<GG>, dim3(grid), dim3(MFEM_BLOCK), 0, ctx->stream, V, T, el_g_cpIDs, targets, \
                                            term_stride, itg_hostIDs, elIDs, n_threads)
   if (G == 8) LAUNCH_VARB(8); else if (G == 16) LAUNCH_VARB(16); else if (G == 32) LAUNCH_VARB(32); else LAUNCH_VARB(64);

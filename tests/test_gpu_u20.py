@@ -350,3 +350,44 @@ def test_node_blocked_layout(mf, B, F):
         _lib.lib.mfem_debug_set_sell(1)
         _lib.lib.mfem_debug_set_bsell(1)
         _lib.lib.mfem_debug_set_layout_min_rows(262144, 1000000)
+
+
+@pytest.mark.parametrize("coloured", [False, True])
+@pytest.mark.parametrize("fields", [1, 3])
+def test_wave_forms_of_the_batched_operators(mf, B, fields, coloured):
+    """mfem_op_var_batch / mfem_op_res_batch on hex-20 (a persistent wave per item, table slabs in LDS: csrc/ops.hip k_op_*_batch_wave) against the
+    sub-wave forms of rounds 2-5 on the same 8^3 shuffled mesh: the residual of K_nonlinear_func at a random x* (inner variables through var, residues
+    through res; FP64 atomics or colour batches), and the oracle-checked small case of test_small_mesh_against_the_oracle stays on the old forms (< 256 items)."""
+    import torch
+
+    import bench_legs as L
+    from metafem_jl_amd import _lib, generic as G, physics
+
+    B._umesh_key = None
+    space, msh, fac = B.unstructured_mesh(8, block=8)
+    if fields == 1:
+        wf = physics.thermal_domain(3, L.K_COND)
+        bnd = [(fac.element_ID, fac.element_eindex, physics.thermal_convection(L.H, L.TENV))]
+    else:
+        wf = physics.elasticity_domain(3, L.LAM, L.MU)
+        c = fac.centroid
+        wall = fac.select(np.abs(c[:, 0]) < 1e-9)
+        bnd = [(wall.element_ID, wall.element_eindex, physics.penalty([0, 1, 2], L.TAU))]
+    res = []
+    try:
+        for on in (1, 0):
+            _lib.lib.mfem_debug_set_op_wave_forms(on)
+            gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, fields, wf, bnd, element_colours="auto" if coloured else None)
+            if fields == 1:
+                gd.controlpoints["s"] = torch.full((msh.ncp,), L.SRC, dtype=torch.float64, device="cuda")
+            rng = np.random.default_rng(3)
+            gd.x_star[:fields * msh.ncp] = torch.tensor(rng.standard_normal(fields * msh.ncp), device="cuda")
+            gd.K_linear_func()
+            gd.K_nonlinear_func()
+            res.append(gd.residue.cpu().numpy().copy())
+    finally:
+        _lib.lib.mfem_debug_set_op_wave_forms(1)
+    assert np.abs(res[0]).max() > 0
+    assert np.abs(res[0] - res[1]).max() <= 1e-13 * np.abs(res[1]).max()
+    B._umesh_key = None
+
