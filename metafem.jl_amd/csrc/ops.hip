@@ -236,7 +236,15 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_op_kval_batch(OpView V, KvalTerm
     el = (int64_t)el_ids[t] - V.base;
     const int64_t host = (int64_t)host_ids[t] - V.base;
     const double* g = slab(V, 0, host);
-    for (int i = sub * 64 + lane; i < V.n_sd * sz; i += 64 * wpi) N[i] = g[i];
+    const int step = 64 * wpi, total = V.n_sd * sz;
+    for (int b = sub * 64 + lane; b < total; b += 8 * step) {  // eight loads of a lane in flight (a copy loop of unknown trip count waits for every load)
+      double r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = b + u * step < total ? g[b + u * step] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b + u * step < total) N[b + u * step] = r[u];
+    }
     for (int i = sub * 64 + lane; i < T.n * V.itg; i += 64 * wpi) {
       const int term = i / V.itg, q = i - term * V.itg;
       vq[i] = vals[term * term_stride + q + (int64_t)V.itg * t];
