@@ -169,25 +169,39 @@ extern "C" int mfem_debug_set_idrs(int bits) try {
 // f_update != 0 (fused update + combine, round 6): f[k+1:] -= beta M[k+1:, k] happens HERE -- the next step's c is formed by the kernel that applies this
 // step's alphas, before ki_step_end runs (which then leaves f alone).  If the stop test of this step ends the solve, f is not used again.
 __global__ void ki_ortho(FoldArg fa, int dst, int m, int k, int s, int last, int f_update, double* __restrict__ S, const int32_t* __restrict__ F) {
+  // (round 6) the scalars the recurrences below walk through -- f, M, d, alpha -- are mirrored in LDS by the whole workgroup first: thread 0's chain of
+  // ~40 dependent reads then costs LDS latency, not a global round trip each (the kernel took 16 us per inner step of idrs!(8); same arithmetic, same bits)
+  constexpr int NL = I_AL + IS_MAXS - I_F;
+  __shared__ double Lm[NL];
+#define LS(i) Lm[(i) - I_F]
   if (F[F_DONE]) return;
-  kk_fold_dev(fa, S);
+  for (int i = threadIdx.x; i < NL; i += blockDim.x) Lm[i] = S[I_F + i];
+  kk_fold_dev(fa, S);  // (its barriers also order the copy above)
   if (threadIdx.x != 0) return;
-  for (int t = 0; t < m; ++t) S[dst + t] = S[I_DOT + t];
+  for (int t = 0; t < m; ++t) {
+    const double v = S[I_DOT + t];
+    S[dst + t] = v;
+    LS(dst + t) = v;
+  }
   if (!last) return;  // (more chunks of d to come)
   for (int j = 0; j < k; ++j) {
-    double v = S[I_D + j];
-    for (int t = 0; t < j; ++t) v -= S[I_AL + t] * S[I_M + j + IS_MAXS * t];
-    S[I_AL + j] = v / S[I_M + j + IS_MAXS * j];
+    double v = LS(I_D + j);
+    for (int t = 0; t < j; ++t) v -= LS(I_AL + t) * LS(I_M + j + IS_MAXS * t);
+    v = v / LS(I_M + j + IS_MAXS * j);
+    LS(I_AL + j) = v;
+    S[I_AL + j] = v;
   }
   for (int i = k; i < s; ++i) {
-    double v = S[I_D + i];
-    for (int t = 0; t < k; ++t) v -= S[I_AL + t] * S[I_M + i + IS_MAXS * t];
+    double v = LS(I_D + i);
+    for (int t = 0; t < k; ++t) v -= LS(I_AL + t) * LS(I_M + i + IS_MAXS * t);
+    LS(I_M + i + IS_MAXS * k) = v;
     S[I_M + i + IS_MAXS * k] = v;
   }
-  const double beta = S[I_F + k] / S[I_M + k + IS_MAXS * k];
+  const double beta = LS(I_F + k) / LS(I_M + k + IS_MAXS * k);
   S[I_BETA] = beta;
   if (f_update)
-    for (int i = k + 1; i < s; ++i) S[I_F + i] -= beta * S[I_M + i + IS_MAXS * k];
+    for (int i = k + 1; i < s; ++i) S[I_F + i] = LS(I_F + i) - beta * LS(I_M + i + IS_MAXS * k);
+#undef LS
 }
 // ... vector part: g -= sum alpha_t g_t ; u -= sum alpha_t u_t ; x += beta u ; r -= beta g ; partial sums of r'r over the owned entries
 template <int M>  // (M = L.m for 0 .. 8 -- all loads of an index up front, see ki_combine --, -1: the run-time form)
