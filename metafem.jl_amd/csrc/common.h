@@ -135,6 +135,9 @@ struct mfem_csr_s {
   int32_t rows_per_block;  // power of two, 0 => long-row fallback
   // tiles cut by nonzeros for rows of uneven length (spmv.hip: k_spmv_csr_rb): rb_state 1 = planned, -1 = not used
   int rb_state;
+  // node-blocked form of a field-major multi-field pattern (round 6): nb_F = fields F > 1 when the F rows of every node list the node's coupled nodes once
+  // per column field (mfem_node_block_fields: checked entry by entry once per pattern -- nb_checked), 0 = no or not asked
+  int nb_F, nb_checked;
   int64_t rb_ntiles;
   int64_t rb_elided;        // tiles of them whose columns the kernel derives from the tile's first two rows (bit 31 of rb_rows[t])
   int32_t* rb_rows;         // owned, [rb_ntiles + 1]: first row of every tile
@@ -278,6 +281,7 @@ int mfem_spmv_lat27_launch(mfem_context_s* ctx, mfem_csr_s* A, const double* val
                            double beta, const double* dotw, double* partials, int* n_partials, const int32_t* done_flag, int part);
 int64_t mfem_lat27_design_bytes(const mfem_csr_s* A);
 int64_t mfem_lat27_entries(const mfem_csr_s* A);
+int mfem_node_block_fields(mfem_context_s* ctx, mfem_csr_s* A);  // fills A->nb_F (spmv_sell.hip)
 int mfem_sell_plan(mfem_context_s* ctx, mfem_csr_s* A);
 size_t mfem_sell_vals_bytes(const mfem_csr_s* A);
 int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, double* buf, const double* dsc);

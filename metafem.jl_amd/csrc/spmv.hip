@@ -833,6 +833,8 @@ int mfem_csr_plan(mfem_context_s* ctx, mfem_csr_s* A) {
   MFEM_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->max_row_nnz = ctx->h_flags[8];
   A->rows_per_block = (A->max_row_nnz > 0 && A->max_row_nnz <= SPMV_CAP_MAX - 2) ? 1 : 0;  // LDS path usable
+  A->nb_F = 0;  // (asked by the layout plan: mfem_node_block_fields)
+  A->nb_checked = 0;
   // rows of uneven length (tiles of a fixed row count would be less than 0.65 full): tiles cut by nonzeros, k_spmv_csr_rb
   A->rb_state = -1;
   if (A->rows_per_block > 0 && (g_spmv_variant == 3 || !csr_w_default(A)) && A->max_row_nnz <= RB_CAP / 4 && A->nnz >= 16 * A->n && A->n < ((int64_t)1 << 31) - 1) {
