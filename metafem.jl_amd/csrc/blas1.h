@@ -34,7 +34,16 @@ int mfem_spmv_halo(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
 // workgroups.  np <= MFEM_MAX_PARTIALS.  smem >= 4 doubles.
 __device__ __forceinline__ double reduce_partials_bcast(const double* __restrict__ p, int np, double* smem) {
   double acc = 0.0;
-  for (int i = threadIdx.x; i < np; i += blockDim.x) acc += p[i];
+  // four loads of a thread in flight, added in the order of the plain loop (a `for ... acc += p[i]` of unknown trip count waits for every load: three to
+  // eight round trips at the head of every kernel that folds its predecessor's partial sums); a term past the end adds +0.0
+  const int B = blockDim.x;
+  for (int i = threadIdx.x; i < np; i += 4 * B) {
+    const double v0 = p[i], v1 = i + B < np ? p[i + B] : 0.0, v2 = i + 2 * B < np ? p[i + 2 * B] : 0.0, v3 = i + 3 * B < np ? p[i + 3 * B] : 0.0;
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
   acc = wave_reduce_sum(acc);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __syncthreads();
