@@ -12,7 +12,7 @@
 // reference's FP64 atomics are used.
 #include "common.h"
 
-int g_op_wave_forms = 1;  // mfem_debug_set("op_wave_forms"): 0 = the sub-wave forms of the batched var / res operators on every element (A/B, tests)
+int g_op_wave_forms = 1;  // mfem_debug_set("op_wave_forms"): 0 = the sub-wave forms of the batched var / res operators on every element (A/B, tests); 2 = the wave forms for any item count (tests on small meshes)
 
 struct OpView {
   int itg, itp, n_sd, base;
@@ -549,7 +549,7 @@ extern "C" int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, cons
     }
     const SlabUse U{sd_lo, sd_hi - sd_lo + 1};
     const size_t per_wave = sizeof(double) * ((size_t)U.n * L->itg * L->itp + (size_t)n_terms * L->itg);
-    if (g_op_wave_forms && L->itp >= 16 && L->itp <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= 256) {
+    if (g_op_wave_forms && L->itp >= 16 && L->itp <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= (g_op_wave_forms == 2 ? 1 : 256)) {
       const size_t ldsb = per_wave * 4;
       const int per_cu = (int)(160 * 1024 / ldsb);
       return for_each_batch(L, n_threads, [&](int64_t a, int64_t b) -> int {
@@ -609,7 +609,7 @@ extern "C" int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, cons
     }
     const SlabUse U{sd_lo, sd_hi - sd_lo + 1};
     const size_t per_wave = sizeof(double) * ((size_t)U.n * L->itg * L->itp + (size_t)n_terms * L->itp);
-    if (g_op_wave_forms && L->itp >= 16 && L->itg <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= 256) {
+    if (g_op_wave_forms && L->itp >= 16 && L->itg <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= (g_op_wave_forms == 2 ? 1 : 256)) {
       const size_t ldsb = per_wave * 4;
       const int per_cu = (int)(160 * 1024 / ldsb);
       int gridw = (int)((n_threads + 3) / 4);

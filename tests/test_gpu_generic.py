@@ -417,3 +417,49 @@ def test_fused_mesh_assembly_equals_the_operator_path(mf, case, coloured):
         finally:
             _lib.lib.mfem_debug_set_mesh_gather_rows(0)
         assert np.abs(by_row - doms[0]).max() <= 1e-14 * np.abs(doms[0]).max()  # (the facets add with atomics: bitwise is tests/test_gpu_u20.py, elements alone)
+
+
+@pytest.mark.parametrize("case", ["cantilever", "hex27_thermal"])
+def test_wave_forms_of_the_batched_operators_on_small_meshes(mf, case):
+    """mfem_op_var_batch / _res_batch in their wave-per-item forms (csrc/ops.hip, round 6; default from 256 items) forced on meshes of a few elements
+    (knob value 2): hex-20 elasticity with penalty facets (the cantilever pin's domain) and a hex-27 Lagrange thermal domain (27 nodes, 27 Gauss points:
+    two lane groups) -- the residual of K_nonlinear_func at a random x* against the oracle's term-by-term one."""
+    import torch
+    from metafem_jl_amd import _lib
+    from oracle import cantilever as cl, fem, mesh as om, problems, reference_element as re_
+
+    if case == "cantilever":
+        od = cl.build_cantilever(ne_x=6, e_number=2)
+        cl.set_load(od, 3)
+        args = ("Serendipity", 2, 5)
+    else:
+        disc = re_.initialize_classical_element(3, "CUBE", 2, 1, 5)
+        n = (3, 2, 2)
+        msh = om.lattice_mesh((1.0, 0.8, 0.6), n, disc)
+        msh.coords[:, 0] += 0.05 * np.sin(3.0 * msh.coords[:, 1]) * msh.coords[:, 2]
+        fac = om.boundary_facets_structured((1.0, 0.8, 0.6), n, 3)
+        od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6), [(fac, problems.thermal_convection(25.0, 293.15))])
+        od.controlpoints["s"] = 1600.0 * (1.0 + msh.coords[:, 1])
+        args = ("Lagrange", 2, 5)
+    rng = np.random.default_rng(5)
+    xs = rng.standard_normal(od.n_fields * od.mesh.ncp)
+    od.update_time()
+    od.K_linear_func()
+    od.x_star[:xs.size] = xs
+    od.K_nonlinear_func()
+    try:
+        _lib.lib.mfem_debug_set_op_wave_forms(2)
+        gd = _gpu_domain(mf, od, *args)
+        for k, v in od.controlpoints.items():
+            gd.controlpoints[k] = torch.tensor(np.asarray(v, dtype=np.float64), device="cuda")
+        gd.dt = od.dt
+        gd.update_Time()
+        gd.K_linear_func()
+        gd.x_star[:xs.size] = torch.tensor(xs, device="cuda")
+        gd.K_nonlinear_func()
+        got = gd.residue.cpu().numpy()
+    finally:
+        _lib.lib.mfem_debug_set_op_wave_forms(1)
+    assert np.abs(od.residue).max() > 0
+    assert np.abs(got - od.residue).max() <= 1e-11 * np.abs(od.residue).max()
+

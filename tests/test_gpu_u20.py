@@ -390,4 +390,3 @@ def test_wave_forms_of_the_batched_operators(mf, B, fields, coloured):
     assert np.abs(res[0]).max() > 0
     assert np.abs(res[0] - res[1]).max() <= 1e-13 * np.abs(res[1]).max()
     B._umesh_key = None
-
