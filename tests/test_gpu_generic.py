@@ -342,7 +342,7 @@ def test_batched_operators_equal_the_per_term_call_sequence(mf, case):
 
 
 @pytest.mark.parametrize("coloured", [False, True, "rows"])
-@pytest.mark.parametrize("case", ["cavity", "cantilever", "thermal_hex8", "tet10"])
+@pytest.mark.parametrize("case", ["cavity", "cantilever", "thermal_hex8", "thermal_hex27", "tet10"])
 def test_fused_mesh_assembly_equals_the_operator_path(mf, case, coloured):
     """mfem_mesh_assemble_elements / _facets (geometry on the fly + all constant-coefficient terms of a domain in one launch)
     against the stored-table operator path (mfem_update_basic_* + mfem_op_kval_batch): same K_linear to round-off, with
@@ -362,15 +362,16 @@ def test_fused_mesh_assembly_equals_the_operator_path(mf, case, coloured):
         od = cl.build_cantilever(ne_x=6, e_number=2)
         cl.set_load(od, 3)
         args = ("Serendipity", 2, 5)
-    elif case == "thermal_hex8":
-        disc = re_.initialize_classical_element(3, "CUBE", 1, 1, 3)
-        n = (5, 4, 3)
+    elif case in ("thermal_hex8", "thermal_hex27"):
+        order = 1 if case == "thermal_hex8" else 2  # (hex-27: 27 nodes x 27 Gauss points -- the staged form of the row-owner kernel with two waves per workgroup)
+        disc = re_.initialize_classical_element(3, "CUBE", order, 1, 3 if order == 1 else 5)
+        n = (5, 4, 3) if order == 1 else (3, 2, 2)
         msh = om.lattice_mesh((1.0, 0.8, 0.6), n, disc)
         msh.coords[:, 0] += 0.05 * np.sin(3.0 * msh.coords[:, 1]) * msh.coords[:, 2]  # non-affine elements
         fac = om.boundary_facets_structured((1.0, 0.8, 0.6), n, 3)
         od = fem.FEMDomain(msh, disc, 1, problems.thermal_domain(3, 0.6, alpha=2.0, Tenv=300.0), [(fac, problems.thermal_convection(25.0, 293.15))])
         od.controlpoints["s"] = 1600.0 * (1.0 + msh.coords[:, 1])
-        args = ("Lagrange", 1, 3)
+        args = ("Lagrange", order, 3 if order == 1 else 5)
     else:
         shape = "SIMPLEX"
         space_h = element.classical_space(3, "Serendipity", 2, 5, shape="SIMPLEX")
