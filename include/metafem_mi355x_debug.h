@@ -197,6 +197,9 @@ long long mfem_debug_bsell_spmv_count(void);
 /* mfem_op_var_batch / mfem_op_res_batch on elements of 16+ nodes run a persistent wave per item with the table slabs in LDS (round 6); 0 = the sub-wave
  * forms of rounds 2-5 on every element (A/B, tests); 2 = the wave forms for any item count (default: from 256 items). */
 /* ^ key "op_wave_forms": mfem_debug_set("op_wave_forms", a, b) with (int on) = (a[, b]) */
+/* Elements with at least this many nodes take the staged persistent form of the row-owner element kernel (k_mesh_assemble<.., STAGE>; default 16: hex-20,
+ * hex-27; 0 restores the default). */
+/* ^ key "mesh_stage_min_itp": mfem_debug_set("mesh_stage_min_itp", a, b) with (int nodes) = (a[, b]) */
 /* TIMING ONLY (wrong results): phases of k_mesh_assemble left out -- 1 the pair products, 2 the stores of the row-owner form, 4 the geometry, 8 the
  * physical table, 16 the coordinate gather (tools/u20_assembly_ab.py). */
 /* ^ key "mesh_abl": mfem_debug_set("mesh_abl", a, b) with (int bits) = (a[, b]) */

@@ -40,6 +40,7 @@ struct MeshItems {
   int base;
 };
 
+int g_mesh_stage_min_itp = 16;  // mfem_debug_set("mesh_stage_min_itp"): elements from this many nodes take the staged persistent form of the row-owner kernel
 int g_mesh_abl = 0;  // mfem_debug_set("mesh_abl"): ablation of k_mesh_assemble phases (tools/u20_assembly_ab.py): 1 no pair products, 2 no stores, 4 no geometry, 8 no table, 16 no coordinate gather
 
 template <int DIM>
@@ -388,7 +389,7 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
   const int NS = mode == 2 ? 1 : mode == 1 ? dim : 1 + dim;
   const size_t per_wave = sizeof(double) * ((size_t)V.itg * V.itp * NS + (size_t)V.itg * (1 + dim * dim) + (size_t)V.itp * dim);
   // the row-owner form on elements with a table worth staging (16+ nodes): persistent workgroups, the reference table in LDS (k_mesh_assemble: STAGE)
-  const bool stage = scratch_blocks > 0 && !V.eindex && !V.order && V.itp >= 16 && n_colours == 0;
+  const bool stage = scratch_blocks > 0 && !V.eindex && !V.order && V.itp >= g_mesh_stage_min_itp && n_colours == 0;
   bool diag = true;  // every term pairs a word with itself
   for (int i = 0; i < T.n; ++i) diag = diag && T.ds[i] == T.bs[i];
   const size_t shared_ref = stage ? sizeof(double) * ((size_t)V.itg * V.itp * (1 + dim) + (size_t)scratch_blocks * (diag ? NS : NS * NS)) : 0;
