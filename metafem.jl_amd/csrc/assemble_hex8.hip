@@ -151,6 +151,19 @@ __device__ __forceinline__ void hex8_load_coords(const BrickView& B, int I, int 
   }
 }
 
+// the same, nodes b and b + 4 (neighbours along k: adjacent in memory) by one 16-byte load: 12 load instructions per element instead of 24
+typedef double h8_d2 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void hex8_load_coords_pairs(const BrickView& B, int I, int J, int K, double (&X)[8][3]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int64_t c = brick_cindex(B, I + (b & 1), J + ((b >> 1) & 1), K);
+    const h8_d2 v0 = *reinterpret_cast<const h8_d2*>(B.X0 + c), v1 = *reinterpret_cast<const h8_d2*>(B.X1 + c), v2 = *reinterpret_cast<const h8_d2*>(B.X2 + c);
+    X[b][0] = v0.x; X[b + 4][0] = v0.y;
+    X[b][1] = v1.x; X[b + 4][1] = v1.y;
+    X[b][2] = v2.x; X[b + 4][2] = v2.y;
+  }
+}
+
 // The same geometry from the element's trilinear map x(xi) = X_0 + sum_{b > 0} C[b - 1] prod_{d in b} xi_d (C: differences of the nodal
 // coordinates along the set bits of b, one butterfly per element): a column of J is 3 multiply-adds instead of the 8 of the table form.
 __device__ __forceinline__ void hex8_trilinear(const double (&X)[8][3], double (&C)[7][3]) {
@@ -969,6 +982,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_elasticity_matrix(BrickView B, d
 // no colours.  128^3: 1.80 ms (profiles/r03_elasticity_matrix_steps.txt).
 #define EL2_NODES 32
 #define EL2_ROW 243  // 3 fields x 81 slots; an ODD number of doubles: the lanes of a step (one control point each) then spread over all banks (244: 1.94 -> 2.04 ms)
+#define EL2_CH (EL2_NODES * 81)  // doubles of one row field's chunk of the LDS copy (32 rows of up to 81 values; a node's row starts at 3 x its prefix: an odd stride too)
 // G[b][s][t] = sum_q w det d_sN_a d_tN_b for the row node a = AH + 1 - ex of the thread's element
 template <int AH>
 __device__ __forceinline__ void el2_integrate(const double (&C)[7][3], int nq, int ex, double (&G)[8][3][3]) {
@@ -1056,7 +1070,7 @@ __device__ __forceinline__ bool hex8_is_affine(const double (&X)[8][3], const do
 }
 __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_elasticity_matrix_lds(BrickView B, double lam, double mu, double tau,
                                                                         uint32_t penalty, int64_t T, double* __restrict__ vals, int abl) {
-  __shared__ double rows[EL2_NODES * EL2_ROW];
+  __shared__ double rows[3 * EL2_CH];
   __shared__ int64_t s_pre[EL2_NODES];
   __shared__ int32_t s_cn[EL2_NODES];
   // lane <-> control point, half-wave <-> adjacent element (two elements that differ in dimension 0 per wave): neighbouring lanes load
@@ -1064,7 +1078,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   const int tid = threadIdx.x, nl = tid & (EL2_NODES - 1), e = tid / EL2_NODES;
   const int64_t node = (int64_t)blockIdx.x * EL2_NODES + nl;
   const bool live = node < B.n_owned;
-  for (int t = tid; t < EL2_NODES * EL2_ROW; t += MFEM_BLOCK) rows[t] = 0.0;
+  for (int t = tid; t < 3 * EL2_CH; t += MFEM_BLOCK) rows[t] = 0.0;
   int i = 0, j = 0, k = 0, li = 0, lj = 0, lk = 0, cj = 1, ck = 1, cn = 0;
   if (live) {
     node_ijk(B, node, i, j, k);
@@ -1094,7 +1108,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
     bool affine;
     {
       double X[8][3];
-      hex8_load_coords(B, I, J, K, X);
+      hex8_load_coords_pairs(B, I, J, K, X);
       hex8_trilinear(X, C);
       affine = !(abl & 8) && hex8_is_affine(X, C);  // (bit 5 of mfem_debug_set_elasticity: every element takes the general path)
     }
@@ -1118,7 +1132,12 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
     }
   }
   __syncthreads();
-  double* R = rows + nl * EL2_ROW;  // [field fi][block fk * cn + slot]
+  // (round 6) the LDS copy is laid out IN MEMORY ORDER -- per row field one chunk holding the nodes' rows back to back, 3 cn values each (a node's row
+  // sits at 3 (pre(node) - pre(first node)), as in the value array) -- so that the write-out below is a plain linear copy with unit-stride lanes.  The old
+  // layout (a fixed 243-double block per node, a half-wave per row at the write-out: 256-byte pieces, 8 bytes per lane) spent 0.54 - 0.77 of the
+  // kernel's 1.50 ms issuing stores.
+  const int relp = 3 * (int)(s_pre[nl] - s_pre[0]);
+  double* R = rows + relp;  // + fi * EL2_CH: [block fk * cn + slot]
   // Accumulation without conflicts: in step b EVERY thread adds its element's block towards the element's node b.  The eight threads of a
   // control point sit in eight different elements (offsets e), so in one step they touch the eight different neighbours e + b -- all 256
   // threads work in every step, and a barrier orders the steps (an entry's contributions arrive by decreasing e: a fixed order, the same
@@ -1133,7 +1152,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
         for (int fi = 0; fi < 3; ++fi)
 #pragma unroll
-          for (int fk = 0; fk < 3; ++fk) cur[fi][fk] = R[fi * 81 + fk * cn + slot];
+          for (int fk = 0; fk < 3; ++fk) cur[fi][fk] = R[fi * EL2_CH + fk * cn + slot];
         const double tr = G[b][0][0] + G[b][1][1] + G[b][2][2];
 #pragma unroll
         for (int fi = 0; fi < 3; ++fi)
@@ -1141,7 +1160,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
           for (int fk = 0; fk < 3; ++fk) {
             double v = lam * G[b][fi][fk] + mu * G[b][fk][fi];
             if (fi == fk) v += mu * tr;
-            R[fi * 81 + fk * cn + slot] = cur[fi][fk] - v;
+            R[fi * EL2_CH + fk * cn + slot] = cur[fi][fk] - v;
           }
       }
       // steps b and b + 1 (b even) meet only in neighbours e + b == e' + b + 1, i.e. between the two threads of a control point whose
@@ -1165,24 +1184,31 @@ __global__ __launch_bounds__(MFEM_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
       for (int c = 0; c < 4; ++c) {
         const int slot = ((fn[c][0] - li) * cj + (fn[c][1] - lj)) * ck + (fn[c][2] - lk);
 #pragma unroll
-        for (int fi = 0; fi < 3; ++fi) R[fi * 81 + fi * cn + slot] -= tau * mab[c];
+        for (int fi = 0; fi < 3; ++fi) R[fi * EL2_CH + fi * cn + slot] -= tau * mab[c];
       }
     });
   }
   __syncthreads();
-  // write-out: row (f, node) = 3 cn contiguous values at f * 3 T + 3 pre(node); a half-wave per row, three steps of 32 values
-  {
-    const int grp = tid >> 5, l32 = tid & 31;
-    for (int p = grp; p < ((abl & 2) ? 0 : EL2_NODES * 3); p += MFEM_BLOCK / 32) {
-      const int n2 = (p * 171) >> 9, f = p - 3 * n2;  // p / 3 for p < 96
-      const int c3 = 3 * s_cn[n2];
-      double* dst = vals + (int64_t)f * 3 * T + 3 * s_pre[n2];
-      const double* src = rows + n2 * EL2_ROW + f * 81;
+  // write-out: per row field f the chunk [3 pre(first node), 3 (pre(last) + cn(last))) of the value array = the LDS chunk f, copied with unit-stride lanes
+  if (!(abl & 2)) {
+    // 3 x the couplings of the block's live nodes (the nodes behind the mesh's last one carry pre = 0, cn = 0)
+    const int64_t nlive = B.n_owned - (int64_t)blockIdx.x * EL2_NODES;
+    const int lastlive = nlive < EL2_NODES ? (int)nlive - 1 : EL2_NODES - 1;
+    const int L3 = 3 * (int)(s_pre[lastlive] + s_cn[lastlive] - s_pre[0]);
 #pragma unroll
-      for (int o = l32; o < 81; o += 32)
-        if (o < c3) {
-          __builtin_nontemporal_store(src[o], dst + o);  // (K is not read again by this kernel: 1.94 -> 1.79 ms)
-        }
+    for (int f = 0; f < 3; ++f) {
+      double* dst = vals + (int64_t)f * 3 * T + 3 * s_pre[0];
+      const double* src = rows + f * EL2_CH;
+      // 16 bytes per lane from the first 16-byte boundary of the destination on (a wave's store = 1 KB of one run); the odd ends by single lanes
+      const int head = L3 > 0 ? (int)(((uintptr_t)dst >> 3) & 1) : 0;
+      const int np = (L3 - head) >> 1;
+      typedef double el2_d2 __attribute__((ext_vector_type(2)));
+      for (int m = tid; m < np; m += MFEM_BLOCK) {
+        const int idx = head + 2 * m;
+        __builtin_nontemporal_store(el2_d2{src[idx], src[idx + 1]}, reinterpret_cast<el2_d2*>(dst + idx));
+      }
+      if (tid == 0 && head) __builtin_nontemporal_store(src[0], dst);
+      if (tid == 64 && ((L3 - head) & 1)) __builtin_nontemporal_store(src[L3 - 1], dst + L3 - 1);
     }
   }
 }
