@@ -850,7 +850,15 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
           if (jl < 1 || jl >= B.ne1 || jl >= B.m1 || cnt <= 0) continue;
           double* dst = vals + sw1_prefix(B, I, jl, k0);
           const double* src = Ke + (line * SW_E + (k0 - T.tk0)) * 27;
-          for (int o = tid & 63; o < cnt; o += 64) __builtin_nontemporal_store(src[o], dst + o);
+          // 16 bytes per lane from the destination's first 16-byte boundary on (round 6: a wave's store instruction covers 1 KB of the run instead of 512 bytes)
+          const int head = (int)(((uintptr_t)dst >> 3) & 1), np = (cnt - head) >> 1, ln = tid & 63;
+          typedef double sw_d2 __attribute__((ext_vector_type(2)));
+          for (int m = ln; m < np; m += 64) {
+            const int idx = head + 2 * m;
+            __builtin_nontemporal_store(sw_d2{src[idx], src[idx + 1]}, reinterpret_cast<sw_d2*>(dst + idx));
+          }
+          if (ln == 0 && head) __builtin_nontemporal_store(src[0], dst);
+          if (ln == 1 && ((cnt - head) & 1)) __builtin_nontemporal_store(src[cnt - 1], dst + cnt - 1);
         }
       }
     }
