@@ -194,6 +194,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   if (STAGE) {
     constexpr int TA = 4, TB = 2;
     const int ng = (itp + TA - 1) / TA, nbp = (itp + TB - 1) / TB;
+    const bool pair16 = (itp & 1) == 0 && (((uintptr_t)K) & 15) == 0;  // (even row length: every (row, pair) of the scratch starts on a 16-byte boundary)
     for (int w_ = lane; w_ < ng * nbp; w_ += 64) {
       const int ag = w_ / nbp, bp = w_ - ag * nbp, a0 = ag * TA, b0 = bp * TB;
       double M[TA][TB][NM];
@@ -247,12 +248,23 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
 #pragma unroll
         for (int i = 0; i < TA; ++i) {
           double* dst = K + (((int64_t)el * itp + (a0 + i)) * nb + k) * itp + b0;
+          double sum[TB];
 #pragma unroll
           for (int j = 0; j < TB; ++j) {
-            double sum = 0.0;
+            sum[j] = 0.0;
 #pragma unroll
-            for (int c = 0; c < NM; ++c) sum += ck[c] * M[i][j][c];
-            if (a0 + i < itp && b0 + j < itp && !(abl & 2)) dst[j] = sum;
+            for (int c = 0; c < NM; ++c) sum[j] += ck[c] * M[i][j][c];
+          }
+          if (a0 + i < itp && !(abl & 2)) {
+            // the lane's two base nodes are neighbours in the scratch row: one 16-byte store where the row length is even (hex-20: every pair)
+            if (TB == 2 && pair16 && b0 + 1 < itp) {
+              typedef double ma_d2 __attribute__((ext_vector_type(2)));
+              *reinterpret_cast<ma_d2*>(dst) = ma_d2{sum[0], sum[1]};
+            } else {
+#pragma unroll
+              for (int j = 0; j < TB; ++j)
+                if (b0 + j < itp) dst[j] = sum[j];
+            }
           }
         }
       }
