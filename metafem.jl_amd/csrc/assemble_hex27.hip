@@ -921,7 +921,13 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
   };
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     for (int t = lane; t < 8 * G27_ROW; t += 64) rows[wv * 8 * G27_ROW + t] = 0.0;
-    const PairPre cur = phase_a(blk);  // (its loads wait behind the other waves' arithmetic: two workgroups of eight waves per CU)
+    PairPre cur = phase_a(blk);  // (its loads wait behind the other waves' arithmetic: two workgroups of eight waves per CU)
+    // (round 6) the wave's eight rows -- consecutive control points: back to back in the value array -- sit IN MEMORY ORDER in its LDS block (a row at its
+    // prefix minus the first row's, not at a fixed 125-entry stride): the write-out below is one linear copy with 16-byte stores instead of one or two
+    // stores of `len` eight-byte lanes per row (27 .. 125 entries: a third of the lanes on average)
+    const uint32_t p0lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)cur.pre, 0), p0hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)cur.pre >> 32), 0);
+    const int64_t pre0 = (int64_t)(((uint64_t)p0hi << 32) | p0lo);
+    cur.b0 += (int)(cur.pre - pre0) - (lane >> 3) * G27_ROW;
     __builtin_amdgcn_wave_barrier();
     if (cur.valid && cur.slot < 0) {
       const int a0 = cur.la % 3, a1 = (cur.la / 3) % 3, a2 = cur.la / 9;
@@ -987,14 +993,20 @@ __global__ __launch_bounds__(D27_THREADS, 4) void k_hex27_direct(BrickView B, co
       }
     }
     __builtin_amdgcn_wave_barrier();
+    {
+      int total = 0;  // entries of the wave's live rows (rows behind row_hi carry len = 0)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {  // (row r's length and first entry sit in lane 8 r: scalars, no LDS round trip)
-      const int len = __builtin_amdgcn_readlane(cur.len, 8 * r);
-      const uint32_t plo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)cur.pre, 8 * r), phi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)cur.pre >> 32), 8 * r);
-      double* dst = vals + (int64_t)(((uint64_t)phi << 32) | plo);
-      const double* src = rows + (wv * 8 + r) * G27_ROW;
-      if (lane < len) __builtin_nontemporal_store(src[lane], dst + lane);
-      if (lane + 64 < len) __builtin_nontemporal_store(src[lane + 64], dst + lane + 64);  // (at most 125 entries per row)
+      for (int r = 0; r < 8; ++r) total += __builtin_amdgcn_readlane(cur.len, 8 * r);
+      double* dst = vals + pre0;
+      const double* src = rows + wv * 8 * G27_ROW;
+      const int head = total > 0 ? (int)(((uintptr_t)dst >> 3) & 1) : 0, np = (total - head) >> 1;
+      typedef double d27_d2 __attribute__((ext_vector_type(2)));
+      for (int m = lane; m < np; m += 64) {
+        const int idx = head + 2 * m;
+        __builtin_nontemporal_store(d27_d2{src[idx], src[idx + 1]}, reinterpret_cast<d27_d2*>(dst + idx));
+      }
+      if (lane == 0 && head) __builtin_nontemporal_store(src[0], dst);
+      if (lane == 1 && ((total - head) & 1)) __builtin_nontemporal_store(src[total - 1], dst + total - 1);
     }
     __builtin_amdgcn_wave_barrier();
   }
