@@ -186,7 +186,8 @@ int mfem_debug_fail_host_alloc(int nth);
 /* ^ key "recheck_scale_ppm": mfem_debug_set("recheck_scale_ppm", a, b) with (a = scale in millionths) = (a[, b]) */
 /* Node-blocked sliced layout (round 6, csrc/spmv_sell.hip "BSELL"): mode 3 on a field-major F-field matrix (F = 2, 3, 4) whose F rows of a node share
  * the node's coupling list -- a lane owns a node: one column index and F gathers of x per F x F values.  Taken for patterns without a lattice hint and
- * without ghost columns.  0 = off (the row-sorted form, as before; read when the pattern's layout is planned).
+ * without ghost columns.  Bit 0: on (default 1; 0 = the row-sorted form, as before; read when the pattern's layout is planned).  Bit 1 (default 0): the
+ * per-solve copy by lane quads per row instead of the LDS transpose (A/B).
  * mfem_debug_bsell_fields: F of the pattern's planned layout (0: row-sorted form, -1: null handle); mfem_debug_bsell_spmv_count: products so far. */
 /* ^ key "bsell": mfem_debug_set("bsell", a, b) with (int on) = (a[, b]) */
 int mfem_debug_bsell_fields(mfem_csr A);

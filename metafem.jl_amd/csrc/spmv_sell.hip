@@ -310,11 +310,13 @@ __device__ __forceinline__ void sell_periodic_block(int Kb, int64_t shift, const
 // a third of the gathers.  Nodes are stably sorted by their number of coupled nodes; a block is 64 nodes; slot t of a block holds, for each of its nodes,
 // the F x F values towards the node's t-th coupled node as F * F unit-stride runs of 64 doubles.
 // =====================================================================================================================================================
+static std::atomic<int> g_bsell_fill_quads{0};  // mfem_debug_set("bsell", 3): the layout copy by lane quads per row (the first form) instead of the LDS transpose
 static std::atomic<int> g_bsell_enable{1};  // bit 9 of mfem_debug_set_sell's word... (own key: mfem_debug_set("bsell", on))
 static std::atomic<long long> g_bsell_spmv_count{0};
 extern "C" int mfem_debug_set_bsell(int on) {
   ++mfem_debug_epoch;
-  g_bsell_enable = on ? 1 : 0;
+  g_bsell_enable = (on & 1) ? 1 : 0;
+  g_bsell_fill_quads = (on & 2) ? 1 : 0;
   return MFEM_OK;
 }
 extern "C" long long mfem_debug_bsell_spmv_count(void) { return g_bsell_spmv_count; }
@@ -433,6 +435,89 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_fill(int64_t ncp, int64_t 
         for (int u = 0; u < 4; ++u) og[(int64_t)(t + 4 * u) * (64 * F * F)] = t4[u];
       }
       for (; t < Kb; t += 4) og[(int64_t)t * (64 * F * F)] = t < L ? (dsc ? sg[t] / dsc[cg[t] - base] : sg[t]) : 0.0;
+    }
+  }
+}
+
+// The same copy through an LDS transpose (round 6, for coupling lists of up to BSELL_T_MAXL nodes): a workgroup takes (block, row field f, column field g);
+// its waves read the 64 nodes' g-segments of row (f, node) -- L contiguous values each, unit-stride lanes -- into LDS [node][t], then every slot t leaves
+// as ONE 512-byte run of 64 lanes.  The quad-per-row form above reads 32-byte pieces and writes 128-byte pieces, 8 bytes per lane: 16.3 ms for the 15 GB
+// of the hex-20 elasticity matrix at 96^3 (1.8 TB/s).
+#define BSELL_T_MAXL 127
+// (a first version with a workgroup per (block, f, g) ran at 15.3 ms: the copy is bound by the 1.9e9 gathers of dsc[column], not by its access pattern --
+// the divisor depends on the COLUMN (g, coupled node) alone, so a workgroup now takes (block, g), gathers the divisors once into registers and walks the F
+// row fields with them: a third of the gathers)
+template <typename RP, int F>
+__global__ __launch_bounds__(MFEM_BLOCK) void k_bsell_fill_t(int64_t ncp, int64_t nblk, const RP* __restrict__ rowptr, const int32_t* __restrict__ nodeid,
+                                                               const int64_t* __restrict__ ptr, const double* __restrict__ src, int base,
+                                                               double* __restrict__ out, const int32_t* __restrict__ col, const double* __restrict__ dsc,
+                                                               int ldl) {
+  extern __shared__ double tl[];  // [64][ldl] values, then [F][64] segment starts (int64), then [64] lengths (int)
+  int64_t* s_lo = reinterpret_cast<int64_t*>(tl + (size_t)64 * ldl);
+  int* s_L = reinterpret_cast<int*>(s_lo + F * 64);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int64_t job = blockIdx.x; job < nblk * F; job += gridDim.x) {
+    const int64_t b = job / F;
+    const int g = (int)(job - b * F);
+    const int64_t p0 = ptr[b];
+    const int Kb = (int)((ptr[b + 1] - p0) / 64);
+    if (tid < 64) {
+      const int64_t ns = b * 64 + tid;
+      int L = 0;
+      int64_t i = 0;
+      if (ns < ncp) {
+        i = nodeid[ns];
+        L = (int)(((int64_t)rowptr[i + 1] - (int64_t)rowptr[i]) / F);
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) s_lo[f * 64 + tid] = ns < ncp ? (int64_t)rowptr[(int64_t)f * ncp + i] - base + (int64_t)g * L : 0;
+      s_L[tid] = L;
+    }
+    __syncthreads();
+    // the divisors of this wave's 16 nodes x 2 entries per lane (columns: from the node's first row -- every row field lists the same)
+    double dv[4][4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nl = w * 4 + 16 * q + u;
+        const int64_t lo = s_lo[nl];
+        const int L = s_L[nl];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t = lane + 64 * h;
+          dv[q][u][h] = (dsc && t < L) ? dsc[col[lo + t] - base] : 1.0;
+        }
+      }
+    for (int f = 0; f < F; ++f) {
+      // phase 1: a wave per node, four nodes' loads in flight
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int nl = w * 4 + 16 * q + u;
+          const int64_t lo = s_lo[f * 64 + nl];
+          const int L = s_L[nl];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int t = lane + 64 * h;
+            v[u][h] = t < L ? src[lo + t] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int t = lane + 64 * h;
+            if (t < Kb) tl[(size_t)(w * 4 + 16 * q + u) * ldl + t] = dsc ? v[u][h] / dv[q][u][h] : v[u][h];  // (zeros behind a node's own list: the block's padding)
+          }
+      }
+      __syncthreads();
+      // phase 2: a slot per wave trip, lane = node
+      double* o = out + p0 * (F * F) + (int64_t)(f * F + g) * 64 + lane;
+      for (int t = w; t < Kb; t += 4) o[(int64_t)t * (64 * F * F)] = tl[(size_t)lane * ldl + t];
+      __syncthreads();
     }
   }
 }
@@ -929,6 +1014,29 @@ int mfem_sell_bind(mfem_context_s* ctx, mfem_csr_s* A, const double* vals, doubl
   A->sell_src = nullptr;
   if (A->sell_state != 1 || !g_sell_enable || !buf) return MFEM_OK;
   if (A->bsell_F > 0) {
+    const int maxL = A->max_row_nnz / A->bsell_F;
+    if (maxL <= BSELL_T_MAXL && !g_bsell_fill_quads) {  // through an LDS transpose (k_bsell_fill_t)
+      const int ldl = maxL | 1;  // (odd row stride: phase 2's lanes -- one node each -- spread over the banks)
+      const size_t ldsb = sizeof(double) * (size_t)64 * ldl + (size_t)A->bsell_F * 64 * sizeof(int64_t) + 64 * sizeof(int);
+      const int64_t jobs = A->sell_nblk * A->bsell_F;
+      const int gt = (int)(jobs < (int64_t)ctx->num_cus * 12 ? jobs : (int64_t)ctx->num_cus * 12);
+#define BSELL_FILL_T(RP, F)                                                                                                                     \
+  hipLaunchKernelGGL((k_bsell_fill_t<RP, F>), dim3(gt), dim3(MFEM_BLOCK), ldsb, ctx->stream, A->bsell_ncp, A->sell_nblk, (const RP*)A->rowptr, \
+                     A->sell_rowid, A->sell_ptr, vals, A->index_base, buf, A->colidx, dsc, ldl)
+#define BSELL_FILL_TF(RP)                           \
+  do {                                              \
+    if (A->bsell_F == 3) BSELL_FILL_T(RP, 3);       \
+    else if (A->bsell_F == 2) BSELL_FILL_T(RP, 2);  \
+    else BSELL_FILL_T(RP, 4);                       \
+  } while (0)
+      if (A->rowptr_bits == 64) BSELL_FILL_TF(int64_t); else BSELL_FILL_TF(int32_t);
+#undef BSELL_FILL_TF
+#undef BSELL_FILL_T
+      MFEM_CHECK_LAUNCH();
+      A->sell_vals = buf;
+      A->sell_src = vals;
+      return MFEM_OK;
+    }
     const int gb = mfem_grid_for(A->sell_nblk * A->bsell_F * 4 * 64, MFEM_BLOCK, ctx->num_cus * 16);
 #define BSELL_FILL(RP, F)                                                                                                                      \
   hipLaunchKernelGGL((k_bsell_fill<RP, F>), dim3(gb), dim3(MFEM_BLOCK), 0, ctx->stream, A->bsell_ncp, A->sell_nblk, (const RP*)A->rowptr,    \
