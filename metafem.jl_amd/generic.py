@@ -198,7 +198,12 @@ class GenericDomain:
         self.max_time_level = max_time_level
         nglob = (max_time_level + 1) * n
         self.x, self.dx, self.x_star, self.residue = z(nglob), z(nglob), z(nglob), z(n)
-        self.K_linear, self.K_total = z(self.A.nnz), z(self.A.nnz)
+        self.K_linear = z(self.A.nnz)
+        # K_total = K_linear + the nonlinear gradient terms (05_CodeGenerator.jl:282-283).  A form without nonlinear gradient terms never adds anything: its
+        # K_total IS K_linear (the same storage; the solver reads K, it does not scale it in place) -- no second nnz-sized array (15 GB for hex-20
+        # elasticity at 96^3), no copy per Newton step
+        self._K_total_aliases = not any(wf.nonlinear_gradients for wf in [domain_wf] + [b[-1] for b in boundaries])
+        self.K_total = self.K_linear if self._K_total_aliases else z(self.A.nnz)
         self.controlpoints: Dict[str, torch.Tensor] = {}
         self.converge_tol = 1e-6
         # GeneralAlpha (04_Time_Domain.jl:1-7); FEM_Domain builds it with dissipative = true (01_Types.jl:168)
@@ -404,7 +409,8 @@ class GenericDomain:
 
     def K_nonlinear_func(self):
         self.residue.zero_()
-        self.K_total.copy_(self.K_linear)  # 05_CodeGenerator.jl:282-283
+        if not self._K_total_aliases:
+            self.K_total.copy_(self.K_linear)  # 05_CodeGenerator.jl:282-283
         for wf, g in self._parts():
             env: dict = {}
             if self.batched:
