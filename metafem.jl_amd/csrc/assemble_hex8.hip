@@ -764,7 +764,10 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
       double k36[36];
       // affine elements (bit 1 of the kernel's flag word): one adjugate instead of NG^3 -- the FP64 work is what this kernel's time follows (a table of
       // reference integrals, ke = sum_t g0[t] K6[t], was measured too: 216 constant loads per element made the kernel 1.7x SLOWER)
-      if ((stage_rows & 2) && sf_is_affine(X)) sf_thermal_ke<NG, true>(X, kcond, k36);
+      if (stage_rows & 4) {
+#pragma unroll
+        for (int t = 0; t < 36; ++t) k36[t] = 0.0;
+      } else if ((stage_rows & 2) && sf_is_affine(X)) sf_thermal_ke<NG, true>(X, kcond, k36);
       else sf_thermal_ke<NG, false>(X, kcond, k36);
 #pragma unroll
       for (int t = 0; t < 36; ++t) Ke[tid * SW_KSTRIDE + t] = k36[t];
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
     double now[18], up[18];
 #pragma unroll
     for (int t = 0; t < 18; ++t) now[t] = up[t] = 0.0;
-    if (nd_ok && plane) {
+    if (nd_ok && plane && !(stage_rows & 8)) {
 #pragma unroll
       for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         const int cnt = (k1 - k0) * 27;
         for (int line = tid >> 6; line < SW_N; line += SW_THREADS / 64) {
           const int jl = T.tj0 + line;
-          if (jl < 1 || jl >= B.ne1 || jl >= B.m1 || cnt <= 0) continue;
+          if (jl < 1 || jl >= B.ne1 || jl >= B.m1 || cnt <= 0 || (stage_rows & 16)) continue;
           double* dst = vals + sw1_prefix(B, I, jl, k0);
           const double* src = Ke + (line * SW_E + (k0 - T.tk0)) * 27;
           // 16 bytes per lane from the destination's first 16-byte boundary on (round 6: a wave's store instruction covers 1 KB of the run instead of 512 bytes)
@@ -875,7 +878,7 @@ static std::atomic<int> g_thermal_stage_rows{3};  // the matrix sweep kernel's f
 extern "C" int mfem_debug_set_hex8_thermal(int variant) try {
   ++mfem_debug_epoch;
   g_thermal_variant = (variant & 1) ? 1 : 0;
-  g_thermal_stage_rows = ((variant & 2) ? 0 : 1) | ((variant & 4) ? 0 : 2);
+  g_thermal_stage_rows = ((variant & 2) ? 0 : 1) | ((variant & 4) ? 0 : 2) | ((variant >> 3) & 7) << 2;  // bits 3-5: TIMING-ONLY ablations of the matrix sweep (no integration / no gather from LDS / no write-out)
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex8_thermal")
 // planes per sweep segment: 32, shorter when the (j, k) tiles alone cannot fill the chip
