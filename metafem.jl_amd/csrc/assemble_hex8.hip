@@ -709,16 +709,32 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
   }
 }
 
+// The matrix sweep on its own, smaller tile (round 6): 8 x 16 elements, 128 threads, 38 KB of LDS -- FOUR workgroups per CU instead of two (the waves per
+// CU stay 8: 250 VGPRs), so that the load / integrate / gather / write-out phases of more independent workgroups overlap (ablation: the phases of two did not).
+#define MS_EJ 8
+#define MS_EK 16
+#define MS_NJ (MS_EJ - 1)
+#define MS_NK (MS_EK - 1)
+#define MS_THREADS (MS_EJ * MS_EK)
+__device__ __forceinline__ SweepTile sweep_tile_m(const BrickView& B, int L) {
+  const int ntk = (B.m2 + MS_NK - 1) / MS_NK, ntj = (B.m1 + MS_NJ - 1) / MS_NJ;
+  SweepTile t;
+  t.tk0 = (int)(blockIdx.x % ntk) * MS_NK;
+  t.tj0 = (int)((blockIdx.x / ntk) % ntj) * MS_NJ;
+  t.i0 = B.plo + (int)(blockIdx.x / (ntk * ntj)) * L;
+  t.i1 = min(t.i0 + L, B.phi);
+  return t;
+}
 template <int NG>
-__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals, int stage_rows) {
-  __shared__ double Ke[SW_THREADS * SW_KSTRIDE];
-  const int tid = threadIdx.x, ek = tid % SW_E, ej = tid / SW_E;
-  const SweepTile T = sweep_tile(B, L);
+__global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(NG == 2 ? 2 : 1))) void k_thermal_matrix_sweep(BrickView B, int L, double kcond, double* __restrict__ vals, int stage_rows) {
+  __shared__ double Ke[MS_THREADS * SW_KSTRIDE];
+  const int tid = threadIdx.x, ek = tid % MS_EK, ej = tid / MS_EK;
+  const SweepTile T = sweep_tile_m(B, L);
   if (T.i0 >= T.i1) return;
   const int J = T.tj0 - 1 + ej, K = T.tk0 - 1 + ek;
   const bool el_ok = J >= 0 && J < B.ne1 && K >= 0 && K < B.ne2;
   const int j = T.tj0 + ej, k = T.tk0 + ek;
-  const bool nd_ok = ej < SW_N && ek < SW_N && j < B.m1 && k < B.m2;
+  const bool nd_ok = ej < MS_NJ && ek < MS_NK && j < B.m1 && k < B.m2;
   int lj0 = 0, lk0 = 0, cj = 1, ck = 1;
   if (nd_ok) {
     lj0 = B.lo1[j];
@@ -786,7 +802,7 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
         for (int ey = 0; ey < 2; ++ey) {
           const int Jn = j - 1 + ey, Kn = k - 1 + ez;
           if (Jn < 0 || Jn >= B.ne1 || Kn < 0 || Kn >= B.ne2) continue;
-          const double* ke = Ke + ((ej + ey) * SW_E + ek + ez) * SW_KSTRIDE;
+          const double* ke = Ke + ((ej + ey) * MS_EK + ek + ez) * SW_KSTRIDE;
           const int a0 = 2 * (1 - ey) + 4 * (1 - ez);
 #pragma unroll
           for (int b = 0; b < 8; ++b) {
@@ -846,13 +862,13 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(NG =
     if (staged) {
       mfem_lds_barrier();  // the staged rows are complete
       if (I >= T.i0 && I > 0 && I < B.ne0) {
-        const int k0 = max(T.tk0, 1), k1 = min(min(T.tk0 + SW_N, B.ne2), B.m2);  // points of a tile line with a full row: k in [k0, k1)
+        const int k0 = max(T.tk0, 1), k1 = min(min(T.tk0 + MS_NK, B.ne2), B.m2);  // points of a tile line with a full row: k in [k0, k1)
         const int cnt = (k1 - k0) * 27;
-        for (int line = tid >> 6; line < SW_N; line += SW_THREADS / 64) {
+        for (int line = tid >> 6; line < MS_NJ; line += MS_THREADS / 64) {
           const int jl = T.tj0 + line;
           if (jl < 1 || jl >= B.ne1 || jl >= B.m1 || cnt <= 0 || (stage_rows & 16)) continue;
           double* dst = vals + sw1_prefix(B, I, jl, k0);
-          const double* src = Ke + (line * SW_E + (k0 - T.tk0)) * 27;
+          const double* src = Ke + (line * MS_EK + (k0 - T.tk0)) * 27;
           // 16 bytes per lane from the destination's first 16-byte boundary on (round 6: a wave's store instruction covers 1 KB of the run instead of 512 bytes)
           const int head = (int)(((uintptr_t)dst >> 3) & 1), np = (cnt - head) >> 1, ln = tid & 63;
           typedef double sw_d2 __attribute__((ext_vector_type(2)));
@@ -881,6 +897,14 @@ extern "C" int mfem_debug_set_hex8_thermal(int variant) try {
   g_thermal_stage_rows = ((variant & 2) ? 0 : 1) | ((variant & 4) ? 0 : 2) | ((variant >> 3) & 7) << 2;  // bits 3-5: TIMING-ONLY ablations of the matrix sweep (no integration / no gather from LDS / no write-out)
   return MFEM_OK;
 } MFEM_API_CATCH("mfem_debug_set_hex8_thermal")
+static int sweep_planes_m(const mfem_brick_s* m, int64_t* grid) {  // (the matrix sweep's tile)
+  const int64_t ntj = (m->m[1] + MS_NJ - 1) / MS_NJ, ntk = (m->m[2] + MS_NK - 1) / MS_NK;
+  const int planes = m->phi - m->plo;
+  int L = 32;
+  while (L > 4 && ntj * ntk * ((planes + L - 1) / L) < 4096) L /= 2;
+  *grid = ntj * ntk * ((planes + L - 1) / L);
+  return L;
+}
 // planes per sweep segment: 32, shorter when the (j, k) tiles alone cannot fill the chip
 static int sweep_planes(const mfem_brick_s* m, int64_t* grid) {
   const int64_t ntj = (m->m[1] + SW_N - 1) / SW_N, ntk = (m->m[2] + SW_N - 1) / SW_N;
@@ -1453,11 +1477,11 @@ extern "C" int mfem_brick_assemble_thermal(mfem_context ctx, mfem_brick m, mfem_
   BrickView B = mfem_brick_view(m, 1);
   if (g_thermal_variant == 0 && (m->ng == 2 || m->ng == 3)) {
     int64_t grid;
-    const int L = sweep_planes(m, &grid);
+    const int L = sweep_planes_m(m, &grid);
     if (m->ng == 2)
-      hipLaunchKernelGGL(k_thermal_matrix_sweep<2>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals, g_thermal_stage_rows.load());
+      hipLaunchKernelGGL(k_thermal_matrix_sweep<2>, dim3((unsigned)grid), dim3(MS_THREADS), 0, ctx->stream, B, L, p->k, vals, g_thermal_stage_rows.load());
     else
-      hipLaunchKernelGGL(k_thermal_matrix_sweep<3>, dim3((unsigned)grid), dim3(SW_THREADS), 0, ctx->stream, B, L, p->k, vals, g_thermal_stage_rows.load());
+      hipLaunchKernelGGL(k_thermal_matrix_sweep<3>, dim3((unsigned)grid), dim3(MS_THREADS), 0, ctx->stream, B, L, p->k, vals, g_thermal_stage_rows.load());
   } else {
     const int64_t nti = ((m->phi - m->plo) + TT_NI - 1) / TT_NI, ntj = (m->m[1] + TT_NJ - 1) / TT_NJ, ntk = (m->m[2] + TT_NK - 1) / TT_NK;
     hipLaunchKernelGGL(k_thermal_matrix, dim3((unsigned)(nti * ntj * ntk)), dim3(TT_THREADS), 0, ctx->stream, B, p->k, vals);
