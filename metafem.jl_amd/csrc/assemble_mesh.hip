@@ -126,16 +126,28 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   // ---- geometry per Gauss point (lane <-> q)
-  for (int q = lane; q < ((abl & 4) ? 0 : itg); q += 64) {
+  const bool split_j = STAGE && 2 * itg <= 64;  // (hex-20 / hex-27 with 27 Gauss points: two lane groups share a point's Jacobian sum, half the nodes each)
+  for (int q0 = 0; q0 < ((abl & 4) ? 0 : itg); q0 += 64) {
+    const int hq = split_j ? lane / itg : 0, q = split_j ? lane - hq * itg : q0 + lane;
+    const int half = split_j ? (itp + 1) >> 1 : itp;
+    const int a_lo = hq < 2 ? hq * half : 0, a_hi = hq < 2 ? (a_lo + half < itp ? a_lo + half : itp) : 0;
+    const bool qon = q < itg;
     double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int a = 0; a < itp; ++a) {
+    for (int a = a_lo; a < a_hi; ++a) {
 #pragma unroll
       for (int m = 0; m < DIM; ++m) {
-        const double r = R[q + itg * (a + itp * (1 + m))];
+        const double r = R[(qon ? q : 0) + itg * (a + itp * (1 + m))];
 #pragma unroll
         for (int i = 0; i < DIM; ++i) J[i][m] += r * X[a * DIM + i];
       }
     }
+    if (split_j) {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) J[i][m] += __shfl_down(J[i][m], itg);  // (group 0 takes group 1's half)
+    }
+    if (!qon || hq != 0) continue;
     double I[3][3];
     const double det = ma_inv<DIM>(J, I);
 #pragma unroll
