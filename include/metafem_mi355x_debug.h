@@ -195,7 +195,7 @@ long long mfem_debug_bsell_spmv_count(void);
 /* The gather of mfem_mesh_assemble_elements_rows runs by NODE when a node's blocks x element nodes fit a wave (round 6: the rows of a node's fields share one
  * adjacency walk, several nodes per wave); 1 = by row, as in round 5 (A/B and the bitwise comparison in tests/test_gpu_unstructured.py). */
 /* ^ key "mesh_gather_rows": mfem_debug_set("mesh_gather_rows", a, b) with (int by_row) = (a[, b]) */
-/* mfem_op_var_batch / mfem_op_res_batch on elements of 16+ nodes run a persistent wave per item with the table slabs in LDS (round 6); 0 = the sub-wave
+/* mfem_op_var_batch / mfem_op_res_batch on elements of 10+ nodes (b > 0: of b+ nodes) run a persistent wave per item with the table slabs in LDS (round 6); 0 = the sub-wave
  * forms of rounds 2-5 on every element (A/B, tests); 2 = the wave forms for any item count (default: from 256 items). */
 /* ^ key "op_wave_forms": mfem_debug_set("op_wave_forms", a, b) with (int on) = (a[, b]) */
 /* Elements with at least this many nodes take the staged persistent form of the row-owner element kernel (k_mesh_assemble<.., STAGE>; default 16: hex-20,

@@ -12,6 +12,7 @@
 // reference's FP64 atomics are used.
 #include "common.h"
 
+int g_op_wave_min_itp = 10;  // mfem_debug_set("op_wave_forms", a, b): b > 0 = elements from b nodes take the wave forms (default 10: tet-10, hex-20, hex-27; measured on tet-10 64^3: residual 7.1 -> 4.9 ms thermal, 16.1 -> 9.2 ms elasticity)
 int g_op_wave_forms = 1;  // mfem_debug_set("op_wave_forms"): 0 = the sub-wave forms of the batched var / res operators on every element (A/B, tests); 2 = the wave forms for any item count (tests on small meshes)
 
 struct OpView {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_op_var_batch(OpView V, VarTerms 
   }
 }
 
-// ---- wave-per-item forms of the two batched operators for elements of 16..64 nodes (round 6) ------------------------------------------
+// ---- wave-per-item forms of the two batched operators for elements of 10..64 nodes (round 6) ------------------------------------------
 // The sub-wave forms above give a lane a node (res) or a Gauss point (var) and let it walk its own 216-byte run of the table: 20 lanes of an element pull
 // 20 different sectors per load, and every term re-reads its slab -- hex-20 96^3: 12.0 ms per residual of four terms (1.3 TB/s), 9.3 ms for the nine
 // inner variables of elasticity.  Here a PERSISTENT wave owns an item: the slabs the terms use are copied to LDS once with unit-stride lanes (each slab
@@ -549,7 +550,7 @@ extern "C" int mfem_op_res_batch(mfem_context ctx, const mfem_op_layout* L, cons
     }
     const SlabUse U{sd_lo, sd_hi - sd_lo + 1};
     const size_t per_wave = sizeof(double) * ((size_t)U.n * L->itg * L->itp + (size_t)n_terms * L->itg);
-    if (g_op_wave_forms && L->itp >= 16 && L->itp <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= (g_op_wave_forms == 2 ? 1 : 256)) {
+    if (g_op_wave_forms && L->itp >= g_op_wave_min_itp && L->itp <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= (g_op_wave_forms == 2 ? 1 : 256)) {
       const size_t ldsb = per_wave * 4;
       const int per_cu = (int)(160 * 1024 / ldsb);
       return for_each_batch(L, n_threads, [&](int64_t a, int64_t b) -> int {
@@ -609,7 +610,7 @@ extern "C" int mfem_op_var_batch(mfem_context ctx, const mfem_op_layout* L, cons
     }
     const SlabUse U{sd_lo, sd_hi - sd_lo + 1};
     const size_t per_wave = sizeof(double) * ((size_t)U.n * L->itg * L->itp + (size_t)n_terms * L->itp);
-    if (g_op_wave_forms && L->itp >= 16 && L->itg <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= (g_op_wave_forms == 2 ? 1 : 256)) {
+    if (g_op_wave_forms && L->itp >= g_op_wave_min_itp && L->itg <= 64 && n_terms <= 64 && per_wave * 4 <= 80 * 1024 && n_threads >= (g_op_wave_forms == 2 ? 1 : 256)) {
       const size_t ldsb = per_wave * 4;
       const int per_cu = (int)(160 * 1024 / ldsb);
       int gridw = (int)((n_threads + 3) / 4);
