@@ -49,6 +49,8 @@ def parse_args(argv=None):
                          "functional checks of the line's schema)")
     ap.add_argument("--ref-legs", type=int, default=1, help="c2 at N = 1, default size: also run the reference's own solver / boundary-condition path (0 = skip)")
     ap.add_argument("--newton-like", type=int, default=20, help="secondary 256^3 leg: also time assembly + a solve of this many iterations (0 = skip)")
+    ap.add_argument("--tet10-n", type=int, default=64, help="c2 at N = 1, default size: the unstructured legs on a 10-node tetrahedron mesh (an n^3 brick cut into tetrahedra), thermal and "
+                    "3-field elasticity with idrs!(8); 0 = skip")
     ap.add_argument("--u20-n", type=int, default=96, help="c2 at N = 1, default size: unstructured serendipity hex-20 legs (thermal, elasticity) of this many elements "
                                                           "per side through mfem_pattern_build + mfem_mesh_assemble_elements_rows + idrs!(8) (0 = skip)")
     ap.add_argument("--time-to-tol", type=int, default=1, help="c3 legs: also solve the same system to 1e-8 ||r0|| with bicgstabl_GS!(2), idrs!(8), cg! (0 = skip)")
@@ -264,6 +266,10 @@ def main():
         n20 = min(args.u20_n, args.secondary_config_n) if args.secondary_config_n > 0 else args.u20_n
         for fields, key in ((1, "u20_thermal"), (3, "u20_elasticity")):
             guarded(f"{key}_{args.u20_n}", lambda fields=fields: B.unstructured_leg(n20, fields, max(args.secondary_steps // 2, 2)))
+    if default_line and args.tet10_n > 0 and hasattr(B, "unstructured_leg"):
+        nt = min(args.tet10_n, args.secondary_config_n) if args.secondary_config_n > 0 else args.tet10_n
+        for fields, key in ((1, "tet10_thermal"), (3, "tet10_elasticity")):
+            guarded(f"{key}_{args.tet10_n}", lambda fields=fields: B.unstructured_leg(nt, fields, max(args.secondary_steps // 2, 2), shape="SIMPLEX"))
     if rank == 0 and world == 1 and args.config == "c2" and args.hex27_n > 0:
         def csr27():  # the CSR kernel on the other matrix shape of the configs: hex-27 (27..125 entries per row), configs[3]'s size
             import metafem_jl_amd as mf

@@ -626,7 +626,7 @@ class Bench:
                    plain_bytes=plain_bytes)
 
     # ---- the unstructured path: what mesh_Classical(...; itp_type = :Serendipity, itp_order = 2) users get -----------------------------------------------
-    def unstructured_mesh(self, n, block=512, seed=0x5EED):
+    def unstructured_mesh(self, n, block=512, seed=0x5EED, shape="CUBE"):
         """An n^3 brick of serendipity hex-20 elements as an UNSTRUCTURED mesh: vertices + 8-vertex connectivity (make_Brick) -> control points the way
         mesh_Classical numbers them (vertices first, then one node per unique edge: 3_InitializeMesh.jl:70-163) -> element order shuffled in blocks of
         `block` elements -- no lattice structure is left for the library to find.  Host side (numpy), cached for the two field counts."""
@@ -634,10 +634,12 @@ class Bench:
 
         from metafem_jl_amd import element, mesh as pm
 
-        key = (n, block, seed)
+        key = (n, block, seed, shape)
         if getattr(self, "_umesh_key", None) != key:
-            space = element.classical_space(3, "Serendipity", 2, 5)  # examples/thermal_conduction/3D_Script.jl:39-40: itp_order = 2, itg_order = 5
-            vert, conn = pm.make_Brick((1.0, 1.0, 1.0), (n, n, n))
+            # examples/thermal_conduction/3D_Script.jl:39-40: itp_order = 2, itg_order = 5; shape = "SIMPLEX": the brick cut into tetrahedra -- the 10-node
+            # tetrahedron of the reference's simplex meshes (read_Mesh of .inp / .mphtxt files, e.g. examples/*/3D_Script.jl with the pikachu mesh)
+            space = element.classical_space(3, "Serendipity", 2, 5, shape=shape) if shape != "CUBE" else element.classical_space(3, "Serendipity", 2, 5)
+            vert, conn = pm.make_Brick((1.0, 1.0, 1.0), (n, n, n), shape=shape) if shape != "CUBE" else pm.make_Brick((1.0, 1.0, 1.0), (n, n, n))
             nel = conn.shape[1]
             nb = (nel + block - 1) // block
             perm = (np.random.default_rng(seed).permutation(nb)[:, None] * block + np.arange(block)[None, :]).ravel()
@@ -647,7 +649,7 @@ class Bench:
             self._umesh_key, self._umesh = key, (space, msh, fac)
         return self._umesh
 
-    def unstructured_leg(self, n, fields, steps, iters=None):
+    def unstructured_leg(self, n, fields, steps, iters=None, shape="CUBE"):
         """One step on the unstructured hex-20 mesh = K_linear_func (constant-coefficient terms: mfem_mesh_assemble_elements_rows + _facets on the pattern of
         mfem_pattern_build) + K_nonlinear_func (generic S3 operators: residual at x* = 0) + `iters` steps of idrs!(s = 8) with Pr_Jacobi! -- the solver and
         preconditioner every example script selects (3D_Script.jl:49).  fields = 1: the thermal form of thermal_conduction/3D_Script.jl:29-32;
@@ -659,8 +661,9 @@ class Bench:
         args, ctx, dev = self.args, self.ctx, self.dev
         iters = args.iters if iters is None else iters
         t_host = time.perf_counter()
-        space, msh, fac = self.unstructured_mesh(n)
+        space, msh, fac = self.unstructured_mesh(n, shape=shape)
         t_host = time.perf_counter() - t_host
+        tag = "u20" if shape == "CUBE" else "tet10"
         t_setup = time.perf_counter()
         if fields == 1:
             wf = physics.thermal_domain(3, K_COND)
@@ -729,15 +732,16 @@ class Bench:
         del rr, dx
         # (idrs! on the penalty-constrained hex-20 elasticity operator starts with a hump of one to two decades: ||r|| after a fixed count says little here --
         # finite, and within 100 x ||r0||; whether the same system CONVERGES is tests/test_gpu_u20.py)
-        self.check_residual(res, f"u20 {n}^3 x {fields}", loose=100.0)
+        self.check_residual(res, f"{tag} {n}^3 x {fields}", loose=100.0)
         self.describe_layout(res, A, fields, lat_count0, lat8_count0, sym_count0)
-        csr = self.csr_kernel_roofline(A, gd.K_total, f"u20_{fields}_{n}")
-        rf = self.solver_roofline(res, f"u20_{fields}_{n}")
+        csr = self.csr_kernel_roofline(A, gd.K_total, f"{tag}_{fields}_{n}")
+        rf = self.solver_roofline(res, f"{tag}_{fields}_{n}")
         # SURVEY 8(d), assembly (matrix): each CSR value written once + connectivity read + coordinates read
         asm_bytes = A.nnz * 8 + msh.cp_ids.size * 4 + msh.ncp * 3 * 8
         k_ms, r_ms = k_ms / steps, r_ms / steps
         rows_ran = None if rows_before is None else int(_lib.lib.mfem_debug_mesh_rows_count()) > rows_before
-        out = {"workload": f"UNSTRUCTURED serendipity hex-20 mesh, {n}^3 elements ({msh.nel} elements, {msh.ncp} control points numbered by mesh_Classical, element "
+        out = {"workload": ("UNSTRUCTURED serendipity hex-20 mesh, " if shape == "CUBE" else "UNSTRUCTURED 10-node tetrahedron mesh (an n^3 brick cut into tetrahedra), ") +
+                           f"{n}^3 {'elements' if shape == 'CUBE' else 'cells'} ({msh.nel} elements, {msh.ncp} control points numbered by mesh_Classical, element "
                            f"order shuffled in blocks of 512), {fields} field(s): " + ("thermal conduction + convection faces" if fields == 1 else
                            "linear elasticity, penalty wall on x = 0, traction on y = 1") + f"; step = K_linear_func (fused) + K_nonlinear_func (S3 operators) + "
                            f"{iters} SpMV-equivalent steps of idrs!(8) with Pr_Jacobi!; {steps} timed steps after 1 warm-up",

@@ -44,7 +44,7 @@ KERNEL_NOTES = {
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 CONFIG_KEYS = ("workload", "baseline_config", "n_dof", "nnz", "krylov_steps_per_step", "parallelism", "solve_ms_per_step", "assembly_ms_per_step",
                "initial_res", "final_res", "final_res_recomputed", "first_step_s")
-LEG_PREFIXES = ("secondary_", "ref_", "nitsche_", "u20_", "newton_like")
+LEG_PREFIXES = ("secondary_", "ref_", "nitsche_", "u20_", "tet10_", "newton_like")
 
 
 def sig(x, digits=5):

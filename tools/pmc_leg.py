@@ -16,7 +16,7 @@ REF = {"ref_idrs8": ("c2", "idrs8", False), "nitsche_c2": ("c2", "bicgstabl2", T
 cfg, N = leg.rsplit("_", 1)
 N = int(N)
 lam, mu = 0.5769230769230769, 0.38461538461538464
-if cfg in ("u20_1", "u20_3"):
+if cfg in ("u20_1", "u20_3", "tet10_1", "tet10_3"):
     # round 6: the unstructured hex-20 legs of bench.py (u20_thermal_96 / u20_elasticity_96): the same mesh and domain as bench_legs.Bench.unstructured_leg
     import bench
     import bench_legs as BL
@@ -25,7 +25,7 @@ if cfg in ("u20_1", "u20_3"):
 
     F = int(cfg[-1])
     Bn = BL.Bench(bench.parse_args([]))
-    space, msh, fac = Bn.unstructured_mesh(N)
+    space, msh, fac = Bn.unstructured_mesh(N, shape="SIMPLEX" if cfg.startswith("tet10") else "CUBE")
     if F == 1:
         gd = G.GenericDomain(Bn.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, 0.6), [(fac.element_ID, fac.element_eindex, physics.thermal_convection(25.0, 293.15))])
         gd.controlpoints["s"] = torch.full((msh.ncp,), 1600.0, dtype=torch.float64, device="cuda")

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 what=${@:-"pmc stats lines"}
 mkdir -p $R/gpurun_out/pmc_r06 $R/gpurun_out/prof_r06
 if echo "$what" | grep -q pmc; then
-  for leg in c2_256 c2_512 c3_128 c4_128 ref_idrs8_256 nitsche_c2_256 nitsche_c4_128 u20_1_96 u20_3_96; do
+  for leg in c2_256 c2_512 c3_128 c4_128 ref_idrs8_256 nitsche_c2_256 nitsche_c4_128 u20_1_96 u20_3_96 tet10_1_64 tet10_3_64; do
     for grp in FETCH_SIZE WRITE_SIZE; do
       timeout -k 10 400 rocprofv3 --kernel-trace --pmc $grp -d $R/gpurun_out/pmc_r06/${leg}_$grp -o out --output-format csv -- python3 $R/tools/pmc_leg.py $leg > $R/gpurun_out/pmc_r06/${leg}_$grp.log 2>&1 || { echo "pass $leg $grp failed"; tail -5 $R/gpurun_out/pmc_r06/${leg}_$grp.log; exit 1; }
       echo "done $leg $grp"
@@ -22,7 +22,7 @@ if echo "$what" | grep -q pmc; then
 fi
 if echo "$what" | grep -q stats; then
   i=0
-  for leg in "c2_512:--config c2 --secondary-n 0 --secondary-configs 0 --ref-legs 0 --hex27-n 0 --u20-n 0" "c2_256:--config c2 --n 256 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c3_128:--config c3" "c4_128:--config c4" "ref_idrs8_256:--config ref_idrs8" "nitsche_c2_256:--config nitsche_c2" "nitsche_c4_128:--config nitsche_c4"; do
+  for leg in "c2_512:--config c2 --secondary-n 0 --secondary-configs 0 --ref-legs 0 --hex27-n 0 --u20-n 0 --tet10-n 0" "c2_256:--config c2 --n 256 --secondary-n 0 --secondary-configs 0 --hex27-n 0" "c3_128:--config c3" "c4_128:--config c4" "ref_idrs8_256:--config ref_idrs8" "nitsche_c2_256:--config nitsche_c2" "nitsche_c4_128:--config nitsche_c4"; do
     name=${leg%%:*}; args=${leg#*:}
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r06/$name -o bench --output-format csv -- python3 $R/bench.py $args --steps 3 --warmup 1 --live-traffic 0 --cpu-n 0 --full-out gpurun_out/prof_r06/${name}_full.json > $R/gpurun_out/prof_r06/${name}_under_rocprof.json 2> $R/gpurun_out/prof_r06/${name}.err || { echo "stats $name failed"; tail -3 $R/gpurun_out/prof_r06/${name}.err; exit 1; }
     cp $R/gpurun_out/prof_r06/$name/bench_kernel_stats.csv $R/gpurun_out/prof_r06/${name}_kernel_stats.csv
@@ -35,6 +35,12 @@ if echo "$what" | grep -q stats; then
     cp $R/gpurun_out/prof_r06/u20_$f/bench_kernel_stats.csv $R/gpurun_out/prof_r06/u20_${f}_96_kernel_stats.csv
     rm -f $R/gpurun_out/prof_r06/u20_$f/bench_kernel_trace.csv
     echo "done stats u20_$f"
+  done
+  for f in 1 3; do  # ... and on the tet-10 mesh
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r06/tet10_$f -o bench --output-format csv -- python3 $R/tools/u20_leg.py 64 $f 2 200 SIMPLEX > $R/gpurun_out/prof_r06/tet10_${f}_64_under_rocprof.json 2> $R/gpurun_out/prof_r06/tet10_$f.err || { echo "stats tet10 $f failed"; tail -3 $R/gpurun_out/prof_r06/tet10_$f.err; exit 1; }
+    cp $R/gpurun_out/prof_r06/tet10_$f/bench_kernel_stats.csv $R/gpurun_out/prof_r06/tet10_${f}_64_kernel_stats.csv
+    rm -f $R/gpurun_out/prof_r06/tet10_$f/bench_kernel_trace.csv
+    echo "done stats tet10_$f"
   done
 fi
 if echo "$what" | grep -q lines; then
