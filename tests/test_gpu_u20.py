@@ -108,15 +108,17 @@ def test_gather_by_node_adds_in_the_order_of_the_gather_by_row(mf, B, fields):
 
 
 @pytest.mark.parametrize("fields", [1, 3])
-def test_full_size_properties(mf, B, fields):
-    """96^3 hex-20 elements (3.6 M control points; 1.9e9 nonzeros with three fields), unstructured: properties that hold at any size."""
+@pytest.mark.parametrize("shape", ["CUBE", "SIMPLEX"])
+def test_full_size_properties(mf, B, fields, shape):
+    """96^3 hex-20 elements (3.6 M control points; 1.9e9 nonzeros with three fields) and the tet-10 leg's mesh (a 64^3 brick cut into 1.31 M 10-node
+    tetrahedra), unstructured: properties that hold at any size."""
     import torch
 
     import bench_legs as L
     from metafem_jl_amd import _lib, generic as G, physics
 
-    n = 96
-    space, msh, fac = B.unstructured_mesh(n)
+    n = 96 if shape == "CUBE" else 64
+    space, msh, fac = B.unstructured_mesh(n, shape=shape)
     ncp = msh.ncp
     if fields == 1:
         gd = G.GenericDomain(B.ctx, space, msh.coords, msh.cp_ids, 1, physics.thermal_domain(3, L.K_COND),
