@@ -201,6 +201,9 @@ long long mfem_debug_bsell_spmv_count(void);
 /* Elements with at least this many nodes take the staged persistent form of the row-owner element kernel (k_mesh_assemble<.., STAGE>; default 16: hex-20,
  * hex-27; 0 restores the default). */
 /* ^ key "mesh_stage_min_itp": mfem_debug_set("mesh_stage_min_itp", a, b) with (int nodes) = (a[, b]) */
+/* The non-staged element kernel of the fused mesh assembly applies the terms as one dense coefficient row per sparse block (default 1); 0 = it walks the
+ * term list, as in rounds 2-5 (A/B). */
+/* ^ key "mesh_term_matrix": mfem_debug_set("mesh_term_matrix", a, b) with (int on) = (a[, b]) */
 /* TIMING ONLY (wrong results): phases of k_mesh_assemble left out -- 1 the pair products, 2 the stores of the row-owner form, 4 the geometry, 8 the
  * physical table, 16 the coordinate gather (tools/u20_assembly_ab.py). */
 /* ^ key "mesh_abl": mfem_debug_set("mesh_abl", a, b) with (int bits) = (a[, b]) */

@@ -336,7 +336,7 @@ int mfem_debug_set_remainder(int);
 int mfem_debug_set_recheck_scale(double);
 int mfem_debug_set_bsell(int);
 }
-extern int g_mesh_gather_rows, g_mesh_abl, g_mesh_stage_min_itp;  // assemble_mesh.hip
+extern int g_mesh_gather_rows, g_mesh_abl, g_mesh_stage_min_itp, g_mesh_term_matrix;  // assemble_mesh.hip
 extern int g_op_wave_forms, g_op_wave_min_itp;  // ops.hip
 extern "C" int mfem_debug_set(const char* key, int64_t a, int64_t b) try {
   MFEM_REQUIRE(key, "null key");
@@ -365,6 +365,7 @@ extern "C" int mfem_debug_set(const char* key, int64_t a, int64_t b) try {
   if (k == "bsell") return mfem_debug_set_bsell((int)a);
   if (k == "op_wave_forms") { g_op_wave_forms = (int)a; g_op_wave_min_itp = b > 0 ? (int)b : 10; return MFEM_OK; }
   if (k == "mesh_stage_min_itp") { g_mesh_stage_min_itp = a > 0 ? (int)a : 16; return MFEM_OK; }
+  if (k == "mesh_term_matrix") { g_mesh_term_matrix = (int)a; return MFEM_OK; }
   if (k == "mesh_abl") { g_mesh_abl = (int)a; return MFEM_OK; }
   if (k == "recheck_scale_ppm") return mfem_debug_set_recheck_scale((double)a * 1e-6);
   mfem_set_error("mfem_debug_set: unknown key '%s'", key);

@@ -23,6 +23,15 @@ struct ConstTerms {
   double coef[MA_MAX_TERMS];
 };
 
+// The terms as one dense coefficient row per sparse block (run of the term list): block value = sum_c c[k][c] * M[c], M = the NS x NS products of a node
+// pair.  Built on the host per launch; read with uniform indices (scalar loads from the kernel arguments, no branch per term).
+#define MA_MAX_RUNS 16
+struct TermMatrix {
+  int nruns;
+  int32_t block[MA_MAX_RUNS];
+  double c[MA_MAX_RUNS][16];
+};
+
 struct MeshItems {
   int itg, itp;
   int64_t ncp;
@@ -41,6 +50,7 @@ struct MeshItems {
 };
 
 int g_mesh_stage_min_itp = 16;  // mfem_debug_set("mesh_stage_min_itp"): elements from this many nodes take the staged persistent form of the row-owner kernel
+int g_mesh_term_matrix = 1;  // mfem_debug_set("mesh_term_matrix"): 0 = the non-staged element kernel walks the term list (A/B)
 int g_mesh_abl = 0;  // mfem_debug_set("mesh_abl"): ablation of k_mesh_assemble phases (tools/u20_assembly_ab.py): 1 no pair products, 2 no stores, 4 no geometry, 8 no table, 16 no coordinate gather
 
 template <int DIM>
@@ -83,7 +93,7 @@ __device__ __forceinline__ double ma_inv(const double (&J)[3][3], double (&I)[3]
 template <int DIM, int S0, int NS, int OUT, bool STAGE = false, bool DIAGT = false>
 __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, ConstTerms T, const int32_t* __restrict__ slots,
                                                                 int64_t block_stride, double* __restrict__ K, int64_t t0,
-                                                                int64_t t1, int nb, int abl) {
+                                                                int64_t t1, int nb, int abl, TermMatrix TM) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int itg = V.itg, itp = V.itp;
@@ -371,6 +381,22 @@ __global__ __launch_bounds__(MFEM_BLOCK) void k_mesh_assemble(MeshItems V, Const
           for (int u = 0; u < NS; ++u) M[s * NS + u] += va[s] * vb[u];
       }
     }
+    if (TM.nruns > 0) {
+      // (round 6) one dense coefficient row per sparse block instead of the term list: the list cost three dependent scalar loads and a branch per term and
+      // pair group -- on tet-10 elasticity (21 terms) nearly all of the kernel's 7.3 ms
+      for (int k = 0; k < TM.nruns; ++k) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS * NS; ++c) sum += TM.c[k][c] * M[c];
+        if (OUT == 2) {
+          K[(((int64_t)el * itp + a) * nb + k) * itp + b] = sum;
+        } else {
+          double* dst = K + ((int64_t)slots[TM.block[k] * block_stride + (int64_t)npair * el + p] - V.base);
+          if (OUT == 1) atomicAdd(dst, sum); else *dst += sum;
+        }
+      }
+      continue;
+    }
     int i = 0, krun = 0;
     while (i < T.n) {  // runs of terms with the same sparse block: one accumulate per run
       const int block = T.block[i];
@@ -414,6 +440,23 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
   const size_t per_wave = sizeof(double) * ((size_t)V.itg * V.itp * NS + (size_t)V.itg * (1 + dim * dim) + (size_t)V.itp * dim);
   // the row-owner form on elements with a table worth staging (16+ nodes): persistent workgroups, the reference table in LDS (k_mesh_assemble: STAGE)
   const bool stage = scratch_blocks > 0 && !V.eindex && !V.order && V.itp >= g_mesh_stage_min_itp && n_colours == 0;
+  TermMatrix TM;
+  memset(&TM, 0, sizeof(TM));
+  {
+    int run = -1;
+    bool fits = true;
+    for (int i = 0; i < T.n; ++i) {
+      if (i == 0 || T.block[i] != T.block[i - 1]) {
+        ++run;
+        if (run >= MA_MAX_RUNS) { fits = false; break; }
+        TM.block[run] = T.block[i];
+      }
+      const int S0_ = mode == 1 ? 1 : 0, sel = (T.ds[i] - S0_) * NS + (T.bs[i] - S0_);
+      if (sel < 0 || sel >= 16) { fits = false; break; }
+      TM.c[run][sel] += T.coef[i];
+    }
+    TM.nruns = fits && g_mesh_term_matrix ? run + 1 : 0;  // (0: the kernel walks the term list)
+  }
   bool diag = true;  // every term pairs a word with itself
   for (int i = 0; i < T.n; ++i) diag = diag && T.ds[i] == T.bs[i];
   const size_t shared_ref = stage ? sizeof(double) * ((size_t)V.itg * V.itp * (1 + dim) + (size_t)scratch_blocks * (diag ? NS : NS * NS)) : 0;
@@ -441,16 +484,16 @@ static int ma_launch(mfem_context_s* ctx, int dim, const MeshItems& V, const Con
         MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_assemble<D, S0, NSS, 2, true, true>),       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));                         \
       hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, 2, true, true>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, \
-                         slots, block_stride, K, a, b, scratch_blocks, g_mesh_abl);                                          \
+                         slots, block_stride, K, a, b, scratch_blocks, g_mesh_abl, TM);                                          \
     } else if (stage && AT == 2) {                                                                                            \
       if (ldsb > 64 * 1024)                                                                                                   \
         MFEM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_assemble<D, S0, NSS, 2, true>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));                         \
       hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, 2, true>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots, \
-                         block_stride, K, a, b, scratch_blocks, g_mesh_abl);                                                             \
+                         block_stride, K, a, b, scratch_blocks, g_mesh_abl, TM);                                                             \
     } else                                                                                                                    \
       hipLaunchKernelGGL((k_mesh_assemble<D, S0, NSS, AT>), dim3(grid), dim3(64 * waves), ldsb, ctx->stream, V, T, slots,     \
-                         block_stride, K, a, b, scratch_blocks, g_mesh_abl);                                                             \
+                         block_stride, K, a, b, scratch_blocks, g_mesh_abl, TM);                                                             \
   } while (0)
 #define MA_MODE(D, AT)                                  \
   do {                                                  \

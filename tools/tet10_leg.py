@@ -17,6 +17,8 @@ from metafem_jl_amd import _lib, element, generic as G, mesh as pm, physics  # n
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 fields = [int(f) for f in (sys.argv[2] if len(sys.argv) > 2 else "1,3").split(",")]
 B = L.Bench(bench.parse_args([]))
+if os.environ.get("MFEM_TERM_MATRIX"):  # A/B: 0 = the non-staged element kernel walks the term list
+    _lib.lib.mfem_debug_set_mesh_term_matrix(int(os.environ["MFEM_TERM_MATRIX"]))
 if os.environ.get("MFEM_OP_WAVE_MIN_ITP"):  # A/B: elements from this many nodes take the wave forms of the batched var / res operators (default 16)
     _lib.lib.mfem_debug_set_op_wave_forms(1, int(os.environ["MFEM_OP_WAVE_MIN_ITP"]))
 space = element.classical_space(3, "Serendipity", 2, 5, shape="SIMPLEX")
